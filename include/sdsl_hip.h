@@ -1,0 +1,193 @@
+/* sdsl_hip.h — C ABI of the MI355X (gfx950) batched rank/select + wavelet-tree query engine.
+ *
+ * This is the drop-in boundary for SDSL's rank/select/wt/count hot path.
+ * SDSL has no FFI layer: its boundary is a set of C++ concepts (`rank(i)`, `select(i)`,
+ * `wt.rank(i,c)`, `count(csa,begin,end)`), all scalar.  Every entry point below is the
+ * *batched* form of one of those members; the header-only adaptors in
+ * include/sdsl_hip/adaptors.hpp put them back behind SDSL's operator()/rank/select names.
+ *
+ * Conventions
+ *  - plain C, opaque handles, status codes (no exceptions cross the ABI);
+ *  - every array argument may be a HOST or a DEVICE pointer (detected with
+ *    hipPointerGetAttributes).  Device pointers: the call is asynchronous on `stream`
+ *    (a hipStream_t passed as void*; NULL = the null stream).  Host pointers: the library
+ *    stages through device memory and returns after the results are back on the host;
+ *  - all integers are unsigned 64-bit, little endian, exactly SDSL's size_type;
+ *  - out-of-range arguments are undefined behaviour in SDSL (asserts only,
+ *    rank_support_v5.hpp:133-134, select_support_mcl.hpp:386, wt_pc.hpp:373).  Here they
+ *    are *defined*: the result slot is set to SDSL_HIP_NPOS (all ones).  The one overflow
+ *    SDSL does define — select_support_rrr returns size() (rrr_vector.hpp:641-642,686-689)
+ *    — is reproduced exactly;
+ *  - there is NO CPU fallback: without a usable gfx950 device every create call fails with
+ *    SDSL_HIP_ERR_NO_DEVICE.
+ */
+#ifndef SDSL_HIP_H
+#define SDSL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDSL_HIP_VERSION_MAJOR 0
+#define SDSL_HIP_VERSION_MINOR 1
+
+typedef int32_t sdsl_hip_status;
+enum {
+    SDSL_HIP_OK = 0,
+    SDSL_HIP_ERR_INVALID = -1,   /* bad argument (null handle, bit not in {0,1}, ...) */
+    SDSL_HIP_ERR_NOMEM = -2,     /* host or device allocation failed */
+    SDSL_HIP_ERR_HIP = -3,       /* HIP runtime error, see sdsl_hip_last_error() */
+    SDSL_HIP_ERR_FORMAT = -4,    /* malformed / truncated SDSL serialised stream */
+    SDSL_HIP_ERR_NO_DEVICE = -5, /* no gfx950 device visible: the engine has no CPU path */
+    SDSL_HIP_ERR_UNSUPPORTED = -6
+};
+
+#define SDSL_HIP_NPOS UINT64_C(0xFFFFFFFFFFFFFFFF)
+
+/* build flags for sdsl_hip_bv_create */
+#define SDSL_HIP_BV_SELECT1 1u /* build the select_1 sample directory */
+#define SDSL_HIP_BV_SELECT0 2u /* build the select_0 sample directory */
+
+typedef struct sdsl_hip_bv_s * sdsl_hip_bv_t;   /* bit_vector + rank_support_v5 + select_support_mcl */
+typedef struct sdsl_hip_rrr_s * sdsl_hip_rrr_t; /* rrr_vector<63> + rank_support_rrr + select_support_rrr */
+typedef struct sdsl_hip_wt_s * sdsl_hip_wt_t;   /* wt_huff<bit_vector, rank_support_v5<>> */
+typedef struct sdsl_hip_fm_s * sdsl_hip_fm_t;   /* csa_wt<wt_huff<...>> restricted to count() */
+
+/* ---- library ------------------------------------------------------------------------- */
+const char * sdsl_hip_last_error(void); /* thread-local message of the last failing call */
+const char * sdsl_hip_version(void);
+int32_t sdsl_hip_device_count(void);    /* number of visible gfx950 devices (0 if none) */
+
+/* ---- synthetic input helpers (host) ----------------------------------------------------
+ * util::set_random_bits (util.hpp:467-485): words = successive std::mt19937_64(seed) outputs.
+ * Only the host container is touched; like SDSL the last word keeps its stray high bits. */
+sdsl_hip_status sdsl_hip_util_set_random_bits(uint64_t * words, uint64_t n_bits, uint64_t seed);
+
+/* ---- plain bit vector: rank_support_v5 / select_support_mcl ---------------------------
+ * Replaces: rank_support_v5<b>::rank / operator() (rank_support_v5.hpp:131-154),
+ *           select_support_mcl<b>::select / operator() (select_support_mcl.hpp:384-445),
+ *           their constructors from `bit_vector const*` (rank_support_v5.hpp:68-124,
+ *           select_support_mcl.hpp:121-128).
+ * `words` = bit_vector::data() (int_vector.hpp:619-630): ceil(n_bits/64) u64, bit i is
+ * (words[i>>6]>>(i&63))&1.  Bits at positions >= n_bits in the last word are ignored.
+ * The data is COPIED into the device layout; the caller keeps ownership of `words`. */
+sdsl_hip_status sdsl_hip_bv_create(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t flags,
+                                   sdsl_hip_bv_t * out);
+sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv);
+uint64_t sdsl_hip_bv_size(sdsl_hip_bv_t bv);         /* bit_vector::size() */
+uint64_t sdsl_hip_bv_ones(sdsl_hip_bv_t bv);         /* == rank_1(size()) */
+uint64_t sdsl_hip_bv_device_bytes(sdsl_hip_bv_t bv); /* HBM footprint of the device layout */
+/* out[q] = number of `bit`-bits in [0, idx[q]), idx[q] in [0, size()] */
+sdsl_hip_status sdsl_hip_bv_rank_batch(sdsl_hip_bv_t bv, int32_t bit, const uint64_t * idx, uint64_t n,
+                                       uint64_t * out, void * stream);
+/* out[q] = position of the i[q]-th `bit`-bit, i[q] in [1, #bit-bits] (1-based like SDSL) */
+sdsl_hip_status sdsl_hip_bv_select_batch(sdsl_hip_bv_t bv, int32_t bit, const uint64_t * i, uint64_t n,
+                                         uint64_t * out, void * stream);
+/* out[q] = bit idx[q]  (bit_vector::operator[], int_vector.hpp:1900-1904), as 0/1 bytes */
+sdsl_hip_status sdsl_hip_bv_access_batch(sdsl_hip_bv_t bv, const uint64_t * idx, uint64_t n, uint8_t * out,
+                                         void * stream);
+/* Writes the bit vector back as SDSL words (inverse of create; used by round-trip tests). */
+sdsl_hip_status sdsl_hip_bv_export_words(sdsl_hip_bv_t bv, uint64_t * words_out, void * stream);
+
+/* ---- rrr_vector<63, int_vector<>, 32> --------------------------------------------------
+ * Replaces: rrr_vector(bit_vector const&) (rrr_vector.hpp:158-270),
+ *           rank_support_rrr<b,63>::rank (rrr_vector.hpp:503-544),
+ *           select_support_rrr<b,63>::select (rrr_vector.hpp:639-726),
+ *           rrr_vector::operator[] (rrr_vector.hpp:276-298). */
+sdsl_hip_status sdsl_hip_rrr_create(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_rrr_t * out);
+/* from the bytes written by rrr_vector<63>::serialize (rrr_vector.hpp:366-378) */
+sdsl_hip_status sdsl_hip_rrr_create_from_sdsl(const void * bytes, size_t len, int32_t device, sdsl_hip_rrr_t * out);
+sdsl_hip_status sdsl_hip_rrr_destroy(sdsl_hip_rrr_t v);
+uint64_t sdsl_hip_rrr_size(sdsl_hip_rrr_t v);
+uint64_t sdsl_hip_rrr_ones(sdsl_hip_rrr_t v);
+uint64_t sdsl_hip_rrr_device_bytes(sdsl_hip_rrr_t v);
+sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uint64_t * idx, uint64_t n,
+                                        uint64_t * out, void * stream);
+/* i[q] > #bit-bits  ->  out[q] = size()   (SDSL's defined overflow, rrr_vector.hpp:641-642) */
+sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const uint64_t * i, uint64_t n,
+                                          uint64_t * out, void * stream);
+sdsl_hip_status sdsl_hip_rrr_access_batch(sdsl_hip_rrr_t v, const uint64_t * idx, uint64_t n, uint8_t * out,
+                                          void * stream);
+
+/* ---- wt_huff<bit_vector, rank_support_v5<>> over bytes ----------------------------------
+ * Replaces: wt_pc(begin,end) (wt_pc.hpp:194-248) with the Huffman shape (wt_huff.hpp:83-115)
+ *           and byte tree (wt_helper.hpp:230-327); wt_pc::rank (wt_pc.hpp:371-399);
+ *           wt_pc::operator[] (wt_pc.hpp:336-357); wt_pc::inverse_select (wt_pc.hpp:411-430);
+ *           wt_pc::select (wt_pc.hpp:443-474). */
+sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t device, sdsl_hip_wt_t * out);
+/* from wt_pc::serialize bytes (wt_pc.hpp:713-726).  `select_is_mcl`: 1 if the serialised type
+ * used select_support_mcl for bv_select1/bv_select0 (the wt_huff<> default), 0 if it used
+ * select_support_scan (serialises to zero bytes; benchmark/indexing_count/index.config:8). */
+sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int32_t select_is_mcl, int32_t device,
+                                             sdsl_hip_wt_t * out, size_t * consumed);
+sdsl_hip_status sdsl_hip_wt_destroy(sdsl_hip_wt_t wt);
+uint64_t sdsl_hip_wt_size(sdsl_hip_wt_t wt);     /* wt.size()  */
+uint64_t sdsl_hip_wt_sigma(sdsl_hip_wt_t wt);    /* wt.sigma   */
+uint64_t sdsl_hip_wt_bv_size(sdsl_hip_wt_t wt);  /* wt.bv.size() */
+uint64_t sdsl_hip_wt_device_bytes(sdsl_hip_wt_t wt);
+/* sum over c of count(c) * code_length(c) / size() is what bench.py needs for the roofline */
+sdsl_hip_status sdsl_hip_wt_code_lengths(sdsl_hip_wt_t wt, uint8_t len_out[256]);
+/* out[q] = occurrences of c[q] in [0, i[q]),  i[q] in [0, size()]   (wt.rank(i,c)) */
+sdsl_hip_status sdsl_hip_wt_rank_batch(sdsl_hip_wt_t wt, const uint64_t * i, const uint8_t * c, uint64_t n,
+                                       uint64_t * out, void * stream);
+/* out_c[q] = wt[i[q]]  (operator[]) */
+sdsl_hip_status sdsl_hip_wt_access_batch(sdsl_hip_wt_t wt, const uint64_t * i, uint64_t n, uint8_t * out_c,
+                                         void * stream);
+/* (out_rank[q], out_c[q]) = wt.inverse_select(i[q]) */
+sdsl_hip_status sdsl_hip_wt_inverse_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, uint64_t n,
+                                                 uint64_t * out_rank, uint8_t * out_c, void * stream);
+/* out[q] = wt.select(i[q], c[q]),  i[q] in [1, rank(size(), c[q])] */
+sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, const uint8_t * c, uint64_t n,
+                                         uint64_t * out, void * stream);
+
+/* ---- csa_wt<wt_huff<...>>: backward_search / count --------------------------------------
+ * Replaces: backward_search(csa,l,r,c,..) (suffix_array_algorithm.hpp:167-201),
+ *           backward_search(csa,l,r,begin,end,..) (:228-248), count (:464-471),
+ *           csa_wt::rank_bwt (csa_wt.hpp:286-289), byte_alphabet C/char2comp
+ *           (csa_alphabet_strategy.hpp:175-212).
+ * create_from_bwt: `bwt` is the BWT of text+'\0' (n = text length + 1, exactly one 0 byte),
+ * i.e. what construct_bwt (construct_bwt.hpp:38-80) hands to csa_wt (csa_wt.hpp:323-355).
+ * create_from_text: builds the suffix array of text+'\0' on the device (prefix doubling) and
+ * derives the BWT; `text` must not contain 0 bytes (construct.hpp:41 throws in that case). */
+sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int32_t device, sdsl_hip_fm_t * out);
+sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_text, int32_t device,
+                                             sdsl_hip_fm_t * out);
+/* from csa_wt::serialize bytes (csa_wt.hpp:389-402); SA/ISA samples are skipped */
+sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int32_t select_is_mcl, int32_t device,
+                                             sdsl_hip_fm_t * out);
+sdsl_hip_status sdsl_hip_fm_destroy(sdsl_hip_fm_t fm);
+uint64_t sdsl_hip_fm_size(sdsl_hip_fm_t fm);  /* csa.size() = text length + 1 */
+uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm); /* csa.sigma */
+uint64_t sdsl_hip_fm_device_bytes(sdsl_hip_fm_t fm);
+sdsl_hip_wt_t sdsl_hip_fm_wavelet_tree(sdsl_hip_fm_t fm); /* csa.wavelet_tree (borrowed handle) */
+sdsl_hip_status sdsl_hip_fm_alphabet(sdsl_hip_fm_t fm, uint8_t char2comp_out[256], uint64_t C_out[257]);
+/* one LF step per element: (l_out,r_out) = backward_search(csa, l, r, c); an empty result is
+ * (l_out > r_out) exactly as SDSL leaves it */
+sdsl_hip_status sdsl_hip_fm_backward_search_batch(sdsl_hip_fm_t fm, const uint64_t * l, const uint64_t * r,
+                                                  const uint8_t * c, uint64_t n, uint64_t * l_out,
+                                                  uint64_t * r_out, void * stream);
+/* n_patterns fixed-length patterns, pattern p = patterns[p*m .. p*m+m);  out[p] = count(csa, pattern p) */
+sdsl_hip_status sdsl_hip_fm_count_batch(sdsl_hip_fm_t fm, const uint8_t * patterns, uint32_t m,
+                                        uint64_t n_patterns, uint64_t * out, void * stream);
+/* ragged patterns: pattern p = bytes[offsets[p] .. offsets[p+1]);  offsets has n_patterns+1 entries */
+sdsl_hip_status sdsl_hip_fm_count_ragged(sdsl_hip_fm_t fm, const uint8_t * bytes, const uint64_t * offsets,
+                                         uint64_t n_patterns, uint64_t * out, void * stream);
+/* same as count_batch but also returns the SA interval [l_out[p], r_out[p]] */
+sdsl_hip_status sdsl_hip_fm_interval_batch(sdsl_hip_fm_t fm, const uint8_t * patterns, uint32_t m,
+                                           uint64_t n_patterns, uint64_t * l_out, uint64_t * r_out,
+                                           void * stream);
+
+/* ---- measurement hooks -------------------------------------------------------------------
+ * Duration (ms) of the most recent kernel launched by a *_batch call on this handle's device,
+ * measured with hipEvents recorded on the launch stream.  Timing is off by default because
+ * the event pair adds a few microseconds; bench.py turns it on. */
+sdsl_hip_status sdsl_hip_set_timing(int32_t enabled);
+sdsl_hip_status sdsl_hip_last_kernel_ms(float * ms_out); /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDSL_HIP_H */

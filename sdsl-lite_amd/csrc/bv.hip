@@ -1,0 +1,520 @@
+// bv.hip — plain bit vector on the device: construction of the rank-line layout and of the
+// select sample directories, and the batched rank / select / access kernels.
+//
+// Reference semantics reproduced (results are bit-identical, the layout is not):
+//   rank_support_v5<b>::rank            rank_support_v5.hpp:131-149
+//   select_support_mcl<b>::select       select_support_mcl.hpp:384-439
+//   bit_vector::operator[]              int_vector.hpp:1900-1904
+#include "bv_host.hpp"
+
+namespace sdslhip {
+
+// =========================================================================================
+// construction
+// =========================================================================================
+
+// one thread per line: copy the 7 data words (masked to n_bits) and record the line popcount
+__global__ __launch_bounds__(256) void k_build_lines(const uint64_t * __restrict__ words, uint64_t n_bits,
+                                                     uint64_t n_lines, uint64_t * __restrict__ lines,
+                                                     uint32_t * __restrict__ cnts)
+{
+    const uint64_t n_words = (n_bits + 63) >> 6;
+    for (uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; L < n_lines;
+         L += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int d = 0; d < kDW; ++d)
+        {
+            uint64_t wi = L * kDW + d;
+            uint64_t w = wi < n_words ? words[wi] : 0;
+            if (wi + 1 == n_words && (n_bits & 63))
+                w &= lo_set((unsigned)(n_bits & 63));
+            lines[L * kLW + 1 + d] = w;
+            c += popc64(w);
+        }
+        cnts[L] = c;
+    }
+}
+
+constexpr int kScanPerThread = 8;
+constexpr int kScanPerBlock = 256 * kScanPerThread;
+
+__device__ __forceinline__ uint64_t block_excl_scan_256(uint64_t v, uint64_t * sh, uint64_t & total)
+{
+    // simple LDS Hillis-Steele over 256 thread sums
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1)
+    {
+        uint64_t x = t >= d ? sh[t - d] : 0;
+        __syncthreads();
+        sh[t] += x;
+        __syncthreads();
+    }
+    total = sh[255];
+    uint64_t incl = sh[t];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t * __restrict__ in, uint64_t n,
+                                                     uint64_t * __restrict__ bsum)
+{
+    __shared__ uint64_t sh[256];
+    uint64_t base = (uint64_t)blockIdx.x * kScanPerBlock + (uint64_t)threadIdx.x * kScanPerThread;
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i)
+        if (base + i < n)
+            s += in[base + i];
+    uint64_t tot;
+    (void)block_excl_scan_256(s, sh, tot);
+    if (threadIdx.x == 0)
+        bsum[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of bsum[0..nb) in place, total written to bsum[nb]
+__global__ __launch_bounds__(256) void k_scan_top(uint64_t * bsum, uint64_t nb)
+{
+    __shared__ uint64_t sh[256];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < nb; base += 256)
+    {
+        uint64_t i = base + threadIdx.x;
+        uint64_t v = i < nb ? bsum[i] : 0;
+        uint64_t tot;
+        uint64_t ex = block_excl_scan_256(v, sh, tot);
+        if (i < nb)
+            bsum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0)
+        bsum[nb] = carry;
+}
+
+// out[i*stride] = exclusive prefix of in[0..i)
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t * __restrict__ in, uint64_t n,
+                                                    const uint64_t * __restrict__ bsum, uint64_t * __restrict__ out,
+                                                    uint64_t stride)
+{
+    __shared__ uint64_t sh[256];
+    uint64_t base = (uint64_t)blockIdx.x * kScanPerBlock + (uint64_t)threadIdx.x * kScanPerThread;
+    uint32_t v[kScanPerThread];
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i)
+    {
+        v[i] = base + i < n ? in[base + i] : 0;
+        s += v[i];
+    }
+    uint64_t tot;
+    uint64_t ex = block_excl_scan_256(s, sh, tot) + bsum[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < kScanPerThread; ++i)
+    {
+        if (base + i < n)
+            out[(base + i) * stride] = ex;
+        ex += v[i];
+    }
+}
+
+// select samples: sample[j] = line that holds the BIT-argument of 0-based rank j << shift
+template <int BIT>
+__global__ __launch_bounds__(256) void k_build_sel(const uint64_t * __restrict__ lines,
+                                                   const uint32_t * __restrict__ cnts, uint64_t n_bits,
+                                                   uint64_t n_lines, uint32_t shift, uint32_t * __restrict__ sample)
+{
+    for (uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; L < n_lines;
+         L += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t h1 = lines[L * kLW];
+        uint64_t c1 = cnts[L];
+        uint64_t h, c;
+        if (BIT)
+        {
+            h = h1;
+            c = c1;
+        }
+        else
+        {
+            uint64_t start = L * kDB;
+            uint64_t valid = n_bits - start < kDB ? n_bits - start : kDB;
+            h = start - h1;
+            c = valid - c1;
+        }
+        if (c == 0)
+            continue;
+        uint64_t S = UINT64_C(1) << shift;
+        for (uint64_t j = (h + S - 1) >> shift; (j << shift) < h + c; ++j)
+            sample[j] = (uint32_t)L;
+    }
+}
+
+__global__ void k_set_u32(uint32_t * p, uint32_t v)
+{
+    *p = v;
+}
+
+sdsl_hip_status build_select_dir(BvHost & bv, int bit)
+{
+    uint64_t total = bit ? bv.view.ones : bv.view.n_bits - bv.view.ones;
+    uint32_t sh = bv.view.sel_shift;
+    uint64_t ns = (total + (UINT64_C(1) << sh) - 1) >> sh;
+    SH_TRY(bv.sel[bit].alloc((ns + 2) * sizeof(uint32_t), true));
+    uint32_t * smp = bv.sel[bit].as<uint32_t>();
+    unsigned grid = grid_for(bv.view.n_lines, 256, 65536);
+    if (bit)
+        hipLaunchKernelGGL(k_build_sel<1>, dim3(grid), dim3(256), 0, 0, bv.view.lines, bv.cnts.as<uint32_t>(),
+                           bv.view.n_bits, bv.view.n_lines, sh, smp);
+    else
+        hipLaunchKernelGGL(k_build_sel<0>, dim3(grid), dim3(256), 0, 0, bv.view.lines, bv.cnts.as<uint32_t>(),
+                           bv.view.n_bits, bv.view.n_lines, sh, smp);
+    SH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, 0, smp + ns, (uint32_t)(bv.view.n_lines - 1));
+    SH_HIP(hipGetLastError());
+    bv.view.sel[bit] = smp;
+    return SDSL_HIP_OK;
+}
+
+// Build the device layout from SDSL words that already live on the device.
+sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words, uint64_t n_bits, uint32_t flags,
+                                           uint32_t sel_shift)
+{
+    bv.view = BvView{};
+    bv.view.n_bits = n_bits;
+    bv.view.n_lines = n_bits / kDB + 1;
+    bv.view.sel_shift = sel_shift;
+    if (bv.view.n_lines > UINT64_C(0xFFFFFFFF))
+    {
+        set_error("bit vector of %llu bits exceeds the 2^32-line limit of the select directory",
+                  (unsigned long long)n_bits);
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    const uint64_t nl = bv.view.n_lines;
+    SH_TRY(bv.lines.alloc(nl * kLW * sizeof(uint64_t)));
+    SH_TRY(bv.cnts.alloc(nl * sizeof(uint32_t)));
+    uint64_t * lines = bv.lines.as<uint64_t>();
+    uint32_t * cnts = bv.cnts.as<uint32_t>();
+    bv.view.lines = lines;
+
+    hipLaunchKernelGGL(k_build_lines, dim3(grid_for(nl, 256, 65536)), dim3(256), 0, 0, d_words, n_bits, nl, lines,
+                       cnts);
+    SH_HIP(hipGetLastError());
+
+    const uint64_t nb = (nl + kScanPerBlock - 1) / kScanPerBlock;
+    DevBuf bsum;
+    SH_TRY(bsum.alloc((nb + 1) * sizeof(uint64_t)));
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, 0, cnts, nl, bsum.as<uint64_t>());
+    SH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, 0, bsum.as<uint64_t>(), nb);
+    SH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, 0, cnts, nl, bsum.as<uint64_t>(), lines,
+                       (uint64_t)kLW);
+    SH_HIP(hipGetLastError());
+    SH_HIP(hipMemcpy(&bv.view.ones, bsum.as<uint64_t>() + nb, sizeof(uint64_t), hipMemcpyDeviceToHost));
+
+    if (flags & SDSL_HIP_BV_SELECT1)
+        SH_TRY(build_select_dir(bv, 1));
+    if (flags & SDSL_HIP_BV_SELECT0)
+        SH_TRY(build_select_dir(bv, 0));
+    SH_HIP(hipDeviceSynchronize());
+    bv.cnts.release(); // only needed while building
+    return SDSL_HIP_OK;
+}
+
+// =========================================================================================
+// query kernels
+// =========================================================================================
+
+// U queries per quad per round: all U line loads are issued before the first is consumed.
+template <int U, bool NT>
+__global__ __launch_bounds__(kBlock) void k_rank(BvView bv, int bit, const uint64_t * __restrict__ idx,
+                                                 uint64_t * __restrict__ out, uint64_t n)
+{
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    const uint64_t stride = (uint64_t)gridDim.x * kQPB * U;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB * U; base < n; base += stride)
+    {
+        uint64_t id[U], L[U];
+        Pair w[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            uint64_t q = base + (uint64_t)u * kQPB + gq;
+            id[u] = q < n ? idx[q] : 0;
+            ok[u] = id[u] <= bv.n_bits;
+            L[u] = ok[u] ? id[u] / kDB : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            w[u] = load_pair<NT>(bv.lines, L[u], s);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            uint64_t q = base + (uint64_t)u * kQPB + gq;
+            uint64_t r = quad_rank1(w[u], s, ok[u] ? id[u] : 0, L[u]);
+            if (!bit)
+                r = id[u] - r;
+            if (s == 0 && q < n)
+                out[q] = ok[u] ? r : SDSL_HIP_NPOS;
+        }
+    }
+}
+
+template <int BIT, bool NT>
+__global__ __launch_bounds__(kBlock) void k_select(BvView bv, const uint64_t * __restrict__ iq,
+                                                   uint64_t * __restrict__ out, uint64_t n)
+{
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    const uint64_t total = BIT ? bv.ones : bv.n_bits - bv.ones;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
+    {
+        uint64_t q = base + gq;
+        if (q >= n)
+            continue; // uniform over the quad
+        uint64_t i = iq[q];
+        if (i == 0 || i > total)
+        { // outside SDSL's precondition (select_support_mcl.hpp:386)
+            if (s == 0)
+                out[q] = SDSL_HIP_NPOS;
+            continue;
+        }
+        bool mine;
+        uint64_t pos = quad_select<BIT, NT>(bv, s, i - 1, mine);
+        if (mine)
+            out[q] = pos;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_access(BvView bv, const uint64_t * __restrict__ idx,
+                                                uint8_t * __restrict__ out, uint64_t n)
+{
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t i = idx[q];
+        if (i >= bv.n_bits)
+        {
+            out[q] = 0xFF;
+            continue;
+        }
+        uint64_t L = i / kDB;
+        unsigned off = (unsigned)(i - L * kDB);
+        uint64_t w = bv.lines[L * kLW + 1 + (off >> 6)];
+        out[q] = (uint8_t)((w >> (off & 63)) & 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_export_words(BvView bv, uint64_t * __restrict__ words, uint64_t n_words)
+{
+    for (uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < n_words;
+         wi += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t L = wi / kDW;
+        unsigned d = (unsigned)(wi - L * kDW);
+        words[wi] = bv.lines[L * kLW + 1 + d];
+    }
+}
+
+static unsigned query_grid(uint64_t n, unsigned q_per_block)
+{
+    // memory-latency bound gathers: fill every CU with 8 blocks of 256 threads, grid-stride the rest
+    return grid_for(n, q_per_block, 256u * 8u);
+}
+
+sdsl_hip_status bv_launch_rank(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
+                               hipStream_t s)
+{
+    if (n == 0)
+        return SDSL_HIP_OK;
+    constexpr int U = 4;
+    KernelTimer t(s);
+    hipLaunchKernelGGL((k_rank<U, true>), dim3(query_grid(n, kQPB * U)), dim3(kBlock), 0, s, v, bit, d_idx, d_out,
+                       n);
+    SH_HIP(hipGetLastError());
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out,
+                                 hipStream_t s)
+{
+    if (n == 0)
+        return SDSL_HIP_OK;
+    if (!v.sel[bit])
+    {
+        set_error("select_%d directory was not built (pass SDSL_HIP_BV_SELECT%d to sdsl_hip_bv_create)", bit, bit);
+        return SDSL_HIP_ERR_INVALID;
+    }
+    KernelTimer t(s);
+    if (bit)
+        hipLaunchKernelGGL((k_select<1, true>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
+    else
+        hipLaunchKernelGGL((k_select<0, true>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
+    SH_HIP(hipGetLastError());
+    return SDSL_HIP_OK;
+}
+
+uint32_t default_sel_shift()
+{
+    uint32_t sh = 9; // one sample per 512 arguments
+    if (const char * e = getenv("SDSL_HIP_SELECT_SAMPLE_LOG2"))
+    {
+        int v = atoi(e);
+        if (v >= 6 && v <= 20)
+            sh = (uint32_t)v;
+    }
+    return sh;
+}
+
+} // namespace sdslhip
+
+using namespace sdslhip;
+
+struct sdsl_hip_bv_s
+{
+    BvHost h;
+};
+
+extern "C" {
+
+sdsl_hip_status sdsl_hip_bv_create(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t flags,
+                                   sdsl_hip_bv_t * out)
+{
+    if (!out || (!words && n_bits))
+    {
+        set_error("bv_create: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    sdsl_hip_bv_s * bv = new (std::nothrow) sdsl_hip_bv_s();
+    if (!bv)
+        return SDSL_HIP_ERR_NOMEM;
+    bv->h.device = device;
+    Staged w;
+    sdsl_hip_status st = w.in(words, ((n_bits + 63) >> 6) * sizeof(uint64_t), nullptr);
+    if (st == SDSL_HIP_OK)
+        st = bv_build_from_device_words(bv->h, (const uint64_t *)w.dev, n_bits, flags, default_sel_shift());
+    if (st != SDSL_HIP_OK)
+    {
+        delete bv;
+        return st;
+    }
+    *out = bv;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv)
+{
+    if (!bv)
+        return SDSL_HIP_OK;
+    (void)hipSetDevice(bv->h.device);
+    delete bv;
+    return SDSL_HIP_OK;
+}
+
+uint64_t sdsl_hip_bv_size(sdsl_hip_bv_t bv)
+{
+    return bv ? bv->h.view.n_bits : 0;
+}
+uint64_t sdsl_hip_bv_ones(sdsl_hip_bv_t bv)
+{
+    return bv ? bv->h.view.ones : 0;
+}
+uint64_t sdsl_hip_bv_device_bytes(sdsl_hip_bv_t bv)
+{
+    return bv ? bv->h.device_bytes() : 0;
+}
+
+sdsl_hip_status sdsl_hip_bv_rank_batch(sdsl_hip_bv_t bv, int32_t bit, const uint64_t * idx, uint64_t n,
+                                       uint64_t * out, void * stream)
+{
+    if (!bv || (bit != 0 && bit != 1) || (n && (!idx || !out)))
+    {
+        set_error("bv_rank_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(bv->h.device));
+    Staged in, o;
+    SH_TRY(in.in(idx, n * 8, s));
+    SH_TRY(o.out(out, n * 8));
+    SH_TRY(bv_launch_rank(bv->h.view, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s));
+    SH_TRY(o.finish(s));
+    if (in.host && !o.host)
+        SH_HIP(hipStreamSynchronize(s)); // staging buffer must outlive the kernel
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_bv_select_batch(sdsl_hip_bv_t bv, int32_t bit, const uint64_t * i, uint64_t n,
+                                         uint64_t * out, void * stream)
+{
+    if (!bv || (bit != 0 && bit != 1) || (n && (!i || !out)))
+    {
+        set_error("bv_select_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(bv->h.device));
+    Staged in, o;
+    SH_TRY(in.in(i, n * 8, s));
+    SH_TRY(o.out(out, n * 8));
+    SH_TRY(bv_launch_select(bv->h.view, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s));
+    SH_TRY(o.finish(s));
+    if (in.host && !o.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_bv_access_batch(sdsl_hip_bv_t bv, const uint64_t * idx, uint64_t n, uint8_t * out,
+                                         void * stream)
+{
+    if (!bv || (n && (!idx || !out)))
+    {
+        set_error("bv_access_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(bv->h.device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged in, o;
+    SH_TRY(in.in(idx, n * 8, s));
+    SH_TRY(o.out(out, n));
+    {
+        KernelTimer t(s);
+        hipLaunchKernelGGL(k_access, dim3(grid_for(n, 256, 256u * 8u)), dim3(256), 0, s, bv->h.view,
+                           (const uint64_t *)in.dev, (uint8_t *)o.dev, n);
+    }
+    SH_HIP(hipGetLastError());
+    SH_TRY(o.finish(s));
+    if (in.host && !o.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_bv_export_words(sdsl_hip_bv_t bv, uint64_t * words_out, void * stream)
+{
+    if (!bv || (!words_out && bv->h.view.n_bits))
+    {
+        set_error("bv_export_words: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(bv->h.device));
+    uint64_t nw = (bv->h.view.n_bits + 63) >> 6;
+    if (nw == 0)
+        return SDSL_HIP_OK;
+    Staged o;
+    SH_TRY(o.out(words_out, nw * 8));
+    hipLaunchKernelGGL(k_export_words, dim3(grid_for(nw, 256, 65536)), dim3(256), 0, s, bv->h.view,
+                       (uint64_t *)o.dev, nw);
+    SH_HIP(hipGetLastError());
+    SH_TRY(o.finish(s));
+    return SDSL_HIP_OK;
+}
+}

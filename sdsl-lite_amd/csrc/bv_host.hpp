@@ -1,0 +1,30 @@
+// bv_host.hpp — host-side owner of a device bit vector (rank lines + select directories) and the
+// launch helpers other translation units (wavelet tree, FM-index) call.
+#pragma once
+#include "bv_device.hpp"
+#include "common.hpp"
+
+namespace sdslhip {
+
+struct BvHost
+{
+    int device = 0;
+    BvView view{};
+    DevBuf lines;  // n_lines * 64 B
+    DevBuf cnts;   // u32 per line, build-time only
+    DevBuf sel[2]; // select sample directories
+    size_t device_bytes() const
+    {
+        return lines.bytes + sel[0].bytes + sel[1].bytes;
+    }
+};
+
+uint32_t default_sel_shift();
+sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words, uint64_t n_bits, uint32_t flags,
+                                           uint32_t sel_shift);
+sdsl_hip_status bv_launch_rank(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
+                               hipStream_t s);
+sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out,
+                                 hipStream_t s);
+
+} // namespace sdslhip

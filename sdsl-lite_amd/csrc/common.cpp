@@ -1,0 +1,228 @@
+// common.cpp — error state, device checks, staging buffers, timing hooks, library-level C ABI.
+#include "common.hpp"
+
+#include <cstdarg>
+#include <random>
+
+namespace sdslhip {
+
+static thread_local std::string g_err;
+static bool g_timing = false;
+static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static bool g_ev_valid = false;
+
+void set_error(const char * fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+sdsl_hip_status hip_fail(hipError_t e, const char * what, const char * file, int line)
+{
+    set_error("HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return e == hipErrorOutOfMemory ? SDSL_HIP_ERR_NOMEM : SDSL_HIP_ERR_HIP;
+}
+
+bool is_device_ptr(const void * p)
+{
+    if (p == nullptr)
+        return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess)
+    {
+        (void)hipGetLastError(); // plain malloc'ed memory: not an error for us
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+sdsl_hip_status check_device(int32_t device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+    {
+        (void)hipGetLastError();
+        set_error("no HIP device visible (hipGetDeviceCount: %s); this engine has no CPU path",
+                  e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return SDSL_HIP_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n)
+    {
+        set_error("device index %d out of range [0,%d)", device, n);
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipDeviceProp_t prop;
+    SH_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    {
+        set_error("device %d is %s; the kernels in this library are built for gfx950 only", device,
+                  prop.gcnArchName);
+        return SDSL_HIP_ERR_NO_DEVICE;
+    }
+    SH_HIP(hipSetDevice(device));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status DevBuf::alloc(size_t n, bool zero)
+{
+    release();
+    if (n == 0)
+        n = 16; // keep a valid pointer for empty structures
+    void * q = nullptr;
+    SH_HIP(hipMalloc(&q, n));
+    p = q;
+    bytes = n;
+    if (zero)
+        SH_HIP(hipMemset(p, 0, n));
+    return SDSL_HIP_OK;
+}
+
+void DevBuf::release()
+{
+    if (p)
+        (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+}
+
+sdsl_hip_status Staged::in(const void * ptr, size_t nbytes, hipStream_t s)
+{
+    bytes = nbytes;
+    if (nbytes == 0 || is_device_ptr(ptr))
+    {
+        dev = const_cast<void *>(ptr);
+        host = nullptr;
+        return SDSL_HIP_OK;
+    }
+    SH_TRY(tmp.alloc(nbytes));
+    SH_HIP(hipMemcpyAsync(tmp.p, ptr, nbytes, hipMemcpyHostToDevice, s));
+    dev = tmp.p;
+    host = const_cast<void *>(ptr);
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status Staged::out(void * ptr, size_t nbytes)
+{
+    bytes = nbytes;
+    if (nbytes == 0 || is_device_ptr(ptr))
+    {
+        dev = ptr;
+        host = nullptr;
+        return SDSL_HIP_OK;
+    }
+    SH_TRY(tmp.alloc(nbytes));
+    dev = tmp.p;
+    host = ptr;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status Staged::finish(hipStream_t s)
+{
+    if (host && bytes)
+    {
+        SH_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+        SH_HIP(hipStreamSynchronize(s));
+    }
+    return SDSL_HIP_OK;
+}
+
+KernelTimer::KernelTimer(hipStream_t stream) : s(stream), on(g_timing)
+{
+    if (!on)
+        return;
+    if (!g_ev_start)
+    {
+        if (hipEventCreate(&g_ev_start) != hipSuccess || hipEventCreate(&g_ev_stop) != hipSuccess)
+        {
+            on = false;
+            return;
+        }
+    }
+    (void)hipEventRecord(g_ev_start, s);
+}
+
+KernelTimer::~KernelTimer()
+{
+    if (!on)
+        return;
+    (void)hipEventRecord(g_ev_stop, s);
+    g_ev_valid = true;
+}
+
+} // namespace sdslhip
+
+using namespace sdslhip;
+
+extern "C" {
+
+const char * sdsl_hip_last_error(void)
+{
+    return g_err.c_str();
+}
+
+const char * sdsl_hip_version(void)
+{
+    return "sdsl_hip 0.1 (gfx950)";
+}
+
+int32_t sdsl_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int ok = 0;
+    for (int d = 0; d < n; ++d)
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+            ++ok;
+    }
+    return ok;
+}
+
+sdsl_hip_status sdsl_hip_util_set_random_bits(uint64_t * words, uint64_t n_bits, uint64_t seed)
+{
+    if (!words && n_bits)
+    {
+        set_error("set_random_bits: null words");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    // util.hpp:467-485 — one mt19937_64 output per 64-bit word; like SDSL the last word is NOT
+    // masked (stray bits above n_bits are legal in an int_vector and every consumer ignores them)
+    std::mt19937_64 rng(seed);
+    uint64_t nw = (n_bits + 63) >> 6;
+    for (uint64_t i = 0; i < nw; ++i)
+        words[i] = rng();
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_set_timing(int32_t enabled)
+{
+    g_timing = enabled != 0;
+    g_ev_valid = false;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_last_kernel_ms(float * ms_out)
+{
+    if (!ms_out)
+        return SDSL_HIP_ERR_INVALID;
+    if (!g_ev_valid)
+    {
+        set_error("no timed kernel launch recorded (call sdsl_hip_set_timing(1) first)");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_HIP(hipEventSynchronize(g_ev_stop));
+    SH_HIP(hipEventElapsedTime(ms_out, g_ev_start, g_ev_stop));
+    return SDSL_HIP_OK;
+}
+}

@@ -1,0 +1,189 @@
+// gather_probe.hip — calibration micro-benchmark behind DESIGN.md §3: how fast can gfx950 fetch
+// RANDOM aligned chunks of 32 / 64 / 128 bytes from a multi-GiB table, as a function of how
+// many lanes cooperate on one chunk and of the cache policy of the load?  Not part of the
+// library; built by build.py into sdsl-lite_amd/lib/gather_probe and run by hand via gpurun.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                                                      \
+    do {                                                                                                           \
+        hipError_t e = (x);                                                                                        \
+        if (e != hipSuccess)                                                                                       \
+        {                                                                                                          \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__);                 \
+            exit(1);                                                                                               \
+        }                                                                                                          \
+    } while (0)
+
+typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint64_t mix(uint64_t x)
+{ // splitmix64 finaliser: query positions are generated in-kernel so only the table is read
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// CHUNK bytes per query, LPC lanes per chunk (each lane loads CHUNK/LPC bytes as 16-B vectors),
+// U queries in flight per lane group.
+template <int CHUNK, int LPC, int U, bool NT, bool IDX_FROM_MEM>
+__global__ __launch_bounds__(256) void k_gather(const v2u64 * __restrict__ table, uint64_t n_chunks,
+                                                const uint64_t * __restrict__ idx, uint64_t * __restrict__ out,
+                                                uint64_t n_q)
+{
+    constexpr int V = CHUNK / 16 / LPC; // 16-B vectors per lane
+    const int s = threadIdx.x % LPC;
+    const unsigned gq = threadIdx.x / LPC;
+    constexpr unsigned QPB = 256 / LPC;
+    for (uint64_t base = (uint64_t)blockIdx.x * QPB * U; base < n_q; base += (uint64_t)gridDim.x * QPB * U)
+    {
+        v2u64 v[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            uint64_t q = base + (uint64_t)u * QPB + gq;
+            uint64_t c;
+            if (IDX_FROM_MEM)
+                c = q < n_q ? idx[q] : 0;
+            else
+                c = mix(q) % n_chunks;
+            const v2u64 * p = table + c * (CHUNK / 16) + s * V;
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                v[u][k] = NT ? __builtin_nontemporal_load(p + k) : p[k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            uint64_t q = base + (uint64_t)u * QPB + gq;
+            uint64_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < V; ++k)
+                acc += __popcll(v[u][k].x) + __popcll(v[u][k].y);
+            // reduce over the LPC lanes with shuffles (cost is irrelevant here)
+            for (int m = 1; m < LPC; m <<= 1)
+                acc += __shfl_xor(acc, m, 64);
+            if (s == 0 && q < n_q)
+                out[q] = acc;
+        }
+    }
+}
+
+__global__ void k_fill(uint64_t * p, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i] = mix(i);
+}
+__global__ void k_fill_idx(uint64_t * p, uint64_t n, uint64_t mod)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i] = mix(i * 7 + 1) % mod;
+}
+__global__ void k_stream(const v2u64 * __restrict__ t, uint64_t n16, uint64_t * out)
+{
+    uint64_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        v2u64 v = t[i];
+        acc += v.x ^ v.y;
+    }
+    if (acc == 0x1234567)
+        out[0] = acc;
+}
+
+template <class F>
+static float time_ms(F f, int reps)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i)
+        f();
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+template <int CHUNK, int LPC, int U, bool NT, bool IDXM>
+static void run(const char * name, const v2u64 * table, uint64_t table_bytes, const uint64_t * idx, uint64_t * out,
+                uint64_t nq, unsigned blocks_per_cu)
+{
+    uint64_t n_chunks = table_bytes / CHUNK;
+    unsigned grid = 256u * blocks_per_cu;
+    float ms = time_ms(
+        [&] {
+            hipLaunchKernelGGL((k_gather<CHUNK, LPC, U, NT, IDXM>), dim3(grid), dim3(256), 0, 0, table, n_chunks, idx,
+                               out, nq);
+        },
+        3);
+    double gq = nq / (ms * 1e-3) / 1e9;
+    printf("%-34s chunk=%3d lpc=%d U=%d nt=%d idxmem=%d bpc=%u : %8.3f ms  %7.2f Gq/s  chunk-GB/s=%8.1f\n", name, CHUNK,
+           LPC, U, (int)NT, (int)IDXM, blocks_per_cu, ms, gq, gq * CHUNK);
+    fflush(stdout);
+}
+
+int main(int argc, char ** argv)
+{
+    uint64_t table_bytes = (argc > 1 ? strtoull(argv[1], 0, 10) : 2304ull) << 20; // MiB
+    uint64_t nq = argc > 2 ? strtoull(argv[2], 0, 10) : (1ull << 28);
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s  CUs=%d  clock=%d MHz  L2=%d KiB\n", prop.gcnArchName, prop.multiProcessorCount,
+           prop.clockRate / 1000, prop.l2CacheSize / 1024);
+    v2u64 * table;
+    uint64_t *idx, *out;
+    CK(hipMalloc(&table, table_bytes));
+    CK(hipMalloc(&idx, nq * 8));
+    CK(hipMalloc(&out, nq * 8));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint64_t *)table, table_bytes / 8);
+    CK(hipDeviceSynchronize());
+    printf("table = %.2f GiB, queries = %llu\n", table_bytes / 1073741824.0, (unsigned long long)nq);
+
+    float ms = time_ms([&] { hipLaunchKernelGGL(k_stream, dim3(2048), dim3(256), 0, 0, table, table_bytes / 16, out); }, 3);
+    printf("streaming read of the table: %.3f ms = %.1f GB/s\n", ms, table_bytes / (ms * 1e-3) / 1e9);
+
+    // ---- in-kernel generated positions: isolates the gather itself -------------------------
+    run<32, 2, 4, false, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<32, 2, 4, true, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<32, 1, 4, true, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<64, 4, 4, false, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<64, 4, 4, true, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<64, 4, 2, true, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<64, 4, 8, true, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<64, 2, 4, true, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<64, 1, 4, true, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<64, 1, 2, true, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<128, 8, 4, false, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<128, 8, 4, true, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<128, 4, 4, true, false>("gen idx", table, table_bytes, idx, out, nq, 8);
+    run<64, 4, 4, true, false>("gen idx bpc4", table, table_bytes, idx, out, nq, 4);
+    run<64, 4, 4, true, false>("gen idx bpc16", table, table_bytes, idx, out, nq, 16);
+
+    // ---- positions read from memory + results written: the real query I/O ------------------
+    for (int chunk : {32, 64, 128})
+    {
+        hipLaunchKernelGGL(k_fill_idx, dim3(4096), dim3(256), 0, 0, idx, nq, table_bytes / chunk);
+        CK(hipDeviceSynchronize());
+        if (chunk == 32)
+            run<32, 2, 4, true, true>("mem idx", table, table_bytes, idx, out, nq, 8);
+        if (chunk == 64)
+        {
+            run<64, 4, 4, true, true>("mem idx", table, table_bytes, idx, out, nq, 8);
+            run<64, 4, 4, false, true>("mem idx", table, table_bytes, idx, out, nq, 8);
+            run<64, 1, 4, true, true>("mem idx", table, table_bytes, idx, out, nq, 8);
+        }
+        if (chunk == 128)
+            run<128, 8, 4, true, true>("mem idx", table, table_bytes, idx, out, nq, 8);
+    }
+    return 0;
+}

@@ -1,0 +1,184 @@
+"""Python host mirror of the SDSL concepts served by libsdsl_hip (used by tests/ and bench.py).
+
+Class and method names follow the reference (bit_vector / rank_support_v5 / select_support_mcl /
+rrr_vector / wt_huff / csa_wt / count); every query method takes an ARRAY of arguments and
+returns an array, on the device when the input is a CUDA(HIP) torch tensor and on the host when
+it is a numpy array.  torch is plumbing here: device memory, streams, torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_tensor(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _ptr(x) -> int:
+    if _is_tensor(x):
+        return x.data_ptr()
+    return x.ctypes.data
+
+
+def _stream_for(x) -> int:
+    if _is_tensor(x) and x.is_cuda:
+        return torch.cuda.current_stream(x.device).cuda_stream
+    return 0
+
+
+def _as_array(x, dtype, name):
+    """Contiguous array of `dtype`: torch tensors stay where they are, everything else -> numpy."""
+    if _is_tensor(x):
+        want = {np.uint64: (torch.int64, torch.uint64), np.uint8: (torch.uint8,)}[dtype]
+        if x.dtype not in want:
+            raise TypeError(f"{name}: expected {want}, got {x.dtype}")
+        return x.contiguous()
+    a = np.ascontiguousarray(x, dtype=dtype)
+    return a
+
+
+def _empty_like(x, n, dtype):
+    if _is_tensor(x):
+        tdt = {np.uint64: torch.int64, np.uint8: torch.uint8}[dtype]
+        return torch.empty(n, dtype=tdt, device=x.device)
+    return np.empty(n, dtype=dtype)
+
+
+class _Handle:
+    _destroy = None
+
+    def __init__(self):
+        self._h = C.c_void_p(None)
+        self._own = True
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h and self._own:
+            getattr(capi.lib(), self._destroy)(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class bit_vector(_Handle):
+    """Device-resident sdsl::bit_vector with rank_support_v5<0/1> and select_support_mcl<0/1>.
+
+    words: uint64 array (numpy, or torch int64/uint64 tensor on host or device) = bit_vector::data()
+    """
+    _destroy = "sdsl_hip_bv_destroy"
+
+    def __init__(self, words, n_bits: int | None = None, device: int = 0, select1: bool = True,
+                 select0: bool = True):
+        super().__init__()
+        w = _as_array(words, np.uint64, "words")
+        nw = w.numel() if _is_tensor(w) else w.size
+        if n_bits is None:
+            n_bits = nw * 64
+        if (n_bits + 63) // 64 > nw:
+            raise ValueError("words too short for n_bits")
+        flags = (capi.BV_SELECT1 if select1 else 0) | (capi.BV_SELECT0 if select0 else 0)
+        capi.check(capi.lib().sdsl_hip_bv_create(_ptr(w) if nw else None, n_bits, device, flags,
+                                                 C.byref(self._h)))
+        self.device = device
+
+    def size(self) -> int:
+        return capi.lib().sdsl_hip_bv_size(self._h)
+
+    __len__ = size
+
+    def ones(self) -> int:
+        return capi.lib().sdsl_hip_bv_ones(self._h)
+
+    def device_bytes(self) -> int:
+        return capi.lib().sdsl_hip_bv_device_bytes(self._h)
+
+    def rank(self, idx, bit: int = 1, out=None):
+        idx = _as_array(idx, np.uint64, "idx")
+        n = idx.numel() if _is_tensor(idx) else idx.size
+        if out is None:
+            out = _empty_like(idx, n, np.uint64)
+        capi.check(capi.lib().sdsl_hip_bv_rank_batch(self._h, bit, _ptr(idx), n, _ptr(out), _stream_for(idx)))
+        return out
+
+    def select(self, i, bit: int = 1, out=None):
+        i = _as_array(i, np.uint64, "i")
+        n = i.numel() if _is_tensor(i) else i.size
+        if out is None:
+            out = _empty_like(i, n, np.uint64)
+        capi.check(capi.lib().sdsl_hip_bv_select_batch(self._h, bit, _ptr(i), n, _ptr(out), _stream_for(i)))
+        return out
+
+    def access(self, idx, out=None):
+        idx = _as_array(idx, np.uint64, "idx")
+        n = idx.numel() if _is_tensor(idx) else idx.size
+        if out is None:
+            out = _empty_like(idx, n, np.uint8)
+        capi.check(capi.lib().sdsl_hip_bv_access_batch(self._h, _ptr(idx), n, _ptr(out), _stream_for(idx)))
+        return out
+
+    __getitem__ = access
+
+    def export_words(self) -> np.ndarray:
+        out = np.zeros((self.size() + 63) // 64, dtype=np.uint64)
+        capi.check(capi.lib().sdsl_hip_bv_export_words(self._h, _ptr(out) if out.size else None, 0))
+        return out
+
+
+class rank_support_v5:
+    """rank_support_v5<t_b> view of a device bit_vector (rank_support_v5.hpp:44)."""
+
+    def __init__(self, bv: bit_vector, t_b: int = 1):
+        self.m_v, self.t_b = bv, t_b
+
+    def rank(self, idx, out=None):
+        return self.m_v.rank(idx, self.t_b, out)
+
+    __call__ = rank
+
+    def size(self):
+        return self.m_v.size()
+
+
+class select_support_mcl:
+    """select_support_mcl<t_b> view of a device bit_vector (select_support_mcl.hpp:64)."""
+
+    def __init__(self, bv: bit_vector, t_b: int = 1):
+        self.m_v, self.t_b = bv, t_b
+
+    def select(self, i, out=None):
+        return self.m_v.select(i, self.t_b, out)
+
+    __call__ = select
+
+    def size(self):
+        return self.m_v.size()
+
+
+def set_timing(enabled: bool) -> None:
+    capi.check(capi.lib().sdsl_hip_set_timing(1 if enabled else 0))
+
+
+def last_kernel_ms() -> float:
+    ms = C.c_float(0)
+    capi.check(capi.lib().sdsl_hip_last_kernel_ms(C.byref(ms)))
+    return float(ms.value)
+
+
+def set_random_bits(n_bits: int, seed: int) -> np.ndarray:
+    """util::set_random_bits on a fresh bit_vector(n_bits): returns the uint64 words."""
+    w = np.zeros((n_bits + 63) // 64, dtype=np.uint64)
+    if w.size:
+        capi.check(capi.lib().sdsl_hip_util_set_random_bits(_ptr(w), n_bits, seed))
+    return w
