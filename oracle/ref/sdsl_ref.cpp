@@ -1,0 +1,358 @@
+// sdsl_ref.cpp — extern "C" wrappers around the REAL sdsl-lite headers (compiled from
+// /root/reference/include where they lie; nothing of the reference is copied into this repo).
+// Built by oracle/Makefile into oracle/_ref/libsdsl_ref.so.  TEST INFRASTRUCTURE ONLY: it pins the
+// C restatement (oracle.c), generates the golden fixtures (tests/golden/make_golden.py) and serves
+// as bench.py's cpu_baseline of kind "reference".  It is never loaded by the product library.
+#include <sdsl/bit_vectors.hpp>
+#include <sdsl/suffix_arrays.hpp>
+#include <sdsl/wavelet_trees.hpp>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <string>
+#include <vector>
+
+using namespace sdsl;
+
+namespace {
+
+template <class T>
+void to_bytes(T const & x, uint8_t ** out, uint64_t * len)
+{
+    std::ostringstream os;
+    x.serialize(os);
+    std::string s = os.str();
+    *len = s.size();
+    *out = (uint8_t *)malloc(s.size() ? s.size() : 1);
+    memcpy(*out, s.data(), s.size());
+}
+
+struct RefBv
+{
+    bit_vector bv;
+    rank_support_v5<1> r1;
+    rank_support_v5<0> r0;
+    rank_support_v<1> rv1;
+    select_support_mcl<1> s1;
+    select_support_mcl<0> s0;
+};
+
+typedef rrr_vector<63> rrr_t;
+struct RefRrr
+{
+    rrr_t v;
+    rrr_t::rank_1_type r1;
+    rrr_t::rank_0_type r0;
+    rrr_t::select_1_type s1;
+    rrr_t::select_0_type s0;
+};
+
+typedef wt_huff<bit_vector, rank_support_v5<>> wt_t; // selects default to select_support_mcl<1>/<0>
+typedef wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>> wt_scan_t;
+typedef csa_wt<wt_t> csa_t;                                   // t_dens 32, t_inv_dens 64
+typedef csa_wt<wt_scan_t, 1 << 20, 1 << 20> csa_fmhuff_t;   // benchmark/indexing_count/index.config:8
+
+struct RefWt
+{
+    wt_t wt;
+    wt_scan_t wts;
+};
+struct RefCsa
+{
+    csa_t csa;
+    csa_fmhuff_t csa2;
+    bool have2 = false;
+};
+
+} // namespace
+
+extern "C" {
+
+void ref_free(void * p)
+{
+    free(p);
+}
+
+// ---------------- plain bit vector -------------------------------------------------------
+void * ref_bv_create(const uint64_t * words, uint64_t n_bits)
+{
+    RefBv * h = new RefBv();
+    h->bv = bit_vector(n_bits, 0);
+    if (n_bits)
+        memcpy(h->bv.data(), words, ((n_bits + 63) >> 6) * 8); // keeps stray bits of the last word
+    h->r1 = rank_support_v5<1>(&h->bv);
+    h->r0 = rank_support_v5<0>(&h->bv);
+    h->rv1 = rank_support_v<1>(&h->bv);
+    h->s1 = select_support_mcl<1>(&h->bv);
+    h->s0 = select_support_mcl<0>(&h->bv);
+    return h;
+}
+void ref_bv_destroy(void * p)
+{
+    delete (RefBv *)p;
+}
+void ref_bv_rank(void * p, int bit, const uint64_t * idx, uint64_t n, uint64_t * out)
+{
+    RefBv * h = (RefBv *)p;
+    if (bit)
+        for (uint64_t q = 0; q < n; ++q)
+            out[q] = h->r1(idx[q]);
+    else
+        for (uint64_t q = 0; q < n; ++q)
+            out[q] = h->r0(idx[q]);
+}
+void ref_bv_rank_v(void * p, const uint64_t * idx, uint64_t n, uint64_t * out)
+{
+    RefBv * h = (RefBv *)p;
+    for (uint64_t q = 0; q < n; ++q)
+        out[q] = h->rv1(idx[q]);
+}
+void ref_bv_select(void * p, int bit, const uint64_t * i, uint64_t n, uint64_t * out)
+{
+    RefBv * h = (RefBv *)p;
+    if (bit)
+        for (uint64_t q = 0; q < n; ++q)
+            out[q] = h->s1(i[q]);
+    else
+        for (uint64_t q = 0; q < n; ++q)
+            out[q] = h->s0(i[q]);
+}
+// which: 0 bit_vector, 1 rank_support_v5<1>, 2 rank_support_v5<0>, 3 select_support_mcl<1>, 4 select_support_mcl<0>
+void ref_bv_serialize(void * p, int which, uint8_t ** out, uint64_t * len)
+{
+    RefBv * h = (RefBv *)p;
+    switch (which)
+    {
+    case 0: to_bytes(h->bv, out, len); break;
+    case 1: to_bytes(h->r1, out, len); break;
+    case 2: to_bytes(h->r0, out, len); break;
+    case 3: to_bytes(h->s1, out, len); break;
+    default: to_bytes(h->s0, out, len); break;
+    }
+}
+
+// ---------------- rrr_vector<63> -----------------------------------------------------------
+void * ref_rrr_create(const uint64_t * words, uint64_t n_bits)
+{
+    bit_vector bv(n_bits, 0);
+    if (n_bits)
+        memcpy(bv.data(), words, ((n_bits + 63) >> 6) * 8);
+    if (n_bits & 63) // rrr_vector reads whole blocks through get_int: keep the padding clean like SDSL users do
+        bv.data()[(n_bits - 1) >> 6] &= bits::lo_set[n_bits & 63];
+    RefRrr * h = new RefRrr();
+    h->v = rrr_t(bv);
+    h->r1 = rrr_t::rank_1_type(&h->v);
+    h->r0 = rrr_t::rank_0_type(&h->v);
+    h->s1 = rrr_t::select_1_type(&h->v);
+    h->s0 = rrr_t::select_0_type(&h->v);
+    return h;
+}
+void ref_rrr_destroy(void * p)
+{
+    delete (RefRrr *)p;
+}
+void ref_rrr_rank(void * p, int bit, const uint64_t * i, uint64_t n, uint64_t * out)
+{
+    RefRrr * h = (RefRrr *)p;
+    if (bit)
+        for (uint64_t q = 0; q < n; ++q)
+            out[q] = h->r1(i[q]);
+    else
+        for (uint64_t q = 0; q < n; ++q)
+            out[q] = h->r0(i[q]);
+}
+void ref_rrr_select(void * p, int bit, const uint64_t * i, uint64_t n, uint64_t * out)
+{
+    RefRrr * h = (RefRrr *)p;
+    if (bit)
+        for (uint64_t q = 0; q < n; ++q)
+            out[q] = h->s1(i[q]);
+    else
+        for (uint64_t q = 0; q < n; ++q)
+            out[q] = h->s0(i[q]);
+}
+void ref_rrr_access(void * p, const uint64_t * i, uint64_t n, uint8_t * out)
+{
+    RefRrr * h = (RefRrr *)p;
+    for (uint64_t q = 0; q < n; ++q)
+        out[q] = h->v[i[q]];
+}
+void ref_rrr_serialize(void * p, uint8_t ** out, uint64_t * len)
+{
+    to_bytes(((RefRrr *)p)->v, out, len);
+}
+
+// ---------------- wt_huff<bit_vector, rank_support_v5<>> -----------------------------------
+void * ref_wt_create(const uint8_t * text, uint64_t n)
+{
+    RefWt * h = new RefWt();
+    h->wt = wt_t(text, text + n);       // unsigned bytes (wt_helper.hpp:50-57 pitfall in SURVEY §3.4)
+    h->wts = wt_scan_t(text, text + n);
+    return h;
+}
+void ref_wt_destroy(void * p)
+{
+    delete (RefWt *)p;
+}
+uint64_t ref_wt_size(void * p)
+{
+    return ((RefWt *)p)->wt.size();
+}
+uint64_t ref_wt_sigma(void * p)
+{
+    return ((RefWt *)p)->wt.sigma;
+}
+uint64_t ref_wt_bv_size(void * p)
+{
+    return ((RefWt *)p)->wt.bv.size();
+}
+void ref_wt_rank(void * p, const uint64_t * i, const uint8_t * c, uint64_t n, uint64_t * out)
+{
+    RefWt * h = (RefWt *)p;
+    for (uint64_t q = 0; q < n; ++q)
+        out[q] = h->wt.rank(i[q], c[q]);
+}
+void ref_wt_access(void * p, const uint64_t * i, uint64_t n, uint8_t * out)
+{
+    RefWt * h = (RefWt *)p;
+    for (uint64_t q = 0; q < n; ++q)
+        out[q] = h->wt[i[q]];
+}
+void ref_wt_inverse_select(void * p, const uint64_t * i, uint64_t n, uint64_t * out_rank, uint8_t * out_c)
+{
+    RefWt * h = (RefWt *)p;
+    for (uint64_t q = 0; q < n; ++q)
+    {
+        auto r = h->wt.inverse_select(i[q]);
+        out_rank[q] = r.first;
+        out_c[q] = r.second;
+    }
+}
+void ref_wt_select(void * p, const uint64_t * i, const uint8_t * c, uint64_t n, uint64_t * out)
+{
+    RefWt * h = (RefWt *)p;
+    for (uint64_t q = 0; q < n; ++q)
+        out[q] = h->wt.select(i[q], c[q]);
+}
+void ref_wt_serialize(void * p, int select_is_mcl, uint8_t ** out, uint64_t * len)
+{
+    RefWt * h = (RefWt *)p;
+    if (select_is_mcl)
+        to_bytes(h->wt, out, len);
+    else
+        to_bytes(h->wts, out, len);
+}
+
+// ---------------- csa_wt<wt_huff<...>> -----------------------------------------------------
+void * ref_csa_create(const uint8_t * text, uint64_t n, int also_fm_huff)
+{
+    RefCsa * h = new RefCsa();
+    std::string s((const char *)text, n);
+    construct_im(h->csa, s, 1);
+    if (also_fm_huff)
+    {
+        construct_im(h->csa2, s, 1);
+        h->have2 = true;
+    }
+    return h;
+}
+void ref_csa_destroy(void * p)
+{
+    delete (RefCsa *)p;
+}
+uint64_t ref_csa_size(void * p)
+{
+    return ((RefCsa *)p)->csa.size();
+}
+uint64_t ref_csa_sigma(void * p)
+{
+    return ((RefCsa *)p)->csa.sigma;
+}
+void ref_csa_bwt(void * p, uint8_t * out)
+{
+    RefCsa * h = (RefCsa *)p;
+    for (uint64_t i = 0; i < h->csa.size(); ++i)
+        out[i] = h->csa.bwt[i];
+}
+void ref_csa_alphabet(void * p, uint8_t * char2comp, uint64_t * C)
+{
+    RefCsa * h = (RefCsa *)p;
+    for (int c = 0; c < 256; ++c)
+        char2comp[c] = h->csa.char2comp[c];
+    for (uint64_t i = 0; i <= h->csa.sigma; ++i)
+        C[i] = h->csa.C[i];
+}
+void ref_csa_count(void * p, const uint8_t * pats, uint32_t m, uint64_t n_pat, uint64_t * out)
+{
+    RefCsa * h = (RefCsa *)p;
+    for (uint64_t q = 0; q < n_pat; ++q)
+    {
+        const uint8_t * b = pats + q * (uint64_t)m;
+        out[q] = count(h->csa, b, b + m);
+    }
+}
+void ref_csa_count_ragged(void * p, const uint8_t * bytes, const uint64_t * offs, uint64_t n_pat, uint64_t * out)
+{
+    RefCsa * h = (RefCsa *)p;
+    for (uint64_t q = 0; q < n_pat; ++q)
+        out[q] = count(h->csa, bytes + offs[q], bytes + offs[q + 1]);
+}
+void ref_csa_interval(void * p, const uint8_t * pats, uint32_t m, uint64_t n_pat, uint64_t * l_out, uint64_t * r_out)
+{
+    RefCsa * h = (RefCsa *)p;
+    for (uint64_t q = 0; q < n_pat; ++q)
+    {
+        const uint8_t * b = pats + q * (uint64_t)m;
+        uint64_t l, r;
+        backward_search(h->csa, 0, h->csa.size() - 1, b, b + m, l, r);
+        l_out[q] = l;
+        r_out[q] = r;
+    }
+}
+void ref_csa_backward_search(void * p, const uint64_t * l, const uint64_t * r, const uint8_t * c, uint64_t n,
+                             uint64_t * l_out, uint64_t * r_out)
+{
+    RefCsa * h = (RefCsa *)p;
+    for (uint64_t q = 0; q < n; ++q)
+    {
+        uint64_t a, b;
+        backward_search(h->csa, l[q], r[q], (csa_t::char_type)c[q], a, b);
+        l_out[q] = a;
+        r_out[q] = b;
+    }
+}
+// which: 0 = csa_wt<wt_huff<bit_vector,rank_support_v5<>>>, 1 = the FM_HUFF type of the count benchmark
+void ref_csa_serialize(void * p, int which, uint8_t ** out, uint64_t * len)
+{
+    RefCsa * h = (RefCsa *)p;
+    if (which == 0)
+        to_bytes(h->csa, out, len);
+    else
+        to_bytes(h->csa2, out, len);
+}
+void ref_csa_wt_rank(void * p, const uint64_t * i, const uint8_t * c, uint64_t n, uint64_t * out)
+{
+    RefCsa * h = (RefCsa *)p;
+    for (uint64_t q = 0; q < n; ++q)
+        out[q] = h->csa.wavelet_tree.rank(i[q], c[q]);
+}
+
+void ref_set_random_bits(uint64_t * words, uint64_t n_bits, int seed)
+{
+    bit_vector bv(n_bits, 0);
+    util::set_random_bits(bv, seed);
+    memcpy(words, bv.data(), ((n_bits + 63) >> 6) * 8);
+}
+
+uint32_t ref_bits_sel(uint64_t x, uint32_t i)
+{
+    return bits::sel(x, i);
+}
+uint32_t ref_bits_hi(uint64_t x)
+{
+    return bits::hi(x);
+}
+}

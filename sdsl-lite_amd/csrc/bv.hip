@@ -331,10 +331,19 @@ sdsl_hip_status bv_launch_rank(const BvView & v, int bit, const uint64_t * d_idx
 {
     if (n == 0)
         return SDSL_HIP_OK;
-    constexpr int U = 4;
+    static const int variant = getenv("SDSL_HIP_RANK_VARIANT") ? atoi(getenv("SDSL_HIP_RANK_VARIANT")) : 0;
     KernelTimer t(s);
-    hipLaunchKernelGGL((k_rank<U, true>), dim3(query_grid(n, kQPB * U)), dim3(kBlock), 0, s, v, bit, d_idx, d_out,
-                       n);
+#define SH_LAUNCH_RANK(U, NT)                                                                                      \
+    hipLaunchKernelGGL((k_rank<U, NT>), dim3(query_grid(n, kQPB * U)), dim3(kBlock), 0, s, v, bit, d_idx, d_out, n)
+    switch (variant)
+    { // experiment knob; 0 is the tuned default
+    case 1: SH_LAUNCH_RANK(4, true); break;
+    case 2: SH_LAUNCH_RANK(2, false); break;
+    case 3: SH_LAUNCH_RANK(8, false); break;
+    case 4: SH_LAUNCH_RANK(1, false); break;
+    default: SH_LAUNCH_RANK(4, false); break;
+    }
+#undef SH_LAUNCH_RANK
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK(x)                                                                                                      \
@@ -132,8 +133,36 @@ static void run(const char * name, const v2u64 * table, uint64_t table_bytes, co
     fflush(stdout);
 }
 
+static int sweep(int argc, char ** argv)
+{ // gather_probe sweep <nq> <MiB> <MiB> ... : random-gather rate as a function of table size
+    uint64_t nq = strtoull(argv[2], 0, 10);
+    uint64_t max_bytes = 0;
+    for (int i = 3; i < argc; ++i)
+        if ((strtoull(argv[i], 0, 10) << 20) > max_bytes)
+            max_bytes = strtoull(argv[i], 0, 10) << 20;
+    v2u64 * table;
+    uint64_t *idx, *out;
+    CK(hipMalloc(&table, max_bytes));
+    CK(hipMalloc(&idx, nq * 8));
+    CK(hipMalloc(&out, nq * 8));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint64_t *)table, max_bytes / 8);
+    CK(hipDeviceSynchronize());
+    for (int i = 3; i < argc; ++i)
+    {
+        uint64_t tb = strtoull(argv[i], 0, 10) << 20;
+        printf("--- table %llu MiB\n", (unsigned long long)(tb >> 20));
+        run<64, 4, 4, false, false>("sweep", table, tb, idx, out, nq, 8);
+        run<64, 4, 4, true, false>("sweep", table, tb, idx, out, nq, 8);
+        run<128, 8, 4, false, false>("sweep", table, tb, idx, out, nq, 8);
+        run<32, 2, 4, false, false>("sweep", table, tb, idx, out, nq, 8);
+    }
+    return 0;
+}
+
 int main(int argc, char ** argv)
 {
+    if (argc > 3 && !strcmp(argv[1], "sweep"))
+        return sweep(argc, argv);
     uint64_t table_bytes = (argc > 1 ? strtoull(argv[1], 0, 10) : 2304ull) << 20; // MiB
     uint64_t nq = argc > 2 ? strtoull(argv[2], 0, 10) : (1ull << 28);
     hipDeviceProp_t prop;
