@@ -251,11 +251,19 @@ void * ref_csa_create(const uint8_t * text, uint64_t n, int also_fm_huff)
 {
     RefCsa * h = new RefCsa();
     std::string s((const char *)text, n);
-    construct_im(h->csa, s, 1);
-    if (also_fm_huff)
+    try
     {
-        construct_im(h->csa2, s, 1);
-        h->have2 = true;
+        construct_im(h->csa, s, 1);
+        if (also_fm_huff)
+        {
+            construct_im(h->csa2, s, 1);
+            h->have2 = true;
+        }
+    }
+    catch (std::exception const &)
+    { // e.g. construct.hpp:41 "contains zero symbol"
+        delete h;
+        return nullptr;
     }
     return h;
 }

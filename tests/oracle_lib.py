@@ -541,6 +541,8 @@ class RCsa:
     def __init__(self, text: bytes, also_fm_huff=False):
         t = _u8arr(np.frombuffer(text, dtype=np.uint8))
         self.h = ref().L.ref_csa_create(_p(t) if t.size else None, t.size, 1 if also_fm_huff else 0)
+        if not self.h:
+            raise ValueError("sdsl::construct_im threw (text contains a 0 byte?)")
 
     def size(self):
         return ref().L.ref_csa_size(self.h)

@@ -56,7 +56,7 @@ def test_bits_primitives():
             assert L.orc_sel(x, i) == R.ref_bits_sel(x, i)
 
 
-@pytest.mark.parametrize("name", ["example01.txt", "abc_abc_abc.txt", "faust.txt", "rnd"])
+@pytest.mark.parametrize("name", ["example01.txt", "100a.txt", "faust.txt", "rnd"])
 def test_wt_and_csa(name):
     rng = np.random.default_rng(3)
     t = bytes(rng.integers(1, 256, size=30000, dtype=np.uint8)) if name == "rnd" else gd.text(name)
@@ -73,6 +73,8 @@ def test_wt_and_csa(name):
     assert ser[: len(sw)] == sw and ser[-len(sa):] == sa
     arr = np.frombuffer(t, dtype=np.uint8)
     for m in (3, 20):
+        if n < m:
+            continue
         st = rng.integers(0, n - m + 1, size=400)
         pats = np.concatenate([arr[s:s + m] for s in st])
         assert np.array_equal(oc.count_batch(pats, m), rc.count_batch(pats, m))
