@@ -1,0 +1,530 @@
+// fm.hip — csa_wt<wt_huff<bit_vector, rank_support_v5<>>> restricted to the count() path:
+// byte alphabet (C, char2comp), batched backward_search steps and whole-pattern count.
+//
+// Reference semantics reproduced:
+//   backward_search(csa,l,r,c,..)          suffix_array_algorithm.hpp:167-201
+//   backward_search(csa,l,r,begin,end,..)  suffix_array_algorithm.hpp:228-248
+//   count(csa,begin,end)                   suffix_array_algorithm.hpp:464-471
+//   byte_alphabet                          csa_alphabet_strategy.hpp:175-212
+//   csa_wt::rank_bwt                       csa_wt.hpp:286-289
+#include "wt_host.hpp"
+
+struct sdsl_hip_wt_s;
+sdsl_hip_wt_s * sdsl_hip_wt_alloc();
+sdslhip::WtHost & sdsl_hip_wt_host(sdsl_hip_wt_s * w);
+sdsl_hip_status sdsl_hip_wt_finish(sdsl_hip_wt_s * w);
+
+namespace sdslhip {
+
+struct FmTables
+{
+    uint64_t C[257];        // C[cc] = number of symbols smaller than comp2char[cc]; C[sigma] = size
+    uint8_t char2comp[256]; // 0 for absent bytes (and for the sentinel itself)
+};
+
+sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, std::vector<uint8_t> & bwt);
+
+// One pattern per quad.  The two rank cascades of every LF step run level-synchronously with both
+// line fetches in flight (wt_device.hpp: quad_wt_rank2).
+template <bool NT, bool WANT_IVAL>
+__global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables * __restrict__ ftab,
+                                                     uint64_t csa_size, const uint8_t * __restrict__ pats,
+                                                     uint32_t m, const uint64_t * __restrict__ offsets,
+                                                     uint64_t n_pat, uint64_t * __restrict__ out_cnt,
+                                                     uint64_t * __restrict__ out_l, uint64_t * __restrict__ out_r)
+{
+    __shared__ WtTables T;
+    __shared__ FmTables F;
+    {
+        const uint64_t * src = reinterpret_cast<const uint64_t *>(ftab);
+        uint64_t * dst = reinterpret_cast<uint64_t *>(&F);
+        for (unsigned i = threadIdx.x; i < sizeof(FmTables) / 8; i += blockDim.x)
+            dst[i] = src[i];
+    }
+    wt_stage_tables(&T, wt.tables); // ends with __syncthreads()
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n_pat; base += (uint64_t)gridDim.x * kQPB)
+    {
+        uint64_t q = base + gq;
+        if (q >= n_pat)
+            continue;
+        uint64_t begin = offsets ? offsets[q] : q * (uint64_t)m;
+        uint64_t end = offsets ? offsets[q + 1] : begin + m;
+        uint64_t l = 0, r = csa_size - 1;
+        if (!WANT_IVAL && end - begin > csa_size)
+        { // count(): a pattern longer than the text cannot occur (:466-467)
+            l = 1;
+            r = 0;
+            end = begin;
+        }
+        for (uint64_t it = end; it > begin && r + 1 - l > 0;)
+        {
+            --it;
+            unsigned c = pats[it];
+            unsigned cc = F.char2comp[c];
+            if (cc == 0 && c > 0)
+            { // character does not occur (:180-184)
+                l = 1;
+                r = 0;
+            }
+            else
+            {
+                uint64_t cb = F.C[cc];
+                if (l == 0 && r + 1 == csa_size)
+                { // whole interval: no rank needed (:188-192)
+                    l = cb;
+                    r = F.C[cc + 1] - 1;
+                }
+                else
+                {
+                    uint64_t a = l, b = r + 1;
+                    quad_wt_rank2<NT>(wt, &T, s, c, a, b);
+                    l = cb + a;
+                    r = cb + b - 1;
+                }
+            }
+        }
+        if (s == 0)
+        {
+            if (WANT_IVAL)
+            {
+                out_l[q] = l;
+                out_r[q] = r;
+            }
+            else
+                out_cnt[q] = r + 1 - l;
+        }
+    }
+}
+
+// one LF step per element
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void k_fm_backward_step(WtView wt, const FmTables * __restrict__ ftab,
+                                                             uint64_t csa_size, const uint64_t * __restrict__ lq,
+                                                             const uint64_t * __restrict__ rq,
+                                                             const uint8_t * __restrict__ cq, uint64_t n,
+                                                             uint64_t * __restrict__ out_l,
+                                                             uint64_t * __restrict__ out_r)
+{
+    __shared__ WtTables T;
+    __shared__ FmTables F;
+    {
+        const uint64_t * src = reinterpret_cast<const uint64_t *>(ftab);
+        uint64_t * dst = reinterpret_cast<uint64_t *>(&F);
+        for (unsigned i = threadIdx.x; i < sizeof(FmTables) / 8; i += blockDim.x)
+            dst[i] = src[i];
+    }
+    wt_stage_tables(&T, wt.tables);
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
+    {
+        uint64_t q = base + gq;
+        if (q >= n)
+            continue;
+        uint64_t l = lq[q], r = rq[q];
+        unsigned c = cq[q];
+        uint64_t lo, ro;
+        if (!(l <= r && r < csa_size))
+        { // outside SDSL's precondition (asserts :177-178)
+            lo = ro = SDSL_HIP_NPOS;
+        }
+        else
+        {
+            unsigned cc = F.char2comp[c];
+            if (cc == 0 && c > 0)
+            {
+                lo = 1;
+                ro = 0;
+            }
+            else
+            {
+                uint64_t cb = F.C[cc];
+                if (l == 0 && r + 1 == csa_size)
+                {
+                    lo = cb;
+                    ro = F.C[cc + 1] - 1;
+                }
+                else
+                {
+                    uint64_t a = l, b = r + 1;
+                    quad_wt_rank2<NT>(wt, &T, s, c, a, b);
+                    lo = cb + a;
+                    ro = cb + b - 1;
+                }
+            }
+        }
+        if (s == 0)
+        {
+            out_l[q] = lo;
+            out_r[q] = ro;
+        }
+    }
+}
+
+} // namespace sdslhip
+
+using namespace sdslhip;
+
+struct sdsl_hip_fm_s
+{
+    int device = 0;
+    uint64_t size = 0;
+    uint32_t sigma = 0;
+    sdsl_hip_wt_s * wt = nullptr;
+    FmTables tab;
+    DevBuf d_tab;
+};
+
+static void fm_free(sdsl_hip_fm_s * f)
+{
+    if (!f)
+        return;
+    if (f->wt)
+        sdsl_hip_wt_destroy(f->wt);
+    delete f;
+}
+
+// byte_alphabet from the symbol histogram (csa_alphabet_strategy.hpp:175-212)
+static void alphabet_from_counts(sdsl_hip_fm_s * f, const uint64_t occ[256])
+{
+    memset(&f->tab, 0, sizeof f->tab);
+    uint32_t sigma = 0;
+    uint64_t run = 0;
+    for (int c = 0; c < 256; ++c)
+        if (occ[c])
+        {
+            f->tab.char2comp[c] = (uint8_t)sigma;
+            f->tab.C[sigma] = run;
+            run += occ[c];
+            ++sigma;
+        }
+    f->tab.C[sigma] = run;
+    f->sigma = sigma;
+}
+
+static sdsl_hip_status fm_upload_tables(sdsl_hip_fm_s * f)
+{
+    SH_TRY(f->d_tab.alloc(sizeof(FmTables)));
+    SH_HIP(hipMemcpy(f->d_tab.p, &f->tab, sizeof(FmTables), hipMemcpyHostToDevice));
+    return SDSL_HIP_OK;
+}
+
+static sdsl_hip_status fm_from_host_bwt(sdsl_hip_fm_s * f, const uint8_t * bwt, uint64_t n, int device)
+{
+    f->device = device;
+    f->size = n;
+    f->wt = sdsl_hip_wt_alloc();
+    if (!f->wt)
+        return SDSL_HIP_ERR_NOMEM;
+    WtHost & w = sdsl_hip_wt_host(f->wt);
+    SH_TRY(wt_build_from_text(w, bwt, n, device)); // csa_wt.hpp:337-343: the WT is built over the BWT
+    SH_TRY(sdsl_hip_wt_finish(f->wt));
+    if (n == 0 || w.occ[0] != 1)
+    {
+        set_error("the BWT must contain exactly one 0 byte (the sentinel appended by construct.hpp:100-108); found %llu",
+                  (unsigned long long)(n ? w.occ[0] : 0));
+        return SDSL_HIP_ERR_INVALID;
+    }
+    alphabet_from_counts(f, w.occ);
+    return fm_upload_tables(f);
+}
+
+extern "C" {
+
+sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int32_t device, sdsl_hip_fm_t * out)
+{
+    if (!out || !bwt || n == 0)
+    {
+        set_error("fm_create_from_bwt: null/empty argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    sdsl_hip_fm_s * f = new (std::nothrow) sdsl_hip_fm_s();
+    if (!f)
+        return SDSL_HIP_ERR_NOMEM;
+    std::vector<uint8_t> tmp;
+    const uint8_t * host = bwt;
+    sdsl_hip_status st = SDSL_HIP_OK;
+    if (is_device_ptr(bwt))
+    {
+        tmp.resize(n);
+        hipError_t e = hipMemcpy(tmp.data(), bwt, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            st = hip_fail(e, "hipMemcpy(bwt)", __FILE__, __LINE__);
+        host = tmp.data();
+    }
+    if (st == SDSL_HIP_OK)
+        st = fm_from_host_bwt(f, host, n, device);
+    if (st != SDSL_HIP_OK)
+    {
+        fm_free(f);
+        return st;
+    }
+    *out = f;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_text, int32_t device,
+                                             sdsl_hip_fm_t * out)
+{
+    if (!out || (!text && n_text))
+    {
+        set_error("fm_create_from_text: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    std::vector<uint8_t> tmp;
+    const uint8_t * host = text;
+    if (n_text && is_device_ptr(text))
+    {
+        tmp.resize(n_text);
+        SH_HIP(hipMemcpy(tmp.data(), text, n_text, hipMemcpyDeviceToHost));
+        host = tmp.data();
+    }
+    for (uint64_t i = 0; i < n_text; ++i)
+        if (host[i] == 0)
+        {
+            set_error("text contains a 0 byte at %llu (SDSL's construct refuses this too, construct.hpp:41)",
+                      (unsigned long long)i);
+            return SDSL_HIP_ERR_INVALID;
+        }
+    std::vector<uint8_t> bwt;
+    SH_TRY(sa_build_bwt_device(host, n_text, device, bwt));
+    sdsl_hip_fm_s * f = new (std::nothrow) sdsl_hip_fm_s();
+    if (!f)
+        return SDSL_HIP_ERR_NOMEM;
+    sdsl_hip_status st = fm_from_host_bwt(f, bwt.data(), bwt.size(), device);
+    if (st != SDSL_HIP_OK)
+    {
+        fm_free(f);
+        return st;
+    }
+    *out = f;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int32_t select_is_mcl, int32_t device,
+                                             sdsl_hip_fm_t * out)
+{
+    if (!out || !bytes)
+    {
+        set_error("fm_create_from_sdsl: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    sdsl_hip_fm_s * f = new (std::nothrow) sdsl_hip_fm_s();
+    if (!f)
+        return SDSL_HIP_ERR_NOMEM;
+    f->device = device;
+    f->wt = sdsl_hip_wt_alloc();
+    StreamReader rd(bytes, len);
+    sdsl_hip_status st = f->wt ? SDSL_HIP_OK : SDSL_HIP_ERR_NOMEM;
+    if (st == SDSL_HIP_OK)
+        st = wt_build_from_stream(sdsl_hip_wt_host(f->wt), rd, select_is_mcl != 0, device);
+    if (st == SDSL_HIP_OK)
+        st = sdsl_hip_wt_finish(f->wt);
+    if (st == SDSL_HIP_OK)
+    {
+        // csa_wt::serialize (csa_wt.hpp:389-402): wt, sa_sample, isa_sample, alphabet.  The default
+        // sampling policies are plain int_vector<0> (csa_sampling_strategy.hpp:72,735) — skipped.
+        HostIntVec c2c, comp2char, Cv;
+        uint16_t sigma = 0;
+        if (!rd.skip_int_vector() || !rd.skip_int_vector() || !rd.int_vector(c2c, 8) || !rd.int_vector(comp2char, 8)
+            || !rd.int_vector(Cv, 64) || !rd.u16(sigma) || c2c.size() != 256 || sigma == 0 || sigma > 256
+            || Cv.size() != (uint64_t)sigma + 1)
+        {
+            set_error("malformed csa_wt stream (offset %zu of %zu)", rd.pos, rd.len);
+            st = SDSL_HIP_ERR_FORMAT;
+        }
+        else
+        {
+            memset(&f->tab, 0, sizeof f->tab);
+            for (int c = 0; c < 256; ++c)
+                f->tab.char2comp[c] = (uint8_t)c2c.get((uint64_t)c);
+            for (uint32_t i = 0; i <= sigma; ++i)
+                f->tab.C[i] = Cv.get(i);
+            f->sigma = sigma;
+            f->size = sdsl_hip_wt_host(f->wt).size;
+            if (f->tab.C[sigma] != f->size)
+            {
+                set_error("csa_wt stream: C[sigma] = %llu does not match the wavelet tree size %llu",
+                          (unsigned long long)f->tab.C[sigma], (unsigned long long)f->size);
+                st = SDSL_HIP_ERR_FORMAT;
+            }
+            else
+                st = fm_upload_tables(f);
+        }
+    }
+    if (st != SDSL_HIP_OK)
+    {
+        fm_free(f);
+        return st;
+    }
+    *out = f;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_destroy(sdsl_hip_fm_t fm)
+{
+    if (fm)
+        (void)hipSetDevice(fm->device);
+    fm_free(fm);
+    return SDSL_HIP_OK;
+}
+
+uint64_t sdsl_hip_fm_size(sdsl_hip_fm_t fm)
+{
+    return fm ? fm->size : 0;
+}
+uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm)
+{
+    return fm ? fm->sigma : 0;
+}
+uint64_t sdsl_hip_fm_device_bytes(sdsl_hip_fm_t fm)
+{
+    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes : 0;
+}
+sdsl_hip_wt_t sdsl_hip_fm_wavelet_tree(sdsl_hip_fm_t fm)
+{
+    return fm ? fm->wt : nullptr;
+}
+
+sdsl_hip_status sdsl_hip_fm_alphabet(sdsl_hip_fm_t fm, uint8_t char2comp_out[256], uint64_t C_out[257])
+{
+    if (!fm || !char2comp_out || !C_out)
+        return SDSL_HIP_ERR_INVALID;
+    memcpy(char2comp_out, fm->tab.char2comp, 256);
+    memcpy(C_out, fm->tab.C, sizeof fm->tab.C);
+    return SDSL_HIP_OK;
+}
+
+static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m, const uint64_t * offsets,
+                              uint64_t total_bytes, uint64_t n_pat, uint64_t * out_cnt, uint64_t * out_l,
+                              uint64_t * out_r, hipStream_t s)
+{
+    SH_HIP(hipSetDevice(fm->device));
+    if (n_pat == 0)
+        return SDSL_HIP_OK;
+    Staged sp, so, sc, sl, sr;
+    SH_TRY(sp.in(pats, total_bytes, s));
+    if (offsets)
+        SH_TRY(so.in(offsets, (n_pat + 1) * 8, s));
+    const bool ival = out_l != nullptr;
+    if (ival)
+    {
+        SH_TRY(sl.out(out_l, n_pat * 8));
+        SH_TRY(sr.out(out_r, n_pat * 8));
+    }
+    else
+        SH_TRY(sc.out(out_cnt, n_pat * 8));
+    const WtHost & w = sdsl_hip_wt_host(fm->wt);
+    unsigned grid = grid_for(n_pat, kQPB, 256u * 8u);
+    {
+        KernelTimer t(s);
+        if (ival)
+            hipLaunchKernelGGL((k_fm_count<false, true>), dim3(grid), dim3(kBlock), 0, s, w.view(),
+                               fm->d_tab.as<FmTables>(), fm->size, (const uint8_t *)sp.dev, m,
+                               offsets ? (const uint64_t *)so.dev : nullptr, n_pat, (uint64_t *)nullptr,
+                               (uint64_t *)sl.dev, (uint64_t *)sr.dev);
+        else
+            hipLaunchKernelGGL((k_fm_count<false, false>), dim3(grid), dim3(kBlock), 0, s, w.view(),
+                               fm->d_tab.as<FmTables>(), fm->size, (const uint8_t *)sp.dev, m,
+                               offsets ? (const uint64_t *)so.dev : nullptr, n_pat, (uint64_t *)sc.dev,
+                               (uint64_t *)nullptr, (uint64_t *)nullptr);
+    }
+    SH_HIP(hipGetLastError());
+    if (ival)
+    {
+        SH_TRY(sl.finish(s));
+        SH_TRY(sr.finish(s));
+    }
+    else
+        SH_TRY(sc.finish(s));
+    if (sp.host || so.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_count_batch(sdsl_hip_fm_t fm, const uint8_t * patterns, uint32_t m,
+                                        uint64_t n_patterns, uint64_t * out, void * stream)
+{
+    if (!fm || (n_patterns && (!out || (!patterns && m))))
+    {
+        set_error("fm_count_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    return fm_run(fm, patterns, m, nullptr, (uint64_t)m * n_patterns, n_patterns, out, nullptr, nullptr,
+                  (hipStream_t)stream);
+}
+
+sdsl_hip_status sdsl_hip_fm_interval_batch(sdsl_hip_fm_t fm, const uint8_t * patterns, uint32_t m,
+                                           uint64_t n_patterns, uint64_t * l_out, uint64_t * r_out, void * stream)
+{
+    if (!fm || (n_patterns && (!l_out || !r_out || (!patterns && m))))
+    {
+        set_error("fm_interval_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    return fm_run(fm, patterns, m, nullptr, (uint64_t)m * n_patterns, n_patterns, nullptr, l_out, r_out,
+                  (hipStream_t)stream);
+}
+
+sdsl_hip_status sdsl_hip_fm_count_ragged(sdsl_hip_fm_t fm, const uint8_t * bytes, const uint64_t * offsets,
+                                         uint64_t n_patterns, uint64_t * out, void * stream)
+{
+    if (!fm || (n_patterns && (!out || !offsets)))
+    {
+        set_error("fm_count_ragged: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    if (n_patterns == 0)
+        return SDSL_HIP_OK;
+    // total byte count = offsets[n]; fetch it wherever the offsets live
+    uint64_t total = 0;
+    if (is_device_ptr(offsets))
+        SH_HIP(hipMemcpy(&total, offsets + n_patterns, 8, hipMemcpyDeviceToHost));
+    else
+        total = offsets[n_patterns];
+    return fm_run(fm, bytes, 0, offsets, total, n_patterns, out, nullptr, nullptr, (hipStream_t)stream);
+}
+
+sdsl_hip_status sdsl_hip_fm_backward_search_batch(sdsl_hip_fm_t fm, const uint64_t * l, const uint64_t * r,
+                                                  const uint8_t * c, uint64_t n, uint64_t * l_out,
+                                                  uint64_t * r_out, void * stream)
+{
+    if (!fm || (n && (!l || !r || !c || !l_out || !r_out)))
+    {
+        set_error("fm_backward_search_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(fm->device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged sl, sr, sc, ol, orr;
+    SH_TRY(sl.in(l, n * 8, s));
+    SH_TRY(sr.in(r, n * 8, s));
+    SH_TRY(sc.in(c, n, s));
+    SH_TRY(ol.out(l_out, n * 8));
+    SH_TRY(orr.out(r_out, n * 8));
+    const WtHost & w = sdsl_hip_wt_host(fm->wt);
+    {
+        KernelTimer t(s);
+        hipLaunchKernelGGL((k_fm_backward_step<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s,
+                           w.view(), fm->d_tab.as<FmTables>(), fm->size, (const uint64_t *)sl.dev,
+                           (const uint64_t *)sr.dev, (const uint8_t *)sc.dev, n, (uint64_t *)ol.dev,
+                           (uint64_t *)orr.dev);
+    }
+    SH_HIP(hipGetLastError());
+    SH_TRY(ol.finish(s));
+    SH_TRY(orr.finish(s));
+    if (sl.host || sr.host || sc.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+}

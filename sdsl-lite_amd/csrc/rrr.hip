@@ -1,0 +1,772 @@
+// rrr.hip — rrr_vector<63, int_vector<>, 32> on the device: H0-compressed bit vector with
+// class/offset coding (block size 63, one sample per 32 blocks), its rank / select / access.
+//
+// Reference semantics reproduced (bit-identical answers; SDSL's serialised arrays are accepted as
+// input, the device layout differs):
+//   rrr_vector(bit_vector const&)        rrr_vector.hpp:158-270   (+ bin_to_nr rrr_helper.hpp:346-366)
+//   rank_support_rrr<b,63>::rank         rrr_vector.hpp:503-544
+//   select_support_rrr<b,63>::select     rrr_vector.hpp:639-726   (overflow -> size())
+//   rrr_vector::operator[]               rrr_vector.hpp:276-298
+//   binomial table / space[]             rrr_helper.hpp:194-237, 262-295
+//
+// Device layout: one 128-byte RECORD per superblock of 32 blocks (2016 bits)
+//   word 0      ones before the superblock                       (SDSL m_rank[s])
+//   word 1      bits 0..47  bit pointer into the offset stream   (SDSL m_btnrp[s])
+//               bits 48..59 ones inside the superblock
+//   words 2..5  the 32 block classes as bytes, inversion already undone (SDSL m_bt + m_invert)
+//   words 6..15 inline copy of the first 640 bits of the superblock's offsets (SDSL m_btnr)
+// plus the full offset stream.  An L2 miss costs the same for 64 and 128 bytes on MI355X (the
+// random-request rate is the bound, profiles/gather_probe_r01.txt), so packing header, classes and
+// the usually-sufficient head of the offsets into ONE line turns SDSL's five scattered arrays into
+// one fetch for most queries; only long offset runs touch the stream (second fetch).
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <thread>
+
+#include "bv_device.hpp"
+#include "common.hpp"
+#include "sdsl_stream.hpp"
+
+namespace sdslhip {
+
+constexpr unsigned kRrrBS = 63;
+constexpr unsigned kRrrK = 32;
+constexpr uint64_t kRrrSB = (uint64_t)kRrrBS * kRrrK; // 2016 bits per superblock
+constexpr unsigned kRecWords = 16;
+constexpr unsigned kInlineBits = 640;
+constexpr unsigned kRrrBlock = 512; // threads per block (LDS holds the 32 KiB binomial table)
+
+struct RrrTables
+{
+    uint64_t binom[64][64]; // binom[m][k] = C(m, k), m,k in [0,63]
+    uint8_t space[64];      // bits of an offset field for class k: hi(C(63,k))+1, 0 if C == 1
+};
+
+struct RrrView
+{
+    const uint64_t * rec;    // n_sb * 16 words
+    const uint64_t * stream; // offset stream (SDSL's m_btnr), padded by one word
+    const RrrTables * tables;
+    const uint32_t * sel[2]; // select sample directories (superblock of the j<<shift-th argument) + sentinel
+    uint64_t n_bits, n_blocks, n_sb, ones;
+    uint32_t sel_shift;
+};
+
+// ---- host: tables + encoder --------------------------------------------------------------------
+static RrrTables g_host_tables;
+static std::atomic<bool> g_tables_ready{false};
+
+static const RrrTables & host_tables()
+{
+    if (!g_tables_ready.load())
+    {
+        static std::mutex m;
+        std::lock_guard<std::mutex> lk(m);
+        if (!g_tables_ready.load())
+        {
+            RrrTables & T = g_host_tables;
+            memset(&T, 0, sizeof T);
+            for (int m2 = 0; m2 < 64; ++m2)
+            {
+                T.binom[m2][0] = 1;
+                for (int k = 1; k <= m2; ++k)
+                    T.binom[m2][k] = T.binom[m2 - 1][k - 1] + (k <= m2 - 1 ? T.binom[m2 - 1][k] : 0);
+            }
+            for (int k = 0; k < 64; ++k)
+            {
+                uint64_t c = T.binom[63][k];
+                T.space[k] = c == 1 ? 0 : (uint8_t)(hi64(c) + 1);
+            }
+            g_tables_ready.store(true);
+        }
+    }
+    return g_host_tables;
+}
+
+// offset of a 63-bit block inside its class (combinatorial number system, positions counted from the
+// least significant bit; matches the bytes SDSL writes so that its streams can be loaded as they are)
+static uint64_t encode_block(uint64_t bits, unsigned k, const RrrTables & T)
+{
+    uint64_t nr = 0;
+    while (bits)
+    {
+        unsigned p = (unsigned)__builtin_ctzll(bits);
+        nr += T.binom[62 - p][k];
+        --k;
+        bits &= bits - 1;
+    }
+    return nr;
+}
+
+struct RrrArrays // the host image both creation paths produce
+{
+    uint64_t n_bits = 0, n_blocks = 0, n_sb = 0, ones = 0;
+    std::vector<uint8_t> cls;      // n_sb*32 actual classes
+    std::vector<uint64_t> stream;  // offset bits
+    uint64_t stream_bits = 0;
+    std::vector<uint64_t> sb_rank; // ones before each superblock
+    std::vector<uint64_t> sb_ptr;  // stream position of each superblock
+};
+
+static void atomic_or_bits(uint64_t * d, uint64_t pos, uint64_t v, unsigned len)
+{
+    if (!len)
+        return;
+    unsigned off = (unsigned)(pos & 63);
+    __atomic_fetch_or(&d[pos >> 6], v << off, __ATOMIC_RELAXED);
+    if (off + len > 64)
+        __atomic_fetch_or(&d[(pos >> 6) + 1], v >> (64 - off), __ATOMIC_RELAXED);
+}
+
+static void rrr_encode_host(const uint64_t * words, uint64_t n, RrrArrays & A)
+{
+    const RrrTables & T = host_tables();
+    A.n_bits = n;
+    A.n_blocks = (n + kRrrBS) / kRrrBS; // one all-zero dummy block when 63 | n (rrr_vector.hpp:163)
+    A.n_sb = (A.n_blocks + kRrrK - 1) / kRrrK;
+    A.cls.assign(A.n_sb * kRrrK, 0);
+    A.sb_rank.assign(A.n_sb + 1, 0);
+    A.sb_ptr.assign(A.n_sb + 1, 0);
+    const uint64_t nw = (n + 63) >> 6;
+    auto block_bits = [&](uint64_t b) -> uint64_t {
+        uint64_t pos = b * kRrrBS;
+        if (pos >= n)
+            return 0;
+        unsigned len = (unsigned)std::min<uint64_t>(kRrrBS, n - pos);
+        uint64_t wi = pos >> 6;
+        unsigned off = (unsigned)(pos & 63);
+        uint64_t v = words[wi] >> off;
+        if (off + len > 64 && wi + 1 < nw)
+            v |= words[wi + 1] << (64 - off);
+        return v & lo_set(len);
+    };
+    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+    if (A.n_sb < 4096)
+        nt = 1;
+    auto chunk = [&](unsigned t) { return std::make_pair(A.n_sb * t / nt, A.n_sb * (t + 1) / nt); };
+    // pass 1: classes, per-superblock ones and offset lengths
+    std::vector<uint64_t> sb_len(A.n_sb + 1, 0);
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                auto r = chunk(t);
+                for (uint64_t s = r.first; s < r.second; ++s)
+                {
+                    uint64_t ones = 0, len = 0;
+                    for (unsigned j = 0; j < kRrrK; ++j)
+                    {
+                        uint64_t b = s * kRrrK + j;
+                        if (b >= A.n_blocks)
+                            break;
+                        unsigned k = popc64(block_bits(b));
+                        A.cls[b] = (uint8_t)k;
+                        ones += k;
+                        len += T.space[k];
+                    }
+                    A.sb_rank[s + 1] = ones;
+                    sb_len[s] = len;
+                }
+            });
+        for (auto & x : th)
+            x.join();
+    }
+    for (uint64_t s = 0; s < A.n_sb; ++s)
+    {
+        A.sb_rank[s + 1] += A.sb_rank[s];
+        A.sb_ptr[s + 1] = A.sb_ptr[s] + sb_len[s];
+    }
+    A.ones = A.sb_rank[A.n_sb];
+    A.stream_bits = A.sb_ptr[A.n_sb];
+    A.stream.assign(((std::max<uint64_t>(A.stream_bits, 64) + 63) >> 6) + 2, 0);
+    // pass 2: offsets
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                auto r = chunk(t);
+                for (uint64_t s = r.first; s < r.second; ++s)
+                {
+                    uint64_t pos = A.sb_ptr[s];
+                    for (unsigned j = 0; j < kRrrK; ++j)
+                    {
+                        uint64_t b = s * kRrrK + j;
+                        if (b >= A.n_blocks)
+                            break;
+                        unsigned k = A.cls[b], len = T.space[k];
+                        if (len)
+                            atomic_or_bits(A.stream.data(), pos, encode_block(block_bits(b), k, T), len);
+                        pos += len;
+                    }
+                }
+            });
+        for (auto & x : th)
+            x.join();
+    }
+}
+
+// rrr_vector<63>::load layout (rrr_vector.hpp:366-378,381-392)
+static sdsl_hip_status rrr_parse_sdsl(StreamReader & rd, RrrArrays & A)
+{
+    HostIntVec bt, btnr, btnrp, rank, inv;
+    uint64_t n = 0;
+    if (!rd.u64(n) || !rd.int_vector(bt) || !rd.int_vector(btnr, 1) || !rd.int_vector(btnrp) || !rd.int_vector(rank)
+        || !rd.int_vector(inv, 1))
+        goto bad;
+    {
+        A.n_bits = n;
+        A.n_blocks = (n + kRrrBS) / kRrrBS;
+        A.n_sb = (A.n_blocks + kRrrK - 1) / kRrrK;
+        if (bt.width != 6 || bt.size() != A.n_blocks || btnrp.size() != A.n_sb || inv.size() != A.n_sb
+            || rank.size() != A.n_sb + ((n % kRrrSB) > 0))
+            goto bad;
+        const RrrTables & T = host_tables();
+        A.cls.assign(A.n_sb * kRrrK, 0);
+        A.sb_rank.assign(A.n_sb + 1, 0);
+        A.sb_ptr.assign(A.n_sb + 1, 0);
+        uint64_t run = 0, ptr = 0;
+        for (uint64_t s = 0; s < A.n_sb; ++s)
+        {
+            bool iv = inv.get(s) != 0;
+            if (rank.get(s) != run || btnrp.get(s) != ptr)
+            { // the dummy-block superblock stores pointer 0 (never dereferenced): tolerate exactly that
+                if (!(rank.get(s) == run && s * kRrrK + 1 == A.n_blocks && n % kRrrBS == 0 && btnrp.get(s) == 0))
+                    goto bad;
+            }
+            A.sb_rank[s] = run;
+            A.sb_ptr[s] = ptr;
+            for (unsigned j = 0; j < kRrrK; ++j)
+            {
+                uint64_t b = s * kRrrK + j;
+                if (b >= A.n_blocks)
+                    break;
+                unsigned k = (unsigned)bt.get(b);
+                if (iv)
+                    k = kRrrBS - k;
+                A.cls[b] = (uint8_t)k;
+                run += k;
+                ptr += T.space[k];
+            }
+        }
+        A.sb_rank[A.n_sb] = run;
+        A.sb_ptr[A.n_sb] = ptr;
+        A.ones = run;
+        A.stream_bits = ptr;
+        if (ptr > btnr.bit_size || (rank.size() > A.n_sb && rank.get(A.n_sb) != run) || run > n)
+            goto bad;
+        A.stream = btnr.words;
+        A.stream.resize(((std::max<uint64_t>(btnr.bit_size, 64) + 63) >> 6) + 2, 0);
+        return SDSL_HIP_OK;
+    }
+bad:
+    set_error("malformed rrr_vector<63> stream (offset %zu of %zu)", rd.pos, rd.len);
+    return SDSL_HIP_ERR_FORMAT;
+}
+
+// ---- device: block decoder -----------------------------------------------------------------------
+// Decodes the 63-bit block with k ones and offset nr.  Sparse blocks: one bisection over the
+// binomial column per set bit (the same idea as the reference's k <= 10 path, rrr_helper.hpp:506-534);
+// dense blocks: one compare/subtract per position.
+__device__ __forceinline__ uint64_t rrr_decode_block(const RrrTables * T, unsigned k, uint64_t nr)
+{
+    if (k == 0)
+        return 0;
+    if (k == kRrrBS)
+        return lo_set(kRrrBS);
+    uint64_t bits = 0;
+    if (k <= 10)
+    {
+        int hi = 62; // candidate rows m = 62 - position
+        while (k > 0)
+        {
+            // largest m in [k-1, hi] with C(m, k) <= nr  (C(k-1,k) = 0 always qualifies)
+            int lo = (int)k - 1, h = hi;
+            while (lo < h)
+            {
+                int mid = (lo + h + 1) >> 1;
+                if (T->binom[mid][k] <= nr)
+                    lo = mid;
+                else
+                    h = mid - 1;
+            }
+            bits |= UINT64_C(1) << (62 - lo);
+            nr -= T->binom[lo][k];
+            --k;
+            hi = lo - 1;
+        }
+    }
+    else
+    {
+        for (int m = 62; m >= 0 && k > 0; --m)
+        {
+            uint64_t c = T->binom[m][k];
+            if (nr >= c)
+            {
+                nr -= c;
+                --k;
+                bits |= UINT64_C(1) << (62 - m);
+            }
+        }
+    }
+    return bits;
+}
+
+__device__ __forceinline__ void rrr_stage_tables(RrrTables * lds, const RrrTables * g)
+{
+    const uint64_t * src = reinterpret_cast<const uint64_t *>(g);
+    uint64_t * dst = reinterpret_cast<uint64_t *>(lds);
+    for (unsigned i = threadIdx.x; i < sizeof(RrrTables) / 8; i += blockDim.x)
+        dst[i] = src[i];
+    __syncthreads();
+}
+
+// offset field of `len` bits at relative position `rel` inside superblock record `r`
+__device__ __forceinline__ uint64_t rrr_field(const RrrView & v, const uint64_t * r, uint64_t ptr, unsigned rel,
+                                              unsigned len)
+{
+    if (rel + len <= kInlineBits)
+        return read_bits(r + 6, rel, len); // same 128-byte line as the header
+    return read_bits(v.stream, ptr + rel, len);
+}
+
+// Sum of (class, space[class]) over this lane's 8 classes with in-superblock index < j; the quad sum
+// gives ones and offset bits before block j.  packed = ones | bits << 16
+__device__ __forceinline__ unsigned rrr_lane_prefix(const RrrTables * T, uint64_t cls8, int s, unsigned j)
+{
+    int cnt = (int)j - 8 * s;
+    unsigned acc = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+    {
+        unsigned k = (unsigned)(cls8 >> (8 * t)) & 0xFF;
+        if (t < cnt)
+            acc += k | ((unsigned)T->space[k] << 16);
+    }
+    return acc;
+}
+
+template <int MODE> // 0: rank, 1: access
+__global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, const uint64_t * __restrict__ iq,
+                                                        uint64_t * __restrict__ out, uint8_t * __restrict__ out8,
+                                                        uint64_t n)
+{
+    __shared__ RrrTables T;
+    rrr_stage_tables(&T, v.tables);
+    const int s = threadIdx.x & 3;
+    const unsigned gq = threadIdx.x >> 2;
+    constexpr unsigned QPB = kRrrBlock / 4;
+    for (uint64_t base = (uint64_t)blockIdx.x * QPB; base < n; base += (uint64_t)gridDim.x * QPB)
+    {
+        uint64_t q = base + gq;
+        if (q >= n)
+            continue;
+        uint64_t i = iq[q];
+        const bool ok = MODE == 0 ? i <= v.n_bits : i < v.n_bits;
+        uint64_t res = SDSL_HIP_NPOS;
+        if (ok)
+        {
+            uint64_t blk = i / kRrrBS;
+            unsigned off = (unsigned)(i - blk * kRrrBS);
+            uint64_t sb = blk / kRrrK;
+            unsigned j = (unsigned)(blk % kRrrK);
+            const uint64_t * r = v.rec + sb * kRecWords;
+            uint64_t rank = r[0];
+            uint64_t ptr = r[1] & ((UINT64_C(1) << 48) - 1);
+            uint64_t cls8 = r[2 + s];
+            unsigned tot = quad_sum(rrr_lane_prefix(&T, cls8, s, j));
+            rank += tot & 0xFFFF;
+            unsigned rel = tot >> 16;
+            unsigned pop = 0, thebit = 0;
+            if (off != 0 || MODE == 1)
+            {
+                unsigned k = (unsigned)(r[2 + (j >> 3)] >> (8 * (j & 7))) & 0xFF;
+                unsigned len = T.space[k];
+                uint64_t nr = rrr_field(v, r, ptr, rel, len);
+                uint64_t bits = rrr_decode_block(&T, k, nr);
+                pop = popc64(bits & lo_set(off));
+                thebit = (unsigned)(bits >> off) & 1;
+            }
+            res = MODE == 1 ? thebit : (bit ? rank + pop : i - (rank + pop));
+        }
+        if (s == 0)
+        {
+            if (MODE == 1)
+                out8[q] = ok ? (uint8_t)res : 0xFF;
+            else
+                out[q] = res;
+        }
+    }
+}
+
+// select: superblock search over the record headers (interpolated probe between two samples, then
+// capacity-bounded steps, then bisection — the same scheme as bv_device.hpp quad_select), then the
+// block inside the superblock from the class bytes, then in-block select on the decoded block.
+template <int BIT>
+__global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint64_t * __restrict__ iq,
+                                                          uint64_t * __restrict__ out, uint64_t n)
+{
+    __shared__ RrrTables T;
+    rrr_stage_tables(&T, v.tables);
+    const int s = threadIdx.x & 3;
+    const unsigned gq = threadIdx.x >> 2;
+    constexpr unsigned QPB = kRrrBlock / 4;
+    const uint64_t total = BIT ? v.ones : v.n_bits - v.ones;
+    for (uint64_t base = (uint64_t)blockIdx.x * QPB; base < n; base += (uint64_t)gridDim.x * QPB)
+    {
+        uint64_t q = base + gq;
+        if (q >= n)
+            continue;
+        uint64_t i = iq[q];
+        if (i == 0 || i > total)
+        { // i > #args: SDSL returns size() (rrr_vector.hpp:641-642, 686-689); i == 0 is outside its domain
+            if (s == 0)
+                out[q] = i == 0 ? SDSL_HIP_NPOS : v.n_bits;
+            continue;
+        }
+        const uint64_t k0 = i - 1; // 0-based rank of the wanted argument
+        const uint32_t sh = v.sel_shift;
+        uint64_t lo = v.sel[BIT][k0 >> sh], hi = v.sel[BIT][(k0 >> sh) + 1];
+        uint64_t g = lo + (((hi - lo) * (k0 - ((k0 >> sh) << sh))) >> sh);
+        const uint64_t * r;
+        uint64_t before; // arguments before superblock g
+        int tries = 0;
+        for (;;)
+        {
+            r = v.rec + g * kRecWords;
+            uint64_t r0 = r[0], r1 = r[1];
+            uint64_t ones_in = (r1 >> 48) & 0xFFF;
+            uint64_t start = g * kRrrSB;
+            uint64_t len_in = v.n_bits - start < kRrrSB ? v.n_bits - start : kRrrSB;
+            before = BIT ? r0 : start - r0;
+            uint64_t c = BIT ? ones_in : len_in - ones_in;
+            if (k0 < before)
+            {
+                uint64_t d = before - k0;
+                hi = g - (d + kRrrSB - 1) / kRrrSB;
+            }
+            else if (k0 >= before + c)
+            {
+                uint64_t d = k0 - (before + c);
+                lo = g + 1 + d / kRrrSB;
+            }
+            else
+                break;
+            ++tries;
+            if (lo >= hi)
+                g = lo;
+            else if (tries <= 2)
+                g = (k0 < before) ? hi : lo;
+            else
+                g = lo + ((hi - lo) >> 1);
+        }
+        // inside superblock g: lane s owns classes [8s, 8s+8)
+        unsigned want = (unsigned)(k0 - before); // 0-based among the superblock's arguments
+        uint64_t ptr = r[1] & ((UINT64_C(1) << 48) - 1);
+        uint64_t cls8 = r[2 + s];
+        unsigned my_args = 0, my_bits = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+        {
+            unsigned k = (unsigned)(cls8 >> (8 * t)) & 0xFF;
+            uint64_t b = g * kRrrK + 8 * s + t;
+            uint64_t bstart = b * kRrrBS;
+            unsigned blen = bstart >= v.n_bits ? 0u : (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS);
+            my_args += BIT ? k : blen - k;
+            my_bits += T.space[k];
+        }
+        unsigned ex = quad_excl(my_args | (my_bits << 16), s);
+        unsigned ex_args = ex & 0xFFFF, ex_bits = ex >> 16;
+        bool mine = want >= ex_args && want < ex_args + my_args;
+        if (mine)
+        {
+            unsigned acc = ex_args, rel = ex_bits;
+            uint64_t pos = 0;
+            for (int t = 0; t < 8; ++t)
+            {
+                unsigned k = (unsigned)(cls8 >> (8 * t)) & 0xFF;
+                uint64_t b = g * kRrrK + 8 * s + t;
+                uint64_t bstart = b * kRrrBS;
+                unsigned blen =
+                    bstart >= v.n_bits ? 0u : (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS);
+                unsigned a = BIT ? k : blen - k;
+                unsigned len = T.space[k];
+                if (want < acc + a)
+                {
+                    uint64_t nr = rrr_field(v, r, ptr, rel, len);
+                    uint64_t bits = rrr_decode_block(&T, k, nr);
+                    if (!BIT)
+                        bits = ~bits & lo_set(blen);
+                    pos = bstart + sel64(bits, want - acc + 1);
+                    break;
+                }
+                acc += a;
+                rel += len;
+            }
+            out[q] = pos;
+        }
+    }
+}
+
+struct RrrHost
+{
+    int device = 0;
+    RrrView view{};
+    DevBuf rec, stream, tables, sel[2];
+    size_t device_bytes() const
+    {
+        return rec.bytes + stream.bytes + tables.bytes + sel[0].bytes + sel[1].bytes;
+    }
+};
+
+static uint32_t rrr_sel_shift()
+{
+    return 12; // one sample per 4096 arguments (~2 superblocks at density 1); tiny directory
+}
+
+static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
+{
+    h.device = device;
+    const RrrTables & T = host_tables();
+    if (A.stream_bits >= (UINT64_C(1) << 48) || A.n_sb > UINT64_C(0xFFFFFFFF))
+    {
+        set_error("rrr_vector too large for the device record format");
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    std::vector<uint64_t> rec((size_t)A.n_sb * kRecWords, 0);
+    const uint32_t sh = rrr_sel_shift();
+    const uint64_t zeros = A.n_bits - A.ones;
+    std::vector<uint32_t> sel1(((A.ones + (UINT64_C(1) << sh) - 1) >> sh) + 2, 0);
+    std::vector<uint32_t> sel0(((zeros + (UINT64_C(1) << sh) - 1) >> sh) + 2, 0);
+    for (uint64_t s = 0; s < A.n_sb; ++s)
+    {
+        uint64_t * r = &rec[(size_t)s * kRecWords];
+        uint64_t ones_in = A.sb_rank[s + 1] - A.sb_rank[s];
+        r[0] = A.sb_rank[s];
+        r[1] = A.sb_ptr[s] | (ones_in << 48);
+        memcpy(r + 2, &A.cls[(size_t)s * kRrrK], kRrrK);
+        uint64_t avail = A.sb_ptr[s + 1] - A.sb_ptr[s];
+        if (avail > kInlineBits)
+            avail = kInlineBits;
+        for (unsigned w = 0; w * 64 < avail; ++w)
+        {
+            unsigned len = (unsigned)std::min<uint64_t>(64, avail - w * 64);
+            r[6 + w] = read_bits(A.stream.data(), A.sb_ptr[s] + w * 64, len);
+        }
+        // select samples: superblock holding the argument of 0-based rank j << sh
+        uint64_t start = s * kRrrSB;
+        uint64_t len_in = A.n_bits - start < kRrrSB ? A.n_bits - start : kRrrSB;
+        uint64_t h1 = A.sb_rank[s], c1 = ones_in;
+        uint64_t h0 = start - h1, c0 = len_in - ones_in;
+        for (uint64_t j = (h1 + (UINT64_C(1) << sh) - 1) >> sh; (j << sh) < h1 + c1; ++j)
+            sel1[j] = (uint32_t)s;
+        for (uint64_t j = (h0 + (UINT64_C(1) << sh) - 1) >> sh; (j << sh) < h0 + c0; ++j)
+            sel0[j] = (uint32_t)s;
+    }
+    uint32_t last = A.n_sb ? (uint32_t)(A.n_sb - 1) : 0;
+    sel1[((A.ones + (UINT64_C(1) << sh) - 1) >> sh)] = last;
+    sel0[((zeros + (UINT64_C(1) << sh) - 1) >> sh)] = last;
+    SH_TRY(h.rec.alloc(rec.size() * 8));
+    if (!rec.empty())
+        SH_HIP(hipMemcpy(h.rec.p, rec.data(), rec.size() * 8, hipMemcpyHostToDevice));
+    SH_TRY(h.stream.alloc(A.stream.size() * 8));
+    SH_HIP(hipMemcpy(h.stream.p, A.stream.data(), A.stream.size() * 8, hipMemcpyHostToDevice));
+    SH_TRY(h.tables.alloc(sizeof(RrrTables)));
+    SH_HIP(hipMemcpy(h.tables.p, &T, sizeof(RrrTables), hipMemcpyHostToDevice));
+    SH_TRY(h.sel[1].alloc(sel1.size() * 4));
+    SH_HIP(hipMemcpy(h.sel[1].p, sel1.data(), sel1.size() * 4, hipMemcpyHostToDevice));
+    SH_TRY(h.sel[0].alloc(sel0.size() * 4));
+    SH_HIP(hipMemcpy(h.sel[0].p, sel0.data(), sel0.size() * 4, hipMemcpyHostToDevice));
+    h.view.rec = h.rec.as<uint64_t>();
+    h.view.stream = h.stream.as<uint64_t>();
+    h.view.tables = h.tables.as<RrrTables>();
+    h.view.sel[0] = h.sel[0].as<uint32_t>();
+    h.view.sel[1] = h.sel[1].as<uint32_t>();
+    h.view.n_bits = A.n_bits;
+    h.view.n_blocks = A.n_blocks;
+    h.view.n_sb = A.n_sb;
+    h.view.ones = A.ones;
+    h.view.sel_shift = sh;
+    return SDSL_HIP_OK;
+}
+
+} // namespace sdslhip
+
+using namespace sdslhip;
+
+struct sdsl_hip_rrr_s
+{
+    RrrHost h;
+};
+
+extern "C" {
+
+sdsl_hip_status sdsl_hip_rrr_create(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_rrr_t * out)
+{
+    if (!out || (!words && n_bits))
+    {
+        set_error("rrr_create: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    std::vector<uint64_t> tmp;
+    const uint64_t * host = words;
+    uint64_t nw = (n_bits + 63) >> 6;
+    if (nw && is_device_ptr(words))
+    {
+        tmp.resize(nw);
+        SH_HIP(hipMemcpy(tmp.data(), words, nw * 8, hipMemcpyDeviceToHost));
+        host = tmp.data();
+    }
+    sdsl_hip_rrr_s * r = new (std::nothrow) sdsl_hip_rrr_s();
+    if (!r)
+        return SDSL_HIP_ERR_NOMEM;
+    RrrArrays A;
+    rrr_encode_host(host, n_bits, A);
+    sdsl_hip_status st = rrr_upload(r->h, A, device);
+    if (st != SDSL_HIP_OK)
+    {
+        delete r;
+        return st;
+    }
+    *out = r;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_rrr_create_from_sdsl(const void * bytes, size_t len, int32_t device, sdsl_hip_rrr_t * out)
+{
+    if (!out || !bytes)
+    {
+        set_error("rrr_create_from_sdsl: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    StreamReader rd(bytes, len);
+    RrrArrays A;
+    SH_TRY(rrr_parse_sdsl(rd, A));
+    sdsl_hip_rrr_s * r = new (std::nothrow) sdsl_hip_rrr_s();
+    if (!r)
+        return SDSL_HIP_ERR_NOMEM;
+    sdsl_hip_status st = rrr_upload(r->h, A, device);
+    if (st != SDSL_HIP_OK)
+    {
+        delete r;
+        return st;
+    }
+    *out = r;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_rrr_destroy(sdsl_hip_rrr_t v)
+{
+    if (!v)
+        return SDSL_HIP_OK;
+    (void)hipSetDevice(v->h.device);
+    delete v;
+    return SDSL_HIP_OK;
+}
+uint64_t sdsl_hip_rrr_size(sdsl_hip_rrr_t v)
+{
+    return v ? v->h.view.n_bits : 0;
+}
+uint64_t sdsl_hip_rrr_ones(sdsl_hip_rrr_t v)
+{
+    return v ? v->h.view.ones : 0;
+}
+uint64_t sdsl_hip_rrr_device_bytes(sdsl_hip_rrr_t v)
+{
+    return v ? v->h.device_bytes() : 0;
+}
+
+static unsigned rrr_grid(uint64_t n)
+{
+    return grid_for(n, kRrrBlock / 4, 256u * 4u);
+}
+
+sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uint64_t * idx, uint64_t n,
+                                        uint64_t * out, void * stream)
+{
+    if (!v || (bit != 0 && bit != 1) || (n && (!idx || !out)))
+    {
+        set_error("rrr_rank_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(v->h.device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged in, o;
+    SH_TRY(in.in(idx, n * 8, s));
+    SH_TRY(o.out(out, n * 8));
+    {
+        KernelTimer t(s);
+        hipLaunchKernelGGL((k_rrr_rank<0>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view, bit,
+                           (const uint64_t *)in.dev, (uint64_t *)o.dev, (uint8_t *)nullptr, n);
+    }
+    SH_HIP(hipGetLastError());
+    SH_TRY(o.finish(s));
+    if (in.host && !o.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_rrr_access_batch(sdsl_hip_rrr_t v, const uint64_t * idx, uint64_t n, uint8_t * out,
+                                          void * stream)
+{
+    if (!v || (n && (!idx || !out)))
+    {
+        set_error("rrr_access_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(v->h.device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged in, o;
+    SH_TRY(in.in(idx, n * 8, s));
+    SH_TRY(o.out(out, n));
+    {
+        KernelTimer t(s);
+        hipLaunchKernelGGL((k_rrr_rank<1>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view, 1,
+                           (const uint64_t *)in.dev, (uint64_t *)nullptr, (uint8_t *)o.dev, n);
+    }
+    SH_HIP(hipGetLastError());
+    SH_TRY(o.finish(s));
+    if (in.host && !o.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const uint64_t * i, uint64_t n,
+                                          uint64_t * out, void * stream)
+{
+    if (!v || (bit != 0 && bit != 1) || (n && (!i || !out)))
+    {
+        set_error("rrr_select_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(v->h.device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged in, o;
+    SH_TRY(in.in(i, n * 8, s));
+    SH_TRY(o.out(out, n * 8));
+    {
+        KernelTimer t(s);
+        if (bit)
+            hipLaunchKernelGGL((k_rrr_select<1>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view,
+                               (const uint64_t *)in.dev, (uint64_t *)o.dev, n);
+        else
+            hipLaunchKernelGGL((k_rrr_select<0>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view,
+                               (const uint64_t *)in.dev, (uint64_t *)o.dev, n);
+    }
+    SH_HIP(hipGetLastError());
+    SH_TRY(o.finish(s));
+    if (in.host && !o.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+}

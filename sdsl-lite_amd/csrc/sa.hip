@@ -1,0 +1,140 @@
+// sa.hip — suffix array / BWT construction of text+'\0' on the device by prefix doubling
+// (Manber-Myers with radix sorts), feeding sdsl_hip_fm_create_from_text.
+//
+// This is SURVEY.md §8(f) row n4: the reference builds SA with divsufsort on one CPU core
+// (construct_sa.hpp:120-153) and derives the BWT from it (construct_bwt.hpp:38-80); any correct
+// suffix sorter yields the same SA, hence the same BWT, hence the same index.  The device version
+// keeps everything in HBM: per round one 64-bit-key radix sort of n (key, suffix) pairs
+// (rocPRIM — a plain library sort is exactly what this step is), one adjacent-difference + scan to
+// re-rank, one gather to form the next keys.  k starts at 8 (first 8 bytes packed big-endian).
+#include <cstring>
+
+#include "common.hpp"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace sdslhip {
+
+__global__ void k_sa_init_keys(const uint8_t * __restrict__ s, uint64_t n, uint64_t * __restrict__ keys,
+                               uint32_t * __restrict__ idx)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t k = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            k = (k << 8) | (i + j < n ? (uint64_t)s[i + j] : 0);
+        keys[i] = k;
+        idx[i] = (uint32_t)i;
+    }
+}
+
+// flags[i] = 1 if sorted key i differs from sorted key i-1 (flags[0] = 0)
+__global__ void k_sa_flags(const uint64_t * __restrict__ keys, uint64_t n, uint32_t * __restrict__ flags)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        flags[i] = (i > 0 && keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// rank[sa[i]] = scanned[i]
+__global__ void k_sa_scatter_rank(const uint32_t * __restrict__ sa, const uint32_t * __restrict__ scanned, uint64_t n,
+                                  uint32_t * __restrict__ rank)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        rank[sa[i]] = scanned[i];
+}
+
+// keys for the next round, in suffix order i = 0..n-1: (rank[i], rank[i+k]+1 or 0 past the end)
+__global__ void k_sa_next_keys(const uint32_t * __restrict__ rank, uint64_t n, uint64_t k, unsigned shift,
+                               uint64_t * __restrict__ keys, uint32_t * __restrict__ idx)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t second = i + k < n ? (uint64_t)rank[i + k] + 1 : 0;
+        keys[i] = ((uint64_t)rank[i] << shift) | second;
+        idx[i] = (uint32_t)i;
+    }
+}
+
+__global__ void k_sa_bwt(const uint8_t * __restrict__ s, const uint32_t * __restrict__ sa, uint64_t n,
+                         uint8_t * __restrict__ bwt)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t p = sa[i];
+        bwt[i] = s[p == 0 ? n - 1 : p - 1];
+    }
+}
+
+sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, std::vector<uint8_t> & bwt)
+{
+    const uint64_t n = n_text + 1;
+    if (n >= UINT64_C(0xFFFFFFFE))
+    {
+        set_error("device suffix sorter handles texts below 2^32-2 bytes (got %llu)", (unsigned long long)n_text);
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    SH_HIP(hipSetDevice(device));
+    DevBuf d_s, d_k0, d_k1, d_i0, d_i1, d_rank, d_flags, d_tmp;
+    SH_TRY(d_s.alloc(n));
+    SH_HIP(hipMemcpy(d_s.p, host_text, n_text, hipMemcpyHostToDevice));
+    SH_HIP(hipMemset((uint8_t *)d_s.p + n_text, 0, 1));
+    SH_TRY(d_k0.alloc(n * 8));
+    SH_TRY(d_k1.alloc(n * 8));
+    SH_TRY(d_i0.alloc(n * 4));
+    SH_TRY(d_i1.alloc(n * 4));
+    SH_TRY(d_rank.alloc(n * 4));
+    SH_TRY(d_flags.alloc(n * 4));
+    uint64_t *k0 = d_k0.as<uint64_t>(), *k1 = d_k1.as<uint64_t>();
+    uint32_t *i0 = d_i0.as<uint32_t>(), *i1 = d_i1.as<uint32_t>();
+    uint32_t *rank = d_rank.as<uint32_t>(), *flags = d_flags.as<uint32_t>();
+    const unsigned grid = grid_for(n, 256, 256u * 16u);
+
+    unsigned rank_bits = 1;
+    while ((UINT64_C(1) << rank_bits) < n + 1)
+        ++rank_bits;
+
+    size_t tmp_sort = 0, tmp_scan = 0;
+    SH_HIP(rocprim::radix_sort_pairs(nullptr, tmp_sort, k0, k1, i0, i1, (size_t)n, 0u, 64u));
+    SH_HIP(rocprim::inclusive_scan(nullptr, tmp_scan, flags, flags, (size_t)n, rocprim::plus<uint32_t>()));
+    SH_TRY(d_tmp.alloc(std::max(tmp_sort, tmp_scan)));
+
+    hipLaunchKernelGGL(k_sa_init_keys, dim3(grid), dim3(256), 0, 0, d_s.as<uint8_t>(), n, k0, i0);
+    SH_HIP(hipGetLastError());
+    uint64_t k = 8;
+    unsigned end_bit = 64;
+    for (int round = 0; round < 40; ++round)
+    {
+        size_t ts = d_tmp.bytes;
+        SH_HIP(rocprim::radix_sort_pairs(d_tmp.p, ts, k0, k1, i0, i1, (size_t)n, 0u, end_bit));
+        hipLaunchKernelGGL(k_sa_flags, dim3(grid), dim3(256), 0, 0, k1, n, flags);
+        SH_HIP(hipGetLastError());
+        ts = d_tmp.bytes;
+        SH_HIP(rocprim::inclusive_scan(d_tmp.p, ts, flags, flags, (size_t)n, rocprim::plus<uint32_t>()));
+        uint32_t max_rank = 0;
+        SH_HIP(hipMemcpy(&max_rank, flags + (n - 1), 4, hipMemcpyDeviceToHost));
+        if ((uint64_t)max_rank == n - 1)
+            break; // all suffixes distinct: i1 is the suffix array
+        if (k >= n)
+        {
+            set_error("suffix sorter did not converge (duplicate suffixes?)");
+            return SDSL_HIP_ERR_HIP;
+        }
+        hipLaunchKernelGGL(k_sa_scatter_rank, dim3(grid), dim3(256), 0, 0, i1, flags, n, rank);
+        SH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_sa_next_keys, dim3(grid), dim3(256), 0, 0, rank, n, k, rank_bits, k0, i0);
+        SH_HIP(hipGetLastError());
+        end_bit = 2 * rank_bits;
+        k <<= 1;
+    }
+    DevBuf d_bwt;
+    SH_TRY(d_bwt.alloc(n));
+    hipLaunchKernelGGL(k_sa_bwt, dim3(grid), dim3(256), 0, 0, d_s.as<uint8_t>(), i1, n, d_bwt.as<uint8_t>());
+    SH_HIP(hipGetLastError());
+    bwt.resize(n);
+    SH_HIP(hipMemcpy(bwt.data(), d_bwt.p, n, hipMemcpyDeviceToHost));
+    return SDSL_HIP_OK;
+}
+
+} // namespace sdslhip

@@ -1,0 +1,131 @@
+// sdsl_stream.hpp — reader for SDSL's serialised byte format (the second drop-in boundary,
+// SURVEY.md §8(b)).  Little-endian, no magic, no versioning:
+//   int_vector<w>      : u64 (width<<56 | bit_size), then ceil(bit_size/64) u64 words
+//                        (int_vector.hpp:884-916, 1978-2004)
+//   write_member(x)    : raw bytes of x (io.hpp:93-101)
+// The reader copies words into aligned host vectors (streams may place them at odd offsets,
+// e.g. after the 22-byte wavelet-tree nodes or the u16 sigma).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "bits.hpp"
+
+namespace sdslhip {
+
+struct HostIntVec
+{
+    std::vector<uint64_t> words; // always one extra zero word so read_bits may touch p[1]
+    uint64_t bit_size = 0;
+    uint8_t width = 64;
+    uint64_t size() const
+    {
+        return width ? bit_size / width : 0;
+    }
+    uint64_t get(uint64_t i) const
+    {
+        return read_bits(words.data(), i * width, width);
+    }
+    bool empty() const
+    {
+        return bit_size == 0;
+    }
+};
+
+struct StreamReader
+{
+    const uint8_t * p;
+    size_t len;
+    size_t pos = 0;
+    bool ok = true;
+    StreamReader(const void * bytes, size_t n) : p((const uint8_t *)bytes), len(n)
+    {}
+    bool raw(void * dst, size_t n)
+    {
+        if (!ok || n > len - pos)
+        {
+            ok = false;
+            return false;
+        }
+        memcpy(dst, p + pos, n);
+        pos += n;
+        return true;
+    }
+    bool skip(size_t n)
+    {
+        if (!ok || n > len - pos)
+        {
+            ok = false;
+            return false;
+        }
+        pos += n;
+        return true;
+    }
+    bool u64(uint64_t & v)
+    {
+        return raw(&v, 8);
+    }
+    bool u16(uint16_t & v)
+    {
+        return raw(&v, 2);
+    }
+    // int_vector<w>::load; expect_width = 0 accepts any width (int_vector<0>)
+    bool int_vector(HostIntVec & out, uint8_t expect_width = 0)
+    {
+        uint64_t hdr;
+        if (!u64(hdr))
+            return false;
+        out.bit_size = hdr & ((UINT64_C(1) << 56) - 1);
+        out.width = (uint8_t)(hdr >> 56);
+        if (out.width == 0 || out.width > 64 || (expect_width && out.width != expect_width))
+        {
+            ok = false;
+            return false;
+        }
+        uint64_t nw = (out.bit_size + 63) >> 6;
+        if (nw > (len - pos) / 8)
+        {
+            ok = false;
+            return false;
+        }
+        out.words.assign(nw + 1, 0);
+        return raw(out.words.data(), nw * 8);
+    }
+    bool skip_int_vector()
+    {
+        uint64_t hdr;
+        if (!u64(hdr))
+            return false;
+        uint64_t bits = hdr & ((UINT64_C(1) << 56) - 1);
+        uint64_t nw = (bits + 63) >> 6;
+        if (nw > (len - pos) / 8)
+        {
+            ok = false;
+            return false;
+        }
+        return skip(nw * 8);
+    }
+    // select_support_mcl<b>::load layout (select_support_mcl.hpp:521-554): only skipped here —
+    // the device select directory is rebuilt from the bits.
+    bool skip_select_mcl()
+    {
+        uint64_t arg_cnt;
+        if (!u64(arg_cnt))
+            return false;
+        if (arg_cnt == 0)
+            return true;
+        uint64_t sb = (arg_cnt + 4095) >> 12;
+        if (!skip_int_vector()) // m_superblock
+            return false;
+        HostIntVec mol;
+        if (!int_vector(mol, 1)) // mini_or_long
+            return false;
+        for (uint64_t i = 0; i < sb; ++i)
+            if (!skip_int_vector()) // either the long or the mini vector of superblock i
+                return false;
+        return ok;
+    }
+};
+
+} // namespace sdslhip

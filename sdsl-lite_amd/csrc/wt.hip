@@ -1,0 +1,609 @@
+// wt.hip — byte wavelet tree (wt_huff<bit_vector, rank_support_v5<>>) on the device:
+// host-side construction of the Huffman-shaped tree and its bit vector, the loader for SDSL's
+// serialised form, and the batched rank / access / inverse_select / select kernels.
+//
+// Reference semantics reproduced:
+//   wt_pc::rank            wt_pc.hpp:371-399      wt_pc::operator[]       wt_pc.hpp:336-357
+//   wt_pc::inverse_select  wt_pc.hpp:411-430      wt_pc::select           wt_pc.hpp:443-474
+//   Huffman shape          wt_huff.hpp:83-115     BFS byte tree + paths   wt_helper.hpp:230-327
+#include <algorithm>
+#include <queue>
+
+#include "wt_host.hpp"
+
+namespace sdslhip {
+
+// =========================================================================================
+// host construction
+// =========================================================================================
+
+static uint64_t popcount_range(const uint64_t * w, uint64_t from, uint64_t to)
+{ // ones in bit positions [from, to)
+    if (from >= to)
+        return 0;
+    uint64_t fw = from >> 6, tw = to >> 6, c = 0;
+    if (fw == tw)
+        return popc64((w[fw] >> (from & 63)) & lo_set((unsigned)(to - from)));
+    c += popc64(w[fw] >> (from & 63));
+    for (uint64_t i = fw + 1; i < tw; ++i)
+        c += popc64(w[i]);
+    if (to & 63)
+        c += popc64(w[tw] & lo_set((unsigned)(to & 63)));
+    return c;
+}
+
+static void tables_clear(WtTables & T)
+{
+    memset(&T, 0, sizeof T);
+    for (int v = 0; v < kWtMaxNodes; ++v)
+        T.child[v][0] = T.child[v][1] = T.parent[v] = kWtUndef;
+    for (int c = 0; c < 256; ++c)
+        T.c_to_leaf[c] = kWtUndef;
+}
+
+// Huffman code tree in SDSL's node numbering.  Leaves are created in symbol order, the two
+// smallest (frequency, creation index) pairs are merged first-popped = left; nodes are then
+// renumbered breadth-first from the root and every inner node gets the running sum of the
+// preceding inner-node frequencies as the start of its slice.
+static sdsl_hip_status build_shape(const uint64_t occ[256], WtTables & T, uint32_t & n_nodes, uint64_t & bv_size,
+                                   uint64_t & sigma)
+{
+    struct Tmp
+    {
+        uint64_t freq;
+        int sym, left, right;
+    };
+    std::vector<Tmp> tmp;
+    typedef std::pair<uint64_t, int> Item;
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
+    sigma = 0;
+    for (int c = 0; c < 256; ++c)
+        if (occ[c])
+        {
+            heap.push(Item(occ[c], (int)tmp.size()));
+            tmp.push_back(Tmp{occ[c], c, -1, -1});
+            ++sigma;
+        }
+    tables_clear(T);
+    n_nodes = 0;
+    bv_size = 0;
+    if (tmp.empty())
+        return SDSL_HIP_OK;
+    while (heap.size() > 1)
+    {
+        Item a = heap.top();
+        heap.pop();
+        Item b = heap.top();
+        heap.pop();
+        heap.push(Item(a.first + b.first, (int)tmp.size()));
+        tmp.push_back(Tmp{a.first + b.first, -1, a.second, b.second});
+    }
+    n_nodes = (uint32_t)tmp.size();
+    // breadth-first renumbering
+    std::vector<int> order; // order[bfs id] = tmp id
+    order.reserve(n_nodes);
+    order.push_back((int)tmp.size() - 1);
+    for (size_t head = 0; head < order.size(); ++head)
+    {
+        const Tmp & t = tmp[order[head]];
+        T.bv_pos[head] = bv_size;
+        if (t.left >= 0)
+        {
+            bv_size += t.freq;
+            for (int k = 0; k < 2; ++k)
+            {
+                uint16_t id = (uint16_t)order.size();
+                order.push_back(k ? t.right : t.left);
+                T.child[head][k] = id;
+                T.parent[id] = (uint16_t)head;
+            }
+        }
+        else
+        {
+            T.bv_pos_rank[head] = (uint64_t)t.sym;
+            T.c_to_leaf[t.sym] = (uint16_t)head;
+        }
+    }
+    // root-to-leaf paths, LSB = edge leaving the root; absent symbols: length 0, payload = previous
+    // present symbol (wt_helper.hpp:311-315)
+    uint64_t prev = 0;
+    for (int c = 0; c < 256; ++c)
+    {
+        if (T.c_to_leaf[c] == kWtUndef)
+        {
+            T.path[c] = prev;
+            continue;
+        }
+        uint64_t bits = 0, len = 0;
+        for (uint16_t v = T.c_to_leaf[c]; v != 0; v = T.parent[v])
+        {
+            bits = (bits << 1) | (T.child[T.parent[v]][1] == v ? 1u : 0u);
+            ++len;
+        }
+        if (len > 56)
+        {
+            set_error("wavelet tree code depth %llu exceeds 56 (SDSL throws here too, wt_helper.hpp:304-307)",
+                      (unsigned long long)len);
+            return SDSL_HIP_ERR_UNSUPPORTED;
+        }
+        T.path[c] = bits | (len << 56);
+        prev = (uint64_t)c;
+    }
+    return SDSL_HIP_OK;
+}
+
+static sdsl_hip_status upload(WtHost & wt, const std::vector<uint64_t> & words, uint64_t bv_size, int device)
+{
+    wt.device = device;
+    DevBuf d_words;
+    uint64_t nw = (bv_size + 63) >> 6;
+    SH_TRY(d_words.alloc(nw * 8));
+    if (nw)
+        SH_HIP(hipMemcpy(d_words.p, words.data(), nw * 8, hipMemcpyHostToDevice));
+    wt.bv.device = device;
+    SH_TRY(bv_build_from_device_words(wt.bv, d_words.as<uint64_t>(), bv_size,
+                                      SDSL_HIP_BV_SELECT1 | SDSL_HIP_BV_SELECT0, default_sel_shift()));
+    SH_TRY(wt.d_tables.alloc(sizeof(WtTables)));
+    SH_HIP(hipMemcpy(wt.d_tables.p, &wt.tables, sizeof(WtTables), hipMemcpyHostToDevice));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status wt_build_from_text(WtHost & wt, const uint8_t * text, uint64_t n, int device)
+{
+    memset(wt.occ, 0, sizeof wt.occ);
+    for (uint64_t i = 0; i < n; ++i)
+        ++wt.occ[text[i]];
+    wt.size = n;
+    uint64_t bv_size = 0;
+    SH_TRY(build_shape(wt.occ, wt.tables, wt.n_nodes, bv_size, wt.sigma));
+    WtTables & T = wt.tables;
+    std::vector<uint64_t> words(((bv_size + 63) >> 6) + 1, 0);
+    // every symbol appends one bit at the cursor of each node on its path
+    std::vector<uint64_t> cursor(T.bv_pos, T.bv_pos + kWtMaxNodes);
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        uint64_t p = T.path[text[i]];
+        unsigned len = (unsigned)(p >> 56), v = 0;
+        for (unsigned l = 0; l < len; ++l, p >>= 1)
+        {
+            uint64_t pos = cursor[v]++;
+            unsigned bit = (unsigned)(p & 1);
+            words[pos >> 6] |= (uint64_t)bit << (pos & 63);
+            v = T.child[v][bit];
+        }
+    }
+    // bv_pos_rank of inner nodes = ones before the slice; slices are contiguous in BFS order
+    uint64_t run = 0;
+    for (uint32_t v = 0; v < wt.n_nodes; ++v)
+    {
+        if (T.child[v][0] == kWtUndef)
+            continue;
+        uint64_t end = v + 1 < wt.n_nodes ? T.bv_pos[v + 1] : bv_size;
+        T.bv_pos_rank[v] = run;
+        run += popcount_range(words.data(), T.bv_pos[v], end);
+    }
+    return upload(wt, words, bv_size, device);
+}
+
+sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, bool select_is_mcl, int device)
+{
+    HostIntVec bv;
+    uint64_t n_nodes64 = 0;
+    if (!rd.u64(wt.size) || !rd.u64(wt.sigma) || !rd.int_vector(bv, 1) || !rd.skip_int_vector() /* bv_rank */)
+        goto bad;
+    if (select_is_mcl && (!rd.skip_select_mcl() || !rd.skip_select_mcl()))
+        goto bad;
+    if (!rd.u64(n_nodes64) || n_nodes64 >= (uint64_t)kWtMaxNodes)
+        goto bad;
+    {
+        WtTables & T = wt.tables;
+        tables_clear(T);
+        wt.n_nodes = (uint32_t)n_nodes64;
+        for (uint32_t v = 0; v < wt.n_nodes; ++v)
+        { // _node::serialize wt_helper.hpp:139-150 — 22 bytes
+            uint16_t par, ch[2];
+            if (!rd.u64(T.bv_pos[v]) || !rd.u64(T.bv_pos_rank[v]) || !rd.u16(par) || !rd.raw(ch, 4))
+                goto bad;
+            T.parent[v] = par;
+            T.child[v][0] = ch[0];
+            T.child[v][1] = ch[1];
+            bool leaf = ch[0] == kWtUndef;
+            if ((!leaf && (ch[0] >= wt.n_nodes || ch[1] >= wt.n_nodes)) || (v > 0 && par >= wt.n_nodes)
+                || T.bv_pos[v] > bv.bit_size)
+                goto bad;
+        }
+        uint16_t c2l[256];
+        uint64_t path[256];
+        if (!rd.raw(c2l, sizeof c2l) || !rd.raw(path, sizeof path))
+            goto bad;
+        if (wt.size != 0)
+        { // a default-constructed (empty) wt_pc serialises uninitialised tables: ignore them
+            for (int c = 0; c < 256; ++c)
+            {
+                if (c2l[c] != kWtUndef && (c2l[c] >= wt.n_nodes || (path[c] >> 56) > 56))
+                    goto bad;
+                T.c_to_leaf[c] = c2l[c];
+                T.path[c] = path[c];
+            }
+        }
+        // occurrences per symbol from the slices: ones go right, zeros go left
+        memset(wt.occ, 0, sizeof wt.occ);
+        for (uint32_t v = 0; v < wt.n_nodes; ++v)
+        {
+            if (T.child[v][0] == kWtUndef)
+            {
+                if (wt.n_nodes == 1)
+                    wt.occ[(uint8_t)T.bv_pos_rank[v]] = wt.size;
+                continue;
+            }
+            uint64_t end = v + 1 < wt.n_nodes ? T.bv_pos[v + 1] : bv.bit_size;
+            if (end < T.bv_pos[v] || end > bv.bit_size)
+                goto bad;
+            uint64_t ones = popcount_range(bv.words.data(), T.bv_pos[v], end);
+            uint64_t zeros = (end - T.bv_pos[v]) - ones;
+            for (int k = 0; k < 2; ++k)
+            {
+                uint16_t ch = T.child[v][k];
+                if (T.child[ch][0] == kWtUndef)
+                    wt.occ[(uint8_t)T.bv_pos_rank[ch]] = k ? ones : zeros;
+            }
+        }
+        return upload(wt, bv.words, bv.bit_size, device);
+    }
+bad:
+    set_error("malformed wt_huff stream (offset %zu of %zu)", rd.pos, rd.len);
+    return SDSL_HIP_ERR_FORMAT;
+}
+
+// =========================================================================================
+// kernels
+// =========================================================================================
+
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void k_wt_rank(WtView wt, const uint64_t * __restrict__ iq,
+                                                    const uint8_t * __restrict__ cq, uint64_t * __restrict__ out,
+                                                    uint64_t n)
+{
+    __shared__ WtTables T;
+    wt_stage_tables(&T, wt.tables);
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
+    {
+        uint64_t q = base + gq;
+        if (q >= n)
+            continue;
+        uint64_t i = iq[q];
+        unsigned c = cq[q];
+        uint64_t r = i <= wt.size ? quad_wt_rank<NT>(wt, &T, s, i, c) : SDSL_HIP_NPOS;
+        if (s == 0)
+            out[q] = r;
+    }
+}
+
+// operator[] and inverse_select share one traversal
+template <bool NT, bool WITH_RANK>
+__global__ __launch_bounds__(kBlock) void k_wt_inverse_select(WtView wt, const uint64_t * __restrict__ iq,
+                                                              uint64_t * __restrict__ out_rank,
+                                                              uint8_t * __restrict__ out_c, uint64_t n)
+{
+    __shared__ WtTables T;
+    wt_stage_tables(&T, wt.tables);
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
+    {
+        uint64_t q = base + gq;
+        if (q >= n)
+            continue;
+        uint64_t i = iq[q];
+        unsigned c = 0xFF;
+        uint64_t r = SDSL_HIP_NPOS;
+        if (i < wt.size)
+            r = quad_wt_inverse_select<NT>(wt, &T, s, i, c);
+        if (s == 0)
+        {
+            out_c[q] = (uint8_t)c;
+            if (WITH_RANK)
+                out_rank[q] = r;
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t quad_gather_u64(uint64_t v, bool mine)
+{ // exactly one lane of the quad has mine == true: give its value to all four
+    uint64_t x = mine ? v : 0;
+    unsigned lo = quad_sum((unsigned)x), hi = quad_sum((unsigned)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void k_wt_select(WtView wt, const uint64_t * __restrict__ occ,
+                                                      const uint64_t * __restrict__ iq,
+                                                      const uint8_t * __restrict__ cq, uint64_t * __restrict__ out,
+                                                      uint64_t n)
+{
+    __shared__ WtTables T;
+    wt_stage_tables(&T, wt.tables);
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
+    {
+        uint64_t q = base + gq;
+        if (q >= n)
+            continue;
+        uint64_t i = iq[q];
+        unsigned c = cq[q];
+        uint64_t res;
+        unsigned v = T.c_to_leaf[c];
+        if (v == kWtUndef)
+            res = wt.size; // c not in the text (wt_pc.hpp:447-450)
+        else if (i == 0 || i > occ[c])
+            res = SDSL_HIP_NPOS; // outside SDSL's precondition
+        else if (wt.sigma == 1)
+            res = i - 1 < wt.size ? i - 1 : wt.size;
+        else
+        {
+            res = i - 1;
+            uint64_t p = T.path[c];
+            unsigned len = (unsigned)(p >> 56);
+            p <<= (64 - len);
+            for (unsigned l = 0; l < len; ++l, p <<= 1)
+            {
+                unsigned par = T.parent[v];
+                bool mine;
+                uint64_t pos;
+                if ((p >> 63) == 0) // v is a left child: zeros of the parent's slice
+                    pos = quad_select<0, NT>(wt.bv, s, T.bv_pos[par] - T.bv_pos_rank[par] + res, mine);
+                else
+                    pos = quad_select<1, NT>(wt.bv, s, T.bv_pos_rank[par] + res, mine);
+                res = quad_gather_u64(pos, mine) - T.bv_pos[par];
+                v = par;
+            }
+        }
+        if (s == 0)
+            out[q] = res;
+    }
+}
+
+static unsigned wt_grid(uint64_t n)
+{
+    return grid_for(n, kQPB, 256u * 8u);
+}
+
+sdsl_hip_status wt_launch_rank(const WtHost & wt, const uint64_t * d_i, const uint8_t * d_c, uint64_t n,
+                               uint64_t * d_out, hipStream_t s)
+{
+    if (n == 0)
+        return SDSL_HIP_OK;
+    KernelTimer t(s);
+    hipLaunchKernelGGL((k_wt_rank<false>), dim3(wt_grid(n)), dim3(kBlock), 0, s, wt.view(), d_i, d_c, d_out, n);
+    SH_HIP(hipGetLastError());
+    return SDSL_HIP_OK;
+}
+
+} // namespace sdslhip
+
+using namespace sdslhip;
+
+struct sdsl_hip_wt_s
+{
+    WtHost h;
+    DevBuf d_occ;
+};
+
+// shared with fm.hip
+sdsl_hip_wt_s * sdsl_hip_wt_alloc()
+{
+    return new (std::nothrow) sdsl_hip_wt_s();
+}
+WtHost & sdsl_hip_wt_host(sdsl_hip_wt_s * w)
+{
+    return w->h;
+}
+sdsl_hip_status sdsl_hip_wt_finish(sdsl_hip_wt_s * w)
+{
+    SH_TRY(w->d_occ.alloc(sizeof w->h.occ));
+    SH_HIP(hipMemcpy(w->d_occ.p, w->h.occ, sizeof w->h.occ, hipMemcpyHostToDevice));
+    return SDSL_HIP_OK;
+}
+
+// Host copy of a byte array that may live on the device.
+static sdsl_hip_status host_bytes(const uint8_t * p, uint64_t n, std::vector<uint8_t> & tmp, const uint8_t *& host)
+{
+    if (n && is_device_ptr(p))
+    {
+        tmp.resize(n);
+        SH_HIP(hipMemcpy(tmp.data(), p, n, hipMemcpyDeviceToHost));
+        host = tmp.data();
+    }
+    else
+        host = p;
+    return SDSL_HIP_OK;
+}
+
+extern "C" {
+
+sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t device, sdsl_hip_wt_t * out)
+{
+    if (!out || (!text && n))
+    {
+        set_error("wt_create: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    sdsl_hip_wt_s * w = sdsl_hip_wt_alloc();
+    if (!w)
+        return SDSL_HIP_ERR_NOMEM;
+    std::vector<uint8_t> tmp;
+    const uint8_t * host = nullptr;
+    sdsl_hip_status st = host_bytes(text, n, tmp, host);
+    if (st == SDSL_HIP_OK)
+        st = wt_build_from_text(w->h, host, n, device);
+    if (st == SDSL_HIP_OK)
+        st = sdsl_hip_wt_finish(w);
+    if (st != SDSL_HIP_OK)
+    {
+        delete w;
+        return st;
+    }
+    *out = w;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int32_t select_is_mcl, int32_t device,
+                                             sdsl_hip_wt_t * out, size_t * consumed)
+{
+    if (!out || !bytes)
+    {
+        set_error("wt_create_from_sdsl: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    sdsl_hip_wt_s * w = sdsl_hip_wt_alloc();
+    if (!w)
+        return SDSL_HIP_ERR_NOMEM;
+    StreamReader rd(bytes, len);
+    sdsl_hip_status st = wt_build_from_stream(w->h, rd, select_is_mcl != 0, device);
+    if (st == SDSL_HIP_OK)
+        st = sdsl_hip_wt_finish(w);
+    if (st != SDSL_HIP_OK)
+    {
+        delete w;
+        return st;
+    }
+    if (consumed)
+        *consumed = rd.pos;
+    *out = w;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_wt_destroy(sdsl_hip_wt_t wt)
+{
+    if (!wt)
+        return SDSL_HIP_OK;
+    (void)hipSetDevice(wt->h.device);
+    delete wt;
+    return SDSL_HIP_OK;
+}
+
+uint64_t sdsl_hip_wt_size(sdsl_hip_wt_t wt)
+{
+    return wt ? wt->h.size : 0;
+}
+uint64_t sdsl_hip_wt_sigma(sdsl_hip_wt_t wt)
+{
+    return wt ? wt->h.sigma : 0;
+}
+uint64_t sdsl_hip_wt_bv_size(sdsl_hip_wt_t wt)
+{
+    return wt ? wt->h.bv.view.n_bits : 0;
+}
+uint64_t sdsl_hip_wt_device_bytes(sdsl_hip_wt_t wt)
+{
+    return wt ? wt->h.device_bytes() : 0;
+}
+
+sdsl_hip_status sdsl_hip_wt_code_lengths(sdsl_hip_wt_t wt, uint8_t len_out[256])
+{
+    if (!wt || !len_out)
+        return SDSL_HIP_ERR_INVALID;
+    for (int c = 0; c < 256; ++c)
+        len_out[c] = wt->h.tables.c_to_leaf[c] == kWtUndef ? 0 : (uint8_t)(wt->h.tables.path[c] >> 56);
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_wt_rank_batch(sdsl_hip_wt_t wt, const uint64_t * i, const uint8_t * c, uint64_t n,
+                                       uint64_t * out, void * stream)
+{
+    if (!wt || (n && (!i || !c || !out)))
+    {
+        set_error("wt_rank_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(wt->h.device));
+    Staged si, sc, so;
+    SH_TRY(si.in(i, n * 8, s));
+    SH_TRY(sc.in(c, n, s));
+    SH_TRY(so.out(out, n * 8));
+    SH_TRY(wt_launch_rank(wt->h, (const uint64_t *)si.dev, (const uint8_t *)sc.dev, n, (uint64_t *)so.dev, s));
+    SH_TRY(so.finish(s));
+    if ((si.host || sc.host) && !so.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_wt_inverse_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, uint64_t n,
+                                                 uint64_t * out_rank, uint8_t * out_c, void * stream)
+{
+    if (!wt || (n && (!i || !out_c)))
+    {
+        set_error("wt_inverse_select_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(wt->h.device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged si, sr, sc;
+    SH_TRY(si.in(i, n * 8, s));
+    SH_TRY(sc.out(out_c, n));
+    if (out_rank)
+        SH_TRY(sr.out(out_rank, n * 8));
+    {
+        KernelTimer t(s);
+        unsigned grid = grid_for(n, kQPB, 256u * 8u);
+        if (out_rank)
+            hipLaunchKernelGGL((k_wt_inverse_select<false, true>), dim3(grid), dim3(kBlock), 0, s, wt->h.view(),
+                               (const uint64_t *)si.dev, (uint64_t *)sr.dev, (uint8_t *)sc.dev, n);
+        else
+            hipLaunchKernelGGL((k_wt_inverse_select<false, false>), dim3(grid), dim3(kBlock), 0, s, wt->h.view(),
+                               (const uint64_t *)si.dev, (uint64_t *)nullptr, (uint8_t *)sc.dev, n);
+    }
+    SH_HIP(hipGetLastError());
+    SH_TRY(sc.finish(s));
+    if (out_rank)
+        SH_TRY(sr.finish(s));
+    if (si.host && !sc.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_wt_access_batch(sdsl_hip_wt_t wt, const uint64_t * i, uint64_t n, uint8_t * out_c,
+                                         void * stream)
+{
+    return sdsl_hip_wt_inverse_select_batch(wt, i, n, nullptr, out_c, stream);
+}
+
+sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, const uint8_t * c, uint64_t n,
+                                         uint64_t * out, void * stream)
+{
+    if (!wt || (n && (!i || !c || !out)))
+    {
+        set_error("wt_select_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(wt->h.device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged si, sc, so;
+    SH_TRY(si.in(i, n * 8, s));
+    SH_TRY(sc.in(c, n, s));
+    SH_TRY(so.out(out, n * 8));
+    {
+        KernelTimer t(s);
+        hipLaunchKernelGGL((k_wt_select<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s,
+                           wt->h.view(), wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev,
+                           (const uint8_t *)sc.dev, (uint64_t *)so.dev, n);
+    }
+    SH_HIP(hipGetLastError());
+    SH_TRY(so.finish(s));
+    if ((si.host || sc.host) && !so.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+}

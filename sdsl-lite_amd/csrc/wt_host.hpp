@@ -1,0 +1,42 @@
+// wt_host.hpp — host-side owner of a device wavelet tree and its builders.
+#pragma once
+#include "bv_host.hpp"
+#include "sdsl_stream.hpp"
+#include "wt_device.hpp"
+
+namespace sdslhip {
+
+struct WtHost
+{
+    int device = 0;
+    uint64_t size = 0, sigma = 0;
+    uint32_t n_nodes = 0;
+    BvHost bv;          // the concatenated WT bit vector as rank lines (+ select directories)
+    DevBuf d_tables;    // WtTables image in HBM
+    WtTables tables;    // host copy (code lengths, alphabet queries)
+    uint64_t occ[256];  // occurrences of every byte (== wt.rank(size(), c))
+    WtView view() const
+    {
+        WtView v;
+        v.bv = bv.view;
+        v.tables = d_tables.as<WtTables>();
+        v.size = size;
+        v.sigma = sigma;
+        v.n_nodes = n_nodes;
+        return v;
+    }
+    size_t device_bytes() const
+    {
+        return bv.device_bytes() + d_tables.bytes;
+    }
+};
+
+// Builds shape + bit vector on the host from the symbol sequence (host pointer) and uploads.
+sdsl_hip_status wt_build_from_text(WtHost & wt, const uint8_t * text, uint64_t n, int device);
+// Parses wt_pc::serialize output (wt_pc.hpp:713-726) and uploads; advances the reader.
+sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, bool select_is_mcl, int device);
+
+sdsl_hip_status wt_launch_rank(const WtHost & wt, const uint64_t * d_i, const uint8_t * d_c, uint64_t n,
+                               uint64_t * d_out, hipStream_t s);
+
+} // namespace sdslhip

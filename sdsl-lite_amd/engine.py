@@ -182,3 +182,223 @@ def set_random_bits(n_bits: int, seed: int) -> np.ndarray:
     if w.size:
         capi.check(capi.lib().sdsl_hip_util_set_random_bits(_ptr(w), n_bits, seed))
     return w
+
+
+class rrr_vector(_Handle):
+    """Device rrr_vector<63, int_vector<>, 32> with its rank/select supports (rrr_vector.hpp:68)."""
+    _destroy = "sdsl_hip_rrr_destroy"
+
+    def __init__(self, words=None, n_bits: int | None = None, device: int = 0, sdsl_bytes: bytes | None = None):
+        super().__init__()
+        if sdsl_bytes is not None:
+            buf = np.frombuffer(sdsl_bytes, dtype=np.uint8)
+            capi.check(capi.lib().sdsl_hip_rrr_create_from_sdsl(_ptr(buf), buf.size, device, C.byref(self._h)))
+        else:
+            w = _as_array(words, np.uint64, "words")
+            nw = w.numel() if _is_tensor(w) else w.size
+            if n_bits is None:
+                n_bits = nw * 64
+            capi.check(capi.lib().sdsl_hip_rrr_create(_ptr(w) if nw else None, n_bits, device, C.byref(self._h)))
+        self.device = device
+
+    def size(self) -> int:
+        return capi.lib().sdsl_hip_rrr_size(self._h)
+
+    def ones(self) -> int:
+        return capi.lib().sdsl_hip_rrr_ones(self._h)
+
+    def device_bytes(self) -> int:
+        return capi.lib().sdsl_hip_rrr_device_bytes(self._h)
+
+    def rank(self, idx, bit: int = 1, out=None):
+        idx = _as_array(idx, np.uint64, "idx")
+        n = idx.numel() if _is_tensor(idx) else idx.size
+        if out is None:
+            out = _empty_like(idx, n, np.uint64)
+        capi.check(capi.lib().sdsl_hip_rrr_rank_batch(self._h, bit, _ptr(idx), n, _ptr(out), _stream_for(idx)))
+        return out
+
+    def select(self, i, bit: int = 1, out=None):
+        i = _as_array(i, np.uint64, "i")
+        n = i.numel() if _is_tensor(i) else i.size
+        if out is None:
+            out = _empty_like(i, n, np.uint64)
+        capi.check(capi.lib().sdsl_hip_rrr_select_batch(self._h, bit, _ptr(i), n, _ptr(out), _stream_for(i)))
+        return out
+
+    def access(self, idx, out=None):
+        idx = _as_array(idx, np.uint64, "idx")
+        n = idx.numel() if _is_tensor(idx) else idx.size
+        if out is None:
+            out = _empty_like(idx, n, np.uint8)
+        capi.check(capi.lib().sdsl_hip_rrr_access_batch(self._h, _ptr(idx), n, _ptr(out), _stream_for(idx)))
+        return out
+
+    __getitem__ = access
+
+
+def _bytes_arg(x, name):
+    if isinstance(x, (bytes, bytearray)):
+        return np.frombuffer(bytes(x), dtype=np.uint8)
+    return _as_array(x, np.uint8, name)
+
+
+class wt_huff(_Handle):
+    """Device wt_huff<bit_vector, rank_support_v5<>> over bytes (wt_huff.hpp:62-67, wt_pc.hpp:59)."""
+    _destroy = "sdsl_hip_wt_destroy"
+
+    def __init__(self, text=None, device: int = 0, sdsl_bytes: bytes | None = None, select_is_mcl: bool = True,
+                 _borrowed=None):
+        super().__init__()
+        self.consumed = None
+        if _borrowed is not None:
+            self._h = C.c_void_p(_borrowed)
+            self._own = False
+        elif sdsl_bytes is not None:
+            buf = np.frombuffer(sdsl_bytes, dtype=np.uint8)
+            used = C.c_size_t(0)
+            capi.check(capi.lib().sdsl_hip_wt_create_from_sdsl(_ptr(buf), buf.size, 1 if select_is_mcl else 0, device,
+                                                               C.byref(self._h), C.byref(used)))
+            self.consumed = used.value
+        else:
+            t = _bytes_arg(text, "text")
+            n = t.numel() if _is_tensor(t) else t.size
+            capi.check(capi.lib().sdsl_hip_wt_create(_ptr(t) if n else None, n, device, C.byref(self._h)))
+        self.device = device
+
+    def size(self) -> int:
+        return capi.lib().sdsl_hip_wt_size(self._h)
+
+    def sigma(self) -> int:
+        return capi.lib().sdsl_hip_wt_sigma(self._h)
+
+    def bv_size(self) -> int:
+        return capi.lib().sdsl_hip_wt_bv_size(self._h)
+
+    def device_bytes(self) -> int:
+        return capi.lib().sdsl_hip_wt_device_bytes(self._h)
+
+    def code_lengths(self) -> np.ndarray:
+        out = np.zeros(256, dtype=np.uint8)
+        capi.check(capi.lib().sdsl_hip_wt_code_lengths(self._h, _ptr(out)))
+        return out
+
+    def rank(self, i, c, out=None):
+        i = _as_array(i, np.uint64, "i")
+        c = _as_array(c, np.uint8, "c")
+        n = i.numel() if _is_tensor(i) else i.size
+        if out is None:
+            out = _empty_like(i, n, np.uint64)
+        capi.check(capi.lib().sdsl_hip_wt_rank_batch(self._h, _ptr(i), _ptr(c), n, _ptr(out), _stream_for(i)))
+        return out
+
+    def access(self, i, out=None):
+        i = _as_array(i, np.uint64, "i")
+        n = i.numel() if _is_tensor(i) else i.size
+        if out is None:
+            out = _empty_like(i, n, np.uint8)
+        capi.check(capi.lib().sdsl_hip_wt_access_batch(self._h, _ptr(i), n, _ptr(out), _stream_for(i)))
+        return out
+
+    __getitem__ = access
+
+    def inverse_select(self, i):
+        i = _as_array(i, np.uint64, "i")
+        n = i.numel() if _is_tensor(i) else i.size
+        r = _empty_like(i, n, np.uint64)
+        c = _empty_like(i, n, np.uint8)
+        capi.check(capi.lib().sdsl_hip_wt_inverse_select_batch(self._h, _ptr(i), n, _ptr(r), _ptr(c), _stream_for(i)))
+        return r, c
+
+    def select(self, i, c, out=None):
+        i = _as_array(i, np.uint64, "i")
+        c = _as_array(c, np.uint8, "c")
+        n = i.numel() if _is_tensor(i) else i.size
+        if out is None:
+            out = _empty_like(i, n, np.uint64)
+        capi.check(capi.lib().sdsl_hip_wt_select_batch(self._h, _ptr(i), _ptr(c), n, _ptr(out), _stream_for(i)))
+        return out
+
+
+class csa_wt(_Handle):
+    """Device csa_wt<wt_huff<bit_vector, rank_support_v5<>>> restricted to backward_search/count
+    (csa_wt.hpp:56, suffix_array_algorithm.hpp:167-248,464-471)."""
+    _destroy = "sdsl_hip_fm_destroy"
+
+    def __init__(self, text=None, bwt=None, device: int = 0, sdsl_bytes: bytes | None = None,
+                 select_is_mcl: bool = True):
+        super().__init__()
+        L = capi.lib()
+        if sdsl_bytes is not None:
+            buf = np.frombuffer(sdsl_bytes, dtype=np.uint8)
+            capi.check(L.sdsl_hip_fm_create_from_sdsl(_ptr(buf), buf.size, 1 if select_is_mcl else 0, device,
+                                                      C.byref(self._h)))
+        elif bwt is not None:
+            b = _bytes_arg(bwt, "bwt")
+            n = b.numel() if _is_tensor(b) else b.size
+            capi.check(L.sdsl_hip_fm_create_from_bwt(_ptr(b) if n else None, n, device, C.byref(self._h)))
+        else:
+            t = _bytes_arg(text, "text")
+            n = t.numel() if _is_tensor(t) else t.size
+            capi.check(L.sdsl_hip_fm_create_from_text(_ptr(t) if n else None, n, device, C.byref(self._h)))
+        self.device = device
+        self.wavelet_tree = wt_huff(_borrowed=L.sdsl_hip_fm_wavelet_tree(self._h), device=device)
+        self.wavelet_tree._keepalive = self
+
+    def size(self) -> int:
+        return capi.lib().sdsl_hip_fm_size(self._h)
+
+    def sigma(self) -> int:
+        return capi.lib().sdsl_hip_fm_sigma(self._h)
+
+    def device_bytes(self) -> int:
+        return capi.lib().sdsl_hip_fm_device_bytes(self._h)
+
+    def alphabet(self):
+        c2c = np.zeros(256, dtype=np.uint8)
+        Cc = np.zeros(257, dtype=np.uint64)
+        capi.check(capi.lib().sdsl_hip_fm_alphabet(self._h, _ptr(c2c), _ptr(Cc)))
+        return c2c, Cc
+
+    def backward_search(self, l, r, c):
+        l = _as_array(l, np.uint64, "l")
+        r = _as_array(r, np.uint64, "r")
+        c = _as_array(c, np.uint8, "c")
+        n = l.numel() if _is_tensor(l) else l.size
+        lo, ro = _empty_like(l, n, np.uint64), _empty_like(l, n, np.uint64)
+        capi.check(capi.lib().sdsl_hip_fm_backward_search_batch(self._h, _ptr(l), _ptr(r), _ptr(c), n, _ptr(lo),
+                                                                _ptr(ro), _stream_for(l)))
+        return lo, ro
+
+    def count(self, patterns, m: int, out=None):
+        """patterns: n*m bytes (fixed length m) -> uint64[n]"""
+        p = _bytes_arg(patterns, "patterns")
+        total = p.numel() if _is_tensor(p) else p.size
+        n = total // m if m else 0
+        if out is None:
+            out = _empty_like(p, n, np.uint64)
+        capi.check(capi.lib().sdsl_hip_fm_count_batch(self._h, _ptr(p) if total else None, m, n, _ptr(out),
+                                                      _stream_for(p)))
+        return out
+
+    def interval(self, patterns, m: int):
+        p = _bytes_arg(patterns, "patterns")
+        total = p.numel() if _is_tensor(p) else p.size
+        n = total // m if m else 0
+        l, r = _empty_like(p, n, np.uint64), _empty_like(p, n, np.uint64)
+        capi.check(capi.lib().sdsl_hip_fm_interval_batch(self._h, _ptr(p) if total else None, m, n, _ptr(l), _ptr(r),
+                                                         _stream_for(p)))
+        return l, r
+
+    def count_ragged(self, pats: list[bytes]):
+        offs = np.zeros(len(pats) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(x) for x in pats])
+        blob = np.frombuffer(b"".join(pats) + b"\0", dtype=np.uint8)  # never empty
+        out = np.empty(len(pats), dtype=np.uint64)
+        capi.check(capi.lib().sdsl_hip_fm_count_ragged(self._h, _ptr(blob), _ptr(offs), len(pats), _ptr(out), 0))
+        return out
+
+
+def count(csa: csa_wt, patterns, m: int, out=None):
+    """sdsl::count(csa, begin, end) over a batch of fixed-length patterns."""
+    return csa.count(patterns, m, out)

@@ -1,0 +1,359 @@
+"""GPU parity tests proper: every call goes through the C ABI of libsdsl_hip.so and is compared
+bit-exactly with (a) the committed golden vectors produced by the real sdsl-lite, (b) the CPU
+restatement (oracle/) on seeded inputs, and (c) the real library itself when oracle/_ref travelled
+with the snapshot.  Integer work only: the bar is equality, no tolerances anywhere."""
+import numpy as np
+import pytest
+
+import golden_data as gd
+import oracle_lib as ol
+from conftest import unpack_bits
+
+pytestmark = pytest.mark.gpu
+NPOS = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def mk(n, d, seed):
+    r = np.random.default_rng(seed)
+    nw = (n + 63) // 64
+    if d == 0.5:
+        return r.integers(0, 2**64, size=nw, dtype=np.uint64)
+    bits = (r.random(nw * 64) < d).astype(np.uint8)
+    return np.packbits(bits, bitorder="little").view(np.uint64).copy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# plain bit vector: rank_support_v5 / select_support_mcl
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", gd.bv_case_names())
+def test_bv_golden(gpu, name):
+    g = gd.bv_golden()
+    w, n = gd.bv_case(name)
+    bv = gpu.bit_vector(w, n)
+    idx = g[f"{name}/idx"]
+    for b in (0, 1):
+        assert np.array_equal(bv.rank(idx, b), g[f"{name}/rank{b}"])
+        tot = int(g[f"{name}/total{b}"][0])
+        assert (bv.ones() if b else n - bv.ones()) == tot
+        if tot:
+            assert np.array_equal(bv.select(g[f"{name}/sel{b}_i"], b), g[f"{name}/sel{b}"])
+
+
+@pytest.mark.parametrize("n,d", [(1 << 20, 0.5), (3_000_000, 0.02), (999_999, 0.97), (200_000, 0.5)])
+def test_bv_vs_oracle(gpu, n, d):
+    rng = np.random.default_rng(n)
+    w = mk(n, d, 21)
+    o = ol.OBitVector(w, n)
+    bv = gpu.bit_vector(w, n)
+    idx = rng.integers(0, n + 1, size=200_000, dtype=np.uint64)
+    for b in (0, 1):
+        assert np.array_equal(bv.rank(idx, b), o.rank(idx, b))
+        ac = o.arg_cnt(b)
+        i = rng.integers(1, ac + 1, size=200_000, dtype=np.uint64)
+        assert np.array_equal(bv.select(i, b), o.select(i, b))
+
+
+def test_bv_vs_real_sdsl(gpu):
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not present")
+    n = 2_500_000
+    w = mk(n, 0.3, 77)
+    r = ol.RBitVector(w, n)
+    bv = gpu.bit_vector(w, n)
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, n + 1, size=100_000, dtype=np.uint64)
+    assert np.array_equal(bv.rank(idx, 1), r.rank(idx, 1))
+    assert np.array_equal(bv.rank(idx, 1), r.rank_v(idx))  # rank_support_v gives the same answers
+    i = rng.integers(1, bv.ones() + 1, size=100_000, dtype=np.uint64)
+    assert np.array_equal(bv.select(i, 1), r.select(i, 1))
+
+
+def test_bv_reference_test_semantics(gpu):
+    """test/rank_support_test.cpp:109-128 and test/select_support_test.cpp:85-104 on the fixture every
+    int-vec.* entry of the reference's config resolves to: all positions, all set bits."""
+    w, n = gd.bv_case("CRAFTED-MAT-SELECT")
+    bits = unpack_bits(w, n).astype(np.uint64)
+    bv = gpu.bit_vector(w, n)
+    pref = np.concatenate([[0], np.cumsum(bits)]).astype(np.uint64)
+    assert np.array_equal(bv.rank(np.arange(n + 1, dtype=np.uint64), 1), pref)
+    pos = np.nonzero(bits)[0].astype(np.uint64)
+    assert pos.size == 4061
+    assert np.array_equal(bv.select(np.arange(1, pos.size + 1, dtype=np.uint64), 1), pos)
+
+
+# ---------------------------------------------------------------------------------------------------
+# rrr_vector<63>
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", gd.bv_case_names())
+def test_rrr_golden(gpu, name):
+    g = gd.bv_golden()
+    w, n = gd.bv_case(name)
+    v = gpu.rrr_vector(w, n)
+    assert v.size() == n
+    idx = g[f"{name}/idx"]
+    for b in (0, 1):
+        assert np.array_equal(v.rank(idx, b), g[f"{name}/rank{b}"])
+        assert np.array_equal(v.select(g[f"{name}/rrr_sel{b}_i"], b), g[f"{name}/rrr_sel{b}"])
+    assert v.ones() == int(g[f"{name}/total1"][0])
+
+
+@pytest.mark.parametrize("n", [0, 1, 62, 63, 64, 126, 630, 2015, 2016, 2017, 63 * 32 * 3, 100_000, 1_000_003])
+@pytest.mark.parametrize("d", [0.5, 0.05, 0.95, 0.0, 1.0])
+def test_rrr_vs_oracle(gpu, n, d):
+    rng = np.random.default_rng(n + 1)
+    w = mk(n, d, n + 5)
+    o = ol.ORrr(w, n)
+    v = gpu.rrr_vector(w, n)
+    idx = np.arange(n + 1, dtype=np.uint64) if n <= 5000 else rng.integers(0, n + 1, size=50_000, dtype=np.uint64)
+    for b in (0, 1):
+        assert np.array_equal(v.rank(idx, b), o.rank(idx, b))
+        tot = int(o.rank([n], b)[0])
+        i = (np.arange(1, tot + 2, dtype=np.uint64) if tot <= 5000 else
+             rng.integers(1, tot + 2, size=50_000, dtype=np.uint64))  # includes the overflow value tot+1 -> size()
+        assert np.array_equal(v.select(i, b), o.select(i, b))
+        assert int(v.select(np.array([0], dtype=np.uint64), b)[0]) == int(NPOS)
+    if n:
+        ia = idx[idx < n][:20000]
+        assert np.array_equal(v.access(ia), unpack_bits(w, n)[ia.astype(np.int64)])
+
+
+@pytest.mark.parametrize("name", ["CRAFTED-32", "rnd.8192.1043", "rnd.200000.7", "rnd.10080.9"])
+def test_rrr_loads_sdsl_stream(gpu, name):
+    """the bytes written by the real rrr_vector<63>::serialize are accepted as they are"""
+    g = gd.bv_golden()
+    v = gpu.rrr_vector(sdsl_bytes=gd.sdsl_file(f"{name}.rrr63.sdsl"))
+    idx = g[f"{name}/idx"]
+    for b in (0, 1):
+        assert np.array_equal(v.rank(idx, b), g[f"{name}/rank{b}"])
+        assert np.array_equal(v.select(g[f"{name}/rrr_sel{b}_i"], b), g[f"{name}/rrr_sel{b}"])
+    with pytest.raises(gpu.capi.SdslHipError) as e:
+        gpu.rrr_vector(sdsl_bytes=gd.sdsl_file(f"{name}.rrr63.sdsl")[:-9])
+    assert e.value.status == gpu.capi.ERR_FORMAT
+
+
+def test_rrr_inline_overflow_path(gpu):
+    # dense superblocks have ~1950 offset bits: fields beyond the 640 inline bits come from the stream
+    n = 63 * 32 * 50 + 17
+    w = mk(n, 0.5, 3)
+    o = ol.ORrr(w, n)
+    v = gpu.rrr_vector(w, n)
+    idx = np.arange(n + 1, dtype=np.uint64)
+    assert np.array_equal(v.rank(idx, 1), o.rank(idx, 1))
+    tot = v.ones()
+    i = np.arange(1, tot + 1, dtype=np.uint64)
+    assert np.array_equal(v.select(i, 1), o.select(i, 1))
+
+
+# ---------------------------------------------------------------------------------------------------
+# wt_huff
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", gd.TEXTS)
+def test_wt_golden(gpu, name):
+    g = gd.text_golden()
+    data = gd.text(name)
+    wt = gpu.wt_huff(data)
+    n, sigma, bvs = (int(x) for x in g[f"{name}/meta"])
+    assert (wt.size(), wt.sigma(), wt.bv_size()) == (n, sigma, bvs)
+    assert np.array_equal(wt.rank(g[f"{name}/rank_i"], g[f"{name}/rank_c"]), g[f"{name}/rank"])
+    assert np.array_equal(wt.rank(np.full(256, n, dtype=np.uint64), np.arange(256, dtype=np.uint8)),
+                          g[f"{name}/rank_full"])
+    if n:
+        ai = g[f"{name}/acc_i"]
+        assert np.array_equal(wt.access(ai), g[f"{name}/acc"])
+        r, c = wt.inverse_select(ai)
+        assert np.array_equal(r, g[f"{name}/invsel_rank"]) and np.array_equal(c, g[f"{name}/acc"])
+        assert np.array_equal(wt.select(g[f"{name}/sel_i"], g[f"{name}/sel_c"]), g[f"{name}/sel"])
+
+
+def test_wt_reference_test_semantics(gpu):
+    """test/wt_byte_test.cpp:134-168: rank(j+1, text[j]) = running count for every j; 1000 random
+    positions for every absent symbol return 0; rank(size(), c) for all 256 c."""
+    data = gd.text("faust.txt")
+    arr = np.frombuffer(data, dtype=np.uint8)
+    wt = gpu.wt_huff(data)
+    cnt = np.zeros(256, dtype=np.int64)
+    exp = np.empty(arr.size, dtype=np.uint64)
+    for c in range(256):
+        m = arr == c
+        exp[m] = np.arange(1, int(m.sum()) + 1, dtype=np.uint64)
+        cnt[c] = m.sum()
+    assert np.array_equal(wt.rank(np.arange(1, arr.size + 1, dtype=np.uint64), arr), exp)
+    absent = np.nonzero(cnt == 0)[0].astype(np.uint8)
+    rng = np.random.default_rng(4)
+    pos = rng.integers(0, arr.size + 1, size=1000 * absent.size, dtype=np.uint64)
+    assert not wt.rank(pos, np.repeat(absent, 1000)).any()
+    assert np.array_equal(wt.rank(np.full(256, arr.size, dtype=np.uint64), np.arange(256, dtype=np.uint8)),
+                          cnt.astype(np.uint64))
+    assert int(wt.rank(np.array([arr.size + 1], dtype=np.uint64), arr[:1])[0]) == int(NPOS)
+
+
+@pytest.mark.parametrize("name", ["example01.txt", "abc_abc_abc.txt", "100a.txt", "one_byte.txt"])
+@pytest.mark.parametrize("mcl", [True, False])
+def test_wt_loads_sdsl_stream(gpu, name, mcl):
+    g = gd.text_golden()
+    blob = gd.sdsl_file(f"{name}.wt_huff_v5_{'mcl' if mcl else 'scan'}.sdsl")
+    wt = gpu.wt_huff(sdsl_bytes=blob, select_is_mcl=mcl)
+    assert wt.consumed == len(blob)
+    assert np.array_equal(wt.rank(g[f"{name}/rank_i"], g[f"{name}/rank_c"]), g[f"{name}/rank"])
+    assert np.array_equal(wt.select(g[f"{name}/sel_i"], g[f"{name}/sel_c"]), g[f"{name}/sel"])
+    assert np.array_equal(wt.access(g[f"{name}/acc_i"]), g[f"{name}/acc"])
+
+
+def test_wt_random_vs_oracle(gpu):
+    rng = np.random.default_rng(9)
+    for sigma, n in [(2, 5000), (3, 70000), (256, 300000), (40, 1_000_000)]:
+        p = rng.random(sigma) ** 3
+        p /= p.sum()
+        syms = rng.choice(256, size=sigma, replace=False).astype(np.uint8)
+        t = syms[rng.choice(sigma, size=n, p=p)]
+        o = ol.OWt(t)
+        wt = gpu.wt_huff(t)
+        assert np.array_equal(wt.code_lengths(), o.code_lengths())
+        i = rng.integers(0, n + 1, size=100_000, dtype=np.uint64)
+        c = rng.integers(0, 256, size=100_000, dtype=np.uint8)
+        c[:60_000] = t[rng.integers(0, n, size=60_000)]
+        assert np.array_equal(wt.rank(i, c), o.rank(i, c))
+        ia = rng.integers(0, n, size=3000, dtype=np.uint64)
+        assert np.array_equal(wt.access(ia), t[ia.astype(np.int64)])
+        cs = t[rng.integers(0, n, size=2000)]
+        tot = o.rank(np.full(cs.size, n, dtype=np.uint64), cs)
+        si = rng.integers(0, 2**62, size=cs.size, dtype=np.uint64) % tot + np.uint64(1)
+        assert np.array_equal(wt.select(si, cs), o.select(si, cs))
+
+
+# ---------------------------------------------------------------------------------------------------
+# csa_wt: backward_search / count
+# ---------------------------------------------------------------------------------------------------
+FM_TEXTS = [t for t in gd.TEXTS if t not in ("empty.txt", "all_symbols.txt")]
+
+
+def _fm_cases(name):
+    g = gd.text_golden()
+    if f"{name}/csa_meta" not in g.files:
+        pytest.skip("text contains a 0 byte: not indexable (construct.hpp:41)")
+    return g
+
+
+@pytest.mark.parametrize("name", FM_TEXTS)
+@pytest.mark.parametrize("how", ["bwt", "text"])
+def test_fm_golden(gpu, name, how):
+    g = _fm_cases(name)
+    data = gd.text(name)
+    if how == "bwt":
+        csa = gpu.csa_wt(bwt=ol.OCsa(data).bwt())
+    else:
+        csa = gpu.csa_wt(text=data)  # suffix array built on the device
+    assert [csa.size(), csa.sigma()] == [int(x) for x in g[f"{name}/csa_meta"]]
+    c2c, Cc = csa.alphabet()
+    assert np.array_equal(c2c, g[f"{name}/char2comp"]) and np.array_equal(Cc, g[f"{name}/C"])
+    for m in (1, 2, 4, 20):
+        if f"{name}/pat{m}" not in g.files:
+            continue
+        pats = g[f"{name}/pat{m}"]
+        assert np.array_equal(csa.count(pats, m), g[f"{name}/count{m}"])
+        l, r = csa.interval(pats, m)
+        assert np.array_equal(l, g[f"{name}/ival_l{m}"]) and np.array_equal(r, g[f"{name}/ival_r{m}"])
+
+
+@pytest.mark.parametrize("name,which", [("example01.txt", "csa_wt_huff_v5"), ("faust.txt", "csa_wt_huff_v5"),
+                                        ("example01.txt", "csa_fm_huff"), ("faust.txt", "csa_fm_huff")])
+def test_fm_loads_sdsl_stream(gpu, name, which):
+    """serialised csa_wt files of the real library: the default type (mcl selects) and the FM_HUFF type of
+    benchmark/indexing_count/index.config:8 (scan selects, 2^20 sampling)"""
+    g = gd.text_golden()
+    csa = gpu.csa_wt(sdsl_bytes=gd.sdsl_file(f"{name}.{which}.sdsl"), select_is_mcl=(which == "csa_wt_huff_v5"))
+    assert [csa.size(), csa.sigma()] == [int(x) for x in g[f"{name}/csa_meta"]]
+    for m in (1, 4, 20):
+        if f"{name}/pat{m}" in g.files:
+            assert np.array_equal(csa.count(g[f"{name}/pat{m}"], m), g[f"{name}/count{m}"])
+    assert np.array_equal(csa.wavelet_tree.rank(g[f"{name}/rank_i"][:0], g[f"{name}/rank_c"][:0]), np.zeros(0, np.uint64))
+
+
+def test_fm_known_answers_and_edges(gpu):
+    f = gpu.csa_wt(text=gd.text("faust.txt"))
+    assert (f.size(), f.sigma(), f.wavelet_tree.bv_size()) == (226836, 92, 1096825)
+    assert list(f.count_ragged([b"und", b"", b"Faust", b"\xff\xfe", b"x" * 300000])) == [
+        690, 226836, ol.OCsa(gd.text("faust.txt")).count(b"Faust"), 0, 0]
+    a = gpu.csa_wt(text=b"abracadabra")
+    assert list(a.count_ragged([b"abra", b"xyz", b"a" * 22, b""])) == [2, 0, 0, 12]
+    assert list(a.alphabet()[1][:7]) == [0, 1, 6, 8, 9, 10, 12]
+    # test/csa_byte_test.cpp:81-106: the whole text matches exactly once; empty pattern -> [0, size-1]
+    t = gd.text("example01.txt")
+    c = gpu.csa_wt(text=t)
+    l, r = c.interval(np.frombuffer(t, dtype=np.uint8), len(t))
+    assert int(r[0]) + 1 - int(l[0]) == 1
+    with pytest.raises(gpu.capi.SdslHipError):
+        gpu.csa_wt(text=b"ab\0cd")
+
+
+def test_fm_backward_search_steps_vs_oracle(gpu):
+    data = gd.text("faust.txt")
+    o = ol.OCsa(data)
+    csa = gpu.csa_wt(bwt=o.bwt())
+    rng = np.random.default_rng(12)
+    n = o.size()
+    l = rng.integers(0, n, size=20000, dtype=np.uint64)
+    r = np.minimum(l + rng.integers(0, 5000, size=l.size, dtype=np.uint64), np.uint64(n - 1))
+    l[:100], r[:100] = 0, n - 1  # whole-interval shortcut
+    c = np.frombuffer(data, dtype=np.uint8)[rng.integers(0, len(data), size=l.size)].copy()
+    c[::9] = rng.integers(0, 256, size=c[::9].size)
+    lo, ro = csa.backward_search(l, r, c)
+    exp = np.array([o.backward_search(a, b, cc) for a, b, cc in zip(l, r, c)], dtype=np.uint64)
+    assert np.array_equal(lo, exp[:, 0]) and np.array_equal(ro, exp[:, 1])
+
+
+def test_fm_synthetic_text_device_sa_vs_oracle(gpu):
+    rng = np.random.default_rng(8)
+    words = [bytes(rng.integers(97, 123, size=rng.integers(2, 9), dtype=np.uint8)) for _ in range(300)]
+    t = b" ".join(words[i] for i in rng.integers(0, len(words), size=60000))
+    o = ol.OCsa(t)
+    csa = gpu.csa_wt(text=t)
+    arr = np.frombuffer(t, dtype=np.uint8)
+    st = rng.integers(0, len(t) - 20, size=20000)
+    pats = np.concatenate([arr[s:s + 20] for s in st])
+    got = csa.count(pats, 20)
+    assert np.array_equal(got, o.count_batch(pats, 20))
+    assert (got >= 1).all()
+    if ol.have_ref():
+        assert np.array_equal(got, ol.RCsa(t).count_batch(pats, 20))
+
+
+# ---------------------------------------------------------------------------------------------------
+# full-size properties (BASELINE.json configs[1]: 2^34-bit vector) — size-independent invariants
+# ---------------------------------------------------------------------------------------------------
+def test_full_size_properties(gpu):
+    import torch
+    n = 1 << 34
+    g = torch.Generator(device="cuda").manual_seed(42)
+    words = torch.randint(-2**63, 2**63 - 1, (n // 64,), device="cuda", dtype=torch.int64, generator=g)
+    bv = gpu.bit_vector(words, n)
+    # exact ones count from an independent torch computation (byte LUT)
+    lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.uint8, device="cuda")
+    total = 0
+    per_word = torch.empty(n // 64, dtype=torch.int32, device="cuda")
+    step = 1 << 24
+    for s in range(0, n // 64, step):
+        pw = lut[words[s:s + step].view(torch.uint8).long()].view(-1, 8).sum(dim=1, dtype=torch.int32)
+        per_word[s:s + step] = pw
+        total += int(pw.sum())
+    assert bv.ones() == total
+    nq = 1 << 22
+    idx = torch.randint(0, n + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
+    r1, r0 = bv.rank(idx, 1), bv.rank(idx, 0)
+    assert bool((r1 + r0 == idx).all())
+    # rank at word boundaries equals the torch prefix sum
+    widx = torch.randint(0, n // 64 + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
+    csum = torch.cumsum(per_word.long(), 0)
+    expect = torch.where(widx > 0, csum[(widx - 1).clamp(min=0)], torch.zeros_like(widx))
+    assert bool((bv.rank(widx * 64, 1) == expect).all())
+    del csum, per_word
+    # select/rank round trips
+    for b, tot in ((1, total), (0, n - total)):
+        i = torch.randint(1, tot + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
+        pos = bv.select(i, b)
+        assert bool((bv.rank(pos, b) == i - 1).all())
+        assert bool((bv.access(pos) == b).all())
+        assert bool((bv.rank(pos + 1, b) == i).all())
+    i = torch.arange(1, nq + 1, device="cuda", dtype=torch.int64) * (total // nq)
+    pos = bv.select(i, 1)
+    assert bool((pos[1:] > pos[:-1]).all())  # sortedness
