@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X rank/select engine (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch: `--queries` (default 10^9) batched rank_1
+queries, uniformly random in [0, n], on a 2^34-bit random bit vector resident in HBM together with
+the query and result arrays.  N > 1: one process per GPU (torchrun / torch.distributed, backend nccl =
+RCCL); the index is replicated, every rank answers its own resident shard of the same size (weak
+scaling, no data-path collective); the step time is the MAX over ranks and `value` is the whole-job
+aggregate.  Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (dominant kernel
+against the HBM roofline, algorithmic bytes per SURVEY.md §8(d)) and `cpu_baseline` (the reference's CPU
+path on a bounded sample of the same workload, timed on this box's host cores, N=1 only).
+
+Optional secondary measurements (`--extras select,rrr,wt,fm`) are reported under "extras"; they never
+enter the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy achieves
+ALG_BYTES = {"rank": 96, "select": 112, "rrr": 144}  # SURVEY.md §8(d), bytes per query
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--log-n", type=int, default=34, help="bit vector length = 2^log_n (BASELINE: 34)")
+    p.add_argument("--queries", type=float, default=1e9, help="queries per step per GPU (BASELINE: 1e9)")
+    p.add_argument("--extras", type=str, default="select", help="comma list of: select,rrr,wt,fm (or 'none')")
+    p.add_argument("--text-mib", type=int, default=256, help="synthetic text size for the wt/fm extras")
+    p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    p.add_argument("--cpu-seconds", type=float, default=10.0)
+    return p.parse_args()
+
+
+def time_steps(fn, steps, warmup, barrier):
+    """barrier + synchronize on both sides of exactly `steps` calls; HIP events on the launch stream
+    give the average kernel duration of the same region."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+    return wall, e0.elapsed_time(e1) / steps
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed PMC summary (profiles/pmc_latest.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        return json.load(open(path)).get(kernel_key)
+    except Exception:
+        return None
+
+
+def cpu_baseline(pkg, words_dev, n_bits, idx_dev, gpu_out_dev, seconds):
+    """The reference's CPU path on this host: real sdsl-lite (oracle/_ref, kind 'reference') if the
+    prebuilt library travelled with the repo, else the C restatement (kind 'port').  One thread, scalar
+    loop over distinct queries like the reference's harnesses; results are compared with the GPU's."""
+    import oracle_lib as ol
+    words = words_dev.cpu().numpy().view(np.uint64)
+    kind = "reference" if ol.have_ref() else "port"
+    t0 = time.perf_counter()
+    if kind == "reference":
+        words_p = ol.padded(words, n_bits)
+        h = ol.ref().L.ref_bv_create(words_p.ctypes.data, n_bits)
+
+        def run(idx):
+            out = np.empty(idx.size, dtype=np.uint64)
+            ol.ref().L.ref_bv_rank(h, 1, idx.ctypes.data, idx.size, out.ctypes.data)
+            return out
+    else:
+        words_p = ol.padded(words, n_bits)
+        h = ol.oracle().L.orc_rank_v5_build(words_p.ctypes.data, n_bits, 1)
+
+        def run(idx):
+            out = np.empty(idx.size, dtype=np.uint64)
+            ol.oracle().L.orc_rank_v5_batch(h, idx.ctypes.data, idx.size, out.ctypes.data)
+            return out
+    build_s = time.perf_counter() - t0
+    probe = idx_dev[:1_000_000].cpu().numpy().view(np.uint64)
+    t0 = time.perf_counter()
+    run(probe)
+    per_q = (time.perf_counter() - t0) / probe.size
+    n_s = int(min(idx_dev.numel(), max(1_000_000, seconds / per_q)))
+    sample = idx_dev[:n_s].cpu().numpy().view(np.uint64)
+    t0 = time.perf_counter()
+    res = run(sample)
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(res, gpu_out_dev[:n_s].cpu().numpy().view(np.uint64)))
+    return {
+        "value": n_s / dt / 1e9, "unit": "Grank/s", "cores": 1, "kind": kind,
+        "sample": f"first {n_s} of the step's queries, scalar loop, 1 thread; "
+                  f"rank_support_v5 on the same 2^{int(np.log2(n_bits))}-bit vector (build {build_s:.1f}s)",
+        "ns_per_query": dt / n_s * 1e9, "matches_gpu": same,
+    }
+
+
+def synthetic_text(n_bytes, seed, device):
+    """English-like stand-in for Pizza&Chili english (not available offline): words drawn from a fixed
+    4096-word vocabulary with a Zipf-like distribution, separated by spaces.  Built on the device."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    vocab_n, max_len = 4096, 12
+    lens = torch.randint(2, max_len + 1, (vocab_n,), generator=g)
+    letters = torch.tensor(list(b"etaoinshrdlcumwfgypbvkjxqz"), dtype=torch.uint8)
+    lw = torch.arange(1, 27, dtype=torch.float64).pow(-0.9)
+    vocab = torch.zeros(vocab_n, max_len + 1, dtype=torch.uint8)
+    pick = torch.multinomial(lw, vocab_n * max_len, replacement=True, generator=g).view(vocab_n, max_len)
+    vocab[:, :max_len] = letters[pick]
+    for i in range(vocab_n):
+        vocab[i, lens[i]:] = 0
+        vocab[i, lens[i]] = 32
+    zipf = torch.arange(1, vocab_n + 1, dtype=torch.float64).pow(-1.0)
+    cdf = torch.cumsum(zipf / zipf.sum(), 0).to(device)
+    gd = torch.Generator(device=device).manual_seed(seed)
+    n_words = int(n_bytes / 5.5) + 1024
+    u = torch.rand(n_words, device=device, dtype=torch.float64, generator=gd)
+    ids = torch.searchsorted(cdf, u).clamp_(max=vocab_n - 1)
+    del u
+    flat = vocab.to(device)[ids].reshape(-1)
+    flat = flat[flat != 0][:n_bytes]
+    assert flat.numel() == n_bytes, "increase n_words"
+    return flat.contiguous()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+        def barrier():
+            dist.barrier(device_ids=[local])
+    else:
+        def barrier():
+            pass
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pkg = importlib.import_module("sdsl-lite_amd")
+    n_bits = 1 << a.log_n
+    nq = int(a.queries)
+
+    # index: replicated (same seed on every rank); queries: this rank's resident shard
+    g = torch.Generator(device=dev).manual_seed(42)
+    words = torch.randint(-2**63, 2**63 - 1, (n_bits // 64,), device=dev, dtype=torch.int64, generator=g)
+    extras = [] if a.extras in ("", "none") else a.extras.split(",")
+    bv = pkg.bit_vector(words, n_bits, device=local, select1="select" in extras, select0=False)
+    gq = torch.Generator(device=dev).manual_seed(7 + rank)
+    idx = torch.randint(0, n_bits + 1, (nq,), device=dev, dtype=torch.int64, generator=gq)
+    out = torch.empty_like(idx)
+
+    wall, kernel_ms = time_steps(lambda: bv.rank(idx, 1, out), a.steps, a.warmup, barrier)
+    if world > 1:
+        wall = pkg.dist.max_over_ranks(wall, dev)
+        kernel_ms = pkg.dist.max_over_ranks(kernel_ms, dev)
+    value = nq * world * a.steps / wall / 1e9
+    achieved = ALG_BYTES["rank"] * nq / (kernel_ms * 1e-3) / 1e9
+    result = {
+        "metric": "Grank/s, batched rank_1 on a 2^%d-bit vector" % a.log_n, "value": value, "unit": "Grank/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "configs[1]: batched rank_1 on a 2^%d-bit random bit_vector (density 0.5), "
+                               "%d uniform queries per step per GPU, index+queries+results resident in HBM"
+                               % (a.log_n, nq),
+                   "n_bits": n_bits, "queries_per_step_per_gpu": nq, "parallelism": "replicated index, query shards x%d" % world,
+                   "index_bytes_per_gpu": bv.device_bytes()},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_rank_bytes_per_launch"),
+                     "kernel": "sdslhip::k_rank<4,false>", "kernel_ms": kernel_ms,
+                     "algorithmic_bytes_per_query": ALG_BYTES["rank"]},
+    }
+
+    if rank == 0 and world == 1 and not a.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(pkg, words, n_bits, idx, out, a.cpu_seconds)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    ex = {}
+    if "select" in extras:
+        ones = bv.ones()
+        si = torch.randint(1, ones + 1, (nq,), device=dev, dtype=torch.int64, generator=gq)
+        _, ms = time_steps(lambda: bv.select(si, 1, out), max(2, a.steps // 2), 1, barrier)
+        ex["select_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms,
+                          "roofline_frac": ALG_BYTES["select"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        pos = out[: 1 << 20].clone()
+        assert bool((bv.rank(pos, 1) == si[: 1 << 20] - 1).all()), "select/rank round trip failed"
+        del si
+    del words
+    if "rrr" in extras:
+        del bv
+        torch.cuda.empty_cache()
+        gw = torch.Generator(device=dev).manual_seed(9)
+        # 5 % dense 2^log_n-bit vector (BASELINE.json configs[2]); bits packed on the device in chunks
+        nw = n_bits // 64
+        w5 = torch.empty(nw, dtype=torch.int64, device=dev)
+        weights = (torch.ones(64, dtype=torch.int64, device=dev) << torch.arange(64, device=dev)).view(1, 64)
+        chunk = 1 << 22
+        for s in range(0, nw, chunk):
+            e = min(nw, s + chunk)
+            b = (torch.rand((e - s, 64), device=dev, generator=gw) < 0.05).to(torch.int64)
+            w5[s:e] = (b * weights).sum(dim=1)
+        t0 = time.perf_counter()
+        rv = pkg.rrr_vector(w5, n_bits, device=local)
+        build = time.perf_counter() - t0
+        del w5
+        _, ms = time_steps(lambda: rv.rank(idx, 1, out), max(2, a.steps // 2), 1, barrier)
+        ex["rrr63_rank_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms, "build_s": build,
+                              "bits_per_bit": rv.device_bytes() * 8 / n_bits,
+                              "roofline_frac": ALG_BYTES["rrr"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        si = torch.randint(1, rv.ones() + 1, (nq,), device=dev, dtype=torch.int64, generator=gq)
+        _, ms = time_steps(lambda: rv.select(si, 1, out), max(2, a.steps // 2), 1, barrier)
+        ex["rrr63_select_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms,
+                                "roofline_frac": ALG_BYTES["rrr"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        assert bool((rv.rank(out[: 1 << 20].clone(), 1) == si[: 1 << 20] - 1).all())
+        del rv, si
+    if "wt" in extras or "fm" in extras:
+        torch.cuda.empty_cache()
+        nt = a.text_mib << 20
+        text = synthetic_text(nt, 1234, dev)
+        t0 = time.perf_counter()
+        csa = pkg.csa_wt(text=text, device=local)
+        build = time.perf_counter() - t0
+        wt = csa.wavelet_tree
+        lens = torch.from_numpy(wt.code_lengths().astype(np.int64)).to(dev)
+        nq2 = min(nq, 100_000_000)
+        gi = torch.randint(0, nt + 1, (nq2,), device=dev, dtype=torch.int64, generator=gq)
+        gc = text[torch.randint(0, nt, (nq2,), device=dev, generator=gq)]
+        out2 = torch.empty(nq2, dtype=torch.int64, device=dev)
+        hbar = float(lens[gc.long()].double().mean())
+        ex["text"] = {"bytes": nt, "kind": "synthetic English-like stand-in (Zipf over a 4096-word vocabulary)",
+                      "sigma": csa.sigma(), "index_build_s": build, "mean_code_length_of_queried_symbols": hbar,
+                      "wt_bits": wt.bv_size(), "index_bytes": csa.device_bytes()}
+        if "wt" in extras:
+            _, ms = time_steps(lambda: wt.rank(gi, gc, out2), max(2, a.steps // 2), 1, barrier)
+            alg = 17 + 80 * hbar
+            ex["wt_huff_rank"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2,
+                                  "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if "fm" in extras:
+            m = 20
+            st = torch.randint(0, nt - m, (nq2,), device=dev, generator=gq)
+            pats = text[(st.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()
+            _, ms = time_steps(lambda: csa.count(pats, m, out2), max(2, a.steps // 2), 1, barrier)
+            sum_l = float(lens[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
+            alg = 28 + 160 * sum_l
+            assert bool((out2 >= 1).all()), "every pattern was cut from the text"
+            ex["fm_count"] = {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "patterns": nq2, "m": m,
+                              "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if ex:
+        result["extras"] = ex
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
