@@ -5,6 +5,8 @@
 //   rank_support_v5<b>::rank            rank_support_v5.hpp:131-149
 //   select_support_mcl<b>::select       select_support_mcl.hpp:384-439
 //   bit_vector::operator[]              int_vector.hpp:1900-1904
+#include <algorithm>
+
 #include "bv_host.hpp"
 
 namespace sdslhip {
@@ -120,35 +122,58 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t * __restrict_
     }
 }
 
-// select samples: sample[j] = line that holds the BIT-argument of 0-based rank j << shift
+// select samples: sample[j] = (position of the BIT-argument of 0-based rank j << shift) >> pshift
 template <int BIT>
 __global__ __launch_bounds__(256) void k_build_sel(const uint64_t * __restrict__ lines,
                                                    const uint32_t * __restrict__ cnts, uint64_t n_bits,
-                                                   uint64_t n_lines, uint32_t shift, uint32_t * __restrict__ sample)
+                                                   uint64_t n_lines, uint32_t shift, uint32_t pshift,
+                                                   uint32_t * __restrict__ sample)
 {
     for (uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; L < n_lines;
          L += (uint64_t)gridDim.x * blockDim.x)
     {
-        uint64_t h1 = lines[L * kLW];
-        uint64_t c1 = cnts[L];
-        uint64_t h, c;
-        if (BIT)
-        {
-            h = h1;
-            c = c1;
-        }
-        else
-        {
-            uint64_t start = L * kDB;
-            uint64_t valid = n_bits - start < kDB ? n_bits - start : kDB;
-            h = start - h1;
-            c = valid - c1;
-        }
-        if (c == 0)
+        const uint64_t start = L * kDB;
+        if (start >= n_bits)
             continue;
-        uint64_t S = UINT64_C(1) << shift;
-        for (uint64_t j = (h + S - 1) >> shift; (j << shift) < h + c; ++j)
-            sample[j] = (uint32_t)L;
+        const uint64_t valid = n_bits - start < kDB ? n_bits - start : kDB;
+        const uint64_t h1 = lines[L * kLW], c1 = cnts[L];
+        const uint64_t h = BIT ? h1 : start - h1;
+        const uint64_t c = BIT ? c1 : valid - c1;
+        const uint64_t S = UINT64_C(1) << shift;
+        uint64_t j = (h + S - 1) >> shift;
+        if (c == 0 || (j << shift) >= h + c)
+            continue;
+        uint64_t w[kDW];
+#pragma unroll
+        for (int d = 0; d < kDW; ++d)
+        {
+            uint64_t x = lines[L * kLW + 1 + d];
+            if (!BIT)
+            {
+                uint64_t ws = 64ull * d;
+                uint64_t m = ws >= valid ? 0 : (valid - ws >= 64 ? ~UINT64_C(0) : lo_set((unsigned)(valid - ws)));
+                x = ~x & m;
+            }
+            w[d] = x;
+        }
+        for (; (j << shift) < h + c; ++j)
+        {
+            unsigned r = (unsigned)((j << shift) - h); // 0-based rank inside the line
+            uint64_t pos = 0;
+#pragma unroll
+            for (int d = 0; d < kDW; ++d)
+            {
+                unsigned pc = popc64(w[d]);
+                if (r < pc)
+                {
+                    pos = start + 64ull * d + sel64(w[d], r + 1);
+                    r = 0xFFFFFFFFu; // found
+                }
+                else if (r != 0xFFFFFFFFu)
+                    r -= pc;
+            }
+            sample[j] = (uint32_t)(pos >> pshift);
+        }
     }
 }
 
@@ -167,12 +192,12 @@ sdsl_hip_status build_select_dir(BvHost & bv, int bit)
     unsigned grid = grid_for(bv.view.n_lines, 256, 65536);
     if (bit)
         hipLaunchKernelGGL(k_build_sel<1>, dim3(grid), dim3(256), 0, 0, bv.view.lines, bv.cnts.as<uint32_t>(),
-                           bv.view.n_bits, bv.view.n_lines, sh, smp);
+                           bv.view.n_bits, bv.view.n_lines, sh, bv.view.sel_pshift, smp);
     else
         hipLaunchKernelGGL(k_build_sel<0>, dim3(grid), dim3(256), 0, 0, bv.view.lines, bv.cnts.as<uint32_t>(),
-                           bv.view.n_bits, bv.view.n_lines, sh, smp);
+                           bv.view.n_bits, bv.view.n_lines, sh, bv.view.sel_pshift, smp);
     SH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, 0, smp + ns, (uint32_t)(bv.view.n_lines - 1));
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, 0, smp + ns, (uint32_t)(bv.view.n_bits >> bv.view.sel_pshift));
     SH_HIP(hipGetLastError());
     bv.view.sel[bit] = smp;
     return SDSL_HIP_OK;
@@ -185,13 +210,17 @@ sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words
     bv.view = BvView{};
     bv.view.n_bits = n_bits;
     bv.view.n_lines = n_bits / kDB + 1;
-    bv.view.sel_shift = sel_shift;
-    if (bv.view.n_lines > UINT64_C(0xFFFFFFFF))
+    bv.view.n_lines += bv.view.n_lines & 1; // even: select probes aligned pairs of lines
+    if (n_bits >= (UINT64_C(1) << 40))
     {
-        set_error("bit vector of %llu bits exceeds the 2^32-line limit of the select directory",
+        set_error("bit vector of %llu bits exceeds the 2^40-bit limit of the select directory",
                   (unsigned long long)n_bits);
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
+    bv.view.sel_pshift = 0;
+    while ((n_bits >> bv.view.sel_pshift) >= UINT64_C(0xFFFFFFFF))
+        ++bv.view.sel_pshift;
+    bv.view.sel_shift = sel_shift; // 0 = choose per directory below
     const uint64_t nl = bv.view.n_lines;
     SH_TRY(bv.lines.alloc(nl * kLW * sizeof(uint64_t)));
     SH_TRY(bv.cnts.alloc(nl * sizeof(uint32_t)));
@@ -215,6 +244,17 @@ sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words
     SH_HIP(hipGetLastError());
     SH_HIP(hipMemcpy(&bv.view.ones, bsum.as<uint64_t>() + nb, sizeof(uint64_t), hipMemcpyDeviceToHost));
 
+    if (bv.view.sel_shift == 0)
+    { // one rate for both directories: at most 2^21 four-byte samples (8 MiB) per directory.  Measured
+      // on 2^34 bits (profiles/select_sweep_r01.txt): 2^12 beats both finer rates (directory falls out
+      // of L2/MALL, +1 fabric request per query) and coarser ones (interpolation misses the 128-byte
+      // window more often, and a miss stalls the whole wave)
+        uint64_t most = std::max(bv.view.ones, n_bits - bv.view.ones);
+        uint32_t sh = 9;
+        while (sh < 20 && (most >> sh) > (UINT64_C(1) << 21))
+            ++sh;
+        bv.view.sel_shift = sh;
+    }
     if (flags & SDSL_HIP_BV_SELECT1)
         SH_TRY(build_select_dir(bv, 1));
     if (flags & SDSL_HIP_BV_SELECT0)
@@ -265,29 +305,69 @@ __global__ __launch_bounds__(kBlock) void k_rank(BvView bv, int bit, const uint6
     }
 }
 
-template <int BIT, bool NT>
+// U queries per quad per round; the three dependent stages (argument, samples, window) are each issued
+// for all U queries before the first result is consumed.
+template <int BIT, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void k_select(BvView bv, const uint64_t * __restrict__ iq,
                                                    uint64_t * __restrict__ out, uint64_t n)
 {
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
     const uint64_t total = BIT ? bv.ones : bv.n_bits - bv.ones;
-    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
+    const uint32_t * __restrict__ smp = bv.sel[BIT];
+    const uint64_t stride = (uint64_t)gridDim.x * kQPB * U;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB * U; base < n; base += stride)
     {
-        uint64_t q = base + gq;
-        if (q >= n)
-            continue; // uniform over the quad
-        uint64_t i = iq[q];
-        if (i == 0 || i > total)
-        { // outside SDSL's precondition (select_support_mcl.hpp:386)
-            if (s == 0)
-                out[q] = SDSL_HIP_NPOS;
-            continue;
+        uint64_t k[U], W[U];
+        bool ok[U];
+        uint32_t s0[U], s1[U];
+        SelBracket br[U];
+        Pair wa[U], wb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            uint64_t q = base + (uint64_t)u * kQPB + gq;
+            uint64_t i = q < n ? iq[q] : 0;
+            ok[u] = i >= 1 && i <= total; // outside: SDSL's precondition (select_support_mcl.hpp:386)
+            k[u] = ok[u] ? i - 1 : 0;
         }
-        bool mine;
-        uint64_t pos = quad_select<BIT, NT>(bv, s, i - 1, mine);
-        if (mine)
-            out[q] = pos;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            uint64_t j = k[u] >> bv.sel_shift;
+            s0[u] = smp[j];
+            s1[u] = smp[j + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            br[u] = sel_bracket<BIT>(bv, k[u], s0[u], s1[u]);
+            W[u] = sel_guess(bv, br[u], k[u], 0);
+            wa[u] = load_pair<NT>(bv.lines, 2 * W[u], s);
+            wb[u] = load_pair<NT>(bv.lines, 2 * W[u] + 1, s);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            uint64_t q = base + (uint64_t)u * kQPB + gq;
+            bool mine = false;
+            uint64_t pos = 0;
+            bool found = sel_eval<BIT>(bv, s, k[u], W[u], wa[u], wb[u], br[u], mine, pos);
+            if (ok[u])
+            {
+                for (int tries = 1; !found; ++tries)
+                { // interpolation missed the window: rare, handled one probe at a time
+                    uint64_t W2 = sel_guess(bv, br[u], k[u], tries);
+                    Pair a2 = load_pair<NT>(bv.lines, 2 * W2, s);
+                    Pair b2 = load_pair<NT>(bv.lines, 2 * W2 + 1, s);
+                    found = sel_eval<BIT>(bv, s, k[u], W2, a2, b2, br[u], mine, pos);
+                }
+                if (mine)
+                    out[q] = pos;
+            }
+            else if (s == 0 && q < n)
+                out[q] = SDSL_HIP_NPOS;
+        }
     }
 }
 
@@ -358,18 +438,27 @@ sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i
         set_error("select_%d directory was not built (pass SDSL_HIP_BV_SELECT%d to sdsl_hip_bv_create)", bit, bit);
         return SDSL_HIP_ERR_INVALID;
     }
+    static const int variant = getenv("SDSL_HIP_SELECT_VARIANT") ? atoi(getenv("SDSL_HIP_SELECT_VARIANT")) : 0;
     KernelTimer t(s);
-    if (bit)
-        hipLaunchKernelGGL((k_select<1, true>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
-    else
-        hipLaunchKernelGGL((k_select<0, true>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
+#define SH_LAUNCH_SEL(B, U)                                                                                        \
+    hipLaunchKernelGGL((k_select<B, U, false>), dim3(query_grid(n, kQPB * U)), dim3(kBlock), 0, s, v, d_i, d_out, n)
+    switch (variant * 2 + (bit ? 1 : 0))
+    { // experiment knob; variant 0 is the tuned default (one query per quad per round)
+    case 2: SH_LAUNCH_SEL(0, 2); break;
+    case 3: SH_LAUNCH_SEL(1, 2); break;
+    case 4: SH_LAUNCH_SEL(0, 4); break;
+    case 5: SH_LAUNCH_SEL(1, 4); break;
+    case 1: SH_LAUNCH_SEL(1, 1); break;
+    default: SH_LAUNCH_SEL(0, 1); break;
+    }
+#undef SH_LAUNCH_SEL
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }
 
 uint32_t default_sel_shift()
 {
-    uint32_t sh = 9; // one sample per 512 arguments
+    uint32_t sh = 0; // 0 = automatic: smallest rate >= 512 that keeps a directory within 2^21 samples
     if (const char * e = getenv("SDSL_HIP_SELECT_SAMPLE_LOG2"))
     {
         int v = atoi(e);

@@ -27,10 +27,11 @@ struct BvView
 {
     const uint64_t * lines; // n_lines * kLW words
     uint64_t n_bits;
-    uint64_t n_lines;       // n_bits / kDB + 1  (always >= 1; the last line may hold 0 valid bits)
+    uint64_t n_lines;       // n_bits / kDB + 1 rounded up to even (>= 2); trailing lines hold 0 valid bits
     uint64_t ones;
-    const uint32_t * sel[2]; // sel[b][j] = line holding the b-bit of 0-based rank j<<sel_shift; +1 sentinel
+    const uint32_t * sel[2]; // sel[b][j] = (position of the b-bit of 0-based rank j<<sel_shift) >> sel_pshift; + sentinel
     uint32_t sel_shift;      // log2 of the sampling rate
+    uint32_t sel_pshift;     // position quantisation so that samples fit 32 bits (0 for n_bits < 2^32)
 };
 
 struct Pair
@@ -176,46 +177,98 @@ __device__ __forceinline__ uint64_t quad_select_in_line(Pair aw, int s, uint64_t
     return pos;
 }
 
-// Find the line holding the BIT-argument of 0-based rank k (k < total args) and select inside it.
-// All four lanes pass identical (k).  Returns the position in the lane with mine==true.
-// Search = one interpolated probe between the two surrounding samples, then capacity-bounded
-// neighbour steps, then bisection; every probe is one 64-byte line.
+// ---- select ------------------------------------------------------------------------------------
+// Directory: sel[BIT][j] = (position of the argument of rank j << sel_shift) >> sel_pshift, plus a
+// sentinel n_bits >> sel_pshift.  The probe position is interpolated between the two surrounding
+// (position, count) pairs and ONE aligned 128-byte window (two rank lines, the unit a fabric request
+// moves anyway) is fetched; the window's two headers give exact counts, so a miss tightens the bracket
+// to (window edge, exact count) and the next guess is interpolated again; every second late probe
+// bisects, which bounds the worst case at O(log n) probes.  The stages are separate functions so that
+// a kernel can keep several queries per quad in flight (the chain idx -> samples -> window is
+// latency-bound, not request-bound).
+struct SelBracket
+{ // invariant: lo_pos <= position(k) < hi_pos,  lo_cnt <= k < hi_cnt
+    uint64_t lo_pos, lo_cnt, hi_pos, hi_cnt;
+};
+
+template <int BIT>
+__device__ __forceinline__ SelBracket sel_bracket(const BvView & bv, uint64_t k, uint32_t s0, uint32_t s1)
+{
+    const uint32_t sh = bv.sel_shift, ps = bv.sel_pshift;
+    const uint64_t j = k >> sh;
+    const uint64_t total = BIT ? bv.ones : bv.n_bits - bv.ones;
+    SelBracket b;
+    b.lo_pos = (uint64_t)s0 << ps;
+    b.lo_cnt = j << sh;
+    b.hi_pos = ((uint64_t)s1 + 1) << ps;
+    b.hi_cnt = (j + 1) << sh;
+    if (b.hi_cnt > total)
+        b.hi_cnt = total;
+    return b;
+}
+
+// window (pair of lines) to probe next
+__device__ __forceinline__ uint64_t sel_guess(const BvView & bv, const SelBracket & b, uint64_t k, int tries)
+{
+    const uint64_t span = b.hi_pos - b.lo_pos, dc = b.hi_cnt - b.lo_cnt;
+    uint64_t p;
+    if (tries >= 3 && (tries & 1))
+        p = b.lo_pos + (span >> 1);
+    else if (dc == (UINT64_C(1) << bv.sel_shift))
+        p = b.lo_pos + (((k - b.lo_cnt) * span) >> bv.sel_shift); // < 2^20 * 2^40: no overflow
+    else
+        p = b.lo_pos + ((k - b.lo_cnt) * span) / (dc ? dc : 1);
+    uint64_t W = (p / kDB) >> 1;
+    const uint64_t last_win = (bv.n_lines >> 1) - 1; // n_lines is even
+    return W > last_win ? last_win : W;
+}
+
+// Evaluate window W given its two lines.  Returns true when the argument lies inside (then exactly one
+// lane has mine == true and pos); otherwise tightens the bracket.
+template <int BIT>
+__device__ __forceinline__ bool sel_eval(const BvView & bv, int s, uint64_t k, uint64_t W, Pair wa, Pair wb,
+                                         SelBracket & b, bool & mine, uint64_t & pos)
+{
+    const uint64_t LA = 2 * W, LB = LA + 1;
+    uint64_t h1a = quad_bcast0_u64(wa.a), h1b = quad_bcast0_u64(wb.a);
+    uint64_t ha = BIT ? h1a : LA * kDB - h1a; // arguments before line A
+    uint64_t hb = BIT ? h1b : LB * kDB - h1b; // ... before line B (== ha + count(A))
+    Pair awa = arg_words<BIT>(wa, s, bv.n_bits, LA);
+    Pair awb = arg_words<BIT>(wb, s, bv.n_bits, LB);
+    unsigned cb = quad_sum(popc64(awb.a) + popc64(awb.b));
+    mine = false;
+    if (k < ha)
+    {
+        b.hi_pos = LA * kDB;
+        b.hi_cnt = ha;
+        return false;
+    }
+    if (k >= hb + cb)
+    {
+        b.lo_pos = (LB + 1) * kDB;
+        b.lo_cnt = hb + cb;
+        return false;
+    }
+    const bool inB = k >= hb; // quad-uniform
+    Pair aw = inB ? awb : awa;
+    pos = quad_select_in_line(aw, s, inB ? LB : LA, (unsigned)(k - (inB ? hb : ha)), mine);
+    return true;
+}
+
+// One query per quad, probes issued one after the other (used by the wavelet-tree select cascade).
 template <int BIT, bool NT>
 __device__ __forceinline__ uint64_t quad_select(const BvView & bv, int s, uint64_t k, bool & mine)
 {
-    const uint32_t sh = bv.sel_shift;
-    const uint64_t j = k >> sh;
-    uint64_t lo = bv.sel[BIT][j], hi = bv.sel[BIT][j + 1];
-    uint64_t g = lo + (((hi - lo) * (k - (j << sh))) >> sh);
-    int tries = 0;
-    for (;;)
+    const uint64_t j = k >> bv.sel_shift;
+    SelBracket b = sel_bracket<BIT>(bv, k, bv.sel[BIT][j], bv.sel[BIT][j + 1]);
+    uint64_t pos = 0;
+    for (int tries = 0;; ++tries)
     {
-        Pair w = load_pair<NT>(bv.lines, g, s);
-        uint64_t h1 = quad_bcast0_u64(w.a);
-        uint64_t h = BIT ? h1 : g * kDB - h1; // arguments before line g
-        Pair aw = arg_words<BIT>(w, s, bv.n_bits, g);
-        unsigned c = quad_sum(popc64(aw.a) + popc64(aw.b));
-        if (k < h)
-        { // target is in an earlier line; d arguments lie in [target line, g) so it is >= ceil(d/448) lines back
-            uint64_t d = h - k;
-            hi = g - (d + kDB - 1) / kDB;
-        }
-        else if (k >= h + c)
-        {
-            uint64_t d = k - (h + c); // arguments strictly between line g and the target's
-            lo = g + 1 + d / kDB;
-        }
-        else
-        {
-            return quad_select_in_line(aw, s, g, (unsigned)(k - h), mine);
-        }
-        ++tries;
-        if (lo >= hi)
-            g = lo;
-        else if (tries <= 2)
-            g = (k < h) ? hi : lo;
-        else
-            g = lo + ((hi - lo) >> 1);
+        uint64_t W = sel_guess(bv, b, k, tries);
+        Pair wa = load_pair<NT>(bv.lines, 2 * W, s);
+        Pair wb = load_pair<NT>(bv.lines, 2 * W + 1, s);
+        if (sel_eval<BIT>(bv, s, k, W, wa, wb, b, mine, pos))
+            return pos;
     }
 }
 
