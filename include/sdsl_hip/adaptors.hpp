@@ -1,0 +1,488 @@
+// sdsl_hip/adaptors.hpp — header-only C++ adaptors that put the batched MI355X engine (sdsl_hip.h)
+// back behind SDSL's own concepts, for header-only callers of xxsds/sdsl-lite.
+//
+//   #include <sdsl/bit_vectors.hpp>          // the caller's SDSL, unchanged
+//   #include <sdsl_hip/adaptors.hpp>         // this file; link with -lsdsl_hip
+//
+//   sdsl::bit_vector bv = ...;
+//   sdsl::rank_support_v5_hip<1> rs(&bv);            // same constructor shape as rank_support_v5<1>
+//   rs(i);                                           // SDSL's scalar operator() — answered on the GPU
+//   rs.rank_batch(idx, n, out);                      // the reason to switch: one launch for n queries
+//
+// Every class mirrors the reference interface it replaces (constructor from `bit_vector const*`,
+// rank/select/operator(), size(), set_vector, serialize/load writing and reading SDSL's OWN byte
+// format, ==/!=, nested typedefs) so that it satisfies the t_rank / t_select concepts
+// (rank_support_v5.hpp:44-200, select_support_mcl.hpp:64-117, rrr_vector.hpp:455-600).
+// There is no CPU path in here: scalar members are one-element batches.  Errors surface as
+// std::runtime_error carrying sdsl_hip_last_error() (SDSL itself throws std::logic_error /
+// std::bad_alloc on its own failures, memory_management.hpp:907-910).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <sdsl/bit_vectors.hpp>
+#include <sdsl/suffix_arrays.hpp>
+#include <sdsl/wavelet_trees.hpp>
+
+#include "../sdsl_hip.h"
+
+namespace sdsl
+{
+namespace hip_detail
+{
+inline void check(sdsl_hip_status st, char const * what)
+{
+    if (st != SDSL_HIP_OK)
+        throw std::runtime_error(std::string(what) + ": " + sdsl_hip_last_error());
+}
+template <class T>
+inline std::string to_stream(T const & x)
+{
+    std::ostringstream os;
+    x.serialize(os);
+    return os.str();
+}
+struct bv_deleter
+{
+    void operator()(sdsl_hip_bv_s * p) const
+    {
+        sdsl_hip_bv_destroy(p);
+    }
+};
+typedef std::shared_ptr<sdsl_hip_bv_s> bv_ptr;
+inline bv_ptr make_device_bv(bit_vector const * v, int device, uint32_t flags)
+{
+    sdsl_hip_bv_t h = nullptr;
+    check(sdsl_hip_bv_create(v->data(), v->bit_size(), device, flags, &h), "sdsl_hip_bv_create");
+    return bv_ptr(h, bv_deleter());
+}
+} // namespace hip_detail
+
+//! Drop-in for rank_support_v5<t_b, 1> (rank_support_v5.hpp:44) with a batched member.
+template <uint8_t t_b = 1, uint8_t t_pat_len = 1>
+class rank_support_v5_hip
+{
+    static_assert(t_pat_len == 1 and (t_b == 0 or t_b == 1), "rank_support_v5_hip: patterns 0 and 1 only");
+
+public:
+    typedef bit_vector bit_vector_type;
+    typedef bit_vector::size_type size_type;
+    enum
+    {
+        bit_pat = t_b
+    };
+    enum
+    {
+        bit_pat_len = t_pat_len
+    };
+
+private:
+    bit_vector const * m_v = nullptr;
+    hip_detail::bv_ptr m_dev;
+    int m_device = 0;
+
+public:
+    explicit rank_support_v5_hip(bit_vector const * v = nullptr, int device = 0) : m_device(device)
+    {
+        set_vector(v);
+    }
+    //! Number of t_b bits in [0, idx), idx in [0, size()]   (rank_support_v5.hpp:131-149)
+    size_type rank(size_type idx) const
+    {
+        size_type r = 0;
+        rank_batch(&idx, 1, &r);
+        return r;
+    }
+    size_type operator()(size_type idx) const
+    {
+        return rank(idx);
+    }
+    //! out[q] = rank(idx[q]); host or device pointers; asynchronous on `stream` for device pointers
+    void rank_batch(size_type const * idx, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        if (!m_dev)
+            throw std::runtime_error("rank_support_v5_hip: no vector set");
+        hip_detail::check(sdsl_hip_bv_rank_batch(m_dev.get(), t_b, idx, n, out, stream), "sdsl_hip_bv_rank_batch");
+    }
+    size_type size() const
+    {
+        return m_v->size();
+    }
+    //! Writes exactly the bytes rank_support_v5<t_b>::serialize writes (rank_support_v5.hpp:160-167)
+    size_type serialize(std::ostream & out, structure_tree_node * v = nullptr, std::string name = "") const
+    {
+        rank_support_v5<t_b, t_pat_len> host(m_v);
+        return host.serialize(out, v, name);
+    }
+    //! Reads (and skips) SDSL's directory, then re-lays the supported vector on the device (:169-173)
+    void load(std::istream & in, bit_vector const * v = nullptr)
+    {
+        int_vector<64> skipped;
+        skipped.load(in);
+        set_vector(v);
+    }
+    void set_vector(bit_vector const * v = nullptr)
+    {
+        m_v = v;
+        m_dev = v ? hip_detail::make_device_bv(v, m_device, 0) : hip_detail::bv_ptr();
+    }
+    bool operator==(rank_support_v5_hip const & o) const noexcept
+    {
+        return m_v == o.m_v or (m_v and o.m_v and *m_v == *o.m_v);
+    }
+    bool operator!=(rank_support_v5_hip const & o) const noexcept
+    {
+        return !(*this == o);
+    }
+};
+
+//! Drop-in for select_support_mcl<t_b, 1> (select_support_mcl.hpp:64) with a batched member.
+template <uint8_t t_b = 1, uint8_t t_pat_len = 1>
+class select_support_mcl_hip
+{
+    static_assert(t_pat_len == 1 and (t_b == 0 or t_b == 1), "select_support_mcl_hip: patterns 0 and 1 only");
+
+public:
+    typedef bit_vector bit_vector_type;
+    typedef bit_vector::size_type size_type;
+    enum
+    {
+        bit_pat = t_b
+    };
+    enum
+    {
+        bit_pat_len = t_pat_len
+    };
+
+private:
+    bit_vector const * m_v = nullptr;
+    hip_detail::bv_ptr m_dev;
+    int m_device = 0;
+
+public:
+    explicit select_support_mcl_hip(bit_vector const * v = nullptr, int device = 0) : m_device(device)
+    {
+        set_vector(v);
+    }
+    //! Position of the i-th t_b bit, i in [1, #t_b bits]   (select_support_mcl.hpp:384-439)
+    size_type select(size_type i) const
+    {
+        size_type r = 0;
+        select_batch(&i, 1, &r);
+        return r;
+    }
+    size_type operator()(size_type i) const
+    {
+        return select(i);
+    }
+    void select_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        if (!m_dev)
+            throw std::runtime_error("select_support_mcl_hip: no vector set");
+        hip_detail::check(sdsl_hip_bv_select_batch(m_dev.get(), t_b, i, n, out, stream), "sdsl_hip_bv_select_batch");
+    }
+    size_type size() const
+    {
+        return m_v->size();
+    }
+    //! Writes exactly the bytes select_support_mcl<t_b>::serialize writes (select_support_mcl.hpp:474-518)
+    size_type serialize(std::ostream & out, structure_tree_node * v = nullptr, std::string name = "") const
+    {
+        select_support_mcl<t_b, t_pat_len> host(m_v);
+        return host.serialize(out, v, name);
+    }
+    void load(std::istream & in, bit_vector const * v = nullptr)
+    {
+        select_support_mcl<t_b, t_pat_len> skipped;
+        skipped.load(in, v);
+        set_vector(v);
+    }
+    void set_vector(bit_vector const * v = nullptr)
+    {
+        m_v = v;
+        m_dev = v ? hip_detail::make_device_bv(v, m_device, t_b ? SDSL_HIP_BV_SELECT1 : SDSL_HIP_BV_SELECT0)
+                  : hip_detail::bv_ptr();
+    }
+    bool operator==(select_support_mcl_hip const & o) const noexcept
+    {
+        return m_v == o.m_v or (m_v and o.m_v and *m_v == *o.m_v);
+    }
+    bool operator!=(select_support_mcl_hip const & o) const noexcept
+    {
+        return !(*this == o);
+    }
+};
+
+//! Device image of an rrr_vector<63> (rrr_vector.hpp:68) built from the host object's own serialised
+//! arrays; exposes the rank/select/access members of rank_support_rrr / select_support_rrr in batch form.
+class rrr_vector_hip
+{
+public:
+    typedef rrr_vector<63> host_type;
+    typedef host_type::size_type size_type;
+
+private:
+    struct deleter
+    {
+        void operator()(sdsl_hip_rrr_s * p) const
+        {
+            sdsl_hip_rrr_destroy(p);
+        }
+    };
+    std::shared_ptr<sdsl_hip_rrr_s> m_dev;
+
+public:
+    rrr_vector_hip() = default;
+    explicit rrr_vector_hip(host_type const & v, int device = 0)
+    {
+        std::string s = hip_detail::to_stream(v);
+        sdsl_hip_rrr_t h = nullptr;
+        hip_detail::check(sdsl_hip_rrr_create_from_sdsl(s.data(), s.size(), device, &h), "sdsl_hip_rrr_create_from_sdsl");
+        m_dev.reset(h, deleter());
+    }
+    explicit rrr_vector_hip(bit_vector const & bv, int device = 0)
+    {
+        sdsl_hip_rrr_t h = nullptr;
+        hip_detail::check(sdsl_hip_rrr_create(bv.data(), bv.bit_size(), device, &h), "sdsl_hip_rrr_create");
+        m_dev.reset(h, deleter());
+    }
+    size_type size() const
+    {
+        return sdsl_hip_rrr_size(m_dev.get());
+    }
+    template <uint8_t t_b>
+    void rank_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_rrr_rank_batch(m_dev.get(), t_b, i, n, out, stream), "sdsl_hip_rrr_rank_batch");
+    }
+    template <uint8_t t_b>
+    void select_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_rrr_select_batch(m_dev.get(), t_b, i, n, out, stream), "sdsl_hip_rrr_select_batch");
+    }
+    void access_batch(size_type const * i, size_t n, uint8_t * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_rrr_access_batch(m_dev.get(), i, n, out, stream), "sdsl_hip_rrr_access_batch");
+    }
+    bool operator[](size_type i) const
+    {
+        uint8_t b = 0;
+        access_batch(&i, 1, &b);
+        return b != 0;
+    }
+};
+
+//! rank_support_rrr<t_b, 63> look-alike (rrr_vector.hpp:455) over an rrr_vector_hip
+template <uint8_t t_b = 1>
+class rank_support_rrr_hip
+{
+    rrr_vector_hip const * m_v;
+
+public:
+    typedef rrr_vector_hip bit_vector_type;
+    typedef rrr_vector_hip::size_type size_type;
+    explicit rank_support_rrr_hip(rrr_vector_hip const * v = nullptr) : m_v(v)
+    {}
+    size_type rank(size_type i) const
+    {
+        size_type r = 0;
+        m_v->rank_batch<t_b>(&i, 1, &r);
+        return r;
+    }
+    size_type operator()(size_type i) const
+    {
+        return rank(i);
+    }
+    void rank_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        m_v->rank_batch<t_b>(i, n, out, stream);
+    }
+    size_type size() const
+    {
+        return m_v->size();
+    }
+    void set_vector(rrr_vector_hip const * v = nullptr)
+    {
+        m_v = v;
+    }
+};
+
+//! select_support_rrr<t_b, 63> look-alike (rrr_vector.hpp:602)
+template <uint8_t t_b = 1>
+class select_support_rrr_hip
+{
+    rrr_vector_hip const * m_v;
+
+public:
+    typedef rrr_vector_hip bit_vector_type;
+    typedef rrr_vector_hip::size_type size_type;
+    explicit select_support_rrr_hip(rrr_vector_hip const * v = nullptr) : m_v(v)
+    {}
+    size_type select(size_type i) const
+    {
+        size_type r = 0;
+        m_v->select_batch<t_b>(&i, 1, &r);
+        return r;
+    }
+    size_type operator()(size_type i) const
+    {
+        return select(i);
+    }
+    void select_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        m_v->select_batch<t_b>(i, n, out, stream);
+    }
+    size_type size() const
+    {
+        return m_v->size();
+    }
+    void set_vector(rrr_vector_hip const * v = nullptr)
+    {
+        m_v = v;
+    }
+};
+
+//! Device image of a byte wavelet tree of the wt_pc family over a plain bit_vector with
+//! rank_support_v5 (wt_huff / wt_blcd / wt_hutu share wt_pc's layout, wt_pc.hpp:53-59), built from the
+//! host object's serialised form.  t_select_is_mcl tells whether the host type serialises
+//! select_support_mcl (wt_huff<bit_vector, rank_support_v5<>>) or select_support_scan (zero bytes).
+class wt_huff_hip
+{
+public:
+    typedef uint64_t size_type;
+    typedef uint8_t value_type;
+
+private:
+    struct deleter
+    {
+        void operator()(sdsl_hip_wt_s * p) const
+        {
+            sdsl_hip_wt_destroy(p);
+        }
+    };
+    std::shared_ptr<sdsl_hip_wt_s> m_dev;
+
+public:
+    wt_huff_hip() = default;
+    template <class t_wt>
+    explicit wt_huff_hip(t_wt const & wt, bool select_is_mcl, int device = 0)
+    {
+        std::string s = hip_detail::to_stream(wt);
+        sdsl_hip_wt_t h = nullptr;
+        size_t used = 0;
+        hip_detail::check(sdsl_hip_wt_create_from_sdsl(s.data(), s.size(), select_is_mcl ? 1 : 0, device, &h, &used),
+                          "sdsl_hip_wt_create_from_sdsl");
+        m_dev.reset(h, deleter());
+    }
+    size_type size() const
+    {
+        return sdsl_hip_wt_size(m_dev.get());
+    }
+    size_type rank(size_type i, value_type c) const
+    {
+        size_type r = 0;
+        rank_batch(&i, &c, 1, &r);
+        return r;
+    }
+    //! out[q] = wt.rank(i[q], c[q])   (wt_pc.hpp:371-399)
+    void rank_batch(size_type const * i, value_type const * c, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_wt_rank_batch(m_dev.get(), i, c, n, out, stream), "sdsl_hip_wt_rank_batch");
+    }
+    void access_batch(size_type const * i, size_t n, value_type * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_wt_access_batch(m_dev.get(), i, n, out, stream), "sdsl_hip_wt_access_batch");
+    }
+    value_type operator[](size_type i) const
+    {
+        value_type c = 0;
+        access_batch(&i, 1, &c);
+        return c;
+    }
+    void select_batch(size_type const * i, value_type const * c, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_wt_select_batch(m_dev.get(), i, c, n, out, stream), "sdsl_hip_wt_select_batch");
+    }
+    size_type select(size_type i, value_type c) const
+    {
+        size_type r = 0;
+        select_batch(&i, &c, 1, &r);
+        return r;
+    }
+    std::pair<size_type, value_type> inverse_select(size_type i) const
+    {
+        size_type r = 0;
+        value_type c = 0;
+        hip_detail::check(sdsl_hip_wt_inverse_select_batch(m_dev.get(), &i, 1, &r, &c, nullptr),
+                          "sdsl_hip_wt_inverse_select_batch");
+        return std::make_pair(r, c);
+    }
+};
+
+//! Device image of a csa_wt over such a wavelet tree, restricted to backward_search / count.
+class csa_wt_hip
+{
+public:
+    typedef uint64_t size_type;
+
+private:
+    struct deleter
+    {
+        void operator()(sdsl_hip_fm_s * p) const
+        {
+            sdsl_hip_fm_destroy(p);
+        }
+    };
+    std::shared_ptr<sdsl_hip_fm_s> m_dev;
+
+public:
+    csa_wt_hip() = default;
+    template <class t_csa>
+    explicit csa_wt_hip(t_csa const & csa, bool select_is_mcl, int device = 0)
+    {
+        std::string s = hip_detail::to_stream(csa);
+        sdsl_hip_fm_t h = nullptr;
+        hip_detail::check(sdsl_hip_fm_create_from_sdsl(s.data(), s.size(), select_is_mcl ? 1 : 0, device, &h),
+                          "sdsl_hip_fm_create_from_sdsl");
+        m_dev.reset(h, deleter());
+    }
+    size_type size() const
+    {
+        return sdsl_hip_fm_size(m_dev.get());
+    }
+    sdsl_hip_fm_t handle() const
+    {
+        return m_dev.get();
+    }
+};
+
+//! sdsl::count (suffix_array_algorithm.hpp:464-471) for n fixed-length patterns
+inline void count_batch(csa_wt_hip const & csa, uint8_t const * patterns, uint32_t m, size_t n, uint64_t * out,
+                        void * stream = nullptr)
+{
+    hip_detail::check(sdsl_hip_fm_count_batch(csa.handle(), patterns, m, n, out, stream), "sdsl_hip_fm_count_batch");
+}
+//! sdsl::count for one pattern, the reference's own call shape
+template <class t_pat_iter>
+inline uint64_t count(csa_wt_hip const & csa, t_pat_iter begin, t_pat_iter end)
+{
+    std::vector<uint8_t> p(begin, end);
+    uint64_t offs[2] = {0, p.size()}, r = 0;
+    uint8_t dummy = 0;
+    hip_detail::check(sdsl_hip_fm_count_ragged(csa.handle(), p.empty() ? &dummy : p.data(), offs, 1, &r, nullptr),
+                      "sdsl_hip_fm_count_ragged");
+    return r;
+}
+//! backward_search(csa, l, r, c, l_res, r_res) (suffix_array_algorithm.hpp:167-201), batched
+inline void backward_search_batch(csa_wt_hip const & csa, uint64_t const * l, uint64_t const * r, uint8_t const * c,
+                                  size_t n, uint64_t * l_res, uint64_t * r_res, void * stream = nullptr)
+{
+    hip_detail::check(sdsl_hip_fm_backward_search_batch(csa.handle(), l, r, c, n, l_res, r_res, stream),
+                      "sdsl_hip_fm_backward_search_batch");
+}
+
+} // namespace sdsl

@@ -1,0 +1,192 @@
+// adaptor_parity.cpp — compiles the header-only adaptors (include/sdsl_hip/adaptors.hpp) against the REAL
+// sdsl-lite headers and checks, in one process, every batched answer of the HIP engine against the
+// scalar answer of the unmodified reference object it was built from.  TEST INFRASTRUCTURE: built by
+// oracle/Makefile into oracle/_ref/adaptor_parity (needs /root/reference at build time), run on the GPU
+// box by tests/test_gpu_adaptors.py.  Exit code 0 = all comparisons equal.
+#include <sdsl_hip/adaptors.hpp>
+
+#include <cstdio>
+#include <fstream>
+#include <random>
+
+using namespace sdsl;
+
+static int g_fail = 0;
+#define CHECK(cond, what)                                                                                          \
+    do {                                                                                                           \
+        if (!(cond))                                                                                               \
+        {                                                                                                          \
+            ++g_fail;                                                                                              \
+            printf("FAIL %s (%s:%d)\n", what, __FILE__, __LINE__);                                                 \
+        }                                                                                                          \
+    } while (0)
+
+template <class t_rs, class t_hip>
+static void check_rank(bit_vector const & bv, std::mt19937_64 & rng, char const * what)
+{
+    t_rs rs(&bv);
+    t_hip hs(&bv);
+    size_t n = 20000;
+    std::vector<uint64_t> idx(n), out(n);
+    for (auto & x : idx)
+        x = rng() % (bv.size() + 1);
+    idx[0] = 0;
+    idx[1] = bv.size();
+    hs.rank_batch(idx.data(), n, out.data());
+    bool ok = true;
+    for (size_t q = 0; q < n; ++q)
+        ok &= out[q] == rs(idx[q]);
+    CHECK(ok, what);
+    CHECK(hs(idx[7]) == rs(idx[7]) and hs.size() == rs.size(), "scalar operator()");
+    // serialised bytes are SDSL's own
+    std::ostringstream a, b;
+    rs.serialize(a);
+    hs.serialize(b);
+    CHECK(a.str() == b.str(), "rank serialize bytes");
+    std::istringstream in(a.str());
+    t_hip loaded;
+    loaded.load(in, &bv);
+    CHECK(loaded(idx[5]) == rs(idx[5]), "rank load");
+}
+
+template <class t_ss, class t_hip>
+static void check_select(bit_vector const & bv, uint64_t args, std::mt19937_64 & rng, char const * what)
+{
+    if (!args)
+        return;
+    t_ss ss(&bv);
+    t_hip hs(&bv);
+    size_t n = 20000;
+    std::vector<uint64_t> i(n), out(n);
+    for (auto & x : i)
+        x = 1 + rng() % args;
+    i[0] = 1;
+    i[1] = args;
+    hs.select_batch(i.data(), n, out.data());
+    bool ok = true;
+    for (size_t q = 0; q < n; ++q)
+        ok &= out[q] == ss(i[q]);
+    CHECK(ok, what);
+    std::ostringstream a, b;
+    ss.serialize(a);
+    hs.serialize(b);
+    CHECK(a.str() == b.str(), "select serialize bytes");
+}
+
+int main(int argc, char ** argv)
+{
+    std::mt19937_64 rng(4242);
+    for (uint64_t n : {1000ull, 100000ull, 1000003ull})
+        for (int dens : {50, 3, 97})
+        {
+            bit_vector bv(n, 0);
+            for (uint64_t i = 0; i < n; ++i)
+                bv[i] = (rng() % 100) < (uint64_t)dens;
+            uint64_t ones = util::cnt_one_bits(bv);
+            check_rank<rank_support_v5<1>, rank_support_v5_hip<1>>(bv, rng, "rank_support_v5<1>");
+            check_rank<rank_support_v5<0>, rank_support_v5_hip<0>>(bv, rng, "rank_support_v5<0>");
+            check_select<select_support_mcl<1>, select_support_mcl_hip<1>>(bv, ones, rng, "select_support_mcl<1>");
+            check_select<select_support_mcl<0>, select_support_mcl_hip<0>>(bv, n - ones, rng, "select_support_mcl<0>");
+            // rrr_vector<63>
+            rrr_vector<63> rv(bv);
+            rrr_vector<63>::rank_1_type r1(&rv);
+            rrr_vector<63>::select_1_type s1(&rv);
+            rrr_vector<63>::select_0_type s0(&rv);
+            rrr_vector_hip dv(rv), dv2(bv);
+            rank_support_rrr_hip<1> hr1(&dv);
+            select_support_rrr_hip<1> hs1(&dv2);
+            select_support_rrr_hip<0> hs0(&dv);
+            size_t q = 5000;
+            std::vector<uint64_t> a(q), o(q);
+            for (auto & x : a)
+                x = rng() % (n + 1);
+            hr1.rank_batch(a.data(), q, o.data());
+            bool ok = true;
+            for (size_t k = 0; k < q; ++k)
+                ok &= o[k] == r1(a[k]);
+            CHECK(ok, "rank_support_rrr<1,63>");
+            for (auto & x : a)
+                x = 1 + rng() % (ones + 1); // includes the overflow value ones+1 -> size()
+            hs1.select_batch(a.data(), q, o.data());
+            ok = true;
+            for (size_t k = 0; k < q; ++k)
+                ok &= o[k] == s1(a[k]);
+            CHECK(ok, "select_support_rrr<1,63>");
+            for (auto & x : a)
+                x = 1 + rng() % (n - ones + 1);
+            hs0.select_batch(a.data(), q, o.data());
+            ok = true;
+            for (size_t k = 0; k < q; ++k)
+                ok &= o[k] == s0(a[k]);
+            CHECK(ok, "select_support_rrr<0,63>");
+            CHECK(dv[n / 2] == rv[n / 2], "rrr operator[]");
+        }
+    // wavelet tree + FM-index over a text file (argv[1]) or a built-in sample
+    std::string text;
+    if (argc > 1)
+    {
+        std::ifstream f(argv[1], std::ios::binary);
+        text.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    }
+    if (text.empty())
+        for (int i = 0; i < 3000; ++i)
+            text += "she sells sea shells by the sea shore; ";
+    typedef wt_huff<bit_vector, rank_support_v5<>> wt_t;
+    typedef csa_wt<wt_t> csa_t;
+    typedef csa_wt<wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>, 1 << 20, 1 << 20>
+        fm_huff_t; // benchmark/indexing_count/index.config:8
+    {
+        std::vector<uint8_t> bytes(text.begin(), text.end());
+        wt_t wt(bytes.begin(), bytes.end());
+        wt_huff_hip dw(wt, true);
+        size_t q = 20000;
+        std::vector<uint64_t> i(q), o(q);
+        std::vector<uint8_t> c(q);
+        for (size_t k = 0; k < q; ++k)
+        {
+            i[k] = rng() % (bytes.size() + 1);
+            c[k] = (k & 3) ? bytes[rng() % bytes.size()] : (uint8_t)(rng() & 0xFF);
+        }
+        dw.rank_batch(i.data(), c.data(), q, o.data());
+        bool ok = true;
+        for (size_t k = 0; k < q; ++k)
+            ok &= o[k] == wt.rank(i[k], c[k]);
+        CHECK(ok, "wt_huff::rank");
+        uint64_t p = bytes.size() / 3;
+        CHECK(dw[p] == wt[p] and dw.inverse_select(p) == wt.inverse_select(p), "wt_huff::operator[] / inverse_select");
+        CHECK(dw.select(1, bytes[p]) == wt.select(1, bytes[p]), "wt_huff::select");
+    }
+    {
+        csa_t csa;
+        construct_im(csa, text, 1);
+        fm_huff_t fm;
+        construct_im(fm, text, 1);
+        csa_wt_hip d1(csa, true), d2(fm, false);
+        size_t q = 5000;
+        uint32_t m = 20;
+        std::vector<uint8_t> pats(q * m);
+        for (size_t k = 0; k < q; ++k)
+        {
+            size_t st = rng() % (text.size() - m);
+            for (uint32_t j = 0; j < m; ++j)
+                pats[k * m + j] = (uint8_t)text[st + j];
+            if (k % 7 == 0)
+                pats[k * m + (rng() % m)] ^= 0x55; // some misses
+        }
+        std::vector<uint64_t> o1(q), o2(q);
+        count_batch(d1, pats.data(), m, q, o1.data());
+        count_batch(d2, pats.data(), m, q, o2.data());
+        bool ok = true;
+        for (size_t k = 0; k < q; ++k)
+        {
+            uint64_t ref = count(csa, pats.begin() + k * m, pats.begin() + (k + 1) * m);
+            ok &= o1[k] == ref and o2[k] == ref;
+        }
+        CHECK(ok, "count(csa_wt)");
+        std::string und = "sea";
+        CHECK(count(d1, und.begin(), und.end()) == count(csa, und.begin(), und.end()), "count single");
+        CHECK(d1.size() == csa.size(), "csa size");
+    }
+    printf(g_fail ? "adaptor parity: %d FAILED\n" : "adaptor parity: all equal\n", g_fail);
+    return g_fail ? 1 : 0;
+}

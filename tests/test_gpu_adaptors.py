@@ -1,0 +1,22 @@
+"""GPU: the header-only C++ adaptors (include/sdsl_hip/adaptors.hpp) compiled against the REAL sdsl-lite
+and linked with libsdsl_hip.so — every batched answer against the scalar answer of the unmodified
+reference object, plus SDSL's own serialise/load round trip through the adaptors."""
+import os
+import subprocess
+
+import pytest
+
+import golden_data as gd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "adaptor_parity")
+
+
+def test_adaptors_against_real_sdsl(gpu):
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/adaptor_parity not built (needs the reference tree at build time)")
+    r = subprocess.run([EXE, os.path.join(gd.GOLDEN, "texts", "faust.txt")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all equal" in r.stdout
