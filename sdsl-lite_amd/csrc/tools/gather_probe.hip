@@ -142,7 +142,14 @@ static int sweep(int argc, char ** argv)
             max_bytes = strtoull(argv[i], 0, 10) << 20;
     v2u64 * table;
     uint64_t *idx, *out;
-    CK(hipMalloc(&table, max_bytes));
+    const char * mode = getenv("PROBE_ALLOC");
+    if (mode && !strcmp(mode, "uncached"))
+        CK(hipExtMallocWithFlags((void **)&table, max_bytes, hipDeviceMallocUncached));
+    else if (mode && !strcmp(mode, "finegrained"))
+        CK(hipExtMallocWithFlags((void **)&table, max_bytes, hipDeviceMallocFinegrained));
+    else
+        CK(hipMalloc(&table, max_bytes));
+    printf("alloc mode: %s\n", mode ? mode : "default");
     CK(hipMalloc(&idx, nq * 8));
     CK(hipMalloc(&out, nq * 8));
     hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint64_t *)table, max_bytes / 8);
