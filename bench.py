@@ -137,14 +137,18 @@ def synthetic_text(n_bytes, seed, device):
     zipf = torch.arange(1, vocab_n + 1, dtype=torch.float64).pow(-1.0)
     cdf = torch.cumsum(zipf / zipf.sum(), 0).to(device)
     gd = torch.Generator(device=device).manual_seed(seed)
-    n_words = int(n_bytes / 5.5) + 1024
-    u = torch.rand(n_words, device=device, dtype=torch.float64, generator=gd)
-    ids = torch.searchsorted(cdf, u).clamp_(max=vocab_n - 1)
-    del u
-    flat = vocab.to(device)[ids].reshape(-1)
-    flat = flat[flat != 0][:n_bytes]
-    assert flat.numel() == n_bytes, "increase n_words"
-    return flat.contiguous()
+    vocab_d = vocab.to(device)
+    out = torch.empty(n_bytes, dtype=torch.uint8, device=device)
+    filled, chunk_words = 0, 1 << 24  # chunked: boolean compaction of > 2^31 elements is not safe in torch
+    while filled < n_bytes:
+        u = torch.rand(chunk_words, device=device, dtype=torch.float64, generator=gd)
+        ids = torch.searchsorted(cdf, u).clamp_(max=vocab_n - 1)
+        piece = vocab_d[ids].reshape(-1)
+        piece = piece[piece != 0]
+        take = min(piece.numel(), n_bytes - filled)
+        out[filled:filled + take] = piece[:take]
+        filled += take
+    return out
 
 
 def main():

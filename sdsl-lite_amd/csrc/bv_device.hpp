@@ -207,17 +207,28 @@ __device__ __forceinline__ SelBracket sel_bracket(const BvView & bv, uint64_t k,
     return b;
 }
 
+// position estimate inside a bracket: lo_pos + (k - lo_cnt) / (hi_cnt - lo_cnt) * span.  Only a probe hint
+// (exact header counts decide), so a float quotient replaces the 64-bit division; the first probe of a query
+// has a power-of-two denominator and stays exact.
+__device__ __forceinline__ uint64_t sel_interpolate(uint64_t lo_pos, uint64_t span, uint64_t num, uint64_t den,
+                                                    uint32_t first_shift)
+{
+    if (den == (UINT64_C(1) << first_shift))
+        return lo_pos + ((num * span) >> first_shift); // num < 2^20, span < 2^40: no overflow
+    float f = __fdividef((float)num, (float)(den ? den : 1));
+    uint64_t off = (uint64_t)(f * (float)span);
+    return lo_pos + (off >= span ? span - 1 : off);
+}
+
 // window (pair of lines) to probe next
 __device__ __forceinline__ uint64_t sel_guess(const BvView & bv, const SelBracket & b, uint64_t k, int tries)
 {
-    const uint64_t span = b.hi_pos - b.lo_pos, dc = b.hi_cnt - b.lo_cnt;
+    const uint64_t span = b.hi_pos - b.lo_pos;
     uint64_t p;
     if (tries >= 3 && (tries & 1))
         p = b.lo_pos + (span >> 1);
-    else if (dc == (UINT64_C(1) << bv.sel_shift))
-        p = b.lo_pos + (((k - b.lo_cnt) * span) >> bv.sel_shift); // < 2^20 * 2^40: no overflow
     else
-        p = b.lo_pos + ((k - b.lo_cnt) * span) / (dc ? dc : 1);
+        p = sel_interpolate(b.lo_pos, span, k - b.lo_cnt, b.hi_cnt - b.lo_cnt, bv.sel_shift);
     uint64_t W = (p / kDB) >> 1;
     const uint64_t last_win = (bv.n_lines >> 1) - 1; // n_lines is even
     return W > last_win ? last_win : W;

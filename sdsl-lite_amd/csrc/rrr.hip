@@ -48,9 +48,10 @@ struct RrrView
     const uint64_t * rec;    // n_sb * 16 words
     const uint64_t * stream; // offset stream (SDSL's m_btnr), padded by one word
     const RrrTables * tables;
-    const uint32_t * sel[2]; // select sample directories (superblock of the j<<shift-th argument) + sentinel
+    const uint32_t * sel[2]; // select directories: (position of the j<<shift-th argument) >> pshift, + sentinel
     uint64_t n_bits, n_blocks, n_sb, ones;
-    uint32_t sel_shift;
+    uint32_t sel_shift;  // log2 of the select sampling rate
+    uint32_t sel_pshift; // position quantisation of the samples (0 for n_bits < 2^32)
 };
 
 // ---- host: tables + encoder --------------------------------------------------------------------
@@ -346,6 +347,58 @@ __device__ __forceinline__ unsigned rrr_lane_prefix(const RrrTables * T, uint64_
     return acc;
 }
 
+// value of quad lane U in all four lanes (U is a compile-time constant: DPP quad_perm:[U,U,U,U])
+template <int U>
+__device__ __forceinline__ unsigned quad_bcast_lane(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, U * 0x55, 0xF, 0xF, true);
+}
+template <int U>
+__device__ __forceinline__ uint64_t quad_bcast_lane_u64(uint64_t v)
+{
+    unsigned lo = quad_bcast_lane<U>((unsigned)v), hi = quad_bcast_lane<U>((unsigned)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// sum of the eight bytes of x (each <= 63)
+__device__ __forceinline__ unsigned sum_bytes8(uint64_t x)
+{
+    uint64_t t = (x & UINT64_C(0x00FF00FF00FF00FF)) + ((x >> 8) & UINT64_C(0x00FF00FF00FF00FF));
+    return (unsigned)((t * UINT64_C(0x0001000100010001)) >> 48);
+}
+
+// What the lane-parallel phase needs to finish one rank/access query.
+struct RankTail
+{
+    uint64_t rank; // ones before the block
+    uint64_t nr;   // the block's offset
+    unsigned k, off;
+};
+
+// Cooperative half of rank(i): the quad fetches the superblock record of i (one 128-byte line), sums the
+// class bytes below the block (8 per lane, DPP reduction) and fetches the block's offset field.
+__device__ __forceinline__ RankTail rrr_rank_head(const RrrView & v, const RrrTables * T, int s, uint64_t i)
+{
+    uint64_t blk = i / kRrrBS;
+    RankTail t;
+    t.off = (unsigned)(i - blk * kRrrBS);
+    uint64_t sb = blk / kRrrK;
+    unsigned j = (unsigned)(blk % kRrrK);
+    const uint64_t * r = v.rec + sb * kRecWords;
+    uint64_t r0 = r[0], r1 = r[1];
+    uint64_t cls8 = r[2 + s];
+    uint64_t clsj = r[2 + (j >> 3)];
+    unsigned tot = quad_sum(rrr_lane_prefix(T, cls8, s, j));
+    t.rank = r0 + (tot & 0xFFFF);
+    t.k = (unsigned)(clsj >> (8 * (j & 7))) & 0xFF;
+    t.nr = rrr_field(v, r, r1 & ((UINT64_C(1) << 48) - 1), tot >> 16, T->space[t.k]);
+    return t;
+}
+
+// rank / access.  Four queries per quad per round: the cooperative half runs once per query with all four
+// lanes (sub-round U serves the query owned by lane U), the expensive half — decoding the 63-bit block — runs
+// ONCE with every lane decoding its own query, i.e. 64 different blocks per wave instead of 16 blocks four
+// times over.
 template <int MODE> // 0: rank, 1: access
 __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, const uint64_t * __restrict__ iq,
                                                         uint64_t * __restrict__ out, uint8_t * __restrict__ out8,
@@ -354,54 +407,161 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, cons
     __shared__ RrrTables T;
     rrr_stage_tables(&T, v.tables);
     const int s = threadIdx.x & 3;
-    const unsigned gq = threadIdx.x >> 2;
-    constexpr unsigned QPB = kRrrBlock / 4;
-    for (uint64_t base = (uint64_t)blockIdx.x * QPB; base < n; base += (uint64_t)gridDim.x * QPB)
+    for (uint64_t base = (uint64_t)blockIdx.x * kRrrBlock; base < n; base += (uint64_t)gridDim.x * kRrrBlock)
     {
-        uint64_t q = base + gq;
-        if (q >= n)
-            continue;
-        uint64_t i = iq[q];
-        const bool ok = MODE == 0 ? i <= v.n_bits : i < v.n_bits;
-        uint64_t res = SDSL_HIP_NPOS;
-        if (ok)
-        {
-            uint64_t blk = i / kRrrBS;
-            unsigned off = (unsigned)(i - blk * kRrrBS);
-            uint64_t sb = blk / kRrrK;
-            unsigned j = (unsigned)(blk % kRrrK);
-            const uint64_t * r = v.rec + sb * kRecWords;
-            uint64_t rank = r[0];
-            uint64_t ptr = r[1] & ((UINT64_C(1) << 48) - 1);
-            uint64_t cls8 = r[2 + s];
-            unsigned tot = quad_sum(rrr_lane_prefix(&T, cls8, s, j));
-            rank += tot & 0xFFFF;
-            unsigned rel = tot >> 16;
-            unsigned pop = 0, thebit = 0;
-            if (off != 0 || MODE == 1)
-            {
-                unsigned k = (unsigned)(r[2 + (j >> 3)] >> (8 * (j & 7))) & 0xFF;
-                unsigned len = T.space[k];
-                uint64_t nr = rrr_field(v, r, ptr, rel, len);
-                uint64_t bits = rrr_decode_block(&T, k, nr);
-                pop = popc64(bits & lo_set(off));
-                thebit = (unsigned)(bits >> off) & 1;
-            }
-            res = MODE == 1 ? thebit : (bit ? rank + pop : i - (rank + pop));
-        }
-        if (s == 0)
+        const uint64_t q = base + threadIdx.x;
+        const uint64_t i_mine = q < n ? iq[q] : 0;
+        const bool ok_mine = MODE == 0 ? i_mine <= v.n_bits : i_mine < v.n_bits;
+        const uint64_t i_safe = ok_mine ? i_mine : 0;
+        RankTail mine, t;
+        t = rrr_rank_head(v, &T, s, quad_bcast_lane_u64<0>(i_safe));
+        mine = t;
+        t = rrr_rank_head(v, &T, s, quad_bcast_lane_u64<1>(i_safe));
+        if (s == 1)
+            mine = t;
+        t = rrr_rank_head(v, &T, s, quad_bcast_lane_u64<2>(i_safe));
+        if (s == 2)
+            mine = t;
+        t = rrr_rank_head(v, &T, s, quad_bcast_lane_u64<3>(i_safe));
+        if (s == 3)
+            mine = t;
+        // lane-parallel half
+        uint64_t bits = rrr_decode_block(&T, mine.k, mine.nr);
+        if (q < n)
         {
             if (MODE == 1)
-                out8[q] = ok ? (uint8_t)res : 0xFF;
+                out8[q] = ok_mine ? (uint8_t)((bits >> mine.off) & 1) : 0xFF;
             else
-                out[q] = res;
+            {
+                uint64_t r1 = mine.rank + popc64(bits & lo_set(mine.off));
+                out[q] = ok_mine ? (bit ? r1 : i_mine - r1) : SDSL_HIP_NPOS;
+            }
         }
     }
 }
 
-// select: superblock search over the record headers (interpolated probe between two samples, then
-// capacity-bounded steps, then bisection — the same scheme as bv_device.hpp quad_select), then the
-// block inside the superblock from the class bytes, then in-block select on the decoded block.
+// What the lane-parallel phase needs to finish one select query.
+struct SelTail
+{
+    const uint64_t * r; // superblock record
+    uint64_t bstart;    // first bit of the block
+    unsigned k, blen, rel, want; // class, valid bits, offset position in the superblock's stream, 0-based rank in block
+};
+
+// Cooperative half of select: superblock search over the record headers (directory of argument POSITIONS,
+// interpolated probe, exact counts from the probed header, bisection every second late probe — the scheme of
+// bv_device.hpp) and block location from the class bytes.  All four lanes return the same tail.
+template <int BIT>
+__device__ __forceinline__ SelTail rrr_select_head(const RrrView & v, const RrrTables * T, int s, uint64_t k0)
+{
+    const uint64_t total = BIT ? v.ones : v.n_bits - v.ones;
+    const uint32_t sh = v.sel_shift, ps = v.sel_pshift;
+    const uint64_t j = k0 >> sh;
+    uint64_t lo_pos = (uint64_t)v.sel[BIT][j] << ps, lo_cnt = j << sh;
+    uint64_t hi_pos = ((uint64_t)v.sel[BIT][j + 1] + 1) << ps, hi_cnt = (j + 1) << sh;
+    if (hi_cnt > total)
+        hi_cnt = total;
+    const uint64_t * r;
+    uint64_t g, before, cls8, r1;
+    for (int tries = 0;; ++tries)
+    { // invariant: lo_pos <= position(k0) < hi_pos, lo_cnt <= k0 < hi_cnt
+        uint64_t span = hi_pos - lo_pos, p;
+        if (tries >= 3 && (tries & 1))
+            p = lo_pos + (span >> 1);
+        else
+            p = sel_interpolate(lo_pos, span, k0 - lo_cnt, hi_cnt - lo_cnt, sh);
+        g = p / kRrrSB;
+        if (g >= v.n_sb)
+            g = v.n_sb - 1;
+        r = v.rec + g * kRecWords;
+        uint64_t r0 = r[0];
+        r1 = r[1];
+        cls8 = r[2 + s]; // same line: free, and needed as soon as the probe hits
+        uint64_t ones_in = (r1 >> 48) & 0xFFF;
+        uint64_t start = g * kRrrSB;
+        uint64_t len_in = v.n_bits - start < kRrrSB ? v.n_bits - start : kRrrSB;
+        before = BIT ? r0 : start - r0;
+        uint64_t c = BIT ? ones_in : len_in - ones_in;
+        if (k0 < before)
+        {
+            hi_pos = start;
+            hi_cnt = before;
+        }
+        else if (k0 >= before + c)
+        {
+            lo_pos = start + kRrrSB;
+            lo_cnt = before + c;
+        }
+        else
+            break;
+    }
+    // inside superblock g: lane s owns classes [8s, 8s+8)
+    const unsigned want = (unsigned)(k0 - before);
+    const uint64_t b0 = g * kRrrK + 8 * (uint64_t)s;
+    const bool full = (b0 + 8) * kRrrBS <= v.n_bits; // all eight blocks are complete 63-bit blocks
+    unsigned my_args;
+    if (BIT)
+        my_args = sum_bytes8(cls8);
+    else if (full)
+        my_args = sum_bytes8(UINT64_C(0x3F3F3F3F3F3F3F3F) - cls8);
+    else
+    {
+        my_args = 0;
+        for (int t = 0; t < 8; ++t)
+        {
+            uint64_t bstart = (b0 + t) * kRrrBS;
+            unsigned blen = bstart >= v.n_bits ? 0u : (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS);
+            my_args += blen - ((unsigned)(cls8 >> (8 * t)) & 0xFF);
+        }
+    }
+    unsigned my_bits = 0;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        my_bits += T->space[(unsigned)(cls8 >> (8 * t)) & 0xFF];
+    unsigned ex = quad_excl(my_args | (my_bits << 16), s);
+    unsigned acc = ex & 0xFFFF, rel = ex >> 16;
+    const bool owner = want >= acc && want < acc + my_args;
+    // the owner lane walks its eight classes; packed = block-in-lane | k<<8 | blen<<16 | (want-acc)<<24, rel
+    unsigned kk = 0, bl = 0, tt = 0;
+    bool done = !owner;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+    {
+        unsigned k = (unsigned)(cls8 >> (8 * t)) & 0xFF;
+        uint64_t bstart = (b0 + t) * kRrrBS;
+        unsigned blen =
+            full ? kRrrBS : (bstart >= v.n_bits ? 0u : (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS));
+        unsigned a = BIT ? k : blen - k;
+        bool here = !done && want < acc + a;
+        bool skip = !done && !here;
+        if (here)
+        {
+            kk = k;
+            bl = blen;
+            tt = (unsigned)t + 8u * (unsigned)s;
+            done = true;
+        }
+        if (skip)
+        {
+            acc += a;
+            rel += T->space[k];
+        }
+    }
+    // hand the owner's findings to the whole quad (exactly one lane contributes non-zero values)
+    unsigned p0 = owner ? (tt | (kk << 8) | (bl << 16) | ((want - acc) << 24)) : 0u;
+    unsigned p1 = owner ? rel : 0u;
+    p0 = quad_sum(p0);
+    p1 = quad_sum(p1);
+    SelTail t;
+    t.r = r;
+    t.bstart = (g * kRrrK + (p0 & 0xFF)) * kRrrBS;
+    t.k = (p0 >> 8) & 0xFF;
+    t.blen = (p0 >> 16) & 0xFF;
+    t.want = p0 >> 24;
+    t.rel = p1;
+    return t;
+}
+
 template <int BIT>
 __global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint64_t * __restrict__ iq,
                                                           uint64_t * __restrict__ out, uint64_t n)
@@ -409,102 +569,43 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint6
     __shared__ RrrTables T;
     rrr_stage_tables(&T, v.tables);
     const int s = threadIdx.x & 3;
-    const unsigned gq = threadIdx.x >> 2;
-    constexpr unsigned QPB = kRrrBlock / 4;
     const uint64_t total = BIT ? v.ones : v.n_bits - v.ones;
-    for (uint64_t base = (uint64_t)blockIdx.x * QPB; base < n; base += (uint64_t)gridDim.x * QPB)
+    for (uint64_t base = (uint64_t)blockIdx.x * kRrrBlock; base < n; base += (uint64_t)gridDim.x * kRrrBlock)
     {
-        uint64_t q = base + gq;
+        const uint64_t q = base + threadIdx.x;
+        const uint64_t i_mine = q < n ? iq[q] : 0;
+        const bool ok_mine = i_mine >= 1 && i_mine <= total;
+        // out-of-domain arguments ride along as rank 0 (if there is any argument at all) and are overwritten below
+        const uint64_t k_safe = ok_mine ? i_mine - 1 : 0;
+        SelTail mine, t;
+        if (total != 0)
+        { // block-uniform
+            t = rrr_select_head<BIT>(v, &T, s, quad_bcast_lane_u64<0>(k_safe));
+            mine = t;
+            t = rrr_select_head<BIT>(v, &T, s, quad_bcast_lane_u64<1>(k_safe));
+            if (s == 1)
+                mine = t;
+            t = rrr_select_head<BIT>(v, &T, s, quad_bcast_lane_u64<2>(k_safe));
+            if (s == 2)
+                mine = t;
+            t = rrr_select_head<BIT>(v, &T, s, quad_bcast_lane_u64<3>(k_safe));
+            if (s == 3)
+                mine = t;
+        }
         if (q >= n)
             continue;
-        uint64_t i = iq[q];
-        if (i == 0 || i > total)
+        if (!ok_mine)
         { // i > #args: SDSL returns size() (rrr_vector.hpp:641-642, 686-689); i == 0 is outside its domain
-            if (s == 0)
-                out[q] = i == 0 ? SDSL_HIP_NPOS : v.n_bits;
+            out[q] = i_mine == 0 ? SDSL_HIP_NPOS : v.n_bits;
             continue;
         }
-        const uint64_t k0 = i - 1; // 0-based rank of the wanted argument
-        const uint32_t sh = v.sel_shift;
-        uint64_t lo = v.sel[BIT][k0 >> sh], hi = v.sel[BIT][(k0 >> sh) + 1];
-        uint64_t g = lo + (((hi - lo) * (k0 - ((k0 >> sh) << sh))) >> sh);
-        const uint64_t * r;
-        uint64_t before; // arguments before superblock g
-        int tries = 0;
-        for (;;)
-        {
-            r = v.rec + g * kRecWords;
-            uint64_t r0 = r[0], r1 = r[1];
-            uint64_t ones_in = (r1 >> 48) & 0xFFF;
-            uint64_t start = g * kRrrSB;
-            uint64_t len_in = v.n_bits - start < kRrrSB ? v.n_bits - start : kRrrSB;
-            before = BIT ? r0 : start - r0;
-            uint64_t c = BIT ? ones_in : len_in - ones_in;
-            if (k0 < before)
-            {
-                uint64_t d = before - k0;
-                hi = g - (d + kRrrSB - 1) / kRrrSB;
-            }
-            else if (k0 >= before + c)
-            {
-                uint64_t d = k0 - (before + c);
-                lo = g + 1 + d / kRrrSB;
-            }
-            else
-                break;
-            ++tries;
-            if (lo >= hi)
-                g = lo;
-            else if (tries <= 2)
-                g = (k0 < before) ? hi : lo;
-            else
-                g = lo + ((hi - lo) >> 1);
-        }
-        // inside superblock g: lane s owns classes [8s, 8s+8)
-        unsigned want = (unsigned)(k0 - before); // 0-based among the superblock's arguments
-        uint64_t ptr = r[1] & ((UINT64_C(1) << 48) - 1);
-        uint64_t cls8 = r[2 + s];
-        unsigned my_args = 0, my_bits = 0;
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-        {
-            unsigned k = (unsigned)(cls8 >> (8 * t)) & 0xFF;
-            uint64_t b = g * kRrrK + 8 * s + t;
-            uint64_t bstart = b * kRrrBS;
-            unsigned blen = bstart >= v.n_bits ? 0u : (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS);
-            my_args += BIT ? k : blen - k;
-            my_bits += T.space[k];
-        }
-        unsigned ex = quad_excl(my_args | (my_bits << 16), s);
-        unsigned ex_args = ex & 0xFFFF, ex_bits = ex >> 16;
-        bool mine = want >= ex_args && want < ex_args + my_args;
-        if (mine)
-        {
-            unsigned acc = ex_args, rel = ex_bits;
-            uint64_t pos = 0;
-            for (int t = 0; t < 8; ++t)
-            {
-                unsigned k = (unsigned)(cls8 >> (8 * t)) & 0xFF;
-                uint64_t b = g * kRrrK + 8 * s + t;
-                uint64_t bstart = b * kRrrBS;
-                unsigned blen =
-                    bstart >= v.n_bits ? 0u : (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS);
-                unsigned a = BIT ? k : blen - k;
-                unsigned len = T.space[k];
-                if (want < acc + a)
-                {
-                    uint64_t nr = rrr_field(v, r, ptr, rel, len);
-                    uint64_t bits = rrr_decode_block(&T, k, nr);
-                    if (!BIT)
-                        bits = ~bits & lo_set(blen);
-                    pos = bstart + sel64(bits, want - acc + 1);
-                    break;
-                }
-                acc += a;
-                rel += len;
-            }
-            out[q] = pos;
-        }
+        // lane-parallel half: every lane finishes its own query
+        uint64_t ptr = mine.r[1] & ((UINT64_C(1) << 48) - 1);
+        uint64_t nr = rrr_field(v, mine.r, ptr, mine.rel, T.space[mine.k]);
+        uint64_t bits = rrr_decode_block(&T, mine.k, nr);
+        if (!BIT)
+            bits = ~bits & lo_set(mine.blen);
+        out[q] = mine.bstart + sel64(bits, mine.want + 1);
     }
 }
 
@@ -519,9 +620,25 @@ struct RrrHost
     }
 };
 
-static uint32_t rrr_sel_shift()
+// host mirror of rrr_decode_block (used only to place the select samples)
+static uint64_t decode_block_host(const RrrTables & T, unsigned k, uint64_t nr)
 {
-    return 12; // one sample per 4096 arguments (~2 superblocks at density 1); tiny directory
+    if (k == 0)
+        return 0;
+    if (k == kRrrBS)
+        return lo_set(kRrrBS);
+    uint64_t bits = 0;
+    for (int m = 62; m >= 0 && k > 0; --m)
+    {
+        uint64_t c = T.binom[m][k];
+        if (nr >= c)
+        {
+            nr -= c;
+            --k;
+            bits |= UINT64_C(1) << (62 - m);
+        }
+    }
+    return bits;
 }
 
 static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
@@ -534,38 +651,84 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
     std::vector<uint64_t> rec((size_t)A.n_sb * kRecWords, 0);
-    const uint32_t sh = rrr_sel_shift();
     const uint64_t zeros = A.n_bits - A.ones;
-    std::vector<uint32_t> sel1(((A.ones + (UINT64_C(1) << sh) - 1) >> sh) + 2, 0);
-    std::vector<uint32_t> sel0(((zeros + (UINT64_C(1) << sh) - 1) >> sh) + 2, 0);
-    for (uint64_t s = 0; s < A.n_sb; ++s)
+    // sampling rate: smallest power of two >= 256 that keeps a directory within 2^21 samples
+    uint32_t sh = 8;
+    while (sh < 20 && (std::max(A.ones, zeros) >> sh) > (UINT64_C(1) << 21))
+        ++sh;
+    uint32_t ps = 0;
+    while ((A.n_bits >> ps) >= UINT64_C(0xFFFFFFFF))
+        ++ps;
+    const uint64_t S = UINT64_C(1) << sh;
+    const uint64_t ns1 = (A.ones + S - 1) >> sh, ns0 = (zeros + S - 1) >> sh;
+    std::vector<uint32_t> sel1(ns1 + 2, 0), sel0(ns0 + 2, 0);
+    auto fill = [&](uint64_t s0, uint64_t s1)
     {
-        uint64_t * r = &rec[(size_t)s * kRecWords];
-        uint64_t ones_in = A.sb_rank[s + 1] - A.sb_rank[s];
-        r[0] = A.sb_rank[s];
-        r[1] = A.sb_ptr[s] | (ones_in << 48);
-        memcpy(r + 2, &A.cls[(size_t)s * kRrrK], kRrrK);
-        uint64_t avail = A.sb_ptr[s + 1] - A.sb_ptr[s];
-        if (avail > kInlineBits)
-            avail = kInlineBits;
-        for (unsigned w = 0; w * 64 < avail; ++w)
+        for (uint64_t s = s0; s < s1; ++s)
         {
-            unsigned len = (unsigned)std::min<uint64_t>(64, avail - w * 64);
-            r[6 + w] = read_bits(A.stream.data(), A.sb_ptr[s] + w * 64, len);
+            uint64_t * r = &rec[(size_t)s * kRecWords];
+            uint64_t ones_in = A.sb_rank[s + 1] - A.sb_rank[s];
+            r[0] = A.sb_rank[s];
+            r[1] = A.sb_ptr[s] | (ones_in << 48);
+            memcpy(r + 2, &A.cls[(size_t)s * kRrrK], kRrrK);
+            uint64_t avail = A.sb_ptr[s + 1] - A.sb_ptr[s];
+            if (avail > kInlineBits)
+                avail = kInlineBits;
+            for (unsigned w = 0; w * 64 < avail; ++w)
+            {
+                unsigned len = (unsigned)std::min<uint64_t>(64, avail - w * 64);
+                r[6 + w] = read_bits(A.stream.data(), A.sb_ptr[s] + w * 64, len);
+            }
+            // select samples falling into this superblock: walk its blocks, decode only where needed
+            uint64_t start = s * kRrrSB;
+            uint64_t len_in = A.n_bits - start < kRrrSB ? A.n_bits - start : kRrrSB;
+            uint64_t h[2] = {start - A.sb_rank[s], A.sb_rank[s]};
+            uint64_t c[2] = {len_in - ones_in, ones_in};
+            for (int b = 0; b < 2; ++b)
+            {
+                uint64_t jj = (h[b] + S - 1) >> sh;
+                if (c[b] == 0 || (jj << sh) >= h[b] + c[b])
+                    continue;
+                uint64_t acc = h[b], ptr = A.sb_ptr[s];
+                for (unsigned t = 0; t < kRrrK && (jj << sh) < h[b] + c[b]; ++t)
+                {
+                    uint64_t blk = s * kRrrK + t;
+                    if (blk >= A.n_blocks)
+                        break;
+                    unsigned k = A.cls[blk], len = T.space[k];
+                    uint64_t bstart = blk * kRrrBS;
+                    unsigned blen = bstart >= A.n_bits ? 0u : (unsigned)std::min<uint64_t>(kRrrBS, A.n_bits - bstart);
+                    unsigned a = b ? k : blen - k;
+                    if ((jj << sh) < acc + a)
+                    {
+                        uint64_t bits = decode_block_host(T, k, read_bits(A.stream.data(), ptr, len));
+                        if (!b)
+                            bits = ~bits & lo_set(blen);
+                        while ((jj << sh) < acc + a)
+                        {
+                            uint64_t pos = bstart + sel64(bits, (unsigned)((jj << sh) - acc) + 1);
+                            (b ? sel1 : sel0)[jj] = (uint32_t)(pos >> ps);
+                            ++jj;
+                        }
+                    }
+                    acc += a;
+                    ptr += len;
+                }
+            }
         }
-        // select samples: superblock holding the argument of 0-based rank j << sh
-        uint64_t start = s * kRrrSB;
-        uint64_t len_in = A.n_bits - start < kRrrSB ? A.n_bits - start : kRrrSB;
-        uint64_t h1 = A.sb_rank[s], c1 = ones_in;
-        uint64_t h0 = start - h1, c0 = len_in - ones_in;
-        for (uint64_t j = (h1 + (UINT64_C(1) << sh) - 1) >> sh; (j << sh) < h1 + c1; ++j)
-            sel1[j] = (uint32_t)s;
-        for (uint64_t j = (h0 + (UINT64_C(1) << sh) - 1) >> sh; (j << sh) < h0 + c0; ++j)
-            sel0[j] = (uint32_t)s;
+    };
+    {
+        unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+        if (A.n_sb < 4096)
+            nt = 1;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back(fill, A.n_sb * t / nt, A.n_sb * (t + 1) / nt);
+        for (auto & x : th)
+            x.join();
     }
-    uint32_t last = A.n_sb ? (uint32_t)(A.n_sb - 1) : 0;
-    sel1[((A.ones + (UINT64_C(1) << sh) - 1) >> sh)] = last;
-    sel0[((zeros + (UINT64_C(1) << sh) - 1) >> sh)] = last;
+    sel1[ns1] = (uint32_t)(A.n_bits >> ps);
+    sel0[ns0] = (uint32_t)(A.n_bits >> ps);
     SH_TRY(h.rec.alloc(rec.size() * 8));
     if (!rec.empty())
         SH_HIP(hipMemcpy(h.rec.p, rec.data(), rec.size() * 8, hipMemcpyHostToDevice));
@@ -587,6 +750,7 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     h.view.n_sb = A.n_sb;
     h.view.ones = A.ones;
     h.view.sel_shift = sh;
+    h.view.sel_pshift = ps;
     return SDSL_HIP_OK;
 }
 
@@ -682,7 +846,7 @@ uint64_t sdsl_hip_rrr_device_bytes(sdsl_hip_rrr_t v)
 
 static unsigned rrr_grid(uint64_t n)
 {
-    return grid_for(n, kRrrBlock / 4, 256u * 4u);
+    return grid_for(n, kRrrBlock, 256u * 4u);
 }
 
 sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uint64_t * idx, uint64_t n,
