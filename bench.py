@@ -46,6 +46,8 @@ def parse():
     p.add_argument("--text-mib", type=int, default=256, help="synthetic text size for the wt/fm extras")
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
+    p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only "
+                   "for exercising the multi-rank control flow on a single GPU)")
     return p.parse_args()
 
 
@@ -120,6 +122,23 @@ def cpu_baseline(pkg, words_dev, n_bits, idx_dev, gpu_out_dev, seconds):
     }
 
 
+def cpu_time(run, args_dev, gpu_out_dev, seconds, unit_scale, what):
+    """Times `run(*host_arrays)` (a scalar CPU loop of the reference / its restatement) on a bounded prefix of
+    the step's arguments and checks the answers against the GPU's."""
+    probe = [a[:200_000].cpu().numpy() for a in args_dev]
+    t0 = time.perf_counter()
+    run(*probe)
+    per_q = (time.perf_counter() - t0) / 200_000
+    n_s = int(min(args_dev[0].shape[0], max(200_000, seconds / per_q)))
+    host = [a[:n_s].cpu().numpy() for a in args_dev]
+    t0 = time.perf_counter()
+    res = run(*host)
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(np.asarray(res).view(np.uint64), gpu_out_dev[:n_s].cpu().numpy().view(np.uint64)))
+    return {"value": n_s / dt / unit_scale, "ns_per_query": dt / n_s * 1e9, "cores": 1, "sample": f"first {n_s} {what}",
+            "matches_gpu": same}
+
+
 def synthetic_text(n_bytes, seed, device):
     """English-like stand-in for Pizza&Chili english (not available offline): words drawn from a fixed
     4096-word vocabulary with a Zipf-like distribution, separated by spaces.  Built on the device."""
@@ -156,19 +175,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()
+    if a.backend == "gloo":
+        local = local % max(1, n_dev)  # test mode: several ranks may share one GPU
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-        def barrier():
-            dist.barrier(device_ids=[local])
+            def barrier():
+                dist.barrier(device_ids=[local])
+        else:
+            dist.init_process_group(a.backend)
+
+            def barrier():
+                dist.barrier()
     else:
         def barrier():
             pass
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    comm_dev = dev if a.backend == "nccl" else torch.device("cpu")
     pkg = importlib.import_module("sdsl-lite_amd")
     n_bits = 1 << a.log_n
     nq = int(a.queries)
@@ -184,8 +213,8 @@ def main():
 
     wall, kernel_ms = time_steps(lambda: bv.rank(idx, 1, out), a.steps, a.warmup, barrier)
     if world > 1:
-        wall = pkg.dist.max_over_ranks(wall, dev)
-        kernel_ms = pkg.dist.max_over_ranks(kernel_ms, dev)
+        wall = pkg.dist.max_over_ranks(wall, comm_dev)
+        kernel_ms = pkg.dist.max_over_ranks(kernel_ms, comm_dev)
     value = nq * world * a.steps / wall / 1e9
     achieved = ALG_BYTES["rank"] * nq / (kernel_ms * 1e-3) / 1e9
     result = {
@@ -217,6 +246,22 @@ def main():
                           "roofline_frac": ALG_BYTES["select"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         pos = out[: 1 << 20].clone()
         assert bool((bv.rank(pos, 1) == si[: 1 << 20] - 1).all()), "select/rank round trip failed"
+        if rank == 0 and world == 1 and not a.no_cpu:
+            import oracle_lib as ol
+            if ol.have_ref():  # the real select_support_mcl<1>; ref_bv_create builds it together with the rank supports
+                wp = ol.padded(words.cpu().numpy().view(np.uint64), n_bits)
+                hh = ol.ref().L.ref_bv_create(wp.ctypes.data, n_bits)
+
+                def run_sel(i):
+                    o = np.empty(i.size, dtype=np.uint64)
+                    ii = np.ascontiguousarray(i).view(np.uint64)
+                    ol.ref().L.ref_bv_select(hh, 1, ii.ctypes.data, ii.size, o.ctypes.data)
+                    return o
+                bv.select(si, 1, out)
+                cb = cpu_time(run_sel, [si], out, a.cpu_seconds, 1e9, "select_1 arguments, select_support_mcl<1>")
+                cb.update(unit="Gselect/s", kind="reference")
+                ex["select_1"]["cpu_baseline"] = cb
+                ol.ref().L.ref_bv_destroy(hh)
         del si
     del words
     if "rrr" in extras:
@@ -235,6 +280,7 @@ def main():
         t0 = time.perf_counter()
         rv = pkg.rrr_vector(w5, n_bits, device=local)
         build = time.perf_counter() - t0
+        w5h = w5.cpu().numpy().view(np.uint64) if (rank == 0 and world == 1 and not a.no_cpu) else None
         del w5
         _, ms = time_steps(lambda: rv.rank(idx, 1, out), max(2, a.steps // 2), 1, barrier)
         ex["rrr63_rank_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms, "build_s": build,
@@ -245,6 +291,34 @@ def main():
         ex["rrr63_select_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms,
                                 "roofline_frac": ALG_BYTES["rrr"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         assert bool((rv.rank(out[: 1 << 20].clone(), 1) == si[: 1 << 20] - 1).all())
+        if rank == 0 and world == 1 and not a.no_cpu:
+            import oracle_lib as ol
+            if ol.have_ref():  # the real rrr_vector<63> built from the same bits
+                wp = ol.padded(w5h, n_bits)
+                t0 = time.perf_counter()
+                hh = ol.ref().L.ref_rrr_create(wp.ctypes.data, n_bits)
+                cpu_build = time.perf_counter() - t0
+
+                def run_rank(i):
+                    o = np.empty(i.size, dtype=np.uint64)
+                    ii = np.ascontiguousarray(i).view(np.uint64)
+                    ol.ref().L.ref_rrr_rank(hh, 1, ii.ctypes.data, ii.size, o.ctypes.data)
+                    return o
+
+                def run_sel(i):
+                    o = np.empty(i.size, dtype=np.uint64)
+                    ii = np.ascontiguousarray(i).view(np.uint64)
+                    ol.ref().L.ref_rrr_select(hh, 1, ii.ctypes.data, ii.size, o.ctypes.data)
+                    return o
+                rv.rank(idx, 1, out)
+                cb = cpu_time(run_rank, [idx], out, a.cpu_seconds, 1e9, "rank_1 arguments, rank_support_rrr<1,63>")
+                cb.update(unit="Grank/s", kind="reference", build_s=cpu_build)
+                ex["rrr63_rank_1"]["cpu_baseline"] = cb
+                rv.select(si, 1, out)
+                cb = cpu_time(run_sel, [si], out, a.cpu_seconds, 1e9, "select_1 arguments, select_support_rrr<1,63>")
+                cb.update(unit="Gselect/s", kind="reference")
+                ex["rrr63_select_1"]["cpu_baseline"] = cb
+                ol.ref().L.ref_rrr_destroy(hh)
         del rv, si
     if "wt" in extras or "fm" in extras:
         torch.cuda.empty_cache()
@@ -263,11 +337,30 @@ def main():
         ex["text"] = {"bytes": nt, "kind": "synthetic English-like stand-in (Zipf over a 4096-word vocabulary)",
                       "sigma": csa.sigma(), "index_build_s": build, "mean_code_length_of_queried_symbols": hbar,
                       "wt_bits": wt.bv_size(), "index_bytes": csa.device_bytes()}
+        ocsa = None
+        if rank == 0 and world == 1 and not a.no_cpu:
+            # CPU side: the C restatement of wt_huff / backward_search (kind "port") over the SAME BWT, which is
+            # reconstructed from the device index with wt[i] (access) so that no CPU suffix sorting is needed
+            import oracle_lib as ol
+            t0 = time.perf_counter()
+            bwt = torch.empty(nt + 1, dtype=torch.uint8, device=dev)
+            for s0 in range(0, nt + 1, 1 << 27):
+                e0 = min(nt + 1, s0 + (1 << 27))
+                wt.access(torch.arange(s0, e0, device=dev, dtype=torch.int64), bwt[s0:e0])
+            ocsa = ol.OCsa(bwt=bwt.cpu().numpy())
+            ex["text"]["cpu_index_build_s"] = time.perf_counter() - t0
+            del bwt
         if "wt" in extras:
             _, ms = time_steps(lambda: wt.rank(gi, gc, out2), max(2, a.steps // 2), 1, barrier)
             alg = 17 + 80 * hbar
             ex["wt_huff_rank"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2,
                                   "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if ocsa is not None:
+                owt = ocsa.wt()
+                cb = cpu_time(lambda i, c: owt.rank(np.ascontiguousarray(i).view(np.uint64), c), [gi, gc], out2,
+                              a.cpu_seconds, 1e9, "(i,c) pairs, wt_huff<bit_vector,rank_support_v5<>>::rank")
+                cb.update(unit="Grank/s", kind="port")
+                ex["wt_huff_rank"]["cpu_baseline"] = cb
         if "fm" in extras:
             m = 20
             st = torch.randint(0, nt - m, (nq2,), device=dev, generator=gq)
@@ -278,13 +371,18 @@ def main():
             assert bool((out2 >= 1).all()), "every pattern was cut from the text"
             ex["fm_count"] = {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "patterns": nq2, "m": m,
                               "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if ocsa is not None:
+                cb = cpu_time(lambda p: ocsa.count_batch(p.reshape(-1), m), [pats.view(-1, m)], out2, a.cpu_seconds,
+                              1e6, "20-byte patterns, count(csa_wt<wt_huff<>>)")
+                cb.update(unit="Mcount/s", kind="port")
+                ex["fm_count"]["cpu_baseline"] = cb
     if ex:
         result["extras"] = ex
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         import torch.distributed as dist
-        dist.barrier(device_ids=[local])
+        barrier()
         dist.destroy_process_group()
 
 

@@ -133,6 +133,50 @@ static void run(const char * name, const v2u64 * table, uint64_t table_bytes, co
     fflush(stdout);
 }
 
+// random 8-byte scatter: out[(mix(q) % n_slots)] = q   (the un-permute step of a bucketed batch)
+template <bool NT>
+__global__ __launch_bounds__(256) void k_scatter8(uint64_t * __restrict__ out, uint64_t n_slots, uint64_t n_q)
+{
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_q; q += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t p = mix(q) % n_slots;
+        if (NT)
+            __builtin_nontemporal_store(q, out + p);
+        else
+            out[p] = q;
+    }
+}
+// scatter confined to a window of `win` slots that moves with q (results of one bucket land in one L2-sized tile)
+__global__ __launch_bounds__(256) void k_scatter8_windowed(uint64_t * __restrict__ out, uint64_t n_slots, uint64_t win,
+                                                          uint64_t n_q)
+{
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_q; q += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t base = (q / win) * win;
+        uint64_t p = base + mix(q) % win;
+        if (p < n_slots)
+            out[p] = q;
+    }
+}
+
+static int scatter(int argc, char ** argv)
+{
+    uint64_t nq = strtoull(argv[2], 0, 10);
+    uint64_t * out;
+    CK(hipMalloc(&out, nq * 8));
+    CK(hipMemset(out, 0, nq * 8));
+    float ms = time_ms([&] { hipLaunchKernelGGL(k_scatter8<false>, dim3(2048), dim3(256), 0, 0, out, nq, nq); }, 3);
+    printf("random 8-B scatter over %.1f GiB            : %8.3f ms  %7.2f Gw/s\n", nq * 8 / 1073741824.0, ms, nq / ms / 1e6);
+    ms = time_ms([&] { hipLaunchKernelGGL(k_scatter8<true>, dim3(2048), dim3(256), 0, 0, out, nq, nq); }, 3);
+    printf("random 8-B scatter (nontemporal)           : %8.3f ms  %7.2f Gw/s\n", ms, nq / ms / 1e6);
+    for (uint64_t win : {1ull << 17, 1ull << 19, 1ull << 21, 1ull << 23})
+    {
+        ms = time_ms([&] { hipLaunchKernelGGL(k_scatter8_windowed, dim3(2048), dim3(256), 0, 0, out, nq, win, nq); }, 3);
+        printf("8-B scatter inside moving %6.1f MiB windows : %8.3f ms  %7.2f Gw/s\n", win * 8 / 1048576.0, ms, nq / ms / 1e6);
+    }
+    return 0;
+}
+
 static int sweep(int argc, char ** argv)
 { // gather_probe sweep <nq> <MiB> <MiB> ... : random-gather rate as a function of table size
     uint64_t nq = strtoull(argv[2], 0, 10);
@@ -170,6 +214,8 @@ int main(int argc, char ** argv)
 {
     if (argc > 3 && !strcmp(argv[1], "sweep"))
         return sweep(argc, argv);
+    if (argc > 2 && !strcmp(argv[1], "scatter"))
+        return scatter(argc, argv);
     uint64_t table_bytes = (argc > 1 ? strtoull(argv[1], 0, 10) : 2304ull) << 20; // MiB
     uint64_t nq = argc > 2 ? strtoull(argv[2], 0, 10) : (1ull << 28);
     hipDeviceProp_t prop;

@@ -1,0 +1,47 @@
+"""GPU: bench.py honours its contract on a reduced workload — one JSON line with the required keys, the
+roofline and cpu_baseline objects, and a multi-rank run (2 processes sharing the one GPU of the test box,
+gloo for the control-plane collectives) that aggregates over ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_single_gpu_contract(gpu):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--log-n", "26",
+                        "--queries", "4e6", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert all(k in d for k in REQUIRED)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["higher_is_better"] and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["value"] - 4e6 * 3 / (d["ms_per_step"] * 3e-3) / 1e9) < 1e-6 * d["value"] + 1e-9
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["kind"] in ("reference", "port") and cb["matches_gpu"] is True
+    assert "select_1" in d["extras"]
+
+
+def test_two_ranks_share_the_gpu(gpu):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "24", "--queries", "1e6",
+                        "--extras", "none", "--backend", "gloo"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * 1e6 * 2 / (d["ms_per_step"] * 2e-3) / 1e9) < 1e-6 * d["value"] + 1e-9
