@@ -357,3 +357,48 @@ def test_full_size_properties(gpu):
     i = torch.arange(1, nq + 1, device="cuda", dtype=torch.int64) * (total // nq)
     pos = bv.select(i, 1)
     assert bool((pos[1:] > pos[:-1]).all())  # sortedness
+
+
+# ---------------------------------------------------------------------------------------------------
+# small / degenerate inputs and larger-than-2^32 positions
+# ---------------------------------------------------------------------------------------------------
+def test_fm_tiny_texts(gpu):
+    for t in (b"", b"a", b"ab", b"aaaa"):
+        csa = gpu.csa_wt(text=t)
+        o = ol.OCsa(t)
+        assert (csa.size(), csa.sigma()) == (o.size(), o.sigma())
+        pats = [b"", b"a", b"aa", b"b", b"ab", b"aaaaa"]
+        assert list(csa.count_ragged(pats)) == [o.count(p) for p in pats]
+
+
+def test_rrr_beyond_32_bit_positions(gpu):
+    """2^32 + a few bits: select samples are quantised (sel_pshift = 1) and block indices exceed 2^26"""
+    import torch
+    n = (1 << 32) + 12345
+    g = torch.Generator(device="cuda").manual_seed(3)
+    nw = (n + 63) // 64
+    w = torch.zeros(nw, dtype=torch.int64, device="cuda")
+    bits = torch.randint(0, 64, (nw,), device="cuda", generator=g)
+    w = (torch.ones_like(bits) << bits) | (torch.ones_like(bits) << ((bits * 7 + 3) % 64))  # ~2 ones per word
+    rv = gpu.rrr_vector(w, n)
+    bv = gpu.bit_vector(w, n)
+    assert rv.ones() == bv.ones()
+    nq = 1 << 20
+    idx = torch.randint(0, n + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
+    assert bool((rv.rank(idx, 1) == bv.rank(idx, 1)).all())
+    for b, tot in ((1, rv.ones()), (0, n - rv.ones())):
+        i = torch.randint(1, tot + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
+        assert bool((rv.select(i, b) == bv.select(i, b)).all())
+    ia = idx.clamp(max=n - 1)
+    assert bool((rv.access(ia) == bv.access(ia)).all())
+
+
+def test_host_and_device_arguments_agree(gpu):
+    import torch
+    n = 1 << 21
+    w = mk(n, 0.5, 1)
+    bv = gpu.bit_vector(w, n)
+    idx = np.random.default_rng(2).integers(0, n + 1, size=4097, dtype=np.uint64)
+    dev = bv.rank(torch.from_numpy(idx.view(np.int64)).cuda(), 1).cpu().numpy().view(np.uint64)
+    assert np.array_equal(dev, bv.rank(idx, 1))
+    assert bv.rank(np.zeros(0, dtype=np.uint64)).size == 0
