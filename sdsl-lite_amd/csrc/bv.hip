@@ -245,13 +245,12 @@ sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words
     SH_HIP(hipMemcpy(&bv.view.ones, bsum.as<uint64_t>() + nb, sizeof(uint64_t), hipMemcpyDeviceToHost));
 
     if (bv.view.sel_shift == 0)
-    { // one rate for both directories: at most 2^21 four-byte samples (8 MiB) per directory.  Measured
-      // on 2^34 bits (profiles/select_sweep_r01.txt): 2^12 beats both finer rates (directory falls out
-      // of L2/MALL, +1 fabric request per query) and coarser ones (interpolation misses the 128-byte
-      // window more often, and a miss stalls the whole wave)
+    { // one rate for both directories: at most 2^19 four-byte samples (2 MiB) per directory, so that the
+      // directory is mostly L2/Infinity-Cache resident.  With the retry-queue kernel the rate is flat between
+      // 2^12 and 2^16 on 2^34 bits (profiles/select_sweep_r01.txt); 2^14 is the measured optimum.
         uint64_t most = std::max(bv.view.ones, n_bits - bv.view.ones);
         uint32_t sh = 9;
-        while (sh < 20 && (most >> sh) > (UINT64_C(1) << 21))
+        while (sh < 20 && (most >> sh) > (UINT64_C(1) << 19))
             ++sh;
         bv.view.sel_shift = sh;
     }
@@ -371,6 +370,110 @@ __global__ __launch_bounds__(kBlock) void k_select(BvView bv, const uint64_t * _
     }
 }
 
+// Round-based select with a per-block RETRY QUEUE in LDS.  Every round each quad starts one new query (argument and
+// sample loads stay coalesced because the block advances in lock step); a quad whose interpolated window missed
+// parks (query, bracket) in the queue instead of re-probing while the other 15 quads of its wave wait.  As soon as
+// a full round's worth of entries has piled up the whole block spends one round on them.  Misses thus cost one
+// probe of one quad, which is what makes a coarse, L2-resident sample directory pay off (profiles/select_sweep_r01.txt).
+struct RetryEntry
+{
+    uint64_t q, k;
+    SelBracket br;
+    uint32_t tries, pad;
+};
+
+template <int BIT, bool NT>
+__global__ __launch_bounds__(kBlock) void k_select_rq(BvView bv, const uint64_t * __restrict__ iq,
+                                                      uint64_t * __restrict__ out, uint64_t n)
+{
+    __shared__ RetryEntry rq[2 * kQPB];
+    __shared__ unsigned rq_n;
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    const uint64_t total = BIT ? bv.ones : bv.n_bits - bv.ones;
+    const uint32_t * __restrict__ smp = bv.sel[BIT];
+    if (threadIdx.x == 0)
+        rq_n = 0;
+    __syncthreads();
+
+    // one probe of query (q, k); on a miss the tightened bracket goes to the queue.  Quad-uniform.
+    auto probe = [&](uint64_t q, uint64_t k, SelBracket br, uint32_t tries)
+    {
+        const uint64_t W = sel_guess(bv, br, k, (int)tries);
+        Pair wa = load_pair<NT>(bv.lines, 2 * W, s);
+        Pair wb = load_pair<NT>(bv.lines, 2 * W + 1, s);
+        bool mine = false;
+        uint64_t pos = 0;
+        if (sel_eval<BIT>(bv, s, k, W, wa, wb, br, mine, pos))
+        {
+            if (mine)
+                out[q] = pos;
+        }
+        else if (s == 0)
+        {
+            unsigned slot = atomicAdd(&rq_n, 1u);
+            RetryEntry e;
+            e.q = q;
+            e.k = k;
+            e.br = br;
+            e.tries = tries + 1;
+            e.pad = 0;
+            rq[slot] = e;
+        }
+    };
+
+    const uint64_t stride = (uint64_t)gridDim.x * kQPB;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += stride) // block-uniform trip count
+    {
+        const uint64_t q = base + gq;
+        const uint64_t i = q < n ? iq[q] : 0;
+        const bool ok = i >= 1 && i <= total; // outside: SDSL's precondition (select_support_mcl.hpp:386)
+        if (q < n && !ok && s == 0)
+            out[q] = SDSL_HIP_NPOS;
+        if (ok)
+        {
+            const uint64_t k = i - 1, j = k >> bv.sel_shift;
+            probe(q, k, sel_bracket<BIT>(bv, k, smp[j], smp[j + 1]), 0u);
+        }
+        __syncthreads();
+        unsigned cnt = rq_n;
+        __syncthreads(); // everybody has seen the same count before anyone pushes again
+        while (cnt >= kQPB)
+        {
+            RetryEntry e = rq[cnt - kQPB + gq];
+            __syncthreads();
+            if (threadIdx.x == 0)
+                rq_n = cnt - kQPB;
+            __syncthreads();
+            probe(e.q, e.k, e.br, e.tries);
+            __syncthreads();
+            cnt = rq_n;
+            __syncthreads();
+        }
+    }
+    // drain what is left
+    __syncthreads();
+    unsigned cnt = rq_n;
+    __syncthreads();
+    while (cnt > 0)
+    {
+        const unsigned take = cnt < kQPB ? cnt : kQPB;
+        const bool act = gq < take;
+        RetryEntry e{};
+        if (act)
+            e = rq[cnt - take + gq];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            rq_n = cnt - take;
+        __syncthreads();
+        if (act)
+            probe(e.q, e.k, e.br, e.tries);
+        __syncthreads();
+        cnt = rq_n;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k_access(BvView bv, const uint64_t * __restrict__ idx,
                                                 uint8_t * __restrict__ out, uint64_t n)
 {
@@ -448,8 +551,14 @@ sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i
     case 3: SH_LAUNCH_SEL(1, 2); break;
     case 4: SH_LAUNCH_SEL(0, 4); break;
     case 5: SH_LAUNCH_SEL(1, 4); break;
-    case 1: SH_LAUNCH_SEL(1, 1); break;
-    default: SH_LAUNCH_SEL(0, 1); break;
+    case 6: SH_LAUNCH_SEL(0, 1); break;
+    case 7: SH_LAUNCH_SEL(1, 1); break;
+    case 1:
+        hipLaunchKernelGGL((k_select_rq<1, false>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
+        break;
+    default:
+        hipLaunchKernelGGL((k_select_rq<0, false>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
+        break;
     }
 #undef SH_LAUNCH_SEL
     SH_HIP(hipGetLastError());
