@@ -23,6 +23,28 @@ struct FmTables
 };
 
 sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, std::vector<uint8_t> & bwt);
+sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint32_t * vals_in, uint32_t * vals_out,
+                                   uint64_t n, unsigned end_bit, hipStream_t s);
+
+// Sort key of a pattern: its last eight bytes, the LAST byte most significant — backward search consumes a pattern
+// from its end, so patterns that are neighbours in this order walk the same SA intervals (the same rank lines) for
+// their first eight LF steps.
+__global__ __launch_bounds__(256) void k_fm_keys(const uint8_t * __restrict__ pats, uint32_t m,
+                                                 const uint64_t * __restrict__ offsets, uint64_t n_pat,
+                                                 uint64_t * __restrict__ keys, uint32_t * __restrict__ idx)
+{
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pat; p += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t begin = offsets ? offsets[p] : p * (uint64_t)m;
+        uint64_t end = offsets ? offsets[p + 1] : begin + m;
+        uint64_t key = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            key = (key << 8) | (end > begin + (uint64_t)t ? (uint64_t)pats[end - 1 - t] : 0);
+        keys[p] = key;
+        idx[p] = (uint32_t)p;
+    }
+}
 
 // One pattern per quad.  The two rank cascades of every LF step run level-synchronously with both
 // line fetches in flight (wt_device.hpp: quad_wt_rank2).
@@ -30,8 +52,9 @@ template <bool NT, bool WANT_IVAL>
 __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables * __restrict__ ftab,
                                                      uint64_t csa_size, const uint8_t * __restrict__ pats,
                                                      uint32_t m, const uint64_t * __restrict__ offsets,
-                                                     uint64_t n_pat, uint64_t * __restrict__ out_cnt,
-                                                     uint64_t * __restrict__ out_l, uint64_t * __restrict__ out_r)
+                                                     const uint32_t * __restrict__ order, uint64_t n_pat,
+                                                     uint64_t * __restrict__ out_cnt, uint64_t * __restrict__ out_l,
+                                                     uint64_t * __restrict__ out_r)
 {
     __shared__ WtTables T;
     __shared__ FmTables F;
@@ -49,6 +72,8 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
         uint64_t q = base + gq;
         if (q >= n_pat)
             continue;
+        if (order)
+            q = order[q]; // batch ordered by pattern suffix: neighbouring quads share lines; results go back in place
         uint64_t begin = offsets ? offsets[q] : q * (uint64_t)m;
         uint64_t end = offsets ? offsets[q + 1] : begin + m;
         uint64_t l = 0, r = csa_size - 1;
@@ -350,10 +375,21 @@ sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int
                 f->tab.C[i] = Cv.get(i);
             f->sigma = sigma;
             f->size = sdsl_hip_wt_host(f->wt).size;
-            if (f->tab.C[sigma] != f->size)
+            // the alphabet must describe the wavelet tree's symbol counts exactly (the kernels index with it)
+            const WtHost & w = sdsl_hip_wt_host(f->wt);
+            bool good = f->tab.C[sigma] == f->size && f->tab.C[0] == 0 && f->size >= 1;
+            uint32_t next_cc = 0;
+            for (int c = 0; c < 256 && good; ++c)
             {
-                set_error("csa_wt stream: C[sigma] = %llu does not match the wavelet tree size %llu",
-                          (unsigned long long)f->tab.C[sigma], (unsigned long long)f->size);
+                uint32_t cc = f->tab.char2comp[c];
+                if (w.occ[c] == 0)
+                    good = cc == 0;
+                else
+                    good = cc == next_cc && cc < sigma && f->tab.C[cc + 1] - f->tab.C[cc] == w.occ[c] && ++next_cc;
+            }
+            if (!good || next_cc != sigma)
+            {
+                set_error("csa_wt stream: alphabet (C, char2comp, sigma) is inconsistent with the wavelet tree");
                 st = SDSL_HIP_ERR_FORMAT;
             }
             else
@@ -424,19 +460,44 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
         SH_TRY(sc.out(out_cnt, n_pat * 8));
     const WtHost & w = sdsl_hip_wt_host(fm->wt);
     unsigned grid = grid_for(n_pat, kQPB, 256u * 8u);
+    // Large batches are answered in suffix order (see k_fm_keys): one key kernel + one radix sort, no synchronisation
+    static const int sort_knob = getenv("SDSL_HIP_FM_SORT") ? atoi(getenv("SDSL_HIP_FM_SORT")) : -1;
+    const bool ordered = sort_knob < 0 ? (n_pat >= (UINT64_C(1) << 16) && n_pat < UINT64_C(0xFFFFFFFF)) : sort_knob != 0;
+    uint32_t * d_order = nullptr;
+    void * scratch = nullptr;
+    KernelTimer t(s); // covers key generation + sort + search: the whole cost of the batch
+    if (ordered)
     {
-        KernelTimer t(s);
+        const size_t kb = (size_t)n_pat * 8, ib = (size_t)n_pat * 4;
+        SH_HIP(hipMallocAsync(&scratch, 2 * kb + 2 * ib, s));
+        uint64_t * k0 = (uint64_t *)scratch;
+        uint64_t * k1 = k0 + n_pat;
+        uint32_t * i0 = (uint32_t *)(k1 + n_pat);
+        uint32_t * i1 = i0 + n_pat;
+        hipLaunchKernelGGL(k_fm_keys, dim3(grid_for(n_pat, 256, 256u * 8u)), dim3(256), 0, s, (const uint8_t *)sp.dev, m,
+                           offsets ? (const uint64_t *)so.dev : nullptr, n_pat, k0, i0);
+        sdsl_hip_status st = sort_pairs_u64_u32(k0, k1, i0, i1, n_pat, 64u, s);
+        if (st != SDSL_HIP_OK)
+        {
+            (void)hipFreeAsync(scratch, s);
+            return st;
+        }
+        d_order = i1;
+    }
+    {
         if (ival)
             hipLaunchKernelGGL((k_fm_count<false, true>), dim3(grid), dim3(kBlock), 0, s, w.view(),
                                fm->d_tab.as<FmTables>(), fm->size, (const uint8_t *)sp.dev, m,
-                               offsets ? (const uint64_t *)so.dev : nullptr, n_pat, (uint64_t *)nullptr,
+                               offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat, (uint64_t *)nullptr,
                                (uint64_t *)sl.dev, (uint64_t *)sr.dev);
         else
             hipLaunchKernelGGL((k_fm_count<false, false>), dim3(grid), dim3(kBlock), 0, s, w.view(),
                                fm->d_tab.as<FmTables>(), fm->size, (const uint8_t *)sp.dev, m,
-                               offsets ? (const uint64_t *)so.dev : nullptr, n_pat, (uint64_t *)sc.dev,
+                               offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat, (uint64_t *)sc.dev,
                                (uint64_t *)nullptr, (uint64_t *)nullptr);
     }
+    if (scratch)
+        (void)hipFreeAsync(scratch, s);
     SH_HIP(hipGetLastError());
     if (ival)
     {

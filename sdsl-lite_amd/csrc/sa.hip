@@ -67,6 +67,21 @@ __global__ void k_sa_bwt(const uint8_t * __restrict__ s, const uint32_t * __rest
     }
 }
 
+// Stream-ordered sort of (u64 key, u32 value) pairs, used by fm.hip to order a pattern batch.  Scratch comes from
+// the stream-ordered allocator so that the call neither synchronises nor keeps state in the handle.
+sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint32_t * vals_in, uint32_t * vals_out,
+                                   uint64_t n, unsigned end_bit, hipStream_t s)
+{
+    size_t bytes = 0;
+    SH_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, s));
+    void * tmp = nullptr;
+    SH_HIP(hipMallocAsync(&tmp, bytes ? bytes : 16, s));
+    hipError_t e = rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, s);
+    (void)hipFreeAsync(tmp, s);
+    SH_HIP(e);
+    return SDSL_HIP_OK;
+}
+
 sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, std::vector<uint8_t> & bwt)
 {
     const uint64_t n = n_text + 1;

@@ -226,26 +226,62 @@ sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, bool select
                 T.path[c] = path[c];
             }
         }
-        // occurrences per symbol from the slices: ones go right, zeros go left
+        // Structural validation (the kernels trust these tables): BFS numbering (children come after their
+        // parent, so every walk terminates), contiguous slices covering the bit vector, every child's slice as
+        // long as the number of zeros/ones of its parent's slice, stored prefix ranks equal to the real ones.
+        // Along the way: occurrences per symbol (zeros go left, ones go right).
         memset(wt.occ, 0, sizeof wt.occ);
-        for (uint32_t v = 0; v < wt.n_nodes; ++v)
+        if (wt.size != 0 && wt.n_nodes == 0)
+            goto bad;
+        if (wt.size != 0)
         {
-            if (T.child[v][0] == kWtUndef)
+            std::vector<uint64_t> slice(wt.n_nodes, 0), expect(wt.n_nodes, UINT64_MAX);
+            expect[0] = wt.size;
+            uint64_t run_pos = 0, run_rank = 0, leaves = 0;
+            for (uint32_t v = 0; v < wt.n_nodes; ++v)
             {
-                if (wt.n_nodes == 1)
-                    wt.occ[(uint8_t)T.bv_pos_rank[v]] = wt.size;
-                continue;
+                const bool leaf = T.child[v][0] == kWtUndef;
+                if (T.bv_pos[v] != run_pos || expect[v] == UINT64_MAX)
+                    goto bad;
+                if (leaf)
+                {
+                    if (T.child[v][1] != kWtUndef || T.bv_pos_rank[v] > 255)
+                        goto bad;
+                    uint8_t sym = (uint8_t)T.bv_pos_rank[v];
+                    if (T.c_to_leaf[sym] != v)
+                        goto bad;
+                    wt.occ[sym] = expect[v];
+                    ++leaves;
+                    continue;
+                }
+                if (T.child[v][0] <= v || T.child[v][1] <= v || T.child[v][1] == kWtUndef
+                    || T.parent[T.child[v][0]] != v || T.parent[T.child[v][1]] != v)
+                    goto bad;
+                slice[v] = expect[v];
+                if (slice[v] > bv.bit_size - run_pos || T.bv_pos_rank[v] != run_rank)
+                    goto bad;
+                uint64_t ones = popcount_range(bv.words.data(), run_pos, run_pos + slice[v]);
+                expect[T.child[v][0]] = slice[v] - ones;
+                expect[T.child[v][1]] = ones;
+                run_pos += slice[v];
+                run_rank += ones;
             }
-            uint64_t end = v + 1 < wt.n_nodes ? T.bv_pos[v + 1] : bv.bit_size;
-            if (end < T.bv_pos[v] || end > bv.bit_size)
+            if (run_pos != bv.bit_size || leaves != wt.sigma)
                 goto bad;
-            uint64_t ones = popcount_range(bv.words.data(), T.bv_pos[v], end);
-            uint64_t zeros = (end - T.bv_pos[v]) - ones;
-            for (int k = 0; k < 2; ++k)
-            {
-                uint16_t ch = T.child[v][k];
-                if (T.child[ch][0] == kWtUndef)
-                    wt.occ[(uint8_t)T.bv_pos_rank[ch]] = k ? ones : zeros;
+            for (int c = 0; c < 256; ++c)
+            { // paths must lead from the root to the symbol's leaf
+                if (T.c_to_leaf[c] == kWtUndef)
+                    continue;
+                uint64_t p = T.path[c];
+                unsigned len = (unsigned)(p >> 56), v = 0;
+                for (unsigned l = 0; l < len; ++l, p >>= 1)
+                {
+                    if (T.child[v][0] == kWtUndef)
+                        goto bad;
+                    v = T.child[v][p & 1];
+                }
+                if (v != T.c_to_leaf[c] || T.bv_pos_rank[v] != (uint64_t)c)
+                    goto bad;
             }
         }
         return upload(wt, bv.words, bv.bit_size, device);

@@ -402,3 +402,53 @@ def test_host_and_device_arguments_agree(gpu):
     dev = bv.rank(torch.from_numpy(idx.view(np.int64)).cuda(), 1).cpu().numpy().view(np.uint64)
     assert np.array_equal(dev, bv.rank(idx, 1))
     assert bv.rank(np.zeros(0, dtype=np.uint64)).size == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# loaders never trust a stream: truncated or corrupted SDSL bytes give ERR_FORMAT, not a crash or a hang
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fname,kind", [("rnd.200000.7.rrr63.sdsl", "rrr"), ("example01.txt.wt_huff_v5_mcl.sdsl", "wt"),
+                                        ("abc_abc_abc.txt.wt_huff_v5_scan.sdsl", "wts"),
+                                        ("example01.txt.csa_wt_huff_v5.sdsl", "csa"),
+                                        ("example01.txt.csa_fm_huff.sdsl", "fm")])
+def test_malformed_streams(gpu, fname, kind):
+    blob = gd.sdsl_file(fname)
+
+    def load(b):
+        if kind == "rrr":
+            return gpu.rrr_vector(sdsl_bytes=b)
+        if kind in ("wt", "wts"):
+            return gpu.wt_huff(sdsl_bytes=b, select_is_mcl=(kind == "wt"))
+        return gpu.csa_wt(sdsl_bytes=b, select_is_mcl=(kind == "csa"))
+
+    load(blob)  # intact
+    cuts = sorted(set(list(range(0, min(len(blob), 200), 7)) + [len(blob) * k // 37 for k in range(37)] + [len(blob) - 1]))
+    for cut in cuts:
+        with pytest.raises(gpu.capi.SdslHipError) as e:
+            load(blob[:cut])
+        assert e.value.status == gpu.capi.ERR_FORMAT, cut
+    rng = np.random.default_rng(len(blob))
+    ok = bad = 0
+    for _ in range(300):
+        b = bytearray(blob)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, len(b)))
+            b[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            h = load(bytes(b))
+            ok += 1
+            # whatever was accepted must be safe to query
+            if kind == "rrr":
+                h.rank(np.array([0, h.size()], dtype=np.uint64))
+                h.select(np.array([1, max(1, h.ones())], dtype=np.uint64))
+            elif kind in ("wt", "wts"):
+                q = np.array([0, h.size() // 2, h.size()], dtype=np.uint64)
+                h.rank(q, np.array([97, 98, 0], dtype=np.uint8))
+                if h.size():
+                    h.access(np.array([0, h.size() - 1], dtype=np.uint64))
+            else:
+                h.count(np.frombuffer(b"abcaabca", dtype=np.uint8), 4)
+        except gpu.capi.SdslHipError as e:
+            assert e.status in (gpu.capi.ERR_FORMAT, gpu.capi.ERR_UNSUPPORTED)
+            bad += 1
+    assert ok + bad == 300
