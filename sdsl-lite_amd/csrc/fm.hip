@@ -22,7 +22,7 @@ struct FmTables
     uint8_t char2comp[256]; // 0 for absent bytes (and for the sentinel itself)
 };
 
-sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, std::vector<uint8_t> & bwt);
+sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, DevBuf & d_bwt);
 sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint32_t * vals_in, uint32_t * vals_out,
                                    uint64_t n, unsigned end_bit, hipStream_t s);
 
@@ -236,7 +236,7 @@ static sdsl_hip_status fm_upload_tables(sdsl_hip_fm_s * f)
     return SDSL_HIP_OK;
 }
 
-static sdsl_hip_status fm_from_host_bwt(sdsl_hip_fm_s * f, const uint8_t * bwt, uint64_t n, int device)
+static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_bwt, uint64_t n, int device)
 {
     f->device = device;
     f->size = n;
@@ -244,7 +244,7 @@ static sdsl_hip_status fm_from_host_bwt(sdsl_hip_fm_s * f, const uint8_t * bwt, 
     if (!f->wt)
         return SDSL_HIP_ERR_NOMEM;
     WtHost & w = sdsl_hip_wt_host(f->wt);
-    SH_TRY(wt_build_from_text(w, bwt, n, device)); // csa_wt.hpp:337-343: the WT is built over the BWT
+    SH_TRY(wt_build_from_device_text(w, d_bwt, n, device)); // csa_wt.hpp:337-343: the WT is built over the BWT
     SH_TRY(sdsl_hip_wt_finish(f->wt));
     if (n == 0 || w.occ[0] != 1)
     {
@@ -270,19 +270,10 @@ sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int
     sdsl_hip_fm_s * f = new (std::nothrow) sdsl_hip_fm_s();
     if (!f)
         return SDSL_HIP_ERR_NOMEM;
-    std::vector<uint8_t> tmp;
-    const uint8_t * host = bwt;
-    sdsl_hip_status st = SDSL_HIP_OK;
-    if (is_device_ptr(bwt))
-    {
-        tmp.resize(n);
-        hipError_t e = hipMemcpy(tmp.data(), bwt, n, hipMemcpyDeviceToHost);
-        if (e != hipSuccess)
-            st = hip_fail(e, "hipMemcpy(bwt)", __FILE__, __LINE__);
-        host = tmp.data();
-    }
+    Staged b;
+    sdsl_hip_status st = b.in(bwt, n, nullptr);
     if (st == SDSL_HIP_OK)
-        st = fm_from_host_bwt(f, host, n, device);
+        st = fm_from_device_bwt(f, (const uint8_t *)b.dev, n, device);
     if (st != SDSL_HIP_OK)
     {
         fm_free(f);
@@ -317,12 +308,12 @@ sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_te
                       (unsigned long long)i);
             return SDSL_HIP_ERR_INVALID;
         }
-    std::vector<uint8_t> bwt;
-    SH_TRY(sa_build_bwt_device(host, n_text, device, bwt));
+    DevBuf d_bwt;
+    SH_TRY(sa_build_bwt_device(host, n_text, device, d_bwt)); // suffix array and BWT never leave the device
     sdsl_hip_fm_s * f = new (std::nothrow) sdsl_hip_fm_s();
     if (!f)
         return SDSL_HIP_ERR_NOMEM;
-    sdsl_hip_status st = fm_from_host_bwt(f, bwt.data(), bwt.size(), device);
+    sdsl_hip_status st = fm_from_device_bwt(f, d_bwt.as<uint8_t>(), n_text + 1, device);
     if (st != SDSL_HIP_OK)
     {
         fm_free(f);

@@ -82,7 +82,22 @@ sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint
     return SDSL_HIP_OK;
 }
 
-sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, std::vector<uint8_t> & bwt)
+// Stable sort of u16 keys by the bit range [begin_bit, end_bit) only (wt.hip: one wavelet-tree level)
+sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
+                              hipStream_t s)
+{
+    size_t bytes = 0;
+    SH_HIP(rocprim::radix_sort_keys(nullptr, bytes, keys_in, keys_out, (size_t)n, begin_bit, end_bit, s));
+    void * tmp = nullptr;
+    SH_HIP(hipMallocAsync(&tmp, bytes ? bytes : 16, s));
+    hipError_t e = rocprim::radix_sort_keys(tmp, bytes, keys_in, keys_out, (size_t)n, begin_bit, end_bit, s);
+    (void)hipFreeAsync(tmp, s);
+    SH_HIP(e);
+    return SDSL_HIP_OK;
+}
+
+// BWT of text+'\0' left in device memory (d_bwt, n_text+1 bytes)
+sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, DevBuf & d_bwt)
 {
     const uint64_t n = n_text + 1;
     if (n >= UINT64_C(0xFFFFFFFE))
@@ -143,12 +158,10 @@ sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, 
         end_bit = 2 * rank_bits;
         k <<= 1;
     }
-    DevBuf d_bwt;
     SH_TRY(d_bwt.alloc(n));
     hipLaunchKernelGGL(k_sa_bwt, dim3(grid), dim3(256), 0, 0, d_s.as<uint8_t>(), i1, n, d_bwt.as<uint8_t>());
     SH_HIP(hipGetLastError());
-    bwt.resize(n);
-    SH_HIP(hipMemcpy(bwt.data(), d_bwt.p, n, hipMemcpyDeviceToHost));
+    SH_HIP(hipDeviceSynchronize());
     return SDSL_HIP_OK;
 }
 

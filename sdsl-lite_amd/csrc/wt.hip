@@ -148,41 +148,163 @@ static sdsl_hip_status upload(WtHost & wt, const std::vector<uint64_t> & words, 
     return SDSL_HIP_OK;
 }
 
-sdsl_hip_status wt_build_from_text(WtHost & wt, const uint8_t * text, uint64_t n, int device)
+// ---- device-side construction of the bit vector ---------------------------------------------------------------
+// SDSL appends one bit per symbol per level at the cursor of the node on the symbol's path (wt_pc.hpp:97-111,
+// 218-242).  The result has a closed form that maps onto sorts: inner nodes are laid out in BFS order, i.e. level by
+// level, and inside a level a node's slice lists its symbols in text order.  So the bits of level d are: take the
+// text, keep the symbols whose code is longer than d, stable-sort them by the BFS index of their depth-d ancestor,
+// and emit bit d of each code.  One 9-bit stable radix sort per level, independent of the other levels.
+struct WtLevelKeys
 {
-    memset(wt.occ, 0, sizeof wt.occ);
-    for (uint64_t i = 0; i < n; ++i)
-        ++wt.occ[text[i]];
+    uint16_t key[256]; // (BFS index of the depth-d ancestor << 1) | code bit d; 0xFFFF if the code is shorter
+};
+
+__global__ __launch_bounds__(256) void k_wt_hist(const uint8_t * __restrict__ text, uint64_t n,
+                                                 unsigned long long * __restrict__ occ)
+{
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&h[text[i]], 1u);
+    __syncthreads();
+    if (h[threadIdx.x])
+        atomicAdd(&occ[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_wt_level_keys(const uint8_t * __restrict__ text, uint64_t n, WtLevelKeys tab,
+                                                       uint16_t * __restrict__ keys)
+{
+    __shared__ uint16_t k[256];
+    k[threadIdx.x] = tab.key[threadIdx.x];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        keys[i] = k[text[i]];
+}
+
+// thread t packs the code bits of sorted elements [64t, 64t+64) into bit positions level_start + 64t ...
+__global__ __launch_bounds__(256) void k_wt_pack_level(const uint16_t * __restrict__ sorted, uint64_t alive,
+                                                       uint64_t level_start, unsigned long long * __restrict__ words)
+{
+    const uint64_t chunks = (alive + 63) >> 6;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < chunks; t += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t v = 0;
+        const uint64_t base = t << 6;
+        const unsigned cnt = (unsigned)(alive - base < 64 ? alive - base : 64);
+        for (unsigned j = 0; j < cnt; ++j)
+            v |= (uint64_t)(sorted[base + j] & 1u) << j;
+        const uint64_t pos = level_start + base;
+        const unsigned off = (unsigned)(pos & 63);
+        if (v)
+        {
+            atomicOr(&words[pos >> 6], (unsigned long long)(v << off));
+            if (off && (v >> (64 - off)))
+                atomicOr(&words[(pos >> 6) + 1], (unsigned long long)(v >> (64 - off)));
+        }
+    }
+}
+
+__global__ void k_wt_node_positions(const WtTables * __restrict__ T, uint32_t n_nodes, uint64_t * __restrict__ pos)
+{
+    for (uint32_t v = threadIdx.x; v < n_nodes; v += blockDim.x)
+        pos[v] = T->bv_pos[v];
+}
+
+sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
+                              hipStream_t s);
+
+sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device)
+{
+    SH_HIP(hipSetDevice(device));
+    wt.device = device;
     wt.size = n;
+    // 1. symbol histogram
+    {
+        DevBuf d_occ;
+        SH_TRY(d_occ.alloc(256 * 8, true));
+        if (n)
+            hipLaunchKernelGGL(k_wt_hist, dim3(grid_for(n, 256 * 16, 256u * 8u)), dim3(256), 0, 0, d_text, n,
+                               d_occ.as<unsigned long long>());
+        SH_HIP(hipGetLastError());
+        SH_HIP(hipMemcpy(wt.occ, d_occ.p, 256 * 8, hipMemcpyDeviceToHost));
+    }
+    // 2. shape
     uint64_t bv_size = 0;
     SH_TRY(build_shape(wt.occ, wt.tables, wt.n_nodes, bv_size, wt.sigma));
     WtTables & T = wt.tables;
-    std::vector<uint64_t> words(((bv_size + 63) >> 6) + 1, 0);
-    // every symbol appends one bit at the cursor of each node on its path
-    std::vector<uint64_t> cursor(T.bv_pos, T.bv_pos + kWtMaxNodes);
-    for (uint64_t i = 0; i < n; ++i)
+    // 3. bits, level by level
+    const uint64_t nw = (bv_size + 63) >> 6;
+    DevBuf d_words;
+    SH_TRY(d_words.alloc((nw + 2) * 8, true));
+    if (bv_size)
     {
-        uint64_t p = T.path[text[i]];
-        unsigned len = (unsigned)(p >> 56), v = 0;
-        for (unsigned l = 0; l < len; ++l, p >>= 1)
+        DevBuf k0, k1;
+        SH_TRY(k0.alloc(n * 2));
+        SH_TRY(k1.alloc(n * 2));
+        uint64_t level_start = 0;
+        for (unsigned d = 0; d < 57; ++d)
         {
-            uint64_t pos = cursor[v]++;
-            unsigned bit = (unsigned)(p & 1);
-            words[pos >> 6] |= (uint64_t)bit << (pos & 63);
-            v = T.child[v][bit];
+            WtLevelKeys tab;
+            uint64_t alive = 0;
+            for (int c = 0; c < 256; ++c)
+            {
+                tab.key[c] = 0xFFFF;
+                if (T.c_to_leaf[c] == kWtUndef)
+                    continue;
+                uint64_t p = T.path[c];
+                unsigned len = (unsigned)(p >> 56);
+                if (len <= d)
+                    continue;
+                unsigned v = 0;
+                for (unsigned l = 0; l < d; ++l)
+                    v = T.child[v][(p >> l) & 1];
+                tab.key[c] = (uint16_t)((v << 1) | ((p >> d) & 1));
+                alive += wt.occ[c];
+            }
+            if (alive == 0)
+                break;
+            hipLaunchKernelGGL(k_wt_level_keys, dim3(grid_for(n, 256 * 8, 256u * 8u)), dim3(256), 0, 0, d_text, n, tab,
+                               k0.as<uint16_t>());
+            SH_HIP(hipGetLastError());
+            SH_TRY(sort_keys_u16(k0.as<uint16_t>(), k1.as<uint16_t>(), n, 1u, 10u, nullptr)); // dead keys sort last
+            hipLaunchKernelGGL(k_wt_pack_level, dim3(grid_for((alive + 63) >> 6, 256, 256u * 8u)), dim3(256), 0, 0,
+                               k1.as<uint16_t>(), alive, level_start, d_words.as<unsigned long long>());
+            SH_HIP(hipGetLastError());
+            level_start += alive;
+        }
+        if (level_start != bv_size)
+        {
+            set_error("internal: wavelet-tree levels cover %llu of %llu bits", (unsigned long long)level_start,
+                      (unsigned long long)bv_size);
+            return SDSL_HIP_ERR_HIP;
         }
     }
-    // bv_pos_rank of inner nodes = ones before the slice; slices are contiguous in BFS order
-    uint64_t run = 0;
-    for (uint32_t v = 0; v < wt.n_nodes; ++v)
+    // 4. rank lines + select directories
+    wt.bv.device = device;
+    SH_TRY(bv_build_from_device_words(wt.bv, d_words.as<uint64_t>(), bv_size, SDSL_HIP_BV_SELECT1 | SDSL_HIP_BV_SELECT0,
+                                      default_sel_shift()));
+    d_words.release();
+    // 5. bv_pos_rank of the inner nodes = rank_1 at the start of their slices (wt_helper.hpp:320-327)
+    SH_TRY(wt.d_tables.alloc(sizeof(WtTables)));
+    SH_HIP(hipMemcpy(wt.d_tables.p, &T, sizeof(WtTables), hipMemcpyHostToDevice));
+    if (wt.n_nodes)
     {
-        if (T.child[v][0] == kWtUndef)
-            continue;
-        uint64_t end = v + 1 < wt.n_nodes ? T.bv_pos[v + 1] : bv_size;
-        T.bv_pos_rank[v] = run;
-        run += popcount_range(words.data(), T.bv_pos[v], end);
+        DevBuf d_pos, d_rank;
+        SH_TRY(d_pos.alloc(wt.n_nodes * 8));
+        SH_TRY(d_rank.alloc(wt.n_nodes * 8));
+        hipLaunchKernelGGL(k_wt_node_positions, dim3(1), dim3(256), 0, 0, wt.d_tables.as<WtTables>(), wt.n_nodes,
+                           d_pos.as<uint64_t>());
+        SH_HIP(hipGetLastError());
+        SH_TRY(bv_launch_rank(wt.bv.view, 1, d_pos.as<uint64_t>(), wt.n_nodes, d_rank.as<uint64_t>(), nullptr));
+        std::vector<uint64_t> ranks(wt.n_nodes);
+        SH_HIP(hipMemcpy(ranks.data(), d_rank.p, wt.n_nodes * 8, hipMemcpyDeviceToHost));
+        for (uint32_t v = 0; v < wt.n_nodes; ++v)
+            if (T.child[v][0] != kWtUndef)
+                T.bv_pos_rank[v] = ranks[v];
+        SH_HIP(hipMemcpy(wt.d_tables.p, &T, sizeof(WtTables), hipMemcpyHostToDevice));
     }
-    return upload(wt, words, bv_size, device);
+    return SDSL_HIP_OK;
 }
 
 sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, bool select_is_mcl, int device)
@@ -444,20 +566,6 @@ sdsl_hip_status sdsl_hip_wt_finish(sdsl_hip_wt_s * w)
     return SDSL_HIP_OK;
 }
 
-// Host copy of a byte array that may live on the device.
-static sdsl_hip_status host_bytes(const uint8_t * p, uint64_t n, std::vector<uint8_t> & tmp, const uint8_t *& host)
-{
-    if (n && is_device_ptr(p))
-    {
-        tmp.resize(n);
-        SH_HIP(hipMemcpy(tmp.data(), p, n, hipMemcpyDeviceToHost));
-        host = tmp.data();
-    }
-    else
-        host = p;
-    return SDSL_HIP_OK;
-}
-
 extern "C" {
 
 sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t device, sdsl_hip_wt_t * out)
@@ -472,11 +580,10 @@ sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t dev
     sdsl_hip_wt_s * w = sdsl_hip_wt_alloc();
     if (!w)
         return SDSL_HIP_ERR_NOMEM;
-    std::vector<uint8_t> tmp;
-    const uint8_t * host = nullptr;
-    sdsl_hip_status st = host_bytes(text, n, tmp, host);
+    Staged t;
+    sdsl_hip_status st = t.in(text, n, nullptr); // host bytes are uploaded; device bytes are used where they are
     if (st == SDSL_HIP_OK)
-        st = wt_build_from_text(w->h, host, n, device);
+        st = wt_build_from_device_text(w->h, (const uint8_t *)t.dev, n, device);
     if (st == SDSL_HIP_OK)
         st = sdsl_hip_wt_finish(w);
     if (st != SDSL_HIP_OK)

@@ -31,8 +31,9 @@ struct WtHost
     }
 };
 
-// Builds shape + bit vector on the host from the symbol sequence (host pointer) and uploads.
-sdsl_hip_status wt_build_from_text(WtHost & wt, const uint8_t * text, uint64_t n, int device);
+// Builds the tree shape on the host (a 256-entry histogram decides it) and the bit vector on the device, one
+// stable radix sort per tree level, from a symbol sequence that already lives in device memory.
+sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device);
 // Parses wt_pc::serialize output (wt_pc.hpp:713-726) and uploads; advances the reader.
 sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, bool select_is_mcl, int device);
 
