@@ -122,6 +122,29 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t * __restrict_
     }
 }
 
+// out[i * stride] = sum of in[0..i); *total (host) = sum of all.  Asynchronous on the null stream except for the total.
+sdsl_hip_status device_exclusive_scan_u32(const uint32_t * d_in, uint64_t n, uint64_t * d_out, uint64_t stride,
+                                          uint64_t * total)
+{
+    const uint64_t nb = (n + kScanPerBlock - 1) / kScanPerBlock;
+    DevBuf bsum;
+    SH_TRY(bsum.alloc((nb + 1) * sizeof(uint64_t), true));
+    if (n)
+    {
+        hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, 0, d_in, n, bsum.as<uint64_t>());
+        SH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, 0, bsum.as<uint64_t>(), nb);
+        SH_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, 0, d_in, n, bsum.as<uint64_t>(), d_out, stride);
+        SH_HIP(hipGetLastError());
+    }
+    if (total)
+        SH_HIP(hipMemcpy(total, bsum.as<uint64_t>() + nb, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    else
+        SH_HIP(hipDeviceSynchronize()); // bsum is released on return
+    return SDSL_HIP_OK;
+}
+
 // select samples: sample[j] = (position of the BIT-argument of 0-based rank j << shift) >> pshift
 template <int BIT>
 __global__ __launch_bounds__(256) void k_build_sel(const uint64_t * __restrict__ lines,
@@ -232,17 +255,7 @@ sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words
                        cnts);
     SH_HIP(hipGetLastError());
 
-    const uint64_t nb = (nl + kScanPerBlock - 1) / kScanPerBlock;
-    DevBuf bsum;
-    SH_TRY(bsum.alloc((nb + 1) * sizeof(uint64_t)));
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(256), 0, 0, cnts, nl, bsum.as<uint64_t>());
-    SH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, 0, bsum.as<uint64_t>(), nb);
-    SH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, 0, cnts, nl, bsum.as<uint64_t>(), lines,
-                       (uint64_t)kLW);
-    SH_HIP(hipGetLastError());
-    SH_HIP(hipMemcpy(&bv.view.ones, bsum.as<uint64_t>() + nb, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    SH_TRY(device_exclusive_scan_u32(cnts, nl, lines, (uint64_t)kLW, &bv.view.ones)); // headers = word 0 of every line
 
     if (bv.view.sel_shift == 0)
     { // one rate for both directories: at most 2^19 four-byte samples (2 MiB) per directory, so that the

@@ -24,8 +24,7 @@
 #include <mutex>
 #include <thread>
 
-#include "bv_device.hpp"
-#include "common.hpp"
+#include "bv_host.hpp"
 #include "sdsl_stream.hpp"
 
 namespace sdslhip {
@@ -85,22 +84,7 @@ static const RrrTables & host_tables()
     return g_host_tables;
 }
 
-// offset of a 63-bit block inside its class (combinatorial number system, positions counted from the
-// least significant bit; matches the bytes SDSL writes so that its streams can be loaded as they are)
-static uint64_t encode_block(uint64_t bits, unsigned k, const RrrTables & T)
-{
-    uint64_t nr = 0;
-    while (bits)
-    {
-        unsigned p = (unsigned)__builtin_ctzll(bits);
-        nr += T.binom[62 - p][k];
-        --k;
-        bits &= bits - 1;
-    }
-    return nr;
-}
-
-struct RrrArrays // the host image both creation paths produce
+struct RrrArrays // host image of a parsed SDSL stream
 {
     uint64_t n_bits = 0, n_blocks = 0, n_sb = 0, ones = 0;
     std::vector<uint8_t> cls;      // n_sb*32 actual classes
@@ -109,103 +93,6 @@ struct RrrArrays // the host image both creation paths produce
     std::vector<uint64_t> sb_rank; // ones before each superblock
     std::vector<uint64_t> sb_ptr;  // stream position of each superblock
 };
-
-static void atomic_or_bits(uint64_t * d, uint64_t pos, uint64_t v, unsigned len)
-{
-    if (!len)
-        return;
-    unsigned off = (unsigned)(pos & 63);
-    __atomic_fetch_or(&d[pos >> 6], v << off, __ATOMIC_RELAXED);
-    if (off + len > 64)
-        __atomic_fetch_or(&d[(pos >> 6) + 1], v >> (64 - off), __ATOMIC_RELAXED);
-}
-
-static void rrr_encode_host(const uint64_t * words, uint64_t n, RrrArrays & A)
-{
-    const RrrTables & T = host_tables();
-    A.n_bits = n;
-    A.n_blocks = (n + kRrrBS) / kRrrBS; // one all-zero dummy block when 63 | n (rrr_vector.hpp:163)
-    A.n_sb = (A.n_blocks + kRrrK - 1) / kRrrK;
-    A.cls.assign(A.n_sb * kRrrK, 0);
-    A.sb_rank.assign(A.n_sb + 1, 0);
-    A.sb_ptr.assign(A.n_sb + 1, 0);
-    const uint64_t nw = (n + 63) >> 6;
-    auto block_bits = [&](uint64_t b) -> uint64_t {
-        uint64_t pos = b * kRrrBS;
-        if (pos >= n)
-            return 0;
-        unsigned len = (unsigned)std::min<uint64_t>(kRrrBS, n - pos);
-        uint64_t wi = pos >> 6;
-        unsigned off = (unsigned)(pos & 63);
-        uint64_t v = words[wi] >> off;
-        if (off + len > 64 && wi + 1 < nw)
-            v |= words[wi + 1] << (64 - off);
-        return v & lo_set(len);
-    };
-    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
-    if (A.n_sb < 4096)
-        nt = 1;
-    auto chunk = [&](unsigned t) { return std::make_pair(A.n_sb * t / nt, A.n_sb * (t + 1) / nt); };
-    // pass 1: classes, per-superblock ones and offset lengths
-    std::vector<uint64_t> sb_len(A.n_sb + 1, 0);
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t)
-            th.emplace_back([&, t] {
-                auto r = chunk(t);
-                for (uint64_t s = r.first; s < r.second; ++s)
-                {
-                    uint64_t ones = 0, len = 0;
-                    for (unsigned j = 0; j < kRrrK; ++j)
-                    {
-                        uint64_t b = s * kRrrK + j;
-                        if (b >= A.n_blocks)
-                            break;
-                        unsigned k = popc64(block_bits(b));
-                        A.cls[b] = (uint8_t)k;
-                        ones += k;
-                        len += T.space[k];
-                    }
-                    A.sb_rank[s + 1] = ones;
-                    sb_len[s] = len;
-                }
-            });
-        for (auto & x : th)
-            x.join();
-    }
-    for (uint64_t s = 0; s < A.n_sb; ++s)
-    {
-        A.sb_rank[s + 1] += A.sb_rank[s];
-        A.sb_ptr[s + 1] = A.sb_ptr[s] + sb_len[s];
-    }
-    A.ones = A.sb_rank[A.n_sb];
-    A.stream_bits = A.sb_ptr[A.n_sb];
-    A.stream.assign(((std::max<uint64_t>(A.stream_bits, 64) + 63) >> 6) + 2, 0);
-    // pass 2: offsets
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t)
-            th.emplace_back([&, t] {
-                auto r = chunk(t);
-                for (uint64_t s = r.first; s < r.second; ++s)
-                {
-                    uint64_t pos = A.sb_ptr[s];
-                    for (unsigned j = 0; j < kRrrK; ++j)
-                    {
-                        uint64_t b = s * kRrrK + j;
-                        if (b >= A.n_blocks)
-                            break;
-                        unsigned k = A.cls[b], len = T.space[k];
-                        if (len)
-                            atomic_or_bits(A.stream.data(), pos, encode_block(block_bits(b), k, T), len);
-                        pos += len;
-                    }
-                }
-            });
-        for (auto & x : th)
-            x.join();
-    }
-}
 
 // rrr_vector<63>::load layout (rrr_vector.hpp:366-378,381-392)
 static sdsl_hip_status rrr_parse_sdsl(StreamReader & rd, RrrArrays & A)
@@ -609,6 +496,135 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint6
     }
 }
 
+// ---- device-side encoder (rrr_vector(bit_vector const&), rrr_vector.hpp:158-270) -------------------------------
+// the 63 bits of block b (masked to n_bits)
+__device__ __forceinline__ uint64_t rrr_block_bits(const uint64_t * __restrict__ words, uint64_t n_bits, uint64_t b)
+{
+    uint64_t pos = b * kRrrBS;
+    if (pos >= n_bits)
+        return 0;
+    unsigned len = (unsigned)(n_bits - pos < kRrrBS ? n_bits - pos : kRrrBS);
+    uint64_t wi = pos >> 6;
+    unsigned off = (unsigned)(pos & 63);
+    uint64_t v = words[wi] >> off;
+    if (off + len > 64)
+        v |= words[wi + 1] << (64 - off); // the caller pads the word array by one
+    return v & lo_set(len);
+}
+
+// pass 1, one thread per superblock: class bytes into the record, ones and offset bits of the superblock
+__global__ __launch_bounds__(256) void k_rrr_enc_classes(const uint64_t * __restrict__ words, uint64_t n_bits,
+                                                         uint64_t n_blocks, uint64_t n_sb,
+                                                         const RrrTables * __restrict__ tables, uint64_t * __restrict__ rec,
+                                                         uint32_t * __restrict__ sb_ones, uint32_t * __restrict__ sb_len)
+{
+    __shared__ uint8_t space[64];
+    if (threadIdx.x < 64)
+        space[threadIdx.x] = tables->space[threadIdx.x];
+    __syncthreads();
+    for (uint64_t sb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sb < n_sb; sb += (uint64_t)gridDim.x * blockDim.x)
+    {
+        unsigned ones = 0, len = 0;
+        uint64_t cw[4] = {0, 0, 0, 0};
+        for (unsigned j = 0; j < kRrrK; ++j)
+        {
+            uint64_t b = sb * kRrrK + j;
+            if (b >= n_blocks)
+                break;
+            unsigned k = popc64(rrr_block_bits(words, n_bits, b));
+            cw[j >> 3] |= (uint64_t)k << (8 * (j & 7));
+            ones += k;
+            len += space[k];
+        }
+        uint64_t * r = rec + sb * kRecWords;
+        r[2] = cw[0];
+        r[3] = cw[1];
+        r[4] = cw[2];
+        r[5] = cw[3];
+        sb_ones[sb] = ones;
+        sb_len[sb] = len;
+    }
+}
+
+// pass 2, one thread per superblock (headers r[0] = ones before, r[1] = stream pointer are in place): offsets into
+// the stream and the record's inline area, select samples for both bit values
+__global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __restrict__ words, uint64_t n_bits,
+                                                         uint64_t n_blocks, uint64_t n_sb,
+                                                         const RrrTables * __restrict__ tables, uint64_t * __restrict__ rec,
+                                                         const uint32_t * __restrict__ sb_ones,
+                                                         unsigned long long * __restrict__ stream, uint32_t sh, uint32_t ps,
+                                                         uint32_t * __restrict__ sel1, uint32_t * __restrict__ sel0)
+{
+    __shared__ RrrTables T;
+    rrr_stage_tables(&T, tables);
+    const uint64_t S = UINT64_C(1) << sh;
+    for (uint64_t sb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sb < n_sb; sb += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t * r = rec + sb * kRecWords;
+        const uint64_t ones_before = r[0], ptr = r[1];
+        const uint64_t start = sb * kRrrSB;
+        uint64_t acc1 = ones_before, acc0 = start - ones_before; // arguments before the current block
+        uint64_t j1 = (acc1 + S - 1) >> sh, j0 = (acc0 + S - 1) >> sh;
+        uint64_t inl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned rel = 0;
+        for (unsigned j = 0; j < kRrrK; ++j)
+        {
+            const uint64_t b = sb * kRrrK + j;
+            if (b >= n_blocks)
+                break;
+            const uint64_t bstart = b * kRrrBS;
+            const unsigned blen = bstart >= n_bits ? 0u : (unsigned)(n_bits - bstart < kRrrBS ? n_bits - bstart : kRrrBS);
+            const uint64_t bits = rrr_block_bits(words, n_bits, b);
+            const unsigned k = popc64(bits), len = T.space[k];
+            if (len)
+            {
+                uint64_t nr = 0, x = bits;
+                unsigned kk = k;
+                while (x)
+                { // combinatorial number system, positions from the least significant bit
+                    unsigned p = (unsigned)__ffsll((long long)x) - 1;
+                    nr += T.binom[62 - p][kk];
+                    --kk;
+                    x &= x - 1;
+                }
+                const uint64_t pos = ptr + rel;
+                const unsigned off = (unsigned)(pos & 63);
+                atomicOr(&stream[pos >> 6], (unsigned long long)(nr << off));
+                if (off + len > 64)
+                    atomicOr(&stream[(pos >> 6) + 1], (unsigned long long)(nr >> (64 - off)));
+                if (rel < kInlineBits)
+                { // inline copy of the first 640 offset bits (a field may be cut by the boundary; readers only
+                  // use the inline area for fields that lie in it completely)
+                    const unsigned w = rel >> 6, o = rel & 63;
+                    inl[w] |= nr << o;
+                    if (o + len > 64 && w + 1 < 10)
+                        inl[w + 1] |= nr >> (64 - o);
+                }
+            }
+            rel += len;
+            // select samples that fall into this block
+            while ((j1 << sh) < acc1 + k)
+            {
+                sel1[j1] = (uint32_t)((bstart + sel64(bits, (unsigned)((j1 << sh) - acc1) + 1)) >> ps);
+                ++j1;
+            }
+            const uint64_t zb = ~bits & lo_set(blen);
+            while ((j0 << sh) < acc0 + (blen - k))
+            {
+                sel0[j0] = (uint32_t)((bstart + sel64(zb, (unsigned)((j0 << sh) - acc0) + 1)) >> ps);
+                ++j0;
+            }
+            acc1 += k;
+            acc0 += blen - k;
+        }
+        if (rel < kInlineBits && (rel & 63))
+            inl[rel >> 6] &= lo_set(rel & 63);
+        for (unsigned w = 0; w < 10; ++w)
+            r[6 + w] = w * 64 < rel ? inl[w] : 0;
+        r[1] = ptr | ((uint64_t)sb_ones[sb] << 48);
+    }
+}
+
 struct RrrHost
 {
     int device = 0;
@@ -754,6 +770,75 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     return SDSL_HIP_OK;
 }
 
+__global__ void k_rrr_set_sentinels(uint32_t * a, uint64_t ia, uint32_t * b, uint64_t ib, uint32_t v)
+{
+    a[ia] = v;
+    b[ib] = v;
+}
+
+// rrr_vector<63>(bit_vector const&) on the device: words (device memory) -> records, stream, directories
+static sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t n_bits, int device)
+{
+    h.device = device;
+    const RrrTables & T = host_tables();
+    const uint64_t n_blocks = (n_bits + kRrrBS) / kRrrBS; // one all-zero dummy block when 63 | n (rrr_vector.hpp:163)
+    const uint64_t n_sb = (n_blocks + kRrrK - 1) / kRrrK;
+    if (n_sb > UINT64_C(0xFFFFFFFF))
+    {
+        set_error("rrr_vector too large for the device record format");
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    SH_TRY(h.tables.alloc(sizeof(RrrTables)));
+    SH_HIP(hipMemcpy(h.tables.p, &T, sizeof(RrrTables), hipMemcpyHostToDevice));
+    SH_TRY(h.rec.alloc(n_sb * kRecWords * 8, true));
+    DevBuf sb_ones, sb_len;
+    SH_TRY(sb_ones.alloc(n_sb * 4));
+    SH_TRY(sb_len.alloc(n_sb * 4));
+    const unsigned grid = grid_for(n_sb, 256, 65536);
+    hipLaunchKernelGGL(k_rrr_enc_classes, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
+                       h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(), sb_len.as<uint32_t>());
+    SH_HIP(hipGetLastError());
+    uint64_t ones = 0, stream_bits = 0;
+    SH_TRY(device_exclusive_scan_u32(sb_ones.as<uint32_t>(), n_sb, h.rec.as<uint64_t>(), kRecWords, &ones));
+    SH_TRY(device_exclusive_scan_u32(sb_len.as<uint32_t>(), n_sb, h.rec.as<uint64_t>() + 1, kRecWords, &stream_bits));
+    if (stream_bits >= (UINT64_C(1) << 48))
+    {
+        set_error("rrr_vector offset stream too large for the device record format");
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    const uint64_t zeros = n_bits - ones;
+    uint32_t sh = 8; // smallest power of two >= 256 that keeps a directory within 2^21 samples
+    while (sh < 20 && (std::max(ones, zeros) >> sh) > (UINT64_C(1) << 21))
+        ++sh;
+    uint32_t ps = 0;
+    while ((n_bits >> ps) >= UINT64_C(0xFFFFFFFF))
+        ++ps;
+    const uint64_t ns1 = (ones + (UINT64_C(1) << sh) - 1) >> sh, ns0 = (zeros + (UINT64_C(1) << sh) - 1) >> sh;
+    SH_TRY(h.stream.alloc((((std::max<uint64_t>(stream_bits, 64) + 63) >> 6) + 2) * 8, true));
+    SH_TRY(h.sel[1].alloc((ns1 + 2) * 4, true));
+    SH_TRY(h.sel[0].alloc((ns0 + 2) * 4, true));
+    hipLaunchKernelGGL(k_rrr_enc_offsets, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
+                       h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(),
+                       h.stream.as<unsigned long long>(), sh, ps, h.sel[1].as<uint32_t>(), h.sel[0].as<uint32_t>());
+    SH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_rrr_set_sentinels, dim3(1), dim3(1), 0, 0, h.sel[1].as<uint32_t>(), ns1, h.sel[0].as<uint32_t>(),
+                       ns0, (uint32_t)(n_bits >> ps));
+    SH_HIP(hipGetLastError());
+    SH_HIP(hipDeviceSynchronize());
+    h.view.rec = h.rec.as<uint64_t>();
+    h.view.stream = h.stream.as<uint64_t>();
+    h.view.tables = h.tables.as<RrrTables>();
+    h.view.sel[0] = h.sel[0].as<uint32_t>();
+    h.view.sel[1] = h.sel[1].as<uint32_t>();
+    h.view.n_bits = n_bits;
+    h.view.n_blocks = n_blocks;
+    h.view.n_sb = n_sb;
+    h.view.ones = ones;
+    h.view.sel_shift = sh;
+    h.view.sel_pshift = ps;
+    return SDSL_HIP_OK;
+}
+
 } // namespace sdslhip
 
 using namespace sdslhip;
@@ -774,21 +859,13 @@ sdsl_hip_status sdsl_hip_rrr_create(const uint64_t * words, uint64_t n_bits, int
     }
     *out = nullptr;
     SH_TRY(check_device(device));
-    std::vector<uint64_t> tmp;
-    const uint64_t * host = words;
-    uint64_t nw = (n_bits + 63) >> 6;
-    if (nw && is_device_ptr(words))
-    {
-        tmp.resize(nw);
-        SH_HIP(hipMemcpy(tmp.data(), words, nw * 8, hipMemcpyDeviceToHost));
-        host = tmp.data();
-    }
     sdsl_hip_rrr_s * r = new (std::nothrow) sdsl_hip_rrr_s();
     if (!r)
         return SDSL_HIP_ERR_NOMEM;
-    RrrArrays A;
-    rrr_encode_host(host, n_bits, A);
-    sdsl_hip_status st = rrr_upload(r->h, A, device);
+    Staged w; // host words are uploaded, device words are encoded where they are
+    sdsl_hip_status st = w.in(words, ((n_bits + 63) >> 6) * 8, nullptr);
+    if (st == SDSL_HIP_OK)
+        st = rrr_build_device(r->h, (const uint64_t *)w.dev, n_bits, device);
     if (st != SDSL_HIP_OK)
     {
         delete r;
