@@ -100,6 +100,10 @@ sdsl_hip_status sdsl_hip_bv_export_words(sdsl_hip_bv_t bv, uint64_t * words_out,
 sdsl_hip_status sdsl_hip_rrr_create(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_rrr_t * out);
 /* from the bytes written by rrr_vector<63>::serialize (rrr_vector.hpp:366-378) */
 sdsl_hip_status sdsl_hip_rrr_create_from_sdsl(const void * bytes, size_t len, int32_t device, sdsl_hip_rrr_t * out);
+/* Writes exactly the bytes rrr_vector<63>::serialize would write for the same bit vector (rrr_vector.hpp:366-378):
+ * size, bt (with SDSL's superblock inversion, :203-228), btnr, btnrp, rank samples, invert.  buf == NULL queries the
+ * size.  An index encoded on the GPU can thus be handed to unmodified SDSL code (load / load_from_file). */
+sdsl_hip_status sdsl_hip_rrr_serialize(sdsl_hip_rrr_t v, void * buf, size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_rrr_destroy(sdsl_hip_rrr_t v);
 uint64_t sdsl_hip_rrr_size(sdsl_hip_rrr_t v);
 uint64_t sdsl_hip_rrr_ones(sdsl_hip_rrr_t v);
@@ -123,6 +127,10 @@ sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t dev
  * select_support_scan (serialises to zero bytes; benchmark/indexing_count/index.config:8). */
 sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int32_t select_is_mcl, int32_t device,
                                              sdsl_hip_wt_t * out, size_t * consumed);
+/* Writes the bytes of wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>::serialize
+ * (wt_pc.hpp:713-726: size, sigma, bv, rank_support_v5 directory, tree; scan supports serialise to nothing) for a
+ * wavelet tree that was built on the GPU.  buf == NULL queries the size. */
+sdsl_hip_status sdsl_hip_wt_serialize(sdsl_hip_wt_t wt, void * buf, size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_wt_destroy(sdsl_hip_wt_t wt);
 uint64_t sdsl_hip_wt_size(sdsl_hip_wt_t wt);     /* wt.size()  */
 uint64_t sdsl_hip_wt_sigma(sdsl_hip_wt_t wt);    /* wt.sigma   */

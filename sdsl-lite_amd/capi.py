@@ -42,6 +42,7 @@ SIGNATURES = {
     "sdsl_hip_bv_export_words": (C.c_int32, [_vp, _vp, _vp]),
     "sdsl_hip_rrr_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_rrr_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.POINTER(_vp)]),
+    "sdsl_hip_rrr_serialize": (C.c_int32, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sdsl_hip_rrr_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_rrr_size": (C.c_uint64, [_vp]),
     "sdsl_hip_rrr_ones": (C.c_uint64, [_vp]),
@@ -52,6 +53,7 @@ SIGNATURES = {
     "sdsl_hip_wt_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_wt_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp),
                                                  C.POINTER(C.c_size_t)]),
+    "sdsl_hip_wt_serialize": (C.c_int32, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sdsl_hip_wt_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_wt_size": (C.c_uint64, [_vp]),
     "sdsl_hip_wt_sigma": (C.c_uint64, [_vp]),

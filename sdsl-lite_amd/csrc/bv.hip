@@ -516,6 +516,14 @@ __global__ __launch_bounds__(256) void k_export_words(BvView bv, uint64_t * __re
     }
 }
 
+sdsl_hip_status bv_export_words_device(const BvView & v, uint64_t * d_words, uint64_t n_words, hipStream_t s)
+{
+    if (n_words)
+        hipLaunchKernelGGL(k_export_words, dim3(grid_for(n_words, 256, 65536)), dim3(256), 0, s, v, d_words, n_words);
+    SH_HIP(hipGetLastError());
+    return SDSL_HIP_OK;
+}
+
 static unsigned query_grid(uint64_t n, unsigned q_per_block)
 {
     // memory-latency bound gathers: fill every CU with 8 blocks of 256 threads, grid-stride the rest

@@ -900,6 +900,68 @@ sdsl_hip_status sdsl_hip_rrr_create_from_sdsl(const void * bytes, size_t len, in
     return SDSL_HIP_OK;
 }
 
+sdsl_hip_status sdsl_hip_rrr_serialize(sdsl_hip_rrr_t v, void * buf, size_t cap, size_t * written)
+{
+    if (!v)
+    {
+        set_error("rrr_serialize: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_HIP(hipSetDevice(v->h.device));
+    const RrrView & rv = v->h.view;
+    const uint64_t n = rv.n_bits, nb = rv.n_blocks, nsb = rv.n_sb;
+    std::vector<uint64_t> rec((size_t)nsb * kRecWords);
+    if (nsb)
+        SH_HIP(hipMemcpy(rec.data(), rv.rec, rec.size() * 8, hipMemcpyDeviceToHost));
+    // total offset bits = pointer of the last superblock + its own offsets
+    const RrrTables & T = host_tables();
+    auto cls = [&](uint64_t b) -> unsigned { return (unsigned)(rec[(b / kRrrK) * kRecWords + 2 + ((b % kRrrK) >> 3)] >> (8 * (b & 7))) & 0xFF; };
+    uint64_t stream_bits = 0;
+    if (nsb)
+    {
+        stream_bits = rec[(nsb - 1) * kRecWords + 1] & ((UINT64_C(1) << 48) - 1);
+        for (uint64_t b = (nsb - 1) * kRrrK; b < nb; ++b)
+            stream_bits += T.space[cls(b)];
+    }
+    const uint64_t btnr_bits = std::max<uint64_t>(stream_bits, 64); // rrr_vector.hpp:183
+    std::vector<uint64_t> btnr(((btnr_bits + 63) >> 6) + 1, 0);
+    SH_HIP(hipMemcpy(btnr.data(), rv.stream, ((btnr_bits + 63) >> 6) * 8, hipMemcpyDeviceToHost));
+    PackedBuilder bt(nb, 6), btnrp(nsb, (uint8_t)(hi64(stream_bits) + 1)), invert(nsb, 1);
+    const uint64_t n_rank = nsb + ((n % kRrrSB) > 0); // rrr_vector.hpp:185-186
+    PackedBuilder rank(n_rank, (uint8_t)(hi64(rv.ones) + 1));
+    for (uint64_t s = 0; s < nsb; ++s)
+    {
+        const uint64_t i = s * kRrrK;
+        // superblock inversion (rrr_vector.hpp:203-228): only decided inside the full-block loop, i.e. when block i
+        // is a complete 63-bit block, and only for superblocks with all 32 blocks present
+        bool inv = false;
+        if ((i + 1) * kRrrBS <= n && i + kRrrK <= nb)
+        {
+            unsigned gt = 0;
+            for (unsigned j = 0; j < kRrrK; ++j)
+                gt += cls(i + j) > kRrrBS / 2;
+            inv = gt > kRrrK / 2;
+        }
+        invert.set(s, inv);
+        for (uint64_t b = i; b < std::min(nb, i + kRrrK); ++b)
+            bt.set(b, inv ? kRrrBS - cls(b) : cls(b));
+        const bool dummy_only = i * kRrrBS >= n; // superblock that starts with the dummy block: never initialised by SDSL
+        btnrp.set(s, dummy_only ? 0 : (rec[s * kRecWords + 1] & ((UINT64_C(1) << 48) - 1)));
+        if (s + 1 < n_rank)
+            rank.set(s, rec[s * kRecWords]);
+    }
+    if (n_rank)
+        rank.set(n_rank - 1, rv.ones); // the last entry always holds the total (:268)
+    StreamWriter w;
+    w.u64(n);
+    bt.write(w);
+    w.int_vector(btnr.data(), btnr_bits, 1);
+    btnrp.write(w);
+    rank.write(w);
+    invert.write(w);
+    return deliver(w, buf, cap, written);
+}
+
 sdsl_hip_status sdsl_hip_rrr_destroy(sdsl_hip_rrr_t v)
 {
     if (!v)

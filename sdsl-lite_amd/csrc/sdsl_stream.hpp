@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "bits.hpp"
+#include "common.hpp"
 
 namespace sdslhip {
 
@@ -127,5 +128,69 @@ struct StreamReader
         return ok;
     }
 };
+
+// Writer for the same format (used by the *_serialize entry points: structures built on the GPU are handed
+// back to unmodified SDSL code as the bytes its own serialize() would have produced).
+struct StreamWriter
+{
+    std::vector<uint8_t> bytes;
+    void raw(const void * p, size_t n)
+    {
+        const uint8_t * b = (const uint8_t *)p;
+        bytes.insert(bytes.end(), b, b + n);
+    }
+    void u64(uint64_t v)
+    {
+        raw(&v, 8);
+    }
+    void u16(uint16_t v)
+    {
+        raw(&v, 2);
+    }
+    // int_vector<w>::serialize: header + ceil(bit_size/64) words (int_vector.hpp:904-916, 1978-2004)
+    void int_vector(const uint64_t * words, uint64_t bit_size, uint8_t width)
+    {
+        u64(((uint64_t)width << 56) | bit_size);
+        raw(words, (size_t)((bit_size + 63) >> 6) * 8);
+    }
+};
+
+// packed vector of fixed-width integers under construction (host)
+struct PackedBuilder
+{
+    std::vector<uint64_t> words;
+    uint64_t n;
+    uint8_t width;
+    PackedBuilder(uint64_t n_, uint8_t w) : words(((n_ * w + 63) >> 6) + 1, 0), n(n_), width(w)
+    {}
+    void set(uint64_t i, uint64_t v)
+    {
+        uint64_t pos = i * width;
+        unsigned off = (unsigned)(pos & 63);
+        v &= lo_set(width);
+        words[pos >> 6] |= v << off;
+        if (off + width > 64)
+            words[(pos >> 6) + 1] |= v >> (64 - off);
+    }
+    void write(StreamWriter & w) const
+    {
+        w.int_vector(words.data(), n * width, width);
+    }
+};
+
+inline sdsl_hip_status deliver(const StreamWriter & w, void * buf, size_t cap, size_t * written)
+{
+    if (written)
+        *written = w.bytes.size();
+    if (!buf)
+        return SDSL_HIP_OK; // size query
+    if (cap < w.bytes.size())
+    {
+        set_error("serialize: buffer of %zu bytes is too small for %zu", cap, w.bytes.size());
+        return SDSL_HIP_ERR_INVALID;
+    }
+    memcpy(buf, w.bytes.data(), w.bytes.size());
+    return SDSL_HIP_OK;
+}
 
 } // namespace sdslhip

@@ -623,6 +623,71 @@ sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int
     return SDSL_HIP_OK;
 }
 
+sdsl_hip_status sdsl_hip_wt_serialize(sdsl_hip_wt_t wt, void * buf, size_t cap, size_t * written)
+{
+    if (!wt)
+    {
+        set_error("wt_serialize: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    const WtHost & h = wt->h;
+    SH_HIP(hipSetDevice(h.device));
+    const uint64_t nb = h.bv.view.n_bits, W = (nb + 63) >> 6;
+    // the bit vector back in SDSL's word layout
+    std::vector<uint64_t> words(W + 1, 0);
+    if (W)
+    {
+        DevBuf d;
+        SH_TRY(d.alloc(W * 8));
+        SH_TRY(bv_export_words_device(h.bv.view, d.as<uint64_t>(), W, nullptr));
+        SH_HIP(hipMemcpy(words.data(), d.p, W * 8, hipMemcpyDeviceToHost));
+    }
+    // rank_support_v5 directory (rank_support_v5.hpp:68-124): per 2048-bit superblock the absolute count and five
+    // 11-bit counts of the 384-bit blocks before each block boundary, packed at shifts 48,36,24,12,0
+    std::vector<uint64_t> dir;
+    if (h.size == 0)
+        dir.clear(); // default-constructed support: empty int_vector<64>
+    else if (nb == 0)
+        dir.assign(2, 0);
+    else
+    {
+        const uint64_t nsb = ((nb + 63) >> 11) + 1;
+        dir.assign(2 * nsb, 0);
+        uint64_t abs = 0;
+        for (uint64_t s = 0; s < nsb; ++s)
+        {
+            dir[2 * s] = abs;
+            uint64_t rel = 0, packed = 0;
+            for (unsigned j = 0; j < 32 && 32 * s + j < W; ++j)
+            {
+                rel += popc64(words[32 * s + j]);
+                if ((j + 1) % 6 == 0 && j + 1 < 32)
+                    packed |= rel << (60 - 12 * ((j + 1) / 6));
+            }
+            dir[2 * s + 1] = packed;
+            abs += rel;
+        }
+    }
+    StreamWriter w;
+    w.u64(h.size);
+    w.u64(h.sigma);
+    w.int_vector(words.data(), nb, 1);
+    w.int_vector(dir.data(), dir.size() * 64, 64);
+    // select_support_scan<1>, select_support_scan<0>: nothing
+    w.u64(h.n_nodes);
+    for (uint32_t v = 0; v < h.n_nodes; ++v)
+    { // _node::serialize (wt_helper.hpp:139-150)
+        w.u64(h.tables.bv_pos[v]);
+        w.u64(h.tables.bv_pos_rank[v]);
+        w.u16(h.tables.parent[v]);
+        w.u16(h.tables.child[v][0]);
+        w.u16(h.tables.child[v][1]);
+    }
+    w.raw(h.tables.c_to_leaf, sizeof h.tables.c_to_leaf);
+    w.raw(h.tables.path, sizeof h.tables.path);
+    return deliver(w, buf, cap, written);
+}
+
 sdsl_hip_status sdsl_hip_wt_destroy(sdsl_hip_wt_t wt)
 {
     if (!wt)

@@ -184,6 +184,14 @@ def set_random_bits(n_bits: int, seed: int) -> np.ndarray:
     return w
 
 
+def _serialize(fn, handle) -> bytes:
+    need = C.c_size_t(0)
+    capi.check(fn(handle, None, 0, C.byref(need)))
+    buf = np.empty(max(1, need.value), dtype=np.uint8)
+    capi.check(fn(handle, _ptr(buf), need.value, C.byref(need)))
+    return buf[: need.value].tobytes()
+
+
 class rrr_vector(_Handle):
     """Device rrr_vector<63, int_vector<>, 32> with its rank/select supports (rrr_vector.hpp:68)."""
     _destroy = "sdsl_hip_rrr_destroy"
@@ -234,6 +242,10 @@ class rrr_vector(_Handle):
         capi.check(capi.lib().sdsl_hip_rrr_access_batch(self._h, _ptr(idx), n, _ptr(out), _stream_for(idx)))
         return out
 
+    def serialize(self) -> bytes:
+        """the bytes sdsl::rrr_vector<63>::serialize writes for the same bit vector"""
+        return _serialize(capi.lib().sdsl_hip_rrr_serialize, self._h)
+
     __getitem__ = access
 
 
@@ -277,6 +289,10 @@ class wt_huff(_Handle):
 
     def device_bytes(self) -> int:
         return capi.lib().sdsl_hip_wt_device_bytes(self._h)
+
+    def serialize(self) -> bytes:
+        """the bytes of wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>"""
+        return _serialize(capi.lib().sdsl_hip_wt_serialize, self._h)
 
     def code_lengths(self) -> np.ndarray:
         out = np.zeros(256, dtype=np.uint8)

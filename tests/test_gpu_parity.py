@@ -452,3 +452,34 @@ def test_malformed_streams(gpu, fname, kind):
             assert e.status in (gpu.capi.ERR_FORMAT, gpu.capi.ERR_UNSUPPORTED)
             bad += 1
     assert ok + bad == 300
+
+
+# ---------------------------------------------------------------------------------------------------
+# structures BUILT on the GPU serialise to exactly SDSL's bytes (so unmodified SDSL code can load them)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", gd.bv_case_names())
+def test_rrr_serialize_equals_sdsl_bytes(gpu, name):
+    import hashlib
+    g = gd.bv_golden()
+    w, n = gd.bv_case(name)
+    blob = gpu.rrr_vector(w, n).serialize()
+    assert hashlib.sha256(blob).hexdigest() == str(g[f"{name}/sha"][4])
+    if ol.have_ref():
+        assert blob == ol.RRrr(w, n).serialize()
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 2015, 2016, 2017, 63 * 32 * 2, 63 * 32 * 2 + 1, 100_000])
+@pytest.mark.parametrize("d", [0.5, 0.97, 0.03])
+def test_rrr_serialize_vs_oracle_bytes(gpu, n, d):
+    w = mk(n, d, n + 11)
+    assert gpu.rrr_vector(w, n).serialize() == ol.ORrr(w, n).serialize()
+
+
+@pytest.mark.parametrize("name", [t for t in gd.TEXTS if t != "empty.txt"])
+def test_wt_serialize_equals_sdsl_bytes(gpu, name):
+    import hashlib
+    g = gd.text_golden()
+    blob = gpu.wt_huff(gd.text(name)).serialize()
+    assert hashlib.sha256(blob).hexdigest() == str(g[f"{name}/sha"][1])  # the select_support_scan flavour
+    # and a tree loaded from SDSL's own bytes writes the same bytes back
+    assert gpu.wt_huff(sdsl_bytes=blob, select_is_mcl=False).serialize() == blob
