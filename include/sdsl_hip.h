@@ -166,6 +166,16 @@ sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_te
 /* from csa_wt::serialize bytes (csa_wt.hpp:389-402); SA/ISA samples are skipped */
 sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int32_t select_is_mcl, int32_t device,
                                              sdsl_hip_fm_t * out);
+/* An index created from text keeps its suffix array in HBM (4 bytes per suffix) so that it can be written out as a
+ * complete SDSL csa_wt: sdsl_hip_fm_serialize produces the bytes of
+ *   csa_wt<wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>, sa_dens, isa_dens>
+ * ::serialize (csa_wt.hpp:389-402: wavelet tree, SA samples every sa_dens-th suffix, ISA samples every isa_dens-th text
+ * position — csa_sampling_strategy.hpp:97-114,755-777 — and the byte alphabet), i.e. the index type of the reference's
+ * count benchmark (benchmark/indexing_count/index.config:8), loadable by unmodified SDSL for locate/extract.
+ * sdsl_hip_fm_drop_sa releases the suffix array when only count() is needed.  buf == NULL queries the size. */
+sdsl_hip_status sdsl_hip_fm_serialize(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens, void * buf, size_t cap,
+                                      size_t * written);
+sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm);
 sdsl_hip_status sdsl_hip_fm_destroy(sdsl_hip_fm_t fm);
 uint64_t sdsl_hip_fm_size(sdsl_hip_fm_t fm);  /* csa.size() = text length + 1 */
 uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm); /* csa.sigma */

@@ -67,6 +67,8 @@ SIGNATURES = {
     "sdsl_hip_fm_create_from_bwt": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_fm_create_from_text": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_fm_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "sdsl_hip_fm_serialize": (C.c_int32, [_vp, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sdsl_hip_fm_drop_sa": (C.c_int32, [_vp]),
     "sdsl_hip_fm_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_fm_size": (C.c_uint64, [_vp]),
     "sdsl_hip_fm_sigma": (C.c_uint64, [_vp]),

@@ -22,7 +22,9 @@ struct FmTables
     uint8_t char2comp[256]; // 0 for absent bytes (and for the sentinel itself)
 };
 
-sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, DevBuf & d_bwt);
+sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa);
+sdsl_hip_status sa_samples_to_host(const uint32_t * d_sa, uint64_t n, uint64_t sa_dens, uint64_t isa_dens,
+                                   std::vector<uint64_t> & sa_s, std::vector<uint64_t> & isa_s);
 sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint32_t * vals_in, uint32_t * vals_out,
                                    uint64_t n, unsigned end_bit, hipStream_t s);
 
@@ -200,6 +202,7 @@ struct sdsl_hip_fm_s
     sdsl_hip_wt_s * wt = nullptr;
     FmTables tab;
     DevBuf d_tab;
+    DevBuf d_sa; // suffix array (u32 per suffix) of an index created from text; empty otherwise
 };
 
 static void fm_free(sdsl_hip_fm_s * f)
@@ -308,11 +311,12 @@ sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_te
                       (unsigned long long)i);
             return SDSL_HIP_ERR_INVALID;
         }
-    DevBuf d_bwt;
-    SH_TRY(sa_build_bwt_device(host, n_text, device, d_bwt)); // suffix array and BWT never leave the device
+    DevBuf d_bwt, d_sa;
+    SH_TRY(sa_build_bwt_device(host, n_text, device, d_bwt, d_sa)); // suffix array and BWT never leave the device
     sdsl_hip_fm_s * f = new (std::nothrow) sdsl_hip_fm_s();
     if (!f)
         return SDSL_HIP_ERR_NOMEM;
+    f->d_sa = std::move(d_sa);
     sdsl_hip_status st = fm_from_device_bwt(f, d_bwt.as<uint8_t>(), n_text + 1, device);
     if (st != SDSL_HIP_OK)
     {
@@ -394,6 +398,63 @@ sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int
     }
     *out = f;
     return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
+{
+    if (!fm)
+        return SDSL_HIP_ERR_INVALID;
+    (void)hipSetDevice(fm->device);
+    fm->d_sa.release();
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_serialize(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens, void * buf, size_t cap,
+                                      size_t * written)
+{
+    if (!fm || sa_dens == 0 || isa_dens == 0)
+    {
+        set_error("fm_serialize: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    if (!fm->d_sa.p)
+    {
+        set_error("fm_serialize: the suffix array is not available (index not created from text, or dropped)");
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    SH_HIP(hipSetDevice(fm->device));
+    // 1. the wavelet tree in its select_support_scan flavour
+    size_t wt_len = 0;
+    SH_TRY(sdsl_hip_wt_serialize(fm->wt, nullptr, 0, &wt_len));
+    StreamWriter w;
+    w.bytes.resize(wt_len);
+    SH_TRY(sdsl_hip_wt_serialize(fm->wt, w.bytes.data(), wt_len, &wt_len));
+    // 2. SA and ISA samples as int_vector<0> of width hi(n)+1
+    const uint64_t n = fm->size;
+    std::vector<uint64_t> sa_s, isa_s;
+    SH_TRY(sa_samples_to_host(fm->d_sa.as<uint32_t>(), n, sa_dens, isa_dens, sa_s, isa_s));
+    const uint8_t width = (uint8_t)(hi64(n) + 1);
+    PackedBuilder ps(sa_s.size(), width), pi(isa_s.size(), width);
+    for (uint64_t i = 0; i < sa_s.size(); ++i)
+        ps.set(i, sa_s[i]);
+    for (uint64_t i = 0; i < isa_s.size(); ++i)
+        pi.set(i, isa_s[i]);
+    ps.write(w);
+    pi.write(w);
+    // 3. byte_alphabet::serialize (csa_alphabet_strategy.hpp:258-268)
+    uint64_t c2c[32], comp2char[32];
+    memset(c2c, 0, sizeof c2c);
+    memset(comp2char, 0, sizeof comp2char);
+    memcpy(c2c, fm->tab.char2comp, 256);
+    const WtHost & wh = sdsl_hip_wt_host(fm->wt);
+    for (int c = 0; c < 256; ++c)
+        if (wh.occ[c])
+            ((uint8_t *)comp2char)[fm->tab.char2comp[c]] = (uint8_t)c;
+    w.int_vector(c2c, 256 * 8, 8);
+    w.int_vector(comp2char, (uint64_t)fm->sigma * 8, 8);
+    w.int_vector(fm->tab.C, ((uint64_t)fm->sigma + 1) * 64, 64);
+    w.u16((uint16_t)fm->sigma);
+    return deliver(w, buf, cap, written);
 }
 
 sdsl_hip_status sdsl_hip_fm_destroy(sdsl_hip_fm_t fm)

@@ -37,6 +37,43 @@ __global__ void k_sa_flags(const uint64_t * __restrict__ keys, uint64_t n, uint3
         flags[i] = (i > 0 && keys[i] != keys[i - 1]) ? 1u : 0u;
 }
 
+// SA samples in SDSL's two layouts (csa_sampling_strategy.hpp:97-114, 755-777)
+__global__ void k_sa_sample(const uint32_t * __restrict__ sa, uint64_t n, uint64_t dens, uint64_t * __restrict__ out)
+{
+    const uint64_t m = (n + dens - 1) / dens;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t)gridDim.x * blockDim.x)
+        out[j] = sa[j * dens];
+}
+__global__ void k_isa_sample(const uint32_t * __restrict__ sa, uint64_t n, uint64_t dens, uint64_t * __restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t v = sa[i];
+        if (v % dens == 0)
+            out[v / dens] = i;
+    }
+}
+
+sdsl_hip_status sa_samples_to_host(const uint32_t * d_sa, uint64_t n, uint64_t sa_dens, uint64_t isa_dens,
+                                   std::vector<uint64_t> & sa_s, std::vector<uint64_t> & isa_s)
+{
+    const uint64_t ms = (n + sa_dens - 1) / sa_dens, mi = n ? (n - 1) / isa_dens + 1 : 0;
+    DevBuf a, b;
+    SH_TRY(a.alloc(ms * 8, true));
+    SH_TRY(b.alloc(mi * 8, true));
+    hipLaunchKernelGGL(k_sa_sample, dim3(grid_for(ms, 256, 65536)), dim3(256), 0, 0, d_sa, n, sa_dens, a.as<uint64_t>());
+    SH_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_isa_sample, dim3(grid_for(n, 256, 65536)), dim3(256), 0, 0, d_sa, n, isa_dens, b.as<uint64_t>());
+    SH_HIP(hipGetLastError());
+    sa_s.resize(ms);
+    isa_s.resize(mi);
+    if (ms)
+        SH_HIP(hipMemcpy(sa_s.data(), a.p, ms * 8, hipMemcpyDeviceToHost));
+    if (mi)
+        SH_HIP(hipMemcpy(isa_s.data(), b.p, mi * 8, hipMemcpyDeviceToHost));
+    return SDSL_HIP_OK;
+}
+
 // rank[sa[i]] = scanned[i]
 __global__ void k_sa_scatter_rank(const uint32_t * __restrict__ sa, const uint32_t * __restrict__ scanned, uint64_t n,
                                   uint32_t * __restrict__ rank)
@@ -96,8 +133,8 @@ sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t 
     return SDSL_HIP_OK;
 }
 
-// BWT of text+'\0' left in device memory (d_bwt, n_text+1 bytes)
-sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, DevBuf & d_bwt)
+// BWT of text+'\\0' left in device memory (d_bwt, n_text+1 bytes); the suffix array (u32 per suffix) is handed over too
+sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa)
 {
     const uint64_t n = n_text + 1;
     if (n >= UINT64_C(0xFFFFFFFE))
@@ -162,6 +199,7 @@ sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, 
     hipLaunchKernelGGL(k_sa_bwt, dim3(grid), dim3(256), 0, 0, d_s.as<uint8_t>(), i1, n, d_bwt.as<uint8_t>());
     SH_HIP(hipGetLastError());
     SH_HIP(hipDeviceSynchronize());
+    d_sa = std::move(d_i1);
     return SDSL_HIP_OK;
 }
 

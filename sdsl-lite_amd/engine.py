@@ -370,6 +370,19 @@ class csa_wt(_Handle):
     def device_bytes(self) -> int:
         return capi.lib().sdsl_hip_fm_device_bytes(self._h)
 
+    def serialize(self, sa_dens: int, isa_dens: int) -> bytes:
+        """bytes of csa_wt<wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>,
+        sa_dens, isa_dens>::serialize — only for an index created from text (the suffix array is needed)"""
+        need = C.c_size_t(0)
+        L = capi.lib()
+        capi.check(L.sdsl_hip_fm_serialize(self._h, sa_dens, isa_dens, None, 0, C.byref(need)))
+        buf = np.empty(max(1, need.value), dtype=np.uint8)
+        capi.check(L.sdsl_hip_fm_serialize(self._h, sa_dens, isa_dens, _ptr(buf), need.value, C.byref(need)))
+        return buf[: need.value].tobytes()
+
+    def drop_sa(self):
+        capi.check(capi.lib().sdsl_hip_fm_drop_sa(self._h))
+
     def alphabet(self):
         c2c = np.zeros(256, dtype=np.uint8)
         Cc = np.zeros(257, dtype=np.uint64)

@@ -483,3 +483,17 @@ def test_wt_serialize_equals_sdsl_bytes(gpu, name):
     assert hashlib.sha256(blob).hexdigest() == str(g[f"{name}/sha"][1])  # the select_support_scan flavour
     # and a tree loaded from SDSL's own bytes writes the same bytes back
     assert gpu.wt_huff(sdsl_bytes=blob, select_is_mcl=False).serialize() == blob
+
+
+@pytest.mark.parametrize("name", ["example01.txt", "faust.txt"])
+def test_fm_built_on_gpu_serializes_to_sdsl_bytes(gpu, name):
+    """raw text -> suffix array, BWT, wavelet tree, samples on the GPU -> bytes identical to what the real SDSL's
+    construct() + serialize() produced for the FM_HUFF type of the count benchmark (2^20 sampling)"""
+    csa = gpu.csa_wt(text=gd.text(name))
+    assert csa.serialize(1 << 20, 1 << 20) == gd.sdsl_file(f"{name}.csa_fm_huff.sdsl")
+    if ol.have_ref():
+        t = gd.text(name)[:5000]
+        assert gpu.csa_wt(text=t).serialize(1 << 20, 1 << 20) == ol.RCsa(t, also_fm_huff=True).serialize(1)
+    csa.drop_sa()
+    with pytest.raises(gpu.capi.SdslHipError):
+        csa.serialize(32, 64)
