@@ -120,6 +120,21 @@ int main(int argc, char ** argv)
                 ok &= o[k] == s0(a[k]);
             CHECK(ok, "select_support_rrr<0,63>");
             CHECK(dv[n / 2] == rv[n / 2], "rrr operator[]");
+            // encoded on the GPU, loaded into an unmodified rrr_vector<63>
+            {
+                sdsl_hip_rrr_t h = nullptr;
+                CHECK(sdsl_hip_rrr_create(bv.data(), bv.bit_size(), 0, &h) == SDSL_HIP_OK, "rrr_create");
+                size_t len = 0;
+                sdsl_hip_rrr_serialize(h, nullptr, 0, &len);
+                std::string bytes(len, 0);
+                CHECK(sdsl_hip_rrr_serialize(h, &bytes[0], len, &len) == SDSL_HIP_OK, "rrr_serialize");
+                std::istringstream iss(bytes);
+                std::istream & in = iss; // (an istringstream lvalue would select the cereal overload of load)
+                rrr_vector<63> loaded;
+                loaded.load(in);
+                CHECK(loaded == rv, "GPU-encoded rrr_vector loads into SDSL and equals the CPU-built one");
+                sdsl_hip_rrr_destroy(h);
+            }
         }
     // wavelet tree + FM-index over a text file (argv[1]) or a built-in sample
     std::string text;
@@ -186,6 +201,25 @@ int main(int argc, char ** argv)
         std::string und = "sea";
         CHECK(count(d1, und.begin(), und.end()) == count(csa, und.begin(), und.end()), "count single");
         CHECK(d1.size() == csa.size(), "csa size");
+        // FM-index built from the raw text on the GPU, loaded into the unmodified SDSL type: locate / extract work
+        sdsl_hip_fm_t h = nullptr;
+        CHECK(sdsl_hip_fm_create_from_text((const uint8_t *)text.data(), text.size(), 0, &h) == SDSL_HIP_OK, "fm_create_from_text");
+        size_t len = 0;
+        sdsl_hip_fm_serialize(h, 1 << 20, 1 << 20, nullptr, 0, &len);
+        std::string bytes(len, 0);
+        CHECK(sdsl_hip_fm_serialize(h, 1 << 20, 1 << 20, &bytes[0], len, &len) == SDSL_HIP_OK, "fm_serialize");
+        std::istringstream iss(bytes);
+        std::istream & in = iss;
+        fm_huff_t loaded;
+        loaded.load(in);
+        CHECK(loaded == fm, "GPU-built csa_wt loads into SDSL and equals construct()'s result");
+        auto occ1 = locate(loaded, und.begin(), und.end());
+        auto occ2 = locate(fm, und.begin(), und.end());
+        std::sort(occ1.begin(), occ1.end());
+        std::sort(occ2.begin(), occ2.end());
+        CHECK(occ1.size() == occ2.size() and std::equal(occ1.begin(), occ1.end(), occ2.begin()), "locate on the loaded index");
+        CHECK(extract(loaded, 10, 40) == extract(fm, 10, 40), "extract on the loaded index");
+        sdsl_hip_fm_destroy(h);
     }
     printf(g_fail ? "adaptor parity: %d FAILED\n" : "adaptor parity: all equal\n", g_fail);
     return g_fail ? 1 : 0;
