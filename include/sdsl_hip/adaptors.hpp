@@ -140,6 +140,37 @@ public:
     }
 };
 
+//! Drop-in for rank_support_v<t_b, 1> (rank_support_v.hpp:40), the default bit_vector::rank_1_type: its answers are
+//! those of rank_support_v5 (only the directory differs), so it shares the device structure; serialize/load speak
+//! rank_support_v's own byte format.
+template <uint8_t t_b = 1, uint8_t t_pat_len = 1>
+class rank_support_v_hip : public rank_support_v5_hip<t_b, t_pat_len>
+{
+    typedef rank_support_v5_hip<t_b, t_pat_len> base;
+    bit_vector const * m_vv = nullptr;
+
+public:
+    typedef typename base::size_type size_type;
+    explicit rank_support_v_hip(bit_vector const * v = nullptr, int device = 0) : base(v, device), m_vv(v)
+    {}
+    size_type serialize(std::ostream & out, structure_tree_node * v = nullptr, std::string name = "") const
+    {
+        rank_support_v<t_b, t_pat_len> host(m_vv);
+        return host.serialize(out, v, name);
+    }
+    void load(std::istream & in, bit_vector const * v = nullptr)
+    {
+        rank_support_v<t_b, t_pat_len> skipped;
+        skipped.load(in, v);
+        set_vector(v);
+    }
+    void set_vector(bit_vector const * v = nullptr)
+    {
+        m_vv = v;
+        base::set_vector(v);
+    }
+};
+
 //! Drop-in for select_support_mcl<t_b, 1> (select_support_mcl.hpp:64) with a batched member.
 template <uint8_t t_b = 1, uint8_t t_pat_len = 1>
 class select_support_mcl_hip

@@ -85,6 +85,8 @@ int main(int argc, char ** argv)
             uint64_t ones = util::cnt_one_bits(bv);
             check_rank<rank_support_v5<1>, rank_support_v5_hip<1>>(bv, rng, "rank_support_v5<1>");
             check_rank<rank_support_v5<0>, rank_support_v5_hip<0>>(bv, rng, "rank_support_v5<0>");
+            check_rank<rank_support_v<1>, rank_support_v_hip<1>>(bv, rng, "rank_support_v<1>");
+            check_rank<rank_support_v<0>, rank_support_v_hip<0>>(bv, rng, "rank_support_v<0>");
             check_select<select_support_mcl<1>, select_support_mcl_hip<1>>(bv, ones, rng, "select_support_mcl<1>");
             check_select<select_support_mcl<0>, select_support_mcl_hip<0>>(bv, n - ones, rng, "select_support_mcl<0>");
             // rrr_vector<63>
