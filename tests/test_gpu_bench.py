@@ -22,7 +22,7 @@ def _last_json(out):
 
 def test_single_gpu_contract(gpu):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--log-n", "26",
-                        "--queries", "4e6", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=900)
+                        "--queries", "4e6", "--cpu-seconds", "0.5", "--extras", "select"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
     assert all(k in d for k in REQUIRED)
