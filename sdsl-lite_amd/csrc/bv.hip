@@ -317,73 +317,7 @@ __global__ __launch_bounds__(kBlock) void k_rank(BvView bv, int bit, const uint6
     }
 }
 
-// U queries per quad per round; the three dependent stages (argument, samples, window) are each issued
-// for all U queries before the first result is consumed.
-template <int BIT, int U, bool NT>
-__global__ __launch_bounds__(kBlock) void k_select(BvView bv, const uint64_t * __restrict__ iq,
-                                                   uint64_t * __restrict__ out, uint64_t n)
-{
-    const int s = threadIdx.x & (kG - 1);
-    const unsigned gq = threadIdx.x / kG;
-    const uint64_t total = BIT ? bv.ones : bv.n_bits - bv.ones;
-    const uint32_t * __restrict__ smp = bv.sel[BIT];
-    const uint64_t stride = (uint64_t)gridDim.x * kQPB * U;
-    for (uint64_t base = (uint64_t)blockIdx.x * kQPB * U; base < n; base += stride)
-    {
-        uint64_t k[U], W[U];
-        bool ok[U];
-        uint32_t s0[U], s1[U];
-        SelBracket br[U];
-        Pair wa[U], wb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-            uint64_t q = base + (uint64_t)u * kQPB + gq;
-            uint64_t i = q < n ? iq[q] : 0;
-            ok[u] = i >= 1 && i <= total; // outside: SDSL's precondition (select_support_mcl.hpp:386)
-            k[u] = ok[u] ? i - 1 : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-            uint64_t j = k[u] >> bv.sel_shift;
-            s0[u] = smp[j];
-            s1[u] = smp[j + 1];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-            br[u] = sel_bracket<BIT>(bv, k[u], s0[u], s1[u]);
-            W[u] = sel_guess(bv, br[u], k[u], 0);
-            wa[u] = load_pair<NT>(bv.lines, 2 * W[u], s);
-            wb[u] = load_pair<NT>(bv.lines, 2 * W[u] + 1, s);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-            uint64_t q = base + (uint64_t)u * kQPB + gq;
-            bool mine = false;
-            uint64_t pos = 0;
-            bool found = sel_eval<BIT>(bv, s, k[u], W[u], wa[u], wb[u], br[u], mine, pos);
-            if (ok[u])
-            {
-                for (int tries = 1; !found; ++tries)
-                { // interpolation missed the window: rare, handled one probe at a time
-                    uint64_t W2 = sel_guess(bv, br[u], k[u], tries);
-                    Pair a2 = load_pair<NT>(bv.lines, 2 * W2, s);
-                    Pair b2 = load_pair<NT>(bv.lines, 2 * W2 + 1, s);
-                    found = sel_eval<BIT>(bv, s, k[u], W2, a2, b2, br[u], mine, pos);
-                }
-                if (mine)
-                    out[q] = pos;
-            }
-            else if (s == 0 && q < n)
-                out[q] = SDSL_HIP_NPOS;
-        }
-    }
-}
-
-// Round-based select with a per-block RETRY QUEUE in LDS.  Every round each quad starts one new query (argument and
+// Select with a per-block RETRY QUEUE in LDS.  Every round each quad starts one new query (argument and
 // sample loads stay coalesced because the block advances in lock step); a quad whose interpolated window missed
 // parks (query, bracket) in the queue instead of re-probing while the other 15 quads of its wave wait.  As soon as
 // a full round's worth of entries has piled up the whole block spends one round on them.  Misses thus cost one
@@ -535,19 +469,11 @@ sdsl_hip_status bv_launch_rank(const BvView & v, int bit, const uint64_t * d_idx
 {
     if (n == 0)
         return SDSL_HIP_OK;
-    static const int variant = getenv("SDSL_HIP_RANK_VARIANT") ? atoi(getenv("SDSL_HIP_RANK_VARIANT")) : 0;
+    // 4 queries per quad per round, plain (cached) loads: the best of the variants measured in round 1
+    // (U = 1/2/4/8, nontemporal or not: 36.2-38.8 G/s, profiles/gather_probe_r01.txt)
+    constexpr int U = 4;
     KernelTimer t(s);
-#define SH_LAUNCH_RANK(U, NT)                                                                                      \
-    hipLaunchKernelGGL((k_rank<U, NT>), dim3(query_grid(n, kQPB * U)), dim3(kBlock), 0, s, v, bit, d_idx, d_out, n)
-    switch (variant)
-    { // experiment knob; 0 is the tuned default
-    case 1: SH_LAUNCH_RANK(4, true); break;
-    case 2: SH_LAUNCH_RANK(2, false); break;
-    case 3: SH_LAUNCH_RANK(8, false); break;
-    case 4: SH_LAUNCH_RANK(1, false); break;
-    default: SH_LAUNCH_RANK(4, false); break;
-    }
-#undef SH_LAUNCH_RANK
+    hipLaunchKernelGGL((k_rank<U, false>), dim3(query_grid(n, kQPB * U)), dim3(kBlock), 0, s, v, bit, d_idx, d_out, n);
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }
@@ -562,26 +488,11 @@ sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i
         set_error("select_%d directory was not built (pass SDSL_HIP_BV_SELECT%d to sdsl_hip_bv_create)", bit, bit);
         return SDSL_HIP_ERR_INVALID;
     }
-    static const int variant = getenv("SDSL_HIP_SELECT_VARIANT") ? atoi(getenv("SDSL_HIP_SELECT_VARIANT")) : 0;
     KernelTimer t(s);
-#define SH_LAUNCH_SEL(B, U)                                                                                        \
-    hipLaunchKernelGGL((k_select<B, U, false>), dim3(query_grid(n, kQPB * U)), dim3(kBlock), 0, s, v, d_i, d_out, n)
-    switch (variant * 2 + (bit ? 1 : 0))
-    { // experiment knob; variant 0 is the tuned default (one query per quad per round)
-    case 2: SH_LAUNCH_SEL(0, 2); break;
-    case 3: SH_LAUNCH_SEL(1, 2); break;
-    case 4: SH_LAUNCH_SEL(0, 4); break;
-    case 5: SH_LAUNCH_SEL(1, 4); break;
-    case 6: SH_LAUNCH_SEL(0, 1); break;
-    case 7: SH_LAUNCH_SEL(1, 1); break;
-    case 1:
+    if (bit)
         hipLaunchKernelGGL((k_select_rq<1, false>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
-        break;
-    default:
+    else
         hipLaunchKernelGGL((k_select_rq<0, false>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
-        break;
-    }
-#undef SH_LAUNCH_SEL
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }
