@@ -51,6 +51,14 @@ enum {
 #define SDSL_HIP_BV_SELECT1 1u /* build the select_1 sample directory */
 #define SDSL_HIP_BV_SELECT0 2u /* build the select_0 sample directory */
 
+/* build flags for sdsl_hip_wt_create_ex / sdsl_hip_fm_create_from_{text,bwt}_ex */
+#define SDSL_HIP_WT_RRR63 1u /* store the wavelet tree's bit vector as rrr_vector<63>: wt_huff<rrr_vector<63>> */
+
+/* `layout` of a serialised wt_pc / csa_wt stream handed to *_create_from_sdsl */
+#define SDSL_HIP_LAYOUT_BV_SCAN 0 /* wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>> */
+#define SDSL_HIP_LAYOUT_BV_MCL 1  /* wt_huff<bit_vector, rank_support_v5<>> (select_support_mcl<1>, <0>) */
+#define SDSL_HIP_LAYOUT_RRR63 2   /* wt_huff<rrr_vector<63>> (rank/select_support_rrr serialise to nothing) */
+
 typedef struct sdsl_hip_bv_s * sdsl_hip_bv_t;   /* bit_vector + rank_support_v5 + select_support_mcl */
 typedef struct sdsl_hip_rrr_s * sdsl_hip_rrr_t; /* rrr_vector<63> + rank_support_rrr + select_support_rrr */
 typedef struct sdsl_hip_wt_s * sdsl_hip_wt_t;   /* wt_huff<bit_vector, rank_support_v5<>> */
@@ -122,14 +130,18 @@ sdsl_hip_status sdsl_hip_rrr_access_batch(sdsl_hip_rrr_t v, const uint64_t * idx
  *           wt_pc::operator[] (wt_pc.hpp:336-357); wt_pc::inverse_select (wt_pc.hpp:411-430);
  *           wt_pc::select (wt_pc.hpp:443-474). */
 sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t device, sdsl_hip_wt_t * out);
-/* from wt_pc::serialize bytes (wt_pc.hpp:713-726).  `select_is_mcl`: 1 if the serialised type
- * used select_support_mcl for bv_select1/bv_select0 (the wt_huff<> default), 0 if it used
- * select_support_scan (serialises to zero bytes; benchmark/indexing_count/index.config:8). */
-sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int32_t select_is_mcl, int32_t device,
+/* flags: SDSL_HIP_WT_RRR63 -> wt_huff<rrr_vector<63>> (rank, operator[], inverse_select; select is not available) */
+sdsl_hip_status sdsl_hip_wt_create_ex(const uint8_t * text, uint64_t n, int32_t device, uint32_t flags,
+                                      sdsl_hip_wt_t * out);
+/* from wt_pc::serialize bytes (wt_pc.hpp:713-726).  `layout` names the serialised type (SDSL_HIP_LAYOUT_*): plain
+ * bit_vector with select_support_scan (zero bytes; benchmark/indexing_count/index.config:8) or select_support_mcl
+ * (the wt_huff<bit_vector, rank_support_v5<>> default), or rrr_vector<63>. */
+sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int32_t layout, int32_t device,
                                              sdsl_hip_wt_t * out, size_t * consumed);
 /* Writes the bytes of wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>::serialize
- * (wt_pc.hpp:713-726: size, sigma, bv, rank_support_v5 directory, tree; scan supports serialise to nothing) for a
- * wavelet tree that was built on the GPU.  buf == NULL queries the size. */
+ * (wt_pc.hpp:713-726: size, sigma, bv, rank_support_v5 directory, tree; scan supports serialise to nothing) — or, for a
+ * tree created with SDSL_HIP_WT_RRR63, of wt_huff<rrr_vector<63>>::serialize — for a wavelet tree that was built on the
+ * GPU.  buf == NULL queries the size. */
 sdsl_hip_status sdsl_hip_wt_serialize(sdsl_hip_wt_t wt, void * buf, size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_wt_destroy(sdsl_hip_wt_t wt);
 uint64_t sdsl_hip_wt_size(sdsl_hip_wt_t wt);     /* wt.size()  */
@@ -163,12 +175,18 @@ sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, c
 sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int32_t device, sdsl_hip_fm_t * out);
 sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_text, int32_t device,
                                              sdsl_hip_fm_t * out);
-/* from csa_wt::serialize bytes (csa_wt.hpp:389-402); SA/ISA samples are skipped */
-sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int32_t select_is_mcl, int32_t device,
+/* flags: SDSL_HIP_WT_RRR63 -> csa_wt<wt_huff<rrr_vector<63>>> (the compressed FM-index of SDSL's README) */
+sdsl_hip_status sdsl_hip_fm_create_from_bwt_ex(const uint8_t * bwt, uint64_t n, int32_t device, uint32_t flags,
+                                               sdsl_hip_fm_t * out);
+sdsl_hip_status sdsl_hip_fm_create_from_text_ex(const uint8_t * text, uint64_t n_text, int32_t device, uint32_t flags,
+                                                sdsl_hip_fm_t * out);
+/* from csa_wt::serialize bytes (csa_wt.hpp:389-402); SA/ISA samples are skipped; `layout` as for the wavelet tree */
+sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int32_t layout, int32_t device,
                                              sdsl_hip_fm_t * out);
 /* An index created from text keeps its suffix array in HBM (4 bytes per suffix) so that it can be written out as a
  * complete SDSL csa_wt: sdsl_hip_fm_serialize produces the bytes of
  *   csa_wt<wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>, sa_dens, isa_dens>
+ *   (or csa_wt<wt_huff<rrr_vector<63>>, sa_dens, isa_dens> for an index created with SDSL_HIP_WT_RRR63)
  * ::serialize (csa_wt.hpp:389-402: wavelet tree, SA samples every sa_dens-th suffix, ISA samples every isa_dens-th text
  * position — csa_sampling_strategy.hpp:97-114,755-777 — and the byte alphabet), i.e. the index type of the reference's
  * count benchmark (benchmark/indexing_count/index.config:8), loadable by unmodified SDSL for locate/extract.

@@ -52,6 +52,8 @@ struct RefRrr
 
 typedef wt_huff<bit_vector, rank_support_v5<>> wt_t; // selects default to select_support_mcl<1>/<0>
 typedef wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>> wt_scan_t;
+typedef wt_huff<rrr_vector<63>> wt_rrr_t;                    // rank/select_support_rrr by default
+typedef csa_wt<wt_rrr_t, 32, 64> csa_rrr_t;
 typedef csa_wt<wt_t> csa_t;                                   // t_dens 32, t_inv_dens 64
 typedef csa_wt<wt_scan_t, 1 << 20, 1 << 20> csa_fmhuff_t;   // benchmark/indexing_count/index.config:8
 
@@ -346,6 +348,28 @@ void ref_csa_wt_rank(void * p, const uint64_t * i, const uint8_t * c, uint64_t n
     RefCsa * h = (RefCsa *)p;
     for (uint64_t q = 0; q < n; ++q)
         out[q] = h->csa.wavelet_tree.rank(i[q], c[q]);
+}
+
+// ---------------- wt_huff<rrr_vector<63>> and csa_wt over it: serialised bytes only (answers equal the plain tree's)
+void ref_wt_rrr_serialize(const uint8_t * text, uint64_t n, uint8_t ** out, uint64_t * len)
+{
+    wt_rrr_t wt(text, text + n);
+    to_bytes(wt, out, len);
+}
+int ref_csa_rrr_serialize(const uint8_t * text, uint64_t n, uint8_t ** out, uint64_t * len)
+{
+    csa_rrr_t csa;
+    std::string s((const char *)text, n);
+    try
+    {
+        construct_im(csa, s, 1);
+    }
+    catch (std::exception const &)
+    {
+        return 1;
+    }
+    to_bytes(csa, out, len);
+    return 0;
 }
 
 void ref_set_random_bits(uint64_t * words, uint64_t n_bits, int seed)

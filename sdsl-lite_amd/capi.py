@@ -19,6 +19,8 @@ OK = 0
 ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_FORMAT, ERR_NO_DEVICE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 NPOS = 0xFFFFFFFFFFFFFFFF
 BV_SELECT1, BV_SELECT0 = 1, 2
+WT_RRR63 = 1
+LAYOUT_BV_SCAN, LAYOUT_BV_MCL, LAYOUT_RRR63 = 0, 1, 2
 
 _u64p = C.POINTER(C.c_uint64)
 _u8p = C.POINTER(C.c_uint8)
@@ -51,6 +53,7 @@ SIGNATURES = {
     "sdsl_hip_rrr_select_batch": (C.c_int32, [_vp, C.c_int32, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_rrr_access_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_wt_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
+    "sdsl_hip_wt_create_ex": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "sdsl_hip_wt_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp),
                                                  C.POINTER(C.c_size_t)]),
     "sdsl_hip_wt_serialize": (C.c_int32, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -66,6 +69,8 @@ SIGNATURES = {
     "sdsl_hip_wt_select_batch": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_fm_create_from_bwt": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_fm_create_from_text": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
+    "sdsl_hip_fm_create_from_bwt_ex": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
+    "sdsl_hip_fm_create_from_text_ex": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "sdsl_hip_fm_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_fm_serialize": (C.c_int32, [_vp, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sdsl_hip_fm_drop_sa": (C.c_int32, [_vp]),

@@ -7,6 +7,7 @@
 //   count(csa,begin,end)                   suffix_array_algorithm.hpp:464-471
 //   byte_alphabet                          csa_alphabet_strategy.hpp:175-212
 //   csa_wt::rank_bwt                       csa_wt.hpp:286-289
+#include "fm_device.hpp"
 #include "wt_host.hpp"
 
 struct sdsl_hip_wt_s;
@@ -15,12 +16,6 @@ sdslhip::WtHost & sdsl_hip_wt_host(sdsl_hip_wt_s * w);
 sdsl_hip_status sdsl_hip_wt_finish(sdsl_hip_wt_s * w);
 
 namespace sdslhip {
-
-struct FmTables
-{
-    uint64_t C[257];        // C[cc] = number of symbols smaller than comp2char[cc]; C[sigma] = size
-    uint8_t char2comp[256]; // 0 for absent bytes (and for the sentinel itself)
-};
 
 sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa);
 sdsl_hip_status sa_samples_to_host(const uint32_t * d_sa, uint64_t n, uint64_t sa_dens, uint64_t isa_dens,
@@ -60,12 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
 {
     __shared__ WtTables T;
     __shared__ FmTables F;
-    {
-        const uint64_t * src = reinterpret_cast<const uint64_t *>(ftab);
-        uint64_t * dst = reinterpret_cast<uint64_t *>(&F);
-        for (unsigned i = threadIdx.x; i < sizeof(FmTables) / 8; i += blockDim.x)
-            dst[i] = src[i];
-    }
+    fm_stage_tables(&F, ftab);
     wt_stage_tables(&T, wt.tables); // ends with __syncthreads()
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
@@ -136,12 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_fm_backward_step(WtView wt, const Fm
 {
     __shared__ WtTables T;
     __shared__ FmTables F;
-    {
-        const uint64_t * src = reinterpret_cast<const uint64_t *>(ftab);
-        uint64_t * dst = reinterpret_cast<uint64_t *>(&F);
-        for (unsigned i = threadIdx.x; i < sizeof(FmTables) / 8; i += blockDim.x)
-            dst[i] = src[i];
-    }
+    fm_stage_tables(&F, ftab);
     wt_stage_tables(&T, wt.tables);
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
@@ -239,7 +224,8 @@ static sdsl_hip_status fm_upload_tables(sdsl_hip_fm_s * f)
     return SDSL_HIP_OK;
 }
 
-static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_bwt, uint64_t n, int device)
+static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_bwt, uint64_t n, int device,
+                                          uint32_t backend)
 {
     f->device = device;
     f->size = n;
@@ -247,7 +233,7 @@ static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_b
     if (!f->wt)
         return SDSL_HIP_ERR_NOMEM;
     WtHost & w = sdsl_hip_wt_host(f->wt);
-    SH_TRY(wt_build_from_device_text(w, d_bwt, n, device)); // csa_wt.hpp:337-343: the WT is built over the BWT
+    SH_TRY(wt_build_from_device_text(w, d_bwt, n, device, backend)); // csa_wt.hpp:337-343: the WT is built over the BWT
     SH_TRY(sdsl_hip_wt_finish(f->wt));
     if (n == 0 || w.occ[0] != 1)
     {
@@ -261,7 +247,8 @@ static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_b
 
 extern "C" {
 
-sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int32_t device, sdsl_hip_fm_t * out)
+sdsl_hip_status sdsl_hip_fm_create_from_bwt_ex(const uint8_t * bwt, uint64_t n, int32_t device, uint32_t flags,
+                                               sdsl_hip_fm_t * out)
 {
     if (!out || !bwt || n == 0)
     {
@@ -276,7 +263,7 @@ sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int
     Staged b;
     sdsl_hip_status st = b.in(bwt, n, nullptr);
     if (st == SDSL_HIP_OK)
-        st = fm_from_device_bwt(f, (const uint8_t *)b.dev, n, device);
+        st = fm_from_device_bwt(f, (const uint8_t *)b.dev, n, device, (flags & SDSL_HIP_WT_RRR63) ? 1u : 0u);
     if (st != SDSL_HIP_OK)
     {
         fm_free(f);
@@ -286,8 +273,8 @@ sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int
     return SDSL_HIP_OK;
 }
 
-sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_text, int32_t device,
-                                             sdsl_hip_fm_t * out)
+sdsl_hip_status sdsl_hip_fm_create_from_text_ex(const uint8_t * text, uint64_t n_text, int32_t device, uint32_t flags,
+                                                sdsl_hip_fm_t * out)
 {
     if (!out || (!text && n_text))
     {
@@ -317,7 +304,8 @@ sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_te
     if (!f)
         return SDSL_HIP_ERR_NOMEM;
     f->d_sa = std::move(d_sa);
-    sdsl_hip_status st = fm_from_device_bwt(f, d_bwt.as<uint8_t>(), n_text + 1, device);
+    sdsl_hip_status st = fm_from_device_bwt(f, d_bwt.as<uint8_t>(), n_text + 1, device,
+                                            (flags & SDSL_HIP_WT_RRR63) ? 1u : 0u);
     if (st != SDSL_HIP_OK)
     {
         fm_free(f);
@@ -327,7 +315,17 @@ sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_te
     return SDSL_HIP_OK;
 }
 
-sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int32_t select_is_mcl, int32_t device,
+sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int32_t device, sdsl_hip_fm_t * out)
+{
+    return sdsl_hip_fm_create_from_bwt_ex(bwt, n, device, 0, out);
+}
+
+sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_text, int32_t device, sdsl_hip_fm_t * out)
+{
+    return sdsl_hip_fm_create_from_text_ex(text, n_text, device, 0, out);
+}
+
+sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int32_t layout, int32_t device,
                                              sdsl_hip_fm_t * out)
 {
     if (!out || !bytes)
@@ -345,7 +343,7 @@ sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int
     StreamReader rd(bytes, len);
     sdsl_hip_status st = f->wt ? SDSL_HIP_OK : SDSL_HIP_ERR_NOMEM;
     if (st == SDSL_HIP_OK)
-        st = wt_build_from_stream(sdsl_hip_wt_host(f->wt), rd, select_is_mcl != 0, device);
+        st = wt_build_from_stream(sdsl_hip_wt_host(f->wt), rd, layout, device);
     if (st == SDSL_HIP_OK)
         st = sdsl_hip_wt_finish(f->wt);
     if (st == SDSL_HIP_OK)
@@ -536,6 +534,14 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
         }
         d_order = i1;
     }
+    if (w.backend == 1)
+    {
+        SH_TRY(fm_rrr_launch_count(w, fm->d_tab.as<FmTables>(), fm->size, (const uint8_t *)sp.dev, m,
+                                   offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat,
+                                   ival ? nullptr : (uint64_t *)sc.dev, ival ? (uint64_t *)sl.dev : nullptr,
+                                   ival ? (uint64_t *)sr.dev : nullptr, s));
+    }
+    else
     {
         if (ival)
             hipLaunchKernelGGL((k_fm_count<false, true>), dim3(grid), dim3(kBlock), 0, s, w.view(),
@@ -628,10 +634,15 @@ sdsl_hip_status sdsl_hip_fm_backward_search_batch(sdsl_hip_fm_t fm, const uint64
     const WtHost & w = sdsl_hip_wt_host(fm->wt);
     {
         KernelTimer t(s);
-        hipLaunchKernelGGL((k_fm_backward_step<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s,
-                           w.view(), fm->d_tab.as<FmTables>(), fm->size, (const uint64_t *)sl.dev,
-                           (const uint64_t *)sr.dev, (const uint8_t *)sc.dev, n, (uint64_t *)ol.dev,
-                           (uint64_t *)orr.dev);
+        if (w.backend == 1)
+            SH_TRY(fm_rrr_launch_backward_step(w, fm->d_tab.as<FmTables>(), fm->size, (const uint64_t *)sl.dev,
+                                               (const uint64_t *)sr.dev, (const uint8_t *)sc.dev, n, (uint64_t *)ol.dev,
+                                               (uint64_t *)orr.dev, s));
+        else
+            hipLaunchKernelGGL((k_fm_backward_step<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s,
+                               w.view(), fm->d_tab.as<FmTables>(), fm->size, (const uint64_t *)sl.dev,
+                               (const uint64_t *)sr.dev, (const uint8_t *)sc.dev, n, (uint64_t *)ol.dev,
+                               (uint64_t *)orr.dev);
     }
     SH_HIP(hipGetLastError());
     SH_TRY(ol.finish(s));

@@ -214,7 +214,7 @@ __global__ void k_wt_node_positions(const WtTables * __restrict__ T, uint32_t n_
 sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
                               hipStream_t s);
 
-sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device)
+sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t backend)
 {
     SH_HIP(hipSetDevice(device));
     wt.device = device;
@@ -284,7 +284,6 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
     wt.bv.device = device;
     SH_TRY(bv_build_from_device_words(wt.bv, d_words.as<uint64_t>(), bv_size, SDSL_HIP_BV_SELECT1 | SDSL_HIP_BV_SELECT0,
                                       default_sel_shift()));
-    d_words.release();
     // 5. bv_pos_rank of the inner nodes = rank_1 at the start of their slices (wt_helper.hpp:320-327)
     SH_TRY(wt.d_tables.alloc(sizeof(WtTables)));
     SH_HIP(hipMemcpy(wt.d_tables.p, &T, sizeof(WtTables), hipMemcpyHostToDevice));
@@ -304,17 +303,54 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
                 T.bv_pos_rank[v] = ranks[v];
         SH_HIP(hipMemcpy(wt.d_tables.p, &T, sizeof(WtTables), hipMemcpyHostToDevice));
     }
+    // 6. wt_huff<rrr_vector<63>>: encode the same bits as an rrr vector and drop the plain lines
+    wt.backend = backend;
+    if (backend == 1)
+    {
+        SH_TRY(rrr_build_device(wt.rrr, d_words.as<uint64_t>(), bv_size, device));
+        wt.bv.lines.release();
+        wt.bv.sel[0].release();
+        wt.bv.sel[1].release();
+        wt.bv.view.lines = nullptr;
+        wt.bv.view.sel[0] = wt.bv.view.sel[1] = nullptr;
+    }
     return SDSL_HIP_OK;
 }
 
-sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, bool select_is_mcl, int device)
+uint64_t wt_bv_bits(const WtHost & wt)
+{
+    return wt.backend == 1 ? wt.rrr.view.n_bits : wt.bv.view.n_bits;
+}
+
+sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, int layout, int device)
 {
     HostIntVec bv;
     uint64_t n_nodes64 = 0;
-    if (!rd.u64(wt.size) || !rd.u64(wt.sigma) || !rd.int_vector(bv, 1) || !rd.skip_int_vector() /* bv_rank */)
+    if (layout < 0 || layout > 2)
+    {
+        set_error("wt stream layout must be 0 (scan selects), 1 (mcl selects) or 2 (rrr_vector<63>)");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    wt.backend = layout == 2 ? 1u : 0u;
+    if (!rd.u64(wt.size) || !rd.u64(wt.sigma))
         goto bad;
-    if (select_is_mcl && (!rd.skip_select_mcl() || !rd.skip_select_mcl()))
-        goto bad;
+    if (layout == 2)
+    { // wt_pc<…, rrr_vector<63>, rank_support_rrr, select_support_rrr<1>, select_support_rrr<0>>: the supports
+      // serialise to nothing (rrr_vector.hpp:580-585,769-774)
+        wt.rrr.device = device;
+        sdsl_hip_status st = rrr_parse_and_upload(wt.rrr, rd, device, &bv.words);
+        if (st != SDSL_HIP_OK)
+            return st;
+        bv.bit_size = wt.rrr.view.n_bits;
+        bv.width = 1;
+    }
+    else
+    {
+        if (!rd.int_vector(bv, 1) || !rd.skip_int_vector() /* bv_rank */)
+            goto bad;
+        if (layout == 1 && (!rd.skip_select_mcl() || !rd.skip_select_mcl()))
+            goto bad;
+    }
     if (!rd.u64(n_nodes64) || n_nodes64 >= (uint64_t)kWtMaxNodes)
         goto bad;
     {
@@ -405,6 +441,13 @@ sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, bool select
                 if (v != T.c_to_leaf[c] || T.bv_pos_rank[v] != (uint64_t)c)
                     goto bad;
             }
+        }
+        if (wt.backend == 1)
+        { // the rrr vector is already on the device; only the node tables remain
+            wt.device = device;
+            SH_TRY(wt.d_tables.alloc(sizeof(WtTables)));
+            SH_HIP(hipMemcpy(wt.d_tables.p, &wt.tables, sizeof(WtTables), hipMemcpyHostToDevice));
+            return SDSL_HIP_OK;
         }
         return upload(wt, bv.words, bv.bit_size, device);
     }
@@ -568,7 +611,7 @@ sdsl_hip_status sdsl_hip_wt_finish(sdsl_hip_wt_s * w)
 
 extern "C" {
 
-sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t device, sdsl_hip_wt_t * out)
+sdsl_hip_status sdsl_hip_wt_create_ex(const uint8_t * text, uint64_t n, int32_t device, uint32_t flags, sdsl_hip_wt_t * out)
 {
     if (!out || (!text && n))
     {
@@ -583,7 +626,7 @@ sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t dev
     Staged t;
     sdsl_hip_status st = t.in(text, n, nullptr); // host bytes are uploaded; device bytes are used where they are
     if (st == SDSL_HIP_OK)
-        st = wt_build_from_device_text(w->h, (const uint8_t *)t.dev, n, device);
+        st = wt_build_from_device_text(w->h, (const uint8_t *)t.dev, n, device, (flags & SDSL_HIP_WT_RRR63) ? 1u : 0u);
     if (st == SDSL_HIP_OK)
         st = sdsl_hip_wt_finish(w);
     if (st != SDSL_HIP_OK)
@@ -595,7 +638,12 @@ sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t dev
     return SDSL_HIP_OK;
 }
 
-sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int32_t select_is_mcl, int32_t device,
+sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t device, sdsl_hip_wt_t * out)
+{
+    return sdsl_hip_wt_create_ex(text, n, device, 0, out);
+}
+
+sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int32_t layout, int32_t device,
                                              sdsl_hip_wt_t * out, size_t * consumed)
 {
     if (!out || !bytes)
@@ -609,7 +657,7 @@ sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int
     if (!w)
         return SDSL_HIP_ERR_NOMEM;
     StreamReader rd(bytes, len);
-    sdsl_hip_status st = wt_build_from_stream(w->h, rd, select_is_mcl != 0, device);
+    sdsl_hip_status st = wt_build_from_stream(w->h, rd, layout, device);
     if (st == SDSL_HIP_OK)
         st = sdsl_hip_wt_finish(w);
     if (st != SDSL_HIP_OK)
@@ -632,6 +680,25 @@ sdsl_hip_status sdsl_hip_wt_serialize(sdsl_hip_wt_t wt, void * buf, size_t cap, 
     }
     const WtHost & h = wt->h;
     SH_HIP(hipSetDevice(h.device));
+    if (h.backend == 1)
+    { // wt_huff<rrr_vector<63>>: size, sigma, the rrr vector, (supports: nothing), tree
+        StreamWriter w;
+        w.u64(h.size);
+        w.u64(h.sigma);
+        SH_TRY(rrr_serialize_host(h.rrr, w));
+        w.u64(h.n_nodes);
+        for (uint32_t v = 0; v < h.n_nodes; ++v)
+        {
+            w.u64(h.tables.bv_pos[v]);
+            w.u64(h.tables.bv_pos_rank[v]);
+            w.u16(h.tables.parent[v]);
+            w.u16(h.tables.child[v][0]);
+            w.u16(h.tables.child[v][1]);
+        }
+        w.raw(h.tables.c_to_leaf, sizeof h.tables.c_to_leaf);
+        w.raw(h.tables.path, sizeof h.tables.path);
+        return deliver(w, buf, cap, written);
+    }
     const uint64_t nb = h.bv.view.n_bits, W = (nb + 63) >> 6;
     // the bit vector back in SDSL's word layout
     std::vector<uint64_t> words(W + 1, 0);
@@ -707,7 +774,7 @@ uint64_t sdsl_hip_wt_sigma(sdsl_hip_wt_t wt)
 }
 uint64_t sdsl_hip_wt_bv_size(sdsl_hip_wt_t wt)
 {
-    return wt ? wt->h.bv.view.n_bits : 0;
+    return wt ? wt_bv_bits(wt->h) : 0;
 }
 uint64_t sdsl_hip_wt_device_bytes(sdsl_hip_wt_t wt)
 {
@@ -737,7 +804,10 @@ sdsl_hip_status sdsl_hip_wt_rank_batch(sdsl_hip_wt_t wt, const uint64_t * i, con
     SH_TRY(si.in(i, n * 8, s));
     SH_TRY(sc.in(c, n, s));
     SH_TRY(so.out(out, n * 8));
-    SH_TRY(wt_launch_rank(wt->h, (const uint64_t *)si.dev, (const uint8_t *)sc.dev, n, (uint64_t *)so.dev, s));
+    if (wt->h.backend == 1)
+        SH_TRY(wt_rrr_launch_rank(wt->h, (const uint64_t *)si.dev, (const uint8_t *)sc.dev, n, (uint64_t *)so.dev, s));
+    else
+        SH_TRY(wt_launch_rank(wt->h, (const uint64_t *)si.dev, (const uint8_t *)sc.dev, n, (uint64_t *)so.dev, s));
     SH_TRY(so.finish(s));
     if ((si.host || sc.host) && !so.host)
         SH_HIP(hipStreamSynchronize(s));
@@ -761,6 +831,10 @@ sdsl_hip_status sdsl_hip_wt_inverse_select_batch(sdsl_hip_wt_t wt, const uint64_
     SH_TRY(sc.out(out_c, n));
     if (out_rank)
         SH_TRY(sr.out(out_rank, n * 8));
+    if (wt->h.backend == 1)
+        SH_TRY(wt_rrr_launch_inverse_select(wt->h, (const uint64_t *)si.dev, n, out_rank ? (uint64_t *)sr.dev : nullptr,
+                                            (uint8_t *)sc.dev, s));
+    else
     {
         KernelTimer t(s);
         unsigned grid = grid_for(n, kQPB, 256u * 8u);
@@ -796,6 +870,11 @@ sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, c
     }
     hipStream_t s = (hipStream_t)stream;
     SH_HIP(hipSetDevice(wt->h.device));
+    if (wt->h.backend == 1)
+    {
+        set_error("wt.select on an rrr-compressed wavelet tree is not implemented on the device yet");
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
     if (n == 0)
         return SDSL_HIP_OK;
     Staged si, sc, so;

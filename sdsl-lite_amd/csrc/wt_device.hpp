@@ -8,6 +8,7 @@
 // rank lines (bv_device.hpp).  One rank cascade level = ONE 64-byte line fetch.
 #pragma once
 #include "bv_device.hpp"
+#include "rrr_device.hpp"
 
 namespace sdslhip {
 
@@ -26,7 +27,9 @@ struct WtTables // global-memory image, identical layout in LDS
 
 struct WtView
 {
-    BvView bv;
+    BvView bv;   // backend 0: the bit vector as rank lines
+    RrrView rrr; // backend 1: the bit vector as an rrr_vector<63> (wt_huff<rrr_vector<63>>)
+    uint32_t backend;
     const WtTables * tables;
     uint64_t size;  // number of symbols
     uint64_t sigma; // effective alphabet size
@@ -135,6 +138,54 @@ __device__ __forceinline__ uint64_t quad_wt_inverse_select(const WtView & wt, co
     }
     c_out = (unsigned)T->bv_pos_rank[v];
     return i;
+}
+
+// ---- rrr-compressed bit vector (wt_huff<rrr_vector<63>>) -----------------------------------------------------------
+// Four queries per quad advance level-synchronously: in sub-round U all four lanes fetch the record / class prefix /
+// offset field for the query OWNED by lane U (rrr_rank_head), then every lane decodes the block of its own query.
+__device__ __forceinline__ bool quad_any(bool b)
+{
+    return quad_sum(b ? 1u : 0u) != 0;
+}
+
+// rank_1(pos) of this lane's own query on the rrr vector (undefined if !act); optionally the bit at pos
+__device__ __forceinline__ uint64_t quad4_rrr_rank1(const RrrView & v, const RrrTables * RT, int s, uint64_t pos, bool act,
+                                                    unsigned * bit_out = nullptr)
+{
+    const uint64_t safe = act ? pos : 0;
+    RankTail mine, t;
+    mine.rank = 0;
+    mine.nr = 0;
+    mine.k = 0;
+    mine.off = 0;
+    if (quad_bcast_lane<0>(act ? 1u : 0u))
+    {
+        t = rrr_rank_head(v, RT, s, quad_bcast_lane_u64<0>(safe));
+        if (s == 0)
+            mine = t;
+    }
+    if (quad_bcast_lane<1>(act ? 1u : 0u))
+    {
+        t = rrr_rank_head(v, RT, s, quad_bcast_lane_u64<1>(safe));
+        if (s == 1)
+            mine = t;
+    }
+    if (quad_bcast_lane<2>(act ? 1u : 0u))
+    {
+        t = rrr_rank_head(v, RT, s, quad_bcast_lane_u64<2>(safe));
+        if (s == 2)
+            mine = t;
+    }
+    if (quad_bcast_lane<3>(act ? 1u : 0u))
+    {
+        t = rrr_rank_head(v, RT, s, quad_bcast_lane_u64<3>(safe));
+        if (s == 3)
+            mine = t;
+    }
+    uint64_t bits = rrr_decode_block(RT, mine.k, mine.nr);
+    if (bit_out)
+        *bit_out = (unsigned)(bits >> mine.off) & 1u;
+    return mine.rank + popc64(bits & lo_set(mine.off));
 }
 
 } // namespace sdslhip

@@ -1,6 +1,7 @@
 // wt_host.hpp — host-side owner of a device wavelet tree and its builders.
 #pragma once
 #include "bv_host.hpp"
+#include "rrr_host.hpp"
 #include "sdsl_stream.hpp"
 #include "wt_device.hpp"
 
@@ -11,7 +12,9 @@ struct WtHost
     int device = 0;
     uint64_t size = 0, sigma = 0;
     uint32_t n_nodes = 0;
+    uint32_t backend = 0; // 0: plain bit_vector + rank_support_v5 (rank lines); 1: rrr_vector<63>
     BvHost bv;          // the concatenated WT bit vector as rank lines (+ select directories)
+    RrrHost rrr;        // ... or as an rrr_vector<63>
     DevBuf d_tables;    // WtTables image in HBM
     WtTables tables;    // host copy (code lengths, alphabet queries)
     uint64_t occ[256];  // occurrences of every byte (== wt.rank(size(), c))
@@ -19,6 +22,8 @@ struct WtHost
     {
         WtView v;
         v.bv = bv.view;
+        v.rrr = rrr.view;
+        v.backend = backend;
         v.tables = d_tables.as<WtTables>();
         v.size = size;
         v.sigma = sigma;
@@ -27,15 +32,25 @@ struct WtHost
     }
     size_t device_bytes() const
     {
-        return bv.device_bytes() + d_tables.bytes;
+        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes;
     }
 };
 
 // Builds the tree shape on the host (a 256-entry histogram decides it) and the bit vector on the device, one
 // stable radix sort per tree level, from a symbol sequence that already lives in device memory.
-sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device);
+// backend: 0 = plain bit vector (rank lines + select directories), 1 = rrr_vector<63>
+sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t backend = 0);
 // Parses wt_pc::serialize output (wt_pc.hpp:713-726) and uploads; advances the reader.
-sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, bool select_is_mcl, int device);
+// layout: 0 = plain bv + select_support_scan (zero bytes), 1 = plain bv + select_support_mcl, 2 = rrr_vector<63> with
+// its own rank/select supports (zero bytes)
+sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, int layout, int device);
+uint64_t wt_bv_bits(const WtHost & wt);
+
+// kernels over the rrr backend (wt_rrr.hip)
+sdsl_hip_status wt_rrr_launch_rank(const WtHost & wt, const uint64_t * d_i, const uint8_t * d_c, uint64_t n,
+                                   uint64_t * d_out, hipStream_t s);
+sdsl_hip_status wt_rrr_launch_inverse_select(const WtHost & wt, const uint64_t * d_i, uint64_t n, uint64_t * d_rank,
+                                             uint8_t * d_c, hipStream_t s);
 
 sdsl_hip_status wt_launch_rank(const WtHost & wt, const uint64_t * d_i, const uint8_t * d_c, uint64_t n,
                                uint64_t * d_out, hipStream_t s);

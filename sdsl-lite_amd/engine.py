@@ -260,7 +260,9 @@ class wt_huff(_Handle):
     _destroy = "sdsl_hip_wt_destroy"
 
     def __init__(self, text=None, device: int = 0, sdsl_bytes: bytes | None = None, select_is_mcl: bool = True,
-                 _borrowed=None):
+                 rrr: bool = False, _borrowed=None):
+        """rrr=True: wt_huff<rrr_vector<63>> (the bit vector is stored rrr-compressed); for sdsl_bytes it says that
+        the stream is of that type, otherwise select_is_mcl tells the two plain flavours apart."""
         super().__init__()
         self.consumed = None
         if _borrowed is not None:
@@ -269,13 +271,15 @@ class wt_huff(_Handle):
         elif sdsl_bytes is not None:
             buf = np.frombuffer(sdsl_bytes, dtype=np.uint8)
             used = C.c_size_t(0)
-            capi.check(capi.lib().sdsl_hip_wt_create_from_sdsl(_ptr(buf), buf.size, 1 if select_is_mcl else 0, device,
+            layout = capi.LAYOUT_RRR63 if rrr else (capi.LAYOUT_BV_MCL if select_is_mcl else capi.LAYOUT_BV_SCAN)
+            capi.check(capi.lib().sdsl_hip_wt_create_from_sdsl(_ptr(buf), buf.size, layout, device,
                                                                C.byref(self._h), C.byref(used)))
             self.consumed = used.value
         else:
             t = _bytes_arg(text, "text")
             n = t.numel() if _is_tensor(t) else t.size
-            capi.check(capi.lib().sdsl_hip_wt_create(_ptr(t) if n else None, n, device, C.byref(self._h)))
+            capi.check(capi.lib().sdsl_hip_wt_create_ex(_ptr(t) if n else None, n, device,
+                                                        capi.WT_RRR63 if rrr else 0, C.byref(self._h)))
         self.device = device
 
     def size(self) -> int:
@@ -342,21 +346,23 @@ class csa_wt(_Handle):
     _destroy = "sdsl_hip_fm_destroy"
 
     def __init__(self, text=None, bwt=None, device: int = 0, sdsl_bytes: bytes | None = None,
-                 select_is_mcl: bool = True):
+                 select_is_mcl: bool = True, rrr: bool = False):
+        """rrr=True: csa_wt<wt_huff<rrr_vector<63>>> (compressed FM-index)"""
         super().__init__()
         L = capi.lib()
+        flags = capi.WT_RRR63 if rrr else 0
         if sdsl_bytes is not None:
             buf = np.frombuffer(sdsl_bytes, dtype=np.uint8)
-            capi.check(L.sdsl_hip_fm_create_from_sdsl(_ptr(buf), buf.size, 1 if select_is_mcl else 0, device,
-                                                      C.byref(self._h)))
+            layout = capi.LAYOUT_RRR63 if rrr else (capi.LAYOUT_BV_MCL if select_is_mcl else capi.LAYOUT_BV_SCAN)
+            capi.check(L.sdsl_hip_fm_create_from_sdsl(_ptr(buf), buf.size, layout, device, C.byref(self._h)))
         elif bwt is not None:
             b = _bytes_arg(bwt, "bwt")
             n = b.numel() if _is_tensor(b) else b.size
-            capi.check(L.sdsl_hip_fm_create_from_bwt(_ptr(b) if n else None, n, device, C.byref(self._h)))
+            capi.check(L.sdsl_hip_fm_create_from_bwt_ex(_ptr(b) if n else None, n, device, flags, C.byref(self._h)))
         else:
             t = _bytes_arg(text, "text")
             n = t.numel() if _is_tensor(t) else t.size
-            capi.check(L.sdsl_hip_fm_create_from_text(_ptr(t) if n else None, n, device, C.byref(self._h)))
+            capi.check(L.sdsl_hip_fm_create_from_text_ex(_ptr(t) if n else None, n, device, flags, C.byref(self._h)))
         self.device = device
         self.wavelet_tree = wt_huff(_borrowed=L.sdsl_hip_fm_wavelet_tree(self._h), device=device)
         self.wavelet_tree._keepalive = self

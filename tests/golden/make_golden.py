@@ -168,6 +168,9 @@ def main():
         if t in ("example01.txt", "faust.txt"):
             open(os.path.join(HERE, "sdsl", f"{t}.csa_wt_huff_v5.sdsl"), "wb").write(csa.serialize(0))
             open(os.path.join(HERE, "sdsl", f"{t}.csa_fm_huff.sdsl"), "wb").write(csa.serialize(1))
+            # compressed flavour: wt_huff<rrr_vector<63>> and csa_wt<wt_huff<rrr_vector<63>>, 32, 64>
+            open(os.path.join(HERE, "sdsl", f"{t}.wt_huff_rrr63.sdsl"), "wb").write(ol.ref_wt_rrr_bytes(data))
+            open(os.path.join(HERE, "sdsl", f"{t}.csa_wt_huff_rrr63.sdsl"), "wb").write(ol.ref_csa_rrr_bytes(data))
     np.savez_compressed(os.path.join(HERE, "golden_text.npz"), **out)
     print("golden fixtures written under", HERE)
 

@@ -395,6 +395,8 @@ _REF_SIGS = {
     "ref_csa_backward_search": (None, [_vp, _vp, _vp, _vp, _u64, _vp, _vp]),
     "ref_csa_serialize": (None, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_csa_wt_rank": (None, [_vp, _vp, _vp, _u64, _vp]),
+    "ref_wt_rrr_serialize": (None, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
+    "ref_csa_rrr_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_set_random_bits": (None, [_vp, _u64, C.c_int]),
     "ref_bits_sel": (_u32, [_u64, _u32]),
     "ref_bits_hi": (_u32, [_u64]),
@@ -418,6 +420,23 @@ def _ref_bytes(fn, *args) -> bytes:
     p, n = _vp(None), _u64(0)
     fn(*args, C.byref(p), C.byref(n))
     data = C.string_at(p, n.value) if n.value else b""
+    ref().L.ref_free(p)
+    return data
+
+
+def ref_wt_rrr_bytes(text: bytes) -> bytes:
+    """wt_huff<rrr_vector<63>>::serialize of the real library"""
+    t = _u8arr(np.frombuffer(text, dtype=np.uint8))
+    return _ref_bytes(ref().L.ref_wt_rrr_serialize, _p(t) if t.size else None, t.size)
+
+
+def ref_csa_rrr_bytes(text: bytes) -> bytes:
+    """csa_wt<wt_huff<rrr_vector<63>>, 32, 64>::serialize of the real library"""
+    t = _u8arr(np.frombuffer(text, dtype=np.uint8))
+    p, n = _vp(None), _u64(0)
+    if ref().L.ref_csa_rrr_serialize(_p(t), t.size, C.byref(p), C.byref(n)):
+        raise ValueError("sdsl::construct_im threw")
+    data = C.string_at(p, n.value)
     ref().L.ref_free(p)
     return data
 

@@ -497,3 +497,95 @@ def test_fm_built_on_gpu_serializes_to_sdsl_bytes(gpu, name):
     csa.drop_sa()
     with pytest.raises(gpu.capi.SdslHipError):
         csa.serialize(32, 64)
+
+
+# ---------------------------------------------------------------------------------------------------
+# wt_huff<rrr_vector<63>> and csa_wt over it: same answers as the plain tree, rrr-compressed on the device
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", gd.TEXTS)
+def test_wt_rrr_golden(gpu, name):
+    g = gd.text_golden()
+    data = gd.text(name)
+    wt = gpu.wt_huff(data, rrr=True)
+    n, sigma, bvs = (int(x) for x in g[f"{name}/meta"])
+    assert (wt.size(), wt.sigma(), wt.bv_size()) == (n, sigma, bvs)
+    assert np.array_equal(wt.rank(g[f"{name}/rank_i"], g[f"{name}/rank_c"]), g[f"{name}/rank"])
+    assert np.array_equal(wt.rank(np.full(256, n, dtype=np.uint64), np.arange(256, dtype=np.uint8)),
+                          g[f"{name}/rank_full"])
+    assert int(wt.rank(np.array([n + 1], dtype=np.uint64), np.array([97], dtype=np.uint8))[0]) == int(NPOS)
+    if n:
+        ai = g[f"{name}/acc_i"]
+        assert np.array_equal(wt.access(ai), g[f"{name}/acc"])
+        r, c = wt.inverse_select(ai)
+        assert np.array_equal(r, g[f"{name}/invsel_rank"]) and np.array_equal(c, g[f"{name}/acc"])
+        with pytest.raises(gpu.capi.SdslHipError) as e:
+            wt.select(g[f"{name}/sel_i"], g[f"{name}/sel_c"])
+        assert e.value.status == gpu.capi.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("name", ["example01.txt", "faust.txt"])
+def test_wt_rrr_streams(gpu, name):
+    g = gd.text_golden()
+    blob = gd.sdsl_file(f"{name}.wt_huff_rrr63.sdsl")
+    built = gpu.wt_huff(gd.text(name), rrr=True)
+    assert built.serialize() == blob  # built on the GPU == real SDSL's wt_huff<rrr_vector<63>> bytes
+    loaded = gpu.wt_huff(sdsl_bytes=blob, rrr=True)
+    assert loaded.consumed == len(blob)
+    assert np.array_equal(loaded.rank(g[f"{name}/rank_i"], g[f"{name}/rank_c"]), g[f"{name}/rank"])
+    assert np.array_equal(loaded.access(g[f"{name}/acc_i"]), g[f"{name}/acc"])
+    assert loaded.serialize() == blob
+    for cut in (17, len(blob) // 3, len(blob) - 1):
+        with pytest.raises(gpu.capi.SdslHipError):
+            gpu.wt_huff(sdsl_bytes=blob[:cut], rrr=True)
+
+
+@pytest.mark.parametrize("name", FM_TEXTS)
+def test_fm_rrr_golden(gpu, name):
+    g = _fm_cases(name)
+    data = gd.text(name)
+    csa = gpu.csa_wt(text=data, rrr=True)
+    assert [csa.size(), csa.sigma()] == [int(x) for x in g[f"{name}/csa_meta"]]
+    for m in (1, 2, 4, 20):
+        if f"{name}/pat{m}" not in g.files:
+            continue
+        pats = g[f"{name}/pat{m}"]
+        assert np.array_equal(csa.count(pats, m), g[f"{name}/count{m}"])
+        l, r = csa.interval(pats, m)
+        assert np.array_equal(l, g[f"{name}/ival_l{m}"]) and np.array_equal(r, g[f"{name}/ival_r{m}"])
+
+
+@pytest.mark.parametrize("name", ["example01.txt", "faust.txt"])
+def test_fm_rrr_streams(gpu, name):
+    g = gd.text_golden()
+    blob = gd.sdsl_file(f"{name}.csa_wt_huff_rrr63.sdsl")
+    built = gpu.csa_wt(text=gd.text(name), rrr=True)
+    assert built.serialize(32, 64) == blob  # csa_wt<wt_huff<rrr_vector<63>>, 32, 64> of the real library
+    loaded = gpu.csa_wt(sdsl_bytes=blob, rrr=True)
+    for m in (1, 4, 20):
+        if f"{name}/pat{m}" in g.files:
+            assert np.array_equal(loaded.count(g[f"{name}/pat{m}"], m), g[f"{name}/count{m}"])
+
+
+def test_fm_rrr_random_vs_oracle(gpu):
+    rng = np.random.default_rng(21)
+    words = [bytes(rng.integers(97, 123, size=rng.integers(2, 9), dtype=np.uint8)) for _ in range(200)]
+    t = b" ".join(words[i] for i in rng.integers(0, len(words), size=40000))
+    o = ol.OCsa(t)
+    csa = gpu.csa_wt(text=t, rrr=True)
+    arr = np.frombuffer(t, dtype=np.uint8)
+    for m in (3, 20, 33):
+        st = rng.integers(0, len(t) - m, size=100_000)
+        pats = np.concatenate([arr[s:s + m] for s in st])
+        pats[::13] = rng.integers(1, 256, size=pats[::13].size)
+        assert np.array_equal(csa.count(pats, m), o.count_batch(pats, m))  # >= 2^16 patterns: suffix-ordered path
+    n = o.size()
+    l = rng.integers(0, n, size=5000, dtype=np.uint64)
+    r = np.minimum(l + rng.integers(0, 3000, size=l.size, dtype=np.uint64), np.uint64(n - 1))
+    c = arr[rng.integers(0, len(t), size=l.size)].copy()
+    c[::7] = rng.integers(0, 256, size=c[::7].size)
+    lo, ro = csa.backward_search(l, r, c)
+    exp = np.array([o.backward_search(a, b, cc) for a, b, cc in zip(l, r, c)], dtype=np.uint64)
+    assert np.array_equal(lo, exp[:, 0]) and np.array_equal(ro, exp[:, 1])
+    qi = rng.integers(0, len(t) + 2, size=50_000, dtype=np.uint64)
+    qc = rng.integers(0, 256, size=qi.size, dtype=np.uint8)
+    assert np.array_equal(csa.wavelet_tree.rank(qi, qc), o.wt().rank(qi, qc))
