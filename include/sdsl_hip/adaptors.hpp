@@ -377,10 +377,11 @@ public:
     }
 };
 
-//! Device image of a byte wavelet tree of the wt_pc family over a plain bit_vector with
-//! rank_support_v5 (wt_huff / wt_blcd / wt_hutu share wt_pc's layout, wt_pc.hpp:53-59), built from the
-//! host object's serialised form.  t_select_is_mcl tells whether the host type serialises
-//! select_support_mcl (wt_huff<bit_vector, rank_support_v5<>>) or select_support_scan (zero bytes).
+//! Device image of a byte wavelet tree of the wt_pc family (wt_huff / wt_blcd / wt_hutu share wt_pc's layout,
+//! wt_pc.hpp:53-59), built from the host object's serialised form.  `layout` names the host type's bit vector and
+//! select supports: SDSL_HIP_LAYOUT_BV_SCAN (0: bit_vector + rank_support_v5 + select_support_scan, zero bytes),
+//! SDSL_HIP_LAYOUT_BV_MCL (1: ... + select_support_mcl, the wt_huff<bit_vector, rank_support_v5<>> default) or
+//! SDSL_HIP_LAYOUT_RRR63 (2: wt_huff<rrr_vector<63>>).  `false` / `true` still mean 0 / 1.
 class wt_huff_hip
 {
 public:
@@ -400,12 +401,12 @@ private:
 public:
     wt_huff_hip() = default;
     template <class t_wt>
-    explicit wt_huff_hip(t_wt const & wt, bool select_is_mcl, int device = 0)
+    explicit wt_huff_hip(t_wt const & wt, int layout, int device = 0)
     {
         std::string s = hip_detail::to_stream(wt);
         sdsl_hip_wt_t h = nullptr;
         size_t used = 0;
-        hip_detail::check(sdsl_hip_wt_create_from_sdsl(s.data(), s.size(), select_is_mcl ? 1 : 0, device, &h, &used),
+        hip_detail::check(sdsl_hip_wt_create_from_sdsl(s.data(), s.size(), layout, device, &h, &used),
                           "sdsl_hip_wt_create_from_sdsl");
         m_dev.reset(h, deleter());
     }
@@ -472,12 +473,13 @@ private:
 
 public:
     csa_wt_hip() = default;
+    //! layout: as for wt_huff_hip (0 scan selects, 1 mcl selects, 2 = csa_wt<wt_huff<rrr_vector<63>>>)
     template <class t_csa>
-    explicit csa_wt_hip(t_csa const & csa, bool select_is_mcl, int device = 0)
+    explicit csa_wt_hip(t_csa const & csa, int layout, int device = 0)
     {
         std::string s = hip_detail::to_stream(csa);
         sdsl_hip_fm_t h = nullptr;
-        hip_detail::check(sdsl_hip_fm_create_from_sdsl(s.data(), s.size(), select_is_mcl ? 1 : 0, device, &h),
+        hip_detail::check(sdsl_hip_fm_create_from_sdsl(s.data(), s.size(), layout, device, &h),
                           "sdsl_hip_fm_create_from_sdsl");
         m_dev.reset(h, deleter());
     }

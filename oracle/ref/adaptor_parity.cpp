@@ -203,6 +203,18 @@ int main(int argc, char ** argv)
         std::string und = "sea";
         CHECK(count(d1, und.begin(), und.end()) == count(csa, und.begin(), und.end()), "count single");
         CHECK(d1.size() == csa.size(), "csa size");
+        // SDSL's README index family: csa_wt<wt_huff<rrr_vector<63>>>
+        {
+            csa_wt<wt_huff<rrr_vector<63>>, 32, 64> crrr;
+            construct_im(crrr, text, 1);
+            csa_wt_hip d3(crrr, SDSL_HIP_LAYOUT_RRR63);
+            std::vector<uint64_t> o3(q);
+            count_batch(d3, pats.data(), m, q, o3.data());
+            bool ok3 = true;
+            for (size_t k = 0; k < q; ++k)
+                ok3 &= o3[k] == count(crrr, pats.begin() + k * m, pats.begin() + (k + 1) * m);
+            CHECK(ok3, "count(csa_wt<wt_huff<rrr_vector<63>>>)");
+        }
         // FM-index built from the raw text on the GPU, loaded into the unmodified SDSL type: locate / extract work
         sdsl_hip_fm_t h = nullptr;
         CHECK(sdsl_hip_fm_create_from_text((const uint8_t *)text.data(), text.size(), 0, &h) == SDSL_HIP_OK, "fm_create_from_text");

@@ -6,10 +6,11 @@ import bench
 pkg = importlib.import_module("sdsl-lite_amd")
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 nq = int(float(sys.argv[2])) if len(sys.argv) > 2 else 50_000_000
+rrr = len(sys.argv) > 3 and sys.argv[3] == "rrr"
 dev = torch.device("cuda", 0)
 nt = mib << 20
 text = bench.synthetic_text(nt, 1234, dev)
-t0 = time.time(); csa = pkg.csa_wt(text=text); print(f"text {mib} MiB index build {time.time()-t0:.2f}s sigma={csa.sigma()} wt_bits={csa.wavelet_tree.bv_size()}")
+t0 = time.time(); csa = pkg.csa_wt(text=text, rrr=rrr); print(f"text {mib} MiB rrr={rrr} index build {time.time()-t0:.2f}s sigma={csa.sigma()} wt_bits={csa.wavelet_tree.bv_size()} index_bytes={csa.device_bytes()/2**20:.1f} MiB")
 wt = csa.wavelet_tree
 g = torch.Generator(device=dev).manual_seed(5)
 gi = torch.randint(0, nt + 1, (nq,), device=dev, dtype=torch.int64, generator=g)
