@@ -9,8 +9,12 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp
 BENCH="python $R/bench.py --steps 5 --warmup 1 --extras select --no-cpu --queries $Q"
-rocprofv3 --kernel-trace --stats -d $O/trace -o bench --output-format csv -- $BENCH > $O/bench_trace.log 2>&1
+# the trace of the headline command has no extras, so that every k_rank launch in it is a full step and the
+# --stats average can be compared directly with bench.py's own HIP-event figure (roofline.kernel_ms)
+rocprofv3 --kernel-trace --stats -d $O/trace -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 1 --extras none --no-cpu --queries $Q > $O/bench_trace.log 2>&1
 echo "trace exit=$?"
+rocprofv3 --kernel-trace --stats -d $O/trace_select -o bench --output-format csv -- $BENCH > $O/bench_trace_select.log 2>&1
+echo "trace_select exit=$?"
 # PMC passes: counters only (no trace domains), separate runs per counter group (TCC has 4 slots)
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $O/pmc_rd -o bench --output-format csv -- $BENCH > $O/bench_pmc_rd.log 2>&1
 echo "pmc_rd exit=$?"

@@ -31,6 +31,17 @@ with open(os.path.join(dst, f"bench_{tag}_kernel_stats.csv"), "w", newline="") a
         w.writerow([short(r["Name"])[:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                     r["MinNs"], r["MaxNs"], r["StdDev"]])
 
+try:
+    rows2 = list(csv.DictReader(open(os.path.join(src, "trace_select", "bench_kernel_stats.csv"))))
+    with open(os.path.join(dst, f"bench_{tag}_kernel_stats_with_select.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows2[:14]:
+            w.writerow([short(r["Name"])[:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"], r["StdDev"]])
+except Exception:
+    pass
+
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ("pmc_rd", "pmc_wr", "pmc_fetch", "pmc_write", "pmc_sq"):
     p = os.path.join(src, sub, "bench_counter_collection.csv")
