@@ -172,6 +172,26 @@ int main(int argc, char ** argv)
         uint64_t p = bytes.size() / 3;
         CHECK(dw[p] == wt[p] and dw.inverse_select(p) == wt.inverse_select(p), "wt_huff::operator[] / inverse_select");
         CHECK(dw.select(1, bytes[p]) == wt.select(1, bytes[p]), "wt_huff::select");
+        // the compressed flavour through the same adaptor
+        wt_huff<rrr_vector<63>> wr(bytes.begin(), bytes.end());
+        wt_huff_hip dr(wr, SDSL_HIP_LAYOUT_RRR63);
+        dr.rank_batch(i.data(), c.data(), q, o.data());
+        bool okr = true;
+        for (size_t k = 0; k < q; ++k)
+            okr &= o[k] == wr.rank(i[k], c[k]);
+        CHECK(okr, "wt_huff<rrr_vector<63>>::rank");
+        CHECK(dr[p] == wr[p] and dr.inverse_select(p) == wr.inverse_select(p), "wt_huff<rrr>::operator[] / inverse_select");
+        std::vector<uint64_t> si(q);
+        std::vector<uint8_t> sc(q);
+        for (size_t k = 0; k < q; ++k)
+        {
+            sc[k] = bytes[rng() % bytes.size()];
+            si[k] = 1 + rng() % wr.rank(bytes.size(), sc[k]);
+        }
+        dr.select_batch(si.data(), sc.data(), q, o.data());
+        for (size_t k = 0; k < q; ++k)
+            okr &= o[k] == wr.select(si[k], sc[k]);
+        CHECK(okr, "wt_huff<rrr_vector<63>>::select");
     }
     {
         csa_t csa;

@@ -870,17 +870,16 @@ sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, c
     }
     hipStream_t s = (hipStream_t)stream;
     SH_HIP(hipSetDevice(wt->h.device));
-    if (wt->h.backend == 1)
-    {
-        set_error("wt.select on an rrr-compressed wavelet tree is not implemented on the device yet");
-        return SDSL_HIP_ERR_UNSUPPORTED;
-    }
     if (n == 0)
         return SDSL_HIP_OK;
     Staged si, sc, so;
     SH_TRY(si.in(i, n * 8, s));
     SH_TRY(sc.in(c, n, s));
     SH_TRY(so.out(out, n * 8));
+    if (wt->h.backend == 1)
+        SH_TRY(wt_rrr_launch_select(wt->h, wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev, (const uint8_t *)sc.dev, n,
+                                    (uint64_t *)so.dev, s));
+    else
     {
         KernelTimer t(s);
         hipLaunchKernelGGL((k_wt_select<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s,

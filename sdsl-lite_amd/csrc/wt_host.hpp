@@ -49,6 +49,8 @@ uint64_t wt_bv_bits(const WtHost & wt);
 // kernels over the rrr backend (wt_rrr.hip)
 sdsl_hip_status wt_rrr_launch_rank(const WtHost & wt, const uint64_t * d_i, const uint8_t * d_c, uint64_t n,
                                    uint64_t * d_out, hipStream_t s);
+sdsl_hip_status wt_rrr_launch_select(const WtHost & wt, const uint64_t * d_occ, const uint64_t * d_i, const uint8_t * d_c,
+                                     uint64_t n, uint64_t * d_out, hipStream_t s);
 sdsl_hip_status wt_rrr_launch_inverse_select(const WtHost & wt, const uint64_t * d_i, uint64_t n, uint64_t * d_rank,
                                              uint8_t * d_c, hipStream_t s);
 

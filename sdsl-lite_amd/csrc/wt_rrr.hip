@@ -307,6 +307,102 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_backward_step_rrr(WtView wt,
     }
 }
 
+// select on the rrr vector for this lane's own argument: position of the (k0+1)-th BIT-valued bit, where the bit
+// value differs per lane.  The cooperative head (rrr_select_head) runs once per active query of the quad; queries
+// are rotated through quad lane 0 so the loop body exists once per bit value.
+__device__ __forceinline__ uint64_t quad4_rrr_select(const RrrView & v, const RrrTables * RT, int s, uint64_t k0,
+                                                     unsigned bit, bool act)
+{
+    SelTail mine;
+    mine.r = v.rec;
+    mine.bstart = 0;
+    mine.k = mine.blen = mine.rel = mine.want = 0;
+    uint64_t rk = act ? k0 : 0;
+    unsigned rflags = (act ? 1u : 0u) | (bit << 1);
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u)
+    {
+        const unsigned f = quad_bcast0(rflags);
+        const uint64_t k = quad_bcast0_u64(rk);
+        if (f & 1u)
+        { // quad-uniform
+            SelTail t = (f & 2u) ? rrr_select_head<1>(v, RT, s, k) : rrr_select_head<0>(v, RT, s, k);
+            if (s == u)
+                mine = t;
+        }
+        // rotate the queries by one lane: quad_perm:[1,2,3,0]
+        rflags = (unsigned)__builtin_amdgcn_update_dpp(0, (int)rflags, 0x39, 0xF, 0xF, true);
+        unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)rk, 0x39, 0xF, 0xF, true);
+        unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(rk >> 32), 0x39, 0xF, 0xF, true);
+        rk = ((uint64_t)hi << 32) | lo;
+    }
+    if (!act)
+        return 0;
+    const uint64_t ptr = mine.r[1] & ((UINT64_C(1) << 48) - 1);
+    const uint64_t nr = rrr_field(v, mine.r, ptr, mine.rel, RT->space[mine.k]);
+    uint64_t bits = rrr_decode_block(RT, mine.k, nr);
+    if (!bit)
+        bits = ~bits & lo_set(mine.blen);
+    return mine.bstart + sel64(bits, mine.want + 1);
+}
+
+// wt_pc::select (wt_pc.hpp:441-480), one query per lane: bottom-up, one rrr select per level whose bit value is
+// the path bit of that level.
+__global__ __launch_bounds__(kWtRrrBlock) void k_wt_select_rrr(WtView wt, const uint64_t * __restrict__ occ,
+                                                               const uint64_t * __restrict__ iq,
+                                                               const uint8_t * __restrict__ cq,
+                                                               uint64_t * __restrict__ out, uint64_t n)
+{
+    __shared__ WtTables T;
+    __shared__ RrrTables RT;
+    rrr_stage_tables(&RT, wt.rrr.tables);
+    wt_stage_tables(&T, wt.tables);
+    const int s = threadIdx.x & 3;
+    for (uint64_t base = (uint64_t)blockIdx.x * kWtRrrBlock; base < n; base += (uint64_t)gridDim.x * kWtRrrBlock)
+    {
+        const uint64_t q = base + threadIdx.x;
+        const uint64_t i = q < n ? iq[q] : 0;
+        const unsigned c = q < n ? cq[q] : 0;
+        unsigned v = T.c_to_leaf[c];
+        const bool present = v != kWtUndef;
+        const bool in_dom = present && i >= 1 && i <= occ[c];
+        const bool run = q < n && in_dom && wt.sigma != 1;
+        uint64_t res = i - 1;
+        uint64_t p = T.path[c];
+        const unsigned len = (unsigned)(p >> 56);
+        p = len ? p << (64 - len) : 0;
+        for (unsigned l = 0;; ++l)
+        {
+            const bool act = run && l < len;
+            if (!quad_any(act))
+                break;
+            const unsigned par = act ? T.parent[v] : 0;
+            const unsigned bit = (unsigned)(p >> 63);
+            const uint64_t k0 = bit ? T.bv_pos_rank[par] + res : T.bv_pos[par] - T.bv_pos_rank[par] + res;
+            const uint64_t pos = quad4_rrr_select(wt.rrr, &RT, s, k0, bit, act);
+            if (act)
+            {
+                res = pos - T.bv_pos[par];
+                v = par;
+                p <<= 1;
+            }
+        }
+        if (q < n)
+        {
+            uint64_t r;
+            if (!present)
+                r = wt.size; // c not in the text (wt_pc.hpp:447-450)
+            else if (!in_dom)
+                r = SDSL_HIP_NPOS; // outside SDSL's precondition
+            else if (wt.sigma == 1)
+                r = i - 1 < wt.size ? i - 1 : wt.size;
+            else
+                r = res;
+            out[q] = r;
+        }
+    }
+}
+
 static unsigned wt_rrr_grid(uint64_t n)
 {
     return grid_for(n, kWtRrrBlock, 256u * 3u);
@@ -319,6 +415,18 @@ sdsl_hip_status wt_rrr_launch_rank(const WtHost & wt, const uint64_t * d_i, cons
         return SDSL_HIP_OK;
     KernelTimer t(s);
     hipLaunchKernelGGL(k_wt_rank_rrr, dim3(wt_rrr_grid(n)), dim3(kWtRrrBlock), 0, s, wt.view(), d_i, d_c, d_out, n);
+    SH_HIP(hipGetLastError());
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status wt_rrr_launch_select(const WtHost & wt, const uint64_t * d_occ, const uint64_t * d_i, const uint8_t * d_c,
+                                     uint64_t n, uint64_t * d_out, hipStream_t s)
+{
+    if (n == 0)
+        return SDSL_HIP_OK;
+    KernelTimer t(s);
+    hipLaunchKernelGGL(k_wt_select_rrr, dim3(wt_rrr_grid(n)), dim3(kWtRrrBlock), 0, s, wt.view(), d_occ, d_i, d_c, d_out,
+                       n);
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }

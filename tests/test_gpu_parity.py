@@ -518,9 +518,16 @@ def test_wt_rrr_golden(gpu, name):
         assert np.array_equal(wt.access(ai), g[f"{name}/acc"])
         r, c = wt.inverse_select(ai)
         assert np.array_equal(r, g[f"{name}/invsel_rank"]) and np.array_equal(c, g[f"{name}/acc"])
-        with pytest.raises(gpu.capi.SdslHipError) as e:
-            wt.select(g[f"{name}/sel_i"], g[f"{name}/sel_c"])
-        assert e.value.status == gpu.capi.ERR_UNSUPPORTED
+        assert np.array_equal(wt.select(g[f"{name}/sel_i"], g[f"{name}/sel_c"]), g[f"{name}/sel"])
+        # absent symbol -> size(); i outside [1, occ] -> NPOS: the same contract as the plain tree
+        absent = [c for c in range(256) if g[f"{name}/rank_full"][c] == 0]
+        if absent:
+            got = wt.select(np.array([1], dtype=np.uint64), np.array([absent[0]], dtype=np.uint8))
+            assert int(got[0]) == n
+        c0 = int(data[0])
+        occ = int(g[f"{name}/rank_full"][c0])
+        got = wt.select(np.array([0, occ + 1, occ], dtype=np.uint64), np.full(3, c0, dtype=np.uint8))
+        assert int(got[0]) == int(NPOS) and int(got[1]) == int(NPOS) and int(got[2]) < n
 
 
 @pytest.mark.parametrize("name", ["example01.txt", "faust.txt"])
@@ -533,10 +540,32 @@ def test_wt_rrr_streams(gpu, name):
     assert loaded.consumed == len(blob)
     assert np.array_equal(loaded.rank(g[f"{name}/rank_i"], g[f"{name}/rank_c"]), g[f"{name}/rank"])
     assert np.array_equal(loaded.access(g[f"{name}/acc_i"]), g[f"{name}/acc"])
+    assert np.array_equal(loaded.select(g[f"{name}/sel_i"], g[f"{name}/sel_c"]), g[f"{name}/sel"])
     assert loaded.serialize() == blob
     for cut in (17, len(blob) // 3, len(blob) - 1):
         with pytest.raises(gpu.capi.SdslHipError):
             gpu.wt_huff(sdsl_bytes=blob[:cut], rrr=True)
+
+
+def _zipf(k):
+    w = 1.0 / np.arange(1, k + 1)
+    return w / w.sum()
+
+
+def test_wt_rrr_select_roundtrip_large(gpu):
+    """select(rank(i, wt[i]) + 1, wt[i]) == i on a 32 MiB text, both backends agreeing"""
+    rng = np.random.default_rng(5)
+    n = 1 << 25
+    data = rng.choice(np.arange(1, 200, dtype=np.uint8), size=n, p=_zipf(199)).astype(np.uint8)
+    wt = gpu.wt_huff(data, rrr=True)
+    pos = rng.integers(0, n, 200000).astype(np.uint64)
+    r, c = wt.inverse_select(pos)
+    assert np.array_equal(c, data[pos.astype(np.int64)])
+    assert np.array_equal(wt.select(r + np.uint64(1), c), pos)
+    plain = gpu.wt_huff(data)
+    i = rng.integers(1, 1000, 50000).astype(np.uint64)
+    cc = data[rng.integers(0, n, 50000)]
+    assert np.array_equal(plain.select(i, cc), wt.select(i, cc))
 
 
 @pytest.mark.parametrize("name", FM_TEXTS)
