@@ -43,8 +43,11 @@ __global__ __launch_bounds__(256) void k_fm_keys(const uint8_t * __restrict__ pa
     }
 }
 
-// One pattern per quad.  The two rank cascades of every LF step run level-synchronously with both
-// line fetches in flight (wt_device.hpp: quad_wt_rank2).
+// One pattern per quad.  The two rank cascades of every LF step run level by level with both line fetches in
+// flight (wt_device.hpp: quad_wt_rank2_level).  The loop is FLAT — one iteration is one tree level of whatever
+// character the quad is at — so the 16 quads of a wave do not wait for each other at character boundaries (Huffman
+// paths differ in length; a nested loop would cost max(len) instead of len per character).  The next pattern byte is
+// fetched one character ahead.
 template <bool NT, bool WANT_IVAL>
 __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables * __restrict__ ftab,
                                                      uint64_t csa_size, const uint8_t * __restrict__ pats,
@@ -75,31 +78,59 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
             r = 0;
             end = begin;
         }
-        for (uint64_t it = end; it > begin && r + 1 - l > 0;)
+        uint64_t it = end;
+        unsigned c_next = it > begin ? pats[it - 1] : 0;
+        // state of the character being processed
+        unsigned left = 0, v = 0;
+        uint64_t a = 0, b = 0, p = 0, cb = 0;
+        for (;;)
         {
-            --it;
-            unsigned c = pats[it];
-            unsigned cc = F.char2comp[c];
-            if (cc == 0 && c > 0)
-            { // character does not occur (:180-184)
-                l = 1;
-                r = 0;
-            }
-            else
-            {
-                uint64_t cb = F.C[cc];
+            if (left == 0)
+            { // next character (suffix_array_algorithm.hpp:176-200)
+                if (!(it > begin && r + 1 - l > 0))
+                    break;
+                --it;
+                const unsigned c = c_next;
+                if (it > begin)
+                    c_next = pats[it - 1];
+                const unsigned cc = F.char2comp[c];
+                if (cc == 0 && c > 0)
+                { // character does not occur (:180-184)
+                    l = 1;
+                    r = 0;
+                    continue;
+                }
+                cb = F.C[cc];
                 if (l == 0 && r + 1 == csa_size)
                 { // whole interval: no rank needed (:188-192)
                     l = cb;
                     r = F.C[cc + 1] - 1;
+                    continue;
                 }
-                else
-                {
-                    uint64_t a = l, b = r + 1;
-                    quad_wt_rank2<NT>(wt, &T, s, c, a, b);
+                a = l;
+                b = r + 1;
+                if (wt.sigma == 1)
+                { // one symbol: rank(i, c) == i
                     l = cb + a;
                     r = cb + b - 1;
+                    continue;
                 }
+                p = T.path[c]; // the symbol occurs (char2comp said so), so it has a leaf and a path
+                left = (unsigned)(p >> 56);
+                v = 0;
+            }
+            quad_wt_rank2_level<NT>(wt, &T, s, v, (unsigned)(p & 1), a, b);
+            p >>= 1;
+            --left;
+            if (b == 0)
+            { // a <= b: both chains are 0 from here on (wt_pc.hpp:386)
+                a = 0;
+                left = 0;
+            }
+            if (left == 0)
+            {
+                l = cb + a;
+                r = cb + b - 1;
             }
         }
         if (s == 0)

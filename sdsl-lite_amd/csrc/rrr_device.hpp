@@ -31,50 +31,79 @@ struct RrrView
 };
 
 // ---- device: block decoder -----------------------------------------------------------------------
-// Decodes the 63-bit block with k ones and offset nr.  Sparse blocks: one bisection over the
-// binomial column per set bit (the same idea as the reference's k <= 10 path, rrr_helper.hpp:506-534);
-// dense blocks: one compare/subtract per position.
+// Decodes the 63-bit block with k ones and offset nr (rrr_helper.hpp:480-534: blocks of a class are numbered in
+// lexicographic order of (b0, b1, ...), 0 < 1).
+//
+// Two instruction streams, chosen PER WAVE so that a wave never pays for both:
+//  * sparse: one bisection over the binomial column per set bit (the idea of the reference's k <= 10 path).  The
+//    complement of a block with k ones is the block with 63-k ones and offset C(63,k)-1-nr, so classes >= 53 take
+//    this path too;
+//  * dense: 63 unrolled compare/subtract steps without branches or exec-mask traffic; correct for every class,
+//    so a wave with mixed classes runs only this one.
+__device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsigned k, uint64_t nr)
+{
+    uint64_t bits = 0;
+    int hi = 62; // candidate rows m = 62 - position
+    while (k > 0)
+    {
+        // largest m in [k-1, hi] with C(m, k) <= nr  (C(k-1,k) = 0 always qualifies)
+        int lo = (int)k - 1, h = hi;
+        while (lo < h)
+        {
+            int mid = (lo + h + 1) >> 1;
+            if (T->binom[mid][k] <= nr)
+                lo = mid;
+            else
+                h = mid - 1;
+        }
+        bits |= UINT64_C(1) << (62 - lo);
+        nr -= T->binom[lo][k];
+        --k;
+        hi = lo - 1;
+    }
+    return bits;
+}
+
+__device__ __forceinline__ uint64_t rrr_decode_dense(const RrrTables * T, unsigned k, uint64_t nr)
+{
+    // acc collects the decisions MSB-first (one shift-or per step); bit-reversed at the end
+    unsigned acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int p = 0; p < 32; ++p)
+    {
+        const uint64_t c = T->binom[62 - p][k];
+        const bool one = nr >= c;
+        nr -= one ? c : 0;
+        k -= one ? 1u : 0u;
+        acc0 = (acc0 << 1) | (one ? 1u : 0u);
+    }
+#pragma unroll
+    for (int p = 32; p < 63; ++p)
+    {
+        const uint64_t c = T->binom[62 - p][k];
+        const bool one = nr >= c;
+        nr -= one ? c : 0;
+        k -= one ? 1u : 0u;
+        acc1 = (acc1 << 1) | (one ? 1u : 0u);
+    }
+    return (uint64_t)__brev(acc0) | ((uint64_t)(__brev(acc1) >> 1) << 32);
+}
+
 __device__ __forceinline__ uint64_t rrr_decode_block(const RrrTables * T, unsigned k, uint64_t nr)
 {
-    if (k == 0)
-        return 0;
-    if (k == kRrrBS)
-        return lo_set(kRrrBS);
-    uint64_t bits = 0;
-    if (k <= 10)
-    {
-        int hi = 62; // candidate rows m = 62 - position
-        while (k > 0)
-        {
-            // largest m in [k-1, hi] with C(m, k) <= nr  (C(k-1,k) = 0 always qualifies)
-            int lo = (int)k - 1, h = hi;
-            while (lo < h)
-            {
-                int mid = (lo + h + 1) >> 1;
-                if (T->binom[mid][k] <= nr)
-                    lo = mid;
-                else
-                    h = mid - 1;
-            }
-            bits |= UINT64_C(1) << (62 - lo);
-            nr -= T->binom[lo][k];
-            --k;
-            hi = lo - 1;
-        }
+    const bool flip = k > 31;
+    const unsigned ks = flip ? kRrrBS - k : k;
+    uint64_t bits;
+    if (__builtin_amdgcn_ballot_w64(ks > 10) == 0)
+    { // wave-uniform: every active lane has a sparse block (or a sparse complement)
+        if (flip)
+            nr = T->binom[63][k] - 1 - nr;
+        bits = rrr_decode_sparse(T, ks, nr);
+        if (flip)
+            bits = ~bits & lo_set(kRrrBS);
     }
     else
-    {
-        for (int m = 62; m >= 0 && k > 0; --m)
-        {
-            uint64_t c = T->binom[m][k];
-            if (nr >= c)
-            {
-                nr -= c;
-                --k;
-                bits |= UINT64_C(1) << (62 - m);
-            }
-        }
-    }
+        bits = rrr_decode_dense(T, k, nr);
     return bits;
 }
 
@@ -96,20 +125,27 @@ __device__ __forceinline__ uint64_t rrr_field(const RrrView & v, const uint64_t 
     return read_bits(v.stream, ptr + rel, len);
 }
 
+// sum of the eight bytes of x (each <= 63)
+__device__ __forceinline__ unsigned sum_bytes8(uint64_t x)
+{
+    uint64_t t = (x & UINT64_C(0x00FF00FF00FF00FF)) + ((x >> 8) & UINT64_C(0x00FF00FF00FF00FF));
+    return (unsigned)((t * UINT64_C(0x0001000100010001)) >> 48);
+}
+
 // Sum of (class, space[class]) over this lane's 8 classes with in-superblock index < j; the quad sum
 // gives ones and offset bits before block j.  packed = ones | bits << 16
 __device__ __forceinline__ unsigned rrr_lane_prefix(const RrrTables * T, uint64_t cls8, int s, unsigned j)
 {
+    // keep the classes with in-lane index < j - 8s; the others become class 0, which adds nothing (space[0] == 0)
     int cnt = (int)j - 8 * s;
-    unsigned acc = 0;
+    cnt = cnt < 0 ? 0 : (cnt > 8 ? 8 : cnt);
+    const uint64_t keep = cnt == 8 ? ~UINT64_C(0) : ((UINT64_C(1) << (8 * cnt)) - 1);
+    const uint64_t m = cls8 & keep;
+    unsigned bits = 0;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
-    {
-        unsigned k = (unsigned)(cls8 >> (8 * t)) & 0xFF;
-        if (t < cnt)
-            acc += k | ((unsigned)T->space[k] << 16);
-    }
-    return acc;
+        bits += T->space[(unsigned)(m >> (8 * t)) & 0xFF];
+    return sum_bytes8(m) | (bits << 16);
 }
 
 // value of quad lane U in all four lanes (U is a compile-time constant: DPP quad_perm:[U,U,U,U])
@@ -123,13 +159,6 @@ __device__ __forceinline__ uint64_t quad_bcast_lane_u64(uint64_t v)
 {
     unsigned lo = quad_bcast_lane<U>((unsigned)v), hi = quad_bcast_lane<U>((unsigned)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
-}
-
-// sum of the eight bytes of x (each <= 63)
-__device__ __forceinline__ unsigned sum_bytes8(uint64_t x)
-{
-    uint64_t t = (x & UINT64_C(0x00FF00FF00FF00FF)) + ((x >> 8) & UINT64_C(0x00FF00FF00FF00FF));
-    return (unsigned)((t * UINT64_C(0x0001000100010001)) >> 48);
 }
 
 // What the lane-parallel phase needs to finish one rank/access query.

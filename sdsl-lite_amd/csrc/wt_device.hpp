@@ -76,6 +76,26 @@ __device__ __forceinline__ uint64_t quad_wt_rank(const WtView & wt, const WtTabl
 // a = rank(ia, c), b = rank(ib, c).  This is the inner step of backward_search
 // (suffix_array_algorithm.hpp:195-196).  When both positions fall into the same line (the usual
 // case once the SA interval is narrow) the line is fetched once.
+// one level of both cascades: node v, path bit `bit`; a <= b are offsets inside v's slice
+template <bool NT>
+__device__ __forceinline__ void quad_wt_rank2_level(const WtView & wt, const WtTables * T, int s, unsigned & v,
+                                                    unsigned bit, uint64_t & a, uint64_t & b)
+{
+    const uint64_t base = T->bv_pos[v], brank = T->bv_pos_rank[v];
+    uint64_t pa = base + a, pb = base + b;
+    uint64_t La = pa / kDB, Lb = pb / kDB;
+    Pair wb = load_pair<NT>(wt.bv.lines, Lb, s);
+    Pair wa = wb;
+    if (La != Lb) // quad-uniform
+        wa = load_pair<NT>(wt.bv.lines, La, s);
+    // rank at bv_pos+0 equals bv_pos_rank, so a == 0 stays 0 without a special case
+    uint64_t ra = quad_rank1(wa, s, pa, La) - brank;
+    uint64_t rb = quad_rank1(wb, s, pb, Lb) - brank;
+    a = bit ? ra : a - ra;
+    b = bit ? rb : b - rb;
+    v = T->child[v][bit];
+}
+
 template <bool NT>
 __device__ __forceinline__ void quad_wt_rank2(const WtView & wt, const WtTables * T, int s, unsigned c, uint64_t & a,
                                               uint64_t & b)
@@ -91,22 +111,7 @@ __device__ __forceinline__ void quad_wt_rank2(const WtView & wt, const WtTables 
     unsigned len = (unsigned)(p >> 56);
     unsigned v = 0;
     for (unsigned l = 0; l < len && b; ++l, p >>= 1) // a <= b always; b == 0 ends both chains
-    {
-        const uint64_t base = T->bv_pos[v], brank = T->bv_pos_rank[v];
-        uint64_t pa = base + a, pb = base + b;
-        uint64_t La = pa / kDB, Lb = pb / kDB;
-        Pair wb = load_pair<NT>(wt.bv.lines, Lb, s);
-        Pair wa = wb;
-        if (La != Lb) // quad-uniform
-            wa = load_pair<NT>(wt.bv.lines, La, s);
-        // rank at bv_pos+0 equals bv_pos_rank, so a == 0 stays 0 without a special case
-        uint64_t ra = quad_rank1(wa, s, pa, La) - brank;
-        uint64_t rb = quad_rank1(wb, s, pb, Lb) - brank;
-        unsigned bit = (unsigned)(p & 1);
-        a = bit ? ra : a - ra;
-        b = bit ? rb : b - rb;
-        v = T->child[v][bit];
-    }
+        quad_wt_rank2_level<NT>(wt, T, s, v, (unsigned)(p & 1), a, b);
     if (b == 0)
         a = 0;
 }
@@ -148,9 +153,8 @@ __device__ __forceinline__ bool quad_any(bool b)
     return quad_sum(b ? 1u : 0u) != 0;
 }
 
-// rank_1(pos) of this lane's own query on the rrr vector (undefined if !act); optionally the bit at pos
-__device__ __forceinline__ uint64_t quad4_rrr_rank1(const RrrView & v, const RrrTables * RT, int s, uint64_t pos, bool act,
-                                                    unsigned * bit_out = nullptr)
+// cooperative halves for the four queries of a quad: lane U ends up with the tail of its own query
+__device__ __forceinline__ RankTail quad4_rrr_heads(const RrrView & v, const RrrTables * RT, int s, uint64_t pos, bool act)
 {
     const uint64_t safe = act ? pos : 0;
     RankTail mine, t;
@@ -182,10 +186,47 @@ __device__ __forceinline__ uint64_t quad4_rrr_rank1(const RrrView & v, const Rrr
         if (s == 3)
             mine = t;
     }
-    uint64_t bits = rrr_decode_block(RT, mine.k, mine.nr);
+    return mine;
+}
+
+// rank_1(pos) of this lane's own query on the rrr vector (undefined if !act); optionally the bit at pos
+__device__ __forceinline__ uint64_t quad4_rrr_rank1(const RrrView & v, const RrrTables * RT, int s, uint64_t pos, bool act,
+                                                    unsigned * bit_out = nullptr)
+{
+    const RankTail mine = quad4_rrr_heads(v, RT, s, pos, act);
+    uint64_t bits = 0;
+    if (act && (bit_out || mine.off != 0)) // rank at a block boundary needs no decode
+        bits = rrr_decode_block(RT, mine.k, mine.nr);
     if (bit_out)
         *bit_out = (unsigned)(bits >> mine.off) & 1u;
     return mine.rank + popc64(bits & lo_set(mine.off));
+}
+
+// rank_1(pa) and rank_1(pb), pa <= pb, of this lane's own query: the two cascades of an LF step
+// (suffix_array_algorithm.hpp:195-196).  Once the SA interval is narrow both positions usually fall into the same
+// 63-bit block: then b reuses a's head and decoded block; and a b that starts a block needs no decode at all — for
+// an interval of size one (b == a + 1) one of the two always holds.
+__device__ __forceinline__ void quad4_rrr_rank2(const RrrView & v, const RrrTables * RT, int s, uint64_t pa, uint64_t pb,
+                                                bool act, uint64_t & ra, uint64_t & rb)
+{
+    const uint64_t sa = act ? pa : 0, sb = act ? pb : 0;
+    const uint64_t blk_a = sa / kRrrBS, blk_b = sb / kRrrBS;
+    const bool same = blk_a == blk_b;
+    const RankTail ta = quad4_rrr_heads(v, RT, s, sa, act);
+    RankTail tb = quad4_rrr_heads(v, RT, s, sb, act && !same);
+    if (same)
+    {
+        tb.rank = ta.rank;
+        tb.off = (unsigned)(sb - blk_b * kRrrBS);
+    }
+    uint64_t bits_a = 0;
+    if (act && (ta.off != 0 || (same && tb.off != 0)))
+        bits_a = rrr_decode_block(RT, ta.k, ta.nr);
+    ra = ta.rank + popc64(bits_a & lo_set(ta.off));
+    uint64_t bits_b = bits_a;
+    if (act && !same && tb.off != 0)
+        bits_b = rrr_decode_block(RT, tb.k, tb.nr);
+    rb = tb.rank + popc64(bits_b & lo_set(tb.off));
 }
 
 } // namespace sdslhip

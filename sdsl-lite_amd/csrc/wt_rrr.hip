@@ -131,76 +131,77 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const F
             end = begin;
         }
         uint64_t it = end;
+        unsigned c_next = valid && it > begin ? pats[it - 1] : 0;
+        // Flat loop: one iteration is one tree level of whatever character the lane is at, so lanes do not wait for
+        // each other at character boundaries (Huffman paths differ in length).
+        bool alive = valid;
+        unsigned left = 0, v = 0;
+        uint64_t a = 0, b = 0, p = 0, cb = 0;
         for (;;)
         {
-            const bool more = valid && it > begin && r + 1 - l > 0;
-            if (!quad_any(more))
-                break;
-            // this lane's next character (lanes without work idle through the cascade)
-            bool need = false;
-            unsigned c = 0;
-            uint64_t cb = 0, a = 0, b = 0, p = 0;
-            unsigned len = 0;
-            if (more)
-            {
+            while (alive && left == 0)
+            { // next character (suffix_array_algorithm.hpp:176-200); lane-divergent and short
+                if (!(it > begin && r + 1 - l > 0))
+                {
+                    alive = false;
+                    break;
+                }
                 --it;
-                c = pats[it];
-                unsigned cc = F.char2comp[c];
+                const unsigned c = c_next;
+                if (it > begin)
+                    c_next = pats[it - 1];
+                const unsigned cc = F.char2comp[c];
                 if (cc == 0 && c > 0)
                 { // character does not occur (:180-184)
                     l = 1;
                     r = 0;
+                    continue;
                 }
-                else
+                cb = F.C[cc];
+                if (l == 0 && r + 1 == csa_size)
+                { // whole interval: no rank needed (:188-192)
+                    l = cb;
+                    r = F.C[cc + 1] - 1;
+                    continue;
+                }
+                a = l;
+                b = r + 1;
+                if (wt.sigma == 1)
                 {
-                    cb = F.C[cc];
-                    if (l == 0 && r + 1 == csa_size)
-                    { // whole interval: no rank needed (:188-192)
-                        l = cb;
-                        r = F.C[cc + 1] - 1;
-                    }
-                    else
-                    {
-                        a = l;
-                        b = r + 1;
-                        if (wt.sigma != 1)
-                        { // the symbol occurs (char2comp said so): walk its path
-                            p = T.path[c];
-                            len = (unsigned)(p >> 56);
-                            need = true;
-                        }
-                        else
-                        {
-                            l = cb + a;
-                            r = cb + b - 1;
-                        }
-                    }
+                    l = cb + a;
+                    r = cb + b - 1;
+                    continue;
                 }
+                p = T.path[c]; // the symbol occurs (char2comp said so): walk its path
+                left = (unsigned)(p >> 56);
+                v = 0;
             }
-            unsigned v = 0;
-            for (unsigned lev = 0;; ++lev)
+            if (!quad_any(alive))
+                break;
+            const uint64_t bp = T.bv_pos[v], br = T.bv_pos_rank[v];
+            uint64_t ra, rb;
+            quad4_rrr_rank2(wt.rrr, &RT, s, bp + a, bp + b, alive, ra, rb);
+            if (alive)
             {
-                const bool act = need && lev < len && b != 0; // a <= b: b == 0 ends both chains
-                if (!quad_any(act))
-                    break;
-                const uint64_t bp = T.bv_pos[v], br = T.bv_pos_rank[v];
-                uint64_t ra = quad4_rrr_rank1(wt.rrr, &RT, s, bp + a, act) - br;
-                uint64_t rb = quad4_rrr_rank1(wt.rrr, &RT, s, bp + b, act) - br;
-                if (act)
-                {
-                    unsigned bit = (unsigned)(p & 1);
-                    a = bit ? ra : a - ra;
-                    b = bit ? rb : b - rb;
-                    v = T.child[v][bit];
-                    p >>= 1;
-                }
-            }
-            if (need)
-            {
+                ra -= br;
+                rb -= br;
+                const unsigned bit = (unsigned)(p & 1);
+                a = bit ? ra : a - ra;
+                b = bit ? rb : b - rb;
+                v = T.child[v][bit];
+                p >>= 1;
+                --left;
                 if (b == 0)
+                { // a <= b: both chains are 0 from here on (wt_pc.hpp:386)
                     a = 0;
-                l = cb + a;
-                r = cb + b - 1;
+                    left = 0;
+                }
+                if (left == 0)
+                {
+                    l = cb + a;
+                    r = cb + b - 1;
+                    v = 0;
+                }
             }
         }
         if (valid)
@@ -281,8 +282,10 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_backward_step_rrr(WtView wt,
             if (!quad_any(act))
                 break;
             const uint64_t bp = T.bv_pos[v], br = T.bv_pos_rank[v];
-            uint64_t ra = quad4_rrr_rank1(wt.rrr, &RT, s, bp + a, act) - br;
-            uint64_t rb = quad4_rrr_rank1(wt.rrr, &RT, s, bp + b, act) - br;
+            uint64_t ra, rb;
+            quad4_rrr_rank2(wt.rrr, &RT, s, bp + a, bp + b, act, ra, rb);
+            ra -= br;
+            rb -= br;
             if (act)
             {
                 unsigned bit = (unsigned)(p & 1);
