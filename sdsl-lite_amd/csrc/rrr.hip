@@ -13,12 +13,14 @@
 //   word 0      ones before the superblock                       (SDSL m_rank[s])
 //   word 1      bits 0..47  bit pointer into the offset stream   (SDSL m_btnrp[s])
 //               bits 48..59 ones inside the superblock
-//   words 2..5  the 32 block classes as bytes, inversion already undone (SDSL m_bt + m_invert)
-//   words 6..15 inline copy of the first 640 bits of the superblock's offsets (SDSL m_btnr)
+//   word 2      prefix word: ones and offset bits in blocks [0,8), [0,16), [0,24) (rrr_device.hpp rrr_pack_prefix)
+//   words 3..6  the 32 block classes as bytes, inversion already undone (SDSL m_bt + m_invert)
+//   words 7..15 inline copy of the first 576 bits of the superblock's offsets (SDSL m_btnr)
 // plus the full offset stream.  An L2 miss costs the same for 64 and 128 bytes on MI355X (the
 // random-request rate is the bound, profiles/gather_probe_r01.txt), so packing header, classes and
 // the usually-sufficient head of the offsets into ONE line turns SDSL's five scattered arrays into
-// one fetch for most queries; only long offset runs touch the stream (second fetch).
+// one fetch for most queries; only long offset runs touch the stream (second fetch).  The prefix word lets ONE
+// lane locate a block with byte arithmetic on a single class word, so queries run one per lane.
 #include <algorithm>
 #include <atomic>
 #include <mutex>
@@ -127,10 +129,7 @@ bad:
     return SDSL_HIP_ERR_FORMAT;
 }
 
-// rank / access.  Four queries per quad per round: the cooperative half runs once per query with all four
-// lanes (sub-round U serves the query owned by lane U), the expensive half — decoding the 63-bit block — runs
-// ONCE with every lane decoding its own query, i.e. 64 different blocks per wave instead of 16 blocks four
-// times over.
+// rank / access, one query per lane
 template <int MODE> // 0: rank, 1: access
 __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, const uint64_t * __restrict__ iq,
                                                         uint64_t * __restrict__ out, uint8_t * __restrict__ out8,
@@ -138,84 +137,47 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, cons
 {
     __shared__ RrrTables T;
     rrr_stage_tables(&T, v.tables);
-    const int s = threadIdx.x & 3;
-    for (uint64_t base = (uint64_t)blockIdx.x * kRrrBlock; base < n; base += (uint64_t)gridDim.x * kRrrBlock)
+    for (uint64_t q = (uint64_t)blockIdx.x * kRrrBlock + threadIdx.x; q < n; q += (uint64_t)gridDim.x * kRrrBlock)
     {
-        const uint64_t q = base + threadIdx.x;
-        const uint64_t i_mine = q < n ? iq[q] : 0;
-        const bool ok_mine = MODE == 0 ? i_mine <= v.n_bits : i_mine < v.n_bits;
-        const uint64_t i_safe = ok_mine ? i_mine : 0;
-        RankTail mine, t;
-        t = rrr_rank_head(v, &T, s, quad_bcast_lane_u64<0>(i_safe));
-        mine = t;
-        t = rrr_rank_head(v, &T, s, quad_bcast_lane_u64<1>(i_safe));
-        if (s == 1)
-            mine = t;
-        t = rrr_rank_head(v, &T, s, quad_bcast_lane_u64<2>(i_safe));
-        if (s == 2)
-            mine = t;
-        t = rrr_rank_head(v, &T, s, quad_bcast_lane_u64<3>(i_safe));
-        if (s == 3)
-            mine = t;
-        // lane-parallel half
-        uint64_t bits = rrr_decode_block(&T, mine.k, mine.nr);
-        if (q < n)
+        const uint64_t i = iq[q];
+        const bool ok = MODE == 0 ? i <= v.n_bits : i < v.n_bits;
+        if (MODE == 1)
         {
-            if (MODE == 1)
-                out8[q] = ok_mine ? (uint8_t)((bits >> mine.off) & 1) : 0xFF;
-            else
+            unsigned b = 0xFF;
+            if (ok)
+                rrr_rank1(v, &T, i, &b);
+            out8[q] = (uint8_t)b;
+        }
+        else
+        {
+            uint64_t r = SDSL_HIP_NPOS;
+            if (ok)
             {
-                uint64_t r1 = mine.rank + popc64(bits & lo_set(mine.off));
-                out[q] = ok_mine ? (bit ? r1 : i_mine - r1) : SDSL_HIP_NPOS;
+                const uint64_t r1 = rrr_rank1(v, &T, i);
+                r = bit ? r1 : i - r1;
             }
+            out[q] = r;
         }
     }
 }
 
+// select, one query per lane
 template <int BIT>
 __global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint64_t * __restrict__ iq,
                                                           uint64_t * __restrict__ out, uint64_t n)
 {
     __shared__ RrrTables T;
     rrr_stage_tables(&T, v.tables);
-    const int s = threadIdx.x & 3;
     const uint64_t total = BIT ? v.ones : v.n_bits - v.ones;
-    for (uint64_t base = (uint64_t)blockIdx.x * kRrrBlock; base < n; base += (uint64_t)gridDim.x * kRrrBlock)
+    for (uint64_t q = (uint64_t)blockIdx.x * kRrrBlock + threadIdx.x; q < n; q += (uint64_t)gridDim.x * kRrrBlock)
     {
-        const uint64_t q = base + threadIdx.x;
-        const uint64_t i_mine = q < n ? iq[q] : 0;
-        const bool ok_mine = i_mine >= 1 && i_mine <= total;
-        // out-of-domain arguments ride along as rank 0 (if there is any argument at all) and are overwritten below
-        const uint64_t k_safe = ok_mine ? i_mine - 1 : 0;
-        SelTail mine, t;
-        if (total != 0)
-        { // block-uniform
-            t = rrr_select_head<BIT>(v, &T, s, quad_bcast_lane_u64<0>(k_safe));
-            mine = t;
-            t = rrr_select_head<BIT>(v, &T, s, quad_bcast_lane_u64<1>(k_safe));
-            if (s == 1)
-                mine = t;
-            t = rrr_select_head<BIT>(v, &T, s, quad_bcast_lane_u64<2>(k_safe));
-            if (s == 2)
-                mine = t;
-            t = rrr_select_head<BIT>(v, &T, s, quad_bcast_lane_u64<3>(k_safe));
-            if (s == 3)
-                mine = t;
-        }
-        if (q >= n)
-            continue;
-        if (!ok_mine)
-        { // i > #args: SDSL returns size() (rrr_vector.hpp:641-642, 686-689); i == 0 is outside its domain
-            out[q] = i_mine == 0 ? SDSL_HIP_NPOS : v.n_bits;
-            continue;
-        }
-        // lane-parallel half: every lane finishes its own query
-        uint64_t ptr = mine.r[1] & ((UINT64_C(1) << 48) - 1);
-        uint64_t nr = rrr_field(v, mine.r, ptr, mine.rel, T.space[mine.k]);
-        uint64_t bits = rrr_decode_block(&T, mine.k, nr);
-        if (!BIT)
-            bits = ~bits & lo_set(mine.blen);
-        out[q] = mine.bstart + sel64(bits, mine.want + 1);
+        const uint64_t i = iq[q];
+        uint64_t r;
+        if (i >= 1 && i <= total)
+            r = rrr_select<BIT>(v, &T, i - 1);
+        else // i > #args: SDSL returns size() (rrr_vector.hpp:641-642, 686-689); i == 0 is outside its domain
+            r = i == 0 ? SDSL_HIP_NPOS : v.n_bits;
+        out[q] = r;
     }
 }
 
@@ -249,21 +211,28 @@ __global__ __launch_bounds__(256) void k_rrr_enc_classes(const uint64_t * __rest
     {
         unsigned ones = 0, len = 0;
         uint64_t cw[4] = {0, 0, 0, 0};
+        unsigned po[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
         for (unsigned j = 0; j < kRrrK; ++j)
         {
+            if (j && (j & 7) == 0)
+            {
+                po[(j >> 3) - 1] = ones;
+                pb[(j >> 3) - 1] = len;
+            }
             uint64_t b = sb * kRrrK + j;
             if (b >= n_blocks)
-                break;
+                continue; // blocks behind the end count as class 0
             unsigned k = popc64(rrr_block_bits(words, n_bits, b));
             cw[j >> 3] |= (uint64_t)k << (8 * (j & 7));
             ones += k;
             len += space[k];
         }
         uint64_t * r = rec + sb * kRecWords;
-        r[2] = cw[0];
-        r[3] = cw[1];
-        r[4] = cw[2];
-        r[5] = cw[3];
+        r[2] = rrr_pack_prefix(po, pb);
+        r[kRecClasses + 0] = cw[0];
+        r[kRecClasses + 1] = cw[1];
+        r[kRecClasses + 2] = cw[2];
+        r[kRecClasses + 3] = cw[3];
         sb_ones[sb] = ones;
         sb_len[sb] = len;
     }
@@ -288,7 +257,7 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
         const uint64_t start = sb * kRrrSB;
         uint64_t acc1 = ones_before, acc0 = start - ones_before; // arguments before the current block
         uint64_t j1 = (acc1 + S - 1) >> sh, j0 = (acc0 + S - 1) >> sh;
-        uint64_t inl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t inl[kInlineWords] = {};
         unsigned rel = 0;
         for (unsigned j = 0; j < kRrrK; ++j)
         {
@@ -316,11 +285,11 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
                 if (off + len > 64)
                     atomicOr(&stream[(pos >> 6) + 1], (unsigned long long)(nr >> (64 - off)));
                 if (rel < kInlineBits)
-                { // inline copy of the first 640 offset bits (a field may be cut by the boundary; readers only
+                { // inline copy of the first 576 offset bits (a field may be cut by the boundary; readers only
                   // use the inline area for fields that lie in it completely)
                     const unsigned w = rel >> 6, o = rel & 63;
                     inl[w] |= nr << o;
-                    if (o + len > 64 && w + 1 < 10)
+                    if (o + len > 64 && w + 1 < kInlineWords)
                         inl[w + 1] |= nr >> (64 - o);
                 }
             }
@@ -342,8 +311,8 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
         }
         if (rel < kInlineBits && (rel & 63))
             inl[rel >> 6] &= lo_set(rel & 63);
-        for (unsigned w = 0; w < 10; ++w)
-            r[6 + w] = w * 64 < rel ? inl[w] : 0;
+        for (unsigned w = 0; w < kInlineWords; ++w)
+            r[kRecInline + w] = w * 64 < rel ? inl[w] : 0;
         r[1] = ptr | ((uint64_t)sb_ones[sb] << 48);
     }
 }
@@ -398,14 +367,29 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
             uint64_t ones_in = A.sb_rank[s + 1] - A.sb_rank[s];
             r[0] = A.sb_rank[s];
             r[1] = A.sb_ptr[s] | (ones_in << 48);
-            memcpy(r + 2, &A.cls[(size_t)s * kRrrK], kRrrK);
+            memcpy(r + kRecClasses, &A.cls[(size_t)s * kRrrK], kRrrK);
+            {
+                unsigned po[3], pb[3], ones = 0, bits = 0;
+                for (unsigned j = 0; j < 24; ++j)
+                {
+                    unsigned k = A.cls[(size_t)s * kRrrK + j];
+                    ones += k;
+                    bits += T.space[k];
+                    if ((j & 7) == 7)
+                    {
+                        po[j >> 3] = ones;
+                        pb[j >> 3] = bits;
+                    }
+                }
+                r[2] = rrr_pack_prefix(po, pb);
+            }
             uint64_t avail = A.sb_ptr[s + 1] - A.sb_ptr[s];
             if (avail > kInlineBits)
                 avail = kInlineBits;
             for (unsigned w = 0; w * 64 < avail; ++w)
             {
                 unsigned len = (unsigned)std::min<uint64_t>(64, avail - w * 64);
-                r[6 + w] = read_bits(A.stream.data(), A.sb_ptr[s] + w * 64, len);
+                r[kRecInline + w] = read_bits(A.stream.data(), A.sb_ptr[s] + w * 64, len);
             }
             // select samples falling into this superblock: walk its blocks, decode only where needed
             uint64_t start = s * kRrrSB;
@@ -571,7 +555,7 @@ sdsl_hip_status rrr_serialize_host(const RrrHost & h, StreamWriter & w)
         SH_HIP(hipMemcpy(rec.data(), rv.rec, rec.size() * 8, hipMemcpyDeviceToHost));
     // total offset bits = pointer of the last superblock + its own offsets
     const RrrTables & T = host_tables();
-    auto cls = [&](uint64_t b) -> unsigned { return (unsigned)(rec[(b / kRrrK) * kRecWords + 2 + ((b % kRrrK) >> 3)] >> (8 * (b & 7))) & 0xFF; };
+    auto cls = [&](uint64_t b) -> unsigned { return (unsigned)(rec[(b / kRrrK) * kRecWords + kRecClasses + ((b % kRrrK) >> 3)] >> (8 * (b & 7))) & 0xFF; };
     uint64_t stream_bits = 0;
     if (nsb)
     {

@@ -10,7 +10,10 @@ constexpr unsigned kRrrBS = 63;
 constexpr unsigned kRrrK = 32;
 constexpr uint64_t kRrrSB = (uint64_t)kRrrBS * kRrrK; // 2016 bits per superblock
 constexpr unsigned kRecWords = 16;
-constexpr unsigned kInlineBits = 640;
+constexpr unsigned kRecClasses = 3;  // words 3..6: the 32 block classes as bytes
+constexpr unsigned kRecInline = 7;   // words 7..15: inline copy of the head of the superblock's offsets
+constexpr unsigned kInlineWords = kRecWords - kRecInline;
+constexpr unsigned kInlineBits = 64 * kInlineWords; // 576
 constexpr unsigned kRrrBlock = 512; // threads per block (LDS holds the 32 KiB binomial table)
 
 struct RrrTables
@@ -64,29 +67,32 @@ __device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsig
     return bits;
 }
 
+// one position: c = C(62-p, k); one iff nr >= c.  32-bit borrow chain instead of a 64-bit compare + subtract; acc
+// collects the BORROWS (= zero bits) MSB-first, k8 is 8*k (the table column as a byte offset)
+__device__ __forceinline__ void rrr_dense_step(const RrrTables * T, int p, unsigned & nlo, unsigned & nhi, unsigned & k8,
+                                               unsigned & acc)
+{
+    const uint64_t c = *reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(&T->binom[62 - p][0]) + k8);
+    unsigned b0, b1;
+    const unsigned dlo = __builtin_subc(nlo, (unsigned)c, 0u, &b0);
+    const unsigned dhi = __builtin_subc(nhi, (unsigned)(c >> 32), b0, &b1);
+    nlo = b1 ? nlo : dlo;
+    nhi = b1 ? nhi : dhi;
+    k8 -= b1 ? 0u : 8u;
+    acc = (acc << 1) | b1;
+}
+
 __device__ __forceinline__ uint64_t rrr_decode_dense(const RrrTables * T, unsigned k, uint64_t nr)
 {
-    // acc collects the decisions MSB-first (one shift-or per step); bit-reversed at the end
-    unsigned acc0 = 0, acc1 = 0;
+    unsigned nlo = (unsigned)nr, nhi = (unsigned)(nr >> 32), k8 = 8 * k;
+    unsigned acc0 = 0, acc1 = 0; // zero bits of positions 0..31 / 32..62, first position in the highest bit
 #pragma unroll
     for (int p = 0; p < 32; ++p)
-    {
-        const uint64_t c = T->binom[62 - p][k];
-        const bool one = nr >= c;
-        nr -= one ? c : 0;
-        k -= one ? 1u : 0u;
-        acc0 = (acc0 << 1) | (one ? 1u : 0u);
-    }
+        rrr_dense_step(T, p, nlo, nhi, k8, acc0);
 #pragma unroll
     for (int p = 32; p < 63; ++p)
-    {
-        const uint64_t c = T->binom[62 - p][k];
-        const bool one = nr >= c;
-        nr -= one ? c : 0;
-        k -= one ? 1u : 0u;
-        acc1 = (acc1 << 1) | (one ? 1u : 0u);
-    }
-    return (uint64_t)__brev(acc0) | ((uint64_t)(__brev(acc1) >> 1) << 32);
+        rrr_dense_step(T, p, nlo, nhi, k8, acc1);
+    return (uint64_t)__brev(~acc0) | ((uint64_t)(__brev(~acc1 << 1)) << 32);
 }
 
 __device__ __forceinline__ uint64_t rrr_decode_block(const RrrTables * T, unsigned k, uint64_t nr)
@@ -116,102 +122,136 @@ __device__ __forceinline__ void rrr_stage_tables(RrrTables * lds, const RrrTable
     __syncthreads();
 }
 
+// ---- record accessors ------------------------------------------------------------------------------
+// word 2 of a record: for g = 1..3 the offset bits and the ones in blocks [0, 8g) of the superblock, packed as
+// [bits | ones << w] at bit 21*(g-1) with field width w = 10 (g = 1, 2) or 11 (g = 3).
+SH_HD uint64_t rrr_pack_prefix(const unsigned ones[3], const unsigned bits[3])
+{
+    return (uint64_t)bits[0] | ((uint64_t)ones[0] << 10) | ((uint64_t)bits[1] << 21) | ((uint64_t)ones[1] << 31)
+           | ((uint64_t)bits[2] << 42) | ((uint64_t)ones[2] << 53);
+}
+SH_HD void rrr_prefix(uint64_t P, unsigned g, unsigned & ones, unsigned & bits)
+{ // g in [0,3]
+    const unsigned w = g == 3 ? 11u : 10u, m = (1u << w) - 1;
+    const uint64_t x = g ? P >> (21 * (g - 1)) : 0;
+    bits = (unsigned)x & m;
+    ones = (unsigned)(x >> w) & m;
+}
+
 // offset field of `len` bits at relative position `rel` inside superblock record `r`
 __device__ __forceinline__ uint64_t rrr_field(const RrrView & v, const uint64_t * r, uint64_t ptr, unsigned rel,
                                               unsigned len)
 {
     if (rel + len <= kInlineBits)
-        return read_bits(r + 6, rel, len); // same 128-byte line as the header
+        return read_bits(r + kRecInline, rel, len); // same 128-byte line as the header
     return read_bits(v.stream, ptr + rel, len);
 }
 
 // sum of the eight bytes of x (each <= 63)
-__device__ __forceinline__ unsigned sum_bytes8(uint64_t x)
+SH_HD unsigned sum_bytes8(uint64_t x)
 {
     uint64_t t = (x & UINT64_C(0x00FF00FF00FF00FF)) + ((x >> 8) & UINT64_C(0x00FF00FF00FF00FF));
     return (unsigned)((t * UINT64_C(0x0001000100010001)) >> 48);
 }
 
-// Sum of (class, space[class]) over this lane's 8 classes with in-superblock index < j; the quad sum
-// gives ones and offset bits before block j.  packed = ones | bits << 16
-__device__ __forceinline__ unsigned rrr_lane_prefix(const RrrTables * T, uint64_t cls8, int s, unsigned j)
+// sum of space[] over the eight class bytes of m (class 0 adds nothing: space[0] == 0)
+__device__ __forceinline__ unsigned rrr_space_sum8(const RrrTables * T, uint64_t m)
 {
-    // keep the classes with in-lane index < j - 8s; the others become class 0, which adds nothing (space[0] == 0)
-    int cnt = (int)j - 8 * s;
-    cnt = cnt < 0 ? 0 : (cnt > 8 ? 8 : cnt);
-    const uint64_t keep = cnt == 8 ? ~UINT64_C(0) : ((UINT64_C(1) << (8 * cnt)) - 1);
-    const uint64_t m = cls8 & keep;
     unsigned bits = 0;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
         bits += T->space[(unsigned)(m >> (8 * t)) & 0xFF];
-    return sum_bytes8(m) | (bits << 16);
+    return bits;
 }
 
-// value of quad lane U in all four lanes (U is a compile-time constant: DPP quad_perm:[U,U,U,U])
-template <int U>
-__device__ __forceinline__ unsigned quad_bcast_lane(unsigned v)
-{
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, U * 0x55, 0xF, 0xF, true);
-}
-template <int U>
-__device__ __forceinline__ uint64_t quad_bcast_lane_u64(uint64_t v)
-{
-    unsigned lo = quad_bcast_lane<U>((unsigned)v), hi = quad_bcast_lane<U>((unsigned)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// What the lane-parallel phase needs to finish one rank/access query.
+// ---- rank / access ---------------------------------------------------------------------------------
+// One query per lane, no cooperation: the record is laid out so that a lane needs 40 bytes of it (header,
+// prefix word, ONE class word) plus the offset field.
 struct RankTail
 {
     uint64_t rank; // ones before the block
-    uint64_t nr;   // the block's offset
+    uint64_t nr;   // offset of the block
     unsigned k, off;
 };
 
-// Cooperative half of rank(i): the quad fetches the superblock record of i (one 128-byte line), sums the
-// class bytes below the block (8 per lane, DPP reduction) and fetches the block's offset field.
-__device__ __forceinline__ RankTail rrr_rank_head(const RrrView & v, const RrrTables * T, int s, uint64_t i)
+__device__ __forceinline__ RankTail rrr_rank_head(const RrrView & v, const RrrTables * T, uint64_t i)
 {
-    uint64_t blk = i / kRrrBS;
+    const uint64_t blk = i / kRrrBS;
     RankTail t;
     t.off = (unsigned)(i - blk * kRrrBS);
-    uint64_t sb = blk / kRrrK;
-    unsigned j = (unsigned)(blk % kRrrK);
-    const uint64_t * r = v.rec + sb * kRecWords;
-    uint64_t r0 = r[0], r1 = r[1];
-    uint64_t cls8 = r[2 + s];
-    uint64_t clsj = r[2 + (j >> 3)];
-    unsigned tot = quad_sum(rrr_lane_prefix(T, cls8, s, j));
-    t.rank = r0 + (tot & 0xFFFF);
-    t.k = (unsigned)(clsj >> (8 * (j & 7))) & 0xFF;
-    t.nr = rrr_field(v, r, r1 & ((UINT64_C(1) << 48) - 1), tot >> 16, T->space[t.k]);
+    const uint64_t sb = blk / kRrrK;
+    const unsigned j = (unsigned)(blk % kRrrK), g = j >> 3, u = j & 7;
+    const uint64_t * r = (const uint64_t *)__builtin_assume_aligned(v.rec + sb * kRecWords, 128);
+    const uint64_t r0 = r[0], r1 = r[1], P = r[2];
+    const uint64_t cw = r[kRecClasses + g];
+    unsigned ones, bits;
+    rrr_prefix(P, g, ones, bits);
+    const uint64_t below = cw & lo_set(8 * u);
+    ones += sum_bytes8(below);
+    bits += rrr_space_sum8(T, below);
+    t.rank = r0 + ones;
+    t.k = (unsigned)(cw >> (8 * u)) & 0xFF;
+    t.nr = rrr_field(v, r, r1 & ((UINT64_C(1) << 48) - 1), bits, T->space[t.k]);
     return t;
 }
 
-// What the lane-parallel phase needs to finish one select query.
-struct SelTail
+// rank_1(pos); optionally the bit at pos (pos < n_bits then)
+__device__ __forceinline__ uint64_t rrr_rank1(const RrrView & v, const RrrTables * T, uint64_t pos,
+                                              unsigned * bit_out = nullptr)
 {
-    const uint64_t * r; // superblock record
-    uint64_t bstart;    // first bit of the block
-    unsigned k, blen, rel, want; // class, valid bits, offset position in the superblock's stream, 0-based rank in block
-};
+    const RankTail t = rrr_rank_head(v, T, pos);
+    uint64_t bits = 0;
+    if (bit_out || t.off != 0) // rank at a block boundary needs no decode
+        bits = rrr_decode_block(T, t.k, t.nr);
+    if (bit_out)
+        *bit_out = (unsigned)(bits >> t.off) & 1u;
+    return t.rank + popc64(bits & lo_set(t.off));
+}
 
-// Cooperative half of select: superblock search over the record headers (directory of argument POSITIONS,
-// interpolated probe, exact counts from the probed header, bisection every second late probe — the scheme of
-// bv_device.hpp) and block location from the class bytes.  All four lanes return the same tail.
+// rank_1(pa) and rank_1(pb), pa <= pb: the two cascades of an LF step (suffix_array_algorithm.hpp:195-196).  Once
+// the SA interval is narrow both positions usually fall into the same 63-bit block: then b reuses a's head and
+// decoded block; and a b that starts a block needs no decode at all — for an interval of size one (b == a + 1) one
+// of the two always holds.
+__device__ __forceinline__ void rrr_rank2(const RrrView & v, const RrrTables * T, uint64_t pa, uint64_t pb, uint64_t & ra,
+                                          uint64_t & rb)
+{
+    const uint64_t blk_a = pa / kRrrBS, blk_b = pb / kRrrBS;
+    const bool same = blk_a == blk_b;
+    const RankTail ta = rrr_rank_head(v, T, pa);
+    RankTail tb;
+    tb.rank = ta.rank;
+    tb.nr = 0;
+    tb.k = 0;
+    tb.off = (unsigned)(pb - blk_b * kRrrBS);
+    if (!same)
+        tb = rrr_rank_head(v, T, pb);
+    uint64_t bits_a = 0;
+    if (ta.off != 0 || (same && tb.off != 0))
+        bits_a = rrr_decode_block(T, ta.k, ta.nr);
+    ra = ta.rank + popc64(bits_a & lo_set(ta.off));
+    uint64_t bits_b = bits_a;
+    if (!same && tb.off != 0)
+        bits_b = rrr_decode_block(T, tb.k, tb.nr);
+    rb = tb.rank + popc64(bits_b & lo_set(tb.off));
+}
+
+// ---- select ----------------------------------------------------------------------------------------
+// position of the (k0+1)-th BIT-valued bit; 0 <= k0 < #BIT-valued bits.  Superblock search over the record headers
+// (directory of argument POSITIONS, interpolated probe, exact counts from the probed header, bisection every second
+// late probe — the scheme of bv_device.hpp), then the prefix word picks the group of 8 blocks, byte arithmetic on
+// ONE class word the block, and the decoded block the bit.
 template <int BIT>
-__device__ __forceinline__ SelTail rrr_select_head(const RrrView & v, const RrrTables * T, int s, uint64_t k0)
+__device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTables * T, uint64_t k0)
 {
     const uint64_t total = BIT ? v.ones : v.n_bits - v.ones;
     const uint32_t sh = v.sel_shift, ps = v.sel_pshift;
-    const uint64_t j = k0 >> sh;
-    uint64_t lo_pos = (uint64_t)v.sel[BIT][j] << ps, lo_cnt = j << sh;
-    uint64_t hi_pos = ((uint64_t)v.sel[BIT][j + 1] + 1) << ps, hi_cnt = (j + 1) << sh;
+    const uint64_t js = k0 >> sh;
+    uint64_t lo_pos = (uint64_t)v.sel[BIT][js] << ps, lo_cnt = js << sh;
+    uint64_t hi_pos = ((uint64_t)v.sel[BIT][js + 1] + 1) << ps, hi_cnt = (js + 1) << sh;
     if (hi_cnt > total)
         hi_cnt = total;
     const uint64_t * r;
-    uint64_t g, before, cls8, r1;
+    uint64_t g, before, r1, P, c0, c1, c2, c3;
     for (int tries = 0;; ++tries)
     { // invariant: lo_pos <= position(k0) < hi_pos, lo_cnt <= k0 < hi_cnt
         uint64_t span = hi_pos - lo_pos, p;
@@ -222,15 +262,20 @@ __device__ __forceinline__ SelTail rrr_select_head(const RrrView & v, const RrrT
         g = p / kRrrSB;
         if (g >= v.n_sb)
             g = v.n_sb - 1;
-        r = v.rec + g * kRecWords;
-        uint64_t r0 = r[0];
+        r = (const uint64_t *)__builtin_assume_aligned(v.rec + g * kRecWords, 128);
+        const uint64_t r0 = r[0];
         r1 = r[1];
-        cls8 = r[2 + s]; // same line: free, and needed as soon as the probe hits
-        uint64_t ones_in = (r1 >> 48) & 0xFFF;
-        uint64_t start = g * kRrrSB;
-        uint64_t len_in = v.n_bits - start < kRrrSB ? v.n_bits - start : kRrrSB;
+        // prefix and class words ride along (same line, no extra latency): needed as soon as the probe hits
+        P = r[2];
+        c0 = r[kRecClasses];
+        c1 = r[kRecClasses + 1];
+        c2 = r[kRecClasses + 2];
+        c3 = r[kRecClasses + 3];
+        const uint64_t ones_in = (r1 >> 48) & 0xFFF;
+        const uint64_t start = g * kRrrSB;
+        const uint64_t len_in = v.n_bits - start < kRrrSB ? v.n_bits - start : kRrrSB;
         before = BIT ? r0 : start - r0;
-        uint64_t c = BIT ? ones_in : len_in - ones_in;
+        const uint64_t c = BIT ? ones_in : len_in - ones_in;
         if (k0 < before)
         {
             hi_pos = start;
@@ -244,72 +289,71 @@ __device__ __forceinline__ SelTail rrr_select_head(const RrrView & v, const RrrT
         else
             break;
     }
-    // inside superblock g: lane s owns classes [8s, 8s+8)
-    const unsigned want = (unsigned)(k0 - before);
-    const uint64_t b0 = g * kRrrK + 8 * (uint64_t)s;
-    const bool full = (b0 + 8) * kRrrBS <= v.n_bits; // all eight blocks are complete 63-bit blocks
-    unsigned my_args;
-    if (BIT)
-        my_args = sum_bytes8(cls8);
-    else if (full)
-        my_args = sum_bytes8(UINT64_C(0x3F3F3F3F3F3F3F3F) - cls8);
-    else
+    // inside superblock g: the group of 8 blocks.  Zeros before block 8q are 504q - ones (every block in front of
+    // the one that holds an existing argument is a complete 63-bit block).
+    unsigned want = (unsigned)(k0 - before);
+    unsigned o[4], b[4];
+    o[0] = b[0] = 0;
+    rrr_prefix(P, 1, o[1], b[1]);
+    rrr_prefix(P, 2, o[2], b[2]);
+    rrr_prefix(P, 3, o[3], b[3]);
+    unsigned q = 0;
+#pragma unroll
+    for (unsigned t = 1; t < 4; ++t)
+        q += want >= (BIT ? o[t] : 8 * kRrrBS * t - o[t]) ? 1u : 0u;
+    unsigned rel = q == 0 ? 0u : (q == 1 ? b[1] : (q == 2 ? b[2] : b[3]));
+    const unsigned oq = q == 0 ? 0u : (q == 1 ? o[1] : (q == 2 ? o[2] : o[3]));
+    want -= BIT ? oq : 8 * kRrrBS * q - oq;
+    const uint64_t cw = q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
+    // arguments per block of the group as bytes; the block holding the argument is complete or the vector's last
+    // block, and blocks behind the end of the vector must not offer zeros
+    uint64_t args = cw;
+    if (!BIT)
     {
-        my_args = 0;
-        for (int t = 0; t < 8; ++t)
+        const uint64_t b0 = g * kRrrK + 8 * (uint64_t)q;
+        if ((b0 + 8) * kRrrBS <= v.n_bits)
+            args = UINT64_C(0x3F3F3F3F3F3F3F3F) - cw;
+        else
         {
-            uint64_t bstart = (b0 + t) * kRrrBS;
-            unsigned blen = bstart >= v.n_bits ? 0u : (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS);
-            my_args += blen - ((unsigned)(cls8 >> (8 * t)) & 0xFF);
+            args = 0;
+            for (unsigned t = 0; t < 8; ++t)
+            {
+                const uint64_t bstart = (b0 + t) * kRrrBS;
+                const unsigned blen =
+                    bstart >= v.n_bits ? 0u : (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS);
+                args |= (uint64_t)(blen - ((unsigned)(cw >> (8 * t)) & 0xFF)) << (8 * t);
+            }
         }
     }
-    unsigned my_bits = 0;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-        my_bits += T->space[(unsigned)(cls8 >> (8 * t)) & 0xFF];
-    unsigned ex = quad_excl(my_args | (my_bits << 16), s);
-    unsigned acc = ex & 0xFFFF, rel = ex >> 16;
-    const bool owner = want >= acc && want < acc + my_args;
-    // the owner lane walks its eight classes; packed = block-in-lane | k<<8 | blen<<16 | (want-acc)<<24, rel
-    unsigned kk = 0, bl = 0, tt = 0;
-    bool done = !owner;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
+    // first block u with want < a_0 + ... + a_u: half, then quarter sums as bytes (4 * 63 < 256)
+    const unsigned lo4 = (unsigned)args, hi4 = (unsigned)(args >> 32);
+    const unsigned s_lo = ((lo4 & 0x00FF00FFu) + ((lo4 >> 8) & 0x00FF00FFu));
+    const unsigned sum_lo = (s_lo + (s_lo >> 16)) & 0x3FF;
+    unsigned u = 0, half = lo4;
+    if (want >= sum_lo)
     {
-        unsigned k = (unsigned)(cls8 >> (8 * t)) & 0xFF;
-        uint64_t bstart = (b0 + t) * kRrrBS;
-        unsigned blen =
-            full ? kRrrBS : (bstart >= v.n_bits ? 0u : (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS));
-        unsigned a = BIT ? k : blen - k;
-        bool here = !done && want < acc + a;
-        bool skip = !done && !here;
-        if (here)
-        {
-            kk = k;
-            bl = blen;
-            tt = (unsigned)t + 8u * (unsigned)s;
-            done = true;
-        }
-        if (skip)
-        {
-            acc += a;
-            rel += T->space[k];
-        }
+        want -= sum_lo;
+        u = 4;
+        half = hi4;
     }
-    // hand the owner's findings to the whole quad (exactly one lane contributes non-zero values)
-    unsigned p0 = owner ? (tt | (kk << 8) | (bl << 16) | ((want - acc) << 24)) : 0u;
-    unsigned p1 = owner ? rel : 0u;
-    p0 = quad_sum(p0);
-    p1 = quad_sum(p1);
-    SelTail t;
-    t.r = r;
-    t.bstart = (g * kRrrK + (p0 & 0xFF)) * kRrrBS;
-    t.k = (p0 >> 8) & 0xFF;
-    t.blen = (p0 >> 16) & 0xFF;
-    t.want = p0 >> 24;
-    t.rel = p1;
-    return t;
+    const unsigned pre = half * 0x01010100u; // byte t: a_0 + ... + a_{t-1}
+    unsigned t4 = 0;
+#pragma unroll
+    for (unsigned t = 1; t < 4; ++t)
+        t4 += want >= ((pre >> (8 * t)) & 0xFF) ? 1u : 0u;
+    want -= (pre >> (8 * t4)) & 0xFF;
+    u += t4;
+    rel += rrr_space_sum8(T, cw & lo_set(8 * u));
+    const unsigned k = (unsigned)(cw >> (8 * u)) & 0xFF;
+    const uint64_t bstart = (g * kRrrK + 8 * (uint64_t)q + u) * kRrrBS;
+    const uint64_t nr = rrr_field(v, r, r1 & ((UINT64_C(1) << 48) - 1), rel, T->space[k]);
+    uint64_t bits = rrr_decode_block(T, k, nr);
+    if (!BIT)
+    {
+        const unsigned blen = (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS);
+        bits = ~bits & lo_set(blen);
+    }
+    return bstart + sel64(bits, want + 1);
 }
-
 
 } // namespace sdslhip

@@ -210,8 +210,32 @@ static int sweep(int argc, char ** argv)
     return 0;
 }
 
+static int pairs(int argc, char ** argv)
+{ // gather_probe pairs <nq> <MiB>: is a second, ADJACENT line cheaper than a second random line?  And what does a
+  // lane-individual 16-byte read of a random line cost (one query per lane layouts)?
+    uint64_t nq = strtoull(argv[2], 0, 10);
+    uint64_t tb = strtoull(argv[3], 0, 10) << 20;
+    v2u64 * table;
+    uint64_t *idx, *out;
+    CK(hipMalloc(&table, tb));
+    CK(hipMalloc(&idx, 8));
+    CK(hipMalloc(&out, nq * 8));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint64_t *)table, tb / 8);
+    CK(hipDeviceSynchronize());
+    run<128, 8, 4, false, false>("one line, 8 lanes", table, tb, idx, out, nq, 8);
+    run<256, 16, 4, false, false>("two adjacent lines, 16 lanes", table, tb, idx, out, nq, 8);
+    run<256, 8, 4, false, false>("two adjacent lines, 8 lanes", table, tb, idx, out, nq, 8);
+    run<512, 16, 2, false, false>("four adjacent lines, 16 lanes", table, tb, idx, out, nq, 8);
+    run<16, 1, 4, false, false>("16 B of a random line per lane", table, tb, idx, out, nq, 8);
+    run<32, 1, 4, false, false>("32 B of a random line per lane", table, tb, idx, out, nq, 8);
+    run<64, 1, 4, false, false>("64 B of a random line per lane", table, tb, idx, out, nq, 8);
+    return 0;
+}
+
 int main(int argc, char ** argv)
 {
+    if (argc > 3 && !strcmp(argv[1], "pairs"))
+        return pairs(argc, argv);
     if (argc > 3 && !strcmp(argv[1], "sweep"))
         return sweep(argc, argv);
     if (argc > 2 && !strcmp(argv[1], "scatter"))

@@ -145,88 +145,4 @@ __device__ __forceinline__ uint64_t quad_wt_inverse_select(const WtView & wt, co
     return i;
 }
 
-// ---- rrr-compressed bit vector (wt_huff<rrr_vector<63>>) -----------------------------------------------------------
-// Four queries per quad advance level-synchronously: in sub-round U all four lanes fetch the record / class prefix /
-// offset field for the query OWNED by lane U (rrr_rank_head), then every lane decodes the block of its own query.
-__device__ __forceinline__ bool quad_any(bool b)
-{
-    return quad_sum(b ? 1u : 0u) != 0;
-}
-
-// cooperative halves for the four queries of a quad: lane U ends up with the tail of its own query
-__device__ __forceinline__ RankTail quad4_rrr_heads(const RrrView & v, const RrrTables * RT, int s, uint64_t pos, bool act)
-{
-    const uint64_t safe = act ? pos : 0;
-    RankTail mine, t;
-    mine.rank = 0;
-    mine.nr = 0;
-    mine.k = 0;
-    mine.off = 0;
-    if (quad_bcast_lane<0>(act ? 1u : 0u))
-    {
-        t = rrr_rank_head(v, RT, s, quad_bcast_lane_u64<0>(safe));
-        if (s == 0)
-            mine = t;
-    }
-    if (quad_bcast_lane<1>(act ? 1u : 0u))
-    {
-        t = rrr_rank_head(v, RT, s, quad_bcast_lane_u64<1>(safe));
-        if (s == 1)
-            mine = t;
-    }
-    if (quad_bcast_lane<2>(act ? 1u : 0u))
-    {
-        t = rrr_rank_head(v, RT, s, quad_bcast_lane_u64<2>(safe));
-        if (s == 2)
-            mine = t;
-    }
-    if (quad_bcast_lane<3>(act ? 1u : 0u))
-    {
-        t = rrr_rank_head(v, RT, s, quad_bcast_lane_u64<3>(safe));
-        if (s == 3)
-            mine = t;
-    }
-    return mine;
-}
-
-// rank_1(pos) of this lane's own query on the rrr vector (undefined if !act); optionally the bit at pos
-__device__ __forceinline__ uint64_t quad4_rrr_rank1(const RrrView & v, const RrrTables * RT, int s, uint64_t pos, bool act,
-                                                    unsigned * bit_out = nullptr)
-{
-    const RankTail mine = quad4_rrr_heads(v, RT, s, pos, act);
-    uint64_t bits = 0;
-    if (act && (bit_out || mine.off != 0)) // rank at a block boundary needs no decode
-        bits = rrr_decode_block(RT, mine.k, mine.nr);
-    if (bit_out)
-        *bit_out = (unsigned)(bits >> mine.off) & 1u;
-    return mine.rank + popc64(bits & lo_set(mine.off));
-}
-
-// rank_1(pa) and rank_1(pb), pa <= pb, of this lane's own query: the two cascades of an LF step
-// (suffix_array_algorithm.hpp:195-196).  Once the SA interval is narrow both positions usually fall into the same
-// 63-bit block: then b reuses a's head and decoded block; and a b that starts a block needs no decode at all — for
-// an interval of size one (b == a + 1) one of the two always holds.
-__device__ __forceinline__ void quad4_rrr_rank2(const RrrView & v, const RrrTables * RT, int s, uint64_t pa, uint64_t pb,
-                                                bool act, uint64_t & ra, uint64_t & rb)
-{
-    const uint64_t sa = act ? pa : 0, sb = act ? pb : 0;
-    const uint64_t blk_a = sa / kRrrBS, blk_b = sb / kRrrBS;
-    const bool same = blk_a == blk_b;
-    const RankTail ta = quad4_rrr_heads(v, RT, s, sa, act);
-    RankTail tb = quad4_rrr_heads(v, RT, s, sb, act && !same);
-    if (same)
-    {
-        tb.rank = ta.rank;
-        tb.off = (unsigned)(sb - blk_b * kRrrBS);
-    }
-    uint64_t bits_a = 0;
-    if (act && (ta.off != 0 || (same && tb.off != 0)))
-        bits_a = rrr_decode_block(RT, ta.k, ta.nr);
-    ra = ta.rank + popc64(bits_a & lo_set(ta.off));
-    uint64_t bits_b = bits_a;
-    if (act && !same && tb.off != 0)
-        bits_b = rrr_decode_block(RT, tb.k, tb.nr);
-    rb = tb.rank + popc64(bits_b & lo_set(tb.off));
-}
-
 } // namespace sdslhip
