@@ -183,6 +183,12 @@ sdsl_hip_status sdsl_hip_fm_create_from_text_ex(const uint8_t * text, uint64_t n
 /* from csa_wt::serialize bytes (csa_wt.hpp:389-402); SA/ISA samples are skipped; `layout` as for the wavelet tree */
 sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int32_t layout, int32_t device,
                                              sdsl_hip_fm_t * out);
+/* The same with the type's sampling densities (csa_wt's template arguments t_dens and t_inv_dens, csa_wt.hpp:56-64 —
+ * they are not part of the stream): the SA samples (sa_order_sa_sampling, csa_sampling_strategy.hpp:72-135) and ISA
+ * samples (isa_sampling, :735-806) are kept, so that SA / ISA access, locate and extract below work on a loaded index.
+ * sa_dens == 0 or isa_dens == 0: as sdsl_hip_fm_create_from_sdsl. */
+sdsl_hip_status sdsl_hip_fm_create_from_sdsl_ex(const void * bytes, size_t len, int32_t layout, uint32_t sa_dens,
+                                                uint32_t isa_dens, int32_t device, sdsl_hip_fm_t * out);
 /* An index created from text keeps its suffix array in HBM (4 bytes per suffix) so that it can be written out as a
  * complete SDSL csa_wt: sdsl_hip_fm_serialize produces the bytes of
  *   csa_wt<wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>, sa_dens, isa_dens>
@@ -190,7 +196,8 @@ sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int
  * ::serialize (csa_wt.hpp:389-402: wavelet tree, SA samples every sa_dens-th suffix, ISA samples every isa_dens-th text
  * position — csa_sampling_strategy.hpp:97-114,755-777 — and the byte alphabet), i.e. the index type of the reference's
  * count benchmark (benchmark/indexing_count/index.config:8), loadable by unmodified SDSL for locate/extract.
- * sdsl_hip_fm_drop_sa releases the suffix array when only count() is needed.  buf == NULL queries the size. */
+ * sdsl_hip_fm_drop_sa releases the suffix array and keeps SDSL's default samples (SA every 32nd suffix, ISA every 64th
+ * text position) unless the index already has samples.  buf == NULL queries the size. */
 sdsl_hip_status sdsl_hip_fm_serialize(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens, void * buf, size_t cap,
                                       size_t * written);
 sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm);
@@ -215,6 +222,37 @@ sdsl_hip_status sdsl_hip_fm_count_ragged(sdsl_hip_fm_t fm, const uint8_t * bytes
 sdsl_hip_status sdsl_hip_fm_interval_batch(sdsl_hip_fm_t fm, const uint8_t * patterns, uint32_t m,
                                            uint64_t n_patterns, uint64_t * l_out, uint64_t * r_out,
                                            void * stream);
+
+/* ---- csa_wt<wt_huff<...>>: SA / ISA / LF / psi access, extract, locate --------------------
+ * Replaces: csa_wt::operator[] (csa_wt.hpp:363-381), csa.isa[i] (suffix_array_helper.hpp:519-537), csa.lf[i] (:346-360),
+ *           csa.psi[i] (:330-342), extract(csa, begin, end, text) (suffix_array_algorithm.hpp:578-600),
+ *           locate(csa, begin, end) (:505-523).
+ * They need the whole suffix array (index created from text) or SA / ISA samples (create_from_sdsl_ex, or drop_sa);
+ * otherwise SDSL_HIP_ERR_UNSUPPORTED.  Arguments outside [0, size()) give SDSL_HIP_NPOS. */
+sdsl_hip_status sdsl_hip_fm_sampling(sdsl_hip_fm_t fm, uint32_t * sa_dens, uint32_t * isa_dens, int32_t * has_full_sa);
+/* out[q] = csa[idx[q]] */
+sdsl_hip_status sdsl_hip_fm_sa_batch(sdsl_hip_fm_t fm, const uint64_t * idx, uint64_t n, uint64_t * out, void * stream);
+/* out[q] = csa.isa[idx[q]] */
+sdsl_hip_status sdsl_hip_fm_isa_batch(sdsl_hip_fm_t fm, const uint64_t * idx, uint64_t n, uint64_t * out, void * stream);
+/* out[q] = csa.lf[idx[q]] */
+sdsl_hip_status sdsl_hip_fm_lf_batch(sdsl_hip_fm_t fm, const uint64_t * idx, uint64_t n, uint64_t * out, void * stream);
+/* out[q] = csa.psi[idx[q]] */
+sdsl_hip_status sdsl_hip_fm_psi_batch(sdsl_hip_fm_t fm, const uint64_t * idx, uint64_t n, uint64_t * out, void * stream);
+/* Ragged answers follow one protocol: *total receives the number of output elements; out_offsets (optional, n+1
+ * entries) receives where each query's answer starts; with out == NULL the call only sizes the answer, otherwise cap
+ * (elements available in out) must be >= *total.  These calls synchronise the stream.
+ * extract: text[begin[q] .. end[q]] inclusive (begin <= end < size(); other queries yield nothing) */
+sdsl_hip_status sdsl_hip_fm_extract_batch(sdsl_hip_fm_t fm, const uint64_t * begin, const uint64_t * end, uint64_t n,
+                                          uint64_t * out_offsets, uint8_t * out_text, uint64_t cap, uint64_t * total,
+                                          void * stream);
+/* csa[l[q]], ..., csa[r[q]] for every SA interval (an empty interval l > r yields nothing) */
+sdsl_hip_status sdsl_hip_fm_sa_range_batch(sdsl_hip_fm_t fm, const uint64_t * l, const uint64_t * r, uint64_t n,
+                                           uint64_t * out_offsets, uint64_t * out_pos, uint64_t cap, uint64_t * total,
+                                           void * stream);
+/* locate: all occurrences of every pattern, in SA order like the reference (= interval_batch + sa_range_batch) */
+sdsl_hip_status sdsl_hip_fm_locate_batch(sdsl_hip_fm_t fm, const uint8_t * patterns, uint32_t m, uint64_t n_patterns,
+                                         uint64_t * out_offsets, uint64_t * out_pos, uint64_t cap, uint64_t * total,
+                                         void * stream);
 
 /* ---- measurement hooks -------------------------------------------------------------------
  * Duration (ms) of the most recent kernel launched by a *_batch call on this handle's device,

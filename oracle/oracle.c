@@ -1612,6 +1612,10 @@ struct orc_csa
     uint8_t char2comp[256], comp2char[256];
     uint64_t C[257];
     uint16_t sigma;
+    /* samples of a csa built from text: SA[k*sa_dens] (sa_order_sa_sampling, csa_sampling_strategy.hpp:97-114) and
+     * ISA[k*isa_dens] (isa_sampling, :755-777); csa_wt's defaults are 32 and 64 (csa_wt.hpp:56-64) */
+    uint64_t sa_dens, isa_dens, n_sa_s, n_isa_s;
+    uint64_t *sa_s, *isa_s;
 };
 
 /* byte_alphabet(text_buf, len) csa_alphabet_strategy.hpp:175-212; the symbol histogram of the BWT
@@ -1696,6 +1700,11 @@ static uint64_t * build_sa(const uint8_t * s, uint64_t n)
 
 orc_csa * orc_csa_build(const uint8_t * text, uint64_t n_text)
 {
+    return orc_csa_build_ex(text, n_text, 32, 64);
+}
+
+orc_csa * orc_csa_build_ex(const uint8_t * text, uint64_t n_text, uint64_t sa_dens, uint64_t isa_dens)
+{
     uint64_t n = n_text + 1; /* construct.hpp:100-108 appends the 0 sentinel */
     uint8_t * s = (uint8_t *)malloc(n);
     memcpy(s, text, n_text);
@@ -1705,10 +1714,96 @@ orc_csa * orc_csa_build(const uint8_t * text, uint64_t n_text)
     for (uint64_t i = 0; i < n; ++i) /* construct_bwt.hpp:59-77: bwt[i] = text[sa[i]-1], wrapping */
         bwt[i] = s[(sa[i] + n - 1) % n];
     orc_csa * c = orc_csa_build_from_bwt(bwt, n);
+    c->sa_dens = sa_dens;
+    c->isa_dens = isa_dens;
+    c->n_sa_s = (n + sa_dens - 1) / sa_dens;
+    c->n_isa_s = (n + isa_dens - 1) / isa_dens;
+    c->sa_s = (uint64_t *)calloc(c->n_sa_s ? c->n_sa_s : 1, 8);
+    c->isa_s = (uint64_t *)calloc(c->n_isa_s ? c->n_isa_s : 1, 8);
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        if (i % sa_dens == 0)
+            c->sa_s[i / sa_dens] = sa[i];
+        if (sa[i] % isa_dens == 0)
+            c->isa_s[sa[i] / isa_dens] = i;
+    }
     free(bwt);
     free(sa);
     free(s);
     return c;
+}
+
+/* csa.lf[i] (suffix_array_helper.hpp:346-360) */
+uint64_t orc_csa_lf(const orc_csa * c, uint64_t i)
+{
+    uint8_t ch;
+    uint64_t j = orc_wt_inverse_select(c->wt, i, &ch);
+    return c->C[c->char2comp[ch]] + j;
+}
+
+/* first_row_symbol (suffix_array_helper.hpp:28-48) and csa.psi[i] (:330-342) */
+static uint8_t csa_first_row_symbol(const orc_csa * c, uint64_t i)
+{
+    unsigned cc = 0;
+    while (cc + 1 < c->sigma && c->C[cc + 1] <= i)
+        ++cc;
+    return c->comp2char[cc];
+}
+uint64_t orc_csa_psi(const orc_csa * c, uint64_t i)
+{
+    uint8_t ch = csa_first_row_symbol(c, i);
+    return orc_wt_select(c->wt, i - c->C[c->char2comp[ch]] + 1, ch);
+}
+
+/* csa_wt::operator[] (csa_wt.hpp:363-381) */
+uint64_t orc_csa_sa(const orc_csa * c, uint64_t i)
+{
+    uint64_t off = 0;
+    while (i % c->sa_dens != 0)
+    {
+        i = orc_csa_lf(c, i);
+        ++off;
+    }
+    uint64_t result = c->sa_s[i / c->sa_dens];
+    return result + off < c->size ? result + off : result + off - c->size;
+}
+
+/* csa.isa[i] (suffix_array_helper.hpp:519-537, sample_qeq csa_sampling_strategy.hpp:795-799) */
+uint64_t orc_csa_isa(const orc_csa * c, uint64_t i)
+{
+    uint64_t ci = (i / c->isa_dens + 1) % c->n_isa_s;
+    uint64_t result = c->isa_s[ci], pos = ci * c->isa_dens;
+    uint64_t steps = pos < i ? pos + c->size - i : pos - i;
+    while (steps--)
+        result = orc_csa_lf(c, result);
+    return result;
+}
+
+/* extract(csa, begin, end, text) for LF-based CSAs (suffix_array_algorithm.hpp:578-600); end inclusive */
+uint64_t orc_csa_extract(const orc_csa * c, uint64_t begin, uint64_t end, uint8_t * text)
+{
+    uint64_t steps = end - begin + 1;
+    uint64_t order = orc_csa_isa(c, end);
+    text[--steps] = csa_first_row_symbol(c, order);
+    while (steps != 0)
+    {
+        uint8_t ch;
+        uint64_t j = orc_wt_inverse_select(c->wt, order, &ch);
+        order = c->C[c->char2comp[ch]] + j;
+        text[--steps] = ch;
+    }
+    return end - begin + 1;
+}
+
+/* locate(csa, begin, end) (suffix_array_algorithm.hpp:505-523): occurrences in SA order; returns their number and
+ * writes at most cap of them */
+uint64_t orc_csa_locate(const orc_csa * c, const uint8_t * pat, uint64_t m, uint64_t * out, uint64_t cap)
+{
+    uint64_t l, r;
+    uint64_t occs = orc_csa_interval(c, pat, m, &l, &r);
+    for (uint64_t i = 0; i < occs && i < cap; ++i)
+        out[i] = orc_csa_sa(c, l + i);
+    return occs;
 }
 
 void orc_csa_free(orc_csa * c)
@@ -1717,6 +1812,8 @@ void orc_csa_free(orc_csa * c)
         return;
     orc_wt_free(c->wt);
     free(c->bwt);
+    free(c->sa_s);
+    free(c->isa_s);
     free(c);
 }
 uint64_t orc_csa_size(const orc_csa * c)

@@ -88,7 +88,15 @@ void orc_wt_code_lengths(const orc_wt *, uint8_t len_out[256]);
 typedef struct orc_csa orc_csa;
 /* text must not contain 0 bytes (construct.hpp:41); builds SA of text+'\0' by prefix doubling */
 orc_csa * orc_csa_build(const uint8_t * text, uint64_t n_text);
-orc_csa * orc_csa_build_from_bwt(const uint8_t * bwt, uint64_t n); /* csa_wt.hpp:323-355 */
+orc_csa * orc_csa_build_ex(const uint8_t * text, uint64_t n_text, uint64_t sa_dens, uint64_t isa_dens);
+orc_csa * orc_csa_build_from_bwt(const uint8_t * bwt, uint64_t n); /* csa_wt.hpp:323-355 (no samples: count only) */
+/* the rest of the csa_wt API; needs a csa built from text (samples) */
+uint64_t orc_csa_lf(const orc_csa *, uint64_t i);  /* suffix_array_helper.hpp:346-360 */
+uint64_t orc_csa_psi(const orc_csa *, uint64_t i); /* suffix_array_helper.hpp:330-342 */
+uint64_t orc_csa_sa(const orc_csa *, uint64_t i);  /* csa_wt.hpp:363-381 */
+uint64_t orc_csa_isa(const orc_csa *, uint64_t i); /* suffix_array_helper.hpp:519-537 */
+uint64_t orc_csa_extract(const orc_csa *, uint64_t begin, uint64_t end, uint8_t * text); /* suffix_array_algorithm.hpp:578-600 */
+uint64_t orc_csa_locate(const orc_csa *, const uint8_t * pat, uint64_t m, uint64_t * out, uint64_t cap); /* :505-523 */
 void orc_csa_free(orc_csa *);
 uint64_t orc_csa_size(const orc_csa *);
 uint64_t orc_csa_sigma(const orc_csa *);

@@ -334,6 +334,28 @@ void ref_csa_backward_search(void * p, const uint64_t * l, const uint64_t * r, c
         r_out[q] = b;
     }
 }
+// the rest of the csa_wt API on the default-density index csa_wt<wt_huff<bit_vector, rank_support_v5<>>, 32, 64>
+// what: 0 = csa[i], 1 = csa.isa[i], 2 = csa.lf[i], 3 = csa.psi[i]
+void ref_csa_access(void * p, int what, const uint64_t * idx, uint64_t n, uint64_t * out)
+{
+    RefCsa * h = (RefCsa *)p;
+    for (uint64_t q = 0; q < n; ++q)
+        out[q] = what == 0 ? h->csa[idx[q]]
+                           : (what == 1 ? h->csa.isa[idx[q]] : (what == 2 ? h->csa.lf[idx[q]] : h->csa.psi[idx[q]]));
+}
+uint64_t ref_csa_extract(void * p, uint64_t begin, uint64_t end, uint8_t * out)
+{
+    RefCsa * h = (RefCsa *)p;
+    return extract(h->csa, begin, end, out);
+}
+uint64_t ref_csa_locate(void * p, const uint8_t * pat, uint64_t m, uint64_t * out, uint64_t cap)
+{
+    RefCsa * h = (RefCsa *)p;
+    auto occ = locate(h->csa, pat, pat + m);
+    for (uint64_t i = 0; i < occ.size() && i < cap; ++i)
+        out[i] = occ[i];
+    return occ.size();
+}
 // which: 0 = csa_wt<wt_huff<bit_vector,rank_support_v5<>>>, 1 = the FM_HUFF type of the count benchmark
 void ref_csa_serialize(void * p, int which, uint8_t ** out, uint64_t * len)
 {

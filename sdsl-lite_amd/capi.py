@@ -73,7 +73,20 @@ SIGNATURES = {
     "sdsl_hip_fm_create_from_text_ex": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "sdsl_hip_fm_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_fm_serialize": (C.c_int32, [_vp, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sdsl_hip_fm_create_from_sdsl_ex": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32,
+                                                   C.POINTER(_vp)]),
     "sdsl_hip_fm_drop_sa": (C.c_int32, [_vp]),
+    "sdsl_hip_fm_sampling": (C.c_int32, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
+    "sdsl_hip_fm_sa_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "sdsl_hip_fm_isa_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "sdsl_hip_fm_lf_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "sdsl_hip_fm_psi_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "sdsl_hip_fm_extract_batch": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64,
+                                              C.POINTER(C.c_uint64), _vp]),
+    "sdsl_hip_fm_sa_range_batch": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, _vp, _vp, C.c_uint64,
+                                               C.POINTER(C.c_uint64), _vp]),
+    "sdsl_hip_fm_locate_batch": (C.c_int32, [_vp, _vp, C.c_uint32, C.c_uint64, _vp, _vp, C.c_uint64,
+                                             C.POINTER(C.c_uint64), _vp]),
     "sdsl_hip_fm_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_fm_size": (C.c_uint64, [_vp]),
     "sdsl_hip_fm_sigma": (C.c_uint64, [_vp]),

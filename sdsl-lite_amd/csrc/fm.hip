@@ -7,21 +7,9 @@
 //   count(csa,begin,end)                   suffix_array_algorithm.hpp:464-471
 //   byte_alphabet                          csa_alphabet_strategy.hpp:175-212
 //   csa_wt::rank_bwt                       csa_wt.hpp:286-289
-#include "fm_device.hpp"
-#include "wt_host.hpp"
-
-struct sdsl_hip_wt_s;
-sdsl_hip_wt_s * sdsl_hip_wt_alloc();
-sdslhip::WtHost & sdsl_hip_wt_host(sdsl_hip_wt_s * w);
-sdsl_hip_status sdsl_hip_wt_finish(sdsl_hip_wt_s * w);
+#include "fm_host.hpp"
 
 namespace sdslhip {
-
-sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa);
-sdsl_hip_status sa_samples_to_host(const uint32_t * d_sa, uint64_t n, uint64_t sa_dens, uint64_t isa_dens,
-                                   std::vector<uint64_t> & sa_s, std::vector<uint64_t> & isa_s);
-sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint32_t * vals_in, uint32_t * vals_out,
-                                   uint64_t n, unsigned end_bit, hipStream_t s);
 
 // Sort key of a pattern: its last eight bytes, the LAST byte most significant — backward search consumes a pattern
 // from its end, so patterns that are neighbours in this order walk the same SA intervals (the same rank lines) for
@@ -210,17 +198,6 @@ __global__ __launch_bounds__(kBlock) void k_fm_backward_step(WtView wt, const Fm
 
 using namespace sdslhip;
 
-struct sdsl_hip_fm_s
-{
-    int device = 0;
-    uint64_t size = 0;
-    uint32_t sigma = 0;
-    sdsl_hip_wt_s * wt = nullptr;
-    FmTables tab;
-    DevBuf d_tab;
-    DevBuf d_sa; // suffix array (u32 per suffix) of an index created from text; empty otherwise
-};
-
 static void fm_free(sdsl_hip_fm_s * f)
 {
     if (!f)
@@ -359,6 +336,37 @@ sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_te
 sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int32_t layout, int32_t device,
                                              sdsl_hip_fm_t * out)
 {
+    return sdsl_hip_fm_create_from_sdsl_ex(bytes, len, layout, 0, 0, device, out);
+}
+
+// uploads an SDSL sample vector (int_vector<0>) as u64; every value must be < n
+static sdsl_hip_status fm_upload_samples(const HostIntVec & v, uint64_t expect, uint64_t n, const char * what, DevBuf & d)
+{
+    if (v.size() != expect)
+    {
+        set_error("csa_wt stream: %s holds %llu entries, %llu expected for this density", what,
+                  (unsigned long long)v.size(), (unsigned long long)expect);
+        return SDSL_HIP_ERR_FORMAT;
+    }
+    std::vector<uint64_t> h(expect);
+    for (uint64_t i = 0; i < expect; ++i)
+    {
+        h[i] = v.get(i);
+        if (h[i] >= n)
+        {
+            set_error("csa_wt stream: %s[%llu] is out of range", what, (unsigned long long)i);
+            return SDSL_HIP_ERR_FORMAT;
+        }
+    }
+    SH_TRY(d.alloc(expect * 8));
+    if (expect)
+        SH_HIP(hipMemcpy(d.p, h.data(), expect * 8, hipMemcpyHostToDevice));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_create_from_sdsl_ex(const void * bytes, size_t len, int32_t layout, uint32_t sa_dens,
+                                                uint32_t isa_dens, int32_t device, sdsl_hip_fm_t * out)
+{
     if (!out || !bytes)
     {
         set_error("fm_create_from_sdsl: null argument");
@@ -381,9 +389,13 @@ sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int
     {
         // csa_wt::serialize (csa_wt.hpp:389-402): wt, sa_sample, isa_sample, alphabet.  The default
         // sampling policies are plain int_vector<0> (csa_sampling_strategy.hpp:72,735) — skipped.
-        HostIntVec c2c, comp2char, Cv;
+        // With the type's densities (template arguments, not part of the stream) the samples are kept for SA / ISA
+        // access, locate and extract; with 0 they are skipped and the handle answers count-type queries only.
+        HostIntVec c2c, comp2char, Cv, sa_s, isa_s;
         uint16_t sigma = 0;
-        if (!rd.skip_int_vector() || !rd.skip_int_vector() || !rd.int_vector(c2c, 8) || !rd.int_vector(comp2char, 8)
+        const bool keep = sa_dens != 0 && isa_dens != 0;
+        if (!(keep ? rd.int_vector(sa_s) : rd.skip_int_vector()) || !(keep ? rd.int_vector(isa_s) : rd.skip_int_vector())
+            || !rd.int_vector(c2c, 8) || !rd.int_vector(comp2char, 8)
             || !rd.int_vector(Cv, 64) || !rd.u16(sigma) || c2c.size() != 256 || sigma == 0 || sigma > 256
             || Cv.size() != (uint64_t)sigma + 1)
         {
@@ -418,6 +430,20 @@ sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int
             }
             else
                 st = fm_upload_tables(f);
+            if (st == SDSL_HIP_OK && keep)
+            {
+                const uint64_t n = f->size;
+                st = fm_upload_samples(sa_s, (n + sa_dens - 1) / sa_dens, n, "sa_sample", f->d_sa_s);
+                if (st == SDSL_HIP_OK)
+                    st = fm_upload_samples(isa_s, (n + isa_dens - 1) / isa_dens, n, "isa_sample", f->d_isa_s);
+                if (st == SDSL_HIP_OK)
+                {
+                    f->sa_dens = sa_dens;
+                    f->isa_dens = isa_dens;
+                    f->n_sa_s = (n + sa_dens - 1) / sa_dens;
+                    f->n_isa_s = (n + isa_dens - 1) / isa_dens;
+                }
+            }
         }
     }
     if (st != SDSL_HIP_OK)
@@ -433,7 +459,16 @@ sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
 {
     if (!fm)
         return SDSL_HIP_ERR_INVALID;
-    (void)hipSetDevice(fm->device);
+    SH_HIP(hipSetDevice(fm->device));
+    if (fm->d_sa.p && fm->sa_dens == 0)
+    { // keep SDSL's default sampling (csa_wt<..., 32, 64>) so that SA / ISA / locate / extract keep working
+        const uint64_t n = fm->size;
+        SH_TRY(sa_samples_device(fm->d_sa.as<uint32_t>(), n, 32, 64, &fm->d_sa_s, &fm->d_isa_s));
+        fm->sa_dens = 32;
+        fm->isa_dens = 64;
+        fm->n_sa_s = (n + 31) / 32;
+        fm->n_isa_s = (n + 63) / 64;
+    }
     fm->d_sa.release();
     return SDSL_HIP_OK;
 }
@@ -504,7 +539,7 @@ uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm)
 }
 uint64_t sdsl_hip_fm_device_bytes(sdsl_hip_fm_t fm)
 {
-    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes : 0;
+    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes + fm->d_sa_s.bytes + fm->d_isa_s.bytes : 0;
 }
 sdsl_hip_wt_t sdsl_hip_fm_wavelet_tree(sdsl_hip_fm_t fm)
 {

@@ -1,0 +1,54 @@
+// fm_host.hpp — host-side owner of a device FM-index (shared by fm.hip: count path, and locate.hip: SA / ISA /
+// LF / psi / extract / locate).
+#pragma once
+#include <vector>
+
+#include "fm_device.hpp"
+#include "wt_host.hpp"
+
+struct sdsl_hip_wt_s;
+sdsl_hip_wt_s * sdsl_hip_wt_alloc();
+sdslhip::WtHost & sdsl_hip_wt_host(sdsl_hip_wt_s * w);
+const uint64_t * sdsl_hip_wt_device_occ(sdsl_hip_wt_s * w);
+sdsl_hip_status sdsl_hip_wt_finish(sdsl_hip_wt_s * w);
+
+struct sdsl_hip_fm_s
+{
+    int device = 0;
+    uint64_t size = 0;
+    uint32_t sigma = 0;
+    sdsl_hip_wt_s * wt = nullptr;
+    sdslhip::FmTables tab;
+    sdslhip::DevBuf d_tab;
+    sdslhip::DevBuf d_sa; // suffix array (u32 per suffix) of an index created from text; empty otherwise
+    // SA-order SA samples SA[k*sa_dens] and text-order ISA samples ISA[k*isa_dens] (csa_sampling_strategy.hpp:72-135,
+    // 735-806), u64 each; density 0 = not present
+    sdslhip::DevBuf d_sa_s, d_isa_s;
+    uint32_t sa_dens = 0, isa_dens = 0;
+    uint64_t n_sa_s = 0, n_isa_s = 0;
+};
+
+namespace sdslhip {
+
+// what the locate kernels need besides the wavelet tree and the alphabet
+struct FmLocView
+{
+    const uint32_t * sa_full; // or null
+    const uint64_t * sa_s;    // or null
+    const uint64_t * isa_s;   // or null
+    uint64_t sa_dens, isa_dens, n_isa_s;
+    uint64_t size;
+};
+
+sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa);
+sdsl_hip_status sa_samples_to_host(const uint32_t * d_sa, uint64_t n, uint64_t sa_dens, uint64_t isa_dens,
+                                   std::vector<uint64_t> & sa_s, std::vector<uint64_t> & isa_s);
+// samples from the full suffix array, left on the device (either output may be null)
+sdsl_hip_status sa_samples_device(const uint32_t * d_sa, uint64_t n, uint64_t sa_dens, uint64_t isa_dens, DevBuf * sa_s,
+                                  DevBuf * isa_s);
+sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint32_t * vals_in, uint32_t * vals_out,
+                                   uint64_t n, unsigned end_bit, hipStream_t s);
+// out[i] = in[0] + ... + in[i-1] (n entries), stream-ordered
+sdsl_hip_status exclusive_scan_u64(const uint64_t * in, uint64_t * out, uint64_t n, hipStream_t s);
+
+} // namespace sdslhip

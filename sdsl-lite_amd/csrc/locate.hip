@@ -1,0 +1,569 @@
+// locate.hip — the rest of the csa_wt query API on the device: SA and ISA access, LF and psi, extract, locate.
+//
+// Reference semantics reproduced:
+//   csa_wt::operator[] (SA[i])             csa_wt.hpp:363-381          walk LF until a sampled SA index
+//   sa_order_sa_sampling                   csa_sampling_strategy.hpp:72-135   SA[k * dens]
+//   csa.isa[i]                             suffix_array_helper.hpp:519-537    nearest ISA sample to the right + LF
+//   isa_sampling::sample_qeq               csa_sampling_strategy.hpp:795-799
+//   csa.lf[i]                              suffix_array_helper.hpp:346-360
+//   csa.psi[i]                             suffix_array_helper.hpp:330-342
+//   extract(csa, begin, end, text) lf_tag  suffix_array_algorithm.hpp:578-600
+//   locate(csa, begin, end)                suffix_array_algorithm.hpp:505-523 (occurrences in SA order)
+//
+// All of them are LF walks: one LF step is one wt.inverse_select (wt_pc.hpp:411-430) plus a C[] lookup, i.e. one rank
+// line per tree level.  The walks have very different lengths (SA[i] stops at the first sampled index: geometric with
+// mean `dens`), so the kernel is a FLAT loop — one iteration is one tree level of whatever walk the quad (plain
+// bit vector) or lane (rrr) is on — and a finished walker takes its next query at once instead of waiting for the
+// slowest walker of its wave.
+//
+// An index created from text keeps its whole suffix array on the device (4 bytes per symbol — cheap against 288 GB),
+// so SA[i] and locate are plain gathers there; sdsl_hip_fm_drop_sa() reduces it to SDSL's default samples.
+#include "fm_host.hpp"
+
+namespace sdslhip {
+
+// ---- execution policies: who walks, and how one tree level is taken --------------------------------------------
+struct LocPlain
+{
+    static constexpr unsigned kLanes = kG, kThreads = kBlock;
+    struct Shared
+    {
+        WtTables T;
+        FmTables F;
+    };
+    static __device__ __forceinline__ void stage(Shared * S, const WtView & wt, const FmTables * ftab)
+    {
+        fm_stage_tables(&S->F, ftab);
+        wt_stage_tables(&S->T, wt.tables);
+    }
+    static __device__ __forceinline__ void level(const WtView & wt, const Shared * S, int s, unsigned & v, uint64_t & i)
+    {
+        quad_wt_invsel_level<false>(wt, &S->T, s, v, i);
+    }
+};
+
+struct LocRrr
+{
+    static constexpr unsigned kLanes = 1, kThreads = 512;
+    struct Shared
+    {
+        WtTables T;
+        FmTables F;
+        RrrTables RT;
+    };
+    static __device__ __forceinline__ void stage(Shared * S, const WtView & wt, const FmTables * ftab)
+    {
+        fm_stage_tables(&S->F, ftab);
+        rrr_stage_tables(&S->RT, wt.rrr.tables);
+        wt_stage_tables(&S->T, wt.tables);
+    }
+    static __device__ __forceinline__ void level(const WtView & wt, const Shared * S, int, unsigned & v, uint64_t & i)
+    {
+        unsigned bit = 0;
+        const uint64_t r = rrr_rank1(wt.rrr, &S->RT, S->T.bv_pos[v] + i, &bit) - S->T.bv_pos_rank[v];
+        i = bit ? r : i - r;
+        v = S->T.child[v][bit];
+    }
+};
+
+enum
+{
+    kWalkSa = 0,      // in: SA index; walk to the first sampled index; out: SA value
+    kWalkIsa = 1,     // in: text position; walk from the ISA sample to its right; out: ISA value
+    kWalkLf = 2,      // in: SA index; one step; out: LF value
+    kWalkExtract = 3, // in: (begin, end); walk from the ISA sample right of end; out: the bytes of text[begin..end]
+};
+
+// ISA sample to the right of text position i and its position (csa_sampling_strategy.hpp:795-799); past the last
+// sample this is the sample of position 0, which stands for position n of the cyclic text
+__device__ __forceinline__ void isa_sample_right(const FmLocView & L, uint64_t i, uint64_t & order, uint64_t & pos)
+{
+    const uint64_t ci = (i / L.isa_dens + 1) % L.n_isa_s;
+    pos = ci * L.isa_dens;
+    order = L.isa_s[ci];
+}
+
+template <class P, int MODE>
+__global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTables * __restrict__ ftab, FmLocView L,
+                                                         const uint64_t * __restrict__ in0,
+                                                         const uint64_t * __restrict__ in1,
+                                                         const uint64_t * __restrict__ out_off, uint64_t n,
+                                                         uint64_t * __restrict__ out, uint8_t * __restrict__ out_text)
+{
+    __shared__ typename P::Shared S;
+    P::stage(&S, wt, ftab);
+    const int s = threadIdx.x % P::kLanes;
+    constexpr unsigned kWalkers = P::kThreads / P::kLanes;
+    const uint64_t stride = (uint64_t)gridDim.x * kWalkers;
+    uint64_t q = (uint64_t)blockIdx.x * kWalkers + threadIdx.x / P::kLanes;
+    bool busy = false, fresh = false;
+    uint64_t j = 0, i = 0, steps = 0, taken = 0, emit_from = 0, base = 0;
+    unsigned v = 0;
+    for (;;)
+    {
+        if (!busy)
+        { // next query of this walker
+            if (q >= n)
+                break;
+            const uint64_t a = in0[q];
+            bool ok = a < L.size;
+            taken = 0;
+            if (MODE == kWalkSa || MODE == kWalkLf)
+            {
+                j = a;
+                steps = 1;
+            }
+            else if (MODE == kWalkIsa)
+            {
+                if (ok)
+                { // (suffix_array_helper.hpp:522-531)
+                    uint64_t pos;
+                    isa_sample_right(L, a, j, pos);
+                    steps = pos < a ? pos + L.size - a : pos - a;
+                }
+            }
+            else
+            { // extract text[a..e]: the walk from the sample at P > e yields text[P-1], text[P-2], ...
+                const uint64_t e = in1[q];
+                ok = ok && a <= e && e < L.size;
+                if (ok)
+                {
+                    uint64_t pos;
+                    isa_sample_right(L, e, j, pos);
+                    steps = pos <= e ? pos + L.size - e : pos - e; // P - e with P > e (position 0 taken as n)
+                    emit_from = steps;                             // the steps-th character of the walk is text[e]
+                    steps += e - a;            // ... and text[a] is the last one
+                    base = out_off[q] + (e - a) + emit_from; // text[P-k] goes to out_off[q] + (P-k-a) = base - k
+                }
+            }
+            if (!ok)
+            {
+                if (MODE != kWalkExtract && s == 0)
+                    out[q] = SDSL_HIP_NPOS;
+                q += stride;
+                continue;
+            }
+            busy = true;
+            fresh = true;
+        }
+        if (fresh)
+        { // between two LF steps: finished?
+            bool done;
+            if (MODE == kWalkSa) // LF is one cycle of length n in a consistent index: a longer walk means a broken one
+                done = j % L.sa_dens == 0 || taken > L.size;
+            else
+                done = taken == steps;
+            if (done)
+            {
+                if (MODE == kWalkSa)
+                {
+                    uint64_t r = SDSL_HIP_NPOS;
+                    if (j % L.sa_dens == 0)
+                    {
+                        r = L.sa_s[j / L.sa_dens] + taken; // (csa_wt.hpp:373-380)
+                        r = r < L.size ? r : r - L.size;
+                    }
+                    if (s == 0)
+                        out[q] = r;
+                }
+                else if (MODE != kWalkExtract)
+                {
+                    if (s == 0)
+                        out[q] = j;
+                }
+                q += stride;
+                busy = false;
+                continue;
+            }
+            fresh = false;
+            v = 0;
+            i = j;
+        }
+        if (S.T.child[v][0] == kWtUndef)
+        { // leaf: the LF step is complete (suffix_array_helper.hpp:352-358)
+            const unsigned c = (unsigned)S.T.bv_pos_rank[v];
+            j = S.F.C[S.F.char2comp[c]] + i;
+            ++taken;
+            if (MODE == kWalkExtract && taken >= emit_from && s == 0)
+                out_text[base - taken] = (uint8_t)c;
+            fresh = true;
+            continue;
+        }
+        P::level(wt, &S, s, v, i);
+    }
+}
+
+// SA[i] from the whole suffix array
+__global__ __launch_bounds__(256) void k_fm_sa_full(const uint32_t * __restrict__ sa, uint64_t size,
+                                                    const uint64_t * __restrict__ idx, uint64_t n,
+                                                    uint64_t * __restrict__ out)
+{
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t i = idx[q];
+        out[q] = i < size ? (uint64_t)sa[i] : SDSL_HIP_NPOS;
+    }
+}
+
+// psi[i] = wt.select(i - C[cc] + 1, comp2char[cc]) with cc the symbol whose F-range holds i
+// (suffix_array_helper.hpp:330-342, first_row_symbol :28-48); absent/invalid i select the 1st occurrence of an absent
+// symbol, patched to NPOS afterwards
+__global__ __launch_bounds__(256) void k_fm_psi_args(const FmTables * __restrict__ ftab, uint32_t sigma, uint64_t size,
+                                                     const uint64_t * __restrict__ idx, uint64_t n,
+                                                     uint64_t * __restrict__ sel_i, uint8_t * __restrict__ sel_c)
+{
+    __shared__ FmTables F;
+    __shared__ uint8_t comp2char[256];
+    fm_stage_tables(&F, ftab);
+    __syncthreads();
+    for (unsigned c = threadIdx.x; c < 256; c += blockDim.x)
+        if (F.char2comp[c] || c == 0)
+            comp2char[F.char2comp[c]] = (uint8_t)c;
+    __syncthreads();
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t i = idx[q];
+        if (i >= size)
+        {
+            sel_i[q] = 0; // wt.select answers NPOS for i == 0
+            sel_c[q] = comp2char[0];
+            continue;
+        }
+        unsigned lo = 0, hi = sigma; // largest cc with C[cc] <= i
+        while (hi - lo > 1)
+        {
+            unsigned mid = (lo + hi) >> 1;
+            if (F.C[mid] <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        sel_i[q] = i - F.C[lo] + 1;
+        sel_c[q] = comp2char[lo];
+    }
+}
+
+// lengths of the answers of a ragged batch: extract -> end-begin+1, SA ranges -> r+1-l (0 for empty or invalid ones)
+template <bool EXTRACT>
+__global__ __launch_bounds__(256) void k_fm_lengths(const uint64_t * __restrict__ a, const uint64_t * __restrict__ b,
+                                                    uint64_t size, uint64_t n, uint64_t * __restrict__ len)
+{
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q <= n; q += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t v = 0;
+        if (q < n)
+        {
+            const uint64_t x = a[q], y = b[q];
+            if (x <= y && y < size)
+                v = y - x + 1;
+            (void)EXTRACT;
+        }
+        len[q] = v; // entry n is 0: the scan turns it into the total
+    }
+}
+
+// out[z] = l[p] + (z - off[p]) for the p with off[p] <= z < off[p+1]: the SA indices of all occurrences
+__global__ __launch_bounds__(256) void k_fm_expand(const uint64_t * __restrict__ l, const uint64_t * __restrict__ off,
+                                                   uint64_t n, uint64_t total, uint64_t * __restrict__ out)
+{
+    for (uint64_t z = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; z < total; z += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t lo = 0, hi = n; // largest p with off[p] <= z
+        while (hi - lo > 1)
+        {
+            uint64_t mid = (lo + hi) >> 1;
+            if (off[mid] <= z)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        out[z] = l[lo] + (z - off[lo]);
+    }
+}
+
+} // namespace sdslhip
+
+using namespace sdslhip;
+
+static FmLocView loc_view(const sdsl_hip_fm_s * f)
+{
+    FmLocView L;
+    L.sa_full = f->d_sa.as<uint32_t>();
+    L.sa_s = f->d_sa_s.as<uint64_t>();
+    L.isa_s = f->d_isa_s.as<uint64_t>();
+    L.sa_dens = f->sa_dens;
+    L.isa_dens = f->isa_dens;
+    L.n_isa_s = f->n_isa_s;
+    L.size = f->size;
+    return L;
+}
+
+// ISA samples for an index that still has its whole suffix array but no samples yet (SDSL's default density)
+static sdsl_hip_status ensure_isa_samples(sdsl_hip_fm_s * f)
+{
+    if (f->isa_dens)
+        return SDSL_HIP_OK;
+    if (!f->d_sa.p)
+    {
+        set_error("this FM-index has no ISA samples (loaded without densities, or created from a BWT)");
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    SH_TRY(sa_samples_device(f->d_sa.as<uint32_t>(), f->size, 32, 64, nullptr, &f->d_isa_s));
+    f->isa_dens = 64;
+    f->n_isa_s = (f->size + 63) / 64;
+    return SDSL_HIP_OK;
+}
+
+template <int MODE>
+static sdsl_hip_status launch_walk(sdsl_hip_fm_s * f, const uint64_t * d_in0, const uint64_t * d_in1,
+                                   const uint64_t * d_off, uint64_t n, uint64_t * d_out, uint8_t * d_text, hipStream_t s)
+{
+    if (n == 0)
+        return SDSL_HIP_OK;
+    const WtHost & w = sdsl_hip_wt_host(f->wt);
+    const FmLocView L = loc_view(f);
+    KernelTimer t(s);
+    if (w.backend == 1)
+        hipLaunchKernelGGL((k_fm_walk<LocRrr, MODE>), dim3(grid_for(n, LocRrr::kThreads, 256u * 3u)),
+                           dim3(LocRrr::kThreads), 0, s, w.view(), f->d_tab.as<FmTables>(), L, d_in0, d_in1, d_off, n,
+                           d_out, d_text);
+    else
+        hipLaunchKernelGGL((k_fm_walk<LocPlain, MODE>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(LocPlain::kThreads), 0, s,
+                           w.view(), f->d_tab.as<FmTables>(), L, d_in0, d_in1, d_off, n, d_out, d_text);
+    SH_HIP(hipGetLastError());
+    return SDSL_HIP_OK;
+}
+
+// SA values for device-resident indices (in place is fine: every walker reads its index before it writes)
+static sdsl_hip_status sa_lookup(sdsl_hip_fm_s * f, const uint64_t * d_idx, uint64_t n, uint64_t * d_out, hipStream_t s)
+{
+    if (n == 0)
+        return SDSL_HIP_OK;
+    if (f->d_sa.p)
+    {
+        KernelTimer t(s);
+        hipLaunchKernelGGL(k_fm_sa_full, dim3(grid_for(n, 256, 256u * 16u)), dim3(256), 0, s, f->d_sa.as<uint32_t>(),
+                           f->size, d_idx, n, d_out);
+        SH_HIP(hipGetLastError());
+        return SDSL_HIP_OK;
+    }
+    if (!f->sa_dens)
+    {
+        set_error("this FM-index has no SA samples (loaded without densities, or created from a BWT)");
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    return launch_walk<kWalkSa>(f, d_idx, nullptr, nullptr, n, d_out, nullptr, s);
+}
+
+extern "C" {
+
+sdsl_hip_status sdsl_hip_fm_sampling(sdsl_hip_fm_t fm, uint32_t * sa_dens, uint32_t * isa_dens, int32_t * has_full_sa)
+{
+    if (!fm)
+    {
+        set_error("fm_sampling: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    if (sa_dens)
+        *sa_dens = fm->sa_dens;
+    if (isa_dens)
+        *isa_dens = fm->isa_dens;
+    if (has_full_sa)
+        *has_full_sa = fm->d_sa.p ? 1 : 0;
+    return SDSL_HIP_OK;
+}
+
+static sdsl_hip_status simple_batch(sdsl_hip_fm_t fm, const uint64_t * idx, uint64_t n, uint64_t * out, void * stream,
+                                    int what, const char * name)
+{
+    if (!fm || (n && (!idx || !out)))
+    {
+        set_error("%s: invalid argument", name);
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(fm->device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    if (what == kWalkIsa)
+        SH_TRY(ensure_isa_samples(fm));
+    Staged si, so;
+    SH_TRY(si.in(idx, n * 8, s));
+    SH_TRY(so.out(out, n * 8));
+    if (what == kWalkSa)
+        SH_TRY(sa_lookup(fm, (const uint64_t *)si.dev, n, (uint64_t *)so.dev, s));
+    else if (what == kWalkIsa)
+        SH_TRY(launch_walk<kWalkIsa>(fm, (const uint64_t *)si.dev, nullptr, nullptr, n, (uint64_t *)so.dev, nullptr, s));
+    else
+        SH_TRY(launch_walk<kWalkLf>(fm, (const uint64_t *)si.dev, nullptr, nullptr, n, (uint64_t *)so.dev, nullptr, s));
+    SH_TRY(so.finish(s));
+    if (si.host && !so.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_sa_batch(sdsl_hip_fm_t fm, const uint64_t * idx, uint64_t n, uint64_t * out, void * stream)
+{
+    return simple_batch(fm, idx, n, out, stream, kWalkSa, "fm_sa_batch");
+}
+
+sdsl_hip_status sdsl_hip_fm_isa_batch(sdsl_hip_fm_t fm, const uint64_t * idx, uint64_t n, uint64_t * out, void * stream)
+{
+    return simple_batch(fm, idx, n, out, stream, kWalkIsa, "fm_isa_batch");
+}
+
+sdsl_hip_status sdsl_hip_fm_lf_batch(sdsl_hip_fm_t fm, const uint64_t * idx, uint64_t n, uint64_t * out, void * stream)
+{
+    return simple_batch(fm, idx, n, out, stream, kWalkLf, "fm_lf_batch");
+}
+
+sdsl_hip_status sdsl_hip_fm_psi_batch(sdsl_hip_fm_t fm, const uint64_t * idx, uint64_t n, uint64_t * out, void * stream)
+{
+    if (!fm || (n && (!idx || !out)))
+    {
+        set_error("fm_psi_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(fm->device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged si, so;
+    SH_TRY(si.in(idx, n * 8, s));
+    SH_TRY(so.out(out, n * 8));
+    DevBuf d_i, d_c;
+    SH_TRY(d_i.alloc(n * 8));
+    SH_TRY(d_c.alloc(n));
+    hipLaunchKernelGGL(k_fm_psi_args, dim3(grid_for(n, 256, 256u * 8u)), dim3(256), 0, s, fm->d_tab.as<FmTables>(),
+                       fm->sigma, fm->size, (const uint64_t *)si.dev, n, d_i.as<uint64_t>(), d_c.as<uint8_t>());
+    SH_HIP(hipGetLastError());
+    SH_TRY(sdsl_hip_wt_select_batch(fm->wt, d_i.as<uint64_t>(), d_c.as<uint8_t>(), n, (uint64_t *)so.dev, s));
+    SH_TRY(so.finish(s));
+    SH_HIP(hipStreamSynchronize(s)); // the scratch buffers die with this frame
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_extract_batch(sdsl_hip_fm_t fm, const uint64_t * begin, const uint64_t * end, uint64_t n,
+                                          uint64_t * out_offsets, uint8_t * out_text, uint64_t cap, uint64_t * total,
+                                          void * stream)
+{
+    if (!fm || !total || (n && (!begin || !end)))
+    {
+        set_error("fm_extract_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(fm->device));
+    *total = 0;
+    SH_TRY(ensure_isa_samples(fm));
+    Staged sb, se;
+    SH_TRY(sb.in(begin, n * 8, s));
+    SH_TRY(se.in(end, n * 8, s));
+    DevBuf d_len, d_off;
+    SH_TRY(d_len.alloc((n + 1) * 8));
+    SH_TRY(d_off.alloc((n + 1) * 8));
+    hipLaunchKernelGGL((k_fm_lengths<true>), dim3(grid_for(n + 1, 256, 256u * 8u)), dim3(256), 0, s,
+                       (const uint64_t *)sb.dev, (const uint64_t *)se.dev, fm->size, n, d_len.as<uint64_t>());
+    SH_HIP(hipGetLastError());
+    SH_TRY(exclusive_scan_u64(d_len.as<uint64_t>(), d_off.as<uint64_t>(), n + 1, s));
+    SH_HIP(hipMemcpyAsync(total, d_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    SH_HIP(hipStreamSynchronize(s));
+    if (out_offsets)
+    {
+        Staged so;
+        SH_TRY(so.out(out_offsets, (n + 1) * 8));
+        SH_HIP(hipMemcpyAsync(so.dev, d_off.p, (n + 1) * 8, hipMemcpyDeviceToDevice, s));
+        SH_TRY(so.finish(s));
+        SH_HIP(hipStreamSynchronize(s));
+    }
+    if (!out_text)
+        return SDSL_HIP_OK; // size query
+    if (cap < *total)
+    {
+        set_error("fm_extract_batch: the output needs %llu bytes, %llu given", (unsigned long long)*total,
+                  (unsigned long long)cap);
+        return SDSL_HIP_ERR_INVALID;
+    }
+    Staged st;
+    SH_TRY(st.out(out_text, *total));
+    SH_TRY(launch_walk<kWalkExtract>(fm, (const uint64_t *)sb.dev, (const uint64_t *)se.dev, d_off.as<uint64_t>(), n, nullptr,
+                                     (uint8_t *)st.dev, s));
+    SH_TRY(st.finish(s));
+    SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_sa_range_batch(sdsl_hip_fm_t fm, const uint64_t * l, const uint64_t * r, uint64_t n,
+                                           uint64_t * out_offsets, uint64_t * out_pos, uint64_t cap, uint64_t * total,
+                                           void * stream)
+{
+    if (!fm || !total || (n && (!l || !r)))
+    {
+        set_error("fm_sa_range_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(fm->device));
+    *total = 0;
+    Staged sl, sr;
+    SH_TRY(sl.in(l, n * 8, s));
+    SH_TRY(sr.in(r, n * 8, s));
+    DevBuf d_len, d_off;
+    SH_TRY(d_len.alloc((n + 1) * 8));
+    SH_TRY(d_off.alloc((n + 1) * 8));
+    hipLaunchKernelGGL((k_fm_lengths<false>), dim3(grid_for(n + 1, 256, 256u * 8u)), dim3(256), 0, s,
+                       (const uint64_t *)sl.dev, (const uint64_t *)sr.dev, fm->size, n, d_len.as<uint64_t>());
+    SH_HIP(hipGetLastError());
+    SH_TRY(exclusive_scan_u64(d_len.as<uint64_t>(), d_off.as<uint64_t>(), n + 1, s));
+    SH_HIP(hipMemcpyAsync(total, d_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    SH_HIP(hipStreamSynchronize(s));
+    if (out_offsets)
+    {
+        Staged so;
+        SH_TRY(so.out(out_offsets, (n + 1) * 8));
+        SH_HIP(hipMemcpyAsync(so.dev, d_off.p, (n + 1) * 8, hipMemcpyDeviceToDevice, s));
+        SH_TRY(so.finish(s));
+        SH_HIP(hipStreamSynchronize(s));
+    }
+    if (!out_pos)
+        return SDSL_HIP_OK; // size query
+    if (cap < *total)
+    {
+        set_error("fm_sa_range_batch: the output needs %llu entries, %llu given", (unsigned long long)*total,
+                  (unsigned long long)cap);
+        return SDSL_HIP_ERR_INVALID;
+    }
+    if (*total == 0)
+        return SDSL_HIP_OK;
+    Staged sp;
+    SH_TRY(sp.out(out_pos, *total * 8));
+    hipLaunchKernelGGL(k_fm_expand, dim3(grid_for(*total, 256, 256u * 16u)), dim3(256), 0, s, (const uint64_t *)sl.dev,
+                       d_off.as<uint64_t>(), n, *total, (uint64_t *)sp.dev);
+    SH_HIP(hipGetLastError());
+    SH_TRY(sa_lookup(fm, (const uint64_t *)sp.dev, *total, (uint64_t *)sp.dev, s));
+    SH_TRY(sp.finish(s));
+    SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_locate_batch(sdsl_hip_fm_t fm, const uint8_t * patterns, uint32_t m, uint64_t n_pat,
+                                         uint64_t * out_offsets, uint64_t * out_pos, uint64_t cap, uint64_t * total,
+                                         void * stream)
+{
+    if (!fm || !total || (n_pat && !patterns))
+    {
+        set_error("fm_locate_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(fm->device));
+    DevBuf d_l, d_r;
+    SH_TRY(d_l.alloc((n_pat + 1) * 8));
+    SH_TRY(d_r.alloc((n_pat + 1) * 8));
+    Staged sp;
+    SH_TRY(sp.in(patterns, n_pat * (uint64_t)m, s));
+    SH_TRY(sdsl_hip_fm_interval_batch(fm, (const uint8_t *)sp.dev, m, n_pat, d_l.as<uint64_t>(), d_r.as<uint64_t>(), s));
+    return sdsl_hip_fm_sa_range_batch(fm, d_l.as<uint64_t>(), d_r.as<uint64_t>(), n_pat, out_offsets, out_pos, cap, total,
+                                      s);
+}
+}

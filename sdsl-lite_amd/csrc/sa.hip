@@ -74,6 +74,43 @@ sdsl_hip_status sa_samples_to_host(const uint32_t * d_sa, uint64_t n, uint64_t s
     return SDSL_HIP_OK;
 }
 
+sdsl_hip_status sa_samples_device(const uint32_t * d_sa, uint64_t n, uint64_t sa_dens, uint64_t isa_dens, DevBuf * sa_s,
+                                  DevBuf * isa_s)
+{
+    if (sa_s)
+    {
+        const uint64_t ms = (n + sa_dens - 1) / sa_dens;
+        SH_TRY(sa_s->alloc(ms * 8, true));
+        hipLaunchKernelGGL(k_sa_sample, dim3(grid_for(ms, 256, 65536)), dim3(256), 0, 0, d_sa, n, sa_dens,
+                           sa_s->as<uint64_t>());
+        SH_HIP(hipGetLastError());
+    }
+    if (isa_s)
+    {
+        const uint64_t mi = (n + isa_dens - 1) / isa_dens;
+        SH_TRY(isa_s->alloc(mi * 8, true));
+        hipLaunchKernelGGL(k_isa_sample, dim3(grid_for(n, 256, 65536)), dim3(256), 0, 0, d_sa, n, isa_dens,
+                           isa_s->as<uint64_t>());
+        SH_HIP(hipGetLastError());
+    }
+    SH_HIP(hipDeviceSynchronize());
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status exclusive_scan_u64(const uint64_t * in, uint64_t * out, uint64_t n, hipStream_t s)
+{
+    if (n == 0)
+        return SDSL_HIP_OK;
+    size_t bytes = 0;
+    SH_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s));
+    void * tmp = nullptr;
+    SH_HIP(hipMallocAsync(&tmp, bytes ? bytes : 16, s));
+    hipError_t e = rocprim::exclusive_scan(tmp, bytes, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s);
+    (void)hipFreeAsync(tmp, s);
+    SH_HIP(e);
+    return SDSL_HIP_OK;
+}
+
 // rank[sa[i]] = scanned[i]
 __global__ void k_sa_scatter_rank(const uint32_t * __restrict__ sa, const uint32_t * __restrict__ scanned, uint64_t n,
                                   uint32_t * __restrict__ rank)

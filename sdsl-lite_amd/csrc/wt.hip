@@ -602,6 +602,10 @@ WtHost & sdsl_hip_wt_host(sdsl_hip_wt_s * w)
 {
     return w->h;
 }
+const uint64_t * sdsl_hip_wt_device_occ(sdsl_hip_wt_s * w)
+{
+    return w->d_occ.as<uint64_t>();
+}
 sdsl_hip_status sdsl_hip_wt_finish(sdsl_hip_wt_s * w)
 {
     SH_TRY(w->d_occ.alloc(sizeof w->h.occ));

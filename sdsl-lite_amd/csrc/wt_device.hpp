@@ -116,31 +116,37 @@ __device__ __forceinline__ void quad_wt_rank2(const WtView & wt, const WtTables 
         a = 0;
 }
 
+// one level of wt_pc::inverse_select from inner node v at offset i of its slice: the bit at the position and the
+// rank up to it come from the same line
+template <bool NT>
+__device__ __forceinline__ void quad_wt_invsel_level(const WtView & wt, const WtTables * T, int s, unsigned & v,
+                                                     uint64_t & i)
+{
+    uint64_t pos = T->bv_pos[v] + i;
+    uint64_t L = pos / kDB;
+    Pair w = load_pair<NT>(wt.bv.lines, L, s);
+    unsigned off = (unsigned)(pos - L * kDB);
+    // the lane owning data word (off>>6) extracts the bit, then it is summed over the quad
+    int wi = (int)(off >> 6);
+    unsigned mybit = 0;
+    if (wi == 2 * s)
+        mybit = (unsigned)((w.b >> (off & 63)) & 1);
+    else if (s > 0 && wi == 2 * s - 1)
+        mybit = (unsigned)((w.a >> (off & 63)) & 1);
+    unsigned bit = quad_sum(mybit);
+    uint64_t r = quad_rank1(w, s, pos, L) - T->bv_pos_rank[v];
+    i = bit ? r : i - r;
+    v = T->child[v][bit];
+}
+
 // wt_pc::inverse_select(i) (wt_pc.hpp:411-430): returns (rank of wt[i] in [0,i), wt[i]); i < size.
-// The bit at the position and the rank up to it come from the same line.
 template <bool NT>
 __device__ __forceinline__ uint64_t quad_wt_inverse_select(const WtView & wt, const WtTables * T, int s, uint64_t i,
                                                            unsigned & c_out)
 {
     unsigned v = 0;
     while (T->child[v][0] != kWtUndef)
-    {
-        uint64_t pos = T->bv_pos[v] + i;
-        uint64_t L = pos / kDB;
-        Pair w = load_pair<NT>(wt.bv.lines, L, s);
-        unsigned off = (unsigned)(pos - L * kDB);
-        // the lane owning data word (off>>6) extracts the bit, then it is summed over the quad
-        int wi = (int)(off >> 6);
-        unsigned mybit = 0;
-        if (wi == 2 * s)
-            mybit = (unsigned)((w.b >> (off & 63)) & 1);
-        else if (s > 0 && wi == 2 * s - 1)
-            mybit = (unsigned)((w.a >> (off & 63)) & 1);
-        unsigned bit = quad_sum(mybit);
-        uint64_t r = quad_rank1(w, s, pos, L) - T->bv_pos_rank[v];
-        i = bit ? r : i - r;
-        v = T->child[v][bit];
-    }
+        quad_wt_invsel_level<NT>(wt, T, s, v, i);
     c_out = (unsigned)T->bv_pos_rank[v];
     return i;
 }

@@ -346,15 +346,17 @@ class csa_wt(_Handle):
     _destroy = "sdsl_hip_fm_destroy"
 
     def __init__(self, text=None, bwt=None, device: int = 0, sdsl_bytes: bytes | None = None,
-                 select_is_mcl: bool = True, rrr: bool = False):
-        """rrr=True: csa_wt<wt_huff<rrr_vector<63>>> (compressed FM-index)"""
+                 select_is_mcl: bool = True, rrr: bool = False, sa_dens: int = 0, isa_dens: int = 0):
+        """rrr=True: csa_wt<wt_huff<rrr_vector<63>>> (compressed FM-index).  sa_dens / isa_dens: the template arguments
+        of the serialised type (needed to keep its SA / ISA samples for sa / isa / locate / extract)."""
         super().__init__()
         L = capi.lib()
         flags = capi.WT_RRR63 if rrr else 0
         if sdsl_bytes is not None:
             buf = np.frombuffer(sdsl_bytes, dtype=np.uint8)
             layout = capi.LAYOUT_RRR63 if rrr else (capi.LAYOUT_BV_MCL if select_is_mcl else capi.LAYOUT_BV_SCAN)
-            capi.check(L.sdsl_hip_fm_create_from_sdsl(_ptr(buf), buf.size, layout, device, C.byref(self._h)))
+            capi.check(L.sdsl_hip_fm_create_from_sdsl_ex(_ptr(buf), buf.size, layout, sa_dens, isa_dens, device,
+                                                         C.byref(self._h)))
         elif bwt is not None:
             b = _bytes_arg(bwt, "bwt")
             n = b.numel() if _is_tensor(b) else b.size
@@ -424,6 +426,69 @@ class csa_wt(_Handle):
         capi.check(capi.lib().sdsl_hip_fm_interval_batch(self._h, _ptr(p) if total else None, m, n, _ptr(l), _ptr(r),
                                                          _stream_for(p)))
         return l, r
+
+    def sampling(self):
+        """(sa_dens, isa_dens, has_full_sa)"""
+        a, b, f = C.c_uint32(0), C.c_uint32(0), C.c_int32(0)
+        capi.check(capi.lib().sdsl_hip_fm_sampling(self._h, C.byref(a), C.byref(b), C.byref(f)))
+        return a.value, b.value, bool(f.value)
+
+    def _simple(self, fn, idx):
+        idx = _as_array(idx, np.uint64, "idx")
+        n = idx.numel() if _is_tensor(idx) else idx.size
+        out = _empty_like(idx, n, np.uint64)
+        capi.check(getattr(capi.lib(), fn)(self._h, _ptr(idx) if n else None, n, _ptr(out) if n else None,
+                                           _stream_for(idx)))
+        return out
+
+    def sa(self, idx):
+        """csa[i] (csa_wt.hpp:363-381)"""
+        return self._simple("sdsl_hip_fm_sa_batch", idx)
+
+    def isa(self, idx):
+        """csa.isa[i] (suffix_array_helper.hpp:519-537)"""
+        return self._simple("sdsl_hip_fm_isa_batch", idx)
+
+    def lf(self, idx):
+        """csa.lf[i]"""
+        return self._simple("sdsl_hip_fm_lf_batch", idx)
+
+    def psi(self, idx):
+        """csa.psi[i]"""
+        return self._simple("sdsl_hip_fm_psi_batch", idx)
+
+    def _ragged(self, call, like, n, elem_dtype):
+        total = C.c_uint64(0)
+        offs = _empty_like(like, n + 1, np.uint64)
+        capi.check(call(_ptr(offs), None, 0, C.byref(total)))
+        out = _empty_like(like, total.value, elem_dtype)
+        if total.value:
+            capi.check(call(None, _ptr(out), total.value, C.byref(total)))
+        return offs, out
+
+    def extract(self, begin, end):
+        """text[begin[q]..end[q]] (inclusive) for every q -> (offsets[n+1], bytes)  (suffix_array_algorithm.hpp:578-600)"""
+        b = _as_array(begin, np.uint64, "begin")
+        e = _as_array(end, np.uint64, "end")
+        n = b.numel() if _is_tensor(b) else b.size
+        L = capi.lib()
+        return self._ragged(lambda o, t, cap, tot: L.sdsl_hip_fm_extract_batch(
+            self._h, _ptr(b) if n else None, _ptr(e) if n else None, n, o, t, cap, tot, _stream_for(b)), b, n, np.uint8)
+
+    def sa_range(self, l, r):
+        """csa[l[q]..r[q]] for every SA interval -> (offsets[n+1], positions)"""
+        l = _as_array(l, np.uint64, "l")
+        r = _as_array(r, np.uint64, "r")
+        n = l.numel() if _is_tensor(l) else l.size
+        L = capi.lib()
+        return self._ragged(lambda o, t, cap, tot: L.sdsl_hip_fm_sa_range_batch(
+            self._h, _ptr(l) if n else None, _ptr(r) if n else None, n, o, t, cap, tot, _stream_for(l)), l, n, np.uint64)
+
+    def locate(self, patterns, m: int):
+        """all occurrences of n fixed-length patterns, SA order within a pattern -> (offsets[n+1], positions)
+        (suffix_array_algorithm.hpp:505-523)"""
+        l, r = self.interval(patterns, m)
+        return self.sa_range(l, r)
 
     def count_ragged(self, pats: list[bytes]):
         offs = np.zeros(len(pats) + 1, dtype=np.uint64)

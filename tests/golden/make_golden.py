@@ -165,6 +165,28 @@ def main():
             out[f"{t}/count{m}"] = csa.count_batch(allp, m)
             l, r = csa.interval_batch(allp, m)
             out[f"{t}/ival_l{m}"], out[f"{t}/ival_r{m}"] = l, r
+        # the rest of the csa_wt API (default densities 32 / 64): SA, ISA, LF, psi, extract, locate
+        N = csa.size()
+        ai = np.concatenate([queries(1500, N, 40), np.array([0, N - 1, N // 2], dtype=np.uint64)])
+        out[f"{t}/csa_idx"] = ai
+        out[f"{t}/csa_sa"], out[f"{t}/csa_isa"] = csa.sa(ai), csa.isa(ai)
+        out[f"{t}/csa_lf"], out[f"{t}/csa_psi"] = csa.lf(ai), csa.psi(ai)
+        eb = queries(300, N, 41)
+        ee = np.minimum(eb + queries(300, 120, 42), np.uint64(N - 1))
+        eb = np.concatenate([eb, np.array([0, N - 1, 0], dtype=np.uint64)])
+        ee = np.concatenate([ee, np.array([0, N - 1, min(N - 1, 700)], dtype=np.uint64)])
+        out[f"{t}/ext_b"], out[f"{t}/ext_e"] = eb, ee
+        out[f"{t}/ext_text"] = np.frombuffer(b"".join(csa.extract(int(b), int(e)) for b, e in zip(eb, ee)),
+                                             dtype=np.uint8)
+        for m, cnt in ((2, 200), (4, 600), (20, 3000)):
+            if n < m:
+                continue
+            allp = out[f"{t}/pat{m}"]
+            k = min(cnt, allp.size // m)
+            locs = [csa.locate(allp[i * m:(i + 1) * m].tobytes()) for i in range(k)]
+            out[f"{t}/loc_n{m}"] = np.array([k], dtype=np.uint64)
+            out[f"{t}/loc_off{m}"] = np.concatenate([[0], np.cumsum([x.size for x in locs])]).astype(np.uint64)
+            out[f"{t}/loc_pos{m}"] = np.concatenate(locs).astype(np.uint64) if locs else np.zeros(0, np.uint64)
         if t in ("example01.txt", "faust.txt"):
             open(os.path.join(HERE, "sdsl", f"{t}.csa_wt_huff_v5.sdsl"), "wb").write(csa.serialize(0))
             open(os.path.join(HERE, "sdsl", f"{t}.csa_fm_huff.sdsl"), "wb").write(csa.serialize(1))

@@ -95,6 +95,13 @@ _ORC_SIGS = {
     "orc_wt_code_lengths": (None, [_vp, _vp]),
     "orc_csa_build": (_vp, [_vp, _u64]),
     "orc_csa_build_from_bwt": (_vp, [_vp, _u64]),
+    "orc_csa_build_ex": (_vp, [_vp, _u64, _u64, _u64]),
+    "orc_csa_lf": (_u64, [_vp, _u64]),
+    "orc_csa_psi": (_u64, [_vp, _u64]),
+    "orc_csa_sa": (_u64, [_vp, _u64]),
+    "orc_csa_isa": (_u64, [_vp, _u64]),
+    "orc_csa_extract": (_u64, [_vp, _u64, _u64, _vp]),
+    "orc_csa_locate": (_u64, [_vp, _vp, _u64, _vp, _u64]),
     "orc_csa_free": (None, [_vp]),
     "orc_csa_size": (_u64, [_vp]),
     "orc_csa_sigma": (_u64, [_vp]),
@@ -293,14 +300,44 @@ class OWt:
 
 
 class OCsa:
-    def __init__(self, text: bytes | None = None, bwt: np.ndarray | None = None):
+    def __init__(self, text: bytes | None = None, bwt: np.ndarray | None = None, sa_dens: int = 32,
+                 isa_dens: int = 64):
         L = oracle().L
         if bwt is not None:
             b = _u8arr(bwt)
             self.h = L.orc_csa_build_from_bwt(_p(b), b.size)
         else:
             t = _u8arr(np.frombuffer(text, dtype=np.uint8))
-            self.h = L.orc_csa_build(_p(t) if t.size else None, t.size)
+            self.h = L.orc_csa_build_ex(_p(t) if t.size else None, t.size, sa_dens, isa_dens)
+
+    def _each(self, fn, idx):
+        f = getattr(oracle().L, fn)
+        return np.array([f(self.h, int(i)) for i in idx], dtype=np.uint64)
+
+    def sa(self, idx):
+        return self._each("orc_csa_sa", idx)
+
+    def isa(self, idx):
+        return self._each("orc_csa_isa", idx)
+
+    def lf(self, idx):
+        return self._each("orc_csa_lf", idx)
+
+    def psi(self, idx):
+        return self._each("orc_csa_psi", idx)
+
+    def extract(self, begin: int, end: int) -> bytes:
+        out = np.empty(end - begin + 1, dtype=np.uint8)
+        oracle().L.orc_csa_extract(self.h, begin, end, _p(out))
+        return out.tobytes()
+
+    def locate(self, pat: bytes) -> np.ndarray:
+        p = _u8arr(np.frombuffer(pat, dtype=np.uint8))
+        n = oracle().L.orc_csa_locate(self.h, _p(p) if p.size else None, p.size, None, 0)
+        out = np.empty(n, dtype=np.uint64)
+        if n:
+            oracle().L.orc_csa_locate(self.h, _p(p), p.size, _p(out), n)
+        return out
 
     def size(self):
         return oracle().L.orc_csa_size(self.h)
@@ -395,6 +432,9 @@ _REF_SIGS = {
     "ref_csa_backward_search": (None, [_vp, _vp, _vp, _vp, _u64, _vp, _vp]),
     "ref_csa_serialize": (None, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_csa_wt_rank": (None, [_vp, _vp, _vp, _u64, _vp]),
+    "ref_csa_access": (None, [_vp, C.c_int, _vp, _u64, _vp]),
+    "ref_csa_extract": (_u64, [_vp, _u64, _u64, _vp]),
+    "ref_csa_locate": (_u64, [_vp, _vp, _u64, _vp, _u64]),
     "ref_wt_rrr_serialize": (None, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_csa_rrr_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_set_random_bits": (None, [_vp, _u64, C.c_int]),
@@ -615,6 +655,36 @@ class RCsa:
         out = np.empty(i.size, dtype=np.uint64)
         ref().L.ref_csa_wt_rank(self.h, _p(i), _p(c), i.size, _p(out))
         return out
+
+    def _access(self, what, idx):
+        idx = _u64arr(idx)
+        out = np.empty(idx.size, dtype=np.uint64)
+        ref().L.ref_csa_access(self.h, what, _p(idx), idx.size, _p(out))
+        return out
+
+    def sa(self, idx):
+        return self._access(0, idx)
+
+    def isa(self, idx):
+        return self._access(1, idx)
+
+    def lf(self, idx):
+        return self._access(2, idx)
+
+    def psi(self, idx):
+        return self._access(3, idx)
+
+    def extract(self, begin: int, end: int) -> bytes:
+        out = np.empty(end - begin + 1, dtype=np.uint8)
+        ref().L.ref_csa_extract(self.h, begin, end, _p(out))
+        return out.tobytes()
+
+    def locate(self, pat: bytes) -> np.ndarray:
+        p = _u8arr(np.frombuffer(pat, dtype=np.uint8))
+        n = ref().L.ref_csa_locate(self.h, _p(p), p.size, None, 0)
+        out = np.empty(max(n, 1), dtype=np.uint64)
+        ref().L.ref_csa_locate(self.h, _p(p), p.size, _p(out), n)
+        return out[:n]
 
     def serialize(self, which=0) -> bytes:
         return _ref_bytes(ref().L.ref_csa_serialize, self.h, which)

@@ -500,6 +500,137 @@ def test_fm_built_on_gpu_serializes_to_sdsl_bytes(gpu, name):
 
 
 # ---------------------------------------------------------------------------------------------------
+# the rest of the csa_wt API: SA / ISA / LF / psi access, extract, locate
+# ---------------------------------------------------------------------------------------------------
+def _check_locate_api(csa, g, name, n_text):
+    idx = g[f"{name}/csa_idx"]
+    assert np.array_equal(csa.sa(idx), g[f"{name}/csa_sa"])
+    assert np.array_equal(csa.isa(idx), g[f"{name}/csa_isa"])
+    assert np.array_equal(csa.lf(idx), g[f"{name}/csa_lf"])
+    assert np.array_equal(csa.psi(idx), g[f"{name}/csa_psi"])
+    N = csa.size()
+    bad = np.array([N, N + 5, 2**63], dtype=np.uint64)
+    for fn in (csa.sa, csa.isa, csa.lf, csa.psi):
+        assert np.all(fn(bad) == NPOS)
+    eb, ee = g[f"{name}/ext_b"], g[f"{name}/ext_e"]
+    off, text = csa.extract(eb, ee)
+    assert text.tobytes() == g[f"{name}/ext_text"].tobytes()
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum(ee - eb + np.uint64(1))]).astype(np.uint64))
+    # queries outside the precondition (begin > end, end >= size) yield nothing
+    off2, text2 = csa.extract(np.array([5, 0, 0], dtype=np.uint64), np.array([4, N, min(3, N - 1)], dtype=np.uint64))
+    assert list(off2[:3]) == [0, 0, 0] and int(off2[3]) == text2.size == min(3, N - 1) + 1
+    for m in (2, 4, 20):
+        if f"{name}/loc_n{m}" not in g.files:
+            continue
+        k = int(g[f"{name}/loc_n{m}"][0])
+        pats = g[f"{name}/pat{m}"][: k * m]
+        off, pos = csa.locate(pats, m)
+        assert np.array_equal(off, g[f"{name}/loc_off{m}"]) and np.array_equal(pos, g[f"{name}/loc_pos{m}"])
+    # empty batch
+    off, pos = csa.sa_range(np.zeros(0, np.uint64), np.zeros(0, np.uint64))
+    assert off.size == 1 and int(off[0]) == 0 and pos.size == 0
+
+
+@pytest.mark.parametrize("name", FM_TEXTS)
+@pytest.mark.parametrize("how", ["full_sa", "dropped", "rrr_dropped"])
+def test_fm_locate_extract_golden(gpu, name, how):
+    g = _fm_cases(name)
+    data = gd.text(name)
+    csa = gpu.csa_wt(text=data, rrr=how.startswith("rrr"))
+    assert csa.sampling() == (0, 0, True)
+    if how != "full_sa":
+        csa.drop_sa()  # keeps SDSL's default samples: the answers come from LF walks now
+        assert csa.sampling() == (32, 64, False)
+    _check_locate_api(csa, g, name, len(data))
+
+
+@pytest.mark.parametrize("name", ["example01.txt", "faust.txt"])
+@pytest.mark.parametrize("which,rrr,dens", [("csa_wt_huff_v5", False, (32, 64)), ("csa_wt_huff_rrr63", True, (32, 64)),
+                                            ("csa_fm_huff", False, (1 << 20, 1 << 20))])
+def test_fm_locate_extract_on_loaded_stream(gpu, name, which, rrr, dens):
+    """indexes written by the real library, loaded with their type's densities"""
+    g = _fm_cases(name)
+    blob = gd.sdsl_file(f"{name}.{which}.sdsl")
+    csa = gpu.csa_wt(sdsl_bytes=blob, rrr=rrr, select_is_mcl=(which == "csa_wt_huff_v5"), sa_dens=dens[0],
+                     isa_dens=dens[1])
+    assert csa.sampling() == (dens[0], dens[1], False)
+    if dens[0] > 32 and name == "faust.txt":
+        # one SA sample for the whole text: every SA access walks up to n LF steps — keep the check small
+        idx = g[f"{name}/csa_idx"][:64]
+        assert np.array_equal(csa.sa(idx), g[f"{name}/csa_sa"][:64])
+        assert np.array_equal(csa.isa(idx), g[f"{name}/csa_isa"][:64])
+        return
+    _check_locate_api(csa, g, name, len(gd.text(name)))
+    # wrong densities are refused (sample vector sizes do not fit), no samples -> UNSUPPORTED
+    if name == "faust.txt":  # (a text shorter than the density has one sample whatever the density)
+        with pytest.raises(gpu.capi.SdslHipError):
+            gpu.csa_wt(sdsl_bytes=blob, rrr=rrr, select_is_mcl=(which == "csa_wt_huff_v5"), sa_dens=dens[0] * 2 + 1,
+                       isa_dens=dens[1])
+    plain = gpu.csa_wt(sdsl_bytes=blob, rrr=rrr, select_is_mcl=(which == "csa_wt_huff_v5"))
+    with pytest.raises(gpu.capi.SdslHipError) as e:
+        plain.sa(np.array([0], dtype=np.uint64))
+    assert e.value.status == gpu.capi.ERR_UNSUPPORTED
+
+
+def test_fm_locate_c_entry_point(gpu):
+    """sdsl_hip_fm_locate_batch (size query, then fill) equals interval + sa_range"""
+    import ctypes as C
+    g = gd.text_golden()
+    name, m = "faust.txt", 4
+    csa = gpu.csa_wt(text=gd.text(name))
+    k = int(g[f"{name}/loc_n{m}"][0])
+    pats = np.ascontiguousarray(g[f"{name}/pat{m}"][: k * m])
+    L = gpu.capi.lib()
+    total = C.c_uint64(0)
+    off = np.empty(k + 1, dtype=np.uint64)
+    gpu.capi.check(L.sdsl_hip_fm_locate_batch(csa._h, pats.ctypes.data, m, k, off.ctypes.data, None, 0, C.byref(total),
+                                              None))
+    assert total.value == g[f"{name}/loc_pos{m}"].size
+    pos = np.empty(total.value, dtype=np.uint64)
+    assert L.sdsl_hip_fm_locate_batch(csa._h, pats.ctypes.data, m, k, None, pos.ctypes.data, total.value - 1,
+                                      C.byref(total), None) == gpu.capi.ERR_INVALID
+    gpu.capi.check(L.sdsl_hip_fm_locate_batch(csa._h, pats.ctypes.data, m, k, None, pos.ctypes.data, total.value,
+                                              C.byref(total), None))
+    assert np.array_equal(off, g[f"{name}/loc_off{m}"]) and np.array_equal(pos, g[f"{name}/loc_pos{m}"])
+
+
+def test_fm_locate_roundtrip_large(gpu):
+    """32 MiB text: SA[ISA[i]] == i, psi(lf(i)) == i, extract == the text, every located position starts the pattern;
+    whole-SA answers == sampled-walk answers"""
+    rng = np.random.default_rng(11)
+    n = 1 << 25
+    data = rng.choice(np.arange(1, 100, dtype=np.uint8), size=n, p=_zipf(99)).astype(np.uint8)
+    csa = gpu.csa_wt(text=data)
+    N = csa.size()
+    pos = rng.integers(0, N, 100000).astype(np.uint64)
+    isa = csa.isa(pos)
+    assert np.array_equal(csa.sa(isa), pos)
+    j = rng.integers(0, N, 100000).astype(np.uint64)
+    assert np.array_equal(csa.psi(csa.lf(j)), j) and np.array_equal(csa.lf(csa.psi(j)), j)
+    b = rng.integers(0, n - 300, 5000).astype(np.uint64)
+    e = b + rng.integers(0, 256, 5000).astype(np.uint64)
+    off, text = csa.extract(b, e)
+    for q in (0, 17, 4999):
+        assert text[int(off[q]):int(off[q + 1])].tobytes() == data[int(b[q]):int(e[q]) + 1].tobytes()
+    flat = np.concatenate([data[int(x):int(y) + 1] for x, y in zip(b[:500], e[:500])])
+    assert np.array_equal(text[: flat.size], flat)
+    m = 6
+    st = rng.integers(0, n - m, 20000)
+    pats = np.concatenate([data[s:s + m] for s in st])
+    off, occ = csa.locate(pats, m)
+    assert np.array_equal(np.diff(off.astype(np.int64)).astype(np.uint64), csa.count(pats, m))
+    which = np.repeat(np.arange(20000), np.diff(off.astype(np.int64)))
+    sample = rng.integers(0, occ.size, 50000)
+    for t in range(m):
+        assert np.array_equal(data[(occ[sample] + np.uint64(t)).astype(np.int64)], pats[which[sample] * m + t])
+    sa_full = csa.sa(j)
+    csa.drop_sa()
+    assert np.array_equal(csa.sa(j[:20000]), sa_full[:20000])
+    off2, occ2 = csa.locate(pats[: 2000 * m], m)
+    assert np.array_equal(occ2, occ[: int(off[2000])])
+
+
+# ---------------------------------------------------------------------------------------------------
 # wt_huff<rrr_vector<63>> and csa_wt over it: same answers as the plain tree, rrr-compressed on the device
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name", gd.TEXTS)

@@ -147,3 +147,42 @@ def test_fm_known_answers():
     l, r = c.interval(t)
     assert r + 1 - l == 1
     assert c.interval(b"") == (0, c.size() - 1)
+
+
+@pytest.mark.parametrize("name", [t for t in gd.TEXTS if t not in ("empty.txt", "all_symbols.txt")])
+def test_fm_locate_extract(name):
+    """SA / ISA / LF / psi access, extract and locate against the real library's answers"""
+    g = gd.text_golden()
+    if f"{name}/csa_idx" not in g.files:
+        pytest.skip("text contains a 0 byte: not indexable (construct.hpp:41)")
+    data = gd.text(name)
+    csa = ol.OCsa(data)
+    idx = g[f"{name}/csa_idx"][:400]
+    assert np.array_equal(csa.sa(idx), g[f"{name}/csa_sa"][:400])
+    assert np.array_equal(csa.isa(idx), g[f"{name}/csa_isa"][:400])
+    assert np.array_equal(csa.lf(idx), g[f"{name}/csa_lf"][:400])
+    assert np.array_equal(csa.psi(idx), g[f"{name}/csa_psi"][:400])
+    eb, ee = g[f"{name}/ext_b"], g[f"{name}/ext_e"]
+    want = g[f"{name}/ext_text"].tobytes()
+    got = b"".join(csa.extract(int(b), int(e)) for b, e in zip(eb, ee))
+    assert got == want
+    full = data + b"\0"  # the indexed sequence (construct.hpp:100-108)
+    assert all(csa.extract(int(b), int(e)) == full[int(b):int(e) + 1] for b, e in zip(eb[:50], ee[:50]))
+    for m in (2, 4, 20):
+        if f"{name}/loc_n{m}" not in g.files:
+            continue
+        k = min(int(g[f"{name}/loc_n{m}"][0]), 60)
+        off, pos, pats = g[f"{name}/loc_off{m}"], g[f"{name}/loc_pos{m}"], g[f"{name}/pat{m}"]
+        for i in range(k):
+            assert np.array_equal(csa.locate(pats[i * m:(i + 1) * m].tobytes()), pos[int(off[i]):int(off[i + 1])])
+
+
+def test_fm_other_densities_same_answers():
+    """the sampling densities change the walks, never the answers"""
+    data = gd.text("faust.txt")[:20000]
+    a, b = ol.OCsa(data), ol.OCsa(data, sa_dens=7, isa_dens=1000)
+    idx = np.arange(0, a.size(), 97, dtype=np.uint64)
+    assert np.array_equal(a.sa(idx), b.sa(idx)) and np.array_equal(a.isa(idx), b.isa(idx))
+    assert a.extract(19000, 20000) == b.extract(19000, 20000) == data[19000:] + b"\0"
+    assert np.array_equal(a.sa(a.isa(idx)), idx)
+
