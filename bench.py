@@ -380,6 +380,40 @@ def main():
                                   1e6, "20-byte patterns, count(csa_wt<wt_huff<>>)")
                     cb.update(unit="Mcount/s", kind="port")
                     ex["fm_count"]["cpu_baseline"] = cb
+                # locate / extract / SA access, on the whole suffix array the build left in HBM
+                # and on SDSL's default samples (32 / 64) after drop_sa
+                npat = 100_000
+                lq, rq = csa.interval(pats[: npat * m], m)
+                off, pos = csa.sa_range(lq, rq)
+                _, ms = time_steps(lambda: csa.sa_range(lq, rq), 2, 1, barrier)
+                ex["fm_locate_whole_sa"] = {"Gocc/s": pos.numel() / ms / 1e6, "ms": ms, "patterns": npat,
+                                            "occurrences": pos.numel()}
+                del off, pos
+                sidx = torch.randint(0, nt + 1, (2_000_000,), device=dev, dtype=torch.int64, generator=gq)
+                want = csa.sa(sidx)
+                csa.drop_sa()
+                _, ms = time_steps(lambda: csa.sa(sidx), 2, 1, barrier)
+                assert torch.equal(csa.sa(sidx), want), "sampled SA walk != whole SA"
+                ex["fm_sa_access_dens32"] = {"Msa/s": sidx.numel() / ms / 1e3, "ms": ms, "queries": sidx.numel()}
+                eb = torch.randint(0, nt - 64, (1_000_000,), device=dev, dtype=torch.int64, generator=gq)
+                ee = eb + 63
+                eoff, etxt = csa.extract(eb, ee)
+                assert torch.equal(etxt.view(-1, 64)[:4096],
+                                   text[(eb[:4096].view(-1, 1) + torch.arange(64, device=dev).view(1, 64))])
+                _, ms = time_steps(lambda: csa.extract(eb, ee), 2, 1, barrier)
+                ex["fm_extract_64B"] = {"GB/s": etxt.numel() / ms / 1e6, "ms": ms, "snippets": eb.numel()}
+                del eoff, etxt, want
+                # the compressed flavour csa_wt<wt_huff<rrr_vector<63>>> on the same patterns
+                del csa, wt
+                torch.cuda.empty_cache()
+                t0 = time.perf_counter()
+                crrr = pkg.csa_wt(text=text, device=local, rrr=True)
+                rb = time.perf_counter() - t0
+                nq3 = min(nq2, 20_000_000)
+                _, ms = time_steps(lambda: crrr.count(pats[: nq3 * m], m, out2[:nq3]), 2, 1, barrier)
+                ex["fm_count_rrr63"] = {"Mcount/s": nq3 / ms / 1e3, "kernel_ms": ms, "patterns": nq3, "m": m,
+                                        "index_bytes": crrr.device_bytes(), "index_build_s": rb}
+                del crrr
 
     except Exception as e:  # the secondary measurements must never cost the headline line
         ex["error"] = f"{type(e).__name__}: {e}"

@@ -479,13 +479,40 @@ public:
     {
         std::string s = hip_detail::to_stream(csa);
         sdsl_hip_fm_t h = nullptr;
-        hip_detail::check(sdsl_hip_fm_create_from_sdsl(s.data(), s.size(), layout, device, &h),
-                          "sdsl_hip_fm_create_from_sdsl");
+        // the densities are template arguments of the host type, not part of its stream: hand them over so that the
+        // SA / ISA samples are kept and operator[], isa, locate, extract work on the device
+        hip_detail::check(sdsl_hip_fm_create_from_sdsl_ex(s.data(), s.size(), layout, t_csa::sa_sample_dens,
+                                                          t_csa::isa_sample_dens, device, &h),
+                          "sdsl_hip_fm_create_from_sdsl_ex");
         m_dev.reset(h, deleter());
     }
     size_type size() const
     {
         return sdsl_hip_fm_size(m_dev.get());
+    }
+    //! csa[i] (csa_wt.hpp:363-381); one-element batch — use sa_batch in loops
+    size_type operator[](size_type i) const
+    {
+        size_type r = 0;
+        sa_batch(&i, 1, &r);
+        return r;
+    }
+    void sa_batch(size_type const * idx, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_fm_sa_batch(m_dev.get(), idx, n, out, stream), "sdsl_hip_fm_sa_batch");
+    }
+    //! csa.isa[i], csa.lf[i], csa.psi[i] (suffix_array_helper.hpp:519-537, 346-360, 330-342), batched
+    void isa_batch(size_type const * idx, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_fm_isa_batch(m_dev.get(), idx, n, out, stream), "sdsl_hip_fm_isa_batch");
+    }
+    void lf_batch(size_type const * idx, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_fm_lf_batch(m_dev.get(), idx, n, out, stream), "sdsl_hip_fm_lf_batch");
+    }
+    void psi_batch(size_type const * idx, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_fm_psi_batch(m_dev.get(), idx, n, out, stream), "sdsl_hip_fm_psi_batch");
     }
     sdsl_hip_fm_t handle() const
     {
@@ -509,6 +536,67 @@ inline uint64_t count(csa_wt_hip const & csa, t_pat_iter begin, t_pat_iter end)
     hip_detail::check(sdsl_hip_fm_count_ragged(csa.handle(), p.empty() ? &dummy : p.data(), offs, 1, &r, nullptr),
                       "sdsl_hip_fm_count_ragged");
     return r;
+}
+//! sdsl::locate (suffix_array_algorithm.hpp:505-523) for n fixed-length patterns: the occurrences of pattern p are
+//! positions[offsets[p] .. offsets[p+1]), in SA order like the reference's
+inline void locate_batch(csa_wt_hip const & csa, uint8_t const * patterns, uint32_t m, size_t n,
+                         std::vector<uint64_t> & offsets, std::vector<uint64_t> & positions)
+{
+    std::vector<uint64_t> l(n), r(n);
+    hip_detail::check(sdsl_hip_fm_interval_batch(csa.handle(), patterns, m, n, l.data(), r.data(), nullptr),
+                      "sdsl_hip_fm_interval_batch");
+    uint64_t total = 0;
+    offsets.assign(n + 1, 0);
+    hip_detail::check(sdsl_hip_fm_sa_range_batch(csa.handle(), l.data(), r.data(), n, offsets.data(), nullptr, 0, &total,
+                                                 nullptr),
+                      "sdsl_hip_fm_sa_range_batch");
+    positions.assign(total, 0);
+    if (total)
+        hip_detail::check(sdsl_hip_fm_sa_range_batch(csa.handle(), l.data(), r.data(), n, nullptr, positions.data(), total,
+                                                     &total, nullptr),
+                          "sdsl_hip_fm_sa_range_batch");
+}
+//! sdsl::locate for one pattern, the reference's own call shape
+template <class t_pat_iter>
+inline std::vector<uint64_t> locate(csa_wt_hip const & csa, t_pat_iter begin, t_pat_iter end)
+{
+    std::vector<uint8_t> p(begin, end);
+    std::vector<uint64_t> off, pos;
+    if (p.empty())
+    { // the empty pattern matches every suffix: SA[0..size)
+        uint64_t l = 0, r = csa.size() - 1, total = 0;
+        hip_detail::check(sdsl_hip_fm_sa_range_batch(csa.handle(), &l, &r, 1, nullptr, nullptr, 0, &total, nullptr),
+                          "sdsl_hip_fm_sa_range_batch");
+        pos.assign(total, 0);
+        hip_detail::check(sdsl_hip_fm_sa_range_batch(csa.handle(), &l, &r, 1, nullptr, pos.data(), total, &total, nullptr),
+                          "sdsl_hip_fm_sa_range_batch");
+        return pos;
+    }
+    locate_batch(csa, p.data(), (uint32_t)p.size(), 1, off, pos);
+    return pos;
+}
+//! sdsl::extract (suffix_array_algorithm.hpp:578-600) for n ranges [begin[q], end[q]] (inclusive): the text of range q
+//! is text[offsets[q] .. offsets[q+1])
+inline void extract_batch(csa_wt_hip const & csa, uint64_t const * begin, uint64_t const * end, size_t n,
+                          std::vector<uint64_t> & offsets, std::vector<uint8_t> & text)
+{
+    uint64_t total = 0;
+    offsets.assign(n + 1, 0);
+    hip_detail::check(sdsl_hip_fm_extract_batch(csa.handle(), begin, end, n, offsets.data(), nullptr, 0, &total, nullptr),
+                      "sdsl_hip_fm_extract_batch");
+    text.assign(total, 0);
+    if (total)
+        hip_detail::check(sdsl_hip_fm_extract_batch(csa.handle(), begin, end, n, nullptr, text.data(), total, &total,
+                                                    nullptr),
+                          "sdsl_hip_fm_extract_batch");
+}
+//! sdsl::extract for one range, the reference's own call shape (returns the string)
+inline std::string extract(csa_wt_hip const & csa, uint64_t begin, uint64_t end)
+{
+    std::vector<uint64_t> off;
+    std::vector<uint8_t> t;
+    extract_batch(csa, &begin, &end, 1, off, t);
+    return std::string(t.begin(), t.end());
 }
 //! backward_search(csa, l, r, c, l_res, r_res) (suffix_array_algorithm.hpp:167-201), batched
 inline void backward_search_batch(csa_wt_hip const & csa, uint64_t const * l, uint64_t const * r, uint8_t const * c,

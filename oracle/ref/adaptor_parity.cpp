@@ -223,6 +223,47 @@ int main(int argc, char ** argv)
         std::string und = "sea";
         CHECK(count(d1, und.begin(), und.end()) == count(csa, und.begin(), und.end()), "count single");
         CHECK(d1.size() == csa.size(), "csa size");
+        // the rest of the API on the default-density index (samples travel with the adaptor)
+        {
+            size_t qq = 3000;
+            std::vector<uint64_t> idx(qq), o(qq);
+            for (auto & x : idx)
+                x = rng() % csa.size();
+            bool oks = true;
+            d1.sa_batch(idx.data(), qq, o.data());
+            for (size_t k = 0; k < qq; ++k)
+                oks &= o[k] == csa[idx[k]];
+            CHECK(oks, "csa_wt::operator[]");
+            d1.isa_batch(idx.data(), qq, o.data());
+            for (size_t k = 0; k < qq; ++k)
+                oks &= o[k] == csa.isa[idx[k]];
+            CHECK(oks, "csa.isa[]");
+            d1.lf_batch(idx.data(), qq, o.data());
+            for (size_t k = 0; k < qq; ++k)
+                oks &= o[k] == csa.lf[idx[k]];
+            d1.psi_batch(idx.data(), qq, o.data());
+            for (size_t k = 0; k < qq; ++k)
+                oks &= o[k] == csa.psi[idx[k]];
+            CHECK(oks, "csa.lf[] / csa.psi[]");
+            CHECK(d1[7] == csa[7], "csa_wt_hip::operator[]");
+            std::vector<uint64_t> off, pos;
+            locate_batch(d1, pats.data(), m, 200, off, pos);
+            bool okl = off.size() == 201;
+            for (size_t k = 0; k < 200 && okl; ++k)
+            {
+                auto ref = locate(csa, pats.begin() + k * m, pats.begin() + (k + 1) * m);
+                okl &= ref.size() == off[k + 1] - off[k];
+                for (size_t t = 0; t < ref.size() && okl; ++t)
+                    okl &= ref[t] == pos[off[k] + t];
+            }
+            CHECK(okl, "locate(csa_wt)");
+            auto one = locate(d1, und.begin(), und.end());
+            auto one_ref = locate(csa, und.begin(), und.end());
+            CHECK(one.size() == one_ref.size() and std::equal(one.begin(), one.end(), one_ref.begin()), "locate single");
+            CHECK(extract(d1, 10, 60) == extract(csa, 10, 60), "extract(csa_wt)");
+            CHECK(extract(d1, csa.size() - 3, csa.size() - 1) == extract(csa, csa.size() - 3, csa.size() - 1),
+                  "extract at the end (sentinel included)");
+        }
         // SDSL's README index family: csa_wt<wt_huff<rrr_vector<63>>>
         {
             csa_wt<wt_huff<rrr_vector<63>>, 32, 64> crrr;
