@@ -520,6 +520,11 @@ public:
     }
 };
 
+//! The serialised form of wt_pc carries its node table, so the same adaptor serves every byte-alphabet shape:
+//! wt_blcd<...> (wt_blcd.hpp:50) and wt_hutu<...> (wt_hutu.hpp) objects are handed over exactly like wt_huff<...>.
+typedef wt_huff_hip wt_blcd_hip;
+typedef wt_huff_hip wt_hutu_hip;
+
 //! sdsl::count (suffix_array_algorithm.hpp:464-471) for n fixed-length patterns
 inline void count_batch(csa_wt_hip const & csa, uint8_t const * patterns, uint32_t m, size_t n, uint64_t * out,
                         void * stream = nullptr)

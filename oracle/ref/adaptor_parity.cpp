@@ -192,6 +192,20 @@ int main(int argc, char ** argv)
         for (size_t k = 0; k < q; ++k)
             okr &= o[k] == wr.select(si[k], sc[k]);
         CHECK(okr, "wt_huff<rrr_vector<63>>::select");
+        // other byte shapes through the same adaptor: wt_blcd<> and wt_hutu<> (rank_support_v, mcl selects)
+        wt_blcd<> wb(bytes.begin(), bytes.end());
+        wt_hutu<> wh(bytes.begin(), bytes.end());
+        wt_blcd_hip db(wb, SDSL_HIP_LAYOUT_BV_MCL);
+        wt_hutu_hip dh(wh, SDSL_HIP_LAYOUT_BV_MCL);
+        std::vector<uint64_t> o2(q);
+        db.rank_batch(i.data(), c.data(), q, o.data());
+        dh.rank_batch(i.data(), c.data(), q, o2.data());
+        bool oks = true;
+        for (size_t k = 0; k < q; ++k)
+            oks &= o[k] == wb.rank(i[k], c[k]) and o2[k] == wh.rank(i[k], c[k]);
+        CHECK(oks, "wt_blcd::rank / wt_hutu::rank");
+        CHECK(db[p] == wb[p] and dh.inverse_select(p) == wh.inverse_select(p) and db.select(2, bytes[p]) == wb.select(2, bytes[p]),
+              "wt_blcd / wt_hutu access, inverse_select, select");
     }
     {
         csa_t csa;

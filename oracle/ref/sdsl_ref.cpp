@@ -394,6 +394,39 @@ int ref_csa_rrr_serialize(const uint8_t * text, uint64_t n, uint8_t ** out, uint
     return 0;
 }
 
+// other wt_pc shapes over bytes: shape 1 = wt_blcd (balanced), 2 = wt_hutu (Hu-Tucker); flavour 0 = the type with
+// its default template arguments (rank_support_v, select_support_mcl), 1 = <bit_vector, rank_support_v5<>,
+// select_support_scan<>, select_support_scan<0>> (what sdsl_hip_wt_serialize writes)
+void ref_wt_shape_serialize(const uint8_t * text, uint64_t n, int shape, int flavour, uint8_t ** out, uint64_t * len)
+{
+    if (shape == 1 && flavour == 0)
+        to_bytes(wt_blcd<>(text, text + n), out, len);
+    else if (shape == 1)
+        to_bytes(wt_blcd<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>(text, text + n), out,
+                 len);
+    else if (shape == 2 && flavour == 0)
+        to_bytes(wt_hutu<>(text, text + n), out, len);
+    else
+        to_bytes(wt_hutu<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>(text, text + n), out,
+                 len);
+}
+// csa_wt<wt_blcd<bit_vector, rank_support_v5<>, scan, scan>, 32, 64>: the balanced-tree FM-index as the device writes it
+int ref_csa_blcd_serialize(const uint8_t * text, uint64_t n, uint8_t ** out, uint64_t * len)
+{
+    csa_wt<wt_blcd<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>, 32, 64> csa;
+    std::string s((const char *)text, n);
+    try
+    {
+        construct_im(csa, s, 1);
+    }
+    catch (std::exception const &)
+    {
+        return 1;
+    }
+    to_bytes(csa, out, len);
+    return 0;
+}
+
 void ref_set_random_bits(uint64_t * words, uint64_t n_bits, int seed)
 {
     bit_vector bv(n_bits, 0);

@@ -20,6 +20,7 @@ ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_FORMAT, ERR_NO_DEVICE, ERR_UNSUPPORTED = -1
 NPOS = 0xFFFFFFFFFFFFFFFF
 BV_SELECT1, BV_SELECT0 = 1, 2
 WT_RRR63 = 1
+WT_BLCD = 2
 LAYOUT_BV_SCAN, LAYOUT_BV_MCL, LAYOUT_RRR63 = 0, 1, 2
 
 _u64p = C.POINTER(C.c_uint64)

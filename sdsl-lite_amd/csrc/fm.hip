@@ -233,7 +233,7 @@ static sdsl_hip_status fm_upload_tables(sdsl_hip_fm_s * f)
 }
 
 static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_bwt, uint64_t n, int device,
-                                          uint32_t backend)
+                                          uint32_t flags)
 {
     f->device = device;
     f->size = n;
@@ -241,7 +241,7 @@ static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_b
     if (!f->wt)
         return SDSL_HIP_ERR_NOMEM;
     WtHost & w = sdsl_hip_wt_host(f->wt);
-    SH_TRY(wt_build_from_device_text(w, d_bwt, n, device, backend)); // csa_wt.hpp:337-343: the WT is built over the BWT
+    SH_TRY(wt_build_from_device_text(w, d_bwt, n, device, flags)); // csa_wt.hpp:337-343: the WT is built over the BWT
     SH_TRY(sdsl_hip_wt_finish(f->wt));
     if (n == 0 || w.occ[0] != 1)
     {
@@ -271,7 +271,7 @@ sdsl_hip_status sdsl_hip_fm_create_from_bwt_ex(const uint8_t * bwt, uint64_t n, 
     Staged b;
     sdsl_hip_status st = b.in(bwt, n, nullptr);
     if (st == SDSL_HIP_OK)
-        st = fm_from_device_bwt(f, (const uint8_t *)b.dev, n, device, (flags & SDSL_HIP_WT_RRR63) ? 1u : 0u);
+        st = fm_from_device_bwt(f, (const uint8_t *)b.dev, n, device, flags);
     if (st != SDSL_HIP_OK)
     {
         fm_free(f);
@@ -312,8 +312,7 @@ sdsl_hip_status sdsl_hip_fm_create_from_text_ex(const uint8_t * text, uint64_t n
     if (!f)
         return SDSL_HIP_ERR_NOMEM;
     f->d_sa = std::move(d_sa);
-    sdsl_hip_status st = fm_from_device_bwt(f, d_bwt.as<uint8_t>(), n_text + 1, device,
-                                            (flags & SDSL_HIP_WT_RRR63) ? 1u : 0u);
+    sdsl_hip_status st = fm_from_device_bwt(f, d_bwt.as<uint8_t>(), n_text + 1, device, flags);
     if (st != SDSL_HIP_OK)
     {
         fm_free(f);

@@ -41,34 +41,27 @@ static void tables_clear(WtTables & T)
         T.c_to_leaf[c] = kWtUndef;
 }
 
-// Huffman code tree in SDSL's node numbering.  Leaves are created in symbol order, the two
-// smallest (frequency, creation index) pairs are merged first-popped = left; nodes are then
-// renumbered breadth-first from the root and every inner node gets the running sum of the
-// preceding inner-node frequencies as the start of its slice.
-static sdsl_hip_status build_shape(const uint64_t occ[256], WtTables & T, uint32_t & n_nodes, uint64_t & bv_size,
-                                   uint64_t & sigma)
+// Code trees in SDSL's node numbering.  A shape builder fills `tmp` (root last or anywhere, `root` says where);
+// nodes are then renumbered breadth-first from the root (wt_helper.hpp:230-300) and every inner node gets the running
+// sum of the preceding inner-node frequencies as the start of its slice.
+struct ShapeTmp
 {
-    struct Tmp
-    {
-        uint64_t freq;
-        int sym, left, right;
-    };
-    std::vector<Tmp> tmp;
+    uint64_t freq;
+    int sym, left, right;
+};
+
+// wt_huff (wt_huff.hpp:83-115): leaves in symbol order, the two smallest (frequency, creation index) pairs are
+// merged, first popped = left
+static int shape_huffman(const uint64_t occ[256], std::vector<ShapeTmp> & tmp)
+{
     typedef std::pair<uint64_t, int> Item;
     std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
-    sigma = 0;
     for (int c = 0; c < 256; ++c)
         if (occ[c])
         {
             heap.push(Item(occ[c], (int)tmp.size()));
-            tmp.push_back(Tmp{occ[c], c, -1, -1});
-            ++sigma;
+            tmp.push_back(ShapeTmp{occ[c], c, -1, -1});
         }
-    tables_clear(T);
-    n_nodes = 0;
-    bv_size = 0;
-    if (tmp.empty())
-        return SDSL_HIP_OK;
     while (heap.size() > 1)
     {
         Item a = heap.top();
@@ -76,16 +69,54 @@ static sdsl_hip_status build_shape(const uint64_t occ[256], WtTables & T, uint32
         Item b = heap.top();
         heap.pop();
         heap.push(Item(a.first + b.first, (int)tmp.size()));
-        tmp.push_back(Tmp{a.first + b.first, -1, a.second, b.second});
+        tmp.push_back(ShapeTmp{a.first + b.first, -1, a.second, b.second});
     }
+    return (int)tmp.size() - 1;
+}
+
+// wt_blcd (wt_blcd.hpp:86-127): the symbols in order, split into halves of ceil(sigma/2) and the rest, recursively
+static int shape_balanced_rec(const std::vector<int> & syms, size_t lb, size_t sigma, const uint64_t occ[256],
+                              std::vector<ShapeTmp> & tmp)
+{
+    if (sigma == 1)
+    {
+        tmp.push_back(ShapeTmp{occ[syms[lb]], syms[lb], -1, -1});
+        return (int)tmp.size() - 1;
+    }
+    const int id = (int)tmp.size();
+    tmp.push_back(ShapeTmp{0, -1, -1, -1});
+    const size_t l_sigma = (sigma + 1) / 2;
+    const int l = shape_balanced_rec(syms, lb, l_sigma, occ, tmp);
+    const int r = shape_balanced_rec(syms, lb + l_sigma, sigma - l_sigma, occ, tmp);
+    tmp[id].freq = tmp[l].freq + tmp[r].freq;
+    tmp[id].left = l;
+    tmp[id].right = r;
+    return id;
+}
+
+static sdsl_hip_status build_shape(const uint64_t occ[256], bool balanced, WtTables & T, uint32_t & n_nodes,
+                                   uint64_t & bv_size, uint64_t & sigma)
+{
+    std::vector<ShapeTmp> tmp;
+    std::vector<int> syms;
+    for (int c = 0; c < 256; ++c)
+        if (occ[c])
+            syms.push_back(c);
+    sigma = syms.size();
+    tables_clear(T);
+    n_nodes = 0;
+    bv_size = 0;
+    if (syms.empty())
+        return SDSL_HIP_OK;
+    const int root = balanced ? shape_balanced_rec(syms, 0, syms.size(), occ, tmp) : shape_huffman(occ, tmp);
     n_nodes = (uint32_t)tmp.size();
     // breadth-first renumbering
     std::vector<int> order; // order[bfs id] = tmp id
     order.reserve(n_nodes);
-    order.push_back((int)tmp.size() - 1);
+    order.push_back(root);
     for (size_t head = 0; head < order.size(); ++head)
     {
-        const Tmp & t = tmp[order[head]];
+        const ShapeTmp & t = tmp[order[head]];
         T.bv_pos[head] = bv_size;
         if (t.left >= 0)
         {
@@ -214,8 +245,9 @@ __global__ void k_wt_node_positions(const WtTables * __restrict__ T, uint32_t n_
 sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
                               hipStream_t s);
 
-sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t backend)
+sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t flags)
 {
+    const uint32_t backend = (flags & SDSL_HIP_WT_RRR63) ? 1u : 0u;
     SH_HIP(hipSetDevice(device));
     wt.device = device;
     wt.size = n;
@@ -231,7 +263,7 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
     }
     // 2. shape
     uint64_t bv_size = 0;
-    SH_TRY(build_shape(wt.occ, wt.tables, wt.n_nodes, bv_size, wt.sigma));
+    SH_TRY(build_shape(wt.occ, (flags & SDSL_HIP_WT_BLCD) != 0, wt.tables, wt.n_nodes, bv_size, wt.sigma));
     WtTables & T = wt.tables;
     // 3. bits, level by level
     const uint64_t nw = (bv_size + 63) >> 6;
@@ -630,7 +662,7 @@ sdsl_hip_status sdsl_hip_wt_create_ex(const uint8_t * text, uint64_t n, int32_t 
     Staged t;
     sdsl_hip_status st = t.in(text, n, nullptr); // host bytes are uploaded; device bytes are used where they are
     if (st == SDSL_HIP_OK)
-        st = wt_build_from_device_text(w->h, (const uint8_t *)t.dev, n, device, (flags & SDSL_HIP_WT_RRR63) ? 1u : 0u);
+        st = wt_build_from_device_text(w->h, (const uint8_t *)t.dev, n, device, flags);
     if (st == SDSL_HIP_OK)
         st = sdsl_hip_wt_finish(w);
     if (st != SDSL_HIP_OK)

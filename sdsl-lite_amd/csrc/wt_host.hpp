@@ -38,8 +38,9 @@ struct WtHost
 
 // Builds the tree shape on the host (a 256-entry histogram decides it) and the bit vector on the device, one
 // stable radix sort per tree level, from a symbol sequence that already lives in device memory.
-// backend: 0 = plain bit vector (rank lines + select directories), 1 = rrr_vector<63>
-sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t backend = 0);
+// flags: SDSL_HIP_WT_RRR63 (bit vector as rrr_vector<63> instead of rank lines + select directories),
+// SDSL_HIP_WT_BLCD (balanced shape instead of Huffman)
+sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t flags = 0);
 // Parses wt_pc::serialize output (wt_pc.hpp:713-726) and uploads; advances the reader.
 // layout: 0 = plain bv + select_support_scan (zero bytes), 1 = plain bv + select_support_mcl, 2 = rrr_vector<63> with
 // its own rank/select supports (zero bytes)

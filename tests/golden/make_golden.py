@@ -194,6 +194,14 @@ def main():
             open(os.path.join(HERE, "sdsl", f"{t}.wt_huff_rrr63.sdsl"), "wb").write(ol.ref_wt_rrr_bytes(data))
             open(os.path.join(HERE, "sdsl", f"{t}.csa_wt_huff_rrr63.sdsl"), "wb").write(ol.ref_csa_rrr_bytes(data))
     np.savez_compressed(os.path.join(HERE, "golden_text.npz"), **out)
+
+    # 5. other wt_pc shapes: wt_blcd / wt_hutu streams of the real library (answers do not depend on the shape)
+    for name, data in (("example01.txt", open(os.path.join(HERE, "texts", "example01.txt"), "rb").read()),
+                       ("faust60k", open(os.path.join(HERE, "texts", "faust.txt"), "rb").read()[:60000])):
+        open(os.path.join(HERE, "sdsl", f"{name}.wt_blcd.sdsl"), "wb").write(ol.ref_wt_shape_bytes(data, 1, 0))
+        open(os.path.join(HERE, "sdsl", f"{name}.wt_hutu.sdsl"), "wb").write(ol.ref_wt_shape_bytes(data, 2, 0))
+        open(os.path.join(HERE, "sdsl", f"{name}.wt_blcd_v5_scan.sdsl"), "wb").write(ol.ref_wt_shape_bytes(data, 1, 1))
+        open(os.path.join(HERE, "sdsl", f"{name}.csa_wt_blcd_v5_scan.sdsl"), "wb").write(ol.ref_csa_blcd_bytes(data))
     print("golden fixtures written under", HERE)
 
 

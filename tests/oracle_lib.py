@@ -437,6 +437,8 @@ _REF_SIGS = {
     "ref_csa_locate": (_u64, [_vp, _vp, _u64, _vp, _u64]),
     "ref_wt_rrr_serialize": (None, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_csa_rrr_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
+    "ref_wt_shape_serialize": (None, [_vp, _u64, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
+    "ref_csa_blcd_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_set_random_bits": (None, [_vp, _u64, C.c_int]),
     "ref_bits_sel": (_u32, [_u64, _u32]),
     "ref_bits_hi": (_u32, [_u64]),
@@ -468,6 +470,24 @@ def ref_wt_rrr_bytes(text: bytes) -> bytes:
     """wt_huff<rrr_vector<63>>::serialize of the real library"""
     t = _u8arr(np.frombuffer(text, dtype=np.uint8))
     return _ref_bytes(ref().L.ref_wt_rrr_serialize, _p(t) if t.size else None, t.size)
+
+
+def ref_wt_shape_bytes(text: bytes, shape: int, flavour: int) -> bytes:
+    """wt_blcd (shape 1) / wt_hutu (shape 2) ::serialize of the real library; flavour 0 = default template arguments,
+    1 = <bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>"""
+    t = _u8arr(np.frombuffer(text, dtype=np.uint8))
+    return _ref_bytes(ref().L.ref_wt_shape_serialize, _p(t) if t.size else None, t.size, shape, flavour)
+
+
+def ref_csa_blcd_bytes(text: bytes) -> bytes:
+    """csa_wt<wt_blcd<bit_vector, rank_support_v5<>, scan, scan>, 32, 64>::serialize of the real library"""
+    t = _u8arr(np.frombuffer(text, dtype=np.uint8))
+    p, n = _vp(None), _u64(0)
+    if ref().L.ref_csa_blcd_serialize(_p(t), t.size, C.byref(p), C.byref(n)):
+        raise ValueError("sdsl::construct_im threw")
+    data = C.string_at(p, n.value)
+    ref().L.ref_free(p)
+    return data
 
 
 def ref_csa_rrr_bytes(text: bytes) -> bytes:

@@ -500,6 +500,74 @@ def test_fm_built_on_gpu_serializes_to_sdsl_bytes(gpu, name):
 
 
 # ---------------------------------------------------------------------------------------------------
+# other wt_pc shapes: wt_blcd / wt_hutu streams load as they are, wt_blcd can be built on the device
+# ---------------------------------------------------------------------------------------------------
+def _shape_text(name):
+    return gd.text("faust.txt")[:60000] if name == "faust60k" else gd.text(name)
+
+
+def _check_wt_against_oracle(wt, data, seed):
+    """rank / access / inverse_select / select do not depend on the tree shape: the Huffman-shaped oracle answers"""
+    o = ol.OWt(data)
+    n = len(data)
+    arr = np.frombuffer(data, dtype=np.uint8)
+    assert (wt.size(), wt.sigma()) == (n, o.sigma())
+    i = np.concatenate([ol.mt19937_64(4000, seed) % np.uint64(n + 1), np.array([0, n], dtype=np.uint64)])
+    c = (ol.mt19937_64(i.size, seed + 1) % np.uint64(256)).astype(np.uint8)
+    c[::2] = arr[(ol.mt19937_64(i.size, seed + 2) % np.uint64(n)).astype(np.int64)][::2]
+    assert np.array_equal(wt.rank(i, c), o.rank(i, c))
+    j = ol.mt19937_64(3000, seed + 3) % np.uint64(n)
+    assert np.array_equal(wt.access(j), arr[j.astype(np.int64)])
+    r, cc = wt.inverse_select(j)
+    assert np.array_equal(cc, arr[j.astype(np.int64)]) and np.array_equal(r, o.rank(j, cc))
+    assert np.array_equal(wt.select(r + np.uint64(1), cc), j)
+
+
+@pytest.mark.parametrize("name", ["example01.txt", "faust60k"])
+@pytest.mark.parametrize("shape", ["wt_blcd", "wt_hutu"])
+def test_wt_other_shapes_load(gpu, name, shape):
+    blob = gd.sdsl_file(f"{name}.{shape}.sdsl")  # wt_blcd<> / wt_hutu<> of the real library (rank_support_v, mcl selects)
+    wt = gpu.wt_huff(sdsl_bytes=blob, select_is_mcl=True)
+    assert wt.consumed == len(blob)
+    _check_wt_against_oracle(wt, _shape_text(name), 70)
+
+
+@pytest.mark.parametrize("name", ["example01.txt", "faust60k"])
+@pytest.mark.parametrize("rrr", [False, True])
+def test_wt_blcd_built_on_gpu(gpu, name, rrr):
+    data = _shape_text(name)
+    wt = gpu.wt_huff(data, balanced=True, rrr=rrr)
+    _check_wt_against_oracle(wt, data, 80)
+    if not rrr:  # the same bytes as the real wt_blcd<bit_vector, rank_support_v5<>, scan, scan>
+        assert wt.serialize() == gd.sdsl_file(f"{name}.wt_blcd_v5_scan.sdsl")
+    # balanced codes: every symbol has depth ceil(log2 sigma) or one less
+    lens = wt.code_lengths()
+    present = lens[lens > 0]
+    assert present.max() - present.min() <= 1 and present.max() == int(np.ceil(np.log2(wt.sigma())))
+
+
+@pytest.mark.parametrize("name", ["example01.txt", "faust60k"])
+def test_fm_blcd_built_on_gpu(gpu, name):
+    data = _shape_text(name)
+    csa = gpu.csa_wt(text=data, balanced=True)
+    assert csa.serialize(32, 64) == gd.sdsl_file(f"{name}.csa_wt_blcd_v5_scan.sdsl")
+    ref = gpu.csa_wt(text=data)
+    arr = np.frombuffer(data, dtype=np.uint8)
+    m = 5
+    st = ol.mt19937_64(2000, 90) % np.uint64(len(data) - m)
+    pats = np.concatenate([arr[int(x):int(x) + m] for x in st])
+    assert np.array_equal(csa.count(pats, m), ref.count(pats, m))
+    o1, p1 = csa.locate(pats, m)
+    o2, p2 = ref.locate(pats, m)
+    assert np.array_equal(o1, o2) and np.array_equal(p1, p2)
+    loaded = gpu.csa_wt(sdsl_bytes=gd.sdsl_file(f"{name}.csa_wt_blcd_v5_scan.sdsl"), select_is_mcl=False, sa_dens=32,
+                        isa_dens=64)
+    assert np.array_equal(loaded.count(pats, m), ref.count(pats, m))
+    o3, p3 = loaded.locate(pats, m)
+    assert np.array_equal(p3, p2)
+
+
+# ---------------------------------------------------------------------------------------------------
 # the rest of the csa_wt API: SA / ISA / LF / psi access, extract, locate
 # ---------------------------------------------------------------------------------------------------
 def _check_locate_api(csa, g, name, n_text):
