@@ -85,6 +85,15 @@ sdsl_hip_status sdsl_hip_util_set_random_bits(uint64_t * words, uint64_t n_bits,
  * The data is COPIED into the device layout; the caller keeps ownership of `words`. */
 sdsl_hip_status sdsl_hip_bv_create(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t flags,
                                    sdsl_hip_bv_t * out);
+/* Two-bit patterns: rank_support_v / rank_support_v5 <10,2> <01,2> <00,2> <11,2> (rank_support.hpp:160-284) and
+ * select_support_mcl for the same patterns (select_support.hpp:206-409).  The handle holds the pattern's occurrence
+ * vector (bit i set iff the pattern ends at position i, SDSL's carry convention in front of position 0), so
+ *   rank_support_v5<10,2>::rank(idx)      == sdsl_hip_bv_rank_batch(h, 1, ...)
+ *   select_support_mcl<10,2>::select(i)   == sdsl_hip_bv_select_batch(h, 1, ...)   (flags: SDSL_HIP_BV_SELECT1)
+ * (t_b, t_pat_len) exactly as SDSL's template arguments: (10,2) (01 = 1,2) (00 = 0,2) (11,2); (0,1) and (1,1) fall
+ * through to sdsl_hip_bv_create. */
+sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t t_b,
+                                           uint32_t t_pat_len, uint32_t flags, sdsl_hip_bv_t * out);
 sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv);
 uint64_t sdsl_hip_bv_size(sdsl_hip_bv_t bv);         /* bit_vector::size() */
 uint64_t sdsl_hip_bv_ones(sdsl_hip_bv_t bv);         /* == rank_1(size()) */

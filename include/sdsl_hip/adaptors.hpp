@@ -54,11 +54,17 @@ struct bv_deleter
     }
 };
 typedef std::shared_ptr<sdsl_hip_bv_s> bv_ptr;
-inline bv_ptr make_device_bv(bit_vector const * v, int device, uint32_t flags)
+//! (t_b, t_pat_len) as SDSL's template arguments; two-bit patterns get their occurrence vector on the device
+inline bv_ptr make_device_bv(bit_vector const * v, int device, uint32_t flags, uint32_t t_b = 1, uint32_t t_pat_len = 1)
 {
     sdsl_hip_bv_t h = nullptr;
-    check(sdsl_hip_bv_create(v->data(), v->bit_size(), device, flags, &h), "sdsl_hip_bv_create");
+    check(sdsl_hip_bv_create_pattern(v->data(), v->bit_size(), device, t_b, t_pat_len, flags, &h),
+          "sdsl_hip_bv_create_pattern");
     return bv_ptr(h, bv_deleter());
+}
+constexpr bool pattern_ok(unsigned t_b, unsigned t_pat_len)
+{
+    return (t_pat_len == 1 and t_b <= 1) or (t_pat_len == 2 and (t_b == 10 or t_b == 01 or t_b == 00 or t_b == 11));
 }
 } // namespace hip_detail
 
@@ -66,7 +72,9 @@ inline bv_ptr make_device_bv(bit_vector const * v, int device, uint32_t flags)
 template <uint8_t t_b = 1, uint8_t t_pat_len = 1>
 class rank_support_v5_hip
 {
-    static_assert(t_pat_len == 1 and (t_b == 0 or t_b == 1), "rank_support_v5_hip: patterns 0 and 1 only");
+    static_assert(hip_detail::pattern_ok(t_b, t_pat_len), "rank_support_v5_hip: patterns 0, 1, 10, 01, 00, 11");
+    // a two-bit pattern is answered as rank_1 on its occurrence vector
+    static constexpr int dev_bit = t_pat_len == 2 ? 1 : t_b;
 
 public:
     typedef bit_vector bit_vector_type;
@@ -106,7 +114,7 @@ public:
     {
         if (!m_dev)
             throw std::runtime_error("rank_support_v5_hip: no vector set");
-        hip_detail::check(sdsl_hip_bv_rank_batch(m_dev.get(), t_b, idx, n, out, stream), "sdsl_hip_bv_rank_batch");
+        hip_detail::check(sdsl_hip_bv_rank_batch(m_dev.get(), dev_bit, idx, n, out, stream), "sdsl_hip_bv_rank_batch");
     }
     size_type size() const
     {
@@ -128,7 +136,7 @@ public:
     void set_vector(bit_vector const * v = nullptr)
     {
         m_v = v;
-        m_dev = v ? hip_detail::make_device_bv(v, m_device, 0) : hip_detail::bv_ptr();
+        m_dev = v ? hip_detail::make_device_bv(v, m_device, 0, t_b, t_pat_len) : hip_detail::bv_ptr();
     }
     bool operator==(rank_support_v5_hip const & o) const noexcept
     {
@@ -175,7 +183,8 @@ public:
 template <uint8_t t_b = 1, uint8_t t_pat_len = 1>
 class select_support_mcl_hip
 {
-    static_assert(t_pat_len == 1 and (t_b == 0 or t_b == 1), "select_support_mcl_hip: patterns 0 and 1 only");
+    static_assert(hip_detail::pattern_ok(t_b, t_pat_len), "select_support_mcl_hip: patterns 0, 1, 10, 01, 00, 11");
+    static constexpr int dev_bit = t_pat_len == 2 ? 1 : t_b;
 
 public:
     typedef bit_vector bit_vector_type;
@@ -214,7 +223,7 @@ public:
     {
         if (!m_dev)
             throw std::runtime_error("select_support_mcl_hip: no vector set");
-        hip_detail::check(sdsl_hip_bv_select_batch(m_dev.get(), t_b, i, n, out, stream), "sdsl_hip_bv_select_batch");
+        hip_detail::check(sdsl_hip_bv_select_batch(m_dev.get(), dev_bit, i, n, out, stream), "sdsl_hip_bv_select_batch");
     }
     size_type size() const
     {
@@ -235,7 +244,7 @@ public:
     void set_vector(bit_vector const * v = nullptr)
     {
         m_v = v;
-        m_dev = v ? hip_detail::make_device_bv(v, m_device, t_b ? SDSL_HIP_BV_SELECT1 : SDSL_HIP_BV_SELECT0)
+        m_dev = v ? hip_detail::make_device_bv(v, m_device, dev_bit ? SDSL_HIP_BV_SELECT1 : SDSL_HIP_BV_SELECT0, t_b, t_pat_len)
                   : hip_detail::bv_ptr();
     }
     bool operator==(select_support_mcl_hip const & o) const noexcept

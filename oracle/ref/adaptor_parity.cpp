@@ -89,6 +89,21 @@ int main(int argc, char ** argv)
             check_rank<rank_support_v<0>, rank_support_v_hip<0>>(bv, rng, "rank_support_v<0>");
             check_select<select_support_mcl<1>, select_support_mcl_hip<1>>(bv, ones, rng, "select_support_mcl<1>");
             check_select<select_support_mcl<0>, select_support_mcl_hip<0>>(bv, n - ones, rng, "select_support_mcl<0>");
+            // two-bit patterns (rank_support.hpp:160-284, select_support.hpp:206-409): occurrences end at position i
+            {
+                rank_support_v5<10, 2> c10(&bv);
+                rank_support_v5<01, 2> c01(&bv);
+                rank_support_v5<00, 2> c00(&bv);
+                rank_support_v5<11, 2> c11(&bv);
+                check_rank<rank_support_v5<10, 2>, rank_support_v5_hip<10, 2>>(bv, rng, "rank_support_v5<10,2>");
+                check_rank<rank_support_v5<01, 2>, rank_support_v5_hip<01, 2>>(bv, rng, "rank_support_v5<01,2>");
+                check_rank<rank_support_v<00, 2>, rank_support_v_hip<00, 2>>(bv, rng, "rank_support_v<00,2>");
+                check_rank<rank_support_v<11, 2>, rank_support_v_hip<11, 2>>(bv, rng, "rank_support_v<11,2>");
+                check_select<select_support_mcl<10, 2>, select_support_mcl_hip<10, 2>>(bv, c10(n), rng, "select_support_mcl<10,2>");
+                check_select<select_support_mcl<01, 2>, select_support_mcl_hip<01, 2>>(bv, c01(n), rng, "select_support_mcl<01,2>");
+                check_select<select_support_mcl<00, 2>, select_support_mcl_hip<00, 2>>(bv, c00(n), rng, "select_support_mcl<00,2>");
+                check_select<select_support_mcl<11, 2>, select_support_mcl_hip<11, 2>>(bv, c11(n), rng, "select_support_mcl<11,2>");
+            }
             // rrr_vector<63>
             rrr_vector<63> rv(bv);
             rrr_vector<63>::rank_1_type r1(&rv);

@@ -394,6 +394,48 @@ int ref_csa_rrr_serialize(const uint8_t * text, uint64_t n, uint8_t ** out, uint
     return 0;
 }
 
+// two-bit pattern supports on a plain bit vector: pat 0 = <10,2>, 1 = <01,2>, 2 = <00,2>, 3 = <11,2>;
+// which 0 = rank_support_v5, 1 = rank_support_v, 2 = select_support_mcl (arguments 1-based).  Returns the number of
+// arguments the select support counts (0 for rank).
+} // extern "C"
+template <uint8_t t_b>
+static uint64_t pattern_run(bit_vector const & bv, int which, const uint64_t * q, uint64_t n, uint64_t * out)
+{
+    if (which == 0)
+    {
+        rank_support_v5<t_b, 2> r(&bv);
+        for (uint64_t k = 0; k < n; ++k)
+            out[k] = r(q[k]);
+    }
+    else if (which == 1)
+    {
+        rank_support_v<t_b, 2> r(&bv);
+        for (uint64_t k = 0; k < n; ++k)
+            out[k] = r(q[k]);
+    }
+    else
+    {
+        select_support_mcl<t_b, 2> sl(&bv);
+        for (uint64_t k = 0; k < n; ++k)
+            out[k] = sl(q[k]);
+    }
+    return 0;
+}
+extern "C" {
+void ref_bv_pattern(const uint64_t * words, uint64_t n_bits, int pat, int which, const uint64_t * q, uint64_t n,
+                    uint64_t * out)
+{
+    bit_vector bv(n_bits, 0);
+    memcpy(bv.data(), words, ((n_bits + 63) >> 6) * 8);
+    switch (pat)
+    {
+    case 0: pattern_run<10>(bv, which, q, n, out); break;
+    case 1: pattern_run<01>(bv, which, q, n, out); break;
+    case 2: pattern_run<00>(bv, which, q, n, out); break;
+    default: pattern_run<11>(bv, which, q, n, out); break;
+    }
+}
+
 // other wt_pc shapes over bytes: shape 1 = wt_blcd (balanced), 2 = wt_hutu (Hu-Tucker); flavour 0 = the type with
 // its default template arguments (rank_support_v, select_support_mcl), 1 = <bit_vector, rank_support_v5<>,
 // select_support_scan<>, select_support_scan<0>> (what sdsl_hip_wt_serialize writes)

@@ -35,6 +35,8 @@ SIGNATURES = {
     "sdsl_hip_device_count": (C.c_int32, []),
     "sdsl_hip_util_set_random_bits": (C.c_int32, [_vp, C.c_uint64, C.c_uint64]),
     "sdsl_hip_bv_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
+    "sdsl_hip_bv_create_pattern": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                               C.POINTER(_vp)]),
     "sdsl_hip_bv_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_bv_size": (C.c_uint64, [_vp]),
     "sdsl_hip_bv_ones": (C.c_uint64, [_vp]),

@@ -226,6 +226,33 @@ sdsl_hip_status build_select_dir(BvHost & bv, int bit)
     return SDSL_HIP_OK;
 }
 
+// The occurrences of a two-bit pattern as a bit vector: bit i is set iff (x[i-1], x[i]) is the pattern, with SDSL's
+// convention for the bit in front of position 0 (rank_support.hpp:160-284: init_carry 0 for 10 and 11, 1 for 01 and
+// 00; bits.hpp:558-583 map10 / map01).  rank / select on pattern supports are rank_1 / select_1 on this vector.
+// pat: 0 = "10", 1 = "01", 2 = "00", 3 = "11"
+__global__ __launch_bounds__(256) void k_pattern_words(const uint64_t * __restrict__ x, uint64_t n_bits, uint64_t nw, int pat,
+                                                       uint64_t * __restrict__ d)
+{
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t cur = x[w];
+        const uint64_t carry = w ? x[w - 1] >> 63 : ((pat == 1 || pat == 2) ? 1u : 0u);
+        const uint64_t prev = (cur << 1) | carry;
+        uint64_t v;
+        if (pat == 0)
+            v = prev & ~cur;
+        else if (pat == 1)
+            v = (cur ^ prev) & cur;
+        else if (pat == 2)
+            v = ~(cur | prev);
+        else
+            v = cur & prev;
+        if (w == nw - 1 && (n_bits & 63))
+            v &= lo_set((unsigned)(n_bits & 63)); // the padding of the last word holds no positions
+        d[w] = v;
+    }
+}
+
 // Build the device layout from SDSL words that already live on the device.
 sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words, uint64_t n_bits, uint32_t flags,
                                            uint32_t sel_shift)
@@ -538,6 +565,52 @@ sdsl_hip_status sdsl_hip_bv_create(const uint64_t * words, uint64_t n_bits, int3
     sdsl_hip_status st = w.in(words, ((n_bits + 63) >> 6) * sizeof(uint64_t), nullptr);
     if (st == SDSL_HIP_OK)
         st = bv_build_from_device_words(bv->h, (const uint64_t *)w.dev, n_bits, flags, default_sel_shift());
+    if (st != SDSL_HIP_OK)
+    {
+        delete bv;
+        return st;
+    }
+    *out = bv;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t t_b,
+                                           uint32_t t_pat_len, uint32_t flags, sdsl_hip_bv_t * out)
+{
+    if (t_pat_len == 1 && t_b <= 1)
+        return sdsl_hip_bv_create(words, n_bits, device, flags, out);
+    int pat = -1; // (previous bit, this bit)
+    if (t_pat_len == 2)
+        pat = t_b == 10 ? 0 : (t_b == 1 ? 1 : (t_b == 0 ? 2 : (t_b == 11 ? 3 : -1)));
+    if (!out || (!words && n_bits) || pat < 0)
+    {
+        set_error("bv_create_pattern: the pattern must be one of <0,1> <1,1> <10,2> <01,2> <00,2> <11,2>");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    sdsl_hip_bv_s * bv = new (std::nothrow) sdsl_hip_bv_s();
+    if (!bv)
+        return SDSL_HIP_ERR_NOMEM;
+    bv->h.device = device;
+    const uint64_t nw = (n_bits + 63) >> 6;
+    Staged w;
+    DevBuf d;
+    sdsl_hip_status st = w.in(words, nw * sizeof(uint64_t), nullptr);
+    if (st == SDSL_HIP_OK)
+        st = d.alloc((nw + 1) * 8, true);
+    if (st == SDSL_HIP_OK && nw)
+    {
+        hipLaunchKernelGGL(k_pattern_words, dim3(grid_for(nw, 256, 65536)), dim3(256), 0, 0, (const uint64_t *)w.dev, n_bits,
+                           nw, pat, d.as<uint64_t>());
+        if (hipGetLastError() != hipSuccess)
+        {
+            set_error("bv_create_pattern: kernel launch failed");
+            st = SDSL_HIP_ERR_HIP;
+        }
+    }
+    if (st == SDSL_HIP_OK)
+        st = bv_build_from_device_words(bv->h, d.as<uint64_t>(), n_bits, flags, default_sel_shift());
     if (st != SDSL_HIP_OK)
     {
         delete bv;

@@ -80,7 +80,9 @@ class bit_vector(_Handle):
     _destroy = "sdsl_hip_bv_destroy"
 
     def __init__(self, words, n_bits: int | None = None, device: int = 0, select1: bool = True,
-                 select0: bool = True):
+                 select0: bool = True, pattern: tuple[int, int] | None = None):
+        """pattern=(t_b, t_pat_len) as in SDSL's templates, e.g. (10, 2): the handle then holds the occurrence vector
+        of that two-bit pattern, and rank(idx, 1) / select(i, 1) answer rank_support_v5<10,2> / select_support_mcl<10,2>"""
         super().__init__()
         w = _as_array(words, np.uint64, "words")
         nw = w.numel() if _is_tensor(w) else w.size
@@ -89,8 +91,11 @@ class bit_vector(_Handle):
         if (n_bits + 63) // 64 > nw:
             raise ValueError("words too short for n_bits")
         flags = (capi.BV_SELECT1 if select1 else 0) | (capi.BV_SELECT0 if select0 else 0)
-        capi.check(capi.lib().sdsl_hip_bv_create(_ptr(w) if nw else None, n_bits, device, flags,
-                                                 C.byref(self._h)))
+        if pattern is None:
+            capi.check(capi.lib().sdsl_hip_bv_create(_ptr(w) if nw else None, n_bits, device, flags, C.byref(self._h)))
+        else:
+            capi.check(capi.lib().sdsl_hip_bv_create_pattern(_ptr(w) if nw else None, n_bits, device, pattern[0],
+                                                             pattern[1], flags, C.byref(self._h)))
         self.device = device
 
     def size(self) -> int:

@@ -101,6 +101,16 @@ def main():
             sio = np.concatenate([si, np.array([tot + 1], dtype=np.uint64)])  # overflow -> size()
             out[f"{name}/rrr_sel{b}_i"] = sio
             out[f"{name}/rrr_sel{b}"] = rr.select(sio, b)
+        if name in ("CRAFTED-32", "CRAFTED-MAT-SELECT", "rnd.8192.1043", "rnd.200000.7", "rnd.1000000.815", "rnd.64.222"):
+            # two-bit pattern supports: rank_support_v5<pat,2> and select_support_mcl<pat,2> of the real library
+            for pat in range(4):
+                out[f"{name}/pat{pat}_rank"] = ol.ref_bv_pattern(w, n, pat, 0, idx)
+                tot = int(ol.ref_bv_pattern(w, n, pat, 1, np.array([n], dtype=np.uint64))[0])
+                si = (queries(1024, tot, 50 + pat) + np.uint64(1)) if tot else np.zeros(0, np.uint64)
+                if tot:
+                    si = np.concatenate([si, np.array([1, tot], dtype=np.uint64)])
+                out[f"{name}/pat{pat}_sel_i"] = si
+                out[f"{name}/pat{pat}_sel"] = ol.ref_bv_pattern(w, n, pat, 2, si) if tot else np.zeros(0, np.uint64)
         out[f"{name}/sha"] = np.array([sha(rb.serialize(1)), sha(rb.serialize(2)), sha(rb.serialize(3)),
                                        sha(rb.serialize(4)), sha(rr.serialize())])
     np.savez_compressed(os.path.join(HERE, "golden_bitvectors.npz"), **out)

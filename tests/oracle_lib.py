@@ -437,6 +437,7 @@ _REF_SIGS = {
     "ref_csa_locate": (_u64, [_vp, _vp, _u64, _vp, _u64]),
     "ref_wt_rrr_serialize": (None, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_csa_rrr_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
+    "ref_bv_pattern": (None, [_vp, _u64, C.c_int, C.c_int, _vp, _u64, _vp]),
     "ref_wt_shape_serialize": (None, [_vp, _u64, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_csa_blcd_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_set_random_bits": (None, [_vp, _u64, C.c_int]),
@@ -470,6 +471,25 @@ def ref_wt_rrr_bytes(text: bytes) -> bytes:
     """wt_huff<rrr_vector<63>>::serialize of the real library"""
     t = _u8arr(np.frombuffer(text, dtype=np.uint8))
     return _ref_bytes(ref().L.ref_wt_rrr_serialize, _p(t) if t.size else None, t.size)
+
+
+def ref_bv_pattern(words, n_bits, pat: int, which: int, q) -> np.ndarray:
+    """real SDSL two-bit pattern supports: pat 0..3 = <10,2> <01,2> <00,2> <11,2>; which 0 = rank_support_v5,
+    1 = rank_support_v, 2 = select_support_mcl"""
+    w = padded(_u64arr(words), n_bits)
+    q = _u64arr(q)
+    out = np.empty(q.size, dtype=np.uint64)
+    ref().L.ref_bv_pattern(_p(w), n_bits, pat, which, _p(q), q.size, _p(out))
+    return out
+
+
+def pattern_bits(bits: np.ndarray, pat: int) -> np.ndarray:
+    """occurrence vector of a two-bit pattern over a 0/1 array (rank_support.hpp:160-284 restated on plain arrays):
+    bit i is set iff (x[i-1], x[i]) is the pattern; the bit in front of position 0 is 0 for 10 and 11, 1 for 01 and 00"""
+    x = bits.astype(np.uint8)
+    prev = np.concatenate([[1 if pat in (1, 2) else 0], x[:-1]]).astype(np.uint8) if x.size else x
+    want_prev, want_cur = [(1, 0), (0, 1), (0, 0), (1, 1)][pat]
+    return ((prev == want_prev) & (x == want_cur)).astype(np.uint8)
 
 
 def ref_wt_shape_bytes(text: bytes, shape: int, flavour: int) -> bytes:

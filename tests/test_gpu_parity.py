@@ -500,6 +500,49 @@ def test_fm_built_on_gpu_serializes_to_sdsl_bytes(gpu, name):
 
 
 # ---------------------------------------------------------------------------------------------------
+# two-bit patterns: rank_support_v5<pat,2> / select_support_mcl<pat,2>
+# ---------------------------------------------------------------------------------------------------
+PATTERNS = [(10, 2), (1, 2), (0, 2), (11, 2)]  # SDSL's template arguments <10,2> <01,2> <00,2> <11,2>
+
+
+@pytest.mark.parametrize("name", ["CRAFTED-32", "CRAFTED-MAT-SELECT", "rnd.64.222", "rnd.8192.1043", "rnd.200000.7",
+                                  "rnd.1000000.815"])
+def test_two_bit_patterns_golden(gpu, name):
+    g = gd.bv_golden()
+    words, n = gd.bv_case(name)
+    idx = g[f"{name}/idx"]
+    for pat, targ in enumerate(PATTERNS):
+        bv = gpu.bit_vector(words, n, select0=False, pattern=targ)
+        assert bv.size() == n
+        assert np.array_equal(bv.rank(idx, 1), g[f"{name}/pat{pat}_rank"])
+        si = g[f"{name}/pat{pat}_sel_i"]
+        if si.size:
+            assert np.array_equal(bv.select(si, 1), g[f"{name}/pat{pat}_sel"])
+            tot = int(si[-1])
+            assert int(bv.select(np.array([tot + 1], dtype=np.uint64), 1)[0]) == int(NPOS)
+
+
+def test_two_bit_patterns_large(gpu):
+    """2^28 bits against the occurrence-vector model (pinned to the real library by the CPU suite)"""
+    n = (1 << 28) + 37
+    words = ol.set_random_bits(n, 99)
+    bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+    rng = np.random.default_rng(1)
+    idx = np.concatenate([rng.integers(0, n + 1, 200000), [0, n, 64, 63, 65]]).astype(np.uint64)
+    for pat, targ in enumerate(PATTERNS):
+        d = ol.pattern_bits(bits, pat)
+        cum = np.concatenate([[0], np.cumsum(d, dtype=np.int64)]).astype(np.uint64)
+        bv = gpu.bit_vector(words, n, select0=False, pattern=targ)
+        assert bv.ones() == int(cum[-1])
+        assert np.array_equal(bv.rank(idx, 1), cum[idx.astype(np.int64)])
+        i = rng.integers(1, int(cum[-1]) + 1, 200000).astype(np.uint64)
+        pos = bv.select(i, 1)
+        assert np.array_equal(bv.rank(pos, 1) + np.uint64(1), i) and bool(np.all(d[pos.astype(np.int64)] == 1))
+    with pytest.raises(gpu.capi.SdslHipError):
+        gpu.bit_vector(words, n, pattern=(12, 2))
+
+
+# ---------------------------------------------------------------------------------------------------
 # other wt_pc shapes: wt_blcd / wt_hutu streams load as they are, wt_blcd can be built on the device
 # ---------------------------------------------------------------------------------------------------
 def _shape_text(name):

@@ -186,3 +186,22 @@ def test_fm_other_densities_same_answers():
     assert a.extract(19000, 20000) == b.extract(19000, 20000) == data[19000:] + b"\0"
     assert np.array_equal(a.sa(a.isa(idx)), idx)
 
+
+@pytest.mark.parametrize("name", [n for n in gd.bv_case_names()])
+def test_two_bit_pattern_model(name):
+    """the occurrence-vector model of rank_support_v5<pat,2> / select_support_mcl<pat,2> against the real library"""
+    g = gd.bv_golden()
+    if f"{name}/pat0_rank" not in g.files:
+        pytest.skip("no pattern vectors for this case")
+    words, n = gd.bv_case(name)
+    bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+    idx = g[f"{name}/idx"]
+    for pat in range(4):
+        d = ol.pattern_bits(bits, pat)
+        cum = np.concatenate([[0], np.cumsum(d)]).astype(np.uint64)
+        assert np.array_equal(cum[idx.astype(np.int64)], g[f"{name}/pat{pat}_rank"])
+        si = g[f"{name}/pat{pat}_sel_i"]
+        if si.size:
+            assert np.array_equal(np.flatnonzero(d)[(si - np.uint64(1)).astype(np.int64)].astype(np.uint64),
+                                  g[f"{name}/pat{pat}_sel"])
+
