@@ -43,7 +43,8 @@ def parse():
     p.add_argument("--log-n", type=int, default=34, help="bit vector length = 2^log_n (BASELINE: 34)")
     p.add_argument("--queries", type=float, default=1e9, help="queries per step per GPU (BASELINE: 1e9)")
     p.add_argument("--extras", type=str, default=None,
-                   help="comma list of: select,rrr,wt,fm (or 'none'); default: all four on one GPU, none on several")
+                   help="comma list of: select,rrr,wt,fm,fm_sharded (or 'none'); default: the first four on one GPU, "
+                        "fm_sharded (configs[4]: 10^8 patterns sharded over the ranks) on several")
     p.add_argument("--text-mib", type=int, default=1024, help="synthetic text size for the wt/fm extras (BASELINE: 1 GiB)")
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     p.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU time budget per cpu_baseline sample")
@@ -207,7 +208,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(42)
     words = torch.randint(-2**63, 2**63 - 1, (n_bits // 64,), device=dev, dtype=torch.int64, generator=g)
     if a.extras is None:
-        a.extras = "select,rrr,wt,fm" if world == 1 else "none"
+        a.extras = "select,rrr,wt,fm" if world == 1 else "fm_sharded"
     extras = [] if a.extras in ("", "none") else a.extras.split(",")
     bv = pkg.bit_vector(words, n_bits, device=local, select1="select" in extras, select0=False)
     gq = torch.Generator(device=dev).manual_seed(7 + rank)
@@ -415,6 +416,57 @@ def main():
                                         "index_bytes": crrr.device_bytes(), "index_build_s": rb}
                 del crrr
 
+        if "fm_sharded" in extras and world > 1:
+            # configs[4]: count() on a 1 GiB text, 10^8 20-byte patterns sharded across the ranks (strong scaling).
+            # The FM-index is replicated (every rank builds it from the same text on its own GPU); (a) resident
+            # shards: every rank answers its slice of the batch, no collective; (b) root-owned batch: rank 0 holds the
+            # whole batch, one scatter + one gather over RCCL/xGMI around the same local call (dist.sharded_query).
+            import torch.distributed as dist
+            torch.cuda.empty_cache()
+            nt = a.text_mib << 20
+            text = synthetic_text(nt, 1234, dev)
+            t0 = time.perf_counter()
+            csa = pkg.csa_wt(text=text, device=local)
+            build = time.perf_counter() - t0
+            csa.drop_sa()
+            m, total = 20, min(int(a.queries) // 10, 100_000_000)
+            gp = torch.Generator(device=dev).manual_seed(99)  # the same batch on every rank; each takes its slice
+            st = torch.randint(0, nt - m, (total,), device=dev, generator=gp)
+            lo, hi = pkg.dist.shard_bounds(total, world, rank)
+            mine = text[(st[lo:hi].view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()
+            res = torch.empty(hi - lo, dtype=torch.int64, device=dev)
+            wall_s, _ = time_steps(lambda: csa.count(mine, m, res), 3, 1, barrier)
+            wall_s = pkg.dist.max_over_ranks(wall_s, comm_dev)
+            ok = bool((res >= 1).all())
+            fs = {"patterns_total": total, "m": m, "text_bytes": nt, "index_build_s": build,
+                  "resident_shards": {"Mcount/s": total * 3 / wall_s / 1e6, "ms_per_batch": wall_s / 3 * 1e3,
+                                      "all_patterns_found": ok, "scaling": "strong"}}
+            # (b) root-owned batch
+            stage = (lambda t: t) if a.backend == "nccl" else (lambda t: t.cpu())
+            if rank == 0:
+                allp = stage(text[(st.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous())
+            else:
+                allp = stage(torch.empty(1, dtype=torch.uint8, device=dev))
+
+            def local_count(p):
+                r = torch.empty(p.numel() // m, dtype=torch.int64, device=dev)
+                csa.count(p.to(dev), m, r)
+                return stage(r)
+
+            full = pkg.dist.sharded_query(local_count, (allp,), total, widths=(m,))  # warm-up + check
+            if rank == 0:
+                fs["root_owned_batch_matches"] = bool(torch.equal(full[lo:hi].to(dev), res))
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            full = pkg.dist.sharded_query(local_count, (allp,), total, widths=(m,))
+            torch.cuda.synchronize()
+            barrier()
+            dt = pkg.dist.max_over_ranks(time.perf_counter() - t0, comm_dev)
+            fs["root_owned_batch"] = {"Mcount/s": total / dt / 1e6, "ms_per_batch": dt * 1e3,
+                                      "collectives": "1 scatter (patterns) + 1 gather (counts)"}
+            ex["fm_count_sharded"] = fs
+            del csa, text
     except Exception as e:  # the secondary measurements must never cost the headline line
         ex["error"] = f"{type(e).__name__}: {e}"
     if ex:

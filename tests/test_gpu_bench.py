@@ -45,3 +45,21 @@ def test_two_ranks_share_the_gpu(gpu):
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert abs(d["value"] - 2 * 1e6 * 2 / (d["ms_per_step"] * 2e-3) / 1e9) < 1e-6 * d["value"] + 1e-9
+
+
+def test_two_ranks_sharded_fm_count(gpu):
+    """configs[4] path of the multi-GPU bench (default extras of an N > 1 run): replicated FM-index, patterns sharded
+    over the ranks — resident shards and a root-owned batch through dist.sharded_query"""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29534", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--log-n", "24", "--queries", "2e6",
+                        "--text-mib", "16", "--backend", "gloo"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    fs = d["extras"]["fm_count_sharded"]
+    assert "error" not in d["extras"], d["extras"]
+    assert fs["patterns_total"] == 200000 and fs["resident_shards"]["all_patterns_found"] is True
+    assert fs["root_owned_batch_matches"] is True
+    assert fs["resident_shards"]["Mcount/s"] > 0 and fs["root_owned_batch"]["Mcount/s"] > 0
+
