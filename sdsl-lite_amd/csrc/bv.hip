@@ -308,7 +308,7 @@ sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words
 // =========================================================================================
 
 // U queries per quad per round: all U line loads are issued before the first is consumed.
-template <int U, bool NT>
+template <int U, bool NT, bool IO_NT = false>
 __global__ __launch_bounds__(kBlock) void k_rank(BvView bv, int bit, const uint64_t * __restrict__ idx,
                                                  uint64_t * __restrict__ out, uint64_t n)
 {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_rank(BvView bv, int bit, const uint6
         for (int u = 0; u < U; ++u)
         {
             uint64_t q = base + (uint64_t)u * kQPB + gq;
-            id[u] = q < n ? idx[q] : 0;
+            id[u] = q < n ? (IO_NT ? __builtin_nontemporal_load(idx + q) : idx[q]) : 0;
             ok[u] = id[u] <= bv.n_bits;
             L[u] = ok[u] ? id[u] / kDB : 0;
         }
@@ -339,7 +339,12 @@ __global__ __launch_bounds__(kBlock) void k_rank(BvView bv, int bit, const uint6
             if (!bit)
                 r = id[u] - r;
             if (s == 0 && q < n)
-                out[q] = ok[u] ? r : SDSL_HIP_NPOS;
+            {
+                if (IO_NT)
+                    __builtin_nontemporal_store(ok[u] ? r : SDSL_HIP_NPOS, out + q);
+                else
+                    out[q] = ok[u] ? r : SDSL_HIP_NPOS;
+            }
         }
     }
 }
@@ -356,7 +361,7 @@ struct RetryEntry
     uint32_t tries, pad;
 };
 
-template <int BIT, bool NT>
+template <int BIT, bool NT, bool IO_NT = false>
 __global__ __launch_bounds__(kBlock) void k_select_rq(BvView bv, const uint64_t * __restrict__ iq,
                                                       uint64_t * __restrict__ out, uint64_t n)
 {
@@ -381,7 +386,12 @@ __global__ __launch_bounds__(kBlock) void k_select_rq(BvView bv, const uint64_t 
         if (sel_eval<BIT>(bv, s, k, W, wa, wb, br, mine, pos))
         {
             if (mine)
-                out[q] = pos;
+            {
+                if (IO_NT)
+                    __builtin_nontemporal_store(pos, out + q);
+                else
+                    out[q] = pos;
+            }
         }
         else if (s == 0)
         {
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void k_select_rq(BvView bv, const uint64_t 
     for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += stride) // block-uniform trip count
     {
         const uint64_t q = base + gq;
-        const uint64_t i = q < n ? iq[q] : 0;
+        const uint64_t i = q < n ? (IO_NT ? __builtin_nontemporal_load(iq + q) : iq[q]) : 0;
         const bool ok = i >= 1 && i <= total; // outside: SDSL's precondition (select_support_mcl.hpp:386)
         if (q < n && !ok && s == 0)
             out[q] = SDSL_HIP_NPOS;
@@ -500,7 +510,13 @@ sdsl_hip_status bv_launch_rank(const BvView & v, int bit, const uint64_t * d_idx
     // (U = 1/2/4/8, nontemporal or not: 36.2-38.8 G/s, profiles/gather_probe_r01.txt)
     constexpr int U = 4;
     KernelTimer t(s);
-    hipLaunchKernelGGL((k_rank<U, false>), dim3(query_grid(n, kQPB * U)), dim3(kBlock), 0, s, v, bit, d_idx, d_out, n);
+    const char * io_env = getenv("SDSL_HIP_RANK_IO_NT"); // experiment knob (profiles/rank_io_nt_r01.txt)
+    const int io_nt = io_env ? atoi(io_env) : 1; // default on: +2.2 % rank, +0.5 % select (same allocation A/B)
+    if (io_nt)
+        hipLaunchKernelGGL((k_rank<U, false, true>), dim3(query_grid(n, kQPB * U)), dim3(kBlock), 0, s, v, bit, d_idx, d_out,
+                           n);
+    else
+        hipLaunchKernelGGL((k_rank<U, false>), dim3(query_grid(n, kQPB * U)), dim3(kBlock), 0, s, v, bit, d_idx, d_out, n);
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }
@@ -516,8 +532,14 @@ sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i
         return SDSL_HIP_ERR_INVALID;
     }
     KernelTimer t(s);
-    if (bit)
+    const char * io_env = getenv("SDSL_HIP_SELECT_IO_NT");
+    const int io_nt = io_env ? atoi(io_env) : 1; // default on: +2.2 % rank, +0.5 % select (same allocation A/B)
+    if (bit && io_nt)
+        hipLaunchKernelGGL((k_select_rq<1, false, true>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
+    else if (bit)
         hipLaunchKernelGGL((k_select_rq<1, false>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
+    else if (io_nt)
+        hipLaunchKernelGGL((k_select_rq<0, false, true>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
     else
         hipLaunchKernelGGL((k_select_rq<0, false>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
     SH_HIP(hipGetLastError());
