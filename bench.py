@@ -232,7 +232,7 @@ def main():
                    "index_bytes_per_gpu": bv.device_bytes()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_rank_bytes_per_launch"),
-                     "kernel": "sdslhip::k_rank<4,false>", "kernel_ms": kernel_ms,
+                     "kernel": "sdslhip::k_rank<4,false,true>", "kernel_ms": kernel_ms,
                      "algorithmic_bytes_per_query": ALG_BYTES["rank"]},
     }
 
