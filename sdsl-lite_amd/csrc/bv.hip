@@ -406,19 +406,35 @@ __global__ __launch_bounds__(kBlock) void k_select_rq(BvView bv, const uint64_t 
         }
     };
 
+    // Software pipeline over the rounds: a query costs three dependent memory accesses (argument -> directory samples
+    // -> window).  The argument is loaded two rounds ahead and the samples one round ahead, so that only the window
+    // fetch is on the critical path of a round.
     const uint64_t stride = (uint64_t)gridDim.x * kQPB;
+    auto load_arg = [&](uint64_t q) -> uint64_t { return q < n ? (IO_NT ? __builtin_nontemporal_load(iq + q) : iq[q]) : 0; };
+    auto arg_ok = [&](uint64_t i) -> bool { return i >= 1 && i <= total; }; // outside: SDSL's precondition (select_support_mcl.hpp:386)
+    const uint64_t q_first = (uint64_t)blockIdx.x * kQPB + gq;
+    uint64_t i_cur = load_arg(q_first), i_nxt = load_arg(q_first + stride);
+    uint64_t j_cur = arg_ok(i_cur) ? (i_cur - 1) >> bv.sel_shift : 0;
+    uint32_t s0_cur = smp[j_cur], s1_cur = smp[j_cur + 1];
     for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += stride) // block-uniform trip count
     {
         const uint64_t q = base + gq;
-        const uint64_t i = q < n ? (IO_NT ? __builtin_nontemporal_load(iq + q) : iq[q]) : 0;
-        const bool ok = i >= 1 && i <= total; // outside: SDSL's precondition (select_support_mcl.hpp:386)
+        const uint64_t i_nn = load_arg(q + 2 * stride);                                 // argument of round r+2
+        const uint64_t j_nxt = arg_ok(i_nxt) ? (i_nxt - 1) >> bv.sel_shift : 0;
+        const uint32_t s0_nxt = smp[j_nxt], s1_nxt = smp[j_nxt + 1];                    // samples of round r+1
+        const uint64_t i = i_cur;
+        const bool ok = arg_ok(i);
         if (q < n && !ok && s == 0)
             out[q] = SDSL_HIP_NPOS;
         if (ok)
         {
-            const uint64_t k = i - 1, j = k >> bv.sel_shift;
-            probe(q, k, sel_bracket<BIT>(bv, k, smp[j], smp[j + 1]), 0u);
+            const uint64_t k = i - 1;
+            probe(q, k, sel_bracket<BIT>(bv, k, s0_cur, s1_cur), 0u);
         }
+        i_cur = i_nxt;
+        i_nxt = i_nn;
+        s0_cur = s0_nxt;
+        s1_cur = s1_nxt;
         __syncthreads();
         unsigned cnt = rq_n;
         __syncthreads(); // everybody has seen the same count before anyone pushes again
@@ -455,6 +471,121 @@ __global__ __launch_bounds__(kBlock) void k_select_rq(BvView bv, const uint64_t 
         __syncthreads();
         cnt = rq_n;
         __syncthreads();
+    }
+}
+
+// The same scheme with one retry queue PER WAVE and no block-level barrier: the 16 quads of a wave are in lock step
+// anyway, so pushing, counting and popping need nothing but the in-order LDS pipeline of that wave.  A round of one
+// wave no longer waits for the slowest window fetch of the other three waves of its block.
+constexpr unsigned kQPW = 64 / kG; // quads (queries in flight) per wave
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int BIT, bool NT>
+__global__ __launch_bounds__(kBlock) void k_select_wq(BvView bv, const uint64_t * __restrict__ iq,
+                                                      uint64_t * __restrict__ out, uint64_t n)
+{
+    constexpr unsigned kWaves = kBlock / 64;
+    __shared__ RetryEntry rq_all[kWaves][2 * kQPW];
+    __shared__ unsigned rq_cnt[kWaves];
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned wave = threadIdx.x / 64, wq = (threadIdx.x & 63) / kG; // quad index inside the wave
+    const unsigned gq = threadIdx.x / kG;
+    RetryEntry * rq = rq_all[wave];
+    unsigned * rq_n = &rq_cnt[wave];
+    const uint64_t total = BIT ? bv.ones : bv.n_bits - bv.ones;
+    const uint32_t * __restrict__ smp = bv.sel[BIT];
+    if ((threadIdx.x & 63) == 0)
+        *rq_n = 0;
+    wave_lds_sync();
+
+    auto probe = [&](uint64_t q, uint64_t k, SelBracket br, uint32_t tries)
+    {
+        const uint64_t W = sel_guess(bv, br, k, (int)tries);
+        Pair wa = load_pair<NT>(bv.lines, 2 * W, s);
+        Pair wb = load_pair<NT>(bv.lines, 2 * W + 1, s);
+        bool mine = false;
+        uint64_t pos = 0;
+        if (sel_eval<BIT>(bv, s, k, W, wa, wb, br, mine, pos))
+        {
+            if (mine)
+                __builtin_nontemporal_store(pos, out + q);
+        }
+        else if (s == 0)
+        {
+            unsigned slot = atomicAdd(rq_n, 1u);
+            RetryEntry e;
+            e.q = q;
+            e.k = k;
+            e.br = br;
+            e.tries = tries + 1;
+            e.pad = 0;
+            rq[slot] = e;
+        }
+    };
+
+    const uint64_t stride = (uint64_t)gridDim.x * kQPB;
+    auto load_arg = [&](uint64_t q) -> uint64_t { return q < n ? __builtin_nontemporal_load(iq + q) : 0; };
+    auto arg_ok = [&](uint64_t i) -> bool { return i >= 1 && i <= total; }; // SDSL's precondition (select_support_mcl.hpp:386)
+    const uint64_t q_first = (uint64_t)blockIdx.x * kQPB + gq;
+    uint64_t i_cur = load_arg(q_first), i_nxt = load_arg(q_first + stride);
+    uint64_t j_cur = arg_ok(i_cur) ? (i_cur - 1) >> bv.sel_shift : 0;
+    uint32_t s0_cur = smp[j_cur], s1_cur = smp[j_cur + 1];
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += stride) // wave-uniform trip count
+    {
+        const uint64_t q = base + gq;
+        const uint64_t i_nn = load_arg(q + 2 * stride);              // argument of round r+2
+        const uint64_t j_nxt = arg_ok(i_nxt) ? (i_nxt - 1) >> bv.sel_shift : 0;
+        const uint32_t s0_nxt = smp[j_nxt], s1_nxt = smp[j_nxt + 1]; // samples of round r+1
+        const uint64_t i = i_cur;
+        const bool ok = arg_ok(i);
+        if (q < n && !ok && s == 0)
+            out[q] = SDSL_HIP_NPOS;
+        if (ok)
+        {
+            const uint64_t k = i - 1;
+            probe(q, k, sel_bracket<BIT>(bv, k, s0_cur, s1_cur), 0u);
+        }
+        i_cur = i_nxt;
+        i_nxt = i_nn;
+        s0_cur = s0_nxt;
+        s1_cur = s1_nxt;
+        wave_lds_sync();
+        unsigned cnt = *rq_n;
+        while (cnt >= kQPW)
+        { // a full wave's worth of parked queries: spend one round on them
+            RetryEntry e = rq[cnt - kQPW + wq];
+            wave_lds_sync();
+            if ((threadIdx.x & 63) == 0)
+                *rq_n = cnt - kQPW;
+            wave_lds_sync();
+            probe(e.q, e.k, e.br, e.tries);
+            wave_lds_sync();
+            cnt = *rq_n;
+        }
+    }
+    // drain what is left
+    wave_lds_sync();
+    unsigned cnt = *rq_n;
+    while (cnt > 0)
+    {
+        const unsigned take = cnt < kQPW ? cnt : kQPW;
+        const bool act = wq < take;
+        RetryEntry e{};
+        if (act)
+            e = rq[cnt - take + wq];
+        wave_lds_sync();
+        if ((threadIdx.x & 63) == 0)
+            *rq_n = cnt - take;
+        wave_lds_sync();
+        if (act)
+            probe(e.q, e.k, e.br, e.tries);
+        wave_lds_sync();
+        cnt = *rq_n;
     }
 }
 
@@ -534,7 +665,13 @@ sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i
     KernelTimer t(s);
     const char * io_env = getenv("SDSL_HIP_SELECT_IO_NT");
     const int io_nt = io_env ? atoi(io_env) : 1; // default on: +2.2 % rank, +0.5 % select (same allocation A/B)
-    if (bit && io_nt)
+    const char * var_env = getenv("SDSL_HIP_SELECT_VARIANT"); // "wq" (default): per-wave retry queues; "rq": per-block
+    const bool wave_queues = !(var_env && var_env[0] == 'r');
+    if (wave_queues && bit)
+        hipLaunchKernelGGL((k_select_wq<1, false>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
+    else if (wave_queues)
+        hipLaunchKernelGGL((k_select_wq<0, false>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
+    else if (bit && io_nt)
         hipLaunchKernelGGL((k_select_rq<1, false, true>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);
     else if (bit)
         hipLaunchKernelGGL((k_select_rq<1, false>), dim3(query_grid(n, kQPB)), dim3(kBlock), 0, s, v, d_i, d_out, n);

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, cons
     rrr_stage_tables(&T, v.tables);
     for (uint64_t q = (uint64_t)blockIdx.x * kRrrBlock + threadIdx.x; q < n; q += (uint64_t)gridDim.x * kRrrBlock)
     {
-        const uint64_t i = iq[q];
+        const uint64_t i = __builtin_nontemporal_load(iq + q);
         const bool ok = MODE == 0 ? i <= v.n_bits : i < v.n_bits;
         if (MODE == 1)
         {
@@ -169,15 +169,33 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint6
     __shared__ RrrTables T;
     rrr_stage_tables(&T, v.tables);
     const uint64_t total = BIT ? v.ones : v.n_bits - v.ones;
-    for (uint64_t q = (uint64_t)blockIdx.x * kRrrBlock + threadIdx.x; q < n; q += (uint64_t)gridDim.x * kRrrBlock)
+    // Software pipeline over the lane's queries: a select is a chain of dependent accesses (argument -> directory
+    // samples -> record probe(s) -> offset field).  The argument is loaded two queries ahead and the samples one query
+    // ahead, which takes two memory latencies off the chain.
+    const uint64_t stride = (uint64_t)gridDim.x * kRrrBlock;
+    const uint32_t * __restrict__ smp = v.sel[BIT];
+    auto load_arg = [&](uint64_t q) -> uint64_t { return q < n ? __builtin_nontemporal_load(iq + q) : 0; };
+    auto arg_ok = [&](uint64_t i) -> bool { return i >= 1 && i <= total; };
+    uint64_t q = (uint64_t)blockIdx.x * kRrrBlock + threadIdx.x;
+    uint64_t i_cur = load_arg(q), i_nxt = load_arg(q + stride);
+    uint64_t j_cur = arg_ok(i_cur) ? (i_cur - 1) >> v.sel_shift[BIT] : 0;
+    uint32_t s0_cur = smp[j_cur], s1_cur = smp[j_cur + 1];
+    for (; q < n; q += stride)
     {
-        const uint64_t i = iq[q];
+        const uint64_t i_nn = load_arg(q + 2 * stride);
+        const uint64_t j_nxt = arg_ok(i_nxt) ? (i_nxt - 1) >> v.sel_shift[BIT] : 0;
+        const uint32_t s0_nxt = smp[j_nxt], s1_nxt = smp[j_nxt + 1];
+        const uint64_t i = i_cur;
         uint64_t r;
-        if (i >= 1 && i <= total)
-            r = rrr_select<BIT>(v, &T, i - 1);
+        if (arg_ok(i))
+            r = rrr_select<BIT>(v, &T, i - 1, s0_cur, s1_cur);
         else // i > #args: SDSL returns size() (rrr_vector.hpp:641-642, 686-689); i == 0 is outside its domain
             r = i == 0 ? SDSL_HIP_NPOS : v.n_bits;
-        out[q] = r;
+        __builtin_nontemporal_store(r, out + q);
+        i_cur = i_nxt;
+        i_nxt = i_nn;
+        s0_cur = s0_nxt;
+        s1_cur = s1_nxt;
     }
 }
 
@@ -244,19 +262,19 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
                                                          uint64_t n_blocks, uint64_t n_sb,
                                                          const RrrTables * __restrict__ tables, uint64_t * __restrict__ rec,
                                                          const uint32_t * __restrict__ sb_ones,
-                                                         unsigned long long * __restrict__ stream, uint32_t sh, uint32_t ps,
+                                                         unsigned long long * __restrict__ stream, uint32_t sh1, uint32_t sh0, uint32_t ps,
                                                          uint32_t * __restrict__ sel1, uint32_t * __restrict__ sel0)
 {
     __shared__ RrrTables T;
     rrr_stage_tables(&T, tables);
-    const uint64_t S = UINT64_C(1) << sh;
+    const uint64_t S1 = UINT64_C(1) << sh1, S0 = UINT64_C(1) << sh0;
     for (uint64_t sb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sb < n_sb; sb += (uint64_t)gridDim.x * blockDim.x)
     {
         uint64_t * r = rec + sb * kRecWords;
         const uint64_t ones_before = r[0], ptr = r[1];
         const uint64_t start = sb * kRrrSB;
         uint64_t acc1 = ones_before, acc0 = start - ones_before; // arguments before the current block
-        uint64_t j1 = (acc1 + S - 1) >> sh, j0 = (acc0 + S - 1) >> sh;
+        uint64_t j1 = (acc1 + S1 - 1) >> sh1, j0 = (acc0 + S0 - 1) >> sh0;
         uint64_t inl[kInlineWords] = {};
         unsigned rel = 0;
         for (unsigned j = 0; j < kRrrK; ++j)
@@ -295,15 +313,15 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
             }
             rel += len;
             // select samples that fall into this block
-            while ((j1 << sh) < acc1 + k)
+            while ((j1 << sh1) < acc1 + k)
             {
-                sel1[j1] = (uint32_t)((bstart + sel64(bits, (unsigned)((j1 << sh) - acc1) + 1)) >> ps);
+                sel1[j1] = (uint32_t)((bstart + sel64(bits, (unsigned)((j1 << sh1) - acc1) + 1)) >> ps);
                 ++j1;
             }
             const uint64_t zb = ~bits & lo_set(blen);
-            while ((j0 << sh) < acc0 + (blen - k))
+            while ((j0 << sh0) < acc0 + (blen - k))
             {
-                sel0[j0] = (uint32_t)((bstart + sel64(zb, (unsigned)((j0 << sh) - acc0) + 1)) >> ps);
+                sel0[j0] = (uint32_t)((bstart + sel64(zb, (unsigned)((j0 << sh0) - acc0) + 1)) >> ps);
                 ++j0;
             }
             acc1 += k;
@@ -338,6 +356,30 @@ static uint64_t decode_block_host(const RrrTables & T, unsigned k, uint64_t nr)
     return bits;
 }
 
+// Sampling rates of the two select directories, per bit value: the smallest power of two >= 256 that keeps the
+// directory within 2^16 samples (256 KiB: resident in every L2 next to the streaming traffic).  A superblock spans
+// 2016 bits, so even a coarse directory interpolates to the right record or its neighbour; what a denser directory
+// saves in probes it loses in fabric requests for the samples (2^34 bits at 5 % density: select_0 16.0 -> 20.9 Gq/s
+// going from 2^21 to 2^15 samples, select_1 best at 2^16; profiles/rrr_select_sweep_r01.txt).
+// SDSL_HIP_RRR_SEL_LOG2 overrides the rate of both (profiling).
+static void rrr_sel_shifts(uint64_t ones, uint64_t zeros, uint32_t shb[2])
+{
+    const uint64_t cnt[2] = {zeros, ones};
+    for (int b = 0; b < 2; ++b)
+    {
+        uint32_t sh = 8;
+        while (sh < 24 && (cnt[b] >> sh) > (UINT64_C(1) << 16))
+            ++sh;
+        shb[b] = sh;
+    }
+    if (const char * e = getenv("SDSL_HIP_RRR_SEL_LOG2"))
+    {
+        int v = atoi(e);
+        if (v >= 6 && v <= 24)
+            shb[0] = shb[1] = (uint32_t)v;
+    }
+}
+
 static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
 {
     h.device = device;
@@ -350,14 +392,12 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     std::vector<uint64_t> rec((size_t)A.n_sb * kRecWords, 0);
     const uint64_t zeros = A.n_bits - A.ones;
     // sampling rate: smallest power of two >= 256 that keeps a directory within 2^21 samples
-    uint32_t sh = 8;
-    while (sh < 20 && (std::max(A.ones, zeros) >> sh) > (UINT64_C(1) << 21))
-        ++sh;
+    uint32_t shb[2];
+    rrr_sel_shifts(A.ones, zeros, shb);
     uint32_t ps = 0;
     while ((A.n_bits >> ps) >= UINT64_C(0xFFFFFFFF))
         ++ps;
-    const uint64_t S = UINT64_C(1) << sh;
-    const uint64_t ns1 = (A.ones + S - 1) >> sh, ns0 = (zeros + S - 1) >> sh;
+    const uint64_t ns1 = (A.ones + (UINT64_C(1) << shb[1]) - 1) >> shb[1], ns0 = (zeros + (UINT64_C(1) << shb[0]) - 1) >> shb[0];
     std::vector<uint32_t> sel1(ns1 + 2, 0), sel0(ns0 + 2, 0);
     auto fill = [&](uint64_t s0, uint64_t s1)
     {
@@ -398,6 +438,8 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
             uint64_t c[2] = {len_in - ones_in, ones_in};
             for (int b = 0; b < 2; ++b)
             {
+                const uint32_t sh = shb[b];
+                const uint64_t S = UINT64_C(1) << sh;
                 uint64_t jj = (h[b] + S - 1) >> sh;
                 if (c[b] == 0 || (jj << sh) >= h[b] + c[b])
                     continue;
@@ -461,7 +503,8 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     h.view.n_blocks = A.n_blocks;
     h.view.n_sb = A.n_sb;
     h.view.ones = A.ones;
-    h.view.sel_shift = sh;
+    h.view.sel_shift[0] = shb[0];
+    h.view.sel_shift[1] = shb[1];
     h.view.sel_pshift = ps;
     return SDSL_HIP_OK;
 }
@@ -510,19 +553,18 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
     const uint64_t zeros = n_bits - ones;
-    uint32_t sh = 8; // smallest power of two >= 256 that keeps a directory within 2^21 samples
-    while (sh < 20 && (std::max(ones, zeros) >> sh) > (UINT64_C(1) << 21))
-        ++sh;
+    uint32_t shb[2];
+    rrr_sel_shifts(ones, zeros, shb);
     uint32_t ps = 0;
     while ((n_bits >> ps) >= UINT64_C(0xFFFFFFFF))
         ++ps;
-    const uint64_t ns1 = (ones + (UINT64_C(1) << sh) - 1) >> sh, ns0 = (zeros + (UINT64_C(1) << sh) - 1) >> sh;
+    const uint64_t ns1 = (ones + (UINT64_C(1) << shb[1]) - 1) >> shb[1], ns0 = (zeros + (UINT64_C(1) << shb[0]) - 1) >> shb[0];
     SH_TRY(h.stream.alloc((((std::max<uint64_t>(stream_bits, 64) + 63) >> 6) + 2) * 8, true));
     SH_TRY(h.sel[1].alloc((ns1 + 2) * 4, true));
     SH_TRY(h.sel[0].alloc((ns0 + 2) * 4, true));
     hipLaunchKernelGGL(k_rrr_enc_offsets, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
                        h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(),
-                       h.stream.as<unsigned long long>(), sh, ps, h.sel[1].as<uint32_t>(), h.sel[0].as<uint32_t>());
+                       h.stream.as<unsigned long long>(), shb[1], shb[0], ps, h.sel[1].as<uint32_t>(), h.sel[0].as<uint32_t>());
     SH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_rrr_set_sentinels, dim3(1), dim3(1), 0, 0, h.sel[1].as<uint32_t>(), ns1, h.sel[0].as<uint32_t>(),
                        ns0, (uint32_t)(n_bits >> ps));
@@ -537,7 +579,8 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
     h.view.n_blocks = n_blocks;
     h.view.n_sb = n_sb;
     h.view.ones = ones;
-    h.view.sel_shift = sh;
+    h.view.sel_shift[0] = shb[0];
+    h.view.sel_shift[1] = shb[1];
     h.view.sel_pshift = ps;
     return SDSL_HIP_OK;
 }

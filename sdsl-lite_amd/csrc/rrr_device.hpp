@@ -18,7 +18,10 @@ constexpr unsigned kRrrBlock = 512; // threads per block (LDS holds the 32 KiB b
 
 struct RrrTables
 {
-    uint64_t binom[64][64]; // binom[m][k] = C(m, k), m,k in [0,63]
+    // binom[m][k] = C(m, k), m,k in [0,63].  Rows are padded to 65 entries: with a stride of 64 the LDS bank of an
+    // entry would depend on k alone, and the lanes of a wave decoding blocks of the same (small) class at different
+    // rows m — the normal case of the sparse decoder — would all collide (77 % of the LDS cycles were bank conflicts).
+    uint64_t binom[64][65];
     uint8_t space[64];      // bits of an offset field for class k: hi(C(63,k))+1, 0 if C == 1
 };
 
@@ -29,7 +32,7 @@ struct RrrView
     const RrrTables * tables;
     const uint32_t * sel[2]; // select directories: (position of the j<<shift-th argument) >> pshift, + sentinel
     uint64_t n_bits, n_blocks, n_sb, ones;
-    uint32_t sel_shift;  // log2 of the select sampling rate
+    uint32_t sel_shift[2]; // log2 of the select sampling rate, per bit value (the rarer value gets the denser samples)
     uint32_t sel_pshift; // position quantisation of the samples (0 for n_bits < 2^32)
 };
 
@@ -240,14 +243,16 @@ __device__ __forceinline__ void rrr_rank2(const RrrView & v, const RrrTables * T
 // (directory of argument POSITIONS, interpolated probe, exact counts from the probed header, bisection every second
 // late probe — the scheme of bv_device.hpp), then the prefix word picks the group of 8 blocks, byte arithmetic on
 // ONE class word the block, and the decoded block the bit.
+// smp0 / smp1: the directory samples sel[BIT][k0 >> sel_shift] and the next one (callers may load them ahead of time)
 template <int BIT>
-__device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTables * T, uint64_t k0)
+__device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTables * T, uint64_t k0, uint32_t smp0,
+                                               uint32_t smp1)
 {
     const uint64_t total = BIT ? v.ones : v.n_bits - v.ones;
-    const uint32_t sh = v.sel_shift, ps = v.sel_pshift;
+    const uint32_t sh = v.sel_shift[BIT], ps = v.sel_pshift;
     const uint64_t js = k0 >> sh;
-    uint64_t lo_pos = (uint64_t)v.sel[BIT][js] << ps, lo_cnt = js << sh;
-    uint64_t hi_pos = ((uint64_t)v.sel[BIT][js + 1] + 1) << ps, hi_cnt = (js + 1) << sh;
+    uint64_t lo_pos = (uint64_t)smp0 << ps, lo_cnt = js << sh;
+    uint64_t hi_pos = ((uint64_t)smp1 + 1) << ps, hi_cnt = (js + 1) << sh;
     if (hi_cnt > total)
         hi_cnt = total;
     const uint64_t * r;
@@ -354,6 +359,13 @@ __device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTable
         bits = ~bits & lo_set(blen);
     }
     return bstart + sel64(bits, want + 1);
+}
+
+template <int BIT>
+__device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTables * T, uint64_t k0)
+{
+    const uint64_t js = k0 >> v.sel_shift[BIT];
+    return rrr_select<BIT>(v, T, k0, v.sel[BIT][js], v.sel[BIT][js + 1]);
 }
 
 } // namespace sdslhip

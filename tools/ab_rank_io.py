@@ -11,7 +11,7 @@ del words
 idx = torch.randint(0, n + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
 out = torch.empty_like(idx)
 pkg.set_timing(True)
-for rnd in range(4):
+for rnd in range(1):
     for v in ("0", "1"):
         os.environ["SDSL_HIP_RANK_IO_NT"] = v
         ts = []
@@ -21,9 +21,9 @@ for rnd in range(4):
 
 i1 = torch.randint(1, bv.ones() + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
 for rnd in range(3):
-    for v in ("0", "1"):
-        os.environ["SDSL_HIP_SELECT_IO_NT"] = v
+    for v in ("rq", "wq"):
+        os.environ["SDSL_HIP_SELECT_VARIANT"] = v
         ts = []
         for _ in range(4):
             bv.select(i1, 1, out); ts.append(pkg.last_kernel_ms())
-        print(f"select round {rnd} io_nt={v}: min {min(ts):.3f} ms  {nq/min(ts)/1e6:.2f} Gq/s")
+        print(f"select round {rnd} variant={v}: min {min(ts):.3f} ms  {nq/min(ts)/1e6:.2f} Gq/s")
