@@ -266,6 +266,30 @@ sdsl_hip_status sdsl_hip_fm_locate_batch(sdsl_hip_fm_t fm, const uint8_t * patte
                                          uint64_t * out_offsets, uint64_t * out_pos, uint64_t cap, uint64_t * total,
                                          void * stream);
 
+/* ---- sd_vector<>: Elias-Fano coded sparse bit vector ---------------------------------------
+ * Replaces: sd_vector<>::operator[] (sd_vector.hpp:328-349), rank_support_sd<b>::rank (:553-575),
+ *           select_support_sd<b>::select (:621-664).
+ * create: the ones of a plain bit vector (sd_vector(bit_vector const&), :217-257); create_from_positions: a strictly
+ * increasing position list with an explicit size (the builder / iterator constructors, :259-324);
+ * create_from_sdsl: sd_vector<>::serialize bytes (:435-445).  Out-of-domain arguments give SDSL_HIP_NPOS / 0xFF.
+ * select_0 follows the reference's binary search over select_1 (O(log m) probes per query). */
+typedef struct sdsl_hip_sd_s * sdsl_hip_sd_t;
+sdsl_hip_status sdsl_hip_sd_create(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_sd_t * out);
+sdsl_hip_status sdsl_hip_sd_create_from_positions(const uint64_t * positions, uint64_t m, uint64_t n_bits, int32_t device,
+                                                  sdsl_hip_sd_t * out);
+sdsl_hip_status sdsl_hip_sd_create_from_sdsl(const void * bytes, size_t len, int32_t device, sdsl_hip_sd_t * out,
+                                             size_t * consumed);
+sdsl_hip_status sdsl_hip_sd_destroy(sdsl_hip_sd_t v);
+uint64_t sdsl_hip_sd_size(sdsl_hip_sd_t v);
+uint64_t sdsl_hip_sd_ones(sdsl_hip_sd_t v);
+uint32_t sdsl_hip_sd_low_width(sdsl_hip_sd_t v); /* sd_vector::wl */
+uint64_t sdsl_hip_sd_device_bytes(sdsl_hip_sd_t v);
+sdsl_hip_status sdsl_hip_sd_rank_batch(sdsl_hip_sd_t v, int32_t bit, const uint64_t * idx, uint64_t n, uint64_t * out,
+                                       void * stream);
+sdsl_hip_status sdsl_hip_sd_select_batch(sdsl_hip_sd_t v, int32_t bit, const uint64_t * i, uint64_t n, uint64_t * out,
+                                         void * stream);
+sdsl_hip_status sdsl_hip_sd_access_batch(sdsl_hip_sd_t v, const uint64_t * idx, uint64_t n, uint8_t * out, void * stream);
+
 /* ---- measurement hooks -------------------------------------------------------------------
  * Duration (ms) of the most recent kernel launched by a *_batch call on this handle's device,
  * measured with hipEvents recorded on the launch stream.  Timing is off by default because

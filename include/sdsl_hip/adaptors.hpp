@@ -386,6 +386,142 @@ public:
     }
 };
 
+//! Device image of an sd_vector<> (sd_vector.hpp:134), built from the host object's own serialised arrays, from a
+//! plain bit_vector or from a sorted position list; rank_support_sd / select_support_sd members in batch form.
+class sd_vector_hip
+{
+public:
+    typedef uint64_t size_type;
+    typedef sd_vector<> host_type;
+
+private:
+    struct deleter
+    {
+        void operator()(sdsl_hip_sd_s * p) const
+        {
+            sdsl_hip_sd_destroy(p);
+        }
+    };
+    std::shared_ptr<sdsl_hip_sd_s> m_dev;
+
+public:
+    sd_vector_hip() = default;
+    explicit sd_vector_hip(host_type const & v, int device = 0)
+    {
+        std::string s = hip_detail::to_stream(v);
+        sdsl_hip_sd_t h = nullptr;
+        hip_detail::check(sdsl_hip_sd_create_from_sdsl(s.data(), s.size(), device, &h, nullptr), "sdsl_hip_sd_create_from_sdsl");
+        m_dev.reset(h, deleter());
+    }
+    explicit sd_vector_hip(bit_vector const & bv, int device = 0)
+    {
+        sdsl_hip_sd_t h = nullptr;
+        hip_detail::check(sdsl_hip_sd_create(bv.data(), bv.bit_size(), device, &h), "sdsl_hip_sd_create");
+        m_dev.reset(h, deleter());
+    }
+    //! strictly increasing positions of the ones and the size of the vector (sd_vector_builder's arguments)
+    sd_vector_hip(uint64_t const * positions, size_t m, size_type n, int device = 0)
+    {
+        sdsl_hip_sd_t h = nullptr;
+        hip_detail::check(sdsl_hip_sd_create_from_positions(positions, m, n, device, &h), "sdsl_hip_sd_create_from_positions");
+        m_dev.reset(h, deleter());
+    }
+    size_type size() const
+    {
+        return sdsl_hip_sd_size(m_dev.get());
+    }
+    template <uint8_t t_b>
+    void rank_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_sd_rank_batch(m_dev.get(), t_b, i, n, out, stream), "sdsl_hip_sd_rank_batch");
+    }
+    template <uint8_t t_b>
+    void select_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_sd_select_batch(m_dev.get(), t_b, i, n, out, stream), "sdsl_hip_sd_select_batch");
+    }
+    void access_batch(size_type const * i, size_t n, uint8_t * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_sd_access_batch(m_dev.get(), i, n, out, stream), "sdsl_hip_sd_access_batch");
+    }
+    bool operator[](size_type i) const
+    {
+        uint8_t b = 0;
+        access_batch(&i, 1, &b);
+        return b != 0;
+    }
+};
+
+//! rank_support_sd<t_b> look-alike (sd_vector.hpp:527) over an sd_vector_hip
+template <uint8_t t_b = 1>
+class rank_support_sd_hip
+{
+    sd_vector_hip const * m_v;
+
+public:
+    typedef sd_vector_hip bit_vector_type;
+    typedef sd_vector_hip::size_type size_type;
+    explicit rank_support_sd_hip(sd_vector_hip const * v = nullptr) : m_v(v)
+    {}
+    size_type rank(size_type i) const
+    {
+        size_type r = 0;
+        m_v->rank_batch<t_b>(&i, 1, &r);
+        return r;
+    }
+    size_type operator()(size_type i) const
+    {
+        return rank(i);
+    }
+    void rank_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        m_v->rank_batch<t_b>(i, n, out, stream);
+    }
+    size_type size() const
+    {
+        return m_v->size();
+    }
+    void set_vector(sd_vector_hip const * v = nullptr)
+    {
+        m_v = v;
+    }
+};
+
+//! select_support_sd<t_b> look-alike (sd_vector.hpp:676)
+template <uint8_t t_b = 1>
+class select_support_sd_hip
+{
+    sd_vector_hip const * m_v;
+
+public:
+    typedef sd_vector_hip bit_vector_type;
+    typedef sd_vector_hip::size_type size_type;
+    explicit select_support_sd_hip(sd_vector_hip const * v = nullptr) : m_v(v)
+    {}
+    size_type select(size_type i) const
+    {
+        size_type r = 0;
+        m_v->select_batch<t_b>(&i, 1, &r);
+        return r;
+    }
+    size_type operator()(size_type i) const
+    {
+        return select(i);
+    }
+    void select_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        m_v->select_batch<t_b>(i, n, out, stream);
+    }
+    size_type size() const
+    {
+        return m_v->size();
+    }
+    void set_vector(sd_vector_hip const * v = nullptr)
+    {
+        m_v = v;
+    }
+};
+
 //! Device image of a byte wavelet tree of the wt_pc family (wt_huff / wt_blcd / wt_hutu share wt_pc's layout,
 //! wt_pc.hpp:53-59), built from the host object's serialised form.  `layout` names the host type's bit vector and
 //! select supports: SDSL_HIP_LAYOUT_BV_SCAN (0: bit_vector + rank_support_v5 + select_support_scan, zero bytes),

@@ -615,6 +615,206 @@ size_t orc_select_mcl_serialize(const orc_select_mcl * s, orc_buf * out)
 }
 
 /* ======================================================================================== */
+/* sd_vector<> (Elias-Fano)                                                                 */
+/* ======================================================================================== */
+
+struct orc_sd
+{
+    uint64_t size;      /* length of the original bit vector */
+    uint8_t wl;         /* width of the low parts */
+    iv low;             /* m entries of wl bits */
+    uint64_t * high;    /* m ones, 2^logm zeros */
+    uint64_t high_bits;
+    orc_select_mcl *sel1, *sel0; /* select supports of high */
+};
+
+/* the common tail of the constructors (sd_vector.hpp:223-231,271-279): widths and empty arrays */
+static orc_sd * sd_alloc(uint64_t size, uint64_t m)
+{
+    orc_sd * v = (orc_sd *)calloc(1, sizeof *v);
+    v->size = size;
+    uint8_t logm = (uint8_t)(orc_hi(m) + 1), logn = (uint8_t)(orc_hi(size) + 1);
+    if (logm == logn)
+        --logm; /* to ensure logn - logm > 0 */
+    v->wl = (uint8_t)(logn - logm);
+    v->low = iv_make(m, v->wl);
+    v->high_bits = m + (UINT64_C(1) << logm);
+    v->high = (uint64_t *)calloc(((v->high_bits + 63) >> 6) + 2, 8);
+    return v;
+}
+static void sd_init_supports(orc_sd * v)
+{
+    v->sel1 = orc_select_mcl_build(v->high, v->high_bits, 1);
+    v->sel0 = orc_select_mcl_build(v->high, v->high_bits, 0);
+}
+
+/* sd_vector(bit_vector const&) sd_vector.hpp:217-257 */
+orc_sd * orc_sd_build(const uint64_t * words, uint64_t n_bits)
+{
+    uint64_t m = cnt_one_bits(words, n_bits);
+    orc_sd * v = sd_alloc(n_bits, m);
+    uint64_t mm = 0, last_high = 0, highpos = 0;
+    for (uint64_t i = 0; i < n_bits; ++i)
+    {
+        if (!bv_get(words, i))
+            continue;
+        uint64_t cur_high = i >> v->wl;
+        highpos += cur_high - last_high; /* write cur_high - last_high zeros */
+        last_high = cur_high;
+        iv_set(&v->low, mm++, i & lo_set(v->wl)); /* int_vector truncates the most significant bits */
+        v->high[highpos >> 6] |= UINT64_C(1) << (highpos & 63);
+        ++highpos;
+    }
+    sd_init_supports(v);
+    return v;
+}
+
+/* sd_vector(begin, end) sd_vector.hpp:259-305: size = last position + 1; an empty list gives an empty vector */
+orc_sd * orc_sd_build_from_positions(const uint64_t * pos, uint64_t m)
+{
+    if (m == 0)
+    {
+        orc_sd * v = (orc_sd *)calloc(1, sizeof *v);
+        v->low = iv_empty();
+        v->high = (uint64_t *)calloc(2, 8);
+        sd_init_supports(v);
+        return v;
+    }
+    orc_sd * v = sd_alloc(pos[m - 1] + 1, m);
+    uint64_t last_high = 0, highpos = 0;
+    for (uint64_t mm = 0; mm < m; ++mm)
+    {
+        uint64_t cur_high = pos[mm] >> v->wl;
+        highpos += cur_high - last_high;
+        last_high = cur_high;
+        iv_set(&v->low, mm, pos[mm] & lo_set(v->wl));
+        v->high[highpos >> 6] |= UINT64_C(1) << (highpos & 63);
+        ++highpos;
+    }
+    sd_init_supports(v);
+    return v;
+}
+
+void orc_sd_free(orc_sd * v)
+{
+    if (!v)
+        return;
+    iv_free(&v->low);
+    free(v->high);
+    orc_select_mcl_free(v->sel1);
+    orc_select_mcl_free(v->sel0);
+    free(v);
+}
+uint64_t orc_sd_size(const orc_sd * v)
+{
+    return v->size;
+}
+uint64_t orc_sd_ones(const orc_sd * v)
+{
+    return v->low.size;
+}
+uint32_t orc_sd_wl(const orc_sd * v)
+{
+    return v->wl;
+}
+
+/* sd_vector::operator[] sd_vector.hpp:328-349 */
+int orc_sd_access(const orc_sd * v, uint64_t i)
+{
+    uint64_t high_val = i >> v->wl;
+    uint64_t sel_high = orc_select_mcl_select(v->sel0, high_val + 1);
+    uint64_t rank_low = sel_high - high_val;
+    if (rank_low == 0)
+        return 0;
+    uint64_t val_low = i & lo_set(v->wl);
+    --sel_high;
+    --rank_low;
+    while (bv_get(v->high, sel_high) && iv_get(&v->low, rank_low) > val_low)
+    {
+        if (sel_high > 0)
+        {
+            --sel_high;
+            --rank_low;
+        }
+        else
+            return 0;
+    }
+    return bv_get(v->high, sel_high) && iv_get(&v->low, rank_low) == val_low;
+}
+
+/* rank_support_sd<b>::rank sd_vector.hpp:553-575 (+ adjust_rank :505-517) */
+uint64_t orc_sd_rank(const orc_sd * v, uint64_t i, int bit)
+{
+    uint64_t r1;
+    uint64_t high_val = i >> v->wl;
+    uint64_t sel_high = orc_select_mcl_select(v->sel0, high_val + 1);
+    uint64_t rank_low = sel_high - high_val;
+    if (rank_low == 0)
+        r1 = 0;
+    else
+    {
+        uint64_t val_low = i & lo_set(v->wl);
+        r1 = UINT64_MAX;
+        do
+        {
+            if (!sel_high)
+            {
+                r1 = 0;
+                break;
+            }
+            --sel_high;
+            --rank_low;
+        }
+        while (bv_get(v->high, sel_high) && iv_get(&v->low, rank_low) >= val_low);
+        if (r1 == UINT64_MAX)
+            r1 = rank_low + 1;
+    }
+    return bit ? r1 : i - r1;
+}
+
+/* select_support_sd_trait<1>::select sd_vector.hpp:621-631 */
+static uint64_t sd_select1(const orc_sd * v, uint64_t i)
+{
+    return iv_get(&v->low, i - 1) + ((orc_select_mcl_select(v->sel1, i) + 1 - i) << v->wl);
+}
+/* select_support_sd_trait<0>::select sd_vector.hpp:633-664 */
+uint64_t orc_sd_select(const orc_sd * v, uint64_t i, int bit)
+{
+    if (bit)
+        return sd_select1(v, i);
+    uint64_t ones = v->low.size;
+    uint64_t lb = 1, rb = ones + 1, r0 = 0, pos = UINT64_MAX;
+    while (lb < rb)
+    {
+        uint64_t mid = lb + (rb - lb) / 2;
+        uint64_t x = sd_select1(v, mid);
+        uint64_t rank0 = x + 1 - mid;
+        if (rank0 >= i)
+            rb = mid;
+        else
+        {
+            r0 = rank0;
+            pos = x;
+            lb = mid + 1;
+        }
+    }
+    return pos + i - r0;
+}
+
+/* sd_vector::serialize sd_vector.hpp:435-445: size, wl, low, high, high_1_select, high_0_select */
+size_t orc_sd_serialize(const orc_sd * v, orc_buf * out)
+{
+    size_t w = 9;
+    buf_u64(out, v->size);
+    buf_put(out, &v->wl, 1);
+    w += iv_serialize(&v->low, out);
+    w += words_serialize(v->high, v->high_bits, 1, out);
+    w += orc_select_mcl_serialize(v->sel1, out);
+    w += orc_select_mcl_serialize(v->sel0, out);
+    return w;
+}
+
+/* ======================================================================================== */
 /* rrr_vector<63, int_vector<>, 32>                                                         */
 /* ======================================================================================== */
 

@@ -56,6 +56,19 @@ void orc_select_mcl_batch(const orc_select_mcl *, const uint64_t * i, uint64_t n
 size_t orc_select_mcl_serialize(const orc_select_mcl *, orc_buf * out); /* select_support_mcl.hpp:474-518 */
 
 /* ---- rrr_vector<63, int_vector<>, 32> --------------------------------------------------- */
+/* ---- sd_vector<> ------------------------------------------------------------------------- */
+typedef struct orc_sd orc_sd;
+orc_sd * orc_sd_build(const uint64_t * words, uint64_t n_bits);              /* sd_vector.hpp:217-257 */
+orc_sd * orc_sd_build_from_positions(const uint64_t * pos, uint64_t m);      /* sd_vector.hpp:259-305 */
+void orc_sd_free(orc_sd *);
+uint64_t orc_sd_size(const orc_sd *);
+uint64_t orc_sd_ones(const orc_sd *);
+uint32_t orc_sd_wl(const orc_sd *);
+int orc_sd_access(const orc_sd *, uint64_t i);                /* sd_vector.hpp:328-349 */
+uint64_t orc_sd_rank(const orc_sd *, uint64_t i, int bit);    /* sd_vector.hpp:553-575 */
+uint64_t orc_sd_select(const orc_sd *, uint64_t i, int bit);  /* sd_vector.hpp:621-664 */
+size_t orc_sd_serialize(const orc_sd *, orc_buf * out);       /* sd_vector.hpp:435-445 */
+
 typedef struct orc_rrr orc_rrr;
 orc_rrr * orc_rrr_build(const uint64_t * words, uint64_t n_bits); /* rrr_vector.hpp:158-270 */
 void orc_rrr_free(orc_rrr *);

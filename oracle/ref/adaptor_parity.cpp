@@ -104,6 +104,49 @@ int main(int argc, char ** argv)
                 check_select<select_support_mcl<00, 2>, select_support_mcl_hip<00, 2>>(bv, c00(n), rng, "select_support_mcl<00,2>");
                 check_select<select_support_mcl<11, 2>, select_support_mcl_hip<11, 2>>(bv, c11(n), rng, "select_support_mcl<11,2>");
             }
+            // sd_vector<>
+            {
+                sd_vector<> sv(bv);
+                sd_vector<>::rank_1_type sr1(&sv);
+                sd_vector<>::rank_0_type sr0(&sv);
+                sd_vector<>::select_1_type ss1(&sv);
+                sd_vector<>::select_0_type ss0(&sv);
+                sd_vector_hip dsv(sv), dsv2(bv);
+                rank_support_sd_hip<1> hr1(&dsv);
+                rank_support_sd_hip<0> hr0(&dsv2);
+                select_support_sd_hip<1> hs1(&dsv2);
+                select_support_sd_hip<0> hs0(&dsv);
+                size_t q = 5000;
+                std::vector<uint64_t> a(q), o(q);
+                for (auto & x : a)
+                    x = rng() % (n + 1);
+                bool ok = true;
+                hr1.rank_batch(a.data(), q, o.data());
+                for (size_t k = 0; k < q; ++k)
+                    ok &= o[k] == sr1(a[k]);
+                hr0.rank_batch(a.data(), q, o.data());
+                for (size_t k = 0; k < q; ++k)
+                    ok &= o[k] == sr0(a[k]);
+                CHECK(ok, "rank_support_sd<1> / <0>");
+                if (ones)
+                {
+                    for (auto & x : a)
+                        x = 1 + rng() % ones;
+                    hs1.select_batch(a.data(), q, o.data());
+                    for (size_t k = 0; k < q; ++k)
+                        ok &= o[k] == ss1(a[k]);
+                }
+                if (n - ones)
+                {
+                    for (auto & x : a)
+                        x = 1 + rng() % (n - ones);
+                    hs0.select_batch(a.data(), 500, o.data());
+                    for (size_t k = 0; k < 500; ++k)
+                        ok &= o[k] == ss0(a[k]);
+                }
+                CHECK(ok, "select_support_sd<1> / <0>");
+                CHECK(dsv[n / 2] == sv[n / 2] and dsv.size() == sv.size(), "sd_vector::operator[] / size");
+            }
             // rrr_vector<63>
             rrr_vector<63> rv(bv);
             rrr_vector<63>::rank_1_type r1(&rv);

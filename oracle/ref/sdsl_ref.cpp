@@ -436,6 +436,60 @@ void ref_bv_pattern(const uint64_t * words, uint64_t n_bits, int pat, int which,
     }
 }
 
+// ---------------- sd_vector<> ---------------------------------------------------------------
+struct RefSd
+{
+    sd_vector<> v;
+    sd_vector<>::rank_1_type r1;
+    sd_vector<>::rank_0_type r0;
+    sd_vector<>::select_1_type s1;
+    sd_vector<>::select_0_type s0;
+    void init()
+    {
+        r1.set_vector(&v);
+        r0.set_vector(&v);
+        s1.set_vector(&v);
+        s0.set_vector(&v);
+    }
+};
+void * ref_sd_create(const uint64_t * words, uint64_t n_bits)
+{
+    bit_vector bv(n_bits, 0);
+    memcpy(bv.data(), words, ((n_bits + 63) >> 6) * 8);
+    RefSd * h = new RefSd();
+    h->v = sd_vector<>(bv);
+    h->init();
+    return h;
+}
+void * ref_sd_create_from_positions(const uint64_t * pos, uint64_t m)
+{
+    RefSd * h = new RefSd();
+    std::vector<uint64_t> pv(pos, pos + m); // (the constructor finds is_sorted through ADL on the iterator type)
+    h->v = sd_vector<>(pv.begin(), pv.end());
+    h->init();
+    return h;
+}
+void ref_sd_destroy(void * p)
+{
+    delete (RefSd *)p;
+}
+uint64_t ref_sd_size(void * p)
+{
+    return ((RefSd *)p)->v.size();
+}
+// what: 0 = rank_0, 1 = rank_1, 2 = select_0, 3 = select_1, 4 = operator[]
+void ref_sd_query(void * p, int what, const uint64_t * q, uint64_t n, uint64_t * out)
+{
+    RefSd * h = (RefSd *)p;
+    for (uint64_t k = 0; k < n; ++k)
+        out[k] = what == 0 ? h->r0(q[k])
+                           : (what == 1 ? h->r1(q[k]) : (what == 2 ? h->s0(q[k]) : (what == 3 ? h->s1(q[k]) : (uint64_t)h->v[q[k]])));
+}
+void ref_sd_serialize(void * p, uint8_t ** out, uint64_t * len)
+{
+    to_bytes(((RefSd *)p)->v, out, len);
+}
+
 // other wt_pc shapes over bytes: shape 1 = wt_blcd (balanced), 2 = wt_hutu (Hu-Tucker); flavour 0 = the type with
 // its default template arguments (rank_support_v, select_support_mcl), 1 = <bit_vector, rank_support_v5<>,
 // select_support_scan<>, select_support_scan<0>> (what sdsl_hip_wt_serialize writes)

@@ -55,6 +55,17 @@ SIGNATURES = {
     "sdsl_hip_rrr_rank_batch": (C.c_int32, [_vp, C.c_int32, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_rrr_select_batch": (C.c_int32, [_vp, C.c_int32, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_rrr_access_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "sdsl_hip_sd_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
+    "sdsl_hip_sd_create_from_positions": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
+    "sdsl_hip_sd_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "sdsl_hip_sd_destroy": (C.c_int32, [_vp]),
+    "sdsl_hip_sd_size": (C.c_uint64, [_vp]),
+    "sdsl_hip_sd_ones": (C.c_uint64, [_vp]),
+    "sdsl_hip_sd_low_width": (C.c_uint32, [_vp]),
+    "sdsl_hip_sd_device_bytes": (C.c_uint64, [_vp]),
+    "sdsl_hip_sd_rank_batch": (C.c_int32, [_vp, C.c_int32, _vp, C.c_uint64, _vp, _vp]),
+    "sdsl_hip_sd_select_batch": (C.c_int32, [_vp, C.c_int32, _vp, C.c_uint64, _vp, _vp]),
+    "sdsl_hip_sd_access_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_wt_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_wt_create_ex": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "sdsl_hip_wt_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp),

@@ -266,6 +266,14 @@ __device__ __forceinline__ bool sel_eval(const BvView & bv, int s, uint64_t k, u
     return true;
 }
 
+// exactly one lane of the quad has mine == true: give its value to all four
+__device__ __forceinline__ uint64_t quad_gather_u64(uint64_t v, bool mine)
+{
+    uint64_t x = mine ? v : 0;
+    unsigned lo = quad_sum((unsigned)x), hi = quad_sum((unsigned)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // One query per quad, probes issued one after the other (used by the wavelet-tree select cascade).
 template <int BIT, bool NT>
 __device__ __forceinline__ uint64_t quad_select(const BvView & bv, int s, uint64_t k, bool & mine)

@@ -1,0 +1,501 @@
+// sd.hip — sd_vector<> (Elias-Fano coded sparse bit vector) on the device: rank / select / access.
+//
+// Reference semantics reproduced (bit-identical answers; SDSL's serialised arrays are accepted as input):
+//   sd_vector(bit_vector const&) / (begin, end)   sd_vector.hpp:217-305   wl = logn - logm, low = wl low bits of
+//                                                 every position, high = unary-coded high parts (m ones, 2^logm zeros)
+//   sd_vector::operator[]                         sd_vector.hpp:328-349
+//   rank_support_sd<b>::rank                      sd_vector.hpp:553-575
+//   select_support_sd<1>::select                  sd_vector.hpp:621-631   low[i-1] + ((high_1_select(i) + 1 - i) << wl)
+//   select_support_sd<0>::select                  sd_vector.hpp:633-664   binary search over select_1
+//
+// Device layout: `high` as rank lines with both select directories (bv_device.hpp), `low` as SDSL's packed words.
+// One query per quad.  rank(x): the bucket of x's high part is delimited by two select_0 on `high` (they land in the
+// same or neighbouring windows), then a binary search over the bucket's low parts — the reference scans the bucket
+// linearly from its end, which is the same count.  select_1: one select_1 on `high` and one read of `low`.
+#include <algorithm>
+
+#include "bv_host.hpp"
+#include "sdsl_stream.hpp"
+
+namespace sdslhip {
+
+struct SdView
+{
+    BvView high;
+    const uint64_t * low; // packed, wl bits per entry, padded by one word
+    uint64_t n, m;        // size of the bit vector, number of ones
+    uint32_t wl;
+};
+
+struct SdHost
+{
+    int device = 0;
+    BvHost high;
+    DevBuf low;
+    SdView view{};
+    size_t device_bytes() const
+    {
+        return high.device_bytes() + low.bytes;
+    }
+};
+
+__device__ __forceinline__ uint64_t sd_low(const SdView & v, uint64_t i)
+{
+    return read_bits(v.low, i * v.wl, v.wl);
+}
+
+// number of ones in [0, x), x in [0, n]; all four lanes return it.  *hit (optional) = "bit x is set" (x < n)
+template <bool NT>
+__device__ __forceinline__ uint64_t quad_sd_rank1(const SdView & v, int s, uint64_t x, bool * hit)
+{
+    const uint64_t h = x >> v.wl, val_low = x & lo_set(v.wl);
+    bool mine;
+    uint64_t p = quad_select<0, NT>(v.high, s, h, mine); // the (h+1)-th zero
+    const uint64_t end = quad_gather_u64(p, mine) - h;   // entries with high part <= h
+    uint64_t begin = 0;                                  // entries with high part < h
+    if (h > 0)
+    {
+        p = quad_select<0, NT>(v.high, s, h - 1, mine);
+        begin = quad_gather_u64(p, mine) - (h - 1);
+    }
+    uint64_t lo = begin, hi = end; // first entry of the bucket with low part >= val_low
+    while (lo < hi)
+    {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (sd_low(v, mid) < val_low)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (hit)
+        *hit = lo < end && sd_low(v, lo) == val_low;
+    return lo;
+}
+
+// position of the i-th one, i in [1, m]
+template <bool NT>
+__device__ __forceinline__ uint64_t quad_sd_select1(const SdView & v, int s, uint64_t i)
+{
+    bool mine;
+    const uint64_t p = quad_select<1, NT>(v.high, s, i - 1, mine);
+    const uint64_t hp = quad_gather_u64(p, mine);
+    return sd_low(v, i - 1) + ((hp + 1 - i) << v.wl);
+}
+
+template <int MODE> // 0: rank (bit b), 1: access
+__global__ __launch_bounds__(kBlock) void k_sd_rank(SdView v, int bit, const uint64_t * __restrict__ xq,
+                                                    uint64_t * __restrict__ out, uint8_t * __restrict__ out8, uint64_t n)
+{
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
+    {
+        const uint64_t q = base + gq;
+        if (q >= n)
+            continue;
+        const uint64_t x = xq[q];
+        if (MODE == 1)
+        {
+            bool hit = false;
+            if (x < v.n)
+                quad_sd_rank1<false>(v, s, x, &hit);
+            if (s == 0)
+                out8[q] = x < v.n ? (hit ? 1 : 0) : 0xFF;
+        }
+        else
+        {
+            uint64_t r = SDSL_HIP_NPOS;
+            if (x <= v.n)
+            {
+                const uint64_t r1 = quad_sd_rank1<false>(v, s, x, nullptr);
+                r = bit ? r1 : x - r1;
+            }
+            if (s == 0)
+                out[q] = r;
+        }
+    }
+}
+
+template <int BIT>
+__global__ __launch_bounds__(kBlock) void k_sd_select(SdView v, const uint64_t * __restrict__ iq,
+                                                      uint64_t * __restrict__ out, uint64_t n)
+{
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    const uint64_t total = BIT ? v.m : v.n - v.m;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
+    {
+        const uint64_t q = base + gq;
+        if (q >= n)
+            continue;
+        const uint64_t i = iq[q];
+        uint64_t r = SDSL_HIP_NPOS; // outside SDSL's precondition (sd_vector.hpp:639)
+        if (i >= 1 && i <= total)
+        {
+            if (BIT)
+                r = quad_sd_select1<false>(v, s, i);
+            else
+            { // the reference's binary search over the ones (sd_vector.hpp:640-663)
+                uint64_t lb = 1, rb = v.m + 1, r0 = 0, pos = ~UINT64_C(0);
+                while (lb < rb)
+                {
+                    const uint64_t mid = lb + (rb - lb) / 2;
+                    const uint64_t x = quad_sd_select1<false>(v, s, mid);
+                    const uint64_t rank0 = x + 1 - mid;
+                    if (rank0 >= i)
+                        rb = mid;
+                    else
+                    {
+                        r0 = rank0;
+                        pos = x;
+                        lb = mid + 1;
+                    }
+                }
+                r = pos + i - r0;
+            }
+        }
+        if (s == 0)
+            out[q] = r;
+    }
+}
+
+// ---- construction --------------------------------------------------------------------------------------------
+// entry i of the sorted position list: wl low bits into `low`, a one at (pos >> wl) + i into `high`
+__global__ __launch_bounds__(256) void k_sd_fill(const uint64_t * __restrict__ pos, uint64_t m, uint32_t wl,
+                                                 unsigned long long * __restrict__ low,
+                                                 unsigned long long * __restrict__ high)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t p = pos[i];
+        const uint64_t lv = p & lo_set(wl), at = i * wl;
+        const unsigned off = (unsigned)(at & 63);
+        atomicOr(&low[at >> 6], (unsigned long long)(lv << off));
+        if (off + wl > 64)
+            atomicOr(&low[(at >> 6) + 1], (unsigned long long)(lv >> (64 - off)));
+        const uint64_t hp = (p >> wl) + i;
+        atomicOr(&high[hp >> 6], 1ull << (hp & 63));
+    }
+}
+
+// 0 if pos[0..m) is strictly increasing and below n
+__global__ __launch_bounds__(256) void k_sd_check_sorted(const uint64_t * __restrict__ pos, uint64_t m, uint64_t n,
+                                                         unsigned * __restrict__ bad)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x)
+        if (pos[i] >= n || (i && pos[i - 1] >= pos[i]))
+            atomicOr(bad, 1u);
+}
+
+__global__ __launch_bounds__(256) void k_sd_iota1(uint64_t * __restrict__ a, uint64_t m)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (uint64_t)gridDim.x * blockDim.x)
+        a[i] = i + 1;
+}
+
+static unsigned hi64_host(uint64_t x)
+{ // bits::hi: position of the most significant set bit, 0 for x == 0
+    unsigned r = 0;
+    while (x >>= 1)
+        ++r;
+    return r;
+}
+
+static void sd_finish_view(SdHost & h, uint64_t n, uint64_t m, uint32_t wl)
+{
+    h.view.high = h.high.view;
+    h.view.low = h.low.as<uint64_t>();
+    h.view.n = n;
+    h.view.m = m;
+    h.view.wl = wl;
+}
+
+// sd_vector(begin, end) with an explicit size (sd_vector.hpp:217-305; the iterator constructor takes size = last + 1)
+static sdsl_hip_status sd_build_from_device_positions(SdHost & h, const uint64_t * d_pos, uint64_t m, uint64_t n, int device)
+{
+    h.device = device;
+    unsigned logm = hi64_host(m) + 1, logn = hi64_host(n) + 1;
+    if (logm == logn)
+        --logm; // to ensure logn - logm > 0 (:226-229)
+    const uint32_t wl = logn - logm;
+    const uint64_t high_bits = m + (UINT64_C(1) << logm);
+    DevBuf d_high;
+    SH_TRY(d_high.alloc((((high_bits + 63) >> 6) + 1) * 8, true));
+    SH_TRY(h.low.alloc((((m * wl + 63) >> 6) + 2) * 8, true));
+    if (m)
+    {
+        DevBuf bad;
+        SH_TRY(bad.alloc(4, true));
+        hipLaunchKernelGGL(k_sd_check_sorted, dim3(grid_for(m, 256, 65536)), dim3(256), 0, 0, d_pos, m, n, bad.as<unsigned>());
+        SH_HIP(hipGetLastError());
+        unsigned hb = 0;
+        SH_HIP(hipMemcpy(&hb, bad.p, 4, hipMemcpyDeviceToHost));
+        if (hb)
+        {
+            set_error("sd_vector: the positions must be strictly increasing and smaller than the size (sd_vector.hpp:266-269)");
+            return SDSL_HIP_ERR_INVALID;
+        }
+        hipLaunchKernelGGL(k_sd_fill, dim3(grid_for(m, 256, 65536)), dim3(256), 0, 0, d_pos, m, wl,
+                           h.low.as<unsigned long long>(), d_high.as<unsigned long long>());
+        SH_HIP(hipGetLastError());
+    }
+    h.high.device = device;
+    SH_TRY(bv_build_from_device_words(h.high, d_high.as<uint64_t>(), high_bits, SDSL_HIP_BV_SELECT1 | SDSL_HIP_BV_SELECT0,
+                                      default_sel_shift()));
+    SH_HIP(hipDeviceSynchronize());
+    sd_finish_view(h, n, m, wl);
+    return SDSL_HIP_OK;
+}
+
+// sd_vector::load (sd_vector.hpp:447-456): size, wl, low, high, the two select supports of high (skipped)
+static sdsl_hip_status sd_build_from_stream(SdHost & h, StreamReader & rd, int device)
+{
+    h.device = device;
+    uint64_t n = 0;
+    uint8_t wl = 0;
+    HostIntVec low, high;
+    if (!rd.u64(n) || !rd.raw(&wl, 1) || !rd.int_vector(low) || !rd.int_vector(high, 1) || !rd.skip_select_mcl()
+        || !rd.skip_select_mcl())
+    {
+        set_error("malformed sd_vector stream (offset %zu of %zu)", rd.pos, rd.len);
+        return SDSL_HIP_ERR_FORMAT;
+    }
+    const uint64_t m = low.size();
+    uint64_t ones = 0;
+    for (uint64_t w = 0; w < (high.bit_size + 63) >> 6; ++w)
+        ones += popc64(w == (high.bit_size >> 6) && (high.bit_size & 63) ? high.words[w] & lo_set((unsigned)(high.bit_size & 63))
+                                                                        : high.words[w]);
+    // the kernels index with these: every rank needs the (x >> wl) + 1-th zero of high, every select the i-th one
+    const bool sane = wl >= 1 && wl <= 63 && (m == 0 || low.width == wl) && ones == m && high.bit_size >= m
+                      && high.bit_size - m > (n >> wl);
+    if (!sane)
+    {
+        set_error("sd_vector stream: size, wl, low and high do not describe one vector");
+        return SDSL_HIP_ERR_FORMAT;
+    }
+    DevBuf d_high;
+    const uint64_t hw = (high.bit_size + 63) >> 6;
+    SH_TRY(d_high.alloc((hw + 1) * 8, true));
+    if (hw)
+        SH_HIP(hipMemcpy(d_high.p, high.words.data(), hw * 8, hipMemcpyHostToDevice));
+    const uint64_t lw = (m * wl + 63) >> 6;
+    SH_TRY(h.low.alloc((lw + 2) * 8, true));
+    if (lw)
+        SH_HIP(hipMemcpy(h.low.p, low.words.data(), lw * 8, hipMemcpyHostToDevice));
+    h.high.device = device;
+    SH_TRY(bv_build_from_device_words(h.high, d_high.as<uint64_t>(), high.bit_size, SDSL_HIP_BV_SELECT1 | SDSL_HIP_BV_SELECT0,
+                                      default_sel_shift()));
+    SH_HIP(hipDeviceSynchronize());
+    sd_finish_view(h, n, m, wl);
+    return SDSL_HIP_OK;
+}
+
+} // namespace sdslhip
+
+using namespace sdslhip;
+
+struct sdsl_hip_sd_s
+{
+    SdHost h;
+};
+
+extern "C" {
+
+sdsl_hip_status sdsl_hip_sd_create_from_positions(const uint64_t * positions, uint64_t m, uint64_t n_bits, int32_t device,
+                                                  sdsl_hip_sd_t * out)
+{
+    if (!out || (!positions && m))
+    {
+        set_error("sd_create_from_positions: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    sdsl_hip_sd_s * r = new (std::nothrow) sdsl_hip_sd_s();
+    if (!r)
+        return SDSL_HIP_ERR_NOMEM;
+    Staged p;
+    sdsl_hip_status st = p.in(positions, m * 8, nullptr);
+    if (st == SDSL_HIP_OK)
+        st = sd_build_from_device_positions(r->h, (const uint64_t *)p.dev, m, n_bits, device);
+    if (st != SDSL_HIP_OK)
+    {
+        delete r;
+        return st;
+    }
+    *out = r;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_sd_create(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_sd_t * out)
+{
+    if (!out || (!words && n_bits))
+    {
+        set_error("sd_create: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    // positions of the ones through a temporary plain vector: select_1(1..m)
+    BvHost tmp;
+    tmp.device = device;
+    Staged w;
+    SH_TRY(w.in(words, ((n_bits + 63) >> 6) * 8, nullptr));
+    SH_TRY(bv_build_from_device_words(tmp, (const uint64_t *)w.dev, n_bits, SDSL_HIP_BV_SELECT1, default_sel_shift()));
+    const uint64_t m = tmp.view.ones;
+    DevBuf d_pos;
+    SH_TRY(d_pos.alloc((m + 1) * 8));
+    if (m)
+    {
+        hipLaunchKernelGGL(k_sd_iota1, dim3(grid_for(m, 256, 65536)), dim3(256), 0, 0, d_pos.as<uint64_t>(), m);
+        SH_HIP(hipGetLastError());
+        SH_TRY(bv_launch_select(tmp.view, 1, d_pos.as<uint64_t>(), m, d_pos.as<uint64_t>(), nullptr));
+    }
+    sdsl_hip_sd_s * r = new (std::nothrow) sdsl_hip_sd_s();
+    if (!r)
+        return SDSL_HIP_ERR_NOMEM;
+    sdsl_hip_status st = sd_build_from_device_positions(r->h, d_pos.as<uint64_t>(), m, n_bits, device);
+    if (st != SDSL_HIP_OK)
+    {
+        delete r;
+        return st;
+    }
+    *out = r;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_sd_create_from_sdsl(const void * bytes, size_t len, int32_t device, sdsl_hip_sd_t * out,
+                                             size_t * consumed)
+{
+    if (!out || !bytes)
+    {
+        set_error("sd_create_from_sdsl: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    sdsl_hip_sd_s * r = new (std::nothrow) sdsl_hip_sd_s();
+    if (!r)
+        return SDSL_HIP_ERR_NOMEM;
+    StreamReader rd(bytes, len);
+    sdsl_hip_status st = sd_build_from_stream(r->h, rd, device);
+    if (st != SDSL_HIP_OK)
+    {
+        delete r;
+        return st;
+    }
+    if (consumed)
+        *consumed = rd.pos;
+    *out = r;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_sd_destroy(sdsl_hip_sd_t v)
+{
+    if (!v)
+        return SDSL_HIP_OK;
+    (void)hipSetDevice(v->h.device);
+    delete v;
+    return SDSL_HIP_OK;
+}
+uint64_t sdsl_hip_sd_size(sdsl_hip_sd_t v)
+{
+    return v ? v->h.view.n : 0;
+}
+uint64_t sdsl_hip_sd_ones(sdsl_hip_sd_t v)
+{
+    return v ? v->h.view.m : 0;
+}
+uint32_t sdsl_hip_sd_low_width(sdsl_hip_sd_t v)
+{
+    return v ? v->h.view.wl : 0;
+}
+uint64_t sdsl_hip_sd_device_bytes(sdsl_hip_sd_t v)
+{
+    return v ? v->h.device_bytes() : 0;
+}
+
+sdsl_hip_status sdsl_hip_sd_rank_batch(sdsl_hip_sd_t v, int32_t bit, const uint64_t * idx, uint64_t n, uint64_t * out,
+                                       void * stream)
+{
+    if (!v || (bit != 0 && bit != 1) || (n && (!idx || !out)))
+    {
+        set_error("sd_rank_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(v->h.device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged in, o;
+    SH_TRY(in.in(idx, n * 8, s));
+    SH_TRY(o.out(out, n * 8));
+    {
+        KernelTimer t(s);
+        hipLaunchKernelGGL((k_sd_rank<0>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, v->h.view, bit,
+                           (const uint64_t *)in.dev, (uint64_t *)o.dev, (uint8_t *)nullptr, n);
+    }
+    SH_HIP(hipGetLastError());
+    SH_TRY(o.finish(s));
+    if (in.host && !o.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_sd_access_batch(sdsl_hip_sd_t v, const uint64_t * idx, uint64_t n, uint8_t * out, void * stream)
+{
+    if (!v || (n && (!idx || !out)))
+    {
+        set_error("sd_access_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(v->h.device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged in, o;
+    SH_TRY(in.in(idx, n * 8, s));
+    SH_TRY(o.out(out, n));
+    {
+        KernelTimer t(s);
+        hipLaunchKernelGGL((k_sd_rank<1>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, v->h.view, 1,
+                           (const uint64_t *)in.dev, (uint64_t *)nullptr, (uint8_t *)o.dev, n);
+    }
+    SH_HIP(hipGetLastError());
+    SH_TRY(o.finish(s));
+    if (in.host && !o.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_sd_select_batch(sdsl_hip_sd_t v, int32_t bit, const uint64_t * i, uint64_t n, uint64_t * out,
+                                         void * stream)
+{
+    if (!v || (bit != 0 && bit != 1) || (n && (!i || !out)))
+    {
+        set_error("sd_select_batch: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(v->h.device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged in, o;
+    SH_TRY(in.in(i, n * 8, s));
+    SH_TRY(o.out(out, n * 8));
+    {
+        KernelTimer t(s);
+        if (bit)
+            hipLaunchKernelGGL((k_sd_select<1>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, v->h.view,
+                               (const uint64_t *)in.dev, (uint64_t *)o.dev, n);
+        else
+            hipLaunchKernelGGL((k_sd_select<0>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, v->h.view,
+                               (const uint64_t *)in.dev, (uint64_t *)o.dev, n);
+    }
+    SH_HIP(hipGetLastError());
+    SH_TRY(o.finish(s));
+    if (in.host && !o.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+}

@@ -543,12 +543,6 @@ __global__ __launch_bounds__(kBlock) void k_wt_inverse_select(WtView wt, const u
     }
 }
 
-__device__ __forceinline__ uint64_t quad_gather_u64(uint64_t v, bool mine)
-{ // exactly one lane of the quad has mine == true: give its value to all four
-    uint64_t x = mine ? v : 0;
-    unsigned lo = quad_sum((unsigned)x), hi = quad_sum((unsigned)(x >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
 
 template <bool NT>
 __global__ __launch_bounds__(kBlock) void k_wt_select(WtView wt, const uint64_t * __restrict__ occ,

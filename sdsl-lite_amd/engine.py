@@ -254,6 +254,79 @@ class rrr_vector(_Handle):
     __getitem__ = access
 
 
+class sd_vector(_Handle):
+    """Device sd_vector<> (Elias-Fano coded sparse bit vector, sd_vector.hpp:134) with rank_support_sd /
+    select_support_sd semantics.  From a plain bit vector (words, n_bits), from strictly increasing positions
+    (positions, n_bits) or from sd_vector<>::serialize bytes."""
+    _destroy = "sdsl_hip_sd_destroy"
+
+    def __init__(self, words=None, n_bits: int | None = None, positions=None, device: int = 0,
+                 sdsl_bytes: bytes | None = None):
+        super().__init__()
+        L = capi.lib()
+        self.consumed = None
+        if sdsl_bytes is not None:
+            buf = np.frombuffer(sdsl_bytes, dtype=np.uint8)
+            used = C.c_size_t(0)
+            capi.check(L.sdsl_hip_sd_create_from_sdsl(_ptr(buf), buf.size, device, C.byref(self._h), C.byref(used)))
+            self.consumed = used.value
+        elif positions is not None:
+            p = _as_array(positions, np.uint64, "positions")
+            m = p.numel() if _is_tensor(p) else p.size
+            if n_bits is None:
+                raise ValueError("positions need n_bits (the size of the bit vector)")
+            capi.check(L.sdsl_hip_sd_create_from_positions(_ptr(p) if m else None, m, n_bits, device, C.byref(self._h)))
+        else:
+            w = _as_array(words, np.uint64, "words")
+            nw = w.numel() if _is_tensor(w) else w.size
+            if n_bits is None:
+                n_bits = nw * 64
+            if (n_bits + 63) // 64 > nw:
+                raise ValueError("words too short for n_bits")
+            capi.check(L.sdsl_hip_sd_create(_ptr(w) if nw else None, n_bits, device, C.byref(self._h)))
+        self.device = device
+
+    def size(self) -> int:
+        return capi.lib().sdsl_hip_sd_size(self._h)
+
+    __len__ = size
+
+    def ones(self) -> int:
+        return capi.lib().sdsl_hip_sd_ones(self._h)
+
+    def low_width(self) -> int:
+        return capi.lib().sdsl_hip_sd_low_width(self._h)
+
+    def device_bytes(self) -> int:
+        return capi.lib().sdsl_hip_sd_device_bytes(self._h)
+
+    def rank(self, idx, bit: int = 1, out=None):
+        idx = _as_array(idx, np.uint64, "idx")
+        n = idx.numel() if _is_tensor(idx) else idx.size
+        if out is None:
+            out = _empty_like(idx, n, np.uint64)
+        capi.check(capi.lib().sdsl_hip_sd_rank_batch(self._h, bit, _ptr(idx), n, _ptr(out), _stream_for(idx)))
+        return out
+
+    def select(self, i, bit: int = 1, out=None):
+        i = _as_array(i, np.uint64, "i")
+        n = i.numel() if _is_tensor(i) else i.size
+        if out is None:
+            out = _empty_like(i, n, np.uint64)
+        capi.check(capi.lib().sdsl_hip_sd_select_batch(self._h, bit, _ptr(i), n, _ptr(out), _stream_for(i)))
+        return out
+
+    def access(self, idx, out=None):
+        idx = _as_array(idx, np.uint64, "idx")
+        n = idx.numel() if _is_tensor(idx) else idx.size
+        if out is None:
+            out = _empty_like(idx, n, np.uint8)
+        capi.check(capi.lib().sdsl_hip_sd_access_batch(self._h, _ptr(idx), n, _ptr(out), _stream_for(idx)))
+        return out
+
+    __getitem__ = access
+
+
 def _bytes_arg(x, name):
     if isinstance(x, (bytes, bytearray)):
         return np.frombuffer(bytes(x), dtype=np.uint8)

@@ -111,8 +111,34 @@ def main():
                     si = np.concatenate([si, np.array([1, tot], dtype=np.uint64)])
                 out[f"{name}/pat{pat}_sel_i"] = si
                 out[f"{name}/pat{pat}_sel"] = ol.ref_bv_pattern(w, n, pat, 2, si) if tot else np.zeros(0, np.uint64)
+        if name in ("CRAFTED-32", "CRAFTED-SPARSE-0", "CRAFTED-SPARSE-1", "CRAFTED-BLOCK-1", "rnd.8192.1043", "rnd.200000.7",
+                    "rnd.64.222", "rnd.8.17"):
+            # sd_vector<> of the real library on the same bits: rank_1, select_1, select_0 (i <= #zeros), operator[]
+            sd = ol.RSd(w, n)
+            out[f"{name}/sd_rank1"] = sd.rank(idx, 1)
+            for b in (0, 1):
+                si = out[f"{name}/sel{b}_i"][:600]
+                out[f"{name}/sd_sel{b}"] = sd.select(si, b) if si.size else np.zeros(0, np.uint64)
+            ai = idx[idx < n]
+            out[f"{name}/sd_acc"] = sd.access(ai) if ai.size else np.zeros(0, np.uint8)
+            if name in ("CRAFTED-32", "rnd.8192.1043", "rnd.200000.7", "CRAFTED-SPARSE-1"):
+                open(os.path.join(HERE, "sdsl", f"{name}.sd_vector.sdsl"), "wb").write(sd.serialize())
         out[f"{name}/sha"] = np.array([sha(rb.serialize(1)), sha(rb.serialize(2)), sha(rb.serialize(3)),
                                        sha(rb.serialize(4)), sha(rr.serialize())])
+    # a sparse set over a large universe (what sd_vector is for): 20000 positions below 2^40
+    pos = np.unique(ol.mt19937_64(20000, 4242) % np.uint64(1 << 40)).astype(np.uint64)
+    sd = ol.RSd(positions=pos)
+    N = sd.size()
+    qi = np.concatenate([ol.mt19937_64(3000, 4243) % np.uint64(N + 1), pos[:500], pos[:500] + np.uint64(1),
+                         np.array([0, N], dtype=np.uint64)]).astype(np.uint64)
+    out["sdpos/pos"], out["sdpos/n"], out["sdpos/idx"] = pos, np.array([N], dtype=np.uint64), qi
+    out["sdpos/rank1"] = sd.rank(qi, 1)
+    s1 = (ol.mt19937_64(2000, 4244) % np.uint64(pos.size)) + np.uint64(1)
+    out["sdpos/sel1_i"], out["sdpos/sel1"] = s1, sd.select(s1, 1)
+    s0 = (ol.mt19937_64(500, 4245) % np.uint64(N - pos.size)) + np.uint64(1)
+    out["sdpos/sel0_i"], out["sdpos/sel0"] = s0, sd.select(s0, 0)
+    out["sdpos/acc"] = sd.access(qi[qi < N])
+    open(os.path.join(HERE, "sdsl", "sdpos.sd_vector.sdsl"), "wb").write(sd.serialize())
     np.savez_compressed(os.path.join(HERE, "golden_bitvectors.npz"), **out)
 
     # serialised streams for the loader tests (small ones only)

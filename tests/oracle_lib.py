@@ -93,6 +93,16 @@ _ORC_SIGS = {
     "orc_wt_rank_batch": (None, [_vp, _vp, _vp, _u64, _vp]),
     "orc_wt_serialize": (C.c_size_t, [_vp, C.c_int, C.POINTER(OrcBuf)]),
     "orc_wt_code_lengths": (None, [_vp, _vp]),
+    "orc_sd_build": (_vp, [_vp, _u64]),
+    "orc_sd_build_from_positions": (_vp, [_vp, _u64]),
+    "orc_sd_free": (None, [_vp]),
+    "orc_sd_size": (_u64, [_vp]),
+    "orc_sd_ones": (_u64, [_vp]),
+    "orc_sd_wl": (_u32, [_vp]),
+    "orc_sd_access": (C.c_int, [_vp, _u64]),
+    "orc_sd_rank": (_u64, [_vp, _u64, C.c_int]),
+    "orc_sd_select": (_u64, [_vp, _u64, C.c_int]),
+    "orc_sd_serialize": (C.c_size_t, [_vp, C.POINTER(OrcBuf)]),
     "orc_csa_build": (_vp, [_vp, _u64]),
     "orc_csa_build_from_bwt": (_vp, [_vp, _u64]),
     "orc_csa_build_ex": (_vp, [_vp, _u64, _u64, _u64]),
@@ -299,6 +309,51 @@ class OWt:
             pass
 
 
+class OSd:
+    """oracle sd_vector<>"""
+
+    def __init__(self, words=None, n_bits=None, positions=None):
+        L = oracle().L
+        if positions is not None:
+            p = _u64arr(positions)
+            self.h = L.orc_sd_build_from_positions(_p(p) if p.size else None, p.size)
+        else:
+            w = padded(_u64arr(words), n_bits)
+            self.h = L.orc_sd_build(_p(w), n_bits)
+
+    def size(self):
+        return oracle().L.orc_sd_size(self.h)
+
+    def ones(self):
+        return oracle().L.orc_sd_ones(self.h)
+
+    def wl(self):
+        return oracle().L.orc_sd_wl(self.h)
+
+    def rank(self, idx, bit=1):
+        L = oracle().L
+        return np.array([L.orc_sd_rank(self.h, int(i), bit) for i in idx], dtype=np.uint64)
+
+    def select(self, idx, bit=1):
+        L = oracle().L
+        return np.array([L.orc_sd_select(self.h, int(i), bit) for i in idx], dtype=np.uint64)
+
+    def access(self, idx):
+        L = oracle().L
+        return np.array([L.orc_sd_access(self.h, int(i)) for i in idx], dtype=np.uint8)
+
+    def serialize(self) -> bytes:
+        b = OrcBuf()
+        oracle().L.orc_sd_serialize(self.h, C.byref(b))
+        return _take(b)
+
+    def __del__(self):
+        try:
+            oracle().L.orc_sd_free(self.h)
+        except Exception:
+            pass
+
+
 class OCsa:
     def __init__(self, text: bytes | None = None, bwt: np.ndarray | None = None, sa_dens: int = 32,
                  isa_dens: int = 64):
@@ -437,6 +492,12 @@ _REF_SIGS = {
     "ref_csa_locate": (_u64, [_vp, _vp, _u64, _vp, _u64]),
     "ref_wt_rrr_serialize": (None, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_csa_rrr_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
+    "ref_sd_create": (_vp, [_vp, _u64]),
+    "ref_sd_create_from_positions": (_vp, [_vp, _u64]),
+    "ref_sd_destroy": (None, [_vp]),
+    "ref_sd_size": (_u64, [_vp]),
+    "ref_sd_query": (None, [_vp, C.c_int, _vp, _u64, _vp]),
+    "ref_sd_serialize": (None, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_bv_pattern": (None, [_vp, _u64, C.c_int, C.c_int, _vp, _u64, _vp]),
     "ref_wt_shape_serialize": (None, [_vp, _u64, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_csa_blcd_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
@@ -632,6 +693,46 @@ class RWt:
     def __del__(self):
         try:
             ref().L.ref_wt_destroy(self.h)
+        except Exception:
+            pass
+
+
+class RSd:
+    """the real sd_vector<> with its rank / select supports"""
+
+    def __init__(self, words=None, n_bits=None, positions=None):
+        L = ref().L
+        if positions is not None:
+            p = _u64arr(positions)
+            self.h = L.ref_sd_create_from_positions(_p(p) if p.size else None, p.size)
+        else:
+            w = padded(_u64arr(words), n_bits)
+            self.h = L.ref_sd_create(_p(w), n_bits)
+
+    def size(self):
+        return ref().L.ref_sd_size(self.h)
+
+    def _q(self, what, q):
+        q = _u64arr(q)
+        out = np.empty(q.size, dtype=np.uint64)
+        ref().L.ref_sd_query(self.h, what, _p(q), q.size, _p(out))
+        return out
+
+    def rank(self, idx, bit=1):
+        return self._q(1 if bit else 0, idx)
+
+    def select(self, i, bit=1):
+        return self._q(3 if bit else 2, i)
+
+    def access(self, idx):
+        return self._q(4, idx).astype(np.uint8)
+
+    def serialize(self) -> bytes:
+        return _ref_bytes(ref().L.ref_sd_serialize, self.h)
+
+    def __del__(self):
+        try:
+            ref().L.ref_sd_destroy(self.h)
         except Exception:
             pass
 

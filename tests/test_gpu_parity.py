@@ -2,6 +2,8 @@
 bit-exactly with (a) the committed golden vectors produced by the real sdsl-lite, (b) the CPU
 restatement (oracle/) on seeded inputs, and (c) the real library itself when oracle/_ref travelled
 with the snapshot.  Integer work only: the bar is equality, no tolerances anywhere."""
+import os
+
 import numpy as np
 import pytest
 
@@ -497,6 +499,92 @@ def test_fm_built_on_gpu_serializes_to_sdsl_bytes(gpu, name):
     csa.drop_sa()
     with pytest.raises(gpu.capi.SdslHipError):
         csa.serialize(32, 64)
+
+
+# ---------------------------------------------------------------------------------------------------
+# sd_vector<>
+# ---------------------------------------------------------------------------------------------------
+SD_CASES = ["CRAFTED-32", "CRAFTED-SPARSE-0", "CRAFTED-SPARSE-1", "CRAFTED-BLOCK-1", "rnd.8.17", "rnd.64.222",
+            "rnd.8192.1043", "rnd.200000.7"]
+
+
+def _check_sd(sd, g, name, n):
+    idx = g[f"{name}/idx"]
+    assert sd.size() == n
+    assert np.array_equal(sd.rank(idx, 1), g[f"{name}/sd_rank1"])
+    assert np.array_equal(sd.rank(idx, 0), idx - g[f"{name}/sd_rank1"])
+    for b in (0, 1):
+        si = g[f"{name}/sel{b}_i"][:600]
+        if si.size:
+            assert np.array_equal(sd.select(si, b), g[f"{name}/sd_sel{b}"])
+    ai = idx[idx < n]
+    if ai.size:
+        assert np.array_equal(sd.access(ai), g[f"{name}/sd_acc"])
+    # outside the domain
+    bad = np.array([n + 1, 2**63], dtype=np.uint64)
+    assert np.all(sd.rank(bad, 1) == NPOS) and np.all(sd.access(np.array([n, n + 7], dtype=np.uint64)) == 0xFF)
+    tot1 = int(g[f"{name}/total1"][0])
+    assert np.all(sd.select(np.array([0, tot1 + 1], dtype=np.uint64), 1) == NPOS)
+    assert np.all(sd.select(np.array([0, n - tot1 + 1], dtype=np.uint64), 0) == NPOS)
+
+
+@pytest.mark.parametrize("name", SD_CASES)
+@pytest.mark.parametrize("how", ["bits", "positions", "stream"])
+def test_sd_vector_golden(gpu, name, how):
+    g = gd.bv_golden()
+    words, n = gd.bv_case(name)
+    if how == "bits":
+        sd = gpu.sd_vector(words, n)
+    elif how == "positions":
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+        sd = gpu.sd_vector(positions=np.flatnonzero(bits).astype(np.uint64), n_bits=n)
+    else:
+        if not os.path.exists(os.path.join(gd.GOLDEN, "sdsl", f"{name}.sd_vector.sdsl")):
+            pytest.skip("no stream fixture for this case")
+        blob = gd.sdsl_file(f"{name}.sd_vector.sdsl")
+        sd = gpu.sd_vector(sdsl_bytes=blob + b"tail")
+        assert sd.consumed == len(blob)
+        for cut in (5, len(blob) // 2, len(blob) - 3):
+            with pytest.raises(gpu.capi.SdslHipError):
+                gpu.sd_vector(sdsl_bytes=blob[:cut])
+    assert sd.ones() == int(g[f"{name}/total1"][0])
+    assert sd.low_width() == ol.OSd(words, n).wl()
+    _check_sd(sd, g, name, n)
+
+
+def test_sd_vector_large_universe(gpu):
+    g = gd.bv_golden()
+    pos, N = g["sdpos/pos"], int(g["sdpos/n"][0])
+    for sd in (gpu.sd_vector(positions=pos, n_bits=N), gpu.sd_vector(sdsl_bytes=gd.sdsl_file("sdpos.sd_vector.sdsl"))):
+        assert (sd.size(), sd.ones()) == (N, pos.size)
+        assert np.array_equal(sd.rank(g["sdpos/idx"], 1), g["sdpos/rank1"])
+        assert np.array_equal(sd.select(g["sdpos/sel1_i"], 1), g["sdpos/sel1"])
+        assert np.array_equal(sd.select(g["sdpos/sel0_i"], 0), g["sdpos/sel0"])
+        qi = g["sdpos/idx"]
+        assert np.array_equal(sd.access(qi[qi < N]), g["sdpos/acc"])
+    with pytest.raises(gpu.capi.SdslHipError):  # not strictly increasing
+        gpu.sd_vector(positions=np.array([5, 5, 9], dtype=np.uint64), n_bits=100)
+    with pytest.raises(gpu.capi.SdslHipError):  # beyond the size
+        gpu.sd_vector(positions=np.array([5, 100], dtype=np.uint64), n_bits=100)
+
+
+def test_sd_vector_million_ones_in_2_40(gpu):
+    """2^22 ones over a universe of 2^40: select_1(rank_1(p) + 1) == p on members, rank is monotone and exact against
+    numpy's searchsorted, select_0 inverts rank_0"""
+    rng = np.random.default_rng(17)
+    N = 1 << 40
+    pos = np.unique(rng.integers(0, N, 1 << 22).astype(np.uint64))
+    sd = gpu.sd_vector(positions=pos, n_bits=N)
+    assert sd.ones() == pos.size and sd.size() == N
+    q = np.concatenate([rng.integers(0, N + 1, 500000).astype(np.uint64), pos[:100000], pos[:100000] + np.uint64(1)])
+    r = sd.rank(q, 1)
+    assert np.array_equal(r, np.searchsorted(pos, q, side="left").astype(np.uint64))
+    i = rng.integers(1, pos.size + 1, 300000).astype(np.uint64)
+    assert np.array_equal(sd.select(i, 1), pos[(i - np.uint64(1)).astype(np.int64)])
+    assert np.array_equal(sd.access(pos[:50000]), np.ones(50000, np.uint8))
+    z = rng.integers(1, N - pos.size + 1, 20000).astype(np.uint64)
+    pz = sd.select(z, 0)
+    assert np.array_equal(sd.rank(pz, 0) + np.uint64(1), z) and np.all(sd.access(pz) == 0)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 sdsl-lite — answers AND serialised bytes (sha256 of SDSL's own streams).  This is what pins the
 oracle; the GPU parity tests then compare the HIP path with the oracle and with the same vectors."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -204,4 +205,38 @@ def test_two_bit_pattern_model(name):
         if si.size:
             assert np.array_equal(np.flatnonzero(d)[(si - np.uint64(1)).astype(np.int64)].astype(np.uint64),
                                   g[f"{name}/pat{pat}_sel"])
+
+
+@pytest.mark.parametrize("name", gd.bv_case_names())
+def test_sd_vector(name):
+    """sd_vector<> restatement against the real library's answers and serialised bytes"""
+    g = gd.bv_golden()
+    if f"{name}/sd_rank1" not in g.files:
+        pytest.skip("no sd_vector vectors for this case")
+    words, n = gd.bv_case(name)
+    sd = ol.OSd(words, n)
+    idx = g[f"{name}/idx"]
+    assert np.array_equal(sd.rank(idx[:500], 1), g[f"{name}/sd_rank1"][:500])
+    assert np.array_equal(sd.rank(idx[:200], 0), idx[:200] - g[f"{name}/sd_rank1"][:200])
+    for b in (0, 1):
+        si = g[f"{name}/sel{b}_i"][:600]
+        if si.size:
+            assert np.array_equal(sd.select(si[:300], b), g[f"{name}/sd_sel{b}"][:300])
+            assert np.array_equal(g[f"{name}/sd_sel{b}"], g[f"{name}/sel{b}"][:600])  # == the plain vector's select
+    ai = idx[idx < n]
+    assert np.array_equal(sd.access(ai[:500]), g[f"{name}/sd_acc"][:500])
+    if os.path.exists(os.path.join(gd.GOLDEN, "sdsl", f"{name}.sd_vector.sdsl")):
+        assert sd.serialize() == gd.sdsl_file(f"{name}.sd_vector.sdsl")
+
+
+def test_sd_vector_large_universe():
+    g = gd.bv_golden()
+    pos = g["sdpos/pos"]
+    sd = ol.OSd(positions=pos)
+    assert sd.size() == int(g["sdpos/n"][0]) and sd.ones() == pos.size
+    assert np.array_equal(sd.rank(g["sdpos/idx"][:800], 1), g["sdpos/rank1"][:800])
+    assert np.array_equal(sd.select(g["sdpos/sel1_i"][:500], 1), g["sdpos/sel1"][:500])
+    assert np.array_equal(sd.select(g["sdpos/sel0_i"][:100], 0), g["sdpos/sel0"][:100])
+    assert np.array_equal(pos[(g["sdpos/sel1_i"] - np.uint64(1)).astype(np.int64)], g["sdpos/sel1"])
+    assert sd.serialize() == gd.sdsl_file("sdpos.sd_vector.sdsl")
 
