@@ -68,6 +68,23 @@ constexpr bool pattern_ok(unsigned t_b, unsigned t_pat_len)
 }
 } // namespace hip_detail
 
+//! The plain bits of ANY SDSL bit-vector type that offers size() and get_int(idx, len) — bit_vector_il<>, rrr_vector<15>,
+//! hyb_vector<>, sd_vector<>, ... — as a bit_vector.  rank / select answers do not depend on the representation, so
+//! such a vector is served by handing its bits to rank_support_v5_hip / select_support_mcl_hip (plain rank lines),
+//! rrr_vector_hip (H0-compressed on the device) or sd_vector_hip (sparse).
+template <class t_bv>
+inline bit_vector to_bit_vector(t_bv const & v)
+{
+    bit_vector out(v.size(), 0);
+    uint64_t * w = out.data();
+    const uint64_t n = v.size();
+    for (uint64_t i = 0; i + 64 <= n; i += 64)
+        w[i >> 6] = v.get_int(i, 64);
+    if (n & 63)
+        w[n >> 6] = v.get_int(n & ~UINT64_C(63), (uint8_t)(n & 63));
+    return out;
+}
+
 //! Drop-in for rank_support_v5<t_b, 1> (rank_support_v5.hpp:44) with a batched member.
 template <uint8_t t_b = 1, uint8_t t_pat_len = 1>
 class rank_support_v5_hip

@@ -104,6 +104,31 @@ int main(int argc, char ** argv)
                 check_select<select_support_mcl<00, 2>, select_support_mcl_hip<00, 2>>(bv, c00(n), rng, "select_support_mcl<00,2>");
                 check_select<select_support_mcl<11, 2>, select_support_mcl_hip<11, 2>>(bv, c11(n), rng, "select_support_mcl<11,2>");
             }
+            // any other SDSL bit-vector type through its plain bits: bit_vector_il<512>, rrr_vector<15>
+            if (n <= 100000)
+            {
+                bit_vector_il<512> il(bv);
+                rrr_vector<15> r15(bv);
+                bit_vector_il<512>::rank_1_type ilr(&il);
+                rrr_vector<15>::select_1_type r15s(&r15);
+                bit_vector from_il = to_bit_vector(il), from_r15 = to_bit_vector(r15);
+                CHECK(from_il == bv and from_r15 == bv, "to_bit_vector(bit_vector_il / rrr_vector<15>)");
+                rank_support_v5_hip<1> hr(&from_il);
+                rrr_vector_hip dr(from_r15);
+                select_support_rrr_hip<1> hsel(&dr);
+                bool ok = true;
+                for (int t = 0; t < 300; ++t)
+                {
+                    uint64_t x = rng() % (n + 1);
+                    ok &= hr(x) == ilr(x);
+                    if (ones)
+                    {
+                        uint64_t k = 1 + rng() % ones;
+                        ok &= hsel(k) == r15s(k);
+                    }
+                }
+                CHECK(ok, "rank on bit_vector_il<512>, select on rrr_vector<15> through their bits");
+            }
             // sd_vector<>
             {
                 sd_vector<> sv(bv);
