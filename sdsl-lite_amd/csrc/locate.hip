@@ -262,6 +262,50 @@ __global__ __launch_bounds__(256) void k_fm_lengths(const uint64_t * __restrict_
     }
 }
 
+// extract in pieces: a range is cut at the ISA sample positions (multiples of d), so that every piece starts its walk
+// at the sample right behind it and the pieces of one long range are walked in parallel.
+// pieces of query q: floor(e/d) - floor(b/d) + 1 (0 for an invalid range); entry n is 0 (the scan turns it into the total)
+__global__ __launch_bounds__(256) void k_fm_piece_count(const uint64_t * __restrict__ b, const uint64_t * __restrict__ e,
+                                                        uint64_t size, uint64_t d, uint64_t n, uint64_t * __restrict__ cnt)
+{
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q <= n; q += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t v = 0;
+        if (q < n && b[q] <= e[q] && e[q] < size)
+            v = e[q] / d - b[q] / d + 1;
+        cnt[q] = v;
+    }
+}
+
+// piece z belongs to the query q with poff[q] <= z < poff[q+1]; it covers [max(b, k*d), min(e, (k+1)*d - 1)] with
+// k = floor(b/d) + (z - poff[q]) and writes at toff[q] + (its begin - b)
+__global__ __launch_bounds__(256) void k_fm_piece_fill(const uint64_t * __restrict__ b, const uint64_t * __restrict__ e,
+                                                       uint64_t d, const uint64_t * __restrict__ toff,
+                                                       const uint64_t * __restrict__ poff, uint64_t n, uint64_t pieces,
+                                                       uint64_t * __restrict__ pb, uint64_t * __restrict__ pe,
+                                                       uint64_t * __restrict__ po)
+{
+    for (uint64_t z = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; z < pieces; z += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t lo = 0, hi = n; // largest q with poff[q] <= z
+        while (hi - lo > 1)
+        {
+            uint64_t mid = (lo + hi) >> 1;
+            if (poff[mid] <= z)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint64_t bq = b[lo], eq = e[lo];
+        const uint64_t k = bq / d + (z - poff[lo]);
+        const uint64_t first = k * d > bq ? k * d : bq;
+        const uint64_t last = (k + 1) * d - 1 < eq ? (k + 1) * d - 1 : eq;
+        pb[z] = first;
+        pe[z] = last;
+        po[z] = toff[lo] + (first - bq);
+    }
+}
+
 // out[z] = l[p] + (z - off[p]) for the p with off[p] <= z < off[p+1]: the SA indices of all occurrences
 __global__ __launch_bounds__(256) void k_fm_expand(const uint64_t * __restrict__ l, const uint64_t * __restrict__ off,
                                                    uint64_t n, uint64_t total, uint64_t * __restrict__ out)
@@ -484,9 +528,30 @@ sdsl_hip_status sdsl_hip_fm_extract_batch(sdsl_hip_fm_t fm, const uint64_t * beg
                   (unsigned long long)cap);
         return SDSL_HIP_ERR_INVALID;
     }
+    if (*total == 0)
+        return SDSL_HIP_OK;
     Staged st;
     SH_TRY(st.out(out_text, *total));
-    SH_TRY(launch_walk<kWalkExtract>(fm, (const uint64_t *)sb.dev, (const uint64_t *)se.dev, d_off.as<uint64_t>(), n, nullptr,
+    // cut the ranges at the ISA sample positions: one walk per piece
+    const uint64_t d = fm->isa_dens;
+    DevBuf d_cnt, d_poff, d_pb, d_pe, d_po;
+    SH_TRY(d_cnt.alloc((n + 1) * 8));
+    SH_TRY(d_poff.alloc((n + 1) * 8));
+    hipLaunchKernelGGL(k_fm_piece_count, dim3(grid_for(n + 1, 256, 256u * 8u)), dim3(256), 0, s, (const uint64_t *)sb.dev,
+                       (const uint64_t *)se.dev, fm->size, d, n, d_cnt.as<uint64_t>());
+    SH_HIP(hipGetLastError());
+    SH_TRY(exclusive_scan_u64(d_cnt.as<uint64_t>(), d_poff.as<uint64_t>(), n + 1, s));
+    uint64_t pieces = 0;
+    SH_HIP(hipMemcpyAsync(&pieces, d_poff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    SH_HIP(hipStreamSynchronize(s));
+    SH_TRY(d_pb.alloc(pieces * 8));
+    SH_TRY(d_pe.alloc(pieces * 8));
+    SH_TRY(d_po.alloc(pieces * 8));
+    hipLaunchKernelGGL(k_fm_piece_fill, dim3(grid_for(pieces, 256, 256u * 16u)), dim3(256), 0, s, (const uint64_t *)sb.dev,
+                       (const uint64_t *)se.dev, d, d_off.as<uint64_t>(), d_poff.as<uint64_t>(), n, pieces,
+                       d_pb.as<uint64_t>(), d_pe.as<uint64_t>(), d_po.as<uint64_t>());
+    SH_HIP(hipGetLastError());
+    SH_TRY(launch_walk<kWalkExtract>(fm, d_pb.as<uint64_t>(), d_pe.as<uint64_t>(), d_po.as<uint64_t>(), pieces, nullptr,
                                      (uint8_t *)st.dev, s));
     SH_TRY(st.finish(s));
     SH_HIP(hipStreamSynchronize(s));

@@ -715,6 +715,11 @@ def _check_locate_api(csa, g, name, n_text):
     off, text = csa.extract(eb, ee)
     assert text.tobytes() == g[f"{name}/ext_text"].tobytes()
     assert np.array_equal(off, np.concatenate([[0], np.cumsum(ee - eb + np.uint64(1))]).astype(np.uint64))
+    # one long range (cut at the ISA samples into parallel pieces): the whole indexed sequence, sentinel included
+    offw, whole = csa.extract(np.array([0, 1], dtype=np.uint64), np.array([N - 1, N - 1], dtype=np.uint64))
+    full = np.frombuffer(gd.text(name) if name in gd.TEXTS or name == "faust.txt" else b"", dtype=np.uint8)
+    if full.size == n_text:
+        assert whole[:N].tobytes() == full.tobytes() + b"\0" and whole[N:].tobytes() == full.tobytes()[1:] + b"\0"
     # queries outside the precondition (begin > end, end >= size) yield nothing
     off2, text2 = csa.extract(np.array([5, 0, 0], dtype=np.uint64), np.array([4, N, min(3, N - 1)], dtype=np.uint64))
     assert list(off2[:3]) == [0, 0, 0] and int(off2[3]) == text2.size == min(3, N - 1) + 1
@@ -813,6 +818,8 @@ def test_fm_locate_roundtrip_large(gpu):
         assert text[int(off[q]):int(off[q + 1])].tobytes() == data[int(b[q]):int(e[q]) + 1].tobytes()
     flat = np.concatenate([data[int(x):int(y) + 1] for x, y in zip(b[:500], e[:500])])
     assert np.array_equal(text[: flat.size], flat)
+    off1, big = csa.extract(np.array([12345], dtype=np.uint64), np.array([12345 + (1 << 22)], dtype=np.uint64))
+    assert np.array_equal(big, data[12345:12345 + (1 << 22) + 1])  # 4 MiB in one range: 65537 parallel pieces
     m = 6
     st = rng.integers(0, n - m, 20000)
     pats = np.concatenate([data[s:s + m] for s in st])
