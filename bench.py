@@ -116,12 +116,39 @@ def cpu_baseline(pkg, words_dev, n_bits, idx_dev, gpu_out_dev, seconds):
     res = run(sample)
     dt = time.perf_counter() - t0
     same = bool(np.array_equal(res, gpu_out_dev[:n_s].cpu().numpy().view(np.uint64)))
-    return {
+    one = {
         "value": n_s / dt / 1e9, "unit": "Grank/s", "cores": 1, "kind": kind,
         "sample": f"first {n_s} of the step's queries, scalar loop, 1 thread; "
                   f"rank_support_v5 on the same 2^{int(np.log2(n_bits))}-bit vector (build {build_s:.1f}s)",
         "ns_per_query": dt / n_s * 1e9, "matches_gpu": same,
     }
+    # the same loop on every host core (contiguous slices of a larger prefix; queries are const-safe)
+    try:
+        threads = len(os.sched_getaffinity(0))  # the CPUs this process may run on
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    n_m = int(min(idx_dev.numel(), 250_000_000, max(n_s, threads * seconds / per_q)))
+    sample = idx_dev[:n_m].cpu().numpy().view(np.uint64)
+    outm = np.empty(n_m, dtype=np.uint64)
+    t0 = time.perf_counter()
+    if kind == "reference":
+        ol.ref().L.ref_bv_rank_mt(h, 1, sample.ctypes.data, n_m, outm.ctypes.data, threads)
+    else:
+        ol.oracle().L.orc_rank_v5_batch_mt(h, sample.ctypes.data, n_m, outm.ctypes.data, threads)
+    dtm = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    allc = {"value": n_m / dtm / 1e9, "unit": "Grank/s", "cores": threads, "kind": kind, "cpu_model": model,
+            "smt": "one thread per logical CPU of the process's affinity mask (SMT siblings included if exposed)",
+            "sample": f"first {n_m} of the step's queries, contiguous slices, {threads} threads",
+            "matches_gpu": bool(np.array_equal(outm, gpu_out_dev[:n_m].cpu().numpy().view(np.uint64)))}
+    return one, allc
 
 
 def cpu_time(run, args_dev, gpu_out_dev, seconds, unit_scale, what):
@@ -237,7 +264,8 @@ def main():
     }
 
     if rank == 0 and world == 1 and not a.no_cpu:
-        result["cpu_baseline"] = cpu_baseline(pkg, words, n_bits, idx, out, a.cpu_seconds)
+        result["cpu_baseline"], result["cpu_baseline_all_cores"] = cpu_baseline(pkg, words, n_bits, idx, out,
+                                                                                 a.cpu_seconds)
     elif rank == 0:
         result["cpu_baseline"] = None
 

@@ -13,6 +13,7 @@
 
 #include <assert.h>
 #include <stdio.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -324,6 +325,43 @@ void orc_rank_v5_batch(const orc_rank_v5 * r, const uint64_t * idx, uint64_t n, 
 {
     for (uint64_t q = 0; q < n; ++q)
         out[q] = orc_rank_v5_rank(r, idx[q]);
+}
+
+/* the same scalar loop on `threads` host threads, contiguous slices (queries are const-safe) */
+typedef struct
+{
+    const orc_rank_v5 * r;
+    const uint64_t * idx;
+    uint64_t n;
+    uint64_t * out;
+} v5_job;
+static void * v5_worker(void * a)
+{
+    v5_job * j = (v5_job *)a;
+    orc_rank_v5_batch(j->r, j->idx, j->n, j->out);
+    return NULL;
+}
+void orc_rank_v5_batch_mt(const orc_rank_v5 * r, const uint64_t * idx, uint64_t n, uint64_t * out, int threads)
+{
+    if (threads < 1)
+        threads = 1;
+    if (threads > 1024)
+        threads = 1024;
+    pthread_t * th = (pthread_t *)malloc((size_t)threads * sizeof *th);
+    v5_job * jobs = (v5_job *)malloc((size_t)threads * sizeof *jobs);
+    for (int t = 0; t < threads; ++t)
+    {
+        uint64_t lo = n * (uint64_t)t / (uint64_t)threads, hi = n * (uint64_t)(t + 1) / (uint64_t)threads;
+        jobs[t].r = r;
+        jobs[t].idx = idx + lo;
+        jobs[t].n = hi - lo;
+        jobs[t].out = out + lo;
+        pthread_create(&th[t], NULL, v5_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t)
+        pthread_join(th[t], NULL);
+    free(th);
+    free(jobs);
 }
 
 size_t orc_rank_v5_serialize(const orc_rank_v5 * r, orc_buf * out) /* :160-167 — int_vector<64> */

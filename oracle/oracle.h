@@ -44,6 +44,7 @@ orc_rank_v5 * orc_rank_v5_build(const uint64_t * words, uint64_t n_bits, int bit
 void orc_rank_v5_free(orc_rank_v5 *);
 uint64_t orc_rank_v5_rank(const orc_rank_v5 *, uint64_t idx); /* rank_support_v5.hpp:131-149 */
 void orc_rank_v5_batch(const orc_rank_v5 *, const uint64_t * idx, uint64_t n, uint64_t * out);
+void orc_rank_v5_batch_mt(const orc_rank_v5 *, const uint64_t * idx, uint64_t n, uint64_t * out, int threads);
 size_t orc_rank_v5_serialize(const orc_rank_v5 *, orc_buf * out); /* rank_support_v5.hpp:160-167 */
 
 /* ---- select_support_mcl<b,1> ------------------------------------------------------------ */

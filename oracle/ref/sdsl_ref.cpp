@@ -3,6 +3,7 @@
 // Built by oracle/Makefile into oracle/_ref/libsdsl_ref.so.  TEST INFRASTRUCTURE ONLY: it pins the
 // C restatement (oracle.c), generates the golden fixtures (tests/golden/make_golden.py) and serves
 // as bench.py's cpu_baseline of kind "reference".  It is never loaded by the product library.
+#include <thread>
 #include <sdsl/bit_vectors.hpp>
 #include <sdsl/suffix_arrays.hpp>
 #include <sdsl/wavelet_trees.hpp>
@@ -105,6 +106,20 @@ void ref_bv_rank(void * p, int bit, const uint64_t * idx, uint64_t n, uint64_t *
     else
         for (uint64_t q = 0; q < n; ++q)
             out[q] = h->r0(idx[q]);
+}
+// the same scalar loop on `threads` host threads, contiguous slices (queries are const-safe: SURVEY.md §8(b))
+void ref_bv_rank_mt(void * p, int bit, const uint64_t * idx, uint64_t n, uint64_t * out, int threads)
+{
+    if (threads < 1)
+        threads = 1;
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t)
+    {
+        uint64_t lo = n * (uint64_t)t / threads, hi = n * (uint64_t)(t + 1) / threads;
+        th.emplace_back([=] { ref_bv_rank(p, bit, idx + lo, hi - lo, out + lo); });
+    }
+    for (auto & x : th)
+        x.join();
 }
 void ref_bv_rank_v(void * p, const uint64_t * idx, uint64_t n, uint64_t * out)
 {

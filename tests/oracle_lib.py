@@ -67,6 +67,7 @@ _ORC_SIGS = {
     "orc_rank_v5_free": (None, [_vp]),
     "orc_rank_v5_rank": (_u64, [_vp, _u64]),
     "orc_rank_v5_batch": (None, [_vp, _vp, _u64, _vp]),
+    "orc_rank_v5_batch_mt": (None, [_vp, _vp, _u64, _vp, C.c_int]),
     "orc_rank_v5_serialize": (C.c_size_t, [_vp, C.POINTER(OrcBuf)]),
     "orc_select_mcl_build": (_vp, [_vp, _u64, C.c_int]),
     "orc_select_mcl_free": (None, [_vp]),
@@ -456,6 +457,7 @@ _REF_SIGS = {
     "ref_bv_create": (_vp, [_vp, _u64]),
     "ref_bv_destroy": (None, [_vp]),
     "ref_bv_rank": (None, [_vp, C.c_int, _vp, _u64, _vp]),
+    "ref_bv_rank_mt": (None, [_vp, C.c_int, _vp, _u64, _vp, C.c_int]),
     "ref_bv_rank_v": (None, [_vp, _vp, _u64, _vp]),
     "ref_bv_select": (None, [_vp, C.c_int, _vp, _u64, _vp]),
     "ref_bv_serialize": (None, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
