@@ -56,15 +56,22 @@ def _worker(rank, world, port, n_q, out_path):
         pats = torch.zeros(0, dtype=torch.uint8)
     r = pkg.dist.sharded_query(rank_fn, (idx,), n_q)
     c = pkg.dist.sharded_query(count_fn, (pats,), n_q, widths=(m,))
+    # pipelined: the batch in three pieces, scatter / answer / gather of neighbouring pieces overlap
+    r3 = pkg.dist.sharded_query(rank_fn, (idx,), n_q, chunks=3)
+    c3 = pkg.dist.sharded_query(count_fn, (pats,), n_q, widths=(m,), chunks=3)
+    # load-time replication of an index input: rank 0 owns the words, every rank ends up with the same tensor
+    words = torch.from_numpy(w.astype(np.int64)) if rank == 0 else None
+    got = pkg.dist.replicate(words, torch.zeros(0, dtype=torch.int64))
+    assert np.array_equal(got.numpy().astype(np.uint64), w)
     lo, hi = pkg.dist.shard_bounds(n_q, world, rank)
     slow = pkg.dist.max_over_ranks(float(rank + 1), "cpu")
     assert slow == float(world)
     if rank == 0:
-        ok_r = np.array_equal(r.numpy().astype(np.uint64), bv.rank(idx.numpy().astype(np.uint64)))
-        ok_c = np.array_equal(c.numpy().astype(np.uint64), csa.count_batch(pats.numpy(), m))
+        ok_r = np.array_equal(r.numpy().astype(np.uint64), bv.rank(idx.numpy().astype(np.uint64))) and torch.equal(r, r3)
+        ok_c = np.array_equal(c.numpy().astype(np.uint64), csa.count_batch(pats.numpy(), m)) and torch.equal(c, c3)
         open(out_path, "w").write(f"{int(ok_r)}{int(ok_c)} {lo} {hi}")
     else:
-        assert r is None and c is None
+        assert r is None and c is None and r3 is None and c3 is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -62,4 +62,5 @@ def test_two_ranks_sharded_fm_count(gpu):
     assert fs["patterns_total"] == 200000 and fs["resident_shards"]["all_patterns_found"] is True
     assert fs["root_owned_batch_matches"] is True
     assert fs["resident_shards"]["Mcount/s"] > 0 and fs["root_owned_batch"]["Mcount/s"] > 0
+    assert fs["root_owned_batch_pipelined"]["matches"] is True and fs["text_broadcast_s"] >= 0
 
