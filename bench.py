@@ -445,6 +445,32 @@ def main():
                 del crrr
 
         if "fm_sharded" in extras and world > 1:
+            # the headline queries as a ROOT-OWNED batch (the end-to-end column): rank 0 holds all
+            # world * nq positions, scatter -> rank kernel -> gather in eight pipelined pieces.  16 bytes per query cross
+            # xGMI, so this column is link-bound by construction; the resident-shard figure above is the kernel column.
+            stage0 = (lambda t: t) if a.backend == "nccl" else (lambda t: t.cpu())
+            nro = min(nq, 250_000_000) * world
+            allq = stage0(torch.randint(0, n_bits + 1, (nro,), device=dev, dtype=torch.int64, generator=gq)) if rank == 0 \
+                else stage0(torch.empty(1, dtype=torch.int64, device=dev))
+
+            def local_rank(x):
+                xd = x.to(dev)
+                return stage0(bv.rank(xd, 1))
+
+            pkg.dist.sharded_query(local_rank, (allq,), nro, chunks=8)
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            ro = pkg.dist.sharded_query(local_rank, (allq,), nro, chunks=8)
+            torch.cuda.synchronize()
+            barrier()
+            dt = pkg.dist.max_over_ranks(time.perf_counter() - t0, comm_dev)
+            ex["rank_root_owned_batch"] = {"Grank/s": nro / dt / 1e9, "ms": dt * 1e3, "queries": nro, "pieces": 8,
+                                           "bytes_over_links_per_query": 16}
+            if rank == 0:
+                chk = bv.rank(allq[:1_000_000].to(dev), 1)
+                ex["rank_root_owned_batch"]["matches_local"] = bool(torch.equal(stage0(chk), ro[:1_000_000]))
+            del allq, ro
             # configs[4]: count() on a 1 GiB text, 10^8 20-byte patterns sharded across the ranks (strong scaling).
             # The FM-index is replicated (every rank builds it from the same text on its own GPU); (a) resident
             # shards: every rank answers its slice of the batch, no collective; (b) root-owned batch: rank 0 holds the

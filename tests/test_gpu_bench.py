@@ -63,4 +63,6 @@ def test_two_ranks_sharded_fm_count(gpu):
     assert fs["root_owned_batch_matches"] is True
     assert fs["resident_shards"]["Mcount/s"] > 0 and fs["root_owned_batch"]["Mcount/s"] > 0
     assert fs["root_owned_batch_pipelined"]["matches"] is True and fs["text_broadcast_s"] >= 0
+    ro = d["extras"]["rank_root_owned_batch"]
+    assert ro["queries"] == 2 * 2000000 and ro["matches_local"] is True and ro["Grank/s"] > 0
 
