@@ -213,6 +213,12 @@ sdsl_hip_status sdsl_hip_fm_create_from_sdsl_ex(const void * bytes, size_t len, 
 sdsl_hip_status sdsl_hip_fm_serialize(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens, void * buf, size_t cap,
                                       size_t * written);
 sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm);
+/* Jump-start table of count / interval / locate: the SA interval of every k-mer over the index's alphabet (16 bytes
+ * each), read with the last k characters of a pattern instead of walking their k LF steps.  The entries are computed by
+ * the search itself, so answers do not change.  Every index gets a default depth at creation (table <= half the wavelet
+ * tree, >= 64 MiB allowed); k = 0 drops the table, a larger k trades HBM for speed (sigma^k entries). */
+sdsl_hip_status sdsl_hip_fm_set_jump_depth(sdsl_hip_fm_t fm, uint32_t k);
+uint32_t sdsl_hip_fm_jump_depth(sdsl_hip_fm_t fm);
 sdsl_hip_status sdsl_hip_fm_destroy(sdsl_hip_fm_t fm);
 uint64_t sdsl_hip_fm_size(sdsl_hip_fm_t fm);  /* csa.size() = text length + 1 */
 uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm); /* csa.sigma */

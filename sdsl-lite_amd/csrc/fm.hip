@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_fm_keys(const uint8_t * __restrict__ pa
 // paths differ in length; a nested loop would cost max(len) instead of len per character).  The next pattern byte is
 // fetched one character ahead.
 template <bool NT, bool WANT_IVAL>
-__global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables * __restrict__ ftab,
+__global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables * __restrict__ ftab, FmJump J,
                                                      uint64_t csa_size, const uint8_t * __restrict__ pats,
                                                      uint32_t m, const uint64_t * __restrict__ offsets,
                                                      const uint32_t * __restrict__ order, uint64_t n_pat,
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
             r = 0;
             end = begin;
         }
-        uint64_t it = end;
+        uint64_t it = fm_jump_start(J, F, pats, begin, end, l, r);
         unsigned c_next = it > begin ? pats[it - 1] : 0;
         // state of the character being processed
         unsigned left = 0, v = 0;
@@ -131,6 +131,37 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
             else
                 out_cnt[q] = r + 1 - l;
         }
+    }
+}
+
+// all k-mers over the compact alphabet as patterns: pattern `idx` spells the key digits of fm_jump_start (first digit =
+// the LAST character)
+__global__ __launch_bounds__(256) void k_fm_kmers(const FmTables * __restrict__ ftab, uint32_t sigma, uint32_t k,
+                                                  uint64_t count, uint8_t * __restrict__ pats)
+{
+    __shared__ uint8_t comp2char[256];
+    for (unsigned c = threadIdx.x; c < 256; c += blockDim.x)
+        if (ftab->char2comp[c] || c == 0)
+            comp2char[ftab->char2comp[c]] = (uint8_t)c;
+    __syncthreads();
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint64_t key = idx;
+        for (uint32_t t = 0; t < k; ++t)
+        { // least significant digit = the character processed last = the FIRST byte of the k-mer
+            pats[idx * k + t] = comp2char[key % sigma];
+            key /= sigma;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fm_pack_jump(const uint64_t * __restrict__ l, const uint64_t * __restrict__ r,
+                                                      uint64_t count, uint64_t * __restrict__ tab)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        tab[2 * i] = l[i];
+        tab[2 * i + 1] = r[i];
     }
 }
 
@@ -232,6 +263,9 @@ static sdsl_hip_status fm_upload_tables(sdsl_hip_fm_s * f)
     return SDSL_HIP_OK;
 }
 
+static sdsl_hip_status fm_build_jump(sdsl_hip_fm_s * f);
+static sdsl_hip_status fm_build_jump_k(sdsl_hip_fm_s * f, uint32_t k);
+
 static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_bwt, uint64_t n, int device,
                                           uint32_t flags)
 {
@@ -250,7 +284,8 @@ static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_b
         return SDSL_HIP_ERR_INVALID;
     }
     alphabet_from_counts(f, w.occ);
-    return fm_upload_tables(f);
+    SH_TRY(fm_upload_tables(f));
+    return fm_build_jump(f);
 }
 
 extern "C" {
@@ -429,6 +464,8 @@ sdsl_hip_status sdsl_hip_fm_create_from_sdsl_ex(const void * bytes, size_t len, 
             }
             else
                 st = fm_upload_tables(f);
+            if (st == SDSL_HIP_OK)
+                st = fm_build_jump(f);
             if (st == SDSL_HIP_OK && keep)
             {
                 const uint64_t n = f->size;
@@ -452,6 +489,21 @@ sdsl_hip_status sdsl_hip_fm_create_from_sdsl_ex(const void * bytes, size_t len, 
     }
     *out = f;
     return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_set_jump_depth(sdsl_hip_fm_t fm, uint32_t k)
+{
+    if (!fm)
+    {
+        set_error("fm_set_jump_depth: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_HIP(hipSetDevice(fm->device));
+    return fm_build_jump_k(fm, k);
+}
+uint32_t sdsl_hip_fm_jump_depth(sdsl_hip_fm_t fm)
+{
+    return fm ? fm->jump_k : 0;
 }
 
 sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
@@ -538,7 +590,7 @@ uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm)
 }
 uint64_t sdsl_hip_fm_device_bytes(sdsl_hip_fm_t fm)
 {
-    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes + fm->d_sa_s.bytes + fm->d_isa_s.bytes : 0;
+    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes + fm->d_sa_s.bytes + fm->d_isa_s.bytes + fm->d_jump.bytes : 0;
 }
 sdsl_hip_wt_t sdsl_hip_fm_wavelet_tree(sdsl_hip_fm_t fm)
 {
@@ -556,8 +608,9 @@ sdsl_hip_status sdsl_hip_fm_alphabet(sdsl_hip_fm_t fm, uint8_t char2comp_out[256
 
 static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m, const uint64_t * offsets,
                               uint64_t total_bytes, uint64_t n_pat, uint64_t * out_cnt, uint64_t * out_l,
-                              uint64_t * out_r, hipStream_t s)
+                              uint64_t * out_r, hipStream_t s, bool use_jump = true)
 {
+    const FmJump jump = use_jump ? fm->jump() : FmJump{nullptr, 0, 0};
     SH_HIP(hipSetDevice(fm->device));
     if (n_pat == 0)
         return SDSL_HIP_OK;
@@ -601,7 +654,7 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
     }
     if (w.backend == 1)
     {
-        SH_TRY(fm_rrr_launch_count(w, fm->d_tab.as<FmTables>(), fm->size, (const uint8_t *)sp.dev, m,
+        SH_TRY(fm_rrr_launch_count(w, fm->d_tab.as<FmTables>(), jump, fm->size, (const uint8_t *)sp.dev, m,
                                    offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat,
                                    ival ? nullptr : (uint64_t *)sc.dev, ival ? (uint64_t *)sl.dev : nullptr,
                                    ival ? (uint64_t *)sr.dev : nullptr, s));
@@ -610,12 +663,12 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
     {
         if (ival)
             hipLaunchKernelGGL((k_fm_count<false, true>), dim3(grid), dim3(kBlock), 0, s, w.view(),
-                               fm->d_tab.as<FmTables>(), fm->size, (const uint8_t *)sp.dev, m,
+                               fm->d_tab.as<FmTables>(), jump, fm->size, (const uint8_t *)sp.dev, m,
                                offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat, (uint64_t *)nullptr,
                                (uint64_t *)sl.dev, (uint64_t *)sr.dev);
         else
             hipLaunchKernelGGL((k_fm_count<false, false>), dim3(grid), dim3(kBlock), 0, s, w.view(),
-                               fm->d_tab.as<FmTables>(), fm->size, (const uint8_t *)sp.dev, m,
+                               fm->d_tab.as<FmTables>(), jump, fm->size, (const uint8_t *)sp.dev, m,
                                offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat, (uint64_t *)sc.dev,
                                (uint64_t *)nullptr, (uint64_t *)nullptr);
     }
@@ -631,6 +684,67 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
         SH_TRY(sc.finish(s));
     if (sp.host || so.host)
         SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+// The jump-start table (fm_device.hpp FmJump), filled by the search kernel itself on all k-mers.  Default depth: the
+// largest k whose table (16 bytes per k-mer) stays within half the size of the wavelet tree (at least 64 MiB) and
+// within 4 * size entries; sdsl_hip_fm_set_jump_depth() chooses another one, SDSL_HIP_FM_JUMP=<k> overrides the default
+// (0 = none; profiling).
+static sdsl_hip_status fm_build_jump_k(sdsl_hip_fm_s * f, uint32_t k);
+
+static sdsl_hip_status fm_build_jump(sdsl_hip_fm_s * f)
+{
+    const uint64_t sigma = f->sigma;
+    if (sigma < 2)
+        return SDSL_HIP_OK;
+    if (const char * e = getenv("SDSL_HIP_FM_JUMP"))
+        return fm_build_jump_k(f, (uint32_t)std::max(0, atoi(e)));
+    const uint64_t budget = std::max<uint64_t>(UINT64_C(64) << 20, sdsl_hip_wt_device_bytes(f->wt) / 2) / 16;
+    const uint64_t cap = std::min<uint64_t>(budget, 4 * f->size);
+    uint32_t k = 0;
+    uint64_t count = 1;
+    while (count * sigma <= cap && k < 8)
+    {
+        count *= sigma;
+        ++k;
+    }
+    return fm_build_jump_k(f, k);
+}
+
+static sdsl_hip_status fm_build_jump_k(sdsl_hip_fm_s * f, uint32_t k)
+{
+    f->jump_k = 0;
+    f->d_jump.release();
+    const uint64_t sigma = f->sigma;
+    if (k == 0 || sigma < 2)
+        return SDSL_HIP_OK;
+    uint64_t count = 1;
+    for (uint32_t t = 0; t < k; ++t)
+    {
+        if (count > (UINT64_C(1) << 34) / sigma)
+        {
+            set_error("fm jump table: %u characters over an alphabet of %llu symbols is too deep", k,
+                      (unsigned long long)sigma);
+            return SDSL_HIP_ERR_INVALID;
+        }
+        count *= sigma;
+    }
+    DevBuf d_p, d_l, d_r;
+    SH_TRY(d_p.alloc(count * k));
+    SH_TRY(d_l.alloc(count * 8));
+    SH_TRY(d_r.alloc(count * 8));
+    SH_TRY(f->d_jump.alloc(count * 16));
+    hipLaunchKernelGGL(k_fm_kmers, dim3(grid_for(count, 256, 65536)), dim3(256), 0, 0, f->d_tab.as<FmTables>(), (uint32_t)sigma,
+                       k, count, d_p.as<uint8_t>());
+    SH_HIP(hipGetLastError());
+    SH_TRY(fm_run(f, d_p.as<uint8_t>(), k, nullptr, count * k, count, nullptr, d_l.as<uint64_t>(), d_r.as<uint64_t>(), nullptr,
+                  false));
+    hipLaunchKernelGGL(k_fm_pack_jump, dim3(grid_for(count, 256, 65536)), dim3(256), 0, 0, d_l.as<uint64_t>(),
+                       d_r.as<uint64_t>(), count, f->d_jump.as<uint64_t>());
+    SH_HIP(hipGetLastError());
+    SH_HIP(hipDeviceSynchronize());
+    f->jump_k = k;
     return SDSL_HIP_OK;
 }
 

@@ -21,10 +21,44 @@ __device__ __forceinline__ void fm_stage_tables(FmTables * lds, const FmTables *
     // callers follow with wt_stage_tables(), which ends in __syncthreads()
 }
 
+// Jump-start table of backward search: the SA interval after the LAST k characters of a pattern, for every k-mer over
+// the compact alphabet (key = digits char2comp[p[m-1]], char2comp[p[m-2]], ... in base sigma, first digit most
+// significant).  One 16-byte read replaces the first k LF steps — the expensive ones, whose two cascades still walk
+// different lines.  The entries are what the search kernel itself computes for the k-mer, so every answer (including
+// the (l, r) of an empty interval) is unchanged.
+struct FmJump
+{
+    const uint64_t * tab; // (l, r) pairs, sigma^k of them; null = no table
+    uint32_t k, sigma;
+};
+
+// the interval after the last J.k characters of pattern [begin, end), if the table applies; returns the new `it`
+__device__ __forceinline__ uint64_t fm_jump_start(const FmJump & J, const FmTables & F, const uint8_t * __restrict__ pats,
+                                                  uint64_t begin, uint64_t end, uint64_t & l, uint64_t & r)
+{
+    if (!J.tab || end - begin < J.k)
+        return end;
+    uint64_t key = 0;
+    bool ok = true;
+    for (uint32_t t = 0; t < J.k; ++t)
+    {
+        const unsigned c = pats[end - 1 - t];
+        const unsigned cc = F.char2comp[c];
+        ok = ok && !(cc == 0 && c > 0); // a character that does not occur: leave it to the search (it ends there)
+        key = key * J.sigma + cc;
+    }
+    if (!ok)
+        return end;
+    const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(J.tab + 2 * key);
+    l = e.x;
+    r = e.y;
+    return end - J.k;
+}
+
 struct WtHost;
-sdsl_hip_status fm_rrr_launch_count(const WtHost & wt, const FmTables * d_tab, uint64_t csa_size, const uint8_t * d_pats,
-                                    uint32_t m, const uint64_t * d_offsets, const uint32_t * d_order, uint64_t n_pat,
-                                    uint64_t * d_cnt, uint64_t * d_l, uint64_t * d_r, hipStream_t s);
+sdsl_hip_status fm_rrr_launch_count(const WtHost & wt, const FmTables * d_tab, FmJump jump, uint64_t csa_size,
+                                    const uint8_t * d_pats, uint32_t m, const uint64_t * d_offsets, const uint32_t * d_order,
+                                    uint64_t n_pat, uint64_t * d_cnt, uint64_t * d_l, uint64_t * d_r, hipStream_t s);
 sdsl_hip_status fm_rrr_launch_backward_step(const WtHost & wt, const FmTables * d_tab, uint64_t csa_size,
                                             const uint64_t * d_l, const uint64_t * d_r, const uint8_t * d_c, uint64_t n,
                                             uint64_t * d_lo, uint64_t * d_ro, hipStream_t s);

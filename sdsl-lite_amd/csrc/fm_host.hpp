@@ -26,6 +26,16 @@ struct sdsl_hip_fm_s
     sdslhip::DevBuf d_sa_s, d_isa_s;
     uint32_t sa_dens = 0, isa_dens = 0;
     uint64_t n_sa_s = 0, n_isa_s = 0;
+    sdslhip::DevBuf d_jump; // jump-start table (fm_device.hpp FmJump), sigma^jump_k (l, r) pairs
+    uint32_t jump_k = 0;
+    sdslhip::FmJump jump() const
+    {
+        sdslhip::FmJump j;
+        j.tab = jump_k ? d_jump.as<uint64_t>() : nullptr;
+        j.k = jump_k;
+        j.sigma = sigma;
+        return j;
+    }
 };
 
 namespace sdslhip {

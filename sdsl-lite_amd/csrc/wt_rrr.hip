@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_wt_select_rrr(WtView wt, const 
 // count / interval (suffix_array_algorithm.hpp:228-248, 464-471), one pattern per lane.  Both cascades of an LF
 // step (rank at l and at r+1, :195-196) advance level by level (rrr_rank2).
 template <bool WANT_IVAL>
-__global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const FmTables * __restrict__ ftab,
+__global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const FmTables * __restrict__ ftab, FmJump J,
                                                               uint64_t csa_size, const uint8_t * __restrict__ pats,
                                                               uint32_t m, const uint64_t * __restrict__ offsets,
                                                               const uint32_t * __restrict__ order, uint64_t n_pat,
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const F
             r = 0;
             end = begin;
         }
-        uint64_t it = end;
+        uint64_t it = fm_jump_start(J, F, pats, begin, end, l, r);
         unsigned c_next = it > begin ? pats[it - 1] : 0;
         unsigned left = 0, v = 0;
         uint64_t a = 0, b = 0, p = 0, cb = 0;
@@ -340,18 +340,18 @@ sdsl_hip_status wt_rrr_launch_inverse_select(const WtHost & wt, const uint64_t *
     return SDSL_HIP_OK;
 }
 
-sdsl_hip_status fm_rrr_launch_count(const WtHost & wt, const FmTables * d_tab, uint64_t csa_size, const uint8_t * d_pats,
-                                    uint32_t m, const uint64_t * d_offsets, const uint32_t * d_order, uint64_t n_pat,
-                                    uint64_t * d_cnt, uint64_t * d_l, uint64_t * d_r, hipStream_t s)
+sdsl_hip_status fm_rrr_launch_count(const WtHost & wt, const FmTables * d_tab, FmJump jump, uint64_t csa_size,
+                                    const uint8_t * d_pats, uint32_t m, const uint64_t * d_offsets, const uint32_t * d_order,
+                                    uint64_t n_pat, uint64_t * d_cnt, uint64_t * d_l, uint64_t * d_r, hipStream_t s)
 {
     if (n_pat == 0)
         return SDSL_HIP_OK;
     if (d_l)
         hipLaunchKernelGGL((k_fm_count_rrr<true>), dim3(wt_rrr_grid(n_pat)), dim3(kWtRrrBlock), 0, s, wt.view(), d_tab,
-                           csa_size, d_pats, m, d_offsets, d_order, n_pat, (uint64_t *)nullptr, d_l, d_r);
+                           jump, csa_size, d_pats, m, d_offsets, d_order, n_pat, (uint64_t *)nullptr, d_l, d_r);
     else
         hipLaunchKernelGGL((k_fm_count_rrr<false>), dim3(wt_rrr_grid(n_pat)), dim3(kWtRrrBlock), 0, s, wt.view(), d_tab,
-                           csa_size, d_pats, m, d_offsets, d_order, n_pat, d_cnt, (uint64_t *)nullptr, (uint64_t *)nullptr);
+                           jump, csa_size, d_pats, m, d_offsets, d_order, n_pat, d_cnt, (uint64_t *)nullptr, (uint64_t *)nullptr);
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }

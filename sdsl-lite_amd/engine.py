@@ -471,6 +471,13 @@ class csa_wt(_Handle):
     def drop_sa(self):
         capi.check(capi.lib().sdsl_hip_fm_drop_sa(self._h))
 
+    def jump_depth(self) -> int:
+        """characters of a pattern answered by the k-mer interval table instead of LF steps"""
+        return capi.lib().sdsl_hip_fm_jump_depth(self._h)
+
+    def set_jump_depth(self, k: int):
+        capi.check(capi.lib().sdsl_hip_fm_set_jump_depth(self._h, k))
+
     def alphabet(self):
         c2c = np.zeros(256, dtype=np.uint8)
         Cc = np.zeros(257, dtype=np.uint64)

@@ -257,6 +257,31 @@ def test_fm_golden(gpu, name, how):
         assert np.array_equal(l, g[f"{name}/ival_l{m}"]) and np.array_equal(r, g[f"{name}/ival_r{m}"])
 
 
+@pytest.mark.parametrize("rrr", [False, True])
+def test_fm_jump_table_depths_do_not_change_answers(gpu, rrr):
+    """count / interval / locate with the k-mer jump table at depths 0..4 against the golden vectors (which hold
+    patterns with absent characters, patterns shorter than the depth and empty intervals)"""
+    name = "faust.txt"
+    g = _fm_cases(name)
+    csa = gpu.csa_wt(text=gd.text(name), rrr=rrr)
+    assert csa.jump_depth() >= 1  # the default table exists
+    for k in (0, 1, 2, 3, 4):
+        csa.set_jump_depth(k)
+        assert csa.jump_depth() == k
+        for m in (1, 2, 4, 20):
+            pats = g[f"{name}/pat{m}"]
+            assert np.array_equal(csa.count(pats, m), g[f"{name}/count{m}"])
+            l, r = csa.interval(pats, m)
+            assert np.array_equal(l, g[f"{name}/ival_l{m}"]) and np.array_equal(r, g[f"{name}/ival_r{m}"])
+        kk = int(g[f"{name}/loc_n4"][0])
+        off, pos = csa.locate(g[f"{name}/pat4"][: kk * 4], 4)
+        assert np.array_equal(off, g[f"{name}/loc_off4"]) and np.array_equal(pos, g[f"{name}/loc_pos4"])
+        assert list(csa.count_ragged([b"", b"und", b"e", b"Faust", b"\xff\xfe", b"x" * 300000])) == \
+            [csa.size(), 690, 22513, 53, 0, 0]
+    with pytest.raises(gpu.capi.SdslHipError):
+        csa.set_jump_depth(9)  # 92^9 entries: refused
+
+
 @pytest.mark.parametrize("name,which", [("example01.txt", "csa_wt_huff_v5"), ("faust.txt", "csa_wt_huff_v5"),
                                         ("example01.txt", "csa_fm_huff"), ("faust.txt", "csa_fm_huff")])
 def test_fm_loads_sdsl_stream(gpu, name, which):
