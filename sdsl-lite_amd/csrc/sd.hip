@@ -44,20 +44,67 @@ __device__ __forceinline__ uint64_t sd_low(const SdView & v, uint64_t i)
     return read_bits(v.low, i * v.wl, v.wl);
 }
 
+// position of the first zero at or after p inside the rank line of p (all four lanes); NPOS if that line has none
+template <bool NT>
+__device__ __forceinline__ uint64_t quad_next_zero_in_line(const BvView & bv, int s, uint64_t p)
+{
+    const uint64_t L = p / kDB;
+    const unsigned off = (unsigned)(p - L * kDB);
+    const Pair w = load_pair<NT>(bv.lines, L, s);
+    unsigned best = 0xFFFFFFFFu;
+    // lane s holds data words 2s-1 (.a; lane 0 holds the header there) and 2s (.b); data word d covers [64d, 64d+64)
+    if (s > 0)
+    {
+        const unsigned base = 64u * (unsigned)(2 * s - 1);
+        uint64_t z = ~w.a;
+        if (base + 64 <= off)
+            z = 0;
+        else if (base < off)
+            z &= ~lo_set(off - base);
+        if (z)
+            best = base + (unsigned)__builtin_ctzll(z);
+    }
+    if (best == 0xFFFFFFFFu)
+    {
+        const unsigned base = 64u * (unsigned)(2 * s);
+        uint64_t z = ~w.b;
+        if (base + 64 <= off)
+            z = 0;
+        else if (base < off)
+            z &= ~lo_set(off - base);
+        if (z)
+            best = base + (unsigned)__builtin_ctzll(z);
+    }
+    unsigned o = quad_xor1(best);
+    best = best < o ? best : o;
+    o = quad_xor2(best);
+    best = best < o ? best : o;
+    return best == 0xFFFFFFFFu ? SDSL_HIP_NPOS : L * kDB + best;
+}
+
 // number of ones in [0, x), x in [0, n]; all four lanes return it.  *hit (optional) = "bit x is set" (x < n)
 template <bool NT>
 __device__ __forceinline__ uint64_t quad_sd_rank1(const SdView & v, int s, uint64_t x, bool * hit)
 {
     const uint64_t h = x >> v.wl, val_low = x & lo_set(v.wl);
+    // The bucket of high part h is the run of ones between the h-th and the (h+1)-th zero of `high`.  One select_0
+    // finds the h-th zero; the next zero almost always lies in the same 448-bit line (a bucket holds ~1 entry on
+    // average), so it is read off that line instead of paying a second select.
     bool mine;
-    uint64_t p = quad_select<0, NT>(v.high, s, h, mine); // the (h+1)-th zero
-    const uint64_t end = quad_gather_u64(p, mine) - h;   // entries with high part <= h
-    uint64_t begin = 0;                                  // entries with high part < h
+    uint64_t start = 0; // first position of the bucket's run in `high`
     if (h > 0)
     {
-        p = quad_select<0, NT>(v.high, s, h - 1, mine);
-        begin = quad_gather_u64(p, mine) - (h - 1);
+        const uint64_t p = quad_select<0, NT>(v.high, s, h - 1, mine);
+        start = quad_gather_u64(p, mine) + 1;
     }
+    const uint64_t begin = start - h; // entries with high part < h
+    uint64_t nz = quad_next_zero_in_line<NT>(v.high, s, start);
+    if (nz == SDSL_HIP_NPOS)
+    { // the run leaves the line: a clustered bucket
+        const uint64_t p = quad_select<0, NT>(v.high, s, h, mine);
+        nz = quad_gather_u64(p, mine);
+    }
+    const uint64_t end = nz - h; // entries with high part <= h
     uint64_t lo = begin, hi = end; // first entry of the bucket with low part >= val_low
     while (lo < hi)
     {
