@@ -811,6 +811,13 @@ sdsl_hip_status sdsl_hip_bv_rank_batch(sdsl_hip_bv_t bv, int32_t bit, const uint
     }
     hipStream_t s = (hipStream_t)stream;
     SH_HIP(hipSetDevice(bv->h.device));
+    if (n >= kPipelineMinQueries && !is_device_ptr(idx) && !is_device_ptr(out))
+    { // host arrays on both sides: chunked, uploads / kernels / downloads overlapped on several streams
+        const BvView v = bv->h.view;
+        return host_pipeline_u64(bv->h.device, idx, out, n,
+                                 [v, bit](const uint64_t * d_in, uint64_t * d_out, uint64_t cnt, hipStream_t st)
+                                 { return bv_launch_rank(v, bit, d_in, cnt, d_out, st); });
+    }
     Staged in, o;
     SH_TRY(in.in(idx, n * 8, s));
     SH_TRY(o.out(out, n * 8));
@@ -831,6 +838,13 @@ sdsl_hip_status sdsl_hip_bv_select_batch(sdsl_hip_bv_t bv, int32_t bit, const ui
     }
     hipStream_t s = (hipStream_t)stream;
     SH_HIP(hipSetDevice(bv->h.device));
+    if (n >= kPipelineMinQueries && !is_device_ptr(i) && !is_device_ptr(out))
+    {
+        const BvView v = bv->h.view;
+        return host_pipeline_u64(bv->h.device, i, out, n,
+                                 [v, bit](const uint64_t * d_in, uint64_t * d_out, uint64_t cnt, hipStream_t st)
+                                 { return bv_launch_select(v, bit, d_in, cnt, d_out, st); });
+    }
     Staged in, o;
     SH_TRY(in.in(i, n * 8, s));
     SH_TRY(o.out(out, n * 8));

@@ -8,8 +8,14 @@ namespace sdslhip {
 
 static thread_local std::string g_err;
 static bool g_timing = false;
+static thread_local bool g_timing_suppressed = false; // pipeline workers: the event pair is global
 static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static bool g_ev_valid = false;
+
+const char * last_error_message()
+{
+    return g_err.c_str();
+}
 
 void set_error(const char * fmt, ...)
 {
@@ -132,7 +138,12 @@ sdsl_hip_status Staged::finish(hipStream_t s)
     return SDSL_HIP_OK;
 }
 
-KernelTimer::KernelTimer(hipStream_t stream) : s(stream), on(g_timing)
+void suppress_timing_in_this_thread()
+{
+    g_timing_suppressed = true;
+}
+
+KernelTimer::KernelTimer(hipStream_t stream) : s(stream), on(g_timing && !g_timing_suppressed)
 {
     if (!on)
         return;

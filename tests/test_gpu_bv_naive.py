@@ -106,3 +106,29 @@ def test_device_tensors_and_stream(gpu):
     pos = np.nonzero(bits)[0]
     got = bv.select(i).cpu().numpy()
     assert np.array_equal(got, pos[i.cpu().numpy() - 1])
+
+
+def test_host_arrays_take_the_pipelined_path(gpu):
+    """>= 2^23 queries in host arrays: chunks on two streams (upload / kernel / download overlapped) — same answers as
+    the device-resident call, including a ragged last chunk and out-of-range arguments"""
+    import torch
+    n = (1 << 26) + 77
+    w = gpu.set_random_bits(n, 3)
+    bv = gpu.bit_vector(w, n)
+    rng = np.random.default_rng(2)
+    nq = (1 << 23) + (1 << 22) + 12345
+    idx = rng.integers(0, n + 1, nq).astype(np.uint64)
+    idx[5] = n + 9  # outside: NPOS
+    out = np.empty(nq, dtype=np.uint64)
+    bv.rank(idx, 1, out)
+    dev = bv.rank(torch.from_numpy(idx.view(np.int64)).cuda(), 1).cpu().numpy().view(np.uint64)
+    assert np.array_equal(out, dev) and out[5] == np.uint64(2**64 - 1)
+    i = rng.integers(1, bv.ones() + 1, nq).astype(np.uint64)
+    i[7] = 0
+    bv.select(i, 1, out)
+    dev = bv.select(torch.from_numpy(i.view(np.int64)).cuda(), 1).cpu().numpy().view(np.uint64)
+    assert np.array_equal(out, dev) and out[7] == np.uint64(2**64 - 1)
+    nosel = gpu.bit_vector(w, n, select1=False, select0=False)
+    with pytest.raises(gpu.capi.SdslHipError):  # an error inside a pipeline worker reaches the caller
+        nosel.select(i, 1, out)
+
