@@ -791,6 +791,18 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
     SH_HIP(hipSetDevice(v->h.device));
     if (n == 0)
         return SDSL_HIP_OK;
+    if (n >= kPipelineMinQueries && !is_device_ptr(idx) && !is_device_ptr(out))
+    { // host arrays on both sides: chunked over two streams (common.hpp host_pipeline_u64)
+        const RrrView rv = v->h.view;
+        return host_pipeline_u64(v->h.device, idx, out, n,
+                                 [rv, bit](const uint64_t * d_in, uint64_t * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
+                                 {
+                                     hipLaunchKernelGGL((k_rrr_rank<0>), dim3(rrr_grid(cnt)), dim3(kRrrBlock), 0, st, rv, bit,
+                                                        d_in, d_out, (uint8_t *)nullptr, cnt);
+                                     SH_HIP(hipGetLastError());
+                                     return SDSL_HIP_OK;
+                                 });
+    }
     Staged in, o;
     SH_TRY(in.in(idx, n * 8, s));
     SH_TRY(o.out(out, n * 8));
@@ -845,6 +857,22 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
     SH_HIP(hipSetDevice(v->h.device));
     if (n == 0)
         return SDSL_HIP_OK;
+    if (n >= kPipelineMinQueries && !is_device_ptr(i) && !is_device_ptr(out))
+    {
+        const RrrView rv = v->h.view;
+        return host_pipeline_u64(v->h.device, i, out, n,
+                                 [rv, bit](const uint64_t * d_in, uint64_t * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
+                                 {
+                                     if (bit)
+                                         hipLaunchKernelGGL((k_rrr_select<1>), dim3(rrr_grid(cnt)), dim3(kRrrBlock), 0, st, rv,
+                                                            d_in, d_out, cnt);
+                                     else
+                                         hipLaunchKernelGGL((k_rrr_select<0>), dim3(rrr_grid(cnt)), dim3(kRrrBlock), 0, st, rv,
+                                                            d_in, d_out, cnt);
+                                     SH_HIP(hipGetLastError());
+                                     return SDSL_HIP_OK;
+                                 });
+    }
     Staged in, o;
     SH_TRY(in.in(i, n * 8, s));
     SH_TRY(o.out(out, n * 8));

@@ -128,6 +128,18 @@ def test_host_arrays_take_the_pipelined_path(gpu):
     bv.select(i, 1, out)
     dev = bv.select(torch.from_numpy(i.view(np.int64)).cuda(), 1).cpu().numpy().view(np.uint64)
     assert np.array_equal(out, dev) and out[7] == np.uint64(2**64 - 1)
+    # the compressed vectors take the same path
+    import oracle_lib as ol
+    for vec in (gpu.rrr_vector(w, n), gpu.sd_vector(w, n)):
+        idx[5] = n  # in range for both
+        vec.rank(idx, 1, out)
+        assert np.array_equal(out[: 1 << 12], ol.OBitVector(w, n).rank(idx[: 1 << 12], 1))
+        d1 = vec.rank(torch.from_numpy(idx.view(np.int64)).cuda(), 1).cpu().numpy().view(np.uint64)
+        assert np.array_equal(out, d1)
+        i[7] = 1
+        vec.select(i, 1, out)
+        d1 = vec.select(torch.from_numpy(i.view(np.int64)).cuda(), 1).cpu().numpy().view(np.uint64)
+        assert np.array_equal(out, d1)
     nosel = gpu.bit_vector(w, n, select1=False, select0=False)
     with pytest.raises(gpu.capi.SdslHipError):  # an error inside a pipeline worker reaches the caller
         nosel.select(i, 1, out)
