@@ -59,6 +59,7 @@ enum {
 #define SDSL_HIP_LAYOUT_BV_SCAN 0 /* wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>> */
 #define SDSL_HIP_LAYOUT_BV_MCL 1  /* wt_huff<bit_vector, rank_support_v5<>> (select_support_mcl<1>, <0>) */
 #define SDSL_HIP_LAYOUT_RRR63 2   /* wt_huff<rrr_vector<63>> (rank/select_support_rrr serialise to nothing) */
+#define SDSL_HIP_LAYOUT_BV_DEFAULT 3 /* wt_huff<> with its default arguments: rank_support_v<1>, select_support_mcl<1>, <0> */
 
 typedef struct sdsl_hip_bv_s * sdsl_hip_bv_t;   /* bit_vector + rank_support_v5 + select_support_mcl */
 typedef struct sdsl_hip_rrr_s * sdsl_hip_rrr_t; /* rrr_vector<63> + rank_support_rrr + select_support_rrr */
@@ -94,6 +95,18 @@ sdsl_hip_status sdsl_hip_bv_create(const uint64_t * words, uint64_t n_bits, int3
  * through to sdsl_hip_bv_create. */
 sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t t_b,
                                            uint32_t t_pat_len, uint32_t flags, sdsl_hip_bv_t * out);
+/* The bytes SDSL's own serialize() writes for the vector and its supports (bit_vector: int_vector.hpp:1978-2004;
+ * rank_support_v5: rank_support_v5.hpp:160-167; rank_support_v: rank_support_v.hpp:156-163; select_support_mcl:
+ * select_support_mcl.hpp:474-518, including what its two construction paths leave behind).  For a pattern handle
+ * (sdsl_hip_bv_create_pattern) they describe the occurrence vector.  buf == NULL queries the size. */
+#define SDSL_HIP_SER_BIT_VECTOR 0
+#define SDSL_HIP_SER_RANK_V5_1 1
+#define SDSL_HIP_SER_RANK_V5_0 2
+#define SDSL_HIP_SER_SELECT_MCL_1 3
+#define SDSL_HIP_SER_SELECT_MCL_0 4
+#define SDSL_HIP_SER_RANK_V_1 5
+#define SDSL_HIP_SER_RANK_V_0 6
+sdsl_hip_status sdsl_hip_bv_serialize(sdsl_hip_bv_t bv, int32_t what, void * buf, size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv);
 uint64_t sdsl_hip_bv_size(sdsl_hip_bv_t bv);         /* bit_vector::size() */
 uint64_t sdsl_hip_bv_ones(sdsl_hip_bv_t bv);         /* == rank_1(size()) */
@@ -155,6 +168,9 @@ sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int
  * tree created with SDSL_HIP_WT_RRR63, of wt_huff<rrr_vector<63>>::serialize — for a wavelet tree that was built on the
  * GPU.  buf == NULL queries the size. */
 sdsl_hip_status sdsl_hip_wt_serialize(sdsl_hip_wt_t wt, void * buf, size_t cap, size_t * written);
+/* the same with the flavour chosen: SDSL_HIP_LAYOUT_BV_SCAN, SDSL_HIP_LAYOUT_BV_MCL (rank_support_v5 + the two
+ * select_support_mcl) or SDSL_HIP_LAYOUT_BV_DEFAULT (wt_huff<> / wt_blcd<> with SDSL's default arguments) */
+sdsl_hip_status sdsl_hip_wt_serialize_ex(sdsl_hip_wt_t wt, int32_t layout, void * buf, size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_wt_destroy(sdsl_hip_wt_t wt);
 uint64_t sdsl_hip_wt_size(sdsl_hip_wt_t wt);     /* wt.size()  */
 uint64_t sdsl_hip_wt_sigma(sdsl_hip_wt_t wt);    /* wt.sigma   */
@@ -212,6 +228,11 @@ sdsl_hip_status sdsl_hip_fm_create_from_sdsl_ex(const void * bytes, size_t len, 
  * text position) unless the index already has samples.  buf == NULL queries the size. */
 sdsl_hip_status sdsl_hip_fm_serialize(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens, void * buf, size_t cap,
                                       size_t * written);
+/* the same with the flavour of the wavelet tree chosen: SDSL_HIP_LAYOUT_BV_SCAN (as above), SDSL_HIP_LAYOUT_BV_MCL
+ * (csa_wt<wt_huff<bit_vector, rank_support_v5<>>, ...>) or SDSL_HIP_LAYOUT_BV_DEFAULT (csa_wt<> with SDSL's default
+ * wavelet tree: rank_support_v, select_support_mcl); ignored for an index created with SDSL_HIP_WT_RRR63 */
+sdsl_hip_status sdsl_hip_fm_serialize_ex(sdsl_hip_fm_t fm, int32_t layout, uint32_t sa_dens, uint32_t isa_dens, void * buf,
+                                         size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm);
 /* Jump-start table of count / interval / locate: the SA interval of every k-mer over the index's alphabet (16 bytes
  * each), read with the last k characters of a pattern instead of walking their k LF steps.  The entries are computed by
@@ -285,6 +306,9 @@ sdsl_hip_status sdsl_hip_sd_create_from_positions(const uint64_t * positions, ui
                                                   sdsl_hip_sd_t * out);
 sdsl_hip_status sdsl_hip_sd_create_from_sdsl(const void * bytes, size_t len, int32_t device, sdsl_hip_sd_t * out,
                                              size_t * consumed);
+/* the bytes of sd_vector<>::serialize (size, wl, low, high and the two select_support_mcl of high): a vector built on
+ * the device loads into unmodified SDSL.  buf == NULL queries the size. */
+sdsl_hip_status sdsl_hip_sd_serialize(sdsl_hip_sd_t v, void * buf, size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_sd_destroy(sdsl_hip_sd_t v);
 uint64_t sdsl_hip_sd_size(sdsl_hip_sd_t v);
 uint64_t sdsl_hip_sd_ones(sdsl_hip_sd_t v);

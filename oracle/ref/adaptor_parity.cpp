@@ -391,7 +391,42 @@ int main(int argc, char ** argv)
         std::sort(occ2.begin(), occ2.end());
         CHECK(occ1.size() == occ2.size() and std::equal(occ1.begin(), occ1.end(), occ2.begin()), "locate on the loaded index");
         CHECK(extract(loaded, 10, 40) == extract(fm, 10, 40), "extract on the loaded index");
+        // ... and as SDSL's DEFAULT index type csa_wt<> (wt_huff<> with rank_support_v and select_support_mcl)
+        {
+            size_t len2 = 0;
+            sdsl_hip_fm_serialize_ex(h, SDSL_HIP_LAYOUT_BV_DEFAULT, 32, 64, nullptr, 0, &len2);
+            std::string b2(len2, 0);
+            CHECK(sdsl_hip_fm_serialize_ex(h, SDSL_HIP_LAYOUT_BV_DEFAULT, 32, 64, &b2[0], len2, &len2) == SDSL_HIP_OK,
+                  "fm_serialize_ex(default)");
+            std::istringstream iss2(b2);
+            std::istream & in2 = iss2;
+            csa_wt<> def_loaded, def_ref;
+            def_loaded.load(in2);
+            construct_im(def_ref, text, 1);
+            CHECK(def_loaded == def_ref, "GPU-built index loads as csa_wt<> and equals construct()'s result");
+            CHECK(def_loaded[17] == def_ref[17] and def_loaded.wavelet_tree.select(3, 'e') == def_ref.wavelet_tree.select(3, 'e'),
+                  "SA access and wt.select on the loaded default index");
+        }
         sdsl_hip_fm_destroy(h);
+        // an sd_vector built on the device loads into sd_vector<>
+        {
+            bit_vector sparse(500000, 0);
+            for (int t = 0; t < 3000; ++t)
+                sparse[rng() % sparse.size()] = 1;
+            sdsl_hip_sd_t sh = nullptr;
+            CHECK(sdsl_hip_sd_create(sparse.data(), sparse.bit_size(), 0, &sh) == SDSL_HIP_OK, "sd_create");
+            size_t l3 = 0;
+            sdsl_hip_sd_serialize(sh, nullptr, 0, &l3);
+            std::string b3(l3, 0);
+            CHECK(sdsl_hip_sd_serialize(sh, &b3[0], l3, &l3) == SDSL_HIP_OK, "sd_serialize");
+            std::istringstream iss3(b3);
+            std::istream & in3 = iss3;
+            sd_vector<> sdl;
+            sdl.load(in3);
+            sd_vector<> sdr(sparse);
+            CHECK(sdl == sdr, "GPU-built sd_vector loads into sd_vector<> and equals the host-built one");
+            sdsl_hip_sd_destroy(sh);
+        }
     }
     printf(g_fail ? "adaptor parity: %d FAILED\n" : "adaptor parity: all equal\n", g_fail);
     return g_fail ? 1 : 0;

@@ -37,6 +37,7 @@ struct RefBv
     rank_support_v5<1> r1;
     rank_support_v5<0> r0;
     rank_support_v<1> rv1;
+    rank_support_v<0> rv0;
     select_support_mcl<1> s1;
     select_support_mcl<0> s0;
 };
@@ -89,6 +90,7 @@ void * ref_bv_create(const uint64_t * words, uint64_t n_bits)
     h->r1 = rank_support_v5<1>(&h->bv);
     h->r0 = rank_support_v5<0>(&h->bv);
     h->rv1 = rank_support_v<1>(&h->bv);
+    h->rv0 = rank_support_v<0>(&h->bv);
     h->s1 = select_support_mcl<1>(&h->bv);
     h->s0 = select_support_mcl<0>(&h->bv);
     return h;
@@ -137,7 +139,8 @@ void ref_bv_select(void * p, int bit, const uint64_t * i, uint64_t n, uint64_t *
         for (uint64_t q = 0; q < n; ++q)
             out[q] = h->s0(i[q]);
 }
-// which: 0 bit_vector, 1 rank_support_v5<1>, 2 rank_support_v5<0>, 3 select_support_mcl<1>, 4 select_support_mcl<0>
+// which: 0 bit_vector, 1 rank_support_v5<1>, 2 rank_support_v5<0>, 3 select_support_mcl<1>, 4 select_support_mcl<0>,
+// 5 rank_support_v<1>, 6 rank_support_v<0>
 void ref_bv_serialize(void * p, int which, uint8_t ** out, uint64_t * len)
 {
     RefBv * h = (RefBv *)p;
@@ -147,7 +150,9 @@ void ref_bv_serialize(void * p, int which, uint8_t ** out, uint64_t * len)
     case 1: to_bytes(h->r1, out, len); break;
     case 2: to_bytes(h->r0, out, len); break;
     case 3: to_bytes(h->s1, out, len); break;
-    default: to_bytes(h->s0, out, len); break;
+    case 4: to_bytes(h->s0, out, len); break;
+    case 5: to_bytes(h->rv1, out, len); break;
+    default: to_bytes(h->rv0, out, len); break;
     }
 }
 
@@ -503,6 +508,27 @@ void ref_sd_query(void * p, int what, const uint64_t * q, uint64_t n, uint64_t *
 void ref_sd_serialize(void * p, uint8_t ** out, uint64_t * len)
 {
     to_bytes(((RefSd *)p)->v, out, len);
+}
+
+// SDSL's default types: wt_huff<> (rank_support_v, select_support_mcl) and csa_wt<> over it (32 / 64)
+void ref_wt_default_serialize(const uint8_t * text, uint64_t n, uint8_t ** out, uint64_t * len)
+{
+    to_bytes(wt_huff<>(text, text + n), out, len);
+}
+int ref_csa_default_serialize(const uint8_t * text, uint64_t n, uint8_t ** out, uint64_t * len)
+{
+    csa_wt<> csa;
+    std::string s((const char *)text, n);
+    try
+    {
+        construct_im(csa, s, 1);
+    }
+    catch (std::exception const &)
+    {
+        return 1;
+    }
+    to_bytes(csa, out, len);
+    return 0;
 }
 
 // other wt_pc shapes over bytes: shape 1 = wt_blcd (balanced), 2 = wt_hutu (Hu-Tucker); flavour 0 = the type with

@@ -21,7 +21,7 @@ NPOS = 0xFFFFFFFFFFFFFFFF
 BV_SELECT1, BV_SELECT0 = 1, 2
 WT_RRR63 = 1
 WT_BLCD = 2
-LAYOUT_BV_SCAN, LAYOUT_BV_MCL, LAYOUT_RRR63 = 0, 1, 2
+LAYOUT_BV_SCAN, LAYOUT_BV_MCL, LAYOUT_RRR63, LAYOUT_BV_DEFAULT = 0, 1, 2, 3
 
 _u64p = C.POINTER(C.c_uint64)
 _u8p = C.POINTER(C.c_uint8)
@@ -37,6 +37,7 @@ SIGNATURES = {
     "sdsl_hip_bv_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "sdsl_hip_bv_create_pattern": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.POINTER(_vp)]),
+    "sdsl_hip_bv_serialize": (C.c_int32, [_vp, C.c_int32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sdsl_hip_bv_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_bv_size": (C.c_uint64, [_vp]),
     "sdsl_hip_bv_ones": (C.c_uint64, [_vp]),
@@ -58,6 +59,7 @@ SIGNATURES = {
     "sdsl_hip_sd_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_sd_create_from_positions": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_sd_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "sdsl_hip_sd_serialize": (C.c_int32, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sdsl_hip_sd_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_sd_size": (C.c_uint64, [_vp]),
     "sdsl_hip_sd_ones": (C.c_uint64, [_vp]),
@@ -71,6 +73,7 @@ SIGNATURES = {
     "sdsl_hip_wt_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp),
                                                  C.POINTER(C.c_size_t)]),
     "sdsl_hip_wt_serialize": (C.c_int32, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sdsl_hip_wt_serialize_ex": (C.c_int32, [_vp, C.c_int32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sdsl_hip_wt_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_wt_size": (C.c_uint64, [_vp]),
     "sdsl_hip_wt_sigma": (C.c_uint64, [_vp]),
@@ -87,6 +90,8 @@ SIGNATURES = {
     "sdsl_hip_fm_create_from_text_ex": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "sdsl_hip_fm_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_fm_serialize": (C.c_int32, [_vp, C.c_uint32, C.c_uint32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "sdsl_hip_fm_serialize_ex": (C.c_int32, [_vp, C.c_int32, C.c_uint32, C.c_uint32, _vp, C.c_size_t,
+                                             C.POINTER(C.c_size_t)]),
     "sdsl_hip_fm_create_from_sdsl_ex": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32,
                                                    C.POINTER(_vp)]),
     "sdsl_hip_fm_drop_sa": (C.c_int32, [_vp]),

@@ -8,6 +8,7 @@
 #include <algorithm>
 
 #include "bv_host.hpp"
+#include "bv_serialize.hpp"
 
 namespace sdslhip {
 
@@ -777,6 +778,37 @@ sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bi
     }
     *out = bv;
     return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_bv_serialize(sdsl_hip_bv_t bv, int32_t what, void * buf, size_t cap, size_t * written)
+{
+    if (!bv || what < 0 || what > SDSL_HIP_SER_RANK_V_0)
+    {
+        set_error("bv_serialize: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_HIP(hipSetDevice(bv->h.device));
+    const uint64_t n = bv->h.view.n_bits, W = (n + 63) >> 6;
+    std::vector<uint64_t> words(W + 1, 0);
+    if (W)
+    {
+        DevBuf d;
+        SH_TRY(d.alloc(W * 8));
+        SH_TRY(bv_export_words_device(bv->h.view, d.as<uint64_t>(), W, nullptr));
+        SH_HIP(hipMemcpy(words.data(), d.p, W * 8, hipMemcpyDeviceToHost));
+    }
+    StreamWriter w;
+    switch (what)
+    {
+    case SDSL_HIP_SER_BIT_VECTOR: w.int_vector(words.data(), n, 1); break;
+    case SDSL_HIP_SER_RANK_V5_1: rank_v5_serialize_host(words.data(), n, 1, w); break;
+    case SDSL_HIP_SER_RANK_V5_0: rank_v5_serialize_host(words.data(), n, 0, w); break;
+    case SDSL_HIP_SER_SELECT_MCL_1: select_mcl_serialize_host(words.data(), n, 1, w); break;
+    case SDSL_HIP_SER_SELECT_MCL_0: select_mcl_serialize_host(words.data(), n, 0, w); break;
+    case SDSL_HIP_SER_RANK_V_1: rank_v_serialize_host(words.data(), n, 1, w); break;
+    default: rank_v_serialize_host(words.data(), n, 0, w); break;
+    }
+    return deliver(w, buf, cap, written);
 }
 
 sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv)

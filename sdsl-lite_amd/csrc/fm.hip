@@ -527,6 +527,12 @@ sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
 sdsl_hip_status sdsl_hip_fm_serialize(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens, void * buf, size_t cap,
                                       size_t * written)
 {
+    return sdsl_hip_fm_serialize_ex(fm, SDSL_HIP_LAYOUT_BV_SCAN, sa_dens, isa_dens, buf, cap, written);
+}
+
+sdsl_hip_status sdsl_hip_fm_serialize_ex(sdsl_hip_fm_t fm, int32_t layout, uint32_t sa_dens, uint32_t isa_dens, void * buf,
+                                         size_t cap, size_t * written)
+{
     if (!fm || sa_dens == 0 || isa_dens == 0)
     {
         set_error("fm_serialize: invalid argument");
@@ -538,12 +544,12 @@ sdsl_hip_status sdsl_hip_fm_serialize(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
     SH_HIP(hipSetDevice(fm->device));
-    // 1. the wavelet tree in its select_support_scan flavour
+    // 1. the wavelet tree in the requested flavour
     size_t wt_len = 0;
-    SH_TRY(sdsl_hip_wt_serialize(fm->wt, nullptr, 0, &wt_len));
+    SH_TRY(sdsl_hip_wt_serialize_ex(fm->wt, layout, nullptr, 0, &wt_len));
     StreamWriter w;
     w.bytes.resize(wt_len);
-    SH_TRY(sdsl_hip_wt_serialize(fm->wt, w.bytes.data(), wt_len, &wt_len));
+    SH_TRY(sdsl_hip_wt_serialize_ex(fm->wt, layout, w.bytes.data(), wt_len, &wt_len));
     // 2. SA and ISA samples as int_vector<0> of width hi(n)+1
     const uint64_t n = fm->size;
     std::vector<uint64_t> sa_s, isa_s;

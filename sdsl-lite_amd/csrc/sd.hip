@@ -15,6 +15,7 @@
 #include <algorithm>
 
 #include "bv_host.hpp"
+#include "bv_serialize.hpp"
 #include "sdsl_stream.hpp"
 
 namespace sdslhip {
@@ -33,6 +34,7 @@ struct SdHost
     BvHost high;
     DevBuf low;
     SdView view{};
+    uint32_t low_width_when_empty = 64; // width SDSL's `low` reports for m == 0 (wl for built vectors)
     size_t device_bytes() const
     {
         return high.device_bytes() + low.bytes;
@@ -255,6 +257,7 @@ static void sd_finish_view(SdHost & h, uint64_t n, uint64_t m, uint32_t wl)
     h.view.n = n;
     h.view.m = m;
     h.view.wl = wl;
+    h.low_width_when_empty = wl;
 }
 
 // sd_vector(begin, end) with an explicit size (sd_vector.hpp:217-305; the iterator constructor takes size = last + 1)
@@ -435,6 +438,38 @@ sdsl_hip_status sdsl_hip_sd_create_from_sdsl(const void * bytes, size_t len, int
         *consumed = rd.pos;
     *out = r;
     return SDSL_HIP_OK;
+}
+
+// sd_vector<>::serialize (sd_vector.hpp:435-445): size, wl, low, high, select_support_mcl<1> and <0> of high
+sdsl_hip_status sdsl_hip_sd_serialize(sdsl_hip_sd_t v, void * buf, size_t cap, size_t * written)
+{
+    if (!v)
+    {
+        set_error("sd_serialize: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_HIP(hipSetDevice(v->h.device));
+    const SdView & sv = v->h.view;
+    const uint64_t hb = sv.high.n_bits, HW = (hb + 63) >> 6, LW = (sv.m * sv.wl + 63) >> 6;
+    std::vector<uint64_t> high(HW + 1, 0), low(LW + 1, 0);
+    if (HW)
+    {
+        DevBuf d;
+        SH_TRY(d.alloc(HW * 8));
+        SH_TRY(bv_export_words_device(sv.high, d.as<uint64_t>(), HW, nullptr));
+        SH_HIP(hipMemcpy(high.data(), d.p, HW * 8, hipMemcpyDeviceToHost));
+    }
+    if (LW)
+        SH_HIP(hipMemcpy(low.data(), sv.low, LW * 8, hipMemcpyDeviceToHost));
+    StreamWriter w;
+    w.u64(sv.n);
+    const uint8_t wl = (uint8_t)sv.wl;
+    w.raw(&wl, 1);
+    w.int_vector(low.data(), sv.m * sv.wl, sv.m ? wl : (uint8_t)v->h.low_width_when_empty);
+    w.int_vector(high.data(), hb, 1);
+    select_mcl_serialize_host(high.data(), hb, 1, w);
+    select_mcl_serialize_host(high.data(), hb, 0, w);
+    return deliver(w, buf, cap, written);
 }
 
 sdsl_hip_status sdsl_hip_sd_destroy(sdsl_hip_sd_t v)

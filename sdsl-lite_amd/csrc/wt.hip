@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <queue>
 
+#include "bv_serialize.hpp"
 #include "wt_host.hpp"
 
 namespace sdslhip {
@@ -358,11 +359,13 @@ sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, int layout,
 {
     HostIntVec bv;
     uint64_t n_nodes64 = 0;
-    if (layout < 0 || layout > 2)
+    if (layout < 0 || layout > 3)
     {
-        set_error("wt stream layout must be 0 (scan selects), 1 (mcl selects) or 2 (rrr_vector<63>)");
+        set_error("wt stream layout must be 0 (scan selects), 1 or 3 (mcl selects) or 2 (rrr_vector<63>)");
         return SDSL_HIP_ERR_INVALID;
     }
+    if (layout == SDSL_HIP_LAYOUT_BV_DEFAULT)
+        layout = SDSL_HIP_LAYOUT_BV_MCL; // the rank support (v or v5) is skipped either way
     wt.backend = layout == 2 ? 1u : 0u;
     if (!rd.u64(wt.size) || !rd.u64(wt.sigma))
         goto bad;
@@ -703,9 +706,15 @@ sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int
 
 sdsl_hip_status sdsl_hip_wt_serialize(sdsl_hip_wt_t wt, void * buf, size_t cap, size_t * written)
 {
-    if (!wt)
+    return sdsl_hip_wt_serialize_ex(wt, SDSL_HIP_LAYOUT_BV_SCAN, buf, cap, written);
+}
+
+sdsl_hip_status sdsl_hip_wt_serialize_ex(sdsl_hip_wt_t wt, int32_t layout, void * buf, size_t cap, size_t * written)
+{
+    if (!wt || (wt->h.backend == 0 && layout != SDSL_HIP_LAYOUT_BV_SCAN && layout != SDSL_HIP_LAYOUT_BV_MCL
+                && layout != SDSL_HIP_LAYOUT_BV_DEFAULT))
     {
-        set_error("wt_serialize: null handle");
+        set_error("wt_serialize: null handle or unknown layout");
         return SDSL_HIP_ERR_INVALID;
     }
     const WtHost & h = wt->h;
@@ -739,38 +748,30 @@ sdsl_hip_status sdsl_hip_wt_serialize(sdsl_hip_wt_t wt, void * buf, size_t cap, 
         SH_TRY(bv_export_words_device(h.bv.view, d.as<uint64_t>(), W, nullptr));
         SH_HIP(hipMemcpy(words.data(), d.p, W * 8, hipMemcpyDeviceToHost));
     }
-    // rank_support_v5 directory (rank_support_v5.hpp:68-124): per 2048-bit superblock the absolute count and five
-    // 11-bit counts of the 384-bit blocks before each block boundary, packed at shifts 48,36,24,12,0
-    std::vector<uint64_t> dir;
-    if (h.size == 0)
-        dir.clear(); // default-constructed support: empty int_vector<64>
-    else if (nb == 0)
-        dir.assign(2, 0);
-    else
-    {
-        const uint64_t nsb = ((nb + 63) >> 11) + 1;
-        dir.assign(2 * nsb, 0);
-        uint64_t abs = 0;
-        for (uint64_t s = 0; s < nsb; ++s)
-        {
-            dir[2 * s] = abs;
-            uint64_t rel = 0, packed = 0;
-            for (unsigned j = 0; j < 32 && 32 * s + j < W; ++j)
-            {
-                rel += popc64(words[32 * s + j]);
-                if ((j + 1) % 6 == 0 && j + 1 < 32)
-                    packed |= rel << (60 - 12 * ((j + 1) / 6));
-            }
-            dir[2 * s + 1] = packed;
-            abs += rel;
-        }
-    }
     StreamWriter w;
     w.u64(h.size);
     w.u64(h.sigma);
     w.int_vector(words.data(), nb, 1);
-    w.int_vector(dir.data(), dir.size() * 64, 64);
-    // select_support_scan<1>, select_support_scan<0>: nothing
+    if (h.size == 0)
+        w.int_vector(nullptr, 0, 64); // default-constructed support: empty int_vector<64>
+    else if (layout == SDSL_HIP_LAYOUT_BV_DEFAULT)
+        rank_v_serialize_host(words.data(), nb, 1, w);
+    else
+        rank_v5_serialize_host(words.data(), nb, 1, w);
+    if (layout != SDSL_HIP_LAYOUT_BV_SCAN)
+    { // select_support_mcl<1>, select_support_mcl<0> of the tree's bit vector
+        if (h.size == 0)
+        {
+            w.u64(0);
+            w.u64(0);
+        }
+        else
+        {
+            select_mcl_serialize_host(words.data(), nb, 1, w);
+            select_mcl_serialize_host(words.data(), nb, 0, w);
+        }
+    }
+    // (select_support_scan<1>, select_support_scan<0>: nothing)
     w.u64(h.n_nodes);
     for (uint32_t v = 0; v < h.n_nodes; ++v)
     { // _node::serialize (wt_helper.hpp:139-150)

@@ -135,6 +135,16 @@ class bit_vector(_Handle):
 
     __getitem__ = access
 
+    def serialize(self, what: int = 0) -> bytes:
+        """SDSL's own bytes: 0 bit_vector, 1/2 rank_support_v5<1>/<0>, 3/4 select_support_mcl<1>/<0>,
+        5/6 rank_support_v<1>/<0>"""
+        L = capi.lib()
+        need = C.c_size_t(0)
+        capi.check(L.sdsl_hip_bv_serialize(self._h, what, None, 0, C.byref(need)))
+        buf = np.empty(max(1, need.value), dtype=np.uint8)
+        capi.check(L.sdsl_hip_bv_serialize(self._h, what, _ptr(buf), need.value, C.byref(need)))
+        return buf[: need.value].tobytes()
+
     def export_words(self) -> np.ndarray:
         out = np.zeros((self.size() + 63) // 64, dtype=np.uint64)
         capi.check(capi.lib().sdsl_hip_bv_export_words(self._h, _ptr(out) if out.size else None, 0))
@@ -297,6 +307,10 @@ class sd_vector(_Handle):
     def low_width(self) -> int:
         return capi.lib().sdsl_hip_sd_low_width(self._h)
 
+    def serialize(self) -> bytes:
+        """the bytes of sd_vector<>::serialize"""
+        return _serialize(capi.lib().sdsl_hip_sd_serialize, self._h)
+
     def device_bytes(self) -> int:
         return capi.lib().sdsl_hip_sd_device_bytes(self._h)
 
@@ -373,9 +387,16 @@ class wt_huff(_Handle):
     def device_bytes(self) -> int:
         return capi.lib().sdsl_hip_wt_device_bytes(self._h)
 
-    def serialize(self) -> bytes:
-        """the bytes of wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>"""
-        return _serialize(capi.lib().sdsl_hip_wt_serialize, self._h)
+    def serialize(self, layout: int = 0) -> bytes:
+        """the bytes of wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>> (layout 0),
+        wt_huff<bit_vector, rank_support_v5<>> with mcl selects (capi.LAYOUT_BV_MCL) or wt_huff<> with SDSL's default
+        arguments (capi.LAYOUT_BV_DEFAULT); an rrr tree always writes wt_huff<rrr_vector<63>>"""
+        L = capi.lib()
+        need = C.c_size_t(0)
+        capi.check(L.sdsl_hip_wt_serialize_ex(self._h, layout, None, 0, C.byref(need)))
+        buf = np.empty(max(1, need.value), dtype=np.uint8)
+        capi.check(L.sdsl_hip_wt_serialize_ex(self._h, layout, _ptr(buf), need.value, C.byref(need)))
+        return buf[: need.value].tobytes()
 
     def code_lengths(self) -> np.ndarray:
         out = np.zeros(256, dtype=np.uint8)
@@ -458,14 +479,14 @@ class csa_wt(_Handle):
     def device_bytes(self) -> int:
         return capi.lib().sdsl_hip_fm_device_bytes(self._h)
 
-    def serialize(self, sa_dens: int, isa_dens: int) -> bytes:
+    def serialize(self, sa_dens: int, isa_dens: int, layout: int = 0) -> bytes:
         """bytes of csa_wt<wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>>,
         sa_dens, isa_dens>::serialize — only for an index created from text (the suffix array is needed)"""
         need = C.c_size_t(0)
         L = capi.lib()
-        capi.check(L.sdsl_hip_fm_serialize(self._h, sa_dens, isa_dens, None, 0, C.byref(need)))
+        capi.check(L.sdsl_hip_fm_serialize_ex(self._h, layout, sa_dens, isa_dens, None, 0, C.byref(need)))
         buf = np.empty(max(1, need.value), dtype=np.uint8)
-        capi.check(L.sdsl_hip_fm_serialize(self._h, sa_dens, isa_dens, _ptr(buf), need.value, C.byref(need)))
+        capi.check(L.sdsl_hip_fm_serialize_ex(self._h, layout, sa_dens, isa_dens, _ptr(buf), need.value, C.byref(need)))
         return buf[: need.value].tobytes()
 
     def drop_sa(self):

@@ -125,6 +125,7 @@ def main():
                 open(os.path.join(HERE, "sdsl", f"{name}.sd_vector.sdsl"), "wb").write(sd.serialize())
         out[f"{name}/sha"] = np.array([sha(rb.serialize(1)), sha(rb.serialize(2)), sha(rb.serialize(3)),
                                        sha(rb.serialize(4)), sha(rr.serialize())])
+        out[f"{name}/sha_more"] = np.array([sha(rb.serialize(0)), sha(rb.serialize(5)), sha(rb.serialize(6))])
     # a sparse set over a large universe (what sd_vector is for): 20000 positions below 2^40
     pos = np.unique(ol.mt19937_64(20000, 4242) % np.uint64(1 << 40)).astype(np.uint64)
     sd = ol.RSd(positions=pos)
@@ -179,6 +180,7 @@ def main():
             out[f"{t}/sel_i"], out[f"{t}/sel_c"] = si, sc
             out[f"{t}/sel"] = wt.select(si, sc)
         out[f"{t}/sha"] = np.array([sha(wt.serialize(1)), sha(wt.serialize(0))])
+        out[f"{t}/sha_default"] = np.array([sha(ol.ref_wt_default_bytes(data))])
         if t in ("example01.txt", "abc_abc_abc.txt", "100a.txt", "one_byte.txt"):
             open(os.path.join(HERE, "sdsl", f"{t}.wt_huff_v5_mcl.sdsl"), "wb").write(wt.serialize(1))
             open(os.path.join(HERE, "sdsl", f"{t}.wt_huff_v5_scan.sdsl"), "wb").write(wt.serialize(0))
@@ -223,6 +225,7 @@ def main():
             out[f"{t}/loc_n{m}"] = np.array([k], dtype=np.uint64)
             out[f"{t}/loc_off{m}"] = np.concatenate([[0], np.cumsum([x.size for x in locs])]).astype(np.uint64)
             out[f"{t}/loc_pos{m}"] = np.concatenate(locs).astype(np.uint64) if locs else np.zeros(0, np.uint64)
+        out[f"{t}/sha_csa_default"] = np.array([sha(ol.ref_csa_default_bytes(data)), sha(csa.serialize(0))])
         if t in ("example01.txt", "faust.txt"):
             open(os.path.join(HERE, "sdsl", f"{t}.csa_wt_huff_v5.sdsl"), "wb").write(csa.serialize(0))
             open(os.path.join(HERE, "sdsl", f"{t}.csa_fm_huff.sdsl"), "wb").write(csa.serialize(1))

@@ -501,6 +501,8 @@ _REF_SIGS = {
     "ref_sd_query": (None, [_vp, C.c_int, _vp, _u64, _vp]),
     "ref_sd_serialize": (None, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_bv_pattern": (None, [_vp, _u64, C.c_int, C.c_int, _vp, _u64, _vp]),
+    "ref_wt_default_serialize": (None, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
+    "ref_csa_default_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_wt_shape_serialize": (None, [_vp, _u64, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_csa_blcd_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_set_random_bits": (None, [_vp, _u64, C.c_int]),
@@ -553,6 +555,23 @@ def pattern_bits(bits: np.ndarray, pat: int) -> np.ndarray:
     prev = np.concatenate([[1 if pat in (1, 2) else 0], x[:-1]]).astype(np.uint8) if x.size else x
     want_prev, want_cur = [(1, 0), (0, 1), (0, 0), (1, 1)][pat]
     return ((prev == want_prev) & (x == want_cur)).astype(np.uint8)
+
+
+def ref_wt_default_bytes(text: bytes) -> bytes:
+    """wt_huff<>::serialize (SDSL's default arguments: rank_support_v, select_support_mcl) of the real library"""
+    t = _u8arr(np.frombuffer(text, dtype=np.uint8))
+    return _ref_bytes(ref().L.ref_wt_default_serialize, _p(t) if t.size else None, t.size)
+
+
+def ref_csa_default_bytes(text: bytes) -> bytes:
+    """csa_wt<>::serialize of the real library (default wavelet tree, densities 32 / 64)"""
+    t = _u8arr(np.frombuffer(text, dtype=np.uint8))
+    p, n = _vp(None), _u64(0)
+    if ref().L.ref_csa_default_serialize(_p(t), t.size, C.byref(p), C.byref(n)):
+        raise ValueError("sdsl::construct_im threw")
+    data = C.string_at(p, n.value)
+    ref().L.ref_free(p)
+    return data
 
 
 def ref_wt_shape_bytes(text: bytes, shape: int, flavour: int) -> bytes:

@@ -527,6 +527,72 @@ def test_fm_built_on_gpu_serializes_to_sdsl_bytes(gpu, name):
 
 
 # ---------------------------------------------------------------------------------------------------
+# writers: device structures back as SDSL's own bytes (default types included)
+# ---------------------------------------------------------------------------------------------------
+def _sha(b):
+    import hashlib
+    return hashlib.sha256(b).hexdigest()
+
+
+@pytest.mark.parametrize("name", gd.bv_case_names())
+def test_bv_supports_serialize_to_sdsl_bytes(gpu, name):
+    """bit_vector, rank_support_v5<1>/<0>, select_support_mcl<1>/<0> (both construction paths of the reference, long and
+    mini blocks), rank_support_v<1>/<0>: sha256 of the real library's streams"""
+    g = gd.bv_golden()
+    words, n = gd.bv_case(name)
+    bv = gpu.bit_vector(words, n)
+    sha = g[f"{name}/sha"]
+    more = g[f"{name}/sha_more"]
+    # select_support_mcl only looks at positions below size()
+    assert _sha(bv.serialize(3)) == str(sha[2]) and _sha(bv.serialize(4)) == str(sha[3])
+    # the vector itself and the rank directories see the whole last word; bits above size() are unspecified in SDSL
+    # (util::set_random_bits leaves stray ones there), the device holds zeros there
+    masked = words[: (n + 63) // 64].copy()
+    if n % 64:
+        masked[-1] &= np.uint64((1 << (n % 64)) - 1)
+    assert bv.serialize(0) == ((1 << 56) | n).to_bytes(8, "little") + masked.tobytes()
+    if n % 64 == 0 or name.startswith("CRAFTED"):
+        assert _sha(bv.serialize(0)) == str(more[0])
+        assert _sha(bv.serialize(1)) == str(sha[0]) and _sha(bv.serialize(2)) == str(sha[1])
+        assert _sha(bv.serialize(5)) == str(more[1]) and _sha(bv.serialize(6)) == str(more[2])
+    elif ol.have_ref():  # compare with the real library on the clean words
+        rb = ol.RBitVector(masked, n)
+        for what in (1, 2, 5, 6):
+            assert bv.serialize(what) == rb.serialize(what)
+    if name in ("CRAFTED-32", "rnd.200000.7"):
+        assert bv.serialize(3) == gd.sdsl_file(f"{name}.select_mcl_1.sdsl")
+        assert bv.serialize(4) == gd.sdsl_file(f"{name}.select_mcl_0.sdsl")
+
+
+@pytest.mark.parametrize("name", [t for t in gd.TEXTS if t != "empty.txt"])
+def test_wt_and_csa_serialize_default_types(gpu, name):
+    g = gd.text_golden()
+    data = gd.text(name)
+    wt = gpu.wt_huff(data)
+    assert _sha(wt.serialize(gpu.capi.LAYOUT_BV_MCL)) == str(g[f"{name}/sha"][0])       # wt_huff<bit_vector, rank_support_v5<>>
+    assert _sha(wt.serialize(gpu.capi.LAYOUT_BV_SCAN)) == str(g[f"{name}/sha"][1])
+    assert _sha(wt.serialize(gpu.capi.LAYOUT_BV_DEFAULT)) == str(g[f"{name}/sha_default"][0])  # wt_huff<>
+    if f"{name}/sha_csa_default" not in g.files:
+        return
+    csa = gpu.csa_wt(text=data)
+    shas = g[f"{name}/sha_csa_default"]
+    assert _sha(csa.serialize(32, 64, gpu.capi.LAYOUT_BV_DEFAULT)) == str(shas[0])  # csa_wt<>
+    assert _sha(csa.serialize(32, 64, gpu.capi.LAYOUT_BV_MCL)) == str(shas[1])      # csa_wt<wt_huff<bit_vector, rank_support_v5<>>>
+    # and the default stream loads back with its samples
+    again = gpu.csa_wt(sdsl_bytes=csa.serialize(32, 64, gpu.capi.LAYOUT_BV_DEFAULT), select_is_mcl=True, sa_dens=32, isa_dens=64)
+    idx = g[f"{name}/csa_idx"][:200]
+    assert np.array_equal(again.sa(idx), g[f"{name}/csa_sa"][:200])
+
+
+@pytest.mark.parametrize("name", ["CRAFTED-32", "CRAFTED-SPARSE-1", "rnd.8192.1043", "rnd.200000.7"])
+def test_sd_vector_serializes_to_sdsl_bytes(gpu, name):
+    words, n = gd.bv_case(name)
+    assert gpu.sd_vector(words, n).serialize() == gd.sdsl_file(f"{name}.sd_vector.sdsl")
+    g = gd.bv_golden()
+    assert gpu.sd_vector(positions=g["sdpos/pos"], n_bits=int(g["sdpos/n"][0])).serialize() == gd.sdsl_file("sdpos.sd_vector.sdsl")
+
+
+# ---------------------------------------------------------------------------------------------------
 # sd_vector<>
 # ---------------------------------------------------------------------------------------------------
 SD_CASES = ["CRAFTED-32", "CRAFTED-SPARSE-0", "CRAFTED-SPARSE-1", "CRAFTED-BLOCK-1", "rnd.8.17", "rnd.64.222",
