@@ -54,6 +54,7 @@ enum {
 /* build flags for sdsl_hip_wt_create_ex / sdsl_hip_fm_create_from_{text,bwt}_ex */
 #define SDSL_HIP_WT_RRR63 1u /* store the wavelet tree's bit vector as rrr_vector<63>: wt_huff<rrr_vector<63>> */
 #define SDSL_HIP_WT_BLCD 2u  /* balanced tree shape (wt_blcd, wt_blcd.hpp:50-127) instead of the Huffman shape */
+#define SDSL_HIP_WT_HUTU 4u  /* Hu-Tucker shape (wt_hutu, wt_hutu.hpp:355-676): the optimal alphabetic code */
 
 /* `layout` of a serialised wt_pc / csa_wt stream handed to *_create_from_sdsl */
 #define SDSL_HIP_LAYOUT_BV_SCAN 0 /* wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>> */
@@ -153,9 +154,10 @@ sdsl_hip_status sdsl_hip_rrr_access_batch(sdsl_hip_rrr_t v, const uint64_t * idx
  *           wt_pc::operator[] (wt_pc.hpp:336-357); wt_pc::inverse_select (wt_pc.hpp:411-430);
  *           wt_pc::select (wt_pc.hpp:443-474). */
 sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t device, sdsl_hip_wt_t * out);
-/* flags: SDSL_HIP_WT_RRR63 -> wt_huff<rrr_vector<63>>;  SDSL_HIP_WT_BLCD -> wt_blcd<...> (may be combined).
+/* flags: SDSL_HIP_WT_RRR63 -> wt_huff<rrr_vector<63>>;  SDSL_HIP_WT_BLCD -> wt_blcd<...>, SDSL_HIP_WT_HUTU -> wt_hutu<...>
+ * (a shape flag may be combined with SDSL_HIP_WT_RRR63).
  * Trees of any wt_pc byte shape (wt_huff, wt_blcd, wt_hutu) LOAD through sdsl_hip_wt_create_from_sdsl: the stream
- * carries the node table; only wt_huff and wt_blcd can be BUILT here. */
+ * carries the node table. */
 sdsl_hip_status sdsl_hip_wt_create_ex(const uint8_t * text, uint64_t n, int32_t device, uint32_t flags,
                                       sdsl_hip_wt_t * out);
 /* from wt_pc::serialize bytes (wt_pc.hpp:713-726).  `layout` names the serialised type (SDSL_HIP_LAYOUT_*): plain

@@ -21,6 +21,7 @@ NPOS = 0xFFFFFFFFFFFFFFFF
 BV_SELECT1, BV_SELECT0 = 1, 2
 WT_RRR63 = 1
 WT_BLCD = 2
+WT_HUTU = 4
 LAYOUT_BV_SCAN, LAYOUT_BV_MCL, LAYOUT_RRR63, LAYOUT_BV_DEFAULT = 0, 1, 2, 3
 
 _u64p = C.POINTER(C.c_uint64)

@@ -95,7 +95,128 @@ static int shape_balanced_rec(const std::vector<int> & syms, size_t lb, size_t s
     return id;
 }
 
-static sdsl_hip_status build_shape(const uint64_t occ[256], bool balanced, WtTables & T, uint32_t & n_nodes,
+// wt_hutu (wt_hutu.hpp:355-676): Hu-Tucker, the optimal ALPHABETIC code.  Phase 1 works on a sequence of nodes; two
+// nodes are compatible if no leaf lies strictly between them, so the sequence falls into groups delimited by leaves.
+// Every group offers its two smallest nodes by (weight, position); the offer with the smallest (weight sum, left
+// position, right position) is merged into an inner node at the left position (the rules of the reference's master
+// queue, :299-311, 336-343, 605-625).  Only the leaf LEVELS of that merge tree matter; phase 2 rebuilds the
+// alphabetic tree from them with the stack algorithm (:641-676).  sigma <= 256, so the quadratic search is free.
+static int shape_hutu(const std::vector<int> & syms, const uint64_t occ[256], std::vector<ShapeTmp> & tmp)
+{
+    const size_t sigma = syms.size();
+    struct Seq
+    {
+        uint64_t w;
+        bool alive, leaf;
+        int left, right; // indices into `merge` (inner) or -1
+    };
+    struct M
+    {
+        int l_is_leaf, l, r_is_leaf, r; // children: leaf position or merge index
+    };
+    std::vector<Seq> A(sigma);
+    std::vector<M> merge;
+    std::vector<int> node_of(sigma); // position -> merge index of the inner node living there (if !leaf)
+    for (size_t i = 0; i < sigma; ++i)
+        A[i] = Seq{occ[syms[i]], true, true, -1, -1};
+    std::vector<unsigned> level(sigma, 0);
+    for (size_t step = 1; step < sigma; ++step)
+    {
+        bool have = false;
+        uint64_t best_sum = 0;
+        size_t best_i = 0, best_j = 0;
+        // scan the groups: [.. inner .. leaf] [leaf .. inner .. leaf] ...
+        size_t g0 = 0;
+        auto offer = [&](size_t lo, size_t hi)
+        { // two smallest (w, pos) among the alive nodes at positions [lo, hi]
+            size_t a = SIZE_MAX, b = SIZE_MAX;
+            for (size_t p = lo; p <= hi; ++p)
+            {
+                if (!A[p].alive)
+                    continue;
+                if (a == SIZE_MAX || A[p].w < A[a].w)
+                {
+                    b = a;
+                    a = p;
+                }
+                else if (b == SIZE_MAX || A[p].w < A[b].w)
+                    b = p;
+            }
+            if (b == SIZE_MAX)
+                return;
+            const uint64_t sum = A[a].w + A[b].w;
+            const size_t i = std::min(a, b), j = std::max(a, b);
+            if (!have || sum < best_sum || (sum == best_sum && (i < best_i || (i == best_i && j < best_j))))
+            {
+                have = true;
+                best_sum = sum;
+                best_i = i;
+                best_j = j;
+            }
+        };
+        for (size_t p = 0; p < sigma; ++p)
+            if (A[p].alive && A[p].leaf)
+            {
+                offer(g0, p);
+                g0 = p;
+            }
+        offer(g0, sigma - 1);
+        M m;
+        m.l_is_leaf = A[best_i].leaf;
+        m.l = A[best_i].leaf ? (int)best_i : node_of[best_i];
+        m.r_is_leaf = A[best_j].leaf;
+        m.r = A[best_j].leaf ? (int)best_j : node_of[best_j];
+        merge.push_back(m);
+        A[best_i].w = best_sum;
+        A[best_i].leaf = false;
+        node_of[best_i] = (int)merge.size() - 1;
+        A[best_j].alive = false;
+    }
+    // leaf levels: depth in the merge tree (root = the last merge)
+    if (!merge.empty())
+    {
+        std::vector<std::pair<int, unsigned>> st; // (merge index, depth)
+        st.push_back({(int)merge.size() - 1, 0u});
+        while (!st.empty())
+        {
+            auto [mi, d] = st.back();
+            st.pop_back();
+            const M & m = merge[mi];
+            if (m.l_is_leaf)
+                level[m.l] = d + 1;
+            else
+                st.push_back({m.l, d + 1});
+            if (m.r_is_leaf)
+                level[m.r] = d + 1;
+            else
+                st.push_back({m.r, d + 1});
+        }
+    }
+    // phase 2: the alphabetic tree with these leaf levels
+    std::vector<std::pair<int, unsigned>> stack; // (tmp index, level)
+    size_t q = 0;
+    while (q < sigma || stack.size() > 1)
+    {
+        const size_t sp = stack.size();
+        if (sp >= 2 && stack[sp - 1].second == stack[sp - 2].second)
+        {
+            const int l = stack[sp - 2].first, r = stack[sp - 1].first;
+            const unsigned lv = stack[sp - 1].second - 1;
+            tmp.push_back(ShapeTmp{tmp[l].freq + tmp[r].freq, -1, l, r});
+            stack.pop_back();
+            stack.back() = {(int)tmp.size() - 1, lv};
+        }
+        else
+        {
+            tmp.push_back(ShapeTmp{occ[syms[q]], syms[q], -1, -1});
+            stack.push_back({(int)tmp.size() - 1, level[q]});
+            ++q;
+        }
+    }
+    return stack[0].first;
+}
+
+static sdsl_hip_status build_shape(const uint64_t occ[256], uint32_t shape, WtTables & T, uint32_t & n_nodes,
                                    uint64_t & bv_size, uint64_t & sigma)
 {
     std::vector<ShapeTmp> tmp;
@@ -109,7 +230,8 @@ static sdsl_hip_status build_shape(const uint64_t occ[256], bool balanced, WtTab
     bv_size = 0;
     if (syms.empty())
         return SDSL_HIP_OK;
-    const int root = balanced ? shape_balanced_rec(syms, 0, syms.size(), occ, tmp) : shape_huffman(occ, tmp);
+    const int root = shape == 1 ? shape_balanced_rec(syms, 0, syms.size(), occ, tmp)
+                                : (shape == 2 ? shape_hutu(syms, occ, tmp) : shape_huffman(occ, tmp));
     n_nodes = (uint32_t)tmp.size();
     // breadth-first renumbering
     std::vector<int> order; // order[bfs id] = tmp id
@@ -264,7 +386,13 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
     }
     // 2. shape
     uint64_t bv_size = 0;
-    SH_TRY(build_shape(wt.occ, (flags & SDSL_HIP_WT_BLCD) != 0, wt.tables, wt.n_nodes, bv_size, wt.sigma));
+    if ((flags & SDSL_HIP_WT_BLCD) && (flags & SDSL_HIP_WT_HUTU))
+    {
+        set_error("wt_create: SDSL_HIP_WT_BLCD and SDSL_HIP_WT_HUTU exclude each other");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_TRY(build_shape(wt.occ, (flags & SDSL_HIP_WT_BLCD) ? 1u : ((flags & SDSL_HIP_WT_HUTU) ? 2u : 0u), wt.tables, wt.n_nodes,
+                       bv_size, wt.sigma));
     WtTables & T = wt.tables;
     // 3. bits, level by level
     const uint64_t nw = (bv_size + 63) >> 6;

@@ -352,7 +352,7 @@ class wt_huff(_Handle):
     _destroy = "sdsl_hip_wt_destroy"
 
     def __init__(self, text=None, device: int = 0, sdsl_bytes: bytes | None = None, select_is_mcl: bool = True,
-                 rrr: bool = False, balanced: bool = False, _borrowed=None):
+                 rrr: bool = False, balanced: bool = False, hutu: bool = False, _borrowed=None):
         """rrr=True: wt_huff<rrr_vector<63>> (the bit vector is stored rrr-compressed); for sdsl_bytes it says that
         the stream is of that type, otherwise select_is_mcl tells the two plain flavours apart.  balanced=True builds
         the wt_blcd shape instead of the Huffman shape (streams of any wt_pc byte shape load as they are)."""
@@ -371,7 +371,7 @@ class wt_huff(_Handle):
         else:
             t = _bytes_arg(text, "text")
             n = t.numel() if _is_tensor(t) else t.size
-            flags = (capi.WT_RRR63 if rrr else 0) | (capi.WT_BLCD if balanced else 0)
+            flags = (capi.WT_RRR63 if rrr else 0) | (capi.WT_BLCD if balanced else 0) | (capi.WT_HUTU if hutu else 0)
             capi.check(capi.lib().sdsl_hip_wt_create_ex(_ptr(t) if n else None, n, device, flags, C.byref(self._h)))
         self.device = device
 
@@ -447,12 +447,12 @@ class csa_wt(_Handle):
 
     def __init__(self, text=None, bwt=None, device: int = 0, sdsl_bytes: bytes | None = None,
                  select_is_mcl: bool = True, rrr: bool = False, sa_dens: int = 0, isa_dens: int = 0,
-                 balanced: bool = False):
+                 balanced: bool = False, hutu: bool = False):
         """rrr=True: csa_wt<wt_huff<rrr_vector<63>>> (compressed FM-index).  sa_dens / isa_dens: the template arguments
         of the serialised type (needed to keep its SA / ISA samples for sa / isa / locate / extract)."""
         super().__init__()
         L = capi.lib()
-        flags = (capi.WT_RRR63 if rrr else 0) | (capi.WT_BLCD if balanced else 0)
+        flags = (capi.WT_RRR63 if rrr else 0) | (capi.WT_BLCD if balanced else 0) | (capi.WT_HUTU if hutu else 0)
         if sdsl_bytes is not None:
             buf = np.frombuffer(sdsl_bytes, dtype=np.uint8)
             layout = capi.LAYOUT_RRR63 if rrr else (capi.LAYOUT_BV_MCL if select_is_mcl else capi.LAYOUT_BV_SCAN)

@@ -769,6 +769,36 @@ def test_wt_blcd_built_on_gpu(gpu, name, rrr):
 
 
 @pytest.mark.parametrize("name", ["example01.txt", "faust60k"])
+def test_wt_hutu_and_blcd_default_types_built_on_gpu(gpu, name):
+    """Hu-Tucker and balanced trees built on the device, written as wt_hutu<> / wt_blcd<> with SDSL's default arguments
+    (rank_support_v, select_support_mcl): the real library's files byte for byte"""
+    data = _shape_text(name)
+    hutu = gpu.wt_huff(data, hutu=True)
+    _check_wt_against_oracle(hutu, data, 85)
+    assert hutu.serialize(gpu.capi.LAYOUT_BV_DEFAULT) == gd.sdsl_file(f"{name}.wt_hutu.sdsl")
+    blcd = gpu.wt_huff(data, balanced=True)
+    assert blcd.serialize(gpu.capi.LAYOUT_BV_DEFAULT) == gd.sdsl_file(f"{name}.wt_blcd.sdsl")
+    _check_wt_against_oracle(gpu.wt_huff(data, hutu=True, rrr=True), data, 86)
+    with pytest.raises(gpu.capi.SdslHipError):
+        gpu.wt_huff(data, hutu=True, balanced=True)
+
+
+def test_wt_hutu_tie_breaks_match_the_reference(gpu):
+    """alphabets full of equal weights: the merge order of the reference's master queue decides the code lengths"""
+    if not ol.have_ref():
+        pytest.skip("needs oracle/_ref")
+    rng = np.random.default_rng(3)
+    for trial in range(60):
+        sigma = int(rng.integers(1, 60))
+        syms = np.sort(rng.choice(np.arange(1, 256), sigma, replace=False))
+        w = rng.integers(1, 4, sigma) if trial % 2 else np.maximum(1, (300 / np.arange(1, sigma + 1)).astype(int))
+        text = np.concatenate([np.full(int(k), c, dtype=np.uint8) for c, k in zip(syms, w)])
+        rng.shuffle(text)
+        wt = gpu.wt_huff(text, hutu=True)
+        assert wt.serialize(gpu.capi.LAYOUT_BV_DEFAULT) == ol.ref_wt_shape_bytes(text.tobytes(), 2, 0)
+
+
+@pytest.mark.parametrize("name", ["example01.txt", "faust60k"])
 def test_fm_blcd_built_on_gpu(gpu, name):
     data = _shape_text(name)
     csa = gpu.csa_wt(text=data, balanced=True)
