@@ -12,7 +12,7 @@ aggregate.  Prints ONE JSON line on rank 0 with the contract keys plus `roofline
 against the HBM roofline, algorithmic bytes per SURVEY.md §8(d)) and `cpu_baseline` (the reference's CPU
 path on a bounded sample of the same workload, timed on this box's host cores, N=1 only).
 
-Optional secondary measurements (`--extras select,rrr,wt,fm`) are reported under "extras"; they never
+Optional secondary measurements (`--extras select,rrr,sd,wt,fm`) are reported under "extras"; they never
 enter the timed region.
 """
 from __future__ import annotations
@@ -43,7 +43,7 @@ def parse():
     p.add_argument("--log-n", type=int, default=34, help="bit vector length = 2^log_n (BASELINE: 34)")
     p.add_argument("--queries", type=float, default=1e9, help="queries per step per GPU (BASELINE: 1e9)")
     p.add_argument("--extras", type=str, default=None,
-                   help="comma list of: select,rrr,wt,fm,fm_sharded (or 'none'); default: the first four on one GPU, "
+                   help="comma list of: select,rrr,sd,wt,fm,fm_sharded (or 'none'); default: the first five on one GPU, "
                         "fm_sharded (configs[4]: 10^8 patterns sharded over the ranks) on several")
     p.add_argument("--text-mib", type=int, default=1024, help="synthetic text size for the wt/fm extras (BASELINE: 1 GiB)")
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -235,7 +235,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(42)
     words = torch.randint(-2**63, 2**63 - 1, (n_bits // 64,), device=dev, dtype=torch.int64, generator=g)
     if a.extras is None:
-        a.extras = "select,rrr,wt,fm" if world == 1 else "fm_sharded"
+        a.extras = "select,rrr,sd,wt,fm" if world == 1 else "fm_sharded"
     extras = [] if a.extras in ("", "none") else a.extras.split(",")
     bv = pkg.bit_vector(words, n_bits, device=local, select1="select" in extras, select0=False)
     gq = torch.Generator(device=dev).manual_seed(7 + rank)
@@ -353,6 +353,27 @@ def main():
                     ex["rrr63_select_1"]["cpu_baseline"] = cb
                     ol.ref().L.ref_rrr_destroy(hh)
             del rv, si
+        if "sd" in extras:
+            # sd_vector<> (Elias-Fano): 2^28 ones over a universe of 2^40 — the plain vector would need 128 GiB
+            torch.cuda.empty_cache()
+            N_sd = 1 << 40
+            pos = torch.unique(torch.randint(0, N_sd, (1 << 28,), device=dev, dtype=torch.int64, generator=gq))
+            t0 = time.perf_counter()
+            sd = pkg.sd_vector(positions=pos, n_bits=N_sd, device=local)
+            torch.cuda.synchronize()
+            sd_build = time.perf_counter() - t0
+            nq_sd = min(nq, 100_000_000)
+            xi = torch.randint(0, N_sd + 1, (nq_sd,), device=dev, dtype=torch.int64, generator=gq)
+            o_sd = torch.empty(nq_sd, dtype=torch.int64, device=dev)
+            _, ms_r = time_steps(lambda: sd.rank(xi, 1, o_sd), 3, 1, barrier)
+            assert torch.equal(o_sd[:1_000_000], torch.searchsorted(pos, xi[:1_000_000], right=False))
+            si = torch.randint(1, pos.numel() + 1, (nq_sd,), device=dev, dtype=torch.int64, generator=gq)
+            _, ms_s = time_steps(lambda: sd.select(si, 1, o_sd), 3, 1, barrier)
+            assert torch.equal(o_sd, pos[si - 1])
+            ex["sd_vector"] = {"ones": pos.numel(), "universe_log2": 40, "low_width": sd.low_width(),
+                               "bits_per_one": sd.device_bytes() * 8 / pos.numel(), "build_s": sd_build,
+                               "rank_1_Gq/s": nq_sd / ms_r / 1e6, "select_1_Gq/s": nq_sd / ms_s / 1e6, "queries": nq_sd}
+            del sd, pos, xi, si, o_sd
         if "wt" in extras or "fm" in extras:
             torch.cuda.empty_cache()
             nt = a.text_mib << 20

@@ -29,3 +29,9 @@ echo "pmc_sq exit=$?"
 grep -h '^{' $O/bench_trace.log | tail -1 > $O/bench_line_under_trace.json
 cd $R
 ls $O
+# kernel trace of the FULL default bench (all extras): per-kernel averages of the secondary kernels (wavelet tree, FM-index,
+# rrr, sd_vector, locate/extract walks)
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/trace_full -o bench --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/bench_trace_full.log 2>&1
+echo "trace_full exit=$?"
+cd $R

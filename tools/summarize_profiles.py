@@ -42,6 +42,18 @@ try:
 except Exception:
     pass
 
+try:  # the full default bench: every kernel of this library (sdslhip::*), whatever its share
+    rows3 = list(csv.DictReader(open(os.path.join(src, "trace_full", "bench_kernel_stats.csv"))))
+    with open(os.path.join(dst, f"bench_{tag}_kernel_stats_full.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows3:
+            if "sdslhip" in r["Name"]:
+                w.writerow([short(r["Name"])[:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"], r["StdDev"]])
+except Exception:
+    pass
+
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ("pmc_rd", "pmc_wr", "pmc_fetch", "pmc_write", "pmc_sq"):
     p = os.path.join(src, sub, "bench_counter_collection.csv")
