@@ -18,6 +18,13 @@
  *    are *defined*: the result slot is set to SDSL_HIP_NPOS (all ones).  The one overflow
  *    SDSL does define — select_support_rrr returns size() (rrr_vector.hpp:641-642,686-689)
  *    — is reproduced exactly;
+ *  - large batches with BOTH arrays in host memory (>= 2^23 queries; rank / select of the bit-vector family) are cut
+ *    into chunks that travel on two internal streams, so uploads, kernels and downloads overlap; `stream` is then
+ *    only a placeholder and the call returns when all results are in place;
+ *  - threading: like SDSL's, query calls are const on the handle and may run concurrently from
+ *    several host threads (the error text of sdsl_hip_last_error() is per thread).  Calls that change a handle —
+ *    *_destroy, sdsl_hip_fm_drop_sa, sdsl_hip_fm_set_jump_depth, and the first ISA / extract call on an index that
+ *    still holds its whole suffix array (it materialises the ISA samples) — must not overlap other calls on that handle;
  *  - there is NO CPU fallback: without a usable gfx950 device every create call fails with
  *    SDSL_HIP_ERR_NO_DEVICE.
  */
