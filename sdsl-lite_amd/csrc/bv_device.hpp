@@ -148,6 +148,11 @@ __device__ __forceinline__ Pair arg_words(Pair w, int s, uint64_t n_bits, uint64
         r.a = s == 0 ? 0 : w.a;
         r.b = w.b;
     }
+    else if ((L + 1) * kDB <= n_bits)
+    { // every position of the line exists (all lines but the last one or two): no masking (quad-uniform branch)
+        r.a = s == 0 ? 0 : ~w.a;
+        r.b = ~w.b;
+    }
     else
     {
         r.a = s == 0 ? 0 : (~w.a & valid_mask(n_bits, L, 2 * s - 1));
@@ -215,7 +220,7 @@ __device__ __forceinline__ uint64_t sel_interpolate(uint64_t lo_pos, uint64_t sp
 {
     if (den == (UINT64_C(1) << first_shift))
         return lo_pos + ((num * span) >> first_shift); // num < 2^20, span < 2^40: no overflow
-    float f = __fdividef((float)num, (float)(den ? den : 1));
+    const float f = (float)num * __builtin_amdgcn_rcpf((float)(den ? den : 1)); // 1-ulp reciprocal: a hint needs no more
     uint64_t off = (uint64_t)(f * (float)span);
     return lo_pos + (off >= span ? span - 1 : off);
 }
@@ -229,7 +234,10 @@ __device__ __forceinline__ uint64_t sel_guess(const BvView & bv, const SelBracke
         p = b.lo_pos + (span >> 1);
     else
         p = sel_interpolate(b.lo_pos, span, k - b.lo_cnt, b.hi_cnt - b.lo_cnt, bv.sel_shift);
-    uint64_t W = (p / kDB) >> 1;
+    // window index = p / 896 = (p >> 7) / 7: positions are below 2^40 (select directory limit), so (p >> 8) fits 32 bits
+    // and the division by 7 runs on 32-bit multiplies: q = (2 * (p >> 8) + bit 7 of p) / 7
+    const uint32_t hi = (uint32_t)(p >> 8);
+    uint64_t W = ((uint64_t)(hi / 7u) << 1) + (((hi % 7u) * 2u + ((uint32_t)(p >> 7) & 1u)) / 7u);
     const uint64_t last_win = (bv.n_lines >> 1) - 1; // n_lines is even
     return W > last_win ? last_win : W;
 }
