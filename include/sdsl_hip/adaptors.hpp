@@ -274,6 +274,93 @@ public:
     }
 };
 
+//! rank_support_il<t_b, t_bs> / select_support_il<t_b, t_bs> look-alikes (bit_vector_il.hpp:303-317,  :398-460) over a
+//! bit_vector_il<t_bs>: the interleaving is a host cache layout (the device's rank lines are its counterpart), so the
+//! vector travels as its plain bits and the supports answer from rank lines.
+template <uint8_t t_b = 1, uint32_t t_bs = 512>
+class rank_support_il_hip
+{
+    bit_vector m_bits;
+    rank_support_v5_hip<t_b> m_rs;
+
+public:
+    typedef bit_vector_il<t_bs> bit_vector_type;
+    typedef bit_vector::size_type size_type;
+    explicit rank_support_il_hip(bit_vector_type const * v = nullptr, int device = 0) : m_rs(nullptr, device)
+    {
+        set_vector(v);
+    }
+    rank_support_il_hip(rank_support_il_hip const & o) : m_bits(o.m_bits), m_rs(o.m_rs)
+    {
+        if (!m_bits.empty())
+            m_rs.set_vector(&m_bits);
+    }
+    rank_support_il_hip & operator=(rank_support_il_hip const &) = delete;
+    void set_vector(bit_vector_type const * v = nullptr)
+    {
+        m_bits = v ? to_bit_vector(*v) : bit_vector();
+        m_rs.set_vector(v ? &m_bits : nullptr);
+    }
+    size_type rank(size_type i) const
+    {
+        return m_rs.rank(i);
+    }
+    size_type operator()(size_type i) const
+    {
+        return m_rs.rank(i);
+    }
+    void rank_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        m_rs.rank_batch(i, n, out, stream);
+    }
+    size_type size() const
+    {
+        return m_bits.size();
+    }
+};
+
+template <uint8_t t_b = 1, uint32_t t_bs = 512>
+class select_support_il_hip
+{
+    bit_vector m_bits;
+    select_support_mcl_hip<t_b> m_ss;
+
+public:
+    typedef bit_vector_il<t_bs> bit_vector_type;
+    typedef bit_vector::size_type size_type;
+    explicit select_support_il_hip(bit_vector_type const * v = nullptr, int device = 0) : m_ss(nullptr, device)
+    {
+        set_vector(v);
+    }
+    select_support_il_hip(select_support_il_hip const & o) : m_bits(o.m_bits), m_ss(o.m_ss)
+    {
+        if (!m_bits.empty())
+            m_ss.set_vector(&m_bits);
+    }
+    select_support_il_hip & operator=(select_support_il_hip const &) = delete;
+    void set_vector(bit_vector_type const * v = nullptr)
+    {
+        m_bits = v ? to_bit_vector(*v) : bit_vector();
+        m_ss.set_vector(v ? &m_bits : nullptr);
+    }
+    size_type select(size_type i) const
+    {
+        return m_ss.select(i);
+    }
+    size_type operator()(size_type i) const
+    {
+        return m_ss.select(i);
+    }
+    void select_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        m_ss.select_batch(i, n, out, stream);
+    }
+    size_type size() const
+    {
+        return m_bits.size();
+    }
+};
+
 //! Device image of an rrr_vector<63> (rrr_vector.hpp:68) built from the host object's own serialised
 //! arrays; exposes the rank/select/access members of rank_support_rrr / select_support_rrr in batch form.
 class rrr_vector_hip
@@ -307,6 +394,11 @@ public:
         hip_detail::check(sdsl_hip_rrr_create(bv.data(), bv.bit_size(), device, &h), "sdsl_hip_rrr_create");
         m_dev.reset(h, deleter());
     }
+    //! any other rrr_vector<t_bs, t_rac, t_k> (block sizes 15, 31, 127, ..., other sample rates): the device keeps its
+    //! own layout (block size 63), so the vector is handed over through its plain bits — the answers are the same
+    template <uint16_t t_bs, class t_rac, uint16_t t_k>
+    explicit rrr_vector_hip(rrr_vector<t_bs, t_rac, t_k> const & v, int device = 0) : rrr_vector_hip(to_bit_vector(v), device)
+    {}
     size_type size() const
     {
         return sdsl_hip_rrr_size(m_dev.get());

@@ -128,6 +128,25 @@ int main(int argc, char ** argv)
                     }
                 }
                 CHECK(ok, "rank on bit_vector_il<512>, select on rrr_vector<15> through their bits");
+                // the named adaptors for them
+                rank_support_il_hip<1, 512> ilh(&il);
+                select_support_il_hip<0, 512> ils(&il);
+                bit_vector_il<512>::select_0_type ils_ref(&il);
+                rrr_vector_hip d15(r15);
+                rank_support_rrr_hip<0> r15h(&d15);
+                rrr_vector<15>::rank_0_type r15r(&r15);
+                bool ok2 = true;
+                for (int t = 0; t < 200; ++t)
+                {
+                    uint64_t x = rng() % (n + 1);
+                    ok2 &= ilh(x) == ilr(x) and r15h(x) == r15r(x);
+                    if (n - ones)
+                    {
+                        uint64_t k = 1 + rng() % (n - ones);
+                        ok2 &= ils(k) == ils_ref(k);
+                    }
+                }
+                CHECK(ok2, "rank_support_il_hip / select_support_il_hip / rrr_vector_hip(rrr_vector<15>)");
             }
             // sd_vector<>
             {
