@@ -107,12 +107,40 @@ __device__ __forceinline__ Pair load_pair(const uint64_t * lines, uint64_t L, in
 // the header and never contributes.
 __device__ __forceinline__ unsigned lane_ones_below(Pair w, int s, unsigned off)
 {
-    const int wi = (int)(off >> 6);
-    const unsigned bi = off & 63;
-    const int db = 2 * s, da = 2 * s - 1;
-    uint64_t mb = db < wi ? ~UINT64_C(0) : (db == wi ? lo_set(bi) : UINT64_C(0));
-    uint64_t ma = (s == 0) ? UINT64_C(0) : (da < wi ? ~UINT64_C(0) : (da == wi ? lo_set(bi) : UINT64_C(0)));
-    return popc64(w.b & mb) + popc64(w.a & ma);
+    // bits of the lane's 128-bit share below the offset: t = off - 64 * (2s - 1), clamped to [0, 64] per word; the
+    // count of the low t bits of x is popc(x << (64 - t)) for t >= 1
+    const int t = (int)off - 64 * (2 * s - 1);
+    const int ta = t < 0 ? 0 : (t > 64 ? 64 : t), tb = t < 64 ? 0 : (t > 128 ? 64 : t - 64);
+    const uint64_t xa = s == 0 ? UINT64_C(0) : w.a; // lane 0 holds the header there
+    const unsigned ca = ta ? popc64(xa << (64 - ta)) : 0u;
+    const unsigned cb = tb ? popc64(w.b << (64 - tb)) : 0u;
+    return ca + cb;
+}
+
+// line index and in-line offset of a bit position.  Positions below 2^38 (every wavelet tree over < 2^35 symbols, every
+// vector below 32 GiB) take a 32-bit division by 7 instead of the 64-bit division by 448; `small` must be uniform.
+__device__ __forceinline__ void line_of(uint64_t pos, bool small, uint64_t & L, unsigned & off)
+{
+    if (small)
+    {
+        const uint32_t w = (uint32_t)(pos >> 6), l = w / 7u;
+        L = l;
+        off = ((w - 7u * l) << 6) | ((uint32_t)pos & 63u);
+    }
+    else
+    {
+        L = pos / kDB;
+        off = (unsigned)(pos - L * kDB);
+    }
+}
+
+// quad_rank1 with the line index / offset already known
+__device__ __forceinline__ uint64_t quad_rank1_at(Pair w, int s, unsigned off)
+{
+    unsigned part = lane_ones_below(w, s, off);
+    unsigned tot = quad_sum(part);
+    uint64_t hdr = quad_bcast0_u64(w.a);
+    return hdr + tot;
 }
 
 // rank_1(idx) for idx in [0, n_bits]; all four lanes of the quad call it with the same idx and

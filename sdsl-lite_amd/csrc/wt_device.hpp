@@ -59,12 +59,15 @@ __device__ __forceinline__ uint64_t quad_wt_rank(const WtView & wt, const WtTabl
     unsigned len = (unsigned)(p >> 56);
     uint64_t result = i;
     unsigned v = 0;
+    const bool small = wt.bv.n_bits < (UINT64_C(1) << 38);
     for (unsigned l = 0; l < len && result; ++l, p >>= 1)
     {
         uint64_t pos = T->bv_pos[v] + result;
-        uint64_t L = pos / kDB;
+        uint64_t L;
+        unsigned off;
+        line_of(pos, small, L, off);
         Pair w = load_pair<NT>(wt.bv.lines, L, s);
-        uint64_t r = quad_rank1(w, s, pos, L) - T->bv_pos_rank[v];
+        uint64_t r = quad_rank1_at(w, s, off) - T->bv_pos_rank[v];
         unsigned bit = (unsigned)(p & 1);
         result = bit ? r : result - r;
         v = T->child[v][bit];
@@ -82,15 +85,19 @@ __device__ __forceinline__ void quad_wt_rank2_level(const WtView & wt, const WtT
                                                     unsigned bit, uint64_t & a, uint64_t & b)
 {
     const uint64_t base = T->bv_pos[v], brank = T->bv_pos_rank[v];
+    const bool small = wt.bv.n_bits < (UINT64_C(1) << 38);
     uint64_t pa = base + a, pb = base + b;
-    uint64_t La = pa / kDB, Lb = pb / kDB;
+    uint64_t La, Lb;
+    unsigned oa, ob;
+    line_of(pa, small, La, oa);
+    line_of(pb, small, Lb, ob);
     Pair wb = load_pair<NT>(wt.bv.lines, Lb, s);
     Pair wa = wb;
     if (La != Lb) // quad-uniform
         wa = load_pair<NT>(wt.bv.lines, La, s);
     // rank at bv_pos+0 equals bv_pos_rank, so a == 0 stays 0 without a special case
-    uint64_t ra = quad_rank1(wa, s, pa, La) - brank;
-    uint64_t rb = quad_rank1(wb, s, pb, Lb) - brank;
+    uint64_t ra = quad_rank1_at(wa, s, oa) - brank;
+    uint64_t rb = quad_rank1_at(wb, s, ob) - brank;
     a = bit ? ra : a - ra;
     b = bit ? rb : b - rb;
     v = T->child[v][bit];
