@@ -232,10 +232,106 @@ static int pairs(int argc, char ** argv)
     return 0;
 }
 
+// The access skeleton of select with (almost) no arithmetic: argument (streamed) -> two adjacent 4-byte samples of a
+// small directory (cache resident) -> ONE dependent, random, aligned 128-byte window of the big table fetched by a quad
+// (two 64-byte halves) -> streamed result.  Its rate is the ceiling of that access mix.
+template <int U, int SAMPLES>
+__global__ __launch_bounds__(256) void k_chain(const v2u64 * __restrict__ table, uint64_t n_windows,
+                                               const uint32_t * __restrict__ dir, uint64_t dir_n,
+                                               const uint64_t * __restrict__ idx, uint64_t * __restrict__ out, uint64_t n_q)
+{
+    const int s = threadIdx.x & 3;
+    const unsigned gq = threadIdx.x >> 2;
+    constexpr unsigned QPB = 64;
+    for (uint64_t base = (uint64_t)blockIdx.x * QPB * U; base < n_q; base += (uint64_t)gridDim.x * QPB * U)
+    {
+        v2u64 va[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            uint64_t q = base + (uint64_t)u * QPB + gq;
+            uint64_t a = q < n_q ? __builtin_nontemporal_load(idx + q) : 0;
+            uint64_t c = a;
+            if (SAMPLES == 1)
+            {
+                uint64_t j = a % dir_n;
+                c += dir[j] + dir[j + 1]; // zeros: the window index DEPENDS on the samples without changing
+            }
+            else if (SAMPLES == 2)
+            { // both samples with ONE 8-byte load (4-byte aligned)
+                uint64_t j = a % dir_n, two;
+                __builtin_memcpy(&two, dir + j, 8);
+                c += two;
+            }
+            c %= n_windows;
+            const v2u64 * p = table + c * 8 + s;
+            va[u] = p[0];
+            vb[u] = p[4];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            uint64_t q = base + (uint64_t)u * QPB + gq;
+            uint64_t acc = __popcll(va[u].x) + __popcll(va[u].y) + __popcll(vb[u].x) + __popcll(vb[u].y);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if (s == 0 && q < n_q)
+                __builtin_nontemporal_store(acc, out + q);
+        }
+    }
+}
+
+template <int U, int SAMPLES>
+static void run_chain(const v2u64 * table, uint64_t tb, const uint32_t * dir, uint64_t dir_n, const uint64_t * idx,
+                      uint64_t * out, uint64_t nq)
+{
+    float ms = time_ms(
+        [&] {
+            hipLaunchKernelGGL((k_chain<U, SAMPLES>), dim3(256 * 8), dim3(256), 0, 0, table, tb / 128, dir, dir_n, idx, out,
+                               nq);
+        },
+        3);
+    printf("chain U=%d samples=%d dir=%6.2f MiB : %8.3f ms  %7.2f Gq/s\n", U, (int)SAMPLES, dir_n * 4 / 1048576.0, ms,
+           nq / ms / 1e6);
+    fflush(stdout);
+}
+
+static int chain(int argc, char ** argv)
+{ // gather_probe chain <nq> <table MiB>
+    uint64_t nq = strtoull(argv[2], 0, 10);
+    uint64_t tb = strtoull(argv[3], 0, 10) << 20;
+    v2u64 * table;
+    uint64_t *idx, *out;
+    uint32_t * dir;
+    const uint64_t dir_max = 1ull << 23;
+    CK(hipMalloc(&table, tb));
+    CK(hipMalloc(&idx, nq * 8));
+    CK(hipMalloc(&out, nq * 8));
+    CK(hipMalloc(&dir, (dir_max + 1) * 4));
+    CK(hipMemset(dir, 0, (dir_max + 1) * 4));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, (uint64_t *)table, tb / 8);
+    hipLaunchKernelGGL(k_fill_idx, dim3(4096), dim3(256), 0, 0, idx, nq, ~0ull);
+    CK(hipDeviceSynchronize());
+    run_chain<1, 0>(table, tb, dir, 1, idx, out, nq);
+    run_chain<2, 0>(table, tb, dir, 1, idx, out, nq);
+    run_chain<4, 0>(table, tb, dir, 1, idx, out, nq);
+    for (uint64_t dn : {1ull << 17, 1ull << 19, 1ull << 21, 1ull << 23})
+    {
+        run_chain<1, 1>(table, tb, dir, dn, idx, out, nq);
+        run_chain<2, 1>(table, tb, dir, dn, idx, out, nq);
+        run_chain<4, 1>(table, tb, dir, dn, idx, out, nq);
+        run_chain<1, 2>(table, tb, dir, dn, idx, out, nq);
+        run_chain<4, 2>(table, tb, dir, dn, idx, out, nq);
+    }
+    return 0;
+}
+
 int main(int argc, char ** argv)
 {
     if (argc > 3 && !strcmp(argv[1], "pairs"))
         return pairs(argc, argv);
+    if (argc > 3 && !strcmp(argv[1], "chain"))
+        return chain(argc, argv);
     if (argc > 3 && !strcmp(argv[1], "sweep"))
         return sweep(argc, argv);
     if (argc > 2 && !strcmp(argv[1], "scatter"))
