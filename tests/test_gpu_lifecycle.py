@@ -105,3 +105,59 @@ def test_rejected_streams_do_not_leak(gpu):
     leaked = _settled(once, 3)
     assert refused[0] > 0
     assert leaked < SLACK, f"{leaked} bytes leaked on error paths"
+
+
+def test_concurrent_queries_from_host_threads(gpu):
+    """include/sdsl_hip.h: query calls are const on the handle and may run concurrently from several host threads
+    (SDSL's own rule for its const members).  Eight threads hammer shared handles; every answer must equal the
+    single-threaded one."""
+    import threading
+    rng = np.random.default_rng(11)
+    n = 1 << 24
+    w = gpu.set_random_bits(n, 9)
+    bv = gpu.bit_vector(w, n)
+    rv = gpu.rrr_vector(w, n)
+    sd = gpu.sd_vector(w, n)
+    text = rng.integers(97, 105, size=1_000_000, dtype=np.uint8).tobytes()
+    csa = gpu.csa_wt(text=text)
+    crrr = gpu.csa_wt(text=text, rrr=True)
+    crrr.drop_sa()
+    arr = np.frombuffer(text, dtype=np.uint8)
+    jobs = []
+    for t in range(8):
+        r = np.random.default_rng(100 + t)
+        idx = r.integers(0, n + 1, size=200_000).astype(np.uint64)
+        k = r.integers(1, bv.ones() + 1, size=100_000).astype(np.uint64)
+        st = r.integers(0, len(text) - 12, size=3000)
+        pats = np.concatenate([arr[s:s + 12] for s in st])
+        si = r.integers(0, csa.size(), size=2000).astype(np.uint64)
+        jobs.append((idx, k, pats, si))
+
+    def answers(job):
+        idx, k, pats, si = job
+        off, pos = csa.locate(pats, 12)
+        eo, et = crrr.extract(si[:50], np.minimum(si[:50] + np.uint64(40), np.uint64(csa.size() - 1)))
+        return [bv.rank(idx), bv.select(k), rv.rank(idx), rv.select(k), sd.rank(idx), sd.select(k), csa.count(pats, 12),
+                crrr.count(pats, 12), off, pos, csa.sa(si), crrr.sa(si[:300]), crrr.isa(si[:300]), eo, et,
+                csa.wavelet_tree.rank(si, arr[:si.size])]
+
+    expect = [answers(j) for j in jobs]
+    got = [None] * len(jobs)
+    errors = []
+
+    def worker(t):
+        try:
+            for _ in range(3):
+                got[t] = answers(jobs[t])
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(len(jobs)):
+        for a, b in zip(expect[t], got[t]):
+            assert np.array_equal(a, b), f"thread {t} got a different answer"
