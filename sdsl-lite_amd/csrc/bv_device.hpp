@@ -154,6 +154,22 @@ __device__ __forceinline__ uint64_t quad_rank1(Pair w, int s, uint64_t idx, uint
     return hdr + tot;
 }
 
+// rank_1(pos) by ONE lane (construction passes that walk many neighbouring positions; the query kernels use the quad
+// forms above).  pos in [0, n_bits]; *bit receives the bit at pos when asked for (then pos < n_bits).
+__device__ __forceinline__ uint64_t lane_rank1(const uint64_t * lines, uint64_t pos, unsigned * bit)
+{
+    const uint64_t L = pos / kDB;
+    const unsigned off = (unsigned)(pos - L * kDB), wi = off >> 6;
+    const uint64_t * ln = lines + L * kLW;
+    uint64_t r = ln[0];
+    for (unsigned j = 0; j < wi; ++j)
+        r += popc64(ln[1 + j]);
+    const uint64_t w = ln[1 + wi];
+    if (bit)
+        *bit = (unsigned)((w >> (off & 63)) & 1);
+    return r + popc64(w & lo_set(off & 63));
+}
+
 // Mask of the valid data bits of word `d` (0..6) of line L given the vector length.
 __device__ __forceinline__ uint64_t valid_mask(uint64_t n_bits, uint64_t L, int d)
 {

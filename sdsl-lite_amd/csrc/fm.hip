@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_fm_keys(const uint8_t * __restrict__ pa
 // character the quad is at — so the 16 quads of a wave do not wait for each other at character boundaries (Huffman
 // paths differ in length; a nested loop would cost max(len) instead of len per character).  The next pattern byte is
 // fetched one character ahead.
-template <bool NT, bool WANT_IVAL>
+template <bool NT, bool WANT_IVAL, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables * __restrict__ ftab, FmJump J,
                                                      uint64_t csa_size, const uint8_t * __restrict__ pats,
                                                      uint32_t m, const uint64_t * __restrict__ offsets,
@@ -107,9 +107,14 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
                 left = (unsigned)(p >> 56);
                 v = 0;
             }
-            quad_wt_rank2_level<NT>(wt, &T, s, v, (unsigned)(p & 1), a, b);
-            p >>= 1;
-            --left;
+            if (FUSED) // one iteration = up to three levels (wt_device.hpp: fused layout)
+                quad_wt8_rank2_step<NT>(wt, &T, s, v, p, left, a, b);
+            else
+            {
+                quad_wt_rank2_level<NT>(wt, &T, s, v, (unsigned)(p & 1), a, b);
+                p >>= 1;
+                --left;
+            }
             if (b == 0)
             { // a <= b: both chains are 0 from here on (wt_pc.hpp:386)
                 a = 0;
@@ -667,16 +672,24 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
     }
     else
     {
-        if (ival)
-            hipLaunchKernelGGL((k_fm_count<false, true>), dim3(grid), dim3(kBlock), 0, s, w.view(),
-                               fm->d_tab.as<FmTables>(), jump, fm->size, (const uint8_t *)sp.dev, m,
-                               offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat, (uint64_t *)nullptr,
-                               (uint64_t *)sl.dev, (uint64_t *)sr.dev);
+        const FmTables * tab = fm->d_tab.as<FmTables>();
+        const uint8_t * pp = (const uint8_t *)sp.dev;
+        const uint64_t * oo = offsets ? (const uint64_t *)so.dev : nullptr;
+        uint64_t *oc = ival ? nullptr : (uint64_t *)sc.dev, *ol = ival ? (uint64_t *)sl.dev : nullptr,
+                 *orr = ival ? (uint64_t *)sr.dev : nullptr;
+        const WtView v = w.view();
+        if (ival && v.f_lines)
+            hipLaunchKernelGGL((k_fm_count<false, true, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp, m,
+                               oo, d_order, n_pat, oc, ol, orr);
+        else if (ival)
+            hipLaunchKernelGGL((k_fm_count<false, true, false>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
+                               m, oo, d_order, n_pat, oc, ol, orr);
+        else if (v.f_lines)
+            hipLaunchKernelGGL((k_fm_count<false, false, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
+                               m, oo, d_order, n_pat, oc, ol, orr);
         else
-            hipLaunchKernelGGL((k_fm_count<false, false>), dim3(grid), dim3(kBlock), 0, s, w.view(),
-                               fm->d_tab.as<FmTables>(), jump, fm->size, (const uint8_t *)sp.dev, m,
-                               offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat, (uint64_t *)sc.dev,
-                               (uint64_t *)nullptr, (uint64_t *)nullptr);
+            hipLaunchKernelGGL((k_fm_count<false, false, false>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
+                               m, oo, d_order, n_pat, oc, ol, orr);
     }
     if (scratch)
         (void)hipFreeAsync(scratch, s);

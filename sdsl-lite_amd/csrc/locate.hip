@@ -38,7 +38,10 @@ struct LocPlain
     }
     static __device__ __forceinline__ void level(const WtView & wt, const Shared * S, int s, unsigned & v, uint64_t & i)
     {
-        quad_wt_invsel_level<false>(wt, &S->T, s, v, i);
+        if (wt.f_lines) // up to three levels per step
+            quad_wt8_invsel_step<false>(wt, &S->T, s, v, i);
+        else
+            quad_wt_invsel_level<false>(wt, &S->T, s, v, i);
     }
 };
 

@@ -7,6 +7,7 @@
 //   wt_pc::inverse_select  wt_pc.hpp:411-430      wt_pc::select           wt_pc.hpp:443-474
 //   Huffman shape          wt_huff.hpp:83-115     BFS byte tree + paths   wt_helper.hpp:230-327
 #include <algorithm>
+#include <chrono>
 #include <queue>
 
 #include "bv_serialize.hpp"
@@ -639,7 +640,9 @@ __global__ __launch_bounds__(kBlock) void k_wt_rank(WtView wt, const uint64_t * 
             continue;
         uint64_t i = iq[q];
         unsigned c = cq[q];
-        uint64_t r = i <= wt.size ? quad_wt_rank<NT>(wt, &T, s, i, c) : SDSL_HIP_NPOS;
+        uint64_t r = SDSL_HIP_NPOS;
+        if (i <= wt.size)
+            r = wt.f_lines ? quad_wt8_rank<NT>(wt, &T, s, i, c) : quad_wt_rank<NT>(wt, &T, s, i, c);
         if (s == 0)
             out[q] = r;
     }
@@ -724,6 +727,188 @@ __global__ __launch_bounds__(kBlock) void k_wt_select(WtView wt, const uint64_t 
     }
 }
 
+// ---- construction of the fused layout (wt_device.hpp) from the binary tree ---------------------------------------
+// planes: a wave handles 64 consecutive positions of node u's sequence, one lane each.  Consecutive positions of a node
+// stay consecutive inside each child, so a lane's offset one level down = (rank at the group's first position, the
+// same for all lanes that took the same branch) + (number of earlier lanes on that branch, from ballots): two ranks at
+// wave-uniform-per-branch positions and three single-bit reads per lane instead of three full ranks.
+__device__ __forceinline__ unsigned bv_bit(const uint64_t * lines, uint64_t pos)
+{
+    const uint64_t L = pos / kDB;
+    const unsigned off = (unsigned)(pos - L * kDB);
+    return (unsigned)((lines[L * kLW + 1 + (off >> 6)] >> (off & 63)) & 1);
+}
+
+__global__ __launch_bounds__(256) void k_wt8_planes(WtView wt, unsigned u, uint64_t size_u, uint64_t * __restrict__ fl)
+{
+    __shared__ WtTables T;
+    wt_stage_tables(&T, wt.tables);
+    const unsigned lane = threadIdx.x & 63;
+    const uint64_t below = (UINT64_C(1) << lane) - 1; // lanes before this one
+    const uint64_t n_groups = (size_u + 63) >> 6;
+    const uint64_t * lines = wt.bv.lines;
+    for (uint64_t g = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6; g < n_groups; g += (uint64_t)gridDim.x * 4)
+    { // wave-uniform trip count
+        const uint64_t j0 = g * 64, j = j0 + lane;
+        const bool act = j < size_u;
+        const uint64_t m_act = __ballot(act);
+        unsigned b0 = 0, b1 = 0, b2 = 0;
+        // level 0: node u itself (an inner node)
+        if (act)
+            b0 = bv_bit(lines, T.bv_pos[u] + j);
+        const uint64_t m0 = __ballot(b0);
+        const uint64_t r0 = lane_rank1(lines, T.bv_pos[u] + j0, nullptr) - T.bv_pos_rank[u]; // ones before the group
+        const uint64_t start1 = b0 ? r0 : j0 - r0; // where the group's symbols of this branch start inside the child
+        const uint64_t same0 = (b0 ? m0 : ~m0) & m_act;
+        const uint64_t i1 = start1 + (uint64_t)__popcll(same0 & below);
+        const unsigned v1 = T.child[u][b0];
+        const bool in1 = act && T.child[v1][0] != kWtUndef;
+        // level 1
+        if (in1)
+            b1 = bv_bit(lines, T.bv_pos[v1] + i1);
+        const uint64_t m1 = __ballot(b1);
+        uint64_t i2 = 0;
+        unsigned v2 = v1;
+        if (in1)
+        {
+            const uint64_t r1 = lane_rank1(lines, T.bv_pos[v1] + start1, nullptr) - T.bv_pos_rank[v1];
+            const uint64_t start2 = b1 ? r1 : start1 - r1;
+            const uint64_t same1 = same0 & (b1 ? m1 : ~m1);
+            i2 = start2 + (uint64_t)__popcll(same1 & below);
+            v2 = T.child[v1][b1];
+        }
+        // level 2: only the bit is needed
+        if (in1 && T.child[v2][0] != kWtUndef)
+            b2 = bv_bit(lines, T.bv_pos[v2] + i2);
+        const uint64_t m2 = __ballot(b2);
+        if (lane == 0)
+        {
+            uint64_t * sec = fl + (g >> 2) * kFusedWords + (g & 3) * 4;
+            sec[1] = m0;
+            sec[2] = m1;
+            sec[3] = m2;
+        }
+    }
+}
+
+// counts: thread (line, t) cascades position 256 * line of node u down slot t's bits
+__global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint64_t n_lines_u, uint64_t * __restrict__ fl)
+{
+    const WtTables * T = wt.tables;
+    const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t line = id >> 3;
+    const unsigned t = (unsigned)id & 7u;
+    if (line >= n_lines_u)
+        return;
+    unsigned v = u;
+    uint64_t i = line << kFusedLog;
+    bool ok = true;
+    for (unsigned k = 0; k < 3; ++k)
+    {
+        if (T->child[v][0] == kWtUndef)
+        { // a leaf above the third level: its slot is the path padded with zeros
+            ok = (t >> k) == 0;
+            break;
+        }
+        const unsigned bit = (t >> k) & 1;
+        const uint64_t r = lane_rank1(wt.bv.lines, T->bv_pos[v] + i, nullptr) - T->bv_pos_rank[v];
+        i = bit ? r : i - r;
+        v = T->child[v][bit];
+    }
+    reinterpret_cast<uint32_t *>(fl + line * kFusedWords + 4 * (t >> 1))[t & 1] = ok ? (uint32_t)i : 0u;
+}
+
+sdsl_hip_status wt_build_fused(WtHost & wt)
+{
+    const char * env = getenv("SDSL_HIP_WT_FUSED");
+    if (env && atoi(env) == 0)
+        return SDSL_HIP_OK;
+    if (wt.backend != 0 || wt.sigma < 2 || wt.n_nodes < 3 || wt.size == 0 || wt.size >= (UINT64_C(1) << 32) ||
+        !wt.d_tables.p)
+        return SDSL_HIP_OK;
+    WtTables & T = wt.tables;
+    const uint32_t N = wt.n_nodes;
+    // breadth-first order, depths and subtree sizes
+    std::vector<uint32_t> order, depth(N, 0);
+    std::vector<uint64_t> size(N, 0);
+    std::vector<char> seen(N, 0);
+    order.reserve(N);
+    order.push_back(0);
+    seen[0] = 1;
+    for (size_t h = 0; h < order.size(); ++h)
+    {
+        const uint32_t v = order[h];
+        if (T.child[v][0] == kWtUndef)
+            continue;
+        for (int b = 0; b < 2; ++b)
+        {
+            const uint32_t c = T.child[v][b];
+            if (c >= N || seen[c])
+                return SDSL_HIP_OK; // not a tree the fused walk understands: keep the binary layout only
+            seen[c] = 1;
+            depth[c] = depth[v] + 1;
+            order.push_back(c);
+        }
+    }
+    for (size_t h = order.size(); h-- > 0;)
+    {
+        const uint32_t v = order[h];
+        if (T.child[v][0] == kWtUndef)
+            size[v] = wt.occ[T.bv_pos_rank[v] & 0xFF];
+        else
+            size[v] = size[T.child[v][0]] + size[T.child[v][1]];
+    }
+    if (size[0] != wt.size)
+        return SDSL_HIP_OK;
+    uint64_t total = 0;
+    std::vector<uint32_t> roots;
+    for (uint32_t v : order)
+    {
+        T.fline[v] = 0;
+        if (T.child[v][0] == kWtUndef || depth[v] % 3 != 0)
+            continue;
+        T.fline[v] = (uint32_t)total;
+        total += (size[v] >> kFusedLog) + 1;
+        roots.push_back(v);
+    }
+    if (total >= (UINT64_C(1) << 32))
+        return SDSL_HIP_OK;
+    SH_HIP(hipSetDevice(wt.device));
+    const bool trace = getenv("SDSL_HIP_TRACE_BUILD") != nullptr;
+    auto now = [&]() {
+        if (trace)
+            (void)hipDeviceSynchronize();
+        return std::chrono::steady_clock::now();
+    };
+    const auto t0 = now();
+    SH_TRY(wt.d_fused.alloc(total * kFusedWords * 8));
+    SH_HIP(hipMemsetAsync(wt.d_fused.p, 0, total * kFusedWords * 8, 0));
+    WtView view = wt.view();
+    view.f_lines = nullptr;
+    uint64_t * fl = wt.d_fused.as<uint64_t>();
+    const auto t1 = now();
+    for (uint32_t v : roots)
+    {
+        const uint64_t lines_v = (size[v] >> kFusedLog) + 1;
+        uint64_t * at = fl + (uint64_t)T.fline[v] * kFusedWords;
+        if (size[v])
+            hipLaunchKernelGGL(k_wt8_planes, dim3(grid_for((size[v] + 63) >> 6, 4, 256u * 8u)), dim3(256), 0, 0, view, v,
+                               size[v], at);
+        hipLaunchKernelGGL(k_wt8_counts, dim3(grid_for(lines_v * 8, 256, 1u << 20)), dim3(256), 0, 0, view, v, lines_v, at);
+    }
+    SH_HIP(hipGetLastError());
+    SH_HIP(hipMemcpyAsync(wt.d_tables.p, &wt.tables, sizeof(WtTables), hipMemcpyHostToDevice, 0));
+    SH_HIP(hipStreamSynchronize(0));
+    if (trace)
+    {
+        const auto t2 = now();
+        fprintf(stderr, "[sdsl_hip] fused layout: %zu nodes, %llu lines, alloc+clear %.1f ms, kernels %.1f ms\n", roots.size(),
+                (unsigned long long)total, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
+    return SDSL_HIP_OK;
+}
+
 static unsigned wt_grid(uint64_t n)
 {
     return grid_for(n, kQPB, 256u * 8u);
@@ -765,6 +950,7 @@ const uint64_t * sdsl_hip_wt_device_occ(sdsl_hip_wt_s * w)
 }
 sdsl_hip_status sdsl_hip_wt_finish(sdsl_hip_wt_s * w)
 {
+    SH_TRY(wt_build_fused(w->h));
     SH_TRY(w->d_occ.alloc(sizeof w->h.occ));
     SH_HIP(hipMemcpy(w->d_occ.p, w->h.occ, sizeof w->h.occ, hipMemcpyHostToDevice));
     return SDSL_HIP_OK;

@@ -23,6 +23,7 @@ struct WtTables // global-memory image, identical layout in LDS
     uint16_t child[kWtMaxNodes][2];
     uint16_t parent[kWtMaxNodes];
     uint16_t c_to_leaf[256];
+    uint32_t fline[kWtMaxNodes];       // fused layout (below): first line of the node's sequence (nodes at depth 0, 3, 6, ...)
 };
 
 struct WtView
@@ -34,6 +35,7 @@ struct WtView
     uint64_t size;  // number of symbols
     uint64_t sigma; // effective alphabet size
     uint32_t n_nodes;
+    const uint64_t * f_lines; // fused (8-ary) layout of the same tree, nullptr if not built
 };
 
 // cooperative copy of the tables into LDS (all threads of the block)
@@ -103,6 +105,123 @@ __device__ __forceinline__ void quad_wt_rank2_level(const WtView & wt, const WtT
     v = T->child[v][bit];
 }
 
+// ---- fused layout: three tree levels per memory access -----------------------------------------
+// A rank cascade is a chain of DEPENDENT random line fetches, one per tree level, and the fetch rate is what bounds it
+// (DESIGN.md §3.1).  The fused layout stores the same tree a second time with three binary levels collapsed into one
+// 8-ary level: every node u at depth 0, 3, 6, ... owns the sequence of the symbols routed through it (the order of its
+// slice of the binary tree), each symbol reduced to a 3-bit SLOT = its next three path bits (a leaf reached earlier
+// pads with zeros).  128-byte line = 4 sections of 32 bytes; section s = [count[2s] | count[2s+1] << 32, plane 0,
+// plane 1, plane 2] for positions 64s .. 64s+63 of the line's 256: count[t] = occurrences of slot t in the node's
+// sequence before the line (32 bits: the layout is built for sequences below 2^32), plane k = bit k of the slots.
+// One fetch answers "how many of the first i symbols of u continue along slot t" = the offset inside the node three
+// levels down; the answers are those of the binary cascade, level for level.
+struct FSec
+{
+    uint64_t h, p0, p1, p2;
+};
+constexpr unsigned kFusedLog = 8; // 256 positions per line
+constexpr unsigned kFusedWords = 16;
+
+template <bool NT>
+__device__ __forceinline__ FSec load_fsec(const uint64_t * fl, uint64_t L, int s)
+{
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    const v2u64 * ptr = reinterpret_cast<const v2u64 *>(fl + L * kFusedWords) + 2 * s;
+    v2u64 a, b;
+    if (NT)
+    {
+        a = __builtin_nontemporal_load(ptr);
+        b = __builtin_nontemporal_load(ptr + 1);
+    }
+    else
+    {
+        a = ptr[0];
+        b = ptr[1];
+    }
+    FSec x;
+    x.h = a.x;
+    x.p0 = a.y;
+    x.p1 = b.x;
+    x.p2 = b.y;
+    return x;
+}
+
+// this lane's share of "slot t among the first `off` positions of the line, plus the line's count for t"
+__device__ __forceinline__ unsigned fsec_count(const FSec & x, int s, unsigned off, unsigned t)
+{
+    const uint64_t m = ((t & 1) ? x.p0 : ~x.p0) & ((t & 2) ? x.p1 : ~x.p1) & ((t & 4) ? x.p2 : ~x.p2);
+    const int tt = (int)off - 64 * s;
+    const unsigned cnt = tt <= 0 ? 0u : (tt >= 64 ? popc64(m) : popc64(m << (64 - tt)));
+    const unsigned hdr = (s == (int)(t >> 1)) ? (unsigned)(x.h >> (32 * (t & 1))) : 0u;
+    return cnt + hdr;
+}
+
+// the slot stored at position `off` of the line (all four lanes get it)
+__device__ __forceinline__ unsigned quad_fsec_slot(const FSec & x, int s, unsigned off)
+{
+    unsigned t = 0;
+    if ((int)(off >> 6) == s)
+    {
+        const unsigned b = off & 63;
+        t = (unsigned)((x.p0 >> b) & 1) | ((unsigned)((x.p1 >> b) & 1) << 1) | ((unsigned)((x.p2 >> b) & 1) << 2);
+    }
+    return quad_sum(t);
+}
+
+// follow the k low bits of slot t down the binary node table
+__device__ __forceinline__ unsigned wt_descend(const WtTables * T, unsigned v, unsigned t, unsigned k)
+{
+    for (unsigned j = 0; j < k; ++j, t >>= 1)
+        v = T->child[v][t & 1];
+    return v;
+}
+
+// one fused step of two rank cascades for the same symbol: node v (depth 0, 3, ...), `left` path bits remaining in p
+template <bool NT>
+__device__ __forceinline__ void quad_wt8_rank2_step(const WtView & wt, const WtTables * T, int s, unsigned & v,
+                                                    uint64_t & p, unsigned & left, uint64_t & a, uint64_t & b)
+{
+    const unsigned k = left < 3 ? left : 3;
+    const unsigned t = (unsigned)p & ((1u << k) - 1u);
+    const uint64_t base = T->fline[v];
+    const uint64_t La = base + (a >> kFusedLog), Lb = base + (b >> kFusedLog);
+    FSec xb = load_fsec<NT>(wt.f_lines, Lb, s);
+    FSec xa = xb;
+    if (La != Lb) // quad-uniform
+        xa = load_fsec<NT>(wt.f_lines, La, s);
+    a = quad_sum(fsec_count(xa, s, (unsigned)a & 255u, t));
+    b = quad_sum(fsec_count(xb, s, (unsigned)b & 255u, t));
+    v = wt_descend(T, v, t, k);
+    p >>= k;
+    left -= k;
+}
+
+// wt_pc::rank(i, c) on the fused layout
+template <bool NT>
+__device__ __forceinline__ uint64_t quad_wt8_rank(const WtView & wt, const WtTables * T, int s, uint64_t i, unsigned c)
+{
+    if (T->c_to_leaf[c] == kWtUndef)
+        return 0;
+    if (wt.sigma == 1)
+        return i;
+    uint64_t p = T->path[c];
+    unsigned left = (unsigned)(p >> 56);
+    uint64_t res = i;
+    unsigned v = 0;
+    while (left && res)
+    {
+        const unsigned k = left < 3 ? left : 3;
+        const unsigned t = (unsigned)p & ((1u << k) - 1u);
+        FSec x = load_fsec<NT>(wt.f_lines, T->fline[v] + (res >> kFusedLog), s);
+        res = quad_sum(fsec_count(x, s, (unsigned)res & 255u, t));
+        v = wt_descend(T, v, t, k);
+        p >>= k;
+        left -= k;
+    }
+    return res;
+}
+
+// both cascades of one LF step (backward_search)
 template <bool NT>
 __device__ __forceinline__ void quad_wt_rank2(const WtView & wt, const WtTables * T, int s, unsigned c, uint64_t & a,
                                               uint64_t & b)
@@ -117,10 +236,27 @@ __device__ __forceinline__ void quad_wt_rank2(const WtView & wt, const WtTables 
     uint64_t p = T->path[c];
     unsigned len = (unsigned)(p >> 56);
     unsigned v = 0;
-    for (unsigned l = 0; l < len && b; ++l, p >>= 1) // a <= b always; b == 0 ends both chains
-        quad_wt_rank2_level<NT>(wt, T, s, v, (unsigned)(p & 1), a, b);
+    if (wt.f_lines)
+        while (len && b)
+            quad_wt8_rank2_step<NT>(wt, T, s, v, p, len, a, b);
+    else
+        for (unsigned l = 0; l < len && b; ++l, p >>= 1) // a <= b always; b == 0 ends both chains
+            quad_wt_rank2_level<NT>(wt, T, s, v, (unsigned)(p & 1), a, b);
     if (b == 0)
         a = 0;
+}
+
+// one fused step of wt_pc::inverse_select from node v (depth 0, 3, ...) at offset i: up to three levels
+template <bool NT>
+__device__ __forceinline__ void quad_wt8_invsel_step(const WtView & wt, const WtTables * T, int s, unsigned & v,
+                                                     uint64_t & i)
+{
+    FSec x = load_fsec<NT>(wt.f_lines, T->fline[v] + (i >> kFusedLog), s);
+    const unsigned off = (unsigned)i & 255u;
+    unsigned t = quad_fsec_slot(x, s, off);
+    i = quad_sum(fsec_count(x, s, off, t));
+    for (unsigned j = 0; j < 3 && T->child[v][0] != kWtUndef; ++j, t >>= 1)
+        v = T->child[v][t & 1];
 }
 
 // one level of wt_pc::inverse_select from inner node v at offset i of its slice: the bit at the position and the
@@ -152,8 +288,12 @@ __device__ __forceinline__ uint64_t quad_wt_inverse_select(const WtView & wt, co
                                                            unsigned & c_out)
 {
     unsigned v = 0;
-    while (T->child[v][0] != kWtUndef)
-        quad_wt_invsel_level<NT>(wt, T, s, v, i);
+    if (wt.f_lines)
+        while (T->child[v][0] != kWtUndef)
+            quad_wt8_invsel_step<NT>(wt, T, s, v, i);
+    else
+        while (T->child[v][0] != kWtUndef)
+            quad_wt_invsel_level<NT>(wt, T, s, v, i);
     c_out = (unsigned)T->bv_pos_rank[v];
     return i;
 }

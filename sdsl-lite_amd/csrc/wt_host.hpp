@@ -16,6 +16,7 @@ struct WtHost
     BvHost bv;          // the concatenated WT bit vector as rank lines (+ select directories)
     RrrHost rrr;        // ... or as an rrr_vector<63>
     DevBuf d_tables;    // WtTables image in HBM
+    DevBuf d_fused;     // the fused (8-ary) layout used by the rank-type traversals (wt_device.hpp), optional
     WtTables tables;    // host copy (code lengths, alphabet queries)
     uint64_t occ[256];  // occurrences of every byte (== wt.rank(size(), c))
     WtView view() const
@@ -28,11 +29,12 @@ struct WtHost
         v.size = size;
         v.sigma = sigma;
         v.n_nodes = n_nodes;
+        v.f_lines = d_fused.as<uint64_t>();
         return v;
     }
     size_t device_bytes() const
     {
-        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes;
+        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes;
     }
 };
 
@@ -46,6 +48,9 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
 // its own rank/select supports (zero bytes)
 sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, int layout, int device);
 uint64_t wt_bv_bits(const WtHost & wt);
+// Derives the fused layout from the finished binary tree (plain backend, fewer than 2^32 symbols; SDSL_HIP_WT_FUSED=0
+// in the environment turns it off).  A no-op otherwise.
+sdsl_hip_status wt_build_fused(WtHost & wt);
 
 // kernels over the rrr backend (wt_rrr.hip)
 sdsl_hip_status wt_rrr_launch_rank(const WtHost & wt, const uint64_t * d_i, const uint8_t * d_c, uint64_t n,
