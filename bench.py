@@ -32,6 +32,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy achieves
+FUSED_NOTE = ("roofline_frac prices the query as SURVEY.md 8(d) does (80 bytes per tree level, the reference's algorithm); the "
+              "kernel walks the fused layout (one 128-byte line per three levels), so the figure can exceed 1; line_fetch_frac "
+              "prices the lines the fused walk addresses (an upper bound on its HBM traffic: small nodes stay in cache and "
+              "the k-mer table skips the first characters of a pattern)")
 ALG_BYTES = {"rank": 96, "select": 112, "rrr": 144}  # SURVEY.md §8(d), bytes per query
 
 
@@ -407,8 +411,13 @@ def main():
             if "wt" in extras:
                 _, ms = time_steps(lambda: wt.rank(gi, gc, out2), max(2, a.steps // 2), 1, barrier)
                 alg = 17 + 80 * hbar
+                steps = float(((lens[gc.long()] + 2) // 3).double().mean())  # fused layout: three levels per line
                 ex["wt_huff_rank"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2,
-                                      "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                      "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "algorithmic_bytes_per_query": alg,
+                                      "fused_steps_per_query": steps,
+                                      "line_fetch_frac": (17 + 128 * steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "note": FUSED_NOTE}
                 if ocsa is not None:
                     owt = ocsa.wt()
                     cb = cpu_time(lambda i, c: owt.rank(np.ascontiguousarray(i).view(np.uint64), c), [gi, gc], out2,
@@ -422,9 +431,13 @@ def main():
                 _, ms = time_steps(lambda: csa.count(pats, m, out2), max(2, a.steps // 2), 1, barrier)
                 sum_l = float(lens[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
                 alg = 28 + 160 * sum_l
+                sum_steps = float(((lens[pats.view(-1, m)[:, :m - 1].long()] + 2) // 3).double().sum(dim=1).mean())
                 assert bool((out2 >= 1).all()), "every pattern was cut from the text"
                 ex["fm_count"] = {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "patterns": nq2, "m": m,
-                                  "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                  "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_pattern": alg,
+                                  "line_fetch_frac": (28 + 256 * sum_steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "jump_depth": csa.jump_depth(), "note": FUSED_NOTE}
                 if ocsa is not None:
                     cb = cpu_time(lambda p: ocsa.count_batch(p.reshape(-1), m), [pats.view(-1, m)], out2, a.cpu_seconds,
                                   1e6, "20-byte patterns, count(csa_wt<wt_huff<>>)")

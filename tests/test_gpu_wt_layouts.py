@@ -1,0 +1,96 @@
+"""GPU: the plain wavelet tree keeps two layouts in HBM — SDSL's binary levels (select, export) and the fused 8-ary
+layout (three levels per fetch: rank, backward search, inverse_select, LF walks).  SDSL_HIP_WT_FUSED=0 at creation time
+leaves the fused layout out, so every traversal takes the binary path; both must give the oracle's answers on the
+same inputs, for trees whose depth is not a multiple of three, with leaves at depth 1 and 2, and for every shape."""
+import numpy as np
+import pytest
+
+import golden_data as gd
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+TEXTS = {
+    "two_symbols": b"ab" * 300 + b"a" * 77,                                   # depth 1
+    "dna": bytes(np.random.default_rng(1).choice(list(b"ACGT"), 5000)),       # depth 2-3 with the sentinel
+    "skewed": b"a" * 4000 + b"b" * 500 + b"c" * 60 + b"d" * 7 + b"e",         # a chain: leaves at depth 1, 2, 3, 4
+    "bytes256": bytes(np.random.default_rng(2).integers(1, 256, 30000, dtype=np.uint8)),  # depth 8-9
+    "zipf": bytes((np.random.default_rng(3).zipf(1.3, 40000) % 200 + 1).astype(np.uint8)),  # deep Huffman tree
+    "faust": None,
+}
+
+
+def _text(name):
+    return gd.text("faust.txt") if name == "faust" else TEXTS[name]
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("name", list(TEXTS))
+def test_wavelet_tree_queries_on_both_layouts(gpu, monkeypatch, name, fused):
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED", fused)
+    text = _text(name)
+    wt = gpu.wt_huff(text=text)
+    o = ol.OWt(text)
+    n = len(text)
+    rng = np.random.default_rng(7)
+    arr = np.frombuffer(text, dtype=np.uint8)
+    i = np.concatenate([rng.integers(0, n + 1, 4000), [0, 1, n - 1, n, 255, 256, 257, 511, 512]]).astype(np.uint64)
+    i = np.minimum(i, np.uint64(n))
+    c = np.concatenate([arr[rng.integers(0, n, 4000)], rng.integers(0, 256, 9).astype(np.uint8)])
+    assert np.array_equal(wt.rank(i, c), o.rank(i, c))
+    j = np.concatenate([rng.integers(0, n, 3000), [0, n - 1, min(255, n - 1), min(256, n - 1)]]).astype(np.uint64)
+    r, ch = wt.inverse_select(j)
+    orr, och = o.inverse_select(j)
+    assert np.array_equal(r, orr) and np.array_equal(ch, och)
+    assert np.array_equal(wt.access(j), arr[j.astype(np.int64)])
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("kw", [{}, {"balanced": True}, {"hutu": True}])
+def test_fm_index_queries_on_both_layouts(gpu, monkeypatch, kw, fused):
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED", fused)
+    text = gd.text("faust.txt")
+    csa = gpu.csa_wt(text=text, **kw)
+    o = ol.OCsa(text)
+    arr = np.frombuffer(text, dtype=np.uint8)
+    rng = np.random.default_rng(9)
+    for m in (1, 2, 3, 7, 20):
+        st = rng.integers(0, len(text) - m, 1500)
+        pats = np.concatenate([arr[s:s + m] for s in st] + [rng.integers(1, 256, m * 20).astype(np.uint8)])
+        assert np.array_equal(csa.count(pats, m), o.count_batch(pats, m)), m
+    idx = rng.integers(0, csa.size(), 3000).astype(np.uint64)
+    assert np.array_equal(csa.lf(idx), o.lf(idx)) and np.array_equal(csa.psi(idx), o.psi(idx))
+    csa.drop_sa()
+    assert np.array_equal(csa.sa(idx), o.sa(idx)) and np.array_equal(csa.isa(idx), o.isa(idx))
+    off, t = csa.extract(np.array([0, 1000, 200000], dtype=np.uint64), np.array([99, 1900, 200300], dtype=np.uint64))
+    assert t.tobytes() == text[0:100] + text[1000:1901] + text[200000:200301]
+    pats = np.frombuffer(b"und", dtype=np.uint8)
+    off, pos = csa.locate(pats, 3)
+    assert np.array_equal(pos, o.locate(b"und"))
+
+
+def test_the_knob_decides_what_is_resident(gpu, monkeypatch):
+    text = gd.text("faust.txt")
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED", "0")
+    plain = gpu.wt_huff(text=text).device_bytes()
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED", "1")
+    both = gpu.wt_huff(text=text).device_bytes()
+    monkeypatch.delenv("SDSL_HIP_WT_FUSED")
+    default = gpu.wt_huff(text=text).device_bytes()
+    assert both > plain and default == both
+    # the compressed flavour has no fused layout
+    with_knob = gpu.wt_huff(text=text, rrr=True).device_bytes()
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED", "0")
+    assert gpu.wt_huff(text=text, rrr=True).device_bytes() == with_knob
+
+
+def test_loaded_streams_get_the_fused_layout_too(gpu):
+    blob = gd.sdsl_file("example01.txt.wt_huff_v5_mcl.sdsl")
+    text = gd.text("example01.txt")
+    wt = gpu.wt_huff(sdsl_bytes=blob, select_is_mcl=True)
+    assert wt.device_bytes() == gpu.wt_huff(text=text).device_bytes()
+    o = ol.OWt(text)
+    rng = np.random.default_rng(4)
+    i = rng.integers(0, len(text) + 1, 5000).astype(np.uint64)
+    c = np.frombuffer(text, dtype=np.uint8)[rng.integers(0, len(text), 5000)]
+    assert np.array_equal(wt.rank(i, c), o.rank(i, c))
