@@ -48,6 +48,9 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
     __shared__ FmTables F;
     fm_stage_tables(&F, ftab);
     wt_stage_tables(&T, wt.tables); // ends with __syncthreads()
+    __shared__ WtFusedTables FT;
+    if (FUSED)
+        wt_stage_fused(&FT, wt);
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
     for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n_pat; base += (uint64_t)gridDim.x * kQPB)
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
                 v = 0;
             }
             if (FUSED) // one iteration = up to three levels (wt_device.hpp: fused layout)
-                quad_wt8_rank2_step<NT>(wt, &T, s, v, p, left, a, b);
+                quad_wt8_rank2_step<NT>(wt, &T, &FT, s, v, p, left, a, b);
             else
             {
                 quad_wt_rank2_level<NT>(wt, &T, s, v, (unsigned)(p & 1), a, b);
@@ -180,9 +183,11 @@ __global__ __launch_bounds__(kBlock) void k_fm_backward_step(WtView wt, const Fm
                                                              uint64_t * __restrict__ out_r)
 {
     __shared__ WtTables T;
+    __shared__ WtFusedTables FT;
     __shared__ FmTables F;
     fm_stage_tables(&F, ftab);
     wt_stage_tables(&T, wt.tables);
+    wt_stage_fused(&FT, wt);
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
     for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_fm_backward_step(WtView wt, const Fm
                 else
                 {
                     uint64_t a = l, b = r + 1;
-                    quad_wt_rank2<NT>(wt, &T, s, c, a, b);
+                    quad_wt_rank2<NT>(wt, &T, &FT, s, c, a, b);
                     lo = cb + a;
                     ro = cb + b - 1;
                 }

@@ -29,17 +29,19 @@ struct LocPlain
     struct Shared
     {
         WtTables T;
+        WtFusedTables FT;
         FmTables F;
     };
     static __device__ __forceinline__ void stage(Shared * S, const WtView & wt, const FmTables * ftab)
     {
         fm_stage_tables(&S->F, ftab);
         wt_stage_tables(&S->T, wt.tables);
+        wt_stage_fused(&S->FT, wt);
     }
     static __device__ __forceinline__ void level(const WtView & wt, const Shared * S, int s, unsigned & v, uint64_t & i)
     {
         if (wt.f_lines) // up to three levels per step
-            quad_wt8_invsel_step<false>(wt, &S->T, s, v, i);
+            quad_wt8_invsel_step<false>(wt, &S->T, &S->FT, s, v, i);
         else
             quad_wt_invsel_level<false>(wt, &S->T, s, v, i);
     }

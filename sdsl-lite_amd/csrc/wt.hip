@@ -630,7 +630,9 @@ __global__ __launch_bounds__(kBlock) void k_wt_rank(WtView wt, const uint64_t * 
                                                     uint64_t n)
 {
     __shared__ WtTables T;
+    __shared__ WtFusedTables FT;
     wt_stage_tables(&T, wt.tables);
+    wt_stage_fused(&FT, wt);
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
     for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void k_wt_rank(WtView wt, const uint64_t * 
         unsigned c = cq[q];
         uint64_t r = SDSL_HIP_NPOS;
         if (i <= wt.size)
-            r = wt.f_lines ? quad_wt8_rank<NT>(wt, &T, s, i, c) : quad_wt_rank<NT>(wt, &T, s, i, c);
+            r = wt.f_lines ? quad_wt8_rank<NT>(wt, &T, &FT, s, i, c) : quad_wt_rank<NT>(wt, &T, s, i, c);
         if (s == 0)
             out[q] = r;
     }
@@ -655,7 +657,9 @@ __global__ __launch_bounds__(kBlock) void k_wt_inverse_select(WtView wt, const u
                                                               uint8_t * __restrict__ out_c, uint64_t n)
 {
     __shared__ WtTables T;
+    __shared__ WtFusedTables FT;
     wt_stage_tables(&T, wt.tables);
+    wt_stage_fused(&FT, wt);
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
     for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
@@ -667,7 +671,7 @@ __global__ __launch_bounds__(kBlock) void k_wt_inverse_select(WtView wt, const u
         unsigned c = 0xFF;
         uint64_t r = SDSL_HIP_NPOS;
         if (i < wt.size)
-            r = quad_wt_inverse_select<NT>(wt, &T, s, i, c);
+            r = quad_wt_inverse_select<NT>(wt, &T, &FT, s, i, c);
         if (s == 0)
         {
             out_c[q] = (uint8_t)c;
@@ -827,6 +831,9 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         !wt.d_tables.p)
         return SDSL_HIP_OK;
     WtTables & T = wt.tables;
+    std::vector<WtFusedTables> ft_store(1);
+    WtFusedTables & FT = ft_store[0];
+    memset(&FT, 0, sizeof FT);
     const uint32_t N = wt.n_nodes;
     // breadth-first order, depths and subtree sizes
     std::vector<uint32_t> order, depth(N, 0);
@@ -864,10 +871,9 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
     std::vector<uint32_t> roots;
     for (uint32_t v : order)
     {
-        T.fline[v] = 0;
         if (T.child[v][0] == kWtUndef || depth[v] % 3 != 0)
             continue;
-        T.fline[v] = (uint32_t)total;
+        FT.fline[v] = (uint32_t)total;
         total += (size[v] >> kFusedLog) + 1;
         roots.push_back(v);
     }
@@ -890,14 +896,15 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
     for (uint32_t v : roots)
     {
         const uint64_t lines_v = (size[v] >> kFusedLog) + 1;
-        uint64_t * at = fl + (uint64_t)T.fline[v] * kFusedWords;
+        uint64_t * at = fl + (uint64_t)FT.fline[v] * kFusedWords;
         if (size[v])
             hipLaunchKernelGGL(k_wt8_planes, dim3(grid_for((size[v] + 63) >> 6, 4, 256u * 8u)), dim3(256), 0, 0, view, v,
                                size[v], at);
         hipLaunchKernelGGL(k_wt8_counts, dim3(grid_for(lines_v * 8, 256, 1u << 20)), dim3(256), 0, 0, view, v, lines_v, at);
     }
     SH_HIP(hipGetLastError());
-    SH_HIP(hipMemcpyAsync(wt.d_tables.p, &wt.tables, sizeof(WtTables), hipMemcpyHostToDevice, 0));
+    SH_TRY(wt.d_ftables.alloc(sizeof(WtFusedTables)));
+    SH_HIP(hipMemcpy(wt.d_ftables.p, &FT, sizeof(WtFusedTables), hipMemcpyHostToDevice));
     SH_HIP(hipStreamSynchronize(0));
     if (trace)
     {

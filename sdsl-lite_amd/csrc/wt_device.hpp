@@ -23,7 +23,11 @@ struct WtTables // global-memory image, identical layout in LDS
     uint16_t child[kWtMaxNodes][2];
     uint16_t parent[kWtMaxNodes];
     uint16_t c_to_leaf[256];
-    uint32_t fline[kWtMaxNodes];       // fused layout (below): first line of the node's sequence (nodes at depth 0, 3, 6, ...)
+};
+
+struct WtFusedTables // node tables of the fused layout (below); staged in LDS by the kernels that walk it
+{
+    uint32_t fline[kWtMaxNodes]; // first line of the node's sequence (nodes at depth 0, 3, 6, ...)
 };
 
 struct WtView
@@ -36,6 +40,7 @@ struct WtView
     uint64_t sigma; // effective alphabet size
     uint32_t n_nodes;
     const uint64_t * f_lines; // fused (8-ary) layout of the same tree, nullptr if not built
+    const WtFusedTables * f_tables;
 };
 
 // cooperative copy of the tables into LDS (all threads of the block)
@@ -46,6 +51,19 @@ __device__ __forceinline__ void wt_stage_tables(WtTables * lds, const WtTables *
     constexpr unsigned n = sizeof(WtTables) / 8;
     for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
         dst[i] = src[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void wt_stage_fused(WtFusedTables * lds, const WtView & wt)
+{
+    if (wt.f_lines) // kernel-uniform
+    {
+        const uint64_t * src = reinterpret_cast<const uint64_t *>(wt.f_tables);
+        uint64_t * dst = reinterpret_cast<uint64_t *>(lds);
+        constexpr unsigned n = sizeof(WtFusedTables) / 8;
+        for (unsigned i = threadIdx.x; i < n; i += blockDim.x)
+            dst[i] = src[i];
+    }
     __syncthreads();
 }
 
@@ -168,37 +186,45 @@ __device__ __forceinline__ unsigned quad_fsec_slot(const FSec & x, int s, unsign
     return quad_sum(t);
 }
 
-// follow the k low bits of slot t down the binary node table
-__device__ __forceinline__ unsigned wt_descend(const WtTables * T, unsigned v, unsigned t, unsigned k)
+// follow slot t down the binary node table: three levels, or fewer when a leaf comes first (its slot pads with zeros).
+// (A precomputed [node][slot] table would save two LDS reads per step but costs 8 KiB of LDS per workgroup, and the
+// lost occupancy cost more than the reads: 28.9 -> 22.4 G wt.rank/s.)
+__device__ __forceinline__ unsigned wt_descend(const WtTables * T, unsigned v, unsigned t)
 {
-    for (unsigned j = 0; j < k; ++j, t >>= 1)
-        v = T->child[v][t & 1];
+#pragma unroll
+    for (unsigned j = 0; j < 3; ++j, t >>= 1)
+    {
+        const unsigned nv = T->child[v][t & 1];
+        v = nv == kWtUndef ? v : nv;
+    }
     return v;
 }
 
 // one fused step of two rank cascades for the same symbol: node v (depth 0, 3, ...), `left` path bits remaining in p
 template <bool NT>
-__device__ __forceinline__ void quad_wt8_rank2_step(const WtView & wt, const WtTables * T, int s, unsigned & v,
-                                                    uint64_t & p, unsigned & left, uint64_t & a, uint64_t & b)
+__device__ __forceinline__ void quad_wt8_rank2_step(const WtView & wt, const WtTables * T, const WtFusedTables * FT, int s,
+                                                    unsigned & v, uint64_t & p, unsigned & left, uint64_t & a,
+                                                    uint64_t & b)
 {
     const unsigned k = left < 3 ? left : 3;
     const unsigned t = (unsigned)p & ((1u << k) - 1u);
-    const uint64_t base = T->fline[v];
+    const uint64_t base = FT->fline[v];
     const uint64_t La = base + (a >> kFusedLog), Lb = base + (b >> kFusedLog);
     FSec xb = load_fsec<NT>(wt.f_lines, Lb, s);
     FSec xa = xb;
     if (La != Lb) // quad-uniform
         xa = load_fsec<NT>(wt.f_lines, La, s);
+    v = wt_descend(T, v, t); // LDS lookups overlap the line fetches
     a = quad_sum(fsec_count(xa, s, (unsigned)a & 255u, t));
     b = quad_sum(fsec_count(xb, s, (unsigned)b & 255u, t));
-    v = wt_descend(T, v, t, k);
     p >>= k;
     left -= k;
 }
 
 // wt_pc::rank(i, c) on the fused layout
 template <bool NT>
-__device__ __forceinline__ uint64_t quad_wt8_rank(const WtView & wt, const WtTables * T, int s, uint64_t i, unsigned c)
+__device__ __forceinline__ uint64_t quad_wt8_rank(const WtView & wt, const WtTables * T, const WtFusedTables * FT, int s,
+                                                  uint64_t i, unsigned c)
 {
     if (T->c_to_leaf[c] == kWtUndef)
         return 0;
@@ -212,9 +238,9 @@ __device__ __forceinline__ uint64_t quad_wt8_rank(const WtView & wt, const WtTab
     {
         const unsigned k = left < 3 ? left : 3;
         const unsigned t = (unsigned)p & ((1u << k) - 1u);
-        FSec x = load_fsec<NT>(wt.f_lines, T->fline[v] + (res >> kFusedLog), s);
+        FSec x = load_fsec<NT>(wt.f_lines, FT->fline[v] + (res >> kFusedLog), s);
+        v = wt_descend(T, v, t); // LDS lookups overlap the line fetch
         res = quad_sum(fsec_count(x, s, (unsigned)res & 255u, t));
-        v = wt_descend(T, v, t, k);
         p >>= k;
         left -= k;
     }
@@ -223,8 +249,8 @@ __device__ __forceinline__ uint64_t quad_wt8_rank(const WtView & wt, const WtTab
 
 // both cascades of one LF step (backward_search)
 template <bool NT>
-__device__ __forceinline__ void quad_wt_rank2(const WtView & wt, const WtTables * T, int s, unsigned c, uint64_t & a,
-                                              uint64_t & b)
+__device__ __forceinline__ void quad_wt_rank2(const WtView & wt, const WtTables * T, const WtFusedTables * FT, int s,
+                                              unsigned c, uint64_t & a, uint64_t & b)
 {
     if (T->c_to_leaf[c] == kWtUndef)
     {
@@ -238,7 +264,7 @@ __device__ __forceinline__ void quad_wt_rank2(const WtView & wt, const WtTables 
     unsigned v = 0;
     if (wt.f_lines)
         while (len && b)
-            quad_wt8_rank2_step<NT>(wt, T, s, v, p, len, a, b);
+            quad_wt8_rank2_step<NT>(wt, T, FT, s, v, p, len, a, b);
     else
         for (unsigned l = 0; l < len && b; ++l, p >>= 1) // a <= b always; b == 0 ends both chains
             quad_wt_rank2_level<NT>(wt, T, s, v, (unsigned)(p & 1), a, b);
@@ -248,15 +274,14 @@ __device__ __forceinline__ void quad_wt_rank2(const WtView & wt, const WtTables 
 
 // one fused step of wt_pc::inverse_select from node v (depth 0, 3, ...) at offset i: up to three levels
 template <bool NT>
-__device__ __forceinline__ void quad_wt8_invsel_step(const WtView & wt, const WtTables * T, int s, unsigned & v,
-                                                     uint64_t & i)
+__device__ __forceinline__ void quad_wt8_invsel_step(const WtView & wt, const WtTables * T, const WtFusedTables * FT,
+                                                     int s, unsigned & v, uint64_t & i)
 {
-    FSec x = load_fsec<NT>(wt.f_lines, T->fline[v] + (i >> kFusedLog), s);
+    FSec x = load_fsec<NT>(wt.f_lines, FT->fline[v] + (i >> kFusedLog), s);
     const unsigned off = (unsigned)i & 255u;
-    unsigned t = quad_fsec_slot(x, s, off);
+    const unsigned t = quad_fsec_slot(x, s, off);
     i = quad_sum(fsec_count(x, s, off, t));
-    for (unsigned j = 0; j < 3 && T->child[v][0] != kWtUndef; ++j, t >>= 1)
-        v = T->child[v][t & 1];
+    v = wt_descend(T, v, t);
 }
 
 // one level of wt_pc::inverse_select from inner node v at offset i of its slice: the bit at the position and the
@@ -284,13 +309,13 @@ __device__ __forceinline__ void quad_wt_invsel_level(const WtView & wt, const Wt
 
 // wt_pc::inverse_select(i) (wt_pc.hpp:411-430): returns (rank of wt[i] in [0,i), wt[i]); i < size.
 template <bool NT>
-__device__ __forceinline__ uint64_t quad_wt_inverse_select(const WtView & wt, const WtTables * T, int s, uint64_t i,
-                                                           unsigned & c_out)
+__device__ __forceinline__ uint64_t quad_wt_inverse_select(const WtView & wt, const WtTables * T,
+                                                           const WtFusedTables * FT, int s, uint64_t i, unsigned & c_out)
 {
     unsigned v = 0;
     if (wt.f_lines)
         while (T->child[v][0] != kWtUndef)
-            quad_wt8_invsel_step<NT>(wt, T, s, v, i);
+            quad_wt8_invsel_step<NT>(wt, T, FT, s, v, i);
     else
         while (T->child[v][0] != kWtUndef)
             quad_wt_invsel_level<NT>(wt, T, s, v, i);

@@ -17,6 +17,7 @@ struct WtHost
     RrrHost rrr;        // ... or as an rrr_vector<63>
     DevBuf d_tables;    // WtTables image in HBM
     DevBuf d_fused;     // the fused (8-ary) layout used by the rank-type traversals (wt_device.hpp), optional
+    DevBuf d_ftables;   // its node tables (WtFusedTables)
     WtTables tables;    // host copy (code lengths, alphabet queries)
     uint64_t occ[256];  // occurrences of every byte (== wt.rank(size(), c))
     WtView view() const
@@ -30,11 +31,12 @@ struct WtHost
         v.sigma = sigma;
         v.n_nodes = n_nodes;
         v.f_lines = d_fused.as<uint64_t>();
+        v.f_tables = d_ftables.as<WtFusedTables>();
         return v;
     }
     size_t device_bytes() const
     {
-        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes;
+        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes + d_ftables.bytes;
     }
 };
 

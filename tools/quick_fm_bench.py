@@ -27,3 +27,7 @@ m = 20
 st = torch.randint(0, nt - m, (nq,), device=dev, generator=g)
 pats = text[(st.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()
 run("fm_count", lambda: csa.count(pats, m, out), nq)
+if len(sys.argv) > 4 and sys.argv[4] == "depths":
+    for k in (0, 3, 4, 5, 6):
+        csa.set_jump_depth(k)
+        run(f"fm_count jump depth {k}", lambda: csa.count(pats, m, out), nq)
