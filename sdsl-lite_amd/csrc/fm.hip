@@ -273,6 +273,15 @@ static sdsl_hip_status fm_upload_tables(sdsl_hip_fm_s * f)
     return SDSL_HIP_OK;
 }
 
+// position of the first 0 byte of a device-resident text (the sentinel must be unique, construct.hpp:41)
+__global__ __launch_bounds__(256) void k_first_zero_byte(const uint8_t * __restrict__ text, uint64_t n,
+                                                         unsigned long long * __restrict__ first)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        if (text[i] == 0)
+            atomicMin(first, (unsigned long long)i);
+}
+
 static sdsl_hip_status fm_build_jump(sdsl_hip_fm_s * f);
 static sdsl_hip_status fm_build_jump_k(sdsl_hip_fm_s * f, uint32_t k);
 
@@ -285,8 +294,20 @@ static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_b
     if (!f->wt)
         return SDSL_HIP_ERR_NOMEM;
     WtHost & w = sdsl_hip_wt_host(f->wt);
+    const bool trace = getenv("SDSL_HIP_TRACE_BUILD") != nullptr;
+    auto stamp = [&](const char * what, std::chrono::steady_clock::time_point & t) {
+        if (!trace)
+            return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sdsl_hip] fm build: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    };
+    auto t = std::chrono::steady_clock::now();
     SH_TRY(wt_build_from_device_text(w, d_bwt, n, device, flags)); // csa_wt.hpp:337-343: the WT is built over the BWT
+    stamp("wavelet tree levels", t);
     SH_TRY(sdsl_hip_wt_finish(f->wt));
+    stamp("fused layout + occ", t);
     if (n == 0 || w.occ[0] != 1)
     {
         set_error("the BWT must contain exactly one 0 byte (the sentinel appended by construct.hpp:100-108); found %llu",
@@ -295,7 +316,9 @@ static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_b
     }
     alphabet_from_counts(f, w.occ);
     SH_TRY(fm_upload_tables(f));
-    return fm_build_jump(f);
+    const sdsl_hip_status st = fm_build_jump(f);
+    stamp("k-mer interval table", t);
+    return st;
 }
 
 extern "C" {
@@ -336,23 +359,28 @@ sdsl_hip_status sdsl_hip_fm_create_from_text_ex(const uint8_t * text, uint64_t n
     }
     *out = nullptr;
     SH_TRY(check_device(device));
-    std::vector<uint8_t> tmp;
-    const uint8_t * host = text;
+    uint64_t zero_at = ~UINT64_C(0);
     if (n_text && is_device_ptr(text))
-    {
-        tmp.resize(n_text);
-        SH_HIP(hipMemcpy(tmp.data(), text, n_text, hipMemcpyDeviceToHost));
-        host = tmp.data();
+    { // a text that already lives in HBM is checked and sorted where it is
+        SH_HIP(hipSetDevice(device));
+        DevBuf d_first;
+        SH_TRY(d_first.alloc(8));
+        SH_HIP(hipMemset(d_first.p, 0xFF, 8));
+        hipLaunchKernelGGL(k_first_zero_byte, dim3(grid_for(n_text, 256, 256u * 16u)), dim3(256), 0, 0, text, n_text,
+                           d_first.as<unsigned long long>());
+        SH_HIP(hipGetLastError());
+        SH_HIP(hipMemcpy(&zero_at, d_first.p, 8, hipMemcpyDeviceToHost));
     }
-    for (uint64_t i = 0; i < n_text; ++i)
-        if (host[i] == 0)
-        {
-            set_error("text contains a 0 byte at %llu (SDSL's construct refuses this too, construct.hpp:41)",
-                      (unsigned long long)i);
-            return SDSL_HIP_ERR_INVALID;
-        }
+    else if (const void * z = n_text ? memchr(text, 0, n_text) : nullptr)
+        zero_at = (uint64_t)((const uint8_t *)z - text);
+    if (zero_at != ~UINT64_C(0))
+    {
+        set_error("text contains a 0 byte at %llu (SDSL's construct refuses this too, construct.hpp:41)",
+                  (unsigned long long)zero_at);
+        return SDSL_HIP_ERR_INVALID;
+    }
     DevBuf d_bwt, d_sa;
-    SH_TRY(sa_build_bwt_device(host, n_text, device, d_bwt, d_sa)); // suffix array and BWT never leave the device
+    SH_TRY(sa_build_bwt_device(text, n_text, device, d_bwt, d_sa)); // suffix array and BWT never leave the device
     sdsl_hip_fm_s * f = new (std::nothrow) sdsl_hip_fm_s();
     if (!f)
         return SDSL_HIP_ERR_NOMEM;

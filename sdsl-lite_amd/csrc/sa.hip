@@ -171,7 +171,7 @@ sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t 
 }
 
 // BWT of text+'\\0' left in device memory (d_bwt, n_text+1 bytes); the suffix array (u32 per suffix) is handed over too
-sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa)
+sdsl_hip_status sa_build_bwt_device(const uint8_t * text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa)
 {
     const uint64_t n = n_text + 1;
     if (n >= UINT64_C(0xFFFFFFFE))
@@ -182,7 +182,7 @@ sdsl_hip_status sa_build_bwt_device(const uint8_t * host_text, uint64_t n_text, 
     SH_HIP(hipSetDevice(device));
     DevBuf d_s, d_k0, d_k1, d_i0, d_i1, d_rank, d_flags, d_tmp;
     SH_TRY(d_s.alloc(n));
-    SH_HIP(hipMemcpy(d_s.p, host_text, n_text, hipMemcpyHostToDevice));
+    SH_HIP(hipMemcpy(d_s.p, text, n_text, hipMemcpyDefault)); // host or device text
     SH_HIP(hipMemset((uint8_t *)d_s.p + n_text, 0, 1));
     SH_TRY(d_k0.alloc(n * 8));
     SH_TRY(d_k1.alloc(n * 8));
