@@ -94,3 +94,46 @@ def test_loaded_streams_get_the_fused_layout_too(gpu):
     i = rng.integers(0, len(text) + 1, 5000).astype(np.uint64)
     c = np.frombuffer(text, dtype=np.uint8)[rng.integers(0, len(text), 5000)]
     assert np.array_equal(wt.rank(i, c), o.rank(i, c))
+
+
+def test_both_layouts_agree_at_full_size(gpu, monkeypatch):
+    """BASELINE.json's index size (1 GiB text): 10^7 random rank / count / LF queries answered on the fused layout and on
+    the binary levels must be identical, and obey what the domain guarantees at any size."""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dev = torch.device("cuda", 0)
+    nt = 1 << 30
+    text = bench.synthetic_text(nt, 1234, dev)
+    g = torch.Generator(device=dev).manual_seed(77)
+    nq = 10_000_000
+    i = torch.randint(0, nt + 2, (nq,), device=dev, dtype=torch.int64, generator=g)
+    c = text[torch.randint(0, nt, (nq,), device=dev, generator=g)]
+    m = 20
+    st = torch.randint(0, nt - m, (2_000_000,), device=dev, generator=g)
+    pats = text[(st.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()
+    idx = torch.randint(0, nt + 1, (2_000_000,), device=dev, dtype=torch.int64, generator=g)
+    got = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SDSL_HIP_WT_FUSED", fused)
+        csa = gpu.csa_wt(text=text)
+        wt = csa.wavelet_tree
+        r = wt.rank(i, c)
+        cnt = csa.count(pats, m)
+        lf = csa.lf(idx)
+        ir, ic = wt.inverse_select(idx)
+        got[fused] = (r, cnt, lf, ir, ic)
+        if fused == "1":
+            # domain properties: every pattern was cut from the text; LF is a permutation step consistent with
+            # inverse_select + C; rank(n + 1, c) over all symbols sums to n + 1
+            assert bool((cnt >= 1).all())
+            tot = wt.rank(torch.full((256,), nt + 1, device=dev, dtype=torch.int64),
+                          torch.arange(256, device=dev, dtype=torch.uint8))
+            assert int(tot.sum()) == nt + 1
+            assert torch.equal(csa.psi(lf[:200_000]), idx[:200_000])
+        csa.close()
+        del csa, wt
+        torch.cuda.empty_cache()
+    for a, b in zip(got["1"], got["0"]):
+        assert torch.equal(a, b)
