@@ -318,6 +318,49 @@ __device__ __forceinline__ bool sel_eval(const BvView & bv, int s, uint64_t k, u
     return true;
 }
 
+// sel_eval with the bit value chosen at run time (quad-uniform): the wavelet-tree select alternates between ones and
+// zeros from level to level, and a wave whose quads disagree would otherwise execute both instantiations
+__device__ __forceinline__ bool sel_eval_rt(const BvView & bv, int s, bool one, uint64_t k, uint64_t W, Pair wa, Pair wb,
+                                            SelBracket & b, bool & mine, uint64_t & pos)
+{
+    const uint64_t LA = 2 * W, LB = LA + 1;
+    const uint64_t h1a = quad_bcast0_u64(wa.a), h1b = quad_bcast0_u64(wb.a);
+    const uint64_t ha = one ? h1a : LA * kDB - h1a;
+    const uint64_t hb = one ? h1b : LB * kDB - h1b;
+    Pair awa, awb;
+    if (one || (LB + 1) * kDB <= bv.n_bits)
+    { // all positions of both lines exist (or ones are wanted: padding bits are zero): complement by mask
+        const uint64_t cm = one ? UINT64_C(0) : ~UINT64_C(0);
+        awa.a = s == 0 ? 0 : wa.a ^ cm;
+        awa.b = wa.b ^ cm;
+        awb.a = s == 0 ? 0 : wb.a ^ cm;
+        awb.b = wb.b ^ cm;
+    }
+    else
+    {
+        awa = arg_words<0>(wa, s, bv.n_bits, LA);
+        awb = arg_words<0>(wb, s, bv.n_bits, LB);
+    }
+    const unsigned cb = quad_sum(popc64(awb.a) + popc64(awb.b));
+    mine = false;
+    if (k < ha)
+    {
+        b.hi_pos = LA * kDB;
+        b.hi_cnt = ha;
+        return false;
+    }
+    if (k >= hb + cb)
+    {
+        b.lo_pos = (LB + 1) * kDB;
+        b.lo_cnt = hb + cb;
+        return false;
+    }
+    const bool inB = k >= hb; // quad-uniform
+    const Pair aw = inB ? awb : awa;
+    pos = quad_select_in_line(aw, s, inB ? LB : LA, (unsigned)(k - (inB ? hb : ha)), mine);
+    return true;
+}
+
 // exactly one lane of the quad has mine == true: give its value to all four
 __device__ __forceinline__ uint64_t quad_gather_u64(uint64_t v, bool mine)
 {

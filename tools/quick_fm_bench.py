@@ -31,3 +31,11 @@ if len(sys.argv) > 4 and sys.argv[4] == "depths":
     for k in (0, 3, 4, 5, 6):
         csa.set_jump_depth(k)
         run(f"fm_count jump depth {k}", lambda: csa.count(pats, m, out), nq)
+if len(sys.argv) > 4 and sys.argv[4] == "select":
+    occ = torch.bincount(text.long(), minlength=256)
+    cs = text[torch.randint(0, nt, (nq,), device=dev, generator=g)]
+    ks = (torch.rand(nq, device=dev, generator=g, dtype=torch.float64) * occ[cs.long()].double()).long().clamp_(min=0) + 1
+    ks = torch.minimum(ks, occ[cs.long()])
+    run("wt_select", lambda: wt.select(ks, cs, out), nq)
+    run("wt_inverse_select", lambda: wt.inverse_select(gi.clamp(max=nt)), nq)
+    run("wt_access", lambda: wt.access(gi.clamp(max=nt)), nq)
