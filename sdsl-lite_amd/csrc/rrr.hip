@@ -162,6 +162,69 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, cons
 }
 
 // select, one query per lane
+// Flat variant: every wave owns a contiguous range of the batch; a lane that needs a query takes the next unassigned
+// index of the range (rank among the needing lanes, from a ballot), so the queries in flight in a wave stay within a
+// short window of the arrays (argument loads coalesce, result stores merge in L2).  One iteration = one probe.
+template <int BIT, unsigned DECODE_AT>
+__global__ __launch_bounds__(kRrrBlock) void k_rrr_select_flat(RrrView v, const uint64_t * __restrict__ iq,
+                                                               uint64_t * __restrict__ out, uint64_t n)
+{
+    __shared__ RrrTables T;
+    rrr_stage_tables(&T, v.tables);
+    const uint64_t total = BIT ? v.ones : v.n_bits - v.ones;
+    const uint32_t * __restrict__ smp = v.sel[BIT];
+    const uint64_t n_waves = (uint64_t)gridDim.x * (kRrrBlock / 64);
+    const uint64_t wave = (uint64_t)blockIdx.x * (kRrrBlock / 64) + threadIdx.x / 64;
+    const uint64_t per = ((n + n_waves - 1) / n_waves + 63) / 64 * 64;
+    uint64_t base = wave * per; // wave-uniform: next unassigned query
+    const uint64_t end = base + per < n ? base + per : n;
+    const uint64_t below = (UINT64_C(1) << (threadIdx.x & 63)) - 1;
+    bool have = false, ready = false;
+    uint64_t q = 0;
+    RrrSelState st{};
+    RrrSelHit h{};
+    for (;;)
+    {
+        const uint64_t m_need = __ballot(!have);
+        if (!have)
+        {
+            const uint64_t my = base + (uint64_t)__popcll(m_need & below);
+            if (my < end)
+            {
+                q = my;
+                const uint64_t i = iq[q];
+                if (i >= 1 && i <= total)
+                {
+                    const uint64_t j = (i - 1) >> v.sel_shift[BIT];
+                    rrr_sel_init<BIT>(v, st, i - 1, smp[j], smp[j + 1]);
+                    have = true;
+                }
+                else // i > #args: SDSL returns size() (rrr_vector.hpp:641-642, 686-689); i == 0 is outside its domain
+                    out[q] = i == 0 ? SDSL_HIP_NPOS : v.n_bits;
+            }
+        }
+        base += (uint64_t)__popcll(m_need);
+        if (base > end)
+            base = end;
+        if (__ballot(have) == 0 && base >= end)
+            break;
+        if (have && !ready)
+            ready = rrr_sel_probe<BIT>(v, st, h);
+        // the decode is the expensive half in instructions: run it when most of the wave can take part, or when
+        // nobody is left probing
+        const unsigned n_ready = (unsigned)__popcll(__ballot(ready));
+        const bool probing = __ballot(have && !ready) != 0;
+        if (n_ready >= DECODE_AT || !probing)
+        {
+            if (ready)
+            {
+                out[q] = rrr_sel_finish<BIT>(v, &T, st.k0, h);
+                have = ready = false;
+            }
+        }
+    }
+}
+
 template <int BIT>
 __global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint64_t * __restrict__ iq,
                                                           uint64_t * __restrict__ out, uint64_t n)
@@ -197,6 +260,15 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint6
         s0_cur = s0_nxt;
         s1_cur = s1_nxt;
     }
+}
+
+template <int BIT>
+static auto rrr_select_kernel() -> void (*)(RrrView, const uint64_t *, uint64_t *, uint64_t)
+{
+    const char * e = getenv("SDSL_HIP_RRR_SEL_FLAT"); // experiment knob: 0 = the nested loop (profiles/rrr_select_flat_r01.txt)
+    if (e && atoi(e) == 0)
+        return k_rrr_select<BIT>;
+    return k_rrr_select_flat<BIT, 40>; // the threshold hardly matters: 24 .. 56 measured within 2 %
 }
 
 // ---- device-side encoder (rrr_vector(bit_vector const&), rrr_vector.hpp:158-270) -------------------------------
@@ -864,10 +936,10 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
                                  [rv, bit](const uint64_t * d_in, uint64_t * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
                                  {
                                      if (bit)
-                                         hipLaunchKernelGGL((k_rrr_select<1>), dim3(rrr_grid(cnt)), dim3(kRrrBlock), 0, st, rv,
+                                         hipLaunchKernelGGL(rrr_select_kernel<1>(), dim3(rrr_grid(cnt)), dim3(kRrrBlock), 0, st, rv,
                                                             d_in, d_out, cnt);
                                      else
-                                         hipLaunchKernelGGL((k_rrr_select<0>), dim3(rrr_grid(cnt)), dim3(kRrrBlock), 0, st, rv,
+                                         hipLaunchKernelGGL(rrr_select_kernel<0>(), dim3(rrr_grid(cnt)), dim3(kRrrBlock), 0, st, rv,
                                                             d_in, d_out, cnt);
                                      SH_HIP(hipGetLastError());
                                      return SDSL_HIP_OK;
@@ -879,10 +951,10 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
     {
         KernelTimer t(s);
         if (bit)
-            hipLaunchKernelGGL((k_rrr_select<1>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view,
+            hipLaunchKernelGGL(rrr_select_kernel<1>(), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view,
                                (const uint64_t *)in.dev, (uint64_t *)o.dev, n);
         else
-            hipLaunchKernelGGL((k_rrr_select<0>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view,
+            hipLaunchKernelGGL(rrr_select_kernel<0>(), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view,
                                (const uint64_t *)in.dev, (uint64_t *)o.dev, n);
     }
     SH_HIP(hipGetLastError());

@@ -244,56 +244,85 @@ __device__ __forceinline__ void rrr_rank2(const RrrView & v, const RrrTables * T
 // late probe — the scheme of bv_device.hpp), then the prefix word picks the group of 8 blocks, byte arithmetic on
 // ONE class word the block, and the decoded block the bit.
 // smp0 / smp1: the directory samples sel[BIT][k0 >> sel_shift] and the next one (callers may load them ahead of time)
+// The search is split in two so that a kernel can keep every lane busy: rrr_sel_probe does ONE probe of the
+// superblock search, rrr_sel_finish everything after the hit.
+struct RrrSelState
+{ // invariant: lo_pos <= position(k0) < hi_pos, lo_cnt <= k0 < hi_cnt
+    uint64_t k0, lo_pos, lo_cnt, hi_pos, hi_cnt;
+    int tries;
+};
+struct RrrSelHit
+{
+    const uint64_t * r; // the record of superblock g
+    uint64_t g, before, r1, P, c0, c1, c2, c3;
+};
+
 template <int BIT>
-__device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTables * T, uint64_t k0, uint32_t smp0,
-                                               uint32_t smp1)
+__device__ __forceinline__ void rrr_sel_init(const RrrView & v, RrrSelState & st, uint64_t k0, uint32_t smp0, uint32_t smp1)
 {
     const uint64_t total = BIT ? v.ones : v.n_bits - v.ones;
     const uint32_t sh = v.sel_shift[BIT], ps = v.sel_pshift;
     const uint64_t js = k0 >> sh;
-    uint64_t lo_pos = (uint64_t)smp0 << ps, lo_cnt = js << sh;
-    uint64_t hi_pos = ((uint64_t)smp1 + 1) << ps, hi_cnt = (js + 1) << sh;
-    if (hi_cnt > total)
-        hi_cnt = total;
-    const uint64_t * r;
-    uint64_t g, before, r1, P, c0, c1, c2, c3;
-    for (int tries = 0;; ++tries)
-    { // invariant: lo_pos <= position(k0) < hi_pos, lo_cnt <= k0 < hi_cnt
-        uint64_t span = hi_pos - lo_pos, p;
-        if (tries >= 3 && (tries & 1))
-            p = lo_pos + (span >> 1);
-        else
-            p = sel_interpolate(lo_pos, span, k0 - lo_cnt, hi_cnt - lo_cnt, sh);
-        g = p / kRrrSB;
-        if (g >= v.n_sb)
-            g = v.n_sb - 1;
-        r = (const uint64_t *)__builtin_assume_aligned(v.rec + g * kRecWords, 128);
-        const uint64_t r0 = r[0];
-        r1 = r[1];
-        // prefix and class words ride along (same line, no extra latency): needed as soon as the probe hits
-        P = r[2];
-        c0 = r[kRecClasses];
-        c1 = r[kRecClasses + 1];
-        c2 = r[kRecClasses + 2];
-        c3 = r[kRecClasses + 3];
-        const uint64_t ones_in = (r1 >> 48) & 0xFFF;
-        const uint64_t start = g * kRrrSB;
-        const uint64_t len_in = v.n_bits - start < kRrrSB ? v.n_bits - start : kRrrSB;
-        before = BIT ? r0 : start - r0;
-        const uint64_t c = BIT ? ones_in : len_in - ones_in;
-        if (k0 < before)
-        {
-            hi_pos = start;
-            hi_cnt = before;
-        }
-        else if (k0 >= before + c)
-        {
-            lo_pos = start + kRrrSB;
-            lo_cnt = before + c;
-        }
-        else
-            break;
+    st.k0 = k0;
+    st.lo_pos = (uint64_t)smp0 << ps;
+    st.lo_cnt = js << sh;
+    st.hi_pos = ((uint64_t)smp1 + 1) << ps;
+    st.hi_cnt = (js + 1) << sh;
+    if (st.hi_cnt > total)
+        st.hi_cnt = total;
+    st.tries = 0;
+}
+
+// one probe; true when superblock h.g holds the argument
+template <int BIT>
+__device__ __forceinline__ bool rrr_sel_probe(const RrrView & v, RrrSelState & st, RrrSelHit & h)
+{
+    const uint64_t span = st.hi_pos - st.lo_pos;
+    uint64_t p;
+    if (st.tries >= 3 && (st.tries & 1))
+        p = st.lo_pos + (span >> 1);
+    else
+        p = sel_interpolate(st.lo_pos, span, st.k0 - st.lo_cnt, st.hi_cnt - st.lo_cnt, v.sel_shift[BIT]);
+    ++st.tries;
+    uint64_t g = p / kRrrSB;
+    if (g >= v.n_sb)
+        g = v.n_sb - 1;
+    const uint64_t * r = (const uint64_t *)__builtin_assume_aligned(v.rec + g * kRecWords, 128);
+    const uint64_t r0 = r[0];
+    h.r = r;
+    h.g = g;
+    h.r1 = r[1];
+    // prefix and class words ride along (same line, no extra latency): needed as soon as the probe hits
+    h.P = r[2];
+    h.c0 = r[kRecClasses];
+    h.c1 = r[kRecClasses + 1];
+    h.c2 = r[kRecClasses + 2];
+    h.c3 = r[kRecClasses + 3];
+    const uint64_t ones_in = (h.r1 >> 48) & 0xFFF;
+    const uint64_t start = g * kRrrSB;
+    const uint64_t len_in = v.n_bits - start < kRrrSB ? v.n_bits - start : kRrrSB;
+    h.before = BIT ? r0 : start - r0;
+    const uint64_t c = BIT ? ones_in : len_in - ones_in;
+    if (st.k0 < h.before)
+    {
+        st.hi_pos = start;
+        st.hi_cnt = h.before;
+        return false;
     }
+    if (st.k0 >= h.before + c)
+    {
+        st.lo_pos = start + kRrrSB;
+        st.lo_cnt = h.before + c;
+        return false;
+    }
+    return true;
+}
+
+template <int BIT>
+__device__ __forceinline__ uint64_t rrr_sel_finish(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
+{
+    const uint64_t * r = h.r;
+    const uint64_t g = h.g, before = h.before, r1 = h.r1, P = h.P, c0 = h.c0, c1 = h.c1, c2 = h.c2, c3 = h.c3;
     // inside superblock g: the group of 8 blocks.  Zeros before block 8q are 504q - ones (every block in front of
     // the one that holds an existing argument is a complete 63-bit block).
     unsigned want = (unsigned)(k0 - before);
@@ -359,6 +388,19 @@ __device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTable
         bits = ~bits & lo_set(blen);
     }
     return bstart + sel64(bits, want + 1);
+}
+
+template <int BIT>
+__device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTables * T, uint64_t k0, uint32_t smp0,
+                                               uint32_t smp1)
+{
+    RrrSelState st;
+    RrrSelHit h;
+    rrr_sel_init<BIT>(v, st, k0, smp0, smp1);
+    while (!rrr_sel_probe<BIT>(v, st, h))
+    {
+    }
+    return rrr_sel_finish<BIT>(v, T, k0, h);
 }
 
 template <int BIT>
