@@ -6,7 +6,8 @@
 //   sd_vector::operator[]                         sd_vector.hpp:328-349
 //   rank_support_sd<b>::rank                      sd_vector.hpp:553-575
 //   select_support_sd<1>::select                  sd_vector.hpp:621-631   low[i-1] + ((high_1_select(i) + 1 - i) << wl)
-//   select_support_sd<0>::select                  sd_vector.hpp:633-664   binary search over select_1
+//   select_support_sd<0>::select                  sd_vector.hpp:633-664   (reference: binary search over select_1;
+//                                                 here: interpolated search over buckets, same positions)
 //
 // Device layout: `high` as rank lines with both select directories (bv_device.hpp), `low` as SDSL's packed words.
 // One query per quad.  rank(x): the bucket of x's high part is delimited by two select_0 on `high` (they land in the
@@ -131,6 +132,66 @@ __device__ __forceinline__ uint64_t quad_sd_select1(const SdView & v, int s, uin
     return sd_low(v, i - 1) + ((hp + 1 - i) << v.wl);
 }
 
+// position of the i-th zero, i in [1, n - m].  The reference bisects over the ones with one select_1 per step
+// (sd_vector.hpp:633-664: ~log2(m) dependent selects).  Here the search runs over BUCKETS (high parts): f(b) = zeros in
+// front of position b << wl = (b << wl) - (entries with high part < b) is monotone and — the zeros being what a sparse
+// vector mostly consists of — nearly linear in b, so an interpolated guess lands within a few buckets and the bracket
+// (exact f at both ends) closes in two or three probes, one select_0 on `high` each; every second late probe bisects.
+// Inside the bucket the t-th one (0-based) sits in front of the wanted zero iff low_t - t <= r, r the zero's rank
+// inside the bucket: monotone in t, found by bisection over the bucket's few entries.  The answer is the same position.
+template <bool NT>
+__device__ __forceinline__ uint64_t quad_sd_select0(const SdView & v, int s, uint64_t i)
+{
+    const uint64_t k = i - 1;
+    uint64_t blo = 0, flo = 0, bhi = (v.n >> v.wl) + 1, fhi = v.n - v.m; // f(blo) <= k < f(bhi)
+    bool mine;
+    for (int tries = 0; bhi - blo > 1; ++tries)
+    {
+        const uint64_t span = bhi - blo;
+        uint64_t b;
+        if (tries >= 3 && (tries & 1))
+            b = blo + (span >> 1);
+        else
+        {
+            const double f = (double)(k - flo) / (double)(fhi - flo);
+            b = blo + (uint64_t)(f * (double)span);
+        }
+        b = b <= blo ? blo + 1 : (b >= bhi ? bhi - 1 : b);
+        const uint64_t p = quad_select<0, NT>(v.high, s, b - 1, mine); // the zero that closes bucket b - 1
+        const uint64_t before = quad_gather_u64(p, mine) + 1 - b;     // entries with high part < b
+        const uint64_t fb = (b << v.wl) - before;
+        if (fb <= k)
+        {
+            blo = b;
+            flo = fb;
+        }
+        else
+        {
+            bhi = b;
+            fhi = fb;
+        }
+    }
+    // bucket blo: its entries are [begin, end) of `low`
+    const uint64_t begin = (blo << v.wl) - flo, start = begin + blo; // start: the bucket's run in `high`
+    uint64_t nz = quad_next_zero_in_line<NT>(v.high, s, start);
+    if (nz == SDSL_HIP_NPOS)
+    {
+        const uint64_t p = quad_select<0, NT>(v.high, s, blo, mine);
+        nz = quad_gather_u64(p, mine);
+    }
+    const uint64_t cnt = nz - blo - begin, r = k - flo;
+    uint64_t lo = 0, hi = cnt; // first t with low_t - t > r
+    while (lo < hi)
+    {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (sd_low(v, begin + mid) <= r + mid)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return (blo << v.wl) + r + lo;
+}
+
 template <int MODE> // 0: rank (bit b), 1: access
 __global__ __launch_bounds__(kBlock) void k_sd_rank(SdView v, int bit, const uint64_t * __restrict__ xq,
                                                     uint64_t * __restrict__ out, uint8_t * __restrict__ out8, uint64_t n)
@@ -184,24 +245,7 @@ __global__ __launch_bounds__(kBlock) void k_sd_select(SdView v, const uint64_t *
             if (BIT)
                 r = quad_sd_select1<false>(v, s, i);
             else
-            { // the reference's binary search over the ones (sd_vector.hpp:640-663)
-                uint64_t lb = 1, rb = v.m + 1, r0 = 0, pos = ~UINT64_C(0);
-                while (lb < rb)
-                {
-                    const uint64_t mid = lb + (rb - lb) / 2;
-                    const uint64_t x = quad_sd_select1<false>(v, s, mid);
-                    const uint64_t rank0 = x + 1 - mid;
-                    if (rank0 >= i)
-                        rb = mid;
-                    else
-                    {
-                        r0 = rank0;
-                        pos = x;
-                        lb = mid + 1;
-                    }
-                }
-                r = pos + i - r0;
-            }
+                r = quad_sd_select0<false>(v, s, i);
         }
         if (s == 0)
             out[q] = r;

@@ -104,3 +104,33 @@ def test_single_symbol_trees_of_every_shape(gpu):
         assert list(wt.rank(i, np.full(4, ord("x"), np.uint8))) == [0, 0, 0, 0]
         assert list(wt.select(np.array([1, 777], dtype=np.uint64), np.full(2, ord("q"), np.uint8))) == [0, 776]
         assert list(wt.access(np.array([0, 776], dtype=np.uint64))) == [ord("q")] * 2
+
+
+@pytest.mark.parametrize("shape", ["cluster_front", "cluster_back", "dense_half", "two_clusters", "every_4096th", "all_but_one"])
+def test_sd_select0_on_skewed_vectors(gpu, shape):
+    """select_0 interpolates over buckets (sd.hip): vectors whose zeros are anything but evenly spread must still give the
+    position a scan gives — every zero of the vector is asked for"""
+    n = 50_000 + 37
+    bits = np.zeros(n, dtype=np.uint8)
+    if shape == "cluster_front":
+        bits[:20_000] = 1
+    elif shape == "cluster_back":
+        bits[-20_000:] = 1
+    elif shape == "dense_half":
+        bits[np.random.default_rng(1).random(n) < 0.5] = 1
+    elif shape == "two_clusters":
+        bits[1000:9000] = 1
+        bits[30_000:30_700] = 1
+    elif shape == "every_4096th":
+        bits[::4096] = 1
+    else:
+        bits[:] = 1
+        bits[12345] = 0
+    pos = np.flatnonzero(bits).astype(np.uint64)
+    sd = gpu.sd_vector(positions=pos, n_bits=n)
+    zeros = np.flatnonzero(bits == 0).astype(np.uint64)
+    i = np.arange(1, zeros.size + 1, dtype=np.uint64)
+    assert np.array_equal(sd.select(i, 0), zeros)
+    assert np.all(sd.select(np.array([0, zeros.size + 1], dtype=np.uint64), 0) == NPOS)
+    ones_i = np.arange(1, pos.size + 1, dtype=np.uint64)
+    assert np.array_equal(sd.select(ones_i, 1), pos)
