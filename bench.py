@@ -374,10 +374,17 @@ def main():
             si = torch.randint(1, pos.numel() + 1, (nq_sd,), device=dev, dtype=torch.int64, generator=gq)
             _, ms_s = time_steps(lambda: sd.select(si, 1, o_sd), 3, 1, barrier)
             assert torch.equal(o_sd, pos[si - 1])
+            zi = torch.randint(1, N_sd - pos.numel() + 1, (nq_sd,), device=dev, dtype=torch.int64, generator=gq)
+            _, ms_z = time_steps(lambda: sd.select(zi, 0, o_sd), 3, 1, barrier)
+            # the i-th zero sits at p with p - rank_1(p) == i - 1 and bit p clear
+            zr = sd.rank(o_sd[:1_000_000], 1)
+            assert torch.equal(o_sd[:1_000_000] - zr, zi[:1_000_000] - 1)
+            assert bool((sd.access(o_sd[:1_000_000]) == 0).all())
             ex["sd_vector"] = {"ones": pos.numel(), "universe_log2": 40, "low_width": sd.low_width(),
                                "bits_per_one": sd.device_bytes() * 8 / pos.numel(), "build_s": sd_build,
-                               "rank_1_Gq/s": nq_sd / ms_r / 1e6, "select_1_Gq/s": nq_sd / ms_s / 1e6, "queries": nq_sd}
-            del sd, pos, xi, si, o_sd
+                               "rank_1_Gq/s": nq_sd / ms_r / 1e6, "select_1_Gq/s": nq_sd / ms_s / 1e6,
+                               "select_0_Gq/s": nq_sd / ms_z / 1e6, "queries": nq_sd}
+            del sd, pos, xi, si, zi, zr, o_sd
         if "wt" in extras or "fm" in extras:
             torch.cuda.empty_cache()
             nt = a.text_mib << 20
@@ -424,6 +431,16 @@ def main():
                                   a.cpu_seconds, 1e9, "(i,c) pairs, wt_huff<bit_vector,rank_support_v5<>>::rank")
                     cb.update(unit="Grank/s", kind="port")
                     ex["wt_huff_rank"]["cpu_baseline"] = cb
+            if "wt" in extras:
+                # select(k, c) for symbols drawn from the text and k uniform in [1, occ(c)]; checked through rank
+                occ_c = torch.bincount(text, minlength=256)[gc.long()]
+                ks = (torch.rand(nq2, device=dev, generator=gq, dtype=torch.float64) * occ_c.double()).long() + 1
+                ks = torch.minimum(ks, occ_c)
+                _, ms = time_steps(lambda: wt.select(ks, gc, out2), 2, 1, barrier)
+                chk = wt.rank(out2[:1_000_000], gc[:1_000_000])
+                assert torch.equal(chk, ks[:1_000_000] - 1), "rank(select(k, c), c) != k - 1"
+                ex["wt_huff_select"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2}
+                del occ_c, ks, chk
             if "fm" in extras:
                 m = 20
                 st = torch.randint(0, nt - m, (nq2,), device=dev, generator=gq)
