@@ -101,16 +101,51 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
     constexpr unsigned kWalkers = P::kThreads / P::kLanes;
     const uint64_t stride = (uint64_t)gridDim.x * kWalkers;
     uint64_t q = (uint64_t)blockIdx.x * kWalkers + threadIdx.x / P::kLanes;
-    bool busy = false, fresh = false;
+    uint64_t a_next = q < n ? in0[q] : 0; // the walker's next argument, loaded one query ahead
+    bool busy = false;
     uint64_t j = 0, i = 0, steps = 0, taken = 0, emit_from = 0, base = 0;
     unsigned v = 0;
+    // between two LF steps: is the walk finished?  Then the answer is written and the walker is free again.
+    auto settle = [&]() {
+        bool done;
+        if (MODE == kWalkSa) // LF is one cycle of length n in a consistent index: a longer walk means a broken one
+            done = j % L.sa_dens == 0 || taken > L.size;
+        else
+            done = taken == steps;
+        if (!done)
+        { // next LF step starts at the root
+            v = 0;
+            i = j;
+            return;
+        }
+        if (MODE == kWalkSa)
+        {
+            uint64_t r = SDSL_HIP_NPOS;
+            if (j % L.sa_dens == 0)
+            {
+                r = L.sa_s[j / L.sa_dens] + taken; // (csa_wt.hpp:373-380)
+                r = r < L.size ? r : r - L.size;
+            }
+            if (s == 0)
+                out[q] = r;
+        }
+        else if (MODE != kWalkExtract)
+        {
+            if (s == 0)
+                out[q] = j;
+        }
+        q += stride;
+        busy = false;
+    };
+    // Every iteration of the outer loop is ONE tree level (one memory access) for every walker that has work: taking
+    // the next query, finishing an LF step at a leaf and testing for the end of the walk all happen around it.
     for (;;)
     {
-        if (!busy)
+        while (!busy && q < n)
         { // next query of this walker
-            if (q >= n)
-                break;
-            const uint64_t a = in0[q];
+            const uint64_t a = a_next;
+            if (q + stride < n)
+                a_next = in0[q + stride];
             bool ok = a < L.size;
             taken = 0;
             if (MODE == kWalkSa || MODE == kWalkLf)
@@ -149,41 +184,12 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
                 continue;
             }
             busy = true;
-            fresh = true;
+            settle(); // a walk of zero steps ends here
         }
-        if (fresh)
-        { // between two LF steps: finished?
-            bool done;
-            if (MODE == kWalkSa) // LF is one cycle of length n in a consistent index: a longer walk means a broken one
-                done = j % L.sa_dens == 0 || taken > L.size;
-            else
-                done = taken == steps;
-            if (done)
-            {
-                if (MODE == kWalkSa)
-                {
-                    uint64_t r = SDSL_HIP_NPOS;
-                    if (j % L.sa_dens == 0)
-                    {
-                        r = L.sa_s[j / L.sa_dens] + taken; // (csa_wt.hpp:373-380)
-                        r = r < L.size ? r : r - L.size;
-                    }
-                    if (s == 0)
-                        out[q] = r;
-                }
-                else if (MODE != kWalkExtract)
-                {
-                    if (s == 0)
-                        out[q] = j;
-                }
-                q += stride;
-                busy = false;
-                continue;
-            }
-            fresh = false;
-            v = 0;
-            i = j;
-        }
+        if (!busy)
+            break; // out of queries
+        if (S.T.child[v][0] != kWtUndef) // (a one-symbol tree is a single leaf)
+            P::level(wt, &S, s, v, i);
         if (S.T.child[v][0] == kWtUndef)
         { // leaf: the LF step is complete (suffix_array_helper.hpp:352-358)
             const unsigned c = (unsigned)S.T.bv_pos_rank[v];
@@ -191,10 +197,8 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
             ++taken;
             if (MODE == kWalkExtract && taken >= emit_from && s == 0)
                 out_text[base - taken] = (uint8_t)c;
-            fresh = true;
-            continue;
+            settle();
         }
-        P::level(wt, &S, s, v, i);
     }
 }
 
