@@ -7,6 +7,9 @@
 // keeps everything in HBM: per round one 64-bit-key radix sort of n (key, suffix) pairs
 // (rocPRIM — a plain library sort is exactly what this step is), one adjacent-difference + scan to
 // re-rank, one gather to form the next keys.  k starts at 8 (first 8 bytes packed big-endian).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -180,6 +183,16 @@ sdsl_hip_status sa_build_bwt_device(const uint8_t * text, uint64_t n_text, int d
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
     SH_HIP(hipSetDevice(device));
+    const bool trace = getenv("SDSL_HIP_TRACE_BUILD") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stamp = [&](const char * what) {
+        if (!trace)
+            return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sdsl_hip] suffix sort: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     DevBuf d_s, d_k0, d_k1, d_i0, d_i1, d_rank, d_flags, d_tmp;
     SH_TRY(d_s.alloc(n));
     SH_HIP(hipMemcpy(d_s.p, text, n_text, hipMemcpyDefault)); // host or device text
@@ -204,6 +217,7 @@ sdsl_hip_status sa_build_bwt_device(const uint8_t * text, uint64_t n_text, int d
     SH_HIP(rocprim::inclusive_scan(nullptr, tmp_scan, flags, flags, (size_t)n, rocprim::plus<uint32_t>()));
     SH_TRY(d_tmp.alloc(std::max(tmp_sort, tmp_scan)));
 
+    stamp("allocations + text copy");
     hipLaunchKernelGGL(k_sa_init_keys, dim3(grid), dim3(256), 0, 0, d_s.as<uint8_t>(), n, k0, i0);
     SH_HIP(hipGetLastError());
     uint64_t k = 8;
@@ -232,11 +246,13 @@ sdsl_hip_status sa_build_bwt_device(const uint8_t * text, uint64_t n_text, int d
         end_bit = 2 * rank_bits;
         k <<= 1;
     }
+    stamp("doubling rounds");
     SH_TRY(d_bwt.alloc(n));
     hipLaunchKernelGGL(k_sa_bwt, dim3(grid), dim3(256), 0, 0, d_s.as<uint8_t>(), i1, n, d_bwt.as<uint8_t>());
     SH_HIP(hipGetLastError());
     SH_HIP(hipDeviceSynchronize());
     d_sa = std::move(d_i1);
+    stamp("bwt");
     return SDSL_HIP_OK;
 }
 
