@@ -791,6 +791,114 @@ __global__ __launch_bounds__(kBlock) void k_wt_select(WtView wt, const uint64_t 
     }
 }
 
+// wt_pc::select on the fused layout: the same flat persistent loop, but one iteration is one probe of a FUSED step
+// (three tree levels): the path of c is cut into groups of three levels from the root, and the walk goes from the
+// deepest group up, each group one select of its slot inside the fused node above it.
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void k_wt_select_fused(WtView wt, const uint64_t * __restrict__ occ,
+                                                            const uint64_t * __restrict__ iq,
+                                                            const uint8_t * __restrict__ cq, uint64_t * __restrict__ out,
+                                                            uint64_t n)
+{
+    __shared__ WtTables T;
+    __shared__ WtFusedTables FT;
+    __shared__ WtFusedSelTables FS;
+    __shared__ uint64_t occ_s[256];
+    occ_s[threadIdx.x & 255] = occ[threadIdx.x & 255];
+    {
+        const uint64_t * src = reinterpret_cast<const uint64_t *>(wt.f_sel_tables);
+        uint64_t * dst = reinterpret_cast<uint64_t *>(&FS);
+        for (unsigned i = threadIdx.x; i < sizeof(WtFusedSelTables) / 8; i += blockDim.x)
+            dst[i] = src[i];
+    }
+    wt_stage_fused(&FT, wt);
+    wt_stage_tables(&T, wt.tables); // ends with __syncthreads()
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    const uint64_t stride = (uint64_t)gridDim.x * kQPB;
+    uint64_t q_next = (uint64_t)blockIdx.x * kQPB + gq; // this quad's next query, loaded one query ahead
+    uint64_t i_nxt = q_next < n ? iq[q_next] : 0;
+    unsigned c_nxt = q_next < n ? cq[q_next] : 0;
+    bool have = false;
+    uint64_t q = 0, p = 0, base_line = 0;
+    uint32_t res = 0;
+    unsigned groups = 0, len = 0, cur = 0, t = 0;
+    int tries = 0;
+    FselBracket br{};
+    // the fused step that takes node `cur`'s offset `res` up into the fused node above it
+    auto start_group = [&]() {
+        const unsigned g = groups - 1, nlev = len - 3 * g < 3 ? len - 3 * g : 3;
+        t = (unsigned)(p >> (3 * g)) & ((1u << nlev) - 1u);
+        unsigned u = cur;
+        for (unsigned k = 0; k < nlev; ++k)
+            u = T.parent[u];
+        cur = u;
+        len = 3 * g; // levels above u
+        base_line = FT.fline[u];
+        const unsigned rid = FS.root_id[u];
+        br = fsel_bracket(wt.f_sel, FS.off[rid][t], res, FS.cnt[rid][t]);
+        tries = 0;
+    };
+    for (;;)
+    {
+        while (!have && q_next < n)
+        { // next query of this quad; the ones that need no walk are answered on the spot
+            q = q_next;
+            q_next += stride;
+            const uint64_t i = i_nxt;
+            const unsigned c = c_nxt;
+            if (q_next < n)
+            { // in flight while this query walks
+                i_nxt = iq[q_next];
+                c_nxt = cq[q_next];
+            }
+            cur = T.c_to_leaf[c];
+            uint64_t direct = 0;
+            bool walk = false;
+            if (cur == kWtUndef)
+                direct = wt.size; // c not in the text (wt_pc.hpp:447-450)
+            else if (i == 0 || i > occ_s[c])
+                direct = SDSL_HIP_NPOS; // outside SDSL's precondition
+            else if (wt.sigma == 1)
+                direct = i - 1 < wt.size ? i - 1 : wt.size;
+            else
+                walk = true;
+            if (!walk)
+            {
+                if (s == 0)
+                    out[q] = direct;
+                continue;
+            }
+            res = (uint32_t)(i - 1);
+            p = T.path[c];
+            len = (unsigned)(p >> 56);
+            groups = (len + 2) / 3;
+            have = true;
+            start_group();
+        }
+        if (__ballot(have) == 0)
+            break; // every quad of the wave is out of queries
+        if (have)
+        {
+            uint64_t pos;
+            if (quad_fsel_probe<NT>(wt.f_lines, base_line, s, t, res, br, tries, pos))
+            {
+                res = (uint32_t)pos;
+                if (--groups == 0)
+                {
+                    if (s == 0)
+                        out[q] = res;
+                    have = false;
+                }
+                else
+                    start_group();
+            }
+            else
+                ++tries;
+        }
+    }
+}
+
 // ---- construction of the fused layout (wt_device.hpp) from the binary tree ---------------------------------------
 // planes: a wave handles 64 consecutive positions of node u's sequence, one lane each.  Consecutive positions of a node
 // stay consecutive inside each child, so a lane's offset one level down = (rank at the group's first position, the
@@ -882,6 +990,46 @@ __global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint6
     reinterpret_cast<uint32_t *>(fl + line * kFusedWords + 4 * (t >> 1))[t & 1] = ok ? (uint32_t)i : 0u;
 }
 
+// select directory of one fused node: thread (line, t) knows which occurrences of t fall into its line from two
+// neighbouring headers; if occurrence 256 * j is among them it finds its position in the line's match masks
+struct FselNodeArgs
+{
+    uint32_t cnt[8], off[8], n_samples[8];
+    uint32_t size;
+};
+__global__ __launch_bounds__(256) void k_wt8_sel_dir(const uint64_t * __restrict__ fl, uint64_t n_lines, FselNodeArgs a,
+                                                     uint32_t * __restrict__ dir)
+{
+    const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t line = id >> 3;
+    const unsigned t = (unsigned)id & 7u;
+    if (line >= n_lines || a.off[t] == kFselNone)
+        return;
+    const uint64_t * ln = fl + line * kFusedWords;
+    const uint32_t c0 = reinterpret_cast<const uint32_t *>(ln + 4 * (t >> 1))[t & 1];
+    const uint32_t c1 = line + 1 < n_lines ? reinterpret_cast<const uint32_t *>(ln + kFusedWords + 4 * (t >> 1))[t & 1]
+                                          : a.cnt[t];
+    const uint32_t j = (c0 + 255u) >> 8;
+    if (c1 > c0 && (j << 8) < c1)
+    {
+        uint32_t r = (j << 8) - c0; // rank of the wanted occurrence inside the line
+        for (unsigned g = 0; g < 4; ++g)
+        {
+            const uint64_t p0 = ln[4 * g + 1], p1 = ln[4 * g + 2], p2 = ln[4 * g + 3];
+            const uint64_t m = ((t & 1) ? p0 : ~p0) & ((t & 2) ? p1 : ~p1) & ((t & 4) ? p2 : ~p2);
+            const uint32_t c = popc64(m);
+            if (r < c)
+            {
+                dir[a.off[t] + j] = (uint32_t)(line << kFusedLog) + 64u * g + sel64(m, r + 1);
+                break;
+            }
+            r -= c;
+        }
+    }
+    if (line + 1 == n_lines)
+        dir[a.off[t] + a.n_samples[t] - 1] = a.size;
+}
+
 sdsl_hip_status wt_build_fused(WtHost & wt)
 {
     const char * env = getenv("SDSL_HIP_WT_FUSED");
@@ -965,6 +1113,58 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
     SH_HIP(hipGetLastError());
     SH_TRY(wt.d_ftables.alloc(sizeof(WtFusedTables)));
     SH_HIP(hipMemcpy(wt.d_ftables.p, &FT, sizeof(WtFusedTables), hipMemcpyHostToDevice));
+    // select directory (skipped for trees with more fused nodes than its table holds: select then walks the binary levels)
+    const char * env_sel = getenv("SDSL_HIP_WT_FUSED_SELECT"); // 0: select keeps walking the binary levels
+    if (roots.size() <= (size_t)kFselMaxRoots && !(env_sel && atoi(env_sel) == 0))
+    {
+        std::vector<WtFusedSelTables> fs_store(1);
+        WtFusedSelTables & FS = fs_store[0];
+        memset(&FS, 0xFF, sizeof FS);
+        std::vector<FselNodeArgs> args(roots.size());
+        uint64_t n_dir = 0;
+        for (size_t r = 0; r < roots.size(); ++r)
+        {
+            const uint32_t u = roots[r];
+            FS.root_id[u] = (uint16_t)r;
+            args[r].size = (uint32_t)size[u];
+            for (unsigned t = 0; t < 8; ++t)
+            { // the node three levels down along t, or the leaf met earlier (then the rest of t must be zero)
+                uint32_t x = u;
+                bool ok = true;
+                for (unsigned k = 0; k < 3; ++k)
+                {
+                    if (T.child[x][0] == kWtUndef)
+                    {
+                        ok = (t >> k) == 0;
+                        break;
+                    }
+                    x = T.child[x][(t >> k) & 1];
+                }
+                args[r].cnt[t] = args[r].n_samples[t] = 0;
+                args[r].off[t] = kFselNone;
+                if (!ok || size[x] == 0)
+                    continue;
+                args[r].cnt[t] = FS.cnt[r][t] = (uint32_t)size[x];
+                args[r].n_samples[t] = (uint32_t)((size[x] + 255) >> 8) + 1;
+                args[r].off[t] = FS.off[r][t] = (uint32_t)n_dir;
+                n_dir += args[r].n_samples[t];
+            }
+        }
+        if (n_dir < (UINT64_C(1) << 32))
+        {
+            SH_TRY(wt.d_fsel.alloc((n_dir + 1) * 4));
+            for (size_t r = 0; r < roots.size(); ++r)
+            {
+                const uint32_t u = roots[r];
+                const uint64_t lines_u = (size[u] >> kFusedLog) + 1;
+                hipLaunchKernelGGL(k_wt8_sel_dir, dim3(grid_for(lines_u * 8, 256, 1u << 20)), dim3(256), 0, 0,
+                                   fl + (uint64_t)FT.fline[u] * kFusedWords, lines_u, args[r], wt.d_fsel.as<uint32_t>());
+            }
+            SH_HIP(hipGetLastError());
+            SH_TRY(wt.d_fsel_tables.alloc(sizeof(WtFusedSelTables)));
+            SH_HIP(hipMemcpy(wt.d_fsel_tables.p, &FS, sizeof(WtFusedSelTables), hipMemcpyHostToDevice));
+        }
+    }
     SH_HIP(hipStreamSynchronize(0));
     if (trace)
     {
@@ -1294,9 +1494,15 @@ sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, c
     else
     {
         KernelTimer t(s);
-        hipLaunchKernelGGL((k_wt_select<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s,
-                           wt->h.view(), wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev,
-                           (const uint8_t *)sc.dev, (uint64_t *)so.dev, n);
+        const WtView view = wt->h.view();
+        if (view.f_lines && view.f_sel)
+            hipLaunchKernelGGL((k_wt_select_fused<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, view,
+                               wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev, (const uint8_t *)sc.dev,
+                               (uint64_t *)so.dev, n);
+        else
+            hipLaunchKernelGGL((k_wt_select<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, view,
+                               wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev, (const uint8_t *)sc.dev,
+                               (uint64_t *)so.dev, n);
     }
     SH_HIP(hipGetLastError());
     SH_TRY(so.finish(s));

@@ -30,6 +30,18 @@ struct WtFusedTables // node tables of the fused layout (below); staged in LDS b
     uint32_t fline[kWtMaxNodes]; // first line of the node's sequence (nodes at depth 0, 3, 6, ...)
 };
 
+// select on the fused layout: for every fused node u and slot t the directory lists the position (inside u's sequence)
+// of every 256th occurrence of t and ends with u's size.  off[root_id[u]][t] is where the list of (u, t) starts in
+// WtView::f_sel, cnt[..][t] the number of occurrences.
+constexpr int kFselMaxRoots = 80; // a balanced tree over 256 symbols has 1 + 8 + 64 = 73
+constexpr uint32_t kFselNone = 0xFFFFFFFFu;
+struct WtFusedSelTables
+{
+    uint32_t off[kFselMaxRoots][8];
+    uint32_t cnt[kFselMaxRoots][8];
+    uint16_t root_id[kWtMaxNodes];
+};
+
 struct WtView
 {
     BvView bv;   // backend 0: the bit vector as rank lines
@@ -41,6 +53,8 @@ struct WtView
     uint32_t n_nodes;
     const uint64_t * f_lines; // fused (8-ary) layout of the same tree, nullptr if not built
     const WtFusedTables * f_tables;
+    const uint32_t * f_sel;                      // select directory of the fused layout (below), nullptr if not built
+    const struct WtFusedSelTables * f_sel_tables;
 };
 
 // cooperative copy of the tables into LDS (all threads of the block)
@@ -245,6 +259,72 @@ __device__ __forceinline__ uint64_t quad_wt8_rank(const WtView & wt, const WtTab
         left -= k;
     }
     return res;
+}
+
+// ---- select on the fused layout ----------------------------------------------------------------
+// position (inside node u's sequence) of the (k+1)-th occurrence of slot t — the inverse of the fused rank step, and
+// three binary select levels in one.  The directory of (u, t) holds the POSITION of every 256th occurrence (and u's
+// size as the last entry); the guess is interpolated between two (position, count) pairs, the probed line's header
+// count for t and the popcount of its match mask say whether the occurrence is inside, and a miss replaces one end of
+// the bracket by (line edge, exact count) — the scheme of §3.2 of DESIGN.md.
+struct FselBracket
+{ // lo_cnt occurrences lie in front of position plo, hi_cnt in front of phi; lo_cnt <= k < hi_cnt
+    uint32_t plo, phi, lo_cnt, hi_cnt;
+};
+
+__device__ __forceinline__ FselBracket fsel_bracket(const uint32_t * dir, uint32_t off, uint32_t k, uint32_t total)
+{
+    const uint32_t j = k >> 8;
+    FselBracket b;
+    b.plo = dir[off + j];
+    b.phi = dir[off + j + 1];
+    b.lo_cnt = j << 8;
+    b.hi_cnt = (j + 1) << 8;
+    if (b.hi_cnt > total)
+        b.hi_cnt = total; // the last entry is the node's size: all `total` occurrences lie in front of it
+    return b;
+}
+
+// one probe; on a hit all four lanes get the position
+template <bool NT>
+__device__ __forceinline__ bool quad_fsel_probe(const uint64_t * f_lines, uint64_t base_line, int s, unsigned t, uint32_t k,
+                                                FselBracket & b, int tries, uint64_t & pos_out)
+{
+    const uint32_t span = b.phi - b.plo; // > 0
+    uint32_t pe;
+    if (tries >= 3 && (tries & 1))
+        pe = b.plo + (span >> 1);
+    else
+    {
+        const float f = (float)(k - b.lo_cnt) * __builtin_amdgcn_rcpf((float)(b.hi_cnt - b.lo_cnt));
+        const uint32_t o = (uint32_t)(f * (float)span);
+        pe = b.plo + (o >= span ? span - 1 : o);
+    }
+    const uint32_t g = pe >> kFusedLog;
+    const FSec x = load_fsec<NT>(f_lines, base_line + g, s);
+    const uint64_t m = ((t & 1) ? x.p0 : ~x.p0) & ((t & 2) ? x.p1 : ~x.p1) & ((t & 4) ? x.p2 : ~x.p2);
+    const unsigned c_lane = popc64(m);
+    const unsigned hdr = (s == (int)(t >> 1)) ? (unsigned)(x.h >> (32 * (t & 1))) : 0u;
+    const uint32_t c0 = quad_sum(hdr), c_in = quad_sum(c_lane);
+    if (k < c0)
+    {
+        b.phi = g << kFusedLog;
+        b.hi_cnt = c0;
+        return false;
+    }
+    if (k >= c0 + c_in)
+    {
+        b.plo = (g + 1) << kFusedLog;
+        b.lo_cnt = c0 + c_in;
+        return false;
+    }
+    const unsigned r = k - c0, ex = quad_excl(c_lane, s);
+    const bool mine = r >= ex && r < ex + c_lane;
+    uint64_t pos = 0;
+    if (mine)
+        pos = ((uint64_t)g << kFusedLog) + 64u * (unsigned)s + sel64(m, r - ex + 1);
+    pos_out = quad_gather_u64(pos, mine);
+    return true;
 }
 
 // both cascades of one LF step (backward_search)

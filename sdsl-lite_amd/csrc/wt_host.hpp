@@ -18,6 +18,7 @@ struct WtHost
     DevBuf d_tables;    // WtTables image in HBM
     DevBuf d_fused;     // the fused (8-ary) layout used by the rank-type traversals (wt_device.hpp), optional
     DevBuf d_ftables;   // its node tables (WtFusedTables)
+    DevBuf d_fsel, d_fsel_tables; // its select directory (wt_device.hpp: WtFusedSelTables), optional
     WtTables tables;    // host copy (code lengths, alphabet queries)
     uint64_t occ[256];  // occurrences of every byte (== wt.rank(size(), c))
     WtView view() const
@@ -32,11 +33,13 @@ struct WtHost
         v.n_nodes = n_nodes;
         v.f_lines = d_fused.as<uint64_t>();
         v.f_tables = d_ftables.as<WtFusedTables>();
+        v.f_sel = d_fsel.as<uint32_t>();
+        v.f_sel_tables = d_fsel_tables.as<WtFusedSelTables>();
         return v;
     }
     size_t device_bytes() const
     {
-        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes + d_ftables.bytes;
+        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes + d_ftables.bytes + d_fsel.bytes + d_fsel_tables.bytes;
     }
 };
 

@@ -24,10 +24,11 @@ def _text(name):
     return gd.text("faust.txt") if name == "faust" else TEXTS[name]
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("fused", ["1", "0", "no_select_directory"])
 @pytest.mark.parametrize("name", list(TEXTS))
 def test_wavelet_tree_queries_on_both_layouts(gpu, monkeypatch, name, fused):
-    monkeypatch.setenv("SDSL_HIP_WT_FUSED", fused)
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED", "0" if fused == "0" else "1")
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED_SELECT", "0" if fused == "no_select_directory" else "1")
     text = _text(name)
     wt = gpu.wt_huff(text=text)
     o = ol.OWt(text)
@@ -43,6 +44,22 @@ def test_wavelet_tree_queries_on_both_layouts(gpu, monkeypatch, name, fused):
     orr, och = o.inverse_select(j)
     assert np.array_equal(r, orr) and np.array_equal(ch, och)
     assert np.array_equal(wt.access(j), arr[j.astype(np.int64)])
+    # select: EVERY occurrence of every symbol that occurs (and the overflow / absent-symbol answers)
+    order = np.argsort(arr, kind="stable")
+    sym = arr[order]
+    first = np.searchsorted(sym, sym, side="left")
+    kk = (np.arange(n) - first + 1).astype(np.uint64)
+    if n > 40000:
+        pick = rng.choice(n, 40000, replace=False)
+        order, sym, kk = order[pick], sym[pick], kk[pick]
+    assert np.array_equal(wt.select(kk, sym), order.astype(np.uint64))
+    absent = np.setdiff1d(np.arange(256), np.unique(arr))
+    if absent.size:
+        a = absent[:4].astype(np.uint8)
+        assert np.all(wt.select(np.ones(a.size, dtype=np.uint64), a) == np.uint64(n))
+    cnt = np.bincount(arr, minlength=256)
+    present = np.unique(arr)[:8]
+    assert np.all(wt.select(cnt[present].astype(np.uint64) + np.uint64(1), present) == np.uint64(2**64 - 1))
 
 
 @pytest.mark.parametrize("fused", ["1", "0"])
@@ -60,6 +77,7 @@ def test_fm_index_queries_on_both_layouts(gpu, monkeypatch, kw, fused):
         assert np.array_equal(csa.count(pats, m), o.count_batch(pats, m)), m
     idx = rng.integers(0, csa.size(), 3000).astype(np.uint64)
     assert np.array_equal(csa.lf(idx), o.lf(idx)) and np.array_equal(csa.psi(idx), o.psi(idx))
+    assert np.array_equal(csa.psi(csa.lf(idx)), idx)
     csa.drop_sa()
     assert np.array_equal(csa.sa(idx), o.sa(idx)) and np.array_equal(csa.isa(idx), o.isa(idx))
     off, t = csa.extract(np.array([0, 1000, 200000], dtype=np.uint64), np.array([99, 1900, 200300], dtype=np.uint64))
