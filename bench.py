@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy achieves
 FUSED_NOTE = ("roofline_frac prices the query as SURVEY.md 8(d) does (80 bytes per tree level, the reference's algorithm); the "
-              "kernel walks the fused layout (one 128-byte line per three levels), so the figure can exceed 1; line_fetch_frac "
+              "kernel walks the fused layout (one 128-byte line per level of its own 8-ary tree), so the figure can exceed 1; line_fetch_frac "
               "prices the lines the fused walk addresses (an upper bound on its HBM traffic: small nodes stay in cache and "
               "the k-mer table skips the first characters of a pattern)")
 ALG_BYTES = {"rank": 96, "select": 112, "rrr": 144}  # SURVEY.md §8(d), bytes per query
@@ -394,6 +394,7 @@ def main():
             build = time.perf_counter() - t0
             wt = csa.wavelet_tree
             lens = torch.from_numpy(wt.code_lengths().astype(np.int64)).to(dev)
+            fsteps = torch.from_numpy(wt.fused_steps().astype(np.int64)).to(dev)
             nq2 = min(nq, 100_000_000)
             gi = torch.randint(0, nt + 1, (nq2,), device=dev, dtype=torch.int64, generator=gq)
             gc = text[torch.randint(0, nt, (nq2,), device=dev, generator=gq)]
@@ -418,7 +419,7 @@ def main():
             if "wt" in extras:
                 _, ms = time_steps(lambda: wt.rank(gi, gc, out2), max(2, a.steps // 2), 1, barrier)
                 alg = 17 + 80 * hbar
-                steps = float(((lens[gc.long()] + 2) // 3).double().mean())  # fused layout: three levels per line
+                steps = float(fsteps[gc.long()].double().mean())  # fused layout: depth in its own 8-ary tree
                 ex["wt_huff_rank"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2,
                                       "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_query": alg,
@@ -448,7 +449,7 @@ def main():
                 _, ms = time_steps(lambda: csa.count(pats, m, out2), max(2, a.steps // 2), 1, barrier)
                 sum_l = float(lens[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
                 alg = 28 + 160 * sum_l
-                sum_steps = float(((lens[pats.view(-1, m)[:, :m - 1].long()] + 2) // 3).double().sum(dim=1).mean())
+                sum_steps = float(fsteps[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
                 assert bool((out2 >= 1).all()), "every pattern was cut from the text"
                 ex["fm_count"] = {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "patterns": nq2, "m": m,
                                   "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -186,11 +186,15 @@ uint64_t sdsl_hip_wt_sigma(sdsl_hip_wt_t wt);    /* wt.sigma   */
 uint64_t sdsl_hip_wt_bv_size(sdsl_hip_wt_t wt);  /* wt.bv.size() */
 /* HBM held by the handle.  A plain (non-rrr) tree with fewer than 2^32 symbols keeps TWO layouts: SDSL's binary levels
  * (select, writers) and a fused three-levels-per-fetch layout that rank / operator[] / inverse_select — and through
- * them backward_search, count, csa[i], isa, extract, locate — walk (about 4 more bits per symbol per
- * three levels).  SDSL_HIP_WT_FUSED=0 in the environment at creation time leaves it out; answers are the same. */
+ * them backward_search, count, csa[i], isa, extract, locate — and select walk (4 bits per symbol per
+ * fused level, the levels being those of an 8-ary Huffman tree of its own).  SDSL_HIP_WT_FUSED=0 in the environment at
+ * creation time leaves it out; answers are the same. */
 uint64_t sdsl_hip_wt_device_bytes(sdsl_hip_wt_t wt);
 /* sum over c of count(c) * code_length(c) / size() is what bench.py needs for the roofline */
 sdsl_hip_status sdsl_hip_wt_code_lengths(sdsl_hip_wt_t wt, uint8_t len_out[256]);
+/* fetches a rank / access / select of symbol c costs on the fused layout (its depth in the layout's own 8-ary tree);
+ * all zero when the handle has no fused layout */
+sdsl_hip_status sdsl_hip_wt_fused_steps(sdsl_hip_wt_t wt, uint8_t steps_out[256]);
 /* out[q] = occurrences of c[q] in [0, i[q]),  i[q] in [0, size()]   (wt.rank(i,c)) */
 sdsl_hip_status sdsl_hip_wt_rank_batch(sdsl_hip_wt_t wt, const uint64_t * i, const uint8_t * c, uint64_t n,
                                        uint64_t * out, void * stream);

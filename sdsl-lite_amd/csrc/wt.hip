@@ -8,6 +8,7 @@
 //   Huffman shape          wt_huff.hpp:83-115     BFS byte tree + paths   wt_helper.hpp:230-327
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <queue>
 
 #include "bv_serialize.hpp"
@@ -217,6 +218,85 @@ static int shape_hutu(const std::vector<int> & syms, const uint64_t occ[256], st
     return stack[0].first;
 }
 
+// The fused layout's own shape: an 8-ary Huffman tree (the expected number of fused steps per symbol is what it
+// minimises), written as a binary tree in which every 8-ary node is a complete subtree of depth 3.  Zero-weight dummies
+// pad the alphabet to 7k + 1 leaves as usual; they all end up in the first merged node, whose real children are then
+// leaves and form a balanced subtree of depth <= 3.  Returns -1 if the tree cannot be written that way.
+static int shape_huff8(const uint64_t occ[256], std::vector<ShapeTmp> & tmp)
+{
+    struct N8
+    {
+        uint64_t w;
+        int sym; // >= 0 leaf, -1 inner, -2 dummy
+        std::vector<int> kids;
+    };
+    std::vector<N8> nodes;
+    typedef std::pair<uint64_t, int> Item;
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> heap;
+    for (int c = 0; c < 256; ++c)
+        if (occ[c])
+        {
+            heap.push(Item(occ[c], (int)nodes.size()));
+            nodes.push_back(N8{occ[c], c, {}});
+        }
+    if (heap.size() < 2)
+        return -1;
+    while ((heap.size() - 1) % 7 != 0)
+    {
+        heap.push(Item(0, (int)nodes.size()));
+        nodes.push_back(N8{0, -2, {}});
+    }
+    while (heap.size() > 1)
+    {
+        N8 in{0, -1, {}};
+        for (int k = 0; k < 8; ++k)
+        {
+            const Item it = heap.top();
+            heap.pop();
+            in.w += it.first;
+            if (nodes[it.second].sym != -2)
+                in.kids.push_back(it.second);
+        }
+        heap.push(Item(in.w, (int)nodes.size()));
+        nodes.push_back(in);
+    }
+    const int root8 = heap.top().second;
+    bool ok = true;
+    // binary subtree over kids[lo, hi) of an 8-ary node
+    std::function<int(int)> expand;
+    std::function<int(const std::vector<int> &, size_t, size_t)> over = [&](const std::vector<int> & kids, size_t lo,
+                                                                            size_t hi) -> int {
+        if (hi - lo == 1)
+            return expand(kids[lo]);
+        const size_t mid = lo + (hi - lo + 1) / 2;
+        const int l = over(kids, lo, mid), r = over(kids, mid, hi);
+        tmp.push_back(ShapeTmp{tmp[l].freq + tmp[r].freq, -1, l, r});
+        return (int)tmp.size() - 1;
+    };
+    expand = [&](int id) -> int {
+        const N8 & nd = nodes[id];
+        if (nd.sym >= 0)
+        {
+            tmp.push_back(ShapeTmp{nd.w, nd.sym, -1, -1});
+            return (int)tmp.size() - 1;
+        }
+        if (nd.kids.size() < 2)
+            ok = false;
+        if (nd.kids.size() < 8) // fewer than eight children: they must all be leaves (depth <= 3 is then enough)
+            for (int k : nd.kids)
+                if (nodes[k].sym < 0)
+                    ok = false;
+        if (!ok)
+        {
+            tmp.push_back(ShapeTmp{nd.w, 0, -1, -1});
+            return (int)tmp.size() - 1;
+        }
+        return over(nd.kids, 0, nd.kids.size());
+    };
+    const int root = expand(root8);
+    return ok ? root : -1;
+}
+
 static sdsl_hip_status build_shape(const uint64_t occ[256], uint32_t shape, WtTables & T, uint32_t & n_nodes,
                                    uint64_t & bv_size, uint64_t & sigma)
 {
@@ -232,7 +312,13 @@ static sdsl_hip_status build_shape(const uint64_t occ[256], uint32_t shape, WtTa
     if (syms.empty())
         return SDSL_HIP_OK;
     const int root = shape == 1 ? shape_balanced_rec(syms, 0, syms.size(), occ, tmp)
-                                : (shape == 2 ? shape_hutu(syms, occ, tmp) : shape_huffman(occ, tmp));
+                                : (shape == 2 ? shape_hutu(syms, occ, tmp)
+                                              : (shape == 3 ? shape_huff8(occ, tmp) : shape_huffman(occ, tmp)));
+    if (root < 0)
+    {
+        set_error("internal: no 8-ary shape for this alphabet");
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
     n_nodes = (uint32_t)tmp.size();
     // breadth-first renumbering
     std::vector<int> order; // order[bfs id] = tmp id
@@ -392,8 +478,9 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
         set_error("wt_create: SDSL_HIP_WT_BLCD and SDSL_HIP_WT_HUTU exclude each other");
         return SDSL_HIP_ERR_INVALID;
     }
-    SH_TRY(build_shape(wt.occ, (flags & SDSL_HIP_WT_BLCD) ? 1u : ((flags & SDSL_HIP_WT_HUTU) ? 2u : 0u), wt.tables, wt.n_nodes,
-                       bv_size, wt.sigma));
+    SH_TRY(build_shape(wt.occ,
+                       (flags & kWtShapeHuff8) ? 3u : ((flags & SDSL_HIP_WT_BLCD) ? 1u : ((flags & SDSL_HIP_WT_HUTU) ? 2u : 0u)),
+                       wt.tables, wt.n_nodes, bv_size, wt.sigma));
     WtTables & T = wt.tables;
     // 3. bits, level by level
     const uint64_t nw = (bv_size + 63) >> 6;
@@ -444,7 +531,8 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
     }
     // 4. rank lines + select directories
     wt.bv.device = device;
-    SH_TRY(bv_build_from_device_words(wt.bv, d_words.as<uint64_t>(), bv_size, SDSL_HIP_BV_SELECT1 | SDSL_HIP_BV_SELECT0,
+    SH_TRY(bv_build_from_device_words(wt.bv, d_words.as<uint64_t>(), bv_size,
+                                      (flags & kWtNoSelect) ? 0u : (SDSL_HIP_BV_SELECT1 | SDSL_HIP_BV_SELECT0),
                                       default_sel_shift()));
     // 5. bv_pos_rank of the inner nodes = rank_1 at the start of their slices (wt_helper.hpp:320-327)
     SH_TRY(wt.d_tables.alloc(sizeof(WtTables)));
@@ -1030,15 +1118,31 @@ __global__ __launch_bounds__(256) void k_wt8_sel_dir(const uint64_t * __restrict
         dir[a.off[t] + a.n_samples[t] - 1] = a.size;
 }
 
-sdsl_hip_status wt_build_fused(WtHost & wt)
+// the symbol sequence of a tree (wt[0 .. size)), read back through the binary levels
+__global__ __launch_bounds__(kBlock) void k_wt_export_symbols(WtView wt, uint8_t * __restrict__ out, uint64_t n)
 {
-    const char * env = getenv("SDSL_HIP_WT_FUSED");
-    if (env && atoi(env) == 0)
-        return SDSL_HIP_OK;
-    if (wt.backend != 0 || wt.sigma < 2 || wt.n_nodes < 3 || wt.size == 0 || wt.size >= (UINT64_C(1) << 32) ||
-        !wt.d_tables.p)
-        return SDSL_HIP_OK;
-    WtTables & T = wt.tables;
+    __shared__ WtTables T;
+    wt_stage_tables(&T, wt.tables);
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
+    {
+        const uint64_t q = base + gq;
+        if (q >= n)
+            continue;
+        unsigned c = 0;
+        quad_wt_inverse_select<false>(wt, &T, nullptr, s, q, c);
+        if (s == 0)
+            out[q] = (uint8_t)c;
+    }
+}
+
+// Builds the fused layout (lines, node tables, select directory) of the tree `src` into `dst`.  Leaves dst.d_fused
+// empty when the tree does not qualify.
+static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
+{
+    const WtHost & wt = src;
+    const WtTables & T = wt.tables;
     std::vector<WtFusedTables> ft_store(1);
     WtFusedTables & FT = ft_store[0];
     memset(&FT, 0, sizeof FT);
@@ -1095,11 +1199,10 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         return std::chrono::steady_clock::now();
     };
     const auto t0 = now();
-    SH_TRY(wt.d_fused.alloc(total * kFusedWords * 8));
-    SH_HIP(hipMemsetAsync(wt.d_fused.p, 0, total * kFusedWords * 8, 0));
-    WtView view = wt.view();
-    view.f_lines = nullptr;
-    uint64_t * fl = wt.d_fused.as<uint64_t>();
+    SH_TRY(dst.d_fused.alloc(total * kFusedWords * 8));
+    SH_HIP(hipMemsetAsync(dst.d_fused.p, 0, total * kFusedWords * 8, 0));
+    const WtView view = wt.view_binary();
+    uint64_t * fl = dst.d_fused.as<uint64_t>();
     const auto t1 = now();
     for (uint32_t v : roots)
     {
@@ -1111,8 +1214,8 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         hipLaunchKernelGGL(k_wt8_counts, dim3(grid_for(lines_v * 8, 256, 1u << 20)), dim3(256), 0, 0, view, v, lines_v, at);
     }
     SH_HIP(hipGetLastError());
-    SH_TRY(wt.d_ftables.alloc(sizeof(WtFusedTables)));
-    SH_HIP(hipMemcpy(wt.d_ftables.p, &FT, sizeof(WtFusedTables), hipMemcpyHostToDevice));
+    SH_TRY(dst.d_ftables.alloc(sizeof(WtFusedTables)));
+    SH_HIP(hipMemcpy(dst.d_ftables.p, &FT, sizeof(WtFusedTables), hipMemcpyHostToDevice));
     // select directory (skipped for trees with more fused nodes than its table holds: select then walks the binary levels)
     const char * env_sel = getenv("SDSL_HIP_WT_FUSED_SELECT"); // 0: select keeps walking the binary levels
     if (roots.size() <= (size_t)kFselMaxRoots && !(env_sel && atoi(env_sel) == 0))
@@ -1152,17 +1255,17 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         }
         if (n_dir < (UINT64_C(1) << 32))
         {
-            SH_TRY(wt.d_fsel.alloc((n_dir + 1) * 4));
+            SH_TRY(dst.d_fsel.alloc((n_dir + 1) * 4));
             for (size_t r = 0; r < roots.size(); ++r)
             {
                 const uint32_t u = roots[r];
                 const uint64_t lines_u = (size[u] >> kFusedLog) + 1;
                 hipLaunchKernelGGL(k_wt8_sel_dir, dim3(grid_for(lines_u * 8, 256, 1u << 20)), dim3(256), 0, 0,
-                                   fl + (uint64_t)FT.fline[u] * kFusedWords, lines_u, args[r], wt.d_fsel.as<uint32_t>());
+                                   fl + (uint64_t)FT.fline[u] * kFusedWords, lines_u, args[r], dst.d_fsel.as<uint32_t>());
             }
             SH_HIP(hipGetLastError());
-            SH_TRY(wt.d_fsel_tables.alloc(sizeof(WtFusedSelTables)));
-            SH_HIP(hipMemcpy(wt.d_fsel_tables.p, &FS, sizeof(WtFusedSelTables), hipMemcpyHostToDevice));
+            SH_TRY(dst.d_fsel_tables.alloc(sizeof(WtFusedSelTables)));
+            SH_HIP(hipMemcpy(dst.d_fsel_tables.p, &FS, sizeof(WtFusedSelTables), hipMemcpyHostToDevice));
         }
     }
     SH_HIP(hipStreamSynchronize(0));
@@ -1174,6 +1277,46 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
                 std::chrono::duration<double, std::milli>(t2 - t1).count());
     }
     return SDSL_HIP_OK;
+}
+
+sdsl_hip_status wt_build_fused(WtHost & wt)
+{
+    const char * env = getenv("SDSL_HIP_WT_FUSED");
+    if (env && atoi(env) == 0)
+        return SDSL_HIP_OK;
+    if (wt.backend != 0 || wt.sigma < 2 || wt.n_nodes < 3 || wt.size == 0 || wt.size >= (UINT64_C(1) << 32) ||
+        !wt.d_tables.p)
+        return SDSL_HIP_OK;
+    // The fused layout serves rank / access / select, whose answers do not depend on the tree's shape, so it gets the
+    // shape that suits it: an 8-ary Huffman tree (fewest fused steps per symbol) instead of SDSL's binary tree cut
+    // into groups of three levels.  The symbols are read back from the binary levels, a throw-away binary tree of the
+    // new shape is built from them, and the fused layout is derived from that.  SDSL_HIP_WT_FUSED_SHAPE=binary keeps
+    // the derived-from-SDSL's-tree form (also the fallback).
+    const char * shape_env = getenv("SDSL_HIP_WT_FUSED_SHAPE");
+    if (!(shape_env && shape_env[0] == 'b'))
+    {
+        SH_HIP(hipSetDevice(wt.device));
+        DevBuf d_sym;
+        SH_TRY(d_sym.alloc(wt.size));
+        hipLaunchKernelGGL(k_wt_export_symbols, dim3(grid_for(wt.size, kQPB, 256u * 16u)), dim3(kBlock), 0, 0,
+                           wt.view_binary(), d_sym.as<uint8_t>(), wt.size);
+        SH_HIP(hipGetLastError());
+        WtHost own;
+        sdsl_hip_status st = wt_build_from_device_text(own, d_sym.as<uint8_t>(), wt.size, wt.device, kWtShapeHuff8 | kWtNoSelect);
+        if (st == SDSL_HIP_OK)
+            st = fused_from(own, wt);
+        if (st == SDSL_HIP_OK && wt.d_fused.p)
+        {
+            wt.d_tables_f = std::move(own.d_tables);
+            wt.tables_f = own.tables;
+            return SDSL_HIP_OK;
+        }
+        wt.d_fused.release();
+        wt.d_ftables.release();
+        wt.d_fsel.release();
+        wt.d_fsel_tables.release();
+    }
+    return fused_from(wt, wt);
 }
 
 static unsigned wt_grid(uint64_t n)
@@ -1393,6 +1536,16 @@ uint64_t sdsl_hip_wt_device_bytes(sdsl_hip_wt_t wt)
     return wt ? wt->h.device_bytes() : 0;
 }
 
+sdsl_hip_status sdsl_hip_wt_fused_steps(sdsl_hip_wt_t wt, uint8_t steps_out[256])
+{
+    if (!wt || !steps_out)
+        return SDSL_HIP_ERR_INVALID;
+    const WtTables & T = wt->h.d_tables_f.p ? wt->h.tables_f : wt->h.tables;
+    for (int c = 0; c < 256; ++c)
+        steps_out[c] = !wt->h.d_fused.p || T.c_to_leaf[c] == kWtUndef ? 0 : (uint8_t)(((T.path[c] >> 56) + 2) / 3);
+    return SDSL_HIP_OK;
+}
+
 sdsl_hip_status sdsl_hip_wt_code_lengths(sdsl_hip_wt_t wt, uint8_t len_out[256])
 {
     if (!wt || !len_out)
@@ -1499,10 +1652,10 @@ sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, c
             hipLaunchKernelGGL((k_wt_select_fused<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, view,
                                wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev, (const uint8_t *)sc.dev,
                                (uint64_t *)so.dev, n);
-        else
-            hipLaunchKernelGGL((k_wt_select<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, view,
-                               wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev, (const uint8_t *)sc.dev,
-                               (uint64_t *)so.dev, n);
+        else // SDSL's tree and its binary levels
+            hipLaunchKernelGGL((k_wt_select<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s,
+                               wt->h.view_binary(), wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev,
+                               (const uint8_t *)sc.dev, (uint64_t *)so.dev, n);
     }
     SH_HIP(hipGetLastError());
     SH_TRY(so.finish(s));

@@ -18,10 +18,26 @@ struct WtHost
     DevBuf d_tables;    // WtTables image in HBM
     DevBuf d_fused;     // the fused (8-ary) layout used by the rank-type traversals (wt_device.hpp), optional
     DevBuf d_ftables;   // its node tables (WtFusedTables)
+    DevBuf d_tables_f;  // node table of the fused layout's OWN tree shape (8-ary Huffman written as a binary tree); empty
+                        // when the fused layout was derived from the SDSL-shaped tree itself
+    WtTables tables_f;  // host copy of it
     DevBuf d_fsel, d_fsel_tables; // its select directory (wt_device.hpp: WtFusedSelTables), optional
     WtTables tables;    // host copy (code lengths, alphabet queries)
     uint64_t occ[256];  // occurrences of every byte (== wt.rank(size(), c))
+    // what the query kernels see: with a fused layout, the node table of the tree the fused layout was built from
     WtView view() const
+    {
+        WtView v = view_binary();
+        v.f_lines = d_fused.as<uint64_t>();
+        v.f_tables = d_ftables.as<WtFusedTables>();
+        v.f_sel = d_fsel.as<uint32_t>();
+        v.f_sel_tables = d_fsel_tables.as<WtFusedSelTables>();
+        if (v.f_lines && d_tables_f.p)
+            v.tables = d_tables_f.as<WtTables>();
+        return v;
+    }
+    // SDSL's tree only (binary levels): construction passes, select without the fused directory
+    WtView view_binary() const
     {
         WtView v;
         v.bv = bv.view;
@@ -31,22 +47,24 @@ struct WtHost
         v.size = size;
         v.sigma = sigma;
         v.n_nodes = n_nodes;
-        v.f_lines = d_fused.as<uint64_t>();
-        v.f_tables = d_ftables.as<WtFusedTables>();
-        v.f_sel = d_fsel.as<uint32_t>();
-        v.f_sel_tables = d_fsel_tables.as<WtFusedSelTables>();
+        v.f_lines = nullptr;
+        v.f_tables = nullptr;
+        v.f_sel = nullptr;
+        v.f_sel_tables = nullptr;
         return v;
     }
     size_t device_bytes() const
     {
-        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes + d_ftables.bytes + d_fsel.bytes + d_fsel_tables.bytes;
+        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes + d_ftables.bytes + d_fsel.bytes + d_fsel_tables.bytes + d_tables_f.bytes;
     }
 };
 
 // Builds the tree shape on the host (a 256-entry histogram decides it) and the bit vector on the device, one
 // stable radix sort per tree level, from a symbol sequence that already lives in device memory.
 // flags: SDSL_HIP_WT_RRR63 (bit vector as rrr_vector<63> instead of rank lines + select directories),
-// SDSL_HIP_WT_BLCD (balanced shape instead of Huffman)
+// SDSL_HIP_WT_BLCD (balanced shape instead of Huffman); internal: kWtShapeHuff8, kWtNoSelect
+constexpr uint32_t kWtShapeHuff8 = 0x100u; // 8-ary Huffman tree written as a binary tree (the fused layout's own shape)
+constexpr uint32_t kWtNoSelect = 0x200u;   // no select directories on the bit vector
 sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t flags = 0);
 // Parses wt_pc::serialize output (wt_pc.hpp:713-726) and uploads; advances the reader.
 // layout: 0 = plain bv + select_support_scan (zero bytes), 1 = plain bv + select_support_mcl, 2 = rrr_vector<63> with

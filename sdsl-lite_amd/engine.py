@@ -403,6 +403,12 @@ class wt_huff(_Handle):
         capi.check(capi.lib().sdsl_hip_wt_code_lengths(self._h, _ptr(out)))
         return out
 
+    def fused_steps(self) -> np.ndarray:
+        """line fetches a rank / access / select of each symbol costs on the fused layout (zeros without one)"""
+        out = np.zeros(256, dtype=np.uint8)
+        capi.check(capi.lib().sdsl_hip_wt_fused_steps(self._h, _ptr(out)))
+        return out
+
     def rank(self, i, c, out=None):
         i = _as_array(i, np.uint64, "i")
         c = _as_array(c, np.uint8, "c")

@@ -24,11 +24,14 @@ def _text(name):
     return gd.text("faust.txt") if name == "faust" else TEXTS[name]
 
 
-@pytest.mark.parametrize("fused", ["1", "0", "no_select_directory"])
+@pytest.mark.parametrize("fused", ["1", "derived_shape", "0", "no_select_directory"])
 @pytest.mark.parametrize("name", list(TEXTS))
 def test_wavelet_tree_queries_on_both_layouts(gpu, monkeypatch, name, fused):
+    """"1": fused layout with its own 8-ary Huffman shape (the default); "derived_shape": fused layout cut out of SDSL's
+    binary tree; "0": binary levels only; "no_select_directory": fused layout, select on the binary levels"""
     monkeypatch.setenv("SDSL_HIP_WT_FUSED", "0" if fused == "0" else "1")
     monkeypatch.setenv("SDSL_HIP_WT_FUSED_SELECT", "0" if fused == "no_select_directory" else "1")
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED_SHAPE", "binary" if fused == "derived_shape" else "own")
     text = _text(name)
     wt = gpu.wt_huff(text=text)
     o = ol.OWt(text)
@@ -62,10 +65,11 @@ def test_wavelet_tree_queries_on_both_layouts(gpu, monkeypatch, name, fused):
     assert np.all(wt.select(cnt[present].astype(np.uint64) + np.uint64(1), present) == np.uint64(2**64 - 1))
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("fused", ["1", "derived_shape", "0"])
 @pytest.mark.parametrize("kw", [{}, {"balanced": True}, {"hutu": True}])
 def test_fm_index_queries_on_both_layouts(gpu, monkeypatch, kw, fused):
-    monkeypatch.setenv("SDSL_HIP_WT_FUSED", fused)
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED", "0" if fused == "0" else "1")
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED_SHAPE", "binary" if fused == "derived_shape" else "own")
     text = gd.text("faust.txt")
     csa = gpu.csa_wt(text=text, **kw)
     o = ol.OCsa(text)
@@ -96,6 +100,15 @@ def test_the_knob_decides_what_is_resident(gpu, monkeypatch):
     monkeypatch.delenv("SDSL_HIP_WT_FUSED")
     default = gpu.wt_huff(text=text).device_bytes()
     assert both > plain and default == both
+    wt = gpu.wt_huff(text=text)
+    steps, lens = wt.fused_steps(), wt.code_lengths()
+    assert np.all((steps > 0) == (lens > 0)) and np.all(steps[lens > 0] <= (lens[lens > 0] + 2) // 3 + 1)
+    cnt = np.bincount(np.frombuffer(text, dtype=np.uint8), minlength=256)
+    # the layout's own shape is an 8-ary Huffman tree: never more expected steps than SDSL's tree cut in threes
+    assert (cnt * steps).sum() <= (cnt * ((lens.astype(np.int64) + 2) // 3)).sum()
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED", "0")
+    assert not gpu.wt_huff(text=text).fused_steps().any()
+    monkeypatch.setenv("SDSL_HIP_WT_FUSED", "1")
     # the compressed flavour has no fused layout
     with_knob = gpu.wt_huff(text=text, rrr=True).device_bytes()
     monkeypatch.setenv("SDSL_HIP_WT_FUSED", "0")
