@@ -1297,12 +1297,14 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
     {
         SH_HIP(hipSetDevice(wt.device));
         DevBuf d_sym;
-        SH_TRY(d_sym.alloc(wt.size));
-        hipLaunchKernelGGL(k_wt_export_symbols, dim3(grid_for(wt.size, kQPB, 256u * 16u)), dim3(kBlock), 0, 0,
-                           wt.view_binary(), d_sym.as<uint8_t>(), wt.size);
-        SH_HIP(hipGetLastError());
         WtHost own;
-        sdsl_hip_status st = wt_build_from_device_text(own, d_sym.as<uint8_t>(), wt.size, wt.device, kWtShapeHuff8 | kWtNoSelect);
+        sdsl_hip_status st = d_sym.alloc(wt.size);
+        if (st == SDSL_HIP_OK)
+        {
+            hipLaunchKernelGGL(k_wt_export_symbols, dim3(grid_for(wt.size, kQPB, 256u * 16u)), dim3(kBlock), 0, 0,
+                               wt.view_binary(), d_sym.as<uint8_t>(), wt.size);
+            st = wt_build_from_device_text(own, d_sym.as<uint8_t>(), wt.size, wt.device, kWtShapeHuff8 | kWtNoSelect);
+        }
         if (st == SDSL_HIP_OK)
             st = fused_from(own, wt);
         if (st == SDSL_HIP_OK && wt.d_fused.p)
@@ -1316,7 +1318,18 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         wt.d_fsel.release();
         wt.d_fsel_tables.release();
     }
-    return fused_from(wt, wt);
+    // the fused layout is an accelerator: if it cannot be built (memory), the handle works on its binary levels
+    if (fused_from(wt, wt) != SDSL_HIP_OK)
+    {
+        if (getenv("SDSL_HIP_TRACE_BUILD"))
+            fprintf(stderr, "[sdsl_hip] fused layout not built: %s\n", last_error_message());
+        wt.d_fused.release();
+        wt.d_ftables.release();
+        wt.d_fsel.release();
+        wt.d_fsel_tables.release();
+        (void)hipGetLastError();
+    }
+    return SDSL_HIP_OK;
 }
 
 static unsigned wt_grid(uint64_t n)
