@@ -252,6 +252,11 @@ def main():
         kernel_ms = pkg.dist.max_over_ranks(kernel_ms, comm_dev)
     value = nq * world * a.steps / wall / 1e9
     achieved = ALG_BYTES["rank"] * nq / (kernel_ms * 1e-3) / 1e9
+    # the same access pattern with the arithmetic removed, on the same table and positions: what the memory system
+    # allows a batched rank to reach on this GPU in this run
+    probe_out = torch.empty_like(idx)
+    _, probe_ms = time_steps(lambda: bv.gather_probe(idx, probe_out), max(2, a.steps // 2), 1, barrier)
+    del probe_out
     result = {
         "metric": "Grank/s, batched rank_1 on a 2^%d-bit vector" % a.log_n, "value": value, "unit": "Grank/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3,
@@ -264,7 +269,11 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_rank_bytes_per_launch"),
                      "kernel": "sdslhip::k_rank<4,false,true>", "kernel_ms": kernel_ms,
-                     "algorithmic_bytes_per_query": ALG_BYTES["rank"]},
+                     "algorithmic_bytes_per_query": ALG_BYTES["rank"],
+                     "access_skeleton": {"what": "read a position, fetch its 64-byte rank line, write a word: k_rank without "
+                                                 "its arithmetic, same table, same positions, same run",
+                                         "kernel_ms": probe_ms, "Gq/s": nq / probe_ms / 1e6,
+                                         "rank_kernel_over_skeleton": probe_ms / kernel_ms}},
     }
 
     if rank == 0 and world == 1 and not a.no_cpu:

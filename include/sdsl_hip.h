@@ -122,6 +122,11 @@ uint64_t sdsl_hip_bv_device_bytes(sdsl_hip_bv_t bv); /* HBM footprint of the dev
 /* out[q] = number of `bit`-bits in [0, idx[q]), idx[q] in [0, size()] */
 sdsl_hip_status sdsl_hip_bv_rank_batch(sdsl_hip_bv_t bv, int32_t bit, const uint64_t * idx, uint64_t n,
                                        uint64_t * out, void * stream);
+/* Measurement aid, not a query: the memory-access skeleton of sdsl_hip_bv_rank_batch with the arithmetic removed (for
+ * every position: fetch its 64-byte rank line, write one word).  Device arrays only.  Its rate on a given vector is the
+ * ceiling the memory system sets for batched rank there; bench.py reports it next to the real kernel's rate. */
+sdsl_hip_status sdsl_hip_bv_gather_probe(sdsl_hip_bv_t bv, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
+                                         void * stream);
 /* out[q] = position of the i[q]-th `bit`-bit, i[q] in [1, #bit-bits] (1-based like SDSL) */
 sdsl_hip_status sdsl_hip_bv_select_batch(sdsl_hip_bv_t bv, int32_t bit, const uint64_t * i, uint64_t n,
                                          uint64_t * out, void * stream);

@@ -44,6 +44,7 @@ SIGNATURES = {
     "sdsl_hip_bv_ones": (C.c_uint64, [_vp]),
     "sdsl_hip_bv_device_bytes": (C.c_uint64, [_vp]),
     "sdsl_hip_bv_rank_batch": (C.c_int32, [_vp, C.c_int32, _vp, C.c_uint64, _vp, _vp]),
+    "sdsl_hip_bv_gather_probe": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_bv_select_batch": (C.c_int32, [_vp, C.c_int32, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_bv_access_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_bv_export_words": (C.c_int32, [_vp, _vp, _vp]),

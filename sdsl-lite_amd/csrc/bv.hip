@@ -362,6 +362,41 @@ struct RetryEntry
     uint32_t tries, pad;
 };
 
+// The access skeleton of k_rank with the arithmetic taken out: streamed position -> the quad fetches the 64-byte rank
+// line of that position -> one streamed word back.  What this kernel reaches on a given table is what the memory system
+// allows a batched rank to reach (sdsl_hip_bv_gather_probe; bench.py times it next to the real kernel).
+template <int U>
+__global__ __launch_bounds__(kBlock) void k_rank_access_skeleton(BvView bv, const uint64_t * __restrict__ idx,
+                                                                 uint64_t * __restrict__ out, uint64_t n)
+{
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    const uint64_t stride = (uint64_t)gridDim.x * kQPB * U;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB * U; base < n; base += stride)
+    {
+        uint64_t L[U];
+        Pair w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            const uint64_t q = base + (uint64_t)u * kQPB + gq;
+            const uint64_t id = q < n ? __builtin_nontemporal_load(idx + q) : 0;
+            L[u] = id <= bv.n_bits ? id / kDB : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            w[u] = load_pair<false>(bv.lines, L[u], s);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            const uint64_t q = base + (uint64_t)u * kQPB + gq;
+            const unsigned x = quad_sum((unsigned)(w[u].a ^ w[u].b)); // every lane's 16 bytes are consumed
+            if (s == 0 && q < n)
+                __builtin_nontemporal_store((uint64_t)x, out + q);
+        }
+    }
+}
+
 template <int BIT, bool NT, bool IO_NT = false>
 __global__ __launch_bounds__(kBlock) void k_select_rq(BvView bv, const uint64_t * __restrict__ iq,
                                                       uint64_t * __restrict__ out, uint64_t n)
@@ -857,6 +892,25 @@ sdsl_hip_status sdsl_hip_bv_rank_batch(sdsl_hip_bv_t bv, int32_t bit, const uint
     SH_TRY(o.finish(s));
     if (in.host && !o.host)
         SH_HIP(hipStreamSynchronize(s)); // staging buffer must outlive the kernel
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_bv_gather_probe(sdsl_hip_bv_t bv, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
+                                         void * stream)
+{
+    if (!bv || (n && (!d_idx || !d_out)) || (n && (!is_device_ptr(d_idx) || !is_device_ptr(d_out))))
+    {
+        set_error("bv_gather_probe: needs a handle and device arrays");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(bv->h.device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    KernelTimer t(s);
+    hipLaunchKernelGGL((k_rank_access_skeleton<4>), dim3(query_grid(n, kQPB * 4)), dim3(kBlock), 0, s, bv->h.view, d_idx,
+                       d_out, n);
+    SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }
 

@@ -117,6 +117,12 @@ class bit_vector(_Handle):
         capi.check(capi.lib().sdsl_hip_bv_rank_batch(self._h, bit, _ptr(idx), n, _ptr(out), _stream_for(idx)))
         return out
 
+    def gather_probe(self, idx, out):
+        """measurement aid: the memory-access skeleton of rank() without its arithmetic (device tensors only)"""
+        idx = _as_array(idx, np.uint64, "idx")
+        capi.check(capi.lib().sdsl_hip_bv_gather_probe(self._h, _ptr(idx), idx.numel(), _ptr(out), _stream_for(idx)))
+        return out
+
     def select(self, i, bit: int = 1, out=None):
         i = _as_array(i, np.uint64, "i")
         n = i.numel() if _is_tensor(i) else i.size
