@@ -728,13 +728,13 @@ __global__ __launch_bounds__(kBlock) void k_wt_rank(WtView wt, const uint64_t * 
         uint64_t q = base + gq;
         if (q >= n)
             continue;
-        uint64_t i = iq[q];
-        unsigned c = cq[q];
+        uint64_t i = __builtin_nontemporal_load(iq + q); // streamed once: keep the caches for the tree
+        unsigned c = __builtin_nontemporal_load(cq + q);
         uint64_t r = SDSL_HIP_NPOS;
         if (i <= wt.size)
             r = wt.f_lines ? quad_wt8_rank<NT>(wt, &T, &FT, s, i, c) : quad_wt_rank<NT>(wt, &T, s, i, c);
         if (s == 0)
-            out[q] = r;
+            __builtin_nontemporal_store(r, out + q);
     }
 }
 
@@ -755,16 +755,16 @@ __global__ __launch_bounds__(kBlock) void k_wt_inverse_select(WtView wt, const u
         uint64_t q = base + gq;
         if (q >= n)
             continue;
-        uint64_t i = iq[q];
+        uint64_t i = __builtin_nontemporal_load(iq + q);
         unsigned c = 0xFF;
         uint64_t r = SDSL_HIP_NPOS;
         if (i < wt.size)
             r = quad_wt_inverse_select<NT>(wt, &T, &FT, s, i, c);
         if (s == 0)
         {
-            out_c[q] = (uint8_t)c;
+            __builtin_nontemporal_store((uint8_t)c, out_c + q);
             if (WITH_RANK)
-                out_rank[q] = r;
+                __builtin_nontemporal_store(r, out_rank + q);
         }
     }
 }
