@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_sd_rank(SdView v, int bit, const uin
         const uint64_t q = base + gq;
         if (q >= n)
             continue;
-        const uint64_t x = xq[q];
+        const uint64_t x = __builtin_nontemporal_load(xq + q);
         if (MODE == 1)
         {
             bool hit = false;
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kBlock) void k_sd_rank(SdView v, int bit, const uin
                 r = bit ? r1 : x - r1;
             }
             if (s == 0)
-                out[q] = r;
+                __builtin_nontemporal_store(r, out + q);
         }
     }
 }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_sd_select(SdView v, const uint64_t *
         const uint64_t q = base + gq;
         if (q >= n)
             continue;
-        const uint64_t i = iq[q];
+        const uint64_t i = __builtin_nontemporal_load(iq + q);
         uint64_t r = SDSL_HIP_NPOS; // outside SDSL's precondition (sd_vector.hpp:639)
         if (i >= 1 && i <= total)
         {
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_sd_select(SdView v, const uint64_t *
                 r = quad_sd_select0<false>(v, s, i);
         }
         if (s == 0)
-            out[q] = r;
+            __builtin_nontemporal_store(r, out + q);
     }
 }
 
