@@ -888,7 +888,14 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_fused(WtView wt, const uin
                                                             const uint8_t * __restrict__ cq, uint64_t * __restrict__ out,
                                                             uint64_t n)
 {
-    __shared__ WtTables T;
+    // only the parts of the node table this walk reads (parent links, paths, leaves): 3.5 KiB instead of 13.5 — LDS is
+    // what decides how many waves a CU holds here
+    __shared__ struct
+    {
+        uint64_t path[256];
+        uint16_t parent[kWtMaxNodes];
+        uint16_t c_to_leaf[256];
+    } T;
     __shared__ WtFusedTables FT;
     __shared__ WtFusedSelTables FS;
     __shared__ uint64_t occ_s[256];
@@ -898,9 +905,15 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_fused(WtView wt, const uin
         uint64_t * dst = reinterpret_cast<uint64_t *>(&FS);
         for (unsigned i = threadIdx.x; i < sizeof(WtFusedSelTables) / 8; i += blockDim.x)
             dst[i] = src[i];
+        for (unsigned i = threadIdx.x; i < 256; i += blockDim.x)
+        {
+            T.path[i] = wt.tables->path[i];
+            T.c_to_leaf[i] = wt.tables->c_to_leaf[i];
+        }
+        for (unsigned i = threadIdx.x; i < kWtMaxNodes; i += blockDim.x)
+            T.parent[i] = wt.tables->parent[i];
     }
-    wt_stage_fused(&FT, wt);
-    wt_stage_tables(&T, wt.tables); // ends with __syncthreads()
+    wt_stage_fused(&FT, wt); // ends with __syncthreads()
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
     const uint64_t stride = (uint64_t)gridDim.x * kQPB;
