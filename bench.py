@@ -479,13 +479,13 @@ def main():
                 ex["fm_locate_whole_sa"] = {"Gocc/s": pos.numel() / ms / 1e6, "ms": ms, "patterns": npat,
                                             "occurrences": pos.numel()}
                 del off, pos
-                sidx = torch.randint(0, nt + 1, (2_000_000,), device=dev, dtype=torch.int64, generator=gq)
+                sidx = torch.randint(0, nt + 1, (20_000_000,), device=dev, dtype=torch.int64, generator=gq)
                 want = csa.sa(sidx)
                 csa.drop_sa()
                 _, ms = time_steps(lambda: csa.sa(sidx), 2, 1, barrier)
                 assert torch.equal(csa.sa(sidx), want), "sampled SA walk != whole SA"
                 ex["fm_sa_access_dens32"] = {"Msa/s": sidx.numel() / ms / 1e3, "ms": ms, "queries": sidx.numel()}
-                eb = torch.randint(0, nt - 64, (1_000_000,), device=dev, dtype=torch.int64, generator=gq)
+                eb = torch.randint(0, nt - 64, (10_000_000,), device=dev, dtype=torch.int64, generator=gq)
                 ee = eb + 63
                 eoff, etxt = csa.extract(eb, ee)
                 assert torch.equal(etxt.view(-1, 64)[:4096],
