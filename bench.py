@@ -412,11 +412,24 @@ def main():
             ex["text"] = {"bytes": nt, "kind": "synthetic English-like stand-in (Zipf over a 4096-word vocabulary)",
                           "sigma": csa.sigma(), "index_build_s": build, "mean_code_length_of_queried_symbols": hbar,
                           "wt_bits": wt.bv_size(), "index_bytes": csa.device_bytes()}
-            ocsa = None
+            ocsa = rcsa = None
             if rank == 0 and world == 1 and not a.no_cpu:
+                import oracle_lib as ol
+            if rank == 0 and world == 1 and not a.no_cpu and ol.have_ref():
+                # CPU side, kind "reference": the index built on the GPU is written out as the bytes of
+                # csa_wt<wt_huff<bit_vector, rank_support_v5<>>> (32 / 64) and LOADED BY THE REAL sdsl-lite — the unmodified
+                # library then answers the same queries on it (a round trip of the whole index on every run)
+                t0 = time.perf_counter()
+                blob = csa.serialize(32, 64, pkg.capi.LAYOUT_BV_MCL)
+                t1 = time.perf_counter()
+                rcsa = ol.RCsa(sdsl_bytes=blob)
+                ex["text"]["sdsl_stream_bytes"] = len(blob)
+                ex["text"]["gpu_serialize_s"] = t1 - t0
+                ex["text"]["sdsl_load_s"] = time.perf_counter() - t1
+                del blob
+            elif rank == 0 and world == 1 and not a.no_cpu:
                 # CPU side: the C restatement of wt_huff / backward_search (kind "port") over the SAME BWT, which is
                 # reconstructed from the device index with wt[i] (access) so that no CPU suffix sorting is needed
-                import oracle_lib as ol
                 t0 = time.perf_counter()
                 bwt = torch.empty(nt + 1, dtype=torch.uint8, device=dev)
                 for s0 in range(0, nt + 1, 1 << 27):
@@ -435,7 +448,13 @@ def main():
                                       "fused_steps_per_query": steps,
                                       "line_fetch_frac": (17 + 128 * steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "note": FUSED_NOTE}
-                if ocsa is not None:
+                if rcsa is not None:
+                    cb = cpu_time(lambda i, c: rcsa.wt_rank(np.ascontiguousarray(i).view(np.uint64), c), [gi, gc], out2,
+                                  a.cpu_seconds, 1e9, "(i,c) pairs, csa.wavelet_tree.rank of the real sdsl-lite on the "
+                                  "index the GPU built and serialised")
+                    cb.update(unit="Grank/s", kind="reference")
+                    ex["wt_huff_rank"]["cpu_baseline"] = cb
+                elif ocsa is not None:
                     owt = ocsa.wt()
                     cb = cpu_time(lambda i, c: owt.rank(np.ascontiguousarray(i).view(np.uint64), c), [gi, gc], out2,
                                   a.cpu_seconds, 1e9, "(i,c) pairs, wt_huff<bit_vector,rank_support_v5<>>::rank")
@@ -465,7 +484,13 @@ def main():
                                   "algorithmic_bytes_per_pattern": alg,
                                   "line_fetch_frac": (28 + 256 * sum_steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "jump_depth": csa.jump_depth(), "note": FUSED_NOTE}
-                if ocsa is not None:
+                if rcsa is not None:
+                    cb = cpu_time(lambda p: rcsa.count_batch(p.reshape(-1), m), [pats.view(-1, m)], out2, a.cpu_seconds,
+                                  1e6, "20-byte patterns, sdsl::count of the real sdsl-lite on the index the GPU built "
+                                  "and serialised")
+                    cb.update(unit="Mcount/s", kind="reference")
+                    ex["fm_count"]["cpu_baseline"] = cb
+                elif ocsa is not None:
                     cb = cpu_time(lambda p: ocsa.count_batch(p.reshape(-1), m), [pats.view(-1, m)], out2, a.cpu_seconds,
                                   1e6, "20-byte patterns, count(csa_wt<wt_huff<>>)")
                     cb.update(unit="Mcount/s", kind="port")

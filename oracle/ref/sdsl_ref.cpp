@@ -12,7 +12,9 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <istream>
 #include <sstream>
+#include <streambuf>
 #include <string>
 #include <vector>
 
@@ -284,6 +286,36 @@ void * ref_csa_create(const uint8_t * text, uint64_t n, int also_fm_huff)
     }
     catch (std::exception const &)
     { // e.g. construct.hpp:41 "contains zero symbol"
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+// csa_wt<wt_huff<bit_vector, rank_support_v5<>>> (32 / 64) from its serialised bytes — SDSL's own, or the ones the GPU
+// engine writes for an index it built: the unmodified library then answers on it (bench.py times it as the CPU baseline)
+void * ref_csa_load(const uint8_t * bytes, uint64_t len)
+{
+    struct membuf : std::streambuf
+    {
+        membuf(char * b, char * e)
+        {
+            setg(b, b, e);
+        }
+    };
+    RefCsa * h = new RefCsa();
+    try
+    {
+        membuf mb((char *)bytes, (char *)bytes + len);
+        std::istream is(&mb);
+        h->csa.load(is);
+        if (!is)
+        {
+            delete h;
+            return nullptr;
+        }
+    }
+    catch (std::exception const &)
+    {
         delete h;
         return nullptr;
     }

@@ -478,6 +478,7 @@ _REF_SIGS = {
     "ref_wt_select": (None, [_vp, _vp, _vp, _u64, _vp]),
     "ref_wt_serialize": (None, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_csa_create": (_vp, [_vp, _u64, C.c_int]),
+    "ref_csa_load": (_vp, [_vp, _u64]),
     "ref_csa_destroy": (None, [_vp]),
     "ref_csa_size": (_u64, [_vp]),
     "ref_csa_sigma": (_u64, [_vp]),
@@ -759,7 +760,15 @@ class RSd:
 
 
 class RCsa:
-    def __init__(self, text: bytes, also_fm_huff=False):
+    def __init__(self, text: bytes | None = None, also_fm_huff=False, sdsl_bytes=None):
+        """from a text (sdsl::construct_im) or from the serialised bytes of csa_wt<wt_huff<bit_vector,
+        rank_support_v5<>>> (sa / isa density 32 / 64), which the real library then loads"""
+        if sdsl_bytes is not None:
+            b = _u8arr(np.frombuffer(sdsl_bytes, dtype=np.uint8) if isinstance(sdsl_bytes, (bytes, bytearray)) else sdsl_bytes)
+            self.h = ref().L.ref_csa_load(_p(b), b.size)
+            if not self.h:
+                raise ValueError("sdsl::csa_wt::load failed")
+            return
         t = _u8arr(np.frombuffer(text, dtype=np.uint8))
         self.h = ref().L.ref_csa_create(_p(t) if t.size else None, t.size, 1 if also_fm_huff else 0)
         if not self.h:
