@@ -78,3 +78,23 @@ def test_wt_and_csa(name):
         st = rng.integers(0, n - m + 1, size=400)
         pats = np.concatenate([arr[s:s + m] for s in st])
         assert np.array_equal(oc.count_batch(pats, m), rc.count_batch(pats, m))
+
+
+def test_reference_loads_a_serialised_csa():
+    """bench.py hands the real library the bytes of an index (there: the one the GPU built) and times its answers;
+    here the bytes are the library's own, and the loaded object must answer like the one that wrote them"""
+    text = gd.text("faust.txt")
+    a = ol.RCsa(text)
+    blob = ol._ref_bytes(ol.ref().L.ref_csa_serialize, a.h, 0)
+    b = ol.RCsa(sdsl_bytes=blob)
+    assert b.size() == a.size() == 226836 and b.count(b"und") == 690
+    arr = np.frombuffer(text, dtype=np.uint8)
+    rng = np.random.default_rng(2)
+    st = rng.integers(0, len(text) - 9, 300)
+    pats = np.concatenate([arr[s:s + 9] for s in st])
+    assert np.array_equal(a.count_batch(pats, 9), b.count_batch(pats, 9))
+    i = rng.integers(0, len(text) + 2, 2000).astype(np.uint64)
+    c = arr[rng.integers(0, len(text), 2000)]
+    assert np.array_equal(a.wt_rank(i, c), b.wt_rank(i, c))
+    with pytest.raises(ValueError):
+        ol.RCsa(sdsl_bytes=blob[: len(blob) // 2])
