@@ -1,6 +1,7 @@
 // common.cpp — error state, device checks, staging buffers, timing hooks, library-level C ABI.
 #include "common.hpp"
 
+#include <atomic>
 #include <cstdarg>
 #include <random>
 
@@ -164,6 +165,12 @@ KernelTimer::~KernelTimer()
         return;
     (void)hipEventRecord(g_ev_stop, s);
     g_ev_valid = true;
+}
+
+uint64_t next_handle_uid()
+{
+    static std::atomic<uint64_t> n{0};
+    return ++n;
 }
 
 } // namespace sdslhip

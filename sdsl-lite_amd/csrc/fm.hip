@@ -582,12 +582,13 @@ sdsl_hip_status sdsl_hip_fm_serialize_ex(sdsl_hip_fm_t fm, int32_t layout, uint3
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
     SH_HIP(hipSetDevice(fm->device));
+    const uint64_t key = ((uint64_t)(uint32_t)layout << 58) ^ ((uint64_t)sa_dens << 29) ^ (uint64_t)isa_dens;
+    sdsl_hip_status cached;
+    if (deliver_cached(fm->uid, key, buf, cap, written, cached))
+        return cached;
     // 1. the wavelet tree in the requested flavour
-    size_t wt_len = 0;
-    SH_TRY(sdsl_hip_wt_serialize_ex(fm->wt, layout, nullptr, 0, &wt_len));
     StreamWriter w;
-    w.bytes.resize(wt_len);
-    SH_TRY(sdsl_hip_wt_serialize_ex(fm->wt, layout, w.bytes.data(), wt_len, &wt_len));
+    SH_TRY(sdsl_hip_wt_serialize_into(fm->wt, layout, w));
     // 2. SA and ISA samples as int_vector<0> of width hi(n)+1
     const uint64_t n = fm->size;
     std::vector<uint64_t> sa_s, isa_s;
@@ -613,7 +614,7 @@ sdsl_hip_status sdsl_hip_fm_serialize_ex(sdsl_hip_fm_t fm, int32_t layout, uint3
     w.int_vector(comp2char, (uint64_t)fm->sigma * 8, 8);
     w.int_vector(fm->tab.C, ((uint64_t)fm->sigma + 1) * 64, 64);
     w.u16((uint16_t)fm->sigma);
-    return deliver(w, buf, cap, written);
+    return deliver_and_cache(fm->uid, key, w, buf, cap, written);
 }
 
 sdsl_hip_status sdsl_hip_fm_destroy(sdsl_hip_fm_t fm)

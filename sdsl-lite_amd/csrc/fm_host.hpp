@@ -9,6 +9,7 @@
 struct sdsl_hip_wt_s;
 sdsl_hip_wt_s * sdsl_hip_wt_alloc();
 sdslhip::WtHost & sdsl_hip_wt_host(sdsl_hip_wt_s * w);
+sdsl_hip_status sdsl_hip_wt_serialize_into(sdsl_hip_wt_s * wt, int32_t layout, sdslhip::StreamWriter & w);
 const uint64_t * sdsl_hip_wt_device_occ(sdsl_hip_wt_s * w);
 sdsl_hip_status sdsl_hip_wt_finish(sdsl_hip_wt_s * w);
 
@@ -18,6 +19,7 @@ struct sdsl_hip_fm_s
     uint64_t size = 0;
     uint32_t sigma = 0;
     sdsl_hip_wt_s * wt = nullptr;
+    uint64_t uid = sdslhip::next_handle_uid(); // key of the serialiser's size-query cache
     sdslhip::FmTables tab;
     sdslhip::DevBuf d_tab;
     sdslhip::DevBuf d_sa; // suffix array (u32 per suffix) of an index created from text; empty otherwise

@@ -193,4 +193,50 @@ inline sdsl_hip_status deliver(const StreamWriter & w, void * buf, size_t cap, s
     return SDSL_HIP_OK;
 }
 
+// The size-query / fill protocol calls a serialiser twice.  Building a large stream twice is wasted work (seconds for a
+// 1 GiB index), so the size query keeps what it built, per thread, and the fill call that follows with the same handle
+// and arguments takes it.  `uid` is unique per handle for the life of the process (no address reuse).
+struct SerCache
+{
+    uint64_t uid = 0, key = 0;
+    std::vector<uint8_t> bytes;
+};
+inline SerCache & ser_cache()
+{
+    static thread_local SerCache c;
+    return c;
+}
+// true if the call was answered from the cache (status in st)
+inline bool deliver_cached(uint64_t uid, uint64_t key, void * buf, size_t cap, size_t * written, sdsl_hip_status & st)
+{
+    SerCache & c = ser_cache();
+    if (!buf || c.uid != uid || c.key != key || c.bytes.empty())
+        return false;
+    if (written)
+        *written = c.bytes.size();
+    if (cap < c.bytes.size())
+    {
+        set_error("serialize: buffer of %zu bytes is too small for %zu", cap, c.bytes.size());
+        st = SDSL_HIP_ERR_INVALID;
+        return true;
+    }
+    memcpy(buf, c.bytes.data(), c.bytes.size());
+    c = SerCache();
+    st = SDSL_HIP_OK;
+    return true;
+}
+inline sdsl_hip_status deliver_and_cache(uint64_t uid, uint64_t key, StreamWriter & w, void * buf, size_t cap, size_t * written)
+{
+    if (buf)
+        return deliver(w, buf, cap, written);
+    if (written)
+        *written = w.bytes.size();
+    SerCache & c = ser_cache();
+    c.uid = uid;
+    c.key = key;
+    c.bytes = std::move(w.bytes);
+    return SDSL_HIP_OK;
+}
+uint64_t next_handle_uid(); // common.cpp
+
 } // namespace sdslhip

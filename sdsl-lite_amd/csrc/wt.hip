@@ -1369,6 +1369,7 @@ struct sdsl_hip_wt_s
 {
     WtHost h;
     DevBuf d_occ;
+    uint64_t uid = next_handle_uid();
 };
 
 // shared with fm.hip
@@ -1459,7 +1460,10 @@ sdsl_hip_status sdsl_hip_wt_serialize(sdsl_hip_wt_t wt, void * buf, size_t cap, 
     return sdsl_hip_wt_serialize_ex(wt, SDSL_HIP_LAYOUT_BV_SCAN, buf, cap, written);
 }
 
-sdsl_hip_status sdsl_hip_wt_serialize_ex(sdsl_hip_wt_t wt, int32_t layout, void * buf, size_t cap, size_t * written)
+} // extern "C"
+
+// appends wt_pc::serialize of the tree in the requested flavour to w (shared with fm.hip)
+sdsl_hip_status sdsl_hip_wt_serialize_into(sdsl_hip_wt_s * wt, int32_t layout, StreamWriter & w)
 {
     if (!wt || (wt->h.backend == 0 && layout != SDSL_HIP_LAYOUT_BV_SCAN && layout != SDSL_HIP_LAYOUT_BV_MCL
                 && layout != SDSL_HIP_LAYOUT_BV_DEFAULT))
@@ -1471,7 +1475,6 @@ sdsl_hip_status sdsl_hip_wt_serialize_ex(sdsl_hip_wt_t wt, int32_t layout, void 
     SH_HIP(hipSetDevice(h.device));
     if (h.backend == 1)
     { // wt_huff<rrr_vector<63>>: size, sigma, the rrr vector, (supports: nothing), tree
-        StreamWriter w;
         w.u64(h.size);
         w.u64(h.sigma);
         SH_TRY(rrr_serialize_host(h.rrr, w));
@@ -1486,7 +1489,7 @@ sdsl_hip_status sdsl_hip_wt_serialize_ex(sdsl_hip_wt_t wt, int32_t layout, void 
         }
         w.raw(h.tables.c_to_leaf, sizeof h.tables.c_to_leaf);
         w.raw(h.tables.path, sizeof h.tables.path);
-        return deliver(w, buf, cap, written);
+        return SDSL_HIP_OK;
     }
     const uint64_t nb = h.bv.view.n_bits, W = (nb + 63) >> 6;
     // the bit vector back in SDSL's word layout
@@ -1498,7 +1501,6 @@ sdsl_hip_status sdsl_hip_wt_serialize_ex(sdsl_hip_wt_t wt, int32_t layout, void 
         SH_TRY(bv_export_words_device(h.bv.view, d.as<uint64_t>(), W, nullptr));
         SH_HIP(hipMemcpy(words.data(), d.p, W * 8, hipMemcpyDeviceToHost));
     }
-    StreamWriter w;
     w.u64(h.size);
     w.u64(h.sigma);
     w.int_vector(words.data(), nb, 1);
@@ -1533,7 +1535,24 @@ sdsl_hip_status sdsl_hip_wt_serialize_ex(sdsl_hip_wt_t wt, int32_t layout, void 
     }
     w.raw(h.tables.c_to_leaf, sizeof h.tables.c_to_leaf);
     w.raw(h.tables.path, sizeof h.tables.path);
-    return deliver(w, buf, cap, written);
+    return SDSL_HIP_OK;
+}
+
+extern "C" {
+
+sdsl_hip_status sdsl_hip_wt_serialize_ex(sdsl_hip_wt_t wt, int32_t layout, void * buf, size_t cap, size_t * written)
+{
+    if (!wt)
+    {
+        set_error("wt_serialize: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    sdsl_hip_status st;
+    if (deliver_cached(wt->uid, (uint64_t)(uint32_t)layout, buf, cap, written, st))
+        return st;
+    StreamWriter w;
+    SH_TRY(sdsl_hip_wt_serialize_into(wt, layout, w));
+    return deliver_and_cache(wt->uid, (uint64_t)(uint32_t)layout, w, buf, cap, written);
 }
 
 sdsl_hip_status sdsl_hip_wt_destroy(sdsl_hip_wt_t wt)
