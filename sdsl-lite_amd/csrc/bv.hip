@@ -738,6 +738,7 @@ using namespace sdslhip;
 struct sdsl_hip_bv_s
 {
     BvHost h;
+    uint64_t uid = next_handle_uid(); // key of the serialiser's size-query cache
 };
 
 extern "C" {
@@ -822,6 +823,9 @@ sdsl_hip_status sdsl_hip_bv_serialize(sdsl_hip_bv_t bv, int32_t what, void * buf
         set_error("bv_serialize: invalid argument");
         return SDSL_HIP_ERR_INVALID;
     }
+    sdsl_hip_status cached;
+    if (deliver_cached(bv->uid, (uint64_t)what, buf, cap, written, cached))
+        return cached;
     SH_HIP(hipSetDevice(bv->h.device));
     const uint64_t n = bv->h.view.n_bits, W = (n + 63) >> 6;
     std::vector<uint64_t> words(W + 1, 0);
@@ -843,7 +847,7 @@ sdsl_hip_status sdsl_hip_bv_serialize(sdsl_hip_bv_t bv, int32_t what, void * buf
     case SDSL_HIP_SER_RANK_V_1: rank_v_serialize_host(words.data(), n, 1, w); break;
     default: rank_v_serialize_host(words.data(), n, 0, w); break;
     }
-    return deliver(w, buf, cap, written);
+    return deliver_and_cache(bv->uid, (uint64_t)what, w, buf, cap, written);
 }
 
 sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv)

@@ -759,6 +759,7 @@ using namespace sdslhip;
 struct sdsl_hip_rrr_s
 {
     RrrHost h;
+    uint64_t uid = next_handle_uid(); // key of the serialiser's size-query cache
 };
 
 extern "C" {
@@ -820,9 +821,12 @@ sdsl_hip_status sdsl_hip_rrr_serialize(sdsl_hip_rrr_t v, void * buf, size_t cap,
         set_error("rrr_serialize: null handle");
         return SDSL_HIP_ERR_INVALID;
     }
+    sdsl_hip_status cached;
+    if (deliver_cached(v->uid, 0, buf, cap, written, cached))
+        return cached;
     StreamWriter w;
     SH_TRY(rrr_serialize_host(v->h, w));
-    return deliver(w, buf, cap, written);
+    return deliver_and_cache(v->uid, 0, w, buf, cap, written);
 }
 
 sdsl_hip_status sdsl_hip_rrr_destroy(sdsl_hip_rrr_t v)

@@ -391,6 +391,7 @@ using namespace sdslhip;
 struct sdsl_hip_sd_s
 {
     SdHost h;
+    uint64_t uid = next_handle_uid(); // key of the serialiser's size-query cache
 };
 
 extern "C" {
@@ -492,6 +493,9 @@ sdsl_hip_status sdsl_hip_sd_serialize(sdsl_hip_sd_t v, void * buf, size_t cap, s
         set_error("sd_serialize: null handle");
         return SDSL_HIP_ERR_INVALID;
     }
+    sdsl_hip_status cached;
+    if (deliver_cached(v->uid, 0, buf, cap, written, cached))
+        return cached;
     SH_HIP(hipSetDevice(v->h.device));
     const SdView & sv = v->h.view;
     const uint64_t hb = sv.high.n_bits, HW = (hb + 63) >> 6, LW = (sv.m * sv.wl + 63) >> 6;
@@ -513,7 +517,7 @@ sdsl_hip_status sdsl_hip_sd_serialize(sdsl_hip_sd_t v, void * buf, size_t cap, s
     w.int_vector(high.data(), hb, 1);
     select_mcl_serialize_host(high.data(), hb, 1, w);
     select_mcl_serialize_host(high.data(), hb, 0, w);
-    return deliver(w, buf, cap, written);
+    return deliver_and_cache(v->uid, 0, w, buf, cap, written);
 }
 
 sdsl_hip_status sdsl_hip_sd_destroy(sdsl_hip_sd_t v)
