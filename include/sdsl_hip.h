@@ -25,6 +25,9 @@
  *    several host threads (the error text of sdsl_hip_last_error() is per thread).  Calls that change a handle —
  *    *_destroy, sdsl_hip_fm_drop_sa, sdsl_hip_fm_set_jump_depth, and the first ISA / extract call on an index that
  *    still holds its whole suffix array (it materialises the ISA samples) — must not overlap other calls on that handle;
+ *  - serialisers follow a size-query / fill protocol (buf == NULL returns the size in *written): the size query keeps
+ *    the stream it built, per calling thread, and the fill call that follows with the same handle and arguments takes
+ *    it — the stream of a large index is built once, not twice;
  *  - there is NO CPU fallback: without a usable gfx950 device every create call fails with
  *    SDSL_HIP_ERR_NO_DEVICE.
  */
