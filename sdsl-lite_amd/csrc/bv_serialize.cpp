@@ -7,6 +7,7 @@
 #include "bv_serialize.hpp"
 
 #include <algorithm>
+#include <thread>
 
 namespace sdslhip {
 
@@ -84,47 +85,6 @@ void rank_v_serialize_host(const uint64_t * words, uint64_t n_bits, int bit, Str
 
 namespace {
 
-// the arguments (positions of the b-valued bits below n_bits) in increasing order, one at a time
-struct ArgIter
-{
-    const uint64_t * words;
-    uint64_t n_bits, W, w = 0, cur = 0;
-    int bit;
-    ArgIter(const uint64_t * wd, uint64_t n, int b) : words(wd), n_bits(n), W((n + 63) >> 6), bit(b)
-    {
-        load();
-    }
-    void load()
-    {
-        cur = 0;
-        while (w < W)
-        {
-            uint64_t x = bit ? words[w] : ~words[w];
-            if (w == W - 1 && (n_bits & 63))
-                x &= (UINT64_C(1) << (n_bits & 63)) - 1;
-            if (x)
-            {
-                cur = x;
-                return;
-            }
-            ++w;
-        }
-    }
-    bool next(uint64_t & pos)
-    {
-        if (w >= W)
-            return false;
-        pos = 64 * w + (uint64_t)__builtin_ctzll(cur);
-        cur &= cur - 1;
-        if (!cur)
-        {
-            ++w;
-            load();
-        }
-        return true;
-    }
-};
-
 struct Packed
 {
     std::vector<uint64_t> words;
@@ -158,15 +118,26 @@ void select_mcl_serialize_host(const uint64_t * words, uint64_t n_bits, int bit,
 {
     constexpr uint64_t SB = 4096;
     const uint64_t W = (n_bits + 63) >> 6;
-    uint64_t ones = 0;
-    for (uint64_t w = 0; w < W; ++w)
-    {
-        uint64_t x = words[w];
+    // arguments (bits of value `bit` below n_bits) per chunk of 64 words, as a prefix sum: lets a worker start in the
+    // middle of the vector
+    constexpr uint64_t CH = 64;
+    const uint64_t n_chunks = (W + CH - 1) / CH;
+    std::vector<uint64_t> before(n_chunks + 1, 0);
+    auto arg_word = [&](uint64_t w) -> uint64_t {
+        uint64_t x = bit ? words[w] : ~words[w];
         if (w == W - 1 && (n_bits & 63))
             x &= (UINT64_C(1) << (n_bits & 63)) - 1;
-        ones += (uint64_t)__builtin_popcountll(x);
+        return x;
+    };
+    for (uint64_t c = 0; c < n_chunks; ++c)
+    {
+        uint64_t cnt = 0;
+        const uint64_t e = std::min(W, (c + 1) * CH);
+        for (uint64_t w = c * CH; w < e; ++w)
+            cnt += (uint64_t)__builtin_popcountll(arg_word(w));
+        before[c + 1] = before[c] + cnt;
     }
-    const uint64_t A = bit ? ones : n_bits - ones; // select_support.hpp:132-135,171-174
+    const uint64_t A = before[n_chunks]; // select_support.hpp:132-135,171-174
     out.u64(A);
     if (A == 0)
         return;
@@ -175,65 +146,118 @@ void select_mcl_serialize_host(const uint64_t * words, uint64_t n_bits, int bit,
     const bool slow = n_bits < 100000; // dispatch :121-128
     const uint64_t sb = (A + SB - 1) / SB;
 
+    std::vector<uint8_t> is_mini(sb, 1), has_entry(sb, 0);
+    std::vector<uint64_t> entry(sb, 0);
+    std::vector<Packed> blocks(sb);
+
+    // superblocks [k0, k1): every worker walks its own stretch of the argument sequence
+    auto work = [&](uint64_t k0, uint64_t k1) {
+        // position the iterator on argument number SB * k0
+        const uint64_t target = SB * k0;
+        uint64_t c = (uint64_t)(std::upper_bound(before.begin(), before.end(), target) - before.begin()) - 1;
+        uint64_t skip = target - before[c], w = c * CH, cur = 0;
+        auto load = [&]() {
+            cur = 0;
+            while (w < W && !(cur = arg_word(w)))
+                ++w;
+        };
+        load();
+        auto next = [&](uint64_t & pos) -> bool {
+            if (w >= W)
+                return false;
+            pos = 64 * w + (uint64_t)__builtin_ctzll(cur);
+            cur &= cur - 1;
+            if (!cur)
+            {
+                ++w;
+                load();
+            }
+            return true;
+        };
+        uint64_t pending = 0;
+        bool have_pending = true;
+        for (uint64_t i = 0; i <= skip && have_pending; ++i)
+            have_pending = next(pending); // `pending` = first argument of block k0
+        std::vector<uint64_t> P(SB);
+        for (uint64_t k = k0; k < k1; ++k)
+        {
+            uint64_t cn = 0;
+            while (cn < SB && have_pending)
+            {
+                P[cn++] = pending;
+                have_pending = next(pending);
+            }
+            const uint64_t first = P[0];
+            bool is_long;
+            uint64_t long_width, pos_diff;
+            if (slow)
+            { // init_slow :207-266: decided on the block's own last argument
+                const uint64_t last = P[cn - 1];
+                pos_diff = last - first;
+                is_long = pos_diff > logn4;
+                long_width = hi_bit(last) + 1;
+            }
+            else if (cn > SB - 64)
+            { // init_fast :269-352: the block "completes" with its 4033rd argument; from there the scan runs 64 arguments
+              // further, i.e. onto the first argument of the NEXT block if there is one
+                const uint64_t pos_of_last = (cn == SB && have_pending) ? pending : P[cn - 1];
+                pos_diff = pos_of_last - first;
+                is_long = pos_diff > logn4;
+                long_width = hi_bit(pos_of_last) + 1;
+            }
+            else
+            { // init_fast :354-366: an unfinished last block is always long, as wide as the vector's last position — and
+              // its m_superblock entry is never written (stays 0)
+                pos_diff = 0;
+                is_long = true;
+                long_width = hi_bit(n_bits - 1) + 1;
+            }
+            if (slow || cn > SB - 64)
+            {
+                has_entry[k] = 1;
+                entry[k] = first;
+            }
+            if (is_long)
+            {
+                is_mini[k] = 0;
+                blocks[k].init(SB, (uint8_t)long_width);
+                for (uint64_t j = 0; j < cn; ++j)
+                    blocks[k].set(j, P[j]);
+            }
+            else
+            {
+                blocks[k].init(64, (uint8_t)(hi_bit(pos_diff) + 1));
+                for (uint64_t j = 0; j < cn; j += 64)
+                    blocks[k].set(j / 64, P[j] - first);
+            }
+        }
+    };
+    unsigned n_thr = std::thread::hardware_concurrency();
+    n_thr = n_thr < 1 ? 1 : (n_thr > 32 ? 32 : n_thr);
+    if (sb < 64)
+        n_thr = 1;
+    if (n_thr == 1)
+        work(0, sb);
+    else
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < n_thr; ++t)
+        {
+            const uint64_t k0 = sb * t / n_thr, k1 = sb * (t + 1) / n_thr;
+            if (k0 < k1)
+                th.emplace_back(work, k0, k1);
+        }
+        for (auto & x : th)
+            x.join();
+    }
     Packed superblock;
     superblock.init(sb, (uint8_t)logn);
-    std::vector<uint8_t> is_mini(sb, 1);
-    std::vector<Packed> blocks(sb);
     bool any_long = false;
-
-    ArgIter it(words, n_bits, bit);
-    std::vector<uint64_t> P(SB);
-    uint64_t pending = 0;
-    bool have_pending = it.next(pending); // first argument of the block to come
     for (uint64_t k = 0; k < sb; ++k)
     {
-        uint64_t c = 0;
-        while (c < SB && have_pending)
-        {
-            P[c++] = pending;
-            have_pending = it.next(pending);
-        }
-        const uint64_t first = P[0];
-        bool is_long;
-        uint64_t long_width, pos_diff;
-        if (slow)
-        { // init_slow :207-266: decided on the block's own last argument
-            const uint64_t last = P[c - 1];
-            pos_diff = last - first;
-            is_long = pos_diff > logn4;
-            long_width = hi_bit(last) + 1;
-        }
-        else if (c > SB - 64)
-        { // init_fast :269-352: the block "completes" with its 4033rd argument; from there the scan runs 64 arguments
-          // further, i.e. onto the first argument of the NEXT block if there is one
-            const uint64_t pos_of_last = (c == SB && have_pending) ? pending : P[c - 1];
-            pos_diff = pos_of_last - first;
-            is_long = pos_diff > logn4;
-            long_width = hi_bit(pos_of_last) + 1;
-        }
-        else
-        { // init_fast :354-366: an unfinished last block is always long, as wide as the vector's last position — and
-          // its m_superblock entry is never written (stays 0)
-            pos_diff = 0;
-            is_long = true;
-            long_width = hi_bit(n_bits - 1) + 1;
-        }
-        if (slow || c > SB - 64)
-            superblock.set(k, first);
-        if (is_long)
-        {
-            any_long = true;
-            is_mini[k] = 0;
-            blocks[k].init(SB, (uint8_t)long_width);
-            for (uint64_t j = 0; j < c; ++j)
-                blocks[k].set(j, P[j]);
-        }
-        else
-        {
-            blocks[k].init(64, (uint8_t)(hi_bit(pos_diff) + 1));
-            for (uint64_t j = 0; j < c; j += 64)
-                blocks[k].set(j / 64, P[j] - first);
-        }
+        if (has_entry[k])
+            superblock.set(k, entry[k]);
+        any_long = any_long || !is_mini[k];
     }
     superblock.write(out);
     Packed mol; // mini_or_long: empty unless some block is long (:487-494)

@@ -1076,3 +1076,30 @@ def test_fm_rrr_random_vs_oracle(gpu):
     qi = rng.integers(0, len(t) + 2, size=50_000, dtype=np.uint64)
     qc = rng.integers(0, 256, size=qi.size, dtype=np.uint8)
     assert np.array_equal(csa.wavelet_tree.rank(qi, qc), o.wt().rank(qi, qc))
+
+
+@pytest.mark.parametrize("shape", ["dense", "sparse", "clustered", "one_long_gap"])
+def test_select_mcl_writer_on_many_superblocks(gpu, shape):
+    """the select_support_mcl writer cuts the argument sequence into stretches that worker threads handle on their own
+    (bv_serialize.cpp): thousands of superblocks, long and mini blocks mixed, byte for byte the real library's stream"""
+    if not ol.have_ref():
+        pytest.skip("needs the compiled reference")
+    rng = np.random.default_rng(17)
+    n = (1 << 24) + 777
+    bits = np.zeros(n, dtype=np.uint8)
+    if shape == "dense":
+        bits[rng.random(n) < 0.5] = 1
+    elif shape == "sparse":
+        bits[rng.random(n) < 0.003] = 1
+    elif shape == "clustered":
+        for s in rng.integers(0, n - 70000, 40):
+            bits[s:s + int(rng.integers(1000, 70000))] = rng.random(1) < 0.5 or 1
+        bits[rng.random(n) < 0.0005] = 1
+    else:
+        bits[: 1 << 20] = rng.random(1 << 20) < 0.7
+        bits[-(1 << 20):] = rng.random(1 << 20) < 0.7
+    words = np.packbits(np.concatenate([bits, np.zeros((-n) % 64, np.uint8)]), bitorder="little").view(np.uint64)
+    bv = gpu.bit_vector(words, n)
+    rb = ol.RBitVector(words, n)
+    assert bv.serialize(3) == rb.serialize(3)
+    assert bv.serialize(4) == rb.serialize(4)
