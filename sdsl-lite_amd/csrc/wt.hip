@@ -1306,6 +1306,31 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
     // new shape is built from them, and the fused layout is derived from that.  SDSL_HIP_WT_FUSED_SHAPE=binary keeps
     // the derived-from-SDSL's-tree form (also the fallback).
     const char * shape_env = getenv("SDSL_HIP_WT_FUSED_SHAPE");
+    { // the walk below follows child links until it meets a leaf: only on a proper tree (a loaded stream may be anything)
+        const WtTables & T = wt.tables;
+        std::vector<char> seen(wt.n_nodes, 0);
+        std::vector<uint32_t> stack(1, 0);
+        seen[0] = 1;
+        size_t visited = 0;
+        while (!stack.empty())
+        {
+            const uint32_t v = stack.back();
+            stack.pop_back();
+            ++visited;
+            if (T.child[v][0] == kWtUndef)
+                continue;
+            for (int b = 0; b < 2; ++b)
+            {
+                const uint32_t c = T.child[v][b];
+                if (c >= wt.n_nodes || seen[c])
+                    return SDSL_HIP_OK; // keep the binary layout only
+                seen[c] = 1;
+                stack.push_back(c);
+            }
+        }
+        if (visited != wt.n_nodes)
+            return SDSL_HIP_OK;
+    }
     if (!(shape_env && shape_env[0] == 'b'))
     {
         SH_HIP(hipSetDevice(wt.device));
