@@ -126,13 +126,15 @@ inline int pipeline_streams()
     return v >= 1 && v <= kPipelineMaxStreams ? v : 2;
 }
 
+// n items of in_bytes each in host memory -> n items of out_bytes each in host memory, `chunk` items at a time
 template <class Launch>
-sdsl_hip_status host_pipeline_u64(int device, const uint64_t * h_in, uint64_t * h_out, uint64_t n, Launch launch)
+sdsl_hip_status host_pipeline_bytes(int device, const uint8_t * h_in, size_t in_bytes, uint8_t * h_out, size_t out_bytes,
+                                    uint64_t n, uint64_t chunk, Launch launch)
 {
     std::vector<std::thread> workers;
     sdsl_hip_status status[kPipelineMaxStreams];
     std::string msg[kPipelineMaxStreams];
-    const uint64_t kPipelineChunk = pipeline_chunk();
+    const uint64_t kPipelineChunk = chunk;
     const int kPipelineStreams = pipeline_streams();
     const uint64_t n_chunks = (n + kPipelineChunk - 1) / kPipelineChunk;
     for (int t = 0; t < kPipelineStreams; ++t)
@@ -148,19 +150,19 @@ sdsl_hip_status host_pipeline_u64(int device, const uint64_t * h_in, uint64_t * 
                     hipStream_t st = nullptr;
                     SH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
                     DevBuf d_in, d_out;
-                    sdsl_hip_status r = d_in.alloc(kPipelineChunk * 8);
+                    sdsl_hip_status r = d_in.alloc(kPipelineChunk * in_bytes);
                     if (r == SDSL_HIP_OK)
-                        r = d_out.alloc(kPipelineChunk * 8);
+                        r = d_out.alloc(kPipelineChunk * out_bytes);
                     for (uint64_t c = (uint64_t)t; r == SDSL_HIP_OK && c < n_chunks; c += kPipelineStreams)
                     {
                         const uint64_t lo = c * kPipelineChunk, cnt = std::min(kPipelineChunk, n - lo);
-                        hipError_t e = hipMemcpyAsync(d_in.p, h_in + lo, cnt * 8, hipMemcpyHostToDevice, st);
+                        hipError_t e = hipMemcpyAsync(d_in.p, h_in + lo * in_bytes, cnt * in_bytes, hipMemcpyHostToDevice, st);
                         if (e == hipSuccess)
                         {
-                            r = launch((const uint64_t *)d_in.p, (uint64_t *)d_out.p, cnt, st);
+                            r = launch((const void *)d_in.p, (void *)d_out.p, cnt, st);
                             if (r != SDSL_HIP_OK)
                                 break;
-                            e = hipMemcpyAsync(h_out + lo, d_out.p, cnt * 8, hipMemcpyDeviceToHost, st);
+                            e = hipMemcpyAsync(h_out + lo * out_bytes, d_out.p, cnt * out_bytes, hipMemcpyDeviceToHost, st);
                         }
                         if (e == hipSuccess)
                             e = hipStreamSynchronize(st);
@@ -185,6 +187,14 @@ sdsl_hip_status host_pipeline_u64(int device, const uint64_t * h_in, uint64_t * 
             return status[t];
         }
     return SDSL_HIP_OK;
+}
+
+template <class Launch>
+sdsl_hip_status host_pipeline_u64(int device, const uint64_t * h_in, uint64_t * h_out, uint64_t n, Launch launch)
+{
+    return host_pipeline_bytes(device, (const uint8_t *)h_in, 8, (uint8_t *)h_out, 8, n, pipeline_chunk(),
+                               [&](const void * d_in, void * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
+                               { return launch((const uint64_t *)d_in, (uint64_t *)d_out, cnt, st); });
 }
 
 inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigned max_blocks = 1u << 30)

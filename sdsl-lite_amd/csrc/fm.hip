@@ -809,6 +809,16 @@ sdsl_hip_status sdsl_hip_fm_count_batch(sdsl_hip_fm_t fm, const uint8_t * patter
         set_error("fm_count_batch: invalid argument");
         return SDSL_HIP_ERR_INVALID;
     }
+    if (m && n_patterns >= (UINT64_C(1) << 22) && !is_device_ptr(patterns) && !is_device_ptr(out))
+    { // host arrays on both sides: 2^20 patterns at a time on several streams, so that uploads, searches and downloads
+      // overlap (common.hpp host_pipeline_bytes); every piece is answered in suffix order on its own
+        return host_pipeline_bytes(fm->device, patterns, m, (uint8_t *)out, 8, n_patterns, UINT64_C(1) << 20,
+                                   [fm, m](const void * d_in, void * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
+                                   {
+                                       return fm_run(fm, (const uint8_t *)d_in, m, nullptr, (uint64_t)m * cnt, cnt,
+                                                     (uint64_t *)d_out, nullptr, nullptr, st);
+                                   });
+    }
     return fm_run(fm, patterns, m, nullptr, (uint64_t)m * n_patterns, n_patterns, out, nullptr, nullptr,
                   (hipStream_t)stream);
 }

@@ -1103,3 +1103,24 @@ def test_select_mcl_writer_on_many_superblocks(gpu, shape):
     rb = ol.RBitVector(words, n)
     assert bv.serialize(3) == rb.serialize(3)
     assert bv.serialize(4) == rb.serialize(4)
+
+
+def test_count_from_host_arrays_is_pipelined_and_equal(gpu):
+    """>= 2^22 patterns with patterns and answers in host memory travel in pieces over several streams (fm.hip,
+    common.hpp host_pipeline_bytes): same answers as one device-resident batch, and as the oracle on a sample"""
+    import torch
+    text = gd.text("faust.txt")
+    csa = gpu.csa_wt(text=text)
+    arr = np.frombuffer(text, dtype=np.uint8)
+    rng = np.random.default_rng(8)
+    n, m = (1 << 22) + 777, 7
+    st = rng.integers(0, len(text) - m, n)
+    pats = arr[(st[:, None] + np.arange(m)[None, :]).reshape(-1)].copy()
+    pats[: 50 * m] = rng.integers(1, 256, 50 * m).astype(np.uint8)  # some that (mostly) do not occur
+    host = csa.count(pats, m)
+    dev = csa.count(torch.from_numpy(pats).cuda(), m).cpu().numpy().view(np.uint64)
+    assert np.array_equal(host, dev)
+    o = ol.OCsa(text)
+    pick = np.concatenate([np.arange(200), rng.integers(0, n, 2000)])
+    sample = np.concatenate([pats[q * m:(q + 1) * m] for q in pick])
+    assert np.array_equal(host[pick], o.count_batch(sample, m))
