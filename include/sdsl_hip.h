@@ -18,8 +18,8 @@
  *    are *defined*: the result slot is set to SDSL_HIP_NPOS (all ones).  The one overflow
  *    SDSL does define — select_support_rrr returns size() (rrr_vector.hpp:641-642,686-689)
  *    — is reproduced exactly;
- *  - large batches with BOTH arrays in host memory (>= 2^23 queries: rank / select of the bit-vector family;
- *    >= 2^22 patterns: sdsl_hip_fm_count_batch) are cut
+ *  - large batches with ALL arrays in host memory (>= 2^23 queries: rank / select of the bit-vector family,
+ *    sdsl_hip_wt_rank_batch; >= 2^22 patterns: sdsl_hip_fm_count_batch) are cut
  *    into chunks that travel on two internal streams, so uploads, kernels and downloads overlap; `stream` is then
  *    only a placeholder and the call returns when all results are in place;
  *  - threading: like SDSL's, query calls are const on the handle and may run concurrently from

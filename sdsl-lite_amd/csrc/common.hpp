@@ -126,10 +126,11 @@ inline int pipeline_streams()
     return v >= 1 && v <= kPipelineMaxStreams ? v : 2;
 }
 
-// n items of in_bytes each in host memory -> n items of out_bytes each in host memory, `chunk` items at a time
+// n items of in_bytes (and, optionally, a second column of in2_bytes) each in host memory -> n items of out_bytes each
+// in host memory, `chunk` items at a time
 template <class Launch>
-sdsl_hip_status host_pipeline_bytes(int device, const uint8_t * h_in, size_t in_bytes, uint8_t * h_out, size_t out_bytes,
-                                    uint64_t n, uint64_t chunk, Launch launch)
+sdsl_hip_status host_pipeline_bytes2(int device, const uint8_t * h_in, size_t in_bytes, const uint8_t * h_in2, size_t in2_bytes,
+                                     uint8_t * h_out, size_t out_bytes, uint64_t n, uint64_t chunk, Launch launch)
 {
     std::vector<std::thread> workers;
     sdsl_hip_status status[kPipelineMaxStreams];
@@ -149,17 +150,21 @@ sdsl_hip_status host_pipeline_bytes(int device, const uint8_t * h_in, size_t in_
                     SH_HIP(hipSetDevice(device));
                     hipStream_t st = nullptr;
                     SH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-                    DevBuf d_in, d_out;
+                    DevBuf d_in, d_in2, d_out;
                     sdsl_hip_status r = d_in.alloc(kPipelineChunk * in_bytes);
+                    if (r == SDSL_HIP_OK && h_in2)
+                        r = d_in2.alloc(kPipelineChunk * in2_bytes);
                     if (r == SDSL_HIP_OK)
                         r = d_out.alloc(kPipelineChunk * out_bytes);
                     for (uint64_t c = (uint64_t)t; r == SDSL_HIP_OK && c < n_chunks; c += kPipelineStreams)
                     {
                         const uint64_t lo = c * kPipelineChunk, cnt = std::min(kPipelineChunk, n - lo);
                         hipError_t e = hipMemcpyAsync(d_in.p, h_in + lo * in_bytes, cnt * in_bytes, hipMemcpyHostToDevice, st);
+                        if (e == hipSuccess && h_in2)
+                            e = hipMemcpyAsync(d_in2.p, h_in2 + lo * in2_bytes, cnt * in2_bytes, hipMemcpyHostToDevice, st);
                         if (e == hipSuccess)
                         {
-                            r = launch((const void *)d_in.p, (void *)d_out.p, cnt, st);
+                            r = launch((const void *)d_in.p, (const void *)d_in2.p, (void *)d_out.p, cnt, st);
                             if (r != SDSL_HIP_OK)
                                 break;
                             e = hipMemcpyAsync(h_out + lo * out_bytes, d_out.p, cnt * out_bytes, hipMemcpyDeviceToHost, st);
@@ -187,6 +192,15 @@ sdsl_hip_status host_pipeline_bytes(int device, const uint8_t * h_in, size_t in_
             return status[t];
         }
     return SDSL_HIP_OK;
+}
+
+template <class Launch>
+sdsl_hip_status host_pipeline_bytes(int device, const uint8_t * h_in, size_t in_bytes, uint8_t * h_out, size_t out_bytes,
+                                    uint64_t n, uint64_t chunk, Launch launch)
+{
+    return host_pipeline_bytes2(device, h_in, in_bytes, nullptr, 0, h_out, out_bytes, n, chunk,
+                                [&](const void * d_in, const void *, void * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
+                                { return launch(d_in, d_out, cnt, st); });
 }
 
 template <class Launch>

@@ -1635,6 +1635,20 @@ sdsl_hip_status sdsl_hip_wt_rank_batch(sdsl_hip_wt_t wt, const uint64_t * i, con
     }
     hipStream_t s = (hipStream_t)stream;
     SH_HIP(hipSetDevice(wt->h.device));
+    if (n >= kPipelineMinQueries && !is_device_ptr(i) && !is_device_ptr(c) && !is_device_ptr(out))
+    { // all three arrays in host memory: chunked over several streams (common.hpp host_pipeline_bytes2)
+        const WtHost * h = &wt->h;
+        return host_pipeline_bytes2(h->device, (const uint8_t *)i, 8, c, 1, (uint8_t *)out, 8, n, pipeline_chunk(),
+                                    [h](const void * di, const void * dc, void * dout, uint64_t cnt,
+                                        hipStream_t st) -> sdsl_hip_status
+                                    {
+                                        return h->backend == 1
+                                                   ? wt_rrr_launch_rank(*h, (const uint64_t *)di, (const uint8_t *)dc, cnt,
+                                                                        (uint64_t *)dout, st)
+                                                   : wt_launch_rank(*h, (const uint64_t *)di, (const uint8_t *)dc, cnt,
+                                                                    (uint64_t *)dout, st);
+                                    });
+    }
     Staged si, sc, so;
     SH_TRY(si.in(i, n * 8, s));
     SH_TRY(sc.in(c, n, s));

@@ -1124,3 +1124,22 @@ def test_count_from_host_arrays_is_pipelined_and_equal(gpu):
     pick = np.concatenate([np.arange(200), rng.integers(0, n, 2000)])
     sample = np.concatenate([pats[q * m:(q + 1) * m] for q in pick])
     assert np.array_equal(host[pick], o.count_batch(sample, m))
+
+
+def test_wt_rank_from_host_arrays_is_pipelined_and_equal(gpu):
+    """>= 2^23 (i, c) pairs with all three arrays in host memory are answered in pieces over several streams"""
+    import torch
+    text = gd.text("faust.txt")
+    wt = gpu.wt_huff(text=text)
+    arr = np.frombuffer(text, dtype=np.uint8)
+    rng = np.random.default_rng(21)
+    n = (1 << 23) + 4321
+    i = rng.integers(0, len(text) + 2, n).astype(np.uint64)
+    c = arr[rng.integers(0, len(text), n)].copy()
+    c[:100] = rng.integers(0, 256, 100).astype(np.uint8)
+    host = wt.rank(i, c)
+    dev = wt.rank(torch.from_numpy(i.view(np.int64)).cuda(), torch.from_numpy(c).cuda()).cpu().numpy().view(np.uint64)
+    assert np.array_equal(host, dev)
+    o = ol.OWt(text)
+    pick = np.concatenate([np.arange(300), rng.integers(0, n, 3000)])
+    assert np.array_equal(host[pick], o.rank(i[pick], c[pick]))
