@@ -80,6 +80,9 @@ typedef struct sdsl_hip_fm_s * sdsl_hip_fm_t;   /* csa_wt<wt_huff<...>> restrict
 
 /* ---- library ------------------------------------------------------------------------- */
 const char * sdsl_hip_last_error(void); /* thread-local message of the last failing call */
+/* device memory this process currently holds through the library: all live handles plus the staging of calls in flight
+ * (the sum over handles is what the *_device_bytes calls report) */
+uint64_t sdsl_hip_allocated_bytes(void);
 const char * sdsl_hip_version(void);
 int32_t sdsl_hip_device_count(void);    /* number of visible gfx950 devices (0 if none) */
 

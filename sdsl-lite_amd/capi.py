@@ -31,6 +31,7 @@ _vp = C.c_void_p
 # name -> (restype, argtypes); pointers to batch arrays are passed as raw addresses (c_void_p)
 # because they may be host or device memory.
 SIGNATURES = {
+    "sdsl_hip_allocated_bytes": (C.c_uint64, []),
     "sdsl_hip_last_error": (C.c_char_p, []),
     "sdsl_hip_version": (C.c_char_p, []),
     "sdsl_hip_device_count": (C.c_int32, []),

@@ -76,6 +76,8 @@ sdsl_hip_status check_device(int32_t device)
     return SDSL_HIP_OK;
 }
 
+static std::atomic<uint64_t> g_dev_bytes{0}; // device memory currently held through DevBuf (handles + calls in flight)
+
 sdsl_hip_status DevBuf::alloc(size_t n, bool zero)
 {
     release();
@@ -85,6 +87,7 @@ sdsl_hip_status DevBuf::alloc(size_t n, bool zero)
     SH_HIP(hipMalloc(&q, n));
     p = q;
     bytes = n;
+    g_dev_bytes += n;
     if (zero)
         SH_HIP(hipMemset(p, 0, n));
     return SDSL_HIP_OK;
@@ -93,7 +96,10 @@ sdsl_hip_status DevBuf::alloc(size_t n, bool zero)
 void DevBuf::release()
 {
     if (p)
+    {
         (void)hipFree(p);
+        g_dev_bytes -= bytes;
+    }
     p = nullptr;
     bytes = 0;
 }
@@ -228,6 +234,11 @@ sdsl_hip_status sdsl_hip_set_timing(int32_t enabled)
     g_timing = enabled != 0;
     g_ev_valid = false;
     return SDSL_HIP_OK;
+}
+
+uint64_t sdsl_hip_allocated_bytes(void)
+{
+    return g_dev_bytes.load();
 }
 
 sdsl_hip_status sdsl_hip_last_kernel_ms(float * ms_out)

@@ -9,13 +9,16 @@ import pytest
 import golden_data as gd
 
 pytestmark = pytest.mark.gpu
-SLACK = 4 << 20  # the runtime keeps a few MiB of its own pools
+SLACK = 1  # the library's own accounting is exact
 
 
-def _free_bytes():
+def _held_bytes():
+    """device memory the library holds for this process (its own accounting: other processes on the GPU do not disturb
+    it, unlike the device-wide free-memory figure)"""
+    import importlib
     import torch
     torch.cuda.synchronize()
-    return torch.cuda.mem_get_info()[0]
+    return importlib.import_module("sdsl-lite_amd").capi.lib().sdsl_hip_allocated_bytes()
 
 
 def _settled(fn, rounds):
@@ -23,11 +26,11 @@ def _settled(fn, rounds):
     free device memory across the timed rounds"""
     fn()
     gc.collect()
-    before = _free_bytes()
+    before = _held_bytes()
     for _ in range(rounds):
         fn()
     gc.collect()
-    return before - _free_bytes()
+    return _held_bytes() - before
 
 
 def test_build_query_destroy_cycles_do_not_leak(gpu):
