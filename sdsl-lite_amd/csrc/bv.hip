@@ -719,6 +719,29 @@ sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i
     return SDSL_HIP_OK;
 }
 
+// direct kernel or, for a large batch over a large vector, the bucketed path (bv_sorted.hip).  SDSL_HIP_RANK_SORTED:
+// 0 = never, 1 = whenever applicable; unset = automatic.
+sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out, hipStream_t s)
+{
+    static const int mode = getenv("SDSL_HIP_RANK_SORTED") ? atoi(getenv("SDSL_HIP_RANK_SORTED")) : -1;
+    const bool want = mode == 0 ? false : (mode > 0 ? h.view.n_lines >= 2 : bv_sorted_rank_applicable(h.view, n));
+    if (want && n > 0)
+    {
+        const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
+        const size_t need = bv_sorted_rank_scratch_bytes(h.view, pass);
+        if (h.sort_scratch.bytes < need)
+        {
+            SH_HIP(hipStreamSynchronize(s));
+            h.sort_scratch.release();
+            if (h.sort_scratch.alloc(need) != SDSL_HIP_OK)
+                return bv_launch_rank(h.view, bit, d_idx, n, d_out, s); // no room for the scratch: direct kernel
+        }
+        KernelTimer t(s);
+        return bv_launch_rank_sorted(h.view, bit, d_idx, n, d_out, s, h.sort_scratch.p, h.sort_scratch.bytes);
+    }
+    return bv_launch_rank(h.view, bit, d_idx, n, d_out, s);
+}
+
 uint32_t default_sel_shift()
 {
     uint32_t sh = 0; // 0 = automatic: smallest rate >= 512 that keeps a directory within 2^21 samples
@@ -892,7 +915,7 @@ sdsl_hip_status sdsl_hip_bv_rank_batch(sdsl_hip_bv_t bv, int32_t bit, const uint
     Staged in, o;
     SH_TRY(in.in(idx, n * 8, s));
     SH_TRY(o.out(out, n * 8));
-    SH_TRY(bv_launch_rank(bv->h.view, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s));
+    SH_TRY(bv_rank_dispatch(bv->h, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s));
     SH_TRY(o.finish(s));
     if (in.host && !o.host)
         SH_HIP(hipStreamSynchronize(s)); // staging buffer must outlive the kernel

@@ -13,9 +13,10 @@ struct BvHost
     DevBuf lines;  // n_lines * 64 B
     DevBuf cnts;   // u32 per line, build-time only
     DevBuf sel[2]; // select sample directories
+    DevBuf sort_scratch; // working memory of the bucketed batch rank (bv_sorted.hip), grown on demand
     size_t device_bytes() const
     {
-        return lines.bytes + sel[0].bytes + sel[1].bytes;
+        return lines.bytes + sel[0].bytes + sel[1].bytes + sort_scratch.bytes;
     }
 };
 
@@ -27,6 +28,11 @@ sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words
 sdsl_hip_status bv_export_words_device(const BvView & v, uint64_t * d_words, uint64_t n_words, hipStream_t s);
 sdsl_hip_status bv_launch_rank(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                                hipStream_t s);
+// large batches, bucketed by index region (bv_sorted.hip)
+bool bv_sorted_rank_applicable(const BvView & v, uint64_t n);
+size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n);
+sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
+                                      hipStream_t s, void * scratch, size_t scratch_bytes);
 sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out,
                                  hipStream_t s);
 
