@@ -90,6 +90,20 @@ int32_t sdsl_hip_device_count(void);    /* number of visible gfx950 devices (0 i
  * util::set_random_bits (util.hpp:467-485): words = successive std::mt19937_64(seed) outputs.
  * Only the host container is touched; like SDSL the last word keeps its stray high bits. */
 sdsl_hip_status sdsl_hip_util_set_random_bits(uint64_t * words, uint64_t n_bits, uint64_t seed);
+/* The benchmark inputs of SURVEY.md 8(d), integer-only and seeded, so that the build container (where the real
+ * sdsl-lite answers them once: tests/golden/make_golden_large.py) and the GPU box hold identical bytes.
+ *  rnd_positions: out[q] = add + (q-th output of std::mt19937_64(seed)) % mod   (mod 0: the raw outputs) — the way
+ *                 util::rnd_positions draws benchmark arguments (util.hpp:438-448)
+ *  density_bits:  bit i = (i-th output of mt19937_64(seed) % 100 < percent), drawn sequentially (configs[2]); with a
+ *                 table of generator states taken every `stride` draws (313 words each: sdsl_hip_util_mt_checkpoints;
+ *                 committed as tests/golden/mt9_checkpoints.bin) every host thread produces its own stretch
+ *  english_text:  English-class stand-in for Pizza&Chili english (not available offline,
+ *                 benchmark/indexing_count/test_case.config:6): sigma > 200, H0 about 4.6 bits, no zero byte */
+sdsl_hip_status sdsl_hip_util_rnd_positions(uint64_t seed, uint64_t count, uint64_t mod, uint64_t add, uint64_t * out);
+sdsl_hip_status sdsl_hip_util_mt_checkpoints(uint64_t seed, uint64_t stride, uint64_t n, uint64_t * out);
+sdsl_hip_status sdsl_hip_util_density_bits(uint64_t * words, uint64_t n_bits, uint64_t seed, uint32_t percent,
+                                           const uint64_t * checkpoints, uint64_t n_checkpoints, uint64_t stride);
+sdsl_hip_status sdsl_hip_util_english_text(uint8_t * out, uint64_t n_bytes, uint64_t seed);
 
 /* ---- plain bit vector: rank_support_v5 / select_support_mcl ---------------------------
  * Replaces: rank_support_v5<b>::rank / operator() (rank_support_v5.hpp:131-154),

@@ -4,6 +4,7 @@
 // C restatement (oracle.c), generates the golden fixtures (tests/golden/make_golden.py) and serves
 // as bench.py's cpu_baseline of kind "reference".  It is never loaded by the product library.
 #include <thread>
+#include <random>
 #include <sdsl/bit_vectors.hpp>
 #include <sdsl/suffix_arrays.hpp>
 #include <sdsl/wavelet_trees.hpp>
@@ -601,6 +602,21 @@ void ref_set_random_bits(uint64_t * words, uint64_t n_bits, int seed)
     bit_vector bv(n_bits, 0);
     util::set_random_bits(bv, seed);
     memcpy(words, bv.data(), ((n_bits + 63) >> 6) * 8);
+}
+
+// SURVEY.md 8(d) configs[2] vector with the STANDARD LIBRARY's generator (the product restates MT19937-64 on its own,
+// csrc/workload.cpp): bit i = (i-th output of std::mt19937_64(seed) % 100 < percent), drawn sequentially
+void ref_density_bits(uint64_t * words, uint64_t n_bits, uint64_t seed, uint32_t percent)
+{
+    std::mt19937_64 rng(seed);
+    for (uint64_t w = 0; w < (n_bits + 63) / 64; ++w)
+    {
+        uint64_t x = 0;
+        const unsigned nb = (w + 1) * 64 <= n_bits ? 64u : (unsigned)(n_bits & 63);
+        for (unsigned b = 0; b < nb; ++b)
+            x |= (uint64_t)(rng() % 100 < percent) << b;
+        words[w] = x;
+    }
 }
 
 uint32_t ref_bits_sel(uint64_t x, uint32_t i)

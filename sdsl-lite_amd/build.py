@@ -57,7 +57,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
     hdr_m = _headers_mtime()
-    objs, rebuilt = [], False
+    objs, cmds = [], []
     for src in _sources():
         obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
         objs.append(obj)
@@ -66,8 +66,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         cmd = [hipcc, f"--offload-arch={ARCH}", *CXXFLAGS, "-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        _run(cmd)
-        rebuilt = True
+        cmds.append(cmd)
+    rebuilt = bool(cmds)
+    if cmds:  # translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 1)) as ex:
+            list(ex.map(_run, cmds))
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-Wl,-rpath,/opt/rocm/lib",
                "-Wl,--no-undefined"]

@@ -36,6 +36,10 @@ SIGNATURES = {
     "sdsl_hip_version": (C.c_char_p, []),
     "sdsl_hip_device_count": (C.c_int32, []),
     "sdsl_hip_util_set_random_bits": (C.c_int32, [_vp, C.c_uint64, C.c_uint64]),
+    "sdsl_hip_util_rnd_positions": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
+    "sdsl_hip_util_mt_checkpoints": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
+    "sdsl_hip_util_density_bits": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.c_uint64]),
+    "sdsl_hip_util_english_text": (C.c_int32, [_vp, C.c_uint64, C.c_uint64]),
     "sdsl_hip_bv_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "sdsl_hip_bv_create_pattern": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.POINTER(_vp)]),

@@ -724,7 +724,7 @@ sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i
 sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out, hipStream_t s)
 {
     static const int mode = getenv("SDSL_HIP_RANK_SORTED") ? atoi(getenv("SDSL_HIP_RANK_SORTED")) : -1;
-    const bool want = mode == 0 ? false : (mode > 0 ? h.view.n_lines >= 2 : bv_sorted_rank_applicable(h.view, n));
+    const bool want = mode == 0 ? false : (mode > 0 ? bv_sorted_rank_possible(h.view) : bv_sorted_rank_applicable(h.view, n));
     if (want && n > 0)
     {
         const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
@@ -766,7 +766,7 @@ struct sdsl_hip_bv_s
 
 extern "C" {
 
-sdsl_hip_status sdsl_hip_bv_create(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t flags,
+static sdsl_hip_status sdsl_hip_bv_create_impl(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t flags,
                                    sdsl_hip_bv_t * out)
 {
     if (!out || (!words && n_bits))
@@ -792,8 +792,14 @@ sdsl_hip_status sdsl_hip_bv_create(const uint64_t * words, uint64_t n_bits, int3
     *out = bv;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_bv_create(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t flags,
+                                   sdsl_hip_bv_t * out)
+{
+    return guarded("bv_create", [&] { return sdsl_hip_bv_create_impl(words, n_bits, device, flags, out); });
+}
 
-sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t t_b,
+static sdsl_hip_status sdsl_hip_bv_create_pattern_impl(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t t_b,
                                            uint32_t t_pat_len, uint32_t flags, sdsl_hip_bv_t * out)
 {
     if (t_pat_len == 1 && t_b <= 1)
@@ -838,8 +844,14 @@ sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bi
     *out = bv;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t t_b,
+                                           uint32_t t_pat_len, uint32_t flags, sdsl_hip_bv_t * out)
+{
+    return guarded("bv_create_pattern", [&] { return sdsl_hip_bv_create_pattern_impl(words, n_bits, device, t_b, t_pat_len, flags, out); });
+}
 
-sdsl_hip_status sdsl_hip_bv_serialize(sdsl_hip_bv_t bv, int32_t what, void * buf, size_t cap, size_t * written)
+static sdsl_hip_status sdsl_hip_bv_serialize_impl(sdsl_hip_bv_t bv, int32_t what, void * buf, size_t cap, size_t * written)
 {
     if (!bv || what < 0 || what > SDSL_HIP_SER_RANK_V_0)
     {
@@ -871,6 +883,11 @@ sdsl_hip_status sdsl_hip_bv_serialize(sdsl_hip_bv_t bv, int32_t what, void * buf
     default: rank_v_serialize_host(words.data(), n, 0, w); break;
     }
     return deliver_and_cache(bv->uid, (uint64_t)what, w, buf, cap, written);
+}
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_bv_serialize(sdsl_hip_bv_t bv, int32_t what, void * buf, size_t cap, size_t * written)
+{
+    return guarded("bv_serialize", [&] { return sdsl_hip_bv_serialize_impl(bv, what, buf, cap, written); });
 }
 
 sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv)

@@ -29,6 +29,7 @@ sdsl_hip_status bv_export_words_device(const BvView & v, uint64_t * d_words, uin
 sdsl_hip_status bv_launch_rank(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                                hipStream_t s);
 // large batches, bucketed by index region (bv_sorted.hip)
+bool bv_sorted_rank_possible(const BvView & v);
 bool bv_sorted_rank_applicable(const BvView & v, uint64_t n);
 size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n);
 sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,

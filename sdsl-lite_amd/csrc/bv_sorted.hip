@@ -1,23 +1,29 @@
-// bv_sorted.hip — batched rank on a plain bit vector for LARGE batches: the batch is partitioned by the region of
-// the index it addresses, answered region by region out of the XCD's L2, and put back into the caller's order.
+// bv_sorted.hip — batched rank on a plain bit vector for LARGE batches: the batch is radix-partitioned by the
+// 64 KiB slice of the index each position addresses, every slice is staged ONCE into LDS and answers all its
+// positions from there, and the answers travel back through the partition in reverse.
 //
 // Why: a random rank costs one L2 miss = one 128-byte fabric read, and the part serves ≈ 40 G of
 // those per second whatever the kernel does (profiles/gather_probe_r01.txt).  A batch of 10^9 positions over 2^34 bits
-// addresses every 64-byte rank line ≈ 26 times; fetched in the caller's order that is 26 misses, fetched bucket by
-// bucket it is one miss and 25 L2 hits.  The reference answers its queries one at a time
-// (rank_support_v5.hpp:131-149); batching is this library's addition and the answers are the same numbers.
+// addresses every 64-byte rank line ≈ 26 times.  The first cut of this file (profiles/sorted_rank_v1_single_level_r02.txt)
+// partitioned once into 1 MiB buckets and gathered from the XCD's L2: the gather kernel then ran at 82 G/s (139 G/s
+// with everything cache-resident) — a quad fetching a line costs a 128-byte L2->L1 transfer wherever the line lives.
+// Only LDS serves random 64-byte reads an order of magnitude faster, so the buckets must be LDS-sized: two partition
+// passes of <= 8 bits each (least significant digit first), both with runs of 32 keys per (tile, bin).
+// The reference answers its queries one at a time (rank_support_v5.hpp:131-149); batching is this library's addition
+// and the answers are the same numbers.
 //
-// Pipeline (all passes stream; every global access is coalesced or a run):
-//   1. k_sr_hist      block g counts, per bucket, the positions of its contiguous share of the batch
-//   2. k_sr_bucket_*  exclusive scan over (bucket, block) -> where block g's entries of bucket b start
-//   3. k_sr_partition per tile of 16384 positions: counting sort by bucket in LDS, the sorted tile is written out
-//                     bucket run by bucket run as 32-bit keys (line inside the bucket, bit inside the line); every
-//                     position remembers its 16-bit slot in the sorted tile; the tile's histogram is kept (u16)
-//   4. k_sr_rank      sorted keys -> 32-bit answers relative to the bucket's first line, in place; XCD x walks the
-//                     x-th eighth of the sorted array, so a bucket's slice (2^14 lines = 1 MiB) lives in ONE L2
-//   5. k_sr_unpermute per tile: the runs are gathered back into LDS (coalesced), made absolute, and every position
-//                     picks its answer by slot; the result array is written in the caller's order, coalesced
-// No pass scatters single words: the un-permute that sank the idea in round 1 (random 8-byte scatter, 22.9 G/s,
+// line index of a position = [ digit 2 | digit 1 | 10 bits inside the slice ]      (slice = 2^10 lines = 64 KiB)
+//
+//   hist 1 / partition 1   by digit 1: 64-bit positions -> 32-bit keys (digit 2, line in slice, bit in line), u16 slots
+//   hist 2 / partition 2   by digit 2, tiles never straddle a digit-1 group, so the result is ordered by
+//                          (digit 2, digit 1) = by slice; keys shrink to (line in slice, bit in line)
+//   k_sr_rank_lds          per slice: 64 KiB -> LDS, one LANE per position (8 words from LDS, masked popcounts),
+//                          32-bit answers relative to the slice, in place
+//   un-permute 2, 1        per tile the runs are gathered back into LDS, made absolute, and every position picks its
+//                          answer by slot; all global accesses are coalesced or runs
+// A partition pass: per tile of 8192 keys a counting sort in LDS (unstable inside a (tile, bin) pair — the slot array
+// makes the way back exact), the sorted tile is written out bin by bin (16 lanes per bin).  No pass scatters single
+// words: the un-permute that sank the idea in round 1 (random 8-byte scatter, 22.9 G/s,
 // profiles/scatter_probe_r01.txt) is a gather of runs staged through LDS.
 #include "bv_host.hpp"
 
@@ -25,21 +31,39 @@ namespace sdslhip {
 
 namespace {
 
-constexpr unsigned kSrThreads = 1024;            // partition / un-permute block
-constexpr unsigned kSrPer = 16;                  // positions per thread per tile
-constexpr unsigned kSrTile = kSrThreads * kSrPer; // 16384 (slots fit 16 bits)
-constexpr unsigned kSrBMax = 3 * kSrThreads;     // buckets a block can scan (3 per thread)
-constexpr uint32_t kSrBad = 0xFFFFFFFFu;         // key / answer of a position beyond the vector (answer NPOS)
-constexpr unsigned kSrOffBits = 9;               // 448 < 2^9 in-line offsets
+constexpr unsigned kPer = 16;            // keys per thread per tile; a tile = 16 * (threads of the block) keys
+constexpr unsigned kRT = 512;            // threads of a rank block
+constexpr unsigned kBins = 256;          // bins per pass (8-bit digits)
+constexpr unsigned kSliceLog = 10;       // lines per slice (64 KiB)
+constexpr unsigned kOffBits = 9;         // 448 < 2^9 in-line offsets
+constexpr unsigned kKey2Bits = kSliceLog + kOffBits;
+constexpr uint32_t kBad = 0xFFFFFFFFu;   // key / answer of a position beyond the vector (answer NPOS)
+constexpr unsigned kBigRun = 64;         // a (tile, bin) run longer than this is copied by the whole block
+constexpr unsigned kItemKeys = 32768;    // keys of one slice handled by one block before the slice is reloaded
 
 struct SrGeom
 {
-    uint32_t k;        // log2(lines per bucket)
-    uint32_t B;        // buckets
-    uint32_t G;        // partition blocks
-    uint64_t tiles;    // tiles in the batch
-    uint64_t n;        // positions in the batch (< 2^31)
-    bool small;        // 32-bit division path of line_of
+    uint64_t n;      // positions in this pass over the batch (< 2^31)
+    uint64_t n_bits;
+    uint64_t n_lines;
+    uint32_t d1, d2; // digit widths
+    uint32_t G;      // blocks of the partition kernels
+    uint32_t tiles1; // tiles of pass 1
+    uint32_t tile;   // keys per tile
+    bool small;      // 32-bit division path of line_of
+};
+
+struct SrBuf
+{ // carved out of the scratch allocation
+    uint32_t *keys1, *keys2;   // keys1 doubles as the low 32 bits of the absolute answers on the way back
+    uint16_t *slots1, *slots2;
+    uint8_t * hi8;             // bits 32.. of the absolute answers (0xFF: NPOS)
+    uint16_t *thist1, *thist2; // [tile][bin]
+    uint32_t *counts1, *offs1, *bstart1;
+    uint32_t *counts2, *offs2, *bstart2;
+    uint32_t *btot, *tprefix2;
+    uint32_t *fine_count, *fstart, *ioff; // per slice: keys, first key, first work item
+    uint64_t * hf;                        // per slice: ones in front of it
 };
 
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
@@ -54,106 +78,216 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
     return v;
 }
 
-// In-place exclusive scan of a[0 .. 3*kSrThreads) in LDS by a block of kSrThreads; returns the total.  `wsum` is
-// scratch for 16 wave totals + 1.  Ends with a barrier.
-__device__ __forceinline__ unsigned block_excl_scan3(unsigned * a, unsigned * wsum)
+// In-place exclusive scan of a[0 .. kBins) in LDS by the first kBins threads of the block (all threads must call);
+// returns the total.  Ends with a barrier.
+__device__ __forceinline__ unsigned block_excl_scan_bins(unsigned * a, unsigned * wsum)
 {
     const unsigned t = threadIdx.x;
-    const unsigned a0 = a[3 * t], a1 = a[3 * t + 1], a2 = a[3 * t + 2];
-    const unsigned s = a0 + a1 + a2;
-    const unsigned inc = wave_incl_scan(s);
-    if ((t & 63) == 63)
-        wsum[t >> 6] = inc;
-    __syncthreads();
-    if (t < 64)
+    unsigned v = 0, inc = 0;
+    if (t < kBins)
     {
-        unsigned w = t < kSrThreads / 64 ? wsum[t] : 0;
-        unsigned wi = wave_incl_scan(w);
-        if (t < kSrThreads / 64)
-            wsum[t] = wi - w;
-        if (t == kSrThreads / 64 - 1)
-            wsum[kSrThreads / 64] = wi;
+        v = a[t];
+        inc = wave_incl_scan(v);
+        if ((t & 63) == 63)
+            wsum[t >> 6] = inc;
     }
     __syncthreads();
-    const unsigned base = wsum[t >> 6] + inc - s;
-    a[3 * t] = base;
-    a[3 * t + 1] = base + a0;
-    a[3 * t + 2] = base + a0 + a1;
-    const unsigned total = wsum[kSrThreads / 64];
+    if (t < kBins)
+    {
+        unsigned base = 0;
+        for (unsigned w = 0; w < (t >> 6); ++w)
+            base += wsum[w];
+        a[t] = base + inc - v;
+    }
+    unsigned total = 0;
+    for (unsigned w = 0; w < kBins / 64; ++w)
+        total += wsum[w];
     __syncthreads();
     return total;
 }
 
-// bucket and key of a position
-__device__ __forceinline__ void sr_key(uint64_t pos, uint64_t n_bits, const SrGeom & g, unsigned & b, uint32_t & key)
+// pass 1: digit and 32-bit key of a position
+__device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned & dig, uint32_t & key)
 {
-    if (pos > n_bits)
+    if (pos > g.n_bits)
     {
-        b = 0;
-        key = kSrBad;
+        dig = 0;
+        key = kBad;
         return;
     }
     uint64_t L;
     unsigned off;
     line_of(pos, g.small, L, off);
-    b = (unsigned)(L >> g.k);
-    key = ((uint32_t)(L & ((UINT64_C(1) << g.k) - 1)) << kSrOffBits) | off;
+    const uint32_t l = (uint32_t)L; // < 2^26
+    dig = (l >> kSliceLog) & ((1u << g.d1) - 1);
+    key = ((l >> (kSliceLog + g.d1)) << kKey2Bits) | ((l & ((1u << kSliceLog) - 1)) << kOffBits) | off;
 }
-
-// tiles [lo, hi) of block gi
-__device__ __forceinline__ void sr_share(const SrGeom & g, unsigned gi, uint64_t & lo, uint64_t & hi)
+// pass 2: digit and final key of a pass-1 key
+__device__ __forceinline__ void sr_key2(uint32_t k1, unsigned & dig, uint32_t & key)
 {
-    lo = g.tiles * gi / g.G;
-    hi = g.tiles * (gi + 1) / g.G;
-}
-
-// ---- 1. histogram -----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSrThreads) void k_sr_hist(uint64_t n_bits, SrGeom g, const uint64_t * __restrict__ idx,
-                                                        uint32_t * __restrict__ counts /* [B][G] */)
-{
-    __shared__ unsigned hist[kSrBMax];
-    for (unsigned i = threadIdx.x; i < kSrBMax; i += kSrThreads)
-        hist[i] = 0;
-    __syncthreads();
-    uint64_t tlo, thi;
-    sr_share(g, blockIdx.x, tlo, thi);
-    const uint64_t qlo = tlo * kSrTile, qhi = thi * kSrTile < g.n ? thi * kSrTile : g.n;
-    for (uint64_t q0 = qlo + threadIdx.x; q0 < qhi; q0 += (uint64_t)kSrThreads * 4)
+    if (k1 == kBad)
     {
-        uint64_t p[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
+        dig = 0;
+        key = kBad;
+        return;
+    }
+    dig = k1 >> kKey2Bits;
+    key = k1 & ((1u << kKey2Bits) - 1);
+}
+
+// Tiles of a pass.  Pass 1: tile i = keys [i * tile, ...).  Pass 2: the keys are grouped by digit 1 (group starts
+// gs[], tp[] = exclusive prefix of ceil(size / tile)); a tile lies inside one group.
+struct TileMap
+{
+    unsigned tp[kBins + 1], gs[kBins + 1];
+};
+template <int P, unsigned TT>
+__device__ __forceinline__ void sr_load_map(const SrGeom & g, TileMap & m, const uint32_t * tprefix, const uint32_t * gstart)
+{
+    if (P == 2)
+        for (unsigned i = threadIdx.x; i <= (1u << g.d1); i += TT)
         {
-            const uint64_t q = q0 + (uint64_t)u * kSrThreads;
-            p[u] = q < qhi ? __builtin_nontemporal_load(idx + q) : ~UINT64_C(0);
+            m.tp[i] = tprefix[i];
+            m.gs[i] = gstart[i];
+        }
+}
+template <int P>
+__device__ __forceinline__ unsigned sr_tiles(const SrGeom & g, const TileMap & m)
+{
+    return P == 1 ? g.tiles1 : m.tp[1u << g.d1];
+}
+template <int P, unsigned TT>
+__device__ __forceinline__ void sr_tile_range(const SrGeom & g, const TileMap & m, unsigned ti, uint64_t & lo, uint64_t & hi,
+                                              unsigned & grp)
+{
+    constexpr unsigned kTile = TT * kPer;
+    if (P == 1)
+    {
+        grp = 0;
+        lo = (uint64_t)ti * kTile;
+        hi = lo + kTile < g.n ? lo + kTile : g.n;
+        return;
+    }
+    unsigned a = 0, z = 1u << g.d1; // last group a with tp[a] <= ti (groups without tiles are skipped over)
+    while (a + 1 < z)
+    {
+        const unsigned mid = (a + z) >> 1;
+        if (m.tp[mid] <= ti)
+            a = mid;
+        else
+            z = mid;
+    }
+    grp = a;
+    lo = (uint64_t)m.gs[a] + (uint64_t)(ti - m.tp[a]) * kTile;
+    hi = lo + kTile < m.gs[a + 1] ? lo + kTile : m.gs[a + 1];
+}
+
+// digits of the kPer keys of this thread in tile [lo, hi); all loads are issued before the first is used
+template <int P, unsigned TT>
+__device__ __forceinline__ void sr_load_keys(const SrGeom & g, const uint64_t * __restrict__ idx,
+                                             const uint32_t * __restrict__ keys_in, uint64_t lo, uint64_t hi, unsigned (&dig)[kPer],
+                                             uint32_t (&key)[kPer])
+{
+    const unsigned t = threadIdx.x;
+    if (P == 1)
+    {
+        uint64_t p[kPer];
+#pragma unroll
+        for (unsigned u = 0; u < kPer; ++u)
+        {
+            const uint64_t q = lo + (uint64_t)u * TT + t;
+            p[u] = q < hi ? __builtin_nontemporal_load(idx + q) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (unsigned u = 0; u < kPer; ++u)
+            sr_key1(p[u], g, dig[u], key[u]);
+    }
+    else
+    {
+        uint32_t k1[kPer];
+#pragma unroll
+        for (unsigned u = 0; u < kPer; ++u)
         {
-            const uint64_t q = q0 + (uint64_t)u * kSrThreads;
-            if (q < qhi)
-            {
-                unsigned b;
-                uint32_t key;
-                sr_key(p[u], n_bits, g, b, key);
-                atomicAdd(&hist[b], 1u);
-            }
+            const uint64_t q = lo + (uint64_t)u * TT + t;
+            k1[u] = q < hi ? __builtin_nontemporal_load(keys_in + q) : 0;
         }
+#pragma unroll
+        for (unsigned u = 0; u < kPer; ++u)
+            sr_key2(k1[u], dig[u], key[u]);
+    }
+}
+
+// ---- histogram of a pass: counts[bin][block]; pass 2 also counts per slice ------------------------------------------
+template <int P, unsigned TT>
+__global__ __launch_bounds__(TT) void k_sr_hist(SrGeom g, const uint64_t * __restrict__ idx, const uint32_t * __restrict__ keys1,
+                                                const uint32_t * __restrict__ tprefix, const uint32_t * __restrict__ gstart,
+                                                uint32_t * __restrict__ counts, uint32_t * __restrict__ fine_count)
+{
+    __shared__ unsigned hist[kBins], ghist[TT / 64][kBins]; // ghist: one per wave (fewer collisions)
+    __shared__ TileMap map;
+    const unsigned t = threadIdx.x, wv = t >> 6;
+    sr_load_map<P, TT>(g, map, tprefix, gstart);
+    for (unsigned i = t; i < kBins; i += TT)
+    {
+        hist[i] = 0;
+        for (unsigned w = 0; w < TT / 64; ++w)
+            ghist[w][i] = 0;
     }
     __syncthreads();
-    for (unsigned b = threadIdx.x; b < g.B; b += kSrThreads)
-        counts[(uint64_t)b * g.G + blockIdx.x] = hist[b];
+    const unsigned nt = sr_tiles<P>(g, map);
+    const unsigned tlo = (unsigned)((uint64_t)nt * blockIdx.x / g.G), thi = (unsigned)((uint64_t)nt * (blockIdx.x + 1) / g.G);
+    unsigned cur = 0;
+    auto flush = [&](unsigned grp)
+    { // all threads; ghist -> hist (+ the per-slice counts of pass 2)
+        __syncthreads();
+        for (unsigned i = t; i < kBins; i += TT)
+        {
+            unsigned c = 0;
+            for (unsigned w = 0; w < TT / 64; ++w)
+            {
+                c += ghist[w][i];
+                ghist[w][i] = 0;
+            }
+            if (c)
+            {
+                hist[i] += c;
+                if (P == 2)
+                    atomicAdd(&fine_count[((uint64_t)i << g.d1) | grp], c);
+            }
+        }
+        __syncthreads();
+    };
+    for (unsigned ti = tlo; ti < thi; ++ti)
+    {
+        uint64_t lo, hi;
+        unsigned grp;
+        sr_tile_range<P, TT>(g, map, ti, lo, hi, grp);
+        if (P == 2 && grp != cur && ti != tlo)
+            flush(cur);
+        cur = grp;
+        unsigned dig[kPer];
+        uint32_t key[kPer];
+        sr_load_keys<P, TT>(g, idx, keys1, lo, hi, dig, key);
+#pragma unroll
+        for (unsigned u = 0; u < kPer; ++u)
+            if (lo + (uint64_t)u * TT + t < hi)
+                atomicAdd(&ghist[wv][dig[u]], 1u);
+    }
+    flush(cur);
+    const unsigned bins = 1u << (P == 1 ? g.d1 : g.d2);
+    for (unsigned i = t; i < bins; i += TT)
+        counts[(uint64_t)i * g.G + blockIdx.x] = hist[i];
 }
 
-// ---- 2. offsets: offs[b][g] = entries of buckets < b + entries of bucket b in blocks < g ---------------------------
-__global__ __launch_bounds__(256) void k_sr_bucket_totals(SrGeom g, const uint32_t * __restrict__ counts,
+// ---- offsets: offs[b][g] = keys of bins < b + keys of bin b in blocks < g -------------------------------------------
+__global__ __launch_bounds__(256) void k_sr_bucket_totals(unsigned G, const uint32_t * __restrict__ counts,
                                                           uint32_t * __restrict__ btot)
 {
     __shared__ unsigned red[4];
     const unsigned b = blockIdx.x;
     unsigned s = 0;
-    for (unsigned i = threadIdx.x; i < g.G; i += 256)
-        s += counts[(uint64_t)b * g.G + i];
+    for (unsigned i = threadIdx.x; i < G; i += 256)
+        s += counts[(uint64_t)b * G + i];
     for (int d = 32; d; d >>= 1)
         s += __shfl_xor(s, d, 64);
     if ((threadIdx.x & 63) == 0)
@@ -163,33 +297,53 @@ __global__ __launch_bounds__(256) void k_sr_bucket_totals(SrGeom g, const uint32
         btot[b] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ __launch_bounds__(kSrThreads) void k_sr_bucket_scan(SrGeom g, const uint32_t * __restrict__ btot,
-                                                               uint32_t * __restrict__ bstart /* B + 1 */)
+// bstart = exclusive scan of btot (bins + 1 entries); with tprefix: also the tile prefix of the groups
+__global__ __launch_bounds__(kBins) void k_sr_bucket_scan(unsigned bins, unsigned tile, const uint32_t * __restrict__ btot,
+                                                          uint32_t * __restrict__ bstart, uint32_t * __restrict__ tprefix)
 {
-    __shared__ unsigned a[kSrBMax];
-    __shared__ unsigned wsum[kSrThreads / 64 + 1];
-    for (unsigned i = threadIdx.x; i < kSrBMax; i += kSrThreads)
-        a[i] = i < g.B ? btot[i] : 0;
-    __syncthreads();
-    const unsigned total = block_excl_scan3(a, wsum);
-    for (unsigned i = threadIdx.x; i < g.B; i += kSrThreads)
-        bstart[i] = a[i];
-    if (threadIdx.x == 0)
-        bstart[g.B] = total;
+    __shared__ unsigned wsum[kBins / 64];
+    const unsigned t = threadIdx.x;
+    auto scan = [&](unsigned v) -> unsigned
+    { // exclusive
+        const unsigned inc = wave_incl_scan(v);
+        __syncthreads();
+        if ((t & 63) == 63)
+            wsum[t >> 6] = inc;
+        __syncthreads();
+        unsigned base = 0;
+        for (unsigned w = 0; w < (t >> 6); ++w)
+            base += wsum[w];
+        return base + inc - v;
+    };
+    const unsigned v = t < bins ? btot[t] : 0;
+    const unsigned e = scan(v);
+    if (t < bins)
+        bstart[t] = e;
+    if (t == bins - 1)
+        bstart[bins] = e + v;
+    if (tprefix)
+    {
+        const unsigned nt = (v + tile - 1) / tile;
+        const unsigned te = scan(nt);
+        if (t < bins)
+            tprefix[t] = te;
+        if (t == bins - 1)
+            tprefix[bins] = te + nt;
+    }
 }
 
-__global__ __launch_bounds__(256) void k_sr_bucket_offsets(SrGeom g, const uint32_t * __restrict__ counts,
+__global__ __launch_bounds__(256) void k_sr_bucket_offsets(unsigned G, const uint32_t * __restrict__ counts,
                                                            const uint32_t * __restrict__ bstart,
                                                            uint32_t * __restrict__ offs)
-{ // G <= 256 * 4: a thread owns 4 consecutive blocks
-    __shared__ unsigned wtot[5];
+{ // G <= 256 * 8: a thread owns 8 consecutive blocks
+    __shared__ unsigned wtot[4];
     const unsigned b = blockIdx.x, t = threadIdx.x;
-    unsigned c[4], s = 0;
+    unsigned c[8], s = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u)
     {
-        const unsigned gi = 4 * t + u;
-        c[u] = gi < g.G ? counts[(uint64_t)b * g.G + gi] : 0;
+        const unsigned gi = 8 * t + u;
+        c[u] = gi < G ? counts[(uint64_t)b * G + gi] : 0;
         s += c[u];
     }
     const unsigned inc = wave_incl_scan(s);
@@ -200,78 +354,134 @@ __global__ __launch_bounds__(256) void k_sr_bucket_offsets(SrGeom g, const uint3
     for (unsigned w = 0; w < (t >> 6); ++w)
         base += wtot[w];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u)
     {
-        const unsigned gi = 4 * t + u;
-        if (gi < g.G)
-            offs[(uint64_t)b * g.G + gi] = base;
+        const unsigned gi = 8 * t + u;
+        if (gi < G)
+            offs[(uint64_t)b * G + gi] = base;
         base += c[u];
     }
 }
 
-// runs of a sorted tile <-> the bucket-major array.  8 lanes per bucket; a bucket with more than kSrBigRun entries in
-// this tile (skewed batches) is left to the whole block afterwards.  COPY(b, src_in_tile, dst_global, count, lane, step)
-constexpr unsigned kSrBigRun = 64;
-
-// ---- 3. partition -----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSrThreads) void k_sr_partition(uint64_t n_bits, SrGeom g, const uint64_t * __restrict__ idx,
-                                                             const uint32_t * __restrict__ offs,
-                                                             uint32_t * __restrict__ keys, uint16_t * __restrict__ slots,
-                                                             uint16_t * __restrict__ tile_hist /* [tiles][B] */)
+// per slice: first key (fstart) and first work item (ioff; an item = at most kItemKeys keys of one slice)
+__global__ __launch_bounds__(1024) void k_sr_fine_scan(unsigned nf, const uint32_t * __restrict__ fine_count,
+                                                       uint32_t * __restrict__ fstart, uint32_t * __restrict__ ioff)
 {
-    __shared__ uint32_t sorted[kSrTile];
-    __shared__ unsigned hist[kSrBMax];  // counts of the tile, kept beside their scan
-    __shared__ unsigned start[kSrBMax]; // exclusive scan
-    __shared__ unsigned cursor[kSrBMax];
-    __shared__ unsigned wsum[kSrThreads / 64 + 1];
-    __shared__ unsigned big[256], n_big;
+    __shared__ unsigned wk[17], wi[17];
     const unsigned t = threadIdx.x;
-    for (unsigned b = t; b < kSrBMax; b += kSrThreads)
-        cursor[b] = b < g.B ? offs[(uint64_t)b * g.G + blockIdx.x] : 0;
-    uint64_t tlo, thi;
-    sr_share(g, blockIdx.x, tlo, thi);
-    for (uint64_t tile = tlo; tile < thi; ++tile)
+    const unsigned per = (nf + 1023) / 1024;
+    const unsigned lo = t * per, hi = lo + per < nf ? lo + per : nf;
+    unsigned sk = 0, si = 0;
+    for (unsigned f = lo; f < hi; ++f)
     {
-        for (unsigned b = t; b < kSrBMax; b += kSrThreads)
-            hist[b] = 0;
+        const unsigned c = fine_count[f];
+        sk += c;
+        si += (c + kItemKeys - 1) / kItemKeys;
+    }
+    const unsigned ik = wave_incl_scan(sk), ii = wave_incl_scan(si);
+    if ((t & 63) == 63)
+    {
+        wk[t >> 6] = ik;
+        wi[t >> 6] = ii;
+    }
+    __syncthreads();
+    unsigned bk = ik - sk, bi = ii - si;
+    for (unsigned w = 0; w < (t >> 6); ++w)
+    {
+        bk += wk[w];
+        bi += wi[w];
+    }
+    for (unsigned f = lo; f < hi; ++f)
+    {
+        const unsigned c = fine_count[f];
+        fstart[f] = bk;
+        ioff[f] = bi;
+        bk += c;
+        bi += (c + kItemKeys - 1) / kItemKeys;
+    }
+    if (t == 1023)
+    { // threads past the end have empty ranges, so the last thread holds the totals
+        fstart[nf] = bk;
+        ioff[nf] = bi;
+    }
+}
+
+// ones in front of every slice (what makes a slice-relative answer absolute)
+__global__ __launch_bounds__(256) void k_sr_slice_bases(BvView bv, unsigned nf, uint64_t * __restrict__ hf)
+{
+    const unsigned f = blockIdx.x * 256 + threadIdx.x;
+    if (f < nf)
+    {
+        const uint64_t L0 = (uint64_t)f << kSliceLog;
+        hf[f] = L0 < bv.n_lines ? bv.lines[L0 * kLW] : 0;
+    }
+}
+
+// Runs of a sorted tile <-> the bin-major array: kLanes lanes per bin, the first element of every run of kUn bins is
+// fetched before any is consumed (the loop-carried LDS traffic otherwise serialises the global accesses).
+template <unsigned TT>
+struct RunShape
+{
+    static constexpr unsigned kLanes = 16;
+    static constexpr unsigned kBinsPerIter = TT / kLanes;
+};
+
+// ---- a partition pass -------------------------------------------------------------------------------------------
+template <int P, unsigned TT>
+__global__ __launch_bounds__(TT) void k_sr_partition(SrGeom g, const uint64_t * __restrict__ idx,
+                                                     const uint32_t * __restrict__ keys_in,
+                                                     const uint32_t * __restrict__ tprefix, const uint32_t * __restrict__ gstart,
+                                                     const uint32_t * __restrict__ offs, uint32_t * __restrict__ keys_out,
+                                                     uint16_t * __restrict__ slots, uint16_t * __restrict__ tile_hist)
+{
+    constexpr unsigned kTile = TT * kPer;
+    __shared__ uint32_t sorted[kTile];
+    __shared__ unsigned hist[kBins], start[kBins], cursor[kBins];
+    __shared__ unsigned wsum[kBins / 64];
+    __shared__ unsigned big[kTile / (kBigRun + 1) + 1], n_big;
+    __shared__ TileMap map;
+    const unsigned t = threadIdx.x;
+    const unsigned bins = 1u << (P == 1 ? g.d1 : g.d2);
+    sr_load_map<P, TT>(g, map, tprefix, gstart);
+    for (unsigned i = t; i < kBins; i += TT)
+        cursor[i] = i < bins ? offs[(uint64_t)i * g.G + blockIdx.x] : 0;
+    __syncthreads();
+    const unsigned nt = sr_tiles<P>(g, map);
+    const unsigned tlo = (unsigned)((uint64_t)nt * blockIdx.x / g.G), thi = (unsigned)((uint64_t)nt * (blockIdx.x + 1) / g.G);
+    for (unsigned ti = tlo; ti < thi; ++ti)
+    {
+        uint64_t lo, hi;
+        unsigned grp;
+        sr_tile_range<P, TT>(g, map, ti, lo, hi, grp);
+        for (unsigned i = t; i < kBins; i += TT)
+            hist[i] = 0;
         if (t == 0)
             n_big = 0;
         __syncthreads();
-        const uint64_t q0 = tile * kSrTile + t;
-        uint64_t p[kSrPer];
+        uint32_t key[kPer];
+        unsigned br[kPer]; // bin << 16 | rank inside the tile's share of the bin
+        sr_load_keys<P, TT>(g, idx, keys_in, lo, hi, br, key);
 #pragma unroll
-        for (unsigned u = 0; u < kSrPer; ++u)
+        for (unsigned u = 0; u < kPer; ++u)
         {
-            const uint64_t q = q0 + (uint64_t)u * kSrThreads;
-            p[u] = q < g.n ? __builtin_nontemporal_load(idx + q) : ~UINT64_C(0);
-        }
-        uint32_t key[kSrPer], br[kSrPer]; // br = bucket << 16 | rank inside the tile's share of the bucket
-#pragma unroll
-        for (unsigned u = 0; u < kSrPer; ++u)
-        {
-            const uint64_t q = q0 + (uint64_t)u * kSrThreads;
-            unsigned b = 0;
-            key[u] = kSrBad;
-            br[u] = 0;
-            if (q < g.n)
-            {
-                sr_key(p[u], n_bits, g, b, key[u]);
-                const unsigned r = atomicAdd(&hist[b], 1u);
-                br[u] = (b << 16) | r; // r < 16384, b < 3072
-            }
+            const uint64_t q = lo + (uint64_t)u * TT + t;
+            const unsigned d = br[u];
+            br[u] = d << 16;
+            if (q < hi)
+                br[u] |= atomicAdd(&hist[d], 1u); // < 2^14
         }
         __syncthreads();
-        for (unsigned b = t; b < kSrBMax; b += kSrThreads)
-            start[b] = hist[b];
+        for (unsigned i = t; i < kBins; i += TT)
+            start[i] = hist[i];
         __syncthreads();
-        block_excl_scan3(start, wsum);
-        for (unsigned b = t; b < g.B; b += kSrThreads)
-            tile_hist[tile * g.B + b] = (uint16_t)hist[b];
+        block_excl_scan_bins(start, wsum);
+        for (unsigned i = t; i < bins; i += TT)
+            tile_hist[(uint64_t)ti * bins + i] = (uint16_t)hist[i];
 #pragma unroll
-        for (unsigned u = 0; u < kSrPer; ++u)
+        for (unsigned u = 0; u < kPer; ++u)
         {
-            const uint64_t q = q0 + (uint64_t)u * kSrThreads;
-            if (q < g.n)
+            const uint64_t q = lo + (uint64_t)u * TT + t;
+            if (q < hi)
             {
                 const unsigned pos = start[br[u] >> 16] + (br[u] & 0xFFFFu);
                 sorted[pos] = key[u];
@@ -279,186 +489,22 @@ __global__ __launch_bounds__(kSrThreads) void k_sr_partition(uint64_t n_bits, Sr
             }
         }
         __syncthreads();
-        { // runs out: 8 lanes per bucket
-            const unsigned l = t & 7;
-            for (unsigned b = t >> 3; b < g.B; b += kSrThreads / 8)
+        { // runs out: 16 lanes per bin
+            const unsigned l = t & 15;
+            for (unsigned b = t >> 4; b < bins; b += TT / 16)
             {
                 const unsigned cnt = hist[b];
                 if (cnt == 0)
                     continue;
                 const unsigned st = start[b], cur = cursor[b];
-                if (cnt > kSrBigRun)
-                {
-                    if (l == 0)
-                        big[atomicAdd(&n_big, 1u)] = b; // at most kSrTile / (kSrBigRun + 1) = 252 of them
-                    continue;
-                }
-                for (unsigned i = l; i < cnt; i += 8)
-                    keys[(uint64_t)cur + i] = sorted[st + i];
-            }
-        }
-        __syncthreads();
-        const unsigned nb = n_big;
-        for (unsigned k = 0; k < nb; ++k)
-        {
-            const unsigned b = big[k], cnt = hist[b], st = start[b], cur = cursor[b];
-            for (unsigned i = t; i < cnt; i += kSrThreads)
-                keys[(uint64_t)cur + i] = sorted[st + i];
-        }
-        __syncthreads();
-        for (unsigned b = t; b < g.B; b += kSrThreads)
-            cursor[b] += hist[b];
-        __syncthreads();
-    }
-}
-
-// ---- 4. rank over the sorted keys, in place ------------------------------------------------------------------------
-// 256 threads = 64 quads.  XCD x (= blockIdx % 8, the observed placement; any placement is correct) takes the x-th
-// eighth of the sorted array in chunks of kSrChunk, its blocks interleaved, so the blocks of an XCD stay within a
-// window of a few hundred thousand keys = one or two buckets = 1-2 MiB of index in that XCD's 4 MiB L2.
-constexpr unsigned kSrChunk = 2048;
-
-template <int U>
-__global__ __launch_bounds__(256) void k_sr_rank(BvView bv, int bit, SrGeom g, const uint32_t * __restrict__ bstart,
-                                                 uint32_t * __restrict__ keys)
-{
-    __shared__ unsigned sh_b;
-    const int s = threadIdx.x & (kG - 1);
-    const unsigned gq = threadIdx.x / kG;
-    const unsigned xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nbx = gridDim.x >> 3;
-    const uint64_t n_chunks = (g.n + kSrChunk - 1) / kSrChunk;
-    const uint64_t c_lo = n_chunks * xcd / 8, c_hi = n_chunks * (xcd + 1) / 8;
-    for (uint64_t c = c_lo + j; c < c_hi; c += nbx)
-    {
-        uint64_t lo = c * kSrChunk;
-        const uint64_t chi = lo + kSrChunk < g.n ? lo + kSrChunk : g.n;
-        if (threadIdx.x == 0)
-        { // last bucket whose start is <= lo
-            unsigned a = 0, z = g.B; // invariant: bstart[a] <= lo, bstart[z] > lo or z == B
-            while (z - a > 1)
-            {
-                const unsigned m = (a + z) >> 1;
-                if (bstart[m] <= lo)
-                    a = m;
-                else
-                    z = m;
-            }
-            sh_b = a;
-        }
-        __syncthreads();
-        unsigned b = sh_b;
-        __syncthreads();
-        while (lo < chi)
-        {
-            const uint64_t bend = bstart[b + 1];
-            const uint64_t hi = bend < chi ? bend : chi;
-            if (hi > lo)
-            {
-                const uint64_t L0 = (uint64_t)b << g.k;
-                const uint64_t H = bv.lines[L0 * kLW];
-                for (uint64_t base = lo; base < hi; base += 64 * U)
-                {
-                    uint32_t key[U];
-                    Pair w[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-                    {
-                        const uint64_t q = base + (uint64_t)u * 64 + gq;
-                        key[u] = q < hi ? __builtin_nontemporal_load(keys + q) : kSrBad;
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        w[u] = load_pair<false>(bv.lines, key[u] == kSrBad ? L0 : L0 + (key[u] >> kSrOffBits), s);
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-                    {
-                        const uint64_t q = base + (uint64_t)u * 64 + gq;
-                        const unsigned off = key[u] & ((1u << kSrOffBits) - 1);
-                        const uint64_t r1 = quad_rank1_at(w[u], s, off) - H;
-                        uint32_t r = (uint32_t)r1;
-                        if (!bit)
-                            r = (uint32_t)((uint64_t)(key[u] >> kSrOffBits) * kDB + off - r1);
-                        if (key[u] == kSrBad)
-                            r = kSrBad;
-                        if (s == 0 && q < hi)
-                            __builtin_nontemporal_store(r, keys + q);
-                    }
-                }
-            }
-            lo = hi;
-            if (lo < chi)
-                ++b;
-        }
-    }
-}
-
-// ---- 5. back into the caller's order --------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSrThreads) void k_sr_unpermute(BvView bv, int bit, SrGeom g,
-                                                             const uint32_t * __restrict__ offs,
-                                                             const uint32_t * __restrict__ res,
-                                                             const uint16_t * __restrict__ slots,
-                                                             const uint16_t * __restrict__ tile_hist,
-                                                             uint64_t * __restrict__ out)
-{
-    __shared__ uint32_t lo32[kSrTile];
-    __shared__ uint8_t hi8[kSrTile];
-    __shared__ unsigned hist[kSrBMax];
-    __shared__ unsigned start[kSrBMax];
-    __shared__ unsigned cursor[kSrBMax];
-    __shared__ uint64_t hb[kSrBMax]; // what turns a bucket-relative answer into the absolute one
-    __shared__ unsigned wsum[kSrThreads / 64 + 1];
-    __shared__ unsigned big[256], n_big;
-    const unsigned t = threadIdx.x;
-    for (unsigned b = t; b < kSrBMax; b += kSrThreads)
-    {
-        cursor[b] = b < g.B ? offs[(uint64_t)b * g.G + blockIdx.x] : 0;
-        uint64_t h = 0;
-        if (b < g.B)
-        {
-            const uint64_t L0 = (uint64_t)b << g.k;
-            h = bv.lines[L0 * kLW];
-            if (!bit)
-                h = L0 * kDB - h;
-        }
-        hb[b] = h;
-    }
-    uint64_t tlo, thi;
-    sr_share(g, blockIdx.x, tlo, thi);
-    for (uint64_t tile = tlo; tile < thi; ++tile)
-    {
-        for (unsigned b = t; b < kSrBMax; b += kSrThreads)
-        {
-            const unsigned c = b < g.B ? tile_hist[tile * g.B + b] : 0;
-            hist[b] = c;
-            start[b] = c;
-        }
-        if (t == 0)
-            n_big = 0;
-        __syncthreads();
-        block_excl_scan3(start, wsum);
-        auto put = [&](unsigned b, unsigned st, unsigned cur, unsigned i)
-        {
-            const uint32_t v = res[(uint64_t)cur + i];
-            const uint64_t full = hb[b] + v;
-            lo32[st + i] = (uint32_t)full;
-            hi8[st + i] = v == kSrBad ? (uint8_t)0xFF : (uint8_t)(full >> 32);
-        };
-        {
-            const unsigned l = t & 7;
-            for (unsigned b = t >> 3; b < g.B; b += kSrThreads / 8)
-            {
-                const unsigned cnt = hist[b];
-                if (cnt == 0)
-                    continue;
-                const unsigned st = start[b], cur = cursor[b];
-                if (cnt > kSrBigRun)
+                if (cnt > kBigRun)
                 {
                     if (l == 0)
                         big[atomicAdd(&n_big, 1u)] = b;
                     continue;
                 }
-                for (unsigned i = l; i < cnt; i += 8)
-                    put(b, st, cur, i);
+                for (unsigned i = l; i < cnt; i += 16)
+                    keys_out[(uint64_t)cur + i] = sorted[st + i];
             }
         }
         __syncthreads();
@@ -466,31 +512,287 @@ __global__ __launch_bounds__(kSrThreads) void k_sr_unpermute(BvView bv, int bit,
         for (unsigned k = 0; k < nb; ++k)
         {
             const unsigned b = big[k], cnt = hist[b], st = start[b], cur = cursor[b];
-            for (unsigned i = t; i < cnt; i += kSrThreads)
-                put(b, st, cur, i);
+            for (unsigned i = t; i < cnt; i += TT)
+                keys_out[(uint64_t)cur + i] = sorted[st + i];
         }
         __syncthreads();
-        const uint64_t q0 = tile * kSrTile + t;
-        uint16_t sl[kSrPer];
-#pragma unroll
-        for (unsigned u = 0; u < kSrPer; ++u)
-        {
-            const uint64_t q = q0 + (uint64_t)u * kSrThreads;
-            sl[u] = q < g.n ? __builtin_nontemporal_load(slots + q) : (uint16_t)0;
-        }
-#pragma unroll
-        for (unsigned u = 0; u < kSrPer; ++u)
-        {
-            const uint64_t q = q0 + (uint64_t)u * kSrThreads;
-            if (q < g.n)
+        for (unsigned i = t; i < kBins; i += TT)
+            cursor[i] += hist[i];
+        __syncthreads();
+    }
+}
+
+// ---- rank out of LDS, in place over the final keys -----------------------------------------------------------------
+__global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigned nf, const uint32_t * __restrict__ fstart,
+                                                     const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys)
+{
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    __shared__ v2u64 slice[(kLW << kSliceLog) / 2]; // 64 KiB
+    __shared__ unsigned sh_f;
+    constexpr int U = 8;
+    const unsigned t = threadIdx.x;
+    const unsigned n_items = ioff[nf];
+    for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x)
+    {
+        if (t == 0)
+        { // the slice of this item: last f with ioff[f] <= item (empty slices have no items and are skipped over)
+            unsigned a = 0, z = nf;
+            while (a + 1 < z)
             {
-                const unsigned h = hi8[sl[u]];
-                const uint64_t r = h == 0xFFu ? SDSL_HIP_NPOS : ((uint64_t)h << 32) | lo32[sl[u]];
-                __builtin_nontemporal_store(r, out + q);
+                const unsigned m = (a + z) >> 1;
+                if (ioff[m] <= item)
+                    a = m;
+                else
+                    z = m;
+            }
+            sh_f = a;
+        }
+        __syncthreads(); // also: everybody is done with the previous slice
+        const unsigned f = sh_f;
+        const uint64_t L0 = (uint64_t)f << kSliceLog;
+        const uint64_t nl = bv.n_lines - L0 < (UINT64_C(1) << kSliceLog) ? bv.n_lines - L0 : (UINT64_C(1) << kSliceLog);
+        const v2u64 * src = reinterpret_cast<const v2u64 *>(bv.lines + L0 * kLW);
+        for (unsigned i = t; i < nl * (kLW / 2); i += kRT)
+            slice[i] = __builtin_nontemporal_load(src + i);
+        const uint64_t lo = (uint64_t)fstart[f] + (uint64_t)(item - ioff[f]) * kItemKeys;
+        const uint64_t fend = fstart[f + 1];
+        const uint64_t hi = lo + kItemKeys < fend ? lo + kItemKeys : fend;
+        __syncthreads();
+        const uint64_t H = slice[0].x;
+        for (uint64_t q0 = lo + t; q0 < hi; q0 += (uint64_t)kRT * U)
+        {
+            uint32_t key[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                const uint64_t q = q0 + (uint64_t)u * kRT;
+                key[u] = q < hi ? __builtin_nontemporal_load(keys + q) : kBad;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                const uint64_t q = q0 + (uint64_t)u * kRT;
+                const unsigned ln = key[u] == kBad ? 0 : key[u] >> kOffBits;
+                const unsigned off = key[u] & ((1u << kOffBits) - 1);
+                const v2u64 * w = slice + ln * (kLW / 2);
+                // ones below in-line offset `off`: word j contributes its low clamp(off - 64 j, 0, 64) bits; only the
+                // 16-byte quarters that hold such words are read (exec-masked LDS reads: fewer bank conflicts)
+                auto low = [&](uint64_t x, int j) -> unsigned
+                {
+                    const int tt = (int)off - 64 * j;
+                    return tt <= 0 ? 0u : (tt >= 64 ? popc64(x) : popc64(x << (64 - tt)));
+                };
+                const v2u64 a = w[0];
+                unsigned cnt = low(a.y, 0);
+                if (off > 64)
+                {
+                    const v2u64 b = w[1];
+                    cnt += low(b.x, 1) + low(b.y, 2);
+                }
+                if (off > 192)
+                {
+                    const v2u64 c = w[2];
+                    cnt += low(c.x, 3) + low(c.y, 4);
+                }
+                if (off > 320)
+                {
+                    const v2u64 d = w[3];
+                    cnt += low(d.x, 5) + low(d.y, 6);
+                }
+                const uint32_t r1 = (uint32_t)(a.x - H) + cnt;
+                uint32_t r = bit ? r1 : ln * (uint32_t)kDB + off - r1;
+                if (key[u] == kBad)
+                    r = kBad;
+                if (q < hi)
+                    __builtin_nontemporal_store(r, keys + q);
             }
         }
-        for (unsigned b = t; b < g.B; b += kSrThreads)
-            cursor[b] += hist[b];
+    }
+}
+
+// ---- the way back ---------------------------------------------------------------------------------------------------
+// P == 2: slice-relative answers (order of partition 2) -> absolute answers in the order of partition 1 (lo32 / hi8)
+// P == 1: absolute answers in the order of partition 1 -> the caller's array
+// V & 1: the runs are fetched four bins at a time (else bin after bin); V & 2: the slots are asked for before the gather
+template <int P, unsigned TT, int V>
+__global__ __launch_bounds__(TT) void k_sr_unpermute(const uint64_t * __restrict__ hf, int bit, SrGeom g, const uint32_t * __restrict__ tprefix,
+                                                     const uint32_t * __restrict__ gstart, const uint32_t * __restrict__ offs,
+                                                     const uint32_t * __restrict__ res_lo, const uint8_t * __restrict__ res_hi,
+                                                     const uint16_t * __restrict__ slots,
+                                                     const uint16_t * __restrict__ tile_hist, uint32_t * __restrict__ out_lo,
+                                                     uint8_t * __restrict__ out_hi, uint64_t * __restrict__ out)
+{
+    constexpr unsigned kTile = TT * kPer;
+    __shared__ uint32_t lo32[kTile];
+    __shared__ uint8_t hi8[kTile];
+    __shared__ unsigned hist[kBins], start[kBins], cursor[kBins];
+    __shared__ unsigned wsum[kBins / 64];
+    __shared__ unsigned big[kTile / (kBigRun + 1) + 1], n_big;
+    __shared__ TileMap map;
+    const unsigned t = threadIdx.x;
+    const unsigned bins = 1u << (P == 1 ? g.d1 : g.d2);
+    sr_load_map<P, TT>(g, map, tprefix, gstart);
+    for (unsigned i = t; i < kBins; i += TT)
+        cursor[i] = i < bins ? offs[(uint64_t)i * g.G + blockIdx.x] : 0;
+    __syncthreads();
+    const unsigned nt = sr_tiles<P>(g, map);
+    const unsigned tlo = (unsigned)((uint64_t)nt * blockIdx.x / g.G), thi = (unsigned)((uint64_t)nt * (blockIdx.x + 1) / g.G);
+    for (unsigned ti = tlo; ti < thi; ++ti)
+    {
+        uint64_t lo, hi;
+        unsigned grp;
+        sr_tile_range<P, TT>(g, map, ti, lo, hi, grp);
+        uint16_t sl[kPer];
+        if (V & 2)
+        { // the slots of this tile: asked for now, used after the gather
+#pragma unroll
+            for (unsigned u = 0; u < kPer; ++u)
+            {
+                const uint64_t q = lo + (uint64_t)u * TT + t;
+                sl[u] = q < hi ? __builtin_nontemporal_load(slots + q) : (uint16_t)0;
+            }
+        }
+        for (unsigned i = t; i < kBins; i += TT)
+        {
+            const unsigned c = i < bins ? tile_hist[(uint64_t)ti * bins + i] : 0;
+            hist[i] = c;
+            start[i] = c;
+        }
+        if (t == 0)
+            n_big = 0;
+        __syncthreads();
+        block_excl_scan_bins(start, wsum);
+        // what turns the answers of bin b of this tile into absolute ones (pass 2: the slice's first header)
+        auto base_of = [&](unsigned b) -> uint64_t
+        {
+            if (P == 1)
+                return 0;
+            const unsigned f = (b << g.d1) | grp;
+            const uint64_t h = hf[f]; // ones in front of the slice (0 for slices past the end: only NPOS keys live there)
+            return bit ? h : ((uint64_t)f << kSliceLog) * kDB - h;
+        };
+        auto keep = [&](uint64_t base, unsigned at, uint32_t v, uint8_t h)
+        {
+            if (P == 2)
+            {
+                const uint64_t full = base + v;
+                lo32[at] = (uint32_t)full;
+                hi8[at] = v == kBad ? (uint8_t)0xFF : (uint8_t)(full >> 32);
+            }
+            else
+            {
+                lo32[at] = v;
+                hi8[at] = h;
+            }
+        };
+        if (!(V & 1))
+        {
+            const unsigned l = t & 15;
+            for (unsigned b = t >> 4; b < bins; b += TT / 16)
+            {
+                const unsigned cnt = hist[b];
+                if (cnt == 0)
+                    continue;
+                const unsigned st = start[b], cur = cursor[b];
+                if (cnt > kBigRun)
+                {
+                    if (l == 0)
+                        big[atomicAdd(&n_big, 1u)] = b;
+                    continue;
+                }
+                const uint64_t base = base_of(b);
+                for (unsigned i = l; i < cnt; i += 16)
+                    keep(base, st + i, res_lo[(uint64_t)cur + i], P == 1 ? res_hi[(uint64_t)cur + i] : (uint8_t)0);
+            }
+        }
+        else
+        {
+            constexpr unsigned kIter = kBins / (TT / 16); // bins a lane group walks
+            constexpr unsigned kCh = 4;                   // ... four at a time: their first elements are in flight together
+            const unsigned l = t & 15;
+#pragma unroll 1
+            for (unsigned j0 = 0; j0 < kIter; j0 += kCh)
+            {
+                unsigned cnt[kCh], st[kCh], cur[kCh];
+                uint32_t v[kCh];
+                uint8_t h8[kCh];
+                uint64_t base[kCh];
+#pragma unroll
+                for (unsigned j = 0; j < kCh; ++j)
+                {
+                    const unsigned b = (t >> 4) + (j0 + j) * (TT / 16);
+                    cnt[j] = b < bins ? hist[b] : 0;
+                    st[j] = start[b & (kBins - 1)];
+                    cur[j] = cursor[b & (kBins - 1)];
+                }
+#pragma unroll
+                for (unsigned j = 0; j < kCh; ++j)
+                {
+                    const bool on = l < cnt[j] && cnt[j] <= kBigRun;
+                    v[j] = on ? res_lo[(uint64_t)cur[j] + l] : 0;
+                    h8[j] = (P == 1 && on) ? res_hi[(uint64_t)cur[j] + l] : (uint8_t)0;
+                    base[j] = (P == 2 && on) ? base_of((t >> 4) + (j0 + j) * (TT / 16)) : 0;
+                }
+#pragma unroll
+                for (unsigned j = 0; j < kCh; ++j)
+                {
+                    const unsigned b = (t >> 4) + (j0 + j) * (TT / 16);
+                    if (cnt[j] == 0)
+                        continue;
+                    if (cnt[j] > kBigRun)
+                    {
+                        if (l == 0)
+                            big[atomicAdd(&n_big, 1u)] = b;
+                        continue;
+                    }
+                    if (l < cnt[j])
+                        keep(base[j], st[j] + l, v[j], h8[j]);
+                    for (unsigned i = l + 16; i < cnt[j]; i += 16)
+                    {
+                        const uint64_t bs = P == 2 ? base_of(b) : 0;
+                        keep(bs, st[j] + i, res_lo[(uint64_t)cur[j] + i], P == 1 ? res_hi[(uint64_t)cur[j] + i] : (uint8_t)0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned nb = n_big;
+        for (unsigned k = 0; k < nb; ++k)
+        {
+            const unsigned b = big[k], c = hist[b], s0 = start[b], cu = cursor[b];
+            const uint64_t base = base_of(b);
+            for (unsigned i = t; i < c; i += TT)
+                keep(base, s0 + i, res_lo[(uint64_t)cu + i], P == 1 ? res_hi[(uint64_t)cu + i] : (uint8_t)0);
+        }
+        __syncthreads();
+        if (!(V & 2))
+        {
+#pragma unroll
+            for (unsigned u = 0; u < kPer; ++u)
+            {
+                const uint64_t q = lo + (uint64_t)u * TT + t;
+                sl[u] = q < hi ? __builtin_nontemporal_load(slots + q) : (uint16_t)0;
+            }
+        }
+#pragma unroll
+        for (unsigned u = 0; u < kPer; ++u)
+        {
+            const uint64_t q = lo + (uint64_t)u * TT + t;
+            if (q < hi)
+            {
+                const unsigned h = hi8[sl[u]];
+                const uint32_t l32 = lo32[sl[u]];
+                if (P == 2)
+                {
+                    __builtin_nontemporal_store(l32, out_lo + q);
+                    __builtin_nontemporal_store((uint8_t)h, out_hi + q);
+                }
+                else
+                    __builtin_nontemporal_store(h == 0xFFu ? SDSL_HIP_NPOS : ((uint64_t)h << 32) | l32, out + q);
+            }
+        }
+        for (unsigned i = t; i < kBins; i += TT)
+            cursor[i] += hist[i];
         __syncthreads();
     }
 }
@@ -499,7 +801,7 @@ struct PhaseTimer
 {
     bool on;
     hipStream_t s;
-    hipEvent_t ev[8];
+    hipEvent_t ev[12];
     int n = 0;
     PhaseTimer(bool on_, hipStream_t s_) : on(on_), s(s_)
     {
@@ -509,7 +811,7 @@ struct PhaseTimer
     }
     void mark()
     {
-        if (on && n < 8)
+        if (on && n < 12)
             (void)hipEventRecord(ev[n++], s);
     }
     void report(const SrGeom & g)
@@ -517,15 +819,15 @@ struct PhaseTimer
         if (!on)
             return;
         (void)hipEventSynchronize(ev[n - 1]);
-        static const char * name[] = {"hist", "offsets", "partition", "rank", "unpermute"};
+        static const char * name[] = {"hist1", "offs1", "part1", "hist2", "offs2", "part2", "slices", "rank", "unperm2", "unperm1"};
         float total = 0;
-        fprintf(stderr, "[sdsl_hip] sorted rank: n=%llu B=%u k=%u G=%u |", (unsigned long long)g.n, g.B, g.k, g.G);
+        fprintf(stderr, "[sdsl_hip] sorted rank: n=%llu d1=%u d2=%u G=%u |", (unsigned long long)g.n, g.d1, g.d2, g.G);
         for (int i = 0; i + 1 < n; ++i)
         {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
             total += ms;
-            fprintf(stderr, " %s %.3f ms", name[i], ms);
+            fprintf(stderr, " %s %.3f", name[i], ms);
         }
         fprintf(stderr, " | total %.3f ms = %.2f G/s\n", total, g.n / total / 1e6);
     }
@@ -537,86 +839,167 @@ struct PhaseTimer
     }
 };
 
+constexpr uint64_t kMaxPass = UINT64_C(1) << 30; // positions per pass over the batch (32-bit cursors)
+constexpr unsigned kMaxG = 2048;                 // partition blocks (k_sr_bucket_offsets: 8 per thread)
+
+size_t carve(SrBuf & b, void * scratch, uint64_t n, unsigned tile)
+{
+    uint8_t * p = (uint8_t *)scratch;
+    auto take = [&](size_t bytes) -> void *
+    {
+        void * r = p;
+        p += (bytes + 255) & ~(size_t)255;
+        return r;
+    };
+    const uint64_t tiles1 = (n + tile - 1) / tile, tiles2 = tiles1 + kBins;
+    b.keys1 = (uint32_t *)take(n * 4);
+    b.keys2 = (uint32_t *)take(n * 4);
+    b.slots1 = (uint16_t *)take(n * 2);
+    b.slots2 = (uint16_t *)take(n * 2);
+    b.hi8 = (uint8_t *)take(n);
+    b.thist1 = (uint16_t *)take(tiles1 * kBins * 2);
+    b.thist2 = (uint16_t *)take(tiles2 * kBins * 2);
+    b.counts1 = (uint32_t *)take((size_t)kBins * kMaxG * 4);
+    b.offs1 = (uint32_t *)take((size_t)kBins * kMaxG * 4);
+    b.counts2 = (uint32_t *)take((size_t)kBins * kMaxG * 4);
+    b.offs2 = (uint32_t *)take((size_t)kBins * kMaxG * 4);
+    b.bstart1 = (uint32_t *)take((kBins + 1) * 4);
+    b.bstart2 = (uint32_t *)take((kBins + 1) * 4);
+    b.btot = (uint32_t *)take((kBins + 1) * 4);
+    b.tprefix2 = (uint32_t *)take((kBins + 1) * 4);
+    b.fine_count = (uint32_t *)take((size_t)kBins * kBins * 4);
+    b.fstart = (uint32_t *)take(((size_t)kBins * kBins + 1) * 4);
+    b.ioff = (uint32_t *)take(((size_t)kBins * kBins + 1) * 4);
+    b.hf = (uint64_t *)take((size_t)kBins * kBins * 8);
+    return (size_t)(p - (uint8_t *)scratch);
+}
+
+// the partition / un-permute kernels of one block size
+struct SrKernels
+{
+    void (*hist1)(SrGeom, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
+    void (*hist2)(SrGeom, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *);
+    void (*part1)(SrGeom, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *,
+                  uint16_t *, uint16_t *);
+    void (*part2)(SrGeom, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *,
+                  uint16_t *, uint16_t *);
+    void (*unp2)(const uint64_t *, int, SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint8_t *,
+                 const uint16_t *, const uint16_t *, uint32_t *, uint8_t *, uint64_t *);
+    void (*unp1)(const uint64_t *, int, SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint8_t *,
+                 const uint16_t *, const uint16_t *, uint32_t *, uint8_t *, uint64_t *);
+    unsigned threads, blocks_per_cu;
+};
+template <unsigned TT, int V>
+SrKernels sr_kernels_v(unsigned per_cu)
+{
+    return SrKernels{k_sr_hist<1, TT>,         k_sr_hist<2, TT>,         k_sr_partition<1, TT>, k_sr_partition<2, TT>,
+                     k_sr_unpermute<2, TT, V>, k_sr_unpermute<1, TT, V>, TT,                    per_cu};
+}
+template <unsigned TT>
+SrKernels sr_kernels(unsigned per_cu, int variant)
+{
+    switch (variant & 3)
+    {
+    case 0: return sr_kernels_v<TT, 0>(per_cu);
+    case 1: return sr_kernels_v<TT, 1>(per_cu);
+    case 2: return sr_kernels_v<TT, 2>(per_cu);
+    default: return sr_kernels_v<TT, 3>(per_cu);
+    }
+}
+
 } // namespace
 
-// scratch per position: 4 (key / answer) + 2 (slot) bytes, + 2 B per (tile, bucket) + the offset tables
+// scratch: 13 bytes per position (two key arrays, two slot arrays, the high answer byte) + the tables
 size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n)
 {
     (void)v;
-    const uint64_t tiles = (n + kSrTile - 1) / kSrTile;
-    return (size_t)(n * 6 + tiles * kSrBMax * 2 + (size_t)kSrBMax * 1024 * 8 + (1u << 16));
+    SrBuf b;
+    return carve(b, nullptr, n < kMaxPass ? n : kMaxPass, 256 * kPer) + 4096;
+}
+
+bool bv_sorted_rank_possible(const BvView & v)
+{
+    return v.n_lines >= 2 && v.n_lines <= (UINT64_C(1) << (kSliceLog + 16));
 }
 
 bool bv_sorted_rank_applicable(const BvView & v, uint64_t n)
 {
     // worth it when the index is much larger than the L2s (else the direct kernel already hits) and the batch
     // addresses every line several times
-    return v.n_lines >= (UINT64_C(1) << 19) && n >= (UINT64_C(1) << 24) && n >= 4 * v.n_lines;
+    return bv_sorted_rank_possible(v) && v.n_lines >= (UINT64_C(1) << 19) && n >= (UINT64_C(1) << 24) && n >= 4 * v.n_lines;
 }
 
 sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                                       hipStream_t s, void * scratch, size_t scratch_bytes)
 {
     static const bool trace = getenv("SDSL_HIP_TRACE_SORTED") != nullptr;
-    static const int k_env = getenv("SDSL_HIP_SORTED_K") ? atoi(getenv("SDSL_HIP_SORTED_K")) : 0;
+    static const int t_env = getenv("SDSL_HIP_SORTED_THREADS") ? atoi(getenv("SDSL_HIP_SORTED_THREADS")) : 0;
     static const int g_env = getenv("SDSL_HIP_SORTED_G") ? atoi(getenv("SDSL_HIP_SORTED_G")) : 0;
     static const int rb_env = getenv("SDSL_HIP_SORTED_RANK_BLOCKS") ? atoi(getenv("SDSL_HIP_SORTED_RANK_BLOCKS")) : 0;
-    const uint64_t kMaxPass = UINT64_C(1) << 30; // positions per pass (32-bit cursors)
+    if (!bv_sorted_rank_possible(v))
+    {
+        set_error("rank_sorted: vector too large for the bucketed path");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    static const int v_env = getenv("SDSL_HIP_SORTED_VARIANT") ? atoi(getenv("SDSL_HIP_SORTED_VARIANT")) : 0;
+    const SrKernels K = t_env == 512 ? sr_kernels<512>(2, v_env) : sr_kernels<256>(4, v_env);
     for (uint64_t done = 0; done < n;)
     {
         const uint64_t cnt = n - done < kMaxPass ? n - done : kMaxPass;
         SrGeom g;
-        g.k = k_env >= 8 && k_env <= 22 ? (uint32_t)k_env : 14;
-        while (((v.n_lines + (UINT64_C(1) << g.k) - 1) >> g.k) > kSrBMax)
-            ++g.k;
-        if (g.k > 22)
-        {
-            set_error("rank_sorted: vector too large for the bucketed path");
-            return SDSL_HIP_ERR_INVALID;
-        }
-        g.B = (uint32_t)((v.n_lines + (UINT64_C(1) << g.k) - 1) >> g.k);
         g.n = cnt;
-        g.tiles = (cnt + kSrTile - 1) / kSrTile;
-        g.G = g_env >= 1 && g_env <= 1024 ? (uint32_t)g_env : 256;
-        if (g.G > g.tiles)
-            g.G = (uint32_t)g.tiles;
+        g.n_bits = v.n_bits;
+        g.n_lines = v.n_lines;
+        unsigned lb = 0; // bits of a line index
+        while ((v.n_lines - 1) >> lb)
+            ++lb;
+        const unsigned f = lb > kSliceLog ? lb - kSliceLog : 0;
+        g.d1 = f < 8 ? f : 8;
+        g.d2 = f - g.d1;
+        g.tile = K.threads * kPer;
+        g.tiles1 = (uint32_t)((cnt + g.tile - 1) / g.tile);
+        g.G = g_env >= 1 && g_env <= (int)kMaxG ? (uint32_t)g_env : 256u * K.blocks_per_cu;
         g.small = v.n_bits < (UINT64_C(1) << 38);
-        // carve the scratch
-        uint8_t * p = (uint8_t *)scratch;
-        auto take = [&](size_t bytes) -> void *
-        {
-            void * r = p;
-            p += (bytes + 255) & ~(size_t)255;
-            return r;
-        };
-        uint32_t * keys = (uint32_t *)take(cnt * 4);
-        uint16_t * slots = (uint16_t *)take(cnt * 2);
-        uint16_t * tile_hist = (uint16_t *)take(g.tiles * g.B * 2);
-        uint32_t * counts = (uint32_t *)take((size_t)g.B * g.G * 4);
-        uint32_t * offs = (uint32_t *)take((size_t)g.B * g.G * 4);
-        uint32_t * btot = (uint32_t *)take((size_t)(g.B + 1) * 4);
-        uint32_t * bstart = (uint32_t *)take((size_t)(g.B + 1) * 4);
-        if ((size_t)(p - (uint8_t *)scratch) > scratch_bytes)
+        const unsigned bins1 = 1u << g.d1, bins2 = 1u << g.d2, nf = bins1 * bins2;
+        SrBuf b;
+        if (carve(b, scratch, cnt, g.tile) > scratch_bytes)
         {
             set_error("rank_sorted: scratch too small");
             return SDSL_HIP_ERR_INVALID;
         }
+        const uint64_t * idx = d_idx + done;
+        const dim3 G(g.G), T(K.threads);
         PhaseTimer pt(trace, s);
         pt.mark();
-        hipLaunchKernelGGL(k_sr_hist, dim3(g.G), dim3(kSrThreads), 0, s, v.n_bits, g, d_idx + done, counts);
+        hipLaunchKernelGGL(K.hist1, G, T, 0, s, g, idx, nullptr, nullptr, nullptr, b.counts1, nullptr);
         pt.mark();
-        hipLaunchKernelGGL(k_sr_bucket_totals, dim3(g.B), dim3(256), 0, s, g, counts, btot);
-        hipLaunchKernelGGL(k_sr_bucket_scan, dim3(1), dim3(kSrThreads), 0, s, g, btot, bstart);
-        hipLaunchKernelGGL(k_sr_bucket_offsets, dim3(g.B), dim3(256), 0, s, g, counts, bstart, offs);
+        hipLaunchKernelGGL(k_sr_bucket_totals, dim3(bins1), dim3(256), 0, s, g.G, b.counts1, b.btot);
+        hipLaunchKernelGGL(k_sr_bucket_scan, dim3(1), dim3(kBins), 0, s, bins1, g.tile, b.btot, b.bstart1, b.tprefix2);
+        hipLaunchKernelGGL(k_sr_bucket_offsets, dim3(bins1), dim3(256), 0, s, g.G, b.counts1, b.bstart1, b.offs1);
         pt.mark();
-        hipLaunchKernelGGL(k_sr_partition, dim3(g.G), dim3(kSrThreads), 0, s, v.n_bits, g, d_idx + done, offs, keys, slots,
-                           tile_hist);
+        hipLaunchKernelGGL(K.part1, G, T, 0, s, g, idx, nullptr, nullptr, nullptr, b.offs1, b.keys1, b.slots1, b.thist1);
         pt.mark();
-        const unsigned rank_blocks = rb_env >= 8 ? (unsigned)rb_env & ~7u : 256u * 8u;
-        hipLaunchKernelGGL((k_sr_rank<4>), dim3(rank_blocks), dim3(256), 0, s, v, bit, g, bstart, keys);
+        SH_HIP(hipMemsetAsync(b.fine_count, 0, (size_t)nf * 4, s));
+        hipLaunchKernelGGL(K.hist2, G, T, 0, s, g, nullptr, b.keys1, b.tprefix2, b.bstart1, b.counts2, b.fine_count);
         pt.mark();
-        hipLaunchKernelGGL(k_sr_unpermute, dim3(g.G), dim3(kSrThreads), 0, s, v, bit, g, offs, keys, slots, tile_hist,
-                           d_out + done);
+        hipLaunchKernelGGL(k_sr_bucket_totals, dim3(bins2), dim3(256), 0, s, g.G, b.counts2, b.btot);
+        hipLaunchKernelGGL(k_sr_bucket_scan, dim3(1), dim3(kBins), 0, s, bins2, g.tile, b.btot, b.bstart2, nullptr);
+        hipLaunchKernelGGL(k_sr_bucket_offsets, dim3(bins2), dim3(256), 0, s, g.G, b.counts2, b.bstart2, b.offs2);
+        pt.mark();
+        hipLaunchKernelGGL(K.part2, G, T, 0, s, g, nullptr, b.keys1, b.tprefix2, b.bstart1, b.offs2, b.keys2, b.slots2,
+                           b.thist2);
+        pt.mark();
+        hipLaunchKernelGGL(k_sr_fine_scan, dim3(1), dim3(1024), 0, s, nf, b.fine_count, b.fstart, b.ioff);
+        hipLaunchKernelGGL(k_sr_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, s, v, nf, b.hf);
+        pt.mark();
+        const unsigned rank_blocks = rb_env >= 1 ? (unsigned)rb_env : 1024u;
+        hipLaunchKernelGGL(k_sr_rank_lds, dim3(rank_blocks), dim3(kRT), 0, s, v, bit, nf, b.fstart, b.ioff, b.keys2);
+        pt.mark();
+        hipLaunchKernelGGL(K.unp2, G, T, 0, s, b.hf, bit, g, b.tprefix2, b.bstart1, b.offs2, b.keys2, nullptr, b.slots2, b.thist2,
+                           b.keys1, b.hi8, nullptr);
+        pt.mark();
+        hipLaunchKernelGGL(K.unp1, G, T, 0, s, b.hf, bit, g, nullptr, nullptr, b.offs1, b.keys1, b.hi8, b.slots1, b.thist1,
+                           nullptr, nullptr, d_out + done);
         pt.mark();
         SH_HIP(hipGetLastError());
         pt.report(g);

@@ -211,6 +211,31 @@ sdsl_hip_status host_pipeline_u64(int device, const uint64_t * h_in, uint64_t * 
                                { return launch((const uint64_t *)d_in, (uint64_t *)d_out, cnt, st); });
 }
 
+// runs the body of an extern "C" entry point that builds host-side containers from caller-supplied sizes
+template <class F>
+sdsl_hip_status guarded(const char * what, F body) noexcept
+{
+    try
+    {
+        return body();
+    }
+    catch (const std::bad_alloc &)
+    {
+        set_error("%s: out of host memory", what);
+        return SDSL_HIP_ERR_NOMEM;
+    }
+    catch (const std::exception & e)
+    {
+        set_error("%s: %s", what, e.what());
+        return SDSL_HIP_ERR_INVALID;
+    }
+    catch (...)
+    {
+        set_error("%s: unknown failure", what);
+        return SDSL_HIP_ERR_INVALID;
+    }
+}
+
 inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigned max_blocks = 1u << 30)
 {
     uint64_t b = (work_items + per_block - 1) / per_block;

@@ -323,7 +323,7 @@ static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_b
 
 extern "C" {
 
-sdsl_hip_status sdsl_hip_fm_create_from_bwt_ex(const uint8_t * bwt, uint64_t n, int32_t device, uint32_t flags,
+static sdsl_hip_status sdsl_hip_fm_create_from_bwt_ex_impl(const uint8_t * bwt, uint64_t n, int32_t device, uint32_t flags,
                                                sdsl_hip_fm_t * out)
 {
     if (!out || !bwt || n == 0)
@@ -348,8 +348,14 @@ sdsl_hip_status sdsl_hip_fm_create_from_bwt_ex(const uint8_t * bwt, uint64_t n, 
     *out = f;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_fm_create_from_bwt_ex(const uint8_t * bwt, uint64_t n, int32_t device, uint32_t flags,
+                                               sdsl_hip_fm_t * out)
+{
+    return guarded("fm_create_from_bwt_ex", [&] { return sdsl_hip_fm_create_from_bwt_ex_impl(bwt, n, device, flags, out); });
+}
 
-sdsl_hip_status sdsl_hip_fm_create_from_text_ex(const uint8_t * text, uint64_t n_text, int32_t device, uint32_t flags,
+static sdsl_hip_status sdsl_hip_fm_create_from_text_ex_impl(const uint8_t * text, uint64_t n_text, int32_t device, uint32_t flags,
                                                 sdsl_hip_fm_t * out)
 {
     if (!out || (!text && n_text))
@@ -394,21 +400,43 @@ sdsl_hip_status sdsl_hip_fm_create_from_text_ex(const uint8_t * text, uint64_t n
     *out = f;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_fm_create_from_text_ex(const uint8_t * text, uint64_t n_text, int32_t device, uint32_t flags,
+                                                sdsl_hip_fm_t * out)
+{
+    return guarded("fm_create_from_text_ex", [&] { return sdsl_hip_fm_create_from_text_ex_impl(text, n_text, device, flags, out); });
+}
 
-sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int32_t device, sdsl_hip_fm_t * out)
+static sdsl_hip_status sdsl_hip_fm_create_from_bwt_impl(const uint8_t * bwt, uint64_t n, int32_t device, sdsl_hip_fm_t * out)
 {
     return sdsl_hip_fm_create_from_bwt_ex(bwt, n, device, 0, out);
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int32_t device, sdsl_hip_fm_t * out)
+{
+    return guarded("fm_create_from_bwt", [&] { return sdsl_hip_fm_create_from_bwt_impl(bwt, n, device, out); });
+}
 
-sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_text, int32_t device, sdsl_hip_fm_t * out)
+static sdsl_hip_status sdsl_hip_fm_create_from_text_impl(const uint8_t * text, uint64_t n_text, int32_t device, sdsl_hip_fm_t * out)
 {
     return sdsl_hip_fm_create_from_text_ex(text, n_text, device, 0, out);
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_text, int32_t device, sdsl_hip_fm_t * out)
+{
+    return guarded("fm_create_from_text", [&] { return sdsl_hip_fm_create_from_text_impl(text, n_text, device, out); });
+}
 
-sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int32_t layout, int32_t device,
+static sdsl_hip_status sdsl_hip_fm_create_from_sdsl_impl(const void * bytes, size_t len, int32_t layout, int32_t device,
                                              sdsl_hip_fm_t * out)
 {
     return sdsl_hip_fm_create_from_sdsl_ex(bytes, len, layout, 0, 0, device, out);
+}
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_fm_create_from_sdsl(const void * bytes, size_t len, int32_t layout, int32_t device,
+                                             sdsl_hip_fm_t * out)
+{
+    return guarded("fm_create_from_sdsl", [&] { return sdsl_hip_fm_create_from_sdsl_impl(bytes, len, layout, device, out); });
 }
 
 // uploads an SDSL sample vector (int_vector<0>) as u64; every value must be < n
@@ -436,7 +464,7 @@ static sdsl_hip_status fm_upload_samples(const HostIntVec & v, uint64_t expect, 
     return SDSL_HIP_OK;
 }
 
-sdsl_hip_status sdsl_hip_fm_create_from_sdsl_ex(const void * bytes, size_t len, int32_t layout, uint32_t sa_dens,
+static sdsl_hip_status sdsl_hip_fm_create_from_sdsl_ex_impl(const void * bytes, size_t len, int32_t layout, uint32_t sa_dens,
                                                 uint32_t isa_dens, int32_t device, sdsl_hip_fm_t * out)
 {
     if (!out || !bytes)
@@ -528,6 +556,12 @@ sdsl_hip_status sdsl_hip_fm_create_from_sdsl_ex(const void * bytes, size_t len, 
     *out = f;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_fm_create_from_sdsl_ex(const void * bytes, size_t len, int32_t layout, uint32_t sa_dens,
+                                                uint32_t isa_dens, int32_t device, sdsl_hip_fm_t * out)
+{
+    return guarded("fm_create_from_sdsl_ex", [&] { return sdsl_hip_fm_create_from_sdsl_ex_impl(bytes, len, layout, sa_dens, isa_dens, device, out); });
+}
 
 sdsl_hip_status sdsl_hip_fm_set_jump_depth(sdsl_hip_fm_t fm, uint32_t k)
 {
@@ -562,13 +596,19 @@ sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
     return SDSL_HIP_OK;
 }
 
-sdsl_hip_status sdsl_hip_fm_serialize(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens, void * buf, size_t cap,
+static sdsl_hip_status sdsl_hip_fm_serialize_impl(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens, void * buf, size_t cap,
                                       size_t * written)
 {
     return sdsl_hip_fm_serialize_ex(fm, SDSL_HIP_LAYOUT_BV_SCAN, sa_dens, isa_dens, buf, cap, written);
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_fm_serialize(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens, void * buf, size_t cap,
+                                      size_t * written)
+{
+    return guarded("fm_serialize", [&] { return sdsl_hip_fm_serialize_impl(fm, sa_dens, isa_dens, buf, cap, written); });
+}
 
-sdsl_hip_status sdsl_hip_fm_serialize_ex(sdsl_hip_fm_t fm, int32_t layout, uint32_t sa_dens, uint32_t isa_dens, void * buf,
+static sdsl_hip_status sdsl_hip_fm_serialize_ex_impl(sdsl_hip_fm_t fm, int32_t layout, uint32_t sa_dens, uint32_t isa_dens, void * buf,
                                          size_t cap, size_t * written)
 {
     if (!fm || sa_dens == 0 || isa_dens == 0)
@@ -616,6 +656,12 @@ sdsl_hip_status sdsl_hip_fm_serialize_ex(sdsl_hip_fm_t fm, int32_t layout, uint3
     w.u16((uint16_t)fm->sigma);
     return deliver_and_cache(fm->uid, key, w, buf, cap, written);
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_fm_serialize_ex(sdsl_hip_fm_t fm, int32_t layout, uint32_t sa_dens, uint32_t isa_dens, void * buf,
+                                         size_t cap, size_t * written)
+{
+    return guarded("fm_serialize_ex", [&] { return sdsl_hip_fm_serialize_ex_impl(fm, layout, sa_dens, isa_dens, buf, cap, written); });
+}
 
 sdsl_hip_status sdsl_hip_fm_destroy(sdsl_hip_fm_t fm)
 {
@@ -635,7 +681,7 @@ uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm)
 }
 uint64_t sdsl_hip_fm_device_bytes(sdsl_hip_fm_t fm)
 {
-    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes + fm->d_sa_s.bytes + fm->d_isa_s.bytes + fm->d_jump.bytes : 0;
+    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes + fm->d_sa_s.bytes + fm->d_isa_s.bytes + fm->d_jump.bytes + fm->d_sa.bytes : 0;
 }
 sdsl_hip_wt_t sdsl_hip_fm_wavelet_tree(sdsl_hip_fm_t fm)
 {

@@ -79,6 +79,11 @@ static sdsl_hip_status rrr_parse_sdsl(StreamReader & rd, RrrArrays & A)
     if (!rd.u64(n) || !rd.int_vector(bt) || !rd.int_vector(btnr, 1) || !rd.int_vector(btnrp) || !rd.int_vector(rank)
         || !rd.int_vector(inv, 1))
         goto bad;
+    if (n >= (UINT64_C(1) << 40))
+    { // the limit the plain bit vector enforces too; also keeps n + 63 and everything derived from it from wrapping
+        set_error("rrr_vector<63> stream declares %llu bits: beyond the supported 2^40", (unsigned long long)n);
+        return SDSL_HIP_ERR_FORMAT;
+    }
     {
         A.n_bits = n;
         A.n_blocks = (n + kRrrBS) / kRrrBS;
@@ -764,7 +769,7 @@ struct sdsl_hip_rrr_s
 
 extern "C" {
 
-sdsl_hip_status sdsl_hip_rrr_create(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_rrr_t * out)
+static sdsl_hip_status sdsl_hip_rrr_create_impl(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_rrr_t * out)
 {
     if (!out || (!words && n_bits))
     {
@@ -788,8 +793,13 @@ sdsl_hip_status sdsl_hip_rrr_create(const uint64_t * words, uint64_t n_bits, int
     *out = r;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_rrr_create(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_rrr_t * out)
+{
+    return guarded("rrr_create", [&] { return sdsl_hip_rrr_create_impl(words, n_bits, device, out); });
+}
 
-sdsl_hip_status sdsl_hip_rrr_create_from_sdsl(const void * bytes, size_t len, int32_t device, sdsl_hip_rrr_t * out)
+static sdsl_hip_status sdsl_hip_rrr_create_from_sdsl_impl(const void * bytes, size_t len, int32_t device, sdsl_hip_rrr_t * out)
 {
     if (!out || !bytes)
     {
@@ -813,8 +823,13 @@ sdsl_hip_status sdsl_hip_rrr_create_from_sdsl(const void * bytes, size_t len, in
     *out = r;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_rrr_create_from_sdsl(const void * bytes, size_t len, int32_t device, sdsl_hip_rrr_t * out)
+{
+    return guarded("rrr_create_from_sdsl", [&] { return sdsl_hip_rrr_create_from_sdsl_impl(bytes, len, device, out); });
+}
 
-sdsl_hip_status sdsl_hip_rrr_serialize(sdsl_hip_rrr_t v, void * buf, size_t cap, size_t * written)
+static sdsl_hip_status sdsl_hip_rrr_serialize_impl(sdsl_hip_rrr_t v, void * buf, size_t cap, size_t * written)
 {
     if (!v)
     {
@@ -827,6 +842,11 @@ sdsl_hip_status sdsl_hip_rrr_serialize(sdsl_hip_rrr_t v, void * buf, size_t cap,
     StreamWriter w;
     SH_TRY(rrr_serialize_host(v->h, w));
     return deliver_and_cache(v->uid, 0, w, buf, cap, written);
+}
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_rrr_serialize(sdsl_hip_rrr_t v, void * buf, size_t cap, size_t * written)
+{
+    return guarded("rrr_serialize", [&] { return sdsl_hip_rrr_serialize_impl(v, buf, cap, written); });
 }
 
 sdsl_hip_status sdsl_hip_rrr_destroy(sdsl_hip_rrr_t v)

@@ -308,14 +308,13 @@ static void sd_finish_view(SdHost & h, uint64_t n, uint64_t m, uint32_t wl)
 static sdsl_hip_status sd_build_from_device_positions(SdHost & h, const uint64_t * d_pos, uint64_t m, uint64_t n, int device)
 {
     h.device = device;
-    unsigned logm = hi64_host(m) + 1, logn = hi64_host(n) + 1;
-    if (logm == logn)
-        --logm; // to ensure logn - logm > 0 (:226-229)
-    const uint32_t wl = logn - logm;
-    const uint64_t high_bits = m + (UINT64_C(1) << logm);
-    DevBuf d_high;
-    SH_TRY(d_high.alloc((((high_bits + 63) >> 6) + 1) * 8, true));
-    SH_TRY(h.low.alloc((((m * wl + 63) >> 6) + 2) * 8, true));
+    // validate before anything is sized from (m, n): m strictly increasing positions below n need m <= n
+    if (m > n)
+    {
+        set_error("sd_vector: %llu positions cannot be strictly increasing below the size %llu (sd_vector.hpp:266-269)",
+                  (unsigned long long)m, (unsigned long long)n);
+        return SDSL_HIP_ERR_INVALID;
+    }
     if (m)
     {
         DevBuf bad;
@@ -329,6 +328,17 @@ static sdsl_hip_status sd_build_from_device_positions(SdHost & h, const uint64_t
             set_error("sd_vector: the positions must be strictly increasing and smaller than the size (sd_vector.hpp:266-269)");
             return SDSL_HIP_ERR_INVALID;
         }
+    }
+    unsigned logm = hi64_host(m) + 1, logn = hi64_host(n) + 1;
+    if (logm == logn)
+        --logm; // to ensure logn - logm > 0 (:226-229)
+    const uint32_t wl = logn - logm;
+    const uint64_t high_bits = m + (UINT64_C(1) << logm);
+    DevBuf d_high;
+    SH_TRY(d_high.alloc((((high_bits + 63) >> 6) + 1) * 8, true));
+    SH_TRY(h.low.alloc((((m * wl + 63) >> 6) + 2) * 8, true));
+    if (m)
+    {
         hipLaunchKernelGGL(k_sd_fill, dim3(grid_for(m, 256, 65536)), dim3(256), 0, 0, d_pos, m, wl,
                            h.low.as<unsigned long long>(), d_high.as<unsigned long long>());
         SH_HIP(hipGetLastError());
@@ -396,7 +406,7 @@ struct sdsl_hip_sd_s
 
 extern "C" {
 
-sdsl_hip_status sdsl_hip_sd_create_from_positions(const uint64_t * positions, uint64_t m, uint64_t n_bits, int32_t device,
+static sdsl_hip_status sdsl_hip_sd_create_from_positions_impl(const uint64_t * positions, uint64_t m, uint64_t n_bits, int32_t device,
                                                   sdsl_hip_sd_t * out)
 {
     if (!out || (!positions && m))
@@ -421,8 +431,14 @@ sdsl_hip_status sdsl_hip_sd_create_from_positions(const uint64_t * positions, ui
     *out = r;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_sd_create_from_positions(const uint64_t * positions, uint64_t m, uint64_t n_bits, int32_t device,
+                                                  sdsl_hip_sd_t * out)
+{
+    return guarded("sd_create_from_positions", [&] { return sdsl_hip_sd_create_from_positions_impl(positions, m, n_bits, device, out); });
+}
 
-sdsl_hip_status sdsl_hip_sd_create(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_sd_t * out)
+static sdsl_hip_status sdsl_hip_sd_create_impl(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_sd_t * out)
 {
     if (!out || (!words && n_bits))
     {
@@ -458,8 +474,13 @@ sdsl_hip_status sdsl_hip_sd_create(const uint64_t * words, uint64_t n_bits, int3
     *out = r;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_sd_create(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_sd_t * out)
+{
+    return guarded("sd_create", [&] { return sdsl_hip_sd_create_impl(words, n_bits, device, out); });
+}
 
-sdsl_hip_status sdsl_hip_sd_create_from_sdsl(const void * bytes, size_t len, int32_t device, sdsl_hip_sd_t * out,
+static sdsl_hip_status sdsl_hip_sd_create_from_sdsl_impl(const void * bytes, size_t len, int32_t device, sdsl_hip_sd_t * out,
                                              size_t * consumed)
 {
     if (!out || !bytes)
@@ -484,9 +505,15 @@ sdsl_hip_status sdsl_hip_sd_create_from_sdsl(const void * bytes, size_t len, int
     *out = r;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_sd_create_from_sdsl(const void * bytes, size_t len, int32_t device, sdsl_hip_sd_t * out,
+                                             size_t * consumed)
+{
+    return guarded("sd_create_from_sdsl", [&] { return sdsl_hip_sd_create_from_sdsl_impl(bytes, len, device, out, consumed); });
+}
 
 // sd_vector<>::serialize (sd_vector.hpp:435-445): size, wl, low, high, select_support_mcl<1> and <0> of high
-sdsl_hip_status sdsl_hip_sd_serialize(sdsl_hip_sd_t v, void * buf, size_t cap, size_t * written)
+static sdsl_hip_status sdsl_hip_sd_serialize_impl(sdsl_hip_sd_t v, void * buf, size_t cap, size_t * written)
 {
     if (!v)
     {
@@ -518,6 +545,11 @@ sdsl_hip_status sdsl_hip_sd_serialize(sdsl_hip_sd_t v, void * buf, size_t cap, s
     select_mcl_serialize_host(high.data(), hb, 1, w);
     select_mcl_serialize_host(high.data(), hb, 0, w);
     return deliver_and_cache(v->uid, 0, w, buf, cap, written);
+}
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_sd_serialize(sdsl_hip_sd_t v, void * buf, size_t cap, size_t * written)
+{
+    return guarded("sd_serialize", [&] { return sdsl_hip_sd_serialize_impl(v, buf, cap, written); });
 }
 
 sdsl_hip_status sdsl_hip_sd_destroy(sdsl_hip_sd_t v)

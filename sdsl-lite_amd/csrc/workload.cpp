@@ -359,6 +359,16 @@ sdsl_hip_status sdsl_hip_util_rnd_positions(uint64_t seed, uint64_t count, uint6
     Mt64 rng(seed);
     constexpr uint64_t kChunk = UINT64_C(1) << 22;
     const uint64_t n_chunks = (count + kChunk - 1) / kChunk;
+    // first touch of a fresh array is the expensive part on a virtualised host (≈ 20 µs per page fault measured):
+    // every thread faults in its share of the pages before the sequential generator walks over them
+    parallel_blocks((count * 8 + (1u << 21) - 1) >> 21,
+                    [&](uint64_t b)
+                    {
+                        volatile uint8_t * p = (volatile uint8_t *)out;
+                        const uint64_t end = std::min<uint64_t>(count * 8, (b + 1) << 21);
+                        for (uint64_t o = b << 21; o < end; o += 4096)
+                            p[o] = 0;
+                    });
     std::atomic<uint64_t> produced{0}, next{0};
     const unsigned T = mod ? std::min<unsigned>(host_threads(), 8) : 0;
     std::vector<std::thread> th;

@@ -1420,7 +1420,7 @@ sdsl_hip_status sdsl_hip_wt_finish(sdsl_hip_wt_s * w)
 
 extern "C" {
 
-sdsl_hip_status sdsl_hip_wt_create_ex(const uint8_t * text, uint64_t n, int32_t device, uint32_t flags, sdsl_hip_wt_t * out)
+static sdsl_hip_status sdsl_hip_wt_create_ex_impl(const uint8_t * text, uint64_t n, int32_t device, uint32_t flags, sdsl_hip_wt_t * out)
 {
     if (!out || (!text && n))
     {
@@ -1446,13 +1446,23 @@ sdsl_hip_status sdsl_hip_wt_create_ex(const uint8_t * text, uint64_t n, int32_t 
     *out = w;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_wt_create_ex(const uint8_t * text, uint64_t n, int32_t device, uint32_t flags, sdsl_hip_wt_t * out)
+{
+    return guarded("wt_create_ex", [&] { return sdsl_hip_wt_create_ex_impl(text, n, device, flags, out); });
+}
 
-sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t device, sdsl_hip_wt_t * out)
+static sdsl_hip_status sdsl_hip_wt_create_impl(const uint8_t * text, uint64_t n, int32_t device, sdsl_hip_wt_t * out)
 {
     return sdsl_hip_wt_create_ex(text, n, device, 0, out);
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_wt_create(const uint8_t * text, uint64_t n, int32_t device, sdsl_hip_wt_t * out)
+{
+    return guarded("wt_create", [&] { return sdsl_hip_wt_create_impl(text, n, device, out); });
+}
 
-sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int32_t layout, int32_t device,
+static sdsl_hip_status sdsl_hip_wt_create_from_sdsl_impl(const void * bytes, size_t len, int32_t layout, int32_t device,
                                              sdsl_hip_wt_t * out, size_t * consumed)
 {
     if (!out || !bytes)
@@ -1479,10 +1489,21 @@ sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int
     *out = w;
     return SDSL_HIP_OK;
 }
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_wt_create_from_sdsl(const void * bytes, size_t len, int32_t layout, int32_t device,
+                                             sdsl_hip_wt_t * out, size_t * consumed)
+{
+    return guarded("wt_create_from_sdsl", [&] { return sdsl_hip_wt_create_from_sdsl_impl(bytes, len, layout, device, out, consumed); });
+}
 
-sdsl_hip_status sdsl_hip_wt_serialize(sdsl_hip_wt_t wt, void * buf, size_t cap, size_t * written)
+static sdsl_hip_status sdsl_hip_wt_serialize_impl(sdsl_hip_wt_t wt, void * buf, size_t cap, size_t * written)
 {
     return sdsl_hip_wt_serialize_ex(wt, SDSL_HIP_LAYOUT_BV_SCAN, buf, cap, written);
+}
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_wt_serialize(sdsl_hip_wt_t wt, void * buf, size_t cap, size_t * written)
+{
+    return guarded("wt_serialize", [&] { return sdsl_hip_wt_serialize_impl(wt, buf, cap, written); });
 }
 
 } // extern "C"
@@ -1565,7 +1586,7 @@ sdsl_hip_status sdsl_hip_wt_serialize_into(sdsl_hip_wt_s * wt, int32_t layout, S
 
 extern "C" {
 
-sdsl_hip_status sdsl_hip_wt_serialize_ex(sdsl_hip_wt_t wt, int32_t layout, void * buf, size_t cap, size_t * written)
+static sdsl_hip_status sdsl_hip_wt_serialize_ex_impl(sdsl_hip_wt_t wt, int32_t layout, void * buf, size_t cap, size_t * written)
 {
     if (!wt)
     {
@@ -1578,6 +1599,11 @@ sdsl_hip_status sdsl_hip_wt_serialize_ex(sdsl_hip_wt_t wt, int32_t layout, void 
     StreamWriter w;
     SH_TRY(sdsl_hip_wt_serialize_into(wt, layout, w));
     return deliver_and_cache(wt->uid, (uint64_t)(uint32_t)layout, w, buf, cap, written);
+}
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_wt_serialize_ex(sdsl_hip_wt_t wt, int32_t layout, void * buf, size_t cap, size_t * written)
+{
+    return guarded("wt_serialize_ex", [&] { return sdsl_hip_wt_serialize_ex_impl(wt, layout, buf, cap, written); });
 }
 
 sdsl_hip_status sdsl_hip_wt_destroy(sdsl_hip_wt_t wt)

@@ -53,6 +53,24 @@ def _empty_like(x, n, dtype):
     return np.empty(n, dtype=dtype)
 
 
+def _out_for(x, n, dtype, out):
+    """A fresh result array beside x, or the caller's `out` after checking that the library may write n items of
+    `dtype` into it (size, dtype, contiguity, same side of the PCIe link as x)."""
+    if out is None:
+        return _empty_like(x, n, dtype)
+    if _is_tensor(out) != _is_tensor(x):
+        raise TypeError("out must live where the arguments live (torch tensor with torch tensor, numpy with numpy)")
+    if _is_tensor(out):
+        want = {np.uint64: (torch.int64, torch.uint64), np.uint8: (torch.uint8,)}[dtype]
+        if out.dtype not in want or not out.is_contiguous() or out.numel() < n or out.device != x.device:
+            raise ValueError(f"out: need a contiguous {want[0]} tensor of at least {n} elements on {x.device}")
+    else:
+        if not isinstance(out, np.ndarray) or out.dtype != np.dtype(dtype) or not out.flags.c_contiguous or out.size < n \
+                or not out.flags.writeable:
+            raise ValueError(f"out: need a writeable C-contiguous {np.dtype(dtype)} array of at least {n} elements")
+    return out
+
+
 class _Handle:
     _destroy = None
 
@@ -112,8 +130,7 @@ class bit_vector(_Handle):
     def rank(self, idx, bit: int = 1, out=None):
         idx = _as_array(idx, np.uint64, "idx")
         n = idx.numel() if _is_tensor(idx) else idx.size
-        if out is None:
-            out = _empty_like(idx, n, np.uint64)
+        out = _out_for(idx, n, np.uint64, out)
         capi.check(capi.lib().sdsl_hip_bv_rank_batch(self._h, bit, _ptr(idx), n, _ptr(out), _stream_for(idx)))
         return out
 
@@ -126,16 +143,14 @@ class bit_vector(_Handle):
     def select(self, i, bit: int = 1, out=None):
         i = _as_array(i, np.uint64, "i")
         n = i.numel() if _is_tensor(i) else i.size
-        if out is None:
-            out = _empty_like(i, n, np.uint64)
+        out = _out_for(i, n, np.uint64, out)
         capi.check(capi.lib().sdsl_hip_bv_select_batch(self._h, bit, _ptr(i), n, _ptr(out), _stream_for(i)))
         return out
 
     def access(self, idx, out=None):
         idx = _as_array(idx, np.uint64, "idx")
         n = idx.numel() if _is_tensor(idx) else idx.size
-        if out is None:
-            out = _empty_like(idx, n, np.uint8)
+        out = _out_for(idx, n, np.uint8, out)
         capi.check(capi.lib().sdsl_hip_bv_access_batch(self._h, _ptr(idx), n, _ptr(out), _stream_for(idx)))
         return out
 
@@ -205,6 +220,40 @@ def set_random_bits(n_bits: int, seed: int) -> np.ndarray:
     return w
 
 
+def rnd_positions(seed: int, count: int, mod: int = 0, add: int = 0) -> np.ndarray:
+    """add + std::mt19937_64(seed)() % mod, `count` successive draws (SURVEY.md 8(d) query streams)."""
+    out = np.empty(count, dtype=np.uint64)
+    if count:
+        capi.check(capi.lib().sdsl_hip_util_rnd_positions(seed, count, mod, add, _ptr(out)))
+    return out
+
+
+def mt_checkpoints(seed: int, stride: int, n: int) -> np.ndarray:
+    """Generator states of mt19937_64(seed) before draws 0, stride, 2*stride, ...: n rows of 313 words."""
+    out = np.empty((n, 313), dtype=np.uint64)
+    capi.check(capi.lib().sdsl_hip_util_mt_checkpoints(seed, stride, n, _ptr(out)))
+    return out
+
+
+def density_bits(n_bits: int, seed: int, percent: int, checkpoints: np.ndarray | None = None, stride: int = 0) -> np.ndarray:
+    """bit i = (i-th draw of mt19937_64(seed) % 100 < percent): the configs[2] vector, as uint64 words."""
+    w = np.zeros((n_bits + 63) // 64, dtype=np.uint64)
+    if checkpoints is not None:
+        cp = np.ascontiguousarray(checkpoints, dtype=np.uint64).reshape(-1, 313)
+        capi.check(capi.lib().sdsl_hip_util_density_bits(_ptr(w), n_bits, seed, percent, _ptr(cp), cp.shape[0], stride))
+    else:
+        capi.check(capi.lib().sdsl_hip_util_density_bits(_ptr(w), n_bits, seed, percent, None, 0, 0))
+    return w
+
+
+def english_text(n_bytes: int, seed: int) -> np.ndarray:
+    """The English-class stand-in text of the configs[3]/[4] benchmarks (uint8, no zero byte)."""
+    out = np.empty(n_bytes, dtype=np.uint8)
+    if n_bytes:
+        capi.check(capi.lib().sdsl_hip_util_english_text(_ptr(out), n_bytes, seed))
+    return out
+
+
 def _serialize(fn, handle) -> bytes:
     need = C.c_size_t(0)
     capi.check(fn(handle, None, 0, C.byref(need)))
@@ -227,6 +276,8 @@ class rrr_vector(_Handle):
             nw = w.numel() if _is_tensor(w) else w.size
             if n_bits is None:
                 n_bits = nw * 64
+            if (n_bits + 63) // 64 > nw:
+                raise ValueError(f"words too short for n_bits: {nw} words < ceil({n_bits} / 64)")
             capi.check(capi.lib().sdsl_hip_rrr_create(_ptr(w) if nw else None, n_bits, device, C.byref(self._h)))
         self.device = device
 
@@ -242,24 +293,21 @@ class rrr_vector(_Handle):
     def rank(self, idx, bit: int = 1, out=None):
         idx = _as_array(idx, np.uint64, "idx")
         n = idx.numel() if _is_tensor(idx) else idx.size
-        if out is None:
-            out = _empty_like(idx, n, np.uint64)
+        out = _out_for(idx, n, np.uint64, out)
         capi.check(capi.lib().sdsl_hip_rrr_rank_batch(self._h, bit, _ptr(idx), n, _ptr(out), _stream_for(idx)))
         return out
 
     def select(self, i, bit: int = 1, out=None):
         i = _as_array(i, np.uint64, "i")
         n = i.numel() if _is_tensor(i) else i.size
-        if out is None:
-            out = _empty_like(i, n, np.uint64)
+        out = _out_for(i, n, np.uint64, out)
         capi.check(capi.lib().sdsl_hip_rrr_select_batch(self._h, bit, _ptr(i), n, _ptr(out), _stream_for(i)))
         return out
 
     def access(self, idx, out=None):
         idx = _as_array(idx, np.uint64, "idx")
         n = idx.numel() if _is_tensor(idx) else idx.size
-        if out is None:
-            out = _empty_like(idx, n, np.uint8)
+        out = _out_for(idx, n, np.uint8, out)
         capi.check(capi.lib().sdsl_hip_rrr_access_batch(self._h, _ptr(idx), n, _ptr(out), _stream_for(idx)))
         return out
 
@@ -323,24 +371,21 @@ class sd_vector(_Handle):
     def rank(self, idx, bit: int = 1, out=None):
         idx = _as_array(idx, np.uint64, "idx")
         n = idx.numel() if _is_tensor(idx) else idx.size
-        if out is None:
-            out = _empty_like(idx, n, np.uint64)
+        out = _out_for(idx, n, np.uint64, out)
         capi.check(capi.lib().sdsl_hip_sd_rank_batch(self._h, bit, _ptr(idx), n, _ptr(out), _stream_for(idx)))
         return out
 
     def select(self, i, bit: int = 1, out=None):
         i = _as_array(i, np.uint64, "i")
         n = i.numel() if _is_tensor(i) else i.size
-        if out is None:
-            out = _empty_like(i, n, np.uint64)
+        out = _out_for(i, n, np.uint64, out)
         capi.check(capi.lib().sdsl_hip_sd_select_batch(self._h, bit, _ptr(i), n, _ptr(out), _stream_for(i)))
         return out
 
     def access(self, idx, out=None):
         idx = _as_array(idx, np.uint64, "idx")
         n = idx.numel() if _is_tensor(idx) else idx.size
-        if out is None:
-            out = _empty_like(idx, n, np.uint8)
+        out = _out_for(idx, n, np.uint8, out)
         capi.check(capi.lib().sdsl_hip_sd_access_batch(self._h, _ptr(idx), n, _ptr(out), _stream_for(idx)))
         return out
 
@@ -419,16 +464,14 @@ class wt_huff(_Handle):
         i = _as_array(i, np.uint64, "i")
         c = _as_array(c, np.uint8, "c")
         n = i.numel() if _is_tensor(i) else i.size
-        if out is None:
-            out = _empty_like(i, n, np.uint64)
+        out = _out_for(i, n, np.uint64, out)
         capi.check(capi.lib().sdsl_hip_wt_rank_batch(self._h, _ptr(i), _ptr(c), n, _ptr(out), _stream_for(i)))
         return out
 
     def access(self, i, out=None):
         i = _as_array(i, np.uint64, "i")
         n = i.numel() if _is_tensor(i) else i.size
-        if out is None:
-            out = _empty_like(i, n, np.uint8)
+        out = _out_for(i, n, np.uint8, out)
         capi.check(capi.lib().sdsl_hip_wt_access_batch(self._h, _ptr(i), n, _ptr(out), _stream_for(i)))
         return out
 
@@ -446,8 +489,7 @@ class wt_huff(_Handle):
         i = _as_array(i, np.uint64, "i")
         c = _as_array(c, np.uint8, "c")
         n = i.numel() if _is_tensor(i) else i.size
-        if out is None:
-            out = _empty_like(i, n, np.uint64)
+        out = _out_for(i, n, np.uint64, out)
         capi.check(capi.lib().sdsl_hip_wt_select_batch(self._h, _ptr(i), _ptr(c), n, _ptr(out), _stream_for(i)))
         return out
 
@@ -479,8 +521,29 @@ class csa_wt(_Handle):
             n = t.numel() if _is_tensor(t) else t.size
             capi.check(L.sdsl_hip_fm_create_from_text_ex(_ptr(t) if n else None, n, device, flags, C.byref(self._h)))
         self.device = device
-        self.wavelet_tree = wt_huff(_borrowed=L.sdsl_hip_fm_wavelet_tree(self._h), device=device)
-        self.wavelet_tree._keepalive = self
+        self._wt_ref = None
+
+    @property
+    def wavelet_tree(self):
+        """csa.wavelet_tree (csa_wt.hpp:130): a view of the tree inside this index.  The view holds the index alive;
+        the index only remembers the view weakly (no reference cycle: dropping the last user reference frees the
+        HBM at once), and close() detaches it."""
+        import weakref
+        wt = self._wt_ref() if self._wt_ref is not None else None
+        if wt is None:
+            if not self._h:
+                raise ValueError("csa_wt is closed")
+            wt = wt_huff(_borrowed=capi.lib().sdsl_hip_fm_wavelet_tree(self._h), device=self.device)
+            wt._keepalive = self
+            self._wt_ref = weakref.ref(wt)
+        return wt
+
+    def close(self):
+        wt = self._wt_ref() if getattr(self, "_wt_ref", None) is not None else None
+        if wt is not None:
+            wt._h = C.c_void_p(None)  # the borrowed pointer dies with the index
+            wt._keepalive = None
+        super().close()
 
     def size(self) -> int:
         return capi.lib().sdsl_hip_fm_size(self._h)
@@ -532,8 +595,7 @@ class csa_wt(_Handle):
         p = _bytes_arg(patterns, "patterns")
         total = p.numel() if _is_tensor(p) else p.size
         n = total // m if m else 0
-        if out is None:
-            out = _empty_like(p, n, np.uint64)
+        out = _out_for(p, n, np.uint64, out)
         capi.check(capi.lib().sdsl_hip_fm_count_batch(self._h, _ptr(p) if total else None, m, n, _ptr(out),
                                                       _stream_for(p)))
         return out

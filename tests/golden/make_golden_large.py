@@ -1,0 +1,142 @@
+"""BASELINE-size answers of the REAL sdsl-lite (run in the build container only; ~62 GB of RAM, 30-60 minutes).
+
+    python tests/golden/make_golden_large.py [c2] [c3] [c4]
+
+Builds, through oracle/_ref/libsdsl_ref.so (the reference's headers compiled where they lie), the structures of
+BASELINE.json configs[1..4] on the SURVEY.md 8(d) inputs and stores what the GPU tests and bench.py compare against:
+per query stream the sum, the xor and the sha256 of the answers plus the first 10^4 answers themselves
+(the reference's own harness prints such a checksum: benchmark/rrr_vector/src/rrr_time_and_space.cpp:86-108).
+
+  c2  n = 2^34, words = std::mt19937_64(42) (util::set_random_bits, util.hpp:467-485); rank_support_v5<1>,
+      select_support_mcl<1>; 10^7 rank_1 at mt19937_64(7) % (n+1), 10^7 select_1 at 1 + mt19937_64(11) % ones
+  c3  n = 2^34, bit i = (mt19937_64(9)_i % 100 < 5) drawn sequentially; rrr_vector<63> rank_1 / select_1, same streams
+      (+ the generator checkpoints tests/golden/mt9_checkpoints.bin, validated here by comparing the whole vector
+      produced from them with std::mt19937_64's sequential one)
+  c4  text = the library's English-class stand-in (sdsl_hip_util_english_text, seed 1234), 2^30 bytes;
+      csa_wt<wt_huff<bit_vector, rank_support_v5<>>> built by sdsl::construct_im; 10^6 wavelet_tree.rank(i, c) with
+      i = mt19937_64(13) % (n+1), c = text[mt19937_64(14) % n]; 10^6 count() of the 20 bytes at mt19937_64(15) % (n-20)
+
+Everything written is DATA (seeded inputs are regenerated, never stored): tests/golden/golden_large.json,
+tests/golden/mt9_checkpoints.bin.
+"""
+from __future__ import annotations
+
+import hashlib
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as ol  # noqa: E402
+
+OUT = os.path.join(HERE, "golden_large.json")
+CKPT = os.path.join(HERE, "mt9_checkpoints.bin")
+LOG_N = int(os.environ.get("GOLDEN_LOG_N", "34"))
+NQ = int(os.environ.get("GOLDEN_NQ", str(10**7)))
+TEXT_LOG = int(os.environ.get("GOLDEN_TEXT_LOG", "30"))
+NQ_TEXT = int(os.environ.get("GOLDEN_NQ_TEXT", str(10**6)))
+CKPT_STRIDE = 1 << 28
+
+
+def digest(ans: np.ndarray) -> dict:
+    a = np.ascontiguousarray(ans, dtype=np.uint64)
+    return {"n": int(a.size), "sum": int(np.add.reduce(a, dtype=np.uint64)), "xor": int(np.bitwise_xor.reduce(a)),
+            "sha256": hashlib.sha256(a.tobytes()).hexdigest(), "first": [int(x) for x in a[:10_000]]}
+
+
+def main():
+    assert ol.have_ref(), "build oracle/_ref first (make -C oracle)"
+    pkg = importlib.import_module("sdsl-lite_amd")
+    want = set(sys.argv[1:]) or {"c2", "c3", "c4"}
+    res = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    R = ol.ref().L
+    n = 1 << LOG_N
+
+    if "c2" in want:
+        t0 = time.time()
+        words = np.zeros(n // 64 + 2, dtype=np.uint64)
+        R.ref_set_random_bits(words.ctypes.data, n, 42)  # the real util::set_random_bits
+        assert np.array_equal(words[:1024], pkg.set_random_bits(1 << 16, 42)), "product generator != util::set_random_bits"
+        h = R.ref_bv_create(words.ctypes.data, n)
+        idx = pkg.rnd_positions(7, NQ, n + 1, 0)
+        assert np.array_equal(idx[:100000], ol.mt19937_64(100000, 7) % np.uint64(n + 1))
+        out = np.empty(NQ, dtype=np.uint64)
+        R.ref_bv_rank(h, 1, idx.ctypes.data, NQ, out.ctypes.data)
+        one = np.uint64(n)
+        tot = np.empty(1, dtype=np.uint64)
+        R.ref_bv_rank(h, 1, np.array([n], dtype=np.uint64).ctypes.data, 1, tot.ctypes.data)
+        ones = int(tot[0])
+        c2 = {"log_n": LOG_N, "words_seed": 42, "ones": ones, "rank_seed": 7, "rank_1": digest(out)}
+        si = pkg.rnd_positions(11, NQ, ones, 1)
+        R.ref_bv_select(h, 1, si.ctypes.data, NQ, out.ctypes.data)
+        c2.update(select_seed=11, select_1=digest(out))
+        R.ref_bv_destroy(h)
+        res["c2"] = c2
+        del words, idx, out, si
+        print(f"c2 done in {time.time() - t0:.0f}s: ones={ones}", flush=True)
+        json.dump(res, open(OUT, "w"))
+
+    if "c3" in want:
+        t0 = time.time()
+        n_ck = (n + CKPT_STRIDE - 1) // CKPT_STRIDE
+        ck = pkg.mt_checkpoints(9, CKPT_STRIDE, n_ck)
+        w_par = pkg.density_bits(n, 9, 5, ck, CKPT_STRIDE)
+        w_ref = np.zeros(n // 64 + 2, dtype=np.uint64)
+        R.ref_density_bits(w_ref.ctypes.data, n, 9, 5)  # std::mt19937_64, sequential
+        assert np.array_equal(w_par, w_ref[: n // 64]), "checkpointed generator != std::mt19937_64"
+        ck.tofile(CKPT)
+        del w_par
+        print(f"c3 vector {time.time() - t0:.0f}s", flush=True)
+        h = R.ref_rrr_create(w_ref.ctypes.data, n)
+        print(f"c3 rrr built {time.time() - t0:.0f}s", flush=True)
+        idx = pkg.rnd_positions(7, NQ, n + 1, 0)
+        out = np.empty(NQ, dtype=np.uint64)
+        R.ref_rrr_rank(h, 1, idx.ctypes.data, NQ, out.ctypes.data)
+        tot = np.empty(1, dtype=np.uint64)
+        R.ref_rrr_rank(h, 1, np.array([n], dtype=np.uint64).ctypes.data, 1, tot.ctypes.data)
+        ones = int(tot[0])
+        c3 = {"log_n": LOG_N, "bits_seed": 9, "percent": 5, "ones": ones, "checkpoint_stride": CKPT_STRIDE,
+              "checkpoints": int(n_ck), "words_sha256": hashlib.sha256(w_ref[: n // 64].tobytes()).hexdigest(),
+              "rank_seed": 7, "rank_1": digest(out)}
+        si = pkg.rnd_positions(11, NQ, ones, 1)
+        R.ref_rrr_select(h, 1, si.ctypes.data, NQ, out.ctypes.data)
+        c3.update(select_seed=11, select_1=digest(out))
+        R.ref_rrr_destroy(h)
+        res["c3"] = c3
+        del w_ref, idx, out, si
+        print(f"c3 done in {time.time() - t0:.0f}s: ones={ones}", flush=True)
+        json.dump(res, open(OUT, "w"))
+
+    if "c4" in want:
+        t0 = time.time()
+        nt = 1 << TEXT_LOG
+        text = pkg.english_text(nt, 1234)
+        cnt = np.bincount(text, minlength=256)
+        p = cnt[cnt > 0] / nt
+        c4 = {"text_log": TEXT_LOG, "text_seed": 1234, "text_sha256": hashlib.sha256(text.tobytes()).hexdigest(),
+              "sigma_without_sentinel": int((cnt > 0).sum()), "H0": float(-(p * np.log2(p)).sum())}
+        csa = ol.RCsa(text=text.tobytes())
+        print(f"c4 csa built {time.time() - t0:.0f}s", flush=True)
+        c4["csa_size"] = int(csa.size())
+        c4["sigma"] = int(csa.sigma())
+        gi = pkg.rnd_positions(13, NQ_TEXT, nt + 2, 0)  # i in [0, size()] with size() = nt + 1 (sentinel)
+        gc = text[pkg.rnd_positions(14, NQ_TEXT, nt, 0).astype(np.int64)]
+        c4.update(wt_i_seed=13, wt_c_seed=14, wt_rank=digest(csa.wt_rank(gi, np.ascontiguousarray(gc))))
+        m = 20
+        st = pkg.rnd_positions(15, NQ_TEXT, nt - m, 0).astype(np.int64)
+        pats = np.ascontiguousarray(text[st[:, None] + np.arange(m)[None, :]].reshape(-1))
+        c4.update(pattern_seed=15, m=m, count=digest(csa.count_batch(pats, m)))
+        res["c4"] = c4
+        print(f"c4 done in {time.time() - t0:.0f}s", flush=True)
+        json.dump(res, open(OUT, "w"))
+
+
+if __name__ == "__main__":
+    main()

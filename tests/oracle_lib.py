@@ -507,6 +507,7 @@ _REF_SIGS = {
     "ref_wt_shape_serialize": (None, [_vp, _u64, C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_csa_blcd_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_set_random_bits": (None, [_vp, _u64, C.c_int]),
+    "ref_density_bits": (None, [_vp, _u64, _u64, C.c_uint32]),
     "ref_bits_sel": (_u32, [_u64, _u32]),
     "ref_bits_hi": (_u32, [_u64]),
 }

@@ -31,11 +31,13 @@ def child(logn, nq):
     t0 = time.time(); bv.rank(idx2, 1, out); torch.cuda.synchronize(); t1 = time.time()
     print(f"skewed(2^20 window): {(t1-t0)*1e3:.2f} ms sha {hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]}", flush=True)
 
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and sys.argv[3] == "child":
     child(int(sys.argv[1]), int(float(sys.argv[2])))
 else:
-    for mode, extra in (("0", {}), ("1", {"SDSL_HIP_TRACE_SORTED": "1"})):
+    variants = [("0", {})] + [("1", {"SDSL_HIP_TRACE_SORTED": "1", "SDSL_HIP_SORTED_THREADS": a.split(":")[0], "SDSL_HIP_SORTED_VARIANT": (a.split(":") + ["0"])[1]}) for a in (sys.argv[3:] or ["256"])]
+    for mode, extra in variants:
         env = dict(os.environ, SDSL_HIP_RANK_SORTED=mode, **extra)
         print(f"--- SDSL_HIP_RANK_SORTED={mode} {extra}", flush=True)
         r = subprocess.run([sys.executable, __file__, sys.argv[1], sys.argv[2], "child"], env=env, capture_output=True, text=True)
-        print(r.stdout[-3000:]); print(r.stderr[-6000:])
+        err = [l for l in r.stderr.splitlines() if "amdgpu.ids" not in l]
+        print(r.stdout[-3000:]); print("\n".join(err[:2] + err[-3:]))
