@@ -363,11 +363,46 @@ sdsl_hip_status sdsl_hip_sd_select_batch(sdsl_hip_sd_t v, int32_t bit, const uin
                                          void * stream);
 sdsl_hip_status sdsl_hip_sd_access_batch(sdsl_hip_sd_t v, const uint64_t * idx, uint64_t n, uint8_t * out, void * stream);
 
+/* ---- several GPUs of one node, one process ---------------------------------
+ * The reference has no multi-device layer; this is the batch ABI above over a GROUP of devices.  The index is
+ * replicated (load time: one ncclBroadcast per device buffer), a batch owned by the root device devices[0] — its arrays
+ * in that device's memory, or in host memory — is cut into one contiguous shard per device: scatter (grouped
+ * ncclSend / ncclRecv, every peer on its own xGMI link), the single-GPU kernels, gather; `chunks` pieces are pipelined
+ * over three streams per device (chunks <= 1: one piece).  Answers are those of the single-GPU calls, in the caller's
+ * order.  RCCL (librccl.so) is loaded at sdsl_hip_group_create; SDSL_HIP_ERR_NO_DEVICE if it is missing. */
+typedef struct sdsl_hip_group_s * sdsl_hip_group_t;
+sdsl_hip_status sdsl_hip_group_create(const int32_t * devices, int32_t n, sdsl_hip_group_t * out);
+sdsl_hip_status sdsl_hip_group_destroy(sdsl_hip_group_t g);
+int32_t sdsl_hip_group_size(sdsl_hip_group_t g);
+int32_t sdsl_hip_group_device(sdsl_hip_group_t g, int32_t r);
+/* link check: every device sends `bytes` to the next one of the group (to itself in a group of one) through both
+ * communicators; the data is verified; *ms_out (optional) = duration of the first round */
+sdsl_hip_status sdsl_hip_group_loopback(sdsl_hip_group_t g, uint64_t bytes, float * ms_out);
+/* replicas[0] = root (a handle on devices[0]); replicas[1..n) are new handles on the other devices, to be released with
+ * sdsl_hip_bv_destroy */
+sdsl_hip_status sdsl_hip_group_bv_replicate(sdsl_hip_group_t g, sdsl_hip_bv_t root, sdsl_hip_bv_t * replicas);
+sdsl_hip_status sdsl_hip_group_bv_rank_batch(sdsl_hip_group_t g, const sdsl_hip_bv_t * replicas, int32_t bit, const uint64_t * idx,
+                                             uint64_t n, uint64_t * out, int32_t chunks);
+sdsl_hip_status sdsl_hip_group_bv_select_batch(sdsl_hip_group_t g, const sdsl_hip_bv_t * replicas, int32_t bit, const uint64_t * i,
+                                               uint64_t n, uint64_t * out, int32_t chunks);
+/* configs[4]: the text (host memory or devices[0]) reaches every device with one broadcast and every device lays out its
+ * own csa_wt; flags as sdsl_hip_fm_create_from_text_ex; all n handles are new (sdsl_hip_fm_destroy) */
+sdsl_hip_status sdsl_hip_group_fm_create_from_text(sdsl_hip_group_t g, const uint8_t * text, uint64_t n_text, uint32_t flags,
+                                                   sdsl_hip_fm_t * replicas);
+sdsl_hip_status sdsl_hip_group_fm_count_batch(sdsl_hip_group_t g, const sdsl_hip_fm_t * replicas, const uint8_t * patterns,
+                                              uint32_t m, uint64_t n_patterns, uint64_t * out, int32_t chunks);
+
 /* ---- measurement hooks -------------------------------------------------------------------
  * Duration (ms) of the most recent kernel launched by a *_batch call on this handle's device,
  * measured with hipEvents recorded on the launch stream.  Timing is off by default because
  * the event pair adds a few microseconds; bench.py turns it on. */
 sdsl_hip_status sdsl_hip_set_timing(int32_t enabled);
+/* Process-wide knobs.  "rank_sorted": how sdsl_hip_bv_rank_batch answers a batch in device memory: 0 = always the direct
+ * kernel (one rank line per query), 1 = the bucketed path whenever the vector allows it (bv_sorted.hip: the batch is
+ * partitioned by index slice, slices are staged in LDS; 13 bytes of device scratch per query, kept with the handle),
+ * -1 = automatic (bucketed when the batch addresses every line of a vector larger than the caches several times).
+ * Answers are identical in every mode.  Initial value: environment variable SDSL_HIP_RANK_SORTED, else -1. */
+sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value);
 sdsl_hip_status sdsl_hip_last_kernel_ms(float * ms_out); /* synchronises on the stop event */
 
 #ifdef __cplusplus

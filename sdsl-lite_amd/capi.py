@@ -35,11 +35,22 @@ SIGNATURES = {
     "sdsl_hip_last_error": (C.c_char_p, []),
     "sdsl_hip_version": (C.c_char_p, []),
     "sdsl_hip_device_count": (C.c_int32, []),
+    "sdsl_hip_set_option": (C.c_int32, [C.c_char_p, C.c_int64]),
     "sdsl_hip_util_set_random_bits": (C.c_int32, [_vp, C.c_uint64, C.c_uint64]),
     "sdsl_hip_util_rnd_positions": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
     "sdsl_hip_util_mt_checkpoints": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
     "sdsl_hip_util_density_bits": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.c_uint64]),
     "sdsl_hip_util_english_text": (C.c_int32, [_vp, C.c_uint64, C.c_uint64]),
+    "sdsl_hip_group_create": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp)]),
+    "sdsl_hip_group_destroy": (C.c_int32, [_vp]),
+    "sdsl_hip_group_size": (C.c_int32, [_vp]),
+    "sdsl_hip_group_device": (C.c_int32, [_vp, C.c_int32]),
+    "sdsl_hip_group_loopback": (C.c_int32, [_vp, C.c_uint64, C.POINTER(C.c_float)]),
+    "sdsl_hip_group_bv_replicate": (C.c_int32, [_vp, _vp, C.POINTER(_vp)]),
+    "sdsl_hip_group_bv_rank_batch": (C.c_int32, [_vp, C.POINTER(_vp), C.c_int32, _vp, C.c_uint64, _vp, C.c_int32]),
+    "sdsl_hip_group_bv_select_batch": (C.c_int32, [_vp, C.POINTER(_vp), C.c_int32, _vp, C.c_uint64, _vp, C.c_int32]),
+    "sdsl_hip_group_fm_create_from_text": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.POINTER(_vp)]),
+    "sdsl_hip_group_fm_count_batch": (C.c_int32, [_vp, C.POINTER(_vp), _vp, C.c_uint32, C.c_uint64, _vp, C.c_int32]),
     "sdsl_hip_bv_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "sdsl_hip_bv_create_pattern": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.POINTER(_vp)]),

@@ -719,11 +719,11 @@ sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i
     return SDSL_HIP_OK;
 }
 
-// direct kernel or, for a large batch over a large vector, the bucketed path (bv_sorted.hip).  SDSL_HIP_RANK_SORTED:
-// 0 = never, 1 = whenever applicable; unset = automatic.
+// direct kernel or, for a large batch over a large vector, the bucketed path (bv_sorted.hip).  Option "rank_sorted"
+// (sdsl_hip_set_option; initial value from SDSL_HIP_RANK_SORTED): 0 = never, 1 = whenever possible, -1 = automatic.
 sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out, hipStream_t s)
 {
-    static const int mode = getenv("SDSL_HIP_RANK_SORTED") ? atoi(getenv("SDSL_HIP_RANK_SORTED")) : -1;
+    const int mode = g_rank_sorted_mode.load();
     const bool want = mode == 0 ? false : (mode > 0 ? bv_sorted_rank_possible(h.view) : bv_sorted_rank_applicable(h.view, n));
     if (want && n > 0)
     {
@@ -763,6 +763,41 @@ struct sdsl_hip_bv_s
     BvHost h;
     uint64_t uid = next_handle_uid(); // key of the serialiser's size-query cache
 };
+
+namespace sdslhip {
+
+BvHost & bv_host_of(sdsl_hip_bv_t bv)
+{
+    return bv->h;
+}
+
+sdsl_hip_status bv_new_replica(const BvHost & src, int device, sdsl_hip_bv_t * out)
+{
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    sdsl_hip_bv_s * bv = new (std::nothrow) sdsl_hip_bv_s();
+    if (!bv)
+        return SDSL_HIP_ERR_NOMEM;
+    BvHost & d = bv->h;
+    d.device = device;
+    d.view = src.view;
+    sdsl_hip_status st = d.lines.alloc(src.lines.bytes);
+    for (int b = 0; b < 2 && st == SDSL_HIP_OK; ++b)
+        if (src.sel[b].p)
+            st = d.sel[b].alloc(src.sel[b].bytes);
+    if (st != SDSL_HIP_OK)
+    {
+        delete bv;
+        return st;
+    }
+    d.view.lines = d.lines.as<uint64_t>();
+    for (int b = 0; b < 2; ++b)
+        d.view.sel[b] = src.sel[b].p ? d.sel[b].as<uint32_t>() : nullptr;
+    *out = bv;
+    return SDSL_HIP_OK;
+}
+
+} // namespace sdslhip
 
 extern "C" {
 

@@ -28,6 +28,10 @@ sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words
 sdsl_hip_status bv_export_words_device(const BvView & v, uint64_t * d_words, uint64_t n_words, hipStream_t s);
 sdsl_hip_status bv_launch_rank(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                                hipStream_t s);
+// the layout behind a handle, and a handle on another device with buffers of the same sizes (contents: the caller's
+// broadcast) — group.cpp
+BvHost & bv_host_of(sdsl_hip_bv_t bv);
+sdsl_hip_status bv_new_replica(const BvHost & src, int device, sdsl_hip_bv_t * out);
 // large batches, bucketed by index region (bv_sorted.hip)
 bool bv_sorted_rank_possible(const BvView & v);
 bool bv_sorted_rank_applicable(const BvView & v, uint64_t n);

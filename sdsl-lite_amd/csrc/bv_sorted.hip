@@ -38,7 +38,7 @@ constexpr unsigned kSliceLog = 10;       // lines per slice (64 KiB)
 constexpr unsigned kOffBits = 9;         // 448 < 2^9 in-line offsets
 constexpr unsigned kKey2Bits = kSliceLog + kOffBits;
 constexpr uint32_t kBad = 0xFFFFFFFFu;   // key / answer of a position beyond the vector (answer NPOS)
-constexpr unsigned kBigRun = 64;         // a (tile, bin) run longer than this is copied by the whole block
+constexpr unsigned kBigRun = 512;        // a (tile, bin) run longer than this is copied by the whole block
 constexpr unsigned kItemKeys = 32768;    // keys of one slice handled by one block before the slice is reloaded
 
 struct SrGeom
@@ -189,14 +189,17 @@ __device__ __forceinline__ void sr_load_keys(const SrGeom & g, const uint64_t * 
                                              uint32_t (&key)[kPer])
 {
     const unsigned t = threadIdx.x;
+    const unsigned cnt = (unsigned)(hi - lo); // offsets inside a tile are 32-bit (uniform base + lane offset addressing)
+    idx += lo;
+    keys_in += lo;
     if (P == 1)
     {
         uint64_t p[kPer];
 #pragma unroll
         for (unsigned u = 0; u < kPer; ++u)
         {
-            const uint64_t q = lo + (uint64_t)u * TT + t;
-            p[u] = q < hi ? __builtin_nontemporal_load(idx + q) : 0;
+            const unsigned q = u * TT + t;
+            p[u] = q < cnt ? __builtin_nontemporal_load(idx + q) : 0;
         }
 #pragma unroll
         for (unsigned u = 0; u < kPer; ++u)
@@ -208,8 +211,8 @@ __device__ __forceinline__ void sr_load_keys(const SrGeom & g, const uint64_t * 
 #pragma unroll
         for (unsigned u = 0; u < kPer; ++u)
         {
-            const uint64_t q = lo + (uint64_t)u * TT + t;
-            k1[u] = q < hi ? __builtin_nontemporal_load(keys_in + q) : 0;
+            const unsigned q = u * TT + t;
+            k1[u] = q < cnt ? __builtin_nontemporal_load(keys_in + q) : 0;
         }
 #pragma unroll
         for (unsigned u = 0; u < kPer; ++u)
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(TT) void k_sr_hist(SrGeom g, const uint64_t * __res
         sr_load_keys<P, TT>(g, idx, keys1, lo, hi, dig, key);
 #pragma unroll
         for (unsigned u = 0; u < kPer; ++u)
-            if (lo + (uint64_t)u * TT + t < hi)
+            if (u * TT + t < (unsigned)(hi - lo))
                 atomicAdd(&ghist[wv][dig[u]], 1u);
     }
     flush(cur);
@@ -428,7 +431,7 @@ struct RunShape
 
 // ---- a partition pass -------------------------------------------------------------------------------------------
 template <int P, unsigned TT>
-__global__ __launch_bounds__(TT) void k_sr_partition(SrGeom g, const uint64_t * __restrict__ idx,
+__global__ __launch_bounds__(TT, 4) void k_sr_partition(SrGeom g, const uint64_t * __restrict__ idx,
                                                      const uint32_t * __restrict__ keys_in,
                                                      const uint32_t * __restrict__ tprefix, const uint32_t * __restrict__ gstart,
                                                      const uint32_t * __restrict__ offs, uint32_t * __restrict__ keys_out,
@@ -461,13 +464,15 @@ __global__ __launch_bounds__(TT) void k_sr_partition(SrGeom g, const uint64_t * 
         uint32_t key[kPer];
         unsigned br[kPer]; // bin << 16 | rank inside the tile's share of the bin
         sr_load_keys<P, TT>(g, idx, keys_in, lo, hi, br, key);
+        const unsigned cnt_t = (unsigned)(hi - lo);
+        uint16_t * slots_t = slots + lo;
 #pragma unroll
         for (unsigned u = 0; u < kPer; ++u)
         {
-            const uint64_t q = lo + (uint64_t)u * TT + t;
+            const unsigned q = u * TT + t;
             const unsigned d = br[u];
             br[u] = d << 16;
-            if (q < hi)
+            if (q < cnt_t)
                 br[u] |= atomicAdd(&hist[d], 1u); // < 2^14
         }
         __syncthreads();
@@ -480,12 +485,12 @@ __global__ __launch_bounds__(TT) void k_sr_partition(SrGeom g, const uint64_t * 
 #pragma unroll
         for (unsigned u = 0; u < kPer; ++u)
         {
-            const uint64_t q = lo + (uint64_t)u * TT + t;
-            if (q < hi)
+            const unsigned q = u * TT + t;
+            if (q < cnt_t)
             {
                 const unsigned pos = start[br[u] >> 16] + (br[u] & 0xFFFFu);
                 sorted[pos] = key[u];
-                __builtin_nontemporal_store((uint16_t)pos, slots + q);
+                __builtin_nontemporal_store((uint16_t)pos, slots_t + q);
             }
         }
         __syncthreads();
@@ -503,8 +508,9 @@ __global__ __launch_bounds__(TT) void k_sr_partition(SrGeom g, const uint64_t * 
                         big[atomicAdd(&n_big, 1u)] = b;
                     continue;
                 }
+                uint32_t * dst = keys_out + cur;
                 for (unsigned i = l; i < cnt; i += 16)
-                    keys_out[(uint64_t)cur + i] = sorted[st + i];
+                    dst[i] = sorted[st + i];
             }
         }
         __syncthreads();
@@ -523,6 +529,10 @@ __global__ __launch_bounds__(TT) void k_sr_partition(SrGeom g, const uint64_t * 
 }
 
 // ---- rank out of LDS, in place over the final keys -----------------------------------------------------------------
+// Once a slice is in LDS every line header is rewritten for the queries to come: [ones before the line, relative to
+// the slice: 20 bits | ones in word 0: 9 bits | in words 0..2: 9 bits | in words 0..4: 9 bits].  A query then reads
+// the header's 16 bytes and the one 16-byte pair that holds its word: two LDS reads and two popcounts instead of the
+// whole line (the first form of this kernel spent 1.4 wave instructions per key, 65 % of its time in the VALU).
 __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigned nf, const uint32_t * __restrict__ fstart,
                                                      const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys)
 {
@@ -550,61 +560,64 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
         __syncthreads(); // also: everybody is done with the previous slice
         const unsigned f = sh_f;
         const uint64_t L0 = (uint64_t)f << kSliceLog;
-        const uint64_t nl = bv.n_lines - L0 < (UINT64_C(1) << kSliceLog) ? bv.n_lines - L0 : (UINT64_C(1) << kSliceLog);
+        const unsigned nl = (unsigned)(bv.n_lines - L0 < (UINT64_C(1) << kSliceLog) ? bv.n_lines - L0 : (UINT64_C(1) << kSliceLog));
         const v2u64 * src = reinterpret_cast<const v2u64 *>(bv.lines + L0 * kLW);
         for (unsigned i = t; i < nl * (kLW / 2); i += kRT)
             slice[i] = __builtin_nontemporal_load(src + i);
         const uint64_t lo = (uint64_t)fstart[f] + (uint64_t)(item - ioff[f]) * kItemKeys;
         const uint64_t fend = fstart[f + 1];
-        const uint64_t hi = lo + kItemKeys < fend ? lo + kItemKeys : fend;
+        const unsigned cnt = (unsigned)(lo + kItemKeys < fend ? kItemKeys : fend - lo);
+        uint32_t * kp = keys + lo;
+        // the first keys are asked for while the headers are being rewritten
+        uint32_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            const unsigned i = t + (unsigned)u * kRT;
+            key[u] = i < cnt ? __builtin_nontemporal_load(kp + i) : kBad;
+        }
         __syncthreads();
         const uint64_t H = slice[0].x;
-        for (uint64_t q0 = lo + t; q0 < hi; q0 += (uint64_t)kRT * U)
+        __syncthreads();
+        for (unsigned ln = t; ln < nl; ln += kRT)
         {
-            uint32_t key[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
+            v2u64 * w = slice + ln * (kLW / 2);
+            const v2u64 a = w[0], b = w[1], c = w[2];
+            const unsigned ca = popc64(a.y), cb = ca + popc64(b.x) + popc64(b.y), cc = cb + popc64(c.x) + popc64(c.y);
+            w[0].x = (a.x - H) | ((uint64_t)ca << 20) | ((uint64_t)cb << 29) | ((uint64_t)cc << 38);
+        }
+        __syncthreads();
+        for (unsigned i0 = t; i0 < cnt; i0 += kRT * U)
+        {
+            if (i0 != t)
             {
-                const uint64_t q = q0 + (uint64_t)u * kRT;
-                key[u] = q < hi ? __builtin_nontemporal_load(keys + q) : kBad;
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    const unsigned i = i0 + (unsigned)u * kRT;
+                    key[u] = i < cnt ? __builtin_nontemporal_load(kp + i) : kBad;
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
             {
-                const uint64_t q = q0 + (uint64_t)u * kRT;
+                const unsigned i = i0 + (unsigned)u * kRT;
                 const unsigned ln = key[u] == kBad ? 0 : key[u] >> kOffBits;
                 const unsigned off = key[u] & ((1u << kOffBits) - 1);
                 const v2u64 * w = slice + ln * (kLW / 2);
-                // ones below in-line offset `off`: word j contributes its low clamp(off - 64 j, 0, 64) bits; only the
-                // 16-byte quarters that hold such words are read (exec-masked LDS reads: fewer bank conflicts)
-                auto low = [&](uint64_t x, int j) -> unsigned
-                {
-                    const int tt = (int)off - 64 * j;
-                    return tt <= 0 ? 0u : (tt >= 64 ? popc64(x) : popc64(x << (64 - tt)));
-                };
+                const unsigned wi = off >> 6, k = (wi + 1) >> 1; // data word of the position, 16-byte quarter holding it
                 const v2u64 a = w[0];
-                unsigned cnt = low(a.y, 0);
-                if (off > 64)
-                {
-                    const v2u64 b = w[1];
-                    cnt += low(b.x, 1) + low(b.y, 2);
-                }
-                if (off > 192)
-                {
-                    const v2u64 c = w[2];
-                    cnt += low(c.x, 3) + low(c.y, 4);
-                }
-                if (off > 320)
-                {
-                    const v2u64 d = w[3];
-                    cnt += low(d.x, 5) + low(d.y, 6);
-                }
-                const uint32_t r1 = (uint32_t)(a.x - H) + cnt;
+                const v2u64 p = w[k]; // k == 0: the header's own quarter again (same address, no second bank access)
+                const uint64_t x = k ? p.x : 0, y = k ? p.y : a.y;
+                const uint64_t m = lo_set(off & 63);
+                const unsigned base = k ? (unsigned)(a.x >> (11 + 9 * k)) & 0x1FFu : 0u;
+                const unsigned part = (wi & 1) ? popc64(x & m) : popc64(x) + popc64(y & m);
+                const uint32_t r1 = ((uint32_t)a.x & 0xFFFFFu) + base + part;
                 uint32_t r = bit ? r1 : ln * (uint32_t)kDB + off - r1;
                 if (key[u] == kBad)
                     r = kBad;
-                if (q < hi)
-                    __builtin_nontemporal_store(r, keys + q);
+                if (i < cnt)
+                    __builtin_nontemporal_store(r, kp + i);
             }
         }
     }
@@ -615,7 +628,7 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
 // P == 1: absolute answers in the order of partition 1 -> the caller's array
 // V & 1: the runs are fetched four bins at a time (else bin after bin); V & 2: the slots are asked for before the gather
 template <int P, unsigned TT, int V>
-__global__ __launch_bounds__(TT) void k_sr_unpermute(const uint64_t * __restrict__ hf, int bit, SrGeom g, const uint32_t * __restrict__ tprefix,
+__global__ __launch_bounds__(TT, 4) void k_sr_unpermute(const uint64_t * __restrict__ hf, int bit, SrGeom g, const uint32_t * __restrict__ tprefix,
                                                      const uint32_t * __restrict__ gstart, const uint32_t * __restrict__ offs,
                                                      const uint32_t * __restrict__ res_lo, const uint8_t * __restrict__ res_hi,
                                                      const uint16_t * __restrict__ slots,
@@ -643,13 +656,15 @@ __global__ __launch_bounds__(TT) void k_sr_unpermute(const uint64_t * __restrict
         unsigned grp;
         sr_tile_range<P, TT>(g, map, ti, lo, hi, grp);
         uint16_t sl[kPer];
+        const unsigned cnt_t = (unsigned)(hi - lo);
+        const uint16_t * slots_t = slots + lo;
         if (V & 2)
         { // the slots of this tile: asked for now, used after the gather
 #pragma unroll
             for (unsigned u = 0; u < kPer; ++u)
             {
-                const uint64_t q = lo + (uint64_t)u * TT + t;
-                sl[u] = q < hi ? __builtin_nontemporal_load(slots + q) : (uint16_t)0;
+                const unsigned q = u * TT + t;
+                sl[u] = q < cnt_t ? __builtin_nontemporal_load(slots_t + q) : (uint16_t)0;
             }
         }
         for (unsigned i = t; i < kBins; i += TT)
@@ -770,25 +785,28 @@ __global__ __launch_bounds__(TT) void k_sr_unpermute(const uint64_t * __restrict
 #pragma unroll
             for (unsigned u = 0; u < kPer; ++u)
             {
-                const uint64_t q = lo + (uint64_t)u * TT + t;
-                sl[u] = q < hi ? __builtin_nontemporal_load(slots + q) : (uint16_t)0;
+                const unsigned q = u * TT + t;
+                sl[u] = q < cnt_t ? __builtin_nontemporal_load(slots_t + q) : (uint16_t)0;
             }
         }
+        uint32_t * out_lo_t = P == 2 ? out_lo + lo : nullptr;
+        uint8_t * out_hi_t = P == 2 ? out_hi + lo : nullptr;
+        uint64_t * out_t = P == 1 ? out + lo : nullptr;
 #pragma unroll
         for (unsigned u = 0; u < kPer; ++u)
         {
-            const uint64_t q = lo + (uint64_t)u * TT + t;
-            if (q < hi)
+            const unsigned q = u * TT + t;
+            if (q < cnt_t)
             {
                 const unsigned h = hi8[sl[u]];
                 const uint32_t l32 = lo32[sl[u]];
                 if (P == 2)
                 {
-                    __builtin_nontemporal_store(l32, out_lo + q);
-                    __builtin_nontemporal_store((uint8_t)h, out_hi + q);
+                    __builtin_nontemporal_store(l32, out_lo_t + q);
+                    __builtin_nontemporal_store((uint8_t)h, out_hi_t + q);
                 }
                 else
-                    __builtin_nontemporal_store(h == 0xFFu ? SDSL_HIP_NPOS : ((uint64_t)h << 32) | l32, out + q);
+                    __builtin_nontemporal_store(h == 0xFFu ? SDSL_HIP_NPOS : ((uint64_t)h << 32) | l32, out_t + q);
             }
         }
         for (unsigned i = t; i < kBins; i += TT)

@@ -9,6 +9,8 @@ namespace sdslhip {
 
 static thread_local std::string g_err;
 static bool g_timing = false;
+// batched rank on a plain vector: -1 automatic, 0 always the direct kernel, 1 the bucketed path whenever it applies
+std::atomic<int> g_rank_sorted_mode{getenv("SDSL_HIP_RANK_SORTED") ? atoi(getenv("SDSL_HIP_RANK_SORTED")) : -1};
 static thread_local bool g_timing_suppressed = false; // pipeline workers: the event pair is global
 static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static bool g_ev_valid = false;
@@ -227,6 +229,17 @@ sdsl_hip_status sdsl_hip_util_set_random_bits(uint64_t * words, uint64_t n_bits,
     for (uint64_t i = 0; i < nw; ++i)
         words[i] = rng();
     return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value)
+{
+    if (name && !strcmp(name, "rank_sorted"))
+    {
+        sdslhip::g_rank_sorted_mode.store((int)value);
+        return SDSL_HIP_OK;
+    }
+    set_error("set_option: unknown option '%s'", name ? name : "(null)");
+    return SDSL_HIP_ERR_INVALID;
 }
 
 sdsl_hip_status sdsl_hip_set_timing(int32_t enabled)

@@ -2,6 +2,7 @@
 // device buffers, staging of host-resident batches, kernel timing).  gfx950 only.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,6 +21,7 @@
 
 namespace sdslhip {
 
+extern std::atomic<int> g_rank_sorted_mode; // sdsl_hip_set_option("rank_sorted", ...)
 const char * last_error_message();
 void suppress_timing_in_this_thread();
 void set_error(const char * fmt, ...);

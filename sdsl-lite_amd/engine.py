@@ -212,6 +212,11 @@ def last_kernel_ms() -> float:
     return float(ms.value)
 
 
+def set_option(name: str, value: int) -> None:
+    """sdsl_hip_set_option, e.g. set_option("rank_sorted", 1)."""
+    capi.check(capi.lib().sdsl_hip_set_option(name.encode(), int(value)))
+
+
 def set_random_bits(n_bits: int, seed: int) -> np.ndarray:
     """util::set_random_bits on a fresh bit_vector(n_bits): returns the uint64 words."""
     w = np.zeros((n_bits + 63) // 64, dtype=np.uint64)

@@ -1,0 +1,98 @@
+"""GPU, BASELINE size: the HIP path against answers of the REAL sdsl-lite on the SURVEY.md 8(d) inputs.
+
+tests/golden/golden_large.json was produced in the build container by tests/golden/make_golden_large.py through
+oracle/_ref (the reference's own headers): for configs[1] (2^34-bit vector of mt19937_64(42) words), configs[2]
+(2^34 bits, 5 % dense, mt19937_64(9)) and configs[3]/[4] (wavelet tree / FM-index of the 2^30-byte English-class text) it
+holds, per query stream, sum / xor / sha256 of the reference's answers and the first 10^4 answers.  Here the same inputs are
+regenerated from their seeds, the structures are built on the GPU, and the answers must have the same digests — bit-exact
+at full size, no property test standing in for the reference."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "golden_large.json")))
+
+
+def check(ans, want, what):
+    a = np.ascontiguousarray(ans).view(np.uint64)
+    assert a.size == want["n"], what
+    first = np.array(want["first"], dtype=np.uint64)
+    assert np.array_equal(a[: first.size], first), f"{what}: first answers differ from the reference's"
+    assert int(np.add.reduce(a, dtype=np.uint64)) == want["sum"], f"{what}: sum of answers"
+    assert int(np.bitwise_xor.reduce(a)) == want["xor"], f"{what}: xor of answers"
+    assert hashlib.sha256(a.tobytes()).hexdigest() == want["sha256"], f"{what}: sha256 of answers"
+
+
+@pytest.fixture(scope="module")
+def c2_vector(gpu):
+    c = G["c2"]
+    n = 1 << c["log_n"]
+    bv = gpu.bit_vector(gpu.set_random_bits(n, c["words_seed"]), n, device=0)
+    assert bv.ones() == c["ones"]
+    yield bv, n
+    bv.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["direct", "bucketed"])
+def test_c2_rank_1_matches_reference_digests(gpu, c2_vector, mode):
+    import torch
+    bv, n = c2_vector
+    c = G["c2"]
+    idx = torch.from_numpy(gpu.rnd_positions(c["rank_seed"], c["rank_1"]["n"], n + 1, 0).view(np.int64)).cuda()
+    gpu.set_option("rank_sorted", mode)
+    try:
+        out = bv.rank(idx, 1)
+        zeros = bv.rank(idx, 0)
+    finally:
+        gpu.set_option("rank_sorted", -1)
+    check(out.cpu().numpy(), c["rank_1"], f"configs[1] rank_1 ({'bucketed' if mode else 'direct'} path)")
+    assert bool((out + zeros == idx).all())
+
+
+def test_c2_select_1_matches_reference_digests(gpu, c2_vector):
+    import torch
+    bv, n = c2_vector
+    c = G["c2"]
+    i = torch.from_numpy(gpu.rnd_positions(c["select_seed"], c["select_1"]["n"], c["ones"], 1).view(np.int64)).cuda()
+    check(bv.select(i, 1).cpu().numpy(), c["select_1"], "configs[1] select_1")
+
+
+def test_c3_rrr63_rank_select_match_reference_digests(gpu):
+    import torch
+    c = G["c3"]
+    n = 1 << c["log_n"]
+    ck = np.fromfile(os.path.join(HERE, "golden", "mt9_checkpoints.bin"), dtype=np.uint64).reshape(-1, 313)
+    assert ck.shape[0] == c["checkpoints"]
+    words = gpu.density_bits(n, c["bits_seed"], c["percent"], ck, c["checkpoint_stride"])
+    assert hashlib.sha256(words.tobytes()).hexdigest() == c["words_sha256"], "configs[2] input vector"
+    rv = gpu.rrr_vector(words, n, device=0)
+    del words
+    assert rv.ones() == c["ones"]
+    idx = torch.from_numpy(gpu.rnd_positions(c["rank_seed"], c["rank_1"]["n"], n + 1, 0).view(np.int64)).cuda()
+    check(rv.rank(idx, 1).cpu().numpy(), c["rank_1"], "configs[2] rrr rank_1")
+    i = torch.from_numpy(gpu.rnd_positions(c["select_seed"], c["select_1"]["n"], c["ones"], 1).view(np.int64)).cuda()
+    check(rv.select(i, 1).cpu().numpy(), c["select_1"], "configs[2] rrr select_1")
+    rv.close()
+
+
+def test_c4_wt_rank_and_count_match_reference_digests(gpu):
+    import torch
+    c = G["c4"]
+    nt = 1 << c["text_log"]
+    text = gpu.english_text(nt, c["text_seed"])
+    assert hashlib.sha256(text.tobytes()).hexdigest() == c["text_sha256"], "configs[3] text"
+    csa = gpu.csa_wt(text=torch.from_numpy(text).cuda(), device=0)
+    assert csa.size() == c["csa_size"] and csa.sigma() == c["sigma"]
+    gi = torch.from_numpy(gpu.rnd_positions(c["wt_i_seed"], c["wt_rank"]["n"], nt + 2, 0).view(np.int64)).cuda()
+    gc = torch.from_numpy(text[gpu.rnd_positions(c["wt_c_seed"], c["wt_rank"]["n"], nt, 0).astype(np.int64)]).cuda()
+    check(csa.wavelet_tree.rank(gi, gc).cpu().numpy(), c["wt_rank"], "configs[3] wt_huff rank(i, c)")
+    m = c["m"]
+    st = gpu.rnd_positions(c["pattern_seed"], c["count"]["n"], nt - m, 0).astype(np.int64)
+    pats = torch.from_numpy(np.ascontiguousarray(text[st[:, None] + np.arange(m)[None, :]].reshape(-1))).cuda()
+    check(csa.count(pats, m).cpu().numpy(), c["count"], "configs[4] count of 20-byte patterns")
+    csa.close()
