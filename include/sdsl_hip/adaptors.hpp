@@ -865,4 +865,114 @@ inline void backward_search_batch(csa_wt_hip const & csa, uint64_t const * l, ui
                       "sdsl_hip_fm_backward_search_batch");
 }
 
+// ---- several GPUs of one node ------------------------------------------------------------------
+//! The devices a batch is sharded over.  Index structures built on a group are replicated (one RCCL broadcast at load
+//! time); a batch call scatters the arguments from the root device, runs the single-GPU kernels everywhere and gathers
+//! the answers (sdsl_hip.h, "several GPUs of one node").
+class device_group
+{
+    struct deleter
+    {
+        void operator()(sdsl_hip_group_s * p) const
+        {
+            sdsl_hip_group_destroy(p);
+        }
+    };
+    std::shared_ptr<sdsl_hip_group_s> m_g;
+
+public:
+    explicit device_group(std::vector<int32_t> const & devices)
+    {
+        sdsl_hip_group_t g = nullptr;
+        hip_detail::check(sdsl_hip_group_create(devices.data(), (int32_t)devices.size(), &g), "sdsl_hip_group_create");
+        m_g.reset(g, deleter());
+    }
+    int size() const
+    {
+        return sdsl_hip_group_size(m_g.get());
+    }
+    int device(int r) const
+    {
+        return sdsl_hip_group_device(m_g.get(), r);
+    }
+    sdsl_hip_group_t handle() const
+    {
+        return m_g.get();
+    }
+};
+
+//! rank_support_v5<0/1> and select_support_mcl<0/1> of one bit_vector on every device of a group.
+class bit_vector_multi_hip
+{
+public:
+    typedef bit_vector::size_type size_type;
+
+private:
+    device_group m_g;
+    std::shared_ptr<std::vector<sdsl_hip_bv_t>> m_rep;
+
+public:
+    bit_vector_multi_hip(bit_vector const & v, device_group const & g, uint32_t flags = SDSL_HIP_BV_SELECT1 | SDSL_HIP_BV_SELECT0)
+        : m_g(g)
+    {
+        sdsl_hip_bv_t root = nullptr;
+        hip_detail::check(sdsl_hip_bv_create(v.data(), v.bit_size(), g.device(0), flags, &root), "sdsl_hip_bv_create");
+        m_rep.reset(new std::vector<sdsl_hip_bv_t>((size_t)g.size(), nullptr),
+                    [](std::vector<sdsl_hip_bv_t> * r)
+                    {
+                        for (sdsl_hip_bv_t h : *r)
+                            sdsl_hip_bv_destroy(h);
+                        delete r;
+                    });
+        (*m_rep)[0] = root;
+        hip_detail::check(sdsl_hip_group_bv_replicate(g.handle(), root, m_rep->data()), "sdsl_hip_group_bv_replicate");
+    }
+    //! out[q] = rank_support_v5<t_b>(&v)(idx[q]); arrays in host memory or in the root device's memory
+    template <uint8_t t_b = 1>
+    void rank_batch(size_type const * idx, size_t n, size_type * out, int chunks = 4) const
+    {
+        hip_detail::check(sdsl_hip_group_bv_rank_batch(m_g.handle(), m_rep->data(), t_b, idx, n, out, chunks),
+                          "sdsl_hip_group_bv_rank_batch");
+    }
+    //! out[q] = select_support_mcl<t_b>(&v)(i[q])
+    template <uint8_t t_b = 1>
+    void select_batch(size_type const * i, size_t n, size_type * out, int chunks = 4) const
+    {
+        hip_detail::check(sdsl_hip_group_bv_select_batch(m_g.handle(), m_rep->data(), t_b, i, n, out, chunks),
+                          "sdsl_hip_group_bv_select_batch");
+    }
+};
+
+//! csa_wt<wt_huff<>> of one text on every device of a group (the text is broadcast once, every device lays out its own
+//! index); count_batch shards the patterns.
+class csa_wt_multi_hip
+{
+    device_group m_g;
+    std::shared_ptr<std::vector<sdsl_hip_fm_t>> m_rep;
+
+public:
+    csa_wt_multi_hip(uint8_t const * text, size_t n, device_group const & g, uint32_t flags = 0) : m_g(g)
+    {
+        m_rep.reset(new std::vector<sdsl_hip_fm_t>((size_t)g.size(), nullptr),
+                    [](std::vector<sdsl_hip_fm_t> * r)
+                    {
+                        for (sdsl_hip_fm_t h : *r)
+                            sdsl_hip_fm_destroy(h);
+                        delete r;
+                    });
+        hip_detail::check(sdsl_hip_group_fm_create_from_text(g.handle(), text, n, flags, m_rep->data()),
+                          "sdsl_hip_group_fm_create_from_text");
+    }
+    uint64_t size() const
+    {
+        return sdsl_hip_fm_size((*m_rep)[0]);
+    }
+    //! sdsl::count (suffix_array_algorithm.hpp:464-471) for n patterns of m bytes each
+    void count_batch(uint8_t const * patterns, uint32_t m, size_t n, uint64_t * out, int chunks = 4) const
+    {
+        hip_detail::check(sdsl_hip_group_fm_count_batch(m_g.handle(), m_rep->data(), patterns, m, n, out, chunks),
+                          "sdsl_hip_group_fm_count_batch");
+    }
+};
+
 } // namespace sdsl

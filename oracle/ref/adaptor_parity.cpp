@@ -447,6 +447,65 @@ int main(int argc, char ** argv)
             sdsl_hip_sd_destroy(sh);
         }
     }
+    // several GPUs of one node (all the box has; a group of one still goes through the group driver and RCCL's setup)
+    {
+        int n_dev = sdsl_hip_device_count();
+        std::vector<int32_t> devs;
+        for (int d = 0; d < n_dev; ++d)
+            devs.push_back(d);
+        device_group grp(devs);
+        bit_vector bv(3000017, 0);
+        for (uint64_t i = 0; i < bv.size(); ++i)
+            bv[i] = (rng() % 100) < 37;
+        rank_support_v5<1> r1(&bv);
+        rank_support_v5<0> r0(&bv);
+        select_support_mcl<1> s1(&bv);
+        bit_vector_multi_hip mv(bv, grp);
+        const size_t nq = 700001;
+        std::vector<uint64_t> q(nq), out(nq);
+        for (auto & x : q)
+            x = rng() % (bv.size() + 1);
+        mv.rank_batch<1>(q.data(), nq, out.data(), 3);
+        bool ok = true;
+        for (size_t i = 0; i < nq; ++i)
+            ok &= out[i] == r1(q[i]);
+        CHECK(ok, "bit_vector_multi_hip rank_batch<1>");
+        mv.rank_batch<0>(q.data(), nq, out.data(), 1);
+        ok = true;
+        for (size_t i = 0; i < nq; ++i)
+            ok &= out[i] == r0(q[i]);
+        CHECK(ok, "bit_vector_multi_hip rank_batch<0>");
+        const uint64_t ones = r1(bv.size());
+        for (auto & x : q)
+            x = 1 + rng() % ones;
+        mv.select_batch<1>(q.data(), nq, out.data(), 4);
+        ok = true;
+        for (size_t i = 0; i < nq; ++i)
+            ok &= out[i] == s1(q[i]);
+        CHECK(ok, "bit_vector_multi_hip select_batch<1>");
+        // count over a group against sdsl::count on the host index
+        std::string text;
+        for (int i = 0; i < 300000; ++i)
+            text.push_back((char)('a' + rng() % 7));
+        csa_wt<wt_huff<bit_vector, rank_support_v5<>>> csa;
+        construct_im(csa, text, 1);
+        csa_wt_multi_hip mcsa((uint8_t const *)text.data(), text.size(), grp);
+        const uint32_t m = 6;
+        const size_t np = 50000;
+        std::vector<uint8_t> pats(np * m);
+        for (size_t i = 0; i < np; ++i)
+        {
+            size_t at = rng() % (text.size() - m);
+            for (uint32_t k = 0; k < m; ++k)
+                pats[i * m + k] = (uint8_t)text[at + k];
+        }
+        std::vector<uint64_t> cnt(np);
+        mcsa.count_batch(pats.data(), m, np, cnt.data(), 2);
+        ok = mcsa.size() == csa.size();
+        for (size_t i = 0; i < np; ++i)
+            ok &= cnt[i] == count(csa, pats.begin() + i * m, pats.begin() + (i + 1) * m);
+        CHECK(ok, "csa_wt_multi_hip count_batch");
+    }
     printf(g_fail ? "adaptor parity: %d FAILED\n" : "adaptor parity: all equal\n", g_fail);
     return g_fail ? 1 : 0;
 }

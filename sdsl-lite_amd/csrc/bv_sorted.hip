@@ -31,7 +31,6 @@ namespace sdslhip {
 
 namespace {
 
-constexpr unsigned kPer = 16;            // keys per thread per tile; a tile = 16 * (threads of the block) keys
 constexpr unsigned kRT = 512;            // threads of a rank block
 constexpr unsigned kBins = 256;          // bins per pass (8-bit digits)
 constexpr unsigned kSliceLog = 10;       // lines per slice (64 KiB)
@@ -156,11 +155,11 @@ __device__ __forceinline__ unsigned sr_tiles(const SrGeom & g, const TileMap & m
 {
     return P == 1 ? g.tiles1 : m.tp[1u << g.d1];
 }
-template <int P, unsigned TT>
+template <int P>
 __device__ __forceinline__ void sr_tile_range(const SrGeom & g, const TileMap & m, unsigned ti, uint64_t & lo, uint64_t & hi,
                                               unsigned & grp)
 {
-    constexpr unsigned kTile = TT * kPer;
+    const unsigned kTile = g.tile;
     if (P == 1)
     {
         grp = 0;
@@ -182,11 +181,11 @@ __device__ __forceinline__ void sr_tile_range(const SrGeom & g, const TileMap & 
     hi = lo + kTile < m.gs[a + 1] ? lo + kTile : m.gs[a + 1];
 }
 
-// digits of the kPer keys of this thread in tile [lo, hi); all loads are issued before the first is used
-template <int P, unsigned TT>
+// digits of the PER keys of this thread in tile [lo, hi); all loads are issued before the first is used
+template <int P, unsigned TT, unsigned PER>
 __device__ __forceinline__ void sr_load_keys(const SrGeom & g, const uint64_t * __restrict__ idx,
-                                             const uint32_t * __restrict__ keys_in, uint64_t lo, uint64_t hi, unsigned (&dig)[kPer],
-                                             uint32_t (&key)[kPer])
+                                             const uint32_t * __restrict__ keys_in, uint64_t lo, uint64_t hi, unsigned (&dig)[PER],
+                                             uint32_t (&key)[PER])
 {
     const unsigned t = threadIdx.x;
     const unsigned cnt = (unsigned)(hi - lo); // offsets inside a tile are 32-bit (uniform base + lane offset addressing)
@@ -194,34 +193,34 @@ __device__ __forceinline__ void sr_load_keys(const SrGeom & g, const uint64_t * 
     keys_in += lo;
     if (P == 1)
     {
-        uint64_t p[kPer];
+        uint64_t p[PER];
 #pragma unroll
-        for (unsigned u = 0; u < kPer; ++u)
+        for (unsigned u = 0; u < PER; ++u)
         {
             const unsigned q = u * TT + t;
             p[u] = q < cnt ? __builtin_nontemporal_load(idx + q) : 0;
         }
 #pragma unroll
-        for (unsigned u = 0; u < kPer; ++u)
+        for (unsigned u = 0; u < PER; ++u)
             sr_key1(p[u], g, dig[u], key[u]);
     }
     else
     {
-        uint32_t k1[kPer];
+        uint32_t k1[PER];
 #pragma unroll
-        for (unsigned u = 0; u < kPer; ++u)
+        for (unsigned u = 0; u < PER; ++u)
         {
             const unsigned q = u * TT + t;
             k1[u] = q < cnt ? __builtin_nontemporal_load(keys_in + q) : 0;
         }
 #pragma unroll
-        for (unsigned u = 0; u < kPer; ++u)
+        for (unsigned u = 0; u < PER; ++u)
             sr_key2(k1[u], dig[u], key[u]);
     }
 }
 
 // ---- histogram of a pass: counts[bin][block]; pass 2 also counts per slice ------------------------------------------
-template <int P, unsigned TT>
+template <int P, unsigned TT, unsigned PER>
 __global__ __launch_bounds__(TT) void k_sr_hist(SrGeom g, const uint64_t * __restrict__ idx, const uint32_t * __restrict__ keys1,
                                                 const uint32_t * __restrict__ tprefix, const uint32_t * __restrict__ gstart,
                                                 uint32_t * __restrict__ counts, uint32_t * __restrict__ fine_count)
@@ -264,15 +263,15 @@ __global__ __launch_bounds__(TT) void k_sr_hist(SrGeom g, const uint64_t * __res
     {
         uint64_t lo, hi;
         unsigned grp;
-        sr_tile_range<P, TT>(g, map, ti, lo, hi, grp);
+        sr_tile_range<P>(g, map, ti, lo, hi, grp);
         if (P == 2 && grp != cur && ti != tlo)
             flush(cur);
         cur = grp;
-        unsigned dig[kPer];
-        uint32_t key[kPer];
-        sr_load_keys<P, TT>(g, idx, keys1, lo, hi, dig, key);
+        unsigned dig[PER];
+        uint32_t key[PER];
+        sr_load_keys<P, TT, PER>(g, idx, keys1, lo, hi, dig, key);
 #pragma unroll
-        for (unsigned u = 0; u < kPer; ++u)
+        for (unsigned u = 0; u < PER; ++u)
             if (u * TT + t < (unsigned)(hi - lo))
                 atomicAdd(&ghist[wv][dig[u]], 1u);
     }
@@ -430,14 +429,14 @@ struct RunShape
 };
 
 // ---- a partition pass -------------------------------------------------------------------------------------------
-template <int P, unsigned TT>
-__global__ __launch_bounds__(TT, 4) void k_sr_partition(SrGeom g, const uint64_t * __restrict__ idx,
+template <int P, unsigned TT, unsigned PER>
+__global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_partition(SrGeom g, const uint64_t * __restrict__ idx,
                                                      const uint32_t * __restrict__ keys_in,
                                                      const uint32_t * __restrict__ tprefix, const uint32_t * __restrict__ gstart,
                                                      const uint32_t * __restrict__ offs, uint32_t * __restrict__ keys_out,
                                                      uint16_t * __restrict__ slots, uint16_t * __restrict__ tile_hist)
 {
-    constexpr unsigned kTile = TT * kPer;
+    constexpr unsigned kTile = TT * PER;
     __shared__ uint32_t sorted[kTile];
     __shared__ unsigned hist[kBins], start[kBins], cursor[kBins];
     __shared__ unsigned wsum[kBins / 64];
@@ -455,19 +454,19 @@ __global__ __launch_bounds__(TT, 4) void k_sr_partition(SrGeom g, const uint64_t
     {
         uint64_t lo, hi;
         unsigned grp;
-        sr_tile_range<P, TT>(g, map, ti, lo, hi, grp);
+        sr_tile_range<P>(g, map, ti, lo, hi, grp);
         for (unsigned i = t; i < kBins; i += TT)
             hist[i] = 0;
         if (t == 0)
             n_big = 0;
         __syncthreads();
-        uint32_t key[kPer];
-        unsigned br[kPer]; // bin << 16 | rank inside the tile's share of the bin
-        sr_load_keys<P, TT>(g, idx, keys_in, lo, hi, br, key);
+        uint32_t key[PER];
+        unsigned br[PER]; // bin << 16 | rank inside the tile's share of the bin
+        sr_load_keys<P, TT, PER>(g, idx, keys_in, lo, hi, br, key);
         const unsigned cnt_t = (unsigned)(hi - lo);
         uint16_t * slots_t = slots + lo;
 #pragma unroll
-        for (unsigned u = 0; u < kPer; ++u)
+        for (unsigned u = 0; u < PER; ++u)
         {
             const unsigned q = u * TT + t;
             const unsigned d = br[u];
@@ -483,7 +482,7 @@ __global__ __launch_bounds__(TT, 4) void k_sr_partition(SrGeom g, const uint64_t
         for (unsigned i = t; i < bins; i += TT)
             tile_hist[(uint64_t)ti * bins + i] = (uint16_t)hist[i];
 #pragma unroll
-        for (unsigned u = 0; u < kPer; ++u)
+        for (unsigned u = 0; u < PER; ++u)
         {
             const unsigned q = u * TT + t;
             if (q < cnt_t)
@@ -627,15 +626,15 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
 // P == 2: slice-relative answers (order of partition 2) -> absolute answers in the order of partition 1 (lo32 / hi8)
 // P == 1: absolute answers in the order of partition 1 -> the caller's array
 // V & 1: the runs are fetched four bins at a time (else bin after bin); V & 2: the slots are asked for before the gather
-template <int P, unsigned TT, int V>
-__global__ __launch_bounds__(TT, 4) void k_sr_unpermute(const uint64_t * __restrict__ hf, int bit, SrGeom g, const uint32_t * __restrict__ tprefix,
+template <int P, unsigned TT, unsigned PER, int V>
+__global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const uint64_t * __restrict__ hf, int bit, SrGeom g, const uint32_t * __restrict__ tprefix,
                                                      const uint32_t * __restrict__ gstart, const uint32_t * __restrict__ offs,
                                                      const uint32_t * __restrict__ res_lo, const uint8_t * __restrict__ res_hi,
                                                      const uint16_t * __restrict__ slots,
                                                      const uint16_t * __restrict__ tile_hist, uint32_t * __restrict__ out_lo,
                                                      uint8_t * __restrict__ out_hi, uint64_t * __restrict__ out)
 {
-    constexpr unsigned kTile = TT * kPer;
+    constexpr unsigned kTile = TT * PER;
     __shared__ uint32_t lo32[kTile];
     __shared__ uint8_t hi8[kTile];
     __shared__ unsigned hist[kBins], start[kBins], cursor[kBins];
@@ -654,14 +653,14 @@ __global__ __launch_bounds__(TT, 4) void k_sr_unpermute(const uint64_t * __restr
     {
         uint64_t lo, hi;
         unsigned grp;
-        sr_tile_range<P, TT>(g, map, ti, lo, hi, grp);
-        uint16_t sl[kPer];
+        sr_tile_range<P>(g, map, ti, lo, hi, grp);
+        uint16_t sl[PER];
         const unsigned cnt_t = (unsigned)(hi - lo);
         const uint16_t * slots_t = slots + lo;
         if (V & 2)
         { // the slots of this tile: asked for now, used after the gather
 #pragma unroll
-            for (unsigned u = 0; u < kPer; ++u)
+            for (unsigned u = 0; u < PER; ++u)
             {
                 const unsigned q = u * TT + t;
                 sl[u] = q < cnt_t ? __builtin_nontemporal_load(slots_t + q) : (uint16_t)0;
@@ -721,52 +720,51 @@ __global__ __launch_bounds__(TT, 4) void k_sr_unpermute(const uint64_t * __restr
             }
         }
         else
-        {
-            constexpr unsigned kIter = kBins / (TT / 16); // bins a lane group walks
-            constexpr unsigned kCh = 4;                   // ... four at a time: their first elements are in flight together
+        { // two bins per step, up to four elements of each run per lane, all fetched before any is consumed
+            constexpr unsigned kE = 4, kStep = TT / 16;
             const unsigned l = t & 15;
-#pragma unroll 1
-            for (unsigned j0 = 0; j0 < kIter; j0 += kCh)
+            for (unsigned b0 = t >> 4; b0 < bins; b0 += 2 * kStep)
             {
-                unsigned cnt[kCh], st[kCh], cur[kCh];
-                uint32_t v[kCh];
-                uint8_t h8[kCh];
-                uint64_t base[kCh];
+                unsigned cnt[2], st[2], cur[2];
+                uint64_t base[2];
+                uint32_t v[2][kE];
+                uint8_t h8[2][kE];
 #pragma unroll
-                for (unsigned j = 0; j < kCh; ++j)
+                for (unsigned k = 0; k < 2; ++k)
                 {
-                    const unsigned b = (t >> 4) + (j0 + j) * (TT / 16);
-                    cnt[j] = b < bins ? hist[b] : 0;
-                    st[j] = start[b & (kBins - 1)];
-                    cur[j] = cursor[b & (kBins - 1)];
-                }
-#pragma unroll
-                for (unsigned j = 0; j < kCh; ++j)
-                {
-                    const bool on = l < cnt[j] && cnt[j] <= kBigRun;
-                    v[j] = on ? res_lo[(uint64_t)cur[j] + l] : 0;
-                    h8[j] = (P == 1 && on) ? res_hi[(uint64_t)cur[j] + l] : (uint8_t)0;
-                    base[j] = (P == 2 && on) ? base_of((t >> 4) + (j0 + j) * (TT / 16)) : 0;
-                }
-#pragma unroll
-                for (unsigned j = 0; j < kCh; ++j)
-                {
-                    const unsigned b = (t >> 4) + (j0 + j) * (TT / 16);
-                    if (cnt[j] == 0)
-                        continue;
-                    if (cnt[j] > kBigRun)
+                    const unsigned b = b0 + k * kStep;
+                    cnt[k] = b < bins ? hist[b & (kBins - 1)] : 0;
+                    st[k] = start[b & (kBins - 1)];
+                    cur[k] = cursor[b & (kBins - 1)];
+                    if (cnt[k] > kBigRun)
                     {
                         if (l == 0)
                             big[atomicAdd(&n_big, 1u)] = b;
-                        continue;
+                        cnt[k] = 0;
                     }
-                    if (l < cnt[j])
-                        keep(base[j], st[j] + l, v[j], h8[j]);
-                    for (unsigned i = l + 16; i < cnt[j]; i += 16)
+                }
+#pragma unroll
+                for (unsigned k = 0; k < 2; ++k)
+                {
+                    base[k] = (P == 2 && cnt[k]) ? base_of(b0 + k * kStep) : 0;
+#pragma unroll
+                    for (unsigned e = 0; e < kE; ++e)
                     {
-                        const uint64_t bs = P == 2 ? base_of(b) : 0;
-                        keep(bs, st[j] + i, res_lo[(uint64_t)cur[j] + i], P == 1 ? res_hi[(uint64_t)cur[j] + i] : (uint8_t)0);
+                        const unsigned i = l + 16 * e;
+                        const bool on = i < cnt[k];
+                        v[k][e] = on ? res_lo[(uint64_t)cur[k] + i] : 0;
+                        h8[k][e] = (P == 1 && on) ? res_hi[(uint64_t)cur[k] + i] : (uint8_t)0;
                     }
+                }
+#pragma unroll
+                for (unsigned k = 0; k < 2; ++k)
+                {
+#pragma unroll
+                    for (unsigned e = 0; e < kE; ++e)
+                        if (l + 16 * e < cnt[k])
+                            keep(base[k], st[k] + l + 16 * e, v[k][e], h8[k][e]);
+                    for (unsigned i = l + 16 * kE; i < cnt[k]; i += 16)
+                        keep(base[k], st[k] + i, res_lo[(uint64_t)cur[k] + i], P == 1 ? res_hi[(uint64_t)cur[k] + i] : (uint8_t)0);
                 }
             }
         }
@@ -783,7 +781,7 @@ __global__ __launch_bounds__(TT, 4) void k_sr_unpermute(const uint64_t * __restr
         if (!(V & 2))
         {
 #pragma unroll
-            for (unsigned u = 0; u < kPer; ++u)
+            for (unsigned u = 0; u < PER; ++u)
             {
                 const unsigned q = u * TT + t;
                 sl[u] = q < cnt_t ? __builtin_nontemporal_load(slots_t + q) : (uint16_t)0;
@@ -793,7 +791,7 @@ __global__ __launch_bounds__(TT, 4) void k_sr_unpermute(const uint64_t * __restr
         uint8_t * out_hi_t = P == 2 ? out_hi + lo : nullptr;
         uint64_t * out_t = P == 1 ? out + lo : nullptr;
 #pragma unroll
-        for (unsigned u = 0; u < kPer; ++u)
+        for (unsigned u = 0; u < PER; ++u)
         {
             const unsigned q = u * TT + t;
             if (q < cnt_t)
@@ -905,24 +903,14 @@ struct SrKernels
                  const uint16_t *, const uint16_t *, uint32_t *, uint8_t *, uint64_t *);
     void (*unp1)(const uint64_t *, int, SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint8_t *,
                  const uint16_t *, const uint16_t *, uint32_t *, uint8_t *, uint64_t *);
-    unsigned threads, blocks_per_cu;
+    unsigned threads, blocks_per_cu, per;
 };
-template <unsigned TT, int V>
-SrKernels sr_kernels_v(unsigned per_cu)
+template <unsigned TT, unsigned PER>
+SrKernels sr_kernels(unsigned per_cu)
 {
-    return SrKernels{k_sr_hist<1, TT>,         k_sr_hist<2, TT>,         k_sr_partition<1, TT>, k_sr_partition<2, TT>,
-                     k_sr_unpermute<2, TT, V>, k_sr_unpermute<1, TT, V>, TT,                    per_cu};
-}
-template <unsigned TT>
-SrKernels sr_kernels(unsigned per_cu, int variant)
-{
-    switch (variant & 3)
-    {
-    case 0: return sr_kernels_v<TT, 0>(per_cu);
-    case 1: return sr_kernels_v<TT, 1>(per_cu);
-    case 2: return sr_kernels_v<TT, 2>(per_cu);
-    default: return sr_kernels_v<TT, 3>(per_cu);
-    }
+    return SrKernels{k_sr_hist<1, TT, PER>,      k_sr_hist<2, TT, PER>,         k_sr_partition<1, TT, PER>,
+                     k_sr_partition<2, TT, PER>, k_sr_unpermute<2, TT, PER, 3>, k_sr_unpermute<1, TT, PER, 3>,
+                     TT,                         per_cu,                        PER};
 }
 
 } // namespace
@@ -932,7 +920,7 @@ size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n)
 {
     (void)v;
     SrBuf b;
-    return carve(b, nullptr, n < kMaxPass ? n : kMaxPass, 256 * kPer) + 4096;
+    return carve(b, nullptr, n < kMaxPass ? n : kMaxPass, 256 * 8) + 4096;
 }
 
 bool bv_sorted_rank_possible(const BvView & v)
@@ -959,8 +947,9 @@ sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t 
         set_error("rank_sorted: vector too large for the bucketed path");
         return SDSL_HIP_ERR_INVALID;
     }
-    static const int v_env = getenv("SDSL_HIP_SORTED_VARIANT") ? atoi(getenv("SDSL_HIP_SORTED_VARIANT")) : 0;
-    const SrKernels K = t_env == 512 ? sr_kernels<512>(2, v_env) : sr_kernels<256>(4, v_env);
+    // tiles of 8192 keys (512 threads x 16) are the measured optimum on 2^34 bits (profiles/sorted_rank_v6_r02.txt:
+    // 17.9 ms against 18.9 ms for 16384-key tiles and 21.4 ms for 4096-key tiles); the others stay selectable for profiling
+    const SrKernels K = t_env == 1024 ? sr_kernels<1024, 16>(1) : (t_env == 256 ? sr_kernels<256, 16>(4) : sr_kernels<512, 16>(2));
     for (uint64_t done = 0; done < n;)
     {
         const uint64_t cnt = n - done < kMaxPass ? n - done : kMaxPass;
@@ -974,7 +963,7 @@ sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t 
         const unsigned f = lb > kSliceLog ? lb - kSliceLog : 0;
         g.d1 = f < 8 ? f : 8;
         g.d2 = f - g.d1;
-        g.tile = K.threads * kPer;
+        g.tile = K.threads * K.per;
         g.tiles1 = (uint32_t)((cnt + g.tile - 1) / g.tile);
         g.G = g_env >= 1 && g_env <= (int)kMaxG ? (uint32_t)g_env : 256u * K.blocks_per_cu;
         g.small = v.n_bits < (UINT64_C(1) << 38);

@@ -3,7 +3,6 @@
 
 #include <atomic>
 #include <cstdarg>
-#include <random>
 
 namespace sdslhip {
 
@@ -213,22 +212,6 @@ int32_t sdsl_hip_device_count(void)
             ++ok;
     }
     return ok;
-}
-
-sdsl_hip_status sdsl_hip_util_set_random_bits(uint64_t * words, uint64_t n_bits, uint64_t seed)
-{
-    if (!words && n_bits)
-    {
-        set_error("set_random_bits: null words");
-        return SDSL_HIP_ERR_INVALID;
-    }
-    // util.hpp:467-485 — one mt19937_64 output per 64-bit word; like SDSL the last word is NOT
-    // masked (stray bits above n_bits are legal in an int_vector and every consumer ignores them)
-    std::mt19937_64 rng(seed);
-    uint64_t nw = (n_bits + 63) >> 6;
-    for (uint64_t i = 0; i < nw; ++i)
-        words[i] = rng();
-    return SDSL_HIP_OK;
 }
 
 sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value)

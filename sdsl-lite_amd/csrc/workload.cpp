@@ -403,6 +403,18 @@ sdsl_hip_status sdsl_hip_util_rnd_positions(uint64_t seed, uint64_t count, uint6
     return SDSL_HIP_OK;
 }
 
+sdsl_hip_status sdsl_hip_util_set_random_bits(uint64_t * words, uint64_t n_bits, uint64_t seed)
+{
+    if (!words && n_bits)
+    {
+        set_error("set_random_bits: null words");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    // util.hpp:467-485 — one mt19937_64 output per 64-bit word; like SDSL the last word is NOT masked (stray bits above
+    // n_bits are legal in an int_vector and every consumer ignores them)
+    return sdsl_hip_util_rnd_positions(seed, (n_bits + 63) >> 6, 0, 0, words);
+}
+
 sdsl_hip_status sdsl_hip_util_mt_checkpoints(uint64_t seed, uint64_t stride, uint64_t n, uint64_t * out)
 {
     if (!out || stride == 0)

@@ -37,7 +37,7 @@ def child(logn, nq):
 if len(sys.argv) > 3 and sys.argv[3] == "child":
     child(int(sys.argv[1]), int(float(sys.argv[2])))
 else:
-    variants = [("0", {})] + [("1", {"SDSL_HIP_TRACE_SORTED": "1", "SDSL_HIP_SORTED_THREADS": a.split(":")[0], "SDSL_HIP_SORTED_VARIANT": (a.split(":") + ["0"])[1]}) for a in (sys.argv[3:] or ["256"])]
+    variants = [("0", {})] + [("1", {"SDSL_HIP_TRACE_SORTED": "1", "SDSL_HIP_SORTED_THREADS": a.split(":")[0], "SDSL_HIP_SORTED_VARIANT": (a.split(":") + ["0"])[1], "SDSL_HIP_SORTED_PER": (a.split(":") + ["0", "16"])[2]}) for a in (sys.argv[3:] or ["256"])]
     for mode, extra in variants:
         env = dict(os.environ, SDSL_HIP_RANK_SORTED=mode, **extra)
         print(f"--- SDSL_HIP_RANK_SORTED={mode} {extra}", flush=True)
