@@ -4,8 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
 
 A *step* is one pass of the hot path over one batch: `--queries` (default 10^9) batched rank_1
-queries, uniformly random in [0, n], on a 2^34-bit random bit vector resident in HBM together with
-the query and result arrays.  N > 1: one process per GPU (torchrun / torch.distributed, backend nccl =
+queries on a 2^34-bit random bit vector resident in HBM together with the query and result arrays.
+Inputs are SURVEY.md 8(d)'s streams (vector words = std::mt19937_64(42), positions = mt19937_64(7 + rank) % (n + 1),
+generated on the host by the library's integer-only generators), so that the first 10^7 answers can be compared with
+the digests the REAL sdsl-lite produced for them in the build container (tests/golden/golden_large.json).  N > 1: one process per GPU (torchrun / torch.distributed, backend nccl =
 RCCL); the index is replicated, every rank answers its own resident shard of the same size (weak
 scaling, no data-path collective); the step time is the MAX over ranks and `value` is the whole-job
 aggregate.  Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (dominant kernel
@@ -76,13 +78,79 @@ def time_steps(fn, steps, warmup, barrier):
     return wall, e0.elapsed_time(e1) / steps
 
 
+def kernel_sources_sha():
+    """sha256 over the kernel sources a PMC measurement is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("bv.hip", "bv_device.hpp", "bv_sorted.hip", "bits.hpp"):
+        h.update(open(os.path.join(ROOT, "sdsl-lite_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_key):
-    """HBM bytes per launch from the committed PMC summary (profiles/pmc_latest.json), or None."""
+    """HBM bytes per step from the committed PMC summary (profiles/pmc_latest.json) — only if that summary was
+    collected on these very kernel sources (it carries their sha256); otherwise None: a stale number is not a
+    measurement of this run."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
-        return json.load(open(path)).get(kernel_key)
+        d = json.load(open(path))
+        if d.get("kernel_sources_sha") != kernel_sources_sha():
+            return None
+        return d.get(kernel_key)
     except Exception:
         return None
+
+
+def golden():
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "golden_large.json")))
+    except Exception:
+        return {}
+
+
+def digest_matches(ans_dev, want):
+    """The first want['n'] answers against the reference's sum / xor / sha256 / first answers (golden_large.json)."""
+    import hashlib
+    a = ans_dev[: want["n"]].cpu().numpy().view(np.uint64)
+    if a.size != want["n"]:
+        return None
+    first = np.array(want["first"], dtype=np.uint64)
+    return bool(np.array_equal(a[: first.size], first) and int(np.add.reduce(a, dtype=np.uint64)) == want["sum"]
+                and int(np.bitwise_xor.reduce(a)) == want["xor"] and hashlib.sha256(a.tobytes()).hexdigest() == want["sha256"])
+
+
+def to_dev(host_u64, dev):
+    """uint64 numpy array -> int64 device tensor (chunked: no second full-size pinned copy on the host)."""
+    t = torch.empty(host_u64.size, dtype=torch.int64, device=dev)
+    step = 1 << 27
+    for s0 in range(0, host_u64.size, step):
+        t[s0:s0 + step].copy_(torch.from_numpy(host_u64[s0:s0 + step].view(np.int64)))
+    return t
+
+
+def box_facts(dev_index):
+    """Clocks, power cap and memory of the GPU this run landed on (box-to-box spread of the same binary is +-8 %)."""
+    import subprocess
+    out = {}
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        out.update(name=p.name, cus=p.multi_processor_count, total_mem_gib=round(p.total_memory / 2**30, 1))
+    except Exception:
+        pass
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(dev_index), "--showclocks", "--showpower", "--showmaxpower", "--showperflevel",
+                            "--showmemuse", "--json"], capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout)
+        card = next(iter(j.values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(w in kl for w in ("sclk", "mclk", "fclk", "power", "performance level", "memory")):
+                keep[k] = v
+        out["rocm_smi"] = keep
+    except Exception as e:
+        out["rocm_smi"] = f"unavailable: {type(e).__name__}"
+    return out
 
 
 def cpu_baseline(pkg, words_dev, n_bits, idx_dev, gpu_out_dev, seconds):
@@ -126,31 +194,38 @@ def cpu_baseline(pkg, words_dev, n_bits, idx_dev, gpu_out_dev, seconds):
                   f"rank_support_v5 on the same 2^{int(np.log2(n_bits))}-bit vector (build {build_s:.1f}s)",
         "ns_per_query": dt / n_s * 1e9, "matches_gpu": same,
     }
-    # the same loop on every host core (contiguous slices of a larger prefix; queries are const-safe)
+    # the same loop on every host core: threads pinned one per logical CPU of the affinity mask, output pre-faulted,
+    # released together, >= 10^7 queries per thread (several passes over its slice if the step has fewer), clock stopped
+    # when the slowest thread is done — thread creation and page faults are outside the measurement
     try:
-        threads = len(os.sched_getaffinity(0))  # the CPUs this process may run on
+        threads = len(os.sched_getaffinity(0))
     except AttributeError:
         threads = os.cpu_count() or 1
-    n_m = int(min(idx_dev.numel(), 250_000_000, max(n_s, threads * seconds / per_q)))
+    n_m = int(min(idx_dev.numel(), threads * 10_000_000))
+    reps = max(1, int(np.ceil(10_000_000 / max(1, n_m // threads))))
     sample = idx_dev[:n_m].cpu().numpy().view(np.uint64)
-    outm = np.empty(n_m, dtype=np.uint64)
-    t0 = time.perf_counter()
+    outm = np.zeros(n_m, dtype=np.uint64)
     if kind == "reference":
-        ol.ref().L.ref_bv_rank_mt(h, 1, sample.ctypes.data, n_m, outm.ctypes.data, threads)
+        dtm = ol.ref().L.ref_bv_rank_mt_timed(h, 1, sample.ctypes.data, n_m, outm.ctypes.data, threads, reps)
     else:
-        ol.oracle().L.orc_rank_v5_batch_mt(h, sample.ctypes.data, n_m, outm.ctypes.data, threads)
-    dtm = time.perf_counter() - t0
-    model = "unknown"
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ol.oracle().L.orc_rank_v5_batch_mt(h, sample.ctypes.data, n_m, outm.ctypes.data, threads)
+        dtm = time.perf_counter() - t0
+    model, smt = "unknown", "unknown"
     try:
         for line in open("/proc/cpuinfo"):
             if line.startswith("model name"):
                 model = line.split(":", 1)[1].strip()
                 break
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        smt = f"{len(sib.replace('-', ',').split(','))} hardware threads per core (cpu0 siblings: {sib})"
     except OSError:
         pass
-    allc = {"value": n_m / dtm / 1e9, "unit": "Grank/s", "cores": threads, "kind": kind, "cpu_model": model,
-            "smt": "one thread per logical CPU of the process's affinity mask (SMT siblings included if exposed)",
-            "sample": f"first {n_m} of the step's queries, contiguous slices, {threads} threads",
+    allc = {"value": n_m * reps / dtm / 1e9, "unit": "Grank/s", "cores": threads, "kind": kind, "cpu_model": model,
+            "smt": smt, "pinned": True, "queries_per_thread": n_m * reps // threads,
+            "sample": f"first {n_m} of the step's queries, contiguous slices, {threads} pinned threads, {reps} pass(es), "
+                      f"output pre-faulted, timed from a common start to the slowest thread",
             "matches_gpu": bool(np.array_equal(outm, gpu_out_dev[:n_m].cpu().numpy().view(np.uint64)))}
     return one, allc
 
@@ -235,47 +310,72 @@ def main():
     n_bits = 1 << a.log_n
     nq = int(a.queries)
 
-    # index: replicated (same seed on every rank); queries: this rank's resident shard
-    g = torch.Generator(device=dev).manual_seed(42)
-    words = torch.randint(-2**63, 2**63 - 1, (n_bits // 64,), device=dev, dtype=torch.int64, generator=g)
+    # index: replicated (same seed on every rank); queries: this rank's resident shard.  SURVEY.md 8(d) streams.
+    G = golden()
+    t0 = time.perf_counter()
+    words = to_dev(pkg.set_random_bits(n_bits, 42), dev)
     if a.extras is None:
         a.extras = "select,rrr,sd,wt,fm" if world == 1 else "fm_sharded"
     extras = [] if a.extras in ("", "none") else a.extras.split(",")
     bv = pkg.bit_vector(words, n_bits, device=local, select1="select" in extras, select0=False)
-    gq = torch.Generator(device=dev).manual_seed(7 + rank)
-    idx = torch.randint(0, n_bits + 1, (nq,), device=dev, dtype=torch.int64, generator=gq)
+    index_bytes = bv.device_bytes()
+    idx = to_dev(pkg.rnd_positions(7 + rank, nq, n_bits + 1, 0), dev)
     out = torch.empty_like(idx)
+    gq = torch.Generator(device=dev).manual_seed(1007 + rank)  # secondary measurements without a reference digest
+    setup_s = time.perf_counter() - t0
 
+    # the headline: whatever sdsl_hip_bv_rank_batch does with a device-resident batch by default (large batch over a
+    # large vector: the bucketed path, bv_sorted.hip); the direct kernel (one rank line per query) is timed next to it
     wall, kernel_ms = time_steps(lambda: bv.rank(idx, 1, out), a.steps, a.warmup, barrier)
     if world > 1:
         wall = pkg.dist.max_over_ranks(wall, comm_dev)
         kernel_ms = pkg.dist.max_over_ranks(kernel_ms, comm_dev)
     value = nq * world * a.steps / wall / 1e9
     achieved = ALG_BYTES["rank"] * nq / (kernel_ms * 1e-3) / 1e9
-    # the same access pattern with the arithmetic removed, on the same table and positions: what the memory system
-    # allows a batched rank to reach on this GPU in this run
-    probe_out = torch.empty_like(idx)
-    _, probe_ms = time_steps(lambda: bv.gather_probe(idx, probe_out), max(2, a.steps // 2), 1, barrier)
-    del probe_out
+    ref_ok = None
+    if rank == 0 and a.log_n == G.get("c2", {}).get("log_n") and nq >= G["c2"]["rank_1"]["n"]:
+        ref_ok = digest_matches(out, G["c2"]["rank_1"]) and bv.ones() == G["c2"]["ones"]
+    pkg.set_option("trace_phases", 1)
+    bv.rank(idx, 1, out)
+    torch.cuda.synchronize()
+    phases = pkg.last_phases()
+    pkg.set_option("trace_phases", 0)
+    bucketed = bool(phases)
+    scratch_bytes = bv.device_bytes() - index_bytes
+    # the direct kernel and its access skeleton (read a position, fetch its 64-byte rank line, write a word), same table,
+    # same positions, same run
+    pkg.set_option("rank_sorted", 0)
+    out_d = torch.empty_like(idx)
+    _, direct_ms = time_steps(lambda: bv.rank(idx, 1, out_d), max(2, a.steps // 2), 1, barrier)
+    same = bool(torch.equal(out, out_d))
+    _, probe_ms = time_steps(lambda: bv.gather_probe(idx, out_d), max(2, a.steps // 2), 1, barrier)
+    del out_d
+    pkg.set_option("rank_sorted", -1)
     result = {
         "metric": "Grank/s, batched rank_1 on a 2^%d-bit vector" % a.log_n, "value": value, "unit": "Grank/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "configs[1]: batched rank_1 on a 2^%d-bit random bit_vector (density 0.5), "
-                               "%d uniform queries per step per GPU, index+queries+results resident in HBM"
-                               % (a.log_n, nq),
+        "config": {"workload": "configs[1]: batched rank_1 on a 2^%d-bit random bit_vector (words = mt19937_64(42), density "
+                               "0.5), %d queries per step per GPU at mt19937_64(7 + rank) %% (n + 1), index+queries+results "
+                               "resident in HBM" % (a.log_n, nq),
                    "n_bits": n_bits, "queries_per_step_per_gpu": nq, "parallelism": "replicated index, query shards x%d" % world,
-                   "index_bytes_per_gpu": bv.device_bytes()},
+                   "index_bytes_per_gpu": index_bytes, "batch_scratch_bytes_per_gpu": scratch_bytes, "setup_s": setup_s},
+        "reference_digest_match": ref_ok,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_rank_bytes_per_launch"),
-                     "kernel": "sdslhip::k_rank<4,false,true>", "kernel_ms": kernel_ms,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic("rank_bucketed_bytes_per_step" if bucketed else "k_rank_bytes_per_launch"),
+                     "kernel": ("bucketed batch rank (bv_sorted.hip): k_sr_hist<1>, k_sr_partition<1>, k_sr_hist<2>, "
+                                "k_sr_partition<2>, k_sr_rank_lds, k_sr_unpermute<2>, k_sr_unpermute<1> + 8 table kernels; "
+                                "kernel_ms = all of them, one step") if bucketed else "sdslhip::k_rank<4,false,true>",
+                     "kernel_ms": kernel_ms, "phases_ms": phases or None,
                      "algorithmic_bytes_per_query": ALG_BYTES["rank"],
-                     "access_skeleton": {"what": "read a position, fetch its 64-byte rank line, write a word: k_rank without "
-                                                 "its arithmetic, same table, same positions, same run",
-                                         "kernel_ms": probe_ms, "Gq/s": nq / probe_ms / 1e6,
-                                         "rank_kernel_over_skeleton": probe_ms / kernel_ms}},
+                     "direct_kernel": {"kernel": "sdslhip::k_rank<4,false,true>", "kernel_ms": direct_ms,
+                                       "Gq/s": nq / direct_ms / 1e6,
+                                       "frac": ALG_BYTES["rank"] * nq / (direct_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "same_answers": same,
+                                       "access_skeleton_ms": probe_ms, "kernel_over_skeleton": probe_ms / direct_ms}},
+        "box": box_facts(local) if rank == 0 else None,
     }
-
     if rank == 0 and world == 1 and not a.no_cpu:
         result["cpu_baseline"], result["cpu_baseline_all_cores"] = cpu_baseline(pkg, words, n_bits, idx, out,
                                                                                  a.cpu_seconds)
@@ -286,10 +386,12 @@ def main():
     try:
         if "select" in extras:
             ones = bv.ones()
-            si = torch.randint(1, ones + 1, (nq,), device=dev, dtype=torch.int64, generator=gq)
+            si = to_dev(pkg.rnd_positions(11, nq, ones, 1), dev)  # 8(d): 1 + mt19937_64(11) % ones
             _, ms = time_steps(lambda: bv.select(si, 1, out), max(2, a.steps // 2), 1, barrier)
             ex["select_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms,
                               "roofline_frac": ALG_BYTES["select"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if a.log_n == G.get("c2", {}).get("log_n") and nq >= G["c2"]["select_1"]["n"]:
+                ex["select_1"]["reference_digest_match"] = digest_matches(out, G["c2"]["select_1"])
             pos = out[: 1 << 20].clone()
             assert bool((bv.rank(pos, 1) == si[: 1 << 20] - 1).all()), "select/rank round trip failed"
             if rank == 0 and world == 1 and not a.no_cpu:
@@ -313,29 +415,34 @@ def main():
         if "rrr" in extras:
             del bv
             torch.cuda.empty_cache()
-            gw = torch.Generator(device=dev).manual_seed(9)
-            # 5 % dense 2^log_n-bit vector (BASELINE.json configs[2]); bits packed on the device in chunks
-            nw = n_bits // 64
-            w5 = torch.empty(nw, dtype=torch.int64, device=dev)
-            weights = (torch.ones(64, dtype=torch.int64, device=dev) << torch.arange(64, device=dev)).view(1, 64)
-            chunk = 1 << 22
-            for s in range(0, nw, chunk):
-                e = min(nw, s + chunk)
-                b = (torch.rand((e - s, 64), device=dev, generator=gw) < 0.05).to(torch.int64)
-                w5[s:e] = (b * weights).sum(dim=1)
+            # 5 % dense 2^log_n-bit vector (BASELINE.json configs[2]): bit i = (mt19937_64(9)_i % 100 < 5), produced by all
+            # host threads from the committed generator checkpoints (tests/golden/mt9_checkpoints.bin)
+            c3 = G.get("c3", {})
+            ckp = os.path.join(ROOT, "tests", "golden", "mt9_checkpoints.bin")
+            if os.path.exists(ckp) and c3:
+                ck = np.fromfile(ckp, dtype=np.uint64).reshape(-1, 313)
+                w5h_all = pkg.density_bits(n_bits, 9, 5, ck, c3["checkpoint_stride"])
+            else:
+                w5h_all = pkg.density_bits(n_bits, 9, 5)
+            w5 = to_dev(w5h_all, dev)
             t0 = time.perf_counter()
             rv = pkg.rrr_vector(w5, n_bits, device=local)
             build = time.perf_counter() - t0
-            w5h = w5.cpu().numpy().view(np.uint64) if (rank == 0 and world == 1 and not a.no_cpu) else None
-            del w5
+            w5h = w5h_all if (rank == 0 and world == 1 and not a.no_cpu) else None
+            del w5, w5h_all
             _, ms = time_steps(lambda: rv.rank(idx, 1, out), max(2, a.steps // 2), 1, barrier)
             ex["rrr63_rank_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms, "build_s": build,
                                   "bits_per_bit": rv.device_bytes() * 8 / n_bits,
                                   "roofline_frac": ALG_BYTES["rrr"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            si = torch.randint(1, rv.ones() + 1, (nq,), device=dev, dtype=torch.int64, generator=gq)
+            c3ok = a.log_n == c3.get("log_n") and nq >= c3.get("rank_1", {}).get("n", 1 << 62) and rank == 0
+            if c3ok:
+                ex["rrr63_rank_1"]["reference_digest_match"] = digest_matches(out, c3["rank_1"]) and rv.ones() == c3["ones"]
+            si = to_dev(pkg.rnd_positions(11, nq, rv.ones(), 1), dev)
             _, ms = time_steps(lambda: rv.select(si, 1, out), max(2, a.steps // 2), 1, barrier)
             ex["rrr63_select_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms,
                                     "roofline_frac": ALG_BYTES["rrr"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if c3ok:
+                ex["rrr63_select_1"]["reference_digest_match"] = digest_matches(out, c3["select_1"])
             assert bool((rv.rank(out[: 1 << 20].clone(), 1) == si[: 1 << 20] - 1).all())
             if rank == 0 and world == 1 and not a.no_cpu:
                 import oracle_lib as ol
@@ -397,21 +504,31 @@ def main():
         if "wt" in extras or "fm" in extras:
             torch.cuda.empty_cache()
             nt = a.text_mib << 20
-            text = synthetic_text(nt, 1234, dev)
+            text_h = pkg.english_text(nt, 1234)
+            text = torch.from_numpy(text_h).to(dev)
             t0 = time.perf_counter()
             csa = pkg.csa_wt(text=text, device=local)
             build = time.perf_counter() - t0
+            c4 = G.get("c4", {})
+            c4ok = rank == 0 and nt == (1 << c4.get("text_log", -1)) and "wt_rank" in c4
             wt = csa.wavelet_tree
             lens = torch.from_numpy(wt.code_lengths().astype(np.int64)).to(dev)
             fsteps = torch.from_numpy(wt.fused_steps().astype(np.int64)).to(dev)
             nq2 = min(nq, 100_000_000)
-            gi = torch.randint(0, nt + 1, (nq2,), device=dev, dtype=torch.int64, generator=gq)
-            gc = text[torch.randint(0, nt, (nq2,), device=dev, generator=gq)]
+            # 8(d): i = mt19937_64(13) % (size() + 1), c = text[mt19937_64(14) % n] — symbols as the text distributes them
+            gi = to_dev(pkg.rnd_positions(13, nq2, nt + 2, 0), dev)
+            gc = text[to_dev(pkg.rnd_positions(14, nq2, nt, 0), dev)]
             out2 = torch.empty(nq2, dtype=torch.int64, device=dev)
             hbar = float(lens[gc.long()].double().mean())
-            ex["text"] = {"bytes": nt, "kind": "synthetic English-like stand-in (Zipf over a 4096-word vocabulary)",
-                          "sigma": csa.sigma(), "index_build_s": build, "mean_code_length_of_queried_symbols": hbar,
+            cnt_b = np.bincount(text_h, minlength=256)
+            p_b = cnt_b[cnt_b > 0] / nt
+            ex["text"] = {"bytes": nt, "kind": "English-class stand-in for Pizza&Chili english (sdsl_hip_util_english_text, seed 1234: Zipf "
+                                               "words over a 65536-word vocabulary, mixed case, digits, punctuation, rare Latin-1 / control "
+                                               "bytes; integer-only, reproduced bit for bit in the build container)",
+                          "sigma": csa.sigma(), "H0": float(-(p_b * np.log2(p_b)).sum()), "index_build_s": build,
+                          "mean_code_length_of_queried_symbols": hbar,
                           "wt_bits": wt.bv_size(), "index_bytes": csa.device_bytes()}
+            del text_h
             ocsa = rcsa = None
             if rank == 0 and world == 1 and not a.no_cpu:
                 import oracle_lib as ol
@@ -443,6 +560,8 @@ def main():
                 alg = 17 + 80 * hbar
                 steps = float(fsteps[gc.long()].double().mean())  # fused layout: depth in its own 8-ary tree
                 ex["wt_huff_rank"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2,
+                                      "reference_digest_match": digest_matches(out2, c4["wt_rank"])
+                                      if c4ok and nq2 >= c4["wt_rank"]["n"] else None,
                                       "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_query": alg,
                                       "fused_steps_per_query": steps,
@@ -472,7 +591,7 @@ def main():
                 del occ_c, ks, chk
             if "fm" in extras:
                 m = 20
-                st = torch.randint(0, nt - m, (nq2,), device=dev, generator=gq)
+                st = to_dev(pkg.rnd_positions(15, nq2, nt - m, 0), dev)  # 8(d): patterns cut at mt19937_64(15) % (n - m)
                 pats = text[(st.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()
                 _, ms = time_steps(lambda: csa.count(pats, m, out2), max(2, a.steps // 2), 1, barrier)
                 sum_l = float(lens[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
@@ -480,6 +599,9 @@ def main():
                 sum_steps = float(fsteps[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
                 assert bool((out2 >= 1).all()), "every pattern was cut from the text"
                 ex["fm_count"] = {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "patterns": nq2, "m": m,
+                                  "reference_digest_match": digest_matches(out2, c4["count"])
+                                  if c4ok and nq2 >= c4["count"]["n"] else None,
+                                  "fused_steps_per_pattern": sum_steps,
                                   "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_pattern": alg,
                                   "line_fetch_frac": (28 + 256 * sum_steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -529,6 +651,18 @@ def main():
                 ex["fm_count_rrr63"] = {"Mcount/s": nq3 / ms / 1e3, "kernel_ms": ms, "patterns": nq3, "m": m,
                                         "index_bytes": crrr.device_bytes(), "index_build_s": rb}
                 del crrr
+                # second data point: the sigma = 28 lowercase text round 1 reported on (an easier alphabet: shorter codes, a
+                # deeper k-mer table)
+                torch.cuda.empty_cache()
+                t28 = synthetic_text(nt, 1234, dev)
+                c28 = pkg.csa_wt(text=t28, device=local)
+                st28 = torch.randint(0, nt - m, (nq2,), device=dev, generator=gq)
+                p28 = t28[(st28.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()
+                _, ms = time_steps(lambda: c28.count(p28, m, out2), 2, 1, barrier)
+                ex["fm_count_sigma28"] = {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "patterns": nq2, "m": m,
+                                          "sigma": c28.sigma(), "jump_depth": c28.jump_depth(),
+                                          "text": "Zipf over a 4096-word lowercase vocabulary (round 1's stand-in)"}
+                del c28, t28, p28, st28
 
         if "fm_sharded" in extras and world > 1:
             # the headline queries as a ROOT-OWNED batch (the end-to-end column): rank 0 holds all
@@ -567,7 +701,7 @@ def main():
             stage = (lambda t: t) if a.backend == "nccl" else (lambda t: t.cpu())
             # load time: rank 0 owns the text, one broadcast hands it to every rank, every rank lays out its own index
             t0 = time.perf_counter()
-            text = pkg.dist.replicate(stage(synthetic_text(nt, 1234, dev)) if rank == 0 else None,
+            text = pkg.dist.replicate(stage(torch.from_numpy(pkg.english_text(nt, 1234)).to(dev)) if rank == 0 else None,
                                       stage(torch.empty(0, dtype=torch.uint8, device=dev))).to(dev)
             torch.cuda.synchronize()
             bcast = time.perf_counter() - t0
@@ -636,6 +770,13 @@ def main():
                                "n_gpus": world, "scaling": "strong (one batch of %d patterns split over the ranks)"
                                                            % ex["fm_count_sharded"]["patterns_total"],
                                "source": "extras.fm_count_sharded.resident_shards"}
+    if world > 1 and "rank_root_owned_batch" in ex:
+        # both columns of the multi-GPU report, side by side
+        result["scaling_columns"] = {"kernel_only_resident_shards_Grank/s": value,
+                                     "end_to_end_root_owned_batch_Grank/s": ex["rank_root_owned_batch"]["Grank/s"],
+                                     "note": "resident shards: every rank answers its own HBM-resident shard, no collective in the "
+                                             "timed region; root-owned: rank 0 holds the batch, scatter -> kernels -> gather over "
+                                             "RCCL in 8 pipelined pieces, 16 bytes per query cross xGMI"}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

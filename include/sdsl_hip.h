@@ -137,6 +137,9 @@ sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bi
 #define SDSL_HIP_SER_RANK_V_0 6
 sdsl_hip_status sdsl_hip_bv_serialize(sdsl_hip_bv_t bv, int32_t what, void * buf, size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv);
+/* frees the working memory the bucketed batch rank keeps with the handle between calls (13 bytes per query of the largest
+ * batch seen, at most 2^30 queries' worth; counted by sdsl_hip_bv_device_bytes); the next large batch allocates it again */
+sdsl_hip_status sdsl_hip_bv_release_scratch(sdsl_hip_bv_t bv);
 uint64_t sdsl_hip_bv_size(sdsl_hip_bv_t bv);         /* bit_vector::size() */
 uint64_t sdsl_hip_bv_ones(sdsl_hip_bv_t bv);         /* == rank_1(size()) */
 uint64_t sdsl_hip_bv_device_bytes(sdsl_hip_bv_t bv); /* HBM footprint of the device layout */
@@ -403,6 +406,12 @@ sdsl_hip_status sdsl_hip_set_timing(int32_t enabled);
  * -1 = automatic (bucketed when the batch addresses every line of a vector larger than the caches several times).
  * Answers are identical in every mode.  Initial value: environment variable SDSL_HIP_RANK_SORTED, else -1. */
 sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value);
+/* "trace_phases" (0/1): the bucketed batch rank times each of its passes with HIP events on the launch stream (one host
+ * synchronisation per call) and sdsl_hip_last_phases returns them as "hist1=ms;offs1=ms;part1=ms;..." */
+sdsl_hip_status sdsl_hip_last_phases(char * buf, size_t cap);
+/* where a vector's device layout lives: out = { address of the rank lines, their size in bytes, address of the select_1
+ * directory, address of the batch-rank scratch } — for allocation / alignment experiments (tools/alloc_sensitivity.py) */
+sdsl_hip_status sdsl_hip_bv_layout_info(sdsl_hip_bv_t bv, uint64_t out[4]);
 sdsl_hip_status sdsl_hip_last_kernel_ms(float * ms_out); /* synchronises on the stop event */
 
 #ifdef __cplusplus

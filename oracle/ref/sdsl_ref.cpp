@@ -3,6 +3,9 @@
 // Built by oracle/Makefile into oracle/_ref/libsdsl_ref.so.  TEST INFRASTRUCTURE ONLY: it pins the
 // C restatement (oracle.c), generates the golden fixtures (tests/golden/make_golden.py) and serves
 // as bench.py's cpu_baseline of kind "reference".  It is never loaded by the product library.
+#include <atomic>
+#include <sched.h>
+#include <pthread.h>
 #include <thread>
 #include <random>
 #include <sdsl/bit_vectors.hpp>
@@ -125,6 +128,60 @@ void ref_bv_rank_mt(void * p, int bit, const uint64_t * idx, uint64_t n, uint64_
     }
     for (auto & x : th)
         x.join();
+}
+// All host cores, measured the way a throughput number should be: every thread pinned to one CPU of the process's
+// affinity mask, the output pages touched beforehand, the threads released together and the clock stopped when the last
+// one is done (thread creation and first-touch page faults are outside), `reps` passes over the slice so that a thread
+// runs long enough.  Returns the seconds of the slowest thread.
+double ref_bv_rank_mt_timed(void * p, int bit, const uint64_t * idx, uint64_t n, uint64_t * out, int threads, int reps)
+{
+    if (threads < 1)
+        threads = 1;
+    if (reps < 1)
+        reps = 1;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    sched_getaffinity(0, sizeof(allowed), &allowed);
+    std::vector<int> cpus;
+    for (int c = 0; c < CPU_SETSIZE; ++c)
+        if (CPU_ISSET(c, &allowed))
+            cpus.push_back(c);
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false};
+    std::vector<double> secs(threads, 0.0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t)
+        th.emplace_back(
+            [&, t]
+            {
+                if (!cpus.empty())
+                {
+                    cpu_set_t one;
+                    CPU_ZERO(&one);
+                    CPU_SET(cpus[t % cpus.size()], &one);
+                    pthread_setaffinity_np(pthread_self(), sizeof(one), &one);
+                }
+                const uint64_t lo = n * (uint64_t)t / threads, hi = n * (uint64_t)(t + 1) / threads;
+                for (uint64_t q = lo; q < hi; q += 512)
+                    out[q] = 0; // first touch
+                ready.fetch_add(1);
+                while (!go.load(std::memory_order_acquire))
+                    ;
+                auto t0 = std::chrono::steady_clock::now();
+                for (int r = 0; r < reps; ++r)
+                    ref_bv_rank(p, bit, idx + lo, hi - lo, out + lo);
+                secs[t] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            });
+    while (ready.load() < threads)
+        std::this_thread::yield();
+    go.store(true, std::memory_order_release);
+    double worst = 0;
+    for (int t = 0; t < threads; ++t)
+    {
+        th[t].join();
+        worst = std::max(worst, secs[t]);
+    }
+    return worst;
 }
 void ref_bv_rank_v(void * p, const uint64_t * idx, uint64_t n, uint64_t * out)
 {

@@ -727,17 +727,30 @@ sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, ui
     const bool want = mode == 0 ? false : (mode > 0 ? bv_sorted_rank_possible(h.view) : bv_sorted_rank_applicable(h.view, n));
     if (want && n > 0)
     {
+        // the scratch belongs to the handle; queries stay safe to issue from several threads / on several streams: the
+        // host side is serialised here, the device side by an event the next user of the scratch waits for
+        std::lock_guard<std::mutex> lock(h.scratch_mutex);
         const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
         const size_t need = bv_sorted_rank_scratch_bytes(h.view, pass);
+        if (h.scratch_ev)
+            SH_HIP(hipStreamWaitEvent(s, h.scratch_ev, 0));
         if (h.sort_scratch.bytes < need)
         {
-            SH_HIP(hipStreamSynchronize(s));
+            if (h.scratch_ev)
+                SH_HIP(hipEventSynchronize(h.scratch_ev)); // the old buffer may still be in use
             h.sort_scratch.release();
             if (h.sort_scratch.alloc(need) != SDSL_HIP_OK)
                 return bv_launch_rank(h.view, bit, d_idx, n, d_out, s); // no room for the scratch: direct kernel
         }
-        KernelTimer t(s);
-        return bv_launch_rank_sorted(h.view, bit, d_idx, n, d_out, s, h.sort_scratch.p, h.sort_scratch.bytes);
+        if (!h.scratch_ev)
+            SH_HIP(hipEventCreateWithFlags(&h.scratch_ev, hipEventDisableTiming));
+        sdsl_hip_status st;
+        {
+            KernelTimer t(s);
+            st = bv_launch_rank_sorted(h.view, bit, d_idx, n, d_out, s, h.sort_scratch.p, h.sort_scratch.bytes);
+        }
+        SH_HIP(hipEventRecord(h.scratch_ev, s));
+        return st;
     }
     return bv_launch_rank(h.view, bit, d_idx, n, d_out, s);
 }
@@ -930,7 +943,44 @@ sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv)
     if (!bv)
         return SDSL_HIP_OK;
     (void)hipSetDevice(bv->h.device);
+    (void)sdsl_hip_bv_release_scratch(bv);
     delete bv;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_last_phases(char * buf, size_t cap)
+{
+    if (!buf || cap == 0)
+        return SDSL_HIP_ERR_INVALID;
+    const std::string p = bv_sorted_last_phases();
+    snprintf(buf, cap, "%s", p.c_str());
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_bv_layout_info(sdsl_hip_bv_t bv, uint64_t out[4])
+{
+    if (!bv || !out)
+        return SDSL_HIP_ERR_INVALID;
+    out[0] = (uint64_t)(uintptr_t)bv->h.lines.p;
+    out[1] = bv->h.lines.bytes;
+    out[2] = (uint64_t)(uintptr_t)bv->h.sel[1].p;
+    out[3] = (uint64_t)(uintptr_t)bv->h.sort_scratch.p;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_bv_release_scratch(sdsl_hip_bv_t bv)
+{
+    if (!bv)
+        return SDSL_HIP_OK;
+    std::lock_guard<std::mutex> lock(bv->h.scratch_mutex);
+    SH_HIP(hipSetDevice(bv->h.device));
+    if (bv->h.scratch_ev)
+    {
+        SH_HIP(hipEventSynchronize(bv->h.scratch_ev));
+        SH_HIP(hipEventDestroy(bv->h.scratch_ev));
+        bv->h.scratch_ev = nullptr;
+    }
+    bv->h.sort_scratch.release();
     return SDSL_HIP_OK;
 }
 

@@ -2,6 +2,8 @@
 // launch helpers other translation units (wavelet tree, FM-index) call.
 #pragma once
 #include "bv_device.hpp"
+#include <mutex>
+
 #include "common.hpp"
 
 namespace sdslhip {
@@ -14,6 +16,8 @@ struct BvHost
     DevBuf cnts;   // u32 per line, build-time only
     DevBuf sel[2]; // select sample directories
     DevBuf sort_scratch; // working memory of the bucketed batch rank (bv_sorted.hip), grown on demand
+    hipEvent_t scratch_ev = nullptr; // recorded behind the last user of sort_scratch
+    std::mutex scratch_mutex;
     size_t device_bytes() const
     {
         return lines.bytes + sel[0].bytes + sel[1].bytes + sort_scratch.bytes;
@@ -33,6 +37,7 @@ sdsl_hip_status bv_launch_rank(const BvView & v, int bit, const uint64_t * d_idx
 BvHost & bv_host_of(sdsl_hip_bv_t bv);
 sdsl_hip_status bv_new_replica(const BvHost & src, int device, sdsl_hip_bv_t * out);
 // large batches, bucketed by index region (bv_sorted.hip)
+std::string bv_sorted_last_phases();
 bool bv_sorted_rank_possible(const BvView & v);
 bool bv_sorted_rank_applicable(const BvView & v, uint64_t n);
 size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n);

@@ -25,6 +25,9 @@
 // makes the way back exact), the sorted tile is written out bin by bin (16 lanes per bin).  No pass scatters single
 // words: the un-permute that sank the idea in round 1 (random 8-byte scatter, 22.9 G/s,
 // profiles/scatter_probe_r01.txt) is a gather of runs staged through LDS.
+#include <mutex>
+#include <string>
+
 #include "bv_host.hpp"
 
 namespace sdslhip {
@@ -813,6 +816,9 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
     }
 }
 
+std::mutex g_phase_mutex;
+std::string g_last_phases; // "name=ms;..." of the most recent traced call (option "trace_phases")
+
 struct PhaseTimer
 {
     bool on;
@@ -846,6 +852,24 @@ struct PhaseTimer
             fprintf(stderr, " %s %.3f", name[i], ms);
         }
         fprintf(stderr, " | total %.3f ms = %.2f G/s\n", total, g.n / total / 1e6);
+    }
+    void keep()
+    {
+        if (!on)
+            return;
+        (void)hipEventSynchronize(ev[n - 1]);
+        static const char * name[] = {"hist1", "offs1", "part1", "hist2", "offs2", "part2", "slices", "rank", "unperm2", "unperm1"};
+        std::string out;
+        for (int i = 0; i + 1 < n; ++i)
+        {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            char buf[64];
+            snprintf(buf, sizeof(buf), "%s%s=%.4f", i ? ";" : "", name[i], ms);
+            out += buf;
+        }
+        std::lock_guard<std::mutex> lock(g_phase_mutex);
+        g_last_phases = out;
     }
     ~PhaseTimer()
     {
@@ -915,6 +939,12 @@ SrKernels sr_kernels(unsigned per_cu)
 
 } // namespace
 
+std::string bv_sorted_last_phases()
+{
+    std::lock_guard<std::mutex> lock(g_phase_mutex);
+    return g_last_phases;
+}
+
 // scratch: 13 bytes per position (two key arrays, two slot arrays, the high answer byte) + the tables
 size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n)
 {
@@ -930,15 +960,18 @@ bool bv_sorted_rank_possible(const BvView & v)
 
 bool bv_sorted_rank_applicable(const BvView & v, uint64_t n)
 {
-    // worth it when the index is much larger than the L2s (else the direct kernel already hits) and the batch
-    // addresses every line several times
-    return bv_sorted_rank_possible(v) && v.n_lines >= (UINT64_C(1) << 19) && n >= (UINT64_C(1) << 24) && n >= 4 * v.n_lines;
+    // worth it when the index is larger than the Infinity Cache (256 MiB = 2^22 lines; below that the direct kernel's
+    // gathers are served on-die at 52-58 G/s, what this path reaches) and the batch addresses every line at least twice
+    // (the slices are streamed once per batch whatever its size: 2^34 bits cost 0.45 ms before the first answer)
+    return bv_sorted_rank_possible(v) && v.n_lines >= (UINT64_C(1) << 22) && n >= 2 * v.n_lines;
 }
 
 sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                                       hipStream_t s, void * scratch, size_t scratch_bytes)
 {
-    static const bool trace = getenv("SDSL_HIP_TRACE_SORTED") != nullptr;
+    static const bool trace_env = getenv("SDSL_HIP_TRACE_SORTED") != nullptr;
+    const bool trace_opt = g_trace_phases.load() != 0;
+    const bool trace = trace_env || trace_opt;
     static const int t_env = getenv("SDSL_HIP_SORTED_THREADS") ? atoi(getenv("SDSL_HIP_SORTED_THREADS")) : 0;
     static const int g_env = getenv("SDSL_HIP_SORTED_G") ? atoi(getenv("SDSL_HIP_SORTED_G")) : 0;
     static const int rb_env = getenv("SDSL_HIP_SORTED_RANK_BLOCKS") ? atoi(getenv("SDSL_HIP_SORTED_RANK_BLOCKS")) : 0;
@@ -1009,7 +1042,10 @@ sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t 
                            nullptr, nullptr, d_out + done);
         pt.mark();
         SH_HIP(hipGetLastError());
-        pt.report(g);
+        if (trace_env)
+            pt.report(g);
+        if (trace_opt)
+            pt.keep();
         done += cnt;
     }
     return SDSL_HIP_OK;

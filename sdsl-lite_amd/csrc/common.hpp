@@ -22,6 +22,7 @@
 namespace sdslhip {
 
 extern std::atomic<int> g_rank_sorted_mode; // sdsl_hip_set_option("rank_sorted", ...)
+extern std::atomic<int> g_trace_phases;     // sdsl_hip_set_option("trace_phases", ...)
 const char * last_error_message();
 void suppress_timing_in_this_thread();
 void set_error(const char * fmt, ...);

@@ -127,6 +127,15 @@ class bit_vector(_Handle):
     def device_bytes(self) -> int:
         return capi.lib().sdsl_hip_bv_device_bytes(self._h)
 
+    def layout_info(self) -> dict:
+        o = (C.c_uint64 * 4)()
+        capi.check(capi.lib().sdsl_hip_bv_layout_info(self._h, o))
+        return {"lines_ptr": int(o[0]), "lines_bytes": int(o[1]), "select1_ptr": int(o[2]), "scratch_ptr": int(o[3])}
+
+    def release_scratch(self):
+        """Frees the working memory the bucketed batch rank keeps with the handle."""
+        capi.check(capi.lib().sdsl_hip_bv_release_scratch(self._h))
+
     def rank(self, idx, bit: int = 1, out=None):
         idx = _as_array(idx, np.uint64, "idx")
         n = idx.numel() if _is_tensor(idx) else idx.size
@@ -215,6 +224,18 @@ def last_kernel_ms() -> float:
 def set_option(name: str, value: int) -> None:
     """sdsl_hip_set_option, e.g. set_option("rank_sorted", 1)."""
     capi.check(capi.lib().sdsl_hip_set_option(name.encode(), int(value)))
+
+
+def last_phases() -> dict:
+    """Per-pass milliseconds of the most recent bucketed batch rank (needs set_option("trace_phases", 1))."""
+    buf = C.create_string_buffer(1024)
+    capi.check(capi.lib().sdsl_hip_last_phases(buf, 1024))
+    out = {}
+    for kv in buf.value.decode().split(";"):
+        if "=" in kv:
+            k, v = kv.split("=")
+            out[k] = float(v)
+    return out
 
 
 def set_random_bits(n_bits: int, seed: int) -> np.ndarray:

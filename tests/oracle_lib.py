@@ -458,6 +458,7 @@ _REF_SIGS = {
     "ref_bv_destroy": (None, [_vp]),
     "ref_bv_rank": (None, [_vp, C.c_int, _vp, _u64, _vp]),
     "ref_bv_rank_mt": (None, [_vp, C.c_int, _vp, _u64, _vp, C.c_int]),
+    "ref_bv_rank_mt_timed": (C.c_double, [_vp, C.c_int, _vp, _u64, _vp, C.c_int, C.c_int]),
     "ref_bv_rank_v": (None, [_vp, _vp, _u64, _vp]),
     "ref_bv_select": (None, [_vp, C.c_int, _vp, _u64, _vp]),
     "ref_bv_serialize": (None, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
