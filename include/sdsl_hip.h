@@ -183,6 +183,10 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
                                           uint64_t * out, void * stream);
 sdsl_hip_status sdsl_hip_rrr_access_batch(sdsl_hip_rrr_t v, const uint64_t * idx, uint64_t n, uint8_t * out,
                                           void * stream);
+/* rrr_vector::get_int(idx, len) (rrr_vector.hpp:308-356): out[q] = the len <= 64 bits [idx[q], idx[q] + len), bit idx[q]
+ * lowest; a window reaching beyond size() answers SDSL_HIP_NPOS (the reference asserts) */
+sdsl_hip_status sdsl_hip_rrr_get_int_batch(sdsl_hip_rrr_t v, const uint64_t * idx, uint32_t len, uint64_t n, uint64_t * out,
+                                           void * stream);
 
 /* ---- wt_huff<bit_vector, rank_support_v5<>> over bytes ----------------------------------
  * Replaces: wt_pc(begin,end) (wt_pc.hpp:194-248) with the Huffman shape (wt_huff.hpp:83-115)
@@ -345,7 +349,7 @@ sdsl_hip_status sdsl_hip_fm_locate_batch(sdsl_hip_fm_t fm, const uint8_t * patte
  * create: the ones of a plain bit vector (sd_vector(bit_vector const&), :217-257); create_from_positions: a strictly
  * increasing position list with an explicit size (the builder / iterator constructors, :259-324);
  * create_from_sdsl: sd_vector<>::serialize bytes (:435-445).  Out-of-domain arguments give SDSL_HIP_NPOS / 0xFF.
- * select_0 follows the reference's binary search over select_1 (O(log m) probes per query). */
+ * select_0 is served by an interpolated search over buckets over select_1 (O(log m) probes per query). */
 typedef struct sdsl_hip_sd_s * sdsl_hip_sd_t;
 sdsl_hip_status sdsl_hip_sd_create(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_sd_t * out);
 sdsl_hip_status sdsl_hip_sd_create_from_positions(const uint64_t * positions, uint64_t m, uint64_t n_bits, int32_t device,

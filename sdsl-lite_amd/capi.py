@@ -75,6 +75,7 @@ SIGNATURES = {
     "sdsl_hip_rrr_ones": (C.c_uint64, [_vp]),
     "sdsl_hip_rrr_device_bytes": (C.c_uint64, [_vp]),
     "sdsl_hip_rrr_rank_batch": (C.c_int32, [_vp, C.c_int32, _vp, C.c_uint64, _vp, _vp]),
+    "sdsl_hip_rrr_get_int_batch": (C.c_int32, [_vp, _vp, C.c_uint32, C.c_uint64, _vp, _vp]),
     "sdsl_hip_rrr_select_batch": (C.c_int32, [_vp, C.c_int32, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_rrr_access_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_sd_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),

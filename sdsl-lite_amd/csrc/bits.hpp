@@ -106,4 +106,17 @@ SH_HD uint64_t read_bits(const uint64_t * data, uint64_t pos, unsigned len)
     return v & lo_set(len);
 }
 
+// OR `len` (0..64) bits of v into a zero-initialised packed array at bit position `pos` (host-side builders)
+inline void write_bits(uint64_t * data, uint64_t pos, unsigned len, uint64_t v)
+{
+    if (len == 0)
+        return;
+    v &= lo_set(len);
+    uint64_t * p = data + (pos >> 6);
+    const unsigned off = (unsigned)(pos & 63);
+    p[0] |= v << off;
+    if (off + len > 64)
+        p[1] |= v >> (64 - off);
+}
+
 } // namespace sdslhip

@@ -166,6 +166,36 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, cons
     }
 }
 
+// rrr_vector::get_int(idx, len) (rrr_vector.hpp:308-356): the len <= 64 bits starting at idx, bit idx in the lowest
+// position; a window touches at most two 63-bit blocks.  One query per lane.
+__global__ __launch_bounds__(kRrrBlock) void k_rrr_get_int(RrrView v, unsigned len, const uint64_t * __restrict__ iq,
+                                                           uint64_t * __restrict__ out, uint64_t n)
+{
+    __shared__ RrrTables T;
+    rrr_stage_tables(&T, v.tables);
+    for (uint64_t q = (uint64_t)blockIdx.x * kRrrBlock + threadIdx.x; q < n; q += (uint64_t)gridDim.x * kRrrBlock)
+    {
+        const uint64_t i = __builtin_nontemporal_load(iq + q);
+        uint64_t r = SDSL_HIP_NPOS;
+        if (i <= v.n_bits && len <= v.n_bits - i)
+        {
+            r = 0;
+            if (len)
+            {
+                const RankTail t = rrr_rank_head(v, &T, i);
+                r = rrr_decode_block(&T, t.k, t.nr) >> t.off;
+                if (t.off + len > kRrrBS)
+                {
+                    const RankTail u = rrr_rank_head(v, &T, i - t.off + kRrrBS);
+                    r |= rrr_decode_block(&T, u.k, u.nr) << (kRrrBS - t.off);
+                }
+                r &= lo_set(len);
+            }
+        }
+        out[q] = r;
+    }
+}
+
 // select, one query per lane
 // Flat variant: every wave owns a contiguous range of the batch; a lane that needs a query takes the next unassigned
 // index of the range (rank among the needing lanes, from a ballot), so the queries in flight in a wave stay within a
@@ -329,7 +359,7 @@ __global__ __launch_bounds__(256) void k_rrr_enc_classes(const uint64_t * __rest
         r[kRecClasses + 2] = cw[2];
         r[kRecClasses + 3] = cw[3];
         sb_ones[sb] = ones;
-        sb_len[sb] = len;
+        sb_len[sb] = len > kInlineBits ? len : 0; // bits this superblock needs in the offset stream (rrr_device.hpp)
     }
 }
 
@@ -339,6 +369,7 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
                                                          uint64_t n_blocks, uint64_t n_sb,
                                                          const RrrTables * __restrict__ tables, uint64_t * __restrict__ rec,
                                                          const uint32_t * __restrict__ sb_ones,
+                                                         const uint32_t * __restrict__ sb_store,
                                                          unsigned long long * __restrict__ stream, uint32_t sh1, uint32_t sh0, uint32_t ps,
                                                          uint32_t * __restrict__ sel1, uint32_t * __restrict__ sel0)
 {
@@ -349,6 +380,7 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
     {
         uint64_t * r = rec + sb * kRecWords;
         const uint64_t ones_before = r[0], ptr = r[1];
+        const bool stored = sb_store[sb] != 0; // its offsets do not fit the inline area: all of them go to the stream
         const uint64_t start = sb * kRrrSB;
         uint64_t acc1 = ones_before, acc0 = start - ones_before; // arguments before the current block
         uint64_t j1 = (acc1 + S1 - 1) >> sh1, j0 = (acc0 + S0 - 1) >> sh0;
@@ -374,11 +406,14 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
                     --kk;
                     x &= x - 1;
                 }
-                const uint64_t pos = ptr + rel;
-                const unsigned off = (unsigned)(pos & 63);
-                atomicOr(&stream[pos >> 6], (unsigned long long)(nr << off));
-                if (off + len > 64)
-                    atomicOr(&stream[(pos >> 6) + 1], (unsigned long long)(nr >> (64 - off)));
+                if (stored)
+                {
+                    const uint64_t pos = ptr + rel;
+                    const unsigned off = (unsigned)(pos & 63);
+                    atomicOr(&stream[pos >> 6], (unsigned long long)(nr << off));
+                    if (off + len > 64)
+                        atomicOr(&stream[(pos >> 6) + 1], (unsigned long long)(nr >> (64 - off)));
+                }
                 if (rel < kInlineBits)
                 { // inline copy of the first 576 offset bits (a field may be cut by the boundary; readers only
                   // use the inline area for fields that lie in it completely)
@@ -467,6 +502,14 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
     std::vector<uint64_t> rec((size_t)A.n_sb * kRecWords, 0);
+    // the device keeps stream storage only for superblocks whose offsets overflow the record's inline area
+    std::vector<uint64_t> cptr((size_t)A.n_sb + 1, 0);
+    for (uint64_t s = 0; s < A.n_sb; ++s)
+    {
+        const uint64_t len = A.sb_ptr[s + 1] - A.sb_ptr[s];
+        cptr[s + 1] = cptr[s] + (len > kInlineBits ? len : 0);
+    }
+    std::vector<uint64_t> cstream(((std::max<uint64_t>(cptr[A.n_sb], 64) + 63) >> 6) + 2, 0);
     const uint64_t zeros = A.n_bits - A.ones;
     // sampling rate: smallest power of two >= 256 that keeps a directory within 2^21 samples
     uint32_t shb[2];
@@ -483,7 +526,7 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
             uint64_t * r = &rec[(size_t)s * kRecWords];
             uint64_t ones_in = A.sb_rank[s + 1] - A.sb_rank[s];
             r[0] = A.sb_rank[s];
-            r[1] = A.sb_ptr[s] | (ones_in << 48);
+            r[1] = cptr[s] | (ones_in << 48);
             memcpy(r + kRecClasses, &A.cls[(size_t)s * kRrrK], kRrrK);
             {
                 unsigned po[3], pb[3], ones = 0, bits = 0;
@@ -563,8 +606,14 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     SH_TRY(h.rec.alloc(rec.size() * 8));
     if (!rec.empty())
         SH_HIP(hipMemcpy(h.rec.p, rec.data(), rec.size() * 8, hipMemcpyHostToDevice));
-    SH_TRY(h.stream.alloc(A.stream.size() * 8));
-    SH_HIP(hipMemcpy(h.stream.p, A.stream.data(), A.stream.size() * 8, hipMemcpyHostToDevice));
+    for (uint64_t s = 0; s < A.n_sb; ++s) // (sequential: neighbouring superblocks share words of the compact stream)
+        for (uint64_t o = 0, len = cptr[s + 1] - cptr[s]; o < len; o += 64)
+        {
+            const unsigned l = (unsigned)std::min<uint64_t>(64, len - o);
+            write_bits(cstream.data(), cptr[s] + o, l, read_bits(A.stream.data(), A.sb_ptr[s] + o, l));
+        }
+    SH_TRY(h.stream.alloc(cstream.size() * 8));
+    SH_HIP(hipMemcpy(h.stream.p, cstream.data(), cstream.size() * 8, hipMemcpyHostToDevice));
     SH_TRY(h.tables.alloc(sizeof(RrrTables)));
     SH_HIP(hipMemcpy(h.tables.p, &T, sizeof(RrrTables), hipMemcpyHostToDevice));
     SH_TRY(h.sel[1].alloc(sel1.size() * 4));
@@ -640,7 +689,7 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
     SH_TRY(h.sel[1].alloc((ns1 + 2) * 4, true));
     SH_TRY(h.sel[0].alloc((ns0 + 2) * 4, true));
     hipLaunchKernelGGL(k_rrr_enc_offsets, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
-                       h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(),
+                       h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(), sb_len.as<uint32_t>(),
                        h.stream.as<unsigned long long>(), shb[1], shb[0], ps, h.sel[1].as<uint32_t>(), h.sel[0].as<uint32_t>());
     SH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_rrr_set_sentinels, dim3(1), dim3(1), 0, 0, h.sel[1].as<uint32_t>(), ns1, h.sel[0].as<uint32_t>(),
@@ -676,16 +725,37 @@ sdsl_hip_status rrr_serialize_host(const RrrHost & h, StreamWriter & w)
     // total offset bits = pointer of the last superblock + its own offsets
     const RrrTables & T = host_tables();
     auto cls = [&](uint64_t b) -> unsigned { return (unsigned)(rec[(b / kRrrK) * kRecWords + kRecClasses + ((b % kRrrK) >> 3)] >> (8 * (b & 7))) & 0xFF; };
-    uint64_t stream_bits = 0;
-    if (nsb)
+    // SDSL's pointers (m_btnrp) and offset stream (m_btnr) from the classes, the inline areas and the compact stream
+    std::vector<uint64_t> sptr((size_t)nsb + 1, 0);
+    for (uint64_t sb = 0; sb < nsb; ++sb)
     {
-        stream_bits = rec[(nsb - 1) * kRecWords + 1] & ((UINT64_C(1) << 48) - 1);
-        for (uint64_t b = (nsb - 1) * kRrrK; b < nb; ++b)
-            stream_bits += T.space[cls(b)];
+        uint64_t len = 0;
+        for (uint64_t b = sb * kRrrK; b < std::min(nb, (sb + 1) * kRrrK); ++b)
+            len += T.space[cls(b)];
+        sptr[sb + 1] = sptr[sb] + len;
     }
+    const uint64_t stream_bits = sptr[nsb];
     const uint64_t btnr_bits = std::max<uint64_t>(stream_bits, 64); // rrr_vector.hpp:183
     std::vector<uint64_t> btnr(((btnr_bits + 63) >> 6) + 1, 0);
-    SH_HIP(hipMemcpy(btnr.data(), rv.stream, ((btnr_bits + 63) >> 6) * 8, hipMemcpyDeviceToHost));
+    {
+        const uint64_t cbits = nsb ? (rec[(nsb - 1) * kRecWords + 1] & ((UINT64_C(1) << 48) - 1))
+                                         + (sptr[nsb] - sptr[nsb - 1] > kInlineBits ? sptr[nsb] - sptr[nsb - 1] : 0)
+                                   : 0;
+        std::vector<uint64_t> cs(((std::max<uint64_t>(cbits, 64) + 63) >> 6) + 1, 0);
+        SH_HIP(hipMemcpy(cs.data(), rv.stream, ((std::max<uint64_t>(cbits, 64) + 63) >> 6) * 8, hipMemcpyDeviceToHost));
+        for (uint64_t sb = 0; sb < nsb; ++sb)
+        {
+            const uint64_t len = sptr[sb + 1] - sptr[sb];
+            const bool stored = len > kInlineBits;
+            const uint64_t * src = stored ? cs.data() : &rec[sb * kRecWords + kRecInline];
+            const uint64_t base = stored ? rec[sb * kRecWords + 1] & ((UINT64_C(1) << 48) - 1) : 0;
+            for (uint64_t o = 0; o < len; o += 64)
+            {
+                const unsigned l = (unsigned)std::min<uint64_t>(64, len - o);
+                write_bits(btnr.data(), sptr[sb] + o, l, read_bits(src, base + o, l));
+            }
+        }
+    }
     PackedBuilder bt(nb, 6), btnrp(nsb, (uint8_t)(hi64(stream_bits) + 1)), invert(nsb, 1);
     const uint64_t n_rank = nsb + ((n % kRrrSB) > 0); // rrr_vector.hpp:185-186
     PackedBuilder rank(n_rank, (uint8_t)(hi64(rv.ones) + 1));
@@ -706,7 +776,7 @@ sdsl_hip_status rrr_serialize_host(const RrrHost & h, StreamWriter & w)
         for (uint64_t b = i; b < std::min(nb, i + kRrrK); ++b)
             bt.set(b, inv ? kRrrBS - cls(b) : cls(b));
         const bool dummy_only = i * kRrrBS >= n; // superblock that starts with the dummy block: never initialised by SDSL
-        btnrp.set(s, dummy_only ? 0 : (rec[s * kRecWords + 1] & ((UINT64_C(1) << 48) - 1)));
+        btnrp.set(s, dummy_only ? 0 : sptr[s]);
         if (s + 1 < n_rank)
             rank.set(s, rec[s * kRecWords]);
     }
@@ -933,6 +1003,33 @@ sdsl_hip_status sdsl_hip_rrr_access_batch(sdsl_hip_rrr_t v, const uint64_t * idx
         KernelTimer t(s);
         hipLaunchKernelGGL((k_rrr_rank<1>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view, 1,
                            (const uint64_t *)in.dev, (uint64_t *)nullptr, (uint8_t *)o.dev, n);
+    }
+    SH_HIP(hipGetLastError());
+    SH_TRY(o.finish(s));
+    if (in.host && !o.host)
+        SH_HIP(hipStreamSynchronize(s));
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_rrr_get_int_batch(sdsl_hip_rrr_t v, const uint64_t * idx, uint32_t len, uint64_t n, uint64_t * out,
+                                           void * stream)
+{
+    if (!v || len > 64 || (n && (!idx || !out)))
+    {
+        set_error("rrr_get_int_batch: invalid argument (len must be <= 64)");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SH_HIP(hipSetDevice(v->h.device));
+    if (n == 0)
+        return SDSL_HIP_OK;
+    Staged in, o;
+    SH_TRY(in.in(idx, n * 8, s));
+    SH_TRY(o.out(out, n * 8));
+    {
+        KernelTimer t(s);
+        hipLaunchKernelGGL(k_rrr_get_int, dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view, len, (const uint64_t *)in.dev,
+                           (uint64_t *)o.dev, n);
     }
     SH_HIP(hipGetLastError());
     SH_TRY(o.finish(s));
