@@ -137,6 +137,11 @@ sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bi
 #define SDSL_HIP_SER_RANK_V_0 6
 sdsl_hip_status sdsl_hip_bv_serialize(sdsl_hip_bv_t bv, int32_t what, void * buf, size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv);
+/* ONE query, value in, value out: what = 0 rank_<bit>(arg), 1 select_<bit>(arg).  This is what the scalar operator() of
+ * the C++ adaptors calls: the argument and the answer travel through a mapped pinned mailbox, so the call costs one
+ * kernel launch and one stream synchronisation (about 10 microseconds) — correct, but a loop of such
+ * calls is latency-bound: batch whenever there is a loop. */
+sdsl_hip_status sdsl_hip_bv_query_one(sdsl_hip_bv_t bv, int32_t what, int32_t bit, uint64_t arg, uint64_t * out);
 /* frees the working memory the bucketed batch rank keeps with the handle between calls (13 bytes per query of the largest
  * batch seen, at most 2^30 queries' worth; counted by sdsl_hip_bv_device_bytes); the next large batch allocates it again */
 sdsl_hip_status sdsl_hip_bv_release_scratch(sdsl_hip_bv_t bv);

@@ -116,10 +116,14 @@ public:
         set_vector(v);
     }
     //! Number of t_b bits in [0, idx), idx in [0, size()]   (rank_support_v5.hpp:131-149)
+    //! One query = one kernel launch + one synchronisation (about 10 microseconds): fine for occasional calls, latency-bound in a
+    //! loop — use rank_batch there.
     size_type rank(size_type idx) const
     {
-        size_type r = 0;
-        rank_batch(&idx, 1, &r);
+        if (!m_dev)
+            throw std::runtime_error("rank_support_v5_hip: no vector set");
+        uint64_t r = 0;
+        hip_detail::check(sdsl_hip_bv_query_one(m_dev.get(), 0, dev_bit, idx, &r), "sdsl_hip_bv_query_one");
         return r;
     }
     size_type operator()(size_type idx) const
@@ -226,10 +230,13 @@ public:
         set_vector(v);
     }
     //! Position of the i-th t_b bit, i in [1, #t_b bits]   (select_support_mcl.hpp:384-439)
+    //! (one launch + one synchronisation per call: use select_batch in loops)
     size_type select(size_type i) const
     {
-        size_type r = 0;
-        select_batch(&i, 1, &r);
+        if (!m_dev)
+            throw std::runtime_error("select_support_mcl_hip: no vector set");
+        uint64_t r = 0;
+        hip_detail::check(sdsl_hip_bv_query_one(m_dev.get(), 1, dev_bit, i, &r), "sdsl_hip_bv_query_one");
         return r;
     }
     size_type operator()(size_type i) const

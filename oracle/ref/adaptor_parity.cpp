@@ -3,6 +3,7 @@
 // scalar answer of the unmodified reference object it was built from.  TEST INFRASTRUCTURE: built by
 // oracle/Makefile into oracle/_ref/adaptor_parity (needs /root/reference at build time), run on the GPU
 // box by tests/test_gpu_adaptors.py.  Exit code 0 = all comparisons equal.
+#include <chrono>
 #include <sdsl_hip/adaptors.hpp>
 
 #include <cstdio>
@@ -446,6 +447,36 @@ int main(int argc, char ** argv)
             CHECK(sdl == sdr, "GPU-built sd_vector loads into sd_vector<> and equals the host-built one");
             sdsl_hip_sd_destroy(sh);
         }
+    }
+    // what a scalar call costs: rs(i) one at a time against one batch call
+    {
+        bit_vector bv(1 << 24, 0);
+        for (uint64_t i = 0; i < bv.size(); i += 3)
+            bv[i] = 1;
+        rank_support_v5_hip<1> hr(&bv);
+        rank_support_v5<1> r1(&bv);
+        const size_t nq = 20000;
+        std::vector<uint64_t> q(nq), out(nq);
+        for (auto & x : q)
+            x = rng() % (bv.size() + 1);
+        (void)hr(q[0]);
+        auto t0 = std::chrono::steady_clock::now();
+        uint64_t sum = 0;
+        for (size_t i = 0; i < nq; ++i)
+            sum += hr(q[i]);
+        double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / nq;
+        t0 = std::chrono::steady_clock::now();
+        hr.rank_batch(q.data(), nq, out.data());
+        double us_b = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / nq;
+        uint64_t want = 0, got_b = 0;
+        for (size_t i = 0; i < nq; ++i)
+        {
+            want += r1(q[i]);
+            got_b += out[i];
+        }
+        CHECK(sum == want && got_b == want, "scalar operator() loop and batch agree with rank_support_v5");
+        printf("scalar rs(i): %.2f us per call; the same %zu queries as one rank_batch from host arrays: %.4f us per query\n", us, nq,
+               us_b);
     }
     // several GPUs of one node (all the box has; a group of one still goes through the group driver and RCCL's setup)
     {

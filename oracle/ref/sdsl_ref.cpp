@@ -262,6 +262,12 @@ void ref_rrr_access(void * p, const uint64_t * i, uint64_t n, uint8_t * out)
     for (uint64_t q = 0; q < n; ++q)
         out[q] = h->v[i[q]];
 }
+void ref_rrr_get_int(void * p, const uint64_t * i, uint32_t len, uint64_t n, uint64_t * out)
+{
+    RefRrr * h = (RefRrr *)p;
+    for (uint64_t q = 0; q < n; ++q)
+        out[q] = h->v.get_int(i[q], (uint8_t)len);
+}
 void ref_rrr_serialize(void * p, uint8_t ** out, uint64_t * len)
 {
     to_bytes(((RefRrr *)p)->v, out, len);

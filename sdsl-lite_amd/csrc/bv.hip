@@ -206,6 +206,66 @@ __global__ void k_set_u32(uint32_t * p, uint32_t v)
     *p = v;
 }
 
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t * p, uint64_t n, uint32_t v)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+// positions of ALL arguments of the long sample intervals (one thread per line; a line contributes to such an interval
+// only with a few arguments), plus, as entry S of every long interval, the first position of the next interval
+template <int BIT>
+__global__ __launch_bounds__(256) void k_build_sel_long(const uint64_t * __restrict__ lines, const uint32_t * __restrict__ cnts,
+                                                        uint64_t n_bits, uint64_t n_lines, uint32_t shift, uint32_t pshift,
+                                                        const uint32_t * __restrict__ sample, uint64_t ns,
+                                                        const uint32_t * __restrict__ lmask, const uint32_t * __restrict__ lidx,
+                                                        uint32_t * __restrict__ lpos)
+{
+    const uint64_t S = UINT64_C(1) << shift;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ns; j += (uint64_t)gridDim.x * blockDim.x)
+        if ((lmask[j >> 5] >> (j & 31)) & 1u)
+            lpos[(uint64_t)lidx[j] * (S + 1) + S] = sample[j + 1];
+    for (uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; L < n_lines; L += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t start = L * kDB;
+        if (start >= n_bits)
+            continue;
+        const uint64_t valid = n_bits - start < kDB ? n_bits - start : kDB;
+        const uint64_t h1 = lines[L * kLW], c1 = cnts[L];
+        const uint64_t h = BIT ? h1 : start - h1;
+        const uint64_t c = BIT ? c1 : valid - c1;
+        if (c == 0)
+            continue;
+        // is any interval this line's arguments fall into a long one?
+        const uint64_t j0 = h >> shift, j1 = (h + c - 1) >> shift;
+        bool any = false;
+        for (uint64_t j = j0; j <= j1; ++j)
+            any |= ((lmask[j >> 5] >> (j & 31)) & 1u) != 0;
+        if (!any)
+            continue;
+        uint64_t k = h;
+        for (int d = 0; d < kDW; ++d)
+        {
+            uint64_t x = lines[L * kLW + 1 + d];
+            if (!BIT)
+            {
+                const uint64_t ws = 64ull * d;
+                const uint64_t m = ws >= valid ? 0 : (valid - ws >= 64 ? ~UINT64_C(0) : lo_set((unsigned)(valid - ws)));
+                x = ~x & m;
+            }
+            while (x)
+            {
+                const unsigned b = (unsigned)__ffsll((long long)x) - 1;
+                const uint64_t j = k >> shift;
+                if ((lmask[j >> 5] >> (j & 31)) & 1u)
+                    lpos[(uint64_t)lidx[j] * (S + 1) + (k & (S - 1))] = (uint32_t)((start + 64ull * d + b) >> pshift);
+                ++k;
+                x &= x - 1;
+            }
+        }
+    }
+}
+
 sdsl_hip_status build_select_dir(BvHost & bv, int bit)
 {
     uint64_t total = bit ? bv.view.ones : bv.view.n_bits - bv.view.ones;
@@ -224,6 +284,48 @@ sdsl_hip_status build_select_dir(BvHost & bv, int bit)
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, 0, smp + ns, (uint32_t)(bv.view.n_bits >> bv.view.sel_pshift));
     SH_HIP(hipGetLastError());
     bv.view.sel[bit] = smp;
+    // sparse stretches: intervals whose arguments lie more than kSelLongGap bits apart on average keep every position
+    bv.view.lmask[bit] = bv.view.lidx[bit] = bv.view.lpos[bit] = nullptr;
+    if (ns == 0 || getenv("SDSL_HIP_SELECT_NO_LONG"))
+        return SDSL_HIP_OK;
+    std::vector<uint32_t> h_smp(ns + 1);
+    SH_HIP(hipMemcpy(h_smp.data(), smp, (ns + 1) * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> h_mask((ns + 31) / 32 + 1, 0), h_idx(ns, 0);
+    const uint64_t S = UINT64_C(1) << sh;
+    uint64_t n_long = 0;
+    for (uint64_t j = 0; j < ns; ++j)
+    {
+        const uint64_t cnt = std::min<uint64_t>(S, total - j * S);
+        const uint64_t span = ((uint64_t)h_smp[j + 1] - h_smp[j]) << bv.view.sel_pshift;
+        if (cnt > 1 && span > kSelLongGap * cnt)
+        {
+            h_mask[j >> 5] |= 1u << (j & 31);
+            h_idx[j] = (uint32_t)n_long++;
+        }
+    }
+    if (n_long == 0)
+        return SDSL_HIP_OK;
+    SH_TRY(bv.lmask[bit].alloc(h_mask.size() * 4));
+    SH_TRY(bv.lidx[bit].alloc(h_idx.size() * 4));
+    SH_TRY(bv.lpos[bit].alloc(n_long * (S + 1) * 4));
+    SH_HIP(hipMemcpy(bv.lmask[bit].p, h_mask.data(), h_mask.size() * 4, hipMemcpyHostToDevice));
+    SH_HIP(hipMemcpy(bv.lidx[bit].p, h_idx.data(), h_idx.size() * 4, hipMemcpyHostToDevice));
+    const uint32_t sentinel = (uint32_t)(bv.view.n_bits >> bv.view.sel_pshift);
+    hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n_long * (S + 1), 256, 65536)), dim3(256), 0, 0, bv.lpos[bit].as<uint32_t>(),
+                       n_long * (S + 1), sentinel);
+    SH_HIP(hipGetLastError());
+    if (bit)
+        hipLaunchKernelGGL(k_build_sel_long<1>, dim3(grid), dim3(256), 0, 0, bv.view.lines, bv.cnts.as<uint32_t>(), bv.view.n_bits,
+                           bv.view.n_lines, sh, bv.view.sel_pshift, smp, ns, bv.lmask[bit].as<uint32_t>(), bv.lidx[bit].as<uint32_t>(),
+                           bv.lpos[bit].as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_build_sel_long<0>, dim3(grid), dim3(256), 0, 0, bv.view.lines, bv.cnts.as<uint32_t>(), bv.view.n_bits,
+                           bv.view.n_lines, sh, bv.view.sel_pshift, smp, ns, bv.lmask[bit].as<uint32_t>(), bv.lidx[bit].as<uint32_t>(),
+                           bv.lpos[bit].as<uint32_t>());
+    SH_HIP(hipGetLastError());
+    bv.view.lmask[bit] = bv.lmask[bit].as<uint32_t>();
+    bv.view.lidx[bit] = bv.lidx[bit].as<uint32_t>();
+    bv.view.lpos[bit] = bv.lpos[bit].as<uint32_t>();
     return SDSL_HIP_OK;
 }
 
@@ -406,7 +508,6 @@ __global__ __launch_bounds__(kBlock) void k_select_rq(BvView bv, const uint64_t 
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
     const uint64_t total = BIT ? bv.ones : bv.n_bits - bv.ones;
-    const uint32_t * __restrict__ smp = bv.sel[BIT];
     if (threadIdx.x == 0)
         rq_n = 0;
     __syncthreads();
@@ -450,14 +551,12 @@ __global__ __launch_bounds__(kBlock) void k_select_rq(BvView bv, const uint64_t 
     auto arg_ok = [&](uint64_t i) -> bool { return i >= 1 && i <= total; }; // outside: SDSL's precondition (select_support_mcl.hpp:386)
     const uint64_t q_first = (uint64_t)blockIdx.x * kQPB + gq;
     uint64_t i_cur = load_arg(q_first), i_nxt = load_arg(q_first + stride);
-    uint64_t j_cur = arg_ok(i_cur) ? (i_cur - 1) >> bv.sel_shift : 0;
-    uint32_t s0_cur = smp[j_cur], s1_cur = smp[j_cur + 1];
+    SelSamples sm_cur = sel_samples<BIT>(bv, arg_ok(i_cur) ? i_cur - 1 : 0);
     for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += stride) // block-uniform trip count
     {
         const uint64_t q = base + gq;
         const uint64_t i_nn = load_arg(q + 2 * stride);                                 // argument of round r+2
-        const uint64_t j_nxt = arg_ok(i_nxt) ? (i_nxt - 1) >> bv.sel_shift : 0;
-        const uint32_t s0_nxt = smp[j_nxt], s1_nxt = smp[j_nxt + 1];                    // samples of round r+1
+        const SelSamples sm_nxt = sel_samples<BIT>(bv, arg_ok(i_nxt) ? i_nxt - 1 : 0); // samples of round r+1
         const uint64_t i = i_cur;
         const bool ok = arg_ok(i);
         if (q < n && !ok && s == 0)
@@ -465,12 +564,11 @@ __global__ __launch_bounds__(kBlock) void k_select_rq(BvView bv, const uint64_t 
         if (ok)
         {
             const uint64_t k = i - 1;
-            probe(q, k, sel_bracket<BIT>(bv, k, s0_cur, s1_cur), 0u);
+            probe(q, k, sel_bracket<BIT>(bv, k, sm_cur), 0u);
         }
         i_cur = i_nxt;
         i_nxt = i_nn;
-        s0_cur = s0_nxt;
-        s1_cur = s1_nxt;
+        sm_cur = sm_nxt;
         __syncthreads();
         unsigned cnt = rq_n;
         __syncthreads(); // everybody has seen the same count before anyone pushes again
@@ -534,7 +632,6 @@ __global__ __launch_bounds__(kBlock) void k_select_wq(BvView bv, const uint64_t 
     RetryEntry * rq = rq_all[wave];
     unsigned * rq_n = &rq_cnt[wave];
     const uint64_t total = BIT ? bv.ones : bv.n_bits - bv.ones;
-    const uint32_t * __restrict__ smp = bv.sel[BIT];
     if ((threadIdx.x & 63) == 0)
         *rq_n = 0;
     wave_lds_sync();
@@ -569,14 +666,12 @@ __global__ __launch_bounds__(kBlock) void k_select_wq(BvView bv, const uint64_t 
     auto arg_ok = [&](uint64_t i) -> bool { return i >= 1 && i <= total; }; // SDSL's precondition (select_support_mcl.hpp:386)
     const uint64_t q_first = (uint64_t)blockIdx.x * kQPB + gq;
     uint64_t i_cur = load_arg(q_first), i_nxt = load_arg(q_first + stride);
-    uint64_t j_cur = arg_ok(i_cur) ? (i_cur - 1) >> bv.sel_shift : 0;
-    uint32_t s0_cur = smp[j_cur], s1_cur = smp[j_cur + 1];
+    SelSamples sm_cur = sel_samples<BIT>(bv, arg_ok(i_cur) ? i_cur - 1 : 0);
     for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += stride) // wave-uniform trip count
     {
         const uint64_t q = base + gq;
         const uint64_t i_nn = load_arg(q + 2 * stride);              // argument of round r+2
-        const uint64_t j_nxt = arg_ok(i_nxt) ? (i_nxt - 1) >> bv.sel_shift : 0;
-        const uint32_t s0_nxt = smp[j_nxt], s1_nxt = smp[j_nxt + 1]; // samples of round r+1
+        const SelSamples sm_nxt = sel_samples<BIT>(bv, arg_ok(i_nxt) ? i_nxt - 1 : 0); // samples of round r+1
         const uint64_t i = i_cur;
         const bool ok = arg_ok(i);
         if (q < n && !ok && s == 0)
@@ -584,12 +679,11 @@ __global__ __launch_bounds__(kBlock) void k_select_wq(BvView bv, const uint64_t 
         if (ok)
         {
             const uint64_t k = i - 1;
-            probe(q, k, sel_bracket<BIT>(bv, k, s0_cur, s1_cur), 0u);
+            probe(q, k, sel_bracket<BIT>(bv, k, sm_cur), 0u);
         }
         i_cur = i_nxt;
         i_nxt = i_nn;
-        s0_cur = s0_nxt;
-        s1_cur = s1_nxt;
+        sm_cur = sm_nxt;
         wave_lds_sync();
         unsigned cnt = *rq_n;
         while (cnt >= kQPW)
@@ -796,8 +890,16 @@ sdsl_hip_status bv_new_replica(const BvHost & src, int device, sdsl_hip_bv_t * o
     d.view = src.view;
     sdsl_hip_status st = d.lines.alloc(src.lines.bytes);
     for (int b = 0; b < 2 && st == SDSL_HIP_OK; ++b)
+    {
         if (src.sel[b].p)
             st = d.sel[b].alloc(src.sel[b].bytes);
+        if (st == SDSL_HIP_OK && src.lmask[b].p)
+            st = d.lmask[b].alloc(src.lmask[b].bytes);
+        if (st == SDSL_HIP_OK && src.lidx[b].p)
+            st = d.lidx[b].alloc(src.lidx[b].bytes);
+        if (st == SDSL_HIP_OK && src.lpos[b].p)
+            st = d.lpos[b].alloc(src.lpos[b].bytes);
+    }
     if (st != SDSL_HIP_OK)
     {
         delete bv;
@@ -805,7 +907,12 @@ sdsl_hip_status bv_new_replica(const BvHost & src, int device, sdsl_hip_bv_t * o
     }
     d.view.lines = d.lines.as<uint64_t>();
     for (int b = 0; b < 2; ++b)
+    {
         d.view.sel[b] = src.sel[b].p ? d.sel[b].as<uint32_t>() : nullptr;
+        d.view.lmask[b] = src.lmask[b].p ? d.lmask[b].as<uint32_t>() : nullptr;
+        d.view.lidx[b] = src.lidx[b].p ? d.lidx[b].as<uint32_t>() : nullptr;
+        d.view.lpos[b] = src.lpos[b].p ? d.lpos[b].as<uint32_t>() : nullptr;
+    }
     *out = bv;
     return SDSL_HIP_OK;
 }
@@ -1021,6 +1128,29 @@ sdsl_hip_status sdsl_hip_bv_rank_batch(sdsl_hip_bv_t bv, int32_t bit, const uint
     SH_TRY(o.finish(s));
     if (in.host && !o.host)
         SH_HIP(hipStreamSynchronize(s)); // staging buffer must outlive the kernel
+    return SDSL_HIP_OK;
+}
+
+// one query, host value in, host value out (the adaptors' scalar operator())
+sdsl_hip_status sdsl_hip_bv_query_one(sdsl_hip_bv_t bv, int32_t what, int32_t bit, uint64_t arg, uint64_t * out)
+{
+    if (!bv || !out || (bit != 0 && bit != 1) || what < 0 || what > 1)
+    {
+        set_error("bv_query_one: invalid argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    Mailbox * mb = nullptr;
+    SH_TRY(mailbox_for(bv->h.device, &mb));
+    std::lock_guard<std::mutex> lock(mb->m);
+    SH_HIP(hipSetDevice(bv->h.device));
+    mb->host[0] = arg;
+    suppress_timing_in_this_thread();
+    if (what == 0)
+        SH_TRY(bv_launch_rank(bv->h.view, bit, mb->dev, 1, mb->dev + 8, mb->stream));
+    else
+        SH_TRY(bv_launch_select(bv->h.view, bit, mb->dev, 1, mb->dev + 8, mb->stream));
+    SH_HIP(hipStreamSynchronize(mb->stream));
+    *out = mb->host[8];
     return SDSL_HIP_OK;
 }
 

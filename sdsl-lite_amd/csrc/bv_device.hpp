@@ -32,7 +32,40 @@ struct BvView
     const uint32_t * sel[2]; // sel[b][j] = (position of the b-bit of 0-based rank j<<sel_shift) >> sel_pshift; + sentinel
     uint32_t sel_shift;      // log2 of the sampling rate
     uint32_t sel_pshift;     // position quantisation so that samples fit 32 bits (0 for n_bits < 2^32)
+    // Sparse stretches (the counterpart of select_support_mcl's "long" blocks, select_support_mcl.hpp:242-252): a sample
+    // interval whose arguments lie more than kSelLongGap bits apart on average keeps the position of EVERY argument
+    // (S + 1 entries, quantised like the samples).  lmask: one bit per interval; lidx: which long interval it is.
+    // nullptr when the vector has no such interval (then the kernels do not even look).
+    const uint32_t * lmask[2];
+    const uint32_t * lidx[2];
+    const uint32_t * lpos[2];
 };
+constexpr uint64_t kSelLongGap = 512;
+
+// samples of the interval of argument k, refined to the argument itself where the interval is a long one
+struct SelSamples
+{
+    uint32_t s0, s1;
+    bool fine; // s0 / s1 bracket the k-th argument itself
+};
+template <int BIT>
+__device__ __forceinline__ SelSamples sel_samples(const BvView & bv, uint64_t k)
+{
+    const uint64_t j = k >> bv.sel_shift;
+    SelSamples r;
+    r.fine = false;
+    if (bv.lmask[BIT] && ((bv.lmask[BIT][j >> 5] >> (j & 31)) & 1u))
+    {
+        const uint64_t base = (uint64_t)bv.lidx[BIT][j] * ((UINT64_C(1) << bv.sel_shift) + 1) + (k & ((UINT64_C(1) << bv.sel_shift) - 1));
+        r.s0 = bv.lpos[BIT][base];
+        r.s1 = bv.lpos[BIT][base + 1];
+        r.fine = true;
+        return r;
+    }
+    r.s0 = bv.sel[BIT][j];
+    r.s1 = bv.sel[BIT][j + 1];
+    return r;
+}
 
 struct Pair
 {
@@ -241,19 +274,24 @@ struct SelBracket
 };
 
 template <int BIT>
-__device__ __forceinline__ SelBracket sel_bracket(const BvView & bv, uint64_t k, uint32_t s0, uint32_t s1)
+__device__ __forceinline__ SelBracket sel_bracket(const BvView & bv, uint64_t k, uint32_t s0, uint32_t s1, bool fine = false)
 {
     const uint32_t sh = bv.sel_shift, ps = bv.sel_pshift;
     const uint64_t j = k >> sh;
     const uint64_t total = BIT ? bv.ones : bv.n_bits - bv.ones;
     SelBracket b;
     b.lo_pos = (uint64_t)s0 << ps;
-    b.lo_cnt = j << sh;
+    b.lo_cnt = fine ? k : j << sh;
     b.hi_pos = ((uint64_t)s1 + 1) << ps;
-    b.hi_cnt = (j + 1) << sh;
+    b.hi_cnt = fine ? k + 1 : (j + 1) << sh;
     if (b.hi_cnt > total)
         b.hi_cnt = total;
     return b;
+}
+template <int BIT>
+__device__ __forceinline__ SelBracket sel_bracket(const BvView & bv, uint64_t k, const SelSamples & sm)
+{
+    return sel_bracket<BIT>(bv, k, sm.s0, sm.s1, sm.fine);
 }
 
 // position estimate inside a bracket: lo_pos + (k - lo_cnt) / (hi_cnt - lo_cnt) * span.  Only a probe hint
@@ -374,7 +412,7 @@ template <int BIT, bool NT>
 __device__ __forceinline__ uint64_t quad_select(const BvView & bv, int s, uint64_t k, bool & mine)
 {
     const uint64_t j = k >> bv.sel_shift;
-    SelBracket b = sel_bracket<BIT>(bv, k, bv.sel[BIT][j], bv.sel[BIT][j + 1]);
+    SelBracket b = sel_bracket<BIT>(bv, k, sel_samples<BIT>(bv, k));
     uint64_t pos = 0;
     for (int tries = 0;; ++tries)
     {

@@ -15,12 +15,16 @@ struct BvHost
     DevBuf lines;  // n_lines * 64 B
     DevBuf cnts;   // u32 per line, build-time only
     DevBuf sel[2]; // select sample directories
+    DevBuf lmask[2], lidx[2], lpos[2]; // sparse stretches of the select directories (BvView::lmask ...)
     DevBuf sort_scratch; // working memory of the bucketed batch rank (bv_sorted.hip), grown on demand
     hipEvent_t scratch_ev = nullptr; // recorded behind the last user of sort_scratch
     std::mutex scratch_mutex;
     size_t device_bytes() const
     {
-        return lines.bytes + sel[0].bytes + sel[1].bytes + sort_scratch.bytes;
+        size_t b = lines.bytes + sel[0].bytes + sel[1].bytes + sort_scratch.bytes;
+        for (int i = 0; i < 2; ++i)
+            b += lmask[i].bytes + lidx[i].bytes + lpos[i].bytes;
+        return b;
     }
 };
 

@@ -50,6 +50,32 @@ bool is_device_ptr(const void * p)
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+sdsl_hip_status mailbox_for(int device, Mailbox ** out)
+{
+    static Mailbox boxes[64];
+    static std::mutex init;
+    if (device < 0 || device >= 64)
+        return SDSL_HIP_ERR_INVALID;
+    Mailbox & b = boxes[device];
+    if (!b.host)
+    {
+        std::lock_guard<std::mutex> lock(init);
+        if (!b.host)
+        {
+            SH_HIP(hipSetDevice(device));
+            void * h = nullptr;
+            SH_HIP(hipHostMalloc(&h, 16 * sizeof(uint64_t), hipHostMallocMapped));
+            void * d = nullptr;
+            SH_HIP(hipHostGetDevicePointer(&d, h, 0));
+            SH_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+            b.dev = (uint64_t *)d;
+            b.host = (uint64_t *)h;
+        }
+    }
+    *out = &b;
+    return SDSL_HIP_OK;
+}
+
 sdsl_hip_status check_device(int32_t device)
 {
     int n = 0;

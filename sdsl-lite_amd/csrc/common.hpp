@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -96,6 +97,18 @@ struct Staged
     sdsl_hip_status out(void * p, size_t nbytes);                       // write-only argument
     sdsl_hip_status finish(hipStream_t s);                              // D2H for host outputs
 };
+
+// One query at a time (the scalar operator() of the adaptors): a mapped, pinned mailbox per device — the kernel reads
+// the argument from host memory and writes the answer back into it, so a call costs one launch and one stream
+// synchronisation: no pointer classification, no staging allocation, no copies.  lock() the mailbox for the call.
+struct Mailbox
+{
+    std::mutex m;
+    uint64_t * host = nullptr; // 16 words: [0..8) arguments, [8..16) answers
+    uint64_t * dev = nullptr;  // the same memory as the device sees it
+    hipStream_t stream = nullptr;
+};
+sdsl_hip_status mailbox_for(int device, Mailbox ** out);
 
 // kernel timing hook (sdsl_hip_set_timing / sdsl_hip_last_kernel_ms)
 struct KernelTimer

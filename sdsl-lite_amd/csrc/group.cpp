@@ -435,24 +435,39 @@ sdsl_hip_status sdsl_hip_group_bv_replicate(sdsl_hip_group_t g, sdsl_hip_bv_t ro
             return st;
         }
     }
-    // one broadcast per device buffer of the layout (rank lines, the two select directories)
+    // one broadcast per device buffer of the layout (rank lines, the select directories and their sparse-stretch tables)
+    auto buf_of = [](BvHost & h, int which) -> DevBuf &
+    {
+        switch (which)
+        {
+        case 0: return h.lines;
+        case 1: return h.sel[0];
+        case 2: return h.sel[1];
+        case 3: return h.lmask[0];
+        case 4: return h.lmask[1];
+        case 5: return h.lidx[0];
+        case 6: return h.lidx[1];
+        case 7: return h.lpos[0];
+        default: return h.lpos[1];
+        }
+    };
     auto bcast = [&](int which) -> sdsl_hip_status
     {
-        const DevBuf & b0 = which == 0 ? src.lines : src.sel[which - 1];
+        const DevBuf & b0 = buf_of(src, which);
         if (!b0.p || !b0.bytes)
             return SDSL_HIP_OK;
         SH_NCCL(R->GroupStart());
         for (int r = 0; r < G; ++r)
         {
             BvHost & d = bv_host_of(replicas[r]);
-            DevBuf & br = which == 0 ? d.lines : d.sel[which - 1];
+            DevBuf & br = buf_of(d, which);
             SH_NCCL(R->Broadcast(b0.p, br.p, b0.bytes, ncclUint8, 0, g->comm_a[r], g->s_in[r]));
         }
         SH_NCCL(R->GroupEnd());
         return SDSL_HIP_OK;
     };
     sdsl_hip_status st = SDSL_HIP_OK;
-    for (int which = 0; which < 3 && st == SDSL_HIP_OK; ++which)
+    for (int which = 0; which < 9 && st == SDSL_HIP_OK; ++which)
         st = bcast(which);
     for (int r = 0; r < G; ++r)
     {

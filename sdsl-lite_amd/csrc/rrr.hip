@@ -468,7 +468,7 @@ static uint64_t decode_block_host(const RrrTables & T, unsigned k, uint64_t nr)
     return bits;
 }
 
-// Sampling rates of the two select directories, per bit value: the smallest power of two >= 256 that keeps the
+// Sampling rates of the two select directories, per bit value: the smallest power of two >= 16 that keeps the
 // directory within 2^16 samples (256 KiB: resident in every L2 next to the streaming traffic).  A superblock spans
 // 2016 bits, so even a coarse directory interpolates to the right record or its neighbour; what a denser directory
 // saves in probes it loses in fabric requests for the samples (2^34 bits at 5 % density: select_0 16.0 -> 20.9 Gq/s
@@ -479,7 +479,7 @@ static void rrr_sel_shifts(uint64_t ones, uint64_t zeros, uint32_t shb[2])
     const uint64_t cnt[2] = {zeros, ones};
     for (int b = 0; b < 2; ++b)
     {
-        uint32_t sh = 8;
+        uint32_t sh = 4; // few arguments (sparse vectors): sample densely, the directory stays far below 2^16 entries
         while (sh < 24 && (cnt[b] >> sh) > (UINT64_C(1) << 16))
             ++sh;
         shb[b] = sh;

@@ -337,6 +337,14 @@ class rrr_vector(_Handle):
         capi.check(capi.lib().sdsl_hip_rrr_access_batch(self._h, _ptr(idx), n, _ptr(out), _stream_for(idx)))
         return out
 
+    def get_int(self, idx, length: int = 64, out=None):
+        """rrr_vector::get_int(idx, len) for an array of idx (rrr_vector.hpp:308-356)."""
+        idx = _as_array(idx, np.uint64, "idx")
+        n = idx.numel() if _is_tensor(idx) else idx.size
+        out = _out_for(idx, n, np.uint64, out)
+        capi.check(capi.lib().sdsl_hip_rrr_get_int_batch(self._h, _ptr(idx), length, n, _ptr(out), _stream_for(idx)))
+        return out
+
     def serialize(self) -> bytes:
         """the bytes sdsl::rrr_vector<63>::serialize writes for the same bit vector"""
         return _serialize(capi.lib().sdsl_hip_rrr_serialize, self._h)

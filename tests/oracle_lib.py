@@ -467,6 +467,7 @@ _REF_SIGS = {
     "ref_rrr_rank": (None, [_vp, C.c_int, _vp, _u64, _vp]),
     "ref_rrr_select": (None, [_vp, C.c_int, _vp, _u64, _vp]),
     "ref_rrr_access": (None, [_vp, _vp, _u64, _vp]),
+    "ref_rrr_get_int": (None, [_vp, _vp, C.c_uint32, _u64, _vp]),
     "ref_rrr_serialize": (None, [_vp, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_wt_create": (_vp, [_vp, _u64]),
     "ref_wt_destroy": (None, [_vp]),
@@ -660,6 +661,12 @@ class RRrr:
         i = _u64arr(i)
         out = np.empty(i.size, dtype=np.uint8)
         ref().L.ref_rrr_access(self.h, _p(i), i.size, _p(out))
+        return out
+
+    def get_int(self, i, length):
+        i = _u64arr(i)
+        out = np.empty(i.size, dtype=np.uint64)
+        ref().L.ref_rrr_get_int(self.h, _p(i), length, i.size, _p(out))
         return out
 
     def serialize(self) -> bytes:

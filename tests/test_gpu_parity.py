@@ -146,6 +146,58 @@ def test_rrr_inline_overflow_path(gpu):
     assert np.array_equal(v.select(i, 1), o.select(i, 1))
 
 
+@pytest.mark.parametrize("d", [0.05, 0.5, 0.97])
+def test_rrr_get_int_matches_reference(gpu, d):
+    """rrr_vector::get_int(idx, len) (rrr_vector.hpp:308-356): windows of every length at every alignment to the 63-bit
+    blocks, against the real library when it travelled with the repo and against the plain bits always"""
+    n = 63 * 32 * 7 + 29
+    w = mk(n, d, 11)
+    v = gpu.rrr_vector(w, n)
+    bits = unpack_bits(w, n).astype(np.uint64)
+    rng = np.random.default_rng(3)
+    r = ol.RRrr(w, n) if ol.have_ref() else None
+    for length in (1, 2, 31, 62, 63, 64):
+        idx = np.concatenate([np.arange(0, min(n - length, 300), dtype=np.uint64),
+                              rng.integers(0, n - length + 1, size=4000, dtype=np.uint64),
+                              np.array([n - length], dtype=np.uint64)])
+        want = np.zeros(idx.size, dtype=np.uint64)
+        for k in range(length):
+            want |= bits[idx.astype(np.int64) + k] << np.uint64(k)
+        got = v.get_int(idx, length)
+        assert np.array_equal(got, want), length
+        if r is not None:
+            assert np.array_equal(got, r.get_int(idx, length))
+    assert int(v.get_int(np.array([n - 10], dtype=np.uint64), 11)[0]) == int(NPOS)  # window beyond size()
+    assert int(v.get_int(np.array([n], dtype=np.uint64), 0)[0]) == 0
+
+
+def test_rrr_mixed_inline_and_stream_superblocks(gpu):
+    """superblocks whose offsets fit the record's inline area keep no stream storage, dense ones do: a vector that
+    alternates between the two, queried everywhere, serialised back to SDSL's bytes, loaded again from them"""
+    nsb = 40
+    n = 63 * 32 * nsb + 5
+    rng = np.random.default_rng(8)
+    bits = np.zeros(n, dtype=np.uint8)
+    for s in range(nsb):
+        lo, hi = s * 2016, min(n, (s + 1) * 2016)
+        p = (0.03, 0.5, 0.08, 0.97)[s % 4]
+        bits[lo:hi] = rng.random(hi - lo) < p
+    w = np.packbits(np.concatenate([bits, np.zeros((-n) % 64, dtype=np.uint8)]), bitorder="little").view(np.uint64)
+    o = ol.ORrr(w, n)
+    v = gpu.rrr_vector(w, n)
+    idx = np.arange(n + 1, dtype=np.uint64)
+    assert np.array_equal(v.rank(idx, 1), o.rank(idx, 1))
+    tot = v.ones()
+    assert np.array_equal(v.select(np.arange(1, tot + 1, dtype=np.uint64), 1), o.select(np.arange(1, tot + 1, dtype=np.uint64), 1))
+    assert np.array_equal(v.access(idx[:-1]), bits)
+    blob = v.serialize()
+    assert blob == o.serialize()
+    v2 = gpu.rrr_vector(sdsl_bytes=blob)
+    assert np.array_equal(v2.rank(idx, 0), o.rank(idx, 0))
+    assert v2.serialize() == blob
+    assert v.device_bytes() == v2.device_bytes()
+
+
 # ---------------------------------------------------------------------------------------------------
 # wt_huff
 # ---------------------------------------------------------------------------------------------------
