@@ -135,6 +135,16 @@ sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bi
 #define SDSL_HIP_SER_SELECT_MCL_0 4
 #define SDSL_HIP_SER_RANK_V_1 5
 #define SDSL_HIP_SER_RANK_V_0 6
+/* Sibling representations of bit_vectors.hpp, handed over as the bytes of their own serialize() and decoded to plain
+ * bits on the device (their rank / select answers are those of the plain vector): kind SDSL_HIP_SIBLING_IL =
+ * bit_vector_il<t_bs> (bit_vector_il.hpp:212-224; any block size), SDSL_HIP_SIBLING_RRR15 / SDSL_HIP_SIBLING_RRR(t_bs, t_k)
+ * = rrr_vector<...> (rrr_vector_15.hpp:409-420; rrr_vector.hpp:366-378).  flags as sdsl_hip_bv_create. */
+#define SDSL_HIP_SIBLING_IL 0
+#define SDSL_HIP_SIBLING_RRR15 1 /* the rrr_vector<15> SPECIALISATION (only with #include <sdsl/rrr_vector_15.hpp>) */
+/* the generic rrr_vector<t_bs, int_vector<>, t_k>, 2 <= t_bs <= 63 (what rrr_vector<15> is without that include) */
+#define SDSL_HIP_SIBLING_RRR(t_bs, t_k) (2 | ((int32_t)(t_bs) << 8) | ((int32_t)(t_k) << 16))
+sdsl_hip_status sdsl_hip_bv_create_from_sdsl(const void * bytes, size_t len, int32_t kind, int32_t device, uint32_t flags,
+                                             sdsl_hip_bv_t * out);
 sdsl_hip_status sdsl_hip_bv_serialize(sdsl_hip_bv_t bv, int32_t what, void * buf, size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv);
 /* ONE query, value in, value out: what = 0 rank_<bit>(arg), 1 select_<bit>(arg).  This is what the scalar operator() of

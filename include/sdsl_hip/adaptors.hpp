@@ -25,6 +25,8 @@
 #include <vector>
 
 #include <sdsl/bit_vectors.hpp>
+#include <type_traits>
+
 #include <sdsl/suffix_arrays.hpp>
 #include <sdsl/wavelet_trees.hpp>
 
@@ -281,90 +283,177 @@ public:
     }
 };
 
-//! rank_support_il<t_b, t_bs> / select_support_il<t_b, t_bs> look-alikes (bit_vector_il.hpp:303-317,  :398-460) over a
-//! bit_vector_il<t_bs>: the interleaving is a host cache layout (the device's rank lines are its counterpart), so the
-//! vector travels as its plain bits and the supports answer from rank lines.
-template <uint8_t t_b = 1, uint32_t t_bs = 512>
-class rank_support_il_hip
+namespace hip_detail
 {
-    bit_vector m_bits;
-    rank_support_v5_hip<t_b> m_rs;
+//! the plain bits of a bit_vector_il<> / rrr_vector<15> on the device: the object's own serialised bytes are decoded there
+template <class t_bv>
+inline bv_ptr make_device_bv_from_sibling(t_bv const & v, int32_t kind, int device, uint32_t flags)
+{
+    std::string s = to_stream(v);
+    sdsl_hip_bv_t h = nullptr;
+    check(sdsl_hip_bv_create_from_sdsl(s.data(), s.size(), kind, device, flags, &h), "sdsl_hip_bv_create_from_sdsl");
+    return bv_ptr(h, bv_deleter());
+}
+//! rank over device bits that came from some other representation
+template <uint8_t t_b>
+class device_bits_rank
+{
+protected:
+    bv_ptr m_dev;
+    uint64_t m_size = 0;
+    int m_device = 0;
 
 public:
-    typedef bit_vector_il<t_bs> bit_vector_type;
     typedef bit_vector::size_type size_type;
-    explicit rank_support_il_hip(bit_vector_type const * v = nullptr, int device = 0) : m_rs(nullptr, device)
-    {
-        set_vector(v);
-    }
-    rank_support_il_hip(rank_support_il_hip const & o) : m_bits(o.m_bits), m_rs(o.m_rs)
-    {
-        if (!m_bits.empty())
-            m_rs.set_vector(&m_bits);
-    }
-    rank_support_il_hip & operator=(rank_support_il_hip const &) = delete;
-    void set_vector(bit_vector_type const * v = nullptr)
-    {
-        m_bits = v ? to_bit_vector(*v) : bit_vector();
-        m_rs.set_vector(v ? &m_bits : nullptr);
-    }
     size_type rank(size_type i) const
     {
-        return m_rs.rank(i);
+        uint64_t r = 0;
+        check(sdsl_hip_bv_query_one(m_dev.get(), 0, t_b, i, &r), "sdsl_hip_bv_query_one");
+        return r;
     }
     size_type operator()(size_type i) const
     {
-        return m_rs.rank(i);
+        return rank(i);
     }
     void rank_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
     {
-        m_rs.rank_batch(i, n, out, stream);
+        check(sdsl_hip_bv_rank_batch(m_dev.get(), t_b, i, n, out, stream), "sdsl_hip_bv_rank_batch");
     }
     size_type size() const
     {
-        return m_bits.size();
+        return m_size;
+    }
+};
+template <uint8_t t_b>
+class device_bits_select
+{
+protected:
+    bv_ptr m_dev;
+    uint64_t m_size = 0;
+    int m_device = 0;
+
+public:
+    typedef bit_vector::size_type size_type;
+    size_type select(size_type i) const
+    {
+        uint64_t r = 0;
+        check(sdsl_hip_bv_query_one(m_dev.get(), 1, t_b, i, &r), "sdsl_hip_bv_query_one");
+        return r;
+    }
+    size_type operator()(size_type i) const
+    {
+        return select(i);
+    }
+    void select_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    {
+        check(sdsl_hip_bv_select_batch(m_dev.get(), t_b, i, n, out, stream), "sdsl_hip_bv_select_batch");
+    }
+    size_type size() const
+    {
+        return m_size;
+    }
+};
+} // namespace hip_detail
+
+//! rank_support_il<t_b, t_bs> / select_support_il<t_b, t_bs> look-alikes (bit_vector_il.hpp:303-317,  :398-460) over a
+//! bit_vector_il<t_bs>: the interleaving is a host cache layout (the device's rank lines are its counterpart); the
+//! vector's serialised bytes are de-interleaved on the device and the supports answer from rank lines.
+template <uint8_t t_b = 1, uint32_t t_bs = 512>
+class rank_support_il_hip : public hip_detail::device_bits_rank<t_b>
+{
+public:
+    typedef bit_vector_il<t_bs> bit_vector_type;
+    explicit rank_support_il_hip(bit_vector_type const * v = nullptr, int device = 0)
+    {
+        this->m_device = device;
+        set_vector(v);
+    }
+    void set_vector(bit_vector_type const * v = nullptr)
+    {
+        this->m_size = v ? v->size() : 0;
+        this->m_dev = v ? hip_detail::make_device_bv_from_sibling(*v, SDSL_HIP_SIBLING_IL, this->m_device, 0) : hip_detail::bv_ptr();
     }
 };
 
 template <uint8_t t_b = 1, uint32_t t_bs = 512>
-class select_support_il_hip
+class select_support_il_hip : public hip_detail::device_bits_select<t_b>
 {
-    bit_vector m_bits;
-    select_support_mcl_hip<t_b> m_ss;
-
 public:
     typedef bit_vector_il<t_bs> bit_vector_type;
-    typedef bit_vector::size_type size_type;
-    explicit select_support_il_hip(bit_vector_type const * v = nullptr, int device = 0) : m_ss(nullptr, device)
+    explicit select_support_il_hip(bit_vector_type const * v = nullptr, int device = 0)
     {
+        this->m_device = device;
         set_vector(v);
     }
-    select_support_il_hip(select_support_il_hip const & o) : m_bits(o.m_bits), m_ss(o.m_ss)
-    {
-        if (!m_bits.empty())
-            m_ss.set_vector(&m_bits);
-    }
-    select_support_il_hip & operator=(select_support_il_hip const &) = delete;
     void set_vector(bit_vector_type const * v = nullptr)
     {
-        m_bits = v ? to_bit_vector(*v) : bit_vector();
-        m_ss.set_vector(v ? &m_bits : nullptr);
+        this->m_size = v ? v->size() : 0;
+        this->m_dev = v ? hip_detail::make_device_bv_from_sibling(*v, SDSL_HIP_SIBLING_IL, this->m_device,
+                                                                  t_b ? SDSL_HIP_BV_SELECT1 : SDSL_HIP_BV_SELECT0)
+                        : hip_detail::bv_ptr();
     }
-    size_type select(size_type i) const
+};
+
+namespace hip_detail
+{
+//! which stream format an rrr_vector<t_bs, t_rac, t_k> type writes: the generic template's (rrr_vector.hpp:366-378) or,
+//! when the translation unit includes <sdsl/rrr_vector_15.hpp>, the rrr_vector<15> specialisation's (no invert vector)
+template <class T, class = void>
+struct is_rrr15_spec : std::false_type
+{};
+template <class T>
+struct is_rrr15_spec<T, std::void_t<typename T::bi_type>> : std::true_type
+{};
+template <class T>
+struct rrr_params;
+template <uint16_t t_bs, class t_rac, uint16_t t_k>
+struct rrr_params<rrr_vector<t_bs, t_rac, t_k>>
+{
+    static constexpr int32_t kind()
     {
-        return m_ss.select(i);
+        return is_rrr15_spec<rrr_vector<t_bs, t_rac, t_k>>::value ? SDSL_HIP_SIBLING_RRR15 : SDSL_HIP_SIBLING_RRR(t_bs, t_k);
     }
-    size_type operator()(size_type i) const
+    static_assert(t_bs >= 2 and t_bs <= 63, "rrr_vector blocks of 2..63 bits are decoded on the device");
+};
+} // namespace hip_detail
+
+//! rank_support_rrr<t_b, t_bs, ...> / select_support_rrr<t_b, t_bs, ...> look-alikes over an rrr_vector<t_bs, t_rac, t_k>
+//! with 2 <= t_bs <= 63 (rrr_vector<15>, <31>, ...; for <63> prefer rrr_vector_hip, which keeps the vector compressed): its
+//! classes and offsets are decoded to plain bits on the device and the supports answer from rank lines.
+template <uint8_t t_b, class t_rrr>
+class rank_support_rrr_bits_hip : public hip_detail::device_bits_rank<t_b>
+{
+public:
+    typedef t_rrr bit_vector_type;
+    explicit rank_support_rrr_bits_hip(bit_vector_type const * v = nullptr, int device = 0)
     {
-        return m_ss.select(i);
+        this->m_device = device;
+        set_vector(v);
     }
-    void select_batch(size_type const * i, size_t n, size_type * out, void * stream = nullptr) const
+    void set_vector(bit_vector_type const * v = nullptr)
     {
-        m_ss.select_batch(i, n, out, stream);
+        this->m_size = v ? v->size() : 0;
+        this->m_dev = v ? hip_detail::make_device_bv_from_sibling(*v, hip_detail::rrr_params<t_rrr>::kind(), this->m_device, 0)
+                        : hip_detail::bv_ptr();
     }
-    size_type size() const
+};
+
+template <uint8_t t_b, class t_rrr>
+class select_support_rrr_bits_hip : public hip_detail::device_bits_select<t_b>
+{
+public:
+    typedef t_rrr bit_vector_type;
+    explicit select_support_rrr_bits_hip(bit_vector_type const * v = nullptr, int device = 0)
     {
-        return m_bits.size();
+        this->m_device = device;
+        set_vector(v);
+    }
+    void set_vector(bit_vector_type const * v = nullptr)
+    {
+        this->m_size = v ? v->size() : 0;
+        this->m_dev = v ? hip_detail::make_device_bv_from_sibling(*v, hip_detail::rrr_params<t_rrr>::kind(), this->m_device,
+                                                                  t_b ? SDSL_HIP_BV_SELECT1 : SDSL_HIP_BV_SELECT0)
+                        : hip_detail::bv_ptr();
     }
 };
 
@@ -423,6 +512,17 @@ public:
     void access_batch(size_type const * i, size_t n, uint8_t * out, void * stream = nullptr) const
     {
         hip_detail::check(sdsl_hip_rrr_access_batch(m_dev.get(), i, n, out, stream), "sdsl_hip_rrr_access_batch");
+    }
+    //! out[q] = get_int(idx[q], len)   (rrr_vector.hpp:308-356)
+    void get_int_batch(size_type const * idx, uint8_t len, size_t n, uint64_t * out, void * stream = nullptr) const
+    {
+        hip_detail::check(sdsl_hip_rrr_get_int_batch(m_dev.get(), idx, len, n, out, stream), "sdsl_hip_rrr_get_int_batch");
+    }
+    uint64_t get_int(size_type idx, uint8_t len = 64) const
+    {
+        uint64_t r = 0;
+        get_int_batch(&idx, len, 1, &r);
+        return r;
     }
     bool operator[](size_type i) const
     {

@@ -15,6 +15,8 @@ using namespace sdsl;
 static int g_fail = 0;
 #define CHECK(cond, what)                                                                                          \
     do {                                                                                                           \
+        if (getenv("PARITY_TRACE"))                                                                                \
+            fprintf(stderr, "[parity] %s (line %d)\n", what, __LINE__);                                            \
         if (!(cond))                                                                                               \
         {                                                                                                          \
             ++g_fail;                                                                                              \
@@ -76,6 +78,7 @@ static void check_select(bit_vector const & bv, uint64_t args, std::mt19937_64 &
 
 int main(int argc, char ** argv)
 {
+    setvbuf(stderr, nullptr, _IONBF, 0);
     std::mt19937_64 rng(4242);
     for (uint64_t n : {1000ull, 100000ull, 1000003ull})
         for (int dens : {50, 3, 97})
@@ -148,6 +151,24 @@ int main(int argc, char ** argv)
                     }
                 }
                 CHECK(ok2, "rank_support_il_hip / select_support_il_hip / rrr_vector_hip(rrr_vector<15>)");
+                // rrr_vector<15> decoded on the device (no host conversion), batch members included
+                rank_support_rrr_bits_hip<1, rrr_vector<15>> r15dev(&r15);
+                select_support_rrr_bits_hip<1, rrr_vector<15>> s15dev(&r15);
+                rrr_vector<15>::rank_1_type r15r1(&r15);
+                std::vector<uint64_t> qq(500), oo(500);
+                for (auto & x : qq)
+                    x = rng() % (n + 1);
+                r15dev.rank_batch(qq.data(), qq.size(), oo.data());
+                bool ok3 = r15dev.size() == n;
+                for (size_t t = 0; t < qq.size(); ++t)
+                    ok3 &= oo[t] == r15r1(qq[t]);
+                if (ones)
+                    for (int t = 0; t < 100; ++t)
+                    {
+                        uint64_t k = 1 + rng() % ones;
+                        ok3 &= s15dev(k) == r15s(k);
+                    }
+                CHECK(ok3, "rank_support_rrr_bits_hip / select_support_rrr_bits_hip (device decode of rrr_vector<15>)");
             }
             // sd_vector<>
             {

@@ -682,6 +682,29 @@ void ref_density_bits(uint64_t * words, uint64_t n_bits, uint64_t seed, uint32_t
     }
 }
 
+// the serialised bytes of the sibling representations of bit_vectors.hpp over the same bits (in THIS translation unit
+// rrr_vector<15> is the generic template; the specialisation lives in sdsl_ref_r15.cpp)
+void ref_sibling_serialize(const uint64_t * words, uint64_t n_bits, int kind, uint8_t ** out, uint64_t * len)
+{
+    bit_vector bv(n_bits, 0);
+    if (n_bits)
+        memcpy(bv.data(), words, ((n_bits + 63) >> 6) * 8);
+    if (n_bits & 63)
+        bv.data()[n_bits >> 6] &= bits::lo_set[n_bits & 63]; // these constructors read whole words
+    if (kind == 0)
+        to_bytes(bit_vector_il<512>(bv), out, len);
+    else if (kind == 1)
+        to_bytes(rrr_vector<15>(bv), out, len);
+    else if (kind == 2)
+        to_bytes(bit_vector_il<64>(bv), out, len);
+    else if (kind == 3)
+        to_bytes(rrr_vector<15, int_vector<>, 8>(bv), out, len);
+    else if (kind == 4)
+        to_bytes(rrr_vector<31>(bv), out, len);
+    else
+        to_bytes(rrr_vector<62, int_vector<>, 16>(bv), out, len);
+}
+
 uint32_t ref_bits_sel(uint64_t x, uint32_t i)
 {
     return bits::sel(x, i);

@@ -23,6 +23,12 @@ WT_RRR63 = 1
 WT_BLCD = 2
 WT_HUTU = 4
 LAYOUT_BV_SCAN, LAYOUT_BV_MCL, LAYOUT_RRR63, LAYOUT_BV_DEFAULT = 0, 1, 2, 3
+SIBLING_IL, SIBLING_RRR15 = 0, 1
+
+
+def SIBLING_RRR(t_bs: int, t_k: int = 32) -> int:
+    """generic rrr_vector<t_bs, int_vector<>, t_k> (SDSL_HIP_SIBLING_RRR)"""
+    return 2 | (t_bs << 8) | (t_k << 16)
 
 _u64p = C.POINTER(C.c_uint64)
 _u8p = C.POINTER(C.c_uint8)
@@ -54,6 +60,7 @@ SIGNATURES = {
     "sdsl_hip_group_fm_create_from_text": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.POINTER(_vp)]),
     "sdsl_hip_group_fm_count_batch": (C.c_int32, [_vp, C.POINTER(_vp), _vp, C.c_uint32, C.c_uint64, _vp, C.c_int32]),
     "sdsl_hip_bv_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
+    "sdsl_hip_bv_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "sdsl_hip_bv_create_pattern": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.POINTER(_vp)]),
     "sdsl_hip_bv_serialize": (C.c_int32, [_vp, C.c_int32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -954,6 +954,39 @@ sdsl_hip_status sdsl_hip_bv_create(const uint64_t * words, uint64_t n_bits, int3
     return guarded("bv_create", [&] { return sdsl_hip_bv_create_impl(words, n_bits, device, flags, out); });
 }
 
+static sdsl_hip_status sdsl_hip_bv_create_from_sdsl_impl(const void * bytes, size_t len, int32_t kind, int32_t device, uint32_t flags,
+                                             sdsl_hip_bv_t * out)
+{
+    if (!out || !bytes)
+    {
+        set_error("bv_create_from_sdsl: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    DevBuf d_words;
+    uint64_t n_bits = 0;
+    SH_TRY(compressed_stream_to_device_words(bytes, len, kind, d_words, n_bits));
+    sdsl_hip_bv_s * bv = new (std::nothrow) sdsl_hip_bv_s();
+    if (!bv)
+        return SDSL_HIP_ERR_NOMEM;
+    bv->h.device = device;
+    sdsl_hip_status st = bv_build_from_device_words(bv->h, d_words.as<uint64_t>(), n_bits, flags, default_sel_shift());
+    if (st != SDSL_HIP_OK)
+    {
+        delete bv;
+        return st;
+    }
+    *out = bv;
+    return SDSL_HIP_OK;
+}
+// no exception crosses the C ABI: a malformed stream or an exhausted host becomes a status code
+sdsl_hip_status sdsl_hip_bv_create_from_sdsl(const void * bytes, size_t len, int32_t kind, int32_t device, uint32_t flags,
+                                             sdsl_hip_bv_t * out)
+{
+    return guarded("bv_create_from_sdsl", [&] { return sdsl_hip_bv_create_from_sdsl_impl(bytes, len, kind, device, flags, out); });
+}
+
 static sdsl_hip_status sdsl_hip_bv_create_pattern_impl(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t t_b,
                                            uint32_t t_pat_len, uint32_t flags, sdsl_hip_bv_t * out)
 {

@@ -33,6 +33,7 @@ sdsl_hip_status device_exclusive_scan_u32(const uint32_t * d_in, uint64_t n, uin
                                           uint64_t * total);
 sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words, uint64_t n_bits, uint32_t flags,
                                            uint32_t sel_shift);
+sdsl_hip_status compressed_stream_to_device_words(const void * bytes, size_t len, int kind, DevBuf & d_words, uint64_t & n_bits);
 sdsl_hip_status bv_export_words_device(const BvView & v, uint64_t * d_words, uint64_t n_words, hipStream_t s);
 sdsl_hip_status bv_launch_rank(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                                hipStream_t s);

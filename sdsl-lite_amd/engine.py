@@ -97,11 +97,20 @@ class bit_vector(_Handle):
     """
     _destroy = "sdsl_hip_bv_destroy"
 
-    def __init__(self, words, n_bits: int | None = None, device: int = 0, select1: bool = True,
-                 select0: bool = True, pattern: tuple[int, int] | None = None):
+    def __init__(self, words=None, n_bits: int | None = None, device: int = 0, select1: bool = True,
+                 select0: bool = True, pattern: tuple[int, int] | None = None, sdsl_bytes: bytes | None = None,
+                 kind: int | None = None):
         """pattern=(t_b, t_pat_len) as in SDSL's templates, e.g. (10, 2): the handle then holds the occurrence vector
-        of that two-bit pattern, and rank(idx, 1) / select(i, 1) answer rank_support_v5<10,2> / select_support_mcl<10,2>"""
+        of that two-bit pattern, and rank(idx, 1) / select(i, 1) answer rank_support_v5<10,2> / select_support_mcl<10,2>.
+        sdsl_bytes + kind (capi.SIBLING_IL / capi.SIBLING_RRR15): the serialised bytes of a bit_vector_il<> /
+        rrr_vector<15>, decoded to plain bits on the device."""
         super().__init__()
+        if sdsl_bytes is not None:
+            buf = np.frombuffer(sdsl_bytes, dtype=np.uint8)
+            flags = (capi.BV_SELECT1 if select1 else 0) | (capi.BV_SELECT0 if select0 else 0)
+            capi.check(capi.lib().sdsl_hip_bv_create_from_sdsl(_ptr(buf), buf.size, kind, device, flags, C.byref(self._h)))
+            self.device = device
+            return
         w = _as_array(words, np.uint64, "words")
         nw = w.numel() if _is_tensor(w) else w.size
         if n_bits is None:

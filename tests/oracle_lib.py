@@ -510,6 +510,7 @@ _REF_SIGS = {
     "ref_csa_blcd_serialize": (C.c_int, [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_set_random_bits": (None, [_vp, _u64, C.c_int]),
     "ref_density_bits": (None, [_vp, _u64, _u64, C.c_uint32]),
+    "ref_sibling_serialize": (None, [_vp, _u64, C.c_int, C.POINTER(_vp), C.POINTER(_u64)]),
     "ref_bits_sel": (_u32, [_u64, _u32]),
     "ref_bits_hi": (_u32, [_u64]),
 }
@@ -559,6 +560,24 @@ def pattern_bits(bits: np.ndarray, pat: int) -> np.ndarray:
     prev = np.concatenate([[1 if pat in (1, 2) else 0], x[:-1]]).astype(np.uint8) if x.size else x
     want_prev, want_cur = [(1, 0), (0, 1), (0, 0), (1, 1)][pat]
     return ((prev == want_prev) & (x == want_cur)).astype(np.uint8)
+
+
+_ref_r15 = None
+
+
+def ref_sibling_bytes(words, n_bits: int, kind: int) -> bytes:
+    """serialize() of bit_vector_il<512> (0), generic rrr_vector<15> (1), bit_vector_il<64> (2), generic
+    rrr_vector<15, int_vector<>, 8> (3), rrr_vector<31> (4), rrr_vector<62, int_vector<>, 16> (5), and the rrr_vector<15>
+    specialisation of rrr_vector_15.hpp (6)"""
+    w = padded(words, n_bits)
+    if kind == 6:  # a library of its own: the specialisation and the generic template cannot share one shared object
+        global _ref_r15
+        if _ref_r15 is None:
+            _ref_r15 = C.CDLL(os.path.join(os.path.dirname(REF_SO), "libsdsl_ref_r15.so"), mode=os.RTLD_LOCAL)
+            _ref_r15.ref_rrr15_spec_serialize.restype = None
+            _ref_r15.ref_rrr15_spec_serialize.argtypes = [_vp, _u64, C.POINTER(_vp), C.POINTER(_u64)]
+        return _ref_bytes(_ref_r15.ref_rrr15_spec_serialize, _p(w), n_bits)
+    return _ref_bytes(ref().L.ref_sibling_serialize, _p(w), n_bits, kind)
 
 
 def ref_wt_default_bytes(text: bytes) -> bytes:

@@ -43,12 +43,26 @@ SCRIPT = textwrap.dedent('''
 
 
 def test_replicate_and_sharded_query_over_rccl(gpu, tmp_path):
+    import signal
     import torch
     script = tmp_path / "nccl_path.py"
     script.write_text(SCRIPT)
     ranks = max(1, torch.cuda.device_count())
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
-                       capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    assert "NCCL_PATH_OK" in r.stdout
+    # one node, no network: RCCL's bootstrap gets the loop-back interface by name; output goes to files and the whole
+    # process group is killed on a time-out (a hung worker must not hang the test run through an inherited pipe)
+    env = dict(os.environ, OMP_NUM_THREADS="1", NCCL_SOCKET_IFNAME="lo", GLOO_SOCKET_IFNAME="lo", NCCL_DEBUG="WARN",
+               TORCH_NCCL_ASYNC_ERROR_HANDLING="1")
+    out, err = tmp_path / "out.txt", tmp_path / "err.txt"
+    with open(out, "w") as fo, open(err, "w") as fe:
+        p = subprocess.Popen([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                              "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                             stdout=fo, stderr=fe, env=env, start_new_session=True)
+        try:
+            rc = p.wait(timeout=300)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            p.wait()
+            rc = -9
+    so, se = out.read_text(), err.read_text()
+    assert rc == 0, (rc, so[-1500:], se[-3000:])
+    assert "NCCL_PATH_OK" in so

@@ -146,6 +146,34 @@ def test_rrr_inline_overflow_path(gpu):
     assert np.array_equal(v.select(i, 1), o.select(i, 1))
 
 
+@pytest.mark.parametrize("n", [0, 1, 14, 15, 16, 63, 64, 479, 480, 481, 959, 960, 961, 100_003, 3_000_001])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6])
+def test_sibling_streams_are_decoded_on_the_device(gpu, n, kind):
+    """bit_vector_il<512 / 64>, the generic rrr_vector<15 / 31 / 62> and the rrr_vector<15> specialisation built by the REAL
+    library, handed over as their serialised bytes: the device turns them back into the plain bits (exported words equal) and
+    answers rank / select on them.  Densities include 0.97: full superblocks of the generic template are stored inverted."""
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not present")
+    w = mk(n, (0.5, 0.03, 0.97, 0.3)[(n + kind) % 4], n + 7)
+    blob = ol.ref_sibling_bytes(w, n, kind)
+    K = gpu.capi
+    ck = {0: K.SIBLING_IL, 2: K.SIBLING_IL, 1: K.SIBLING_RRR(15, 32), 3: K.SIBLING_RRR(15, 8), 4: K.SIBLING_RRR(31, 32),
+          5: K.SIBLING_RRR(62, 16), 6: K.SIBLING_RRR15}[kind]
+    bv = gpu.bit_vector(sdsl_bytes=blob, kind=ck)
+    assert bv.size() == n
+    plain = gpu.bit_vector(w, n)
+    assert np.array_equal(bv.export_words(), plain.export_words())
+    if n:
+        idx = np.random.default_rng(n).integers(0, n + 1, size=20_000, dtype=np.uint64)
+        assert np.array_equal(bv.rank(idx, 1), plain.rank(idx, 1))
+        if plain.ones():
+            i = np.random.default_rng(n + 1).integers(1, plain.ones() + 1, size=20_000, dtype=np.uint64)
+            assert np.array_equal(bv.select(i, 1), plain.select(i, 1))
+        with pytest.raises(gpu.capi.SdslHipError) as e:
+            gpu.bit_vector(sdsl_bytes=blob[: len(blob) // 2], kind=ck)
+        assert e.value.status == gpu.capi.ERR_FORMAT
+
+
 @pytest.mark.parametrize("d", [0.05, 0.5, 0.97])
 def test_rrr_get_int_matches_reference(gpu, d):
     """rrr_vector::get_int(idx, len) (rrr_vector.hpp:308-356): windows of every length at every alignment to the 63-bit
