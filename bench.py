@@ -392,6 +392,14 @@ def main():
                               "roofline_frac": ALG_BYTES["select"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             if a.log_n == G.get("c2", {}).get("log_n") and nq >= G["c2"]["select_1"]["n"]:
                 ex["select_1"]["reference_digest_match"] = digest_matches(out, G["c2"]["select_1"])
+            # the default above is the bucketed path for a batch of this size; the direct kernel beside it
+            pkg.set_option("select_sorted", 0)
+            out_d = torch.empty_like(out)
+            _, ms_d = time_steps(lambda: bv.select(si, 1, out_d), max(2, a.steps // 2), 1, barrier)
+            pkg.set_option("select_sorted", -1)
+            ex["select_1"]["direct_kernel"] = {"Gq/s": nq / ms_d / 1e6, "kernel_ms": ms_d, "same_answers": bool(torch.equal(out, out_d)),
+                                               "roofline_frac": ALG_BYTES["select"] * nq / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del out_d
             pos = out[: 1 << 20].clone()
             assert bool((bv.rank(pos, 1) == si[: 1 << 20] - 1).all()), "select/rank round trip failed"
             if rank == 0 and world == 1 and not a.no_cpu:

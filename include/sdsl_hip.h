@@ -423,7 +423,10 @@ sdsl_hip_status sdsl_hip_set_timing(int32_t enabled);
  * kernel (one rank line per query), 1 = the bucketed path whenever the vector allows it (bv_sorted.hip: the batch is
  * partitioned by index slice, slices are staged in LDS; 13 bytes of device scratch per query, kept with the handle),
  * -1 = automatic (bucketed when the batch addresses every line of a vector larger than the caches several times).
- * Answers are identical in every mode.  Initial value: environment variable SDSL_HIP_RANK_SORTED, else -1. */
+ * Answers are identical in every mode.  Initial value: environment variable SDSL_HIP_RANK_SORTED, else -1.
+ * "select_sorted": the same for sdsl_hip_bv_select_batch (buckets of consecutive argument ranks, their lines staged in LDS;
+ * automatic only for vectors without long sparse stretches: those are answered by a slow fix-up pass).  Initial value:
+ * SDSL_HIP_SELECT_SORTED, else -1. */
 sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value);
 /* "trace_phases" (0/1): the bucketed batch rank times each of its passes with HIP events on the launch stream (one host
  * synchronisation per call) and sdsl_hip_last_phases returns them as "hist1=ms;offs1=ms;part1=ms;..." */

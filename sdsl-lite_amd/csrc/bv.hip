@@ -849,6 +849,46 @@ sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, ui
     return bv_launch_rank(h.view, bit, d_idx, n, d_out, s);
 }
 
+// select: the same choice (option "select_sorted", initial value SDSL_HIP_SELECT_SORTED)
+sdsl_hip_status bv_select_dispatch(BvHost & h, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out, hipStream_t s)
+{
+    const int mode = g_select_sorted_mode.load();
+    if (mode != 0 && n > 0 && h.view.sel[bit] && (mode > 0 || (h.view.n_lines >= (UINT64_C(1) << 22) && n >= 2 * h.view.n_lines)))
+    {
+        std::lock_guard<std::mutex> lock(h.scratch_mutex);
+        SH_TRY(bv_select_sorted_prepare(h, bit)); // first use: the bucket boundaries (one small batch, synchronous)
+        const bool want = mode > 0 ? h.sel_plan[bit].ok : bv_sorted_select_applicable(h, bit, n);
+        if (want)
+        {
+            const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
+            const size_t need = bv_sorted_rank_scratch_bytes(h.view, pass);
+            if (h.scratch_ev)
+                SH_HIP(hipStreamWaitEvent(s, h.scratch_ev, 0));
+            bool have = h.sort_scratch.bytes >= need;
+            if (!have)
+            {
+                if (h.scratch_ev)
+                    SH_HIP(hipEventSynchronize(h.scratch_ev));
+                h.sort_scratch.release();
+                have = h.sort_scratch.alloc(need) == SDSL_HIP_OK;
+            }
+            if (have)
+            {
+                if (!h.scratch_ev)
+                    SH_HIP(hipEventCreateWithFlags(&h.scratch_ev, hipEventDisableTiming));
+                sdsl_hip_status st;
+                {
+                    KernelTimer t(s);
+                    st = bv_launch_select_sorted(h, bit, d_i, n, d_out, s, h.sort_scratch.p, h.sort_scratch.bytes);
+                }
+                SH_HIP(hipEventRecord(h.scratch_ev, s));
+                return st;
+            }
+        }
+    }
+    return bv_launch_select(h.view, bit, d_i, n, d_out, s);
+}
+
 uint32_t default_sel_shift()
 {
     uint32_t sh = 0; // 0 = automatic: smallest rate >= 512 that keeps a directory within 2^21 samples
@@ -1177,7 +1217,7 @@ sdsl_hip_status sdsl_hip_bv_query_one(sdsl_hip_bv_t bv, int32_t what, int32_t bi
     std::lock_guard<std::mutex> lock(mb->m);
     SH_HIP(hipSetDevice(bv->h.device));
     mb->host[0] = arg;
-    suppress_timing_in_this_thread();
+    TimingPause pause;
     if (what == 0)
         SH_TRY(bv_launch_rank(bv->h.view, bit, mb->dev, 1, mb->dev + 8, mb->stream));
     else
@@ -1226,7 +1266,7 @@ sdsl_hip_status sdsl_hip_bv_select_batch(sdsl_hip_bv_t bv, int32_t bit, const ui
     Staged in, o;
     SH_TRY(in.in(i, n * 8, s));
     SH_TRY(o.out(out, n * 8));
-    SH_TRY(bv_launch_select(bv->h.view, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s));
+    SH_TRY(bv_select_dispatch(bv->h, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s));
     SH_TRY(o.finish(s));
     if (in.host && !o.host)
         SH_HIP(hipStreamSynchronize(s));

@@ -411,7 +411,6 @@ __device__ __forceinline__ uint64_t quad_gather_u64(uint64_t v, bool mine)
 template <int BIT, bool NT>
 __device__ __forceinline__ uint64_t quad_select(const BvView & bv, int s, uint64_t k, bool & mine)
 {
-    const uint64_t j = k >> bv.sel_shift;
     SelBracket b = sel_bracket<BIT>(bv, k, sel_samples<BIT>(bv, k));
     uint64_t pos = 0;
     for (int tries = 0;; ++tries)

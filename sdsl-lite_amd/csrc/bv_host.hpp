@@ -18,12 +18,19 @@ struct BvHost
     DevBuf lmask[2], lidx[2], lpos[2]; // sparse stretches of the select directories (BvView::lmask ...)
     DevBuf sort_scratch; // working memory of the bucketed batch rank (bv_sorted.hip), grown on demand
     hipEvent_t scratch_ev = nullptr; // recorded behind the last user of sort_scratch
+    struct SelPlan // buckets of the bucketed batch select (bv_sorted.hip), built on first use
+    {
+        bool ready = false, ok = false;
+        DevBuf bnd;
+        unsigned r = 0, nf = 0;
+        double wide_frac = 0;
+    } sel_plan[2];
     std::mutex scratch_mutex;
     size_t device_bytes() const
     {
         size_t b = lines.bytes + sel[0].bytes + sel[1].bytes + sort_scratch.bytes;
         for (int i = 0; i < 2; ++i)
-            b += lmask[i].bytes + lidx[i].bytes + lpos[i].bytes;
+            b += lmask[i].bytes + lidx[i].bytes + lpos[i].bytes + sel_plan[i].bnd.bytes;
         return b;
     }
 };
@@ -48,6 +55,10 @@ bool bv_sorted_rank_applicable(const BvView & v, uint64_t n);
 size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n);
 sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                                       hipStream_t s, void * scratch, size_t scratch_bytes);
+sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit);
+bool bv_sorted_select_applicable(const BvHost & h, int bit, uint64_t n);
+sdsl_hip_status bv_launch_select_sorted(BvHost & h, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out, hipStream_t s,
+                                        void * scratch, size_t scratch_bytes);
 sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out,
                                  hipStream_t s);
 

@@ -40,6 +40,8 @@ constexpr unsigned kSliceLog = 10;       // lines per slice (64 KiB)
 constexpr unsigned kOffBits = 9;         // 448 < 2^9 in-line offsets
 constexpr unsigned kKey2Bits = kSliceLog + kOffBits;
 constexpr uint32_t kBad = 0xFFFFFFFFu;   // key / answer of a position beyond the vector (answer NPOS)
+constexpr uint32_t kMark = 0xFFFFFFFEu;  // select: answer left to the fix-up pass (bucket wider than an LDS slice)
+constexpr uint64_t kMark64 = SDSL_HIP_NPOS - 1;
 constexpr unsigned kBigRun = 512;        // a (tile, bin) run longer than this is copied by the whole block
 constexpr unsigned kItemKeys = 32768;    // keys of one slice handled by one block before the slice is reloaded
 
@@ -52,6 +54,10 @@ struct SrGeom
     uint32_t G;      // blocks of the partition kernels
     uint32_t tiles1; // tiles of pass 1
     uint32_t tile;   // keys per tile
+    uint32_t op;     // 0: rank (keys = positions), 1: select (keys = argument ranks)
+    uint32_t kb;     // bits of the final key: line in slice + bit in line (rank), rank inside the bucket (select)
+    uint32_t r;      // select: log2 of the ranks per bucket
+    uint64_t total;  // select: arguments of the vector (ones or zeros)
     bool small;      // 32-bit division path of line_of
 };
 
@@ -111,6 +117,20 @@ __device__ __forceinline__ unsigned block_excl_scan_bins(unsigned * a, unsigned 
 // pass 1: digit and 32-bit key of a position
 __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned & dig, uint32_t & key)
 {
+    if (g.op == 1)
+    { // select: the argument is the 1-based rank i of the wanted bit; buckets of 2^r consecutive ranks
+        if (pos == 0 || pos > g.total)
+        {
+            dig = 0;
+            key = kBad;
+            return;
+        }
+        const uint64_t k = pos - 1;
+        const uint32_t f = (uint32_t)(k >> g.r);
+        dig = f & ((1u << g.d1) - 1);
+        key = ((f >> g.d1) << g.kb) | (uint32_t)(k & ((UINT64_C(1) << g.r) - 1));
+        return;
+    }
     if (pos > g.n_bits)
     {
         dig = 0;
@@ -125,7 +145,7 @@ __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned
     key = ((l >> (kSliceLog + g.d1)) << kKey2Bits) | ((l & ((1u << kSliceLog) - 1)) << kOffBits) | off;
 }
 // pass 2: digit and final key of a pass-1 key
-__device__ __forceinline__ void sr_key2(uint32_t k1, unsigned & dig, uint32_t & key)
+__device__ __forceinline__ void sr_key2(uint32_t k1, const SrGeom & g, unsigned & dig, uint32_t & key)
 {
     if (k1 == kBad)
     {
@@ -133,8 +153,8 @@ __device__ __forceinline__ void sr_key2(uint32_t k1, unsigned & dig, uint32_t & 
         key = kBad;
         return;
     }
-    dig = k1 >> kKey2Bits;
-    key = k1 & ((1u << kKey2Bits) - 1);
+    dig = k1 >> g.kb;
+    key = k1 & ((1u << g.kb) - 1);
 }
 
 // Tiles of a pass.  Pass 1: tile i = keys [i * tile, ...).  Pass 2: the keys are grouped by digit 1 (group starts
@@ -218,7 +238,7 @@ __device__ __forceinline__ void sr_load_keys(const SrGeom & g, const uint64_t * 
         }
 #pragma unroll
         for (unsigned u = 0; u < PER; ++u)
-            sr_key2(k1[u], dig[u], key[u]);
+            sr_key2(k1[u], g, dig[u], key[u]);
     }
 }
 
@@ -625,6 +645,259 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
     }
 }
 
+// ---- select out of LDS, in place over the final keys -----------------------------------------------------------------
+// Bucket f holds the arguments of rank [f * 2^r, (f + 1) * 2^r); select is monotone, so they live in the lines
+// [bnd[f], bnd[f + 1]] — usually fewer than 1024.  The lines are staged in LDS with their headers rewritten as in
+// k_sr_rank_lds (arguments before the line relative to the slice | arguments in word 0 | in words 0..2 | in words 0..4) and,
+// for BIT == 0, the words complemented under the validity mask, so that both bit values search the same way: an
+// interpolated guess at the line, a short bisection over the headers in LDS, then the 16-byte pair that holds the word and
+// sel64 inside it.  A bucket that spans more than an LDS slice (a sparse stretch) is left to the fix-up pass.
+template <int BIT>
+__global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, unsigned r, const uint32_t * __restrict__ bnd,
+                                                       const uint32_t * __restrict__ fstart, const uint32_t * __restrict__ ioff,
+                                                       uint32_t * __restrict__ keys, uint32_t * __restrict__ any_marked)
+{
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    __shared__ v2u64 slice[(kLW << kSliceLog) / 2]; // 64 KiB
+    __shared__ unsigned sh_f;
+    __shared__ unsigned sh_tot;
+    constexpr int U = 4;
+    const unsigned t = threadIdx.x;
+    const unsigned n_items = ioff[nf];
+    for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x)
+    {
+        if (t == 0)
+        {
+            unsigned a = 0, z = nf;
+            while (a + 1 < z)
+            {
+                const unsigned m = (a + z) >> 1;
+                if (ioff[m] <= item)
+                    a = m;
+                else
+                    z = m;
+            }
+            sh_f = a;
+        }
+        __syncthreads();
+        const unsigned f = sh_f;
+        const uint64_t lo = (uint64_t)fstart[f] + (uint64_t)(item - ioff[f]) * kItemKeys;
+        const uint64_t fend = fstart[f + 1];
+        const unsigned cnt = (unsigned)(lo + kItemKeys < fend ? kItemKeys : fend - lo);
+        uint32_t * kp = keys + lo;
+        const uint64_t L0 = bnd[f];
+        const uint64_t L1 = (uint64_t)bnd[f + 1] + 1 < bv.n_lines ? (uint64_t)bnd[f + 1] + 1 : bv.n_lines;
+        if (L1 - L0 > (UINT64_C(1) << kSliceLog))
+        { // wider than a slice: the fix-up pass answers these
+            for (unsigned i = t; i < cnt; i += kRT)
+                if (kp[i] != kBad)
+                    kp[i] = kMark;
+            if (t == 0)
+                *any_marked = 1;
+            continue;
+        }
+        const unsigned nl = (unsigned)(L1 - L0);
+        const v2u64 * src = reinterpret_cast<const v2u64 *>(bv.lines + L0 * kLW);
+        for (unsigned i = t; i < nl * (kLW / 2); i += kRT)
+            slice[i] = __builtin_nontemporal_load(src + i);
+        uint32_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            const unsigned i = t + (unsigned)u * kRT;
+            key[u] = i < cnt ? __builtin_nontemporal_load(kp + i) : kBad;
+        }
+        __syncthreads();
+        const uint64_t h0 = slice[0].x;
+        const uint64_t A0 = BIT ? h0 : L0 * kDB - h0; // arguments in front of the slice
+        __syncthreads();
+        for (unsigned ln = t; ln < nl; ln += kRT)
+        {
+            v2u64 * w = slice + ln * (kLW / 2);
+            v2u64 a = w[0], b = w[1], c = w[2], d = w[3];
+            const uint64_t L = L0 + ln;
+            uint64_t before = a.x;
+            if (!BIT)
+            {
+                before = L * kDB - a.x;
+                if ((L + 1) * kDB <= bv.n_bits)
+                {
+                    a.y = ~a.y, b.x = ~b.x, b.y = ~b.y, c.x = ~c.x, c.y = ~c.y, d.x = ~d.x, d.y = ~d.y;
+                }
+                else
+                {
+                    a.y = ~a.y & valid_mask(bv.n_bits, L, 0);
+                    b.x = ~b.x & valid_mask(bv.n_bits, L, 1);
+                    b.y = ~b.y & valid_mask(bv.n_bits, L, 2);
+                    c.x = ~c.x & valid_mask(bv.n_bits, L, 3);
+                    c.y = ~c.y & valid_mask(bv.n_bits, L, 4);
+                    d.x = ~d.x & valid_mask(bv.n_bits, L, 5);
+                    d.y = ~d.y & valid_mask(bv.n_bits, L, 6);
+                }
+                w[1] = b;
+                w[2] = c;
+                w[3] = d;
+            }
+            const unsigned ca = popc64(a.y), cb = ca + popc64(b.x) + popc64(b.y), cc = cb + popc64(c.x) + popc64(c.y);
+            a.x = (before - A0) | ((uint64_t)ca << 20) | ((uint64_t)cb << 29) | ((uint64_t)cc << 38);
+            w[0] = a;
+            if (ln == nl - 1)
+                sh_tot = (unsigned)(before - A0) + cc + popc64(d.x) + popc64(d.y); // arguments inside the slice
+        }
+        __syncthreads();
+        const uint64_t t0 = ((uint64_t)f << r) - A0; // rank of the bucket's first argument, relative to the slice
+        const float scale = (float)nl / (float)(sh_tot ? sh_tot : 1);
+        for (unsigned i0 = t; i0 < cnt; i0 += kRT * U)
+        {
+            if (i0 != t)
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                {
+                    const unsigned i = i0 + (unsigned)u * kRT;
+                    key[u] = i < cnt ? __builtin_nontemporal_load(kp + i) : kBad;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                const unsigned i = i0 + (unsigned)u * kRT;
+                uint32_t res = kBad;
+                if (key[u] != kBad)
+                {
+                    const unsigned tg = (unsigned)t0 + key[u]; // arguments of the slice in front of the wanted one
+                    // line a with rel(a) <= tg < rel(a + 1).  The arguments are spread almost evenly over a slice, so two
+                    // interpolation steps — the slice-wide guess, then a correction by the guessed line's own count at the
+                    // slice's mean density — land on the line or next to it; a short walk, then bisection if the slice is
+                    // not that regular
+                    auto rel = [&](unsigned j) -> unsigned { return (unsigned)slice[j * (kLW / 2)].x & 0xFFFFFu; };
+                    unsigned j = (unsigned)((float)tg * scale);
+                    j = j >= nl ? nl - 1 : j;
+                    {
+                        const int d = (int)tg - (int)rel(j);
+                        int j2 = (int)j + (int)floorf((float)d * scale);
+                        j = j2 < 0 ? 0u : (j2 >= (int)nl ? nl - 1 : (unsigned)j2);
+                    }
+                    unsigned a = 0, z = nl;
+                    for (int it = 0; it < 4 && z - a > 1; ++it)
+                    {
+                        if (rel(j) <= tg)
+                        {
+                            a = j;
+                            j = j + 1 < z ? j + 1 : j;
+                            if (a + 1 < nl && rel(a + 1) > tg)
+                                z = a + 1;
+                        }
+                        else
+                        {
+                            z = j;
+                            j = j > a + 1 ? j - 1 : a;
+                        }
+                    }
+                    while (z - a > 1)
+                    {
+                        const unsigned m = (a + z) >> 1;
+                        if (rel(m) <= tg)
+                            a = m;
+                        else
+                            z = m;
+                    }
+                    const v2u64 * w = slice + a * (kLW / 2);
+                    const v2u64 hd = w[0];
+                    unsigned tl = tg - ((unsigned)hd.x & 0xFFFFFu); // index inside the line
+                    const unsigned ca = (unsigned)(hd.x >> 20) & 0x1FFu, cb = (unsigned)(hd.x >> 29) & 0x1FFu,
+                                   cc = (unsigned)(hd.x >> 38) & 0x1FFu;
+                    unsigned word, bitpos;
+                    if (tl < ca)
+                    {
+                        word = 0;
+                        bitpos = sel64(hd.y, tl + 1);
+                    }
+                    else
+                    {
+                        const unsigned k = 1 + (tl >= cb ? 1u : 0u) + (tl >= cc ? 1u : 0u);
+                        tl -= k == 1 ? ca : (k == 2 ? cb : cc);
+                        const v2u64 pr = w[k];
+                        const unsigned px = popc64(pr.x);
+                        if (tl < px)
+                        {
+                            word = 2 * k - 1;
+                            bitpos = sel64(pr.x, tl + 1);
+                        }
+                        else
+                        {
+                            word = 2 * k;
+                            bitpos = sel64(pr.y, tl - px + 1);
+                        }
+                    }
+                    res = a * (uint32_t)kDB + 64u * word + bitpos; // relative to the slice's first bit
+                }
+                if (i < cnt)
+                    __builtin_nontemporal_store(res, kp + i);
+            }
+        }
+    }
+}
+
+// first bit of every select bucket's slice (what makes a slice-relative position absolute)
+__global__ __launch_bounds__(256) void k_sr_select_bases(unsigned nf, const uint32_t * __restrict__ bnd, uint64_t * __restrict__ hf)
+{
+    const unsigned f = blockIdx.x * 256 + threadIdx.x;
+    if (f < nf)
+        hf[f] = (uint64_t)bnd[f] * kDB;
+}
+
+// The arguments that were left over (kMark64 in the output): one lane per query, bracket from the directory, bisection over
+// the line headers in global memory, then the line itself.  Slow and rare: stretches where 2^r arguments span more than
+// 1024 lines.
+template <int BIT>
+__global__ __launch_bounds__(256) void k_sr_select_fixup(BvView bv, const uint32_t * __restrict__ any_marked,
+                                                         const uint64_t * __restrict__ iq, uint64_t * __restrict__ out, uint64_t n)
+{
+    if (!*any_marked)
+        return; // the usual case: every bucket fitted a slice
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x)
+    {
+        if (out[q] != kMark64)
+            continue;
+        const uint64_t k = iq[q] - 1;
+        const SelSamples sm = sel_samples<BIT>(bv, k);
+        const SelBracket br = sel_bracket<BIT>(bv, k, sm);
+        uint64_t a = br.lo_pos / kDB, z = (br.hi_pos + kDB - 1) / kDB; // line a has <= k arguments in front, line z more
+        if (z > bv.n_lines)
+            z = bv.n_lines;
+        auto before = [&](uint64_t L) -> uint64_t
+        {
+            const uint64_t h = bv.lines[L * kLW];
+            return BIT ? h : L * kDB - h;
+        };
+        while (z - a > 1)
+        {
+            const uint64_t m = (a + z) >> 1;
+            if (before(m) <= k)
+                a = m;
+            else
+                z = m;
+        }
+        unsigned tl = (unsigned)(k - before(a));
+        uint64_t pos = SDSL_HIP_NPOS;
+        for (int d = 0; d < kDW; ++d)
+        {
+            uint64_t x = bv.lines[a * kLW + 1 + d];
+            if (!BIT)
+                x = ~x & valid_mask(bv.n_bits, a, d);
+            const unsigned pc = popc64(x);
+            if (tl < pc)
+            {
+                pos = a * kDB + 64ull * d + sel64(x, tl + 1);
+                break;
+            }
+            tl -= pc;
+        }
+        out[q] = pos;
+    }
+}
+
 // ---- the way back ---------------------------------------------------------------------------------------------------
 // P == 2: slice-relative answers (order of partition 2) -> absolute answers in the order of partition 1 (lo32 / hi8)
 // P == 1: absolute answers in the order of partition 1 -> the caller's array
@@ -685,7 +958,9 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
             if (P == 1)
                 return 0;
             const unsigned f = (b << g.d1) | grp;
-            const uint64_t h = hf[f]; // ones in front of the slice (0 for slices past the end: only NPOS keys live there)
+            const uint64_t h = hf[f]; // rank: ones in front of the slice (0 past the end); select: first bit of the slice
+            if (g.op == 1)
+                return h;
             return bit ? h : ((uint64_t)f << kSliceLog) * kDB - h;
         };
         auto keep = [&](uint64_t base, unsigned at, uint32_t v, uint8_t h)
@@ -694,7 +969,7 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
             {
                 const uint64_t full = base + v;
                 lo32[at] = (uint32_t)full;
-                hi8[at] = v == kBad ? (uint8_t)0xFF : (uint8_t)(full >> 32);
+                hi8[at] = v == kBad ? (uint8_t)0xFF : (v == kMark ? (uint8_t)0xFE : (uint8_t)(full >> 32));
             }
             else
             {
@@ -807,7 +1082,8 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
                     __builtin_nontemporal_store((uint8_t)h, out_hi_t + q);
                 }
                 else
-                    __builtin_nontemporal_store(h == 0xFFu ? SDSL_HIP_NPOS : ((uint64_t)h << 32) | l32, out_t + q);
+                    __builtin_nontemporal_store(h == 0xFFu ? SDSL_HIP_NPOS : (h == 0xFEu ? kMark64 : ((uint64_t)h << 32) | l32),
+                                                out_t + q);
             }
         }
         for (unsigned i = t; i < kBins; i += TT)
@@ -966,8 +1242,17 @@ bool bv_sorted_rank_applicable(const BvView & v, uint64_t n)
     return bv_sorted_rank_possible(v) && v.n_lines >= (UINT64_C(1) << 22) && n >= 2 * v.n_lines;
 }
 
-sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
-                                      hipStream_t s, void * scratch, size_t scratch_bytes)
+namespace {
+
+struct SelectPlan
+{ // select only
+    const uint32_t * bnd = nullptr; // nf + 1 line indices
+    unsigned r = 0, nf = 0;
+    uint64_t total = 0;
+};
+
+sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
+                       hipStream_t s, void * scratch, size_t scratch_bytes)
 {
     static const bool trace_env = getenv("SDSL_HIP_TRACE_SORTED") != nullptr;
     const bool trace_opt = g_trace_phases.load() != 0;
@@ -975,11 +1260,6 @@ sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t 
     static const int t_env = getenv("SDSL_HIP_SORTED_THREADS") ? atoi(getenv("SDSL_HIP_SORTED_THREADS")) : 0;
     static const int g_env = getenv("SDSL_HIP_SORTED_G") ? atoi(getenv("SDSL_HIP_SORTED_G")) : 0;
     static const int rb_env = getenv("SDSL_HIP_SORTED_RANK_BLOCKS") ? atoi(getenv("SDSL_HIP_SORTED_RANK_BLOCKS")) : 0;
-    if (!bv_sorted_rank_possible(v))
-    {
-        set_error("rank_sorted: vector too large for the bucketed path");
-        return SDSL_HIP_ERR_INVALID;
-    }
     // tiles of 8192 keys (512 threads x 16) are the measured optimum on 2^34 bits (profiles/sorted_rank_v6_r02.txt:
     // 17.9 ms against 18.9 ms for 16384-key tiles and 21.4 ms for 4096-key tiles); the others stay selectable for profiling
     const SrKernels K = t_env == 1024 ? sr_kernels<1024, 16>(1) : (t_env == 256 ? sr_kernels<256, 16>(4) : sr_kernels<512, 16>(2));
@@ -990,10 +1270,26 @@ sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t 
         g.n = cnt;
         g.n_bits = v.n_bits;
         g.n_lines = v.n_lines;
-        unsigned lb = 0; // bits of a line index
-        while ((v.n_lines - 1) >> lb)
-            ++lb;
-        const unsigned f = lb > kSliceLog ? lb - kSliceLog : 0;
+        g.op = (uint32_t)op;
+        unsigned f = 0; // bits of a slice / bucket index
+        if (op == 0)
+        {
+            unsigned lb = 0; // bits of a line index
+            while ((v.n_lines - 1) >> lb)
+                ++lb;
+            f = lb > kSliceLog ? lb - kSliceLog : 0;
+            g.kb = kKey2Bits;
+            g.r = 0;
+            g.total = 0;
+        }
+        else
+        {
+            while (sp.nf > (1u << f))
+                ++f;
+            g.kb = sp.r;
+            g.r = sp.r;
+            g.total = sp.total;
+        }
         g.d1 = f < 8 ? f : 8;
         g.d2 = f - g.d1;
         g.tile = K.threads * K.per;
@@ -1004,7 +1300,7 @@ sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t 
         SrBuf b;
         if (carve(b, scratch, cnt, g.tile) > scratch_bytes)
         {
-            set_error("rank_sorted: scratch too small");
+            set_error("bucketed batch: scratch too small");
             return SDSL_HIP_ERR_INVALID;
         }
         const uint64_t * idx = d_idx + done;
@@ -1030,10 +1326,27 @@ sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t 
                            b.thist2);
         pt.mark();
         hipLaunchKernelGGL(k_sr_fine_scan, dim3(1), dim3(1024), 0, s, nf, b.fine_count, b.fstart, b.ioff);
-        hipLaunchKernelGGL(k_sr_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, s, v, nf, b.hf);
-        pt.mark();
-        const unsigned rank_blocks = rb_env >= 1 ? (unsigned)rb_env : 1024u;
-        hipLaunchKernelGGL(k_sr_rank_lds, dim3(rank_blocks), dim3(kRT), 0, s, v, bit, nf, b.fstart, b.ioff, b.keys2);
+        const unsigned slice_blocks = rb_env >= 1 ? (unsigned)rb_env : 1024u;
+        if (op == 0)
+        {
+            hipLaunchKernelGGL(k_sr_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, s, v, nf, b.hf);
+            pt.mark();
+            hipLaunchKernelGGL(k_sr_rank_lds, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, b.fstart, b.ioff, b.keys2);
+        }
+        else
+        {
+            SH_HIP(hipMemsetAsync(b.hf, 0, (size_t)nf * 8, s));
+            SH_HIP(hipMemsetAsync(b.btot, 0, 4, s)); // doubles as the "some answers are left to the fix-up pass" flag
+            hipLaunchKernelGGL(k_sr_select_bases, dim3((sp.nf + 255) / 256), dim3(256), 0, s, sp.nf, sp.bnd, b.hf);
+            pt.mark();
+            // slices beyond sp.nf are empty (no items), so the kernel never reads bnd past sp.nf
+            if (bit)
+                hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, sp.r, sp.bnd, b.fstart, b.ioff,
+                                   b.keys2, b.btot);
+            else
+                hipLaunchKernelGGL(k_sr_select_lds<0>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, sp.r, sp.bnd, b.fstart, b.ioff,
+                                   b.keys2, b.btot);
+        }
         pt.mark();
         hipLaunchKernelGGL(K.unp2, G, T, 0, s, b.hf, bit, g, b.tprefix2, b.bstart1, b.offs2, b.keys2, nullptr, b.slots2, b.thist2,
                            b.keys1, b.hi8, nullptr);
@@ -1041,6 +1354,13 @@ sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t 
         hipLaunchKernelGGL(K.unp1, G, T, 0, s, b.hf, bit, g, nullptr, nullptr, b.offs1, b.keys1, b.hi8, b.slots1, b.thist1,
                            nullptr, nullptr, d_out + done);
         pt.mark();
+        if (op == 1)
+        { // whatever the slices left over (buckets wider than a slice): one lane per marked answer
+            if (bit)
+                hipLaunchKernelGGL(k_sr_select_fixup<1>, dim3(256 * 8), dim3(256), 0, s, v, b.btot, idx, d_out + done, cnt);
+            else
+                hipLaunchKernelGGL(k_sr_select_fixup<0>, dim3(256 * 8), dim3(256), 0, s, v, b.btot, idx, d_out + done, cnt);
+        }
         SH_HIP(hipGetLastError());
         if (trace_env)
             pt.report(g);
@@ -1049,6 +1369,113 @@ sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t 
         done += cnt;
     }
     return SDSL_HIP_OK;
+}
+
+__global__ __launch_bounds__(256) void k_sr_bnd_args(unsigned nf, unsigned r, uint64_t * __restrict__ out)
+{
+    const unsigned f = blockIdx.x * 256 + threadIdx.x;
+    if (f < nf)
+        out[f] = ((uint64_t)f << r) + 1; // 1-based rank of the bucket's first argument
+}
+__global__ __launch_bounds__(256) void k_sr_bnd_lines(unsigned nf, const uint64_t * __restrict__ pos, uint64_t n_lines,
+                                                      uint32_t * __restrict__ bnd)
+{
+    const unsigned f = blockIdx.x * 256 + threadIdx.x;
+    if (f < nf)
+        bnd[f] = (uint32_t)(pos[f] / kDB);
+    if (f == nf)
+        bnd[nf] = (uint32_t)(n_lines - 1);
+}
+
+} // namespace
+
+sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
+                                      hipStream_t s, void * scratch, size_t scratch_bytes)
+{
+    if (!bv_sorted_rank_possible(v))
+    {
+        set_error("rank_sorted: vector too large for the bucketed path");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    return sr_run(v, 0, bit, SelectPlan{}, d_idx, n, d_out, s, scratch, scratch_bytes);
+}
+
+// Buckets of the bucketed select: 2^r consecutive argument ranks each, at most 2^16 of them, sized so that a bucket of a
+// uniformly dense vector spans about 900 lines; bnd[f] = line of the bucket's first argument.  Built once per handle and bit
+// value (one small batch through the direct kernel).  wide_frac = share of the arguments that live in buckets spanning more
+// than an LDS slice — those are answered by the fix-up pass, so the path only pays when the share is small.
+sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit)
+{
+    if (h.sel_plan[bit].ready)
+        return SDSL_HIP_OK;
+    BvHost::SelPlan & P = h.sel_plan[bit];
+    const BvView & v = h.view;
+    const uint64_t total = bit ? v.ones : v.n_bits - v.ones;
+    P.ready = true;
+    P.ok = false;
+    if (!v.sel[bit] || total < 2 || v.n_lines > UINT64_C(0xFFFFFFFF))
+        return SDSL_HIP_OK;
+    unsigned lt = 0;
+    while ((total - 1) >> lt)
+        ++lt;
+    const unsigned r_min = lt > 16 ? lt - 16 : 0;
+    const double per = 900.0 * (double)kDB * ((double)total / (double)v.n_bits); // arguments in 900 lines
+    unsigned r_fit = 0;
+    while (r_fit < 20 && (double)(UINT64_C(2) << r_fit) <= per)
+        ++r_fit;
+    unsigned r = r_fit > r_min ? r_fit : r_min;
+    if (r < 6)
+        r = 6;
+    if (r > 24)
+        return SDSL_HIP_OK;
+    const unsigned nf = (unsigned)((total + (UINT64_C(1) << r) - 1) >> r);
+    DevBuf args, pos;
+    SH_TRY(args.alloc((size_t)nf * 8));
+    SH_TRY(pos.alloc((size_t)nf * 8));
+    SH_TRY(P.bnd.alloc(((size_t)nf + 1) * 4));
+    hipLaunchKernelGGL(k_sr_bnd_args, dim3((nf + 255) / 256), dim3(256), 0, 0, nf, r, args.as<uint64_t>());
+    SH_HIP(hipGetLastError());
+    {
+        TimingPause pause;
+        SH_TRY(bv_launch_select(v, bit, args.as<uint64_t>(), nf, pos.as<uint64_t>(), nullptr));
+    }
+    hipLaunchKernelGGL(k_sr_bnd_lines, dim3((nf + 256) / 256), dim3(256), 0, 0, nf, pos.as<uint64_t>(), v.n_lines,
+                       P.bnd.as<uint32_t>());
+    SH_HIP(hipGetLastError());
+    std::vector<uint32_t> hb((size_t)nf + 1);
+    SH_HIP(hipMemcpy(hb.data(), P.bnd.p, hb.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t wide = 0;
+    for (unsigned f = 0; f < nf; ++f)
+        if ((uint64_t)hb[f + 1] + 1 - hb[f] > (UINT64_C(1) << kSliceLog))
+            wide += std::min<uint64_t>(UINT64_C(1) << r, total - ((uint64_t)f << r));
+    P.r = r;
+    P.nf = nf;
+    P.wide_frac = (double)wide / (double)total;
+    P.ok = true;
+    return SDSL_HIP_OK;
+}
+
+bool bv_sorted_select_applicable(const BvHost & h, int bit, uint64_t n)
+{
+    const BvHost::SelPlan & P = h.sel_plan[bit];
+    return P.ready && P.ok && P.wide_frac <= 0.01 && h.view.n_lines >= (UINT64_C(1) << 22) && n >= 2 * h.view.n_lines;
+}
+
+sdsl_hip_status bv_launch_select_sorted(BvHost & h, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out, hipStream_t s,
+                                        void * scratch, size_t scratch_bytes)
+{
+    const BvHost::SelPlan & P = h.sel_plan[bit];
+    if (!P.ready || !P.ok)
+    {
+        set_error("select_sorted: no bucket plan for this vector");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SelectPlan sp;
+    sp.bnd = P.bnd.as<uint32_t>();
+    sp.r = P.r;
+    sp.nf = P.nf;
+    sp.total = bit ? h.view.ones : h.view.n_bits - h.view.ones;
+    return sr_run(h.view, 1, bit, sp, d_i, n, d_out, s, scratch, scratch_bytes);
 }
 
 } // namespace sdslhip

@@ -10,6 +10,7 @@ static thread_local std::string g_err;
 static bool g_timing = false;
 // batched rank on a plain vector: -1 automatic, 0 always the direct kernel, 1 the bucketed path whenever it applies
 std::atomic<int> g_trace_phases{0};
+std::atomic<int> g_select_sorted_mode{getenv("SDSL_HIP_SELECT_SORTED") ? atoi(getenv("SDSL_HIP_SELECT_SORTED")) : -1};
 std::atomic<int> g_rank_sorted_mode{getenv("SDSL_HIP_RANK_SORTED") ? atoi(getenv("SDSL_HIP_RANK_SORTED")) : -1};
 static thread_local bool g_timing_suppressed = false; // pipeline workers: the event pair is global
 static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
@@ -178,6 +179,13 @@ void suppress_timing_in_this_thread()
     g_timing_suppressed = true;
 }
 
+bool set_timing_suppressed(bool v)
+{
+    const bool prev = g_timing_suppressed;
+    g_timing_suppressed = v;
+    return prev;
+}
+
 KernelTimer::KernelTimer(hipStream_t stream) : s(stream), on(g_timing && !g_timing_suppressed)
 {
     if (!on)
@@ -246,6 +254,11 @@ sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value)
     if (name && !strcmp(name, "rank_sorted"))
     {
         sdslhip::g_rank_sorted_mode.store((int)value);
+        return SDSL_HIP_OK;
+    }
+    if (name && !strcmp(name, "select_sorted"))
+    {
+        sdslhip::g_select_sorted_mode.store((int)value);
         return SDSL_HIP_OK;
     }
     if (name && !strcmp(name, "trace_phases"))

@@ -23,9 +23,22 @@
 namespace sdslhip {
 
 extern std::atomic<int> g_rank_sorted_mode; // sdsl_hip_set_option("rank_sorted", ...)
+extern std::atomic<int> g_select_sorted_mode; // sdsl_hip_set_option("select_sorted", ...)
 extern std::atomic<int> g_trace_phases;     // sdsl_hip_set_option("trace_phases", ...)
 const char * last_error_message();
-void suppress_timing_in_this_thread();
+void suppress_timing_in_this_thread(); // for good (pipeline worker threads)
+bool set_timing_suppressed(bool v);     // returns the previous state
+// helper launches inside a call must not overwrite the caller's sdsl_hip_last_kernel_ms
+struct TimingPause
+{
+    bool prev;
+    TimingPause() : prev(set_timing_suppressed(true))
+    {}
+    ~TimingPause()
+    {
+        set_timing_suppressed(prev);
+    }
+};
 void set_error(const char * fmt, ...);
 sdsl_hip_status hip_fail(hipError_t e, const char * what, const char * file, int line);
 

@@ -54,12 +54,18 @@ def test_c2_rank_1_matches_reference_digests(gpu, c2_vector, mode):
     assert bool((out + zeros == idx).all())
 
 
-def test_c2_select_1_matches_reference_digests(gpu, c2_vector):
+@pytest.mark.parametrize("mode", [0, 1], ids=["direct", "bucketed"])
+def test_c2_select_1_matches_reference_digests(gpu, c2_vector, mode):
     import torch
     bv, n = c2_vector
     c = G["c2"]
     i = torch.from_numpy(gpu.rnd_positions(c["select_seed"], c["select_1"]["n"], c["ones"], 1).view(np.int64)).cuda()
-    check(bv.select(i, 1).cpu().numpy(), c["select_1"], "configs[1] select_1")
+    gpu.set_option("select_sorted", mode)
+    try:
+        got = bv.select(i, 1)
+    finally:
+        gpu.set_option("select_sorted", -1)
+    check(got.cpu().numpy(), c["select_1"], f"configs[1] select_1 ({'bucketed' if mode else 'direct'} path)")
 
 
 def test_c3_rrr63_rank_select_match_reference_digests(gpu):

@@ -28,6 +28,8 @@ def shape(name):
         k = N >> 16
         pos = np.arange(k, dtype=np.int64) * (1 << 16) + rng.integers(0, 1 << 16, size=k)
         np.bitwise_or.at(w, pos >> 6, np.uint64(1) << (pos & 63).astype(np.uint64))
+    elif name == "uniform":
+        w = dense(nw)
     elif name == "mixed":  # a dense quarter, an isolated quarter, a burst, emptiness, one bit at the very end
         q = nw // 4
         w[:q] = dense(q)
@@ -39,17 +41,31 @@ def shape(name):
     return w
 
 
-@pytest.mark.parametrize("name", ["clustered", "stripes", "isolated", "mixed"])
-def test_plain_select_matches_oracle_on_shape(gpu, name):
+@pytest.mark.parametrize("mode", [0, 1], ids=["direct", "bucketed"])
+@pytest.mark.parametrize("name", ["clustered", "stripes", "isolated", "mixed", "uniform"])
+def test_plain_select_matches_oracle_on_shape(gpu, name, mode):
+    """both ways of answering a batch: the direct kernel, and the bucketed path (bv_sorted.hip) whose buckets of 2^r
+    consecutive ranks are staged in LDS when they fit a slice and left to its fix-up pass when they do not (the sparse
+    stretches of these shapes), on device-resident batches"""
+    import torch
     w = shape(name)
     o = ol.OBitVector(w, N)
     bv = gpu.bit_vector(w, N)
     rng = np.random.default_rng(1)
-    for b in (1, 0):
-        ac = o.arg_cnt(b)
-        i = np.concatenate([rng.integers(1, ac + 1, size=300_000, dtype=np.uint64),
-                            np.array([1, 2, ac - 1, ac], dtype=np.uint64), np.arange(1, min(ac, 5000) + 1, dtype=np.uint64)])
-        assert np.array_equal(bv.select(i, b), o.select(i, b)), (name, b)
+    gpu.set_option("select_sorted", mode)
+    try:
+        for b in (1, 0):
+            ac = o.arg_cnt(b)
+            i = np.concatenate([rng.integers(1, ac + 1, size=300_000, dtype=np.uint64),
+                                np.array([1, 2, ac - 1, ac, ac + 1, 0], dtype=np.uint64),
+                                np.arange(1, min(ac, 5000) + 1, dtype=np.uint64)])
+            want = o.select(i[(i >= 1) & (i <= ac)], b)
+            got = bv.select(torch.from_numpy(i.view(np.int64)).cuda(), b).cpu().numpy().view(np.uint64)
+            ok = (i >= 1) & (i <= ac)
+            assert np.array_equal(got[ok], want), (name, b, mode)
+            assert (got[~ok] == np.uint64(2**64 - 1)).all(), "arguments outside [1, #args] answer NPOS"
+    finally:
+        gpu.set_option("select_sorted", -1)
 
 
 @pytest.mark.parametrize("name", ["clustered", "isolated", "mixed"])

@@ -26,6 +26,19 @@ def child(logn, nq):
         ms = min(ts)
         h = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]
         print(f"rank{bit}: {ms:.3f} ms {nq/ms/1e6:.2f} G/s frac {96*nq/ms/1e6/8000:.3f} sha {h} scratch {bv.device_bytes()/2**30:.2f} GiB", flush=True)
+    # select_1 / select_0 through the same switch (option select_sorted follows SDSL_HIP_RANK_SORTED here)
+    pkg.set_option("select_sorted", int(os.environ.get("SDSL_HIP_RANK_SORTED", "-1")))
+    for bit in ((1,) if light else (1, 0)):
+        tot = bv.ones() if bit else n - bv.ones()
+        si = torch.randint(1, tot + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
+        si[:5] = torch.tensor([1, tot, tot + 1, 0, 2], device="cuda")
+        bv.select(si, bit, out); torch.cuda.synchronize()
+        ts = []
+        for _ in range(2 if light else 3):
+            bv.select(si, bit, out); ts.append(pkg.last_kernel_ms())
+        ms = min(ts)
+        h = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]
+        print(f"select{bit}: {ms:.3f} ms {nq/ms/1e6:.2f} G/s frac {112*nq/ms/1e6/8000:.3f} sha {h}", flush=True)
     if light:
         return
     # skewed batch: everything in one bucket, then two values only
