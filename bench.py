@@ -34,10 +34,20 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy achieves
-FUSED_NOTE = ("roofline_frac prices the query as SURVEY.md 8(d) does (80 bytes per tree level, the reference's algorithm); the "
-              "kernel walks the fused layout (one 128-byte line per level of its own 8-ary tree), so the figure can exceed 1; line_fetch_frac "
-              "prices the lines the fused walk addresses (an upper bound on its HBM traffic: small nodes stay in cache and "
-              "the k-mer table skips the first characters of a pattern)")
+FUSED_NOTE = ("survey_8d_model_frac prices the query as SURVEY.md 8(d) does (80 bytes per tree level: the REFERENCE's level-by-level walk); "
+              "the kernel walks the fused layout (one 128-byte line per level of its own 8-ary tree) and does not move those bytes, so that "
+              "figure can exceed 1 and is no roofline fraction.  roofline_frac is: measured fabric traffic of the kernel (PMC, "
+              "profiles/pmc_latest.json, when it was collected on these kernel sources) over the 8 TB/s peak, else line_fetch_frac — the "
+              "lines the fused walk addresses x 128 B, an upper bound on its HBM traffic (small nodes stay in cache, the k-mer table "
+              "skips the first characters of a pattern)")
+
+
+def fused_frac(key, n, ms, line_frac):
+    """HBM-roofline fraction of a fused-layout kernel: measured fabric bytes per launch (per query x n) if available"""
+    per_q = pmc_traffic(key)
+    if per_q:
+        return per_q * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "pmc"
+    return line_frac, "lines_addressed"
 ALG_BYTES = {"rank": 96, "select": 112, "rrr": 144}  # SURVEY.md §8(d), bytes per query
 
 
@@ -82,7 +92,7 @@ def kernel_sources_sha():
     """sha256 over the kernel sources a PMC measurement is valid for."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("bv.hip", "bv_device.hpp", "bv_sorted.hip", "bits.hpp"):
+    for f in ("bv.hip", "bv_device.hpp", "bv_sorted.hip", "bits.hpp", "wt.hip", "wt_device.hpp", "fm.hip", "fm_device.hpp"):
         h.update(open(os.path.join(ROOT, "sdsl-lite_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -567,13 +577,16 @@ def main():
                 _, ms = time_steps(lambda: wt.rank(gi, gc, out2), max(2, a.steps // 2), 1, barrier)
                 alg = 17 + 80 * hbar
                 steps = float(fsteps[gc.long()].double().mean())  # fused layout: depth in its own 8-ary tree
+                lf = (17 + 128 * steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                rf, how = fused_frac("k_wt_rank_bytes_per_query", nq2, ms, lf)
                 ex["wt_huff_rank"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2,
                                       "reference_digest_match": digest_matches(out2, c4["wt_rank"])
                                       if c4ok and nq2 >= c4["wt_rank"]["n"] else None,
-                                      "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "roofline_frac": rf, "roofline_frac_source": how,
+                                      "survey_8d_model_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "algorithmic_bytes_per_query": alg,
                                       "fused_steps_per_query": steps,
-                                      "line_fetch_frac": (17 + 128 * steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "line_fetch_frac": lf,
                                       "note": FUSED_NOTE}
                 if rcsa is not None:
                     cb = cpu_time(lambda i, c: rcsa.wt_rank(np.ascontiguousarray(i).view(np.uint64), c), [gi, gc], out2,
@@ -606,13 +619,16 @@ def main():
                 alg = 28 + 160 * sum_l
                 sum_steps = float(fsteps[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
                 assert bool((out2 >= 1).all()), "every pattern was cut from the text"
+                lf = (28 + 256 * sum_steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                rf, how = fused_frac("k_fm_count_bytes_per_pattern", nq2, ms, lf)
                 ex["fm_count"] = {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "patterns": nq2, "m": m,
                                   "reference_digest_match": digest_matches(out2, c4["count"])
                                   if c4ok and nq2 >= c4["count"]["n"] else None,
                                   "fused_steps_per_pattern": sum_steps,
-                                  "roofline_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "roofline_frac": rf, "roofline_frac_source": how,
+                                  "survey_8d_model_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_pattern": alg,
-                                  "line_fetch_frac": (28 + 256 * sum_steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "line_fetch_frac": lf,
                                   "jump_depth": csa.jump_depth(), "note": FUSED_NOTE}
                 if rcsa is not None:
                     cb = cpu_time(lambda p: rcsa.count_batch(p.reshape(-1), m), [pats.view(-1, m)], out2, a.cpu_seconds,

@@ -27,6 +27,7 @@
 // profiles/scatter_probe_r01.txt) is a gather of runs staged through LDS.
 #include <mutex>
 #include <string>
+#include <type_traits>
 
 #include "bv_host.hpp"
 
@@ -205,7 +206,7 @@ __device__ __forceinline__ void sr_tile_range(const SrGeom & g, const TileMap & 
 }
 
 // digits of the PER keys of this thread in tile [lo, hi); all loads are issued before the first is used
-template <int P, unsigned TT, unsigned PER>
+template <int P, unsigned TT, unsigned PER, bool FULL>
 __device__ __forceinline__ void sr_load_keys(const SrGeom & g, const uint64_t * __restrict__ idx,
                                              const uint32_t * __restrict__ keys_in, uint64_t lo, uint64_t hi, unsigned (&dig)[PER],
                                              uint32_t (&key)[PER])
@@ -221,7 +222,7 @@ __device__ __forceinline__ void sr_load_keys(const SrGeom & g, const uint64_t * 
         for (unsigned u = 0; u < PER; ++u)
         {
             const unsigned q = u * TT + t;
-            p[u] = q < cnt ? __builtin_nontemporal_load(idx + q) : 0;
+            p[u] = FULL || q < cnt ? __builtin_nontemporal_load(idx + q) : 0;
         }
 #pragma unroll
         for (unsigned u = 0; u < PER; ++u)
@@ -234,7 +235,7 @@ __device__ __forceinline__ void sr_load_keys(const SrGeom & g, const uint64_t * 
         for (unsigned u = 0; u < PER; ++u)
         {
             const unsigned q = u * TT + t;
-            k1[u] = q < cnt ? __builtin_nontemporal_load(keys_in + q) : 0;
+            k1[u] = FULL || q < cnt ? __builtin_nontemporal_load(keys_in + q) : 0;
         }
 #pragma unroll
         for (unsigned u = 0; u < PER; ++u)
@@ -290,13 +291,22 @@ __global__ __launch_bounds__(TT) void k_sr_hist(SrGeom g, const uint64_t * __res
         if (P == 2 && grp != cur && ti != tlo)
             flush(cur);
         cur = grp;
-        unsigned dig[PER];
-        uint32_t key[PER];
-        sr_load_keys<P, TT, PER>(g, idx, keys1, lo, hi, dig, key);
+        // (a full tile — all but the last of a group — takes the branch-free body)
+        auto count_tile = [&](auto full_c)
+        {
+            constexpr bool FULL = decltype(full_c)::value;
+            unsigned dig[PER];
+            uint32_t key[PER];
+            sr_load_keys<P, TT, PER, FULL>(g, idx, keys1, lo, hi, dig, key);
 #pragma unroll
-        for (unsigned u = 0; u < PER; ++u)
-            if (u * TT + t < (unsigned)(hi - lo))
-                atomicAdd(&ghist[wv][dig[u]], 1u);
+            for (unsigned u = 0; u < PER; ++u)
+                if (FULL || u * TT + t < (unsigned)(hi - lo))
+                    atomicAdd(&ghist[wv][dig[u]], 1u);
+        };
+        if (hi - lo == TT * PER)
+            count_tile(std::true_type{});
+        else
+            count_tile(std::false_type{});
     }
     flush(cur);
     const unsigned bins = 1u << (P == 1 ? g.d1 : g.d2);
@@ -483,38 +493,47 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_partition(SrGeom g
         if (t == 0)
             n_big = 0;
         __syncthreads();
-        uint32_t key[PER];
-        unsigned br[PER]; // bin << 16 | rank inside the tile's share of the bin
-        sr_load_keys<P, TT, PER>(g, idx, keys_in, lo, hi, br, key);
-        const unsigned cnt_t = (unsigned)(hi - lo);
-        uint16_t * slots_t = slots + lo;
-#pragma unroll
-        for (unsigned u = 0; u < PER; ++u)
+        // load, count, place: a full tile — all but the last of a group — takes the body without per-key bounds checks
+        auto sort_tile = [&](auto full_c)
         {
-            const unsigned q = u * TT + t;
-            const unsigned d = br[u];
-            br[u] = d << 16;
-            if (q < cnt_t)
-                br[u] |= atomicAdd(&hist[d], 1u); // < 2^14
-        }
-        __syncthreads();
-        for (unsigned i = t; i < kBins; i += TT)
-            start[i] = hist[i];
-        __syncthreads();
-        block_excl_scan_bins(start, wsum);
-        for (unsigned i = t; i < bins; i += TT)
-            tile_hist[(uint64_t)ti * bins + i] = (uint16_t)hist[i];
+            constexpr bool FULL = decltype(full_c)::value;
+            uint32_t key[PER];
+            unsigned br[PER]; // bin << 16 | rank inside the tile's share of the bin
+            sr_load_keys<P, TT, PER, FULL>(g, idx, keys_in, lo, hi, br, key);
+            const unsigned cnt_t = (unsigned)(hi - lo);
+            uint16_t * slots_t = slots + lo;
 #pragma unroll
-        for (unsigned u = 0; u < PER; ++u)
-        {
-            const unsigned q = u * TT + t;
-            if (q < cnt_t)
+            for (unsigned u = 0; u < PER; ++u)
             {
-                const unsigned pos = start[br[u] >> 16] + (br[u] & 0xFFFFu);
-                sorted[pos] = key[u];
-                __builtin_nontemporal_store((uint16_t)pos, slots_t + q);
+                const unsigned q = u * TT + t;
+                const unsigned d = br[u];
+                br[u] = d << 16;
+                if (FULL || q < cnt_t)
+                    br[u] |= atomicAdd(&hist[d], 1u); // < 2^14
             }
-        }
+            __syncthreads();
+            for (unsigned i = t; i < kBins; i += TT)
+                start[i] = hist[i];
+            __syncthreads();
+            block_excl_scan_bins(start, wsum);
+            for (unsigned i = t; i < bins; i += TT)
+                tile_hist[(uint64_t)ti * bins + i] = (uint16_t)hist[i];
+#pragma unroll
+            for (unsigned u = 0; u < PER; ++u)
+            {
+                const unsigned q = u * TT + t;
+                if (FULL || q < cnt_t)
+                {
+                    const unsigned pos = start[br[u] >> 16] + (br[u] & 0xFFFFu);
+                    sorted[pos] = key[u];
+                    __builtin_nontemporal_store((uint16_t)pos, slots_t + q);
+                }
+            }
+        };
+        if (hi - lo == kTile)
+            sort_tile(std::true_type{});
+        else
+            sort_tile(std::false_type{});
         __syncthreads();
         { // runs out: 16 lanes per bin
             const unsigned l = t & 15;
@@ -933,14 +952,23 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
         uint16_t sl[PER];
         const unsigned cnt_t = (unsigned)(hi - lo);
         const uint16_t * slots_t = slots + lo;
-        if (V & 2)
-        { // the slots of this tile: asked for now, used after the gather
+        const bool full_tile = cnt_t == kTile; // all but the last tile of a group: no per-key bounds checks
+        auto load_slots = [&](auto full_c)
+        {
+            constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
             for (unsigned u = 0; u < PER; ++u)
             {
                 const unsigned q = u * TT + t;
-                sl[u] = q < cnt_t ? __builtin_nontemporal_load(slots_t + q) : (uint16_t)0;
+                sl[u] = FULL || q < cnt_t ? __builtin_nontemporal_load(slots_t + q) : (uint16_t)0;
             }
+        };
+        if (V & 2)
+        { // the slots of this tile: asked for now, used after the gather
+            if (full_tile)
+                load_slots(std::true_type{});
+            else
+                load_slots(std::false_type{});
         }
         for (unsigned i = t; i < kBins; i += TT)
         {
@@ -1058,34 +1086,40 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
         __syncthreads();
         if (!(V & 2))
         {
-#pragma unroll
-            for (unsigned u = 0; u < PER; ++u)
-            {
-                const unsigned q = u * TT + t;
-                sl[u] = q < cnt_t ? __builtin_nontemporal_load(slots_t + q) : (uint16_t)0;
-            }
+            if (full_tile)
+                load_slots(std::true_type{});
+            else
+                load_slots(std::false_type{});
         }
         uint32_t * out_lo_t = P == 2 ? out_lo + lo : nullptr;
         uint8_t * out_hi_t = P == 2 ? out_hi + lo : nullptr;
         uint64_t * out_t = P == 1 ? out + lo : nullptr;
-#pragma unroll
-        for (unsigned u = 0; u < PER; ++u)
+        auto store_out = [&](auto full_c)
         {
-            const unsigned q = u * TT + t;
-            if (q < cnt_t)
+            constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+            for (unsigned u = 0; u < PER; ++u)
             {
-                const unsigned h = hi8[sl[u]];
-                const uint32_t l32 = lo32[sl[u]];
-                if (P == 2)
+                const unsigned q = u * TT + t;
+                if (FULL || q < cnt_t)
                 {
-                    __builtin_nontemporal_store(l32, out_lo_t + q);
-                    __builtin_nontemporal_store((uint8_t)h, out_hi_t + q);
+                    const unsigned h = hi8[sl[u]];
+                    const uint32_t l32 = lo32[sl[u]];
+                    if (P == 2)
+                    {
+                        __builtin_nontemporal_store(l32, out_lo_t + q);
+                        __builtin_nontemporal_store((uint8_t)h, out_hi_t + q);
+                    }
+                    else
+                        __builtin_nontemporal_store(h == 0xFFu ? SDSL_HIP_NPOS : (h == 0xFEu ? kMark64 : ((uint64_t)h << 32) | l32),
+                                                    out_t + q);
                 }
-                else
-                    __builtin_nontemporal_store(h == 0xFFu ? SDSL_HIP_NPOS : (h == 0xFEu ? kMark64 : ((uint64_t)h << 32) | l32),
-                                                out_t + q);
             }
-        }
+        };
+        if (full_tile)
+            store_out(std::true_type{});
+        else
+            store_out(std::false_type{});
         for (unsigned i = t; i < kBins; i += TT)
             cursor[i] += hist[i];
         __syncthreads();

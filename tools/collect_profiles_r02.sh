@@ -24,6 +24,12 @@ echo "pmc_sq2 exit=$?"
 # kernel trace of the FULL default bench (all extras): per-kernel averages of the secondary kernels
 rocprofv3 --kernel-trace --stats -d $O/trace_full -o bench --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/bench_trace_full.log 2>&1
 echo "trace_full exit=$?"
+# fabric traffic of the fused wavelet-tree / FM-index kernels: two PMC passes of the wt + fm extras
+FULL="python $R/bench.py --steps 3 --warmup 1 --no-cpu --extras wt,fm"
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $O/pmcfull_rd -o bench --output-format csv -- $FULL > $O/bench_pmcfull_rd.log 2>&1
+echo "pmcfull_rd exit=$?"
+rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -d $O/pmcfull_wr -o bench --output-format csv -- $FULL > $O/bench_pmcfull_wr.log 2>&1
+echo "pmcfull_wr exit=$?"
 find $O -name "*.db" -delete
 cd $R
 python tools/summarize_profiles_r02.py

@@ -89,12 +89,39 @@ except Exception as e:
     lines.append(f"(bench line under the tracer not available: {e})")
 open(os.path.join(dst, "bench_r02_pmc.md"), "w").write("\n".join(lines) + "\n")
 h = hashlib.sha256()
-for f in ("bv.hip", "bv_device.hpp", "bv_sorted.hip", "bits.hpp"):
+for f in ("bv.hip", "bv_device.hpp", "bv_sorted.hip", "bits.hpp", "wt.hip", "wt_device.hpp", "fm.hip", "fm_device.hpp"):
     h.update(open(os.path.join(root, "sdsl-lite_amd", "csrc", f), "rb").read())
 kr = [k for k in acc if k.startswith("k_rank<")]
+# fused-layout kernels of the wt + fm extras (two extra PMC passes: pmcfull_rd, pmcfull_wr).  The extras launch each
+# kernel on the English-class index first (three timed launches of 10^8 queries), later on other indexes / small batches:
+# only the first three dispatches of a kernel are averaged.
+full = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+for f in glob.glob(os.path.join(src, "pmcfull_*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        full[short(row["Kernel_Name"])][row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
+
+
+def full_bytes(k):
+    def pl(c):
+        d = full[k][c]
+        ids = sorted(d)[:3]
+        return sum(d[i] for i in ids) / len(ids) if ids else 0.0
+    rd, r128, r64, r32 = pl("TCC_EA0_RDREQ_sum"), pl("TCC_EA0_RDREQ_128B_sum"), pl("TCC_EA0_RDREQ_64B_sum"), pl("TCC_EA0_RDREQ_32B_sum")
+    wr, w64 = pl("TCC_EA0_WRREQ_sum"), pl("TCC_EA0_WRREQ_64B_sum")
+    return r128 * 128 + r64 * 64 + r32 * 32 + max(0.0, rd - r128 - r64 - r32) * 64 + w64 * 64 + max(0.0, wr - w64) * 32
+
+
+fused = {}
+for k, per in (("k_fm_count", 1e8), ("k_wt_rank", 1e8)):
+    cand = [x for x in full if x == k or x.startswith(k + "<")]
+    if cand and full_bytes(cand[0]) > 0:
+        fused[k] = full_bytes(cand[0]) / per
+        lines.append(f"{cand[0]}: {full_bytes(cand[0]) / 1e9:.2f} GB of fabric traffic per launch = {fused[k]:.1f} B per query")
+open(os.path.join(dst, "bench_r02_pmc.md"), "w").write("\n".join(lines) + "\n")
 out = {"kernel_sources_sha": h.hexdigest()[:16], "rank_bucketed_bytes_per_step": tot_r + tot_w,
        "rank_bucketed_read_bytes_per_step": tot_r, "rank_bucketed_write_bytes_per_step": tot_w,
        "k_rank_bytes_per_launch": sum(bytes_of(kr[0])[:2]) if kr else None,
+       "k_fm_count_bytes_per_pattern": fused.get("k_fm_count"), "k_wt_rank_bytes_per_query": fused.get("k_wt_rank"),
        "source": "tools/collect_profiles_r02.sh: TCC_EA0_RDREQ (32/64/128 B) and TCC_EA0_WRREQ (64 B, else 32 B) per kernel launch"}
 json.dump(out, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
 print("\n".join(lines[-3:]))
