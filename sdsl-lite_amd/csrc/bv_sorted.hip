@@ -579,6 +579,10 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
 {
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
     __shared__ v2u64 slice[(kLW << kSliceLog) / 2]; // 64 KiB
+    // the rewritten headers live in an array of their own: inside the lines they all sit at multiples of 64 bytes, i.e. in
+    // 4 of the 64 LDS banks, and a wave's 64 random header reads serialise 16-fold (SQ_LDS_BANK_CONFLICT was 75 % of the
+    // LDS cycles); packed, consecutive headers are 8 bytes apart and random reads spread over all banks
+    __shared__ uint64_t hdr[1u << kSliceLog];
     __shared__ unsigned sh_f;
     constexpr int U = 8;
     const unsigned t = threadIdx.x;
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
             v2u64 * w = slice + ln * (kLW / 2);
             const v2u64 a = w[0], b = w[1], c = w[2];
             const unsigned ca = popc64(a.y), cb = ca + popc64(b.x) + popc64(b.y), cc = cb + popc64(c.x) + popc64(c.y);
-            w[0].x = (a.x - H) | ((uint64_t)ca << 20) | ((uint64_t)cb << 29) | ((uint64_t)cc << 38);
+            hdr[ln] = (a.x - H) | ((uint64_t)ca << 20) | ((uint64_t)cb << 29) | ((uint64_t)cc << 38);
         }
         __syncthreads();
         for (unsigned i0 = t; i0 < cnt; i0 += kRT * U)
@@ -647,13 +651,13 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
                 const unsigned off = key[u] & ((1u << kOffBits) - 1);
                 const v2u64 * w = slice + ln * (kLW / 2);
                 const unsigned wi = off >> 6, k = (wi + 1) >> 1; // data word of the position, 16-byte quarter holding it
-                const v2u64 a = w[0];
-                const v2u64 p = w[k]; // k == 0: the header's own quarter again (same address, no second bank access)
-                const uint64_t x = k ? p.x : 0, y = k ? p.y : a.y;
+                const uint64_t hx = hdr[ln];
+                const v2u64 p = w[k]; // k == 0: (original header, word 0)
+                const uint64_t x = k ? p.x : 0, y = p.y;
                 const uint64_t m = lo_set(off & 63);
-                const unsigned base = k ? (unsigned)(a.x >> (11 + 9 * k)) & 0x1FFu : 0u;
+                const unsigned base = k ? (unsigned)(hx >> (11 + 9 * k)) & 0x1FFu : 0u;
                 const unsigned part = (wi & 1) ? popc64(x & m) : popc64(x) + popc64(y & m);
-                const uint32_t r1 = ((uint32_t)a.x & 0xFFFFFu) + base + part;
+                const uint32_t r1 = ((uint32_t)hx & 0xFFFFFu) + base + part;
                 uint32_t r = bit ? r1 : ln * (uint32_t)kDB + off - r1;
                 if (key[u] == kBad)
                     r = kBad;
@@ -678,6 +682,7 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
 {
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
     __shared__ v2u64 slice[(kLW << kSliceLog) / 2]; // 64 KiB
+    __shared__ uint64_t hdr[1u << kSliceLog];       // the rewritten headers, packed (see k_sr_rank_lds)
     __shared__ unsigned sh_f;
     __shared__ unsigned sh_tot;
     constexpr int U = 4;
@@ -753,13 +758,13 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
                     d.x = ~d.x & valid_mask(bv.n_bits, L, 5);
                     d.y = ~d.y & valid_mask(bv.n_bits, L, 6);
                 }
+                w[0] = a;
                 w[1] = b;
                 w[2] = c;
                 w[3] = d;
             }
             const unsigned ca = popc64(a.y), cb = ca + popc64(b.x) + popc64(b.y), cc = cb + popc64(c.x) + popc64(c.y);
-            a.x = (before - A0) | ((uint64_t)ca << 20) | ((uint64_t)cb << 29) | ((uint64_t)cc << 38);
-            w[0] = a;
+            hdr[ln] = (before - A0) | ((uint64_t)ca << 20) | ((uint64_t)cb << 29) | ((uint64_t)cc << 38);
             if (ln == nl - 1)
                 sh_tot = (unsigned)(before - A0) + cc + popc64(d.x) + popc64(d.y); // arguments inside the slice
         }
@@ -789,7 +794,7 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
                     // interpolation steps — the slice-wide guess, then a correction by the guessed line's own count at the
                     // slice's mean density — land on the line or next to it; a short walk, then bisection if the slice is
                     // not that regular
-                    auto rel = [&](unsigned j) -> unsigned { return (unsigned)slice[j * (kLW / 2)].x & 0xFFFFFu; };
+                    auto rel = [&](unsigned j) -> unsigned { return (unsigned)hdr[j] & 0xFFFFFu; };
                     unsigned j = (unsigned)((float)tg * scale);
                     j = j >= nl ? nl - 1 : j;
                     {
@@ -822,33 +827,18 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
                             z = m;
                     }
                     const v2u64 * w = slice + a * (kLW / 2);
-                    const v2u64 hd = w[0];
-                    unsigned tl = tg - ((unsigned)hd.x & 0xFFFFFu); // index inside the line
-                    const unsigned ca = (unsigned)(hd.x >> 20) & 0x1FFu, cb = (unsigned)(hd.x >> 29) & 0x1FFu,
-                                   cc = (unsigned)(hd.x >> 38) & 0x1FFu;
-                    unsigned word, bitpos;
-                    if (tl < ca)
-                    {
-                        word = 0;
-                        bitpos = sel64(hd.y, tl + 1);
-                    }
-                    else
-                    {
-                        const unsigned k = 1 + (tl >= cb ? 1u : 0u) + (tl >= cc ? 1u : 0u);
-                        tl -= k == 1 ? ca : (k == 2 ? cb : cc);
-                        const v2u64 pr = w[k];
-                        const unsigned px = popc64(pr.x);
-                        if (tl < px)
-                        {
-                            word = 2 * k - 1;
-                            bitpos = sel64(pr.x, tl + 1);
-                        }
-                        else
-                        {
-                            word = 2 * k;
-                            bitpos = sel64(pr.y, tl - px + 1);
-                        }
-                    }
+                    const uint64_t hx = hdr[a];
+                    unsigned tl = tg - ((unsigned)hx & 0xFFFFFu); // index inside the line
+                    const unsigned ca = (unsigned)(hx >> 20) & 0x1FFu, cb = (unsigned)(hx >> 29) & 0x1FFu,
+                                   cc = (unsigned)(hx >> 38) & 0x1FFu;
+                    // the 16-byte quarter that holds the argument: k = 0 -> word 0 (its .y), k >= 1 -> words 2k - 1, 2k
+                    const unsigned k = (tl >= ca ? 1u : 0u) + (tl >= cb ? 1u : 0u) + (tl >= cc ? 1u : 0u);
+                    tl -= k == 0 ? 0u : (k == 1 ? ca : (k == 2 ? cb : cc));
+                    const v2u64 pr = w[k];
+                    const unsigned px = k ? popc64(pr.x) : 0u;
+                    const bool second = tl >= px;
+                    const unsigned word = k ? 2 * k - 1 + (second ? 1u : 0u) : 0u;
+                    const unsigned bitpos = sel64(second ? pr.y : pr.x, tl - (second ? px : 0u) + 1);
                     res = a * (uint32_t)kDB + 64u * word + bitpos; // relative to the slice's first bit
                 }
                 if (i < cnt)
