@@ -350,6 +350,7 @@ def main():
     torch.cuda.synchronize()
     phases = pkg.last_phases()
     pkg.set_option("trace_phases", 0)
+    phases.pop("select", None)
     bucketed = bool(phases)
     scratch_bytes = bv.device_bytes() - index_bytes
     # the direct kernel and its access skeleton (read a position, fetch its 64-byte rank line, write a word), same table,
@@ -398,7 +399,15 @@ def main():
             ones = bv.ones()
             si = to_dev(pkg.rnd_positions(11, nq, ones, 1), dev)  # 8(d): 1 + mt19937_64(11) % ones
             _, ms = time_steps(lambda: bv.select(si, 1, out), max(2, a.steps // 2), 1, barrier)
+            pkg.set_option("trace_phases", 1)
+            bv.select(si, 1, out)
+            torch.cuda.synchronize()
+            sph = pkg.last_phases()
+            pkg.set_option("trace_phases", 0)
+            sel_bucketed = sph.pop("select", 0) == 1
             ex["select_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms,
+                              "path": "bucketed (bv_sorted.hip, DESIGN.md 3.5b)" if sel_bucketed else "direct kernel",
+                              "phases_ms": sph if sel_bucketed else None,
                               "roofline_frac": ALG_BYTES["select"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             if a.log_n == G.get("c2", {}).get("log_n") and nq >= G["c2"]["select_1"]["n"]:
                 ex["select_1"]["reference_digest_match"] = digest_matches(out, G["c2"]["select_1"])

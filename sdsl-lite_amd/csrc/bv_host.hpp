@@ -22,7 +22,7 @@ struct BvHost
     {
         bool ready = false, ok = false;
         DevBuf bnd;
-        unsigned r = 0, nf = 0;
+        unsigned bm = 8, bs = 3, nf = 0; // buckets of bm << bs argument ranks
         double wide_frac = 0;
     } sel_plan[2];
     std::mutex scratch_mutex;

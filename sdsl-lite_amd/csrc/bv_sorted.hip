@@ -57,7 +57,9 @@ struct SrGeom
     uint32_t tile;   // keys per tile
     uint32_t op;     // 0: rank (keys = positions), 1: select (keys = argument ranks)
     uint32_t kb;     // bits of the final key: line in slice + bit in line (rank), rank inside the bucket (select)
-    uint32_t r;      // select: log2 of the ranks per bucket
+    uint32_t B;      // select: ranks per bucket = m << bs with m in 8..15 (a power of two would waste up to half an LDS slice)
+    uint32_t bs;     // select: the shift of B
+    uint32_t binv;   // select: ceil(2^32 / m); floor(x / m) = (x * binv) >> 32 for x < 2^28
     uint64_t total;  // select: arguments of the vector (ones or zeros)
     bool small;      // 32-bit division path of line_of
 };
@@ -127,9 +129,9 @@ __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned
             return;
         }
         const uint64_t k = pos - 1;
-        const uint32_t f = (uint32_t)(k >> g.r);
+        const uint32_t f = (uint32_t)(((k >> g.bs) * g.binv) >> 32); // k / B
         dig = f & ((1u << g.d1) - 1);
-        key = ((f >> g.d1) << g.kb) | (uint32_t)(k & ((UINT64_C(1) << g.r) - 1));
+        key = ((f >> g.d1) << g.kb) | (uint32_t)(k - (uint64_t)f * g.B);
         return;
     }
     if (pos > g.n_bits)
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
 // interpolated guess at the line, a short bisection over the headers in LDS, then the 16-byte pair that holds the word and
 // sel64 inside it.  A bucket that spans more than an LDS slice (a sparse stretch) is left to the fix-up pass.
 template <int BIT>
-__global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, unsigned r, const uint32_t * __restrict__ bnd,
+__global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, unsigned B, const uint32_t * __restrict__ bnd,
                                                        const uint32_t * __restrict__ fstart, const uint32_t * __restrict__ ioff,
                                                        uint32_t * __restrict__ keys, uint32_t * __restrict__ any_marked)
 {
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
                 sh_tot = (unsigned)(before - A0) + cc + popc64(d.x) + popc64(d.y); // arguments inside the slice
         }
         __syncthreads();
-        const uint64_t t0 = ((uint64_t)f << r) - A0; // rank of the bucket's first argument, relative to the slice
+        const uint64_t t0 = (uint64_t)f * B - A0; // rank of the bucket's first argument, relative to the slice
         const float scale = (float)nl / (float)(sh_tot ? sh_tot : 1);
         for (unsigned i0 = t; i0 < cnt; i0 += kRT * U)
         {
@@ -1153,19 +1155,19 @@ struct PhaseTimer
         }
         fprintf(stderr, " | total %.3f ms = %.2f G/s\n", total, g.n / total / 1e6);
     }
-    void keep()
+    void keep(int op)
     {
         if (!on)
             return;
         (void)hipEventSynchronize(ev[n - 1]);
         static const char * name[] = {"hist1", "offs1", "part1", "hist2", "offs2", "part2", "slices", "rank", "unperm2", "unperm1"};
-        std::string out;
+        std::string out = op ? "select=1" : "select=0"; // which query the passes below belong to
         for (int i = 0; i + 1 < n; ++i)
         {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
             char buf[64];
-            snprintf(buf, sizeof(buf), "%s%s=%.4f", i ? ";" : "", name[i], ms);
+            snprintf(buf, sizeof(buf), ";%s=%.4f", name[i], ms);
             out += buf;
         }
         std::lock_guard<std::mutex> lock(g_phase_mutex);
@@ -1271,7 +1273,7 @@ namespace {
 struct SelectPlan
 { // select only
     const uint32_t * bnd = nullptr; // nf + 1 line indices
-    unsigned r = 0, nf = 0;
+    unsigned bm = 8, bs = 3, nf = 0; // buckets of bm << bs ranks
     uint64_t total = 0;
 };
 
@@ -1303,15 +1305,19 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
                 ++lb;
             f = lb > kSliceLog ? lb - kSliceLog : 0;
             g.kb = kKey2Bits;
-            g.r = 0;
+            g.B = 0;
+            g.bs = 0;
+            g.binv = 0;
             g.total = 0;
         }
         else
         {
             while (sp.nf > (1u << f))
                 ++f;
-            g.kb = sp.r;
-            g.r = sp.r;
+            g.kb = sp.bs + 4; // B <= 15 << bs
+            g.B = sp.bm << sp.bs;
+            g.bs = sp.bs;
+            g.binv = (uint32_t)(((UINT64_C(1) << 32) + sp.bm - 1) / sp.bm);
             g.total = sp.total;
         }
         g.d1 = f < 8 ? f : 8;
@@ -1365,10 +1371,10 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
             pt.mark();
             // slices beyond sp.nf are empty (no items), so the kernel never reads bnd past sp.nf
             if (bit)
-                hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, sp.r, sp.bnd, b.fstart, b.ioff,
+                hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
                                    b.keys2, b.btot);
             else
-                hipLaunchKernelGGL(k_sr_select_lds<0>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, sp.r, sp.bnd, b.fstart, b.ioff,
+                hipLaunchKernelGGL(k_sr_select_lds<0>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
                                    b.keys2, b.btot);
         }
         pt.mark();
@@ -1389,17 +1395,17 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         if (trace_env)
             pt.report(g);
         if (trace_opt)
-            pt.keep();
+            pt.keep(op);
         done += cnt;
     }
     return SDSL_HIP_OK;
 }
 
-__global__ __launch_bounds__(256) void k_sr_bnd_args(unsigned nf, unsigned r, uint64_t * __restrict__ out)
+__global__ __launch_bounds__(256) void k_sr_bnd_args(unsigned nf, unsigned B, uint64_t * __restrict__ out)
 {
     const unsigned f = blockIdx.x * 256 + threadIdx.x;
     if (f < nf)
-        out[f] = ((uint64_t)f << r) + 1; // 1-based rank of the bucket's first argument
+        out[f] = (uint64_t)f * B + 1; // 1-based rank of the bucket's first argument
 }
 __global__ __launch_bounds__(256) void k_sr_bnd_lines(unsigned nf, const uint64_t * __restrict__ pos, uint64_t n_lines,
                                                       uint32_t * __restrict__ bnd)
@@ -1424,8 +1430,8 @@ sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t 
     return sr_run(v, 0, bit, SelectPlan{}, d_idx, n, d_out, s, scratch, scratch_bytes);
 }
 
-// Buckets of the bucketed select: 2^r consecutive argument ranks each, at most 2^16 of them, sized so that a bucket of a
-// uniformly dense vector spans about 900 lines; bnd[f] = line of the bucket's first argument.  Built once per handle and bit
+// Buckets of the bucketed select: B consecutive argument ranks each, at most 2^16 of them, sized so that a bucket of a
+// uniformly dense vector spans about 768 lines; bnd[f] = line of the bucket's first argument.  Built once per handle and bit
 // value (one small batch through the direct kernel).  wide_frac = share of the arguments that live in buckets spanning more
 // than an LDS slice — those are answered by the fix-up pass, so the path only pays when the share is small.
 sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit)
@@ -1439,25 +1445,34 @@ sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit)
     P.ok = false;
     if (!v.sel[bit] || total < 2 || v.n_lines > UINT64_C(0xFFFFFFFF))
         return SDSL_HIP_OK;
-    unsigned lt = 0;
-    while ((total - 1) >> lt)
-        ++lt;
-    const unsigned r_min = lt > 16 ? lt - 16 : 0;
-    const double per = 900.0 * (double)kDB * ((double)total / (double)v.n_bits); // arguments in 900 lines
-    unsigned r_fit = 0;
-    while (r_fit < 20 && (double)(UINT64_C(2) << r_fit) <= per)
-        ++r_fit;
-    unsigned r = r_fit > r_min ? r_fit : r_min;
-    if (r < 6)
-        r = 6;
-    if (r > 24)
+    // B = m << sh, m in 8..15: the largest such value whose bucket spans about 3/4 of a slice at the vector's mean density,
+    // but at least total / 2^16 (two 8-bit digits address the buckets)
+    auto round_down = [](uint64_t x, unsigned & m, unsigned & sh) { // largest m << sh <= x (x >= 64)
+        sh = 0;
+        while ((x >> sh) > 15)
+            ++sh;
+        m = (unsigned)(x >> sh);
+    };
+    const double per = 768.0 * (double)kDB * ((double)total / (double)v.n_bits); // arguments in 768 lines
+    const uint64_t b_fit = per < 64.0 ? 64 : (per > 15.0 * 1048576.0 ? (uint64_t)15 << 20 : (uint64_t)per);
+    const uint64_t b_min = (total + 65535) >> 16;
+    unsigned bm, bs;
+    round_down(b_fit, bm, bs);
+    if (((uint64_t)bm << bs) < b_min)
+    { // smallest m << sh >= b_min
+        round_down(b_min, bm, bs);
+        if (((uint64_t)bm << bs) < b_min && ++bm == 16)
+            bm = 8, ++bs;
+    }
+    if (bs > 20)
         return SDSL_HIP_OK;
-    const unsigned nf = (unsigned)((total + (UINT64_C(1) << r) - 1) >> r);
+    const uint64_t B = (uint64_t)bm << bs;
+    const unsigned nf = (unsigned)((total + B - 1) / B);
     DevBuf args, pos;
     SH_TRY(args.alloc((size_t)nf * 8));
     SH_TRY(pos.alloc((size_t)nf * 8));
     SH_TRY(P.bnd.alloc(((size_t)nf + 1) * 4));
-    hipLaunchKernelGGL(k_sr_bnd_args, dim3((nf + 255) / 256), dim3(256), 0, 0, nf, r, args.as<uint64_t>());
+    hipLaunchKernelGGL(k_sr_bnd_args, dim3((nf + 255) / 256), dim3(256), 0, 0, nf, (unsigned)B, args.as<uint64_t>());
     SH_HIP(hipGetLastError());
     {
         TimingPause pause;
@@ -1471,8 +1486,9 @@ sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit)
     uint64_t wide = 0;
     for (unsigned f = 0; f < nf; ++f)
         if ((uint64_t)hb[f + 1] + 1 - hb[f] > (UINT64_C(1) << kSliceLog))
-            wide += std::min<uint64_t>(UINT64_C(1) << r, total - ((uint64_t)f << r));
-    P.r = r;
+            wide += std::min<uint64_t>(B, total - (uint64_t)f * B);
+    P.bm = bm;
+    P.bs = bs;
     P.nf = nf;
     P.wide_frac = (double)wide / (double)total;
     P.ok = true;
@@ -1496,7 +1512,8 @@ sdsl_hip_status bv_launch_select_sorted(BvHost & h, int bit, const uint64_t * d_
     }
     SelectPlan sp;
     sp.bnd = P.bnd.as<uint32_t>();
-    sp.r = P.r;
+    sp.bm = P.bm;
+    sp.bs = P.bs;
     sp.nf = P.nf;
     sp.total = bit ? h.view.ones : h.view.n_bits - h.view.ones;
     return sr_run(h.view, 1, bit, sp, d_i, n, d_out, s, scratch, scratch_bytes);

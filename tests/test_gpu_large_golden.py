@@ -68,6 +68,36 @@ def test_c2_select_1_matches_reference_digests(gpu, c2_vector, mode):
     check(got.cpu().numpy(), c["select_1"], f"configs[1] select_1 ({'bucketed' if mode else 'direct'} path)")
 
 
+def test_c2_default_dispatch_takes_the_bucketed_path_at_bench_size(gpu, c2_vector):
+    """With no option set, a batch of >= 2 queries per rank line goes through bv_sorted.hip — for rank AND for select on
+    this very vector (its 2^33 + 116138 ones once pushed select over the 2^16-bucket limit and silently back to the
+    direct kernel).  The first 10^7 answers are the reference's."""
+    import torch
+    bv, n = c2_vector
+    c = G["c2"]
+    nq = 100_000_000
+    gpu.set_option("trace_phases", 1)
+    try:
+        idx = torch.from_numpy(gpu.rnd_positions(c["rank_seed"], nq, n + 1, 0).view(np.int64)).cuda()
+        out = bv.rank(idx, 1)
+        torch.cuda.synchronize()
+        ph = gpu.last_phases()
+        assert ph.get("select") == 0 and ph.get("part1", 0) > 0, f"rank took the direct kernel: {ph}"
+        check(out[: c["rank_1"]["n"]].cpu().numpy(), c["rank_1"], "configs[1] rank_1 (default dispatch)")
+        del idx, out
+        i = torch.from_numpy(gpu.rnd_positions(c["select_seed"], nq, c["ones"], 1).view(np.int64)).cuda()
+        got = bv.select(i, 1)
+        torch.cuda.synchronize()
+        ph = gpu.last_phases()
+        assert ph.get("select") == 1 and ph.get("part2", 0) > 0, f"select took the direct kernel: {ph}"
+        check(got[: c["select_1"]["n"]].cpu().numpy(), c["select_1"], "configs[1] select_1 (default dispatch)")
+        back = bv.rank(got[: 1 << 20].clone(), 1)
+        assert bool((back == i[: 1 << 20] - 1).all())
+    finally:
+        gpu.set_option("trace_phases", 0)
+        bv.release_scratch()
+
+
 def test_c3_rrr63_rank_select_match_reference_digests(gpu):
     import torch
     c = G["c3"]
