@@ -14,7 +14,7 @@ aggregate.  Prints ONE JSON line on rank 0 with the contract keys plus `roofline
 against the HBM roofline, algorithmic bytes per SURVEY.md §8(d)) and `cpu_baseline` (the reference's CPU
 path on a bounded sample of the same workload, timed on this box's host cores, N=1 only).
 
-Optional secondary measurements (`--extras select,rrr,sd,wt,fm`) are reported under "extras"; they never
+Optional secondary measurements (`--extras select,rrr,sd,shapes,wt,fm`) are reported under "extras"; they never
 enter the timed region.
 """
 from __future__ import annotations
@@ -325,7 +325,7 @@ def main():
     t0 = time.perf_counter()
     words = to_dev(pkg.set_random_bits(n_bits, 42), dev)
     if a.extras is None:
-        a.extras = "select,rrr,sd,wt,fm" if world == 1 else "fm_sharded"
+        a.extras = "select,rrr,sd,shapes,wt,fm" if world == 1 else "fm_sharded"
     extras = [] if a.extras in ("", "none") else a.extras.split(",")
     bv = pkg.bit_vector(words, n_bits, device=local, select1="select" in extras, select0=False)
     index_bytes = bv.device_bytes()
@@ -528,6 +528,16 @@ def main():
                                "rank_1_Gq/s": nq_sd / ms_r / 1e6, "select_1_Gq/s": nq_sd / ms_s / 1e6,
                                "select_0_Gq/s": nq_sd / ms_z / 1e6, "queries": nq_sd}
             del sd, pos, xi, si, zi, zr, o_sd
+        if "shapes" in extras and world == 1:
+            # select_1 where the ones are NOT spread evenly (select_support_mcl's long blocks,
+            # select_support_mcl.hpp:242-252): clustered in 1 % of the range, 2^20-bit dense/empty stripes, isolated
+            # ones every 2^16 bits; plain, rrr_vector<63>, sd_vector; of_uniform = rate relative to the 50 % vector
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import select_shapes_bench
+            ex["select_shapes"] = {"n_bits_log2": a.log_n, "queries": 10**8,
+                                   "shapes": select_shapes_bench.run(pkg, a.log_n, 10**8, emit=lambda s: None, device=local)}
+            pkg.set_timing(False)
         if "wt" in extras or "fm" in extras:
             torch.cuda.empty_cache()
             nt = a.text_mib << 20

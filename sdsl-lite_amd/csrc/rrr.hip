@@ -9,14 +9,15 @@
 //   rrr_vector::operator[]               rrr_vector.hpp:276-298
 //   binomial table / space[]             rrr_helper.hpp:194-237, 262-295
 //
-// Device layout: one 128-byte RECORD per superblock of 32 blocks (2016 bits)
-//   word 0      ones before the superblock                       (SDSL m_rank[s])
-//   word 1      bits 0..47  bit pointer into the offset stream   (SDSL m_btnrp[s])
-//               bits 48..59 ones inside the superblock
-//   word 2      prefix word: ones and offset bits in blocks [0,8), [0,16), [0,24) (rrr_device.hpp rrr_pack_prefix)
-//   words 3..6  the 32 block classes as bytes, inversion already undone (SDSL m_bt + m_invert)
-//   words 7..15 inline copy of the first 576 bits of the superblock's offsets (SDSL m_btnr)
-// plus the full offset stream.  An L2 miss costs the same for 64 and 128 bytes on MI355X (the
+// Device layout: one 128-byte RECORD per 36 blocks (2268 bits; SDSL samples every 32 blocks — the parser
+// and the serialiser regroup)
+//   word 0      ones before the record's first block              (what SDSL's m_rank holds every 32 blocks)
+//   word 1      bits 0..47  WORD pointer into the overflow stream (the role of SDSL's m_btnrp)
+//               bits 48..59 ones inside the record
+//   word 2      prefix word: ones and offset bits in blocks [0,9), [0,18), [0,27) (rrr_device.hpp rrr_pack_prefix)
+//   words 3..6  the 36 block classes, nine 7-bit fields per word, inversion already undone (SDSL m_bt + m_invert)
+//   words 7..15 the first 576 bits of the record's offsets (SDSL m_btnr)
+// plus a stream that holds, per record, only the offset bits beyond those 576 (in whole words).  An L2 miss costs the same for 64 and 128 bytes on MI355X (the
 // random-request rate is the bound, profiles/gather_probe_r01.txt), so packing header, classes and
 // the usually-sufficient head of the offsets into ONE line turns SDSL's five scattered arrays into
 // one fetch for most queries; only long offset runs touch the stream (second fetch).  The prefix word lets ONE
@@ -63,12 +64,14 @@ static const RrrTables & host_tables()
 
 struct RrrArrays // host image of a parsed SDSL stream
 {
-    uint64_t n_bits = 0, n_blocks = 0, n_sb = 0, ones = 0;
-    std::vector<uint8_t> cls;      // n_sb*32 actual classes
+    uint64_t n_bits = 0, n_blocks = 0, n_sb = 0, ones = 0; // n_sb: SDSL's superblocks (32 blocks)
+    std::vector<uint8_t> cls;      // actual classes per block (padded with zeros to whole SDSL superblocks and records)
     std::vector<uint64_t> stream;  // offset bits
     uint64_t stream_bits = 0;
-    std::vector<uint64_t> sb_rank; // ones before each superblock
-    std::vector<uint64_t> sb_ptr;  // stream position of each superblock
+    std::vector<uint64_t> sb_rank; // ones before each SDSL superblock
+    std::vector<uint64_t> sb_ptr;  // stream position of each SDSL superblock
+    uint64_t n_rec = 0;            // device records (36 blocks)
+    std::vector<uint64_t> rec_rank, rec_ptr; // the same two per device record
 };
 
 // rrr_vector<63>::load layout (rrr_vector.hpp:366-378,381-392)
@@ -92,7 +95,8 @@ static sdsl_hip_status rrr_parse_sdsl(StreamReader & rd, RrrArrays & A)
             || rank.size() != A.n_sb + ((n % kRrrSB) > 0))
             goto bad;
         const RrrTables & T = host_tables();
-        A.cls.assign(A.n_sb * kRrrK, 0);
+        A.n_rec = (A.n_blocks + kRecK - 1) / kRecK;
+        A.cls.assign(std::max(A.n_sb * kRrrK, A.n_rec * kRecK), 0);
         A.sb_rank.assign(A.n_sb + 1, 0);
         A.sb_ptr.assign(A.n_sb + 1, 0);
         uint64_t run = 0, ptr = 0;
@@ -127,6 +131,21 @@ static sdsl_hip_status rrr_parse_sdsl(StreamReader & rd, RrrArrays & A)
             goto bad;
         A.stream = btnr.words;
         A.stream.resize(((std::max<uint64_t>(btnr.bit_size, 64) + 63) >> 6) + 2, 0);
+        A.rec_rank.assign(A.n_rec + 1, 0);
+        A.rec_ptr.assign(A.n_rec + 1, 0);
+        run = ptr = 0;
+        for (uint64_t b = 0; b < A.n_rec * kRecK; ++b)
+        {
+            if (b % kRecK == 0)
+            {
+                A.rec_rank[b / kRecK] = run;
+                A.rec_ptr[b / kRecK] = ptr;
+            }
+            run += A.cls[b];
+            ptr += T.space[A.cls[b]];
+        }
+        A.rec_rank[A.n_rec] = run;
+        A.rec_ptr[A.n_rec] = ptr;
         return SDSL_HIP_OK;
     }
 bad:
@@ -214,10 +233,11 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select_flat(RrrView v, const 
     uint64_t base = wave * per; // wave-uniform: next unassigned query
     const uint64_t end = base + per < n ? base + per : n;
     const uint64_t below = (UINT64_C(1) << (threadIdx.x & 63)) - 1;
-    bool have = false, ready = false;
-    uint64_t q = 0;
+    bool have = false, ready = false, fetched = false;
+    uint64_t q = 0, nr_far = 0;
     RrrSelState st{};
     RrrSelHit h{};
+    RrrSelLoc loc{};
     for (;;)
     {
         const uint64_t m_need = __ballot(!have);
@@ -253,8 +273,28 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select_flat(RrrView v, const 
         {
             if (ready)
             {
-                out[q] = rrr_sel_finish<BIT>(v, &T, st.k0, h);
-                have = ready = false;
+                // a block whose offset field reaches into the overflow stream needs a second, random fetch: such a lane
+                // only issues it in this round and decodes in the next one, so the rest of the wave does not wait for it
+                bool now = true;
+                uint64_t nr = nr_far;
+                if (!fetched)
+                {
+                    loc = rrr_sel_locate<BIT>(v, &T, st.k0, h);
+                    const unsigned len = T.space[loc.k];
+                    if (rrr_sel_in_stream(&T, loc))
+                    {
+                        nr_far = rrr_field(v, h.r, loc.ptr, loc.rel, len);
+                        fetched = true;
+                        now = false;
+                    }
+                    else
+                        nr = rrr_field_inline(h.r, loc.rel, len);
+                }
+                if (now)
+                {
+                    out[q] = rrr_sel_decode<BIT>(v, &T, loc, nr);
+                    have = ready = fetched = false;
+                }
             }
         }
     }
@@ -322,7 +362,7 @@ __device__ __forceinline__ uint64_t rrr_block_bits(const uint64_t * __restrict__
     return v & lo_set(len);
 }
 
-// pass 1, one thread per superblock: class bytes into the record, ones and offset bits of the superblock
+// pass 1, one thread per record: classes into the record, ones and offset bits of the record
 __global__ __launch_bounds__(256) void k_rrr_enc_classes(const uint64_t * __restrict__ words, uint64_t n_bits,
                                                          uint64_t n_blocks, uint64_t n_sb,
                                                          const RrrTables * __restrict__ tables, uint64_t * __restrict__ rec,
@@ -337,18 +377,19 @@ __global__ __launch_bounds__(256) void k_rrr_enc_classes(const uint64_t * __rest
         unsigned ones = 0, len = 0;
         uint64_t cw[4] = {0, 0, 0, 0};
         unsigned po[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
-        for (unsigned j = 0; j < kRrrK; ++j)
+        for (unsigned j = 0; j < kRecK; ++j)
         {
-            if (j && (j & 7) == 0)
+            const unsigned g = j / kGrp, u = j - g * kGrp;
+            if (j && u == 0)
             {
-                po[(j >> 3) - 1] = ones;
-                pb[(j >> 3) - 1] = len;
+                po[g - 1] = ones;
+                pb[g - 1] = len;
             }
-            uint64_t b = sb * kRrrK + j;
+            uint64_t b = sb * kRecK + j;
             if (b >= n_blocks)
                 continue; // blocks behind the end count as class 0
             unsigned k = popc64(rrr_block_bits(words, n_bits, b));
-            cw[j >> 3] |= (uint64_t)k << (8 * (j & 7));
+            cw[g] |= (uint64_t)k << (kClsW * u);
             ones += k;
             len += space[k];
         }
@@ -359,7 +400,7 @@ __global__ __launch_bounds__(256) void k_rrr_enc_classes(const uint64_t * __rest
         r[kRecClasses + 2] = cw[2];
         r[kRecClasses + 3] = cw[3];
         sb_ones[sb] = ones;
-        sb_len[sb] = len > kInlineBits ? len : 0; // bits this superblock needs in the offset stream (rrr_device.hpp)
+        sb_len[sb] = len > kInlineBits ? (len - kInlineBits + 63) >> 6 : 0; // WORDS of this record in the overflow stream (rrr_device.hpp)
     }
 }
 
@@ -369,7 +410,6 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
                                                          uint64_t n_blocks, uint64_t n_sb,
                                                          const RrrTables * __restrict__ tables, uint64_t * __restrict__ rec,
                                                          const uint32_t * __restrict__ sb_ones,
-                                                         const uint32_t * __restrict__ sb_store,
                                                          unsigned long long * __restrict__ stream, uint32_t sh1, uint32_t sh0, uint32_t ps,
                                                          uint32_t * __restrict__ sel1, uint32_t * __restrict__ sel0)
 {
@@ -380,15 +420,14 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
     {
         uint64_t * r = rec + sb * kRecWords;
         const uint64_t ones_before = r[0], ptr = r[1];
-        const bool stored = sb_store[sb] != 0; // its offsets do not fit the inline area: all of them go to the stream
-        const uint64_t start = sb * kRrrSB;
+        const uint64_t start = sb * kRecSB;
         uint64_t acc1 = ones_before, acc0 = start - ones_before; // arguments before the current block
         uint64_t j1 = (acc1 + S1 - 1) >> sh1, j0 = (acc0 + S0 - 1) >> sh0;
         uint64_t inl[kInlineWords] = {};
         unsigned rel = 0;
-        for (unsigned j = 0; j < kRrrK; ++j)
+        for (unsigned j = 0; j < kRecK; ++j)
         {
-            const uint64_t b = sb * kRrrK + j;
+            const uint64_t b = sb * kRecK + j;
             if (b >= n_blocks)
                 break;
             const uint64_t bstart = b * kRrrBS;
@@ -406,21 +445,22 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
                     --kk;
                     x &= x - 1;
                 }
-                if (stored)
-                {
-                    const uint64_t pos = ptr + rel;
-                    const unsigned off = (unsigned)(pos & 63);
-                    atomicOr(&stream[pos >> 6], (unsigned long long)(nr << off));
-                    if (off + len > 64)
-                        atomicOr(&stream[(pos >> 6) + 1], (unsigned long long)(nr >> (64 - off)));
-                }
+                // the record's offsets = its inline area followed by its stretch of the stream; a field may straddle the seam
                 if (rel < kInlineBits)
-                { // inline copy of the first 576 offset bits (a field may be cut by the boundary; readers only
-                  // use the inline area for fields that lie in it completely)
+                {
                     const unsigned w = rel >> 6, o = rel & 63;
                     inl[w] |= nr << o;
                     if (o + len > 64 && w + 1 < kInlineWords)
                         inl[w + 1] |= nr >> (64 - o);
+                }
+                if (rel + len > kInlineBits)
+                {
+                    const unsigned cut = rel < kInlineBits ? kInlineBits - rel : 0u; // bits of the field that went inline
+                    const uint64_t pos = ptr * 64 + (rel + cut - kInlineBits), val = nr >> cut;
+                    const unsigned off = (unsigned)(pos & 63);
+                    atomicOr(&stream[pos >> 6], (unsigned long long)(val << off));
+                    if (off + (len - cut) > 64)
+                        atomicOr(&stream[(pos >> 6) + 1], (unsigned long long)(val >> (64 - off)));
                 }
             }
             rel += len;
@@ -496,20 +536,21 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
 {
     h.device = device;
     const RrrTables & T = host_tables();
-    if (A.stream_bits >= (UINT64_C(1) << 48) || A.n_sb > UINT64_C(0xFFFFFFFF))
+    if (A.stream_bits >= (UINT64_C(1) << 48) || A.n_rec > UINT64_C(0xFFFFFFFF))
     {
         set_error("rrr_vector too large for the device record format");
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
-    std::vector<uint64_t> rec((size_t)A.n_sb * kRecWords, 0);
-    // the device keeps stream storage only for superblocks whose offsets overflow the record's inline area
-    std::vector<uint64_t> cptr((size_t)A.n_sb + 1, 0);
-    for (uint64_t s = 0; s < A.n_sb; ++s)
+    const uint64_t n_rec = A.n_rec;
+    std::vector<uint64_t> rec((size_t)n_rec * kRecWords, 0);
+    // the device keeps stream storage only for the offset bits beyond a record's inline area
+    std::vector<uint64_t> cptr((size_t)n_rec + 1, 0);
+    for (uint64_t s = 0; s < n_rec; ++s)
     {
-        const uint64_t len = A.sb_ptr[s + 1] - A.sb_ptr[s];
-        cptr[s + 1] = cptr[s] + (len > kInlineBits ? len : 0);
+        const uint64_t len = A.rec_ptr[s + 1] - A.rec_ptr[s];
+        cptr[s + 1] = cptr[s] + (len > kInlineBits ? (len - kInlineBits + 63) >> 6 : 0); // words
     }
-    std::vector<uint64_t> cstream(((std::max<uint64_t>(cptr[A.n_sb], 64) + 63) >> 6) + 2, 0);
+    std::vector<uint64_t> cstream(cptr[n_rec] + 3, 0);
     const uint64_t zeros = A.n_bits - A.ones;
     // sampling rate: smallest power of two >= 256 that keeps a directory within 2^21 samples
     uint32_t shb[2];
@@ -524,37 +565,38 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
         for (uint64_t s = s0; s < s1; ++s)
         {
             uint64_t * r = &rec[(size_t)s * kRecWords];
-            uint64_t ones_in = A.sb_rank[s + 1] - A.sb_rank[s];
-            r[0] = A.sb_rank[s];
+            uint64_t ones_in = A.rec_rank[s + 1] - A.rec_rank[s];
+            r[0] = A.rec_rank[s];
             r[1] = cptr[s] | (ones_in << 48);
-            memcpy(r + kRecClasses, &A.cls[(size_t)s * kRrrK], kRrrK);
             {
                 unsigned po[3], pb[3], ones = 0, bits = 0;
-                for (unsigned j = 0; j < 24; ++j)
+                for (unsigned j = 0; j < kRecK; ++j)
                 {
-                    unsigned k = A.cls[(size_t)s * kRrrK + j];
+                    const unsigned g = j / kGrp, u = j - g * kGrp;
+                    if (j && u == 0)
+                    {
+                        po[g - 1] = ones;
+                        pb[g - 1] = bits;
+                    }
+                    unsigned k = A.cls[(size_t)s * kRecK + j];
+                    r[kRecClasses + g] |= (uint64_t)k << (kClsW * u);
                     ones += k;
                     bits += T.space[k];
-                    if ((j & 7) == 7)
-                    {
-                        po[j >> 3] = ones;
-                        pb[j >> 3] = bits;
-                    }
                 }
                 r[2] = rrr_pack_prefix(po, pb);
             }
-            uint64_t avail = A.sb_ptr[s + 1] - A.sb_ptr[s];
+            uint64_t avail = A.rec_ptr[s + 1] - A.rec_ptr[s];
             if (avail > kInlineBits)
                 avail = kInlineBits;
             for (unsigned w = 0; w * 64 < avail; ++w)
             {
                 unsigned len = (unsigned)std::min<uint64_t>(64, avail - w * 64);
-                r[kRecInline + w] = read_bits(A.stream.data(), A.sb_ptr[s] + w * 64, len);
+                r[kRecInline + w] = read_bits(A.stream.data(), A.rec_ptr[s] + w * 64, len);
             }
             // select samples falling into this superblock: walk its blocks, decode only where needed
-            uint64_t start = s * kRrrSB;
-            uint64_t len_in = A.n_bits - start < kRrrSB ? A.n_bits - start : kRrrSB;
-            uint64_t h[2] = {start - A.sb_rank[s], A.sb_rank[s]};
+            uint64_t start = s * kRecSB;
+            uint64_t len_in = A.n_bits - start < kRecSB ? A.n_bits - start : kRecSB;
+            uint64_t h[2] = {start - A.rec_rank[s], A.rec_rank[s]};
             uint64_t c[2] = {len_in - ones_in, ones_in};
             for (int b = 0; b < 2; ++b)
             {
@@ -563,10 +605,10 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
                 uint64_t jj = (h[b] + S - 1) >> sh;
                 if (c[b] == 0 || (jj << sh) >= h[b] + c[b])
                     continue;
-                uint64_t acc = h[b], ptr = A.sb_ptr[s];
-                for (unsigned t = 0; t < kRrrK && (jj << sh) < h[b] + c[b]; ++t)
+                uint64_t acc = h[b], ptr = A.rec_ptr[s];
+                for (unsigned t = 0; t < kRecK && (jj << sh) < h[b] + c[b]; ++t)
                 {
-                    uint64_t blk = s * kRrrK + t;
+                    uint64_t blk = s * kRecK + t;
                     if (blk >= A.n_blocks)
                         break;
                     unsigned k = A.cls[blk], len = T.space[k];
@@ -593,11 +635,11 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     };
     {
         unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
-        if (A.n_sb < 4096)
+        if (n_rec < 4096)
             nt = 1;
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; ++t)
-            th.emplace_back(fill, A.n_sb * t / nt, A.n_sb * (t + 1) / nt);
+            th.emplace_back(fill, n_rec * t / nt, n_rec * (t + 1) / nt);
         for (auto & x : th)
             x.join();
     }
@@ -606,12 +648,12 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     SH_TRY(h.rec.alloc(rec.size() * 8));
     if (!rec.empty())
         SH_HIP(hipMemcpy(h.rec.p, rec.data(), rec.size() * 8, hipMemcpyHostToDevice));
-    for (uint64_t s = 0; s < A.n_sb; ++s) // (sequential: neighbouring superblocks share words of the compact stream)
-        for (uint64_t o = 0, len = cptr[s + 1] - cptr[s]; o < len; o += 64)
-        {
-            const unsigned l = (unsigned)std::min<uint64_t>(64, len - o);
-            write_bits(cstream.data(), cptr[s] + o, l, read_bits(A.stream.data(), A.sb_ptr[s] + o, l));
-        }
+    for (uint64_t s = 0; s < n_rec; ++s)
+    {
+        const uint64_t len = A.rec_ptr[s + 1] - A.rec_ptr[s];
+        for (uint64_t o = kInlineBits; o < len; o += 64)
+            cstream[cptr[s] + ((o - kInlineBits) >> 6)] = read_bits(A.stream.data(), A.rec_ptr[s] + o, (unsigned)std::min<uint64_t>(64, len - o));
+    }
     SH_TRY(h.stream.alloc(cstream.size() * 8));
     SH_HIP(hipMemcpy(h.stream.p, cstream.data(), cstream.size() * 8, hipMemcpyHostToDevice));
     SH_TRY(h.tables.alloc(sizeof(RrrTables)));
@@ -627,7 +669,7 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     h.view.sel[1] = h.sel[1].as<uint32_t>();
     h.view.n_bits = A.n_bits;
     h.view.n_blocks = A.n_blocks;
-    h.view.n_sb = A.n_sb;
+    h.view.n_sb = n_rec;
     h.view.ones = A.ones;
     h.view.sel_shift[0] = shb[0];
     h.view.sel_shift[1] = shb[1];
@@ -654,7 +696,7 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
     h.device = device;
     const RrrTables & T = host_tables();
     const uint64_t n_blocks = (n_bits + kRrrBS) / kRrrBS; // one all-zero dummy block when 63 | n (rrr_vector.hpp:163)
-    const uint64_t n_sb = (n_blocks + kRrrK - 1) / kRrrK;
+    const uint64_t n_sb = (n_blocks + kRecK - 1) / kRecK; // records
     if (n_sb > UINT64_C(0xFFFFFFFF))
     {
         set_error("rrr_vector too large for the device record format");
@@ -670,14 +712,10 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
     hipLaunchKernelGGL(k_rrr_enc_classes, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
                        h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(), sb_len.as<uint32_t>());
     SH_HIP(hipGetLastError());
-    uint64_t ones = 0, stream_bits = 0;
+    uint64_t ones = 0, stream_bits = 0; // stream_bits: total of sb_len
     SH_TRY(device_exclusive_scan_u32(sb_ones.as<uint32_t>(), n_sb, h.rec.as<uint64_t>(), kRecWords, &ones));
     SH_TRY(device_exclusive_scan_u32(sb_len.as<uint32_t>(), n_sb, h.rec.as<uint64_t>() + 1, kRecWords, &stream_bits));
-    if (stream_bits >= (UINT64_C(1) << 48))
-    {
-        set_error("rrr_vector offset stream too large for the device record format");
-        return SDSL_HIP_ERR_UNSUPPORTED;
-    }
+    const uint64_t stream_words = stream_bits; // (the scan summed words)
     const uint64_t zeros = n_bits - ones;
     uint32_t shb[2];
     rrr_sel_shifts(ones, zeros, shb);
@@ -685,11 +723,11 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
     while ((n_bits >> ps) >= UINT64_C(0xFFFFFFFF))
         ++ps;
     const uint64_t ns1 = (ones + (UINT64_C(1) << shb[1]) - 1) >> shb[1], ns0 = (zeros + (UINT64_C(1) << shb[0]) - 1) >> shb[0];
-    SH_TRY(h.stream.alloc((((std::max<uint64_t>(stream_bits, 64) + 63) >> 6) + 2) * 8, true));
+    SH_TRY(h.stream.alloc((stream_words + 3) * 8, true));
     SH_TRY(h.sel[1].alloc((ns1 + 2) * 4, true));
     SH_TRY(h.sel[0].alloc((ns0 + 2) * 4, true));
     hipLaunchKernelGGL(k_rrr_enc_offsets, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
-                       h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(), sb_len.as<uint32_t>(),
+                       h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(),
                        h.stream.as<unsigned long long>(), shb[1], shb[0], ps, h.sel[1].as<uint32_t>(), h.sel[0].as<uint32_t>());
     SH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_rrr_set_sentinels, dim3(1), dim3(1), 0, 0, h.sel[1].as<uint32_t>(), ns1, h.sel[0].as<uint32_t>(),
@@ -718,42 +756,65 @@ sdsl_hip_status rrr_serialize_host(const RrrHost & h, StreamWriter & w)
 {
     SH_HIP(hipSetDevice(h.device));
     const RrrView & rv = h.view;
-    const uint64_t n = rv.n_bits, nb = rv.n_blocks, nsb = rv.n_sb;
-    std::vector<uint64_t> rec((size_t)nsb * kRecWords);
-    if (nsb)
+    const uint64_t n = rv.n_bits, nb = rv.n_blocks, nrec = rv.n_sb;
+    std::vector<uint64_t> rec((size_t)nrec * kRecWords);
+    if (nrec)
         SH_HIP(hipMemcpy(rec.data(), rv.rec, rec.size() * 8, hipMemcpyDeviceToHost));
     // total offset bits = pointer of the last superblock + its own offsets
     const RrrTables & T = host_tables();
-    auto cls = [&](uint64_t b) -> unsigned { return (unsigned)(rec[(b / kRrrK) * kRecWords + kRecClasses + ((b % kRrrK) >> 3)] >> (8 * (b & 7))) & 0xFF; };
-    // SDSL's pointers (m_btnrp) and offset stream (m_btnr) from the classes, the inline areas and the compact stream
-    std::vector<uint64_t> sptr((size_t)nsb + 1, 0);
-    for (uint64_t sb = 0; sb < nsb; ++sb)
+    auto cls = [&](uint64_t b) -> unsigned
     {
-        uint64_t len = 0;
-        for (uint64_t b = sb * kRrrK; b < std::min(nb, (sb + 1) * kRrrK); ++b)
+        const unsigned j = (unsigned)(b % kRecK);
+        return rrr_cls(rec[(b / kRecK) * kRecWords + kRecClasses + j / kGrp], j % kGrp);
+    };
+    // SDSL's samples every 32 blocks (m_rank, m_btnrp) and its offset stream (m_btnr) from the classes, the inline areas and
+    // the overflow stream of the 36-block records
+    const uint64_t nsb = (nb + kRrrK - 1) / kRrrK;
+    std::vector<uint64_t> sptr((size_t)nsb + 1, 0), srank((size_t)nsb + 1, 0);
+    {
+        uint64_t len = 0, ones = 0;
+        for (uint64_t b = 0; b < nb; ++b)
+        {
+            if (b % kRrrK == 0)
+            {
+                sptr[b / kRrrK] = len;
+                srank[b / kRrrK] = ones;
+            }
             len += T.space[cls(b)];
-        sptr[sb + 1] = sptr[sb] + len;
+            ones += cls(b);
+        }
+        sptr[nsb] = len;
+        srank[nsb] = ones;
     }
     const uint64_t stream_bits = sptr[nsb];
     const uint64_t btnr_bits = std::max<uint64_t>(stream_bits, 64); // rrr_vector.hpp:183
     std::vector<uint64_t> btnr(((btnr_bits + 63) >> 6) + 1, 0);
     {
-        const uint64_t cbits = nsb ? (rec[(nsb - 1) * kRecWords + 1] & ((UINT64_C(1) << 48) - 1))
-                                         + (sptr[nsb] - sptr[nsb - 1] > kInlineBits ? sptr[nsb] - sptr[nsb - 1] : 0)
-                                   : 0;
-        std::vector<uint64_t> cs(((std::max<uint64_t>(cbits, 64) + 63) >> 6) + 1, 0);
-        SH_HIP(hipMemcpy(cs.data(), rv.stream, ((std::max<uint64_t>(cbits, 64) + 63) >> 6) * 8, hipMemcpyDeviceToHost));
-        for (uint64_t sb = 0; sb < nsb; ++sb)
+        std::vector<uint64_t> rlen((size_t)nrec, 0); // offset bits per record
+        for (uint64_t b = 0; b < nb; ++b)
+            rlen[b / kRecK] += T.space[cls(b)];
+        const uint64_t cwords = nrec ? (rec[(nrec - 1) * kRecWords + 1] & ((UINT64_C(1) << 48) - 1))
+                                           + (rlen[nrec - 1] > kInlineBits ? (rlen[nrec - 1] - kInlineBits + 63) >> 6 : 0)
+                                     : 0;
+        std::vector<uint64_t> cs(cwords + 2, 0);
+        if (cwords)
+            SH_HIP(hipMemcpy(cs.data(), rv.stream, cwords * 8, hipMemcpyDeviceToHost));
+        uint64_t at = 0;
+        for (uint64_t r = 0; r < nrec; ++r)
         {
-            const uint64_t len = sptr[sb + 1] - sptr[sb];
-            const bool stored = len > kInlineBits;
-            const uint64_t * src = stored ? cs.data() : &rec[sb * kRecWords + kRecInline];
-            const uint64_t base = stored ? rec[sb * kRecWords + 1] & ((UINT64_C(1) << 48) - 1) : 0;
-            for (uint64_t o = 0; o < len; o += 64)
+            const uint64_t len = rlen[r], n_in = std::min<uint64_t>(len, kInlineBits);
+            for (uint64_t o = 0; o < n_in; o += 64)
+            {
+                const unsigned l = (unsigned)std::min<uint64_t>(64, n_in - o);
+                write_bits(btnr.data(), at + o, l, read_bits(&rec[r * kRecWords + kRecInline], o, l));
+            }
+            const uint64_t base = rec[r * kRecWords + 1] & ((UINT64_C(1) << 48) - 1);
+            for (uint64_t o = kInlineBits; o < len; o += 64)
             {
                 const unsigned l = (unsigned)std::min<uint64_t>(64, len - o);
-                write_bits(btnr.data(), sptr[sb] + o, l, read_bits(src, base + o, l));
+                write_bits(btnr.data(), at + o, l, read_bits(cs.data(), base * 64 + (o - kInlineBits), l));
             }
+            at += len;
         }
     }
     PackedBuilder bt(nb, 6), btnrp(nsb, (uint8_t)(hi64(stream_bits) + 1)), invert(nsb, 1);
@@ -778,7 +839,7 @@ sdsl_hip_status rrr_serialize_host(const RrrHost & h, StreamWriter & w)
         const bool dummy_only = i * kRrrBS >= n; // superblock that starts with the dummy block: never initialised by SDSL
         btnrp.set(s, dummy_only ? 0 : sptr[s]);
         if (s + 1 < n_rank)
-            rank.set(s, rec[s * kRecWords]);
+            rank.set(s, srank[s]);
     }
     if (n_rank)
         rank.set(n_rank - 1, rv.ones); // the last entry always holds the total (:268)
@@ -797,14 +858,10 @@ void rrr_arrays_to_words(const RrrArrays & A, std::vector<uint64_t> & words)
 {
     const RrrTables & T = host_tables();
     words.assign(((A.n_bits + 63) >> 6) + 2, 0);
-    for (uint64_t s = 0; s < A.n_sb; ++s)
     {
-        uint64_t ptr = A.sb_ptr[s];
-        for (unsigned j = 0; j < kRrrK; ++j)
+        uint64_t ptr = 0;
+        for (uint64_t b = 0; b < A.n_blocks; ++b)
         {
-            uint64_t b = s * kRrrK + j;
-            if (b >= A.n_blocks)
-                break;
             unsigned k = A.cls[b], len = T.space[k];
             uint64_t bits = decode_block_host(T, k, read_bits(A.stream.data(), ptr, len));
             ptr += len;

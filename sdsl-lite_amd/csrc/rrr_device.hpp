@@ -7,11 +7,18 @@
 namespace sdslhip {
 
 constexpr unsigned kRrrBS = 63;
-constexpr unsigned kRrrK = 32;
-constexpr uint64_t kRrrSB = (uint64_t)kRrrBS * kRrrK; // 2016 bits per superblock
+constexpr unsigned kRrrK = 32; // SDSL's t_k: blocks per sample of the SERIALISED form (m_rank, m_btnrp, m_invert)
+constexpr uint64_t kRrrSB = (uint64_t)kRrrBS * kRrrK; // 2016 bits per SDSL superblock (parser / serialiser only)
+// The device groups 36 blocks per record, not 32: a 128-byte record per 2016 bits costs 0.51 bits/bit before a single
+// offset is stored; per 2268 bits it costs 0.45, and at 5 % density the ~585 offset bits of 36 blocks still (almost) fit
+// the 576 inline bits.  Four groups of nine classes, 7 bits each (9 x 7 = 63 bits of a word).
+constexpr unsigned kRecK = 34;
+constexpr unsigned kGrp = 9;   // blocks per class word
+constexpr unsigned kClsW = 7;  // bits per class field
+constexpr uint64_t kRecSB = (uint64_t)kRrrBS * kRecK; // 2268 bits per record
 constexpr unsigned kRecWords = 16;
-constexpr unsigned kRecClasses = 3;  // words 3..6: the 32 block classes as bytes
-constexpr unsigned kRecInline = 7;   // words 7..15: inline copy of the head of the superblock's offsets
+constexpr unsigned kRecClasses = 3;  // words 3..6: the 36 block classes, nine 7-bit fields per word
+constexpr unsigned kRecInline = 7;   // words 7..15: the first 576 bits of the record's offsets (the rest: RrrView::stream)
 constexpr unsigned kInlineWords = kRecWords - kRecInline;
 constexpr unsigned kInlineBits = 64 * kInlineWords; // 576
 constexpr unsigned kRrrBlock = 512; // threads per block (LDS holds the 32 KiB binomial table)
@@ -27,8 +34,8 @@ struct RrrTables
 
 struct RrrView
 {
-    const uint64_t * rec;    // n_sb * 16 words
-    const uint64_t * stream; // offset stream (SDSL's m_btnr), padded by one word
+    const uint64_t * rec;    // n_sb * 16 words (n_sb = number of RECORDS, 36 blocks each)
+    const uint64_t * stream; // per record the offset bits beyond its inline area, in whole words; padded by two words
     const RrrTables * tables;
     const uint32_t * sel[2]; // select directories: (position of the j<<shift-th argument) >> pshift, + sentinel
     uint64_t n_bits, n_blocks, n_sb, ones;
@@ -126,49 +133,78 @@ __device__ __forceinline__ void rrr_stage_tables(RrrTables * lds, const RrrTable
 }
 
 // ---- record accessors ------------------------------------------------------------------------------
-// word 2 of a record: for g = 1..3 the offset bits and the ones in blocks [0, 8g) of the superblock, packed as
-// [bits | ones << w] at bit 21*(g-1) with field width w = 10 (g = 1, 2) or 11 (g = 3).
+// word 2 of a record: for g = 1..3 the offset bits and the ones in blocks [0, 9g) of the record, packed as
+// [bits | ones << w] with field width w = 10 at bit 0 (g = 1: <= 9 * 60, 9 * 63), w = 11 at bit 20 (g = 2) and at bit 42 (g = 3).
 SH_HD uint64_t rrr_pack_prefix(const unsigned ones[3], const unsigned bits[3])
 {
-    return (uint64_t)bits[0] | ((uint64_t)ones[0] << 10) | ((uint64_t)bits[1] << 21) | ((uint64_t)ones[1] << 31)
+    return (uint64_t)bits[0] | ((uint64_t)ones[0] << 10) | ((uint64_t)bits[1] << 20) | ((uint64_t)ones[1] << 31)
            | ((uint64_t)bits[2] << 42) | ((uint64_t)ones[2] << 53);
 }
 SH_HD void rrr_prefix(uint64_t P, unsigned g, unsigned & ones, unsigned & bits)
 { // g in [0,3]
-    const unsigned w = g == 3 ? 11u : 10u, m = (1u << w) - 1;
-    const uint64_t x = g ? P >> (21 * (g - 1)) : 0;
+    const unsigned w = g <= 1 ? 10u : 11u, m = (1u << w) - 1;
+    const uint64_t x = g == 0 ? 0 : (g == 1 ? P : P >> (g == 2 ? 20 : 42));
     bits = (unsigned)x & m;
     ones = (unsigned)(x >> w) & m;
 }
 
-// offset field of `len` bits at relative position `rel` inside superblock record `r`
+// class fields of a class word
+SH_HD unsigned rrr_cls(uint64_t cw, unsigned u)
+{
+    return (unsigned)(cw >> (kClsW * u)) & 0x7Fu;
+}
+SH_HD uint64_t rrr_cls_below(uint64_t cw, unsigned u)
+{ // the fields of blocks 0..u-1
+    return cw & ((UINT64_C(1) << (kClsW * u)) - 1);
+}
+constexpr uint64_t kCls63 = UINT64_C(0x3F) * ((UINT64_C(1) << 0) | (UINT64_C(1) << 7) | (UINT64_C(1) << 14) | (UINT64_C(1) << 21) | (UINT64_C(1) << 28)
+                                               | (UINT64_C(1) << 35) | (UINT64_C(1) << 42) | (UINT64_C(1) << 49) | (UINT64_C(1) << 56)); // 63 in every field
+
+// offset field of `len` bits at relative position `rel` of record `r`: the record's offsets are the words of its inline
+// area (nine) followed by the words of its stretch of the stream (from word `ptr` on: a stretch starts at a word boundary,
+// so the seam needs no special case — a field simply takes its two words from wherever they live)
 __device__ __forceinline__ uint64_t rrr_field(const RrrView & v, const uint64_t * r, uint64_t ptr, unsigned rel,
                                               unsigned len)
 {
-    if (rel + len <= kInlineBits)
-        return read_bits(r + kRecInline, rel, len); // same 128-byte line as the header
-    return read_bits(v.stream, ptr + rel, len);
+    if (len == 0)
+        return 0;
+    const unsigned w = rel >> 6, o = rel & 63;
+    const uint64_t * far = v.stream + ptr - kInlineWords; // word w of the record's offsets, w >= 9
+    const uint64_t * p0 = w < kInlineWords ? r + kRecInline + w : far + w;
+    uint64_t x = *p0 >> o;
+    if (o + len > 64)
+    {
+        const uint64_t * p1 = w + 1 < kInlineWords ? r + kRecInline + w + 1 : far + w + 1;
+        x |= *p1 << (64 - o);
+    }
+    return x & lo_set(len);
 }
 
-// sum of the eight bytes of x (each <= 63)
-SH_HD unsigned sum_bytes8(uint64_t x)
+// sum of the nine 7-bit fields of x (each <= 63)
+SH_HD unsigned sum_fields9(uint64_t x)
 {
-    uint64_t t = (x & UINT64_C(0x00FF00FF00FF00FF)) + ((x >> 8) & UINT64_C(0x00FF00FF00FF00FF));
-    return (unsigned)((t * UINT64_C(0x0001000100010001)) >> 48);
+    constexpr uint64_t M = UINT64_C(0x7F) * ((UINT64_C(1) << 0) | (UINT64_C(1) << 14) | (UINT64_C(1) << 28) | (UINT64_C(1) << 42) | (UINT64_C(1) << 56));
+    const uint64_t t = (x & M) + ((x >> 7) & M); // five 14-bit lanes, each <= 126
+    const unsigned lo = (unsigned)t, hi = (unsigned)(t >> 28); // lanes 0, 1 | lanes 2, 3
+    return (lo & 0x3FFFu) + ((lo >> 14) & 0x3FFFu) + (hi & 0x3FFFu) + ((hi >> 14) & 0x3FFFu) + (unsigned)(t >> 56);
 }
 
-// sum of space[] over the eight class bytes of m (class 0 adds nothing: space[0] == 0)
-__device__ __forceinline__ unsigned rrr_space_sum8(const RrrTables * T, uint64_t m)
+// sum of space[] over the nine class fields of m (class 0 adds nothing: space[0] == 0)
+__device__ __forceinline__ unsigned rrr_space_sum9(const RrrTables * T, uint64_t m)
 {
+    const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 28); // fields 0..3 | fields 4..8
     unsigned bits = 0;
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-        bits += T->space[(unsigned)(m >> (8 * t)) & 0xFF];
+    for (int t = 0; t < 4; ++t)
+        bits += T->space[(lo >> (7 * t)) & 0x7Fu];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+        bits += T->space[(t < 4 ? (hi >> (7 * t)) : (unsigned)(m >> 56)) & 0x7Fu];
     return bits;
 }
 
 // ---- rank / access ---------------------------------------------------------------------------------
-// One query per lane, no cooperation: the record is laid out so that a lane needs 40 bytes of it (header,
+// One query per lane, no cooperation: the record is laid out so that a lane needs 32 bytes of it (two header words,
 // prefix word, ONE class word) plus the offset field.
 struct RankTail
 {
@@ -179,21 +215,20 @@ struct RankTail
 
 __device__ __forceinline__ RankTail rrr_rank_head(const RrrView & v, const RrrTables * T, uint64_t i)
 {
-    const uint64_t blk = i / kRrrBS;
     RankTail t;
-    t.off = (unsigned)(i - blk * kRrrBS);
-    const uint64_t sb = blk / kRrrK;
-    const unsigned j = (unsigned)(blk % kRrrK), g = j >> 3, u = j & 7;
+    const uint64_t sb = i / kRecSB; // one 64-bit division; everything below it is 32-bit
+    const unsigned in_sb = (unsigned)(i - sb * kRecSB), j = in_sb / kRrrBS, g = j / kGrp, u = j - g * kGrp;
+    t.off = in_sb - j * kRrrBS;
     const uint64_t * r = (const uint64_t *)__builtin_assume_aligned(v.rec + sb * kRecWords, 128);
     const uint64_t r0 = r[0], r1 = r[1], P = r[2];
     const uint64_t cw = r[kRecClasses + g];
     unsigned ones, bits;
     rrr_prefix(P, g, ones, bits);
-    const uint64_t below = cw & lo_set(8 * u);
-    ones += sum_bytes8(below);
-    bits += rrr_space_sum8(T, below);
+    const uint64_t below = rrr_cls_below(cw, u);
+    ones += sum_fields9(below);
+    bits += rrr_space_sum9(T, below);
     t.rank = r0 + ones;
-    t.k = (unsigned)(cw >> (8 * u)) & 0xFF;
+    t.k = rrr_cls(cw, u);
     t.nr = rrr_field(v, r, r1 & ((UINT64_C(1) << 48) - 1), bits, T->space[t.k]);
     return t;
 }
@@ -284,7 +319,7 @@ __device__ __forceinline__ bool rrr_sel_probe(const RrrView & v, RrrSelState & s
     else
         p = sel_interpolate(st.lo_pos, span, st.k0 - st.lo_cnt, st.hi_cnt - st.lo_cnt, v.sel_shift[BIT]);
     ++st.tries;
-    uint64_t g = p / kRrrSB;
+    uint64_t g = p / kRecSB;
     if (g >= v.n_sb)
         g = v.n_sb - 1;
     const uint64_t * r = (const uint64_t *)__builtin_assume_aligned(v.rec + g * kRecWords, 128);
@@ -299,8 +334,8 @@ __device__ __forceinline__ bool rrr_sel_probe(const RrrView & v, RrrSelState & s
     h.c2 = r[kRecClasses + 2];
     h.c3 = r[kRecClasses + 3];
     const uint64_t ones_in = (h.r1 >> 48) & 0xFFF;
-    const uint64_t start = g * kRrrSB;
-    const uint64_t len_in = v.n_bits - start < kRrrSB ? v.n_bits - start : kRrrSB;
+    const uint64_t start = g * kRecSB;
+    const uint64_t len_in = v.n_bits - start < kRecSB ? v.n_bits - start : kRecSB;
     h.before = BIT ? r0 : start - r0;
     const uint64_t c = BIT ? ones_in : len_in - ones_in;
     if (st.k0 < h.before)
@@ -311,19 +346,26 @@ __device__ __forceinline__ bool rrr_sel_probe(const RrrView & v, RrrSelState & s
     }
     if (st.k0 >= h.before + c)
     {
-        st.lo_pos = start + kRrrSB;
+        st.lo_pos = start + kRecSB;
         st.lo_cnt = h.before + c;
         return false;
     }
     return true;
 }
 
-template <int BIT>
-__device__ __forceinline__ uint64_t rrr_sel_finish(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
+// after the hit: the block that holds the argument and where its offset field lies
+struct RrrSelLoc
 {
-    const uint64_t * r = h.r;
-    const uint64_t g = h.g, before = h.before, r1 = h.r1, P = h.P, c0 = h.c0, c1 = h.c1, c2 = h.c2, c3 = h.c3;
-    // inside superblock g: the group of 8 blocks.  Zeros before block 8q are 504q - ones (every block in front of
+    uint64_t bstart; // first position of the block
+    uint64_t ptr;    // the record's stretch of the overflow stream
+    unsigned k, rel, want; // class, position of the offset field among the record's offsets, rank of the argument inside the block
+};
+
+template <int BIT>
+__device__ __forceinline__ RrrSelLoc rrr_sel_locate(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
+{
+    const uint64_t g = h.g, before = h.before, P = h.P, c0 = h.c0, c1 = h.c1, c2 = h.c2, c3 = h.c3;
+    // inside record g: the group of 9 blocks.  Zeros before block 9q are 567q - ones (every block in front of
     // the one that holds an existing argument is a complete 63-bit block).
     unsigned want = (unsigned)(k0 - before);
     unsigned o[4], b[4];
@@ -334,60 +376,94 @@ __device__ __forceinline__ uint64_t rrr_sel_finish(const RrrView & v, const RrrT
     unsigned q = 0;
 #pragma unroll
     for (unsigned t = 1; t < 4; ++t)
-        q += want >= (BIT ? o[t] : 8 * kRrrBS * t - o[t]) ? 1u : 0u;
+        q += want >= (BIT ? o[t] : kGrp * kRrrBS * t - o[t]) ? 1u : 0u;
     unsigned rel = q == 0 ? 0u : (q == 1 ? b[1] : (q == 2 ? b[2] : b[3]));
     const unsigned oq = q == 0 ? 0u : (q == 1 ? o[1] : (q == 2 ? o[2] : o[3]));
-    want -= BIT ? oq : 8 * kRrrBS * q - oq;
+    want -= BIT ? oq : kGrp * kRrrBS * q - oq;
     const uint64_t cw = q == 0 ? c0 : (q == 1 ? c1 : (q == 2 ? c2 : c3));
-    // arguments per block of the group as bytes; the block holding the argument is complete or the vector's last
+    // arguments per block of the group as 7-bit fields; the block holding the argument is complete or the vector's last
     // block, and blocks behind the end of the vector must not offer zeros
     uint64_t args = cw;
     if (!BIT)
     {
-        const uint64_t b0 = g * kRrrK + 8 * (uint64_t)q;
-        if ((b0 + 8) * kRrrBS <= v.n_bits)
-            args = UINT64_C(0x3F3F3F3F3F3F3F3F) - cw;
+        const uint64_t b0 = g * kRecK + kGrp * (uint64_t)q;
+        if ((b0 + kGrp) * kRrrBS <= v.n_bits)
+            args = kCls63 - cw;
         else
         {
             args = 0;
-            for (unsigned t = 0; t < 8; ++t)
+            for (unsigned t = 0; t < kGrp; ++t)
             {
                 const uint64_t bstart = (b0 + t) * kRrrBS;
                 const unsigned blen =
                     bstart >= v.n_bits ? 0u : (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS);
-                args |= (uint64_t)(blen - ((unsigned)(cw >> (8 * t)) & 0xFF)) << (8 * t);
+                args |= (uint64_t)(blen - rrr_cls(cw, t)) << (kClsW * t);
             }
         }
     }
-    // first block u with want < a_0 + ... + a_u: half, then quarter sums as bytes (4 * 63 < 256)
-    const unsigned lo4 = (unsigned)args, hi4 = (unsigned)(args >> 32);
-    const unsigned s_lo = ((lo4 & 0x00FF00FFu) + ((lo4 >> 8) & 0x00FF00FFu));
-    const unsigned sum_lo = (s_lo + (s_lo >> 16)) & 0x3FF;
-    unsigned u = 0, half = lo4;
-    if (want >= sum_lo)
+    // first block u with want < a_0 + ... + a_u: the sum of the first four fields picks a half, three running sums the
+    // block inside it (the ninth field can never be passed: the argument lies in this group)
+    unsigned u = 0;
     {
-        want -= sum_lo;
-        u = 4;
-        half = hi4;
-    }
-    const unsigned pre = half * 0x01010100u; // byte t: a_0 + ... + a_{t-1}
-    unsigned t4 = 0;
+        const unsigned lo = (unsigned)args & 0x0FFFFFFFu, hi = (unsigned)(args >> 28); // fields 0..3 | 4..7 (+ 4 bits of 8)
+        const unsigned pair = (lo & 0x001FC07Fu) + ((lo >> 7) & 0x001FC07Fu); // a0 + a1 | a2 + a3 in 14-bit lanes
+        const unsigned sum4 = (pair & 0x3FFFu) + (pair >> 14);
+        unsigned half = lo;
+        if (want >= sum4)
+        {
+            want -= sum4;
+            u = 4;
+            half = hi;
+        }
+        unsigned acc = 0, sub = 0, t4 = 0;
 #pragma unroll
-    for (unsigned t = 1; t < 4; ++t)
-        t4 += want >= ((pre >> (8 * t)) & 0xFF) ? 1u : 0u;
-    want -= (pre >> (8 * t4)) & 0xFF;
-    u += t4;
-    rel += rrr_space_sum8(T, cw & lo_set(8 * u));
-    const unsigned k = (unsigned)(cw >> (8 * u)) & 0xFF;
-    const uint64_t bstart = (g * kRrrK + 8 * (uint64_t)q + u) * kRrrBS;
-    const uint64_t nr = rrr_field(v, r, r1 & ((UINT64_C(1) << 48) - 1), rel, T->space[k]);
-    uint64_t bits = rrr_decode_block(T, k, nr);
+        for (unsigned t = 0; t < 4; ++t)
+        { // (in the upper half the fourth step compares with a4 + .. + a7: passing it means block 8)
+            acc += (half >> (7 * t)) & 0x7Fu;
+            const bool ge = want >= acc;
+            t4 += ge ? 1u : 0u;
+            sub = ge ? acc : sub;
+        }
+        want -= sub;
+        u += t4;
+    }
+    RrrSelLoc L;
+    L.rel = rel + rrr_space_sum9(T, rrr_cls_below(cw, u));
+    L.k = rrr_cls(cw, u);
+    L.bstart = (g * kRecK + kGrp * (uint64_t)q + u) * kRrrBS;
+    L.ptr = h.r1 & ((UINT64_C(1) << 48) - 1);
+    L.want = want;
+    return L;
+}
+
+// does the offset field of the located block reach into the overflow stream (a second, random fetch)?
+__device__ __forceinline__ bool rrr_sel_in_stream(const RrrTables * T, const RrrSelLoc & L)
+{
+    return L.rel + T->space[L.k] > kInlineBits;
+}
+// the field of a block for which rrr_sel_in_stream is false
+__device__ __forceinline__ uint64_t rrr_field_inline(const uint64_t * r, unsigned rel, unsigned len)
+{
+    return read_bits(r + kRecInline, rel, len);
+}
+
+template <int BIT>
+__device__ __forceinline__ uint64_t rrr_sel_decode(const RrrView & v, const RrrTables * T, const RrrSelLoc & L, uint64_t nr)
+{
+    uint64_t bits = rrr_decode_block(T, L.k, nr);
     if (!BIT)
     {
-        const unsigned blen = (unsigned)(v.n_bits - bstart < kRrrBS ? v.n_bits - bstart : kRrrBS);
+        const unsigned blen = (unsigned)(v.n_bits - L.bstart < kRrrBS ? v.n_bits - L.bstart : kRrrBS);
         bits = ~bits & lo_set(blen);
     }
-    return bstart + sel64(bits, want + 1);
+    return L.bstart + sel64(bits, L.want + 1);
+}
+
+template <int BIT>
+__device__ __forceinline__ uint64_t rrr_sel_finish(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
+{
+    const RrrSelLoc L = rrr_sel_locate<BIT>(v, T, k0, h);
+    return rrr_sel_decode<BIT>(v, T, L, rrr_field(v, h.r, L.ptr, L.rel, T->space[L.k]));
 }
 
 template <int BIT>
