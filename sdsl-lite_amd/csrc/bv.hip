@@ -824,6 +824,15 @@ sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, ui
         // the scratch belongs to the handle; queries stay safe to issue from several threads / on several streams: the
         // host side is serialised here, the device side by an event the next user of the scratch waits for
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
+        if (mode < 0)
+        { // automatic: only a batch that is spread over the vector goes through the passes (a read-back: synchronises s)
+            bool spread = true;
+            if (!h.spread_probe.p)
+                SH_TRY(h.spread_probe.alloc(64));
+            SH_TRY(bv_sorted_rank_is_spread(h.view, d_idx, n, s, h.spread_probe.p, spread));
+            if (!spread)
+                return bv_launch_rank(h.view, bit, d_idx, n, d_out, s);
+        }
         const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
         const size_t need = bv_sorted_rank_scratch_bytes(h.view, pass);
         if (h.scratch_ev)
@@ -857,7 +866,13 @@ sdsl_hip_status bv_select_dispatch(BvHost & h, int bit, const uint64_t * d_i, ui
     {
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
         SH_TRY(bv_select_sorted_prepare(h, bit)); // first use: the bucket boundaries (one small batch, synchronous)
-        const bool want = mode > 0 ? h.sel_plan[bit].ok : bv_sorted_select_applicable(h, bit, n);
+        bool want = mode > 0 ? h.sel_plan[bit].ok : bv_sorted_select_applicable(h, bit, n);
+        if (want && mode < 0)
+        { // automatic: only a batch whose arguments are spread over the vector (a read-back: synchronises s)
+            if (!h.spread_probe.p)
+                SH_TRY(h.spread_probe.alloc(64));
+            SH_TRY(bv_sorted_select_is_spread(h, bit, d_i, n, s, h.spread_probe.p, want));
+        }
         if (want)
         {
             const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
@@ -1161,6 +1176,7 @@ sdsl_hip_status sdsl_hip_bv_release_scratch(sdsl_hip_bv_t bv)
         bv->h.scratch_ev = nullptr;
     }
     bv->h.sort_scratch.release();
+    bv->h.spread_probe.release();
     return SDSL_HIP_OK;
 }
 

@@ -17,6 +17,7 @@ struct BvHost
     DevBuf sel[2]; // select sample directories
     DevBuf lmask[2], lidx[2], lpos[2]; // sparse stretches of the select directories (BvView::lmask ...)
     DevBuf sort_scratch; // working memory of the bucketed batch rank (bv_sorted.hip), grown on demand
+    DevBuf spread_probe; // two words the spread sample of the automatic dispatch writes (bv_sorted.hip)
     hipEvent_t scratch_ev = nullptr; // recorded behind the last user of sort_scratch
     struct SelPlan // buckets of the bucketed batch select (bv_sorted.hip), built on first use
     {
@@ -28,7 +29,7 @@ struct BvHost
     std::mutex scratch_mutex;
     size_t device_bytes() const
     {
-        size_t b = lines.bytes + sel[0].bytes + sel[1].bytes + sort_scratch.bytes;
+        size_t b = lines.bytes + sel[0].bytes + sel[1].bytes + sort_scratch.bytes + spread_probe.bytes;
         for (int i = 0; i < 2; ++i)
             b += lmask[i].bytes + lidx[i].bytes + lpos[i].bytes + sel_plan[i].bnd.bytes;
         return b;
@@ -52,11 +53,15 @@ sdsl_hip_status bv_new_replica(const BvHost & src, int device, sdsl_hip_bv_t * o
 std::string bv_sorted_last_phases();
 bool bv_sorted_rank_possible(const BvView & v);
 bool bv_sorted_rank_applicable(const BvView & v, uint64_t n);
+sdsl_hip_status bv_sorted_rank_is_spread(const BvView & v, const uint64_t * d_idx, uint64_t n, hipStream_t s, void * scratch,
+                                         bool & spread);
 size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n);
 sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                                       hipStream_t s, void * scratch, size_t scratch_bytes);
 sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit);
 bool bv_sorted_select_applicable(const BvHost & h, int bit, uint64_t n);
+sdsl_hip_status bv_sorted_select_is_spread(const BvHost & h, int bit, const uint64_t * d_idx, uint64_t n, hipStream_t s,
+                                           void * scratch, bool & spread);
 sdsl_hip_status bv_launch_select_sorted(BvHost & h, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out, hipStream_t s,
                                         void * scratch, size_t scratch_bytes);
 sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out,

@@ -1241,6 +1241,12 @@ SrKernels sr_kernels(unsigned per_cu)
 
 } // namespace
 
+void bv_sorted_clear_phases()
+{
+    std::lock_guard<std::mutex> lock(g_phase_mutex);
+    g_last_phases.clear();
+}
+
 std::string bv_sorted_last_phases()
 {
     std::lock_guard<std::mutex> lock(g_phase_mutex);
@@ -1277,6 +1283,86 @@ struct SelectPlan
     uint64_t total = 0;
 };
 
+// digits and key widths of a pass over `cnt` positions (everything but the tiling)
+static void sr_fill_geom(SrGeom & g, const BvView & v, int op, const SelectPlan & sp, uint64_t cnt)
+{
+    g.n = cnt;
+    g.n_bits = v.n_bits;
+    g.n_lines = v.n_lines;
+    g.op = (uint32_t)op;
+    unsigned f = 0; // bits of a slice / bucket index
+    if (op == 0)
+    {
+        unsigned lb = 0; // bits of a line index
+        while ((v.n_lines - 1) >> lb)
+            ++lb;
+        f = lb > kSliceLog ? lb - kSliceLog : 0;
+        g.kb = kKey2Bits;
+        g.B = 0;
+        g.bs = 0;
+        g.binv = 0;
+        g.total = 0;
+    }
+    else
+    {
+        while (sp.nf > (1u << f))
+            ++f;
+        g.kb = sp.bs + 4; // B <= 15 << bs
+        g.B = sp.bm << sp.bs;
+        g.bs = sp.bs;
+        g.binv = (uint32_t)(((UINT64_C(1) << 32) + sp.bm - 1) / sp.bm);
+        g.total = sp.total;
+    }
+    g.d1 = f < 8 ? f : 8;
+    g.d2 = f - g.d1;
+    g.small = v.n_bits < (UINT64_C(1) << 38);
+}
+
+// How spread out is a batch?  256 runs of 16 consecutive queries, evenly spaced over the batch: the number of DISTINCT slices
+// (rank) / buckets (select) they touch.  Uniformly random positions on a large vector touch about as many slices as there
+// are samples; a batch confined to a window, or a sorted one (every run inside one slice), touches few — and then the
+// direct kernel, whose fetches hit in L2 / Infinity Cache, beats seven streaming passes (2^20-bit window on 2^34 bits:
+// 9.7 ms against 21.7 ms per 10^9 queries).
+constexpr unsigned kSampleRuns = 256, kSampleRun = 16;
+__global__ __launch_bounds__(1024) void k_sr_sample_spread(SrGeom g, const uint64_t * __restrict__ idx, uint32_t * __restrict__ out)
+{
+    __shared__ uint32_t bm[2048]; // one bit per slice / bucket (at most 2^16)
+    __shared__ unsigned n_valid, n_distinct;
+    const unsigned t = threadIdx.x;
+    for (unsigned i = t; i < 2048; i += 1024)
+        bm[i] = 0;
+    if (t == 0)
+        n_valid = n_distinct = 0;
+    __syncthreads();
+    const uint64_t step = g.n / kSampleRuns;
+    for (unsigned j = t; j < kSampleRuns * kSampleRun; j += 1024)
+    {
+        const uint64_t q = step * (j / kSampleRun) + (j % kSampleRun);
+        if (q >= g.n)
+            continue;
+        unsigned dig;
+        uint32_t key;
+        sr_key1(idx[q], g, dig, key);
+        if (key == kBad)
+            continue;
+        const unsigned id = (dig | ((key >> g.kb) << g.d1)) & 0xFFFFu;
+        atomicOr(&bm[id >> 5], 1u << (id & 31));
+        atomicAdd(&n_valid, 1u);
+    }
+    __syncthreads();
+    unsigned c = 0;
+    for (unsigned i = t; i < 2048; i += 1024)
+        c += (unsigned)__builtin_popcount(bm[i]);
+    if (c)
+        atomicAdd(&n_distinct, c);
+    __syncthreads();
+    if (t == 0)
+    {
+        out[0] = n_distinct;
+        out[1] = n_valid;
+    }
+}
+
 sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                        hipStream_t s, void * scratch, size_t scratch_bytes)
 {
@@ -1293,39 +1379,10 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
     {
         const uint64_t cnt = n - done < kMaxPass ? n - done : kMaxPass;
         SrGeom g;
-        g.n = cnt;
-        g.n_bits = v.n_bits;
-        g.n_lines = v.n_lines;
-        g.op = (uint32_t)op;
-        unsigned f = 0; // bits of a slice / bucket index
-        if (op == 0)
-        {
-            unsigned lb = 0; // bits of a line index
-            while ((v.n_lines - 1) >> lb)
-                ++lb;
-            f = lb > kSliceLog ? lb - kSliceLog : 0;
-            g.kb = kKey2Bits;
-            g.B = 0;
-            g.bs = 0;
-            g.binv = 0;
-            g.total = 0;
-        }
-        else
-        {
-            while (sp.nf > (1u << f))
-                ++f;
-            g.kb = sp.bs + 4; // B <= 15 << bs
-            g.B = sp.bm << sp.bs;
-            g.bs = sp.bs;
-            g.binv = (uint32_t)(((UINT64_C(1) << 32) + sp.bm - 1) / sp.bm);
-            g.total = sp.total;
-        }
-        g.d1 = f < 8 ? f : 8;
-        g.d2 = f - g.d1;
+        sr_fill_geom(g, v, op, sp, cnt);
         g.tile = K.threads * K.per;
         g.tiles1 = (uint32_t)((cnt + g.tile - 1) / g.tile);
         g.G = g_env >= 1 && g_env <= (int)kMaxG ? (uint32_t)g_env : 256u * K.blocks_per_cu;
-        g.small = v.n_bits < (UINT64_C(1) << 38);
         const unsigned bins1 = 1u << g.d1, bins2 = 1u << g.d2, nf = bins1 * bins2;
         SrBuf b;
         if (carve(b, scratch, cnt, g.tile) > scratch_bytes)
@@ -1418,6 +1475,45 @@ __global__ __launch_bounds__(256) void k_sr_bnd_lines(unsigned nf, const uint64_
 }
 
 } // namespace
+
+// true when the batch is spread over the vector (see k_sr_sample_spread); synchronises with stream s (one 8-byte read-back).
+// `out2`: two device words of scratch.
+static sdsl_hip_status sr_batch_is_spread(const BvView & v, int op, const SelectPlan & sp, const uint64_t * d_idx, uint64_t n,
+                                          hipStream_t s, uint32_t * out2, bool & spread)
+{
+    SrGeom g;
+    sr_fill_geom(g, v, op, sp, n);
+    hipLaunchKernelGGL(k_sr_sample_spread, dim3(1), dim3(1024), 0, s, g, d_idx, out2);
+    SH_HIP(hipGetLastError());
+    uint32_t hres[2] = {0, 0};
+    SH_HIP(hipMemcpyAsync(hres, out2, 8, hipMemcpyDeviceToHost, s));
+    SH_HIP(hipStreamSynchronize(s));
+    // uniformly random samples over S slices touch S * (1 - exp(-m / S)) of them; half of the samples' own number is far below
+    // that for every vector the bucketed path applies to (>= 2^12 slices) and far above what a window or a sorted batch gives
+    const unsigned slices = 1u << (g.d1 + g.d2);
+    const unsigned limit = hres[1] / 2 < slices / 2 ? hres[1] / 2 : slices / 2;
+    spread = hres[1] >= 1024 && hres[0] >= limit;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status bv_sorted_rank_is_spread(const BvView & v, const uint64_t * d_idx, uint64_t n, hipStream_t s, void * scratch,
+                                         bool & spread)
+{
+    return sr_batch_is_spread(v, 0, SelectPlan(), d_idx, n, s, (uint32_t *)scratch, spread);
+}
+
+sdsl_hip_status bv_sorted_select_is_spread(const BvHost & h, int bit, const uint64_t * d_idx, uint64_t n, hipStream_t s, void * scratch,
+                                           bool & spread)
+{
+    const BvHost::SelPlan & P = h.sel_plan[bit];
+    SelectPlan sp;
+    sp.bnd = P.bnd.as<uint32_t>();
+    sp.bm = P.bm;
+    sp.bs = P.bs;
+    sp.nf = P.nf;
+    sp.total = bit ? h.view.ones : h.view.n_bits - h.view.ones;
+    return sr_batch_is_spread(h.view, 1, sp, d_idx, n, s, (uint32_t *)scratch, spread);
+}
 
 sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                                       hipStream_t s, void * scratch, size_t scratch_bytes)

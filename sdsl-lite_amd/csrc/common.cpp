@@ -264,6 +264,7 @@ sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value)
     if (name && !strcmp(name, "trace_phases"))
     {
         sdslhip::g_trace_phases.store((int)value);
+        sdslhip::bv_sorted_clear_phases(); // what sdsl_hip_last_phases reports from now on belongs to calls made after this one
         return SDSL_HIP_OK;
     }
     set_error("set_option: unknown option '%s'", name ? name : "(null)");

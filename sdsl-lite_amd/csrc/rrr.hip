@@ -519,9 +519,21 @@ static void rrr_sel_shifts(uint64_t ones, uint64_t zeros, uint32_t shb[2])
     const uint64_t cnt[2] = {zeros, ones};
     for (int b = 0; b < 2; ++b)
     {
-        uint32_t sh = 4; // few arguments (sparse vectors): sample densely, the directory stays far below 2^16 entries
+        uint32_t sh = 4; // few arguments: sample densely, the directory stays far below 2^16 entries
         while (sh < 24 && (cnt[b] >> sh) > (UINT64_C(1) << 16))
             ++sh;
+        // a RARE bit value (mean gap of more than a record): interpolation inside a sample interval of many records misses,
+        // and every miss is a random fetch (isolated ones every 2^16 bits: 4.5 G/s).  Sample so that an interval spans about
+        // two records, as long as that directory stays small (2^18 samples = 1 MiB)
+        if (cnt[b] && (ones + zeros) / cnt[b] > kRecSB / 4)
+        {
+            const uint64_t gap = (ones + zeros) / cnt[b];
+            uint32_t ss = 0;
+            while (ss < sh && (gap << (ss + 1)) <= 2 * kRecSB)
+                ++ss;
+            if ((cnt[b] >> ss) <= (UINT64_C(1) << 18))
+                sh = ss;
+        }
         shb[b] = sh;
     }
     if (const char * e = getenv("SDSL_HIP_RRR_SEL_LOG2"))

@@ -98,6 +98,39 @@ def test_c2_default_dispatch_takes_the_bucketed_path_at_bench_size(gpu, c2_vecto
         bv.release_scratch()
 
 
+@pytest.mark.parametrize("shape", ["window", "sorted"])
+def test_c2_default_dispatch_keeps_local_batches_on_the_direct_kernel(gpu, c2_vector, shape):
+    """A batch confined to a 2^20-bit window, or a sorted one, is served from cache by the direct kernel (9.7 ms against
+    21.7 ms per 10^9 queries for the window): the spread sample of the default dispatch sends it there, for rank and for
+    select, and the answers are those of the bucketed path."""
+    import torch
+    bv, n = c2_vector
+    nq = 100_000_000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    if shape == "window":
+        idx = (n // 3) + torch.randint(0, 1 << 20, (nq,), device="cuda", dtype=torch.int64, generator=g)
+    else:
+        idx = torch.sort(torch.randint(0, n + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)).values
+    ones = G["c2"]["ones"]
+    sel = torch.clamp(idx // 2, 1, ones) if shape == "sorted" else (ones // 3) + torch.randint(1, 1 << 19, (nq,), device="cuda", dtype=torch.int64, generator=g)
+    try:
+        gpu.set_option("trace_phases", 1)
+        r_auto = bv.rank(idx, 1)
+        s_auto = bv.select(sel, 1)
+        torch.cuda.synchronize()
+        assert gpu.last_phases() == {}, f"a local batch went through the bucketed passes: {gpu.last_phases()}"
+        gpu.set_option("rank_sorted", 1)
+        gpu.set_option("select_sorted", 1)
+        assert torch.equal(bv.rank(idx, 1), r_auto)
+        assert torch.equal(bv.select(sel, 1), s_auto)
+        assert gpu.last_phases().get("select") == 1
+    finally:
+        gpu.set_option("trace_phases", 0)
+        gpu.set_option("rank_sorted", -1)
+        gpu.set_option("select_sorted", -1)
+        bv.release_scratch()
+
+
 def test_c3_rrr63_rank_select_match_reference_digests(gpu):
     import torch
     c = G["c3"]
