@@ -422,14 +422,18 @@ sdsl_hip_status sdsl_hip_set_timing(int32_t enabled);
 /* Process-wide knobs.  "rank_sorted": how sdsl_hip_bv_rank_batch answers a batch in device memory: 0 = always the direct
  * kernel (one rank line per query), 1 = the bucketed path whenever the vector allows it (bv_sorted.hip: the batch is
  * partitioned by index slice, slices are staged in LDS; 13 bytes of device scratch per query, kept with the handle),
- * -1 = automatic (bucketed when the batch addresses every line of a vector larger than the caches several times).
+ * -1 = automatic (bucketed when the batch addresses every line of a vector larger than the caches several times AND a
+ * sample of the batch is spread over the vector — a windowed or sorted batch stays on the direct kernel; reading that
+ * sample back synchronises the stream once per call, so use 0 or 1 where a call must stay asynchronous, e.g. under
+ * graph capture).
  * Answers are identical in every mode.  Initial value: environment variable SDSL_HIP_RANK_SORTED, else -1.
  * "select_sorted": the same for sdsl_hip_bv_select_batch (buckets of consecutive argument ranks, their lines staged in LDS;
  * automatic only for vectors without long sparse stretches: those are answered by a slow fix-up pass).  Initial value:
  * SDSL_HIP_SELECT_SORTED, else -1. */
 sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value);
 /* "trace_phases" (0/1): the bucketed batch rank times each of its passes with HIP events on the launch stream (one host
- * synchronisation per call) and sdsl_hip_last_phases returns them as "hist1=ms;offs1=ms;part1=ms;..." */
+ * synchronisation per call) and sdsl_hip_last_phases returns them as "select=0|1;hist1=ms;offs1=ms;part1=ms;..." for the
+ * most recent bucketed batch since the option was last set (empty: no batch took that path) */
 sdsl_hip_status sdsl_hip_last_phases(char * buf, size_t cap);
 /* where a vector's device layout lives: out = { address of the rank lines, their size in bytes, address of the select_1
  * directory, address of the batch-rank scratch } — for allocation / alignment experiments (tools/alloc_sensitivity.py) */
