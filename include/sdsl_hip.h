@@ -429,7 +429,13 @@ sdsl_hip_status sdsl_hip_set_timing(int32_t enabled);
  * Answers are identical in every mode.  Initial value: environment variable SDSL_HIP_RANK_SORTED, else -1.
  * "select_sorted": the same for sdsl_hip_bv_select_batch (buckets of consecutive argument ranks, their lines staged in LDS;
  * automatic only for vectors without long sparse stretches: those are answered by a slow fix-up pass).  Initial value:
- * SDSL_HIP_SELECT_SORTED, else -1. */
+ * SDSL_HIP_SELECT_SORTED, else -1.
+ * "rrr_raw_budget" (permille, default 20): how much of its compressed size an rrr_vector<63> built or loaded AFTER the call
+ * may spend on storing blocks raw instead of as enumerative offsets.  Blocks of the classes 11..52 are always raw on the
+ * device (decoding them costs 63 dependent steps); within the budget the classes next to them follow, largest first, so
+ * that fewer and fewer decoder steps remain per block (0: none beyond 11..52; a wavelet tree over text: 20 -> classes 9..54
+ * raw, count 1.2x; 60 -> 4..59 raw, count 1.4x at +0.6 % of the index).  Answers and the serialised SDSL bytes do not
+ * depend on it. */
 sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value);
 /* "trace_phases" (0/1): the bucketed batch rank times each of its passes with HIP events on the launch stream (one host
  * synchronisation per call) and sdsl_hip_last_phases returns them as "select=0|1;hist1=ms;offs1=ms;part1=ms;..." for the

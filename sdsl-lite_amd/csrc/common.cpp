@@ -10,6 +10,7 @@ static thread_local std::string g_err;
 static bool g_timing = false;
 // batched rank on a plain vector: -1 automatic, 0 always the direct kernel, 1 the bucketed path whenever it applies
 std::atomic<int> g_trace_phases{0};
+std::atomic<int> g_rrr_raw_budget{20}; // permille of the compressed size rrr_vector<63> may spend on raw classes (rrr.hip)
 std::atomic<int> g_select_sorted_mode{getenv("SDSL_HIP_SELECT_SORTED") ? atoi(getenv("SDSL_HIP_SELECT_SORTED")) : -1};
 std::atomic<int> g_rank_sorted_mode{getenv("SDSL_HIP_RANK_SORTED") ? atoi(getenv("SDSL_HIP_RANK_SORTED")) : -1};
 static thread_local bool g_timing_suppressed = false; // pipeline workers: the event pair is global
@@ -259,6 +260,16 @@ sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value)
     if (name && !strcmp(name, "select_sorted"))
     {
         sdslhip::g_select_sorted_mode.store((int)value);
+        return SDSL_HIP_OK;
+    }
+    if (name && !strcmp(name, "rrr_raw_budget"))
+    {
+        if (value < 0 || value > 1000)
+        {
+            set_error("set_option: rrr_raw_budget is in permille of the compressed size (0..1000)");
+            return SDSL_HIP_ERR_INVALID;
+        }
+        sdslhip::g_rrr_raw_budget.store((int)value);
         return SDSL_HIP_OK;
     }
     if (name && !strcmp(name, "trace_phases"))

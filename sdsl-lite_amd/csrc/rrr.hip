@@ -54,12 +54,55 @@ static const RrrTables & host_tables()
             for (int k = 0; k < 64; ++k)
             {
                 uint64_t c = T.binom[63][k];
-                T.space[k] = c == 1 ? 0 : (uint8_t)(hi64(c) + 1);
+                T.sdsl_space[k] = c == 1 ? 0 : (uint8_t)(hi64(c) + 1);
+                T.space[k] = T.sdsl_space[k]; // (per vector: tables_for)
             }
             g_tables_ready.store(true);
         }
     }
     return g_host_tables;
+}
+
+// the tables of a vector whose classes t+1 .. 62-t are stored raw (rrr_device.hpp)
+static RrrTables tables_for(unsigned sparse_max)
+{
+    RrrTables T = host_tables();
+    for (unsigned k = sparse_max + 1; k + sparse_max < kRrrBS; ++k)
+        T.space[k] = (uint8_t)kRrrBS;
+    return T;
+}
+
+// smallest t whose raw classes cost at most 2 % (option "rrr_raw_budget", in permille) of the vector's compressed size on top of t = 10 (the classes 11..52 are
+// always raw: the sparse decoder does not take them); hist[k] = blocks of class k.  Measured on the compressed FM-index of
+// the 1 GiB text (profiles/rrr_raw_classes_r02.txt): t = 10 -> 369, 9 -> 384, 6 -> 437, 3 -> 469, 0 -> 460 Mcount/s at
+// 5.10 .. 5.16 GB; a 5 %-dense vector gets t = 7 (+0.6 % of its length) and keeps its speed (it is bound by the fetches).
+static unsigned choose_sparse_max(const uint64_t hist[64], uint64_t n_bits)
+{
+    if (const char * e = getenv("SDSL_HIP_RRR_SPARSE_MAX"))
+    { // experiment knob
+        const int v = atoi(e);
+        if (v >= 0 && v <= 10)
+            return (unsigned)v;
+    }
+    const RrrTables & T = host_tables();
+    uint64_t size10 = 0; // about what the vector takes at t = 10: 13 bits of record per block + its field
+    for (unsigned k = 0; k < 64; ++k)
+        size10 += hist[k] * (13 + (k > 10 && k < 53 ? kRrrBS : (unsigned)T.sdsl_space[k]));
+    const int budget = g_rrr_raw_budget.load(); // permille of size10 (option "rrr_raw_budget", default 20)
+    unsigned t = 10;
+    uint64_t extra = 0;
+    while (t > 0)
+    { // making classes t and 63 - t raw as well
+        const uint64_t more = hist[t] * (kRrrBS - T.sdsl_space[t]) + hist[kRrrBS - t] * (kRrrBS - T.sdsl_space[kRrrBS - t]);
+        if ((extra + more) * 1000 > size10 * (uint64_t)budget)
+            break;
+        extra += more;
+        --t;
+    }
+    if (getenv("SDSL_HIP_TRACE_BUILD"))
+        fprintf(stderr, "[sdsl_hip] rrr_vector<63> of %llu bits: classes %u..%u raw, +%.2f %% of the length\n", (unsigned long long)n_bits,
+                t + 1, kRrrBS - t - 1, 100.0 * (double)extra / (double)(n_bits ? n_bits : 1));
+    return t;
 }
 
 struct RrrArrays // host image of a parsed SDSL stream
@@ -71,7 +114,7 @@ struct RrrArrays // host image of a parsed SDSL stream
     std::vector<uint64_t> sb_rank; // ones before each SDSL superblock
     std::vector<uint64_t> sb_ptr;  // stream position of each SDSL superblock
     uint64_t n_rec = 0;            // device records (36 blocks)
-    std::vector<uint64_t> rec_rank, rec_ptr; // the same two per device record
+    std::vector<uint64_t> rec_rank, rec_ptr; // the same two per device record (rec_ptr: position in SDSL's stream)
 };
 
 // rrr_vector<63>::load layout (rrr_vector.hpp:366-378,381-392)
@@ -120,7 +163,7 @@ static sdsl_hip_status rrr_parse_sdsl(StreamReader & rd, RrrArrays & A)
                     k = kRrrBS - k;
                 A.cls[b] = (uint8_t)k;
                 run += k;
-                ptr += T.space[k];
+                ptr += T.sdsl_space[k];
             }
         }
         A.sb_rank[A.n_sb] = run;
@@ -142,7 +185,7 @@ static sdsl_hip_status rrr_parse_sdsl(StreamReader & rd, RrrArrays & A)
                 A.rec_ptr[b / kRecK] = ptr;
             }
             run += A.cls[b];
-            ptr += T.space[A.cls[b]];
+            ptr += T.sdsl_space[A.cls[b]];
         }
         A.rec_rank[A.n_rec] = run;
         A.rec_ptr[A.n_rec] = ptr;
@@ -362,6 +405,21 @@ __device__ __forceinline__ uint64_t rrr_block_bits(const uint64_t * __restrict__
     return v & lo_set(len);
 }
 
+// pass 0: blocks per class
+__global__ __launch_bounds__(256) void k_rrr_class_hist(const uint64_t * __restrict__ words, uint64_t n_bits, uint64_t n_blocks,
+                                                        unsigned long long * __restrict__ hist)
+{
+    __shared__ unsigned h[64];
+    if (threadIdx.x < 64)
+        h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks; b += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&h[popc64(rrr_block_bits(words, n_bits, b))], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64 && h[threadIdx.x])
+        atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
 // pass 1, one thread per record: classes into the record, ones and offset bits of the record
 __global__ __launch_bounds__(256) void k_rrr_enc_classes(const uint64_t * __restrict__ words, uint64_t n_bits,
                                                          uint64_t n_blocks, uint64_t n_sb,
@@ -436,8 +494,10 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
             const unsigned k = popc64(bits), len = T.space[k];
             if (len)
             {
-                uint64_t nr = 0, x = bits;
+                uint64_t nr = bits, x = rrr_raw_width(len) ? 0 : bits; // a raw class stores the block itself
                 unsigned kk = k;
+                if (x)
+                    nr = 0;
                 while (x)
                 { // combinatorial number system, positions from the least significant bit
                     unsigned p = (unsigned)__ffsll((long long)x) - 1;
@@ -547,7 +607,13 @@ static void rrr_sel_shifts(uint64_t ones, uint64_t zeros, uint32_t shb[2])
 static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
 {
     h.device = device;
-    const RrrTables & T = host_tables();
+    {
+        uint64_t hist[64] = {};
+        for (uint64_t b = 0; b < A.n_blocks; ++b)
+            ++hist[A.cls[b]];
+        h.sparse_max = choose_sparse_max(hist, A.n_bits);
+    }
+    const RrrTables T = tables_for(h.sparse_max);
     if (A.stream_bits >= (UINT64_C(1) << 48) || A.n_rec > UINT64_C(0xFFFFFFFF))
     {
         set_error("rrr_vector too large for the device record format");
@@ -559,7 +625,9 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     std::vector<uint64_t> cptr((size_t)n_rec + 1, 0);
     for (uint64_t s = 0; s < n_rec; ++s)
     {
-        const uint64_t len = A.rec_ptr[s + 1] - A.rec_ptr[s];
+        uint64_t len = 0; // on the device: raw classes take 63 bits
+        for (unsigned j = 0; j < kRecK; ++j)
+            len += T.space[A.cls[(size_t)s * kRecK + j]];
         cptr[s + 1] = cptr[s] + (len > kInlineBits ? (len - kInlineBits + 63) >> 6 : 0); // words
     }
     std::vector<uint64_t> cstream(cptr[n_rec] + 3, 0);
@@ -597,13 +665,32 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
                 }
                 r[2] = rrr_pack_prefix(po, pb);
             }
-            uint64_t avail = A.rec_ptr[s + 1] - A.rec_ptr[s];
-            if (avail > kInlineBits)
-                avail = kInlineBits;
-            for (unsigned w = 0; w * 64 < avail; ++w)
-            {
-                unsigned len = (unsigned)std::min<uint64_t>(64, avail - w * 64);
-                r[kRecInline + w] = read_bits(A.stream.data(), A.rec_ptr[s] + w * 64, len);
+            { // the record's fields: SDSL's offsets, or the decoded block for a raw class; nine words inline, the rest in
+              // the record's own words of the overflow stream (no other thread writes those)
+                uint64_t sp = A.rec_ptr[s];
+                unsigned rel = 0;
+                for (unsigned j = 0; j < kRecK; ++j)
+                {
+                    const uint64_t blk = s * kRecK + j;
+                    if (blk >= A.n_blocks)
+                        break;
+                    const unsigned k = A.cls[blk], sl = T.sdsl_space[k], dl = T.space[k];
+                    if (dl)
+                    {
+                        uint64_t f = read_bits(A.stream.data(), sp, sl);
+                        if (rrr_raw_width(dl))
+                            f = decode_block_host(T, k, f);
+                        for (unsigned done = 0; done < dl;)
+                        { // word by word of the record's offset string
+                            const unsigned at = rel + done, w = at >> 6, o = at & 63, n = std::min(dl - done, 64 - o);
+                            uint64_t * dst = w < kInlineWords ? &r[kRecInline + w] : &cstream[cptr[s] + (w - kInlineWords)];
+                            *dst |= ((f >> done) & lo_set(n)) << o;
+                            done += n;
+                        }
+                    }
+                    sp += sl;
+                    rel += dl;
+                }
             }
             // select samples falling into this superblock: walk its blocks, decode only where needed
             uint64_t start = s * kRecSB;
@@ -623,7 +710,7 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
                     uint64_t blk = s * kRecK + t;
                     if (blk >= A.n_blocks)
                         break;
-                    unsigned k = A.cls[blk], len = T.space[k];
+                    unsigned k = A.cls[blk], len = T.sdsl_space[k];
                     uint64_t bstart = blk * kRrrBS;
                     unsigned blen = bstart >= A.n_bits ? 0u : (unsigned)std::min<uint64_t>(kRrrBS, A.n_bits - bstart);
                     unsigned a = b ? k : blen - k;
@@ -660,12 +747,6 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     SH_TRY(h.rec.alloc(rec.size() * 8));
     if (!rec.empty())
         SH_HIP(hipMemcpy(h.rec.p, rec.data(), rec.size() * 8, hipMemcpyHostToDevice));
-    for (uint64_t s = 0; s < n_rec; ++s)
-    {
-        const uint64_t len = A.rec_ptr[s + 1] - A.rec_ptr[s];
-        for (uint64_t o = kInlineBits; o < len; o += 64)
-            cstream[cptr[s] + ((o - kInlineBits) >> 6)] = read_bits(A.stream.data(), A.rec_ptr[s] + o, (unsigned)std::min<uint64_t>(64, len - o));
-    }
     SH_TRY(h.stream.alloc(cstream.size() * 8));
     SH_HIP(hipMemcpy(h.stream.p, cstream.data(), cstream.size() * 8, hipMemcpyHostToDevice));
     SH_TRY(h.tables.alloc(sizeof(RrrTables)));
@@ -706,7 +787,6 @@ __global__ void k_rrr_set_sentinels(uint32_t * a, uint64_t ia, uint32_t * b, uin
 sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t n_bits, int device)
 {
     h.device = device;
-    const RrrTables & T = host_tables();
     const uint64_t n_blocks = (n_bits + kRrrBS) / kRrrBS; // one all-zero dummy block when 63 | n (rrr_vector.hpp:163)
     const uint64_t n_sb = (n_blocks + kRecK - 1) / kRecK; // records
     if (n_sb > UINT64_C(0xFFFFFFFF))
@@ -714,6 +794,17 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
         set_error("rrr_vector too large for the device record format");
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
+    { // pass 0: how many blocks of every class -> which classes are stored raw (rrr_device.hpp)
+        DevBuf dh;
+        SH_TRY(dh.alloc(64 * 8, true));
+        hipLaunchKernelGGL(k_rrr_class_hist, dim3(grid_for(n_blocks, 256, 4096)), dim3(256), 0, 0, d_words, n_bits, n_blocks,
+                           dh.as<unsigned long long>());
+        SH_HIP(hipGetLastError());
+        uint64_t hist[64];
+        SH_HIP(hipMemcpy(hist, dh.p, sizeof hist, hipMemcpyDeviceToHost));
+        h.sparse_max = choose_sparse_max(hist, n_bits);
+    }
+    const RrrTables T = tables_for(h.sparse_max);
     SH_TRY(h.tables.alloc(sizeof(RrrTables)));
     SH_HIP(hipMemcpy(h.tables.p, &T, sizeof(RrrTables), hipMemcpyHostToDevice));
     SH_TRY(h.rec.alloc(n_sb * kRecWords * 8, true));
@@ -773,7 +864,7 @@ sdsl_hip_status rrr_serialize_host(const RrrHost & h, StreamWriter & w)
     if (nrec)
         SH_HIP(hipMemcpy(rec.data(), rv.rec, rec.size() * 8, hipMemcpyDeviceToHost));
     // total offset bits = pointer of the last superblock + its own offsets
-    const RrrTables & T = host_tables();
+    const RrrTables T = tables_for(h.sparse_max);
     auto cls = [&](uint64_t b) -> unsigned
     {
         const unsigned j = (unsigned)(b % kRecK);
@@ -783,6 +874,8 @@ sdsl_hip_status rrr_serialize_host(const RrrHost & h, StreamWriter & w)
     // the overflow stream of the 36-block records
     const uint64_t nsb = (nb + kRrrK - 1) / kRrrK;
     std::vector<uint64_t> sptr((size_t)nsb + 1, 0), srank((size_t)nsb + 1, 0);
+    std::vector<uint64_t> rat((size_t)nrec + 1, 0);  // SDSL stream position of every record's first field
+    std::vector<uint32_t> rlen((size_t)nrec + 1, 0); // bits of every record's offset string on the device
     {
         uint64_t len = 0, ones = 0;
         for (uint64_t b = 0; b < nb; ++b)
@@ -792,42 +885,84 @@ sdsl_hip_status rrr_serialize_host(const RrrHost & h, StreamWriter & w)
                 sptr[b / kRrrK] = len;
                 srank[b / kRrrK] = ones;
             }
-            len += T.space[cls(b)];
-            ones += cls(b);
+            if (b % kRecK == 0)
+                rat[b / kRecK] = len;
+            const unsigned k = cls(b);
+            len += T.sdsl_space[k];
+            rlen[b / kRecK] += T.space[k];
+            ones += k;
         }
         sptr[nsb] = len;
         srank[nsb] = ones;
+        rat[nrec] = len;
     }
     const uint64_t stream_bits = sptr[nsb];
     const uint64_t btnr_bits = std::max<uint64_t>(stream_bits, 64); // rrr_vector.hpp:183
     std::vector<uint64_t> btnr(((btnr_bits + 63) >> 6) + 1, 0);
     {
-        std::vector<uint64_t> rlen((size_t)nrec, 0); // offset bits per record
-        for (uint64_t b = 0; b < nb; ++b)
-            rlen[b / kRecK] += T.space[cls(b)];
         const uint64_t cwords = nrec ? (rec[(nrec - 1) * kRecWords + 1] & ((UINT64_C(1) << 48) - 1))
                                            + (rlen[nrec - 1] > kInlineBits ? (rlen[nrec - 1] - kInlineBits + 63) >> 6 : 0)
                                      : 0;
         std::vector<uint64_t> cs(cwords + 2, 0);
         if (cwords)
             SH_HIP(hipMemcpy(cs.data(), rv.stream, cwords * 8, hipMemcpyDeviceToHost));
-        uint64_t at = 0;
-        for (uint64_t r = 0; r < nrec; ++r)
+        // field by field: a raw class is turned back into SDSL's offset (bin_to_nr, rrr_helper.hpp:346-366).  Records are
+        // spread over threads; neighbouring records share words of m_btnr, hence the atomic OR
+        auto emit = [&](uint64_t r0, uint64_t r1)
         {
-            const uint64_t len = rlen[r], n_in = std::min<uint64_t>(len, kInlineBits);
-            for (uint64_t o = 0; o < n_in; o += 64)
+            for (uint64_t r = r0; r < r1; ++r)
             {
-                const unsigned l = (unsigned)std::min<uint64_t>(64, n_in - o);
-                write_bits(btnr.data(), at + o, l, read_bits(&rec[r * kRecWords + kRecInline], o, l));
+                const uint64_t * rp = &rec[r * kRecWords];
+                const uint64_t * far = cs.data() + (rp[1] & ((UINT64_C(1) << 48) - 1));
+                uint64_t at = rat[r];
+                unsigned rel = 0;
+                for (unsigned j = 0; j < kRecK; ++j)
+                {
+                    const uint64_t b = r * kRecK + j;
+                    if (b >= nb)
+                        break;
+                    const unsigned k = rrr_cls(rp[kRecClasses + j / kGrp], j % kGrp), dl = T.space[k], sl = T.sdsl_space[k];
+                    if (dl)
+                    {
+                        uint64_t f = 0;
+                        for (unsigned done = 0; done < dl;)
+                        {
+                            const unsigned p = rel + done, w = p >> 6, o = p & 63, cnt = std::min(dl - done, 64 - o);
+                            const uint64_t word = w < kInlineWords ? rp[kRecInline + w] : far[w - kInlineWords];
+                            f |= ((word >> o) & lo_set(cnt)) << done;
+                            done += cnt;
+                        }
+                        if (rrr_raw_width(dl))
+                        {
+                            uint64_t nr = 0, x = f;
+                            unsigned kk = k;
+                            while (x)
+                            { // combinatorial number system, positions from the least significant bit
+                                const unsigned p = (unsigned)__builtin_ctzll(x);
+                                nr += T.binom[62 - p][kk];
+                                --kk;
+                                x &= x - 1;
+                            }
+                            f = nr;
+                        }
+                        const unsigned o = (unsigned)(at & 63);
+                        __atomic_fetch_or(&btnr[at >> 6], f << o, __ATOMIC_RELAXED);
+                        if (o + sl > 64)
+                            __atomic_fetch_or(&btnr[(at >> 6) + 1], f >> (64 - o), __ATOMIC_RELAXED);
+                    }
+                    at += sl;
+                    rel += dl;
+                }
             }
-            const uint64_t base = rec[r * kRecWords + 1] & ((UINT64_C(1) << 48) - 1);
-            for (uint64_t o = kInlineBits; o < len; o += 64)
-            {
-                const unsigned l = (unsigned)std::min<uint64_t>(64, len - o);
-                write_bits(btnr.data(), at + o, l, read_bits(cs.data(), base * 64 + (o - kInlineBits), l));
-            }
-            at += len;
-        }
+        };
+        unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+        if (nrec < 4096)
+            nt = 1;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back(emit, nrec * t / nt, nrec * (t + 1) / nt);
+        for (auto & x : th)
+            x.join();
     }
     PackedBuilder bt(nb, 6), btnrp(nsb, (uint8_t)(hi64(stream_bits) + 1)), invert(nsb, 1);
     const uint64_t n_rank = nsb + ((n % kRrrSB) > 0); // rrr_vector.hpp:185-186
@@ -874,7 +1009,7 @@ void rrr_arrays_to_words(const RrrArrays & A, std::vector<uint64_t> & words)
         uint64_t ptr = 0;
         for (uint64_t b = 0; b < A.n_blocks; ++b)
         {
-            unsigned k = A.cls[b], len = T.space[k];
+            unsigned k = A.cls[b], len = T.sdsl_space[k];
             uint64_t bits = decode_block_host(T, k, read_bits(A.stream.data(), ptr, len));
             ptr += len;
             uint64_t pos = b * kRrrBS;

@@ -29,8 +29,22 @@ struct RrrTables
     // entry would depend on k alone, and the lanes of a wave decoding blocks of the same (small) class at different
     // rows m — the normal case of the sparse decoder — would all collide (77 % of the LDS cycles were bank conflicts).
     uint64_t binom[64][65];
-    uint8_t space[64];      // bits of an offset field for class k: hi(C(63,k))+1, 0 if C == 1
+    // bits of the field a block of class k occupies on the DEVICE: hi(C(63,k))+1 for the classes the sparse decoder handles
+    // (0 if C == 1), 63 — the block itself — for the classes in between (see RAW classes below)
+    uint8_t space[64];
+    uint8_t sdsl_space[64]; // SDSL's width of the offset field, hi(C(63,k))+1 for every class (parser / serialiser)
 };
+
+// RAW classes.  Decoding a block from its offset costs one bisection per set (or, via the complement, unset) bit, and a WAVE
+// pays for the lane with the most of them; a block of the middle classes (63 dependent steps) bounded every kernel that met
+// one (count on csa_wt<wt_huff<rrr_vector<63>>>: 95 % VALU).  So per vector a threshold t <= 10 is chosen when it is built
+// (rrr.hip, choose_sparse_max): classes k <= t and k >= 63 - t stay enumerative, everything in between is stored as the 63
+// bits themselves (space[k] == 63) and needs no decoder.  t is the smallest value that keeps the extra space within 2 % of
+// the vector's compressed size — a 5 %-dense vector gets t = 7 (+0.6 % of its length), a wavelet tree over text t = 3 or so.
+SH_HD bool rrr_raw_width(unsigned len)
+{
+    return len == kRrrBS;
+}
 
 struct RrrView
 {
@@ -44,15 +58,8 @@ struct RrrView
 };
 
 // ---- device: block decoder -----------------------------------------------------------------------
-// Decodes the 63-bit block with k ones and offset nr (rrr_helper.hpp:480-534: blocks of a class are numbered in
-// lexicographic order of (b0, b1, ...), 0 < 1).
-//
-// Two instruction streams, chosen PER WAVE so that a wave never pays for both:
-//  * sparse: one bisection over the binomial column per set bit (the idea of the reference's k <= 10 path).  The
-//    complement of a block with k ones is the block with 63-k ones and offset C(63,k)-1-nr, so classes >= 53 take
-//    this path too;
-//  * dense: 63 unrolled compare/subtract steps without branches or exec-mask traffic; correct for every class,
-//    so a wave with mixed classes runs only this one.
+// Sparse blocks (k <= 10 ones, or <= 10 zeros via the complement) are decoded from their offset: one bisection over the
+// binomial column per set bit (the idea of the reference's k <= 10 path).  Everything in between is stored raw.
 __device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsigned k, uint64_t nr)
 {
     uint64_t bits = 0;
@@ -77,49 +84,16 @@ __device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsig
     return bits;
 }
 
-// one position: c = C(62-p, k); one iff nr >= c.  32-bit borrow chain instead of a 64-bit compare + subtract; acc
-// collects the BORROWS (= zero bits) MSB-first, k8 is 8*k (the table column as a byte offset)
-__device__ __forceinline__ void rrr_dense_step(const RrrTables * T, int p, unsigned & nlo, unsigned & nhi, unsigned & k8,
-                                               unsigned & acc)
+// the 63-bit block of class k whose device field holds f (rrr_helper.hpp:480-534 for the enumerative classes: blocks of a
+// class are numbered in lexicographic order of (b0, b1, ...), 0 < 1)
+__device__ __forceinline__ uint64_t rrr_decode_block(const RrrTables * T, unsigned k, uint64_t f)
 {
-    const uint64_t c = *reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(&T->binom[62 - p][0]) + k8);
-    unsigned b0, b1;
-    const unsigned dlo = __builtin_subc(nlo, (unsigned)c, 0u, &b0);
-    const unsigned dhi = __builtin_subc(nhi, (unsigned)(c >> 32), b0, &b1);
-    nlo = b1 ? nlo : dlo;
-    nhi = b1 ? nhi : dhi;
-    k8 -= b1 ? 0u : 8u;
-    acc = (acc << 1) | b1;
-}
-
-__device__ __forceinline__ uint64_t rrr_decode_dense(const RrrTables * T, unsigned k, uint64_t nr)
-{
-    unsigned nlo = (unsigned)nr, nhi = (unsigned)(nr >> 32), k8 = 8 * k;
-    unsigned acc0 = 0, acc1 = 0; // zero bits of positions 0..31 / 32..62, first position in the highest bit
-#pragma unroll
-    for (int p = 0; p < 32; ++p)
-        rrr_dense_step(T, p, nlo, nhi, k8, acc0);
-#pragma unroll
-    for (int p = 32; p < 63; ++p)
-        rrr_dense_step(T, p, nlo, nhi, k8, acc1);
-    return (uint64_t)__brev(~acc0) | ((uint64_t)(__brev(~acc1 << 1)) << 32);
-}
-
-__device__ __forceinline__ uint64_t rrr_decode_block(const RrrTables * T, unsigned k, uint64_t nr)
-{
-    const bool flip = k > 31;
-    const unsigned ks = flip ? kRrrBS - k : k;
-    uint64_t bits;
-    if (__builtin_amdgcn_ballot_w64(ks > 10) == 0)
-    { // wave-uniform: every active lane has a sparse block (or a sparse complement)
-        if (flip)
-            nr = T->binom[63][k] - 1 - nr;
-        bits = rrr_decode_sparse(T, ks, nr);
-        if (flip)
-            bits = ~bits & lo_set(kRrrBS);
-    }
-    else
-        bits = rrr_decode_dense(T, k, nr);
+    if (rrr_raw_width(T->space[k]))
+        return f;
+    const bool flip = k > 31; // the complement of a block with k ones is the block with 63-k ones and offset C(63,k)-1-nr
+    uint64_t bits = rrr_decode_sparse(T, flip ? kRrrBS - k : k, flip ? T->binom[63][k] - 1 - f : f);
+    if (flip)
+        bits = ~bits & lo_set(kRrrBS);
     return bits;
 }
 

@@ -11,6 +11,7 @@ struct RrrHost
     int device = 0;
     RrrView view{};
     DevBuf rec, stream, tables, sel[2];
+    unsigned sparse_max = 10; // classes sparse_max + 1 .. 62 - sparse_max are stored raw (rrr_device.hpp)
     size_t device_bytes() const
     {
         return rec.bytes + stream.bytes + tables.bytes + sel[0].bytes + sel[1].bytes;

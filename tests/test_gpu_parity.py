@@ -146,6 +146,39 @@ def test_rrr_inline_overflow_path(gpu):
     assert np.array_equal(v.select(i, 1), o.select(i, 1))
 
 
+@pytest.mark.parametrize("d", [0.02, 0.1, 0.3, 0.5, 0.85, 0.97])
+def test_rrr_raw_class_budget_changes_neither_answers_nor_sdsl_bytes(gpu, d):
+    """Which classes the device stores raw (option rrr_raw_budget: none beyond 11..52, the default 2 %, everything) is a
+    layout choice: rank / select / access / get_int and the serialised rrr_vector<63> bytes are the same for every budget,
+    whether the vector is built from the bits or loaded from SDSL's stream."""
+    n = 2142 * 700 + 29
+    w = mk(n, d, int(d * 1000))
+    o = ol.ORrr(w, n)
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, n + 1, 100_000, dtype=np.uint64)
+    blobs = []
+    try:
+        for budget in (0, 20, 200, 1000):
+            gpu.set_option("rrr_raw_budget", budget)
+            v = gpu.rrr_vector(w, n)
+            blob = v.serialize()
+            blobs.append(blob)
+            for vv in (v, gpu.rrr_vector(sdsl_bytes=blob)):
+                assert np.array_equal(vv.rank(idx, 1), o.rank(idx, 1))
+                tot = vv.ones()
+                i = rng.integers(1, tot + 1, 50_000, dtype=np.uint64)
+                assert np.array_equal(vv.select(i, 1), o.select(i, 1))
+                i0 = rng.integers(1, n - tot + 1, 50_000, dtype=np.uint64)
+                assert np.array_equal(vv.select(i0, 0), o.select(i0, 0))
+                pos = idx[idx + 64 <= n]
+                assert np.array_equal(vv.get_int(pos, 64) & np.uint64(1), vv.access(pos).astype(np.uint64))
+                assert vv.serialize() == blob
+    finally:
+        gpu.set_option("rrr_raw_budget", 20)
+    assert all(b == blobs[0] for b in blobs)
+    assert blobs[0] == o.serialize()
+
+
 @pytest.mark.parametrize("n", [0, 1, 14, 15, 16, 63, 64, 479, 480, 481, 959, 960, 961, 100_003, 3_000_001])
 @pytest.mark.parametrize("kind", [0, 1, 2, 3, 4, 5, 6])
 def test_sibling_streams_are_decoded_on_the_device(gpu, n, kind):
