@@ -73,6 +73,7 @@ struct SrBuf
     uint32_t *counts1, *offs1, *bstart1;
     uint32_t *counts2, *offs2, *bstart2;
     uint32_t *btot, *tprefix2;
+    uint32_t *tot2, *status, *ticket; // one-sweep pass 2: digit-2 totals, per (tile, bin) look-back words, tile tickets
     uint32_t *fine_count, *fstart, *ioff; // per slice: keys, first key, first work item
     uint64_t * hf;                        // per slice: ones in front of it
 };
@@ -252,14 +253,19 @@ __global__ __launch_bounds__(TT) void k_sr_hist(SrGeom g, const uint64_t * __res
                                                 uint32_t * __restrict__ counts, uint32_t * __restrict__ fine_count)
 {
     __shared__ unsigned hist[kBins], ghist[TT / 64][kBins]; // ghist: one per wave (fewer collisions)
+    __shared__ unsigned ghist2[P == 1 ? TT / 64 : 1][kBins]; // pass 1 only: the digit-2 histogram of the whole batch (fine_count = its totals)
     __shared__ TileMap map;
     const unsigned t = threadIdx.x, wv = t >> 6;
+    const bool both = P == 1 && fine_count != nullptr;
     sr_load_map<P, TT>(g, map, tprefix, gstart);
     for (unsigned i = t; i < kBins; i += TT)
     {
         hist[i] = 0;
         for (unsigned w = 0; w < TT / 64; ++w)
             ghist[w][i] = 0;
+        if (P == 1)
+            for (unsigned w = 0; w < TT / 64; ++w)
+                ghist2[w][i] = 0;
     }
     __syncthreads();
     const unsigned nt = sr_tiles<P>(g, map);
@@ -304,6 +310,18 @@ __global__ __launch_bounds__(TT) void k_sr_hist(SrGeom g, const uint64_t * __res
             for (unsigned u = 0; u < PER; ++u)
                 if (FULL || u * TT + t < (unsigned)(hi - lo))
                     atomicAdd(&ghist[wv][dig[u]], 1u);
+            if (P == 1 && both)
+            {
+#pragma unroll
+                for (unsigned u = 0; u < PER; ++u)
+                    if (FULL || u * TT + t < (unsigned)(hi - lo))
+                    {
+                        unsigned d2;
+                        uint32_t k2;
+                        sr_key2(key[u], g, d2, k2);
+                        atomicAdd(&ghist2[wv][d2], 1u);
+                    }
+            }
         };
         if (hi - lo == TT * PER)
             count_tile(std::true_type{});
@@ -314,6 +332,15 @@ __global__ __launch_bounds__(TT) void k_sr_hist(SrGeom g, const uint64_t * __res
     const unsigned bins = 1u << (P == 1 ? g.d1 : g.d2);
     for (unsigned i = t; i < bins; i += TT)
         counts[(uint64_t)i * g.G + blockIdx.x] = hist[i];
+    if (P == 1 && both)
+        for (unsigned i = t; i < (1u << g.d2); i += TT)
+        {
+            unsigned c = 0;
+            for (unsigned w = 0; w < TT / 64; ++w)
+                c += ghist2[w][i];
+            if (c)
+                atomicAdd(&fine_count[i], c);
+        }
 }
 
 // ---- offsets: offs[b][g] = keys of bins < b + keys of bin b in blocks < g -------------------------------------------
@@ -569,6 +596,275 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_partition(SrGeom g
             cursor[i] += hist[i];
         __syncthreads();
     }
+}
+
+// ---- pass 2 in ONE sweep ------------------------------------------------------------------------------------------------
+// The second partition without a histogram pass of its own (1.06 of the step's 18 ms): the digit-2 totals come out of the
+// first histogram pass (k_sr_hist<1>), and where a tile's run of bin b starts is the bin's base + the keys of bin b in all
+// tiles in front of it — a decoupled look-back over per-(tile, bin) status words [flag:2 | count:30]: a tile publishes its own
+// count (AGGREGATE) as soon as it has it, walks back over its predecessors until it meets an INCLUSIVE prefix, and publishes its
+// own inclusive prefix.  Tiles are handed out by a ticket counter, so every tile a block waits for belongs to a block that
+// is already running: no deadlock whatever the residency.  Flag and count travel in one 32-bit word (relaxed device-scope
+// atomics suffice).  The slice starts fall out of the same prefix (a slice = bin x digit-1 group: the bin's position at the
+// group's first tile), and so do the per-(bin, block) offsets the way back (k_sr_unpermute<2>, static tile ranges) starts from.
+constexpr uint32_t kStAgg = 1u << 30, kStIncl = 2u << 30, kStMask = (1u << 30) - 1;
+
+template <unsigned TT, unsigned PER>
+__global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_partition2_sweep(SrGeom g, const uint32_t * __restrict__ keys_in,
+                                                     const uint32_t * __restrict__ tprefix, const uint32_t * __restrict__ gstart,
+                                                     const uint32_t * __restrict__ bstart2, uint32_t * __restrict__ status,
+                                                     uint32_t * __restrict__ ticket, uint32_t * __restrict__ keys_out,
+                                                     uint16_t * __restrict__ slots, uint16_t * __restrict__ tile_hist,
+                                                     uint32_t * __restrict__ offs_out, uint32_t * __restrict__ fstart)
+{
+    constexpr unsigned kTile = TT * PER;
+    __shared__ uint32_t sorted[kTile];
+    __shared__ unsigned hist[kBins], start[kBins], cursor[kBins];
+    __shared__ unsigned wsum[kBins / 64];
+    __shared__ unsigned big[kTile / (kBigRun + 1) + 1], n_big, sh_ti;
+    __shared__ TileMap map;
+    const unsigned t = threadIdx.x;
+    const unsigned bins = 1u << g.d2;
+    sr_load_map<2, TT>(g, map, tprefix, gstart);
+    __syncthreads();
+    const unsigned nt = sr_tiles<2>(g, map);
+    unsigned next_ti = 0; // thread 0: the ticket of the tile after this one, taken while this one is written out
+    if (t == 0)
+        next_ti = atomicAdd(ticket, 1u);
+    for (;;)
+    {
+        if (t == 0)
+        {
+            sh_ti = next_ti;
+            n_big = 0;
+        }
+        for (unsigned i = t; i < kBins; i += TT)
+            hist[i] = 0;
+        __syncthreads();
+        const unsigned ti = sh_ti;
+        if (ti >= nt)
+            break;
+        uint64_t lo, hi;
+        unsigned grp;
+        sr_tile_range<2>(g, map, ti, lo, hi, grp);
+        uint32_t * st_mine = status + (uint64_t)ti * kBins;
+        // the words of the kLook tiles in front of this one are fetched TOGETHER (one round trip): walking back one dependent load
+        // at a time costs a round trip per predecessor, and with all blocks in step the inclusive prefixes lag several tiles behind
+        constexpr unsigned kLook = 8;
+        uint32_t w_prev[kLook] = {};
+        auto sort_tile = [&](auto full_c)
+        {
+            constexpr bool FULL = decltype(full_c)::value;
+            uint32_t key[PER];
+            unsigned br[PER]; // bin << 16 | rank inside the tile's share of the bin
+            sr_load_keys<2, TT, PER, FULL>(g, nullptr, keys_in, lo, hi, br, key);
+            const unsigned cnt_t = (unsigned)(hi - lo);
+            uint16_t * slots_t = slots + lo;
+#pragma unroll
+            for (unsigned u = 0; u < PER; ++u)
+            {
+                const unsigned q = u * TT + t;
+                const unsigned d = br[u];
+                br[u] = d << 16;
+                if (FULL || q < cnt_t)
+                    br[u] |= atomicAdd(&hist[d], 1u); // < 2^14
+            }
+            __syncthreads();
+            if (t < bins)
+            { // the earlier the successors see this tile's counts, the shorter their wait; and the predecessor's word is asked
+              // for now, to be looked at after the keys have been placed
+                __hip_atomic_store(st_mine + t, (ti == 0 ? kStIncl : kStAgg) | hist[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (unsigned k = 0; k < kLook; ++k)
+                    w_prev[k] = k < ti ? __hip_atomic_load(st_mine - (uint64_t)(k + 1) * kBins + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            }
+            for (unsigned i = t; i < kBins; i += TT)
+                start[i] = hist[i];
+            __syncthreads();
+            block_excl_scan_bins(start, wsum);
+            for (unsigned i = t; i < bins; i += TT)
+                tile_hist[(uint64_t)ti * bins + i] = (uint16_t)hist[i];
+#pragma unroll
+            for (unsigned u = 0; u < PER; ++u)
+            {
+                const unsigned q = u * TT + t;
+                if (FULL || q < cnt_t)
+                {
+                    const unsigned pos = start[br[u] >> 16] + (br[u] & 0xFFFFu);
+                    sorted[pos] = key[u];
+                    __builtin_nontemporal_store((uint16_t)pos, slots_t + q);
+                }
+            }
+        };
+        if (hi - lo == kTile)
+            sort_tile(std::true_type{});
+        else
+            sort_tile(std::false_type{});
+        if (t < bins)
+        { // look back: keys of bin t in the tiles in front of this one
+            unsigned sum = 0;
+            if (ti != 0)
+            {
+                bool done = false;
+                for (unsigned base = ti; !done && base > 0;)
+                { // a window of up to kLook predecessors: base-1 .. base-kLook
+                    const unsigned wn = base < kLook ? base : kLook;
+                    if (base != ti)
+                    {
+#pragma unroll
+                        for (unsigned k = 0; k < kLook; ++k)
+                            w_prev[k] = k < wn ? __hip_atomic_load(status + (uint64_t)(base - 1 - k) * kBins + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    }
+#pragma unroll
+                    for (unsigned k = 0; k < kLook; ++k)
+                    {
+                        if (done || k >= wn)
+                            continue;
+                        uint32_t w = w_prev[k];
+                        const uint32_t * sp = status + (uint64_t)(base - 1 - k) * kBins + t;
+                        while ((w >> 30) == 0)
+                        {
+                            __builtin_amdgcn_s_sleep(1);
+                            w = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        sum += w & kStMask;
+                        done = (w & kStIncl) != 0;
+                    }
+                    base -= wn;
+                }
+                __hip_atomic_store(st_mine + t, kStIncl | (sum + hist[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const unsigned at = bstart2[t] + sum;
+            cursor[t] = at;
+            if (ti == map.tp[grp]) // the group's first tile: here the slice (bin t, group) starts
+                fstart[((unsigned)t << g.d1) | grp] = at;
+            // blocks of the static tiling (the way back) whose tile range starts with this tile
+            for (unsigned b = (unsigned)(((uint64_t)ti * g.G + nt - 1) / nt); b < g.G && (unsigned)((uint64_t)nt * b / g.G) == ti; ++b)
+                offs_out[(uint64_t)t * g.G + b] = at;
+        }
+        if (t == 0) // (the answer arrives while the runs are written out)
+            next_ti = atomicAdd(ticket, 1u);
+        __syncthreads();
+        { // runs out: 16 lanes per bin
+            const unsigned l = t & 15;
+            for (unsigned b = t >> 4; b < bins; b += TT / 16)
+            {
+                const unsigned cnt = hist[b];
+                if (cnt == 0)
+                    continue;
+                const unsigned st = start[b], cur = cursor[b];
+                if (cnt > kBigRun)
+                {
+                    if (l == 0)
+                        big[atomicAdd(&n_big, 1u)] = b;
+                    continue;
+                }
+                uint32_t * dst = keys_out + cur;
+                for (unsigned i = l; i < cnt; i += 16)
+                    dst[i] = sorted[st + i];
+            }
+        }
+        __syncthreads();
+        const unsigned nb = n_big;
+        for (unsigned k = 0; k < nb; ++k)
+        {
+            const unsigned b = big[k], cnt = hist[b], st = start[b], cur = cursor[b];
+            for (unsigned i = t; i < cnt; i += TT)
+                keys_out[(uint64_t)cur + i] = sorted[st + i];
+        }
+        __syncthreads();
+    }
+}
+
+// slice starts with holes (0xFFFFFFFF: a slice of a digit-1 group that has no tile, i.e. no keys) -> starts and first work
+// items.  An empty slice starts where the next one does.  One block; the arrays are walked in chunks of 8192 entries staged
+// through LDS so that global accesses stay coalesced (thread t owns entries 8t .. 8t+7 of a chunk).
+__global__ __launch_bounds__(1024) void k_sr_fine_scan_starts(unsigned nf, unsigned total, uint32_t * __restrict__ fstart,
+                                                              uint32_t * __restrict__ ioff)
+{
+    constexpr unsigned kChunk = 8192, kOwn = kChunk / 1024;
+    __shared__ unsigned buf[kChunk + 1], first[1024], wred[16];
+    const unsigned t = threadIdx.x;
+    // backward: fill the holes
+    unsigned carry = total; // the first set value behind the chunk
+    for (unsigned chi = nf; chi > 0;)
+    {
+        const unsigned clo = chi > kChunk ? chi - kChunk : 0, cn = chi - clo;
+        for (unsigned i = t; i < cn; i += 1024)
+            buf[i] = fstart[clo + i];
+        __syncthreads();
+        const unsigned o = t * kOwn;
+        unsigned fv = 0xFFFFFFFFu;
+        for (unsigned j = 0; j < kOwn && o + j < cn && fv == 0xFFFFFFFFu; ++j)
+            fv = buf[o + j];
+        first[t] = fv;
+        __syncthreads();
+        unsigned nxt = carry;
+        for (unsigned u = t + 1; u < 1024; ++u)
+            if (first[u] != 0xFFFFFFFFu)
+            {
+                nxt = first[u];
+                break;
+            }
+        for (unsigned j = kOwn; j-- > 0;)
+            if (o + j < cn)
+            {
+                unsigned v = buf[o + j];
+                if (v == 0xFFFFFFFFu)
+                    v = nxt;
+                buf[o + j] = v;
+                nxt = v;
+            }
+        __syncthreads();
+        for (unsigned i = t; i < cn; i += 1024)
+            fstart[clo + i] = buf[i];
+        carry = buf[0];
+        __syncthreads();
+        chi = clo;
+    }
+    if (t == 0)
+        fstart[nf] = total;
+    __syncthreads(); // (one block: its own global writes are visible to it after the barrier)
+    // forward: first work item of every slice
+    unsigned run = 0;
+    for (unsigned clo = 0; clo < nf; clo += kChunk)
+    {
+        const unsigned cn = nf - clo < kChunk ? nf - clo : kChunk;
+        for (unsigned i = t; i <= cn; i += 1024)
+            buf[i] = fstart[clo + i]; // (entry cn: the start behind the chunk; fstart has nf + 1 entries)
+        __syncthreads();
+        const unsigned o = t * kOwn;
+        unsigned si = 0;
+        for (unsigned j = 0; j < kOwn && o + j < cn; ++j)
+            si += (buf[o + j + 1] - buf[o + j] + kItemKeys - 1) / kItemKeys;
+        const unsigned ii = wave_incl_scan(si);
+        if ((t & 63) == 63)
+            wred[t >> 6] = ii;
+        __syncthreads();
+        unsigned bi = run + ii - si, all = 0;
+        for (unsigned w = 0; w < 16; ++w)
+        {
+            if (w < (t >> 6))
+                bi += wred[w];
+            all += wred[w];
+        }
+        unsigned items[kOwn];
+        for (unsigned j = 0; j < kOwn && o + j < cn; ++j)
+        {
+            items[j] = bi;
+            bi += (buf[o + j + 1] - buf[o + j] + kItemKeys - 1) / kItemKeys;
+        }
+        __syncthreads();
+        for (unsigned j = 0; j < kOwn && o + j < cn; ++j)
+            buf[o + j] = items[j];
+        __syncthreads();
+        for (unsigned i = t; i < cn; i += 1024)
+            ioff[clo + i] = buf[i];
+        run += all;
+        __syncthreads();
+    }
+    if (t == 0)
+        ioff[nf] = run;
 }
 
 // ---- rank out of LDS, in place over the final keys -----------------------------------------------------------------
@@ -1181,7 +1477,8 @@ struct PhaseTimer
     }
 };
 
-constexpr uint64_t kMaxPass = UINT64_C(1) << 30; // positions per pass over the batch (32-bit cursors)
+constexpr uint64_t kMaxPass = (UINT64_C(1) << 30) - (UINT64_C(1) << 20); // positions per pass over the batch (32-bit cursors; the
+                                                                        // look-back words of the one-sweep pass hold 30-bit counts)
 constexpr unsigned kMaxG = 2048;                 // partition blocks (k_sr_bucket_offsets: 8 per thread)
 
 size_t carve(SrBuf & b, void * scratch, uint64_t n, unsigned tile)
@@ -1213,6 +1510,9 @@ size_t carve(SrBuf & b, void * scratch, uint64_t n, unsigned tile)
     b.fstart = (uint32_t *)take(((size_t)kBins * kBins + 1) * 4);
     b.ioff = (uint32_t *)take(((size_t)kBins * kBins + 1) * 4);
     b.hf = (uint64_t *)take((size_t)kBins * kBins * 8);
+    b.tot2 = (uint32_t *)take((kBins + 1) * 4);
+    b.ticket = (uint32_t *)take(256);
+    b.status = (uint32_t *)take(tiles2 * kBins * 4);
     return (size_t)(p - (uint8_t *)scratch);
 }
 
@@ -1229,6 +1529,8 @@ struct SrKernels
                  const uint16_t *, const uint16_t *, uint32_t *, uint8_t *, uint64_t *);
     void (*unp1)(const uint64_t *, int, SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint8_t *,
                  const uint16_t *, const uint16_t *, uint32_t *, uint8_t *, uint64_t *);
+    void (*part2s)(SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *,
+                   uint16_t *, uint16_t *, uint32_t *, uint32_t *);
     unsigned threads, blocks_per_cu, per;
 };
 template <unsigned TT, unsigned PER>
@@ -1236,6 +1538,7 @@ SrKernels sr_kernels(unsigned per_cu)
 {
     return SrKernels{k_sr_hist<1, TT, PER>,      k_sr_hist<2, TT, PER>,         k_sr_partition<1, TT, PER>,
                      k_sr_partition<2, TT, PER>, k_sr_unpermute<2, TT, PER, 3>, k_sr_unpermute<1, TT, PER, 3>,
+                     k_sr_partition2_sweep<TT, PER>,
                      TT,                         per_cu,                        PER};
 }
 
@@ -1372,6 +1675,7 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
     static const int t_env = getenv("SDSL_HIP_SORTED_THREADS") ? atoi(getenv("SDSL_HIP_SORTED_THREADS")) : 0;
     static const int g_env = getenv("SDSL_HIP_SORTED_G") ? atoi(getenv("SDSL_HIP_SORTED_G")) : 0;
     static const int rb_env = getenv("SDSL_HIP_SORTED_RANK_BLOCKS") ? atoi(getenv("SDSL_HIP_SORTED_RANK_BLOCKS")) : 0;
+    static const bool sweep = !(getenv("SDSL_HIP_SORTED_SWEEP") && atoi(getenv("SDSL_HIP_SORTED_SWEEP")) == 0); // 0: histogram pass 2
     // tiles of 8192 keys (512 threads x 16) are the measured optimum on 2^34 bits (profiles/sorted_rank_v6_r02.txt:
     // 17.9 ms against 18.9 ms for 16384-key tiles and 21.4 ms for 4096-key tiles); the others stay selectable for profiling
     const SrKernels K = t_env == 1024 ? sr_kernels<1024, 16>(1) : (t_env == 256 ? sr_kernels<256, 16>(4) : sr_kernels<512, 16>(2));
@@ -1394,7 +1698,9 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         const dim3 G(g.G), T(K.threads);
         PhaseTimer pt(trace, s);
         pt.mark();
-        hipLaunchKernelGGL(K.hist1, G, T, 0, s, g, idx, nullptr, nullptr, nullptr, b.counts1, nullptr);
+        if (sweep)
+            SH_HIP(hipMemsetAsync(b.tot2, 0, (kBins + 1) * 4, s));
+        hipLaunchKernelGGL(K.hist1, G, T, 0, s, g, idx, nullptr, nullptr, nullptr, b.counts1, sweep ? b.tot2 : nullptr);
         pt.mark();
         hipLaunchKernelGGL(k_sr_bucket_totals, dim3(bins1), dim3(256), 0, s, g.G, b.counts1, b.btot);
         hipLaunchKernelGGL(k_sr_bucket_scan, dim3(1), dim3(kBins), 0, s, bins1, g.tile, b.btot, b.bstart1, b.tprefix2);
@@ -1402,17 +1708,33 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         pt.mark();
         hipLaunchKernelGGL(K.part1, G, T, 0, s, g, idx, nullptr, nullptr, nullptr, b.offs1, b.keys1, b.slots1, b.thist1);
         pt.mark();
-        SH_HIP(hipMemsetAsync(b.fine_count, 0, (size_t)nf * 4, s));
-        hipLaunchKernelGGL(K.hist2, G, T, 0, s, g, nullptr, b.keys1, b.tprefix2, b.bstart1, b.counts2, b.fine_count);
-        pt.mark();
-        hipLaunchKernelGGL(k_sr_bucket_totals, dim3(bins2), dim3(256), 0, s, g.G, b.counts2, b.btot);
-        hipLaunchKernelGGL(k_sr_bucket_scan, dim3(1), dim3(kBins), 0, s, bins2, g.tile, b.btot, b.bstart2, nullptr);
-        hipLaunchKernelGGL(k_sr_bucket_offsets, dim3(bins2), dim3(256), 0, s, g.G, b.counts2, b.bstart2, b.offs2);
-        pt.mark();
-        hipLaunchKernelGGL(K.part2, G, T, 0, s, g, nullptr, b.keys1, b.tprefix2, b.bstart1, b.offs2, b.keys2, b.slots2,
-                           b.thist2);
-        pt.mark();
-        hipLaunchKernelGGL(k_sr_fine_scan, dim3(1), dim3(1024), 0, s, nf, b.fine_count, b.fstart, b.ioff);
+        if (sweep)
+        { // pass 2 in one sweep: no histogram pass, offsets by look-back (k_sr_partition2_sweep)
+            pt.mark();
+            hipLaunchKernelGGL(k_sr_bucket_scan, dim3(1), dim3(kBins), 0, s, bins2, g.tile, b.tot2, b.bstart2, nullptr);
+            SH_HIP(hipMemsetAsync(b.status, 0, ((size_t)g.tiles1 + kBins) * kBins * 4, s));
+            SH_HIP(hipMemsetAsync(b.ticket, 0, 4, s));
+            SH_HIP(hipMemsetAsync(b.fstart, 0xFF, ((size_t)nf + 1) * 4, s));
+            pt.mark();
+            hipLaunchKernelGGL(K.part2s, G, T, 0, s, g, b.keys1, b.tprefix2, b.bstart1, b.bstart2, b.status, b.ticket, b.keys2, b.slots2,
+                               b.thist2, b.offs2, b.fstart);
+            pt.mark();
+            hipLaunchKernelGGL(k_sr_fine_scan_starts, dim3(1), dim3(1024), 0, s, nf, (unsigned)cnt, b.fstart, b.ioff);
+        }
+        else
+        {
+            SH_HIP(hipMemsetAsync(b.fine_count, 0, (size_t)nf * 4, s));
+            hipLaunchKernelGGL(K.hist2, G, T, 0, s, g, nullptr, b.keys1, b.tprefix2, b.bstart1, b.counts2, b.fine_count);
+            pt.mark();
+            hipLaunchKernelGGL(k_sr_bucket_totals, dim3(bins2), dim3(256), 0, s, g.G, b.counts2, b.btot);
+            hipLaunchKernelGGL(k_sr_bucket_scan, dim3(1), dim3(kBins), 0, s, bins2, g.tile, b.btot, b.bstart2, nullptr);
+            hipLaunchKernelGGL(k_sr_bucket_offsets, dim3(bins2), dim3(256), 0, s, g.G, b.counts2, b.bstart2, b.offs2);
+            pt.mark();
+            hipLaunchKernelGGL(K.part2, G, T, 0, s, g, nullptr, b.keys1, b.tprefix2, b.bstart1, b.offs2, b.keys2, b.slots2,
+                               b.thist2);
+            pt.mark();
+            hipLaunchKernelGGL(k_sr_fine_scan, dim3(1), dim3(1024), 0, s, nf, b.fine_count, b.fstart, b.ioff);
+        }
         const unsigned slice_blocks = rb_env >= 1 ? (unsigned)rb_env : 1024u;
         if (op == 0)
         {

@@ -1,0 +1,78 @@
+"""The bucketed batch path (bv_sorted.hip) forced on vectors and batches of every shape: its answers are the direct kernel's.
+Covers what the BASELINE-size tests cannot: few lines (one digit only, empty digit-1 groups, slices without keys), batches
+smaller than a tile / than the number of blocks, all keys in one slice, sorted and windowed batches, arguments out of range."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def words(n, d, seed):
+    rng = np.random.default_rng(seed)
+    bits = rng.random(n) < d
+    pad = (-n) % 64
+    b = np.concatenate([bits, np.zeros(pad, dtype=bool)])
+    return np.packbits(b.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint64).copy()
+
+
+def batches(n_bits, rng, big):
+    yield "one", np.array([n_bits // 2], dtype=np.uint64)
+    yield "few", rng.integers(0, n_bits + 1, 100, dtype=np.uint64)
+    for m in (8191, 8192, 8193, big):
+        yield f"uniform{m}", rng.integers(0, n_bits + 1, m, dtype=np.uint64)
+    yield "same", np.full(50_000, n_bits // 3, dtype=np.uint64)
+    yield "sorted", np.sort(rng.integers(0, n_bits + 1, 200_000, dtype=np.uint64))
+    yield "window", (n_bits // 2 + rng.integers(0, min(n_bits // 2, 1 << 12) + 1, 100_000, dtype=np.uint64))
+    bad = rng.integers(0, n_bits + 1, 100_000, dtype=np.uint64)
+    bad[::3] = n_bits + 1 + (bad[::3] << np.uint64(20))
+    bad[5] = np.uint64(2 ** 64 - 1)
+    yield "out_of_range", bad
+    yield "ends", np.concatenate([np.arange(min(n_bits + 1, 3000), dtype=np.uint64), np.arange(max(0, n_bits - 3000), n_bits + 1, dtype=np.uint64)])
+
+
+@pytest.mark.parametrize("n_bits", [1, 447, 448, 449, 448 * 1024, 448 * 1024 + 1, 448 * 1024 * 3 + 5, 448 * 1024 * 300, 40_000_003])
+def test_bucketed_rank_equals_direct(gpu, n_bits):
+    w = words(n_bits, 0.5 if n_bits % 2 else 0.07, n_bits % 997)
+    bv = gpu.bit_vector(w, n_bits)
+    rng = np.random.default_rng(n_bits)
+    for name, idx in batches(n_bits, rng, 1_500_000):
+        for bit in (0, 1):
+            gpu.set_option("rank_sorted", 0)
+            want = bv.rank(idx, bit)
+            try:
+                gpu.set_option("rank_sorted", 1)
+                gpu.set_option("trace_phases", 1)
+                got = bv.rank(idx, bit)
+                assert gpu.last_phases().get("select") == 0, "the bucketed path was not taken"
+            finally:
+                gpu.set_option("rank_sorted", -1)
+                gpu.set_option("trace_phases", 0)
+            assert np.array_equal(got, want), f"{name}, bit {bit}"
+    bv.release_scratch()
+
+
+@pytest.mark.parametrize("n_bits,d", [(449, 0.5), (448 * 1024 + 1, 0.5), (448 * 1024 * 40, 0.5), (448 * 1024 * 40, 0.01), (40_000_003, 0.93)])
+def test_bucketed_select_equals_direct(gpu, n_bits, d):
+    w = words(n_bits, d, n_bits % 991)
+    bv = gpu.bit_vector(w, n_bits)
+    rng = np.random.default_rng(n_bits + 1)
+    for bit in (0, 1):
+        total = bv.ones() if bit else n_bits - bv.ones()
+        if total < 2:
+            continue
+        cases = {"few": rng.integers(1, total + 1, 100, dtype=np.uint64),
+                 "uniform": rng.integers(1, total + 1, 1_000_000, dtype=np.uint64),
+                 "tile": rng.integers(1, total + 1, 8193, dtype=np.uint64),
+                 "same": np.full(30_000, max(1, total // 2), dtype=np.uint64),
+                 "sorted": np.sort(rng.integers(1, total + 1, 200_000, dtype=np.uint64)),
+                 "out_of_range": np.concatenate([rng.integers(0, total + 3, 100_000, dtype=np.uint64), np.array([0, total, total + 1, 2 ** 64 - 1], dtype=np.uint64)])}
+        for name, i in cases.items():
+            gpu.set_option("select_sorted", 0)
+            want = bv.select(i, bit)
+            try:
+                gpu.set_option("select_sorted", 1)
+                got = bv.select(i, bit)
+            finally:
+                gpu.set_option("select_sorted", -1)
+            assert np.array_equal(got, want), f"{name}, bit {bit}"
+    bv.release_scratch()
