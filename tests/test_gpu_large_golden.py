@@ -131,6 +131,33 @@ def test_c2_default_dispatch_keeps_local_batches_on_the_direct_kernel(gpu, c2_ve
         bv.release_scratch()
 
 
+def test_c2_batches_beyond_one_pass(gpu, c2_vector):
+    """A batch of more than 2^30 - 2^20 queries goes through the passes in two rounds (32-bit cursors, 30-bit look-back
+    counts): rank and select agree with the direct kernels on all 1.1 * 10^9 answers."""
+    import torch
+    bv, n = c2_vector
+    nq = 1_100_000_000
+    g = torch.Generator(device="cuda").manual_seed(21)
+    idx = torch.randint(0, n + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
+    try:
+        gpu.set_option("rank_sorted", 0)
+        want = bv.rank(idx, 1)
+        gpu.set_option("rank_sorted", 1)
+        got = bv.rank(idx, 1)
+        assert torch.equal(got, want)
+        del got
+        idx.clamp_(1, G["c2"]["ones"])
+        gpu.set_option("select_sorted", 0)
+        bv.select(idx, 1, out=want)
+        gpu.set_option("select_sorted", 1)
+        got = bv.select(idx, 1)
+        assert torch.equal(got, want)
+    finally:
+        gpu.set_option("rank_sorted", -1)
+        gpu.set_option("select_sorted", -1)
+        bv.release_scratch()
+
+
 def test_c3_rrr63_rank_select_match_reference_digests(gpu):
     import torch
     c = G["c3"]
