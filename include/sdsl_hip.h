@@ -152,7 +152,7 @@ sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv);
  * kernel launch and one stream synchronisation (about 10 microseconds) — correct, but a loop of such
  * calls is latency-bound: batch whenever there is a loop. */
 sdsl_hip_status sdsl_hip_bv_query_one(sdsl_hip_bv_t bv, int32_t what, int32_t bit, uint64_t arg, uint64_t * out);
-/* frees the working memory the bucketed batch rank keeps with the handle between calls (13 bytes per query of the largest
+/* frees the working memory the bucketed batch rank keeps with the handle between calls (12 bytes per query of the largest
  * batch seen, at most 2^30 queries' worth; counted by sdsl_hip_bv_device_bytes); the next large batch allocates it again */
 sdsl_hip_status sdsl_hip_bv_release_scratch(sdsl_hip_bv_t bv);
 uint64_t sdsl_hip_bv_size(sdsl_hip_bv_t bv);         /* bit_vector::size() */
@@ -421,7 +421,7 @@ sdsl_hip_status sdsl_hip_group_fm_count_batch(sdsl_hip_group_t g, const sdsl_hip
 sdsl_hip_status sdsl_hip_set_timing(int32_t enabled);
 /* Process-wide knobs.  "rank_sorted": how sdsl_hip_bv_rank_batch answers a batch in device memory: 0 = always the direct
  * kernel (one rank line per query), 1 = the bucketed path whenever the vector allows it (bv_sorted.hip: the batch is
- * partitioned by index slice, slices are staged in LDS; 13 bytes of device scratch per query, kept with the handle),
+ * partitioned by index slice, slices are staged in LDS; 12 bytes of device scratch per query, kept with the handle),
  * -1 = automatic (bucketed when the batch addresses every line of a vector larger than the caches several times AND a
  * sample of the batch is spread over the vector — a windowed or sorted batch stays on the direct kernel; reading that
  * sample back synchronises the stream once per call, so use 0 or 1 where a call must stay asynchronous, e.g. under

@@ -68,7 +68,6 @@ struct SrBuf
 { // carved out of the scratch allocation
     uint32_t *keys1, *keys2;   // keys1 doubles as the low 32 bits of the absolute answers on the way back
     uint16_t *slots1, *slots2;
-    uint8_t * hi8;             // bits 32.. of the absolute answers (0xFF: NPOS)
     uint16_t *thist1, *thist2; // [tile][bin]
     uint32_t *counts1, *offs1, *bstart1;
     uint32_t *counts2, *offs2, *bstart2;
@@ -131,8 +130,8 @@ __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned
         }
         const uint64_t k = pos - 1;
         const uint32_t f = (uint32_t)(((k >> g.bs) * g.binv) >> 32); // k / B
-        dig = f & ((1u << g.d1) - 1);
-        key = ((f >> g.d1) << g.kb) | (uint32_t)(k - (uint64_t)f * g.B);
+        dig = f >> g.d2;
+        key = ((f & ((1u << g.d2) - 1)) << g.kb) | (uint32_t)(k - (uint64_t)f * g.B);
         return;
     }
     if (pos > g.n_bits)
@@ -145,8 +144,8 @@ __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned
     unsigned off;
     line_of(pos, g.small, L, off);
     const uint32_t l = (uint32_t)L; // < 2^26
-    dig = (l >> kSliceLog) & ((1u << g.d1) - 1);
-    key = ((l >> (kSliceLog + g.d1)) << kKey2Bits) | ((l & ((1u << kSliceLog) - 1)) << kOffBits) | off;
+    dig = l >> (kSliceLog + g.d2);
+    key = (((l >> kSliceLog) & ((1u << g.d2) - 1)) << kKey2Bits) | ((l & ((1u << kSliceLog) - 1)) << kOffBits) | off;
 }
 // pass 2: digit and final key of a pass-1 key
 __device__ __forceinline__ void sr_key2(uint32_t k1, const SrGeom & g, unsigned & dig, uint32_t & key)
@@ -159,6 +158,13 @@ __device__ __forceinline__ void sr_key2(uint32_t k1, const SrGeom & g, unsigned 
     }
     dig = k1 >> g.kb;
     key = k1 & ((1u << g.kb) - 1);
+}
+
+// The tables per slice (fstart, ioff, hf) are indexed in the order of the final array: f = (pass-2 digit << d1) | pass-1 digit.
+// The slice itself (rank: 2^10 lines; select: a bucket of argument ranks) is (pass-1 digit << d2) | pass-2 digit.
+__device__ __forceinline__ unsigned sr_slice_of(unsigned f, unsigned d1, unsigned d2)
+{
+    return ((f & ((1u << d1) - 1)) << d2) | (f >> d1);
 }
 
 // Tiles of a pass.  Pass 1: tile i = keys [i * tile, ...).  Pass 2: the keys are grouped by digit 1 (group starts
@@ -471,12 +477,12 @@ __global__ __launch_bounds__(1024) void k_sr_fine_scan(unsigned nf, const uint32
 }
 
 // ones in front of every slice (what makes a slice-relative answer absolute)
-__global__ __launch_bounds__(256) void k_sr_slice_bases(BvView bv, unsigned nf, uint64_t * __restrict__ hf)
+__global__ __launch_bounds__(256) void k_sr_slice_bases(BvView bv, unsigned nf, unsigned d1, unsigned d2, uint64_t * __restrict__ hf)
 {
     const unsigned f = blockIdx.x * 256 + threadIdx.x;
     if (f < nf)
     {
-        const uint64_t L0 = (uint64_t)f << kSliceLog;
+        const uint64_t L0 = (uint64_t)sr_slice_of(f, d1, d2) << kSliceLog;
         hf[f] = L0 < bv.n_lines ? bv.lines[L0 * kLW] : 0;
     }
 }
@@ -872,7 +878,7 @@ __global__ __launch_bounds__(1024) void k_sr_fine_scan_starts(unsigned nf, unsig
 // the slice: 20 bits | ones in word 0: 9 bits | in words 0..2: 9 bits | in words 0..4: 9 bits].  A query then reads
 // the header's 16 bytes and the one 16-byte pair that holds its word: two LDS reads and two popcounts instead of the
 // whole line (the first form of this kernel spent 1.4 wave instructions per key, 65 % of its time in the VALU).
-__global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigned nf, const uint32_t * __restrict__ fstart,
+__global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigned nf, unsigned d1, unsigned d2, const uint32_t * __restrict__ fstart,
                                                      const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys)
 {
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
@@ -902,7 +908,7 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
         }
         __syncthreads(); // also: everybody is done with the previous slice
         const unsigned f = sh_f;
-        const uint64_t L0 = (uint64_t)f << kSliceLog;
+        const uint64_t L0 = (uint64_t)sr_slice_of(f, d1, d2) << kSliceLog;
         const unsigned nl = (unsigned)(bv.n_lines - L0 < (UINT64_C(1) << kSliceLog) ? bv.n_lines - L0 : (UINT64_C(1) << kSliceLog));
         const v2u64 * src = reinterpret_cast<const v2u64 *>(bv.lines + L0 * kLW);
         for (unsigned i = t; i < nl * (kLW / 2); i += kRT)
@@ -974,7 +980,7 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
 // interpolated guess at the line, a short bisection over the headers in LDS, then the 16-byte pair that holds the word and
 // sel64 inside it.  A bucket that spans more than an LDS slice (a sparse stretch) is left to the fix-up pass.
 template <int BIT>
-__global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, unsigned B, const uint32_t * __restrict__ bnd,
+__global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, unsigned d1, unsigned d2, unsigned B, const uint32_t * __restrict__ bnd,
                                                        const uint32_t * __restrict__ fstart, const uint32_t * __restrict__ ioff,
                                                        uint32_t * __restrict__ keys, uint32_t * __restrict__ any_marked)
 {
@@ -1007,8 +1013,9 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
         const uint64_t fend = fstart[f + 1];
         const unsigned cnt = (unsigned)(lo + kItemKeys < fend ? kItemKeys : fend - lo);
         uint32_t * kp = keys + lo;
-        const uint64_t L0 = bnd[f];
-        const uint64_t L1 = (uint64_t)bnd[f + 1] + 1 < bv.n_lines ? (uint64_t)bnd[f + 1] + 1 : bv.n_lines;
+        const unsigned bk = sr_slice_of(f, d1, d2); // the bucket (f: its place in the tables)
+        const uint64_t L0 = bnd[bk];
+        const uint64_t L1 = (uint64_t)bnd[bk + 1] + 1 < bv.n_lines ? (uint64_t)bnd[bk + 1] + 1 : bv.n_lines;
         if (L1 - L0 > (UINT64_C(1) << kSliceLog))
         { // wider than a slice: the fix-up pass answers these
             for (unsigned i = t; i < cnt; i += kRT)
@@ -1067,7 +1074,7 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
                 sh_tot = (unsigned)(before - A0) + cc + popc64(d.x) + popc64(d.y); // arguments inside the slice
         }
         __syncthreads();
-        const uint64_t t0 = (uint64_t)f * B - A0; // rank of the bucket's first argument, relative to the slice
+        const uint64_t t0 = (uint64_t)bk * B - A0; // rank of the bucket's first argument, relative to the slice
         const float scale = (float)nl / (float)(sh_tot ? sh_tot : 1);
         for (unsigned i0 = t; i0 < cnt; i0 += kRT * U)
         {
@@ -1147,11 +1154,15 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
 }
 
 // first bit of every select bucket's slice (what makes a slice-relative position absolute)
-__global__ __launch_bounds__(256) void k_sr_select_bases(unsigned nf, const uint32_t * __restrict__ bnd, uint64_t * __restrict__ hf)
+__global__ __launch_bounds__(256) void k_sr_select_bases(unsigned nf, unsigned n_buckets, unsigned d1, unsigned d2,
+                                                         const uint32_t * __restrict__ bnd, uint64_t * __restrict__ hf)
 {
     const unsigned f = blockIdx.x * 256 + threadIdx.x;
     if (f < nf)
-        hf[f] = (uint64_t)bnd[f] * kDB;
+    {
+        const unsigned bk = sr_slice_of(f, d1, d2);
+        hf[f] = bk < n_buckets ? (uint64_t)bnd[bk] * kDB : 0; // first bit of the bucket's first line
+    }
 }
 
 // The arguments that were left over (kMark64 in the output): one lane per query, bracket from the directory, bisection over
@@ -1206,20 +1217,20 @@ __global__ __launch_bounds__(256) void k_sr_select_fixup(BvView bv, const uint32
 }
 
 // ---- the way back ---------------------------------------------------------------------------------------------------
-// P == 2: slice-relative answers (order of partition 2) -> absolute answers in the order of partition 1 (lo32 / hi8)
+// P == 2: slice-relative answers (order of partition 2) -> answers relative to their pass-1 bin, in the order of partition 1
 // P == 1: absolute answers in the order of partition 1 -> the caller's array
 // V & 1: the runs are fetched four bins at a time (else bin after bin); V & 2: the slots are asked for before the gather
 template <int P, unsigned TT, unsigned PER, int V>
 __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const uint64_t * __restrict__ hf, int bit, SrGeom g, const uint32_t * __restrict__ tprefix,
                                                      const uint32_t * __restrict__ gstart, const uint32_t * __restrict__ offs,
-                                                     const uint32_t * __restrict__ res_lo, const uint8_t * __restrict__ res_hi,
+                                                     const uint32_t * __restrict__ res_lo, uint32_t * __restrict__ any_marked,
                                                      const uint16_t * __restrict__ slots,
                                                      const uint16_t * __restrict__ tile_hist, uint32_t * __restrict__ out_lo,
-                                                     uint8_t * __restrict__ out_hi, uint64_t * __restrict__ out)
+                                                     uint64_t * __restrict__ out)
 {
     constexpr unsigned kTile = TT * PER;
     __shared__ uint32_t lo32[kTile];
-    __shared__ uint8_t hi8[kTile];
+    __shared__ uint8_t hi8[P == 1 ? kTile : 1]; // pass 1: bits 32.. of the absolute answers (0xFF: NPOS, 0xFE: left to the fix-up)
     __shared__ unsigned hist[kBins], start[kBins], cursor[kBins];
     __shared__ unsigned wsum[kBins / 64];
     __shared__ unsigned big[kTile / (kBigRun + 1) + 1], n_big;
@@ -1269,28 +1280,40 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
         __syncthreads();
         block_excl_scan_bins(start, wsum);
         // what turns the answers of bin b of this tile into absolute ones (pass 2: the slice's first header)
-        auto base_of = [&](unsigned b) -> uint64_t
+        // what turns a slice-relative answer into an absolute one: rank: ones (zeros) in front of the slice; select: the first
+        // bit of the bucket's first line.  f = place of the slice in the tables, (b2, b1) = its pass-2 / pass-1 digits
+        auto abs_base = [&](unsigned b2, unsigned b1) -> uint64_t
         {
-            if (P == 1)
-                return 0;
-            const unsigned f = (b << g.d1) | grp;
-            const uint64_t h = hf[f]; // rank: ones in front of the slice (0 past the end); select: first bit of the slice
+            const uint64_t h = hf[(b2 << g.d1) | b1];
             if (g.op == 1)
                 return h;
-            return bit ? h : ((uint64_t)f << kSliceLog) * kDB - h;
+            return bit ? h : ((uint64_t)((b1 << g.d2) | b2) << kSliceLog) * kDB - h;
         };
-        auto keep = [&](uint64_t base, unsigned at, uint32_t v, uint8_t h)
+        // Between the two passes an answer travels as 32 bits RELATIVE TO ITS PASS-1 BIN: such a bin is a contiguous stretch of
+        // the vector (2^d2 slices), so all its answers lie within 2^32 of its first slice's base (rank: always; select: unless
+        // the stretch is mostly empty space — then the answer is left to the fix-up pass).  0xFFFFFFFF / ..FE stay NPOS / mark.
+        const uint64_t gbase = P == 2 ? abs_base(0, grp) : 0;
+        auto base_of = [&](unsigned b) -> uint64_t { return P == 2 ? abs_base(b, grp) - gbase : abs_base(0, b); };
+        auto keep = [&](uint64_t base, unsigned at, uint32_t v)
         {
             if (P == 2)
+            {
+                const uint64_t rel = base + v;
+                uint32_t r = (uint32_t)rel;
+                if (v >= kMark)
+                    r = v;
+                else if (rel >= kMark)
+                {
+                    r = kMark;
+                    *any_marked = 1;
+                }
+                lo32[at] = r;
+            }
+            else
             {
                 const uint64_t full = base + v;
                 lo32[at] = (uint32_t)full;
                 hi8[at] = v == kBad ? (uint8_t)0xFF : (v == kMark ? (uint8_t)0xFE : (uint8_t)(full >> 32));
-            }
-            else
-            {
-                lo32[at] = v;
-                hi8[at] = h;
             }
         };
         if (!(V & 1))
@@ -1310,7 +1333,7 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
                 }
                 const uint64_t base = base_of(b);
                 for (unsigned i = l; i < cnt; i += 16)
-                    keep(base, st + i, res_lo[(uint64_t)cur + i], P == 1 ? res_hi[(uint64_t)cur + i] : (uint8_t)0);
+                    keep(base, st + i, res_lo[(uint64_t)cur + i]);
             }
         }
         else
@@ -1322,7 +1345,6 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
                 unsigned cnt[2], st[2], cur[2];
                 uint64_t base[2];
                 uint32_t v[2][kE];
-                uint8_t h8[2][kE];
 #pragma unroll
                 for (unsigned k = 0; k < 2; ++k)
                 {
@@ -1340,14 +1362,13 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
 #pragma unroll
                 for (unsigned k = 0; k < 2; ++k)
                 {
-                    base[k] = (P == 2 && cnt[k]) ? base_of(b0 + k * kStep) : 0;
+                    base[k] = cnt[k] ? base_of(b0 + k * kStep) : 0;
 #pragma unroll
                     for (unsigned e = 0; e < kE; ++e)
                     {
                         const unsigned i = l + 16 * e;
                         const bool on = i < cnt[k];
                         v[k][e] = on ? res_lo[(uint64_t)cur[k] + i] : 0;
-                        h8[k][e] = (P == 1 && on) ? res_hi[(uint64_t)cur[k] + i] : (uint8_t)0;
                     }
                 }
 #pragma unroll
@@ -1356,9 +1377,9 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
 #pragma unroll
                     for (unsigned e = 0; e < kE; ++e)
                         if (l + 16 * e < cnt[k])
-                            keep(base[k], st[k] + l + 16 * e, v[k][e], h8[k][e]);
+                            keep(base[k], st[k] + l + 16 * e, v[k][e]);
                     for (unsigned i = l + 16 * kE; i < cnt[k]; i += 16)
-                        keep(base[k], st[k] + i, res_lo[(uint64_t)cur[k] + i], P == 1 ? res_hi[(uint64_t)cur[k] + i] : (uint8_t)0);
+                        keep(base[k], st[k] + i, res_lo[(uint64_t)cur[k] + i]);
                 }
             }
         }
@@ -1369,7 +1390,7 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
             const unsigned b = big[k], c = hist[b], s0 = start[b], cu = cursor[b];
             const uint64_t base = base_of(b);
             for (unsigned i = t; i < c; i += TT)
-                keep(base, s0 + i, res_lo[(uint64_t)cu + i], P == 1 ? res_hi[(uint64_t)cu + i] : (uint8_t)0);
+                keep(base, s0 + i, res_lo[(uint64_t)cu + i]);
         }
         __syncthreads();
         if (!(V & 2))
@@ -1380,7 +1401,6 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
                 load_slots(std::false_type{});
         }
         uint32_t * out_lo_t = P == 2 ? out_lo + lo : nullptr;
-        uint8_t * out_hi_t = P == 2 ? out_hi + lo : nullptr;
         uint64_t * out_t = P == 1 ? out + lo : nullptr;
         auto store_out = [&](auto full_c)
         {
@@ -1391,13 +1411,10 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const ui
                 const unsigned q = u * TT + t;
                 if (FULL || q < cnt_t)
                 {
-                    const unsigned h = hi8[sl[u]];
+                    const unsigned h = P == 1 ? hi8[sl[u]] : 0u;
                     const uint32_t l32 = lo32[sl[u]];
                     if (P == 2)
-                    {
                         __builtin_nontemporal_store(l32, out_lo_t + q);
-                        __builtin_nontemporal_store((uint8_t)h, out_hi_t + q);
-                    }
                     else
                         __builtin_nontemporal_store(h == 0xFFu ? SDSL_HIP_NPOS : (h == 0xFEu ? kMark64 : ((uint64_t)h << 32) | l32),
                                                     out_t + q);
@@ -1495,7 +1512,6 @@ size_t carve(SrBuf & b, void * scratch, uint64_t n, unsigned tile)
     b.keys2 = (uint32_t *)take(n * 4);
     b.slots1 = (uint16_t *)take(n * 2);
     b.slots2 = (uint16_t *)take(n * 2);
-    b.hi8 = (uint8_t *)take(n);
     b.thist1 = (uint16_t *)take(tiles1 * kBins * 2);
     b.thist2 = (uint16_t *)take(tiles2 * kBins * 2);
     b.counts1 = (uint32_t *)take((size_t)kBins * kMaxG * 4);
@@ -1525,10 +1541,10 @@ struct SrKernels
                   uint16_t *, uint16_t *);
     void (*part2)(SrGeom, const uint64_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *,
                   uint16_t *, uint16_t *);
-    void (*unp2)(const uint64_t *, int, SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint8_t *,
-                 const uint16_t *, const uint16_t *, uint32_t *, uint8_t *, uint64_t *);
-    void (*unp1)(const uint64_t *, int, SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, const uint8_t *,
-                 const uint16_t *, const uint16_t *, uint32_t *, uint8_t *, uint64_t *);
+    void (*unp2)(const uint64_t *, int, SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *,
+                 const uint16_t *, const uint16_t *, uint32_t *, uint64_t *);
+    void (*unp1)(const uint64_t *, int, SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *,
+                 const uint16_t *, const uint16_t *, uint32_t *, uint64_t *);
     void (*part2s)(SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *,
                    uint16_t *, uint16_t *, uint32_t *, uint32_t *);
     unsigned threads, blocks_per_cu, per;
@@ -1556,7 +1572,7 @@ std::string bv_sorted_last_phases()
     return g_last_phases;
 }
 
-// scratch: 13 bytes per position (two key arrays, two slot arrays, the high answer byte) + the tables
+// scratch: 12 bytes per position (two key arrays, two slot arrays) + the tables (incl. 1 KiB of look-back words per tile)
 size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n)
 {
     (void)v;
@@ -1616,8 +1632,8 @@ static void sr_fill_geom(SrGeom & g, const BvView & v, int op, const SelectPlan 
         g.binv = (uint32_t)(((UINT64_C(1) << 32) + sp.bm - 1) / sp.bm);
         g.total = sp.total;
     }
-    g.d1 = f < 8 ? f : 8;
-    g.d2 = f - g.d1;
+    g.d2 = f < 8 ? f : 8; // pass 2: the LOW bits of the slice index; pass 1: the high ones, so that a pass-1 bin is a contiguous
+    g.d1 = f - g.d2;      // stretch of the vector and the answers of its keys fit 32 bits relative to the stretch's first one
     g.small = v.n_bits < (UINT64_C(1) << 38);
 }
 
@@ -1738,30 +1754,29 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         const unsigned slice_blocks = rb_env >= 1 ? (unsigned)rb_env : 1024u;
         if (op == 0)
         {
-            hipLaunchKernelGGL(k_sr_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, s, v, nf, b.hf);
+            hipLaunchKernelGGL(k_sr_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, s, v, nf, g.d1, g.d2, b.hf);
             pt.mark();
-            hipLaunchKernelGGL(k_sr_rank_lds, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, b.fstart, b.ioff, b.keys2);
+            hipLaunchKernelGGL(k_sr_rank_lds, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, g.d1, g.d2, b.fstart, b.ioff, b.keys2);
         }
         else
         {
-            SH_HIP(hipMemsetAsync(b.hf, 0, (size_t)nf * 8, s));
             SH_HIP(hipMemsetAsync(b.btot, 0, 4, s)); // doubles as the "some answers are left to the fix-up pass" flag
-            hipLaunchKernelGGL(k_sr_select_bases, dim3((sp.nf + 255) / 256), dim3(256), 0, s, sp.nf, sp.bnd, b.hf);
+            hipLaunchKernelGGL(k_sr_select_bases, dim3((nf + 255) / 256), dim3(256), 0, s, nf, sp.nf, g.d1, g.d2, sp.bnd, b.hf);
             pt.mark();
             // slices beyond sp.nf are empty (no items), so the kernel never reads bnd past sp.nf
             if (bit)
-                hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
+                hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, g.d1, g.d2, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
                                    b.keys2, b.btot);
             else
-                hipLaunchKernelGGL(k_sr_select_lds<0>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
+                hipLaunchKernelGGL(k_sr_select_lds<0>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, g.d1, g.d2, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
                                    b.keys2, b.btot);
         }
         pt.mark();
-        hipLaunchKernelGGL(K.unp2, G, T, 0, s, b.hf, bit, g, b.tprefix2, b.bstart1, b.offs2, b.keys2, nullptr, b.slots2, b.thist2,
-                           b.keys1, b.hi8, nullptr);
+        hipLaunchKernelGGL(K.unp2, G, T, 0, s, b.hf, bit, g, b.tprefix2, b.bstart1, b.offs2, b.keys2, b.btot, b.slots2, b.thist2,
+                           b.keys1, nullptr);
         pt.mark();
-        hipLaunchKernelGGL(K.unp1, G, T, 0, s, b.hf, bit, g, nullptr, nullptr, b.offs1, b.keys1, b.hi8, b.slots1, b.thist1,
-                           nullptr, nullptr, d_out + done);
+        hipLaunchKernelGGL(K.unp1, G, T, 0, s, b.hf, bit, g, nullptr, nullptr, b.offs1, b.keys1, nullptr, b.slots1, b.thist1,
+                           nullptr, d_out + done);
         pt.mark();
         if (op == 1)
         { // whatever the slices left over (buckets wider than a slice): one lane per marked answer
