@@ -76,3 +76,31 @@ def test_bucketed_select_equals_direct(gpu, n_bits, d):
                 gpu.set_option("select_sorted", -1)
             assert np.array_equal(got, want), f"{name}, bit {bit}"
     bv.release_scratch()
+
+
+def test_histogram_pass_2_still_works(gpu):
+    """SDSL_HIP_SORTED_SWEEP=0 keeps the second histogram pass instead of the one-sweep partition (A/B measurements): the
+    path is read from the environment when the library first runs a bucketed batch, so it is exercised in a child process."""
+    import os, subprocess, sys
+    code = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module("sdsl-lite_amd")
+rng = np.random.default_rng(1)
+n = 448 * 1024 * 37 + 11
+w = rng.integers(0, 2**63, (n + 63) // 64, dtype=np.int64).view(np.uint64)
+bv = pkg.bit_vector(w, n)
+idx = rng.integers(0, n + 1, 700_001, dtype=np.uint64)
+i1 = rng.integers(1, bv.ones() + 1, 700_001, dtype=np.uint64)
+pkg.set_option("rank_sorted", 0); pkg.set_option("select_sorted", 0)
+want = bv.rank(idx, 1), bv.rank(idx, 0), bv.select(i1, 1)
+pkg.set_option("rank_sorted", 1); pkg.set_option("select_sorted", 1); pkg.set_option("trace_phases", 1)
+got = bv.rank(idx, 1), bv.rank(idx, 0), bv.select(i1, 1)
+ph = pkg.last_phases()
+assert ph.get("hist2", 0) > 0.0005, ph
+assert all(np.array_equal(a, b) for a, b in zip(got, want))
+print("OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDSL_HIP_SORTED_SWEEP="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
