@@ -615,8 +615,8 @@ __global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_partition(SrGeom g
 // group's first tile), and so do the per-(bin, block) offsets the way back (k_sr_unpermute<2>, static tile ranges) starts from.
 constexpr uint32_t kStAgg = 1u << 30, kStIncl = 2u << 30, kStMask = (1u << 30) - 1;
 
-template <unsigned TT, unsigned PER>
-__global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_partition2_sweep(SrGeom g, const uint32_t * __restrict__ keys_in,
+template <unsigned TT, unsigned PER, unsigned WPE>
+__global__ __launch_bounds__(TT, WPE) void k_sr_partition2_sweep(SrGeom g, const uint32_t * __restrict__ keys_in,
                                                      const uint32_t * __restrict__ tprefix, const uint32_t * __restrict__ gstart,
                                                      const uint32_t * __restrict__ bstart2, uint32_t * __restrict__ status,
                                                      uint32_t * __restrict__ ticket, uint32_t * __restrict__ keys_out,
@@ -1547,6 +1547,8 @@ struct SrKernels
                  const uint16_t *, const uint16_t *, uint32_t *, uint64_t *);
     void (*part2s)(SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *,
                    uint16_t *, uint16_t *, uint32_t *, uint32_t *);
+    void (*part2s3)(SrGeom, const uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t *, uint32_t *, uint32_t *,
+                    uint16_t *, uint16_t *, uint32_t *, uint32_t *); // the same at three blocks per CU (80 VGPRs)
     unsigned threads, blocks_per_cu, per;
 };
 template <unsigned TT, unsigned PER>
@@ -1554,7 +1556,7 @@ SrKernels sr_kernels(unsigned per_cu)
 {
     return SrKernels{k_sr_hist<1, TT, PER>,      k_sr_hist<2, TT, PER>,         k_sr_partition<1, TT, PER>,
                      k_sr_partition<2, TT, PER>, k_sr_unpermute<2, TT, PER, 3>, k_sr_unpermute<1, TT, PER, 3>,
-                     k_sr_partition2_sweep<TT, PER>,
+                     k_sr_partition2_sweep<TT, PER, (PER >= 16 ? 4 : 8)>, k_sr_partition2_sweep<TT, PER, (PER >= 16 ? 6 : 8)>,
                      TT,                         per_cu,                        PER};
 }
 
@@ -1732,7 +1734,10 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
             SH_HIP(hipMemsetAsync(b.ticket, 0, 4, s));
             SH_HIP(hipMemsetAsync(b.fstart, 0xFF, ((size_t)nf + 1) * 4, s));
             pt.mark();
-            hipLaunchKernelGGL(K.part2s, G, T, 0, s, g, b.keys1, b.tprefix2, b.bstart1, b.bstart2, b.status, b.ticket, b.keys2, b.slots2,
+            // three blocks per CU (the 80-VGPR build: a dozen loop invariants live in scratch) cover the look-back's round trips
+            // better than two: 4.06 -> 3.92 ms, same box; SDSL_HIP_SWEEP_BLOCKS=0 runs the 128-VGPR build at two per CU
+            static const int s3 = getenv("SDSL_HIP_SWEEP_BLOCKS") ? atoi(getenv("SDSL_HIP_SWEEP_BLOCKS")) : 768;
+            hipLaunchKernelGGL(s3 > 0 ? K.part2s3 : K.part2s, s3 > 0 ? dim3((unsigned)s3) : G, T, 0, s, g, b.keys1, b.tprefix2, b.bstart1, b.bstart2, b.status, b.ticket, b.keys2, b.slots2,
                                b.thist2, b.offs2, b.fstart);
             pt.mark();
             hipLaunchKernelGGL(k_sr_fine_scan_starts, dim3(1), dim3(1024), 0, s, nf, (unsigned)cnt, b.fstart, b.ioff);
