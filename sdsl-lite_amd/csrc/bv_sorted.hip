@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(256) void k_sr_select_fixup(BvView bv, const uint32
 // P == 1: absolute answers in the order of partition 1 -> the caller's array
 // V & 1: the runs are fetched four bins at a time (else bin after bin); V & 2: the slots are asked for before the gather
 template <int P, unsigned TT, unsigned PER, int V>
-__global__ __launch_bounds__(TT, PER >= 16 ? 4 : 8) void k_sr_unpermute(const uint64_t * __restrict__ hf, int bit, SrGeom g, const uint32_t * __restrict__ tprefix,
+__global__ __launch_bounds__(TT, PER >= 16 ? 6 : 8) void k_sr_unpermute(const uint64_t * __restrict__ hf, int bit, SrGeom g, const uint32_t * __restrict__ tprefix,
                                                      const uint32_t * __restrict__ gstart, const uint32_t * __restrict__ offs,
                                                      const uint32_t * __restrict__ res_lo, uint32_t * __restrict__ any_marked,
                                                      const uint16_t * __restrict__ slots,
@@ -1696,7 +1696,9 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
     static const bool sweep = !(getenv("SDSL_HIP_SORTED_SWEEP") && atoi(getenv("SDSL_HIP_SORTED_SWEEP")) == 0); // 0: histogram pass 2
     // tiles of 8192 keys (512 threads x 16) are the measured optimum on 2^34 bits (profiles/sorted_rank_v6_r02.txt:
     // 17.9 ms against 18.9 ms for 16384-key tiles and 21.4 ms for 4096-key tiles); the others stay selectable for profiling
-    const SrKernels K = t_env == 1024 ? sr_kernels<1024, 16>(1) : (t_env == 256 ? sr_kernels<256, 16>(4) : sr_kernels<512, 16>(2));
+    // three blocks per CU (768): the un-permute kernels are built for 80 VGPRs (six loop invariants in scratch) so that three fit —
+    // 3.96 + 3.24 -> 3.22 + 2.79 ms on one box (SDSL_HIP_SORTED_G=512 for two per CU); the partition of pass 1 stays at 128 VGPRs
+    const SrKernels K = t_env == 1024 ? sr_kernels<1024, 16>(1) : (t_env == 256 ? sr_kernels<256, 16>(4) : sr_kernels<512, 16>(3));
     for (uint64_t done = 0; done < n;)
     {
         const uint64_t cnt = n - done < kMaxPass ? n - done : kMaxPass;
