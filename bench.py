@@ -375,9 +375,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic("rank_bucketed_bytes_per_step" if bucketed else "k_rank_bytes_per_launch"),
-                     "kernel": ("bucketed batch rank (bv_sorted.hip): k_sr_hist<1>, k_sr_partition<1>, k_sr_hist<2>, "
-                                "k_sr_partition<2>, k_sr_rank_lds, k_sr_unpermute<2>, k_sr_unpermute<1> + 8 table kernels; "
-                                "kernel_ms = all of them, one step") if bucketed else "sdslhip::k_rank<4,false,true>",
+                     "kernel": ("bucketed batch rank (bv_sorted.hip): k_sr_hist<1>, k_sr_partition<1>, k_sr_partition2_sweep, "
+                                "k_sr_rank_lds, k_sr_unpermute<2>, k_sr_unpermute<1> + 6 table kernels (and k_sr_sample_spread: the "
+                                "automatic dispatch looks at the batch first); kernel_ms = all of them, one step") if bucketed else "sdslhip::k_rank<4,false,true>",
                      "kernel_ms": kernel_ms, "phases_ms": phases or None,
                      "algorithmic_bytes_per_query": ALG_BYTES["rank"],
                      "direct_kernel": {"kernel": "sdslhip::k_rank<4,false,true>", "kernel_ms": direct_ms,
