@@ -987,6 +987,8 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
     __shared__ v2u64 slice[(kLW << kSliceLog) / 2]; // 64 KiB
     __shared__ uint64_t hdr[1u << kSliceLog];       // the rewritten headers, packed (see k_sr_rank_lds)
+    constexpr unsigned kInv = 2048;
+    __shared__ uint16_t inv[kInv + 1];              // inv[e]: the line that holds the slice's argument number e << s
     __shared__ unsigned sh_f;
     __shared__ unsigned sh_tot;
     constexpr int U = 4;
@@ -1075,7 +1077,23 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
         }
         __syncthreads();
         const uint64_t t0 = (uint64_t)bk * B - A0; // rank of the bucket's first argument, relative to the slice
-        const float scale = (float)nl / (float)(sh_tot ? sh_tot : 1);
+        // the inverse of the headers, sampled: argument number e << s of the slice lies in line inv[e] (every line enters the
+        // samples that fall into it; lines without arguments enter none).  A query then starts at the sample below its
+        // argument and walks forward — two or three dependent LDS reads instead of the six to eight of an interpolated search
+        const unsigned tot = sh_tot;
+        unsigned sh = 0;
+        while ((tot >> sh) >= kInv)
+            ++sh;
+        const unsigned n_inv = ((tot + (1u << sh) - 1) >> sh); // samples 0 .. n_inv - 1 (arguments 0, 2^s, ...)
+        for (unsigned ln = t; ln < nl; ln += kRT)
+        {
+            const unsigned a0 = (unsigned)hdr[ln] & 0xFFFFFu, a1 = ln + 1 < nl ? (unsigned)hdr[ln + 1] & 0xFFFFFu : tot;
+            for (unsigned e = (a0 + (1u << sh) - 1) >> sh; (e << sh) < a1; ++e)
+                inv[e] = (uint16_t)ln;
+        }
+        if (t == 0)
+            inv[n_inv] = (uint16_t)(nl - 1);
+        __syncthreads();
         for (unsigned i0 = t; i0 < cnt; i0 += kRT * U)
         {
             if (i0 != t)
@@ -1095,41 +1113,26 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
                 if (key[u] != kBad)
                 {
                     const unsigned tg = (unsigned)t0 + key[u]; // arguments of the slice in front of the wanted one
-                    // line a with rel(a) <= tg < rel(a + 1).  The arguments are spread almost evenly over a slice, so two
-                    // interpolation steps — the slice-wide guess, then a correction by the guessed line's own count at the
-                    // slice's mean density — land on the line or next to it; a short walk, then bisection if the slice is
-                    // not that regular
+                    // line a with rel(a) <= tg < rel(a + 1): from the sample below tg, a short walk; a bisection up to the next
+                    // sample's line if the walk does not get there (empty lines in between)
                     auto rel = [&](unsigned j) -> unsigned { return (unsigned)hdr[j] & 0xFFFFFu; };
-                    unsigned j = (unsigned)((float)tg * scale);
-                    j = j >= nl ? nl - 1 : j;
+                    const unsigned e = tg >> sh;
+                    unsigned a = inv[e], z = (unsigned)inv[e + 1] + 1; // the line lies in [a, z)
+                    z = z > nl ? nl : z;
+#pragma unroll
+                    for (int it = 0; it < 3; ++it)
+                        if (a + 1 < z && rel(a + 1) <= tg)
+                            ++a;
+                    if (a + 1 < z && rel(a + 1) <= tg)
                     {
-                        const int d = (int)tg - (int)rel(j);
-                        int j2 = (int)j + (int)floorf((float)d * scale);
-                        j = j2 < 0 ? 0u : (j2 >= (int)nl ? nl - 1 : (unsigned)j2);
-                    }
-                    unsigned a = 0, z = nl;
-                    for (int it = 0; it < 4 && z - a > 1; ++it)
-                    {
-                        if (rel(j) <= tg)
+                        while (z - a > 1)
                         {
-                            a = j;
-                            j = j + 1 < z ? j + 1 : j;
-                            if (a + 1 < nl && rel(a + 1) > tg)
-                                z = a + 1;
+                            const unsigned m = (a + z) >> 1;
+                            if (rel(m) <= tg)
+                                a = m;
+                            else
+                                z = m;
                         }
-                        else
-                        {
-                            z = j;
-                            j = j > a + 1 ? j - 1 : a;
-                        }
-                    }
-                    while (z - a > 1)
-                    {
-                        const unsigned m = (a + z) >> 1;
-                        if (rel(m) <= tg)
-                            a = m;
-                        else
-                            z = m;
                     }
                     const v2u64 * w = slice + a * (kLW / 2);
                     const uint64_t hx = hdr[a];
