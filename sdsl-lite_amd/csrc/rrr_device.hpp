@@ -60,7 +60,10 @@ struct RrrView
 // ---- device: block decoder -----------------------------------------------------------------------
 // Sparse blocks (k <= 10 ones, or <= 10 zeros via the complement) are decoded from their offset: one bisection over the
 // binomial column per set bit (the idea of the reference's k <= 10 path).  Everything in between is stored raw.
-__device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsigned k, uint64_t nr)
+// `stop`: only the positions below it are wanted (rank needs the bits in front of its position): set bits come out in
+// increasing position, so the loop ends at the first one at or behind `stop` — a wave then runs as many rounds as its lane
+// with the most set bits IN FRONT of its position, not in its whole block
+__device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsigned k, uint64_t nr, unsigned stop = kRrrBS)
 {
     uint64_t bits = 0;
     int hi = 62; // candidate rows m = 62 - position
@@ -76,6 +79,8 @@ __device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsig
             else
                 h = mid - 1;
         }
+        if (62 - lo >= (int)stop)
+            break;
         bits |= UINT64_C(1) << (62 - lo);
         nr -= T->binom[lo][k];
         --k;
@@ -86,12 +91,13 @@ __device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsig
 
 // the 63-bit block of class k whose device field holds f (rrr_helper.hpp:480-534 for the enumerative classes: blocks of a
 // class are numbered in lexicographic order of (b0, b1, ...), 0 < 1)
-__device__ __forceinline__ uint64_t rrr_decode_block(const RrrTables * T, unsigned k, uint64_t f)
+// (stop < 63: only the bits at positions below `stop` are valid in the result)
+__device__ __forceinline__ uint64_t rrr_decode_block(const RrrTables * T, unsigned k, uint64_t f, unsigned stop = kRrrBS)
 {
     if (rrr_raw_width(T->space[k]))
         return f;
     const bool flip = k > 31; // the complement of a block with k ones is the block with 63-k ones and offset C(63,k)-1-nr
-    uint64_t bits = rrr_decode_sparse(T, flip ? kRrrBS - k : k, flip ? T->binom[63][k] - 1 - f : f);
+    uint64_t bits = rrr_decode_sparse(T, flip ? kRrrBS - k : k, flip ? T->binom[63][k] - 1 - f : f, stop);
     if (flip)
         bits = ~bits & lo_set(kRrrBS);
     return bits;
@@ -214,7 +220,7 @@ __device__ __forceinline__ uint64_t rrr_rank1(const RrrView & v, const RrrTables
     const RankTail t = rrr_rank_head(v, T, pos);
     uint64_t bits = 0;
     if (bit_out || t.off != 0) // rank at a block boundary needs no decode
-        bits = rrr_decode_block(T, t.k, t.nr);
+        bits = rrr_decode_block(T, t.k, t.nr, t.off + (bit_out ? 1u : 0u));
     if (bit_out)
         *bit_out = (unsigned)(bits >> t.off) & 1u;
     return t.rank + popc64(bits & lo_set(t.off));
@@ -239,11 +245,11 @@ __device__ __forceinline__ void rrr_rank2(const RrrView & v, const RrrTables * T
         tb = rrr_rank_head(v, T, pb);
     uint64_t bits_a = 0;
     if (ta.off != 0 || (same && tb.off != 0))
-        bits_a = rrr_decode_block(T, ta.k, ta.nr);
+        bits_a = rrr_decode_block(T, ta.k, ta.nr, same ? tb.off : ta.off); // (same block: pa <= pb)
     ra = ta.rank + popc64(bits_a & lo_set(ta.off));
     uint64_t bits_b = bits_a;
     if (!same && tb.off != 0)
-        bits_b = rrr_decode_block(T, tb.k, tb.nr);
+        bits_b = rrr_decode_block(T, tb.k, tb.nr, tb.off);
     rb = tb.rank + popc64(bits_b & lo_set(tb.off));
 }
 
