@@ -104,3 +104,12 @@ print("OK")
     env = dict(os.environ, SDSL_HIP_SORTED_SWEEP="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_random_vectors_and_batches_for_ten_seconds(gpu):
+    """tools/stress_bucketed.py: random vector sizes / densities / batch sizes / distributions, bucketed against direct."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_bucketed.py"), "10", "3"], capture_output=True, text=True,
+                       timeout=240)
+    assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
