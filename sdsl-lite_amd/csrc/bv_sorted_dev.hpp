@@ -1,0 +1,274 @@
+// bv_sorted_dev.hpp — what the two bucketed pipelines (bv_sorted.hip: one-sweep look-back; bv_swc.hip: static streams with
+// write combining) share: key layout, digits, block scans.  DESIGN.md §3.5.
+#pragma once
+#include <string>
+
+#include "bv_host.hpp"
+
+namespace sdslhip {
+namespace {
+
+constexpr unsigned kRT = 512;            // threads of a rank block
+constexpr unsigned kBins = 256;          // bins per pass (8-bit digits)
+constexpr unsigned kSliceLog = 10;       // lines per slice (64 KiB)
+constexpr unsigned kOffBits = 9;         // 448 < 2^9 in-line offsets
+constexpr unsigned kKey2Bits = kSliceLog + kOffBits;
+constexpr uint32_t kBad = 0xFFFFFFFFu;   // key / answer of a position beyond the vector (answer NPOS)
+constexpr uint32_t kMark = 0xFFFFFFFEu;  // select: answer left to the fix-up pass (bucket wider than an LDS slice)
+constexpr uint64_t kMark64 = SDSL_HIP_NPOS - 1;
+constexpr unsigned kBigRun = 512;        // a (tile, bin) run longer than this is copied by the whole block
+constexpr unsigned kItemKeys = 32768;    // keys of one slice handled by one block before the slice is reloaded
+
+struct SrGeom
+{
+    uint64_t n;      // positions in this pass over the batch (< 2^31)
+    uint64_t n_bits;
+    uint64_t n_lines;
+    uint32_t d1, d2; // digit widths
+    uint32_t G;      // blocks of the partition kernels
+    uint32_t tiles1; // tiles of pass 1
+    uint32_t tile;   // keys per tile
+    uint32_t op;     // 0: rank (keys = positions), 1: select (keys = argument ranks)
+    uint32_t kb;     // bits of the final key: line in slice + bit in line (rank), rank inside the bucket (select)
+    uint32_t B;      // select: ranks per bucket = m << bs with m in 8..15 (a power of two would waste up to half an LDS slice)
+    uint32_t bs;     // select: the shift of B
+    uint32_t binv;   // select: ceil(2^32 / m); floor(x / m) = (x * binv) >> 32 for x < 2^28
+    uint64_t total;  // select: arguments of the vector (ones or zeros)
+    bool small;      // 32-bit division path of line_of
+};
+
+struct SrBuf
+{ // carved out of the scratch allocation
+    uint32_t *keys1, *keys2;   // keys1 doubles as the low 32 bits of the absolute answers on the way back
+    uint16_t *slots1, *slots2;
+    uint16_t *thist1, *thist2; // [tile][bin]
+    uint32_t *counts1, *offs1, *bstart1;
+    uint32_t *counts2, *offs2, *bstart2;
+    uint32_t *btot, *tprefix2;
+    uint32_t *tot2, *status, *ticket; // one-sweep pass 2: digit-2 totals, per (tile, bin) look-back words, tile tickets
+    uint32_t *fine_count, *fstart, *ioff; // per slice: keys, first key, first work item
+    uint64_t * hf;                        // per slice: ones in front of it
+};
+
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+        unsigned u = __shfl_up(v, d, 64);
+        if ((int)(threadIdx.x & 63) >= d)
+            v += u;
+    }
+    return v;
+}
+
+// In-place exclusive scan of a[0 .. kBins) in LDS by the first kBins threads of the block (all threads must call);
+// returns the total.  Ends with a barrier.
+__device__ __forceinline__ unsigned block_excl_scan_bins(unsigned * a, unsigned * wsum)
+{
+    const unsigned t = threadIdx.x;
+    unsigned v = 0, inc = 0;
+    if (t < kBins)
+    {
+        v = a[t];
+        inc = wave_incl_scan(v);
+        if ((t & 63) == 63)
+            wsum[t >> 6] = inc;
+    }
+    __syncthreads();
+    if (t < kBins)
+    {
+        unsigned base = 0;
+        for (unsigned w = 0; w < (t >> 6); ++w)
+            base += wsum[w];
+        a[t] = base + inc - v;
+    }
+    unsigned total = 0;
+    for (unsigned w = 0; w < kBins / 64; ++w)
+        total += wsum[w];
+    __syncthreads();
+    return total;
+}
+
+// pass 1: digit and 32-bit key of a position
+__device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned & dig, uint32_t & key)
+{
+    if (g.op == 1)
+    { // select: the argument is the 1-based rank i of the wanted bit; buckets of 2^r consecutive ranks
+        if (pos == 0 || pos > g.total)
+        {
+            dig = 0;
+            key = kBad;
+            return;
+        }
+        const uint64_t k = pos - 1;
+        const uint32_t f = (uint32_t)(((k >> g.bs) * g.binv) >> 32); // k / B
+        dig = f >> g.d2;
+        key = ((f & ((1u << g.d2) - 1)) << g.kb) | (uint32_t)(k - (uint64_t)f * g.B);
+        return;
+    }
+    if (pos > g.n_bits)
+    {
+        dig = 0;
+        key = kBad;
+        return;
+    }
+    uint64_t L;
+    unsigned off;
+    line_of(pos, g.small, L, off);
+    const uint32_t l = (uint32_t)L; // < 2^26
+    dig = l >> (kSliceLog + g.d2);
+    key = (((l >> kSliceLog) & ((1u << g.d2) - 1)) << kKey2Bits) | ((l & ((1u << kSliceLog) - 1)) << kOffBits) | off;
+}
+// pass 2: digit and final key of a pass-1 key
+__device__ __forceinline__ void sr_key2(uint32_t k1, const SrGeom & g, unsigned & dig, uint32_t & key)
+{
+    if (k1 == kBad)
+    {
+        dig = 0;
+        key = kBad;
+        return;
+    }
+    dig = k1 >> g.kb;
+    key = k1 & ((1u << g.kb) - 1);
+}
+
+// The tables per slice (fstart, ioff, hf) are indexed in the order of the final array: f = (pass-2 digit << d1) | pass-1 digit.
+// The slice itself (rank: 2^10 lines; select: a bucket of argument ranks) is (pass-1 digit << d2) | pass-2 digit.
+__device__ __forceinline__ unsigned sr_slice_of(unsigned f, unsigned d1, unsigned d2)
+{
+    return ((f & ((1u << d1) - 1)) << d2) | (f >> d1);
+}
+
+} // namespace
+
+void bv_sorted_set_phases(const std::string & line); // what sdsl_hip_last_phases reports (bv_sorted.hip)
+
+// HIP events around the passes of one bucketed call (options "trace_phases" / SDSL_HIP_TRACE_SORTED)
+struct PhaseTimer
+{
+    static constexpr int kMax = 16;
+    bool on;
+    hipStream_t s;
+    hipEvent_t ev[kMax];
+    const char * nm[kMax];
+    int n = 0;
+    PhaseTimer(bool on_, hipStream_t s_) : on(on_), s(s_)
+    {
+        if (on)
+            for (auto & e : ev)
+                (void)hipEventCreate(&e);
+    }
+    // the first call opens the first phase; every later one closes the phase `name` (legacy table when null)
+    void mark(const char * name = nullptr)
+    {
+        static const char * legacy[] = {"", "hist1", "offs1", "part1", "hist2", "offs2", "part2", "slices", "rank", "unperm2", "unperm1",
+                                        "p11",  "p12",   "p13",   "p14",   "p15"};
+        if (on && n < kMax)
+        {
+            nm[n] = name ? name : legacy[n];
+            (void)hipEventRecord(ev[n++], s);
+        }
+    }
+    std::string line(int op, float * total = nullptr)
+    {
+        std::string out = op ? "select=1" : "select=0"; // which query the passes below belong to
+        if (!on || n == 0)
+            return out;
+        (void)hipEventSynchronize(ev[n - 1]);
+        float sum = 0;
+        for (int i = 0; i + 1 < n; ++i)
+        {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            sum += ms;
+            char buf[64];
+            snprintf(buf, sizeof(buf), ";%s=%.4f", nm[i + 1], ms);
+            out += buf;
+        }
+        if (total)
+            *total = sum;
+        return out;
+    }
+    void report(const SrGeom & g, const char * what)
+    {
+        if (!on)
+            return;
+        float total = 0;
+        const std::string l = line((int)g.op, &total);
+        fprintf(stderr, "[sdsl_hip] %s: n=%llu d1=%u d2=%u | %s | total %.3f ms = %.2f G/s\n", what, (unsigned long long)g.n, g.d1, g.d2,
+                l.c_str(), total, g.n / total / 1e6);
+    }
+    void keep(int op)
+    {
+        if (on)
+            bv_sorted_set_phases(line(op));
+    }
+    ~PhaseTimer()
+    {
+        if (on)
+            for (auto & e : ev)
+                (void)hipEventDestroy(e);
+    }
+};
+
+struct SelectPlan
+{ // select only
+    const uint32_t * bnd = nullptr; // nf + 1 line indices
+    unsigned bm = 8, bs = 3, nf = 0; // buckets of bm << bs ranks
+    uint64_t total = 0;
+};
+
+// digits and key widths of a pass over `cnt` positions (everything but the tiling)
+inline void sr_fill_geom(SrGeom & g, const BvView & v, int op, const SelectPlan & sp, uint64_t cnt)
+{
+    g.n = cnt;
+    g.n_bits = v.n_bits;
+    g.n_lines = v.n_lines;
+    g.op = (uint32_t)op;
+    unsigned f = 0; // bits of a slice / bucket index
+    if (op == 0)
+    {
+        unsigned lb = 0; // bits of a line index
+        while ((v.n_lines - 1) >> lb)
+            ++lb;
+        f = lb > kSliceLog ? lb - kSliceLog : 0;
+        g.kb = kKey2Bits;
+        g.B = 0;
+        g.bs = 0;
+        g.binv = 0;
+        g.total = 0;
+    }
+    else
+    {
+        while (sp.nf > (1u << f))
+            ++f;
+        g.kb = sp.bs + 4; // B <= 15 << bs
+        g.B = sp.bm << sp.bs;
+        g.bs = sp.bs;
+        g.binv = (uint32_t)(((UINT64_C(1) << 32) + sp.bm - 1) / sp.bm);
+        g.total = sp.total;
+    }
+    g.d2 = f < 8 ? f : 8; // pass 2: the LOW bits of the slice index; pass 1: the high ones, so that a pass-1 bin is a contiguous
+    g.d1 = f - g.d2;      // stretch of the vector and the answers of its keys fit 32 bits relative to the stretch's first one
+    g.small = v.n_bits < (UINT64_C(1) << 38);
+}
+
+sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const SelectPlan & sp, unsigned nf, unsigned d2, const uint32_t * fstart,
+                                  const uint32_t * ioff, uint32_t * keys2, uint64_t * hf, uint32_t * marked, hipStream_t s);
+void sr_launch_select_fixup(const BvView & v, int bit, const uint32_t * marked, const uint64_t * idx, uint64_t * out, uint64_t cnt,
+                            hipStream_t s);
+
+// the write-combined pipeline (bv_swc.hip): same contract as the passes of bv_sorted.hip
+size_t bv_swc_scratch_bytes(const BvView & v, uint64_t n);
+sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
+                       hipStream_t s, void * scratch, size_t scratch_bytes);
+
+// table kernels of bv_sorted.hip, launched on behalf of bv_swc.hip
+// offs[b][g] = keys of bins < b + keys of bin b in streams < g, from counts[b][g]; bstart = bin starts (bins + 1 entries)
+void sr_launch_bin_offsets(unsigned bins, unsigned G, const uint32_t * counts, uint32_t * btot, uint32_t * bstart, uint32_t * offs,
+                           hipStream_t s);
+// per slice: first key (fstart) and first work item (ioff) from the keys per slice
+void sr_launch_fine_scan(unsigned nf, const uint32_t * fine_count, uint32_t * fstart, uint32_t * ioff, hipStream_t s);
+
+} // namespace sdslhip

@@ -101,7 +101,7 @@ assert ph.get("hist2", 0) > 0.0005, ph
 assert all(np.array_equal(a, b) for a, b in zip(got, want))
 print("OK")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SDSL_HIP_SORTED_SWEEP="0")
+    env = dict(os.environ, SDSL_HIP_SORTED_SWEEP="0", SDSL_HIP_SORTED_SWC="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
