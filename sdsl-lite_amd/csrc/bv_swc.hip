@@ -58,6 +58,7 @@ struct SwBuf
     uint64_t * hf;
     uint32_t *in_lo, *tp2;     // pass-2 units: first key, first tile
     uint32_t *ck1, *ck2;       // [tile / kCkS][bin]: stream positions noted by the partition passes
+    uint64_t *tdesc2;          // per tile of pass 2: first key | keys << 32 | unit << 46 | first tile of its unit << 63
     uint32_t *tickets;         // 4 counters
     uint32_t *marked;
 };
@@ -92,6 +93,7 @@ size_t sw_carve(SwBuf & b, void * scratch, uint64_t n, unsigned tile, const SwGe
     b.tp2 = (uint32_t *)take(((size_t)kBins * kMaxK + 1) * 4);
     b.ck1 = (uint32_t *)take((tiles1 / kCkS + 2) * kBins * 4);
     b.ck2 = (uint32_t *)take((tiles2 / kCkS + 2) * kBins * 4);
+    b.tdesc2 = (uint64_t *)take((tiles2 + 64) * 8);
     b.tickets = (uint32_t *)take(256);
     b.marked = (uint32_t *)take(256);
     return (size_t)(p - (uint8_t *)scratch);
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(kHT) void k_sw_hist(SrGeom g, SwGeom w, const uint6
             const uint64_t cn = c + (uint64_t)kHT * PER;
             if (cn < khi)
                 fetch(cn, pn);
+            unsigned fidv[PER]; // slice of the key | what its counter held << 16
 #pragma unroll
             for (unsigned u = 0; u < PER; ++u)
             {
@@ -155,12 +158,16 @@ __global__ __launch_bounds__(kHT) void k_sw_hist(SrGeom g, SwGeom w, const uint6
                 const unsigned fid = key == kBad ? 0u : (dig << g.d2) | (key >> g.kb);
                 const unsigned sh = (fid & 1u) << 4;
                 const uint32_t old = atomicAdd(&fine[on ? fid >> 1 : w.fine_words], on ? 1u << sh : 0u);
-                if (on && ((old >> sh) & 0xFFFFu) == 0x7FFFu)
-                {
-                    atomicSub(&fine[fid >> 1], 0x8000u << sh);
+                fidv[u] = on ? fid | (((old >> sh) & 0xFFFFu) << 16) : 0u;
+            }
+#pragma unroll
+            for (unsigned u = 0; u < PER; ++u)
+                if ((fidv[u] >> 16) == 0x7FFFu)
+                { // this increment took the field to 2^15: move that much to the global row
+                    const unsigned fid = fidv[u] & 0xFFFFu;
+                    atomicSub(&fine[fid >> 1], 0x8000u << ((fid & 1u) << 4));
                     atomicAdd(row + fid, 0x8000u);
                 }
-            }
             if (cn < khi)
             {
 #pragma unroll
@@ -316,13 +323,14 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
                                                        const uint32_t * __restrict__ tp2, const uint32_t * __restrict__ fstart,
                                                        const uint32_t * __restrict__ segsum, uint32_t * __restrict__ ticket,
                                                        uint32_t * __restrict__ keys_out, uint16_t * __restrict__ slots,
-                                                       uint16_t * __restrict__ tile_hist, uint32_t * __restrict__ ckpt)
+                                                       uint16_t * __restrict__ tile_hist, uint32_t * __restrict__ ckpt,
+                                                       uint64_t * __restrict__ tdesc)
 {
     constexpr unsigned kTile = TT * PER;
     typedef typename std::conditional<P == 1, uint64_t, uint32_t>::type raw_t;
     __shared__ uint32_t sorted[kTile];
     __shared__ uint32_t carry[kBins * kCA];
-    __shared__ unsigned hist[kBins + 1], start[kBins], cursor[kBins], ccnt[kBins]; // hist[kBins]: what lies beyond a tile's end
+    __shared__ unsigned hist2[2][kBins + 1], start[kBins], cursor[kBins], ccnt[kBins], meta[kBins]; // hist2[.][kBins]: what lies beyond a tile's end
     __shared__ unsigned wsum[kBins / 64];
     __shared__ unsigned big[kTile / (kBigRun + 1) + 1], n_big, sh_unit;
     const unsigned t = threadIdx.x, l = t & 15;
@@ -343,6 +351,8 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
         un.tbase = __builtin_amdgcn_readfirstlane(un.tbase);
         for (unsigned i = t; i < kBins; i += TT)
             ccnt[i] = 0;
+        if (t == 0)
+            n_big = 0;
         __syncthreads();
         if (un.klo >= un.khi)
             continue;
@@ -362,8 +372,13 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
         raw_t raw[PER];
         fetch(un.klo, raw);
         unsigned ti = un.tbase;
-        for (uint64_t lo = un.klo; lo < un.khi; lo += kTile, ++ti)
+        unsigned hb = 0; // which of the two histograms this tile counts into (the other one is cleared while this tile is written out)
+        for (unsigned i = t; i <= kBins; i += TT)
+            hist2[0][i] = 0;
+        __syncthreads();
+        for (uint64_t lo = un.klo; lo < un.khi; lo += kTile, ++ti, hb ^= 1u)
         {
+            unsigned * hist = hist2[hb];
             const unsigned cnt_t = (unsigned)(un.khi - lo < kTile ? un.khi - lo : kTile);
             const bool has_next = lo + kTile < un.khi;
             // every kCkS-th tile: where its runs start in the streams (what lets the way back begin there)
@@ -371,11 +386,6 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
             unsigned ck = 0;
             if (note && t < bins)
                 ck = cursor[t] + ccnt[t];
-            for (unsigned i = t; i <= kBins; i += TT)
-                hist[i] = 0;
-            if (t == 0)
-                n_big = 0;
-            __syncthreads();
             uint32_t key[PER];
             unsigned br[PER]; // bin << 16 | rank inside the tile's share of the bin; later: the key's slot
 #pragma unroll
@@ -394,10 +404,27 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
             if (has_next)
                 fetch(lo + kTile, nxt);
             __syncthreads();
-            for (unsigned i = t; i < kBins; i += TT)
-                start[i] = hist[i];
-            __syncthreads();
-            block_excl_scan_bins(start, wsum);
+            { // exclusive scan of the counts -> start; the bins' write-out parameters packed into one word each
+                unsigned v = 0, inc = 0;
+                if (t < kBins)
+                {
+                    v = hist[t];
+                    inc = wave_incl_scan(v);
+                    if ((t & 63) == 63)
+                        wsum[t >> 6] = inc;
+                }
+                __syncthreads();
+                if (t < kBins)
+                {
+                    unsigned base = inc - v;
+                    for (unsigned wv = 0; wv < (t >> 6); ++wv)
+                        base += wsum[wv];
+                    start[t] = base;
+                    // first place in the sorted tile : 13 | keys : 14 | carried keys : 5 (a bin without keys may 'start' at kTile: 14 bits)
+                    meta[t] = (v ? base : 0u) | (v << 13) | (ccnt[t] << 27);
+                }
+                __syncthreads();
+            }
 #pragma unroll
             for (unsigned u = 0; u < PER; ++u)
             {
@@ -418,17 +445,31 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
                 tile_hist[(uint64_t)ti * bins + i] = (uint16_t)hist[i];
             if (note && t < bins)
                 ckpt[(uint64_t)(ti / kCkS) * kBins + t] = ck;
+            if (P == 2 && t == 0) // what the way back needs to know about this tile: first key | keys | unit | first tile of its unit
+                tdesc[ti] = (uint64_t)lo | ((uint64_t)cnt_t << 32) | ((uint64_t)unit << 46) | ((uint64_t)(ti == un.tbase) << 63);
             {
                 const rsrc_t rs = make_rsrc(slots + lo, cnt_t * 2u);
 #pragma unroll
                 for (unsigned u = 0; u < PER; ++u)
                     __builtin_amdgcn_raw_buffer_store_b16((unsigned short)br[u], rs, (int)(t * 2u), (int)(u * TT * 2u), kAuxNT);
             }
-            // chunks out: 16 lanes per bin
-            for (unsigned b = t >> 4; b < bins; b += TT / 16)
+            for (unsigned i = t; i <= kBins; i += TT)
+                hist2[hb ^ 1u][i] = 0;
+            // chunks out: 16 lanes per bin; a bin's parameters are read while the bin in front of it is worked on
+            constexpr unsigned kRounds = kBins / (TT / 16);
+            unsigned m_nx = meta[t >> 4], c_nx = cursor[t >> 4];
+#pragma nounroll
+            for (unsigned k = 0; k < kRounds; ++k)
             {
-                const unsigned cnt = hist[b];
-                if (cnt == 0)
+                const unsigned b = (t >> 4) + k * (TT / 16);
+                const unsigned m = m_nx, cur = c_nx;
+                if (k + 1 < kRounds)
+                {
+                    m_nx = meta[b + TT / 16];
+                    c_nx = cursor[b + TT / 16];
+                }
+                const unsigned st = m & 0x1FFFu, cnt = (m >> 13) & 0x3FFFu, cc = m >> 27;
+                if (cnt == 0 || b >= bins)
                     continue;
                 if (cnt > kBigRun)
                 {
@@ -436,7 +477,6 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
                         big[atomicAdd(&n_big, 1u)] = b;
                     continue;
                 }
-                const unsigned cc = ccnt[b], st = start[b], cur = cursor[b];
                 const unsigned end = cur + cc + cnt, aend = end & ~(kCA - 1);
                 if (aend > cur)
                 {
@@ -464,6 +504,12 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
             }
             __syncthreads();
             const unsigned nb = n_big;
+            if (nb)
+            {
+                __syncthreads();
+                if (t == 0)
+                    n_big = 0;
+            }
             for (unsigned k = 0; k < nb; ++k)
             { // a long run (a skewed tile): the whole block writes it
                 const unsigned b = big[k], cnt = hist[b], cc = ccnt[b], st = start[b], cur = cursor[b];
@@ -772,6 +818,189 @@ __global__ __launch_bounds__(TT, WPE) void k_sw_unpermute(const uint64_t * __res
     }
 }
 
+// ---- the way back, runs fetched by LDS DMA ------------------------------------------------------------------------------------
+// The gather above holds a tile's run elements in registers between request and use (24-32 VGPRs per lane, two rounds per tile
+// at 512 threads).  Here the fetch goes global -> LDS directly (buffer_load ... lds): position p of the bin-major tile image
+// is fetched by lane p of its wave from  delta[bin(p)] + p  (delta = where the bin's run starts in the stream - where it starts
+// in the image), sixteen requests per lane in flight and no register waiting for any of them; bin(p) comes from a byte map the
+// bins' lane groups fill after the scan.  What makes an answer absolute is added when it is picked: one more table read per
+// key instead of a pass over the image.  47 KB of LDS and < 80 VGPRs: three blocks per CU.
+template <int P, unsigned TT, unsigned PER>
+__global__ __launch_bounds__(TT, 6) void k_sw_unpermute_dma(const uint64_t * __restrict__ hf, int bit, SrGeom g, SwGeom w,
+                                                           const uint32_t * __restrict__ offs1, const uint32_t * __restrict__ in_lo,
+                                                           const uint32_t * __restrict__ tp2, const uint32_t * __restrict__ fstart,
+                                                           const uint32_t * __restrict__ segsum, const uint32_t * __restrict__ ckpt,
+                                                           uint32_t * __restrict__ ticket, const uint64_t * __restrict__ tdesc,
+                                                           const uint32_t * __restrict__ res_lo,
+                                                           uint32_t * __restrict__ any_marked, const uint16_t * __restrict__ slots,
+                                                           const uint16_t * __restrict__ tile_hist, uint32_t * __restrict__ out_lo,
+                                                           uint64_t * __restrict__ out)
+{
+    constexpr unsigned kTile = TT * PER;
+    __shared__ uint32_t lo32[kTile];
+    __shared__ uint8_t binof[kTile];
+    __shared__ unsigned hist[kBins], start[kBins], cursor[kBins], delta[kBins];
+    __shared__ uint64_t sbase[kBins]; // what makes the answers of bin b absolute (P == 1) / relative to the pass-1 bin (P == 2)
+    __shared__ unsigned wsum[kBins / 64];
+    __shared__ unsigned sh_item, sh_unit;
+    const unsigned t = threadIdx.x, l = t & 15;
+    const unsigned wbase = __builtin_amdgcn_readfirstlane(t & ~63u);
+    const unsigned bins = 1u << (P == 1 ? g.d1 : g.d2);
+    const unsigned n_units = P == 1 ? w.U1 : (1u << g.d1) * w.K;
+    const unsigned T = P == 1 ? w.U1 * w.tpu : __builtin_amdgcn_readfirstlane(tp2[n_units]);
+    const rsrc_t rs_res = make_rsrc(res_lo, (uint32_t)g.n * 4u);
+    auto abs_base = [&](unsigned b1, unsigned b2) -> uint64_t
+    {
+        const unsigned f = (b1 << g.d2) | b2;
+        const uint64_t h = hf[f];
+        if (g.op == 1)
+            return h;
+        return bit ? h : ((uint64_t)f << kSliceLog) * kDB - h;
+    };
+    if (P == 1)
+        for (unsigned i = t; i < kBins; i += TT)
+            sbase[i] = i < bins ? abs_base(i, 0) : 0;
+    unsigned next_item = 0; // thread 0: the ticket after this one, taken while this item is worked on
+    if (t == 0)
+        next_item = atomicAdd(ticket, 1u);
+    for (;;)
+    {
+        if (t == 0)
+            sh_item = next_item;
+        __syncthreads();
+        const unsigned item = __builtin_amdgcn_readfirstlane(sh_item);
+        const unsigned t_lo = item * kCkS;
+        if (t_lo >= T)
+            break;
+        if (t == 0)
+            next_item = atomicAdd(ticket, 1u);
+        const unsigned t_hi = t_lo + kCkS < T ? t_lo + kCkS : T;
+        // pass 2: what the partition noted about the item's tiles (one load; lane j holds tile t_lo + j)
+        uint64_t dsc = 0;
+        if (P == 2 && (t & 63) < kCkS && t_lo + (t & 63) < t_hi)
+            dsc = tdesc[t_lo + (t & 63)];
+        auto tile_of = [&](unsigned ti) -> SwTile<P>
+        {
+            if (P == 1)
+                return sw_tile<P>(g, w, ti, 0u, in_lo, tp2);
+            const unsigned j = ti - t_lo;
+            const uint32_t lo = __builtin_amdgcn_readlane((unsigned)dsc, j), hi = __builtin_amdgcn_readlane((unsigned)(dsc >> 32), j);
+            SwTile<P> r;
+            r.lo = lo;
+            r.cnt = hi & 0x3FFFu;
+            r.unit = (hi >> 14) & 0x1FFFFu;
+            r.tb = (hi >> 31) ? ti : 0xFFFFFFFFu;
+            return r;
+        };
+        SwTile<P> d = tile_of(t_lo);
+        unsigned have_unit = 0xFFFFFFFFu; // the unit sbase was loaded for
+        unsigned nh = t < bins ? tile_hist[(uint64_t)t_lo * bins + t] : 0u;
+        for (unsigned ti = t_lo; ti < t_hi; ++ti)
+        {
+            const bool more = ti + 1 < t_hi;
+            SwTile<P> dn = d;
+            if (more)
+                dn = tile_of(ti + 1);
+            if (d.cnt == 0)
+            { // (pass 1: tiles past the batch's end)
+                d = dn;
+                continue;
+            }
+            const unsigned grp = P == 2 ? d.unit / w.K : 0u;
+            if (ti == d.tb)
+            {
+                (void)sw_unit_setup<P, TT>(g, w, d.unit, offs1, in_lo, tp2, fstart, segsum, cursor);
+            }
+            else if (ti == t_lo)
+            {
+                for (unsigned i = t; i < kBins; i += TT)
+                    cursor[i] = i < bins ? ckpt[(uint64_t)(ti / kCkS) * kBins + i] : 0u;
+            }
+            if (P == 2 && have_unit != d.unit)
+            {
+                const uint64_t gbase = abs_base(grp, 0);
+                for (unsigned i = t; i < kBins; i += TT)
+                    sbase[i] = i < bins ? abs_base(grp, i) - gbase : 0;
+                have_unit = d.unit;
+            }
+            for (unsigned i = t; i < kBins; i += TT)
+            {
+                hist[i] = nh;
+                start[i] = nh;
+            }
+            __syncthreads();
+            if (more)
+                nh = t < bins ? tile_hist[(uint64_t)(ti + 1) * bins + t] : 0u;
+            uint16_t sl[PER];
+            {
+                const rsrc_t rs = make_rsrc(slots + d.lo, d.cnt * 2u);
+#pragma unroll
+                for (unsigned u = 0; u < PER; ++u)
+                    sl[u] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)(t * 2u), (int)(u * TT * 2u), kAuxNT);
+            }
+            block_excl_scan_bins(start, wsum);
+            for (unsigned i = t; i < kBins; i += TT)
+                delta[i] = cursor[i] - start[i];
+            // the byte map: 16 lanes per bin
+            for (unsigned b = t >> 4; b < bins; b += TT / 16)
+            {
+                const unsigned cnt = hist[b], st = start[b];
+                for (unsigned i = l; i < cnt; i += 16)
+                    binof[st + i] = (uint8_t)b;
+            }
+            __syncthreads();
+#pragma unroll
+            for (unsigned u = 0; u < PER; ++u)
+            {
+                const unsigned p = u * TT + t;
+                const unsigned src = delta[binof[p < d.cnt ? p : 0u]] + p;
+                // (beyond the tile's end: an offset past the buffer's end, nothing is fetched)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_res, &lo32[u * TT + wbase], 4, (int)(p < d.cnt ? src * 4u : 0xFFFFFFFCu), 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): this wave's fetches have landed
+            __syncthreads();
+            bool mk = false;
+            {
+                typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+                const rsrc_t rs = P == 2 ? make_rsrc(out_lo + d.lo, d.cnt * 4u) : make_rsrc(out + d.lo, d.cnt * 8u);
+#pragma unroll
+                for (unsigned u = 0; u < PER; ++u)
+                {
+                    const unsigned at = sl[u] & (kTile - 1); // (what lies beyond the tile's end is not written: any slot will do)
+                    const uint32_t v = lo32[at];
+                    const uint64_t full = sbase[binof[at]] + v;
+                    if (P == 2)
+                    { // an answer that does not fit 32 bits relative to its pass-1 bin is left to the fix-up pass
+                        uint32_t r = (uint32_t)full;
+                        if (v >= kMark)
+                            r = v;
+                        else if (full >= kMark)
+                        {
+                            r = kMark;
+                            mk = true;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b32(r, rs, (int)(t * 4u), (int)(u * TT * 4u), kAuxNT);
+                    }
+                    else
+                    {
+                        const uint64_t a = v == kBad ? SDSL_HIP_NPOS : (v == kMark ? kMark64 : full);
+                        v2u32 pr;
+                        pr.x = (unsigned)a;
+                        pr.y = (unsigned)(a >> 32);
+                        __builtin_amdgcn_raw_buffer_store_b64(pr, rs, (int)(t * 8u), (int)(u * TT * 8u), kAuxNT);
+                    }
+                }
+            }
+            if (P == 2 && mk)
+                *any_marked = 1;
+            for (unsigned i = t; i < kBins; i += TT)
+                cursor[i] += hist[i];
+            __syncthreads();
+            d = dn;
+        }
+    }
+}
+
 constexpr uint64_t kSwMaxPass = (UINT64_C(1) << 30) - (UINT64_C(1) << 20); // positions per pass over the batch (32-bit cursors)
 constexpr unsigned kSwT = 512, kSwPer = 16, kSwTile = kSwT * kSwPer;
 
@@ -865,11 +1094,11 @@ sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         hipLaunchKernelGGL((p1wide ? k_sw_partition<1, 1024, 8> : k_sw_partition<1, kSwT, kSwPer>), dim3(p1wide && pb_env < 1 ? 256u : pblocks),
                            dim3(p1wide ? 1024u : kSwT), 0, s, g, w, idx, (const uint32_t *)nullptr, b.offs1,
                            (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
-                           b.tickets + 0, b.keys1, b.slots1, b.thist1, b.ck1);
+                           b.tickets + 0, b.keys1, b.slots1, b.thist1, b.ck1, (uint64_t *)nullptr);
         pt.mark("part1");
         hipLaunchKernelGGL(k_sw_units2, dim3(1), dim3(1024), 0, s, g, w, b.offs1, b.in_lo, b.tp2);
         hipLaunchKernelGGL((k_sw_partition<2, kSwT, kSwPer>), dim3(pblocks), dim3(kSwT), 0, s, g, w, (const uint64_t *)nullptr, b.keys1, b.offs1,
-                           b.in_lo, b.tp2, b.fstart, b.segsum, b.tickets + 1, b.keys2, b.slots2, b.thist2, b.ck2);
+                           b.in_lo, b.tp2, b.fstart, b.segsum, b.tickets + 1, b.keys2, b.slots2, b.thist2, b.ck2, b.tdesc2);
         pt.mark("part2");
         SH_TRY(sr_launch_answers(v, op, bit, sp, w.nf, g.d2, b.fstart, b.ioff, b.keys2, b.hf, b.marked, s));
         pt.mark("answer");
@@ -886,14 +1115,24 @@ sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp,
                                        k_sw_unpermute<2, 1024, 8, 4, 6, 4>};
         static const unp_fn tab1[4] = {k_sw_unpermute<1, 512, 16, 6, 4, 4>, k_sw_unpermute<1, 512, 16, 5, 6, 4>, k_sw_unpermute<1, 1024, 8, 4, 4, 4>,
                                        k_sw_unpermute<1, 1024, 8, 4, 6, 4>};
-        const unp_fn u2 = tab2[sh2 & 3], u1 = tab1[sh1 & 3];
+        const bool dma = unp_env < 0 || unp_env >= 4;
         const unsigned kUT2 = (sh2 & 2) ? 1024u : 512u, kUT1 = (sh1 & 2) ? 1024u : 512u;
-        const unsigned ub2 = ub_env >= 1 ? (unsigned)ub_env : ((sh2 & 2) ? 256u : 512u), ub1b = ub_env >= 1 ? (unsigned)ub_env : ((sh1 & 2) ? 256u : 512u);
-        hipLaunchKernelGGL(u2, dim3(ub2), dim3(kUT2), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart, b.segsum, b.ck2,
-                           b.tickets + 2, b.keys2, b.marked, b.slots2, b.thist2, b.keys1, (uint64_t *)nullptr);
+        const unsigned ub2 = ub_env >= 1 ? (unsigned)ub_env : (dma ? 768u : ((sh2 & 2) ? 256u : 512u)),
+                       ub1b = ub_env >= 1 ? (unsigned)ub_env : (dma ? 768u : ((sh1 & 2) ? 256u : 512u));
+        if (dma)
+            hipLaunchKernelGGL((k_sw_unpermute_dma<2, 512, 16>), dim3(ub2), dim3(512), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart,
+                               b.segsum, b.ck2, b.tickets + 2, b.tdesc2, b.keys2, b.marked, b.slots2, b.thist2, b.keys1, (uint64_t *)nullptr);
+        else
+            hipLaunchKernelGGL(tab2[sh2 & 3], dim3(ub2), dim3(kUT2), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart, b.segsum, b.ck2,
+                               b.tickets + 2, b.keys2, b.marked, b.slots2, b.thist2, b.keys1, (uint64_t *)nullptr);
         pt.mark("unperm2");
-        hipLaunchKernelGGL(u1, dim3(ub1b), dim3(kUT1), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart, b.segsum, b.ck1,
-                           b.tickets + 3, b.keys1, b.marked, b.slots1, b.thist1, (uint32_t *)nullptr, d_out + done);
+        if (dma)
+            hipLaunchKernelGGL((k_sw_unpermute_dma<1, 512, 16>), dim3(ub1b), dim3(512), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart,
+                               b.segsum, b.ck1, b.tickets + 3, (const uint64_t *)nullptr, b.keys1, b.marked, b.slots1, b.thist1, (uint32_t *)nullptr,
+                               d_out + done);
+        else
+            hipLaunchKernelGGL(tab1[sh1 & 3], dim3(ub1b), dim3(kUT1), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart, b.segsum, b.ck1,
+                               b.tickets + 3, b.keys1, b.marked, b.slots1, b.thist1, (uint32_t *)nullptr, d_out + done);
         pt.mark("unperm1");
         if (op == 1)
             sr_launch_select_fixup(v, bit, b.marked, idx, d_out + done, cnt, s);
