@@ -415,6 +415,8 @@ template <int U, bool NT, bool IO_NT = false>
 __global__ __launch_bounds__(kBlock) void k_rank(BvView bv, int bit, const uint64_t * __restrict__ idx,
                                                  uint64_t * __restrict__ out, uint64_t n)
 {
+    if (bv.skip_if && *bv.skip_if)
+        return;
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
     const uint64_t stride = (uint64_t)gridDim.x * kQPB * U;
@@ -505,6 +507,8 @@ __global__ __launch_bounds__(kBlock) void k_select_rq(BvView bv, const uint64_t 
 {
     __shared__ RetryEntry rq[2 * kQPB];
     __shared__ unsigned rq_n;
+    if (bv.skip_if && *bv.skip_if)
+        return;
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
     const uint64_t total = BIT ? bv.ones : bv.n_bits - bv.ones;
@@ -626,6 +630,8 @@ __global__ __launch_bounds__(kBlock) void k_select_wq(BvView bv, const uint64_t 
     constexpr unsigned kWaves = kBlock / 64;
     __shared__ RetryEntry rq_all[kWaves][2 * kQPW];
     __shared__ unsigned rq_cnt[kWaves];
+    if (bv.skip_if && *bv.skip_if)
+        return;
     const int s = threadIdx.x & (kG - 1);
     const unsigned wave = threadIdx.x / 64, wq = (threadIdx.x & 63) / kG; // quad index inside the wave
     const unsigned gq = threadIdx.x / kG;
@@ -813,8 +819,42 @@ sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i
     return SDSL_HIP_OK;
 }
 
-// direct kernel or, for a large batch over a large vector, the bucketed path (bv_sorted.hip).  Option "rank_sorted"
+// direct kernel or, for a large batch over a large vector, the bucketed path (bv_sorted.hip / bv_swc.hip).  Option "rank_sorted"
 // (sdsl_hip_set_option; initial value from SDSL_HIP_RANK_SORTED): 0 = never, 1 = whenever possible, -1 = automatic.
+//
+// Automatic: a batch that is SPREAD over the vector goes through the passes, one confined to a window (or sorted) is better
+// served by the direct kernel out of L2 / Infinity Cache.  Which it is, a sample of the batch says (k_sr_sample_spread) — on
+// the device: the verdict is a word in device memory, BOTH routes are enqueued behind the sample, and the one whose turn it is
+// not returns at once (SrGeom::go / BvView::skip_if).  Nothing is read back, nothing synchronises: the call stays asynchronous
+// on the caller's stream and can be captured into a graph (once the handle's scratch has its size: the first call allocates).
+
+// the handle's scratch at the size a pass over `n` queries needs; false: no room (the caller takes the direct kernel)
+static bool bv_ensure_sort_scratch(BvHost & h, uint64_t n, hipStream_t s, sdsl_hip_status & st)
+{
+    st = SDSL_HIP_OK;
+    const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
+    const size_t need = bv_sorted_rank_scratch_bytes(h.view, pass);
+    if (h.scratch_ev && hipStreamWaitEvent(s, h.scratch_ev, 0) != hipSuccess)
+    {
+        st = SDSL_HIP_ERR_HIP;
+        return false;
+    }
+    if (h.sort_scratch.bytes < need)
+    {
+        if (h.scratch_ev)
+            (void)hipEventSynchronize(h.scratch_ev); // the old buffer may still be in use
+        h.sort_scratch.release();
+        if (h.sort_scratch.alloc(need) != SDSL_HIP_OK)
+            return false;
+    }
+    if (!h.scratch_ev && hipEventCreateWithFlags(&h.scratch_ev, hipEventDisableTiming) != hipSuccess)
+    {
+        st = SDSL_HIP_ERR_HIP;
+        return false;
+    }
+    return true;
+}
+
 sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out, hipStream_t s)
 {
     const int mode = g_rank_sorted_mode.load();
@@ -824,8 +864,9 @@ sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, ui
         // the scratch belongs to the handle; queries stay safe to issue from several threads / on several streams: the
         // host side is serialised here, the device side by an event the next user of the scratch waits for
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
-        if (mode < 0)
-        { // automatic: only a batch that is spread over the vector goes through the passes (a read-back: synchronises s)
+        const bool on_device = mode < 0 && bv_sorted_device_verdict();
+        if (mode < 0 && !on_device)
+        { // (the one-sweep passes, SDSL_HIP_SORTED_SWC=0: the verdict is read back, which synchronises s)
             bool spread = true;
             if (!h.spread_probe.p)
                 SH_TRY(h.spread_probe.alloc(64));
@@ -833,24 +874,27 @@ sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, ui
             if (!spread)
                 return bv_launch_rank(h.view, bit, d_idx, n, d_out, s);
         }
-        const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
-        const size_t need = bv_sorted_rank_scratch_bytes(h.view, pass);
-        if (h.scratch_ev)
-            SH_HIP(hipStreamWaitEvent(s, h.scratch_ev, 0));
-        if (h.sort_scratch.bytes < need)
-        {
-            if (h.scratch_ev)
-                SH_HIP(hipEventSynchronize(h.scratch_ev)); // the old buffer may still be in use
-            h.sort_scratch.release();
-            if (h.sort_scratch.alloc(need) != SDSL_HIP_OK)
-                return bv_launch_rank(h.view, bit, d_idx, n, d_out, s); // no room for the scratch: direct kernel
-        }
-        if (!h.scratch_ev)
-            SH_HIP(hipEventCreateWithFlags(&h.scratch_ev, hipEventDisableTiming));
         sdsl_hip_status st;
+        if (!bv_ensure_sort_scratch(h, n, s, st))
+            return st != SDSL_HIP_OK ? st : bv_launch_rank(h.view, bit, d_idx, n, d_out, s); // no room for the scratch: direct kernel
+        const uint32_t * go = nullptr;
+        if (on_device && !h.spread_probe.p)
+            SH_TRY(h.spread_probe.alloc(64));
         {
             KernelTimer t(s);
-            st = bv_launch_rank_sorted(h.view, bit, d_idx, n, d_out, s, h.sort_scratch.p, h.sort_scratch.bytes);
+            if (on_device)
+            {
+                SH_TRY(bv_sorted_rank_sample(h.view, d_idx, n, s, h.spread_probe.as<uint32_t>()));
+                go = h.spread_probe.as<uint32_t>() + 2;
+            }
+            st = bv_launch_rank_sorted(h.view, bit, d_idx, n, d_out, s, h.sort_scratch.p, h.sort_scratch.bytes, go);
+            if (st == SDSL_HIP_OK && go)
+            {
+                TimingPause pause; // (one timer around both routes)
+                BvView dv = h.view;
+                dv.skip_if = go;
+                st = bv_launch_rank(dv, bit, d_idx, n, d_out, s);
+            }
         }
         SH_HIP(hipEventRecord(h.scratch_ev, s));
         return st;
@@ -867,39 +911,40 @@ sdsl_hip_status bv_select_dispatch(BvHost & h, int bit, const uint64_t * d_i, ui
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
         SH_TRY(bv_select_sorted_prepare(h, bit)); // first use: the bucket boundaries (one small batch, synchronous)
         bool want = mode > 0 ? h.sel_plan[bit].ok : bv_sorted_select_applicable(h, bit, n);
-        if (want && mode < 0)
-        { // automatic: only a batch whose arguments are spread over the vector (a read-back: synchronises s)
+        const bool on_device = mode < 0 && bv_sorted_device_verdict();
+        if (want && mode < 0 && !on_device)
+        { // (the one-sweep passes: read-back, synchronises s)
             if (!h.spread_probe.p)
                 SH_TRY(h.spread_probe.alloc(64));
             SH_TRY(bv_sorted_select_is_spread(h, bit, d_i, n, s, h.spread_probe.p, want));
         }
-        if (want)
+        sdsl_hip_status st = SDSL_HIP_OK;
+        if (want && bv_ensure_sort_scratch(h, n, s, st))
         {
-            const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
-            const size_t need = bv_sorted_rank_scratch_bytes(h.view, pass);
-            if (h.scratch_ev)
-                SH_HIP(hipStreamWaitEvent(s, h.scratch_ev, 0));
-            bool have = h.sort_scratch.bytes >= need;
-            if (!have)
+            const uint32_t * go = nullptr;
+            if (on_device && !h.spread_probe.p)
+                SH_TRY(h.spread_probe.alloc(64));
             {
-                if (h.scratch_ev)
-                    SH_HIP(hipEventSynchronize(h.scratch_ev));
-                h.sort_scratch.release();
-                have = h.sort_scratch.alloc(need) == SDSL_HIP_OK;
-            }
-            if (have)
-            {
-                if (!h.scratch_ev)
-                    SH_HIP(hipEventCreateWithFlags(&h.scratch_ev, hipEventDisableTiming));
-                sdsl_hip_status st;
+                KernelTimer t(s);
+                if (on_device)
                 {
-                    KernelTimer t(s);
-                    st = bv_launch_select_sorted(h, bit, d_i, n, d_out, s, h.sort_scratch.p, h.sort_scratch.bytes);
+                    SH_TRY(bv_sorted_select_sample(h, bit, d_i, n, s, h.spread_probe.as<uint32_t>()));
+                    go = h.spread_probe.as<uint32_t>() + 2;
                 }
-                SH_HIP(hipEventRecord(h.scratch_ev, s));
-                return st;
+                st = bv_launch_select_sorted(h, bit, d_i, n, d_out, s, h.sort_scratch.p, h.sort_scratch.bytes, go);
+                if (st == SDSL_HIP_OK && go)
+                {
+                    TimingPause pause;
+                    BvView dv = h.view;
+                    dv.skip_if = go;
+                    st = bv_launch_select(dv, bit, d_i, n, d_out, s);
+                }
             }
+            SH_HIP(hipEventRecord(h.scratch_ev, s));
+            return st;
         }
+        if (st != SDSL_HIP_OK)
+            return st;
     }
     return bv_launch_select(h.view, bit, d_i, n, d_out, s);
 }

@@ -39,6 +39,9 @@ struct BvView
     const uint32_t * lmask[2];
     const uint32_t * lidx[2];
     const uint32_t * lpos[2];
+    // automatic dispatch of large batches (bv.hip): the direct batch kernels return at once when this word is non-zero — the
+    // batch is then answered by the bucketed path, which was enqueued beside them.  nullptr everywhere else.
+    const uint32_t * skip_if;
 };
 constexpr uint64_t kSelLongGap = 512;
 

@@ -56,14 +56,18 @@ bool bv_sorted_rank_applicable(const BvView & v, uint64_t n);
 sdsl_hip_status bv_sorted_rank_is_spread(const BvView & v, const uint64_t * d_idx, uint64_t n, hipStream_t s, void * scratch,
                                          bool & spread);
 size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n);
+// `go`: nullptr = run; else a device word the passes look at and return at once when it is zero (automatic dispatch)
 sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
-                                      hipStream_t s, void * scratch, size_t scratch_bytes);
+                                      hipStream_t s, void * scratch, size_t scratch_bytes, const uint32_t * go = nullptr);
+bool bv_sorted_device_verdict();
+sdsl_hip_status bv_sorted_rank_sample(const BvView & v, const uint64_t * d_idx, uint64_t n, hipStream_t s, uint32_t * out3);
+sdsl_hip_status bv_sorted_select_sample(const BvHost & h, int bit, const uint64_t * d_idx, uint64_t n, hipStream_t s, uint32_t * out3);
 sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit);
 bool bv_sorted_select_applicable(const BvHost & h, int bit, uint64_t n);
 sdsl_hip_status bv_sorted_select_is_spread(const BvHost & h, int bit, const uint64_t * d_idx, uint64_t n, hipStream_t s,
                                            void * scratch, bool & spread);
 sdsl_hip_status bv_launch_select_sorted(BvHost & h, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out, hipStream_t s,
-                                        void * scratch, size_t scratch_bytes);
+                                        void * scratch, size_t scratch_bytes, const uint32_t * go = nullptr);
 sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out,
                                  hipStream_t s);
 

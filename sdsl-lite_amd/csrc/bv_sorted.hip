@@ -749,8 +749,10 @@ __global__ __launch_bounds__(1024) void k_sr_fine_scan_starts(unsigned nf, unsig
 // the header's 16 bytes and the one 16-byte pair that holds its word: two LDS reads and two popcounts instead of the
 // whole line (the first form of this kernel spent 1.4 wave instructions per key, 65 % of its time in the VALU).
 __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigned nf, unsigned d1, unsigned d2, const uint32_t * __restrict__ fstart,
-                                                     const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys)
+                                                     const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys, const uint32_t * __restrict__ go)
 {
+    if (go && !*go)
+        return;
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
     __shared__ v2u64 slice[(kLW << kSliceLog) / 2]; // 64 KiB
     // the rewritten headers live in an array of their own: inside the lines they all sit at multiples of 64 bytes, i.e. in
@@ -786,15 +788,13 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
         const uint64_t lo = (uint64_t)fstart[f] + (uint64_t)(item - ioff[f]) * kItemKeys;
         const uint64_t fend = fstart[f + 1];
         const unsigned cnt = (unsigned)(lo + kItemKeys < fend ? kItemKeys : fend - lo);
-        uint32_t * kp = keys + lo;
+        // the keys through a buffer of exactly this item's extent: what lies beyond reads as 0 and is not written back
+        const rsrc_t rs_k = make_rsrc(keys + uniform64(lo), __builtin_amdgcn_readfirstlane(cnt) * 4u);
         // the first keys are asked for while the headers are being rewritten
         uint32_t key[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-        {
-            const unsigned i = t + (unsigned)u * kRT;
-            key[u] = i < cnt ? __builtin_nontemporal_load(kp + i) : kBad;
-        }
+            buf_load(rs_k, t * 4u, (unsigned)u * kRT * 4u, key[u]);
         __syncthreads();
         const uint64_t H = slice[0].x;
         __syncthreads();
@@ -806,21 +806,19 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
             hdr[ln] = (a.x - H) | ((uint64_t)ca << 20) | ((uint64_t)cb << 29) | ((uint64_t)cc << 38);
         }
         __syncthreads();
-        for (unsigned i0 = t; i0 < cnt; i0 += kRT * U)
-        {
-            if (i0 != t)
+        for (unsigned i0 = 0; i0 < cnt; i0 += kRT * U)
+        { // the next round's keys are requested before this round's answers are stored (loads and stores share a counter)
+            uint32_t nk[U];
+            const unsigned n0 = (i0 + kRT * U) * 4u;
+            if (i0 + kRT * U < cnt)
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                {
-                    const unsigned i = i0 + (unsigned)u * kRT;
-                    key[u] = i < cnt ? __builtin_nontemporal_load(kp + i) : kBad;
-                }
+                    buf_load(rs_k, t * 4u, n0 + (unsigned)u * kRT * 4u, nk[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
             {
-                const unsigned i = i0 + (unsigned)u * kRT;
                 const unsigned ln = key[u] == kBad ? 0 : key[u] >> kOffBits;
                 const unsigned off = key[u] & ((1u << kOffBits) - 1);
                 const v2u64 * w = slice + ln * (kLW / 2);
@@ -835,8 +833,13 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
                 uint32_t r = bit ? r1 : ln * (uint32_t)kDB + off - r1;
                 if (key[u] == kBad)
                     r = kBad;
-                if (i < cnt)
-                    __builtin_nontemporal_store(r, kp + i);
+                __builtin_amdgcn_raw_buffer_store_b32(r, rs_k, (int)(t * 4u), (int)(i0 * 4u + (unsigned)u * kRT * 4u), kAuxNT);
+            }
+            if (i0 + kRT * U < cnt)
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    key[u] = nk[u];
             }
         }
     }
@@ -852,8 +855,10 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
 template <int BIT>
 __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, unsigned d1, unsigned d2, unsigned B, const uint32_t * __restrict__ bnd,
                                                        const uint32_t * __restrict__ fstart, const uint32_t * __restrict__ ioff,
-                                                       uint32_t * __restrict__ keys, uint32_t * __restrict__ any_marked)
+                                                       uint32_t * __restrict__ keys, uint32_t * __restrict__ any_marked, const uint32_t * __restrict__ go)
 {
+    if (go && !*go)
+        return;
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
     __shared__ v2u64 slice[(kLW << kSliceLog) / 2]; // 64 KiB
     __shared__ uint64_t hdr[1u << kSliceLog];       // the rewritten headers, packed (see k_sr_rank_lds)
@@ -895,19 +900,19 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
                     kp[i] = kMark;
             if (t == 0)
                 *any_marked = 1;
+            __syncthreads(); // (thread 0 rewrites sh_f at the top of the next item: nobody may still be reading it)
             continue;
         }
         const unsigned nl = (unsigned)(L1 - L0);
         const v2u64 * src = reinterpret_cast<const v2u64 *>(bv.lines + L0 * kLW);
         for (unsigned i = t; i < nl * (kLW / 2); i += kRT)
             slice[i] = __builtin_nontemporal_load(src + i);
+        // the keys through a buffer of exactly this item's extent: what lies beyond reads as 0 and is not written back
+        const rsrc_t rs_k = make_rsrc(keys + uniform64(lo), __builtin_amdgcn_readfirstlane(cnt) * 4u);
         uint32_t key[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-        {
-            const unsigned i = t + (unsigned)u * kRT;
-            key[u] = i < cnt ? __builtin_nontemporal_load(kp + i) : kBad;
-        }
+            buf_load(rs_k, t * 4u, (unsigned)u * kRT * 4u, key[u]);
         __syncthreads();
         const uint64_t h0 = slice[0].x;
         const uint64_t A0 = BIT ? h0 : L0 * kDB - h0; // arguments in front of the slice
@@ -964,21 +969,19 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
         if (t == 0)
             inv[n_inv] = (uint16_t)(nl - 1);
         __syncthreads();
-        for (unsigned i0 = t; i0 < cnt; i0 += kRT * U)
-        {
-            if (i0 != t)
+        for (unsigned i0 = 0; i0 < cnt; i0 += kRT * U)
+        { // the next round's keys are requested before this round's answers are stored (loads and stores share a counter)
+            uint32_t nk[U];
+            const unsigned n0 = (i0 + kRT * U) * 4u;
+            if (i0 + kRT * U < cnt)
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                {
-                    const unsigned i = i0 + (unsigned)u * kRT;
-                    key[u] = i < cnt ? __builtin_nontemporal_load(kp + i) : kBad;
-                }
+                    buf_load(rs_k, t * 4u, n0 + (unsigned)u * kRT * 4u, nk[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
             {
-                const unsigned i = i0 + (unsigned)u * kRT;
                 uint32_t res = kBad;
                 if (key[u] != kBad)
                 {
@@ -1019,8 +1022,13 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
                     const unsigned bitpos = sel64(second ? pr.y : pr.x, tl - (second ? px : 0u) + 1);
                     res = a * (uint32_t)kDB + 64u * word + bitpos; // relative to the slice's first bit
                 }
-                if (i < cnt)
-                    __builtin_nontemporal_store(res, kp + i);
+                __builtin_amdgcn_raw_buffer_store_b32(res, rs_k, (int)(t * 4u), (int)(i0 * 4u + (unsigned)u * kRT * 4u), kAuxNT);
+            }
+            if (i0 + kRT * U < cnt)
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    key[u] = nk[u];
             }
         }
     }
@@ -1043,9 +1051,10 @@ __global__ __launch_bounds__(256) void k_sr_select_bases(unsigned nf, unsigned n
 // 1024 lines.
 template <int BIT>
 __global__ __launch_bounds__(256) void k_sr_select_fixup(BvView bv, const uint32_t * __restrict__ any_marked,
-                                                         const uint64_t * __restrict__ iq, uint64_t * __restrict__ out, uint64_t n)
+                                                         const uint64_t * __restrict__ iq, uint64_t * __restrict__ out, uint64_t n,
+                                                         const uint32_t * __restrict__ go)
 {
-    if (!*any_marked)
+    if ((go && !*go) || !*any_marked)
         return; // the usual case: every bucket fitted a slice
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x)
     {
@@ -1378,14 +1387,14 @@ SrKernels sr_kernels(unsigned per_cu)
 // the slices' answers in place over the final keys (tables in SLICE order: d1 = 0 makes sr_slice_of the identity) + the
 // per-slice bases the way back adds (bv_swc.hip)
 sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const SelectPlan & sp, unsigned nf, unsigned d2, const uint32_t * fstart,
-                                  const uint32_t * ioff, uint32_t * keys2, uint64_t * hf, uint32_t * marked, hipStream_t s)
+                                  const uint32_t * ioff, uint32_t * keys2, uint64_t * hf, uint32_t * marked, const uint32_t * go, hipStream_t s)
 {
     static const int rb_env = getenv("SDSL_HIP_SORTED_RANK_BLOCKS") ? atoi(getenv("SDSL_HIP_SORTED_RANK_BLOCKS")) : 0;
     const unsigned slice_blocks = rb_env >= 1 ? (unsigned)rb_env : 1024u;
     if (op == 0)
     {
         hipLaunchKernelGGL(k_sr_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, s, v, nf, 0u, d2, hf);
-        hipLaunchKernelGGL(k_sr_rank_lds, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, 0u, d2, fstart, ioff, keys2);
+        hipLaunchKernelGGL(k_sr_rank_lds, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, 0u, d2, fstart, ioff, keys2, go);
     }
     else
     {
@@ -1393,21 +1402,22 @@ sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const Selec
         hipLaunchKernelGGL(k_sr_select_bases, dim3((nf + 255) / 256), dim3(256), 0, s, nf, sp.nf, 0u, d2, sp.bnd, hf);
         if (bit)
             hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, 0u, d2, sp.bm << sp.bs, sp.bnd, fstart, ioff,
-                               keys2, marked);
+                               keys2, marked, go);
         else
             hipLaunchKernelGGL(k_sr_select_lds<0>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, 0u, d2, sp.bm << sp.bs, sp.bnd, fstart, ioff,
-                               keys2, marked);
+                               keys2, marked, go);
     }
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }
 
-void sr_launch_select_fixup(const BvView & v, int bit, const uint32_t * marked, const uint64_t * idx, uint64_t * out, uint64_t cnt, hipStream_t s)
+void sr_launch_select_fixup(const BvView & v, int bit, const uint32_t * marked, const uint64_t * idx, uint64_t * out, uint64_t cnt,
+                            const uint32_t * go, hipStream_t s)
 {
     if (bit)
-        hipLaunchKernelGGL(k_sr_select_fixup<1>, dim3(256 * 8), dim3(256), 0, s, v, marked, idx, out, cnt);
+        hipLaunchKernelGGL(k_sr_select_fixup<1>, dim3(256 * 8), dim3(256), 0, s, v, marked, idx, out, cnt, go);
     else
-        hipLaunchKernelGGL(k_sr_select_fixup<0>, dim3(256 * 8), dim3(256), 0, s, v, marked, idx, out, cnt);
+        hipLaunchKernelGGL(k_sr_select_fixup<0>, dim3(256 * 8), dim3(256), 0, s, v, marked, idx, out, cnt, go);
 }
 
 void sr_launch_bin_offsets(unsigned bins, unsigned G, const uint32_t * counts, uint32_t * btot, uint32_t * bstart, uint32_t * offs,
@@ -1506,6 +1516,11 @@ __global__ __launch_bounds__(1024) void k_sr_sample_spread(SrGeom g, const uint6
     {
         out[0] = n_distinct;
         out[1] = n_valid;
+        // uniformly random samples over S slices touch S * (1 - exp(-m / S)) of them; half of the samples' own number is far below
+        // that for every vector the bucketed path applies to (>= 2^12 slices) and far above what a window or a sorted batch gives
+        const unsigned slices = 1u << (g.d1 + g.d2);
+        const unsigned limit = n_valid / 2 < slices / 2 ? n_valid / 2 : slices / 2;
+        out[2] = n_valid >= 1024 && n_distinct >= limit ? 1u : 0u; // the verdict: the batch is spread over the vector
     }
 }
 
@@ -1588,7 +1603,7 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         {
             hipLaunchKernelGGL(k_sr_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, s, v, nf, g.d1, g.d2, b.hf);
             pt.mark();
-            hipLaunchKernelGGL(k_sr_rank_lds, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, g.d1, g.d2, b.fstart, b.ioff, b.keys2);
+            hipLaunchKernelGGL(k_sr_rank_lds, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, g.d1, g.d2, b.fstart, b.ioff, b.keys2, (const uint32_t *)nullptr);
         }
         else
         {
@@ -1598,10 +1613,10 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
             // slices beyond sp.nf are empty (no items), so the kernel never reads bnd past sp.nf
             if (bit)
                 hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, g.d1, g.d2, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
-                                   b.keys2, b.btot);
+                                   b.keys2, b.btot, (const uint32_t *)nullptr);
             else
                 hipLaunchKernelGGL(k_sr_select_lds<0>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, g.d1, g.d2, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
-                                   b.keys2, b.btot);
+                                   b.keys2, b.btot, (const uint32_t *)nullptr);
         }
         pt.mark();
         hipLaunchKernelGGL(K.unp2, G, T, 0, s, b.hf, bit, g, b.tprefix2, b.bstart1, b.offs2, b.keys2, b.btot, b.slots2, b.thist2,
@@ -1613,9 +1628,9 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         if (op == 1)
         { // whatever the slices left over (buckets wider than a slice): one lane per marked answer
             if (bit)
-                hipLaunchKernelGGL(k_sr_select_fixup<1>, dim3(256 * 8), dim3(256), 0, s, v, b.btot, idx, d_out + done, cnt);
+                hipLaunchKernelGGL(k_sr_select_fixup<1>, dim3(256 * 8), dim3(256), 0, s, v, b.btot, idx, d_out + done, cnt, (const uint32_t *)nullptr);
             else
-                hipLaunchKernelGGL(k_sr_select_fixup<0>, dim3(256 * 8), dim3(256), 0, s, v, b.btot, idx, d_out + done, cnt);
+                hipLaunchKernelGGL(k_sr_select_fixup<0>, dim3(256 * 8), dim3(256), 0, s, v, b.btot, idx, d_out + done, cnt, (const uint32_t *)nullptr);
         }
         SH_HIP(hipGetLastError());
         if (trace_env)
@@ -1691,8 +1706,40 @@ sdsl_hip_status bv_sorted_select_is_spread(const BvHost & h, int bit, const uint
     return sr_batch_is_spread(h.view, 1, sp, d_idx, n, s, (uint32_t *)scratch, spread);
 }
 
+// The same sample without the read-back: the verdict (1: spread) lands in out3[2] and the routes enqueued behind it look at it
+// themselves (the passes of bv_swc.hip through SrGeom::go, the direct kernels through BvView::skip_if) — nothing synchronises.
+bool bv_sorted_device_verdict()
+{
+    return sr_use_swc();
+}
+
+sdsl_hip_status bv_sorted_rank_sample(const BvView & v, const uint64_t * d_idx, uint64_t n, hipStream_t s, uint32_t * out3)
+{
+    SrGeom g;
+    sr_fill_geom(g, v, 0, SelectPlan(), n);
+    hipLaunchKernelGGL(k_sr_sample_spread, dim3(1), dim3(1024), 0, s, g, d_idx, out3);
+    SH_HIP(hipGetLastError());
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status bv_sorted_select_sample(const BvHost & h, int bit, const uint64_t * d_idx, uint64_t n, hipStream_t s, uint32_t * out3)
+{
+    const BvHost::SelPlan & P = h.sel_plan[bit];
+    SelectPlan sp;
+    sp.bnd = P.bnd.as<uint32_t>();
+    sp.bm = P.bm;
+    sp.bs = P.bs;
+    sp.nf = P.nf;
+    sp.total = bit ? h.view.ones : h.view.n_bits - h.view.ones;
+    SrGeom g;
+    sr_fill_geom(g, h.view, 1, sp, n);
+    hipLaunchKernelGGL(k_sr_sample_spread, dim3(1), dim3(1024), 0, s, g, d_idx, out3);
+    SH_HIP(hipGetLastError());
+    return SDSL_HIP_OK;
+}
+
 sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
-                                      hipStream_t s, void * scratch, size_t scratch_bytes)
+                                      hipStream_t s, void * scratch, size_t scratch_bytes, const uint32_t * go)
 {
     if (!bv_sorted_rank_possible(v))
     {
@@ -1700,7 +1747,7 @@ sdsl_hip_status bv_launch_rank_sorted(const BvView & v, int bit, const uint64_t 
         return SDSL_HIP_ERR_INVALID;
     }
     if (sr_use_swc())
-        return sw_run(v, 0, bit, SelectPlan{}, d_idx, n, d_out, s, scratch, scratch_bytes);
+        return sw_run(v, 0, bit, SelectPlan{}, d_idx, n, d_out, s, scratch, scratch_bytes, go);
     return sr_run(v, 0, bit, SelectPlan{}, d_idx, n, d_out, s, scratch, scratch_bytes);
 }
 
@@ -1715,10 +1762,14 @@ sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit)
     BvHost::SelPlan & P = h.sel_plan[bit];
     const BvView & v = h.view;
     const uint64_t total = bit ? v.ones : v.n_bits - v.ones;
-    P.ready = true;
+    // (ready only once the outcome is definitive: a failed allocation below leaves the plan to be tried again, and the caller
+    // on the direct kernel meanwhile)
     P.ok = false;
     if (!v.sel[bit] || total < 2 || v.n_lines > UINT64_C(0xFFFFFFFF))
+    {
+        P.ready = true;
         return SDSL_HIP_OK;
+    }
     // B = m << sh, m in 8..15: the largest such value whose bucket spans about 3/4 of a slice at the vector's mean density,
     // but at least total / 2^16 (two 8-bit digits address the buckets)
     auto round_down = [](uint64_t x, unsigned & m, unsigned & sh) { // largest m << sh <= x (x >= 64)
@@ -1739,13 +1790,18 @@ sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit)
             bm = 8, ++bs;
     }
     if (bs > 20)
+    {
+        P.ready = true;
         return SDSL_HIP_OK;
+    }
     const uint64_t B = (uint64_t)bm << bs;
     const unsigned nf = (unsigned)((total + B - 1) / B);
     DevBuf args, pos;
-    SH_TRY(args.alloc((size_t)nf * 8));
-    SH_TRY(pos.alloc((size_t)nf * 8));
-    SH_TRY(P.bnd.alloc(((size_t)nf + 1) * 4));
+    if (args.alloc((size_t)nf * 8) != SDSL_HIP_OK || pos.alloc((size_t)nf * 8) != SDSL_HIP_OK || P.bnd.alloc(((size_t)nf + 1) * 4) != SDSL_HIP_OK)
+    { // no room right now: not an error of the query — it takes the direct kernel, and the plan is tried again next time
+        P.bnd.release();
+        return SDSL_HIP_OK;
+    }
     hipLaunchKernelGGL(k_sr_bnd_args, dim3((nf + 255) / 256), dim3(256), 0, 0, nf, (unsigned)B, args.as<uint64_t>());
     SH_HIP(hipGetLastError());
     {
@@ -1766,6 +1822,7 @@ sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit)
     P.nf = nf;
     P.wide_frac = (double)wide / (double)total;
     P.ok = true;
+    P.ready = true;
     return SDSL_HIP_OK;
 }
 
@@ -1776,7 +1833,7 @@ bool bv_sorted_select_applicable(const BvHost & h, int bit, uint64_t n)
 }
 
 sdsl_hip_status bv_launch_select_sorted(BvHost & h, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out, hipStream_t s,
-                                        void * scratch, size_t scratch_bytes)
+                                        void * scratch, size_t scratch_bytes, const uint32_t * go)
 {
     const BvHost::SelPlan & P = h.sel_plan[bit];
     if (!P.ready || !P.ok)
@@ -1791,7 +1848,7 @@ sdsl_hip_status bv_launch_select_sorted(BvHost & h, int bit, const uint64_t * d_
     sp.nf = P.nf;
     sp.total = bit ? h.view.ones : h.view.n_bits - h.view.ones;
     if (sr_use_swc())
-        return sw_run(h.view, 1, bit, sp, d_i, n, d_out, s, scratch, scratch_bytes);
+        return sw_run(h.view, 1, bit, sp, d_i, n, d_out, s, scratch, scratch_bytes, go);
     return sr_run(h.view, 1, bit, sp, d_i, n, d_out, s, scratch, scratch_bytes);
 }
 

@@ -35,6 +35,7 @@ struct SrGeom
     uint32_t binv;   // select: ceil(2^32 / m); floor(x / m) = (x * binv) >> 32 for x < 2^28
     uint64_t total;  // select: arguments of the vector (ones or zeros)
     bool small;      // 32-bit division path of line_of
+    const uint32_t * go; // automatic dispatch: the passes return at once when this word is zero (nullptr: always run)
 };
 
 struct SrBuf
@@ -139,6 +140,30 @@ __device__ __forceinline__ unsigned sr_slice_of(unsigned f, unsigned d1, unsigne
 {
     return ((f & ((1u << d1) - 1)) << d2) | (f >> d1);
 }
+
+// ---- buffer addressing: a uniform base in SGPRs + a 32-bit lane offset; whatever lies beyond num_records reads as 0 and is not
+// written — tiles need no per-key bounds checks and no 64-bit address arithmetic in VGPRs ----
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int kAuxNT = 2; // streamed once: non-temporal
+__device__ __forceinline__ rsrc_t make_rsrc(const void * p, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return ((uint64_t)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v);
+}
+__device__ __forceinline__ void buf_load(rsrc_t r, unsigned voff, unsigned soff, uint32_t & out)
+{
+    out = __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, kAuxNT);
+}
+__device__ __forceinline__ void buf_load(rsrc_t r, unsigned voff, unsigned soff, uint64_t & out)
+{
+    typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+    const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, kAuxNT);
+    out = ((uint64_t)v.y << 32) | v.x;
+}
+
 
 } // namespace
 
@@ -252,17 +277,18 @@ inline void sr_fill_geom(SrGeom & g, const BvView & v, int op, const SelectPlan 
     g.d2 = f < 8 ? f : 8; // pass 2: the LOW bits of the slice index; pass 1: the high ones, so that a pass-1 bin is a contiguous
     g.d1 = f - g.d2;      // stretch of the vector and the answers of its keys fit 32 bits relative to the stretch's first one
     g.small = v.n_bits < (UINT64_C(1) << 38);
+    g.go = nullptr;
 }
 
 sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const SelectPlan & sp, unsigned nf, unsigned d2, const uint32_t * fstart,
-                                  const uint32_t * ioff, uint32_t * keys2, uint64_t * hf, uint32_t * marked, hipStream_t s);
+                                  const uint32_t * ioff, uint32_t * keys2, uint64_t * hf, uint32_t * marked, const uint32_t * go, hipStream_t s);
 void sr_launch_select_fixup(const BvView & v, int bit, const uint32_t * marked, const uint64_t * idx, uint64_t * out, uint64_t cnt,
-                            hipStream_t s);
+                            const uint32_t * go, hipStream_t s);
 
 // the write-combined pipeline (bv_swc.hip): same contract as the passes of bv_sorted.hip
 size_t bv_swc_scratch_bytes(const BvView & v, uint64_t n);
 sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
-                       hipStream_t s, void * scratch, size_t scratch_bytes);
+                       hipStream_t s, void * scratch, size_t scratch_bytes, const uint32_t * go);
 
 // table kernels of bv_sorted.hip, launched on behalf of bv_swc.hip
 // offs[b][g] = keys of bins < b + keys of bin b in streams < g, from counts[b][g]; bstart = bin starts (bins + 1 entries)

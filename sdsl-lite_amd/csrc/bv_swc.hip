@@ -22,7 +22,9 @@
 // Units are handed to persistent blocks by a ticket counter; they are independent, so any order is correct.
 // The answers are the reference's (rank_support_v5.hpp:131-149, select_support_mcl.hpp:384-439); batching is this
 // library's addition.
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "bv_sorted_dev.hpp"
 
@@ -34,6 +36,7 @@ constexpr unsigned kHB = 256;  // histogram blocks = rows of fine_h (one block p
 constexpr unsigned kHT = 1024; // threads of a histogram block
 constexpr unsigned kCA = 32;   // keys per write-combining chunk (128 B)
 constexpr unsigned kMaxK = 64; // segments per pass-1 bin
+constexpr unsigned kMoveAt = 0x1000; // every kMoveAt-th increment of a 16-bit slice counter moves that much to the global row
 constexpr unsigned kCkS = 8;   // the partition notes every stream's position at every kCkS-th tile
 
 struct SwGeom
@@ -102,13 +105,20 @@ size_t sw_carve(SwBuf & b, void * scratch, uint64_t n, unsigned tile, const SwGe
 // ---- the one counting pass ------------------------------------------------------------------------------------------
 // Block h counts the keys of pass-1 units [h * U1 / kHB, ...): per unit the keys per pass-1 bin (counts1[bin][unit]), over
 // the whole range the keys per slice (row h of fine_h, zeroed by the caller).  The slice histogram lives in LDS as two
-// 16-bit fields per word.  A field never overflows: the thread whose increment takes it from 0x7FFF to 0x8000 — exactly one
-// per crossing, the returning atomic tells — moves 0x8000 to the global row; until its subtraction lands the field only
-// grows by what the block's other threads add meanwhile, far from 0xFFFF.
+// 16-bit fields per word.  A field never overflows: the thread whose increment is the field's kMoveAt-th, 2 kMoveAt-th, ...
+// (the returning atomic tells: old value = kMoveAt - 1 modulo kMoveAt — moving kMoveAt out does not change that residue,
+// so exactly one thread per kMoveAt increments qualifies whenever the moves land) subtracts kMoveAt and adds it to the
+// global row.  A move lands at most one LDS queue (a few 10^4 increments) behind its trigger, so the field stays below
+// kMoveAt + that, and it is at least kMoveAt when the move lands: no overflow, no borrow, for any distribution.
+// (The first form triggered on the value 2^15 - 1 itself: a move that landed more than 2^15 increments late left the field
+// above the trigger for good, and a batch of 10^8 positions inside three slices lost 65536 keys of one — found by the
+// reference-digest test on the windowed batch.)
 template <unsigned PER>
 __global__ __launch_bounds__(kHT) void k_sw_hist(SrGeom g, SwGeom w, const uint64_t * __restrict__ idx, uint32_t * __restrict__ counts1,
                                                  uint32_t * __restrict__ fine_h)
 {
+    if (g.go && !*g.go)
+        return;
     extern __shared__ uint32_t sw_lds[];
     uint32_t * fine = sw_lds;
     uint32_t * uhist = sw_lds + w.fine_words + 1; // kBins + 1 (the last one takes what lies beyond the range)
@@ -162,11 +172,11 @@ __global__ __launch_bounds__(kHT) void k_sw_hist(SrGeom g, SwGeom w, const uint6
             }
 #pragma unroll
             for (unsigned u = 0; u < PER; ++u)
-                if ((fidv[u] >> 16) == 0x7FFFu)
+                if (((fidv[u] >> 16) & (kMoveAt - 1)) == kMoveAt - 1)
                 { // this increment took the field to 2^15: move that much to the global row
                     const unsigned fid = fidv[u] & 0xFFFFu;
-                    atomicSub(&fine[fid >> 1], 0x8000u << ((fid & 1u) << 4));
-                    atomicAdd(row + fid, 0x8000u);
+                    atomicSub(&fine[fid >> 1], kMoveAt << ((fid & 1u) << 4));
+                    atomicAdd(row + fid, kMoveAt);
                 }
             if (cn < khi)
             {
@@ -211,6 +221,8 @@ __global__ __launch_bounds__(256) void k_sw_seg_reduce(SwGeom w, const uint32_t 
 __global__ __launch_bounds__(1024) void k_sw_units2(SrGeom g, SwGeom w, const uint32_t * __restrict__ offs1, uint32_t * __restrict__ in_lo,
                                                     uint32_t * __restrict__ tp2)
 {
+    if (g.go && !*g.go)
+        return;
     __shared__ unsigned wred[16];
     const unsigned t = threadIdx.x;
     const unsigned n_units = (1u << g.d1) * w.K, upk = w.U1 / w.K;
@@ -288,29 +300,6 @@ __device__ __forceinline__ unsigned carry_at(unsigned b, unsigned i)
 }
 
 
-// ---- buffer addressing: a uniform base in SGPRs + a 32-bit lane offset; whatever lies beyond num_records reads as 0 and is not
-// written — tiles need no per-key bounds checks and no 64-bit address arithmetic in VGPRs ----
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr int kAuxNT = 2; // streamed once: non-temporal
-__device__ __forceinline__ rsrc_t make_rsrc(const void * p, uint32_t bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), (short)0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ uint64_t uniform64(uint64_t v)
-{
-    return ((uint64_t)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)v);
-}
-__device__ __forceinline__ void buf_load(rsrc_t r, unsigned voff, unsigned soff, uint32_t & out)
-{
-    out = __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, kAuxNT);
-}
-__device__ __forceinline__ void buf_load(rsrc_t r, unsigned voff, unsigned soff, uint64_t & out)
-{
-    typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
-    const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, kAuxNT);
-    out = ((uint64_t)v.y << 32) | v.x;
-}
-
 // ---- a partition pass with write combining ------------------------------------------------------------------------
 // Per tile: counting sort in LDS as in bv_sorted.hip (returning atomic = place inside the tile's share of the bin, slot =
 // place in the sorted tile).  Writing out: a stream's keys not yet written sit in its carry row (fewer than kCA); a tile's run
@@ -326,6 +315,8 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
                                                        uint16_t * __restrict__ tile_hist, uint32_t * __restrict__ ckpt,
                                                        uint64_t * __restrict__ tdesc)
 {
+    if (g.go && !*g.go)
+        return;
     constexpr unsigned kTile = TT * PER;
     typedef typename std::conditional<P == 1, uint64_t, uint32_t>::type raw_t;
     __shared__ uint32_t sorted[kTile];
@@ -546,13 +537,7 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
     }
 }
 
-// ---- the way back: runs gathered into LDS, answers picked by slot ------------------------------------------------------
-// P == 2: slice-relative answers (order of partition 2) -> answers relative to their pass-1 bin, in the order of partition 1
-// P == 1: those -> absolute answers in the caller's order
-// The way back has no carry to keep, so it need not follow the units: the partition left every stream's position at every
-// kCkS-th tile (ckpt), and the work is shared out in items of kCkS tiles — fine enough for any number of blocks.
-// Per tile ONE exposed round trip: the tile histogram is requested a tile ahead; the slots and all the runs of the tile (eight
-// bins per 16-lane group, four elements each) are requested together and waited for once.
+// ---- the way back ------------------------------------------------------------------------------------------------------
 template <int P>
 struct SwTile
 {
@@ -587,240 +572,13 @@ __device__ __forceinline__ SwTile<P> sw_tile(const SrGeom & g, const SwGeom & w,
     return d;
 }
 
-template <int P, unsigned TT, unsigned PER, unsigned NB, unsigned E, unsigned WPE>
-__global__ __launch_bounds__(TT, WPE) void k_sw_unpermute(const uint64_t * __restrict__ hf, int bit, SrGeom g, SwGeom w,
-                                                       const uint32_t * __restrict__ offs1, const uint32_t * __restrict__ in_lo,
-                                                       const uint32_t * __restrict__ tp2, const uint32_t * __restrict__ fstart,
-                                                       const uint32_t * __restrict__ segsum, const uint32_t * __restrict__ ckpt,
-                                                       uint32_t * __restrict__ ticket, const uint32_t * __restrict__ res_lo,
-                                                       uint32_t * __restrict__ any_marked, const uint16_t * __restrict__ slots,
-                                                       const uint16_t * __restrict__ tile_hist, uint32_t * __restrict__ out_lo,
-                                                       uint64_t * __restrict__ out)
-{
-    constexpr unsigned kTile = TT * PER;
-    __shared__ uint32_t lo32[kTile];
-    __shared__ uint8_t hi8[P == 1 ? kTile : 1]; // pass 1: bits 32.. of the absolute answers (0xFF: NPOS, 0xFE: left to the fix-up)
-    __shared__ unsigned hist[kBins], start[kBins], cursor[kBins];
-    __shared__ uint64_t sbase[kBins]; // what makes the answers of bin b absolute (P == 1) / relative to the pass-1 bin (P == 2)
-    __shared__ unsigned wsum[kBins / 64];
-    __shared__ unsigned big[kTile / (kBigRun + 1) + 1], n_big, sh_item, sh_unit;
-    const unsigned t = threadIdx.x, l = t & 15;
-    const unsigned bins = 1u << (P == 1 ? g.d1 : g.d2);
-    const unsigned n_units = P == 1 ? w.U1 : (1u << g.d1) * w.K;
-    const unsigned T = P == 1 ? w.U1 * w.tpu : __builtin_amdgcn_readfirstlane(tp2[n_units]);
-    const rsrc_t rs_res = make_rsrc(res_lo, (uint32_t)g.n * 4u);
-    // what turns a slice-relative answer into an absolute one: rank: ones (zeros) in front of the slice; select: the first
-    // bit of the bucket's first line.  (b1, b2) = the slice's pass-1 / pass-2 digits; the tables are in slice order
-    auto abs_base = [&](unsigned b1, unsigned b2) -> uint64_t
-    {
-        const unsigned f = (b1 << g.d2) | b2;
-        const uint64_t h = hf[f];
-        if (g.op == 1)
-            return h;
-        return bit ? h : ((uint64_t)f << kSliceLog) * kDB - h;
-    };
-    if (P == 1)
-        for (unsigned i = t; i < kBins; i += TT)
-            sbase[i] = i < bins ? abs_base(i, 0) : 0;
-    for (;;)
-    {
-        if (t == 0)
-            sh_item = atomicAdd(ticket, 1u);
-        __syncthreads();
-        const unsigned item = __builtin_amdgcn_readfirstlane(sh_item);
-        const unsigned t_lo = item * kCkS;
-        if (t_lo >= T)
-            break;
-        const unsigned t_hi = t_lo + kCkS < T ? t_lo + kCkS : T;
-        unsigned unit0 = 0;
-        if (P == 2)
-        { // the unit of the item's first tile: the last one that starts at or before it
-            if (t == 0)
-            {
-                unsigned a = 0, z = n_units;
-                while (a + 1 < z)
-                {
-                    const unsigned m = (a + z) >> 1;
-                    if (tp2[m] <= t_lo)
-                        a = m;
-                    else
-                        z = m;
-                }
-                sh_unit = a;
-            }
-            __syncthreads();
-            unit0 = __builtin_amdgcn_readfirstlane(sh_unit);
-        }
-        SwTile<P> d = sw_tile<P>(g, w, t_lo, unit0, in_lo, tp2);
-        unsigned have_unit = 0xFFFFFFFFu; // the unit sbase / the stream starts were loaded for
-        unsigned nh = t < bins ? tile_hist[(uint64_t)t_lo * bins + t] : 0u;
-        for (unsigned ti = t_lo; ti < t_hi; ++ti)
-        {
-            const bool more = ti + 1 < t_hi;
-            SwTile<P> dn = d;
-            if (more)
-                dn = sw_tile<P>(g, w, ti + 1, d.unit, in_lo, tp2);
-            if (d.cnt == 0)
-            { // (pass 1: tiles past the batch's end)
-                d = dn;
-                continue;
-            }
-            const unsigned grp = P == 2 ? d.unit / w.K : 0u;
-            // where this tile's runs start: the streams' starts (first tile of a unit), the partition's note (first tile of the
-            // item), else where the previous tile's runs ended
-            if (ti == d.tb)
-            {
-                (void)sw_unit_setup<P, TT>(g, w, d.unit, offs1, in_lo, tp2, fstart, segsum, cursor);
-            }
-            else if (ti == t_lo)
-            {
-                for (unsigned i = t; i < kBins; i += TT)
-                    cursor[i] = i < bins ? ckpt[(uint64_t)(ti / kCkS) * kBins + i] : 0u;
-            }
-            if (P == 2 && have_unit != d.unit)
-            {
-                const uint64_t gbase = abs_base(grp, 0);
-                for (unsigned i = t; i < kBins; i += TT)
-                    sbase[i] = i < bins ? abs_base(grp, i) - gbase : 0;
-                have_unit = d.unit;
-            }
-            for (unsigned i = t; i < kBins; i += TT)
-            {
-                hist[i] = nh;
-                start[i] = nh;
-            }
-            if (t == 0)
-                n_big = 0;
-            __syncthreads();
-            if (more)
-                nh = t < bins ? tile_hist[(uint64_t)(ti + 1) * bins + t] : 0u;
-            block_excl_scan_bins(start, wsum);
-            bool mk = false; // an answer that does not fit 32 bits relative to its pass-1 bin: left to the fix-up pass
-            auto keep = [&](uint64_t base, unsigned at, uint32_t v)
-            {
-                if (P == 2)
-                {
-                    const uint64_t rel = base + v;
-                    uint32_t r = (uint32_t)rel;
-                    if (v >= kMark)
-                        r = v;
-                    else if (rel >= kMark)
-                    {
-                        r = kMark;
-                        mk = true;
-                    }
-                    lo32[at] = r;
-                }
-                else
-                {
-                    const uint64_t full = base + v;
-                    lo32[at] = (uint32_t)full;
-                    hi8[at] = v == kBad ? (uint8_t)0xFF : (v == kMark ? (uint8_t)0xFE : (uint8_t)(full >> 32));
-                }
-            };
-            uint16_t sl[PER];
-            // a 16-lane group owns bins q, q + TT / 16, ...: NB runs of E x 16 elements are requested before any is consumed (one
-            // round for the whole tile when bins <= NB * TT / 16), and the tile's slots right behind them
-            constexpr unsigned kStep = TT / 16;
-            auto gather_round = [&](unsigned k0, auto first_c)
-            {
-                constexpr bool FIRST = decltype(first_c)::value;
-                unsigned cnt[NB];
-                uint32_t v[NB][E];
-#pragma unroll
-                for (unsigned k = 0; k < NB; ++k)
-                {
-                    const unsigned b = (t >> 4) + (k0 + k) * kStep;
-                    cnt[k] = b < bins ? hist[b & (kBins - 1)] : 0;
-                    const unsigned cur = cursor[b & (kBins - 1)];
-                    if (cnt[k] > kBigRun)
-                    {
-                        if (l == 0)
-                            big[atomicAdd(&n_big, 1u)] = b;
-                        cnt[k] = 0;
-                    }
-#pragma unroll
-                    for (unsigned e = 0; e < E; ++e)
-                    {
-                        const unsigned i = l + 16 * e;
-                        // (beyond the run: an offset past the buffer's end — reads as 0 without touching memory)
-                        v[k][e] = __builtin_amdgcn_raw_buffer_load_b32(rs_res, (int)(i < cnt[k] ? (cur + i) * 4u : 0xFFFFFFFCu), 0, 0);
-                    }
-                }
-                if (FIRST)
-                {
-                    const rsrc_t rs = make_rsrc(slots + d.lo, d.cnt * 2u);
-#pragma unroll
-                    for (unsigned u = 0; u < PER; ++u)
-                        sl[u] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)(t * 2u), (int)(u * TT * 2u), kAuxNT);
-                }
-#pragma unroll
-                for (unsigned k = 0; k < NB; ++k)
-                {
-                    const unsigned b = ((t >> 4) + (k0 + k) * kStep) & (kBins - 1);
-                    const uint64_t base = sbase[b];
-                    const unsigned st = start[b];
-#pragma unroll
-                    for (unsigned e = 0; e < E; ++e)
-                        if (l + 16 * e < cnt[k])
-                            keep(base, st + l + 16 * e, v[k][e]);
-                    if (cnt[k] > 16 * E)
-                    {
-                        const unsigned cur = cursor[b];
-                        for (unsigned i = l + 16 * E; i < cnt[k]; i += 16)
-                            keep(base, st + i, res_lo[(uint64_t)cur + i]);
-                    }
-                }
-            };
-            gather_round(0u, std::true_type{});
-#pragma nounroll
-            for (unsigned k0 = NB; k0 * kStep < bins; k0 += NB)
-                gather_round(k0, std::false_type{});
-            __syncthreads();
-            const unsigned nb = n_big;
-            for (unsigned k = 0; k < nb; ++k)
-            {
-                const unsigned b = big[k], c = hist[b], s0 = start[b], cu = cursor[b];
-                const uint64_t base = sbase[b];
-                for (unsigned i = t; i < c; i += TT)
-                    keep(base, s0 + i, res_lo[(uint64_t)cu + i]);
-            }
-            if (nb)
-                __syncthreads();
-            if (P == 2 && mk)
-                *any_marked = 1;
-            {
-                typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
-                const rsrc_t rs = P == 2 ? make_rsrc(out_lo + d.lo, d.cnt * 4u) : make_rsrc(out + d.lo, d.cnt * 8u);
-#pragma unroll
-                for (unsigned u = 0; u < PER; ++u)
-                {
-                    const unsigned at = sl[u] & (kTile - 1); // (what lies beyond the tile's end is not written: any slot will do)
-                    const unsigned h = P == 1 ? hi8[at] : 0u;
-                    const uint32_t l32 = lo32[at];
-                    if (P == 2)
-                        __builtin_amdgcn_raw_buffer_store_b32(l32, rs, (int)(t * 4u), (int)(u * TT * 4u), kAuxNT);
-                    else
-                    {
-                        const uint64_t a = h == 0xFFu ? SDSL_HIP_NPOS : (h == 0xFEu ? kMark64 : ((uint64_t)h << 32) | l32);
-                        v2u32 pr;
-                        pr.x = (unsigned)a;
-                        pr.y = (unsigned)(a >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b64(pr, rs, (int)(t * 8u), (int)(u * TT * 8u), kAuxNT);
-                    }
-                }
-            }
-            for (unsigned i = t; i < kBins; i += TT)
-                cursor[i] += hist[i];
-            __syncthreads();
-            d = dn;
-        }
-    }
-}
-
-// ---- the way back, runs fetched by LDS DMA ------------------------------------------------------------------------------------
-// The gather above holds a tile's run elements in registers between request and use (24-32 VGPRs per lane, two rounds per tile
-// at 512 threads).  Here the fetch goes global -> LDS directly (buffer_load ... lds): position p of the bin-major tile image
+// P == 2: slice-relative answers (order of partition 2) -> answers relative to their pass-1 bin, in the order of partition 1
+// P == 1: those -> absolute answers in the caller's order
+// The way back has no carry to keep, so it need not follow the units: the partition left every stream's position at every
+// kCkS-th tile (ckpt) and, for pass 2, a descriptor of every tile (tdesc); the work is shared out in items of kCkS tiles.
+// Per tile the runs are gathered into LDS (the bin-major image of the tile), then every position picks its answer by slot.
+// The first form of the gather held the run elements in registers between request and use (24-32 VGPRs per lane, two rounds
+// per tile at 512 threads: 2.7 ms per pass).  Here the fetch goes global -> LDS directly (buffer_load ... lds): position p of the bin-major tile image
 // is fetched by lane p of its wave from  delta[bin(p)] + p  (delta = where the bin's run starts in the stream - where it starts
 // in the image), sixteen requests per lane in flight and no register waiting for any of them; bin(p) comes from a byte map the
 // bins' lane groups fill after the scan.  What makes an answer absolute is added when it is picked: one more table read per
@@ -836,6 +594,8 @@ __global__ __launch_bounds__(TT, 6) void k_sw_unpermute_dma(const uint64_t * __r
                                                            const uint16_t * __restrict__ tile_hist, uint32_t * __restrict__ out_lo,
                                                            uint64_t * __restrict__ out)
 {
+    if (g.go && !*g.go)
+        return;
     constexpr unsigned kTile = TT * PER;
     __shared__ uint32_t lo32[kTile];
     __shared__ uint8_t binof[kTile];
@@ -1046,19 +806,15 @@ size_t bv_swc_scratch_bytes(const BvView & v, uint64_t n)
 }
 
 sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
-                       hipStream_t s, void * scratch, size_t scratch_bytes)
+                       hipStream_t s, void * scratch, size_t scratch_bytes, const uint32_t * go)
 {
     static const bool trace_env = getenv("SDSL_HIP_TRACE_SORTED") != nullptr;
     const bool trace_opt = g_trace_phases.load() != 0;
     const bool trace = trace_env || trace_opt;
     static const int pb_env = getenv("SDSL_HIP_SWC_PART_BLOCKS") ? atoi(getenv("SDSL_HIP_SWC_PART_BLOCKS")) : 0;
     static const int ub_env = getenv("SDSL_HIP_SWC_UNP_BLOCKS") ? atoi(getenv("SDSL_HIP_SWC_UNP_BLOCKS")) : 0;
-    static bool attr_done = false;
-    if (!attr_done)
-    { // the slice histogram may fill the CU's LDS
-        SH_HIP(hipFuncSetAttribute((const void *)k_sw_hist<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    // the slice histogram may fill the CU's LDS (a per-device attribute of the kernel; setting it is a host-side table write)
+    SH_HIP(hipFuncSetAttribute((const void *)k_sw_hist<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     for (uint64_t done = 0; done < n;)
     {
         const uint64_t cnt = n - done < kSwMaxPass ? n - done : kSwMaxPass;
@@ -1067,6 +823,7 @@ sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         g.tile = kSwTile;
         g.tiles1 = (uint32_t)((cnt + g.tile - 1) / g.tile);
         g.G = 0;
+        g.go = go;
         SwGeom w;
         sw_fill(w, g, cnt);
         const unsigned bins1 = 1u << g.d1;
@@ -1087,60 +844,66 @@ sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         hipLaunchKernelGGL(k_sw_seg_reduce, dim3((w.nf + 255) / 256), dim3(256), 0, s, w, b.fine_h, b.segsum, b.tot);
         sr_launch_fine_scan(w.nf, b.tot, b.fstart, b.ioff, s);
         pt.mark("tables");
+        static const bool dbg = getenv("SDSL_HIP_SWC_DEBUG") != nullptr;
+        if (dbg)
+        { // the slice counts must add up to the batch
+            std::vector<uint32_t> ht(w.nf), hrow((size_t)kHB * w.nfw);
+            SH_HIP(hipStreamSynchronize(s));
+            SH_HIP(hipMemcpy(ht.data(), b.tot, (size_t)w.nf * 4, hipMemcpyDeviceToHost));
+            SH_HIP(hipMemcpy(hrow.data(), b.fine_h, hrow.size() * 4, hipMemcpyDeviceToHost));
+            uint64_t sum = 0;
+            for (uint32_t x : ht)
+                sum += x;
+            fprintf(stderr, "[swc debug] n=%llu sum(tot)=%llu diff=%lld U1=%u tpu=%u K=%u nf=%u\n", (unsigned long long)cnt, (unsigned long long)sum,
+                    (long long)cnt - (long long)sum, w.U1, w.tpu, w.K, w.nf);
+            for (unsigned h = 0; h < kHB; ++h)
+            {
+                uint64_t rs = 0;
+                for (unsigned f = 0; f < w.nf; ++f)
+                    rs += hrow[(size_t)h * w.nfw + f];
+                const uint64_t lo = std::min<uint64_t>((uint64_t)h * (w.U1 / kHB) * w.tpu * g.tile, cnt), hi = std::min<uint64_t>(lo + (uint64_t)(w.U1 / kHB) * w.tpu * g.tile, cnt);
+                if (rs != hi - lo)
+                    fprintf(stderr, "[swc debug] row %u: %llu counted, %llu keys\n", h, (unsigned long long)rs, (unsigned long long)(hi - lo));
+            }
+        }
         const unsigned pblocks = pb_env >= 1 ? (unsigned)pb_env : 512u;
-        static const int p1t_env = getenv("SDSL_HIP_SWC_P1T") ? atoi(getenv("SDSL_HIP_SWC_P1T")) : 1024;
-        // pass 1 holds 64-bit positions: 1024 threads x 8 keep a tile's keys and the next tile's within the register file
-        const bool p1wide = p1t_env == 1024;
-        hipLaunchKernelGGL((p1wide ? k_sw_partition<1, 1024, 8> : k_sw_partition<1, kSwT, kSwPer>), dim3(p1wide && pb_env < 1 ? 256u : pblocks),
-                           dim3(p1wide ? 1024u : kSwT), 0, s, g, w, idx, (const uint32_t *)nullptr, b.offs1,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
-                           b.tickets + 0, b.keys1, b.slots1, b.thist1, b.ck1, (uint64_t *)nullptr);
+        // pass 1 holds 64-bit positions: 1024 threads x 8 keep a tile's keys and the next tile's within the register file (512 x 16
+        // spilled 33 VGPRs: 4.2 against 3.1 ms); one block per CU
+        hipLaunchKernelGGL((k_sw_partition<1, 1024, 8>), dim3(pb_env >= 1 ? (unsigned)pb_env : 256u), dim3(1024), 0, s, g, w, idx,
+                           (const uint32_t *)nullptr, b.offs1, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                           (const uint32_t *)nullptr, b.tickets + 0, b.keys1, b.slots1, b.thist1, b.ck1, (uint64_t *)nullptr);
         pt.mark("part1");
         hipLaunchKernelGGL(k_sw_units2, dim3(1), dim3(1024), 0, s, g, w, b.offs1, b.in_lo, b.tp2);
         hipLaunchKernelGGL((k_sw_partition<2, kSwT, kSwPer>), dim3(pblocks), dim3(kSwT), 0, s, g, w, (const uint64_t *)nullptr, b.keys1, b.offs1,
                            b.in_lo, b.tp2, b.fstart, b.segsum, b.tickets + 1, b.keys2, b.slots2, b.thist2, b.ck2, b.tdesc2);
         pt.mark("part2");
-        SH_TRY(sr_launch_answers(v, op, bit, sp, w.nf, g.d2, b.fstart, b.ioff, b.keys2, b.hf, b.marked, s));
+        SH_TRY(sr_launch_answers(v, op, bit, sp, w.nf, g.d2, b.fstart, b.ioff, b.keys2, b.hf, b.marked, go, s));
         pt.mark("answer");
-        // gather shape by the pass's mean run: eight runs of <= 64 keys or five of <= 96 per 16-lane group and round
-        const unsigned ub1 = (unsigned)((((v.n_lines + (UINT64_C(1) << kSliceLog) - 1) >> kSliceLog) + (1u << g.d2) - 1) >> g.d2);
-        const unsigned used1 = op == 0 ? (ub1 < bins1 ? ub1 : bins1) : ((sp.nf + (1u << g.d2) - 1) >> g.d2);
-        const bool long2 = g.tile / (1u << g.d2) > 40, long1 = g.tile / (used1 ? used1 : 1u) > 40;
-        // the gather's shape (experiment switch SDSL_HIP_SWC_UNP): 0 = 512 threads, runs of <= 64 keys, six bins per group and
-        // round | 1 = 512 threads, runs of <= 96, five bins | 2 = 1024 threads x 8 keys, four bins of <= 64 | 3 = ... of <= 96
-        static const int unp_env = getenv("SDSL_HIP_SWC_UNP") ? atoi(getenv("SDSL_HIP_SWC_UNP")) : -1;
-        const int sh2 = unp_env >= 0 ? unp_env : (long2 ? 1 : 0), sh1 = unp_env >= 0 ? unp_env : (long1 ? 1 : 0);
-        typedef decltype(&k_sw_unpermute<2, 512, 16, 6, 4, 4>) unp_fn;
-        static const unp_fn tab2[4] = {k_sw_unpermute<2, 512, 16, 6, 4, 4>, k_sw_unpermute<2, 512, 16, 5, 6, 4>, k_sw_unpermute<2, 1024, 8, 4, 4, 4>,
-                                       k_sw_unpermute<2, 1024, 8, 4, 6, 4>};
-        static const unp_fn tab1[4] = {k_sw_unpermute<1, 512, 16, 6, 4, 4>, k_sw_unpermute<1, 512, 16, 5, 6, 4>, k_sw_unpermute<1, 1024, 8, 4, 4, 4>,
-                                       k_sw_unpermute<1, 1024, 8, 4, 6, 4>};
-        const bool dma = unp_env < 0 || unp_env >= 4;
-        const unsigned kUT2 = (sh2 & 2) ? 1024u : 512u, kUT1 = (sh1 & 2) ? 1024u : 512u;
-        const unsigned ub2 = ub_env >= 1 ? (unsigned)ub_env : (dma ? 768u : ((sh2 & 2) ? 256u : 512u)),
-                       ub1b = ub_env >= 1 ? (unsigned)ub_env : (dma ? 768u : ((sh1 & 2) ? 256u : 512u));
-        if (dma)
-            hipLaunchKernelGGL((k_sw_unpermute_dma<2, 512, 16>), dim3(ub2), dim3(512), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart,
-                               b.segsum, b.ck2, b.tickets + 2, b.tdesc2, b.keys2, b.marked, b.slots2, b.thist2, b.keys1, (uint64_t *)nullptr);
-        else
-            hipLaunchKernelGGL(tab2[sh2 & 3], dim3(ub2), dim3(kUT2), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart, b.segsum, b.ck2,
-                               b.tickets + 2, b.keys2, b.marked, b.slots2, b.thist2, b.keys1, (uint64_t *)nullptr);
+        const unsigned ublocks = ub_env >= 1 ? (unsigned)ub_env : 768u;
+        hipLaunchKernelGGL((k_sw_unpermute_dma<2, 512, 16>), dim3(ublocks), dim3(512), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart,
+                           b.segsum, b.ck2, b.tickets + 2, b.tdesc2, b.keys2, b.marked, b.slots2, b.thist2, b.keys1, (uint64_t *)nullptr);
         pt.mark("unperm2");
-        if (dma)
-            hipLaunchKernelGGL((k_sw_unpermute_dma<1, 512, 16>), dim3(ub1b), dim3(512), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart,
-                               b.segsum, b.ck1, b.tickets + 3, (const uint64_t *)nullptr, b.keys1, b.marked, b.slots1, b.thist1, (uint32_t *)nullptr,
-                               d_out + done);
-        else
-            hipLaunchKernelGGL(tab1[sh1 & 3], dim3(ub1b), dim3(kUT1), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart, b.segsum, b.ck1,
-                               b.tickets + 3, b.keys1, b.marked, b.slots1, b.thist1, (uint32_t *)nullptr, d_out + done);
+        hipLaunchKernelGGL((k_sw_unpermute_dma<1, 512, 16>), dim3(ublocks), dim3(512), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart,
+                           b.segsum, b.ck1, b.tickets + 3, (const uint64_t *)nullptr, b.keys1, b.marked, b.slots1, b.thist1, (uint32_t *)nullptr,
+                           d_out + done);
         pt.mark("unperm1");
         if (op == 1)
-            sr_launch_select_fixup(v, bit, b.marked, idx, d_out + done, cnt, s);
+            sr_launch_select_fixup(v, bit, b.marked, idx, d_out + done, cnt, go, s);
         SH_HIP(hipGetLastError());
         if (trace_env)
             pt.report(g, "bucketed (write-combined)");
         if (trace_opt)
+        {
             pt.keep(op);
+            if (go)
+            { // (tracing only: the passes were skipped when the sample's verdict sent the batch to the direct kernel)
+                uint32_t verdict = 1;
+                SH_HIP(hipMemcpyAsync(&verdict, go, 4, hipMemcpyDeviceToHost, s));
+                SH_HIP(hipStreamSynchronize(s));
+                if (!verdict)
+                    bv_sorted_set_phases("");
+            }
+        }
         done += cnt;
     }
     return SDSL_HIP_OK;

@@ -113,3 +113,26 @@ def test_random_vectors_and_batches_for_ten_seconds(gpu):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_bucketed.py"), "10", "3"], capture_output=True, text=True,
                        timeout=240)
     assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("window_log2", [8, 20])
+def test_heavily_skewed_large_batch(gpu, window_log2):
+    """6 * 10^7 positions inside one line / inside three slices of a 2^30-bit vector, forced through the passes: every
+    histogram block then sends > 2 * 10^5 keys to one 16-bit slice counter, which must hand them on to its global row without
+    ever overflowing (the first form of that hand-over lost 65536 keys of a slice on exactly such a batch)."""
+    import torch
+    n_bits = (1 << 30) - 37
+    g = torch.Generator(device="cuda").manual_seed(11)
+    words = torch.randint(-2**63, 2**63 - 1, ((n_bits + 63) // 64,), device="cuda", dtype=torch.int64, generator=g)
+    bv = gpu.bit_vector(words, n_bits)
+    del words
+    idx = (n_bits // 3) + torch.randint(0, 1 << window_log2, (60_000_000,), device="cuda", dtype=torch.int64, generator=g)
+    try:
+        gpu.set_option("rank_sorted", 0)
+        want = bv.rank(idx, 1).clone()
+        gpu.set_option("rank_sorted", 1)
+        got = bv.rank(idx, 1)
+        assert torch.equal(got, want)
+    finally:
+        gpu.set_option("rank_sorted", -1)
+        bv.release_scratch()
