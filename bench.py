@@ -66,33 +66,62 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU time budget per cpu_baseline sample")
     p.add_argument("--backend", type=str, default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only "
                    "for exercising the multi-rank control flow on a single GPU)")
+    p.add_argument("--mode", type=str, default="ranks", choices=["ranks", "group"],
+                   help="ranks: one process per GPU (torch.distributed; --gpus N > 1 without WORLD_SIZE launches the ranks itself); "
+                        "group: ONE process drives all N GPUs through the C ABI's device group (sdsl_hip_group_*: RCCL broadcast at "
+                        "load time, scatter / kernels / gather per batch)")
+    p.add_argument("--text-file", type=str, default=None, help="a text for the wt / fm extras instead of the synthetic stand-in "
+                   "(e.g. Pizza&Chili english.1GB; the first --text-mib MiB are used, zero bytes are dropped)")
     return p.parse_args()
 
 
-def time_steps(fn, steps, warmup, barrier):
+def self_launch(a):
+    """--gpus N > 1 without a launcher: start the N ranks ourselves (torch.distributed.run on 127.0.0.1).  Never returns."""
+    import socket
+    if a.backend == "nccl" and torch.cuda.device_count() < a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} device(s) are visible\n")
+        sys.exit(2)
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def time_steps(fn, steps, warmup, barrier, per_step=None):
     """barrier + synchronize on both sides of exactly `steps` calls; HIP events on the launch stream
-    give the average kernel duration of the same region."""
+    give the average kernel duration of the same region (and, with `per_step`, every step's own duration: an event between
+    consecutive steps costs nothing — the stream is in order anyway)."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
+    ev[0].record()
+    for i in range(steps):
         fn()
-    e1.record()
+        ev[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     wall = time.perf_counter() - t0
-    return wall, e0.elapsed_time(e1) / steps
+    if per_step is not None:
+        per_step.extend(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    return wall, ev[0].elapsed_time(ev[steps]) / steps
+
+
+def spread_of(xs):
+    xs = sorted(xs)
+    return {"min": xs[0], "median": xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2]), "max": xs[-1]}
 
 
 def kernel_sources_sha():
     """sha256 over the kernel sources a PMC measurement is valid for."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("bv.hip", "bv_device.hpp", "bv_sorted.hip", "bits.hpp", "wt.hip", "wt_device.hpp", "fm.hip", "fm_device.hpp"):
+    for f in ("bv.hip", "bv_device.hpp", "bv_sorted.hip", "bv_sorted_dev.hpp", "bv_swc.hip", "bits.hpp", "wt.hip", "wt_device.hpp", "fm.hip",
+              "fm_device.hpp"):
         h.update(open(os.path.join(ROOT, "sdsl-lite_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -163,6 +192,59 @@ def box_facts(dev_index):
     return out
 
 
+def host_cpu_limits():
+    """What the container may really use: affinity mask, cgroup CPU quota (v2 cpu.max / v1 cfs quota), cpuset, NUMA nodes."""
+    out = {}
+    try:
+        out["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        out["affinity_cpus"] = os.cpu_count()
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        out["cgroup_cpu_max"] = f"{q} {per}"
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            out["cgroup_cfs_quota_us"] = q
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    for f in ("/sys/fs/cgroup/cpuset.cpus.effective", "/sys/fs/cgroup/cpuset/cpuset.effective_cpus"):
+        try:
+            out["cpuset_effective"] = open(f).read().strip()
+            break
+        except OSError:
+            pass
+    try:
+        out["numa_nodes"] = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except OSError:
+        out["numa_nodes"] = None
+    out["cgroup_quota_cpus"] = quota
+    out["effective_cpus"] = min(out["affinity_cpus"], quota) if quota else float(out["affinity_cpus"])
+    return out
+
+
+def set_mempolicy_interleave(on):
+    """MPOL_INTERLEAVE over all NUMA nodes for this thread's next allocations (off: back to the default policy); False if the
+    kernel refuses (no NUMA, no permission)."""
+    import ctypes
+    try:
+        nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+        if nodes < 2 and on:
+            return False
+        libc = ctypes.CDLL(None, use_errno=True)
+        mask = ctypes.c_ulong((1 << nodes) - 1)
+        r = libc.syscall(238, 3 if on else 0, ctypes.byref(mask) if on else None, nodes + 1 if on else 0)  # set_mempolicy
+        return r == 0
+    except Exception:
+        return False
+
+
 def cpu_baseline(pkg, words_dev, n_bits, idx_dev, gpu_out_dev, seconds):
     """The reference's CPU path on this host: real sdsl-lite (oracle/_ref, kind 'reference') if the
     prebuilt library travelled with the repo, else the C restatement (kind 'port').  One thread, scalar
@@ -206,18 +288,27 @@ def cpu_baseline(pkg, words_dev, n_bits, idx_dev, gpu_out_dev, seconds):
     }
     # the same loop on every host core: threads pinned one per logical CPU of the affinity mask, output pre-faulted,
     # released together, >= 10^7 queries per thread (several passes over its slice if the step has fewer), clock stopped
-    # when the slowest thread is done — thread creation and page faults are outside the measurement
+    # when the slowest thread is done — thread creation and page faults are outside the measurement.  What the box really
+    # grants is reported beside it: the cgroup's CPU quota (a container may see 256 CPUs and be allowed a few of them) and
+    # the NUMA placement of the index (interleaved over all nodes for this leg, so that no socket reads it remotely)
     try:
         threads = len(os.sched_getaffinity(0))
     except AttributeError:
         threads = os.cpu_count() or 1
+    limits = host_cpu_limits()
     n_m = int(min(idx_dev.numel(), threads * 10_000_000))
     reps = max(1, int(np.ceil(10_000_000 / max(1, n_m // threads))))
     sample = idx_dev[:n_m].cpu().numpy().view(np.uint64)
     outm = np.zeros(n_m, dtype=np.uint64)
     if kind == "reference":
-        dtm = ol.ref().L.ref_bv_rank_mt_timed(h, 1, sample.ctypes.data, n_m, outm.ctypes.data, threads, reps)
+        interleaved = set_mempolicy_interleave(True)
+        h2 = ol.ref().L.ref_bv_create(words_p.ctypes.data, n_bits) if interleaved else h
+        set_mempolicy_interleave(False)
+        dtm = ol.ref().L.ref_bv_rank_mt_timed(h2, 1, sample.ctypes.data, n_m, outm.ctypes.data, threads, reps)
+        if h2 is not h:
+            ol.ref().L.ref_bv_destroy(h2)
     else:
+        interleaved = False
         t0 = time.perf_counter()
         for _ in range(reps):
             ol.oracle().L.orc_rank_v5_batch_mt(h, sample.ctypes.data, n_m, outm.ctypes.data, threads)
@@ -232,8 +323,13 @@ def cpu_baseline(pkg, words_dev, n_bits, idx_dev, gpu_out_dev, seconds):
         smt = f"{len(sib.replace('-', ',').split(','))} hardware threads per core (cpu0 siblings: {sib})"
     except OSError:
         pass
+    eff = limits.get("effective_cpus")
     allc = {"value": n_m * reps / dtm / 1e9, "unit": "Grank/s", "cores": threads, "kind": kind, "cpu_model": model,
             "smt": smt, "pinned": True, "queries_per_thread": n_m * reps // threads,
+            "ns_per_query_per_thread": dtm / (n_m * reps / threads) * 1e9,
+            "host_limits": limits, "index_interleaved_over_numa_nodes": interleaved,
+            "note": (f"{threads} threads were started (one per CPU of the affinity mask) but the cgroup grants {eff:.1f} CPUs' worth of time: "
+                     "the figure is what this container may use, not what the machine can do") if eff and eff < 0.9 * threads else None,
             "sample": f"first {n_m} of the step's queries, contiguous slices, {threads} pinned threads, {reps} pass(es), "
                       f"output pre-faulted, timed from a common start to the slowest thread",
             "matches_gpu": bool(np.array_equal(outm, gpu_out_dev[:n_m].cpu().numpy().view(np.uint64)))}
@@ -288,8 +384,130 @@ def synthetic_text(n_bytes, seed, device):
     return out
 
 
+def group_leg(pkg, a, N, n_bits, nq, steps, warmup):
+    """ONE process, N GPUs, through the C ABI's device group (sdsl_hip_group_*, csrc/group.cpp) — the path a header-only C++ caller
+    has.  Both columns of SURVEY.md 8(e): resident shards (every device answers nq positions that already live in its HBM, no
+    collective) and a root-owned batch (device 0 holds all the positions: scatter -> kernels -> gather over RCCL in 8 pieces)."""
+    G = golden()
+    devs = list(range(N))
+    d0 = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    words = to_dev(pkg.set_random_bits(n_bits, 42), d0)
+    bv0 = pkg.bit_vector(words, n_bits, device=0, select1=False, select0=False)
+    del words
+    t0 = time.perf_counter()
+    grp = pkg.device_group(devs)
+    reps = grp.replicate(bv0)
+    for r in devs:
+        torch.cuda.synchronize(r)
+    repl_s = time.perf_counter() - t0
+    idx_d, out_d = [], []
+    for r in devs:
+        idx_d.append(to_dev(pkg.rnd_positions(7 + r, nq, n_bits + 1, 0), torch.device("cuda", r)))
+        out_d.append(torch.empty_like(idx_d[r]))
+
+    def step():
+        for r in devs:
+            torch.cuda.set_device(r)
+            reps[r].rank(idx_d[r], 1, out_d[r])
+
+    def sync_all():
+        for r in devs:
+            torch.cuda.synchronize(r)
+
+    for _ in range(warmup):
+        step()
+    sync_all()
+    ev = []
+    for r in devs:
+        torch.cuda.set_device(r)
+        ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+    t0 = time.perf_counter()
+    for r in devs:
+        torch.cuda.set_device(r)
+        ev[r][0].record()
+    for _ in range(steps):
+        step()
+    for r in devs:
+        torch.cuda.set_device(r)
+        ev[r][1].record()
+    sync_all()
+    wall = time.perf_counter() - t0
+    kernel_ms = max(ev[r][0].elapsed_time(ev[r][1]) for r in devs) / steps
+    ref_ok = None
+    if a.log_n == G.get("c2", {}).get("log_n") and nq >= G["c2"]["rank_1"]["n"]:
+        ref_ok = digest_matches(out_d[0], G["c2"]["rank_1"])
+    resident = {"Grank/s": nq * N * steps / wall / 1e9, "ms_per_step": wall / steps * 1e3, "kernel_ms": kernel_ms,
+                "reference_digest_match_device0": ref_ok}
+    # root-owned batch
+    torch.cuda.set_device(0)
+    del idx_d[1:], out_d[1:]
+    nro = min(nq, 250_000_000) * N
+    gq = torch.Generator(device=d0).manual_seed(1007)
+    allq = torch.randint(0, n_bits + 1, (nro,), device=d0, dtype=torch.int64, generator=gq)
+    ro = torch.empty_like(allq)
+    grp.rank(reps, allq, 1, ro, chunks=8)
+    sync_all()
+    t0 = time.perf_counter()
+    reps_ro = max(2, steps // 4)
+    for _ in range(reps_ro):
+        grp.rank(reps, allq, 1, ro, chunks=8)
+    sync_all()
+    dt = (time.perf_counter() - t0) / reps_ro
+    chk = bv0.rank(allq[:1_000_000].clone(), 1)
+    root = {"Grank/s": nro / dt / 1e9, "ms": dt * 1e3, "queries": nro, "pieces": 8, "bytes_over_links_per_query": 16,
+            "matches_single_gpu": bool(torch.equal(chk, ro[:1_000_000]))}
+    index_bytes = bv0.device_bytes()
+    del allq, ro, chk, idx_d, out_d
+    for o in reps[1:]:
+        o.close()
+    bv0.close()
+    grp.close()
+    for r in devs:
+        with torch.cuda.device(r):
+            torch.cuda.empty_cache()
+    return {"driver": "device group (one process, C ABI sdsl_hip_group_*)", "n_gpus": N, "replicate_s": repl_s,
+            "index_bytes_per_gpu": index_bytes,
+            "kernel_only_resident_shards_Grank/s": resident["Grank/s"], "resident_shards": resident,
+            "end_to_end_root_owned_batch_Grank/s": root["Grank/s"], "root_owned_batch": root}
+
+
+def main_group(a):
+    """--mode group: the whole line from one process driving N GPUs."""
+    N = a.gpus
+    if torch.cuda.device_count() < N:
+        sys.stderr.write(f"bench.py --mode group: --gpus {N} but only {torch.cuda.device_count()} device(s) are visible\n")
+        sys.exit(2)
+    pkg = importlib.import_module("sdsl-lite_amd")
+    n_bits, nq = 1 << a.log_n, int(a.queries)
+    cols = group_leg(pkg, a, N, n_bits, nq, a.steps, a.warmup)
+    kernel_ms = cols["resident_shards"]["kernel_ms"]
+    achieved = ALG_BYTES["rank"] * nq / (kernel_ms * 1e-3) / 1e9
+    result = {
+        "metric": "Grank/s, batched rank_1 on a 2^%d-bit vector" % a.log_n, "value": cols["kernel_only_resident_shards_Grank/s"],
+        "unit": "Grank/s", "n_gpus": N, "steps": a.steps, "warmup": a.warmup, "ms_per_step": cols["resident_shards"]["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "configs[1]: batched rank_1 on a 2^%d-bit random bit_vector (words = mt19937_64(42)), %d queries per step "
+                               "per GPU at mt19937_64(7 + device) %% (n + 1), index replicated by one RCCL broadcast per buffer, queries and "
+                               "results resident in each GPU's HBM" % (a.log_n, nq),
+                   "n_bits": n_bits, "queries_per_step_per_gpu": nq,
+                   "parallelism": "one process, device group of %d (sdsl_hip_group_*), replicated index, query shards" % N},
+        "reference_digest_match": cols["resident_shards"]["reference_digest_match_device0"],
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic("rank_bucketed_bytes_per_step"), "kernel": "bucketed batch rank, slowest device of the group",
+                     "kernel_ms": kernel_ms, "algorithmic_bytes_per_query": ALG_BYTES["rank"]},
+        "cpu_baseline": None,
+        "scaling_columns": cols,
+    }
+    print(json.dumps(result))
+
+
 def main():
     a = parse()
+    if a.mode == "group":
+        return main_group(a)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -301,6 +519,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            cpu_group = dist.new_group(backend="gloo")  # a rendezvous that keeps no kernel spinning on the waiting GPUs
 
             def barrier():
                 dist.barrier(device_ids=[local])
@@ -312,7 +531,9 @@ def main():
     else:
         def barrier():
             pass
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: the line would report a device count that was not asked for"
+    if a.backend == "nccl":
+        assert n_dev >= world, f"{world} ranks but {n_dev} visible device(s)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if a.backend == "nccl" else torch.device("cpu")
@@ -325,7 +546,7 @@ def main():
     t0 = time.perf_counter()
     words = to_dev(pkg.set_random_bits(n_bits, 42), dev)
     if a.extras is None:
-        a.extras = "select,rrr,sd,shapes,wt,fm" if world == 1 else "fm_sharded"
+        a.extras = "select,rrr,sd,shapes,wt,fm" if world == 1 else "fm_sharded,group"
     extras = [] if a.extras in ("", "none") else a.extras.split(",")
     bv = pkg.bit_vector(words, n_bits, device=local, select1="select" in extras, select0=False)
     index_bytes = bv.device_bytes()
@@ -336,7 +557,8 @@ def main():
 
     # the headline: whatever sdsl_hip_bv_rank_batch does with a device-resident batch by default (large batch over a
     # large vector: the bucketed path, bv_sorted.hip); the direct kernel (one rank line per query) is timed next to it
-    wall, kernel_ms = time_steps(lambda: bv.rank(idx, 1, out), a.steps, a.warmup, barrier)
+    step_ms = []
+    wall, kernel_ms = time_steps(lambda: bv.rank(idx, 1, out), a.steps, a.warmup, barrier, per_step=step_ms)
     if world > 1:
         wall = pkg.dist.max_over_ranks(wall, comm_dev)
         kernel_ms = pkg.dist.max_over_ranks(kernel_ms, comm_dev)
@@ -345,12 +567,19 @@ def main():
     ref_ok = None
     if rank == 0 and a.log_n == G.get("c2", {}).get("log_n") and nq >= G["c2"]["rank_1"]["n"]:
         ref_ok = digest_matches(out, G["c2"]["rank_1"]) and bv.ones() == G["c2"]["ones"]
+    # the passes of the step, one by one, over as many traced steps as were timed (tracing synchronises after every step, so
+    # these runs are not the timed ones)
     pkg.set_option("trace_phases", 1)
-    bv.rank(idx, 1, out)
-    torch.cuda.synchronize()
-    phases = pkg.last_phases()
+    traced = []
+    for _ in range(max(3, min(a.steps, 20))):
+        bv.rank(idx, 1, out)
+        torch.cuda.synchronize()
+        ph = pkg.last_phases()
+        ph.pop("select", None)
+        traced.append(ph)
     pkg.set_option("trace_phases", 0)
-    phases.pop("select", None)
+    phases = {k: spread_of([t[k] for t in traced if k in t])["median"] for k in traced[0]} if traced[0] else {}
+    phases_spread = {k: spread_of([t[k] for t in traced if k in t]) for k in traced[0]} if traced[0] else None
     bucketed = bool(phases)
     scratch_bytes = bv.device_bytes() - index_bytes
     # the direct kernel and its access skeleton (read a position, fetch its 64-byte rank line, write a word), same table,
@@ -375,10 +604,12 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic("rank_bucketed_bytes_per_step" if bucketed else "k_rank_bytes_per_launch"),
-                     "kernel": ("bucketed batch rank (bv_sorted.hip): k_sr_hist<1>, k_sr_partition<1>, k_sr_partition2_sweep, "
-                                "k_sr_rank_lds, k_sr_unpermute<2>, k_sr_unpermute<1> + 6 table kernels (and k_sr_sample_spread: the "
-                                "automatic dispatch looks at the batch first); kernel_ms = all of them, one step") if bucketed else "sdslhip::k_rank<4,false,true>",
-                     "kernel_ms": kernel_ms, "phases_ms": phases or None,
+                     "kernel": ("bucketed batch rank (bv_swc.hip + bv_sorted.hip): k_sr_sample_spread, k_sw_hist, k_sw_partition<1>, "
+                                "k_sw_partition<2>, k_sr_rank_lds, k_sw_unpermute_dma<2>, k_sw_unpermute_dma<1> + 7 table kernels and two "
+                                "memsets (and the direct kernel, which returns at once when the sample says 'spread'); kernel_ms = all of "
+                                "them, one step") if bucketed else "sdslhip::k_rank<4,false,true>",
+                     "kernel_ms": kernel_ms, "kernel_ms_per_step": spread_of(step_ms), "phases_ms": phases or None,
+                     "phases_ms_spread": phases_spread,
                      "algorithmic_bytes_per_query": ALG_BYTES["rank"],
                      "direct_kernel": {"kernel": "sdslhip::k_rank<4,false,true>", "kernel_ms": direct_ms,
                                        "Gq/s": nq / direct_ms / 1e6,
@@ -541,13 +772,21 @@ def main():
         if "wt" in extras or "fm" in extras:
             torch.cuda.empty_cache()
             nt = a.text_mib << 20
-            text_h = pkg.english_text(nt, 1234)
+            if a.text_file:
+                # a real corpus (Pizza&Chili english.1GB the day it is on the box): first --text-mib MiB, zero bytes dropped
+                # (SDSL's byte alphabet reserves 0 for the sentinel, construct.hpp:127-193)
+                raw = np.fromfile(a.text_file, dtype=np.uint8, count=nt)
+                text_h = np.ascontiguousarray(raw[raw != 0])
+                nt = int(text_h.size)
+                del raw
+            else:
+                text_h = pkg.english_text(nt, 1234)
             text = torch.from_numpy(text_h).to(dev)
             t0 = time.perf_counter()
             csa = pkg.csa_wt(text=text, device=local)
             build = time.perf_counter() - t0
             c4 = G.get("c4", {})
-            c4ok = rank == 0 and nt == (1 << c4.get("text_log", -1)) and "wt_rank" in c4
+            c4ok = rank == 0 and not a.text_file and nt == (1 << c4.get("text_log", -1)) and "wt_rank" in c4
             wt = csa.wavelet_tree
             lens = torch.from_numpy(wt.code_lengths().astype(np.int64)).to(dev)
             fsteps = torch.from_numpy(wt.fused_steps().astype(np.int64)).to(dev)
@@ -559,7 +798,7 @@ def main():
             hbar = float(lens[gc.long()].double().mean())
             cnt_b = np.bincount(text_h, minlength=256)
             p_b = cnt_b[cnt_b > 0] / nt
-            ex["text"] = {"bytes": nt, "kind": "English-class stand-in for Pizza&Chili english (sdsl_hip_util_english_text, seed 1234: Zipf "
+            ex["text"] = {"bytes": nt, "kind": ("file " + os.path.basename(a.text_file)) if a.text_file else "English-class stand-in for Pizza&Chili english (sdsl_hip_util_english_text, seed 1234: Zipf "
                                                "words over a 65536-word vocabulary, mixed case, digits, punctuation, rare Latin-1 / control "
                                                "bytes; integer-only, reproduced bit for bit in the build container)",
                           "sigma": csa.sigma(), "H0": float(-(p_b * np.log2(p_b)).sum()), "index_build_s": build,
@@ -813,9 +1052,25 @@ def main():
                                "n_gpus": world, "scaling": "strong (one batch of %d patterns split over the ranks)"
                                                            % ex["fm_count_sharded"]["patterns_total"],
                                "source": "extras.fm_count_sharded.resident_shards"}
+    if world > 1 and "group" in extras and a.backend == "nccl":
+        # the other driver of 8(e): rank 0 alone drives all the GPUs through the C ABI's device group while the other ranks (their
+        # memory released) wait at the barrier — both drivers' columns in one line
+        try:
+            import torch.distributed as dist
+            torch.cuda.empty_cache()
+            torch.cuda.synchronize()
+            dist.barrier(group=cpu_group)
+            if rank == 0:
+                ex["device_group"] = group_leg(pkg, a, world, n_bits, min(nq, 250_000_000), max(3, a.steps // 2), 1)
+                torch.cuda.set_device(local)
+            dist.barrier(group=cpu_group)
+        except Exception as e:
+            ex["device_group"] = {"error": f"{type(e).__name__}: {e}"}
+        result["extras"] = ex
     if world > 1 and "rank_root_owned_batch" in ex:
         # both columns of the multi-GPU report, side by side
         result["scaling_columns"] = {"kernel_only_resident_shards_Grank/s": value,
+                                     "device_group": ex.get("device_group"),
                                      "end_to_end_root_owned_batch_Grank/s": ex["rank_root_owned_batch"]["Grank/s"],
                                      "note": "resident shards: every rank answers its own HBM-resident shard, no collective in the "
                                              "timed region; root-owned: rank 0 holds the batch, scatter -> kernels -> gather over "

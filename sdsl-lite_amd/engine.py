@@ -727,3 +727,73 @@ class csa_wt(_Handle):
 def count(csa: csa_wt, patterns, m: int, out=None):
     """sdsl::count(csa, begin, end) over a batch of fixed-length patterns."""
     return csa.count(patterns, m, out)
+
+
+class device_group(_Handle):
+    """Several GPUs of one node driven by ONE process (SURVEY.md 8(e), C ABI sdsl_hip_group_*): the index is replicated with
+    one RCCL broadcast per buffer, a batch owned by the root device is scattered, answered by the single-GPU kernels and
+    gathered, in `chunks` pipelined pieces."""
+    _destroy = "sdsl_hip_group_destroy"
+
+    def __init__(self, devices):
+        super().__init__()
+        self.devices = list(devices)
+        arr = (C.c_int32 * len(self.devices))(*self.devices)
+        capi.check(capi.lib().sdsl_hip_group_create(arr, len(self.devices), C.byref(self._h)))
+
+    def __len__(self):
+        return len(self.devices)
+
+    def replicate(self, bv: bit_vector):
+        """[bv, replica on devices[1], ...]: the replicas are bit_vector objects that own their handles."""
+        n = len(self.devices)
+        reps = (C.c_void_p * n)()
+        capi.check(capi.lib().sdsl_hip_group_bv_replicate(self._h, bv._h, reps))
+        out = [bv]
+        for r in range(1, n):
+            o = bit_vector.__new__(bit_vector)
+            _Handle.__init__(o)
+            o._h = C.c_void_p(reps[r])
+            o.device = self.devices[r]
+            out.append(o)
+        return out
+
+    def _handles(self, objs):
+        return (C.c_void_p * len(objs))(*[o._h.value if isinstance(o._h, C.c_void_p) else o._h for o in objs])
+
+    def rank(self, replicas, idx, bit: int = 1, out=None, chunks: int = 8):
+        """The whole batch lives with the root (host memory, or devices[0]); answers come back in the caller's order."""
+        idx = _as_array(idx, np.uint64, "idx")
+        n = idx.numel() if _is_tensor(idx) else idx.size
+        out = _out_for(idx, n, np.uint64, out)
+        capi.check(capi.lib().sdsl_hip_group_bv_rank_batch(self._h, self._handles(replicas), bit, _ptr(idx), n, _ptr(out), chunks))
+        return out
+
+    def select(self, replicas, i, bit: int = 1, out=None, chunks: int = 8):
+        i = _as_array(i, np.uint64, "i")
+        n = i.numel() if _is_tensor(i) else i.size
+        out = _out_for(i, n, np.uint64, out)
+        capi.check(capi.lib().sdsl_hip_group_bv_select_batch(self._h, self._handles(replicas), bit, _ptr(i), n, _ptr(out), chunks))
+        return out
+
+    def csa_from_text(self, text, flags: int = 0):
+        """One csa_wt per device from one text (host memory or devices[0]): one broadcast, every device lays out its own."""
+        t = _bytes_arg(text, "text")
+        n = len(self.devices)
+        reps = (C.c_void_p * n)()
+        capi.check(capi.lib().sdsl_hip_group_fm_create_from_text(self._h, _ptr(t), t.numel() if _is_tensor(t) else t.size, flags, reps))
+        out = []
+        for r in range(n):
+            o = csa_wt.__new__(csa_wt)
+            _Handle.__init__(o)
+            o._h = C.c_void_p(reps[r])
+            o.device = self.devices[r]
+            out.append(o)
+        return out
+
+    def count(self, replicas, patterns, m: int, out=None, chunks: int = 4):
+        p = _bytes_arg(patterns, "patterns")
+        n = (p.numel() if _is_tensor(p) else p.size) // m
+        out = _out_for(p, n, np.uint64, out)
+        capi.check(capi.lib().sdsl_hip_group_fm_count_batch(self._h, self._handles(replicas), _ptr(p), m, n, _ptr(out), chunks))
+        return out
