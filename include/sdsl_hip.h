@@ -124,6 +124,10 @@ sdsl_hip_status sdsl_hip_bv_create(const uint64_t * words, uint64_t n_bits, int3
  * through to sdsl_hip_bv_create. */
 sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bits, int32_t device, uint32_t t_b,
                                            uint32_t t_pat_len, uint32_t flags, sdsl_hip_bv_t * out);
+/* Builds the select directories named in `flags` (SDSL_HIP_BV_SELECT1 / SELECT0) if the handle does not have them yet: what
+ * lets rank and select supports of one bit_vector share one device replica (select_support_mcl.hpp:95-117 holds no copy of
+ * the vector either; rank_support.hpp:33, select_support.hpp:35). */
+sdsl_hip_status sdsl_hip_bv_add_select(sdsl_hip_bv_t bv, uint32_t flags);
 /* The bytes SDSL's own serialize() writes for the vector and its supports (bit_vector: int_vector.hpp:1978-2004;
  * rank_support_v5: rank_support_v5.hpp:160-167; rank_support_v: rank_support_v.hpp:156-163; select_support_mcl:
  * select_support_mcl.hpp:474-518, including what its two construction paths leave behind).  For a pattern handle

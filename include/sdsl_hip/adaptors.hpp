@@ -6,22 +6,32 @@
 //
 //   sdsl::bit_vector bv = ...;
 //   sdsl::rank_support_v5_hip<1> rs(&bv);            // same constructor shape as rank_support_v5<1>
-//   rs(i);                                           // SDSL's scalar operator() — answered on the GPU
+//   rs(i);                                           // SDSL's scalar operator(): answered by the CALLER'S OWN rank_support_v5 over
+//                                                    //   the same bit_vector (built on first use) — a one-element launch is never
+//                                                    //   the right thing; ~40 ns as before the switch
 //   rs.rank_batch(idx, n, out);                      // the reason to switch: one launch for n queries
 //
 // Every class mirrors the reference interface it replaces (constructor from `bit_vector const*`,
 // rank/select/operator(), size(), set_vector, serialize/load writing and reading SDSL's OWN byte
 // format, ==/!=, nested typedefs) so that it satisfies the t_rank / t_select concepts
 // (rank_support_v5.hpp:44-200, select_support_mcl.hpp:64-117, rrr_vector.hpp:455-600).
-// There is no CPU path in here: scalar members are one-element batches.  Errors surface as
+// The batch members have no CPU path.  The scalar members of the supports of a plain bit_vector forward to the caller's SDSL
+// (the header includes it anyway: it is the caller's library, not this one's); those of the compressed / tree types, which
+// hold no host-side SDSL object, are one-element batches through a pinned mailbox (about 14 microseconds).  Supports of one
+// bit_vector share ONE device replica per device (ref-counted; select directories are added when a select support asks).
+// Errors surface as
 // std::runtime_error carrying sdsl_hip_last_error() (SDSL itself throws std::logic_error /
 // std::bad_alloc on its own failures, memory_management.hpp:907-910).
 #pragma once
 #include <cstdint>
+#include <map>
 #include <memory>
+#include <mutex>
+#include <iterator>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include <sdsl/bit_vectors.hpp>
@@ -56,14 +66,85 @@ struct bv_deleter
     }
 };
 typedef std::shared_ptr<sdsl_hip_bv_s> bv_ptr;
+//! 64-bit fingerprint of a bit_vector's content (four independent multiply-fold lanes: runs at memory bandwidth)
+inline uint64_t fingerprint(bit_vector const * v)
+{
+    uint64_t const * w = v->data();
+    const uint64_t n = (v->bit_size() + 63) >> 6;
+    uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    uint64_t i = 0;
+    for (; i + 4 <= n; i += 4)
+        for (int k = 0; k < 4; ++k)
+        {
+            h[k] = (h[k] ^ w[i + k]) * 0xFF51AFD7ED558CCDull;
+            h[k] ^= h[k] >> 29;
+        }
+    for (; i < n; ++i)
+        h[0] = ((h[0] ^ w[i]) * 0xFF51AFD7ED558CCDull) ^ (h[0] >> 31);
+    return (h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7)) + v->bit_size();
+}
+//! One device replica per (bit_vector object, device, pattern): SDSL's supports hold a non-owning pointer to the vector they
+//! support (rank_support.hpp:33, select_support.hpp:35) and three supports of one vector cost no copy of it; here they share
+//! one replica.  A replica is reused only while the vector's size AND content fingerprint are what they were when it was made
+//! (a support constructed after the vector was modified gets a fresh replica, as a fresh SDSL support would read the new bits).
+struct replica_registry
+{
+    struct entry
+    {
+        std::weak_ptr<sdsl_hip_bv_s> dev;
+        uint64_t bits = 0, print = 0;
+    };
+    std::mutex m;
+    std::map<std::tuple<void const *, int, unsigned>, entry> map;
+};
+inline replica_registry & replicas()
+{
+    static replica_registry r; // (inline function: one registry per program)
+    return r;
+}
 //! (t_b, t_pat_len) as SDSL's template arguments; two-bit patterns get their occurrence vector on the device
 inline bv_ptr make_device_bv(bit_vector const * v, int device, uint32_t flags, uint32_t t_b = 1, uint32_t t_pat_len = 1)
 {
+    const unsigned pat = t_pat_len == 2 ? 100u + t_b : 0u; // plain supports of both bit values share the replica
+    const uint64_t print = fingerprint(v);
+    replica_registry & R = replicas();
+    std::lock_guard<std::mutex> lock(R.m);
+    for (auto it = R.map.begin(); it != R.map.end();) // (replicas nobody holds any more leave the table)
+        it = it->second.dev.expired() ? R.map.erase(it) : std::next(it);
+    auto key = std::make_tuple((void const *)v, device, pat);
+    auto hit = R.map.find(key);
+    if (hit != R.map.end())
+        if (bv_ptr have = hit->second.dev.lock())
+            if (hit->second.bits == v->bit_size() and hit->second.print == print)
+            {
+                if (flags)
+                    check(sdsl_hip_bv_add_select(have.get(), flags), "sdsl_hip_bv_add_select");
+                return have;
+            }
     sdsl_hip_bv_t h = nullptr;
     check(sdsl_hip_bv_create_pattern(v->data(), v->bit_size(), device, t_b, t_pat_len, flags, &h),
           "sdsl_hip_bv_create_pattern");
-    return bv_ptr(h, bv_deleter());
+    bv_ptr made(h, bv_deleter());
+    replica_registry::entry e;
+    e.dev = made;
+    e.bits = v->bit_size();
+    e.print = print;
+    R.map[key] = e;
+    return made;
 }
+//! The caller's own SDSL support over the same vector, built when the first scalar query arrives (thread-safe; shared by
+//! copies of the adaptor, which support the same vector)
+template <class t_support>
+struct lazy_host_support
+{
+    std::once_flag once;
+    std::unique_ptr<t_support> s;
+    t_support const & get(bit_vector const * v)
+    {
+        std::call_once(once, [&] { s.reset(new t_support(v)); });
+        return *s;
+    }
+};
 constexpr bool pattern_ok(unsigned t_b, unsigned t_pat_len)
 {
     return (t_pat_len == 1 and t_b <= 1) or (t_pat_len == 2 and (t_b == 10 or t_b == 01 or t_b == 00 or t_b == 11));
@@ -108,8 +189,10 @@ public:
     };
 
 private:
+    typedef hip_detail::lazy_host_support<rank_support_v5<t_b, t_pat_len>> host_type;
     bit_vector const * m_v = nullptr;
     hip_detail::bv_ptr m_dev;
+    std::shared_ptr<host_type> m_host;
     int m_device = 0;
 
 public:
@@ -118,9 +201,16 @@ public:
         set_vector(v);
     }
     //! Number of t_b bits in [0, idx), idx in [0, size()]   (rank_support_v5.hpp:131-149)
-    //! One query = one kernel launch + one synchronisation (about 10 microseconds): fine for occasional calls, latency-bound in a
-    //! loop — use rank_batch there.
+    //! A scalar query is answered by the caller's own rank_support_v5 over the same vector, built when the first one arrives
+    //! (unmodified SDSL loops such as wt_pc's level walk keep their speed); batches go to the GPU.
     size_type rank(size_type idx) const
+    {
+        if (!m_v)
+            throw std::runtime_error("rank_support_v5_hip: no vector set");
+        return m_host->get(m_v).rank(idx);
+    }
+    //! the same query through the device (one launch + one synchronisation, about 14 microseconds): for checking the replica
+    size_type rank_on_device(size_type idx) const
     {
         if (!m_dev)
             throw std::runtime_error("rank_support_v5_hip: no vector set");
@@ -160,6 +250,12 @@ public:
     {
         m_v = v;
         m_dev = v ? hip_detail::make_device_bv(v, m_device, 0, t_b, t_pat_len) : hip_detail::bv_ptr();
+        m_host = std::make_shared<host_type>();
+    }
+    //! the device replica (shared with the other supports of the same vector on this device)
+    sdsl_hip_bv_t device_handle() const
+    {
+        return m_dev.get();
     }
     bool operator==(rank_support_v5_hip const & o) const noexcept
     {
@@ -222,8 +318,10 @@ public:
     };
 
 private:
+    typedef hip_detail::lazy_host_support<select_support_mcl<t_b, t_pat_len>> host_type;
     bit_vector const * m_v = nullptr;
     hip_detail::bv_ptr m_dev;
+    std::shared_ptr<host_type> m_host;
     int m_device = 0;
 
 public:
@@ -232,8 +330,15 @@ public:
         set_vector(v);
     }
     //! Position of the i-th t_b bit, i in [1, #t_b bits]   (select_support_mcl.hpp:384-439)
-    //! (one launch + one synchronisation per call: use select_batch in loops)
+    //! Scalar: the caller's own select_support_mcl over the same vector, built when the first scalar query arrives.
     size_type select(size_type i) const
+    {
+        if (!m_v)
+            throw std::runtime_error("select_support_mcl_hip: no vector set");
+        return m_host->get(m_v).select(i);
+    }
+    //! the same query through the device (one launch + one synchronisation)
+    size_type select_on_device(size_type i) const
     {
         if (!m_dev)
             throw std::runtime_error("select_support_mcl_hip: no vector set");
@@ -272,6 +377,11 @@ public:
         m_v = v;
         m_dev = v ? hip_detail::make_device_bv(v, m_device, dev_bit ? SDSL_HIP_BV_SELECT1 : SDSL_HIP_BV_SELECT0, t_b, t_pat_len)
                   : hip_detail::bv_ptr();
+        m_host = std::make_shared<host_type>();
+    }
+    sdsl_hip_bv_t device_handle() const
+    {
+        return m_dev.get();
     }
     bool operator==(select_support_mcl_hip const & o) const noexcept
     {

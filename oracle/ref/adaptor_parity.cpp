@@ -469,35 +469,110 @@ int main(int argc, char ** argv)
             sdsl_hip_sd_destroy(sh);
         }
     }
-    // what a scalar call costs: rs(i) one at a time against one batch call
+    // what a scalar call costs: rs(i) one at a time — answered by the caller's own rank_support_v5, built on
+    // first use — against the unmodified reference object and against one batch call
     {
-        bit_vector bv(1 << 24, 0);
+        bit_vector bv(1 << 28, 0);
         for (uint64_t i = 0; i < bv.size(); i += 3)
             bv[i] = 1;
         rank_support_v5_hip<1> hr(&bv);
         rank_support_v5<1> r1(&bv);
-        const size_t nq = 20000;
+        const size_t nq = 1000000;
         std::vector<uint64_t> q(nq), out(nq);
         for (auto & x : q)
             x = rng() % (bv.size() + 1);
-        (void)hr(q[0]);
+        (void)hr(q[0]); // (builds the host support)
         auto t0 = std::chrono::steady_clock::now();
         uint64_t sum = 0;
         for (size_t i = 0; i < nq; ++i)
             sum += hr(q[i]);
-        double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / nq;
+        double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq;
+        t0 = std::chrono::steady_clock::now();
+        uint64_t want = 0;
+        for (size_t i = 0; i < nq; ++i)
+            want += r1(q[i]);
+        double ns_ref = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq;
         t0 = std::chrono::steady_clock::now();
         hr.rank_batch(q.data(), nq, out.data());
-        double us_b = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / nq;
-        uint64_t want = 0, got_b = 0;
+        double ns_b = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq;
+        uint64_t got_b = 0;
         for (size_t i = 0; i < nq; ++i)
-        {
-            want += r1(q[i]);
             got_b += out[i];
-        }
         CHECK(sum == want && got_b == want, "scalar operator() loop and batch agree with rank_support_v5");
-        printf("scalar rs(i): %.2f us per call; the same %zu queries as one rank_batch from host arrays: %.4f us per query\n", us, nq,
-               us_b);
+        CHECK(ns < 2.0 * ns_ref + 20.0, "a scalar loop over the adaptor runs within 2x of the reference object");
+        uint64_t dsum = 0;
+        t0 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < 2000; ++i)
+            dsum += hr.rank_on_device(q[i]);
+        double us_dev = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 2000;
+        uint64_t dwant = 0;
+        for (size_t i = 0; i < 2000; ++i)
+            dwant += r1(q[i]);
+        CHECK(dsum == dwant, "rank_on_device");
+        printf("scalar rs(i), 10^6 calls on 2^28 bits: %.1f ns per call (rank_support_v5<1> itself: %.1f ns; through the device: %.2f us); "
+               "the same queries as one rank_batch from host arrays: %.2f ns per query\n", ns, ns_ref, us_dev, ns_b);
+        // supports of one vector share one device replica; a select support adds its directory to it
+        select_support_mcl_hip<1> hs1(&bv);
+        select_support_mcl_hip<0> hs0(&bv);
+        rank_support_v5_hip<0> hr0(&bv);
+        CHECK(hs1.device_handle() == hr.device_handle() && hs0.device_handle() == hr.device_handle() &&
+                  hr0.device_handle() == hr.device_handle(),
+              "rank and select supports of one bit_vector share one device replica");
+        select_support_mcl<1> s1(&bv);
+        select_support_mcl<0> s0(&bv);
+        std::vector<uint64_t> a(5000), o1(5000), o0(5000);
+        const uint64_t ones = r1(bv.size());
+        for (auto & x : a)
+            x = 1 + rng() % ones;
+        hs1.select_batch(a.data(), a.size(), o1.data());
+        bool ok = true;
+        for (size_t i = 0; i < a.size(); ++i)
+            ok &= o1[i] == s1(a[i]) && hs1(a[i]) == s1(a[i]);
+        for (auto & x : a)
+            x = 1 + rng() % (bv.size() - ones);
+        hs0.select_batch(a.data(), a.size(), o0.data());
+        for (size_t i = 0; i < a.size(); ++i)
+            ok &= o0[i] == s0(a[i]);
+        CHECK(ok, "select on the shared replica (directories added on demand)");
+        // a support made after the vector changed must not see the old replica
+        bv[1] = !bv[1];
+        rank_support_v5_hip<1> hr2(&bv);
+        rank_support_v5<1> r2(&bv);
+        CHECK(hr2.device_handle() != hr.device_handle(), "a modified vector gets a fresh replica");
+        uint64_t two[2] = {2, bv.size()}, got2[2];
+        hr2.rank_batch(two, 2, got2);
+        CHECK(got2[0] == r2(2) && got2[1] == r2(bv.size()) && hr2(2) == r2(2), "fresh replica answers for the modified vector");
+    }
+    // an UNMODIFIED SDSL container over the adaptors: wt_pc's level walk calls m_bv_rank(pos) once per level (wt_pc.hpp:371-399)
+    {
+        std::string text;
+        for (int i = 0; i < 400000; ++i)
+            text += (char)('a' + (rng() % 100 < 60 ? rng() % 4 : rng() % 26));
+        wt_huff<bit_vector, rank_support_v5_hip<1>, select_support_mcl_hip<1>, select_support_mcl_hip<0>> wth;
+        wt_huff<> wtr;
+        construct_im(wth, text, 1);
+        construct_im(wtr, text, 1);
+        bool ok = wth.size() == wtr.size();
+        auto t0 = std::chrono::steady_clock::now();
+        uint64_t acc = 0;
+        for (int i = 0; i < 200000; ++i)
+        {
+            uint64_t pos = rng() % (wtr.size() + 1);
+            unsigned char c = (unsigned char)text[rng() % text.size()];
+            acc += wth.rank(pos, c);
+            ok &= wth.rank(pos, c) == wtr.rank(pos, c);
+        }
+        double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / 400000;
+        for (int i = 0; i < 2000; ++i)
+        {
+            unsigned char c = (unsigned char)text[rng() % text.size()];
+            uint64_t occ = wtr.rank(wtr.size(), c);
+            uint64_t k = 1 + rng() % occ;
+            ok &= wth.select(k, c) == wtr.select(k, c) && wth[k % wtr.size()] == wtr[k % wtr.size()];
+        }
+        CHECK(ok, "wt_huff<bit_vector, rank_support_v5_hip, select_support_mcl_hip...> answers like wt_huff<>");
+        printf("unmodified wt_huff over the hip supports: %.0f ns per rank(i, c) (scalar path = the caller's SDSL)\n", ns);
+        (void)acc;
     }
     // several GPUs of one node (all the box has; a group of one still goes through the group driver and RCCL's setup)
     {

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sdsl_hip_group_fm_count_batch": (C.c_int32, [_vp, C.POINTER(_vp), _vp, C.c_uint32, C.c_uint64, _vp, C.c_int32]),
     "sdsl_hip_bv_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "sdsl_hip_bv_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_int32, C.c_uint32, C.POINTER(_vp)]),
+    "sdsl_hip_bv_add_select": (C.c_int32, [_vp, C.c_uint32]),
     "sdsl_hip_bv_create_pattern": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                C.POINTER(_vp)]),
     "sdsl_hip_bv_serialize": (C.c_int32, [_vp, C.c_int32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),

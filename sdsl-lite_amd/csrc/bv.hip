@@ -40,6 +40,19 @@ __global__ __launch_bounds__(256) void k_build_lines(const uint64_t * __restrict
     }
 }
 
+// ones per line, from the lines themselves (a select directory added after the build: sdsl_hip_bv_add_select)
+__global__ __launch_bounds__(256) void k_line_counts(const uint64_t * __restrict__ lines, uint64_t n_lines, uint32_t * __restrict__ cnts)
+{
+    for (uint64_t L = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; L < n_lines; L += (uint64_t)gridDim.x * blockDim.x)
+    {
+        uint32_t c = 0;
+#pragma unroll
+        for (int d = 0; d < kDW; ++d)
+            c += popc64(lines[L * kLW + 1 + d]);
+        cnts[L] = c;
+    }
+}
+
 constexpr int kScanPerThread = 8;
 constexpr int kScanPerBlock = 256 * kScanPerThread;
 
@@ -1137,6 +1150,39 @@ sdsl_hip_status sdsl_hip_bv_create_pattern(const uint64_t * words, uint64_t n_bi
                                            uint32_t t_pat_len, uint32_t flags, sdsl_hip_bv_t * out)
 {
     return guarded("bv_create_pattern", [&] { return sdsl_hip_bv_create_pattern_impl(words, n_bits, device, t_b, t_pat_len, flags, out); });
+}
+
+static sdsl_hip_status sdsl_hip_bv_add_select_impl(sdsl_hip_bv_t bv, uint32_t flags)
+{
+    if (!bv)
+    {
+        set_error("bv_add_select: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    BvHost & h = bv->h;
+    std::lock_guard<std::mutex> lock(h.scratch_mutex);
+    const bool need1 = (flags & SDSL_HIP_BV_SELECT1) && !h.view.sel[1], need0 = (flags & SDSL_HIP_BV_SELECT0) && !h.view.sel[0];
+    if (!need1 && !need0)
+        return SDSL_HIP_OK;
+    SH_HIP(hipSetDevice(h.device));
+    SH_TRY(h.cnts.alloc(h.view.n_lines * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_line_counts, dim3(grid_for(h.view.n_lines, 256, 65536)), dim3(256), 0, 0, h.view.lines, h.view.n_lines,
+                       h.cnts.as<uint32_t>());
+    sdsl_hip_status st = hipGetLastError() == hipSuccess ? SDSL_HIP_OK : SDSL_HIP_ERR_HIP;
+    if (st == SDSL_HIP_OK && need1)
+        st = build_select_dir(h, 1);
+    if (st == SDSL_HIP_OK && need0)
+        st = build_select_dir(h, 0);
+    if (hipDeviceSynchronize() != hipSuccess && st == SDSL_HIP_OK)
+        st = SDSL_HIP_ERR_HIP;
+    h.cnts.release();
+    return st;
+}
+// a select directory for a handle that was created without it (several supports of one vector share one device replica:
+// include/sdsl_hip/adaptors.hpp); queries already in flight are not disturbed — they cannot be select queries of that bit value
+sdsl_hip_status sdsl_hip_bv_add_select(sdsl_hip_bv_t bv, uint32_t flags)
+{
+    return guarded("bv_add_select", [&] { return sdsl_hip_bv_add_select_impl(bv, flags); });
 }
 
 static sdsl_hip_status sdsl_hip_bv_serialize_impl(sdsl_hip_bv_t bv, int32_t what, void * buf, size_t cap, size_t * written)

@@ -77,6 +77,13 @@ def main():
         si = pkg.rnd_positions(11, NQ, ones, 1)
         R.ref_bv_select(h, 1, si.ctypes.data, NQ, out.ctypes.data)
         c2.update(select_seed=11, select_1=digest(out))
+        # the other bit value (rank_support_v5<0>, select_support_mcl<0>): the same positions; arguments 1 + mt19937_64(12) % zeros
+        R.ref_bv_rank(h, 0, idx.ctypes.data, NQ, out.ctypes.data)
+        c2.update(rank_0=digest(out))
+        s0 = pkg.rnd_positions(12, NQ, n - ones, 1)
+        R.ref_bv_select(h, 0, s0.ctypes.data, NQ, out.ctypes.data)
+        c2.update(select0_seed=12, select_0=digest(out))
+        del s0
         R.ref_bv_destroy(h)
         res["c2"] = c2
         del words, idx, out, si

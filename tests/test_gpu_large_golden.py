@@ -55,6 +55,30 @@ def test_c2_rank_1_matches_reference_digests(gpu, c2_vector, mode):
 
 
 @pytest.mark.parametrize("mode", [0, 1], ids=["direct", "bucketed"])
+def test_c2_bit_value_0_matches_reference_digests(gpu, c2_vector, mode):
+    """rank_support_v5<0> and select_support_mcl<0> of the real library at 2^34 bits (b = 0 was only compared with the
+    direct kernel and through rank_1 + rank_0 == idx)."""
+    import torch
+    bv, n = c2_vector
+    c = G["c2"]
+    if "rank_0" not in c:
+        pytest.skip("golden_large.json predates the b = 0 digests")
+    idx = torch.from_numpy(gpu.rnd_positions(c["rank_seed"], c["rank_0"]["n"], n + 1, 0).view(np.int64)).cuda()
+    i0 = torch.from_numpy(gpu.rnd_positions(c["select0_seed"], c["select_0"]["n"], n - c["ones"], 1).view(np.int64)).cuda()
+    gpu.set_option("rank_sorted", mode)
+    gpu.set_option("select_sorted", mode)
+    try:
+        r0 = bv.rank(idx, 0)
+        s0 = bv.select(i0, 0)
+    finally:
+        gpu.set_option("rank_sorted", -1)
+        gpu.set_option("select_sorted", -1)
+    what = "bucketed" if mode else "direct"
+    check(r0.cpu().numpy(), c["rank_0"], f"configs[1] rank_0 ({what} path)")
+    check(s0.cpu().numpy(), c["select_0"], f"configs[1] select_0 ({what} path)")
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["direct", "bucketed"])
 def test_c2_select_1_matches_reference_digests(gpu, c2_vector, mode):
     import torch
     bv, n = c2_vector
