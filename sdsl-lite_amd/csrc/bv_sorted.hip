@@ -1706,6 +1706,11 @@ sdsl_hip_status bv_sorted_select_is_spread(const BvHost & h, int bit, const uint
     return sr_batch_is_spread(h.view, 1, sp, d_idx, n, s, (uint32_t *)scratch, spread);
 }
 
+void sr_launch_sample(const SrGeom & g, const uint64_t * d_idx, uint32_t * out3, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sr_sample_spread, dim3(1), dim3(1024), 0, s, g, d_idx, out3);
+}
+
 // The same sample without the read-back: the verdict (1: spread) lands in out3[2] and the routes enqueued behind it look at it
 // themselves (the passes of bv_swc.hip through SrGeom::go, the direct kernels through BvView::skip_if) — nothing synchronises.
 bool bv_sorted_device_verdict()

@@ -1,24 +1,14 @@
 // bv_sorted_dev.hpp — what the two bucketed pipelines (bv_sorted.hip: one-sweep look-back; bv_swc.hip: static streams with
 // write combining) share: key layout, digits, block scans.  DESIGN.md §3.5.
 #pragma once
+#include <functional>
 #include <string>
 
 #include "bv_host.hpp"
 
 namespace sdslhip {
-namespace {
 
-constexpr unsigned kRT = 512;            // threads of a rank block
-constexpr unsigned kBins = 256;          // bins per pass (8-bit digits)
-constexpr unsigned kSliceLog = 10;       // lines per slice (64 KiB)
-constexpr unsigned kOffBits = 9;         // 448 < 2^9 in-line offsets
-constexpr unsigned kKey2Bits = kSliceLog + kOffBits;
-constexpr uint32_t kBad = 0xFFFFFFFFu;   // key / answer of a position beyond the vector (answer NPOS)
-constexpr uint32_t kMark = 0xFFFFFFFEu;  // select: answer left to the fix-up pass (bucket wider than an LDS slice)
-constexpr uint64_t kMark64 = SDSL_HIP_NPOS - 1;
-constexpr unsigned kBigRun = 512;        // a (tile, bin) run longer than this is copied by the whole block
-constexpr unsigned kItemKeys = 32768;    // keys of one slice handled by one block before the slice is reloaded
-
+// geometry of one pass over a batch (a plain struct with external linkage: it crosses translation units)
 struct SrGeom
 {
     uint64_t n;      // positions in this pass over the batch (< 2^31)
@@ -35,8 +25,26 @@ struct SrGeom
     uint32_t binv;   // select: ceil(2^32 / m); floor(x / m) = (x * binv) >> 32 for x < 2^28
     uint64_t total;  // select: arguments of the vector (ones or zeros)
     bool small;      // 32-bit division path of line_of
+    uint64_t slice_bits; // bits of the vector a slice covers (rank_0: zeros in front of a slice = its first bit - ones in front)
+    uint32_t rbits;  // op 2 (rank on rrr records): bits per record; a key is [record in the slice : 8 | block : 6 | bit : 6]
+    uint32_t rlog;   // op 2: log2 of the records per slice (7 or 8)
     const uint32_t * go; // automatic dispatch: the passes return at once when this word is zero (nullptr: always run)
 };
+
+namespace {
+
+constexpr uint32_t kSrRecBits = 63 * 34;   // bits per record of the rrr_vector<63> device layout (rrr_device.hpp: kRecSB)
+constexpr unsigned kRT = 512;            // threads of a rank block
+constexpr unsigned kBins = 256;          // bins per pass (8-bit digits)
+constexpr unsigned kSliceLog = 10;       // lines per slice (64 KiB)
+constexpr unsigned kOffBits = 9;         // 448 < 2^9 in-line offsets
+constexpr unsigned kKey2Bits = kSliceLog + kOffBits;
+constexpr uint32_t kBad = 0xFFFFFFFFu;   // key / answer of a position beyond the vector (answer NPOS)
+constexpr uint32_t kMark = 0xFFFFFFFEu;  // select: answer left to the fix-up pass (bucket wider than an LDS slice)
+constexpr uint64_t kMark64 = SDSL_HIP_NPOS - 1;
+constexpr unsigned kBigRun = 512;        // a (tile, bin) run longer than this is copied by the whole block
+constexpr unsigned kItemKeys = 32768;    // keys of one slice handled by one block before the slice is reloaded
+
 
 struct SrBuf
 { // carved out of the scratch allocation
@@ -112,6 +120,23 @@ __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned
     {
         dig = 0;
         key = kBad;
+        return;
+    }
+    if (g.op == 2)
+    { // rank on an rrr_vector<63>'s records (rrr_sorted.hip): record, 63-bit block inside it, bit inside the block
+        // (the record length is a compile-time constant here: a 64-bit division by a run-time value costs more than the rest
+        // of the pass — 4.4 instead of 1.6 ms per 10^9 keys in the counting pass)
+        uint64_t rec = pos / kSrRecBits;
+        unsigned in_rec = (unsigned)(pos - rec * kSrRecBits);
+        if (in_rec == 0 && pos == g.n_bits && pos != 0)
+        { // rank(size()) when the vector ends with a record: "all 63 bits of its last block"
+            --rec;
+            in_rec = kSrRecBits;
+        }
+        const unsigned blk = in_rec == kSrRecBits ? kSrRecBits / 63 - 1 : in_rec / 63, off = in_rec - blk * 63; // off <= 63
+        const uint32_t sl = (uint32_t)(rec >> g.rlog);
+        dig = sl >> g.d2;
+        key = ((sl & ((1u << g.d2) - 1)) << g.kb) | (((uint32_t)rec & ((1u << g.rlog) - 1)) << 12) | (blk << 6) | off;
         return;
     }
     uint64_t L;
@@ -263,6 +288,7 @@ inline void sr_fill_geom(SrGeom & g, const BvView & v, int op, const SelectPlan 
         g.bs = 0;
         g.binv = 0;
         g.total = 0;
+        g.slice_bits = (UINT64_C(1) << kSliceLog) * kDB;
     }
     else
     {
@@ -278,6 +304,10 @@ inline void sr_fill_geom(SrGeom & g, const BvView & v, int op, const SelectPlan 
     g.d1 = f - g.d2;      // stretch of the vector and the answers of its keys fit 32 bits relative to the stretch's first one
     g.small = v.n_bits < (UINT64_C(1) << 38);
     g.go = nullptr;
+    g.rbits = 0;
+    g.rlog = 0;
+    if (op != 0)
+        g.slice_bits = 0;
 }
 
 sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const SelectPlan & sp, unsigned nf, unsigned d2, const uint32_t * fstart,
@@ -289,6 +319,20 @@ void sr_launch_select_fixup(const BvView & v, int bit, const uint32_t * marked, 
 size_t bv_swc_scratch_bytes(const BvView & v, uint64_t n);
 sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                        hipStream_t s, void * scratch, size_t scratch_bytes, const uint32_t * go);
+// the passes around any answering kernel: `fill` sets digits / key width / op of a pass over cnt positions (everything but the
+// tiling), `answers` enqueues the kernel(s) that answer the slices in place over the final keys and fill the per-slice bases,
+// `fixup` (may be empty) what runs on the caller's arrays afterwards
+struct SwCallbacks
+{
+    std::function<void(SrGeom &, uint64_t)> fill;
+    std::function<sdsl_hip_status(const SrGeom &, unsigned, const uint32_t *, const uint32_t *, uint32_t *, uint64_t *, uint32_t *, hipStream_t)> answers;
+    std::function<void(const uint32_t *, const uint64_t *, uint64_t *, uint64_t, hipStream_t)> fixup;
+    const char * what = "bucketed (write-combined)";
+};
+sdsl_hip_status sw_run_with(const SwCallbacks & cb, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out, hipStream_t s,
+                            void * scratch, size_t scratch_bytes, const uint32_t * go);
+// the spread sample on any geometry (out3[2] = verdict)
+void sr_launch_sample(const SrGeom & g, const uint64_t * d_idx, uint32_t * out3, hipStream_t s);
 
 // table kernels of bv_sorted.hip, launched on behalf of bv_swc.hip
 // offs[b][g] = keys of bins < b + keys of bin b in streams < g, from counts[b][g]; bstart = bin starts (bins + 1 entries)

@@ -615,7 +615,7 @@ __global__ __launch_bounds__(TT, 6) void k_sw_unpermute_dma(const uint64_t * __r
         const uint64_t h = hf[f];
         if (g.op == 1)
             return h;
-        return bit ? h : ((uint64_t)f << kSliceLog) * kDB - h;
+        return bit ? h : (uint64_t)f * g.slice_bits - h;
     };
     if (P == 1)
         for (unsigned i = t; i < kBins; i += TT)
@@ -808,6 +808,19 @@ size_t bv_swc_scratch_bytes(const BvView & v, uint64_t n)
 sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp, const uint64_t * d_idx, uint64_t n, uint64_t * d_out,
                        hipStream_t s, void * scratch, size_t scratch_bytes, const uint32_t * go)
 {
+    SwCallbacks cb;
+    cb.fill = [&](SrGeom & g, uint64_t cnt) { sr_fill_geom(g, v, op, sp, cnt); };
+    cb.answers = [&](const SrGeom & g, unsigned nf, const uint32_t * fstart, const uint32_t * ioff, uint32_t * keys2, uint64_t * hf,
+                     uint32_t * marked, hipStream_t st) { return sr_launch_answers(v, op, bit, sp, nf, g.d2, fstart, ioff, keys2, hf, marked, g.go, st); };
+    if (op == 1)
+        cb.fixup = [&](const uint32_t * marked, const uint64_t * idx, uint64_t * out, uint64_t cnt, hipStream_t st)
+        { sr_launch_select_fixup(v, bit, marked, idx, out, cnt, go, st); };
+    return sw_run_with(cb, bit, d_idx, n, d_out, s, scratch, scratch_bytes, go);
+}
+
+sdsl_hip_status sw_run_with(const SwCallbacks & cb, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out, hipStream_t s,
+                            void * scratch, size_t scratch_bytes, const uint32_t * go)
+{
     static const bool trace_env = getenv("SDSL_HIP_TRACE_SORTED") != nullptr;
     const bool trace_opt = g_trace_phases.load() != 0;
     const bool trace = trace_env || trace_opt;
@@ -819,7 +832,8 @@ sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp,
     {
         const uint64_t cnt = n - done < kSwMaxPass ? n - done : kSwMaxPass;
         SrGeom g;
-        sr_fill_geom(g, v, op, sp, cnt);
+        cb.fill(g, cnt);
+        const int op = (int)g.op;
         g.tile = kSwTile;
         g.tiles1 = (uint32_t)((cnt + g.tile - 1) / g.tile);
         g.G = 0;
@@ -877,7 +891,7 @@ sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         hipLaunchKernelGGL((k_sw_partition<2, kSwT, kSwPer>), dim3(pblocks), dim3(kSwT), 0, s, g, w, (const uint64_t *)nullptr, b.keys1, b.offs1,
                            b.in_lo, b.tp2, b.fstart, b.segsum, b.tickets + 1, b.keys2, b.slots2, b.thist2, b.ck2, b.tdesc2);
         pt.mark("part2");
-        SH_TRY(sr_launch_answers(v, op, bit, sp, w.nf, g.d2, b.fstart, b.ioff, b.keys2, b.hf, b.marked, go, s));
+        SH_TRY(cb.answers(g, w.nf, b.fstart, b.ioff, b.keys2, b.hf, b.marked, s));
         pt.mark("answer");
         const unsigned ublocks = ub_env >= 1 ? (unsigned)ub_env : 768u;
         hipLaunchKernelGGL((k_sw_unpermute_dma<2, 512, 16>), dim3(ublocks), dim3(512), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart,
@@ -887,11 +901,11 @@ sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp,
                            b.segsum, b.ck1, b.tickets + 3, (const uint64_t *)nullptr, b.keys1, b.marked, b.slots1, b.thist1, (uint32_t *)nullptr,
                            d_out + done);
         pt.mark("unperm1");
-        if (op == 1)
-            sr_launch_select_fixup(v, bit, b.marked, idx, d_out + done, cnt, go, s);
+        if (cb.fixup)
+            cb.fixup(b.marked, idx, d_out + done, cnt, s);
         SH_HIP(hipGetLastError());
         if (trace_env)
-            pt.report(g, "bucketed (write-combined)");
+            pt.report(g, cb.what);
         if (trace_opt)
         {
             pt.keep(op);

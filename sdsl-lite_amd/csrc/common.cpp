@@ -13,6 +13,7 @@ std::atomic<int> g_trace_phases{0};
 std::atomic<int> g_rrr_raw_budget{20}; // permille of the compressed size rrr_vector<63> may spend on raw classes (rrr.hip)
 std::atomic<int> g_select_sorted_mode{getenv("SDSL_HIP_SELECT_SORTED") ? atoi(getenv("SDSL_HIP_SELECT_SORTED")) : -1};
 std::atomic<int> g_rank_sorted_mode{getenv("SDSL_HIP_RANK_SORTED") ? atoi(getenv("SDSL_HIP_RANK_SORTED")) : -1};
+std::atomic<int> g_rrr_sorted_mode{getenv("SDSL_HIP_RRR_SORTED") ? atoi(getenv("SDSL_HIP_RRR_SORTED")) : -1};
 static thread_local bool g_timing_suppressed = false; // pipeline workers: the event pair is global
 static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static bool g_ev_valid = false;
@@ -260,6 +261,11 @@ sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value)
     if (name && !strcmp(name, "select_sorted"))
     {
         sdslhip::g_select_sorted_mode.store((int)value);
+        return SDSL_HIP_OK;
+    }
+    if (name && !strcmp(name, "rrr_sorted"))
+    {
+        sdslhip::g_rrr_sorted_mode.store((int)value);
         return SDSL_HIP_OK;
     }
     if (name && !strcmp(name, "rrr_raw_budget"))

@@ -23,6 +23,7 @@
 namespace sdslhip {
 
 extern std::atomic<int> g_rank_sorted_mode; // sdsl_hip_set_option("rank_sorted", ...)
+extern std::atomic<int> g_rrr_sorted_mode;  // sdsl_hip_set_option("rrr_sorted", ...)
 extern std::atomic<int> g_select_sorted_mode; // sdsl_hip_set_option("select_sorted", ...)
 extern std::atomic<int> g_trace_phases;     // sdsl_hip_set_option("trace_phases", ...)
 void bv_sorted_clear_phases();              // bv_sorted.hip

@@ -203,6 +203,8 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, cons
                                                         uint64_t n)
 {
     __shared__ RrrTables T;
+    if (v.skip_if && *v.skip_if)
+        return;
     rrr_stage_tables(&T, v.tables);
     for (uint64_t q = (uint64_t)blockIdx.x * kRrrBlock + threadIdx.x; q < n; q += (uint64_t)gridDim.x * kRrrBlock)
     {
@@ -1128,6 +1130,11 @@ sdsl_hip_status sdsl_hip_rrr_destroy(sdsl_hip_rrr_t v)
     if (!v)
         return SDSL_HIP_OK;
     (void)hipSetDevice(v->h.device);
+    if (v->h.scratch_ev)
+    {
+        (void)hipEventSynchronize(v->h.scratch_ev);
+        (void)hipEventDestroy(v->h.scratch_ev);
+    }
     delete v;
     return SDSL_HIP_OK;
 }
@@ -1176,6 +1183,60 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
     Staged in, o;
     SH_TRY(in.in(idx, n * 8, s));
     SH_TRY(o.out(out, n * 8));
+    // A large batch over a large vector that is spread over it goes through the passes of bv_swc.hip around the slice-wise
+    // decoder of rrr_sorted.hip (option "rrr_sorted": 0 never, 1 whenever possible, -1 automatic: the spread sample's verdict
+    // stays on the device, both routes are enqueued, the one whose turn it is not returns at once — as for the plain vector)
+    RrrHost & h = v->h;
+    const int mode = g_rrr_sorted_mode.load();
+    const bool want = mode == 0 ? false : (mode > 0 ? rrr_sorted_rank_possible(h.view) : rrr_sorted_rank_applicable(h.view, n));
+    if (want)
+    {
+        std::lock_guard<std::mutex> lock(h.scratch_mutex);
+        const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
+        const size_t need = bv_swc_scratch_bytes(BvView{}, pass);
+        if (h.scratch_ev)
+            SH_HIP(hipStreamWaitEvent(s, h.scratch_ev, 0));
+        bool have = h.sort_scratch.bytes >= need;
+        if (!have)
+        {
+            if (h.scratch_ev)
+                SH_HIP(hipEventSynchronize(h.scratch_ev));
+            h.sort_scratch.release();
+            have = h.sort_scratch.alloc(need) == SDSL_HIP_OK;
+        }
+        if (have && !h.spread_probe.p)
+            have = h.spread_probe.alloc(64) == SDSL_HIP_OK;
+        if (have)
+        {
+            if (!h.scratch_ev)
+                SH_HIP(hipEventCreateWithFlags(&h.scratch_ev, hipEventDisableTiming));
+            sdsl_hip_status st;
+            {
+                KernelTimer t(s);
+                const uint32_t * go = nullptr;
+                if (mode < 0)
+                {
+                    rrr_sorted_rank_sample(h.view, (const uint64_t *)in.dev, n, s, h.spread_probe.as<uint32_t>());
+                    go = h.spread_probe.as<uint32_t>() + 2;
+                }
+                st = rrr_launch_rank_sorted(h.view, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s, h.sort_scratch.p, h.sort_scratch.bytes, go);
+                if (st == SDSL_HIP_OK && go)
+                {
+                    RrrView dv = h.view;
+                    dv.skip_if = go;
+                    hipLaunchKernelGGL((k_rrr_rank<0>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, dv, bit, (const uint64_t *)in.dev,
+                                       (uint64_t *)o.dev, (uint8_t *)nullptr, n);
+                }
+            }
+            SH_HIP(hipEventRecord(h.scratch_ev, s));
+            SH_TRY(st);
+            SH_HIP(hipGetLastError());
+            SH_TRY(o.finish(s));
+            if (in.host && !o.host)
+                SH_HIP(hipStreamSynchronize(s));
+            return SDSL_HIP_OK;
+        }
+    }
     {
         KernelTimer t(s);
         hipLaunchKernelGGL((k_rrr_rank<0>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view, bit,

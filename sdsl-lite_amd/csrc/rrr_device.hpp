@@ -55,6 +55,9 @@ struct RrrView
     uint64_t n_bits, n_blocks, n_sb, ones;
     uint32_t sel_shift[2]; // log2 of the select sampling rate, per bit value (the rarer value gets the denser samples)
     uint32_t sel_pshift; // position quantisation of the samples (0 for n_bits < 2^32)
+    // automatic dispatch of large batches (rrr.hip): the direct rank kernel returns at once when this word is non-zero (the batch
+    // is then answered by the bucketed path enqueued beside it, rrr_sorted.hip); nullptr everywhere else
+    const uint32_t * skip_if;
 };
 
 // ---- device: block decoder -----------------------------------------------------------------------

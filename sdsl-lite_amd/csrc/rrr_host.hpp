@@ -1,5 +1,6 @@
 // rrr_host.hpp — host-side owner of a device rrr_vector<63> and its builders.
 #pragma once
+#include <mutex>
 #include "bv_host.hpp"
 #include "rrr_device.hpp"
 #include "sdsl_stream.hpp"
@@ -12,11 +13,21 @@ struct RrrHost
     RrrView view{};
     DevBuf rec, stream, tables, sel[2];
     unsigned sparse_max = 10; // classes sparse_max + 1 .. 62 - sparse_max are stored raw (rrr_device.hpp)
+    DevBuf sort_scratch, spread_probe; // working memory of the bucketed batch rank (rrr_sorted.hip), grown on demand
+    hipEvent_t scratch_ev = nullptr;   // recorded behind the last user of sort_scratch
+    std::mutex scratch_mutex;
     size_t device_bytes() const
     {
-        return rec.bytes + stream.bytes + tables.bytes + sel[0].bytes + sel[1].bytes;
+        return rec.bytes + stream.bytes + tables.bytes + sel[0].bytes + sel[1].bytes + sort_scratch.bytes + spread_probe.bytes;
     }
 };
+// large batches, bucketed by slice of the record array (rrr_sorted.hip)
+bool rrr_sorted_rank_possible(const RrrView & v);
+bool rrr_sorted_rank_applicable(const RrrView & v, uint64_t n);
+void rrr_sorted_rank_sample(const RrrView & v, const uint64_t * d_idx, uint64_t n, hipStream_t s, uint32_t * out3);
+size_t bv_swc_scratch_bytes(const BvView & v, uint64_t n); // (bv_swc.hip: the scratch of a pass depends on the batch only)
+sdsl_hip_status rrr_launch_rank_sorted(const RrrView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out, hipStream_t s,
+                                       void * scratch, size_t scratch_bytes, const uint32_t * go);
 
 // rrr_vector<63>(bit_vector const&) on the device: words (device memory) -> records, stream, directories
 sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t n_bits, int device);

@@ -1,0 +1,331 @@
+// rrr_sorted.hip — large batches of rank on rrr_vector<63>: the passes of bv_swc.hip around an answering kernel of its own.
+//
+// The direct kernel (rrr.hip, k_rrr_rank) fetches one 128-byte record per query and runs the block decoder once per query: on
+// 2^34 bits at 5 % density it sits at the part's random-fetch ceiling (33 G/s, 1.2 fabric requests per query,
+// profiles/bench_r03_pmc.md).  A batch that is partitioned by slice of the record array reads every record once — and, what
+// decides it here, DECODES EVERY BLOCK ONCE: a slice of 2^7 records (16 KiB, 4352 blocks) is turned into its plain 63-bit
+// blocks in LDS, and every key of the slice is then a table read and a popcount.  Round 2 tried the partition with the
+// decoder left per key and lost (decoder-bound: a wave pays for its lane with the most set bits, ~800 wave instructions per 64
+// keys, profiles/rrr_bucketed_rank_r02.txt).  Per slice the blocks are first sorted by class (a counting sort in LDS), so the
+// lanes of a wave decode blocks of ONE class: the decoder's cost is the mean class, not the maximum over 64 lanes.
+// Answers are rank_support_rrr<1,63>::rank's (rrr_vector.hpp:503-544); batching is this library's addition.
+#include <mutex>
+
+#include "bv_sorted_dev.hpp"
+#include "rrr_device.hpp"
+#include "rrr_host.hpp"
+
+namespace sdslhip {
+
+namespace {
+
+static_assert(kSrRecBits == kRecSB, "bv_sorted_dev.hpp: kSrRecBits must be the record length of rrr_device.hpp");
+constexpr unsigned kRsT = 1024;      // threads of an answering block
+constexpr unsigned kRsCols = 12;     // binomial columns the sparse decoder needs (classes <= 10 after the complement)
+constexpr unsigned kRsBins = 16;     // decode-cost classes of the per-slice counting sort
+
+struct RsLds
+{ // carved out of dynamic LDS; NB = blocks of a slice
+    uint64_t * raw;      // [NB] the slice's blocks, plain
+    uint64_t * cbin;     // [64][kRsCols]
+    uint64_t * top;      // [64]: C(63, k)
+    uint64_t * rptr;     // [S]: first word of the record's stretch of the overflow stream
+    uint32_t * rones;    // [S]: ones in front of the record, relative to the slice
+    uint16_t * pre;      // [NB] ones of the record in front of the block
+    uint16_t * obit;     // [NB] where the block's field starts in the record's offset bits
+    uint16_t * ord;      // [NB] blocks in order of decode cost
+    uint8_t * cls;       // [NB]
+    uint8_t * space;     // [64]
+    unsigned * cnt;      // [kRsBins + 1]
+};
+
+__device__ __forceinline__ RsLds rs_carve(unsigned char * base, unsigned S)
+{
+    const unsigned NB = S * kRecK;
+    RsLds L;
+    unsigned char * p = base;
+    auto take = [&](size_t bytes) -> unsigned char *
+    {
+        unsigned char * r = p;
+        p += (bytes + 15) & ~(size_t)15;
+        return r;
+    };
+    L.raw = (uint64_t *)take((size_t)NB * 8);
+    L.cbin = (uint64_t *)take(64 * kRsCols * 8);
+    L.top = (uint64_t *)take(64 * 8);
+    L.rptr = (uint64_t *)take((size_t)S * 8);
+    L.rones = (uint32_t *)take((size_t)S * 4);
+    L.pre = (uint16_t *)take((size_t)NB * 2);
+    L.obit = (uint16_t *)take((size_t)NB * 2);
+    L.ord = (uint16_t *)take((size_t)NB * 2);
+    L.cls = (uint8_t *)take(NB);
+    L.space = (uint8_t *)take(64);
+    L.cnt = (unsigned *)take((kRsBins + 1) * 4);
+    return L;
+}
+
+size_t rs_lds_bytes(unsigned S)
+{
+    const size_t NB = (size_t)S * kRecK;
+    auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    return up(NB * 8) + up(64 * kRsCols * 8) + up(64 * 8) + up((size_t)S * 8) + up((size_t)S * 4) + 3 * up(NB * 2) + up(NB) + up(64) + up((kRsBins + 1) * 4);
+}
+
+// the block of class k whose field holds f, with the compact tables (rrr_decode_block, rrr_device.hpp)
+__device__ __forceinline__ uint64_t rs_decode(const RsLds & L, unsigned k, uint64_t f)
+{
+    if (rrr_raw_width(L.space[k]))
+        return f;
+    const bool flip = k > 31;
+    unsigned kk = flip ? kRrrBS - k : k;
+    uint64_t nr = flip ? L.top[k] - 1 - f : f;
+    uint64_t bits = 0;
+    int hi = 62;
+    while (kk > 0)
+    { // largest m in [kk - 1, hi] with C(m, kk) <= nr
+        int lo = (int)kk - 1, h = hi;
+        while (lo < h)
+        {
+            const int mid = (lo + h + 1) >> 1;
+            if (L.cbin[mid * kRsCols + kk] <= nr)
+                lo = mid;
+            else
+                h = mid - 1;
+        }
+        bits |= UINT64_C(1) << (62 - lo);
+        nr -= L.cbin[lo * kRsCols + kk];
+        --kk;
+        hi = lo - 1;
+    }
+    if (flip)
+        bits = ~bits & lo_set(kRrrBS);
+    return bits;
+}
+
+// ones in front of every slice of records
+__global__ __launch_bounds__(256) void k_rs_slice_bases(RrrView v, unsigned nf, unsigned rlog, uint64_t * __restrict__ hf)
+{
+    const unsigned f = blockIdx.x * 256 + threadIdx.x;
+    if (f < nf)
+    {
+        const uint64_t r0 = (uint64_t)f << rlog;
+        hf[f] = r0 < v.n_sb ? v.rec[r0 * kRecWords] : 0;
+    }
+}
+
+// ---- rank out of LDS, in place over the final keys -------------------------------------------------------------------
+// key = [record in the slice : 8 | block in the record : 6 | bits of the block in front of the position : 6 (0..63)]
+__global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsigned nf, unsigned rlog, const uint32_t * __restrict__ fstart,
+                                                      const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys,
+                                                      const uint32_t * __restrict__ go)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];
+    __shared__ unsigned sh_f;
+    if (go && !*go)
+        return;
+    const unsigned S = 1u << rlog, t = threadIdx.x;
+    const RsLds L = rs_carve(rs_lds, S);
+    // the tables the decoder reads, once per block of threads
+    for (unsigned i = t; i < 64 * kRsCols; i += kRsT)
+        L.cbin[i] = v.tables->binom[i / kRsCols][i % kRsCols];
+    for (unsigned i = t; i < 64; i += kRsT)
+    {
+        L.top[i] = v.tables->binom[63][i];
+        L.space[i] = v.tables->space[i];
+    }
+    const unsigned n_items = ioff[nf];
+    for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x)
+    {
+        if (t == 0)
+        { // the slice of this item: last f with ioff[f] <= item
+            unsigned a = 0, z = nf;
+            while (a + 1 < z)
+            {
+                const unsigned m = (a + z) >> 1;
+                if (ioff[m] <= item)
+                    a = m;
+                else
+                    z = m;
+            }
+            sh_f = a;
+        }
+        for (unsigned i = t; i <= kRsBins; i += kRsT)
+            L.cnt[i] = 0;
+        __syncthreads(); // also: everybody is done with the previous slice
+        const unsigned f = __builtin_amdgcn_readfirstlane(sh_f);
+        const uint64_t R0 = (uint64_t)f << rlog;
+        const unsigned nrec = (unsigned)(v.n_sb - R0 < S ? v.n_sb - R0 : S), nb = nrec * kRecK;
+        const uint64_t * recs = v.rec + R0 * kRecWords;
+        const uint64_t lo = (uint64_t)fstart[f] + (uint64_t)(item - ioff[f]) * kItemKeys;
+        const uint64_t fend = fstart[f + 1];
+        const unsigned cnt = (unsigned)(lo + kItemKeys < fend ? kItemKeys : fend - lo);
+        const rsrc_t rs_k = make_rsrc(keys + uniform64(lo), __builtin_amdgcn_readfirstlane(cnt) * 4u);
+        constexpr int U = 4;
+        uint32_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            buf_load(rs_k, t * 4u, (unsigned)u * kRsT * 4u, key[u]); // (the first keys travel while the slice is decoded)
+        // 1. per (record, group of nine blocks): classes, ones and offset bits in front of every block
+        const uint64_t ones0 = recs[0];
+        for (unsigned x = t; x < nrec * 4; x += kRsT)
+        {
+            const unsigned r = x >> 2, gi = x & 3;
+            const uint64_t * rec = recs + (uint64_t)r * kRecWords;
+            const uint64_t P = rec[2], cw = rec[kRecClasses + gi];
+            unsigned ones, bits;
+            rrr_prefix(P, gi, ones, bits);
+            if (gi == 0)
+            {
+                L.rones[r] = (uint32_t)(rec[0] - ones0);
+                L.rptr[r] = rec[1] & ((UINT64_C(1) << 48) - 1);
+            }
+            const unsigned nblk = gi < 3 ? kGrp : kRecK - 3 * kGrp;
+            for (unsigned u = 0; u < nblk; ++u)
+            {
+                const unsigned k = rrr_cls(cw, u), b = r * kRecK + gi * kGrp + u, len = L.space[k];
+                L.cls[b] = (uint8_t)k;
+                L.pre[b] = (uint16_t)ones;
+                L.obit[b] = (uint16_t)bits;
+                ones += k;
+                bits += len;
+                // decode cost: nothing for the raw classes and for k = 0 / 63, else the set bits the decoder walks
+                const unsigned c = rrr_raw_width(len) ? 0u : (k > 31 ? kRrrBS - k : k);
+                atomicAdd(&L.cnt[c < kRsBins ? c : kRsBins - 1], 1u);
+            }
+        }
+        __syncthreads();
+        // 2. exclusive scan of the cost classes (sixteen values: one thread), then the order
+        if (t == 0)
+        {
+            unsigned run = 0;
+            for (unsigned c = 0; c < kRsBins; ++c)
+            {
+                const unsigned x = L.cnt[c];
+                L.cnt[c] = run;
+                run += x;
+            }
+        }
+        __syncthreads();
+        for (unsigned b = t; b < nb; b += kRsT)
+        {
+            const unsigned k = L.cls[b], len = L.space[k];
+            const unsigned c = rrr_raw_width(len) ? 0u : (k > 31 ? kRrrBS - k : k);
+            L.ord[atomicAdd(&L.cnt[c < kRsBins ? c : kRsBins - 1], 1u)] = (uint16_t)b;
+        }
+        __syncthreads();
+        // 3. every block decoded once; the lanes of a wave hold blocks of one cost class
+        for (unsigned i = t; i < nb; i += kRsT)
+        {
+            const unsigned b = L.ord[i], r = b / kRecK, k = L.cls[b], len = L.space[k];
+            const uint64_t fld = rrr_field(v, recs + (uint64_t)r * kRecWords, L.rptr[r], L.obit[b], len);
+            L.raw[b] = rs_decode(L, k, fld);
+        }
+        __syncthreads();
+        // 4. the keys
+        for (unsigned i0 = 0; i0 < cnt; i0 += kRsT * U)
+        {
+            uint32_t nk[U];
+            const unsigned n0 = (i0 + kRsT * U) * 4u;
+            if (i0 + kRsT * U < cnt)
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    buf_load(rs_k, t * 4u, n0 + (unsigned)u * kRsT * 4u, nk[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                const uint32_t kq = key[u];
+                uint32_t res = kBad;
+                if (kq != kBad)
+                {
+                    const unsigned r = (kq >> 12) & 255u, j = (kq >> 6) & 63u, o = kq & 63u, b = r * kRecK + j;
+                    const uint32_t r1 = L.rones[r] + L.pre[b] + popc64(L.raw[b] & lo_set(o));
+                    res = bit ? r1 : r * (uint32_t)kRecSB + j * kRrrBS + o - r1;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(res, rs_k, (int)(t * 4u), (int)(i0 * 4u + (unsigned)u * kRsT * 4u), kAuxNT);
+            }
+            if (i0 + kRsT * U < cnt)
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    key[u] = nk[u];
+            }
+        }
+    }
+}
+
+} // namespace
+
+// records per slice: 2^7 (two answering blocks per CU) while that keeps the slices within two 8-bit digits, else 2^8
+static unsigned rs_rlog(const RrrView & v)
+{
+    return ((v.n_sb + 127) >> 7) <= 65536 ? 7u : 8u;
+}
+
+bool rrr_sorted_rank_possible(const RrrView & v)
+{
+    return v.n_sb >= 2 && ((v.n_sb + 255) >> 8) <= 65536;
+}
+
+bool rrr_sorted_rank_applicable(const RrrView & v, uint64_t n)
+{
+    // worth it when the records exceed the Infinity Cache (2^21 records = 256 MiB) and the batch addresses every record a few
+    // times over (the passes cost about what twelve bytes of streaming per key cost, whatever the vector)
+    return rrr_sorted_rank_possible(v) && v.n_sb >= (UINT64_C(1) << 21) && n >= 8 * v.n_sb;
+}
+
+static void rs_fill(SrGeom & g, const RrrView & v, uint64_t cnt)
+{
+    g = SrGeom{};
+    g.n = cnt;
+    g.n_bits = v.n_bits;
+    g.n_lines = 0;
+    g.op = 2;
+    g.rbits = (uint32_t)kRecSB;
+    g.rlog = rs_rlog(v);
+    const uint64_t slices = (v.n_sb + (UINT64_C(1) << g.rlog) - 1) >> g.rlog;
+    unsigned f = 0;
+    while (((slices - 1) >> f) != 0)
+        ++f;
+    g.d2 = f < 8 ? f : 8;
+    g.d1 = f - g.d2;
+    g.kb = 20;
+    g.slice_bits = kRecSB << g.rlog;
+    g.small = false;
+    g.go = nullptr;
+}
+
+void rrr_sorted_rank_sample(const RrrView & v, const uint64_t * d_idx, uint64_t n, hipStream_t s, uint32_t * out3)
+{
+    SrGeom g;
+    rs_fill(g, v, n);
+    sr_launch_sample(g, d_idx, out3, s);
+}
+
+sdsl_hip_status rrr_launch_rank_sorted(const RrrView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out, hipStream_t s,
+                                       void * scratch, size_t scratch_bytes, const uint32_t * go)
+{
+    if (!rrr_sorted_rank_possible(v))
+    {
+        set_error("rrr rank_sorted: vector too large for the bucketed path");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    const unsigned rlog = rs_rlog(v);
+    const size_t lds = rs_lds_bytes(1u << rlog);
+    SH_HIP(hipFuncSetAttribute((const void *)k_rs_rank_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SwCallbacks cb;
+    cb.what = "bucketed rrr rank";
+    cb.fill = [&](SrGeom & g, uint64_t cnt) { rs_fill(g, v, cnt); };
+    cb.answers = [&](const SrGeom & g, unsigned nf, const uint32_t * fstart, const uint32_t * ioff, uint32_t * keys2, uint64_t * hf, uint32_t *,
+                     hipStream_t st) -> sdsl_hip_status
+    {
+        hipLaunchKernelGGL(k_rs_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, st, v, nf, rlog, hf);
+        hipLaunchKernelGGL(k_rs_rank_lds, dim3(rlog == 7 ? 512u : 256u), dim3(kRsT), lds, st, v, bit, nf, rlog, fstart, ioff, keys2, g.go);
+        SH_HIP(hipGetLastError());
+        return SDSL_HIP_OK;
+    };
+    return sw_run_with(cb, bit, d_idx, n, d_out, s, scratch, scratch_bytes, go);
+}
+
+} // namespace sdslhip

@@ -136,3 +136,24 @@ def test_heavily_skewed_large_batch(gpu, window_log2):
     finally:
         gpu.set_option("rank_sorted", -1)
         bv.release_scratch()
+
+
+@pytest.mark.parametrize("n_bits,d", [(1, 1.0), (2141, 0.3), (2142, 0.05), (2143, 0.5), (2142 * 128, 0.05), (2142 * 128 + 1, 0.95), (2142 * 128 * 3 + 5, 0.5),
+                                      (40_000_003, 0.05), (2142 * 128 * 300, 0.02)])
+def test_bucketed_rrr_rank_equals_direct(gpu, n_bits, d):
+    """rank on rrr_vector<63> through the passes and the slice-wise decoder (rrr_sorted.hip) against the direct kernel: vectors
+    that end inside / at the end of a record and of a slice, every density class (sparse decoder, complement, raw classes),
+    batches of every shape."""
+    w = words(n_bits, d, n_bits % 983)
+    rv = gpu.rrr_vector(w, n_bits)
+    rng = np.random.default_rng(n_bits + 3)
+    for name, idx in batches(n_bits, rng, 1_200_000):
+        for bit in (0, 1):
+            gpu.set_option("rrr_sorted", 0)
+            want = rv.rank(idx, bit)
+            try:
+                gpu.set_option("rrr_sorted", 1)
+                got = rv.rank(idx, bit)
+            finally:
+                gpu.set_option("rrr_sorted", -1)
+            assert np.array_equal(got, want), f"{name}, bit {bit}"
