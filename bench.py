@@ -688,10 +688,21 @@ def main():
             build = time.perf_counter() - t0
             w5h = w5h_all if (rank == 0 and world == 1 and not a.no_cpu) else None
             del w5, w5h_all
+            rrr_bytes = rv.device_bytes()
             _, ms = time_steps(lambda: rv.rank(idx, 1, out), max(2, a.steps // 2), 1, barrier)
             ex["rrr63_rank_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms, "build_s": build,
-                                  "bits_per_bit": rv.device_bytes() * 8 / n_bits,
+                                  "bits_per_bit": rrr_bytes * 8 / n_bits,
+                                  "path": "default dispatch (a spread batch of this size: the passes of bv_swc.hip around the slice-wise "
+                                          "decoder of rrr_sorted.hip)",
                                   "roofline_frac": ALG_BYTES["rrr"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            # the direct kernel (one record fetch and one block decode per query) beside it, same answers
+            pkg.set_option("rrr_sorted", 0)
+            out_d = torch.empty_like(out)
+            _, ms_d = time_steps(lambda: rv.rank(idx, 1, out_d), 2, 1, barrier)
+            pkg.set_option("rrr_sorted", -1)
+            ex["rrr63_rank_1"]["direct_kernel"] = {"Gq/s": nq / ms_d / 1e6, "kernel_ms": ms_d, "same_answers": bool(torch.equal(out, out_d)),
+                                                   "roofline_frac": ALG_BYTES["rrr"] * nq / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del out_d
             c3ok = a.log_n == c3.get("log_n") and nq >= c3.get("rank_1", {}).get("n", 1 << 62) and rank == 0
             if c3ok:
                 ex["rrr63_rank_1"]["reference_digest_match"] = digest_matches(out, c3["rank_1"]) and rv.ones() == c3["ones"]
@@ -699,6 +710,13 @@ def main():
             _, ms = time_steps(lambda: rv.select(si, 1, out), max(2, a.steps // 2), 1, barrier)
             ex["rrr63_select_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms,
                                     "roofline_frac": ALG_BYTES["rrr"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            pkg.set_option("rrr_sorted", 0)
+            out_d = torch.empty_like(out)
+            _, ms_d = time_steps(lambda: rv.select(si, 1, out_d), 2, 1, barrier)
+            pkg.set_option("rrr_sorted", -1)
+            ex["rrr63_select_1"]["direct_kernel"] = {"Gq/s": nq / ms_d / 1e6, "kernel_ms": ms_d, "same_answers": bool(torch.equal(out, out_d)),
+                                                     "roofline_frac": ALG_BYTES["rrr"] * nq / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del out_d
             if c3ok:
                 ex["rrr63_select_1"]["reference_digest_match"] = digest_matches(out, c3["select_1"])
             assert bool((rv.rank(out[: 1 << 20].clone(), 1) == si[: 1 << 20] - 1).all())

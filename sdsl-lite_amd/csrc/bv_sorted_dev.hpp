@@ -28,6 +28,8 @@ struct SrGeom
     uint64_t slice_bits; // bits of the vector a slice covers (rank_0: zeros in front of a slice = its first bit - ones in front)
     uint32_t rbits;  // op 2 (rank on rrr records): bits per record; a key is [record in the slice : 8 | block : 6 | bit : 6]
     uint32_t rlog;   // op 2: log2 of the records per slice (7 or 8)
+    uint32_t over_is_size; // op 1: an argument beyond the last one is not NPOS but size() (select_support_rrr, rrr_vector.hpp:641-642):
+                           // its key is kMark and the fix-up pass writes the answer
     const uint32_t * go; // automatic dispatch: the passes return at once when this word is zero (nullptr: always run)
 };
 
@@ -107,7 +109,7 @@ __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned
         if (pos == 0 || pos > g.total)
         {
             dig = 0;
-            key = kBad;
+            key = pos != 0 && g.over_is_size ? kMark : kBad;
             return;
         }
         const uint64_t k = pos - 1;
@@ -149,10 +151,10 @@ __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned
 // pass 2: digit and final key of a pass-1 key
 __device__ __forceinline__ void sr_key2(uint32_t k1, const SrGeom & g, unsigned & dig, uint32_t & key)
 {
-    if (k1 == kBad)
-    {
+    if (k1 >= kMark)
+    { // NPOS / left to the fix-up pass: travels with slice 0
         dig = 0;
-        key = kBad;
+        key = k1;
         return;
     }
     dig = k1 >> g.kb;
@@ -306,6 +308,7 @@ inline void sr_fill_geom(SrGeom & g, const BvView & v, int op, const SelectPlan 
     g.go = nullptr;
     g.rbits = 0;
     g.rlog = 0;
+    g.over_is_size = 0;
     if (op != 0)
         g.slice_bits = 0;
 }

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kHT) void k_sw_hist(SrGeom g, SwGeom w, const uint6
                 sr_key1(p[u], g, dig, key);
                 const bool on = q < khi;
                 atomicAdd(&uhist[on ? dig : kBins], 1u);
-                const unsigned fid = key == kBad ? 0u : (dig << g.d2) | (key >> g.kb);
+                const unsigned fid = key >= kMark ? 0u : (dig << g.d2) | (key >> g.kb);
                 const unsigned sh = (fid & 1u) << 4;
                 const uint32_t old = atomicAdd(&fine[on ? fid >> 1 : w.fine_words], on ? 1u << sh : 0u);
                 fidv[u] = on ? fid | (((old >> sh) & 0xFFFFu) << 16) : 0u;
@@ -901,6 +901,18 @@ sdsl_hip_status sw_run_with(const SwCallbacks & cb, int bit, const uint64_t * d_
                            b.segsum, b.ck1, b.tickets + 3, (const uint64_t *)nullptr, b.keys1, b.marked, b.slots1, b.thist1, (uint32_t *)nullptr,
                            d_out + done);
         pt.mark("unperm1");
+        if (dbg && cb.fixup)
+        { // how much is left to the fix-up pass
+            uint32_t mk = 0;
+            SH_HIP(hipStreamSynchronize(s));
+            SH_HIP(hipMemcpy(&mk, b.marked, 4, hipMemcpyDeviceToHost));
+            std::vector<uint64_t> ho(std::min<uint64_t>(cnt, 1 << 24));
+            SH_HIP(hipMemcpy(ho.data(), d_out + done, ho.size() * 8, hipMemcpyDeviceToHost));
+            uint64_t m = 0;
+            for (uint64_t x : ho)
+                m += x == kMark64;
+            fprintf(stderr, "[swc debug] any_marked=%u, %llu of the first %zu answers are left to the fix-up\n", mk, (unsigned long long)m, ho.size());
+        }
         if (cb.fixup)
             cb.fixup(b.marked, idx, d_out + done, cnt, s);
         SH_HIP(hipGetLastError());

@@ -269,6 +269,8 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select_flat(RrrView v, const 
                                                                uint64_t * __restrict__ out, uint64_t n)
 {
     __shared__ RrrTables T;
+    if (v.skip_if && *v.skip_if)
+        return;
     rrr_stage_tables(&T, v.tables);
     const uint64_t total = BIT ? v.ones : v.n_bits - v.ones;
     const uint32_t * __restrict__ smp = v.sel[BIT];
@@ -350,6 +352,8 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint6
                                                           uint64_t * __restrict__ out, uint64_t n)
 {
     __shared__ RrrTables T;
+    if (v.skip_if && *v.skip_if)
+        return;
     rrr_stage_tables(&T, v.tables);
     const uint64_t total = BIT ? v.ones : v.n_bits - v.ones;
     // Software pipeline over the lane's queries: a select is a chain of dependent accesses (argument -> directory
@@ -1303,6 +1307,23 @@ sdsl_hip_status sdsl_hip_rrr_get_int_batch(sdsl_hip_rrr_t v, const uint64_t * id
     return SDSL_HIP_OK;
 }
 
+} // extern "C"
+namespace sdslhip {
+sdsl_hip_status rrr_launch_select(const RrrView & v, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out, hipStream_t s)
+{
+    if (n == 0)
+        return SDSL_HIP_OK;
+    KernelTimer t(s);
+    if (bit)
+        hipLaunchKernelGGL(rrr_select_kernel<1>(), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v, d_i, d_out, n);
+    else
+        hipLaunchKernelGGL(rrr_select_kernel<0>(), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v, d_i, d_out, n);
+    SH_HIP(hipGetLastError());
+    return SDSL_HIP_OK;
+}
+} // namespace sdslhip
+extern "C" {
+
 sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const uint64_t * i, uint64_t n,
                                           uint64_t * out, void * stream)
 {
@@ -1334,15 +1355,63 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
     Staged in, o;
     SH_TRY(in.in(i, n * 8, s));
     SH_TRY(o.out(out, n * 8));
+    // large spread batches: the bucketed path (rrr_sorted.hip), chosen as for rank (option "rrr_sorted")
+    RrrHost & h = v->h;
+    const int mode = g_rrr_sorted_mode.load();
+    if (mode != 0 && h.view.sel[bit] && (mode > 0 || (h.view.n_sb >= (UINT64_C(1) << 21) && n >= 8 * h.view.n_sb)))
     {
-        KernelTimer t(s);
-        if (bit)
-            hipLaunchKernelGGL(rrr_select_kernel<1>(), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view,
-                               (const uint64_t *)in.dev, (uint64_t *)o.dev, n);
-        else
-            hipLaunchKernelGGL(rrr_select_kernel<0>(), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view,
-                               (const uint64_t *)in.dev, (uint64_t *)o.dev, n);
+        std::lock_guard<std::mutex> lock(h.scratch_mutex);
+        SH_TRY(rrr_select_sorted_prepare(h, bit)); // first use: the bucket boundaries (one small batch, synchronous)
+        const bool want = mode > 0 ? h.sel_plan[bit].ok : rrr_sorted_select_applicable(h, bit, n);
+        const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
+        const size_t need = bv_swc_scratch_bytes(BvView{}, pass);
+        bool have = want;
+        if (have)
+        {
+            if (h.scratch_ev)
+                SH_HIP(hipStreamWaitEvent(s, h.scratch_ev, 0));
+            if (h.sort_scratch.bytes < need)
+            {
+                if (h.scratch_ev)
+                    SH_HIP(hipEventSynchronize(h.scratch_ev));
+                h.sort_scratch.release();
+                have = h.sort_scratch.alloc(need) == SDSL_HIP_OK;
+            }
+            if (have && !h.spread_probe.p)
+                have = h.spread_probe.alloc(64) == SDSL_HIP_OK;
+        }
+        if (have)
+        {
+            if (!h.scratch_ev)
+                SH_HIP(hipEventCreateWithFlags(&h.scratch_ev, hipEventDisableTiming));
+            sdsl_hip_status st;
+            {
+                KernelTimer t(s);
+                const uint32_t * go = nullptr;
+                if (mode < 0)
+                {
+                    rrr_sorted_select_sample(h, bit, (const uint64_t *)in.dev, n, s, h.spread_probe.as<uint32_t>());
+                    go = h.spread_probe.as<uint32_t>() + 2;
+                }
+                st = rrr_launch_select_sorted(h, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s, h.sort_scratch.p, h.sort_scratch.bytes, go);
+                if (st == SDSL_HIP_OK && go)
+                {
+                    TimingPause pause;
+                    RrrView dv = h.view;
+                    dv.skip_if = go;
+                    st = rrr_launch_select(dv, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s);
+                }
+            }
+            SH_HIP(hipEventRecord(h.scratch_ev, s));
+            SH_TRY(st);
+            SH_HIP(hipGetLastError());
+            SH_TRY(o.finish(s));
+            if (in.host && !o.host)
+                SH_HIP(hipStreamSynchronize(s));
+            return SDSL_HIP_OK;
+        }
     }
+    SH_TRY(rrr_launch_select(v->h.view, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s));
     SH_HIP(hipGetLastError());
     SH_TRY(o.finish(s));
     if (in.host && !o.host)

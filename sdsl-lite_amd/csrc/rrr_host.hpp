@@ -14,6 +14,13 @@ struct RrrHost
     DevBuf rec, stream, tables, sel[2];
     unsigned sparse_max = 10; // classes sparse_max + 1 .. 62 - sparse_max are stored raw (rrr_device.hpp)
     DevBuf sort_scratch, spread_probe; // working memory of the bucketed batch rank (rrr_sorted.hip), grown on demand
+    struct SelPlan // buckets of the bucketed batch select (rrr_sorted.hip), built on first use
+    {
+        bool ready = false, ok = false;
+        DevBuf bnd;
+        unsigned bm = 8, bs = 3, nf = 0, rlog = 7; // buckets of bm << bs argument ranks; 2^rlog records per slice
+        double wide_frac = 0;
+    } sel_plan[2];
     hipEvent_t scratch_ev = nullptr;   // recorded behind the last user of sort_scratch
     std::mutex scratch_mutex;
     size_t device_bytes() const
@@ -25,6 +32,13 @@ struct RrrHost
 bool rrr_sorted_rank_possible(const RrrView & v);
 bool rrr_sorted_rank_applicable(const RrrView & v, uint64_t n);
 void rrr_sorted_rank_sample(const RrrView & v, const uint64_t * d_idx, uint64_t n, hipStream_t s, uint32_t * out3);
+sdsl_hip_status rrr_select_sorted_prepare(RrrHost & h, int bit);
+bool rrr_sorted_select_applicable(const RrrHost & h, int bit, uint64_t n);
+void rrr_sorted_select_sample(const RrrHost & h, int bit, const uint64_t * d_idx, uint64_t n, hipStream_t s, uint32_t * out3);
+sdsl_hip_status rrr_launch_select_sorted(RrrHost & h, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out, hipStream_t s, void * scratch,
+                                         size_t scratch_bytes, const uint32_t * go);
+// the direct select kernel on device arrays (rrr.hip)
+sdsl_hip_status rrr_launch_select(const RrrView & v, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out, hipStream_t s);
 size_t bv_swc_scratch_bytes(const BvView & v, uint64_t n); // (bv_swc.hip: the scratch of a pass depends on the batch only)
 sdsl_hip_status rrr_launch_rank_sorted(const RrrView & v, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out, hipStream_t s,
                                        void * scratch, size_t scratch_bytes, const uint32_t * go);

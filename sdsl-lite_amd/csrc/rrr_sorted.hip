@@ -102,6 +102,69 @@ __device__ __forceinline__ uint64_t rs_decode(const RsLds & L, unsigned k, uint6
     return bits;
 }
 
+// The records [recs, recs + nrec) as plain blocks in LDS: classes / ones / offset bits in front of every block, the blocks
+// in order of decode cost, every block decoded once.  All threads of the block; L.cnt must be zero on entry; ends with a barrier.
+__device__ __forceinline__ void rs_decode_records(const RsLds & L, const RrrView & v, const uint64_t * recs, unsigned nrec)
+{
+    const unsigned t = threadIdx.x, nb = nrec * kRecK;
+    // 1. per (record, group of nine blocks): classes, ones and offset bits in front of every block
+    const uint64_t ones0 = recs[0];
+    for (unsigned x = t; x < nrec * 4; x += kRsT)
+    {
+        const unsigned r = x >> 2, gi = x & 3;
+        const uint64_t * rec = recs + (uint64_t)r * kRecWords;
+        const uint64_t P = rec[2], cw = rec[kRecClasses + gi];
+        unsigned ones, bits;
+        rrr_prefix(P, gi, ones, bits);
+        if (gi == 0)
+        {
+            L.rones[r] = (uint32_t)(rec[0] - ones0);
+            L.rptr[r] = rec[1] & ((UINT64_C(1) << 48) - 1);
+        }
+        const unsigned nblk = gi < 3 ? kGrp : kRecK - 3 * kGrp;
+        for (unsigned u = 0; u < nblk; ++u)
+        {
+            const unsigned k = rrr_cls(cw, u), b = r * kRecK + gi * kGrp + u, len = L.space[k];
+            L.cls[b] = (uint8_t)k;
+            L.pre[b] = (uint16_t)ones;
+            L.obit[b] = (uint16_t)bits;
+            ones += k;
+            bits += len;
+            // decode cost: nothing for the raw classes and for k = 0 / 63, else the set bits the decoder walks
+            const unsigned c = rrr_raw_width(len) ? 0u : (k > 31 ? kRrrBS - k : k);
+            atomicAdd(&L.cnt[c < kRsBins ? c : kRsBins - 1], 1u);
+        }
+    }
+    __syncthreads();
+    // 2. exclusive scan of the cost classes (sixteen values: one thread), then the order
+    if (t == 0)
+    {
+        unsigned run = 0;
+        for (unsigned c = 0; c < kRsBins; ++c)
+        {
+            const unsigned x = L.cnt[c];
+            L.cnt[c] = run;
+            run += x;
+        }
+    }
+    __syncthreads();
+    for (unsigned b = t; b < nb; b += kRsT)
+    {
+        const unsigned k = L.cls[b], len = L.space[k];
+        const unsigned c = rrr_raw_width(len) ? 0u : (k > 31 ? kRrrBS - k : k);
+        L.ord[atomicAdd(&L.cnt[c < kRsBins ? c : kRsBins - 1], 1u)] = (uint16_t)b;
+    }
+    __syncthreads();
+    // 3. every block decoded once; the lanes of a wave hold blocks of one cost class
+    for (unsigned i = t; i < nb; i += kRsT)
+    {
+        const unsigned b = L.ord[i], r = b / kRecK, k = L.cls[b], len = L.space[k];
+        const uint64_t fld = rrr_field(v, recs + (uint64_t)r * kRecWords, L.rptr[r], L.obit[b], len);
+        L.raw[b] = rs_decode(L, k, fld);
+    }
+    __syncthreads();
+}
+
 // ones in front of every slice of records
 __global__ __launch_bounds__(256) void k_rs_slice_bases(RrrView v, unsigned nf, unsigned rlog, uint64_t * __restrict__ hf)
 {
@@ -165,62 +228,7 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
 #pragma unroll
         for (int u = 0; u < U; ++u)
             buf_load(rs_k, t * 4u, (unsigned)u * kRsT * 4u, key[u]); // (the first keys travel while the slice is decoded)
-        // 1. per (record, group of nine blocks): classes, ones and offset bits in front of every block
-        const uint64_t ones0 = recs[0];
-        for (unsigned x = t; x < nrec * 4; x += kRsT)
-        {
-            const unsigned r = x >> 2, gi = x & 3;
-            const uint64_t * rec = recs + (uint64_t)r * kRecWords;
-            const uint64_t P = rec[2], cw = rec[kRecClasses + gi];
-            unsigned ones, bits;
-            rrr_prefix(P, gi, ones, bits);
-            if (gi == 0)
-            {
-                L.rones[r] = (uint32_t)(rec[0] - ones0);
-                L.rptr[r] = rec[1] & ((UINT64_C(1) << 48) - 1);
-            }
-            const unsigned nblk = gi < 3 ? kGrp : kRecK - 3 * kGrp;
-            for (unsigned u = 0; u < nblk; ++u)
-            {
-                const unsigned k = rrr_cls(cw, u), b = r * kRecK + gi * kGrp + u, len = L.space[k];
-                L.cls[b] = (uint8_t)k;
-                L.pre[b] = (uint16_t)ones;
-                L.obit[b] = (uint16_t)bits;
-                ones += k;
-                bits += len;
-                // decode cost: nothing for the raw classes and for k = 0 / 63, else the set bits the decoder walks
-                const unsigned c = rrr_raw_width(len) ? 0u : (k > 31 ? kRrrBS - k : k);
-                atomicAdd(&L.cnt[c < kRsBins ? c : kRsBins - 1], 1u);
-            }
-        }
-        __syncthreads();
-        // 2. exclusive scan of the cost classes (sixteen values: one thread), then the order
-        if (t == 0)
-        {
-            unsigned run = 0;
-            for (unsigned c = 0; c < kRsBins; ++c)
-            {
-                const unsigned x = L.cnt[c];
-                L.cnt[c] = run;
-                run += x;
-            }
-        }
-        __syncthreads();
-        for (unsigned b = t; b < nb; b += kRsT)
-        {
-            const unsigned k = L.cls[b], len = L.space[k];
-            const unsigned c = rrr_raw_width(len) ? 0u : (k > 31 ? kRrrBS - k : k);
-            L.ord[atomicAdd(&L.cnt[c < kRsBins ? c : kRsBins - 1], 1u)] = (uint16_t)b;
-        }
-        __syncthreads();
-        // 3. every block decoded once; the lanes of a wave hold blocks of one cost class
-        for (unsigned i = t; i < nb; i += kRsT)
-        {
-            const unsigned b = L.ord[i], r = b / kRecK, k = L.cls[b], len = L.space[k];
-            const uint64_t fld = rrr_field(v, recs + (uint64_t)r * kRecWords, L.rptr[r], L.obit[b], len);
-            L.raw[b] = rs_decode(L, k, fld);
-        }
-        __syncthreads();
+        rs_decode_records(L, v, recs, nrec);
         // 4. the keys
         for (unsigned i0 = 0; i0 < cnt; i0 += kRsT * U)
         {
@@ -253,6 +261,179 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
             }
         }
     }
+}
+
+// ---- select out of LDS ----------------------------------------------------------------------------------------------------
+// Bucket f holds the arguments of rank [f * B, (f + 1) * B); select is monotone, so they live in the records bnd[f] .. bnd[f + 1]
+// — usually fewer than a slice's worth.  The records are decoded as for rank; a key is then two bisections over counts that
+// are already in LDS (records of the slice, blocks of the record) and sel64 inside the plain block.  A bucket that spans more
+// records than a slice holds (a sparse stretch) is left to the fix-up pass.  Answers: select_support_rrr<BIT,63>::select
+// (rrr_vector.hpp:639-726).
+template <int BIT>
+__global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, unsigned rlog, unsigned B, const uint32_t * __restrict__ bnd,
+                                                        const uint32_t * __restrict__ fstart, const uint32_t * __restrict__ ioff,
+                                                        uint32_t * __restrict__ keys, uint32_t * __restrict__ any_marked,
+                                                        const uint32_t * __restrict__ go)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];
+    __shared__ unsigned sh_f;
+    if (go && !*go)
+        return;
+    const unsigned S = 1u << rlog, t = threadIdx.x;
+    const RsLds L = rs_carve(rs_lds, S);
+    for (unsigned i = t; i < 64 * kRsCols; i += kRsT)
+        L.cbin[i] = v.tables->binom[i / kRsCols][i % kRsCols];
+    for (unsigned i = t; i < 64; i += kRsT)
+    {
+        L.top[i] = v.tables->binom[63][i];
+        L.space[i] = v.tables->space[i];
+    }
+    const unsigned n_items = ioff[nf];
+    for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x)
+    {
+        if (t == 0)
+        {
+            unsigned a = 0, z = nf;
+            while (a + 1 < z)
+            {
+                const unsigned m = (a + z) >> 1;
+                if (ioff[m] <= item)
+                    a = m;
+                else
+                    z = m;
+            }
+            sh_f = a;
+        }
+        for (unsigned i = t; i <= kRsBins; i += kRsT)
+            L.cnt[i] = 0;
+        __syncthreads();
+        const unsigned f = __builtin_amdgcn_readfirstlane(sh_f); // (tables in slice order: f is the bucket)
+        const uint64_t lo = (uint64_t)fstart[f] + (uint64_t)(item - ioff[f]) * kItemKeys;
+        const uint64_t fend = fstart[f + 1];
+        const unsigned cnt = (unsigned)(lo + kItemKeys < fend ? kItemKeys : fend - lo);
+        const uint64_t R0 = bnd[f];
+        const uint64_t R1 = (uint64_t)bnd[f + 1] + 1 < v.n_sb ? (uint64_t)bnd[f + 1] + 1 : v.n_sb;
+        if (R1 - R0 > S)
+        { // wider than a slice: the fix-up pass answers these
+            uint32_t * kp = keys + lo;
+            for (unsigned i = t; i < cnt; i += kRsT)
+                if (kp[i] != kBad)
+                    kp[i] = kMark;
+            if (t == 0)
+                *any_marked = 1;
+            __syncthreads();
+            continue;
+        }
+        const unsigned nrec = (unsigned)(R1 - R0);
+        const uint64_t * recs = v.rec + R0 * kRecWords;
+        const rsrc_t rs_k = make_rsrc(keys + uniform64(lo), __builtin_amdgcn_readfirstlane(cnt) * 4u);
+        constexpr int U = 4;
+        uint32_t key[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            buf_load(rs_k, t * 4u, (unsigned)u * kRsT * 4u, key[u]);
+        rs_decode_records(L, v, recs, nrec);
+        const uint64_t ones0 = recs[0];
+        const uint64_t A0 = BIT ? ones0 : R0 * kRecSB - ones0; // arguments in front of the slice
+        const unsigned t0 = (unsigned)((uint64_t)f * B - A0);   // rank of the bucket's first argument, relative to the slice
+        auto rargs = [&](unsigned r) -> unsigned { return BIT ? L.rones[r] : r * (unsigned)kRecSB - L.rones[r]; };
+        bool mk = false;
+        for (unsigned i0 = 0; i0 < cnt; i0 += kRsT * U)
+        {
+            uint32_t nk[U];
+            const unsigned n0 = (i0 + kRsT * U) * 4u;
+            if (i0 + kRsT * U < cnt)
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    buf_load(rs_k, t * 4u, n0 + (unsigned)u * kRsT * 4u, nk[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+            {
+                const uint32_t kq = key[u];
+                uint32_t res = kq; // (NPOS and "size()" keys travel on as they are)
+                mk |= kq == kMark;
+                if (kq < kMark)
+                {
+                    const unsigned tg = t0 + kq; // arguments of the slice in front of the wanted one
+                    unsigned a = 0, z = nrec;    // last record with rargs <= tg
+                    while (z - a > 1)
+                    {
+                        const unsigned m = (a + z) >> 1;
+                        if (rargs(m) <= tg)
+                            a = m;
+                        else
+                            z = m;
+                    }
+                    unsigned want = tg - rargs(a);
+                    const unsigned b0 = a * kRecK;
+                    unsigned ja = 0, jz = kRecK; // last block of the record with (arguments of the record in front of it) <= want
+                    while (jz - ja > 1)
+                    {
+                        const unsigned m = (ja + jz) >> 1;
+                        const unsigned in_front = BIT ? L.pre[b0 + m] : m * kRrrBS - L.pre[b0 + m];
+                        if (in_front <= want)
+                            ja = m;
+                        else
+                            jz = m;
+                    }
+                    want -= BIT ? L.pre[b0 + ja] : ja * kRrrBS - L.pre[b0 + ja];
+                    const uint64_t bits = BIT ? L.raw[b0 + ja] : ~L.raw[b0 + ja] & lo_set(kRrrBS);
+                    res = a * (uint32_t)kRecSB + ja * kRrrBS + sel64(bits, want + 1); // relative to the slice's first bit
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(res, rs_k, (int)(t * 4u), (int)(i0 * 4u + (unsigned)u * kRsT * 4u), kAuxNT);
+            }
+            if (i0 + kRsT * U < cnt)
+            {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    key[u] = nk[u];
+            }
+        }
+        if (mk)
+            *any_marked = 1;
+    }
+}
+
+// first bit of every bucket's first record (what makes a slice-relative position absolute)
+__global__ __launch_bounds__(256) void k_rs_select_bases(unsigned nf, unsigned n_buckets, const uint32_t * __restrict__ bnd, uint64_t * __restrict__ hf)
+{
+    const unsigned f = blockIdx.x * 256 + threadIdx.x;
+    if (f < nf)
+        hf[f] = f < n_buckets ? (uint64_t)bnd[f] * kRecSB : 0;
+}
+
+// the arguments that were left over (kMark64 in the output): the direct search, one lane per marked answer
+template <int BIT>
+__global__ __launch_bounds__(kRrrBlock) void k_rs_select_fixup(RrrView v, const uint32_t * __restrict__ any_marked, const uint64_t * __restrict__ iq,
+                                                               uint64_t * __restrict__ out, uint64_t n, const uint32_t * __restrict__ go)
+{
+    __shared__ RrrTables T;
+    if ((go && !*go) || !*any_marked)
+        return;
+    rrr_stage_tables(&T, v.tables);
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x)
+        if (out[q] == kMark64)
+        {
+            const uint64_t i = iq[q], total = BIT ? v.ones : v.n_bits - v.ones;
+            out[q] = i > total ? v.n_bits : rrr_select<BIT>(v, &T, i - 1); // (beyond the last argument: size(), rrr_vector.hpp:641-642)
+        }
+}
+
+__global__ __launch_bounds__(256) void k_rs_bnd_args(unsigned nf, unsigned B, uint64_t * __restrict__ out)
+{
+    const unsigned f = blockIdx.x * 256 + threadIdx.x;
+    if (f < nf)
+        out[f] = (uint64_t)f * B + 1; // 1-based rank of the bucket's first argument
+}
+__global__ __launch_bounds__(256) void k_rs_bnd_records(unsigned nf, const uint64_t * __restrict__ pos, uint64_t n_sb, uint32_t * __restrict__ bnd)
+{
+    const unsigned f = blockIdx.x * 256 + threadIdx.x;
+    if (f < nf)
+        bnd[f] = (uint32_t)(pos[f] / kRecSB);
+    if (f == nf)
+        bnd[nf] = (uint32_t)(n_sb - 1);
 }
 
 } // namespace
@@ -326,6 +507,153 @@ sdsl_hip_status rrr_launch_rank_sorted(const RrrView & v, int bit, const uint64_
         return SDSL_HIP_OK;
     };
     return sw_run_with(cb, bit, d_idx, n, d_out, s, scratch, scratch_bytes, go);
+}
+
+// Buckets of the bucketed select: B consecutive argument ranks each, at most 2^16 of them, sized so that a bucket of a uniformly
+// dense vector spans about 70 % of a slice's records; bnd[f] = record of the bucket's first argument (one small batch through the
+// direct kernel, once per handle and bit value).
+sdsl_hip_status rrr_select_sorted_prepare(RrrHost & h, int bit)
+{
+    RrrHost::SelPlan & P = h.sel_plan[bit];
+    if (P.ready)
+        return SDSL_HIP_OK;
+    const RrrView & v = h.view;
+    const uint64_t total = bit ? v.ones : v.n_bits - v.ones;
+    P.ok = false;
+    if (!v.sel[bit] || total < 2 || !rrr_sorted_rank_possible(v))
+    {
+        P.ready = true;
+        return SDSL_HIP_OK;
+    }
+    auto round_down = [](uint64_t x, unsigned & m, unsigned & sh) { // largest m << sh <= x (x >= 64), m in 8..15
+        sh = 0;
+        while ((x >> sh) > 15)
+            ++sh;
+        m = (unsigned)(x >> sh);
+    };
+    // records per slice: 2^7 (two answering blocks per CU) unless 2^16 buckets of that capacity cannot hold the arguments
+    const uint64_t b_min = (total + 65535) >> 16;
+    unsigned rlog = 7;
+    if (0.7 * 128 * (double)kRecSB * ((double)total / (double)v.n_bits) < 1.15 * (double)b_min)
+        rlog = 8;
+    P.rlog = rlog;
+    const unsigned S = 1u << rlog;
+    const double per = 0.7 * S * (double)kRecSB * ((double)total / (double)v.n_bits);
+    const uint64_t b_fit = per < 64.0 ? 64 : (per > 15.0 * 1048576.0 ? (uint64_t)15 << 20 : (uint64_t)per);
+    unsigned bm, bs;
+    round_down(b_fit, bm, bs);
+    if (((uint64_t)bm << bs) < b_min)
+    {
+        round_down(b_min < 64 ? 64 : b_min, bm, bs);
+        if (((uint64_t)bm << bs) < b_min && ++bm == 16)
+            bm = 8, ++bs;
+    }
+    if (bs > 20)
+    {
+        P.ready = true;
+        return SDSL_HIP_OK;
+    }
+    const uint64_t B = (uint64_t)bm << bs;
+    const unsigned nf = (unsigned)((total + B - 1) / B);
+    DevBuf args, pos;
+    if (args.alloc((size_t)nf * 8) != SDSL_HIP_OK || pos.alloc((size_t)nf * 8) != SDSL_HIP_OK || P.bnd.alloc(((size_t)nf + 1) * 4) != SDSL_HIP_OK)
+    {
+        P.bnd.release();
+        return SDSL_HIP_OK; // (no room right now: the query takes the direct kernel, the plan is tried again next time)
+    }
+    hipLaunchKernelGGL(k_rs_bnd_args, dim3((nf + 255) / 256), dim3(256), 0, 0, nf, (unsigned)B, args.as<uint64_t>());
+    SH_HIP(hipGetLastError());
+    {
+        TimingPause pause;
+        SH_TRY(rrr_launch_select(v, bit, args.as<uint64_t>(), nf, pos.as<uint64_t>(), nullptr));
+    }
+    hipLaunchKernelGGL(k_rs_bnd_records, dim3((nf + 256) / 256), dim3(256), 0, 0, nf, pos.as<uint64_t>(), v.n_sb, P.bnd.as<uint32_t>());
+    SH_HIP(hipGetLastError());
+    std::vector<uint32_t> hb((size_t)nf + 1);
+    SH_HIP(hipMemcpy(hb.data(), P.bnd.p, hb.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t wide = 0;
+    for (unsigned f = 0; f < nf; ++f)
+        if ((uint64_t)hb[f + 1] + 1 - hb[f] > S)
+            wide += std::min<uint64_t>(B, total - (uint64_t)f * B);
+    P.bm = bm;
+    P.bs = bs;
+    P.nf = nf;
+    P.wide_frac = (double)wide / (double)total;
+    P.ok = true;
+    P.ready = true;
+    return SDSL_HIP_OK;
+}
+
+bool rrr_sorted_select_applicable(const RrrHost & h, int bit, uint64_t n)
+{
+    const RrrHost::SelPlan & P = h.sel_plan[bit];
+    return P.ready && P.ok && P.wide_frac <= 0.01 && h.view.n_sb >= (UINT64_C(1) << 21) && n >= 8 * h.view.n_sb;
+}
+
+static void rs_fill_select(SrGeom & g, const RrrHost & h, int bit, uint64_t cnt)
+{
+    const RrrHost::SelPlan & P = h.sel_plan[bit];
+    SelectPlan sp;
+    sp.bnd = P.bnd.as<uint32_t>();
+    sp.bm = P.bm;
+    sp.bs = P.bs;
+    sp.nf = P.nf;
+    sp.total = bit ? h.view.ones : h.view.n_bits - h.view.ones;
+    BvView none{};
+    none.n_bits = h.view.n_bits;
+    none.n_lines = 2;
+    sr_fill_geom(g, none, 1, sp, cnt); // (select keys depend on the bucket plan only)
+    g.over_is_size = 1;
+}
+
+void rrr_sorted_select_sample(const RrrHost & h, int bit, const uint64_t * d_idx, uint64_t n, hipStream_t s, uint32_t * out3)
+{
+    SrGeom g;
+    rs_fill_select(g, h, bit, n);
+    sr_launch_sample(g, d_idx, out3, s);
+}
+
+sdsl_hip_status rrr_launch_select_sorted(RrrHost & h, int bit, const uint64_t * d_i, uint64_t n, uint64_t * d_out, hipStream_t s, void * scratch,
+                                         size_t scratch_bytes, const uint32_t * go)
+{
+    const RrrHost::SelPlan & P = h.sel_plan[bit];
+    if (!P.ready || !P.ok)
+    {
+        set_error("rrr select_sorted: no bucket plan for this vector");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    const RrrView & v = h.view;
+    const unsigned rlog = P.rlog;
+    const size_t lds = rs_lds_bytes(1u << rlog);
+    SH_HIP(hipFuncSetAttribute((const void *)k_rs_select_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SH_HIP(hipFuncSetAttribute((const void *)k_rs_select_lds<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t * bnd = P.bnd.as<uint32_t>();
+    const unsigned B = P.bm << P.bs, n_buckets = P.nf;
+    SwCallbacks cb;
+    cb.what = "bucketed rrr select";
+    cb.fill = [&](SrGeom & g, uint64_t cnt) { rs_fill_select(g, h, bit, cnt); };
+    cb.answers = [&](const SrGeom & g, unsigned nf, const uint32_t * fstart, const uint32_t * ioff, uint32_t * keys2, uint64_t * hf, uint32_t * marked,
+                     hipStream_t st) -> sdsl_hip_status
+    {
+        SH_HIP(hipMemsetAsync(marked, 0, 4, st));
+        hipLaunchKernelGGL(k_rs_select_bases, dim3((nf + 255) / 256), dim3(256), 0, st, nf, n_buckets, bnd, hf);
+        // (slices beyond the plan's buckets have no keys, so the kernel never reads bnd past n_buckets)
+        const dim3 grid(rlog == 7 ? 512u : 256u);
+        if (bit)
+            hipLaunchKernelGGL(k_rs_select_lds<1>, grid, dim3(kRsT), lds, st, v, nf, rlog, B, bnd, fstart, ioff, keys2, marked, g.go);
+        else
+            hipLaunchKernelGGL(k_rs_select_lds<0>, grid, dim3(kRsT), lds, st, v, nf, rlog, B, bnd, fstart, ioff, keys2, marked, g.go);
+        SH_HIP(hipGetLastError());
+        return SDSL_HIP_OK;
+    };
+    cb.fixup = [&](const uint32_t * marked, const uint64_t * idx, uint64_t * out, uint64_t cnt, hipStream_t st)
+    {
+        if (bit)
+            hipLaunchKernelGGL(k_rs_select_fixup<1>, dim3(256 * 4), dim3(kRrrBlock), 0, st, v, marked, idx, out, cnt, go);
+        else
+            hipLaunchKernelGGL(k_rs_select_fixup<0>, dim3(256 * 4), dim3(kRrrBlock), 0, st, v, marked, idx, out, cnt, go);
+    };
+    return sw_run_with(cb, bit, d_i, n, d_out, s, scratch, scratch_bytes, go);
 }
 
 } // namespace sdslhip

@@ -157,3 +157,31 @@ def test_bucketed_rrr_rank_equals_direct(gpu, n_bits, d):
             finally:
                 gpu.set_option("rrr_sorted", -1)
             assert np.array_equal(got, want), f"{name}, bit {bit}"
+
+
+@pytest.mark.parametrize("n_bits,d", [(2143, 0.5), (2142 * 128 + 1, 0.05), (2142 * 128 * 5 + 77, 0.5), (40_000_003, 0.05), (40_000_003, 0.97),
+                                      (2142 * 128 * 300, 0.003)])
+def test_bucketed_rrr_select_equals_direct(gpu, n_bits, d):
+    """select_1 / select_0 on rrr_vector<63> through the passes (buckets of argument ranks, records decoded slice-wise) against
+    the direct kernel; sparse vectors put buckets wider than a slice into the fix-up pass."""
+    w = words(n_bits, d, n_bits % 977)
+    rv = gpu.rrr_vector(w, n_bits)
+    rng = np.random.default_rng(n_bits + 5)
+    for bit in (0, 1):
+        total = rv.ones() if bit else n_bits - rv.ones()
+        if total < 2:
+            continue
+        cases = {"few": rng.integers(1, total + 1, 100, dtype=np.uint64),
+                 "uniform": rng.integers(1, total + 1, 700_000, dtype=np.uint64),
+                 "same": np.full(30_000, max(1, total // 2), dtype=np.uint64),
+                 "sorted": np.sort(rng.integers(1, total + 1, 150_000, dtype=np.uint64)),
+                 "out_of_range": np.concatenate([rng.integers(0, total + 3, 50_000, dtype=np.uint64), np.array([0, total, total + 1, 2 ** 64 - 1], dtype=np.uint64)])}
+        for name, i in cases.items():
+            gpu.set_option("rrr_sorted", 0)
+            want = rv.select(i, bit)
+            try:
+                gpu.set_option("rrr_sorted", 1)
+                got = rv.select(i, bit)
+            finally:
+                gpu.set_option("rrr_sorted", -1)
+            assert np.array_equal(got, want), f"{name}, bit {bit}"

@@ -38,6 +38,25 @@ for bit in (1, 0):
     if not same:
         bad = (res[(0, bit)] != res[(1, bit)]).nonzero().flatten()
         print("  mismatches", bad.numel(), bad[:5].tolist(), idx[bad[:5]].tolist(), res[(0, bit)][bad[:5]].tolist(), res[(1, bit)][bad[:5]].tolist())
+for bit in (1, 0):
+    tot = rv.ones() if bit else n - rv.ones()
+    si = torch.randint(1, tot + 1, (nq,), device=dev, dtype=torch.int64, generator=gw)
+    si[:5] = torch.tensor([1, tot, tot + 1, 0, 2], device=dev)
+    r = {}
+    for mode in (0, 1):
+        pkg.set_option("rrr_sorted", mode)
+        rv.select(si, bit, out); torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            rv.select(si, bit, out); ts.append(pkg.last_kernel_ms())
+        ms = min(ts)
+        r[mode] = out.clone()
+        print(f"mode {mode} select{bit}: {ms:.3f} ms {nq/ms/1e6:.2f} G/s frac {144*nq/ms/1e6/8000:.3f}", flush=True)
+    same = torch.equal(r[0], r[1])
+    print(f"select{bit}: bucketed == direct: {same}")
+    if not same:
+        bad = (r[0] != r[1]).nonzero().flatten()
+        print("  mismatches", bad.numel(), bad[:5].tolist(), si[bad[:5]].tolist(), r[0][bad[:5]].tolist(), r[1][bad[:5]].tolist())
 pkg.set_option("rrr_sorted", -1)
 rv.rank(idx, 1, out); torch.cuda.synchronize()
 ts = []
