@@ -890,14 +890,19 @@ def main():
                 m = 20
                 st = to_dev(pkg.rnd_positions(15, nq2, nt - m, 0), dev)  # 8(d): patterns cut at mt19937_64(15) % (n - m)
                 pats = text[(st.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()
-                _, ms = time_steps(lambda: csa.count(pats, m, out2), max(2, a.steps // 2), 1, barrier)
+                fm_steps = []
+                _, ms = time_steps(lambda: csa.count(pats, m, out2), max(6, a.steps // 2), 1, barrier, per_step=fm_steps)
                 sum_l = float(lens[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
                 alg = 28 + 160 * sum_l
                 sum_steps = float(fsteps[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
                 assert bool((out2 >= 1).all()), "every pattern was cut from the text"
                 lf = (28 + 256 * sum_steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 rf, how = fused_frac("k_fm_count_bytes_per_pattern", nq2, ms, lf)
-                ex["fm_count"] = {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "patterns": nq2, "m": m,
+                ex["fm_count"] = {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "kernel_ms_per_batch": spread_of(fm_steps),
+                                  "spread": (max(fm_steps) - min(fm_steps)) / ms, "patterns": nq2, "m": m,
+                                  "path": ("search until one suffix is left, then the remaining characters are compared with the text at "
+                                           "SA[l] (k_fm_count<verify> + k_fm_verify: the whole suffix array and the text are resident)")
+                                  if os.environ.get("SDSL_HIP_FM_VERIFY", "1") != "0" else "every character walked (SDSL_HIP_FM_VERIFY=0)",
                                   "reference_digest_match": digest_matches(out2, c4["count"])
                                   if c4ok and nq2 >= c4["count"]["n"] else None,
                                   "fused_steps_per_pattern": sum_steps,

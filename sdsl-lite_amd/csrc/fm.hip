@@ -36,13 +36,25 @@ __global__ __launch_bounds__(256) void k_fm_keys(const uint8_t * __restrict__ pa
 // character the quad is at — so the 16 quads of a wave do not wait for each other at character boundaries (Huffman
 // paths differ in length; a nested loop would cost max(len) instead of len per character).  The next pattern byte is
 // fetched one character ahead.
-template <bool NT, bool WANT_IVAL, bool FUSED>
+static bool fm_verify_enabled()
+{ // SDSL_HIP_FM_VERIFY=0: count() walks every character of every pattern (the round-2 behaviour, for A/B)
+    static const bool on = !(getenv("SDSL_HIP_FM_VERIFY") && atoi(getenv("SDSL_HIP_FM_VERIFY")) == 0);
+    return on;
+}
+
+// VERIFY (count only, index created from a text that is still resident with its whole suffix array): once the interval is ONE
+// suffix the rest of the pattern can only occur right in front of that suffix in the text — SA[l] says where, and the remaining
+// characters are compared with the text there: two fetches instead of one or two per remaining character (the late steps are
+// the random ones: 25.6 fabric requests per 20-byte pattern without it).  The answer is the same number: 1 if the characters
+// match, else 0 — what the remaining LF steps would have found.
+template <bool NT, bool WANT_IVAL, bool FUSED, bool VERIFY = false>
 __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables * __restrict__ ftab, FmJump J,
                                                      uint64_t csa_size, const uint8_t * __restrict__ pats,
                                                      uint32_t m, const uint64_t * __restrict__ offsets,
                                                      const uint32_t * __restrict__ order, uint64_t n_pat,
                                                      uint64_t * __restrict__ out_cnt, uint64_t * __restrict__ out_l,
-                                                     uint64_t * __restrict__ out_r)
+                                                     uint64_t * __restrict__ out_r, const uint32_t * __restrict__ sa = nullptr,
+                                                     const uint8_t * __restrict__ text = nullptr)
 {
     __shared__ WtTables T;
     __shared__ FmTables F;
@@ -74,12 +86,18 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
         // state of the character being processed
         unsigned left = 0, v = 0;
         uint64_t a = 0, b = 0, p = 0, cb = 0;
+        bool pending = false; // VERIFY: the search stopped at a single suffix with characters left (see k_fm_verify)
         for (;;)
         {
             if (left == 0)
             { // next character (suffix_array_algorithm.hpp:176-200)
                 if (!(it > begin && r + 1 - l > 0))
                     break;
+                if (VERIFY && !WANT_IVAL && l == r && it > begin + 1)
+                { // one suffix left and at least two characters to go: k_fm_verify compares them with the text
+                    pending = true;
+                    break;
+                }
                 --it;
                 const unsigned c = c_next;
                 if (it > begin)
@@ -136,9 +154,35 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
                 out_l[q] = l;
                 out_r[q] = r;
             }
-            else
-                out_cnt[q] = r + 1 - l;
+            else // (pending: [1 : 1 | characters left : 31 | the suffix : 32] — the fused layout is for < 2^32 symbols)
+                out_cnt[q] = VERIFY && pending ? (UINT64_C(1) << 63) | ((uint64_t)(it - begin) << 32) | l : r + 1 - l;
         }
+    }
+}
+
+// count() of the patterns whose search stopped at a single suffix: the suffix stands at SA[l] in the text, so the pattern's
+// remaining characters pats[begin .. begin + rem) occur there or nowhere.  One lane per pattern.
+__global__ __launch_bounds__(256) void k_fm_verify(const uint32_t * __restrict__ sa, const uint8_t * __restrict__ text,
+                                                   const uint8_t * __restrict__ pats, uint32_t m, const uint64_t * __restrict__ offsets,
+                                                   uint64_t n_pat, uint64_t * __restrict__ out_cnt)
+{
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_pat; q += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t v = out_cnt[q];
+        if (!(v >> 63))
+            continue;
+        const uint32_t l = (uint32_t)v, rem = (uint32_t)(v >> 32) & 0x7FFFFFFFu;
+        const uint64_t begin = offsets ? offsets[q] : q * (uint64_t)m;
+        const uint32_t at = sa[l];
+        bool ok = at >= rem;
+        if (ok)
+        {
+            const uint8_t * t = text + (at - rem);
+            const uint8_t * p = pats + begin;
+            for (uint32_t j = 0; j < rem && ok; ++j)
+                ok = t[j] == p[j];
+        }
+        out_cnt[q] = ok ? 1 : 0;
     }
 }
 
@@ -391,6 +435,9 @@ static sdsl_hip_status sdsl_hip_fm_create_from_text_ex_impl(const uint8_t * text
     if (!f)
         return SDSL_HIP_ERR_NOMEM;
     f->d_sa = std::move(d_sa);
+    if (n_text && fm_verify_enabled() && f->d_text.alloc(n_text) == SDSL_HIP_OK) // (no room: count() simply walks every character)
+        if (hipMemcpy(f->d_text.p, text, n_text, hipMemcpyDefault) != hipSuccess)
+            f->d_text.release();
     sdsl_hip_status st = fm_from_device_bwt(f, d_bwt.as<uint8_t>(), n_text + 1, device, flags);
     if (st != SDSL_HIP_OK)
     {
@@ -593,6 +640,7 @@ sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
         fm->n_isa_s = (n + 63) / 64;
     }
     fm->d_sa.release();
+    fm->d_text.release(); // (only useful beside the whole suffix array)
     return SDSL_HIP_OK;
 }
 
@@ -681,7 +729,7 @@ uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm)
 }
 uint64_t sdsl_hip_fm_device_bytes(sdsl_hip_fm_t fm)
 {
-    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes + fm->d_sa_s.bytes + fm->d_isa_s.bytes + fm->d_jump.bytes + fm->d_sa.bytes : 0;
+    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes + fm->d_sa_s.bytes + fm->d_isa_s.bytes + fm->d_jump.bytes + fm->d_sa.bytes + fm->d_text.bytes : 0;
 }
 sdsl_hip_wt_t sdsl_hip_fm_wavelet_tree(sdsl_hip_fm_t fm)
 {
@@ -760,16 +808,23 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
         const WtView v = w.view();
         if (ival && v.f_lines)
             hipLaunchKernelGGL((k_fm_count<false, true, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp, m,
-                               oo, d_order, n_pat, oc, ol, orr);
+                               oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
         else if (ival)
             hipLaunchKernelGGL((k_fm_count<false, true, false>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
-                               m, oo, d_order, n_pat, oc, ol, orr);
+                               m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
+        else if (v.f_lines && fm->d_sa.p && fm->d_text.p && fm_verify_enabled())
+        {
+            hipLaunchKernelGGL((k_fm_count<false, false, true, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
+                               m, oo, d_order, n_pat, oc, ol, orr, fm->d_sa.as<uint32_t>(), fm->d_text.as<uint8_t>());
+            hipLaunchKernelGGL(k_fm_verify, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa.as<uint32_t>(),
+                               fm->d_text.as<uint8_t>(), pp, m, oo, n_pat, oc);
+        }
         else if (v.f_lines)
             hipLaunchKernelGGL((k_fm_count<false, false, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
-                               m, oo, d_order, n_pat, oc, ol, orr);
+                               m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
         else
             hipLaunchKernelGGL((k_fm_count<false, false, false>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
-                               m, oo, d_order, n_pat, oc, ol, orr);
+                               m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
     }
     if (scratch)
         (void)hipFreeAsync(scratch, s);

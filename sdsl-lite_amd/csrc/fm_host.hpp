@@ -23,6 +23,8 @@ struct sdsl_hip_fm_s
     sdslhip::FmTables tab;
     sdslhip::DevBuf d_tab;
     sdslhip::DevBuf d_sa; // suffix array (u32 per suffix) of an index created from text; empty otherwise
+    sdslhip::DevBuf d_text; // the text itself, kept beside the whole suffix array: count() verifies a pattern whose interval has
+                            // shrunk to ONE suffix against the text instead of walking its remaining characters (fm.hip)
     // SA-order SA samples SA[k*sa_dens] and text-order ISA samples ISA[k*isa_dens] (csa_sampling_strategy.hpp:72-135,
     // 735-806), u64 each; density 0 = not present
     sdslhip::DevBuf d_sa_s, d_isa_s;
