@@ -55,25 +55,33 @@ bool is_device_ptr(const void * p)
 
 sdsl_hip_status mailbox_for(int device, Mailbox ** out)
 {
+    // one mailbox per device, made on first use.  Everything happens under the mutex (a scalar query costs microseconds of
+    // launch and synchronisation anyway): no unsynchronised read of a half-published entry, and a failure half way frees what
+    // it had pinned instead of leaking it on every retry
     static Mailbox boxes[64];
+    static bool ready[64];
     static std::mutex init;
     if (device < 0 || device >= 64)
         return SDSL_HIP_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(init);
     Mailbox & b = boxes[device];
-    if (!b.host)
+    if (!ready[device])
     {
-        std::lock_guard<std::mutex> lock(init);
-        if (!b.host)
+        SH_HIP(hipSetDevice(device));
+        void * h = nullptr;
+        SH_HIP(hipHostMalloc(&h, 16 * sizeof(uint64_t), hipHostMallocMapped));
+        void * d = nullptr;
+        hipStream_t st = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
         {
-            SH_HIP(hipSetDevice(device));
-            void * h = nullptr;
-            SH_HIP(hipHostMalloc(&h, 16 * sizeof(uint64_t), hipHostMallocMapped));
-            void * d = nullptr;
-            SH_HIP(hipHostGetDevicePointer(&d, h, 0));
-            SH_HIP(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
-            b.dev = (uint64_t *)d;
-            b.host = (uint64_t *)h;
+            (void)hipHostFree(h);
+            set_error("scalar query mailbox: %s", hipGetErrorString(hipGetLastError()));
+            return SDSL_HIP_ERR_HIP;
         }
+        b.stream = st;
+        b.dev = (uint64_t *)d;
+        b.host = (uint64_t *)h;
+        ready[device] = true;
     }
     *out = &b;
     return SDSL_HIP_OK;

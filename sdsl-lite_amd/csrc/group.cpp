@@ -77,6 +77,18 @@ sdsl_hip_status rccl_fail(ncclResult_t r, const char * what)
         if (_r != ncclSuccess)                                                                                     \
             return rccl_fail(_r, #expr);                                                                           \
     } while (0)
+// between ncclGroupStart and ncclGroupEnd: a failing call must not leave the group open on this thread (every later RCCL
+// call would silently queue into it) — close it, then report the FIRST error
+#define SH_NCCL_G(expr)                                                                                            \
+    do {                                                                                                           \
+        ncclResult_t _r = (expr);                                                                                  \
+        if (_r != ncclSuccess)                                                                                     \
+        {                                                                                                          \
+            const sdsl_hip_status _st = rccl_fail(_r, #expr);                                                      \
+            (void)R->GroupEnd();                                                                                   \
+            return _st;                                                                                            \
+        }                                                                                                          \
+    } while (0)
 
 } // namespace
 
@@ -173,8 +185,8 @@ sdsl_hip_status group_run(sdsl_hip_group_s * g, const uint8_t * d_in, size_t in_
                 for (int r = 1; r < G; ++r)
                     if (pcnt[r])
                     {
-                        SH_NCCL(R->Send(d_in + (slo[r] + plo[r]) * in_bytes, pcnt[r] * in_bytes, ncclUint8, r, g->comm_a[0], g->s_in[0]));
-                        SH_NCCL(R->Recv(g->in[r].as<uint8_t>() + plo[r] * in_bytes, pcnt[r] * in_bytes, ncclUint8, 0, g->comm_a[r],
+                        SH_NCCL_G(R->Send(d_in + (slo[r] + plo[r]) * in_bytes, pcnt[r] * in_bytes, ncclUint8, r, g->comm_a[0], g->s_in[0]));
+                        SH_NCCL_G(R->Recv(g->in[r].as<uint8_t>() + plo[r] * in_bytes, pcnt[r] * in_bytes, ncclUint8, 0, g->comm_a[r],
                                         g->s_in[r]));
                     }
                 SH_NCCL(R->GroupEnd());
@@ -210,9 +222,9 @@ sdsl_hip_status group_run(sdsl_hip_group_s * g, const uint8_t * d_in, size_t in_
                 for (int r = 1; r < G; ++r)
                     if (pcnt[r])
                     {
-                        SH_NCCL(R->Send(g->out[r].as<uint8_t>() + plo[r] * out_bytes, pcnt[r] * out_bytes, ncclUint8, 0, g->comm_b[r],
+                        SH_NCCL_G(R->Send(g->out[r].as<uint8_t>() + plo[r] * out_bytes, pcnt[r] * out_bytes, ncclUint8, 0, g->comm_b[r],
                                         g->s_out[r]));
-                        SH_NCCL(R->Recv(d_out + (slo[r] + plo[r]) * out_bytes, pcnt[r] * out_bytes, ncclUint8, r, g->comm_b[0],
+                        SH_NCCL_G(R->Recv(d_out + (slo[r] + plo[r]) * out_bytes, pcnt[r] * out_bytes, ncclUint8, r, g->comm_b[0],
                                         g->s_out[0]));
                     }
                 SH_NCCL(R->GroupEnd());
@@ -362,8 +374,8 @@ sdsl_hip_status sdsl_hip_group_loopback(sdsl_hip_group_t g, uint64_t bytes, floa
             SH_NCCL(R->GroupStart());
             for (int r = 0; r < G; ++r)
             {
-                SH_NCCL(R->Send(src[r].p, bytes, ncclUint8, (r + 1) % G, comm[r], str[r]));
-                SH_NCCL(R->Recv(dst[r].p, bytes, ncclUint8, (r + G - 1) % G, comm[r], str[r]));
+                SH_NCCL_G(R->Send(src[r].p, bytes, ncclUint8, (r + 1) % G, comm[r], str[r]));
+                SH_NCCL_G(R->Recv(dst[r].p, bytes, ncclUint8, (r + G - 1) % G, comm[r], str[r]));
             }
             SH_NCCL(R->GroupEnd());
             return SDSL_HIP_OK;
@@ -461,7 +473,7 @@ sdsl_hip_status sdsl_hip_group_bv_replicate(sdsl_hip_group_t g, sdsl_hip_bv_t ro
         {
             BvHost & d = bv_host_of(replicas[r]);
             DevBuf & br = buf_of(d, which);
-            SH_NCCL(R->Broadcast(b0.p, br.p, b0.bytes, ncclUint8, 0, g->comm_a[r], g->s_in[r]));
+            SH_NCCL_G(R->Broadcast(b0.p, br.p, b0.bytes, ncclUint8, 0, g->comm_a[r], g->s_in[r]));
         }
         SH_NCCL(R->GroupEnd());
         return SDSL_HIP_OK;
@@ -554,7 +566,7 @@ sdsl_hip_status sdsl_hip_group_fm_create_from_text(sdsl_hip_group_t g, const uin
     {
         SH_NCCL(R->GroupStart());
         for (int r = 0; r < G; ++r)
-            SH_NCCL(R->Broadcast(tp[0], (void *)tp[r], n_text, ncclUint8, 0, g->comm_a[r], g->s_in[r]));
+            SH_NCCL_G(R->Broadcast(tp[0], (void *)tp[r], n_text, ncclUint8, 0, g->comm_a[r], g->s_in[r]));
         SH_NCCL(R->GroupEnd());
         for (int r = 0; r < G; ++r)
         {

@@ -9,7 +9,7 @@
 //   rrr_vector::operator[]               rrr_vector.hpp:276-298
 //   binomial table / space[]             rrr_helper.hpp:194-237, 262-295
 //
-// Device layout: one 128-byte RECORD per 36 blocks (2268 bits; SDSL samples every 32 blocks — the parser
+// Device layout: one 128-byte RECORD per 34 blocks (2142 bits; SDSL samples every 32 blocks — the parser
 // and the serialiser regroup)
 //   word 0      ones before the record's first block              (what SDSL's m_rank holds every 32 blocks)
 //   word 1      bits 0..47  WORD pointer into the overflow stream (the role of SDSL's m_btnrp)
@@ -113,7 +113,7 @@ struct RrrArrays // host image of a parsed SDSL stream
     uint64_t stream_bits = 0;
     std::vector<uint64_t> sb_rank; // ones before each SDSL superblock
     std::vector<uint64_t> sb_ptr;  // stream position of each SDSL superblock
-    uint64_t n_rec = 0;            // device records (36 blocks)
+    uint64_t n_rec = 0;            // device records (34 blocks)
     std::vector<uint64_t> rec_rank, rec_ptr; // the same two per device record (rec_ptr: position in SDSL's stream)
 };
 

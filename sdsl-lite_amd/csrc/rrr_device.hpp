@@ -9,15 +9,17 @@ namespace sdslhip {
 constexpr unsigned kRrrBS = 63;
 constexpr unsigned kRrrK = 32; // SDSL's t_k: blocks per sample of the SERIALISED form (m_rank, m_btnrp, m_invert)
 constexpr uint64_t kRrrSB = (uint64_t)kRrrBS * kRrrK; // 2016 bits per SDSL superblock (parser / serialiser only)
-// The device groups 36 blocks per record, not 32: a 128-byte record per 2016 bits costs 0.51 bits/bit before a single
-// offset is stored; per 2268 bits it costs 0.45, and at 5 % density the ~585 offset bits of 36 blocks still (almost) fit
-// the 576 inline bits.  Four groups of nine classes, 7 bits each (9 x 7 = 63 bits of a word).
+// The device groups 34 blocks per record, not 32: a 128-byte record per 2016 bits costs 0.51 bits/bit before a single
+// offset is stored; per 2142 bits it costs 0.478, and at 5 % density the ~552 offset bits of 34 blocks fit the 576 inline
+// bits for all but 1.7 % of the queries (36 blocks: 0.457 bits/bit, but 585 offset bits: four waves in five then wait for a
+// lane with a second fetch, profiles/rrr_record_size_r02.txt).  Groups of nine classes, 7 bits each (9 x 7 = 63 bits of a
+// word); the fourth class word holds seven.
 constexpr unsigned kRecK = 34;
 constexpr unsigned kGrp = 9;   // blocks per class word
 constexpr unsigned kClsW = 7;  // bits per class field
-constexpr uint64_t kRecSB = (uint64_t)kRrrBS * kRecK; // 2268 bits per record
+constexpr uint64_t kRecSB = (uint64_t)kRrrBS * kRecK; // 2142 bits per record
 constexpr unsigned kRecWords = 16;
-constexpr unsigned kRecClasses = 3;  // words 3..6: the 36 block classes, nine 7-bit fields per word
+constexpr unsigned kRecClasses = 3;  // words 3..6: the 34 block classes, nine 7-bit fields per word (seven in the last)
 constexpr unsigned kRecInline = 7;   // words 7..15: the first 576 bits of the record's offsets (the rest: RrrView::stream)
 constexpr unsigned kInlineWords = kRecWords - kRecInline;
 constexpr unsigned kInlineBits = 64 * kInlineWords; // 576
@@ -48,7 +50,7 @@ SH_HD bool rrr_raw_width(unsigned len)
 
 struct RrrView
 {
-    const uint64_t * rec;    // n_sb * 16 words (n_sb = number of RECORDS, 36 blocks each)
+    const uint64_t * rec;    // n_sb * 16 words (n_sb = number of RECORDS, 34 blocks each)
     const uint64_t * stream; // per record the offset bits beyond its inline area, in whole words; padded by two words
     const RrrTables * tables;
     const uint32_t * sel[2]; // select directories: (position of the j<<shift-th argument) >> pshift, + sentinel
