@@ -36,6 +36,7 @@ struct SrGeom
 namespace {
 
 constexpr uint32_t kSrRecBits = 63 * 34;   // bits per record of the rrr_vector<63> device layout (rrr_device.hpp: kRecSB)
+constexpr uint32_t kSrRecBitsSlim = 63 * 42; // ... of its slim format (RrrFmtS::SB)
 constexpr unsigned kRT = 512;            // threads of a rank block
 constexpr unsigned kBins = 256;          // bins per pass (8-bit digits)
 constexpr unsigned kSliceLog = 10;       // lines per slice (64 KiB)
@@ -101,6 +102,22 @@ __device__ __forceinline__ unsigned block_excl_scan_bins(unsigned * a, unsigned 
     return total;
 }
 
+template <uint32_t REC_BITS>
+__device__ __forceinline__ void sr_key1_rrr(uint64_t pos, const SrGeom & g, unsigned & dig, uint32_t & key)
+{
+    uint64_t rec = pos / REC_BITS;
+    unsigned in_rec = (unsigned)(pos - rec * REC_BITS);
+    if (in_rec == 0 && pos == g.n_bits && pos != 0)
+    { // rank(size()) when the vector ends with a record: "all 63 bits of its last block"
+        --rec;
+        in_rec = REC_BITS;
+    }
+    const unsigned blk = in_rec == REC_BITS ? REC_BITS / 63 - 1 : in_rec / 63, off = in_rec - blk * 63; // off <= 63
+    const uint32_t sl = (uint32_t)(rec >> g.rlog);
+    dig = sl >> g.d2;
+    key = ((sl & ((1u << g.d2) - 1)) << g.kb) | (((uint32_t)rec & ((1u << g.rlog) - 1)) << 12) | (blk << 6) | off;
+}
+
 // pass 1: digit and 32-bit key of a position
 __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned & dig, uint32_t & key)
 {
@@ -124,21 +141,14 @@ __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned
         key = kBad;
         return;
     }
-    if (g.op == 2)
+    if (g.op >= 2)
     { // rank on an rrr_vector<63>'s records (rrr_sorted.hip): record, 63-bit block inside it, bit inside the block
         // (the record length is a compile-time constant here: a 64-bit division by a run-time value costs more than the rest
-        // of the pass — 4.4 instead of 1.6 ms per 10^9 keys in the counting pass)
-        uint64_t rec = pos / kSrRecBits;
-        unsigned in_rec = (unsigned)(pos - rec * kSrRecBits);
-        if (in_rec == 0 && pos == g.n_bits && pos != 0)
-        { // rank(size()) when the vector ends with a record: "all 63 bits of its last block"
-            --rec;
-            in_rec = kSrRecBits;
-        }
-        const unsigned blk = in_rec == kSrRecBits ? kSrRecBits / 63 - 1 : in_rec / 63, off = in_rec - blk * 63; // off <= 63
-        const uint32_t sl = (uint32_t)(rec >> g.rlog);
-        dig = sl >> g.d2;
-        key = ((sl & ((1u << g.d2) - 1)) << g.kb) | (((uint32_t)rec & ((1u << g.rlog) - 1)) << 12) | (blk << 6) | off;
+        // of the pass — 4.4 instead of 1.6 ms per 10^9 keys in the counting pass; op 2: wide records, op 3: slim ones)
+        if (g.op == 2)
+            sr_key1_rrr<kSrRecBits>(pos, g, dig, key);
+        else
+            sr_key1_rrr<kSrRecBitsSlim>(pos, g, dig, key);
         return;
     }
     uint64_t L;

@@ -14,6 +14,7 @@ std::atomic<int> g_rrr_raw_budget{20}; // permille of the compressed size rrr_ve
 std::atomic<int> g_select_sorted_mode{getenv("SDSL_HIP_SELECT_SORTED") ? atoi(getenv("SDSL_HIP_SELECT_SORTED")) : -1};
 std::atomic<int> g_rank_sorted_mode{getenv("SDSL_HIP_RANK_SORTED") ? atoi(getenv("SDSL_HIP_RANK_SORTED")) : -1};
 std::atomic<int> g_rrr_sorted_mode{getenv("SDSL_HIP_RRR_SORTED") ? atoi(getenv("SDSL_HIP_RRR_SORTED")) : -1};
+std::atomic<int> g_rrr_format{getenv("SDSL_HIP_RRR_FORMAT") ? atoi(getenv("SDSL_HIP_RRR_FORMAT")) : -1}; // record format of new rrr vectors
 static thread_local bool g_timing_suppressed = false; // pipeline workers: the event pair is global
 static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static bool g_ev_valid = false;
@@ -274,6 +275,16 @@ sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value)
     if (name && !strcmp(name, "rrr_sorted"))
     {
         sdslhip::g_rrr_sorted_mode.store((int)value);
+        return SDSL_HIP_OK;
+    }
+    if (name && !strcmp(name, "rrr_format"))
+    { // record format of the stand-alone rrr_vector<63> handles created from now on: 0 wide, 1 slim, -1 chosen per vector
+        if (value < -1 || value > 1)
+        {
+            set_error("set_option: rrr_format is -1 (automatic), 0 (wide records) or 1 (slim records)");
+            return SDSL_HIP_ERR_INVALID;
+        }
+        sdslhip::g_rrr_format.store((int)value);
         return SDSL_HIP_OK;
     }
     if (name && !strcmp(name, "rrr_raw_budget"))

@@ -69,7 +69,55 @@ static RrrTables tables_for(unsigned sparse_max)
     RrrTables T = host_tables();
     for (unsigned k = sparse_max + 1; k + sparse_max < kRrrBS; ++k)
         T.space[k] = (uint8_t)kRrrBS;
+    for (unsigned b = 0; b < 256; ++b) // (field 15 of a slim record is the escape: 63 bits, which is what space[15] says anyway)
+        T.space2[b] = (uint8_t)(T.space[b & 15] + T.space[b >> 4]);
     return T;
+}
+
+// geometry of the two record formats for the host-side code (rrr_device.hpp: RrrFmtW, RrrFmtS)
+struct RrrGeo
+{
+    unsigned fmt, K, GRP, CLSW, NCW, CLS0, INL0, INLW, INLB;
+    uint64_t SB;
+    unsigned field_value(unsigned k) const { return fmt && k >= kEsc ? kEsc : k; }             // what the class word holds
+    unsigned dev_len(const RrrTables & T, unsigned k) const { return fmt && k >= kEsc ? kRrrBS : T.space[k]; } // bits of its field
+};
+static RrrGeo geo_of(unsigned fmt)
+{
+    if (fmt)
+        return RrrGeo{1, RrrFmtS::K, RrrFmtS::GRP, 4, RrrFmtS::NCW, RrrFmtS::CLS0, RrrFmtS::INL0, RrrFmtS::INLW, RrrFmtS::INLB, RrrFmtS::SB};
+    return RrrGeo{0, kRecK, kGrp, kClsW, 4, kRecClasses, kRecInline, kInlineWords, kInlineBits, kRecSB};
+}
+
+// Which record format a stand-alone vector gets (option "rrr_format" / SDSL_HIP_RRR_FORMAT overrides): slim when escapes are rare
+// (at most one block in 512 has 15 or more ones) and the estimate of its size — records plus the offset bits beyond a record's
+// inline area — is at least 5 % below the wide format's.
+static unsigned choose_format(const uint64_t hist[64], uint64_t n_blocks, const RrrTables & T, bool allow_slim)
+{
+    if (!allow_slim)
+        return 0;
+    const int forced = g_rrr_format.load();
+    if (forced == 0 || forced == 1)
+        return (unsigned)forced;
+    if (n_blocks == 0)
+        return 0;
+    uint64_t esc = 0;
+    double bits_w = 0, bits_s = 0; // offset bits of the whole vector in either format
+    for (unsigned k = 0; k < 64; ++k)
+    {
+        if (k >= kEsc)
+            esc += hist[k];
+        bits_w += (double)hist[k] * T.space[k];
+        bits_s += (double)hist[k] * (k >= kEsc ? kRrrBS : T.space[k]);
+    }
+    if (esc * 512 > n_blocks)
+        return 0;
+    auto size = [&](const RrrGeo & G, double bits)
+    {
+        const double nrec = (double)n_blocks / G.K, per = bits / nrec;
+        return nrec * (1024.0 + (per > G.INLB ? per - G.INLB + 32.0 : 16.0));
+    };
+    return size(geo_of(1), bits_s) < 0.95 * size(geo_of(0), bits_w) ? 1u : 0u;
 }
 
 // smallest t whose raw classes cost at most 2 % (option "rrr_raw_budget", in permille) of the vector's compressed size on top of t = 10 (the classes 11..52 are
@@ -113,8 +161,6 @@ struct RrrArrays // host image of a parsed SDSL stream
     uint64_t stream_bits = 0;
     std::vector<uint64_t> sb_rank; // ones before each SDSL superblock
     std::vector<uint64_t> sb_ptr;  // stream position of each SDSL superblock
-    uint64_t n_rec = 0;            // device records (34 blocks)
-    std::vector<uint64_t> rec_rank, rec_ptr; // the same two per device record (rec_ptr: position in SDSL's stream)
 };
 
 // rrr_vector<63>::load layout (rrr_vector.hpp:366-378,381-392)
@@ -138,8 +184,7 @@ static sdsl_hip_status rrr_parse_sdsl(StreamReader & rd, RrrArrays & A)
             || rank.size() != A.n_sb + ((n % kRrrSB) > 0))
             goto bad;
         const RrrTables & T = host_tables();
-        A.n_rec = (A.n_blocks + kRecK - 1) / kRecK;
-        A.cls.assign(std::max(A.n_sb * kRrrK, A.n_rec * kRecK), 0);
+        A.cls.assign(A.n_blocks + 64, 0); // (padded: a device record may reach up to 41 blocks beyond the last one)
         A.sb_rank.assign(A.n_sb + 1, 0);
         A.sb_ptr.assign(A.n_sb + 1, 0);
         uint64_t run = 0, ptr = 0;
@@ -174,21 +219,6 @@ static sdsl_hip_status rrr_parse_sdsl(StreamReader & rd, RrrArrays & A)
             goto bad;
         A.stream = btnr.words;
         A.stream.resize(((std::max<uint64_t>(btnr.bit_size, 64) + 63) >> 6) + 2, 0);
-        A.rec_rank.assign(A.n_rec + 1, 0);
-        A.rec_ptr.assign(A.n_rec + 1, 0);
-        run = ptr = 0;
-        for (uint64_t b = 0; b < A.n_rec * kRecK; ++b)
-        {
-            if (b % kRecK == 0)
-            {
-                A.rec_rank[b / kRecK] = run;
-                A.rec_ptr[b / kRecK] = ptr;
-            }
-            run += A.cls[b];
-            ptr += T.sdsl_space[A.cls[b]];
-        }
-        A.rec_rank[A.n_rec] = run;
-        A.rec_ptr[A.n_rec] = ptr;
         return SDSL_HIP_OK;
     }
 bad:
@@ -197,7 +227,7 @@ bad:
 }
 
 // rank / access, one query per lane
-template <int MODE> // 0: rank, 1: access
+template <int MODE, class F> // MODE 0: rank, 1: access; F: record format
 __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, const uint64_t * __restrict__ iq,
                                                         uint64_t * __restrict__ out, uint8_t * __restrict__ out8,
                                                         uint64_t n)
@@ -214,7 +244,7 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, cons
         {
             unsigned b = 0xFF;
             if (ok)
-                rrr_rank1(v, &T, i, &b);
+                rrr_rank1<F>(v, &T, i, &b);
             out8[q] = (uint8_t)b;
         }
         else
@@ -222,7 +252,7 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, cons
             uint64_t r = SDSL_HIP_NPOS;
             if (ok)
             {
-                const uint64_t r1 = rrr_rank1(v, &T, i);
+                const uint64_t r1 = rrr_rank1<F>(v, &T, i);
                 r = bit ? r1 : i - r1;
             }
             out[q] = r;
@@ -232,6 +262,7 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_rank(RrrView v, int bit, cons
 
 // rrr_vector::get_int(idx, len) (rrr_vector.hpp:308-356): the len <= 64 bits starting at idx, bit idx in the lowest
 // position; a window touches at most two 63-bit blocks.  One query per lane.
+template <class F>
 __global__ __launch_bounds__(kRrrBlock) void k_rrr_get_int(RrrView v, unsigned len, const uint64_t * __restrict__ iq,
                                                            uint64_t * __restrict__ out, uint64_t n)
 {
@@ -246,11 +277,11 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_get_int(RrrView v, unsigned l
             r = 0;
             if (len)
             {
-                const RankTail t = rrr_rank_head(v, &T, i);
+                const RankTail t = rrr_rank_head_f<F>(v, &T, i);
                 r = rrr_decode_block(&T, t.k, t.nr) >> t.off;
                 if (t.off + len > kRrrBS)
                 {
-                    const RankTail u = rrr_rank_head(v, &T, i - t.off + kRrrBS);
+                    const RankTail u = rrr_rank_head_f<F>(v, &T, i - t.off + kRrrBS);
                     r |= rrr_decode_block(&T, u.k, u.nr) << (kRrrBS - t.off);
                 }
                 r &= lo_set(len);
@@ -264,7 +295,7 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_get_int(RrrView v, unsigned l
 // Flat variant: every wave owns a contiguous range of the batch; a lane that needs a query takes the next unassigned
 // index of the range (rank among the needing lanes, from a ballot), so the queries in flight in a wave stay within a
 // short window of the arrays (argument loads coalesce, result stores merge in L2).  One iteration = one probe.
-template <int BIT, unsigned DECODE_AT>
+template <int BIT, unsigned DECODE_AT, class F>
 __global__ __launch_bounds__(kRrrBlock) void k_rrr_select_flat(RrrView v, const uint64_t * __restrict__ iq,
                                                                uint64_t * __restrict__ out, uint64_t n)
 {
@@ -311,7 +342,7 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select_flat(RrrView v, const 
         if (__ballot(have) == 0 && base >= end)
             break;
         if (have && !ready)
-            ready = rrr_sel_probe<BIT>(v, st, h);
+            ready = rrr_sel_probe<BIT, F>(v, st, h);
         // the decode is the expensive half in instructions: run it when most of the wave can take part, or when
         // nobody is left probing
         const unsigned n_ready = (unsigned)__popcll(__ballot(ready));
@@ -326,16 +357,16 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select_flat(RrrView v, const 
                 uint64_t nr = nr_far;
                 if (!fetched)
                 {
-                    loc = rrr_sel_locate<BIT>(v, &T, st.k0, h);
+                    loc = rrr_sel_locate<BIT, F>(v, &T, st.k0, h);
                     const unsigned len = T.space[loc.k];
-                    if (rrr_sel_in_stream(&T, loc))
+                    if (rrr_sel_in_stream<F>(&T, loc))
                     {
-                        nr_far = rrr_field(v, h.r, loc.ptr, loc.rel, len);
+                        nr_far = rrr_field_t<F::INL0, F::INLW>(v, h.r, loc.ptr, loc.rel, len);
                         fetched = true;
                         now = false;
                     }
                     else
-                        nr = rrr_field_inline(h.r, loc.rel, len);
+                        nr = rrr_field_inline<F>(h.r, loc.rel, len);
                 }
                 if (now)
                 {
@@ -347,7 +378,7 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select_flat(RrrView v, const 
     }
 }
 
-template <int BIT>
+template <int BIT, class F>
 __global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint64_t * __restrict__ iq,
                                                           uint64_t * __restrict__ out, uint64_t n)
 {
@@ -375,7 +406,7 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint6
         const uint64_t i = i_cur;
         uint64_t r;
         if (arg_ok(i))
-            r = rrr_select<BIT>(v, &T, i - 1, s0_cur, s1_cur);
+            r = rrr_select<BIT, F>(v, &T, i - 1, s0_cur, s1_cur);
         else // i > #args: SDSL returns size() (rrr_vector.hpp:641-642, 686-689); i == 0 is outside its domain
             r = i == 0 ? SDSL_HIP_NPOS : v.n_bits;
         __builtin_nontemporal_store(r, out + q);
@@ -386,13 +417,13 @@ __global__ __launch_bounds__(kRrrBlock) void k_rrr_select(RrrView v, const uint6
     }
 }
 
-template <int BIT>
+template <int BIT, class F>
 static auto rrr_select_kernel() -> void (*)(RrrView, const uint64_t *, uint64_t *, uint64_t)
 {
     const char * e = getenv("SDSL_HIP_RRR_SEL_FLAT"); // experiment knob: 0 = the nested loop (profiles/rrr_select_flat_r01.txt)
     if (e && atoi(e) == 0)
-        return k_rrr_select<BIT>;
-    return k_rrr_select_flat<BIT, 40>; // the threshold hardly matters: 24 .. 56 measured within 2 %
+        return k_rrr_select<BIT, F>;
+    return k_rrr_select_flat<BIT, 40, F>; // the threshold hardly matters: 24 .. 56 measured within 2 %
 }
 
 // ---- device-side encoder (rrr_vector(bit_vector const&), rrr_vector.hpp:158-270) -------------------------------
@@ -427,6 +458,8 @@ __global__ __launch_bounds__(256) void k_rrr_class_hist(const uint64_t * __restr
 }
 
 // pass 1, one thread per record: classes into the record, ones and offset bits of the record
+// (slim format: the prefix counts wait in word 5 — the first inline word, written last by pass 2 — until the header words exist)
+template <class F>
 __global__ __launch_bounds__(256) void k_rrr_enc_classes(const uint64_t * __restrict__ words, uint64_t n_bits,
                                                          uint64_t n_blocks, uint64_t n_sb,
                                                          const RrrTables * __restrict__ tables, uint64_t * __restrict__ rec,
@@ -436,40 +469,48 @@ __global__ __launch_bounds__(256) void k_rrr_enc_classes(const uint64_t * __rest
     if (threadIdx.x < 64)
         space[threadIdx.x] = tables->space[threadIdx.x];
     __syncthreads();
+    constexpr unsigned CLSW = F::id ? 4u : kClsW;
     for (uint64_t sb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sb < n_sb; sb += (uint64_t)gridDim.x * blockDim.x)
     {
         unsigned ones = 0, len = 0;
         uint64_t cw[4] = {0, 0, 0, 0};
         unsigned po[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
-        for (unsigned j = 0; j < kRecK; ++j)
+        for (unsigned j = 0; j < F::K; ++j)
         {
-            const unsigned g = j / kGrp, u = j - g * kGrp;
+            const unsigned g = j / F::GRP, u = j - g * F::GRP;
             if (j && u == 0)
             {
                 po[g - 1] = ones;
                 pb[g - 1] = len;
             }
-            uint64_t b = sb * kRecK + j;
+            uint64_t b = sb * F::K + j;
             if (b >= n_blocks)
                 continue; // blocks behind the end count as class 0
             unsigned k = popc64(rrr_block_bits(words, n_bits, b));
-            cw[g] |= (uint64_t)k << (kClsW * u);
+            const bool esc = F::id && k >= kEsc;
+            cw[g] |= (uint64_t)(esc ? kEsc : k) << (CLSW * u);
             ones += k;
-            len += space[k];
+            len += esc ? kRrrBS : space[k];
         }
         uint64_t * r = rec + sb * kRecWords;
-        r[2] = rrr_pack_prefix(po, pb);
-        r[kRecClasses + 0] = cw[0];
-        r[kRecClasses + 1] = cw[1];
-        r[kRecClasses + 2] = cw[2];
-        r[kRecClasses + 3] = cw[3];
+        if (F::id == 0)
+        {
+            r[2] = rrr_pack_prefix(po, pb);
+            r[kRecClasses + 3] = cw[3];
+        }
+        else
+            r[F::INL0] = (uint64_t)po[0] | ((uint64_t)po[1] << 10) | ((uint64_t)pb[0] << 21) | ((uint64_t)pb[1] << 31) | ((uint64_t)ones << 42);
+        r[F::CLS0 + 0] = cw[0];
+        r[F::CLS0 + 1] = cw[1];
+        r[F::CLS0 + 2] = cw[2];
         sb_ones[sb] = ones;
-        sb_len[sb] = len > kInlineBits ? (len - kInlineBits + 63) >> 6 : 0; // WORDS of this record in the overflow stream (rrr_device.hpp)
+        sb_len[sb] = len > F::INLB ? (len - F::INLB + 63) >> 6 : 0; // WORDS of this record in the overflow stream (rrr_device.hpp)
     }
 }
 
 // pass 2, one thread per superblock (headers r[0] = ones before, r[1] = stream pointer are in place): offsets into
 // the stream and the record's inline area, select samples for both bit values
+template <class F>
 __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __restrict__ words, uint64_t n_bits,
                                                          uint64_t n_blocks, uint64_t n_sb,
                                                          const RrrTables * __restrict__ tables, uint64_t * __restrict__ rec,
@@ -484,20 +525,21 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
     {
         uint64_t * r = rec + sb * kRecWords;
         const uint64_t ones_before = r[0], ptr = r[1];
-        const uint64_t start = sb * kRecSB;
+        const uint64_t stash = F::id ? r[F::INL0] : 0;
+        const uint64_t start = sb * F::SB;
         uint64_t acc1 = ones_before, acc0 = start - ones_before; // arguments before the current block
         uint64_t j1 = (acc1 + S1 - 1) >> sh1, j0 = (acc0 + S0 - 1) >> sh0;
-        uint64_t inl[kInlineWords] = {};
+        uint64_t inl[F::INLW] = {};
         unsigned rel = 0;
-        for (unsigned j = 0; j < kRecK; ++j)
+        for (unsigned j = 0; j < F::K; ++j)
         {
-            const uint64_t b = sb * kRecK + j;
+            const uint64_t b = sb * F::K + j;
             if (b >= n_blocks)
                 break;
             const uint64_t bstart = b * kRrrBS;
             const unsigned blen = bstart >= n_bits ? 0u : (unsigned)(n_bits - bstart < kRrrBS ? n_bits - bstart : kRrrBS);
             const uint64_t bits = rrr_block_bits(words, n_bits, b);
-            const unsigned k = popc64(bits), len = T.space[k];
+            const unsigned k = popc64(bits), len = F::id && k >= kEsc ? kRrrBS : T.space[k];
             if (len)
             {
                 uint64_t nr = bits, x = rrr_raw_width(len) ? 0 : bits; // a raw class stores the block itself
@@ -512,17 +554,17 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
                     x &= x - 1;
                 }
                 // the record's offsets = its inline area followed by its stretch of the stream; a field may straddle the seam
-                if (rel < kInlineBits)
+                if (rel < F::INLB)
                 {
                     const unsigned w = rel >> 6, o = rel & 63;
                     inl[w] |= nr << o;
-                    if (o + len > 64 && w + 1 < kInlineWords)
+                    if (o + len > 64 && w + 1 < F::INLW)
                         inl[w + 1] |= nr >> (64 - o);
                 }
-                if (rel + len > kInlineBits)
+                if (rel + len > F::INLB)
                 {
-                    const unsigned cut = rel < kInlineBits ? kInlineBits - rel : 0u; // bits of the field that went inline
-                    const uint64_t pos = ptr * 64 + (rel + cut - kInlineBits), val = nr >> cut;
+                    const unsigned cut = rel < F::INLB ? F::INLB - rel : 0u; // bits of the field that went inline
+                    const uint64_t pos = ptr * 64 + (rel + cut - F::INLB), val = nr >> cut;
                     const unsigned off = (unsigned)(pos & 63);
                     atomicOr(&stream[pos >> 6], (unsigned long long)(val << off));
                     if (off + (len - cut) > 64)
@@ -545,11 +587,19 @@ __global__ __launch_bounds__(256) void k_rrr_enc_offsets(const uint64_t * __rest
             acc1 += k;
             acc0 += blen - k;
         }
-        if (rel < kInlineBits && (rel & 63))
+        if (rel < F::INLB && (rel & 63))
             inl[rel >> 6] &= lo_set(rel & 63);
-        for (unsigned w = 0; w < kInlineWords; ++w)
-            r[kRecInline + w] = w * 64 < rel ? inl[w] : 0;
-        r[1] = ptr | ((uint64_t)sb_ones[sb] << 48);
+        for (unsigned w = 0; w < F::INLW; ++w)
+            r[F::INL0 + w] = w * 64 < rel ? inl[w] : 0;
+        if (F::id == 0)
+            r[1] = ptr | ((uint64_t)sb_ones[sb] << 48);
+        else
+        {
+            const unsigned o16 = (unsigned)stash & 0x3FFu, o32 = (unsigned)(stash >> 10) & 0x7FFu, b16 = (unsigned)(stash >> 21) & 0x3FFu,
+                           b32 = (unsigned)(stash >> 31) & 0x7FFu, ones_in = (unsigned)(stash >> 42) & 0xFFFu;
+            r[0] = rrs_pack0(ones_before, o16, o32);
+            r[1] = rrs_pack1(ptr, b16, b32, ones_in - o32);
+        }
     }
 }
 
@@ -580,7 +630,7 @@ static uint64_t decode_block_host(const RrrTables & T, unsigned k, uint64_t nr)
 // saves in probes it loses in fabric requests for the samples (2^34 bits at 5 % density: select_0 16.0 -> 20.9 Gq/s
 // going from 2^21 to 2^15 samples, select_1 best at 2^16; profiles/rrr_select_sweep_r01.txt).
 // SDSL_HIP_RRR_SEL_LOG2 overrides the rate of both (profiling).
-static void rrr_sel_shifts(uint64_t ones, uint64_t zeros, uint32_t shb[2])
+static void rrr_sel_shifts(uint64_t ones, uint64_t zeros, uint64_t rec_bits, uint32_t shb[2])
 {
     const uint64_t cnt[2] = {zeros, ones};
     for (int b = 0; b < 2; ++b)
@@ -591,11 +641,11 @@ static void rrr_sel_shifts(uint64_t ones, uint64_t zeros, uint32_t shb[2])
         // a RARE bit value (mean gap of more than a record): interpolation inside a sample interval of many records misses,
         // and every miss is a random fetch (isolated ones every 2^16 bits: 4.5 G/s).  Sample so that an interval spans about
         // two records, as long as that directory stays small (2^18 samples = 1 MiB)
-        if (cnt[b] && (ones + zeros) / cnt[b] > kRecSB / 4)
+        if (cnt[b] && (ones + zeros) / cnt[b] > rec_bits / 4)
         {
             const uint64_t gap = (ones + zeros) / cnt[b];
             uint32_t ss = 0;
-            while (ss < sh && (gap << (ss + 1)) <= 2 * kRecSB)
+            while (ss < sh && (gap << (ss + 1)) <= 2 * rec_bits)
                 ++ss;
             if ((cnt[b] >> ss) <= (UINT64_C(1) << 18))
                 sh = ss;
@@ -618,29 +668,53 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
         for (uint64_t b = 0; b < A.n_blocks; ++b)
             ++hist[A.cls[b]];
         h.sparse_max = choose_sparse_max(hist, A.n_bits);
+        h.fmt = choose_format(hist, A.n_blocks, tables_for(h.sparse_max), h.allow_slim);
     }
     const RrrTables T = tables_for(h.sparse_max);
-    if (A.stream_bits >= (UINT64_C(1) << 48) || A.n_rec > UINT64_C(0xFFFFFFFF))
+    RrrGeo G = geo_of(h.fmt);
+    uint64_t n_rec = (A.n_blocks + G.K - 1) / G.K;
+    if (A.stream_bits >= (UINT64_C(1) << 48) || n_rec > UINT64_C(0xFFFFFFFF))
     {
         set_error("rrr_vector too large for the device record format");
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
-    const uint64_t n_rec = A.n_rec;
-    std::vector<uint64_t> rec((size_t)n_rec * kRecWords, 0);
-    // the device keeps stream storage only for the offset bits beyond a record's inline area
-    std::vector<uint64_t> cptr((size_t)n_rec + 1, 0);
-    for (uint64_t s = 0; s < n_rec; ++s)
+    // per device record: ones in front of it, position of its first field in SDSL's stream, words of overflow stream in front of it
+    // (the device keeps stream storage only for the offset bits beyond a record's inline area)
+    std::vector<uint64_t> rec_rank, rec_ptr, cptr;
+    for (;;)
     {
-        uint64_t len = 0; // on the device: raw classes take 63 bits
-        for (unsigned j = 0; j < kRecK; ++j)
-            len += T.space[A.cls[(size_t)s * kRecK + j]];
-        cptr[s + 1] = cptr[s] + (len > kInlineBits ? (len - kInlineBits + 63) >> 6 : 0); // words
+        rec_rank.assign((size_t)n_rec + 1, 0);
+        rec_ptr.assign((size_t)n_rec + 1, 0);
+        cptr.assign((size_t)n_rec + 1, 0);
+        uint64_t run = 0, ptr = 0;
+        for (uint64_t s = 0; s < n_rec; ++s)
+        {
+            rec_rank[s] = run;
+            rec_ptr[s] = ptr;
+            uint64_t len = 0; // on the device: raw classes take 63 bits
+            for (unsigned j = 0; j < G.K; ++j)
+            {
+                const unsigned k = A.cls[(size_t)s * G.K + j];
+                run += k;
+                ptr += T.sdsl_space[k];
+                len += G.dev_len(T, k);
+            }
+            cptr[s + 1] = cptr[s] + (len > G.INLB ? (len - G.INLB + 63) >> 6 : 0); // words
+        }
+        rec_rank[n_rec] = run;
+        rec_ptr[n_rec] = ptr;
+        if (G.fmt == 0 || cptr[n_rec] + 3 < kSlimMaxStream)
+            break;
+        h.fmt = 0; // (a slim vector with more overflow than its 33-bit pointers address: only a forced format gets here)
+        G = geo_of(0);
+        n_rec = (A.n_blocks + G.K - 1) / G.K;
     }
+    std::vector<uint64_t> rec((size_t)n_rec * kRecWords, 0);
     std::vector<uint64_t> cstream(cptr[n_rec] + 3, 0);
     const uint64_t zeros = A.n_bits - A.ones;
     // sampling rate: smallest power of two >= 256 that keeps a directory within 2^21 samples
     uint32_t shb[2];
-    rrr_sel_shifts(A.ones, zeros, shb);
+    rrr_sel_shifts(A.ones, zeros, G.SB, shb);
     uint32_t ps = 0;
     while ((A.n_bits >> ps) >= UINT64_C(0xFFFFFFFF))
         ++ps;
@@ -651,36 +725,44 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
         for (uint64_t s = s0; s < s1; ++s)
         {
             uint64_t * r = &rec[(size_t)s * kRecWords];
-            uint64_t ones_in = A.rec_rank[s + 1] - A.rec_rank[s];
-            r[0] = A.rec_rank[s];
-            r[1] = cptr[s] | (ones_in << 48);
+            uint64_t ones_in = rec_rank[s + 1] - rec_rank[s];
             {
-                unsigned po[3], pb[3], ones = 0, bits = 0;
-                for (unsigned j = 0; j < kRecK; ++j)
+                unsigned po[3] = {0, 0, 0}, pb[3] = {0, 0, 0}, ones = 0, bits = 0;
+                for (unsigned j = 0; j < G.K; ++j)
                 {
-                    const unsigned g = j / kGrp, u = j - g * kGrp;
+                    const unsigned g = j / G.GRP, u = j - g * G.GRP;
                     if (j && u == 0)
                     {
                         po[g - 1] = ones;
                         pb[g - 1] = bits;
                     }
-                    unsigned k = A.cls[(size_t)s * kRecK + j];
-                    r[kRecClasses + g] |= (uint64_t)k << (kClsW * u);
+                    unsigned k = A.cls[(size_t)s * G.K + j];
+                    r[G.CLS0 + g] |= (uint64_t)G.field_value(k) << (G.CLSW * u);
                     ones += k;
-                    bits += T.space[k];
+                    bits += G.dev_len(T, k);
                 }
-                r[2] = rrr_pack_prefix(po, pb);
+                if (G.fmt == 0)
+                {
+                    r[0] = rec_rank[s];
+                    r[1] = cptr[s] | (ones_in << 48);
+                    r[2] = rrr_pack_prefix(po, pb);
+                }
+                else
+                {
+                    r[0] = rrs_pack0(rec_rank[s], po[0], po[1]);
+                    r[1] = rrs_pack1(cptr[s], pb[0], pb[1], (unsigned)ones_in - po[1]);
+                }
             }
             { // the record's fields: SDSL's offsets, or the decoded block for a raw class; nine words inline, the rest in
               // the record's own words of the overflow stream (no other thread writes those)
-                uint64_t sp = A.rec_ptr[s];
+                uint64_t sp = rec_ptr[s];
                 unsigned rel = 0;
-                for (unsigned j = 0; j < kRecK; ++j)
+                for (unsigned j = 0; j < G.K; ++j)
                 {
-                    const uint64_t blk = s * kRecK + j;
+                    const uint64_t blk = s * G.K + j;
                     if (blk >= A.n_blocks)
                         break;
-                    const unsigned k = A.cls[blk], sl = T.sdsl_space[k], dl = T.space[k];
+                    const unsigned k = A.cls[blk], sl = T.sdsl_space[k], dl = G.dev_len(T, k);
                     if (dl)
                     {
                         uint64_t f = read_bits(A.stream.data(), sp, sl);
@@ -689,7 +771,7 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
                         for (unsigned done = 0; done < dl;)
                         { // word by word of the record's offset string
                             const unsigned at = rel + done, w = at >> 6, o = at & 63, n = std::min(dl - done, 64 - o);
-                            uint64_t * dst = w < kInlineWords ? &r[kRecInline + w] : &cstream[cptr[s] + (w - kInlineWords)];
+                            uint64_t * dst = w < G.INLW ? &r[G.INL0 + w] : &cstream[cptr[s] + (w - G.INLW)];
                             *dst |= ((f >> done) & lo_set(n)) << o;
                             done += n;
                         }
@@ -699,9 +781,9 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
                 }
             }
             // select samples falling into this superblock: walk its blocks, decode only where needed
-            uint64_t start = s * kRecSB;
-            uint64_t len_in = A.n_bits - start < kRecSB ? A.n_bits - start : kRecSB;
-            uint64_t h[2] = {start - A.rec_rank[s], A.rec_rank[s]};
+            uint64_t start = s * G.SB;
+            uint64_t len_in = A.n_bits - start < G.SB ? A.n_bits - start : G.SB;
+            uint64_t h[2] = {start - rec_rank[s], rec_rank[s]};
             uint64_t c[2] = {len_in - ones_in, ones_in};
             for (int b = 0; b < 2; ++b)
             {
@@ -710,10 +792,10 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
                 uint64_t jj = (h[b] + S - 1) >> sh;
                 if (c[b] == 0 || (jj << sh) >= h[b] + c[b])
                     continue;
-                uint64_t acc = h[b], ptr = A.rec_ptr[s];
-                for (unsigned t = 0; t < kRecK && (jj << sh) < h[b] + c[b]; ++t)
+                uint64_t acc = h[b], ptr = rec_ptr[s];
+                for (unsigned t = 0; t < G.K && (jj << sh) < h[b] + c[b]; ++t)
                 {
-                    uint64_t blk = s * kRecK + t;
+                    uint64_t blk = s * G.K + t;
                     if (blk >= A.n_blocks)
                         break;
                     unsigned k = A.cls[blk], len = T.sdsl_space[k];
@@ -773,6 +855,7 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     h.view.sel_shift[0] = shb[0];
     h.view.sel_shift[1] = shb[1];
     h.view.sel_pshift = ps;
+    h.view.fmt = h.fmt;
     return SDSL_HIP_OK;
 }
 
@@ -794,8 +877,7 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
 {
     h.device = device;
     const uint64_t n_blocks = (n_bits + kRrrBS) / kRrrBS; // one all-zero dummy block when 63 | n (rrr_vector.hpp:163)
-    const uint64_t n_sb = (n_blocks + kRecK - 1) / kRecK; // records
-    if (n_sb > UINT64_C(0xFFFFFFFF))
+    if ((n_blocks + kRecK - 1) / kRecK > UINT64_C(0xFFFFFFFF))
     {
         set_error("rrr_vector too large for the device record format");
         return SDSL_HIP_ERR_UNSUPPORTED;
@@ -809,8 +891,12 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
         uint64_t hist[64];
         SH_HIP(hipMemcpy(hist, dh.p, sizeof hist, hipMemcpyDeviceToHost));
         h.sparse_max = choose_sparse_max(hist, n_bits);
+        h.fmt = choose_format(hist, n_blocks, tables_for(h.sparse_max), h.allow_slim);
     }
     const RrrTables T = tables_for(h.sparse_max);
+again:
+    const RrrGeo G = geo_of(h.fmt);
+    const uint64_t n_sb = (n_blocks + G.K - 1) / G.K; // records
     SH_TRY(h.tables.alloc(sizeof(RrrTables)));
     SH_HIP(hipMemcpy(h.tables.p, &T, sizeof(RrrTables), hipMemcpyHostToDevice));
     SH_TRY(h.rec.alloc(n_sb * kRecWords * 8, true));
@@ -818,16 +904,27 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
     SH_TRY(sb_ones.alloc(n_sb * 4));
     SH_TRY(sb_len.alloc(n_sb * 4));
     const unsigned grid = grid_for(n_sb, 256, 65536);
-    hipLaunchKernelGGL(k_rrr_enc_classes, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
-                       h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(), sb_len.as<uint32_t>());
+    if (G.fmt)
+        hipLaunchKernelGGL(k_rrr_enc_classes<RrrFmtS>, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
+                           h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(), sb_len.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_rrr_enc_classes<RrrFmtW>, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
+                           h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(), sb_len.as<uint32_t>());
     SH_HIP(hipGetLastError());
     uint64_t ones = 0, stream_bits = 0; // stream_bits: total of sb_len
     SH_TRY(device_exclusive_scan_u32(sb_ones.as<uint32_t>(), n_sb, h.rec.as<uint64_t>(), kRecWords, &ones));
     SH_TRY(device_exclusive_scan_u32(sb_len.as<uint32_t>(), n_sb, h.rec.as<uint64_t>() + 1, kRecWords, &stream_bits));
     const uint64_t stream_words = stream_bits; // (the scan summed words)
+    if (G.fmt && stream_words + 3 >= kSlimMaxStream)
+    { // more overflow than a slim record's 33-bit pointer addresses (only a forced format gets here)
+        h.fmt = 0;
+        h.rec.release();
+        h.tables.release();
+        goto again;
+    }
     const uint64_t zeros = n_bits - ones;
     uint32_t shb[2];
-    rrr_sel_shifts(ones, zeros, shb);
+    rrr_sel_shifts(ones, zeros, G.SB, shb);
     uint32_t ps = 0;
     while ((n_bits >> ps) >= UINT64_C(0xFFFFFFFF))
         ++ps;
@@ -835,9 +932,14 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
     SH_TRY(h.stream.alloc((stream_words + 3) * 8, true));
     SH_TRY(h.sel[1].alloc((ns1 + 2) * 4, true));
     SH_TRY(h.sel[0].alloc((ns0 + 2) * 4, true));
-    hipLaunchKernelGGL(k_rrr_enc_offsets, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
-                       h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(),
-                       h.stream.as<unsigned long long>(), shb[1], shb[0], ps, h.sel[1].as<uint32_t>(), h.sel[0].as<uint32_t>());
+    if (G.fmt)
+        hipLaunchKernelGGL(k_rrr_enc_offsets<RrrFmtS>, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
+                           h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(),
+                           h.stream.as<unsigned long long>(), shb[1], shb[0], ps, h.sel[1].as<uint32_t>(), h.sel[0].as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_rrr_enc_offsets<RrrFmtW>, dim3(grid), dim3(256), 0, 0, d_words, n_bits, n_blocks, n_sb,
+                           h.tables.as<RrrTables>(), h.rec.as<uint64_t>(), sb_ones.as<uint32_t>(),
+                           h.stream.as<unsigned long long>(), shb[1], shb[0], ps, h.sel[1].as<uint32_t>(), h.sel[0].as<uint32_t>());
     SH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_rrr_set_sentinels, dim3(1), dim3(1), 0, 0, h.sel[1].as<uint32_t>(), ns1, h.sel[0].as<uint32_t>(),
                        ns0, (uint32_t)(n_bits >> ps));
@@ -855,6 +957,7 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
     h.view.sel_shift[0] = shb[0];
     h.view.sel_shift[1] = shb[1];
     h.view.sel_pshift = ps;
+    h.view.fmt = h.fmt;
     return SDSL_HIP_OK;
 }
 
@@ -865,23 +968,64 @@ sdsl_hip_status rrr_serialize_host(const RrrHost & h, StreamWriter & w)
 {
     SH_HIP(hipSetDevice(h.device));
     const RrrView & rv = h.view;
+    const RrrGeo G = geo_of(h.fmt);
     const uint64_t n = rv.n_bits, nb = rv.n_blocks, nrec = rv.n_sb;
     std::vector<uint64_t> rec((size_t)nrec * kRecWords);
     if (nrec)
         SH_HIP(hipMemcpy(rec.data(), rv.rec, rec.size() * 8, hipMemcpyDeviceToHost));
-    // total offset bits = pointer of the last superblock + its own offsets
+    std::vector<uint64_t> cs(h.stream.bytes / 8 + 2, 0); // the overflow stream
+    if (h.stream.bytes)
+        SH_HIP(hipMemcpy(cs.data(), rv.stream, h.stream.bytes, hipMemcpyDeviceToHost));
     const RrrTables T = tables_for(h.sparse_max);
-    auto cls = [&](uint64_t b) -> unsigned
+    auto rec_ptr = [&](const uint64_t * rp) -> uint64_t { return G.fmt ? RrrFmtS::ptr(rp[1]) : RrrFmtW::ptr(rp[1]); };
+    // the device fields of a record, in order: f(j, class, field bits, field).  An escaped block of a slim record says its class itself
+    auto walk = [&](uint64_t r, auto && f)
     {
-        const unsigned j = (unsigned)(b % kRecK);
-        return rrr_cls(rec[(b / kRecK) * kRecWords + kRecClasses + j / kGrp], j % kGrp);
+        const uint64_t * rp = &rec[r * kRecWords];
+        const uint64_t * far = cs.data() + rec_ptr(rp);
+        unsigned rel = 0;
+        for (unsigned j = 0; j < G.K; ++j)
+        {
+            if (r * G.K + j >= nb)
+                break;
+            const unsigned fv = (unsigned)(rp[G.CLS0 + j / G.GRP] >> (G.CLSW * (j % G.GRP))) & ((1u << G.CLSW) - 1);
+            const unsigned dl = T.space[fv]; // (space[15] == 63: the escape reads as the raw class it is)
+            uint64_t fld = 0;
+            for (unsigned done = 0; done < dl;)
+            {
+                const unsigned p = rel + done, wd = p >> 6, o = p & 63, cnt = std::min(dl - done, 64 - o);
+                const uint64_t word = wd < G.INLW ? rp[G.INL0 + wd] : far[wd - G.INLW];
+                fld |= ((word >> o) & lo_set(cnt)) << done;
+                done += cnt;
+            }
+            const unsigned k = G.fmt && fv == kEsc ? (unsigned)__builtin_popcountll(fld) : fv;
+            f(j, k, dl, fld);
+            rel += dl;
+        }
     };
+    unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+    if (nrec < 4096)
+        nt = 1;
+    auto spread = [&](auto && fn)
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back(fn, nrec * t / nt, nrec * (t + 1) / nt);
+        for (auto & x : th)
+            x.join();
+    };
+    std::vector<uint8_t> clsv((size_t)nb + 64, 0); // classes per block
+    spread([&](uint64_t r0, uint64_t r1)
+           {
+               for (uint64_t r = r0; r < r1; ++r)
+                   walk(r, [&](unsigned j, unsigned k, unsigned, uint64_t) { clsv[r * G.K + j] = (uint8_t)k; });
+           });
+    auto cls = [&](uint64_t b) -> unsigned { return clsv[b]; };
     // SDSL's samples every 32 blocks (m_rank, m_btnrp) and its offset stream (m_btnr) from the classes, the inline areas and
-    // the overflow stream of the 36-block records
+    // the overflow stream of the device records
     const uint64_t nsb = (nb + kRrrK - 1) / kRrrK;
     std::vector<uint64_t> sptr((size_t)nsb + 1, 0), srank((size_t)nsb + 1, 0);
     std::vector<uint64_t> rat((size_t)nrec + 1, 0);  // SDSL stream position of every record's first field
-    std::vector<uint32_t> rlen((size_t)nrec + 1, 0); // bits of every record's offset string on the device
     {
         uint64_t len = 0, ones = 0;
         for (uint64_t b = 0; b < nb; ++b)
@@ -891,11 +1035,10 @@ sdsl_hip_status rrr_serialize_host(const RrrHost & h, StreamWriter & w)
                 sptr[b / kRrrK] = len;
                 srank[b / kRrrK] = ones;
             }
-            if (b % kRecK == 0)
-                rat[b / kRecK] = len;
+            if (b % G.K == 0)
+                rat[b / G.K] = len;
             const unsigned k = cls(b);
             len += T.sdsl_space[k];
-            rlen[b / kRecK] += T.space[k];
             ones += k;
         }
         sptr[nsb] = len;
@@ -905,71 +1048,40 @@ sdsl_hip_status rrr_serialize_host(const RrrHost & h, StreamWriter & w)
     const uint64_t stream_bits = sptr[nsb];
     const uint64_t btnr_bits = std::max<uint64_t>(stream_bits, 64); // rrr_vector.hpp:183
     std::vector<uint64_t> btnr(((btnr_bits + 63) >> 6) + 1, 0);
-    {
-        const uint64_t cwords = nrec ? (rec[(nrec - 1) * kRecWords + 1] & ((UINT64_C(1) << 48) - 1))
-                                           + (rlen[nrec - 1] > kInlineBits ? (rlen[nrec - 1] - kInlineBits + 63) >> 6 : 0)
-                                     : 0;
-        std::vector<uint64_t> cs(cwords + 2, 0);
-        if (cwords)
-            SH_HIP(hipMemcpy(cs.data(), rv.stream, cwords * 8, hipMemcpyDeviceToHost));
-        // field by field: a raw class is turned back into SDSL's offset (bin_to_nr, rrr_helper.hpp:346-366).  Records are
-        // spread over threads; neighbouring records share words of m_btnr, hence the atomic OR
-        auto emit = [&](uint64_t r0, uint64_t r1)
-        {
-            for (uint64_t r = r0; r < r1; ++r)
-            {
-                const uint64_t * rp = &rec[r * kRecWords];
-                const uint64_t * far = cs.data() + (rp[1] & ((UINT64_C(1) << 48) - 1));
-                uint64_t at = rat[r];
-                unsigned rel = 0;
-                for (unsigned j = 0; j < kRecK; ++j)
-                {
-                    const uint64_t b = r * kRecK + j;
-                    if (b >= nb)
-                        break;
-                    const unsigned k = rrr_cls(rp[kRecClasses + j / kGrp], j % kGrp), dl = T.space[k], sl = T.sdsl_space[k];
-                    if (dl)
-                    {
-                        uint64_t f = 0;
-                        for (unsigned done = 0; done < dl;)
+    // field by field: a raw block is turned back into SDSL's offset (bin_to_nr, rrr_helper.hpp:346-366).  Records are
+    // spread over threads; neighbouring records share words of m_btnr, hence the atomic OR
+    spread([&](uint64_t r0, uint64_t r1)
+           {
+               for (uint64_t r = r0; r < r1; ++r)
+               {
+                   uint64_t at = rat[r];
+                   walk(r, [&](unsigned, unsigned k, unsigned dl, uint64_t f)
                         {
-                            const unsigned p = rel + done, w = p >> 6, o = p & 63, cnt = std::min(dl - done, 64 - o);
-                            const uint64_t word = w < kInlineWords ? rp[kRecInline + w] : far[w - kInlineWords];
-                            f |= ((word >> o) & lo_set(cnt)) << done;
-                            done += cnt;
-                        }
-                        if (rrr_raw_width(dl))
-                        {
-                            uint64_t nr = 0, x = f;
-                            unsigned kk = k;
-                            while (x)
-                            { // combinatorial number system, positions from the least significant bit
-                                const unsigned p = (unsigned)__builtin_ctzll(x);
-                                nr += T.binom[62 - p][kk];
-                                --kk;
-                                x &= x - 1;
+                            const unsigned sl = T.sdsl_space[k];
+                            if (sl)
+                            {
+                                if (rrr_raw_width(dl))
+                                {
+                                    uint64_t nr = 0, x = f;
+                                    unsigned kk = k;
+                                    while (x)
+                                    { // combinatorial number system, positions from the least significant bit
+                                        const unsigned p = (unsigned)__builtin_ctzll(x);
+                                        nr += T.binom[62 - p][kk];
+                                        --kk;
+                                        x &= x - 1;
+                                    }
+                                    f = nr;
+                                }
+                                const unsigned o = (unsigned)(at & 63);
+                                __atomic_fetch_or(&btnr[at >> 6], f << o, __ATOMIC_RELAXED);
+                                if (o + sl > 64)
+                                    __atomic_fetch_or(&btnr[(at >> 6) + 1], f >> (64 - o), __ATOMIC_RELAXED);
                             }
-                            f = nr;
-                        }
-                        const unsigned o = (unsigned)(at & 63);
-                        __atomic_fetch_or(&btnr[at >> 6], f << o, __ATOMIC_RELAXED);
-                        if (o + sl > 64)
-                            __atomic_fetch_or(&btnr[(at >> 6) + 1], f >> (64 - o), __ATOMIC_RELAXED);
-                    }
-                    at += sl;
-                    rel += dl;
-                }
-            }
-        };
-        unsigned nt = std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
-        if (nrec < 4096)
-            nt = 1;
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; ++t)
-            th.emplace_back(emit, nrec * t / nt, nrec * (t + 1) / nt);
-        for (auto & x : th)
-            x.join();
-    }
+                            at += sl;
+                        });
+               }
+           });
     PackedBuilder bt(nb, 6), btnrp(nsb, (uint8_t)(hi64(stream_bits) + 1)), invert(nsb, 1);
     const uint64_t n_rank = nsb + ((n % kRrrSB) > 0); // rrr_vector.hpp:185-186
     PackedBuilder rank(n_rank, (uint8_t)(hi64(rv.ones) + 1));
@@ -1063,6 +1175,7 @@ static sdsl_hip_status sdsl_hip_rrr_create_impl(const uint64_t * words, uint64_t
         return SDSL_HIP_ERR_NOMEM;
     Staged w; // host words are uploaded, device words are encoded where they are
     sdsl_hip_status st = w.in(words, ((n_bits + 63) >> 6) * 8, nullptr);
+    r->h.allow_slim = true; // (a stand-alone vector: the record format follows its density)
     if (st == SDSL_HIP_OK)
         st = rrr_build_device(r->h, (const uint64_t *)w.dev, n_bits, device);
     if (st != SDSL_HIP_OK)
@@ -1094,6 +1207,7 @@ static sdsl_hip_status sdsl_hip_rrr_create_from_sdsl_impl(const void * bytes, si
     sdsl_hip_rrr_s * r = new (std::nothrow) sdsl_hip_rrr_s();
     if (!r)
         return SDSL_HIP_ERR_NOMEM;
+    r->h.allow_slim = true;
     sdsl_hip_status st = rrr_upload(r->h, A, device);
     if (st != SDSL_HIP_OK)
     {
@@ -1160,6 +1274,45 @@ static unsigned rrr_grid(uint64_t n)
     return grid_for(n, kRrrBlock, 256u * 4u);
 }
 
+// the direct kernels for the vector's record format
+static void rrr_launch_rank_direct(const RrrView & v, int mode, int bit, const uint64_t * d_in, uint64_t * d_out, uint8_t * d_out8, uint64_t n,
+                                   hipStream_t s)
+{
+    const dim3 grid(rrr_grid(n)), block(kRrrBlock);
+    if (mode == 0)
+    {
+        if (v.fmt)
+            hipLaunchKernelGGL((k_rrr_rank<0, RrrFmtS>), grid, block, 0, s, v, bit, d_in, d_out, d_out8, n);
+        else
+            hipLaunchKernelGGL((k_rrr_rank<0, RrrFmtW>), grid, block, 0, s, v, bit, d_in, d_out, d_out8, n);
+    }
+    else
+    {
+        if (v.fmt)
+            hipLaunchKernelGGL((k_rrr_rank<1, RrrFmtS>), grid, block, 0, s, v, bit, d_in, d_out, d_out8, n);
+        else
+            hipLaunchKernelGGL((k_rrr_rank<1, RrrFmtW>), grid, block, 0, s, v, bit, d_in, d_out, d_out8, n);
+    }
+}
+static void rrr_launch_select_direct(const RrrView & v, int bit, const uint64_t * d_in, uint64_t * d_out, uint64_t n, hipStream_t s)
+{
+    const dim3 grid(rrr_grid(n)), block(kRrrBlock);
+    if (v.fmt)
+    {
+        if (bit)
+            hipLaunchKernelGGL((rrr_select_kernel<1, RrrFmtS>()), grid, block, 0, s, v, d_in, d_out, n);
+        else
+            hipLaunchKernelGGL((rrr_select_kernel<0, RrrFmtS>()), grid, block, 0, s, v, d_in, d_out, n);
+    }
+    else
+    {
+        if (bit)
+            hipLaunchKernelGGL((rrr_select_kernel<1, RrrFmtW>()), grid, block, 0, s, v, d_in, d_out, n);
+        else
+            hipLaunchKernelGGL((rrr_select_kernel<0, RrrFmtW>()), grid, block, 0, s, v, d_in, d_out, n);
+    }
+}
+
 sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uint64_t * idx, uint64_t n,
                                         uint64_t * out, void * stream)
 {
@@ -1178,8 +1331,7 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
         return host_pipeline_u64(v->h.device, idx, out, n,
                                  [rv, bit](const uint64_t * d_in, uint64_t * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
                                  {
-                                     hipLaunchKernelGGL((k_rrr_rank<0>), dim3(rrr_grid(cnt)), dim3(kRrrBlock), 0, st, rv, bit,
-                                                        d_in, d_out, (uint8_t *)nullptr, cnt);
+                                     rrr_launch_rank_direct(rv, 0, bit, d_in, d_out, nullptr, cnt, st);
                                      SH_HIP(hipGetLastError());
                                      return SDSL_HIP_OK;
                                  });
@@ -1228,8 +1380,7 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
                 {
                     RrrView dv = h.view;
                     dv.skip_if = go;
-                    hipLaunchKernelGGL((k_rrr_rank<0>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, dv, bit, (const uint64_t *)in.dev,
-                                       (uint64_t *)o.dev, (uint8_t *)nullptr, n);
+                    rrr_launch_rank_direct(dv, 0, bit, (const uint64_t *)in.dev, (uint64_t *)o.dev, nullptr, n, s);
                 }
             }
             SH_HIP(hipEventRecord(h.scratch_ev, s));
@@ -1243,8 +1394,7 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
     }
     {
         KernelTimer t(s);
-        hipLaunchKernelGGL((k_rrr_rank<0>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view, bit,
-                           (const uint64_t *)in.dev, (uint64_t *)o.dev, (uint8_t *)nullptr, n);
+        rrr_launch_rank_direct(v->h.view, 0, bit, (const uint64_t *)in.dev, (uint64_t *)o.dev, nullptr, n, s);
     }
     SH_HIP(hipGetLastError());
     SH_TRY(o.finish(s));
@@ -1270,8 +1420,7 @@ sdsl_hip_status sdsl_hip_rrr_access_batch(sdsl_hip_rrr_t v, const uint64_t * idx
     SH_TRY(o.out(out, n));
     {
         KernelTimer t(s);
-        hipLaunchKernelGGL((k_rrr_rank<1>), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view, 1,
-                           (const uint64_t *)in.dev, (uint64_t *)nullptr, (uint8_t *)o.dev, n);
+        rrr_launch_rank_direct(v->h.view, 1, 1, (const uint64_t *)in.dev, nullptr, (uint8_t *)o.dev, n, s);
     }
     SH_HIP(hipGetLastError());
     SH_TRY(o.finish(s));
@@ -1297,8 +1446,12 @@ sdsl_hip_status sdsl_hip_rrr_get_int_batch(sdsl_hip_rrr_t v, const uint64_t * id
     SH_TRY(o.out(out, n * 8));
     {
         KernelTimer t(s);
-        hipLaunchKernelGGL(k_rrr_get_int, dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view, len, (const uint64_t *)in.dev,
-                           (uint64_t *)o.dev, n);
+        if (v->h.view.fmt)
+            hipLaunchKernelGGL(k_rrr_get_int<RrrFmtS>, dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view, len, (const uint64_t *)in.dev,
+                               (uint64_t *)o.dev, n);
+        else
+            hipLaunchKernelGGL(k_rrr_get_int<RrrFmtW>, dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v->h.view, len, (const uint64_t *)in.dev,
+                               (uint64_t *)o.dev, n);
     }
     SH_HIP(hipGetLastError());
     SH_TRY(o.finish(s));
@@ -1314,10 +1467,7 @@ sdsl_hip_status rrr_launch_select(const RrrView & v, int bit, const uint64_t * d
     if (n == 0)
         return SDSL_HIP_OK;
     KernelTimer t(s);
-    if (bit)
-        hipLaunchKernelGGL(rrr_select_kernel<1>(), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v, d_i, d_out, n);
-    else
-        hipLaunchKernelGGL(rrr_select_kernel<0>(), dim3(rrr_grid(n)), dim3(kRrrBlock), 0, s, v, d_i, d_out, n);
+    rrr_launch_select_direct(v, bit, d_i, d_out, n, s);
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }
@@ -1342,12 +1492,7 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
         return host_pipeline_u64(v->h.device, i, out, n,
                                  [rv, bit](const uint64_t * d_in, uint64_t * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
                                  {
-                                     if (bit)
-                                         hipLaunchKernelGGL(rrr_select_kernel<1>(), dim3(rrr_grid(cnt)), dim3(kRrrBlock), 0, st, rv,
-                                                            d_in, d_out, cnt);
-                                     else
-                                         hipLaunchKernelGGL(rrr_select_kernel<0>(), dim3(rrr_grid(cnt)), dim3(kRrrBlock), 0, st, rv,
-                                                            d_in, d_out, cnt);
+                                     rrr_launch_select_direct(rv, bit, d_in, d_out, cnt, st);
                                      SH_HIP(hipGetLastError());
                                      return SDSL_HIP_OK;
                                  });

@@ -35,6 +35,7 @@ struct RrrTables
     // (0 if C == 1), 63 — the block itself — for the classes in between (see RAW classes below)
     uint8_t space[64];
     uint8_t sdsl_space[64]; // SDSL's width of the offset field, hi(C(63,k))+1 for every class (parser / serialiser)
+    uint8_t space2[256];    // space[b & 15] + space[b >> 4]: two 4-bit class fields of the slim record format at once
 };
 
 // RAW classes.  Decoding a block from its offset costs one bisection per set (or, via the complement, unset) bit, and a WAVE
@@ -60,6 +61,7 @@ struct RrrView
     // automatic dispatch of large batches (rrr.hip): the direct rank kernel returns at once when this word is non-zero (the batch
     // is then answered by the bucketed path enqueued beside it, rrr_sorted.hip); nullptr everywhere else
     const uint32_t * skip_if;
+    uint32_t fmt; // record format: 0 = RrrFmtW (34 blocks, 7-bit classes), 1 = RrrFmtS (42 blocks, 4-bit classes)
 };
 
 // ---- device: block decoder -----------------------------------------------------------------------
@@ -146,23 +148,28 @@ constexpr uint64_t kCls63 = UINT64_C(0x3F) * ((UINT64_C(1) << 0) | (UINT64_C(1) 
                                                | (UINT64_C(1) << 35) | (UINT64_C(1) << 42) | (UINT64_C(1) << 49) | (UINT64_C(1) << 56)); // 63 in every field
 
 // offset field of `len` bits at relative position `rel` of record `r`: the record's offsets are the words of its inline
-// area (nine) followed by the words of its stretch of the stream (from word `ptr` on: a stretch starts at a word boundary,
+// area followed by the words of its stretch of the stream (from word `ptr` on: a stretch starts at a word boundary,
 // so the seam needs no special case — a field simply takes its two words from wherever they live)
-__device__ __forceinline__ uint64_t rrr_field(const RrrView & v, const uint64_t * r, uint64_t ptr, unsigned rel,
-                                              unsigned len)
+template <unsigned INL0, unsigned INLW>
+__device__ __forceinline__ uint64_t rrr_field_t(const RrrView & v, const uint64_t * r, uint64_t ptr, unsigned rel, unsigned len)
 {
     if (len == 0)
         return 0;
     const unsigned w = rel >> 6, o = rel & 63;
-    const uint64_t * far = v.stream + ptr - kInlineWords; // word w of the record's offsets, w >= 9
-    const uint64_t * p0 = w < kInlineWords ? r + kRecInline + w : far + w;
+    const uint64_t * far = v.stream + ptr - INLW; // word w of the record's offsets, w >= INLW
+    const uint64_t * p0 = w < INLW ? r + INL0 + w : far + w;
     uint64_t x = *p0 >> o;
     if (o + len > 64)
     {
-        const uint64_t * p1 = w + 1 < kInlineWords ? r + kRecInline + w + 1 : far + w + 1;
+        const uint64_t * p1 = w + 1 < INLW ? r + INL0 + w + 1 : far + w + 1;
         x |= *p1 << (64 - o);
     }
     return x & lo_set(len);
+}
+__device__ __forceinline__ uint64_t rrr_field(const RrrView & v, const uint64_t * r, uint64_t ptr, unsigned rel,
+                                              unsigned len)
+{
+    return rrr_field_t<kRecInline, kInlineWords>(v, r, ptr, rel, len);
 }
 
 // sum of the nine 7-bit fields of x (each <= 63)
@@ -185,6 +192,82 @@ __device__ __forceinline__ unsigned rrr_space_sum9(const RrrTables * T, uint64_t
 #pragma unroll
     for (int t = 0; t < 5; ++t)
         bits += T->space[(t < 4 ? (hi >> (7 * t)) : (unsigned)(m >> 56)) & 0x7Fu];
+    return bits;
+}
+
+// ---- the two record formats -------------------------------------------------------------------------
+// W ("wide", everything above): 34 blocks, 7-bit classes, three header words.  Right for the vectors of a wavelet tree (classes
+// around 31, raw blocks) and for anything dense; 0.478 bits per bit before the first overflow word.
+// S ("slim"): for SPARSE vectors, where the classes are most of the overhead.  42 blocks per 128-byte record (2646 bits):
+//   word 0      bits 0..39 ones before the record | 40..49 ones in blocks [0,16) | 50..60 ones in blocks [0,32)
+//   word 1      bits 0..32 WORD pointer into the overflow stream | 33..42 offset bits of blocks [0,16) | 43..53 of [0,32)
+//               | 54..63 ones in blocks [32,42)
+//   words 2..4  the 42 classes as 4-bit fields, sixteen per word (ten in the last).  Field 15 is an ESCAPE: the block has 15 or
+//               more ones and its field in the offsets is the block itself (63 bits); its class is the popcount of that.  (In a
+//               vector of density 5 % one block in 2.5 million has 15 ones; the slow paths below are correct for any number.)
+//   words 5..15 the first 704 bits of the record's offsets
+// 2^34 bits at 5 %: 682 +- 51 offset bits per record: 0.40 bits per bit all in (W: 0.488, SDSL: 0.37), and as with W-34 fewer than
+// 2 % of the queries need a second fetch.  Chosen per vector when it is built (rrr.hip, choose_format).
+struct RrrFmtW
+{
+    static constexpr unsigned id = 0, K = kRecK, GRP = kGrp, NCW = 4, CLS0 = kRecClasses, INL0 = kRecInline, INLW = kInlineWords;
+    static constexpr unsigned INLB = kInlineBits;
+    static constexpr uint64_t SB = kRecSB;
+    static SH_HD uint64_t ones_before(uint64_t r0) { return r0; }
+    static SH_HD uint64_t ptr(uint64_t r1) { return r1 & ((UINT64_C(1) << 48) - 1); }
+};
+struct RrrFmtS
+{
+    static constexpr unsigned id = 1, K = 42, GRP = 16, NCW = 3, CLS0 = 2, INL0 = 5, INLW = 11;
+    static constexpr unsigned INLB = 64 * INLW; // 704
+    static constexpr uint64_t SB = (uint64_t)kRrrBS * K; // 2646
+    static SH_HD uint64_t ones_before(uint64_t r0) { return r0 & ((UINT64_C(1) << 40) - 1); }
+    static SH_HD uint64_t ptr(uint64_t r1) { return r1 & ((UINT64_C(1) << 33) - 1); }
+};
+constexpr unsigned kEsc = 15;            // class field of an escaped block (format S)
+constexpr uint64_t kSlimMaxStream = UINT64_C(1) << 33; // words of overflow stream a slim vector may have
+
+SH_HD uint64_t rrs_pack0(uint64_t ones_before, unsigned o16, unsigned o32)
+{
+    return ones_before | ((uint64_t)o16 << 40) | ((uint64_t)o32 << 50);
+}
+SH_HD uint64_t rrs_pack1(uint64_t ptr, unsigned b16, unsigned b32, unsigned ones3)
+{
+    return ptr | ((uint64_t)b16 << 33) | ((uint64_t)b32 << 43) | ((uint64_t)ones3 << 54);
+}
+SH_HD void rrs_prefix(uint64_t r0, uint64_t r1, unsigned g, unsigned & ones, unsigned & bits)
+{ // g in [0,2]: ones and offset bits in blocks [0, 16 g)
+    ones = g == 0 ? 0u : (g == 1 ? (unsigned)(r0 >> 40) & 0x3FFu : (unsigned)(r0 >> 50) & 0x7FFu);
+    bits = g == 0 ? 0u : (g == 1 ? (unsigned)(r1 >> 33) & 0x3FFu : (unsigned)(r1 >> 43) & 0x7FFu);
+}
+SH_HD unsigned rrs_ones_in(uint64_t r0, uint64_t r1)
+{
+    return ((unsigned)(r0 >> 50) & 0x7FFu) + (unsigned)(r1 >> 54);
+}
+SH_HD unsigned rrs_cls(uint64_t cw, unsigned u)
+{
+    return (unsigned)(cw >> (4 * u)) & 15u;
+}
+SH_HD uint64_t rrs_below(uint64_t cw, unsigned u)
+{ // the fields of blocks 0..u-1, u in [0,16]
+    return u >= 16 ? cw : cw & ((UINT64_C(1) << (4 * u)) - 1);
+}
+SH_HD unsigned rrs_sum16(uint64_t x)
+{ // sum of the sixteen 4-bit fields
+    const uint64_t t = (x & UINT64_C(0x0F0F0F0F0F0F0F0F)) + ((x >> 4) & UINT64_C(0x0F0F0F0F0F0F0F0F)); // bytes <= 30
+    return (unsigned)((t * UINT64_C(0x0101010101010101)) >> 56);
+}
+SH_HD uint64_t rrs_esc(uint64_t x)
+{ // bit 4u set for every field u that holds the escape
+    return x & (x >> 1) & (x >> 2) & (x >> 3) & UINT64_C(0x1111111111111111);
+}
+__device__ __forceinline__ unsigned rrs_space_sum(const RrrTables * T, uint64_t m)
+{ // offset bits of the fields of m (an escape: 63; a zero field: 0)
+    const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+    unsigned bits = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        bits += T->space2[(lo >> (8 * t)) & 0xFFu] + T->space2[(hi >> (8 * t)) & 0xFFu];
     return bits;
 }
 
@@ -218,11 +301,53 @@ __device__ __forceinline__ RankTail rrr_rank_head(const RrrView & v, const RrrTa
     return t;
 }
 
+// the same on a slim record
+__device__ __forceinline__ RankTail rrs_rank_head(const RrrView & v, const RrrTables * T, uint64_t i)
+{
+    using F = RrrFmtS;
+    RankTail t;
+    const uint64_t sb = i / F::SB;
+    const unsigned in_sb = (unsigned)(i - sb * F::SB), j = in_sb / kRrrBS, g = j / F::GRP, u = j - g * F::GRP;
+    t.off = in_sb - j * kRrrBS;
+    const uint64_t * r = (const uint64_t *)__builtin_assume_aligned(v.rec + sb * kRecWords, 128);
+    const uint64_t r0 = r[0], r1 = r[1];
+    const uint64_t cw = r[F::CLS0 + g];
+    unsigned ones, bits;
+    rrs_prefix(r0, r1, g, ones, bits);
+    const uint64_t below = rrs_below(cw, u), ptr = F::ptr(r1);
+    uint64_t esc = rrs_esc(below);
+    if (esc)
+    { // an escaped block in front: its field counted 15, the block says how many it really has
+        do
+        {
+            const unsigned e = (unsigned)__builtin_ctzll(esc) >> 2;
+            esc &= esc - 1;
+            const uint64_t raw = rrr_field_t<F::INL0, F::INLW>(v, r, ptr, bits + rrs_space_sum(T, rrs_below(cw, e)), kRrrBS);
+            ones += popc64(raw) - kEsc;
+        } while (esc);
+    }
+    ones += rrs_sum16(below);
+    bits += rrs_space_sum(T, below);
+    t.rank = F::ones_before(r0) + ones;
+    t.k = rrs_cls(cw, u); // (an escape decodes as class 15: raw, like every class from 11 to 52)
+    t.nr = rrr_field_t<F::INL0, F::INLW>(v, r, ptr, bits, T->space[t.k]);
+    return t;
+}
+template <class F>
+__device__ __forceinline__ RankTail rrr_rank_head_f(const RrrView & v, const RrrTables * T, uint64_t i)
+{
+    if constexpr (F::id == 0)
+        return rrr_rank_head(v, T, i);
+    else
+        return rrs_rank_head(v, T, i);
+}
+
 // rank_1(pos); optionally the bit at pos (pos < n_bits then)
+template <class F = RrrFmtW>
 __device__ __forceinline__ uint64_t rrr_rank1(const RrrView & v, const RrrTables * T, uint64_t pos,
                                               unsigned * bit_out = nullptr)
 {
-    const RankTail t = rrr_rank_head(v, T, pos);
+    const RankTail t = rrr_rank_head_f<F>(v, T, pos);
     uint64_t bits = 0;
     if (bit_out || t.off != 0) // rank at a block boundary needs no decode
         bits = rrr_decode_block(T, t.k, t.nr, t.off + (bit_out ? 1u : 0u));
@@ -294,7 +419,7 @@ __device__ __forceinline__ void rrr_sel_init(const RrrView & v, RrrSelState & st
 }
 
 // one probe; true when superblock h.g holds the argument
-template <int BIT>
+template <int BIT, class F = RrrFmtW>
 __device__ __forceinline__ bool rrr_sel_probe(const RrrView & v, RrrSelState & st, RrrSelHit & h)
 {
     const uint64_t span = st.hi_pos - st.lo_pos;
@@ -304,7 +429,7 @@ __device__ __forceinline__ bool rrr_sel_probe(const RrrView & v, RrrSelState & s
     else
         p = sel_interpolate(st.lo_pos, span, st.k0 - st.lo_cnt, st.hi_cnt - st.lo_cnt, v.sel_shift[BIT]);
     ++st.tries;
-    uint64_t g = p / kRecSB;
+    uint64_t g = p / F::SB;
     if (g >= v.n_sb)
         g = v.n_sb - 1;
     const uint64_t * r = (const uint64_t *)__builtin_assume_aligned(v.rec + g * kRecWords, 128);
@@ -313,15 +438,29 @@ __device__ __forceinline__ bool rrr_sel_probe(const RrrView & v, RrrSelState & s
     h.g = g;
     h.r1 = r[1];
     // prefix and class words ride along (same line, no extra latency): needed as soon as the probe hits
-    h.P = r[2];
-    h.c0 = r[kRecClasses];
-    h.c1 = r[kRecClasses + 1];
-    h.c2 = r[kRecClasses + 2];
-    h.c3 = r[kRecClasses + 3];
-    const uint64_t ones_in = (h.r1 >> 48) & 0xFFF;
-    const uint64_t start = g * kRecSB;
-    const uint64_t len_in = v.n_bits - start < kRecSB ? v.n_bits - start : kRecSB;
-    h.before = BIT ? r0 : start - r0;
+    uint64_t ones_in;
+    if constexpr (F::id == 0)
+    {
+        h.P = r[2];
+        h.c0 = r[kRecClasses];
+        h.c1 = r[kRecClasses + 1];
+        h.c2 = r[kRecClasses + 2];
+        h.c3 = r[kRecClasses + 3];
+        ones_in = (h.r1 >> 48) & 0xFFF;
+    }
+    else
+    {
+        h.P = r0; // (the slim format keeps its prefix counts in the two header words)
+        h.c0 = r[F::CLS0];
+        h.c1 = r[F::CLS0 + 1];
+        h.c2 = r[F::CLS0 + 2];
+        h.c3 = 0;
+        ones_in = rrs_ones_in(r0, h.r1);
+    }
+    const uint64_t before1 = F::ones_before(r0);
+    const uint64_t start = g * F::SB;
+    const uint64_t len_in = v.n_bits - start < F::SB ? v.n_bits - start : F::SB;
+    h.before = BIT ? before1 : start - before1;
     const uint64_t c = BIT ? ones_in : len_in - ones_in;
     if (st.k0 < h.before)
     {
@@ -331,7 +470,7 @@ __device__ __forceinline__ bool rrr_sel_probe(const RrrView & v, RrrSelState & s
     }
     if (st.k0 >= h.before + c)
     {
-        st.lo_pos = start + kRecSB;
+        st.lo_pos = start + F::SB;
         st.lo_cnt = h.before + c;
         return false;
     }
@@ -347,7 +486,7 @@ struct RrrSelLoc
 };
 
 template <int BIT>
-__device__ __forceinline__ RrrSelLoc rrr_sel_locate(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
+__device__ __forceinline__ RrrSelLoc rrr_sel_locate_w(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
 {
     const uint64_t g = h.g, before = h.before, P = h.P, c0 = h.c0, c1 = h.c1, c2 = h.c2, c3 = h.c3;
     // inside record g: the group of 9 blocks.  Zeros before block 9q are 567q - ones (every block in front of
@@ -421,15 +560,84 @@ __device__ __forceinline__ RrrSelLoc rrr_sel_locate(const RrrView & v, const Rrr
     return L;
 }
 
+// the same on a slim record: two prefix counts pick the group of sixteen blocks, a bisection over running sums of its 4-bit
+// fields the block
+template <int BIT>
+__device__ __forceinline__ RrrSelLoc rrr_sel_locate_s(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
+{
+    using F = RrrFmtS;
+    unsigned want = (unsigned)(k0 - h.before);
+    unsigned o[3], b[3];
+    rrs_prefix(h.P, h.r1, 0, o[0], b[0]);
+    rrs_prefix(h.P, h.r1, 1, o[1], b[1]);
+    rrs_prefix(h.P, h.r1, 2, o[2], b[2]);
+    unsigned q = 0;
+#pragma unroll
+    for (unsigned t = 1; t < 3; ++t)
+        q += want >= (BIT ? o[t] : F::GRP * kRrrBS * t - o[t]) ? 1u : 0u;
+    unsigned rel = q == 0 ? 0u : (q == 1 ? b[1] : b[2]);
+    const unsigned oq = q == 0 ? 0u : (q == 1 ? o[1] : o[2]);
+    want -= BIT ? oq : F::GRP * kRrrBS * q - oq;
+    const uint64_t cw = q == 0 ? h.c0 : (q == 1 ? h.c1 : h.c2);
+    const uint64_t ptr = F::ptr(h.r1);
+    unsigned u = 0;
+    if (!rrs_esc(cw))
+    { // largest u with (arguments in blocks [0, u) of the group) <= want.  Blocks in front of the one that holds an existing
+      // argument are complete, and phantom blocks behind the end of the vector lie behind it: 63 u - ones is exact where it matters
+#pragma unroll
+        for (unsigned step = 8; step; step >>= 1)
+        {
+            const unsigned c = u + step, ob = rrs_sum16(rrs_below(cw, c));
+            if ((BIT ? ob : kRrrBS * c - ob) <= want)
+                u = c;
+        }
+        const unsigned ob = rrs_sum16(rrs_below(cw, u));
+        want -= BIT ? ob : kRrrBS * u - ob;
+        rel += rrs_space_sum(T, rrs_below(cw, u));
+    }
+    else
+    { // an escaped block in the group: walk it, asking the blocks themselves
+        for (;; ++u)
+        {
+            const unsigned c = rrs_cls(cw, u);
+            unsigned k = c;
+            if (c == kEsc)
+                k = popc64(rrr_field_t<F::INL0, F::INLW>(v, h.r, ptr, rel, kRrrBS));
+            const unsigned a = BIT ? k : kRrrBS - k;
+            if (want < a || u == F::GRP - 1)
+                break;
+            want -= a;
+            rel += T->space[c];
+        }
+    }
+    RrrSelLoc L;
+    L.rel = rel;
+    L.k = rrs_cls(cw, u);
+    L.bstart = (h.g * F::K + F::GRP * (uint64_t)q + u) * kRrrBS;
+    L.ptr = ptr;
+    L.want = want;
+    return L;
+}
+template <int BIT, class F = RrrFmtW>
+__device__ __forceinline__ RrrSelLoc rrr_sel_locate(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
+{
+    if constexpr (F::id == 0)
+        return rrr_sel_locate_w<BIT>(v, T, k0, h);
+    else
+        return rrr_sel_locate_s<BIT>(v, T, k0, h);
+}
+
 // does the offset field of the located block reach into the overflow stream (a second, random fetch)?
+template <class F = RrrFmtW>
 __device__ __forceinline__ bool rrr_sel_in_stream(const RrrTables * T, const RrrSelLoc & L)
 {
-    return L.rel + T->space[L.k] > kInlineBits;
+    return L.rel + T->space[L.k] > F::INLB;
 }
 // the field of a block for which rrr_sel_in_stream is false
+template <class F = RrrFmtW>
 __device__ __forceinline__ uint64_t rrr_field_inline(const uint64_t * r, unsigned rel, unsigned len)
 {
-    return read_bits(r + kRecInline, rel, len);
+    return read_bits(r + F::INL0, rel, len);
 }
 
 template <int BIT>
@@ -444,31 +652,31 @@ __device__ __forceinline__ uint64_t rrr_sel_decode(const RrrView & v, const RrrT
     return L.bstart + sel64(bits, L.want + 1);
 }
 
-template <int BIT>
+template <int BIT, class F = RrrFmtW>
 __device__ __forceinline__ uint64_t rrr_sel_finish(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
 {
-    const RrrSelLoc L = rrr_sel_locate<BIT>(v, T, k0, h);
-    return rrr_sel_decode<BIT>(v, T, L, rrr_field(v, h.r, L.ptr, L.rel, T->space[L.k]));
+    const RrrSelLoc L = rrr_sel_locate<BIT, F>(v, T, k0, h);
+    return rrr_sel_decode<BIT>(v, T, L, rrr_field_t<F::INL0, F::INLW>(v, h.r, L.ptr, L.rel, T->space[L.k]));
 }
 
-template <int BIT>
+template <int BIT, class F = RrrFmtW>
 __device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTables * T, uint64_t k0, uint32_t smp0,
                                                uint32_t smp1)
 {
     RrrSelState st;
     RrrSelHit h;
     rrr_sel_init<BIT>(v, st, k0, smp0, smp1);
-    while (!rrr_sel_probe<BIT>(v, st, h))
+    while (!rrr_sel_probe<BIT, F>(v, st, h))
     {
     }
-    return rrr_sel_finish<BIT>(v, T, k0, h);
+    return rrr_sel_finish<BIT, F>(v, T, k0, h);
 }
 
-template <int BIT>
+template <int BIT, class F = RrrFmtW>
 __device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTables * T, uint64_t k0)
 {
     const uint64_t js = k0 >> v.sel_shift[BIT];
-    return rrr_select<BIT>(v, T, k0, v.sel[BIT][js], v.sel[BIT][js + 1]);
+    return rrr_select<BIT, F>(v, T, k0, v.sel[BIT][js], v.sel[BIT][js + 1]);
 }
 
 } // namespace sdslhip

@@ -13,6 +13,8 @@ struct RrrHost
     RrrView view{};
     DevBuf rec, stream, tables, sel[2];
     unsigned sparse_max = 10; // classes sparse_max + 1 .. 62 - sparse_max are stored raw (rrr_device.hpp)
+    unsigned fmt = 0;         // record format (rrr_device.hpp: RrrFmtW / RrrFmtS); the vectors of a wavelet tree are always wide
+    bool allow_slim = false;  // set by the stand-alone handle before the vector is built
     DevBuf sort_scratch, spread_probe; // working memory of the bucketed batch rank (rrr_sorted.hip), grown on demand
     struct SelPlan // buckets of the bucketed batch select (rrr_sorted.hip), built on first use
     {

@@ -19,29 +19,36 @@ namespace sdslhip {
 
 namespace {
 
-static_assert(kSrRecBits == kRecSB, "bv_sorted_dev.hpp: kSrRecBits must be the record length of rrr_device.hpp");
+static_assert(kSrRecBits == RrrFmtW::SB && kSrRecBitsSlim == RrrFmtS::SB, "bv_sorted_dev.hpp: kSrRecBits* must be the record lengths of rrr_device.hpp");
 constexpr unsigned kRsT = 1024;      // threads of an answering block
 constexpr unsigned kRsCols = 12;     // binomial columns the sparse decoder needs (classes <= 10 after the complement)
 constexpr unsigned kRsBins = 16;     // decode-cost classes of the per-slice counting sort
 
+// Records are decoded in CHUNKS of a slice (wide records: the whole slice; slim ones, 42 blocks each: half of it, so that two
+// answering blocks still fit a CU): what only the decoder needs is sized for a chunk (NC blocks), what the keys read for the slice.
+template <class F>
+constexpr unsigned rs_chunks()
+{
+    return F::id ? 2u : 1u;
+}
 struct RsLds
-{ // carved out of dynamic LDS; NB = blocks of a slice
+{ // carved out of dynamic LDS; NB = blocks of a slice, NC = blocks of a chunk
     uint64_t * raw;      // [NB] the slice's blocks, plain
     uint64_t * cbin;     // [64][kRsCols]
     uint64_t * top;      // [64]: C(63, k)
     uint64_t * rptr;     // [S]: first word of the record's stretch of the overflow stream
     uint32_t * rones;    // [S]: ones in front of the record, relative to the slice
     uint16_t * pre;      // [NB] ones of the record in front of the block
-    uint16_t * obit;     // [NB] where the block's field starts in the record's offset bits
-    uint16_t * ord;      // [NB] blocks in order of decode cost
-    uint8_t * cls;       // [NB]
+    uint16_t * obit;     // [NC] where the block's field starts in the record's offset bits
+    uint16_t * ord;      // [NC] blocks in order of decode cost
+    uint8_t * cls;       // [NC] class fields
     uint8_t * space;     // [64]
     unsigned * cnt;      // [kRsBins + 1]
 };
 
-__device__ __forceinline__ RsLds rs_carve(unsigned char * base, unsigned S)
+__device__ __forceinline__ RsLds rs_carve(unsigned char * base, unsigned S, unsigned K, unsigned chunks)
 {
-    const unsigned NB = S * kRecK;
+    const unsigned NB = S * K, NC = NB / chunks;
     RsLds L;
     unsigned char * p = base;
     auto take = [&](size_t bytes) -> unsigned char *
@@ -56,19 +63,20 @@ __device__ __forceinline__ RsLds rs_carve(unsigned char * base, unsigned S)
     L.rptr = (uint64_t *)take((size_t)S * 8);
     L.rones = (uint32_t *)take((size_t)S * 4);
     L.pre = (uint16_t *)take((size_t)NB * 2);
-    L.obit = (uint16_t *)take((size_t)NB * 2);
-    L.ord = (uint16_t *)take((size_t)NB * 2);
-    L.cls = (uint8_t *)take(NB);
+    L.obit = (uint16_t *)take((size_t)NC * 2);
+    L.ord = (uint16_t *)take((size_t)NC * 2);
+    L.cls = (uint8_t *)take(NC);
     L.space = (uint8_t *)take(64);
     L.cnt = (unsigned *)take((kRsBins + 1) * 4);
     return L;
 }
 
-size_t rs_lds_bytes(unsigned S)
+size_t rs_lds_bytes(unsigned S, unsigned fmt)
 {
-    const size_t NB = (size_t)S * kRecK;
+    const size_t NB = (size_t)S * (fmt ? RrrFmtS::K : RrrFmtW::K), NC = NB / (fmt ? rs_chunks<RrrFmtS>() : rs_chunks<RrrFmtW>());
     auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    return up(NB * 8) + up(64 * kRsCols * 8) + up(64 * 8) + up((size_t)S * 8) + up((size_t)S * 4) + 3 * up(NB * 2) + up(NB) + up(64) + up((kRsBins + 1) * 4);
+    return up(NB * 8) + up(64 * kRsCols * 8) + up(64 * 8) + up((size_t)S * 8) + up((size_t)S * 4) + up(NB * 2) + 2 * up(NC * 2) + up(NC) + up(64)
+           + up((kRsBins + 1) * 4);
 }
 
 // the block of class k whose field holds f, with the compact tables (rrr_decode_block, rrr_device.hpp)
@@ -104,65 +112,88 @@ __device__ __forceinline__ uint64_t rs_decode(const RsLds & L, unsigned k, uint6
 
 // The records [recs, recs + nrec) as plain blocks in LDS: classes / ones / offset bits in front of every block, the blocks
 // in order of decode cost, every block decoded once.  All threads of the block; L.cnt must be zero on entry; ends with a barrier.
-__device__ __forceinline__ void rs_decode_records(const RsLds & L, const RrrView & v, const uint64_t * recs, unsigned nrec)
+// S: records of a slice (a chunk holds S / rs_chunks of them).
+template <class F>
+__device__ __forceinline__ void rs_decode_records(const RsLds & L, const RrrView & v, const uint64_t * recs, unsigned nrec, unsigned S)
 {
-    const unsigned t = threadIdx.x, nb = nrec * kRecK;
-    // 1. per (record, group of nine blocks): classes, ones and offset bits in front of every block
-    const uint64_t ones0 = recs[0];
-    for (unsigned x = t; x < nrec * 4; x += kRsT)
+    const unsigned t = threadIdx.x, CH = S / rs_chunks<F>();
+    const uint64_t ones0 = F::ones_before(recs[0]);
+    for (unsigned c0 = 0; c0 < nrec; c0 += CH)
     {
-        const unsigned r = x >> 2, gi = x & 3;
-        const uint64_t * rec = recs + (uint64_t)r * kRecWords;
-        const uint64_t P = rec[2], cw = rec[kRecClasses + gi];
-        unsigned ones, bits;
-        rrr_prefix(P, gi, ones, bits);
-        if (gi == 0)
+        const unsigned nr = nrec - c0 < CH ? nrec - c0 : CH, nb = nr * F::K;
+        if (c0)
         {
-            L.rones[r] = (uint32_t)(rec[0] - ones0);
-            L.rptr[r] = rec[1] & ((UINT64_C(1) << 48) - 1);
+            for (unsigned i = t; i <= kRsBins; i += kRsT)
+                L.cnt[i] = 0;
+            __syncthreads();
         }
-        const unsigned nblk = gi < 3 ? kGrp : kRecK - 3 * kGrp;
-        for (unsigned u = 0; u < nblk; ++u)
+        // 1. per (record, group of blocks): classes, ones and offset bits in front of every block
+        for (unsigned x = t; x < nr * F::NCW; x += kRsT)
         {
-            const unsigned k = rrr_cls(cw, u), b = r * kRecK + gi * kGrp + u, len = L.space[k];
-            L.cls[b] = (uint8_t)k;
-            L.pre[b] = (uint16_t)ones;
-            L.obit[b] = (uint16_t)bits;
-            ones += k;
-            bits += len;
-            // decode cost: nothing for the raw classes and for k = 0 / 63, else the set bits the decoder walks
+            const unsigned lr = x / F::NCW, gi = x - lr * F::NCW, r = c0 + lr;
+            const uint64_t * rec = recs + (uint64_t)r * kRecWords;
+            const uint64_t r0 = rec[0], r1 = rec[1], cw = rec[F::CLS0 + gi];
+            unsigned ones, bits;
+            if constexpr (F::id == 0)
+                rrr_prefix(rec[2], gi, ones, bits);
+            else
+                rrs_prefix(r0, r1, gi, ones, bits);
+            if (gi == 0)
+            {
+                L.rones[r] = (uint32_t)(F::ones_before(r0) - ones0);
+                L.rptr[r] = F::ptr(r1);
+            }
+            const unsigned nblk = gi + 1 < F::NCW ? F::GRP : F::K - (F::NCW - 1) * F::GRP;
+            for (unsigned u = 0; u < nblk; ++u)
+            {
+                unsigned k;
+                if constexpr (F::id == 0)
+                    k = rrr_cls(cw, u);
+                else
+                    k = rrs_cls(cw, u);
+                const unsigned lb = lr * F::K + gi * F::GRP + u, len = L.space[k];
+                L.cls[lb] = (uint8_t)k;
+                L.pre[c0 * F::K + lb] = (uint16_t)ones;
+                L.obit[lb] = (uint16_t)bits;
+                unsigned real = k;
+                if (F::id && k == kEsc) // an escaped block says how many ones it has
+                    real = popc64(rrr_field_t<F::INL0, F::INLW>(v, rec, F::ptr(r1), bits, kRrrBS));
+                ones += real;
+                bits += len;
+                // decode cost: nothing for the raw classes and for k = 0 / 63, else the set bits the decoder walks
+                const unsigned c = rrr_raw_width(len) ? 0u : (k > 31 ? kRrrBS - k : k);
+                atomicAdd(&L.cnt[c < kRsBins ? c : kRsBins - 1], 1u);
+            }
+        }
+        __syncthreads();
+        // 2. exclusive scan of the cost classes (sixteen values: one thread), then the order
+        if (t == 0)
+        {
+            unsigned run = 0;
+            for (unsigned c = 0; c < kRsBins; ++c)
+            {
+                const unsigned x = L.cnt[c];
+                L.cnt[c] = run;
+                run += x;
+            }
+        }
+        __syncthreads();
+        for (unsigned b = t; b < nb; b += kRsT)
+        {
+            const unsigned k = L.cls[b], len = L.space[k];
             const unsigned c = rrr_raw_width(len) ? 0u : (k > 31 ? kRrrBS - k : k);
-            atomicAdd(&L.cnt[c < kRsBins ? c : kRsBins - 1], 1u);
+            L.ord[atomicAdd(&L.cnt[c < kRsBins ? c : kRsBins - 1], 1u)] = (uint16_t)b;
         }
-    }
-    __syncthreads();
-    // 2. exclusive scan of the cost classes (sixteen values: one thread), then the order
-    if (t == 0)
-    {
-        unsigned run = 0;
-        for (unsigned c = 0; c < kRsBins; ++c)
+        __syncthreads();
+        // 3. every block decoded once; the lanes of a wave hold blocks of one cost class
+        for (unsigned i = t; i < nb; i += kRsT)
         {
-            const unsigned x = L.cnt[c];
-            L.cnt[c] = run;
-            run += x;
+            const unsigned b = L.ord[i], r = c0 + b / F::K, k = L.cls[b], len = L.space[k];
+            const uint64_t fld = rrr_field_t<F::INL0, F::INLW>(v, recs + (uint64_t)r * kRecWords, L.rptr[r], L.obit[b], len);
+            L.raw[c0 * F::K + b] = rs_decode(L, k, fld);
         }
+        __syncthreads();
     }
-    __syncthreads();
-    for (unsigned b = t; b < nb; b += kRsT)
-    {
-        const unsigned k = L.cls[b], len = L.space[k];
-        const unsigned c = rrr_raw_width(len) ? 0u : (k > 31 ? kRrrBS - k : k);
-        L.ord[atomicAdd(&L.cnt[c < kRsBins ? c : kRsBins - 1], 1u)] = (uint16_t)b;
-    }
-    __syncthreads();
-    // 3. every block decoded once; the lanes of a wave hold blocks of one cost class
-    for (unsigned i = t; i < nb; i += kRsT)
-    {
-        const unsigned b = L.ord[i], r = b / kRecK, k = L.cls[b], len = L.space[k];
-        const uint64_t fld = rrr_field(v, recs + (uint64_t)r * kRecWords, L.rptr[r], L.obit[b], len);
-        L.raw[b] = rs_decode(L, k, fld);
-    }
-    __syncthreads();
 }
 
 // ones in front of every slice of records
@@ -172,12 +203,13 @@ __global__ __launch_bounds__(256) void k_rs_slice_bases(RrrView v, unsigned nf, 
     if (f < nf)
     {
         const uint64_t r0 = (uint64_t)f << rlog;
-        hf[f] = r0 < v.n_sb ? v.rec[r0 * kRecWords] : 0;
+        hf[f] = r0 < v.n_sb ? (v.fmt ? RrrFmtS::ones_before(v.rec[r0 * kRecWords]) : v.rec[r0 * kRecWords]) : 0;
     }
 }
 
 // ---- rank out of LDS, in place over the final keys -------------------------------------------------------------------
 // key = [record in the slice : 8 | block in the record : 6 | bits of the block in front of the position : 6 (0..63)]
+template <class F>
 __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsigned nf, unsigned rlog, const uint32_t * __restrict__ fstart,
                                                       const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys,
                                                       const uint32_t * __restrict__ go)
@@ -187,7 +219,7 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
     if (go && !*go)
         return;
     const unsigned S = 1u << rlog, t = threadIdx.x;
-    const RsLds L = rs_carve(rs_lds, S);
+    const RsLds L = rs_carve(rs_lds, S, F::K, rs_chunks<F>());
     // the tables the decoder reads, once per block of threads
     for (unsigned i = t; i < 64 * kRsCols; i += kRsT)
         L.cbin[i] = v.tables->binom[i / kRsCols][i % kRsCols];
@@ -217,7 +249,7 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
         __syncthreads(); // also: everybody is done with the previous slice
         const unsigned f = __builtin_amdgcn_readfirstlane(sh_f);
         const uint64_t R0 = (uint64_t)f << rlog;
-        const unsigned nrec = (unsigned)(v.n_sb - R0 < S ? v.n_sb - R0 : S), nb = nrec * kRecK;
+        const unsigned nrec = (unsigned)(v.n_sb - R0 < S ? v.n_sb - R0 : S);
         const uint64_t * recs = v.rec + R0 * kRecWords;
         const uint64_t lo = (uint64_t)fstart[f] + (uint64_t)(item - ioff[f]) * kItemKeys;
         const uint64_t fend = fstart[f + 1];
@@ -228,7 +260,7 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
 #pragma unroll
         for (int u = 0; u < U; ++u)
             buf_load(rs_k, t * 4u, (unsigned)u * kRsT * 4u, key[u]); // (the first keys travel while the slice is decoded)
-        rs_decode_records(L, v, recs, nrec);
+        rs_decode_records<F>(L, v, recs, nrec, S);
         // 4. the keys
         for (unsigned i0 = 0; i0 < cnt; i0 += kRsT * U)
         {
@@ -247,9 +279,9 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
                 uint32_t res = kBad;
                 if (kq != kBad)
                 {
-                    const unsigned r = (kq >> 12) & 255u, j = (kq >> 6) & 63u, o = kq & 63u, b = r * kRecK + j;
+                    const unsigned r = (kq >> 12) & 255u, j = (kq >> 6) & 63u, o = kq & 63u, b = r * F::K + j;
                     const uint32_t r1 = L.rones[r] + L.pre[b] + popc64(L.raw[b] & lo_set(o));
-                    res = bit ? r1 : r * (uint32_t)kRecSB + j * kRrrBS + o - r1;
+                    res = bit ? r1 : r * (uint32_t)F::SB + j * kRrrBS + o - r1;
                 }
                 __builtin_amdgcn_raw_buffer_store_b32(res, rs_k, (int)(t * 4u), (int)(i0 * 4u + (unsigned)u * kRsT * 4u), kAuxNT);
             }
@@ -269,7 +301,7 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
 // are already in LDS (records of the slice, blocks of the record) and sel64 inside the plain block.  A bucket that spans more
 // records than a slice holds (a sparse stretch) is left to the fix-up pass.  Answers: select_support_rrr<BIT,63>::select
 // (rrr_vector.hpp:639-726).
-template <int BIT>
+template <int BIT, class F>
 __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, unsigned rlog, unsigned B, const uint32_t * __restrict__ bnd,
                                                         const uint32_t * __restrict__ fstart, const uint32_t * __restrict__ ioff,
                                                         uint32_t * __restrict__ keys, uint32_t * __restrict__ any_marked,
@@ -280,7 +312,7 @@ __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, 
     if (go && !*go)
         return;
     const unsigned S = 1u << rlog, t = threadIdx.x;
-    const RsLds L = rs_carve(rs_lds, S);
+    const RsLds L = rs_carve(rs_lds, S, F::K, rs_chunks<F>());
     for (unsigned i = t; i < 64 * kRsCols; i += kRsT)
         L.cbin[i] = v.tables->binom[i / kRsCols][i % kRsCols];
     for (unsigned i = t; i < 64; i += kRsT)
@@ -332,11 +364,11 @@ __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, 
 #pragma unroll
         for (int u = 0; u < U; ++u)
             buf_load(rs_k, t * 4u, (unsigned)u * kRsT * 4u, key[u]);
-        rs_decode_records(L, v, recs, nrec);
-        const uint64_t ones0 = recs[0];
-        const uint64_t A0 = BIT ? ones0 : R0 * kRecSB - ones0; // arguments in front of the slice
+        rs_decode_records<F>(L, v, recs, nrec, S);
+        const uint64_t ones0 = F::ones_before(recs[0]);
+        const uint64_t A0 = BIT ? ones0 : R0 * F::SB - ones0; // arguments in front of the slice
         const unsigned t0 = (unsigned)((uint64_t)f * B - A0);   // rank of the bucket's first argument, relative to the slice
-        auto rargs = [&](unsigned r) -> unsigned { return BIT ? L.rones[r] : r * (unsigned)kRecSB - L.rones[r]; };
+        auto rargs = [&](unsigned r) -> unsigned { return BIT ? L.rones[r] : r * (unsigned)F::SB - L.rones[r]; };
         bool mk = false;
         for (unsigned i0 = 0; i0 < cnt; i0 += kRsT * U)
         {
@@ -367,8 +399,8 @@ __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, 
                             z = m;
                     }
                     unsigned want = tg - rargs(a);
-                    const unsigned b0 = a * kRecK;
-                    unsigned ja = 0, jz = kRecK; // last block of the record with (arguments of the record in front of it) <= want
+                    const unsigned b0 = a * F::K;
+                    unsigned ja = 0, jz = F::K; // last block of the record with (arguments of the record in front of it) <= want
                     while (jz - ja > 1)
                     {
                         const unsigned m = (ja + jz) >> 1;
@@ -380,7 +412,7 @@ __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, 
                     }
                     want -= BIT ? L.pre[b0 + ja] : ja * kRrrBS - L.pre[b0 + ja];
                     const uint64_t bits = BIT ? L.raw[b0 + ja] : ~L.raw[b0 + ja] & lo_set(kRrrBS);
-                    res = a * (uint32_t)kRecSB + ja * kRrrBS + sel64(bits, want + 1); // relative to the slice's first bit
+                    res = a * (uint32_t)F::SB + ja * kRrrBS + sel64(bits, want + 1); // relative to the slice's first bit
                 }
                 __builtin_amdgcn_raw_buffer_store_b32(res, rs_k, (int)(t * 4u), (int)(i0 * 4u + (unsigned)u * kRsT * 4u), kAuxNT);
             }
@@ -397,15 +429,16 @@ __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, 
 }
 
 // first bit of every bucket's first record (what makes a slice-relative position absolute)
-__global__ __launch_bounds__(256) void k_rs_select_bases(unsigned nf, unsigned n_buckets, const uint32_t * __restrict__ bnd, uint64_t * __restrict__ hf)
+__global__ __launch_bounds__(256) void k_rs_select_bases(unsigned nf, unsigned n_buckets, uint64_t rec_bits, const uint32_t * __restrict__ bnd,
+                                                         uint64_t * __restrict__ hf)
 {
     const unsigned f = blockIdx.x * 256 + threadIdx.x;
     if (f < nf)
-        hf[f] = f < n_buckets ? (uint64_t)bnd[f] * kRecSB : 0;
+        hf[f] = f < n_buckets ? (uint64_t)bnd[f] * rec_bits : 0;
 }
 
 // the arguments that were left over (kMark64 in the output): the direct search, one lane per marked answer
-template <int BIT>
+template <int BIT, class F>
 __global__ __launch_bounds__(kRrrBlock) void k_rs_select_fixup(RrrView v, const uint32_t * __restrict__ any_marked, const uint64_t * __restrict__ iq,
                                                                uint64_t * __restrict__ out, uint64_t n, const uint32_t * __restrict__ go)
 {
@@ -417,7 +450,7 @@ __global__ __launch_bounds__(kRrrBlock) void k_rs_select_fixup(RrrView v, const 
         if (out[q] == kMark64)
         {
             const uint64_t i = iq[q], total = BIT ? v.ones : v.n_bits - v.ones;
-            out[q] = i > total ? v.n_bits : rrr_select<BIT>(v, &T, i - 1); // (beyond the last argument: size(), rrr_vector.hpp:641-642)
+            out[q] = i > total ? v.n_bits : rrr_select<BIT, F>(v, &T, i - 1); // (beyond the last argument: size(), rrr_vector.hpp:641-642)
         }
 }
 
@@ -427,11 +460,12 @@ __global__ __launch_bounds__(256) void k_rs_bnd_args(unsigned nf, unsigned B, ui
     if (f < nf)
         out[f] = (uint64_t)f * B + 1; // 1-based rank of the bucket's first argument
 }
-__global__ __launch_bounds__(256) void k_rs_bnd_records(unsigned nf, const uint64_t * __restrict__ pos, uint64_t n_sb, uint32_t * __restrict__ bnd)
+__global__ __launch_bounds__(256) void k_rs_bnd_records(unsigned nf, const uint64_t * __restrict__ pos, uint64_t n_sb, uint64_t rec_bits,
+                                                        uint32_t * __restrict__ bnd)
 {
     const unsigned f = blockIdx.x * 256 + threadIdx.x;
     if (f < nf)
-        bnd[f] = (uint32_t)(pos[f] / kRecSB);
+        bnd[f] = (uint32_t)(pos[f] / rec_bits);
     if (f == nf)
         bnd[nf] = (uint32_t)(n_sb - 1);
 }
@@ -462,8 +496,9 @@ static void rs_fill(SrGeom & g, const RrrView & v, uint64_t cnt)
     g.n = cnt;
     g.n_bits = v.n_bits;
     g.n_lines = 0;
-    g.op = 2;
-    g.rbits = (uint32_t)kRecSB;
+    const uint64_t rec_bits = v.fmt ? RrrFmtS::SB : RrrFmtW::SB;
+    g.op = v.fmt ? 3 : 2;
+    g.rbits = (uint32_t)rec_bits;
     g.rlog = rs_rlog(v);
     const uint64_t slices = (v.n_sb + (UINT64_C(1) << g.rlog) - 1) >> g.rlog;
     unsigned f = 0;
@@ -472,7 +507,7 @@ static void rs_fill(SrGeom & g, const RrrView & v, uint64_t cnt)
     g.d2 = f < 8 ? f : 8;
     g.d1 = f - g.d2;
     g.kb = 20;
-    g.slice_bits = kRecSB << g.rlog;
+    g.slice_bits = rec_bits << g.rlog;
     g.small = false;
     g.go = nullptr;
 }
@@ -493,8 +528,9 @@ sdsl_hip_status rrr_launch_rank_sorted(const RrrView & v, int bit, const uint64_
         return SDSL_HIP_ERR_INVALID;
     }
     const unsigned rlog = rs_rlog(v);
-    const size_t lds = rs_lds_bytes(1u << rlog);
-    SH_HIP(hipFuncSetAttribute((const void *)k_rs_rank_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = rs_lds_bytes(1u << rlog, v.fmt);
+    SH_HIP(hipFuncSetAttribute((const void *)k_rs_rank_lds<RrrFmtW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SH_HIP(hipFuncSetAttribute((const void *)k_rs_rank_lds<RrrFmtS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SwCallbacks cb;
     cb.what = "bucketed rrr rank";
     cb.fill = [&](SrGeom & g, uint64_t cnt) { rs_fill(g, v, cnt); };
@@ -502,7 +538,10 @@ sdsl_hip_status rrr_launch_rank_sorted(const RrrView & v, int bit, const uint64_
                      hipStream_t st) -> sdsl_hip_status
     {
         hipLaunchKernelGGL(k_rs_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, st, v, nf, rlog, hf);
-        hipLaunchKernelGGL(k_rs_rank_lds, dim3(rlog == 7 ? 512u : 256u), dim3(kRsT), lds, st, v, bit, nf, rlog, fstart, ioff, keys2, g.go);
+        if (v.fmt)
+            hipLaunchKernelGGL(k_rs_rank_lds<RrrFmtS>, dim3(rlog == 7 ? 512u : 256u), dim3(kRsT), lds, st, v, bit, nf, rlog, fstart, ioff, keys2, g.go);
+        else
+            hipLaunchKernelGGL(k_rs_rank_lds<RrrFmtW>, dim3(rlog == 7 ? 512u : 256u), dim3(kRsT), lds, st, v, bit, nf, rlog, fstart, ioff, keys2, g.go);
         SH_HIP(hipGetLastError());
         return SDSL_HIP_OK;
     };
@@ -533,12 +572,13 @@ sdsl_hip_status rrr_select_sorted_prepare(RrrHost & h, int bit)
     };
     // records per slice: 2^7 (two answering blocks per CU) unless 2^16 buckets of that capacity cannot hold the arguments
     const uint64_t b_min = (total + 65535) >> 16;
+    const uint64_t rec_bits = v.fmt ? RrrFmtS::SB : RrrFmtW::SB;
     unsigned rlog = 7;
-    if (0.7 * 128 * (double)kRecSB * ((double)total / (double)v.n_bits) < 1.15 * (double)b_min)
+    if (0.7 * 128 * (double)rec_bits * ((double)total / (double)v.n_bits) < 1.15 * (double)b_min)
         rlog = 8;
     P.rlog = rlog;
     const unsigned S = 1u << rlog;
-    const double per = 0.7 * S * (double)kRecSB * ((double)total / (double)v.n_bits);
+    const double per = 0.7 * S * (double)rec_bits * ((double)total / (double)v.n_bits);
     const uint64_t b_fit = per < 64.0 ? 64 : (per > 15.0 * 1048576.0 ? (uint64_t)15 << 20 : (uint64_t)per);
     unsigned bm, bs;
     round_down(b_fit, bm, bs);
@@ -567,7 +607,7 @@ sdsl_hip_status rrr_select_sorted_prepare(RrrHost & h, int bit)
         TimingPause pause;
         SH_TRY(rrr_launch_select(v, bit, args.as<uint64_t>(), nf, pos.as<uint64_t>(), nullptr));
     }
-    hipLaunchKernelGGL(k_rs_bnd_records, dim3((nf + 256) / 256), dim3(256), 0, 0, nf, pos.as<uint64_t>(), v.n_sb, P.bnd.as<uint32_t>());
+    hipLaunchKernelGGL(k_rs_bnd_records, dim3((nf + 256) / 256), dim3(256), 0, 0, nf, pos.as<uint64_t>(), v.n_sb, rec_bits, P.bnd.as<uint32_t>());
     SH_HIP(hipGetLastError());
     std::vector<uint32_t> hb((size_t)nf + 1);
     SH_HIP(hipMemcpy(hb.data(), P.bnd.p, hb.size() * 4, hipMemcpyDeviceToHost));
@@ -624,9 +664,12 @@ sdsl_hip_status rrr_launch_select_sorted(RrrHost & h, int bit, const uint64_t * 
     }
     const RrrView & v = h.view;
     const unsigned rlog = P.rlog;
-    const size_t lds = rs_lds_bytes(1u << rlog);
-    SH_HIP(hipFuncSetAttribute((const void *)k_rs_select_lds<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SH_HIP(hipFuncSetAttribute((const void *)k_rs_select_lds<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = rs_lds_bytes(1u << rlog, v.fmt);
+    const uint64_t rec_bits = v.fmt ? RrrFmtS::SB : RrrFmtW::SB;
+    SH_HIP(hipFuncSetAttribute((const void *)k_rs_select_lds<1, RrrFmtW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SH_HIP(hipFuncSetAttribute((const void *)k_rs_select_lds<0, RrrFmtW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SH_HIP(hipFuncSetAttribute((const void *)k_rs_select_lds<1, RrrFmtS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SH_HIP(hipFuncSetAttribute((const void *)k_rs_select_lds<0, RrrFmtS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t * bnd = P.bnd.as<uint32_t>();
     const unsigned B = P.bm << P.bs, n_buckets = P.nf;
     SwCallbacks cb;
@@ -636,22 +679,42 @@ sdsl_hip_status rrr_launch_select_sorted(RrrHost & h, int bit, const uint64_t * 
                      hipStream_t st) -> sdsl_hip_status
     {
         SH_HIP(hipMemsetAsync(marked, 0, 4, st));
-        hipLaunchKernelGGL(k_rs_select_bases, dim3((nf + 255) / 256), dim3(256), 0, st, nf, n_buckets, bnd, hf);
+        hipLaunchKernelGGL(k_rs_select_bases, dim3((nf + 255) / 256), dim3(256), 0, st, nf, n_buckets, rec_bits, bnd, hf);
         // (slices beyond the plan's buckets have no keys, so the kernel never reads bnd past n_buckets)
         const dim3 grid(rlog == 7 ? 512u : 256u);
-        if (bit)
-            hipLaunchKernelGGL(k_rs_select_lds<1>, grid, dim3(kRsT), lds, st, v, nf, rlog, B, bnd, fstart, ioff, keys2, marked, g.go);
+        if (v.fmt)
+        {
+            if (bit)
+                hipLaunchKernelGGL((k_rs_select_lds<1, RrrFmtS>), grid, dim3(kRsT), lds, st, v, nf, rlog, B, bnd, fstart, ioff, keys2, marked, g.go);
+            else
+                hipLaunchKernelGGL((k_rs_select_lds<0, RrrFmtS>), grid, dim3(kRsT), lds, st, v, nf, rlog, B, bnd, fstart, ioff, keys2, marked, g.go);
+        }
         else
-            hipLaunchKernelGGL(k_rs_select_lds<0>, grid, dim3(kRsT), lds, st, v, nf, rlog, B, bnd, fstart, ioff, keys2, marked, g.go);
+        {
+            if (bit)
+                hipLaunchKernelGGL((k_rs_select_lds<1, RrrFmtW>), grid, dim3(kRsT), lds, st, v, nf, rlog, B, bnd, fstart, ioff, keys2, marked, g.go);
+            else
+                hipLaunchKernelGGL((k_rs_select_lds<0, RrrFmtW>), grid, dim3(kRsT), lds, st, v, nf, rlog, B, bnd, fstart, ioff, keys2, marked, g.go);
+        }
         SH_HIP(hipGetLastError());
         return SDSL_HIP_OK;
     };
     cb.fixup = [&](const uint32_t * marked, const uint64_t * idx, uint64_t * out, uint64_t cnt, hipStream_t st)
     {
-        if (bit)
-            hipLaunchKernelGGL(k_rs_select_fixup<1>, dim3(256 * 4), dim3(kRrrBlock), 0, st, v, marked, idx, out, cnt, go);
+        if (v.fmt)
+        {
+            if (bit)
+                hipLaunchKernelGGL((k_rs_select_fixup<1, RrrFmtS>), dim3(256 * 4), dim3(kRrrBlock), 0, st, v, marked, idx, out, cnt, go);
+            else
+                hipLaunchKernelGGL((k_rs_select_fixup<0, RrrFmtS>), dim3(256 * 4), dim3(kRrrBlock), 0, st, v, marked, idx, out, cnt, go);
+        }
         else
-            hipLaunchKernelGGL(k_rs_select_fixup<0>, dim3(256 * 4), dim3(kRrrBlock), 0, st, v, marked, idx, out, cnt, go);
+        {
+            if (bit)
+                hipLaunchKernelGGL((k_rs_select_fixup<1, RrrFmtW>), dim3(256 * 4), dim3(kRrrBlock), 0, st, v, marked, idx, out, cnt, go);
+            else
+                hipLaunchKernelGGL((k_rs_select_fixup<0, RrrFmtW>), dim3(256 * 4), dim3(kRrrBlock), 0, st, v, marked, idx, out, cnt, go);
+        }
     };
     return sw_run_with(cb, bit, d_i, n, d_out, s, scratch, scratch_bytes, go);
 }
