@@ -75,7 +75,7 @@ size_t sw_carve(SwBuf & b, void * scratch, uint64_t n, unsigned tile, const SwGe
         p += (bytes + 255) & ~(size_t)255;
         return r;
     };
-    const uint64_t tiles1 = (n + tile - 1) / tile + w.U1, tiles2 = (n + tile - 1) / tile + (uint64_t)bins1 * w.K;
+    const uint64_t tiles1 = (n + tile - 1) / tile + w.U1, tiles2 = (n + tile - 1) / tile + 2 * (uint64_t)bins1 * w.K;
     b.keys1 = (uint32_t *)take(n * 4 + 256);
     b.keys2 = (uint32_t *)take(n * 4 + 256);
     b.slots1 = (uint16_t *)take(n * 2);
@@ -228,10 +228,16 @@ __global__ __launch_bounds__(1024) void k_sw_units2(SrGeom g, SwGeom w, const ui
     const unsigned n_units = (1u << g.d1) * w.K, upk = w.U1 / w.K;
     const unsigned per = (n_units + 1023) / 1024;
     auto lo_of = [&](unsigned x) -> uint32_t { return x < n_units ? offs1[(size_t)(x / w.K) * w.U1 + (x % w.K) * upk] : (uint32_t)g.n; };
+    // (tiles end on 128-byte lines of the array: k_sw_partition<2>)
+    auto tiles_of = [&](unsigned x) -> unsigned
+    {
+        const uint32_t a = lo_of(x), z = lo_of(x + 1);
+        return z > a ? (z - (a & ~31u) + g.tile - 1) / g.tile : 0u;
+    };
     const unsigned x0 = t * per, x1 = x0 + per < n_units ? x0 + per : n_units;
     unsigned s = 0;
     for (unsigned x = x0; x < x1; ++x)
-        s += (lo_of(x + 1) - lo_of(x) + g.tile - 1) / g.tile;
+        s += tiles_of(x);
     const unsigned inc = wave_incl_scan(s);
     if ((t & 63) == 63)
         wred[t >> 6] = inc;
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(1024) void k_sw_units2(SrGeom g, SwGeom w, const ui
     {
         in_lo[x] = lo_of(x);
         tp2[x] = base;
-        base += (lo_of(x + 1) - lo_of(x) + g.tile - 1) / g.tile;
+        base += tiles_of(x);
     }
     if (t == 1023)
     { // (threads past the end have empty ranges, so the last thread holds the total)
@@ -351,9 +357,18 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
         // vector loads and stores share one counter per wave, so a wait for loads that were issued after stores also waits for
         // the stores' acknowledgements — placed behind the write-out, every tile would drain its own stores before the next
         // one could even be counted (3.1 instead of 2.x ms per pass)
+        // Pass 2: a unit starts wherever its stream of pass 1 starts, but its tiles END on 128-byte lines of the array (the first one
+        // is short): the slots written here and, on the way back, the answers written by k_sw_unpermute_dma<2> then cover whole
+        // lines — non-temporal stores that start mid-sector went out as partial writes (4.33 GB for 4.0 GB of answers).
+        const uint64_t kal = P == 2 ? (un.klo & ~UINT64_C(31)) : un.klo;
+        auto tile_end = [&](uint64_t lo) -> uint64_t
+        {
+            const uint64_t e = kal + ((lo - kal) / kTile + 1) * kTile;
+            return e < un.khi ? e : un.khi;
+        };
         auto fetch = [&](uint64_t lo, raw_t (&r)[PER])
         {
-            const unsigned c = (unsigned)(un.khi - lo < kTile ? un.khi - lo : kTile);
+            const unsigned c = (unsigned)(tile_end(lo) - lo);
             const rsrc_t rs = make_rsrc(in + lo, c * (unsigned)sizeof(raw_t));
 #pragma unroll
             for (unsigned u = 0; u < PER; ++u)
@@ -367,11 +382,12 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
         for (unsigned i = t; i <= kBins; i += TT)
             hist2[0][i] = 0;
         __syncthreads();
-        for (uint64_t lo = un.klo; lo < un.khi; lo += kTile, ++ti, hb ^= 1u)
+        for (uint64_t lo = un.klo, nlo; lo < un.khi; lo = nlo, ++ti, hb ^= 1u)
         {
             unsigned * hist = hist2[hb];
-            const unsigned cnt_t = (unsigned)(un.khi - lo < kTile ? un.khi - lo : kTile);
-            const bool has_next = lo + kTile < un.khi;
+            nlo = tile_end(lo);
+            const unsigned cnt_t = (unsigned)(nlo - lo);
+            const bool has_next = nlo < un.khi;
             // every kCkS-th tile: where its runs start in the streams (what lets the way back begin there)
             const bool note = (ti % kCkS) == 0;
             unsigned ck = 0;
@@ -393,7 +409,7 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
             }
             raw_t nxt[PER]; // (requested once this tile's own keys are out of the way: the registers are the same)
             if (has_next)
-                fetch(lo + kTile, nxt);
+                fetch(nlo, nxt);
             __syncthreads();
             { // exclusive scan of the counts -> start; the bins' write-out parameters packed into one word each
                 unsigned v = 0, inc = 0;
@@ -566,8 +582,9 @@ __device__ __forceinline__ SwTile<P> sw_tile(const SrGeom & g, const SwGeom & w,
         d.unit = u;
         d.tb = __builtin_amdgcn_readfirstlane(tp2[u]);
         const uint32_t a = __builtin_amdgcn_readfirstlane(in_lo[u]), z = __builtin_amdgcn_readfirstlane(in_lo[u + 1]);
-        d.lo = (uint64_t)a + (uint64_t)(ti - d.tb) * g.tile;
-        d.cnt = (unsigned)(z - d.lo < g.tile ? z - d.lo : g.tile);
+        const uint64_t al = a & ~31u, end = al + (uint64_t)(ti - d.tb + 1) * g.tile; // (tiles end on 128-byte lines: k_sw_partition<2>)
+        d.lo = ti == d.tb ? (uint64_t)a : al + (uint64_t)(ti - d.tb) * g.tile;
+        d.cnt = (unsigned)((end < z ? end : z) - d.lo);
     }
     return d;
 }
@@ -893,7 +910,9 @@ sdsl_hip_status sw_run_with(const SwCallbacks & cb, int bit, const uint64_t * d_
         pt.mark("part2");
         SH_TRY(cb.answers(g, w.nf, b.fstart, b.ioff, b.keys2, b.hf, b.marked, s));
         pt.mark("answer");
-        const unsigned ublocks = ub_env >= 1 ? (unsigned)ub_env : 768u;
+        // two blocks per CU on the way back (three fit): what a block gathers per tile then survives in its XCD's L2 until the next
+        // tile continues the same streams — 7.0 + 8.5 GB read instead of 7.8 + 9.9 at the same 4.7 ms (profiles/swc_traffic_r03.txt)
+        const unsigned ublocks = ub_env >= 1 ? (unsigned)ub_env : 512u;
         hipLaunchKernelGGL((k_sw_unpermute_dma<2, 512, 16>), dim3(ublocks), dim3(512), 0, s, b.hf, bit, g, w, b.offs1, b.in_lo, b.tp2, b.fstart,
                            b.segsum, b.ck2, b.tickets + 2, b.tdesc2, b.keys2, b.marked, b.slots2, b.thist2, b.keys1, (uint64_t *)nullptr);
         pt.mark("unperm2");

@@ -254,19 +254,22 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
         const uint64_t lo = (uint64_t)fstart[f] + (uint64_t)(item - ioff[f]) * kItemKeys;
         const uint64_t fend = fstart[f + 1];
         const unsigned cnt = (unsigned)(lo + kItemKeys < fend ? kItemKeys : fend - lo);
-        const rsrc_t rs_k = make_rsrc(keys + uniform64(lo), __builtin_amdgcn_readfirstlane(cnt) * 4u);
+        // (whole 128-byte lines of the key array, as in k_sr_rank_lds: the lanes of the `head` keys in front of the item's first one skip)
+        const unsigned head = (unsigned)lo & 31u, cnth = cnt + head;
+        const unsigned vo0 = t < head ? 0xFFFFFFFCu : t * 4u;
+        const rsrc_t rs_k = make_rsrc(keys + uniform64(lo - head), __builtin_amdgcn_readfirstlane(cnth) * 4u);
         constexpr int U = 4;
         uint32_t key[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            buf_load(rs_k, t * 4u, (unsigned)u * kRsT * 4u, key[u]); // (the first keys travel while the slice is decoded)
+            buf_load(rs_k, t * 4u, (unsigned)u * kRsT * 4u, key[u]);
         rs_decode_records<F>(L, v, recs, nrec, S);
         // 4. the keys
-        for (unsigned i0 = 0; i0 < cnt; i0 += kRsT * U)
+        for (unsigned i0 = 0; i0 < cnth; i0 += kRsT * U)
         {
             uint32_t nk[U];
             const unsigned n0 = (i0 + kRsT * U) * 4u;
-            if (i0 + kRsT * U < cnt)
+            if (i0 + kRsT * U < cnth)
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -275,6 +278,8 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
 #pragma unroll
             for (int u = 0; u < U; ++u)
             {
+                if (u == 0 && i0 == 0 && t < head)
+                    key[u] = kBad; // (a key of the line's head: the item in front of this one answers it)
                 const uint32_t kq = key[u];
                 uint32_t res = kBad;
                 if (kq != kBad)
@@ -283,9 +288,9 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
                     const uint32_t r1 = L.rones[r] + L.pre[b] + popc64(L.raw[b] & lo_set(o));
                     res = bit ? r1 : r * (uint32_t)F::SB + j * kRrrBS + o - r1;
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(res, rs_k, (int)(t * 4u), (int)(i0 * 4u + (unsigned)u * kRsT * 4u), kAuxNT);
+                __builtin_amdgcn_raw_buffer_store_b32(res, rs_k, (int)(u == 0 && i0 == 0 ? vo0 : t * 4u), (int)(i0 * 4u + (unsigned)u * kRsT * 4u), kAuxNT);
             }
-            if (i0 + kRsT * U < cnt)
+            if (i0 + kRsT * U < cnth)
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -358,7 +363,10 @@ __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, 
         }
         const unsigned nrec = (unsigned)(R1 - R0);
         const uint64_t * recs = v.rec + R0 * kRecWords;
-        const rsrc_t rs_k = make_rsrc(keys + uniform64(lo), __builtin_amdgcn_readfirstlane(cnt) * 4u);
+        // (whole 128-byte lines of the key array, as in k_sr_rank_lds: the lanes of the `head` keys in front of the item's first one skip)
+        const unsigned head = (unsigned)lo & 31u, cnth = cnt + head;
+        const unsigned vo0 = t < head ? 0xFFFFFFFCu : t * 4u;
+        const rsrc_t rs_k = make_rsrc(keys + uniform64(lo - head), __builtin_amdgcn_readfirstlane(cnth) * 4u);
         constexpr int U = 4;
         uint32_t key[U];
 #pragma unroll
@@ -370,11 +378,11 @@ __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, 
         const unsigned t0 = (unsigned)((uint64_t)f * B - A0);   // rank of the bucket's first argument, relative to the slice
         auto rargs = [&](unsigned r) -> unsigned { return BIT ? L.rones[r] : r * (unsigned)F::SB - L.rones[r]; };
         bool mk = false;
-        for (unsigned i0 = 0; i0 < cnt; i0 += kRsT * U)
+        for (unsigned i0 = 0; i0 < cnth; i0 += kRsT * U)
         {
             uint32_t nk[U];
             const unsigned n0 = (i0 + kRsT * U) * 4u;
-            if (i0 + kRsT * U < cnt)
+            if (i0 + kRsT * U < cnth)
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -383,6 +391,8 @@ __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, 
 #pragma unroll
             for (int u = 0; u < U; ++u)
             {
+                if (u == 0 && i0 == 0 && t < head)
+                    key[u] = kBad; // (a key of the line's head: the item in front of this one answers it)
                 const uint32_t kq = key[u];
                 uint32_t res = kq; // (NPOS and "size()" keys travel on as they are)
                 mk |= kq == kMark;
@@ -414,9 +424,9 @@ __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, 
                     const uint64_t bits = BIT ? L.raw[b0 + ja] : ~L.raw[b0 + ja] & lo_set(kRrrBS);
                     res = a * (uint32_t)F::SB + ja * kRrrBS + sel64(bits, want + 1); // relative to the slice's first bit
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(res, rs_k, (int)(t * 4u), (int)(i0 * 4u + (unsigned)u * kRsT * 4u), kAuxNT);
+                __builtin_amdgcn_raw_buffer_store_b32(res, rs_k, (int)(u == 0 && i0 == 0 ? vo0 : t * 4u), (int)(i0 * 4u + (unsigned)u * kRsT * 4u), kAuxNT);
             }
-            if (i0 + kRsT * U < cnt)
+            if (i0 + kRsT * U < cnth)
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
