@@ -482,16 +482,23 @@ int main(int argc, char ** argv)
         for (auto & x : q)
             x = rng() % (bv.size() + 1);
         (void)hr(q[0]); // (builds the host support)
+        // (best of five passes each, interleaved: the box's CPUs are shared and a single pass can be preempted)
         auto t0 = std::chrono::steady_clock::now();
-        uint64_t sum = 0;
-        for (size_t i = 0; i < nq; ++i)
-            sum += hr(q[i]);
-        double ns = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq;
-        t0 = std::chrono::steady_clock::now();
-        uint64_t want = 0;
-        for (size_t i = 0; i < nq; ++i)
-            want += r1(q[i]);
-        double ns_ref = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq;
+        uint64_t sum = 0, want = 0;
+        double ns = 1e30, ns_ref = 1e30;
+        for (int rep = 0; rep < 5; ++rep)
+        {
+            t0 = std::chrono::steady_clock::now();
+            sum = 0;
+            for (size_t i = 0; i < nq; ++i)
+                sum += hr(q[i]);
+            ns = std::min(ns, std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq);
+            t0 = std::chrono::steady_clock::now();
+            want = 0;
+            for (size_t i = 0; i < nq; ++i)
+                want += r1(q[i]);
+            ns_ref = std::min(ns_ref, std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq);
+        }
         t0 = std::chrono::steady_clock::now();
         hr.rank_batch(q.data(), nq, out.data());
         double ns_b = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq;

@@ -48,67 +48,93 @@ __device__ __forceinline__ unsigned rg_class(const RrrGenParams & P, const uint6
     return c;
 }
 
-// offset bits of every group of 64 blocks (= bs words of plain bits)
+// A GROUP is 64 consecutive blocks (= bs words of plain bits, starting on a word boundary).  Both kernels give a group to a WAVE,
+// one block per lane: the classes are read side by side, the offset widths are summed / prefix-summed across the wave, every
+// lane decodes its own block, the bs words of the group are assembled in LDS and written out side by side.  (The first form
+// walked the 64 blocks of a group in ONE thread, OR-ing into global memory: 64 dependent decodes per thread.)
+__device__ __forceinline__ unsigned rg_wave_incl_scan(unsigned v)
+{
+    const unsigned lane = threadIdx.x & 63;
+#pragma unroll
+    for (unsigned d = 1; d < 64; d <<= 1)
+    {
+        const unsigned o = (unsigned)__shfl_up((int)v, d, 64);
+        if (lane >= d)
+            v += o;
+    }
+    return v;
+}
+
+// offset bits of every group
 __global__ __launch_bounds__(256) void k_rg_group_len(RrrGenParams P, const uint64_t * __restrict__ bt,
                                                       const uint64_t * __restrict__ inv, uint64_t n_groups,
                                                       const RrrGenTables * __restrict__ T, uint32_t * __restrict__ glen)
 {
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (uint64_t)gridDim.x * blockDim.x)
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + wv; g < n_groups; g += (uint64_t)gridDim.x * 4)
     {
+        const uint64_t b = g * 64 + lane;
         unsigned len = 0;
-        for (unsigned j = 0; j < 64; ++j)
+        if (b < P.n_blocks)
         {
-            const uint64_t b = g * 64 + j;
-            if (b < P.n_blocks)
-            {
-                const unsigned c = rg_class(P, bt, inv, b);
-                len += c <= P.bs ? T->space[c] : 0;
-            }
+            const unsigned c = rg_class(P, bt, inv, b);
+            len = c <= P.bs ? T->space[c] : 0;
         }
-        glen[g] = len;
+        const unsigned total = rg_wave_incl_scan(len);
+        if (lane == 63)
+            glen[g] = total;
     }
 }
 
-__global__ __launch_bounds__(64) void k_rg_decode(RrrGenParams P, const uint64_t * __restrict__ bt, const uint64_t * __restrict__ inv,
-                                                  const uint64_t * __restrict__ btnr, uint64_t btnr_bits,
-                                                  const uint64_t * __restrict__ gptr, uint64_t n_groups, uint64_t n_words,
-                                                  const RrrGenTables * __restrict__ T, unsigned long long * __restrict__ out)
+__global__ __launch_bounds__(256) void k_rg_decode(RrrGenParams P, const uint64_t * __restrict__ bt, const uint64_t * __restrict__ inv,
+                                                   const uint64_t * __restrict__ btnr, uint64_t btnr_bits,
+                                                   const uint64_t * __restrict__ gptr, uint64_t n_groups, uint64_t n_words,
+                                                   const RrrGenTables * __restrict__ T, unsigned long long * __restrict__ out)
 {
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (uint64_t)gridDim.x * blockDim.x)
+    __shared__ unsigned long long wbuf[4][64];
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long * wb = wbuf[wv]; // (a wave's own words: LDS operations of one wave complete in order, no block barrier)
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + wv; g < n_groups; g += (uint64_t)gridDim.x * 4)
     {
-        uint64_t ptr = gptr[g];
-        for (unsigned j = 0; j < 64; ++j)
+        wb[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t b = g * 64 + lane;
+        unsigned k = 0, len = 0;
+        if (b < P.n_blocks)
         {
-            const uint64_t b = g * 64 + j;
-            if (b >= P.n_blocks)
-                break;
-            unsigned k = rg_class(P, bt, inv, b);
+            k = rg_class(P, bt, inv, b);
             if (k > P.bs)
                 k = 0; // a malformed class: the block decodes to zeros
-            const unsigned len = T->space[k];
-            uint64_t nr = len && ptr + len <= btnr_bits ? read_bits(btnr, ptr, len) : 0;
-            ptr += len;
-            uint64_t bits = 0;
-            for (unsigned p = 0; p < P.bs && k; ++p)
-            {
-                const uint64_t c = T->C[P.bs - 1 - p][k]; // members that have a 0 at position p
-                if (nr >= c)
-                {
-                    nr -= c;
-                    --k;
-                    bits |= UINT64_C(1) << p;
-                }
-            }
-            if (!bits)
-                continue;
-            const uint64_t at = b * P.bs; // the group's first block starts on a word boundary (64 * bs bits)
-            const uint64_t wi = at >> 6;
-            const unsigned o = (unsigned)(at & 63);
-            if (wi < n_words)
-                atomicOr(&out[wi], (unsigned long long)(bits << o)); // (the bs words of a group belong to this thread alone; OR-ing
-            if (o + P.bs > 64 && wi + 1 < n_words)                   // into the zeroed output spares a 63-word local array)
-                atomicOr(&out[wi + 1], (unsigned long long)(bits >> (64 - o)));
+            len = T->space[k];
         }
+        const uint64_t ptr = gptr[g] + (rg_wave_incl_scan(len) - len);
+        uint64_t nr = len && ptr + len <= btnr_bits ? read_bits(btnr, ptr, len) : 0;
+        uint64_t bits = 0;
+        for (unsigned p = 0; p < P.bs && k; ++p)
+        {
+            const uint64_t c = T->C[P.bs - 1 - p][k]; // members that have a 0 at position p
+            if (nr >= c)
+            {
+                nr -= c;
+                --k;
+                bits |= UINT64_C(1) << p;
+            }
+        }
+        if (bits)
+        {
+            const unsigned at = lane * P.bs, wi = at >> 6, o = at & 63; // (lane 63 with bs = 63 ends exactly at word 62's last bit)
+            atomicOr(&wb[wi], (unsigned long long)(bits << o));
+            if (o + P.bs > 64)
+                atomicOr(&wb[wi + 1], (unsigned long long)(bits >> (64 - o)));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t wi = g * P.bs + lane;
+        if (lane < P.bs && wi < n_words)
+            out[wi] = wb[lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -197,14 +223,14 @@ sdsl_hip_status compressed_stream_to_device_words(const void * bytes, size_t len
         {
             SH_TRY(d_glen.alloc(n_groups * 4));
             SH_TRY(d_gptr.alloc(n_groups * 8));
-            hipLaunchKernelGGL(k_rg_group_len, dim3(grid_for(n_groups, 256, 65536)), dim3(256), 0, 0, P, d_bt.as<uint64_t>(),
+            hipLaunchKernelGGL(k_rg_group_len, dim3(grid_for(n_groups * 64, 256, 65536)), dim3(256), 0, 0, P, d_bt.as<uint64_t>(),
                                d_inv.as<uint64_t>(), n_groups, d_T.as<RrrGenTables>(), d_glen.as<uint32_t>());
             SH_HIP(hipGetLastError());
             uint64_t total = 0;
             SH_TRY(device_exclusive_scan_u32(d_glen.as<uint32_t>(), n_groups, d_gptr.as<uint64_t>(), 1, &total));
             if (total > btnr.bit_size)
                 return fmt(what, rd); // the classes ask for more offset bits than the stream holds
-            hipLaunchKernelGGL(k_rg_decode, dim3(grid_for(n_groups, 64, 65536)), dim3(64), 0, 0, P, d_bt.as<uint64_t>(),
+            hipLaunchKernelGGL(k_rg_decode, dim3(grid_for(n_groups * 64, 256, 65536)), dim3(256), 0, 0, P, d_bt.as<uint64_t>(),
                                d_inv.as<uint64_t>(), d_btnr.as<uint64_t>(), btnr.bit_size, d_gptr.as<uint64_t>(), n_groups, nw,
                                d_T.as<RrrGenTables>(), d_words.as<unsigned long long>());
             SH_HIP(hipGetLastError());

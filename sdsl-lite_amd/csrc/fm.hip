@@ -793,10 +793,15 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
     }
     if (w.backend == 1)
     {
+        const bool verify = !ival && fm->d_sa.p && fm->d_text.p && fm_verify_enabled() && fm->size < (UINT64_C(1) << 32);
         SH_TRY(fm_rrr_launch_count(w, fm->d_tab.as<FmTables>(), jump, fm->size, (const uint8_t *)sp.dev, m,
                                    offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat,
                                    ival ? nullptr : (uint64_t *)sc.dev, ival ? (uint64_t *)sl.dev : nullptr,
-                                   ival ? (uint64_t *)sr.dev : nullptr, s));
+                                   ival ? (uint64_t *)sr.dev : nullptr, s, verify));
+        if (verify)
+            hipLaunchKernelGGL(k_fm_verify, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa.as<uint32_t>(),
+                               fm->d_text.as<uint8_t>(), (const uint8_t *)sp.dev, m, offsets ? (const uint64_t *)so.dev : nullptr, n_pat,
+                               (uint64_t *)sc.dev);
     }
     else
     {

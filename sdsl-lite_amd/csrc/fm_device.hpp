@@ -58,7 +58,7 @@ __device__ __forceinline__ uint64_t fm_jump_start(const FmJump & J, const FmTabl
 struct WtHost;
 sdsl_hip_status fm_rrr_launch_count(const WtHost & wt, const FmTables * d_tab, FmJump jump, uint64_t csa_size,
                                     const uint8_t * d_pats, uint32_t m, const uint64_t * d_offsets, const uint32_t * d_order,
-                                    uint64_t n_pat, uint64_t * d_cnt, uint64_t * d_l, uint64_t * d_r, hipStream_t s);
+                                    uint64_t n_pat, uint64_t * d_cnt, uint64_t * d_l, uint64_t * d_r, hipStream_t s, bool verify = false);
 sdsl_hip_status fm_rrr_launch_backward_step(const WtHost & wt, const FmTables * d_tab, uint64_t csa_size,
                                             const uint64_t * d_l, const uint64_t * d_r, const uint8_t * d_c, uint64_t n,
                                             uint64_t * d_lo, uint64_t * d_ro, hipStream_t s);

@@ -129,7 +129,10 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_wt_select_rrr(WtView wt, const 
 
 // count / interval (suffix_array_algorithm.hpp:228-248, 464-471), one pattern per lane.  Both cascades of an LF
 // step (rank at l and at r+1, :195-196) advance level by level (rrr_rank2).
-template <bool WANT_IVAL>
+// VERIFY (count only; the whole suffix array and the text are resident): a search that is down to ONE suffix with two or more
+// characters to go stops and leaves [1 : 1 | characters left : 31 | the suffix : 32] for k_fm_verify (fm.hip), which compares
+// them with the text — on this index every LF step it saves is a cascade of block decodes.
+template <bool WANT_IVAL, bool VERIFY = false>
 __global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const FmTables * __restrict__ ftab, FmJump J,
                                                               uint64_t csa_size, const uint8_t * __restrict__ pats,
                                                               uint32_t m, const uint64_t * __restrict__ offsets,
@@ -160,12 +163,18 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const F
         unsigned c_next = it > begin ? pats[it - 1] : 0;
         unsigned left = 0, v = 0;
         uint64_t a = 0, b = 0, p = 0, cb = 0;
+        bool pending = false;
         for (;;)
         {
             if (left == 0)
             { // next character (suffix_array_algorithm.hpp:176-200)
                 if (!(it > begin && r + 1 - l > 0))
                     break;
+                if (VERIFY && !WANT_IVAL && l == r && it > begin + 1)
+                {
+                    pending = true;
+                    break;
+                }
                 --it;
                 const unsigned c = c_next;
                 if (it > begin)
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const F
             out_r[q] = r;
         }
         else
-            out_cnt[q] = r + 1 - l;
+            out_cnt[q] = VERIFY && pending ? (UINT64_C(1) << 63) | ((uint64_t)(it - begin) << 32) | l : r + 1 - l;
     }
 }
 
@@ -342,13 +351,16 @@ sdsl_hip_status wt_rrr_launch_inverse_select(const WtHost & wt, const uint64_t *
 
 sdsl_hip_status fm_rrr_launch_count(const WtHost & wt, const FmTables * d_tab, FmJump jump, uint64_t csa_size,
                                     const uint8_t * d_pats, uint32_t m, const uint64_t * d_offsets, const uint32_t * d_order,
-                                    uint64_t n_pat, uint64_t * d_cnt, uint64_t * d_l, uint64_t * d_r, hipStream_t s)
+                                    uint64_t n_pat, uint64_t * d_cnt, uint64_t * d_l, uint64_t * d_r, hipStream_t s, bool verify)
 {
     if (n_pat == 0)
         return SDSL_HIP_OK;
     if (d_l)
         hipLaunchKernelGGL((k_fm_count_rrr<true>), dim3(wt_rrr_grid(n_pat)), dim3(kWtRrrBlock), 0, s, wt.view(), d_tab,
                            jump, csa_size, d_pats, m, d_offsets, d_order, n_pat, (uint64_t *)nullptr, d_l, d_r);
+    else if (verify && csa_size < (UINT64_C(1) << 32))
+        hipLaunchKernelGGL((k_fm_count_rrr<false, true>), dim3(wt_rrr_grid(n_pat)), dim3(kWtRrrBlock), 0, s, wt.view(), d_tab,
+                           jump, csa_size, d_pats, m, d_offsets, d_order, n_pat, d_cnt, (uint64_t *)nullptr, (uint64_t *)nullptr);
     else
         hipLaunchKernelGGL((k_fm_count_rrr<false>), dim3(wt_rrr_grid(n_pat)), dim3(kWtRrrBlock), 0, s, wt.view(), d_tab,
                            jump, csa_size, d_pats, m, d_offsets, d_order, n_pat, d_cnt, (uint64_t *)nullptr, (uint64_t *)nullptr);

@@ -9,12 +9,13 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("rrr", [False, True])
 @pytest.mark.parametrize("sigma,n", [(4, 50_000), (26, 200_000), (200, 300_000)])
-def test_count_with_text_verification_equals_oracle(gpu, sigma, n):
+def test_count_with_text_verification_equals_oracle(gpu, sigma, n, rrr):
     rng = np.random.default_rng(sigma * 1000 + 7)
     text = rng.integers(1, sigma + 1, n, dtype=np.uint8)
     text[1000:1200] = text[5000:5200]  # a long repeat: intervals of size two deep into the pattern
-    csa = gpu.csa_wt(text=text)
+    csa = gpu.csa_wt(text=text, rrr=rrr)  # (rrr: csa_wt<wt_huff<rrr_vector<63>>>, k_fm_count_rrr<verify>)
     ocsa = ol.OCsa(bytes(text))
     for m in (2, 3, 8, 20, 41):
         npat = 30_000
