@@ -581,7 +581,7 @@ def main():
     phases = {k: spread_of([t[k] for t in traced if k in t])["median"] for k in traced[0]} if traced[0] else {}
     phases_spread = {k: spread_of([t[k] for t in traced if k in t]) for k in traced[0]} if traced[0] else None
     bucketed = bool(phases)
-    scratch_bytes = bv.device_bytes() - index_bytes
+    scratch_bytes = pkg.device_scratch_bytes(dev.index if dev.index is not None else 0)  # one pool per device, shared by all handles
     # the direct kernel and its access skeleton (read a position, fetch its 64-byte rank line, write a word), same table,
     # same positions, same run
     pkg.set_option("rank_sorted", 0)

@@ -156,9 +156,13 @@ sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv);
  * kernel launch and one stream synchronisation (about 10 microseconds) — correct, but a loop of such
  * calls is latency-bound: batch whenever there is a loop. */
 sdsl_hip_status sdsl_hip_bv_query_one(sdsl_hip_bv_t bv, int32_t what, int32_t bit, uint64_t arg, uint64_t * out);
-/* frees the working memory the bucketed batch rank keeps with the handle between calls (12 bytes per query of the largest
- * batch seen, at most 2^30 queries' worth; counted by sdsl_hip_bv_device_bytes); the next large batch allocates it again */
+/* The bucketed batch paths (large rank / select batches on plain and rrr vectors) work in ONE scratch pool per device, shared by
+ * every handle on it and kept between calls: 12 bytes per query of the largest pass so far (at most 2^30 queries' worth) plus
+ * about 70 MB of tables.  sdsl_hip_bv_release_scratch frees the pool of the handle's device (after its last user has finished);
+ * the next large batch allocates it again.  sdsl_hip_device_scratch_bytes reports its size (the *_device_bytes calls do not
+ * include it). */
 sdsl_hip_status sdsl_hip_bv_release_scratch(sdsl_hip_bv_t bv);
+uint64_t sdsl_hip_device_scratch_bytes(int32_t device);
 uint64_t sdsl_hip_bv_size(sdsl_hip_bv_t bv);         /* bit_vector::size() */
 uint64_t sdsl_hip_bv_ones(sdsl_hip_bv_t bv);         /* == rank_1(size()) */
 uint64_t sdsl_hip_bv_device_bytes(sdsl_hip_bv_t bv); /* HBM footprint of the device layout */

@@ -67,6 +67,7 @@ SIGNATURES = {
     "sdsl_hip_bv_serialize": (C.c_int32, [_vp, C.c_int32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sdsl_hip_bv_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_bv_release_scratch": (C.c_int32, [_vp]),
+    "sdsl_hip_device_scratch_bytes": (C.c_uint64, [C.c_int32]),
     "sdsl_hip_bv_query_one": (C.c_int32, [_vp, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "sdsl_hip_bv_size": (C.c_uint64, [_vp]),
     "sdsl_hip_bv_ones": (C.c_uint64, [_vp]),

@@ -841,26 +841,27 @@ sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i
 // not returns at once (SrGeom::go / BvView::skip_if).  Nothing is read back, nothing synchronises: the call stays asynchronous
 // on the caller's stream and can be captured into a graph (once the handle's scratch has its size: the first call allocates).
 
-// the handle's scratch at the size a pass over `n` queries needs; false: no room (the caller takes the direct kernel)
-static bool bv_ensure_sort_scratch(BvHost & h, uint64_t n, hipStream_t s, sdsl_hip_status & st)
+// the device's scratch pool at the size a pass over `n` queries needs (the caller holds P.m); false: no room (the caller takes
+// the direct kernel)
+static bool bv_ensure_sort_scratch(BvHost & h, DeviceScratch & P, uint64_t n, hipStream_t s, sdsl_hip_status & st)
 {
     st = SDSL_HIP_OK;
     const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
     const size_t need = bv_sorted_rank_scratch_bytes(h.view, pass);
-    if (h.scratch_ev && hipStreamWaitEvent(s, h.scratch_ev, 0) != hipSuccess)
+    if (P.ev && hipStreamWaitEvent(s, P.ev, 0) != hipSuccess)
     {
         st = SDSL_HIP_ERR_HIP;
         return false;
     }
-    if (h.sort_scratch.bytes < need)
+    if (P.buf.bytes < need)
     {
-        if (h.scratch_ev)
-            (void)hipEventSynchronize(h.scratch_ev); // the old buffer may still be in use
-        h.sort_scratch.release();
-        if (h.sort_scratch.alloc(need) != SDSL_HIP_OK)
+        if (P.ev)
+            (void)hipEventSynchronize(P.ev); // the old buffer may still be in use
+        P.buf.release();
+        if (P.buf.alloc(need) != SDSL_HIP_OK)
             return false;
     }
-    if (!h.scratch_ev && hipEventCreateWithFlags(&h.scratch_ev, hipEventDisableTiming) != hipSuccess)
+    if (!P.ev && hipEventCreateWithFlags(&P.ev, hipEventDisableTiming) != hipSuccess)
     {
         st = SDSL_HIP_ERR_HIP;
         return false;
@@ -888,7 +889,9 @@ sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, ui
                 return bv_launch_rank(h.view, bit, d_idx, n, d_out, s);
         }
         sdsl_hip_status st;
-        if (!bv_ensure_sort_scratch(h, n, s, st))
+        DeviceScratch & P = device_scratch(h.device);
+        std::lock_guard<std::mutex> plock(P.m);
+        if (!bv_ensure_sort_scratch(h, P, n, s, st))
             return st != SDSL_HIP_OK ? st : bv_launch_rank(h.view, bit, d_idx, n, d_out, s); // no room for the scratch: direct kernel
         const uint32_t * go = nullptr;
         if (on_device && !h.spread_probe.p)
@@ -900,7 +903,7 @@ sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, ui
                 SH_TRY(bv_sorted_rank_sample(h.view, d_idx, n, s, h.spread_probe.as<uint32_t>()));
                 go = h.spread_probe.as<uint32_t>() + 2;
             }
-            st = bv_launch_rank_sorted(h.view, bit, d_idx, n, d_out, s, h.sort_scratch.p, h.sort_scratch.bytes, go);
+            st = bv_launch_rank_sorted(h.view, bit, d_idx, n, d_out, s, P.buf.p, P.buf.bytes, go);
             if (st == SDSL_HIP_OK && go)
             {
                 TimingPause pause; // (one timer around both routes)
@@ -909,7 +912,7 @@ sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, ui
                 st = bv_launch_rank(dv, bit, d_idx, n, d_out, s);
             }
         }
-        SH_HIP(hipEventRecord(h.scratch_ev, s));
+        SH_HIP(hipEventRecord(P.ev, s));
         return st;
     }
     return bv_launch_rank(h.view, bit, d_idx, n, d_out, s);
@@ -932,7 +935,9 @@ sdsl_hip_status bv_select_dispatch(BvHost & h, int bit, const uint64_t * d_i, ui
             SH_TRY(bv_sorted_select_is_spread(h, bit, d_i, n, s, h.spread_probe.p, want));
         }
         sdsl_hip_status st = SDSL_HIP_OK;
-        if (want && bv_ensure_sort_scratch(h, n, s, st))
+        DeviceScratch & P = device_scratch(h.device);
+        std::lock_guard<std::mutex> plock(P.m);
+        if (want && bv_ensure_sort_scratch(h, P, n, s, st))
         {
             const uint32_t * go = nullptr;
             if (on_device && !h.spread_probe.p)
@@ -944,7 +949,7 @@ sdsl_hip_status bv_select_dispatch(BvHost & h, int bit, const uint64_t * d_i, ui
                     SH_TRY(bv_sorted_select_sample(h, bit, d_i, n, s, h.spread_probe.as<uint32_t>()));
                     go = h.spread_probe.as<uint32_t>() + 2;
                 }
-                st = bv_launch_select_sorted(h, bit, d_i, n, d_out, s, h.sort_scratch.p, h.sort_scratch.bytes, go);
+                st = bv_launch_select_sorted(h, bit, d_i, n, d_out, s, P.buf.p, P.buf.bytes, go);
                 if (st == SDSL_HIP_OK && go)
                 {
                     TimingPause pause;
@@ -953,7 +958,7 @@ sdsl_hip_status bv_select_dispatch(BvHost & h, int bit, const uint64_t * d_i, ui
                     st = bv_launch_select(dv, bit, d_i, n, d_out, s);
                 }
             }
-            SH_HIP(hipEventRecord(h.scratch_ev, s));
+            SH_HIP(hipEventRecord(P.ev, s));
             return st;
         }
         if (st != SDSL_HIP_OK)
@@ -1229,7 +1234,7 @@ sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv)
     if (!bv)
         return SDSL_HIP_OK;
     (void)hipSetDevice(bv->h.device);
-    (void)sdsl_hip_bv_release_scratch(bv);
+    device_scratch_quiesce(bv->h.device); // (a bucketed batch over this vector may still be running on some stream)
     delete bv;
     return SDSL_HIP_OK;
 }
@@ -1250,7 +1255,7 @@ sdsl_hip_status sdsl_hip_bv_layout_info(sdsl_hip_bv_t bv, uint64_t out[4])
     out[0] = (uint64_t)(uintptr_t)bv->h.lines.p;
     out[1] = bv->h.lines.bytes;
     out[2] = (uint64_t)(uintptr_t)bv->h.sel[1].p;
-    out[3] = (uint64_t)(uintptr_t)bv->h.sort_scratch.p;
+    out[3] = (uint64_t)(uintptr_t)device_scratch(bv->h.device).buf.p;
     return SDSL_HIP_OK;
 }
 
@@ -1260,15 +1265,17 @@ sdsl_hip_status sdsl_hip_bv_release_scratch(sdsl_hip_bv_t bv)
         return SDSL_HIP_OK;
     std::lock_guard<std::mutex> lock(bv->h.scratch_mutex);
     SH_HIP(hipSetDevice(bv->h.device));
-    if (bv->h.scratch_ev)
-    {
-        SH_HIP(hipEventSynchronize(bv->h.scratch_ev));
-        SH_HIP(hipEventDestroy(bv->h.scratch_ev));
-        bv->h.scratch_ev = nullptr;
-    }
-    bv->h.sort_scratch.release();
     bv->h.spread_probe.release();
-    return SDSL_HIP_OK;
+    return device_scratch_release(bv->h.device);
+}
+
+uint64_t sdsl_hip_device_scratch_bytes(int32_t device)
+{
+    if (device < 0 || device >= 64)
+        return 0;
+    DeviceScratch & P = device_scratch(device);
+    std::lock_guard<std::mutex> lock(P.m);
+    return P.buf.bytes;
 }
 
 uint64_t sdsl_hip_bv_size(sdsl_hip_bv_t bv)

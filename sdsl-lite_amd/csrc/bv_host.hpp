@@ -8,6 +8,19 @@
 
 namespace sdslhip {
 
+// Working memory of the bucketed batch paths (bv_swc.hip / bv_sorted.hip / rrr_sorted.hip): ONE pool per device, shared by every
+// handle on it (12 bytes per query of the largest pass so far + tables: 13 GB for 10^9 queries — round 2 kept one per handle).
+// `ev` is recorded behind the last user, `m` orders the host threads that enqueue users; sdsl_hip_*_release_scratch frees it.
+struct DeviceScratch
+{
+    std::mutex m;
+    DevBuf buf;
+    hipEvent_t ev = nullptr;
+};
+DeviceScratch & device_scratch(int device); // (common.cpp; never destroyed: the runtime may be gone by the time statics are)
+void device_scratch_quiesce(int device);            // waits for the pool's last user (before a handle's memory is freed)
+sdsl_hip_status device_scratch_release(int device); // the same, then frees the pool
+
 struct BvHost
 {
     int device = 0;
@@ -16,9 +29,7 @@ struct BvHost
     DevBuf cnts;   // u32 per line, build-time only
     DevBuf sel[2]; // select sample directories
     DevBuf lmask[2], lidx[2], lpos[2]; // sparse stretches of the select directories (BvView::lmask ...)
-    DevBuf sort_scratch; // working memory of the bucketed batch rank (bv_sorted.hip), grown on demand
     DevBuf spread_probe; // two words the spread sample of the automatic dispatch writes (bv_sorted.hip)
-    hipEvent_t scratch_ev = nullptr; // recorded behind the last user of sort_scratch
     struct SelPlan // buckets of the bucketed batch select (bv_sorted.hip), built on first use
     {
         bool ready = false, ok = false;
@@ -26,10 +37,10 @@ struct BvHost
         unsigned bm = 8, bs = 3, nf = 0; // buckets of bm << bs argument ranks
         double wide_frac = 0;
     } sel_plan[2];
-    std::mutex scratch_mutex;
+    std::mutex scratch_mutex; // the handle's own lazily built state (select plans, added directories, the spread probe)
     size_t device_bytes() const
-    {
-        size_t b = lines.bytes + sel[0].bytes + sel[1].bytes + sort_scratch.bytes + spread_probe.bytes;
+    { // (without the device's scratch pool: sdsl_hip_device_scratch_bytes)
+        size_t b = lines.bytes + sel[0].bytes + sel[1].bytes + spread_probe.bytes;
         for (int i = 0; i < 2; ++i)
             b += lmask[i].bytes + lidx[i].bytes + lpos[i].bytes + sel_plan[i].bnd.bytes;
         return b;

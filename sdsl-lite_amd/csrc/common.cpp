@@ -1,5 +1,6 @@
 // common.cpp — error state, device checks, staging buffers, timing hooks, library-level C ABI.
 #include "common.hpp"
+#include "bv_host.hpp"
 
 #include <atomic>
 #include <cstdarg>
@@ -229,6 +230,40 @@ uint64_t next_handle_uid()
 } // namespace sdslhip
 
 using namespace sdslhip;
+
+namespace sdslhip {
+DeviceScratch & device_scratch(int device)
+{
+    static std::mutex mk;
+    static DeviceScratch * pools[64] = {};
+    const int d = device < 0 ? 0 : (device > 63 ? 63 : device);
+    std::lock_guard<std::mutex> lock(mk);
+    if (!pools[d])
+        pools[d] = new DeviceScratch();
+    return *pools[d];
+}
+void device_scratch_quiesce(int device)
+{
+    DeviceScratch & P = device_scratch(device);
+    std::lock_guard<std::mutex> lock(P.m);
+    if (P.ev)
+        (void)hipEventSynchronize(P.ev);
+}
+sdsl_hip_status device_scratch_release(int device)
+{
+    DeviceScratch & P = device_scratch(device);
+    std::lock_guard<std::mutex> lock(P.m);
+    SH_HIP(hipSetDevice(device));
+    if (P.ev)
+    {
+        SH_HIP(hipEventSynchronize(P.ev));
+        SH_HIP(hipEventDestroy(P.ev));
+        P.ev = nullptr;
+    }
+    P.buf.release();
+    return SDSL_HIP_OK;
+}
+} // namespace sdslhip
 
 extern "C" {
 

@@ -1248,11 +1248,7 @@ sdsl_hip_status sdsl_hip_rrr_destroy(sdsl_hip_rrr_t v)
     if (!v)
         return SDSL_HIP_OK;
     (void)hipSetDevice(v->h.device);
-    if (v->h.scratch_ev)
-    {
-        (void)hipEventSynchronize(v->h.scratch_ev);
-        (void)hipEventDestroy(v->h.scratch_ev);
-    }
+    device_scratch_quiesce(v->h.device); // (a bucketed batch over this vector may still be running on some stream)
     delete v;
     return SDSL_HIP_OK;
 }
@@ -1348,24 +1344,26 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
     if (want)
     {
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
+        DeviceScratch & P = device_scratch(h.device);
+        std::lock_guard<std::mutex> plock(P.m);
         const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
         const size_t need = bv_swc_scratch_bytes(BvView{}, pass);
-        if (h.scratch_ev)
-            SH_HIP(hipStreamWaitEvent(s, h.scratch_ev, 0));
-        bool have = h.sort_scratch.bytes >= need;
+        if (P.ev)
+            SH_HIP(hipStreamWaitEvent(s, P.ev, 0));
+        bool have = P.buf.bytes >= need;
         if (!have)
         {
-            if (h.scratch_ev)
-                SH_HIP(hipEventSynchronize(h.scratch_ev));
-            h.sort_scratch.release();
-            have = h.sort_scratch.alloc(need) == SDSL_HIP_OK;
+            if (P.ev)
+                SH_HIP(hipEventSynchronize(P.ev));
+            P.buf.release();
+            have = P.buf.alloc(need) == SDSL_HIP_OK;
         }
         if (have && !h.spread_probe.p)
             have = h.spread_probe.alloc(64) == SDSL_HIP_OK;
         if (have)
         {
-            if (!h.scratch_ev)
-                SH_HIP(hipEventCreateWithFlags(&h.scratch_ev, hipEventDisableTiming));
+            if (!P.ev)
+                SH_HIP(hipEventCreateWithFlags(&P.ev, hipEventDisableTiming));
             sdsl_hip_status st;
             {
                 KernelTimer t(s);
@@ -1375,7 +1373,7 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
                     rrr_sorted_rank_sample(h.view, (const uint64_t *)in.dev, n, s, h.spread_probe.as<uint32_t>());
                     go = h.spread_probe.as<uint32_t>() + 2;
                 }
-                st = rrr_launch_rank_sorted(h.view, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s, h.sort_scratch.p, h.sort_scratch.bytes, go);
+                st = rrr_launch_rank_sorted(h.view, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s, P.buf.p, P.buf.bytes, go);
                 if (st == SDSL_HIP_OK && go)
                 {
                     RrrView dv = h.view;
@@ -1383,7 +1381,7 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
                     rrr_launch_rank_direct(dv, 0, bit, (const uint64_t *)in.dev, (uint64_t *)o.dev, nullptr, n, s);
                 }
             }
-            SH_HIP(hipEventRecord(h.scratch_ev, s));
+            SH_HIP(hipEventRecord(P.ev, s));
             SH_TRY(st);
             SH_HIP(hipGetLastError());
             SH_TRY(o.finish(s));
@@ -1506,6 +1504,8 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
     if (mode != 0 && h.view.sel[bit] && (mode > 0 || (h.view.n_sb >= (UINT64_C(1) << 21) && n >= 8 * h.view.n_sb)))
     {
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
+        DeviceScratch & P = device_scratch(h.device);
+        std::lock_guard<std::mutex> plock(P.m);
         SH_TRY(rrr_select_sorted_prepare(h, bit)); // first use: the bucket boundaries (one small batch, synchronous)
         const bool want = mode > 0 ? h.sel_plan[bit].ok : rrr_sorted_select_applicable(h, bit, n);
         const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
@@ -1513,22 +1513,22 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
         bool have = want;
         if (have)
         {
-            if (h.scratch_ev)
-                SH_HIP(hipStreamWaitEvent(s, h.scratch_ev, 0));
-            if (h.sort_scratch.bytes < need)
+            if (P.ev)
+                SH_HIP(hipStreamWaitEvent(s, P.ev, 0));
+            if (P.buf.bytes < need)
             {
-                if (h.scratch_ev)
-                    SH_HIP(hipEventSynchronize(h.scratch_ev));
-                h.sort_scratch.release();
-                have = h.sort_scratch.alloc(need) == SDSL_HIP_OK;
+                if (P.ev)
+                    SH_HIP(hipEventSynchronize(P.ev));
+                P.buf.release();
+                have = P.buf.alloc(need) == SDSL_HIP_OK;
             }
             if (have && !h.spread_probe.p)
                 have = h.spread_probe.alloc(64) == SDSL_HIP_OK;
         }
         if (have)
         {
-            if (!h.scratch_ev)
-                SH_HIP(hipEventCreateWithFlags(&h.scratch_ev, hipEventDisableTiming));
+            if (!P.ev)
+                SH_HIP(hipEventCreateWithFlags(&P.ev, hipEventDisableTiming));
             sdsl_hip_status st;
             {
                 KernelTimer t(s);
@@ -1538,7 +1538,7 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
                     rrr_sorted_select_sample(h, bit, (const uint64_t *)in.dev, n, s, h.spread_probe.as<uint32_t>());
                     go = h.spread_probe.as<uint32_t>() + 2;
                 }
-                st = rrr_launch_select_sorted(h, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s, h.sort_scratch.p, h.sort_scratch.bytes, go);
+                st = rrr_launch_select_sorted(h, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s, P.buf.p, P.buf.bytes, go);
                 if (st == SDSL_HIP_OK && go)
                 {
                     TimingPause pause;
@@ -1547,7 +1547,7 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
                     st = rrr_launch_select(dv, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s);
                 }
             }
-            SH_HIP(hipEventRecord(h.scratch_ev, s));
+            SH_HIP(hipEventRecord(P.ev, s));
             SH_TRY(st);
             SH_HIP(hipGetLastError());
             SH_TRY(o.finish(s));

@@ -15,7 +15,7 @@ struct RrrHost
     unsigned sparse_max = 10; // classes sparse_max + 1 .. 62 - sparse_max are stored raw (rrr_device.hpp)
     unsigned fmt = 0;         // record format (rrr_device.hpp: RrrFmtW / RrrFmtS); the vectors of a wavelet tree are always wide
     bool allow_slim = false;  // set by the stand-alone handle before the vector is built
-    DevBuf sort_scratch, spread_probe; // working memory of the bucketed batch rank (rrr_sorted.hip), grown on demand
+    DevBuf spread_probe; // the verdict of the spread sample (rrr_sorted.hip); the passes' working memory is the device's pool (bv_host.hpp)
     struct SelPlan // buckets of the bucketed batch select (rrr_sorted.hip), built on first use
     {
         bool ready = false, ok = false;
@@ -23,11 +23,10 @@ struct RrrHost
         unsigned bm = 8, bs = 3, nf = 0, rlog = 7; // buckets of bm << bs argument ranks; 2^rlog records per slice
         double wide_frac = 0;
     } sel_plan[2];
-    hipEvent_t scratch_ev = nullptr;   // recorded behind the last user of sort_scratch
     std::mutex scratch_mutex;
     size_t device_bytes() const
     {
-        return rec.bytes + stream.bytes + tables.bytes + sel[0].bytes + sel[1].bytes + sort_scratch.bytes + spread_probe.bytes;
+        return rec.bytes + stream.bytes + tables.bytes + sel[0].bytes + sel[1].bytes + spread_probe.bytes;
     }
 };
 // large batches, bucketed by slice of the record array (rrr_sorted.hip)

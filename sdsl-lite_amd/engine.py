@@ -235,6 +235,11 @@ def set_option(name: str, value: int) -> None:
     capi.check(capi.lib().sdsl_hip_set_option(name.encode(), int(value)))
 
 
+def device_scratch_bytes(device: int = 0) -> int:
+    """Bytes of the device's scratch pool for the bucketed batch paths (shared by all handles; release_scratch frees it)."""
+    return int(capi.lib().sdsl_hip_device_scratch_bytes(int(device)))
+
+
 def last_phases() -> dict:
     """Per-pass milliseconds of the most recent bucketed batch rank (needs set_option("trace_phases", 1))."""
     buf = C.create_string_buffer(1024)
