@@ -74,7 +74,7 @@ __device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsig
 {
     uint64_t bits = 0;
     int hi = 62; // candidate rows m = 62 - position
-    while (k > 0)
+    while (k > 2)
     {
         // largest m in [k-1, hi] with C(m, k) <= nr  (C(k-1,k) = 0 always qualifies)
         int lo = (int)k - 1, h = hi;
@@ -87,12 +87,30 @@ __device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsig
                 h = mid - 1;
         }
         if (62 - lo >= (int)stop)
-            break;
+            return bits;
         bits |= UINT64_C(1) << (62 - lo);
         nr -= T->binom[lo][k];
         --k;
         hi = lo - 1;
     }
+    // the last two set bits in closed form, without table reads: nr = C(m2, 2) + m3 with m2 > m3 — m2 from a square root,
+    // checked in integers (a block of class k costs max(0, k - 2) bisections instead of k)
+    if (k == 2)
+    {
+        const unsigned x = (unsigned)nr; // < C(63, 2)
+        unsigned m = (unsigned)((1.0f + __builtin_sqrtf(1.0f + 8.0f * (float)x)) * 0.5f);
+        if (m * (m - 1) / 2 > x)
+            --m;
+        else if ((m + 1) * m / 2 <= x)
+            ++m;
+        if (62 - m >= stop)
+            return bits;
+        bits |= UINT64_C(1) << (62 - m);
+        nr = x - m * (m - 1) / 2;
+        k = 1;
+    }
+    if (k == 1 && 62 - (unsigned)nr < stop)
+        bits |= UINT64_C(1) << (62 - (unsigned)nr);
     return bits;
 }
 
