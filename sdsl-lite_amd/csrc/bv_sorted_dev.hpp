@@ -1,6 +1,7 @@
 // bv_sorted_dev.hpp — what the two bucketed pipelines (bv_sorted.hip: one-sweep look-back; bv_swc.hip: static streams with
 // write combining) share: key layout, digits, block scans.  DESIGN.md §3.5.
 #pragma once
+#include <type_traits>
 #include <functional>
 #include <string>
 
@@ -157,6 +158,58 @@ __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned
     const uint32_t l = (uint32_t)L; // < 2^26
     dig = l >> (kSliceLog + g.d2);
     key = (((l >> kSliceLog) & ((1u << g.d2) - 1)) << kKey2Bits) | ((l & ((1u << kSliceLog) - 1)) << kOffBits) | off;
+}
+// The same with the kind of query fixed at compile time (OP = SrGeom::op; plain rank: 0 for vectors below 2^38 bits, 4 above) and
+// without per-key branches: the counting pass and pass 1 are bound by the instructions they issue per key (47 and 54 of them —
+// 1.2 and 1.4 ms of VALU issue per 10^9 keys), and with the run-time dispatch every one of the sixteen unrolled keys carried its
+// own ladder of scalar branches (the counting kernel had grown to 4800 instructions).
+template <int OP>
+__device__ __forceinline__ void sr_key1_t(uint64_t pos, const SrGeom & g, unsigned & dig, uint32_t & key)
+{
+    if constexpr (OP == 1)
+    {
+        const bool bad = pos == 0 || pos > g.total;
+        const uint64_t k = pos - 1;
+        const uint32_t f = (uint32_t)(((k >> g.bs) * g.binv) >> 32); // k / B
+        const uint32_t ky = ((f & ((1u << g.d2) - 1)) << g.kb) | (uint32_t)(k - (uint64_t)f * g.B);
+        dig = bad ? 0u : f >> g.d2;
+        key = bad ? (pos != 0 && g.over_is_size ? kMark : kBad) : ky;
+    }
+    else if constexpr (OP == 2 || OP == 3)
+    {
+        const bool bad = pos > g.n_bits;
+        unsigned d;
+        uint32_t ky;
+        sr_key1_rrr<OP == 2 ? kSrRecBits : kSrRecBitsSlim>(pos, g, d, ky);
+        dig = bad ? 0u : d;
+        key = bad ? kBad : ky;
+    }
+    else
+    {
+        const bool bad = pos > g.n_bits;
+        uint64_t L;
+        unsigned off;
+        line_of(pos, OP == 0, L, off);
+        const uint32_t l = (uint32_t)L; // < 2^26
+        dig = bad ? 0u : l >> (kSliceLog + g.d2);
+        key = bad ? kBad : (((l >> kSliceLog) & ((1u << g.d2) - 1)) << kKey2Bits) | ((l & ((1u << kSliceLog) - 1)) << kOffBits) | off;
+    }
+}
+// calls f with the compile-time kind of a geometry's queries
+template <class Fn>
+inline void sr_dispatch_op(const SrGeom & g, Fn && f)
+{
+    switch (g.op)
+    {
+        case 1: f(std::integral_constant<int, 1>{}); break;
+        case 2: f(std::integral_constant<int, 2>{}); break;
+        case 3: f(std::integral_constant<int, 3>{}); break;
+        default:
+            if (g.small)
+                f(std::integral_constant<int, 0>{});
+            else
+                f(std::integral_constant<int, 4>{});
+    }
 }
 // pass 2: digit and final key of a pass-1 key
 __device__ __forceinline__ void sr_key2(uint32_t k1, const SrGeom & g, unsigned & dig, uint32_t & key)

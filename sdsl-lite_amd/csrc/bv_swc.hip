@@ -113,7 +113,7 @@ size_t sw_carve(SwBuf & b, void * scratch, uint64_t n, unsigned tile, const SwGe
 // (The first form triggered on the value 2^15 - 1 itself: a move that landed more than 2^15 increments late left the field
 // above the trigger for good, and a batch of 10^8 positions inside three slices lost 65536 keys of one — found by the
 // reference-digest test on the windowed batch.)
-template <unsigned PER>
+template <unsigned PER, int OP>
 __global__ __launch_bounds__(kHT) void k_sw_hist(SrGeom g, SwGeom w, const uint64_t * __restrict__ idx, uint32_t * __restrict__ counts1,
                                                  uint32_t * __restrict__ fine_h)
 {
@@ -156,28 +156,45 @@ __global__ __launch_bounds__(kHT) void k_sw_hist(SrGeom g, SwGeom w, const uint6
             if (cn < khi)
                 fetch(cn, pn);
             unsigned fidv[PER]; // slice of the key | what its counter held << 16
-#pragma unroll
-            for (unsigned u = 0; u < PER; ++u)
+            // (a chunk that lies inside the unit — all but the last one — needs no per-key range checks: 5 of 44 instructions)
+            auto count = [&](auto full)
             {
-                const uint64_t q = c + u * kHT + t;
-                unsigned dig;
-                uint32_t key;
-                sr_key1(p[u], g, dig, key);
-                const bool on = q < khi;
-                atomicAdd(&uhist[on ? dig : kBins], 1u);
-                const unsigned fid = key >= kMark ? 0u : (dig << g.d2) | (key >> g.kb);
-                const unsigned sh = (fid & 1u) << 4;
-                const uint32_t old = atomicAdd(&fine[on ? fid >> 1 : w.fine_words], on ? 1u << sh : 0u);
-                fidv[u] = on ? fid | (((old >> sh) & 0xFFFFu) << 16) : 0u;
-            }
+                constexpr bool FULL = decltype(full)::value;
+#pragma unroll
+                for (unsigned u = 0; u < PER; ++u)
+                {
+                    unsigned dig;
+                    uint32_t key;
+                    sr_key1_t<OP>(p[u], g, dig, key);
+                    const bool on = FULL || c + u * kHT + t < khi;
+                    atomicAdd(&uhist[on ? dig : kBins], 1u);
+                    const unsigned fid = key >= kMark ? 0u : (dig << g.d2) | (key >> g.kb);
+                    const unsigned sh = (fid & 1u) << 4;
+                    const uint32_t old = atomicAdd(&fine[on ? fid >> 1 : w.fine_words], on ? 1u << sh : 0u);
+                    fidv[u] = on ? fid | (((old >> sh) & 0xFFFFu) << 16) : 0u;
+                }
+            };
+            if (cn <= khi)
+                count(std::true_type{});
+            else
+                count(std::false_type{});
+            // an increment that was its field's 4096th, 8192nd, ...: move that much to the global row.  Rare (one key in 4096 of
+            // a slice's): one test per chunk instead of one branch per key
+            bool any = false;
 #pragma unroll
             for (unsigned u = 0; u < PER; ++u)
-                if (((fidv[u] >> 16) & (kMoveAt - 1)) == kMoveAt - 1)
-                { // this increment took the field to 2^15: move that much to the global row
-                    const unsigned fid = fidv[u] & 0xFFFFu;
-                    atomicSub(&fine[fid >> 1], kMoveAt << ((fid & 1u) << 4));
-                    atomicAdd(row + fid, kMoveAt);
-                }
+                any |= ((fidv[u] >> 16) & (kMoveAt - 1)) == kMoveAt - 1;
+            if (any)
+            {
+#pragma unroll
+                for (unsigned u = 0; u < PER; ++u)
+                    if (((fidv[u] >> 16) & (kMoveAt - 1)) == kMoveAt - 1)
+                    {
+                        const unsigned fid = fidv[u] & 0xFFFFu;
+                        atomicSub(&fine[fid >> 1], kMoveAt << ((fid & 1u) << 4));
+                        atomicAdd(row + fid, kMoveAt);
+                    }
+            }
             if (cn < khi)
             {
 #pragma unroll
@@ -312,7 +329,7 @@ __device__ __forceinline__ unsigned carry_at(unsigned b, unsigned i)
 // is appended to them, every whole kCA-aligned chunk goes out (carry first), the tail becomes the new carry.  The global
 // layout is exactly that of the unbuffered pass — only when and in which pieces a key is written changes — so slots and
 // tile histograms mean what they always meant.  The next tile's keys are requested before this tile is written out.
-template <int P, unsigned TT, unsigned PER>
+template <int P, unsigned TT, unsigned PER, int OP>
 __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, const uint64_t * __restrict__ idx, const uint32_t * __restrict__ keys_in,
                                                        const uint32_t * __restrict__ offs1, const uint32_t * __restrict__ in_lo,
                                                        const uint32_t * __restrict__ tp2, const uint32_t * __restrict__ fstart,
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(TT, 4) void k_sw_partition(SrGeom g, SwGeom w, cons
                 const unsigned q = u * TT + t;
                 unsigned d;
                 if (P == 1)
-                    sr_key1((uint64_t)raw[u], g, d, key[u]);
+                    sr_key1_t<OP>((uint64_t)raw[u], g, d, key[u]);
                 else
                     sr_key2((uint32_t)raw[u], g, d, key[u]);
                 // (what lies beyond the tile's end counts into a bin of its own: all the atomics are issued back to back)
@@ -844,7 +861,16 @@ sdsl_hip_status sw_run_with(const SwCallbacks & cb, int bit, const uint64_t * d_
     static const int pb_env = getenv("SDSL_HIP_SWC_PART_BLOCKS") ? atoi(getenv("SDSL_HIP_SWC_PART_BLOCKS")) : 0;
     static const int ub_env = getenv("SDSL_HIP_SWC_UNP_BLOCKS") ? atoi(getenv("SDSL_HIP_SWC_UNP_BLOCKS")) : 0;
     // the slice histogram may fill the CU's LDS (a per-device attribute of the kernel; setting it is a host-side table write)
-    SH_HIP(hipFuncSetAttribute((const void *)k_sw_hist<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    {
+        hipError_t e = hipSuccess;
+        auto set = [&](const void * f) { const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e = e == hipSuccess ? r : e; };
+        set((const void *)k_sw_hist<16, 0>);
+        set((const void *)k_sw_hist<16, 1>);
+        set((const void *)k_sw_hist<16, 2>);
+        set((const void *)k_sw_hist<16, 3>);
+        set((const void *)k_sw_hist<16, 4>);
+        SH_HIP(e);
+    }
     for (uint64_t done = 0; done < n;)
     {
         const uint64_t cnt = n - done < kSwMaxPass ? n - done : kSwMaxPass;
@@ -869,7 +895,8 @@ sdsl_hip_status sw_run_with(const SwCallbacks & cb, int bit, const uint64_t * d_
         pt.mark();
         SH_HIP(hipMemsetAsync(b.fine_h, 0, (size_t)kHB * w.nfw * 4, s));
         SH_HIP(hipMemsetAsync(b.tickets, 0, 16, s));
-        hipLaunchKernelGGL(k_sw_hist<16>, dim3(kHB), dim3(kHT), (w.fine_words + kBins + 2) * 4, s, g, w, idx, b.counts1, b.fine_h);
+        sr_dispatch_op(g, [&](auto op)
+                       { hipLaunchKernelGGL((k_sw_hist<16, decltype(op)::value>), dim3(kHB), dim3(kHT), (w.fine_words + kBins + 2) * 4, s, g, w, idx, b.counts1, b.fine_h); });
         pt.mark("hist");
         sr_launch_bin_offsets(bins1, w.U1, b.counts1, b.btot, b.bstart1, b.offs1, s);
         hipLaunchKernelGGL(k_sw_seg_reduce, dim3((w.nf + 255) / 256), dim3(256), 0, s, w, b.fine_h, b.segsum, b.tot);
@@ -900,12 +927,16 @@ sdsl_hip_status sw_run_with(const SwCallbacks & cb, int bit, const uint64_t * d_
         const unsigned pblocks = pb_env >= 1 ? (unsigned)pb_env : 512u;
         // pass 1 holds 64-bit positions: 1024 threads x 8 keep a tile's keys and the next tile's within the register file (512 x 16
         // spilled 33 VGPRs: 4.2 against 3.1 ms); one block per CU
-        hipLaunchKernelGGL((k_sw_partition<1, 1024, 8>), dim3(pb_env >= 1 ? (unsigned)pb_env : 256u), dim3(1024), 0, s, g, w, idx,
-                           (const uint32_t *)nullptr, b.offs1, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
-                           (const uint32_t *)nullptr, b.tickets + 0, b.keys1, b.slots1, b.thist1, b.ck1, (uint64_t *)nullptr);
+        sr_dispatch_op(g, [&](auto op)
+                       {
+                           hipLaunchKernelGGL((k_sw_partition<1, 1024, 8, decltype(op)::value>), dim3(pb_env >= 1 ? (unsigned)pb_env : 256u), dim3(1024), 0, s,
+                                              g, w, idx, (const uint32_t *)nullptr, b.offs1, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                              (const uint32_t *)nullptr, (const uint32_t *)nullptr, b.tickets + 0, b.keys1, b.slots1, b.thist1, b.ck1,
+                                              (uint64_t *)nullptr);
+                       });
         pt.mark("part1");
         hipLaunchKernelGGL(k_sw_units2, dim3(1), dim3(1024), 0, s, g, w, b.offs1, b.in_lo, b.tp2);
-        hipLaunchKernelGGL((k_sw_partition<2, kSwT, kSwPer>), dim3(pblocks), dim3(kSwT), 0, s, g, w, (const uint64_t *)nullptr, b.keys1, b.offs1,
+        hipLaunchKernelGGL((k_sw_partition<2, kSwT, kSwPer, 0>), dim3(pblocks), dim3(kSwT), 0, s, g, w, (const uint64_t *)nullptr, b.keys1, b.offs1,
                            b.in_lo, b.tp2, b.fstart, b.segsum, b.tickets + 1, b.keys2, b.slots2, b.thist2, b.ck2, b.tdesc2);
         pt.mark("part2");
         SH_TRY(cb.answers(g, w.nf, b.fstart, b.ioff, b.keys2, b.hf, b.marked, s));
