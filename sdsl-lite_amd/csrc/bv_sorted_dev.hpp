@@ -106,17 +106,23 @@ __device__ __forceinline__ unsigned block_excl_scan_bins(unsigned * a, unsigned 
 template <uint32_t REC_BITS>
 __device__ __forceinline__ void sr_key1_rrr(uint64_t pos, const SrGeom & g, unsigned & dig, uint32_t & key)
 {
-    uint64_t rec = pos / REC_BITS;
-    unsigned in_rec = (unsigned)(pos - rec * REC_BITS);
+    // pos / REC_BITS in 32-bit arithmetic (positions are below 2^40): pos = hi 2^20 + lo, 2^20 = q0 REC + r0, so
+    // pos / REC = hi q0 + (hi r0 + lo) / REC with a 32-bit numerator — half the instructions of the 64-bit division by a constant
+    constexpr uint32_t q0 = (1u << 20) / REC_BITS, r0 = (1u << 20) % REC_BITS;
+    static_assert((uint64_t)(r0 + 1) << 20 < (UINT64_C(1) << 32), "numerator of the second term must fit 32 bits");
+    const uint32_t hi = (uint32_t)(pos >> 20), lo = (uint32_t)pos & 0xFFFFFu;
+    const uint32_t num = hi * r0 + lo, q1 = num / REC_BITS;
+    uint32_t rec = hi * q0 + q1;
+    unsigned in_rec = num - q1 * REC_BITS;
     if (in_rec == 0 && pos == g.n_bits && pos != 0)
     { // rank(size()) when the vector ends with a record: "all 63 bits of its last block"
         --rec;
         in_rec = REC_BITS;
     }
     const unsigned blk = in_rec == REC_BITS ? REC_BITS / 63 - 1 : in_rec / 63, off = in_rec - blk * 63; // off <= 63
-    const uint32_t sl = (uint32_t)(rec >> g.rlog);
+    const uint32_t sl = rec >> g.rlog;
     dig = sl >> g.d2;
-    key = ((sl & ((1u << g.d2) - 1)) << g.kb) | (((uint32_t)rec & ((1u << g.rlog) - 1)) << 12) | (blk << 6) | off;
+    key = ((sl & ((1u << g.d2) - 1)) << g.kb) | ((rec & ((1u << g.rlog) - 1)) << 12) | (blk << 6) | off;
 }
 
 // pass 1: digit and 32-bit key of a position
