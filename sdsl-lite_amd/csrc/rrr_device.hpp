@@ -581,9 +581,10 @@ __device__ __forceinline__ RrrSelLoc rrr_sel_locate_w(const RrrView & v, const R
 // the same on a slim record: two prefix counts pick the group of sixteen blocks, a bisection over running sums of its 4-bit
 // fields the block
 template <int BIT>
-__device__ __forceinline__ RrrSelLoc rrr_sel_locate_s(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
+__device__ __forceinline__ RrrSelLoc rrr_sel_locate_s(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & hit)
 {
     using F = RrrFmtS;
+    const RrrSelHit h = hit; // (a copy: taken by reference the hit stayed in scratch memory, 80 bytes per lane)
     unsigned want = (unsigned)(k0 - h.before);
     unsigned o[3], b[3];
     rrs_prefix(h.P, h.r1, 0, o[0], b[0]);
