@@ -1110,10 +1110,10 @@ __global__ __launch_bounds__(256) void k_wt8_sel_dir(const uint64_t * __restrict
     const uint32_t c0 = reinterpret_cast<const uint32_t *>(ln + 4 * (t >> 1))[t & 1];
     const uint32_t c1 = line + 1 < n_lines ? reinterpret_cast<const uint32_t *>(ln + kFusedWords + 4 * (t >> 1))[t & 1]
                                           : a.cnt[t];
-    const uint32_t j = (c0 + 255u) >> 8;
-    if (c1 > c0 && (j << 8) < c1)
+    constexpr uint32_t S = 1u << kFselLog;
+    for (uint32_t j = (c0 + S - 1) >> kFselLog; c1 > c0 && (j << kFselLog) < c1; ++j)
     {
-        uint32_t r = (j << 8) - c0; // rank of the wanted occurrence inside the line
+        uint32_t r = (j << kFselLog) - c0; // rank of the wanted occurrence inside the line
         for (unsigned g = 0; g < 4; ++g)
         {
             const uint64_t p0 = ln[4 * g + 1], p1 = ln[4 * g + 2], p2 = ln[4 * g + 3];
@@ -1261,7 +1261,7 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
                 if (!ok || size[x] == 0)
                     continue;
                 args[r].cnt[t] = FS.cnt[r][t] = (uint32_t)size[x];
-                args[r].n_samples[t] = (uint32_t)((size[x] + 255) >> 8) + 1;
+                args[r].n_samples[t] = (uint32_t)((size[x] + (1u << kFselLog) - 1) >> kFselLog) + 1;
                 args[r].off[t] = FS.off[r][t] = (uint32_t)n_dir;
                 n_dir += args[r].n_samples[t];
             }

@@ -7,6 +7,9 @@
 // workgroup stages it in LDS once; the concatenated bit vector (wt_pc.hpp:90) lives in HBM as
 // rank lines (bv_device.hpp).  One rank cascade level = ONE 64-byte line fetch.
 #pragma once
+#ifndef SDSL_HIP_FSEL_LOG
+#define SDSL_HIP_FSEL_LOG 8
+#endif
 #include "bv_device.hpp"
 #include "rrr_device.hpp"
 
@@ -33,6 +36,7 @@ struct WtFusedTables // node tables of the fused layout (below); staged in LDS b
 // select on the fused layout: for every fused node u and slot t the directory lists the position (inside u's sequence)
 // of every 256th occurrence of t and ends with u's size.  off[root_id[u]][t] is where the list of (u, t) starts in
 // WtView::f_sel, cnt[..][t] the number of occurrences.
+constexpr unsigned kFselLog = SDSL_HIP_FSEL_LOG; // the directory lists every 2^kFselLog-th occurrence
 constexpr int kFselMaxRoots = 80; // a balanced tree over 256 symbols has 1 + 8 + 64 = 73
 constexpr uint32_t kFselNone = 0xFFFFFFFFu;
 struct WtFusedSelTables
@@ -274,12 +278,12 @@ struct FselBracket
 
 __device__ __forceinline__ FselBracket fsel_bracket(const uint32_t * dir, uint32_t off, uint32_t k, uint32_t total)
 {
-    const uint32_t j = k >> 8;
+    const uint32_t j = k >> kFselLog;
     FselBracket b;
     b.plo = dir[off + j];
     b.phi = dir[off + j + 1];
-    b.lo_cnt = j << 8;
-    b.hi_cnt = (j + 1) << 8;
+    b.lo_cnt = j << kFselLog;
+    b.hi_cnt = (j + 1) << kFselLog;
     if (b.hi_cnt > total)
         b.hi_cnt = total; // the last entry is the node's size: all `total` occurrences lie in front of it
     return b;

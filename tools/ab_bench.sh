@@ -3,7 +3,7 @@
 # alternating.  usage (via gpurun): tools/ab_bench.sh [bench args]     (default: the headline only)
 L=sdsl-lite_amd/lib
 ARGS=${*:---extras none --no-cpu --steps 8}
-for v in A B A B; do
+for v in ${VARIANTS:-A B A B}; do
   cp $L/$v.so $L/libsdsl_hip.so
   python bench.py $ARGS 2>/dev/null | python -c "
 import json,sys
