@@ -79,6 +79,7 @@ static void check_select(bit_vector const & bv, uint64_t args, std::mt19937_64 &
 int main(int argc, char ** argv)
 {
     setvbuf(stderr, nullptr, _IONBF, 0);
+    setvbuf(stdout, nullptr, _IOLBF, 0); // (piped into a test: a hang must show how far the run got)
     std::mt19937_64 rng(4242);
     for (uint64_t n : {1000ull, 100000ull, 1000003ull})
         for (int dens : {50, 3, 97})
