@@ -16,9 +16,9 @@ EXE = os.path.join(ROOT, "oracle", "_ref", "adaptor_parity")
 def test_adaptors_against_real_sdsl(gpu):
     if not os.path.exists(EXE):
         pytest.skip("oracle/_ref/adaptor_parity not built (needs the reference tree at build time)")
-    # (the client takes a few seconds.  Once in some forty runs on the test pool it hung until the timeout without having printed
-    # anything — before its first check, i.e. while the process attached to the GPU / RCCL came up; a second attempt is made
-    # before that counts as a failure, and what the first one printed is kept)
+    # (the client takes a few seconds.  Once on the test pool it did not finish within ten minutes — not reproduced in forty
+    # further runs, three of them full suites back to back; a second attempt is made before that counts as a failure, and what
+    # the first one printed is kept for the message)
     r, notes = None, ""
     for attempt, limit in enumerate((240, 600)):
         try:
