@@ -21,32 +21,37 @@ namespace {
 
 static_assert(kSrRecBits == RrrFmtW::SB && kSrRecBitsSlim == RrrFmtS::SB, "bv_sorted_dev.hpp: kSrRecBits* must be the record lengths of rrr_device.hpp");
 constexpr unsigned kRsT = 1024;      // threads of an answering block
-constexpr unsigned kRsCols = 12;     // binomial columns the sparse decoder needs (classes <= 10 after the complement)
+constexpr unsigned kRsCol0 = 3, kRsCols = 8; // binomial columns the sparse decoder reads: classes 3..10 after the complement
+                                             // (the last two set bits come in closed form)
+constexpr unsigned kRsTop0 = 53;     // C(63, k) is needed for the complemented classes only: k >= 63 - 10
 constexpr unsigned kRsBins = 16;     // decode-cost classes of the per-slice counting sort
 
-// Records are decoded in CHUNKS of a slice (wide records: the whole slice; slim ones, 42 blocks each: half of it, so that two
-// answering blocks still fit a CU): what only the decoder needs is sized for a chunk (NC blocks), what the keys read for the slice.
+// Records may be decoded in CHUNKS of a slice (what only the decoder needs is then sized for a chunk of NC blocks, what the keys
+// read for the slice).  Slim records (42 blocks: 5376 per slice) took two chunks to leave room for two answering blocks per CU,
+// at the price of a second round of barriers and of exposed fetches (5.35 ms against the wide format's 4.65); with the class fields
+// in the spare bits of the offset positions (slim classes are 4-bit fields, positions below 2^12) and only the tables the
+// decoder still reads, a whole slice fits in 79.3 KiB and is decoded in one.
 template <class F>
 constexpr unsigned rs_chunks()
 {
-    return F::id ? 2u : 1u;
+    return 1u;
 }
 struct RsLds
 { // carved out of dynamic LDS; NB = blocks of a slice, NC = blocks of a chunk
     uint64_t * raw;      // [NB] the slice's blocks, plain
-    uint64_t * cbin;     // [64][kRsCols]
-    uint64_t * top;      // [64]: C(63, k)
+    uint64_t * cbin;     // [64][kRsCols]: C(m, kRsCol0 + j)
+    uint64_t * top;      // [11]: C(63, kRsTop0 + j)
     uint64_t * rptr;     // [S]: first word of the record's stretch of the overflow stream
     uint32_t * rones;    // [S]: ones in front of the record, relative to the slice
     uint16_t * pre;      // [NB] ones of the record in front of the block
-    uint16_t * obit;     // [NC] where the block's field starts in the record's offset bits
+    uint16_t * obit;     // [NC] where the block's field starts in the record's offset bits (slim: | class field << 12)
     uint16_t * ord;      // [NC] blocks in order of decode cost
-    uint8_t * cls;       // [NC] class fields
+    uint8_t * cls;       // [NC] class fields (wide records only)
     uint8_t * space;     // [64]
     unsigned * cnt;      // [kRsBins + 1]
 };
 
-__device__ __forceinline__ RsLds rs_carve(unsigned char * base, unsigned S, unsigned K, unsigned chunks)
+__device__ __forceinline__ RsLds rs_carve(unsigned char * base, unsigned S, unsigned K, unsigned chunks, bool packed_cls)
 {
     const unsigned NB = S * K, NC = NB / chunks;
     RsLds L;
@@ -59,13 +64,13 @@ __device__ __forceinline__ RsLds rs_carve(unsigned char * base, unsigned S, unsi
     };
     L.raw = (uint64_t *)take((size_t)NB * 8);
     L.cbin = (uint64_t *)take(64 * kRsCols * 8);
-    L.top = (uint64_t *)take(64 * 8);
+    L.top = (uint64_t *)take((64 - kRsTop0) * 8);
     L.rptr = (uint64_t *)take((size_t)S * 8);
     L.rones = (uint32_t *)take((size_t)S * 4);
     L.pre = (uint16_t *)take((size_t)NB * 2);
     L.obit = (uint16_t *)take((size_t)NC * 2);
     L.ord = (uint16_t *)take((size_t)NC * 2);
-    L.cls = (uint8_t *)take(NC);
+    L.cls = (uint8_t *)take(packed_cls ? 0 : NC);
     L.space = (uint8_t *)take(64);
     L.cnt = (unsigned *)take((kRsBins + 1) * 4);
     return L;
@@ -75,8 +80,8 @@ size_t rs_lds_bytes(unsigned S, unsigned fmt)
 {
     const size_t NB = (size_t)S * (fmt ? RrrFmtS::K : RrrFmtW::K), NC = NB / (fmt ? rs_chunks<RrrFmtS>() : rs_chunks<RrrFmtW>());
     auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    return up(NB * 8) + up(64 * kRsCols * 8) + up(64 * 8) + up((size_t)S * 8) + up((size_t)S * 4) + up(NB * 2) + 2 * up(NC * 2) + up(NC) + up(64)
-           + up((kRsBins + 1) * 4);
+    return up(NB * 8) + up(64 * kRsCols * 8) + up((64 - kRsTop0) * 8) + up((size_t)S * 8) + up((size_t)S * 4) + up(NB * 2) + 2 * up(NC * 2)
+           + up(fmt ? 0 : NC) + up(64) + up((kRsBins + 1) * 4);
 }
 
 // the block of class k whose field holds f, with the compact tables (rrr_decode_block, rrr_device.hpp)
@@ -86,7 +91,7 @@ __device__ __forceinline__ uint64_t rs_decode(const RsLds & L, unsigned k, uint6
         return f;
     const bool flip = k > 31;
     unsigned kk = flip ? kRrrBS - k : k;
-    uint64_t nr = flip ? L.top[k] - 1 - f : f;
+    uint64_t nr = flip ? L.top[k - kRsTop0] - 1 - f : f;
     uint64_t bits = 0;
     int hi = 62;
     while (kk > 2)
@@ -95,13 +100,13 @@ __device__ __forceinline__ uint64_t rs_decode(const RsLds & L, unsigned k, uint6
         while (lo < h)
         {
             const int mid = (lo + h + 1) >> 1;
-            if (L.cbin[mid * kRsCols + kk] <= nr)
+            if (L.cbin[mid * kRsCols + kk - kRsCol0] <= nr)
                 lo = mid;
             else
                 h = mid - 1;
         }
         bits |= UINT64_C(1) << (62 - lo);
-        nr -= L.cbin[lo * kRsCols + kk];
+        nr -= L.cbin[lo * kRsCols + kk - kRsCol0];
         --kk;
         hi = lo - 1;
     }
@@ -191,9 +196,14 @@ __device__ __forceinline__ void rs_decode_records(const RsLds & L, const RrrView
                 else
                     k = rrs_cls(cw, u);
                 const unsigned lb = lr * F::K + gi * F::GRP + u, len = L.space[k];
-                L.cls[lb] = (uint8_t)k;
+                if constexpr (F::id == 0)
+                {
+                    L.cls[lb] = (uint8_t)k;
+                    L.obit[lb] = (uint16_t)bits;
+                }
+                else
+                    L.obit[lb] = (uint16_t)(bits | (k << 12));
                 L.pre[c0 * F::K + lb] = (uint16_t)ones;
-                L.obit[lb] = (uint16_t)bits;
                 unsigned real = k;
                 if (F::id && k == kEsc) // an escaped block says how many ones it has
                     real = popc64(rrr_field_t<F::INL0, F::INLW>(v, rec, F::ptr(r1), bits, kRrrBS));
@@ -219,7 +229,7 @@ __device__ __forceinline__ void rs_decode_records(const RsLds & L, const RrrView
         __syncthreads();
         for (unsigned b = t; b < nb; b += kRsT)
         {
-            const unsigned k = L.cls[b], len = L.space[k];
+            const unsigned k = F::id ? L.obit[b] >> 12 : L.cls[b], len = L.space[k];
             const unsigned c = rrr_raw_width(len) ? 0u : (k > 31 ? kRrrBS - k : k);
             L.ord[atomicAdd(&L.cnt[c < kRsBins ? c : kRsBins - 1], 1u)] = (uint16_t)b;
         }
@@ -232,9 +242,10 @@ __device__ __forceinline__ void rs_decode_records(const RsLds & L, const RrrView
             const unsigned i2 = i + kRsT;
             const bool two = i2 < nb;
             const unsigned b1 = L.ord[i], b2 = two ? L.ord[i2] : b1;
-            const unsigned ra = c0 + b1 / F::K, rb = c0 + b2 / F::K, k1 = L.cls[b1], k2 = L.cls[b2];
-            const uint64_t f1 = rrr_field_t<F::INL0, F::INLW>(v, recs + (uint64_t)ra * kRecWords, L.rptr[ra], L.obit[b1], L.space[k1]);
-            const uint64_t f2 = rrr_field_t<F::INL0, F::INLW>(v, recs + (uint64_t)rb * kRecWords, L.rptr[rb], L.obit[b2], L.space[k2]);
+            const unsigned ra = c0 + b1 / F::K, rb = c0 + b2 / F::K, o1 = L.obit[b1], o2 = L.obit[b2];
+            const unsigned k1 = F::id ? o1 >> 12 : L.cls[b1], k2 = F::id ? o2 >> 12 : L.cls[b2];
+            const uint64_t f1 = rrr_field_t<F::INL0, F::INLW>(v, recs + (uint64_t)ra * kRecWords, L.rptr[ra], o1 & 0xFFFu, L.space[k1]);
+            const uint64_t f2 = rrr_field_t<F::INL0, F::INLW>(v, recs + (uint64_t)rb * kRecWords, L.rptr[rb], o2 & 0xFFFu, L.space[k2]);
             L.raw[c0 * F::K + b1] = rs_decode(L, k1, f1);
             if (two)
                 L.raw[c0 * F::K + b2] = rs_decode(L, k2, f2);
@@ -267,13 +278,14 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
     if (go && !*go)
         return;
     const unsigned S = 1u << rlog, t = threadIdx.x;
-    const RsLds L = rs_carve(rs_lds, S, F::K, rs_chunks<F>());
+    const RsLds L = rs_carve(rs_lds, S, F::K, rs_chunks<F>(), F::id != 0);
     // the tables the decoder reads, once per block of threads
     for (unsigned i = t; i < 64 * kRsCols; i += kRsT)
-        L.cbin[i] = v.tables->binom[i / kRsCols][i % kRsCols];
+        L.cbin[i] = v.tables->binom[i / kRsCols][kRsCol0 + i % kRsCols];
     for (unsigned i = t; i < 64; i += kRsT)
     {
-        L.top[i] = v.tables->binom[63][i];
+        if (i >= kRsTop0)
+            L.top[i - kRsTop0] = v.tables->binom[63][i];
         L.space[i] = v.tables->space[i];
     }
     const unsigned n_items = ioff[nf];
@@ -365,12 +377,13 @@ __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, 
     if (go && !*go)
         return;
     const unsigned S = 1u << rlog, t = threadIdx.x;
-    const RsLds L = rs_carve(rs_lds, S, F::K, rs_chunks<F>());
+    const RsLds L = rs_carve(rs_lds, S, F::K, rs_chunks<F>(), F::id != 0);
     for (unsigned i = t; i < 64 * kRsCols; i += kRsT)
-        L.cbin[i] = v.tables->binom[i / kRsCols][i % kRsCols];
+        L.cbin[i] = v.tables->binom[i / kRsCols][kRsCol0 + i % kRsCols];
     for (unsigned i = t; i < 64; i += kRsT)
     {
-        L.top[i] = v.tables->binom[63][i];
+        if (i >= kRsTop0)
+            L.top[i - kRsTop0] = v.tables->binom[63][i];
         L.space[i] = v.tables->space[i];
     }
     const unsigned n_items = ioff[nf];
