@@ -887,11 +887,11 @@ sdsl_hip_status sw_run_with(const SwCallbacks & cb, int bit, const uint64_t * d_
     {
         hipError_t e = hipSuccess;
         auto set = [&](const void * f) { const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); e = e == hipSuccess ? r : e; };
-        set((const void *)k_sw_hist<16, 0>);
-        set((const void *)k_sw_hist<16, 1>);
-        set((const void *)k_sw_hist<16, 2>);
-        set((const void *)k_sw_hist<16, 3>);
-        set((const void *)k_sw_hist<16, 4>);
+        set((const void *)k_sw_hist<8, 0>);
+        set((const void *)k_sw_hist<8, 1>);
+        set((const void *)k_sw_hist<8, 2>);
+        set((const void *)k_sw_hist<8, 3>);
+        set((const void *)k_sw_hist<8, 4>);
         SH_HIP(e);
     }
     for (uint64_t done = 0; done < n;)
@@ -918,8 +918,10 @@ sdsl_hip_status sw_run_with(const SwCallbacks & cb, int bit, const uint64_t * d_
         pt.mark();
         SH_HIP(hipMemsetAsync(b.fine_h, 0, (size_t)kHB * w.nfw * 4, s));
         SH_HIP(hipMemsetAsync(b.tickets, 0, 16, s));
+        // (eight positions per thread and chunk: with sixteen, the positions, the prefetched ones and their keys did not fit 128
+        // VGPRs — 6 spilled, 1.52 against 1.45 ms)
         sr_dispatch_op(g, [&](auto op)
-                       { hipLaunchKernelGGL((k_sw_hist<16, decltype(op)::value>), dim3(kHB), dim3(kHT), (w.fine_words + kBins + 2) * 4, s, g, w, idx, b.counts1, b.fine_h); });
+                       { hipLaunchKernelGGL((k_sw_hist<8, decltype(op)::value>), dim3(kHB), dim3(kHT), (w.fine_words + kBins + 2) * 4, s, g, w, idx, b.counts1, b.fine_h); });
         pt.mark("hist");
         sr_launch_bin_offsets(bins1, w.U1, b.counts1, b.btot, b.bstart1, b.offs1, s);
         hipLaunchKernelGGL(k_sw_seg_reduce, dim3((w.nf + 255) / 256), dim3(256), 0, s, w, b.fine_h, b.segsum, b.tot);
