@@ -860,7 +860,7 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
 // interpolated guess at the line, a short bisection over the headers in LDS, then the 16-byte pair that holds the word and
 // sel64 inside it.  A bucket that spans more than an LDS slice (a sparse stretch) is left to the fix-up pass.
 template <int BIT>
-__global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, unsigned d1, unsigned d2, unsigned B, const uint32_t * __restrict__ bnd,
+__global__ __launch_bounds__(kST) void k_sr_select_lds(BvView bv, unsigned nf, unsigned d1, unsigned d2, unsigned B, const uint32_t * __restrict__ bnd,
                                                        const uint32_t * __restrict__ fstart, const uint32_t * __restrict__ ioff,
                                                        uint32_t * __restrict__ keys, uint32_t * __restrict__ any_marked, const uint32_t * __restrict__ go)
 {
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
         const uint64_t L1 = (uint64_t)bnd[bk + 1] + 1 < bv.n_lines ? (uint64_t)bnd[bk + 1] + 1 : bv.n_lines;
         if (L1 - L0 > (UINT64_C(1) << kSliceLog))
         { // wider than a slice: the fix-up pass answers these
-            for (unsigned i = t; i < cnt; i += kRT)
+            for (unsigned i = t; i < cnt; i += kST)
                 if (kp[i] != kBad)
                     kp[i] = kMark;
             if (t == 0)
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
         }
         const unsigned nl = (unsigned)(L1 - L0);
         const v2u64 * src = reinterpret_cast<const v2u64 *>(bv.lines + L0 * kLW);
-        for (unsigned i = t; i < nl * (kLW / 2); i += kRT)
+        for (unsigned i = t; i < nl * (kLW / 2); i += kST)
             slice[i] = __builtin_nontemporal_load(src + i);
         // the keys through a buffer of exactly this item's extent: what lies beyond reads as 0 and is not written back
         // (the item is worked on in whole 128-byte lines of the key array: the `head` keys of the line in front of its first one are
@@ -924,12 +924,12 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
         uint32_t key[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            buf_load(rs_k, t * 4u, (unsigned)u * kRT * 4u, key[u]);
+            buf_load(rs_k, t * 4u, (unsigned)u * kST * 4u, key[u]);
         __syncthreads();
         const uint64_t h0 = slice[0].x;
         const uint64_t A0 = BIT ? h0 : L0 * kDB - h0; // arguments in front of the slice
         __syncthreads();
-        for (unsigned ln = t; ln < nl; ln += kRT)
+        for (unsigned ln = t; ln < nl; ln += kST)
         {
             v2u64 * w = slice + ln * (kLW / 2);
             v2u64 a = w[0], b = w[1], c = w[2], d = w[3];
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
         while ((tot >> sh) >= kInv)
             ++sh;
         const unsigned n_inv = ((tot + (1u << sh) - 1) >> sh); // samples 0 .. n_inv - 1 (arguments 0, 2^s, ...)
-        for (unsigned ln = t; ln < nl; ln += kRT)
+        for (unsigned ln = t; ln < nl; ln += kST)
         {
             const unsigned a0 = (unsigned)hdr[ln] & 0xFFFFFu, a1 = ln + 1 < nl ? (unsigned)hdr[ln + 1] & 0xFFFFFu : tot;
             for (unsigned e = (a0 + (1u << sh) - 1) >> sh; (e << sh) < a1; ++e)
@@ -981,15 +981,15 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
         if (t == 0)
             inv[n_inv] = (uint16_t)(nl - 1);
         __syncthreads();
-        for (unsigned i0 = 0; i0 < cnth; i0 += kRT * U)
+        for (unsigned i0 = 0; i0 < cnth; i0 += kST * U)
         { // the next round's keys are requested before this round's answers are stored (loads and stores share a counter)
             uint32_t nk[U];
-            const unsigned n0 = (i0 + kRT * U) * 4u;
-            if (i0 + kRT * U < cnth)
+            const unsigned n0 = (i0 + kST * U) * 4u;
+            if (i0 + kST * U < cnth)
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    buf_load(rs_k, t * 4u, n0 + (unsigned)u * kRT * 4u, nk[u]);
+                    buf_load(rs_k, t * 4u, n0 + (unsigned)u * kST * 4u, nk[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -1036,9 +1036,9 @@ __global__ __launch_bounds__(kRT) void k_sr_select_lds(BvView bv, unsigned nf, u
                     const unsigned bitpos = sel64(second ? pr.y : pr.x, tl - (second ? px : 0u) + 1);
                     res = a * (uint32_t)kDB + 64u * word + bitpos; // relative to the slice's first bit
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(res, rs_k, (int)(u == 0 && i0 == 0 ? vo0 : t * 4u), (int)(i0 * 4u + (unsigned)u * kRT * 4u), kAuxNT);
+                __builtin_amdgcn_raw_buffer_store_b32(res, rs_k, (int)(u == 0 && i0 == 0 ? vo0 : t * 4u), (int)(i0 * 4u + (unsigned)u * kST * 4u), kAuxNT);
             }
-            if (i0 + kRT * U < cnth)
+            if (i0 + kST * U < cnth)
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -1415,10 +1415,10 @@ sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const Selec
         SH_HIP(hipMemsetAsync(marked, 0, 4, s));
         hipLaunchKernelGGL(k_sr_select_bases, dim3((nf + 255) / 256), dim3(256), 0, s, nf, sp.nf, 0u, d2, sp.bnd, hf);
         if (bit)
-            hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, 0u, d2, sp.bm << sp.bs, sp.bnd, fstart, ioff,
+            hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kST), 0, s, v, nf, 0u, d2, sp.bm << sp.bs, sp.bnd, fstart, ioff,
                                keys2, marked, go);
         else
-            hipLaunchKernelGGL(k_sr_select_lds<0>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, 0u, d2, sp.bm << sp.bs, sp.bnd, fstart, ioff,
+            hipLaunchKernelGGL(k_sr_select_lds<0>, dim3(slice_blocks), dim3(kST), 0, s, v, nf, 0u, d2, sp.bm << sp.bs, sp.bnd, fstart, ioff,
                                keys2, marked, go);
     }
     SH_HIP(hipGetLastError());
@@ -1626,10 +1626,10 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
             pt.mark();
             // slices beyond sp.nf are empty (no items), so the kernel never reads bnd past sp.nf
             if (bit)
-                hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, g.d1, g.d2, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
+                hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kST), 0, s, v, nf, g.d1, g.d2, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
                                    b.keys2, b.btot, (const uint32_t *)nullptr);
             else
-                hipLaunchKernelGGL(k_sr_select_lds<0>, dim3(slice_blocks), dim3(kRT), 0, s, v, nf, g.d1, g.d2, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
+                hipLaunchKernelGGL(k_sr_select_lds<0>, dim3(slice_blocks), dim3(kST), 0, s, v, nf, g.d1, g.d2, sp.bm << sp.bs, sp.bnd, b.fstart, b.ioff,
                                    b.keys2, b.btot, (const uint32_t *)nullptr);
         }
         pt.mark();

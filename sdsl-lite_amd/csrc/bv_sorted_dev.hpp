@@ -38,7 +38,9 @@ namespace {
 
 constexpr uint32_t kSrRecBits = 63 * 34;   // bits per record of the rrr_vector<63> device layout (rrr_device.hpp: kRecSB)
 constexpr uint32_t kSrRecBitsSlim = 63 * 42; // ... of its slim format (RrrFmtS::SB)
-constexpr unsigned kRT = 512;            // threads of a rank block
+constexpr unsigned kRT = 512;            // threads of a rank block (two per CU)
+constexpr unsigned kST = 1024;           // threads of a select block: its search is a chain of dependent LDS reads per key, and with 8
+                                         // waves per SIMD instead of 4 the VALU stays busy (k_sr_select_lds: 4.42 -> 3.54 ms); rank loses (1.90 -> 1.98)
 constexpr unsigned kBins = 256;          // bins per pass (8-bit digits)
 constexpr unsigned kSliceLog = 10;       // lines per slice (64 KiB)
 constexpr unsigned kOffBits = 9;         // 448 < 2^9 in-line offsets
