@@ -877,15 +877,20 @@ def main():
                     cb.update(unit="Grank/s", kind="port")
                     ex["wt_huff_rank"]["cpu_baseline"] = cb
             if "wt" in extras:
-                # select(k, c) for symbols drawn from the text and k uniform in [1, occ(c)]; checked through rank
+                # select(k, c) for symbols drawn from the text (the stream of rank) and k = 1 + mt19937_64(16) % occ(c): checked
+                # through rank and against the real library's answers (golden_large.json, c4.wt_select)
+                # (on the wavelet tree of the TEXT — same size and symbol distribution as the index's tree over the BWT — because that
+                # is the sequence the reference's digest was made on: wt_huff<> constructed from the text by the real library)
+                wt_t = pkg.wt_huff(text=text, device=local)
                 occ_c = torch.bincount(text, minlength=256)[gc.long()]
-                ks = (torch.rand(nq2, device=dev, generator=gq, dtype=torch.float64) * occ_c.double()).long() + 1
-                ks = torch.minimum(ks, occ_c)
-                _, ms = time_steps(lambda: wt.select(ks, gc, out2), 2, 1, barrier)
-                chk = wt.rank(out2[:1_000_000], gc[:1_000_000])
+                ks = 1 + to_dev(pkg.rnd_positions(16, nq2, 1 << 62, 0), dev) % occ_c
+                _, ms = time_steps(lambda: wt_t.select(ks, gc, out2), 2, 1, barrier)
+                chk = wt_t.rank(out2[:1_000_000], gc[:1_000_000])
                 assert torch.equal(chk, ks[:1_000_000] - 1), "rank(select(k, c), c) != k - 1"
-                ex["wt_huff_select"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2}
-                del occ_c, ks, chk
+                ex["wt_huff_select"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2,
+                                        "reference_digest_match": digest_matches(out2, c4["wt_select"])
+                                        if c4ok and "wt_select" in c4 and nq2 >= c4["wt_select"]["n"] else None}
+                del occ_c, ks, chk, wt_t
             if "fm" in extras:
                 m = 20
                 st = to_dev(pkg.rnd_positions(15, nq2, nt - m, 0), dev)  # 8(d): patterns cut at mt19937_64(15) % (n - m)

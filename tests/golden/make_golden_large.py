@@ -1,6 +1,6 @@
 """BASELINE-size answers of the REAL sdsl-lite (run in the build container only; ~62 GB of RAM, 30-60 minutes).
 
-    python tests/golden/make_golden_large.py [c2] [c3] [c4]
+    python tests/golden/make_golden_large.py [c2] [c3] [c4] [c4sel]
 
 Builds, through oracle/_ref/libsdsl_ref.so (the reference's headers compiled where they lie), the structures of
 BASELINE.json configs[1..4] on the SURVEY.md 8(d) inputs and stores what the GPU tests and bench.py compare against:
@@ -119,6 +119,22 @@ def main():
         res["c3"] = c3
         del w_ref, idx, out, si
         print(f"c3 done in {time.time() - t0:.0f}s: ones={ones}", flush=True)
+        json.dump(res, open(OUT, "w"))
+
+    if "c4sel" in want:
+        # wt_huff<>::select on the same text (wt_pc.hpp:443-474): c = text[mt19937_64(14) % n] as for rank, k = 1 + mt19937_64(16) % occ(c)
+        t0 = time.time()
+        nt = 1 << TEXT_LOG
+        text = pkg.english_text(nt, 1234)
+        assert hashlib.sha256(text.tobytes()).hexdigest() == res["c4"]["text_sha256"]
+        wt = ol.RWt(text)
+        print(f"c4sel wt built {time.time() - t0:.0f}s", flush=True)
+        nqs = int(os.environ.get("GOLDEN_NQ_WTSEL", str(10**6)))
+        gc = np.ascontiguousarray(text[pkg.rnd_positions(14, nqs, nt, 0).astype(np.int64)])
+        occ = np.bincount(text, minlength=256).astype(np.uint64)
+        ks = np.uint64(1) + pkg.rnd_positions(16, nqs, 1 << 62, 0) % occ[gc]
+        res["c4"].update(wt_k_seed=16, wt_select=digest(wt.select(ks, gc)))
+        print(f"c4sel done in {time.time() - t0:.0f}s", flush=True)
         json.dump(res, open(OUT, "w"))
 
     if "c4" in want:

@@ -215,4 +215,13 @@ def test_c4_wt_rank_and_count_match_reference_digests(gpu):
     st = gpu.rnd_positions(c["pattern_seed"], c["count"]["n"], nt - m, 0).astype(np.int64)
     pats = torch.from_numpy(np.ascontiguousarray(text[st[:, None] + np.arange(m)[None, :]].reshape(-1))).cuda()
     check(csa.count(pats, m).cpu().numpy(), c["count"], "configs[4] count of 20-byte patterns")
+    if "wt_select" in c:  # wt_huff<>::select of the real library on the same text (make_golden_large.py c4sel)
+        ns = c["wt_select"]["n"]
+        gcs = torch.from_numpy(text[gpu.rnd_positions(c["wt_c_seed"], ns, nt, 0).astype(np.int64)]).cuda()
+        occ = torch.bincount(torch.from_numpy(text).cuda(), minlength=256)
+        ks = 1 + torch.from_numpy(gpu.rnd_positions(c["wt_k_seed"], ns, 1 << 62, 0).view(np.int64)).cuda() % occ[gcs.long()]
+        csa.close()
+        wt_t = gpu.wt_huff(text=torch.from_numpy(text).cuda(), device=0)  # (the digest was made on the text's own tree)
+        check(wt_t.select(ks, gcs).cpu().numpy(), c["wt_select"], "configs[3] wt_huff select(k, c)")
+        return
     csa.close()
