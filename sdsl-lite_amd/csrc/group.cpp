@@ -103,6 +103,11 @@ struct sdsl_hip_group_s
     std::vector<ncclComm_t> comm_a, comm_b; // scatter / gather
     std::vector<hipStream_t> s_in, s_k, s_out;
     std::vector<DevBuf> in, out; // per device: its shard of the batch in flight (peers only)
+    // Transport.  Default: RCCL (two communicators).  copy == true (SDSL_HIP_GROUP_TRANSPORT=copy at creation): every transfer is a
+    // device-to-device hipMemcpyAsync on the RECEIVING member's stream, ordered behind the sender's stream by an event — for
+    // processes that cannot load librccl, and the only transport that accepts the same device twice (a group of two on a
+    // one-GPU box: the sharding, the chunk pipeline and the event chains of G > 1 then run where only one GPU is at hand).
+    bool copy = false;
     ~sdsl_hip_group_s()
     {
         const Rccl * R = rccl();
@@ -130,6 +135,22 @@ void shard(uint64_t n, int G, int r, uint64_t & lo, uint64_t & hi)
 {
     lo = n * (uint64_t)r / (uint64_t)G;
     hi = n * (uint64_t)(r + 1) / (uint64_t)G;
+}
+
+// copy transport: `bytes` from member ra's memory to member rb's, behind everything queued on sa, carried out on sb
+sdsl_hip_status copy_xfer(sdsl_hip_group_s * g, const void * src, int ra, hipStream_t sa, void * dst, int rb, hipStream_t sb, size_t bytes)
+{
+    if (!bytes)
+        return SDSL_HIP_OK;
+    hipEvent_t e;
+    SH_HIP(hipSetDevice(g->dev[ra]));
+    SH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    SH_HIP(hipEventRecord(e, sa));
+    SH_HIP(hipSetDevice(g->dev[rb]));
+    SH_HIP(hipStreamWaitEvent(sb, e, 0));
+    SH_HIP(hipEventDestroy(e)); // (released once the wait has been satisfied)
+    SH_HIP(hipMemcpyPeerAsync(dst, g->dev[rb], src, g->dev[ra], bytes, sb));
+    return SDSL_HIP_OK;
 }
 
 // The root-owned batch: n items of in_bytes each (device memory of devices[0]) -> n items of out_bytes each.
@@ -179,7 +200,13 @@ sdsl_hip_status group_run(sdsl_hip_group_s * g, const uint8_t * d_in, size_t in_
                 pcnt[r] = b - a;
             }
             // scatter
-            if (G > 1)
+            if (G > 1 && g->copy)
+            {
+                for (int r = 1; r < G; ++r)
+                    SH_TRY(copy_xfer(g, d_in + (slo[r] + plo[r]) * in_bytes, 0, g->s_in[0], g->in[r].as<uint8_t>() + plo[r] * in_bytes, r, g->s_in[r],
+                                     pcnt[r] * in_bytes));
+            }
+            else if (G > 1)
             {
                 SH_NCCL(R->GroupStart());
                 for (int r = 1; r < G; ++r)
@@ -216,7 +243,13 @@ sdsl_hip_status group_run(sdsl_hip_group_s * g, const uint8_t * d_in, size_t in_
                 }
             }
             // gather
-            if (G > 1)
+            if (G > 1 && g->copy)
+            {
+                for (int r = 1; r < G; ++r)
+                    SH_TRY(copy_xfer(g, g->out[r].as<uint8_t>() + plo[r] * out_bytes, r, g->s_out[r], d_out + (slo[r] + plo[r]) * out_bytes, 0,
+                                     g->s_out[r], pcnt[r] * out_bytes)); // (on the peer's stream: the call ends with every stream synchronised)
+            }
+            else if (G > 1)
             {
                 SH_NCCL(R->GroupStart());
                 for (int r = 1; r < G; ++r)
@@ -267,18 +300,20 @@ sdsl_hip_status sdsl_hip_group_create(const int32_t * devices, int32_t n, sdsl_h
         return SDSL_HIP_ERR_INVALID;
     }
     *out = nullptr;
+    const char * tr = getenv("SDSL_HIP_GROUP_TRANSPORT");
+    const bool copy_transport = tr && !strcmp(tr, "copy");
     for (int i = 0; i < n; ++i)
     {
         SH_TRY(check_device(devices[i]));
         for (int j = 0; j < i; ++j)
-            if (devices[j] == devices[i])
+            if (devices[j] == devices[i] && !copy_transport)
             {
-                set_error("group_create: device %d listed twice", devices[i]);
+                set_error("group_create: device %d listed twice (only the copy transport accepts that)", devices[i]);
                 return SDSL_HIP_ERR_INVALID;
             }
     }
-    const Rccl * R = rccl();
-    if (!R)
+    const Rccl * R = copy_transport ? nullptr : rccl();
+    if (!R && !copy_transport)
     {
         set_error("group_create: librccl.so not found (%s)", dlerror() ? dlerror() : "dlopen failed");
         return SDSL_HIP_ERR_NO_DEVICE;
@@ -296,8 +331,12 @@ sdsl_hip_status sdsl_hip_group_create(const int32_t * devices, int32_t n, sdsl_h
                        g->s_out.assign(n, nullptr);
                        g->in.resize(n);
                        g->out.resize(n);
-                       SH_NCCL(R->CommInitAll(g->comm_a.data(), n, g->dev.data()));
-                       SH_NCCL(R->CommInitAll(g->comm_b.data(), n, g->dev.data()));
+                       g->copy = copy_transport;
+                       if (!copy_transport)
+                       {
+                           SH_NCCL(R->CommInitAll(g->comm_a.data(), n, g->dev.data()));
+                           SH_NCCL(R->CommInitAll(g->comm_b.data(), n, g->dev.data()));
+                       }
                        for (int r = 0; r < n; ++r)
                        {
                            SH_HIP(hipSetDevice(g->dev[r]));
@@ -371,6 +410,12 @@ sdsl_hip_status sdsl_hip_group_loopback(sdsl_hip_group_t g, uint64_t bytes, floa
             SH_HIP(hipEventRecord(e0, str[0]));
         auto go = [&]() -> sdsl_hip_status
         {
+            if (g->copy)
+            {
+                for (int r = 0; r < G; ++r)
+                    SH_TRY(copy_xfer(g, src[r].p, r, str[r], dst[(r + 1) % G].p, (r + 1) % G, str[(r + 1) % G], bytes));
+                return SDSL_HIP_OK;
+            }
             SH_NCCL(R->GroupStart());
             for (int r = 0; r < G; ++r)
             {
@@ -468,6 +513,12 @@ sdsl_hip_status sdsl_hip_group_bv_replicate(sdsl_hip_group_t g, sdsl_hip_bv_t ro
         const DevBuf & b0 = buf_of(src, which);
         if (!b0.p || !b0.bytes)
             return SDSL_HIP_OK;
+        if (g->copy)
+        {
+            for (int r = 1; r < G; ++r)
+                SH_TRY(copy_xfer(g, b0.p, 0, g->s_in[0], buf_of(bv_host_of(replicas[r]), which).p, r, g->s_in[r], b0.bytes));
+            return SDSL_HIP_OK;
+        }
         SH_NCCL(R->GroupStart());
         for (int r = 0; r < G; ++r)
         {
@@ -562,7 +613,17 @@ sdsl_hip_status sdsl_hip_group_fm_create_from_text(sdsl_hip_group_t g, const uin
         SH_TRY(copy[r].alloc(n_text));
         tp[r] = copy[r].as<uint8_t>();
     }
-    if (G > 1 && n_text)
+    if (G > 1 && n_text && g->copy)
+    {
+        for (int r = 1; r < G; ++r)
+            SH_TRY(copy_xfer(g, tp[0], 0, g->s_in[0], (void *)tp[r], r, g->s_in[r], n_text));
+        for (int r = 0; r < G; ++r)
+        {
+            SH_HIP(hipSetDevice(g->dev[r]));
+            SH_HIP(hipStreamSynchronize(g->s_in[r]));
+        }
+    }
+    else if (G > 1 && n_text)
     {
         SH_NCCL(R->GroupStart());
         for (int r = 0; r < G; ++r)

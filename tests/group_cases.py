@@ -9,20 +9,33 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def group(pkg):
+@pytest.fixture(scope="module", params=["rccl", "copy"])
+def group(pkg, request):
+    """rccl: the devices the box has, RCCL transport.  copy: THREE members on device 0 over the copy transport
+    (SDSL_HIP_GROUP_TRANSPORT=copy: device-to-device copies ordered by events; the only transport that accepts a device twice) —
+    uneven shards, peers' staging buffers, the chunk pipeline and its event chains for G > 1 run on a one-GPU box this way."""
+    import os
     import torch
-    n = torch.cuda.device_count()
     L = pkg.capi.lib()
-    devs = (C.c_int32 * n)(*range(n))
     g = C.c_void_p(None)
-    pkg.capi.check(L.sdsl_hip_group_create(devs, n, C.byref(g)))
+    if request.param == "copy":
+        n = 3
+        devs = (C.c_int32 * n)(0, 0, 0)
+        os.environ["SDSL_HIP_GROUP_TRANSPORT"] = "copy"
+        try:
+            pkg.capi.check(L.sdsl_hip_group_create(devs, n, C.byref(g)))
+        finally:
+            del os.environ["SDSL_HIP_GROUP_TRANSPORT"]
+    else:
+        n = torch.cuda.device_count()
+        devs = (C.c_int32 * n)(*range(n))
+        pkg.capi.check(L.sdsl_hip_group_create(devs, n, C.byref(g)))
     assert L.sdsl_hip_group_size(g) == n and L.sdsl_hip_group_device(g, 0) == 0
     yield g, n
     pkg.capi.check(L.sdsl_hip_group_destroy(g))
 
 
-def test_group_loopback_moves_data_through_rccl(pkg, group):
+def test_group_loopback_moves_data_around_the_group(pkg, group):
     g, n = group
     ms = C.c_float(0)
     pkg.capi.check(pkg.capi.lib().sdsl_hip_group_loopback(g, 1 << 20, C.byref(ms)))
