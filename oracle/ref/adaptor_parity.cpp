@@ -582,13 +582,21 @@ int main(int argc, char ** argv)
         printf("unmodified wt_huff over the hip supports: %.0f ns per rank(i, c) (scalar path = the caller's SDSL)\n", ns);
         (void)acc;
     }
-    // several GPUs of one node (all the box has; a group of one still goes through the group driver and RCCL's setup)
+    // several GPUs of one node (all the box has; a group of one still goes through the group driver and RCCL's setup), then the same
+    // through a group of two members on device 0 over the copy transport: shards and pipelined pieces for G > 1 on a one-GPU box
+    for (int pass = 0; pass < 2; ++pass)
     {
         int n_dev = sdsl_hip_device_count();
         std::vector<int32_t> devs;
         for (int d = 0; d < n_dev; ++d)
             devs.push_back(d);
+        if (pass == 1)
+        {
+            devs.assign(2, 0);
+            setenv("SDSL_HIP_GROUP_TRANSPORT", "copy", 1);
+        }
         device_group grp(devs);
+        unsetenv("SDSL_HIP_GROUP_TRANSPORT");
         bit_vector bv(3000017, 0);
         for (uint64_t i = 0; i < bv.size(); ++i)
             bv[i] = (rng() % 100) < 37;
