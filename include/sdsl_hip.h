@@ -313,6 +313,15 @@ sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm);
  * tree, >= 64 MiB allowed); k = 0 drops the table, a larger k trades HBM for speed (sigma^k entries). */
 sdsl_hip_status sdsl_hip_fm_set_jump_depth(sdsl_hip_fm_t fm, uint32_t k);
 uint32_t sdsl_hip_fm_jump_depth(sdsl_hip_fm_t fm);
+/* The k-mer table of count(): the SA interval of every k-mer (k <= 8 bytes) that occurs in the text, in a hash table of 128-byte
+ * buckets — ONE fetch replaces the first k backward-search steps (suffix_array_algorithm.hpp:228-248) of a pattern, and a pattern
+ * whose last k bytes are not in the table cannot occur.  Built by default for an index created from text (which still holds its
+ * suffix array and the text), as deep as fits into the wavelet tree's own size; sdsl_hip_fm_set_kmer_table rebuilds it with the
+ * deepest k <= k_max whose table (32 bytes per distinct k-mer) stays within budget_bytes (k_max 0: release it).  The table
+ * survives sdsl_hip_fm_drop_sa.  Answers never depend on it. */
+sdsl_hip_status sdsl_hip_fm_set_kmer_table(sdsl_hip_fm_t fm, uint32_t k_max, uint64_t budget_bytes);
+uint32_t sdsl_hip_fm_kmer_table_depth(sdsl_hip_fm_t fm);
+uint64_t sdsl_hip_fm_kmer_table_bytes(sdsl_hip_fm_t fm);
 sdsl_hip_status sdsl_hip_fm_destroy(sdsl_hip_fm_t fm);
 uint64_t sdsl_hip_fm_size(sdsl_hip_fm_t fm);  /* csa.size() = text length + 1 */
 uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm); /* csa.sigma */

@@ -360,8 +360,10 @@ static sdsl_hip_status fm_from_device_bwt(sdsl_hip_fm_s * f, const uint8_t * d_b
     }
     alphabet_from_counts(f, w.occ);
     SH_TRY(fm_upload_tables(f));
-    const sdsl_hip_status st = fm_build_jump(f);
+    sdsl_hip_status st = fm_build_jump(f);
     stamp("k-mer interval table", t);
+    if (st == SDSL_HIP_OK)
+        st = fm_build_count_tab(f);
     return st;
 }
 
@@ -439,6 +441,8 @@ static sdsl_hip_status sdsl_hip_fm_create_from_text_ex_impl(const uint8_t * text
         if (hipMemcpy(f->d_text.p, text, n_text, hipMemcpyDefault) != hipSuccess)
             f->d_text.release();
     sdsl_hip_status st = fm_from_device_bwt(f, d_bwt.as<uint8_t>(), n_text + 1, device, flags);
+    if (st == SDSL_HIP_OK)
+        st = fm_build_deep_default(f); // the k-mer table of count() (fm_count2.hip), from the suffix array and the text
     if (st != SDSL_HIP_OK)
     {
         fm_free(f);
@@ -579,6 +583,8 @@ static sdsl_hip_status sdsl_hip_fm_create_from_sdsl_ex_impl(const void * bytes, 
                 st = fm_upload_tables(f);
             if (st == SDSL_HIP_OK)
                 st = fm_build_jump(f);
+            if (st == SDSL_HIP_OK)
+                st = fm_build_count_tab(f);
             if (st == SDSL_HIP_OK && keep)
             {
                 const uint64_t n = f->size;
@@ -623,6 +629,24 @@ sdsl_hip_status sdsl_hip_fm_set_jump_depth(sdsl_hip_fm_t fm, uint32_t k)
 uint32_t sdsl_hip_fm_jump_depth(sdsl_hip_fm_t fm)
 {
     return fm ? fm->jump_k : 0;
+}
+
+sdsl_hip_status sdsl_hip_fm_set_kmer_table(sdsl_hip_fm_t fm, uint32_t k_max, uint64_t budget_bytes)
+{
+    if (!fm)
+    {
+        set_error("fm_set_kmer_table: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    return fm_build_deep(fm, k_max, budget_bytes);
+}
+uint32_t sdsl_hip_fm_kmer_table_depth(sdsl_hip_fm_t fm)
+{
+    return fm ? fm->deep_k : 0;
+}
+uint64_t sdsl_hip_fm_kmer_table_bytes(sdsl_hip_fm_t fm)
+{
+    return fm ? fm->d_deep.bytes : 0;
 }
 
 sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
@@ -729,7 +753,7 @@ uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm)
 }
 uint64_t sdsl_hip_fm_device_bytes(sdsl_hip_fm_t fm)
 {
-    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes + fm->d_sa_s.bytes + fm->d_isa_s.bytes + fm->d_jump.bytes + fm->d_sa.bytes + fm->d_text.bytes : 0;
+    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes + fm->d_sa_s.bytes + fm->d_isa_s.bytes + fm->d_jump.bytes + fm->d_sa.bytes + fm->d_text.bytes + fm->d_ctab.bytes + fm->d_deep.bytes : 0;
 }
 sdsl_hip_wt_t sdsl_hip_fm_wavelet_tree(sdsl_hip_fm_t fm)
 {
@@ -766,6 +790,17 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
     else
         SH_TRY(sc.out(out_cnt, n_pat * 8));
     const WtHost & w = sdsl_hip_wt_host(fm->wt);
+    if (!ival && !offsets && use_jump && w.backend == 0 && fm_fast_applies(fm, m, n_pat))
+    { // large batches of fixed-length patterns on the fused layout: k-mer table + flat kernel + text comparison (fm_count2.hip)
+        {
+            KernelTimer t(s);
+            SH_TRY(fm_count_fast(fm, (const uint8_t *)sp.dev, m, n_pat, (uint64_t *)sc.dev, fm_verify_enabled(), s));
+        }
+        SH_TRY(sc.finish(s));
+        if (sp.host)
+            SH_HIP(hipStreamSynchronize(s));
+        return SDSL_HIP_OK;
+    }
     unsigned grid = grid_for(n_pat, kQPB, 256u * 8u);
     // Large batches are answered in suffix order (see k_fm_keys): one key kernel + one radix sort, no synchronisation
     static const int sort_knob = getenv("SDSL_HIP_FM_SORT") ? atoi(getenv("SDSL_HIP_FM_SORT")) : -1;

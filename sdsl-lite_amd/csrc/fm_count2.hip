@@ -1,0 +1,736 @@
+// fm_count2.hip — count() of a large batch of fixed-length patterns on the fused wavelet tree, in three kernels:
+//
+//   k_fm_start   one pattern per quad, in the caller's order (patterns stream in, nothing is sorted): the SA interval of the
+//                pattern's LAST k bytes comes from ONE 128-byte bucket of the k-mer hash table (FmDeep, below) instead of k LF
+//                steps.  A pattern whose k-mer is absent cannot occur (count 0); one whose interval is a single suffix goes
+//                straight to the text comparison (k_fm_verify2); one with no characters left is done; the rest are appended to
+//                a work list as 32-byte records [q, l, e, characters left, the next 16 pattern bytes].
+//   k_fm_count_flat  persistent quads over the work list.  The state of a search lives in registers; one loop iteration is ONE
+//                fused tree step (three binary levels, one or two line fetches) of whatever pattern the quad holds, and a quad
+//                that finishes takes the next record at once — its record was requested an iteration earlier, so the hand-over
+//                costs no memory latency.  (k_fm_count, fm.hip, keeps its 16 quads in lock step per pattern: a wave lasts as
+//                long as its longest search.)  Everything is 32-bit: the fused layout exists for fewer than 2^32 symbols.
+//   k_fm_verify2 the searches that stopped at ONE suffix with characters left: SA[l] says where that suffix starts, the remaining
+//                characters are compared with the text in front of it, eight bytes at a time.
+//
+// Reference semantics (unchanged, every answer is the number the reference computes):
+//   backward_search(csa,l,r,begin,end,..)  suffix_array_algorithm.hpp:228-248  (characters from the pattern's end)
+//   backward_search(csa,l,r,c,..)          suffix_array_algorithm.hpp:167-201  (l = C[c] + rank(l,c), r = C[c] + rank(r+1,c) - 1)
+//   count(csa,begin,end)                   suffix_array_algorithm.hpp:464-471  (r + 1 - l, 0 for an empty interval)
+//   csa_wt::rank_bwt -> wt_pc::rank        csa_wt.hpp:286-289, wt_pc.hpp:371-399
+// The k-mer table holds, for every k-mer that occurs in the text, exactly the [l, r] the k LF steps produce (the SA range of
+// the suffixes that start with it); a k-mer that does not occur has an empty range, i.e. count 0.
+#include <chrono>
+
+#include "fm_host.hpp"
+
+namespace sdslhip {
+
+// ---- tables of the flat count kernel ----------------------------------------------------------------------------------
+__device__ __forceinline__ void fm_stage_ctab(FmCountTab * lds, const FmCountTab * g)
+{
+    static_assert(sizeof(FmCountTab) % 8 == 0, "FmCountTab is copied in 8-byte words");
+    const uint64_t * src = reinterpret_cast<const uint64_t *>(g);
+    uint64_t * dst = reinterpret_cast<uint64_t *>(lds);
+    for (unsigned i = threadIdx.x; i < sizeof(FmCountTab) / 8; i += blockDim.x)
+        dst[i] = src[i];
+    __syncthreads();
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// the 16 bytes in front of byte offset `end` of the pattern array (as a little-endian 128-bit number: .w's top byte is the
+// byte at end - 1); what lies in front of the array's first byte reads as 0
+__device__ __forceinline__ u32x4 load_tail16(const uint8_t * __restrict__ pats, uint64_t end)
+{
+    u32x4 v;
+    if (end >= 16)
+        __builtin_memcpy(&v, pats + end - 16, 16);
+    else
+    {
+        uint8_t b[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            b[j] = (uint64_t)(15 - j) < end ? pats[end - 16 + j] : 0; // (only reached for the first pattern of a batch)
+        __builtin_memcpy(&v, b, 16);
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint64_t load_tail8(const uint8_t * __restrict__ pats, uint64_t end)
+{
+    uint64_t v;
+    if (end >= 8)
+        __builtin_memcpy(&v, pats + end - 8, 8);
+    else
+    {
+        v = 0;
+        for (uint64_t j = 0; j < end; ++j)
+            v |= (uint64_t)pats[j] << (8 * (8 - end + j));
+    }
+    return v;
+}
+
+constexpr uint64_t kDeepMul = UINT64_C(0x9E3779B97F4A7C15);
+__device__ __forceinline__ uint32_t deep_bucket(uint64_t key, uint32_t n_buckets)
+{
+    return (uint32_t)__umul64hi(key * kDeepMul, (uint64_t)n_buckets);
+}
+// does any of the low k bytes of x equal zero?
+__device__ __forceinline__ bool has_zero_byte(uint64_t x, uint32_t k)
+{
+    const uint64_t m = k >= 8 ? ~UINT64_C(0) : ((UINT64_C(1) << (8 * k)) - 1);
+    return (((x - UINT64_C(0x0101010101010101)) & ~x & UINT64_C(0x8080808080808080)) & m) != 0;
+}
+
+struct FmRec
+{
+    uint32_t q, l, e, rem; // pattern number inside the slab, interval [l, e), characters still to process
+    u32x4 w;               // pattern bytes [rem - 16, rem) of the pattern
+};
+static_assert(sizeof(FmRec) == 32, "FmRec is two 16-byte loads");
+
+constexpr uint64_t kFmPending = UINT64_C(1) << 63;
+
+// quad lookup of `key` in the k-mer table: true (and [l, e)) if present
+__device__ __forceinline__ bool quad_deep_find(const FmDeep & D, int s, uint64_t key, uint32_t & l, uint32_t & e)
+{
+    uint32_t b = deep_bucket(key, D.n_buckets);
+    for (uint32_t tries = 0; tries < D.n_buckets; ++tries)
+    {
+        const ulonglong2 * bp = D.tab + (uint64_t)b * 8 + 2 * s;
+        const ulonglong2 e0 = bp[0], e1 = bp[1];
+        const bool h0 = e0.x == key, h1 = e1.x == key;
+        const unsigned lh = h0 ? (unsigned)e0.y : (h1 ? (unsigned)e1.y : 0u);
+        const unsigned eh = h0 ? (unsigned)(e0.y >> 32) : (h1 ? (unsigned)(e1.y >> 32) : 0u);
+        const unsigned hit = quad_sum((h0 || h1) ? 1u : 0u);
+        if (hit)
+        { // keys are unique: exactly one lane holds it
+            l = quad_sum(lh);
+            e = quad_sum(eh);
+            return true;
+        }
+        const unsigned full = quad_sum((e0.x != 0 ? 1u : 0u) + (e1.x != 0 ? 1u : 0u));
+        if (full < 8)
+            return false; // an insertion would have used the free slot
+        b = b + 1 == D.n_buckets ? 0 : b + 1;
+    }
+    return false;
+}
+
+constexpr uint32_t kFmDead = 0xFFFFFFFFu; // FmRec::rem of a pattern that k_fm_start has already answered
+
+template <bool VERIFY>
+__global__ __launch_bounds__(256) void k_fm_start(FmDeep D, uint32_t csa_size, const uint8_t * __restrict__ pats, uint32_t m,
+                                                  uint32_t n_pat, uint64_t * __restrict__ out, FmRec * __restrict__ recs)
+{
+    const int s = threadIdx.x & 3;
+    const uint32_t quads = (gridDim.x * blockDim.x) >> 2;
+    for (uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; q < n_pat; q += quads)
+    {
+        uint32_t l = 0, e = csa_size, rem = m;
+        const uint64_t end = (uint64_t)(q + 1) * m;
+        const uint64_t key = load_tail8(pats, end) >> (8 * (8 - D.k));
+        uint64_t res = 0;
+        bool done = false;
+        if (has_zero_byte(key, D.k))
+            ; // a 0 byte is the sentinel's character: left to the search, from the whole interval
+        else if (!quad_deep_find(D, s, key, l, e))
+            done = true; // the pattern's last k bytes do not occur in the text: count 0
+        else
+        {
+            rem = m - D.k;
+            if (rem == 0)
+            {
+                done = true;
+                res = e - l;
+            }
+            else if (VERIFY && e - l == 1 && rem >= 2)
+            { // (one character left: its LF step is cheaper than SA[l] + the text)
+                done = true;
+                res = kFmPending | ((uint64_t)rem << 32) | l;
+            }
+        }
+        u32x4 h;
+        h.x = q;
+        h.y = l;
+        h.z = e;
+        h.w = done ? kFmDead : rem;
+        u32x4 * dst = reinterpret_cast<u32x4 *>(recs + q);
+        if (done)
+        {
+            if (s == 0)
+            {
+                out[q] = res;
+                dst[0] = h;
+            }
+        }
+        else
+        {
+            const u32x4 w = load_tail16(pats, (uint64_t)q * m + rem);
+            if (s == 0)
+            {
+                dst[0] = h;
+                dst[1] = w;
+            }
+        }
+    }
+}
+
+// without a k-mer hash table: the dense table of fm.hip (FmJump: every k-mer over the compact alphabet, sigma^k entries) takes
+// the pattern's last J.k characters — unsorted, but only the entries of k-mers that occur are ever touched (a few MiB that
+// stay in the L2) — or the search starts from the whole interval.  One pattern per lane.
+template <bool VERIFY>
+__global__ __launch_bounds__(256) void k_fm_start_dense(FmJump J, const FmTables * __restrict__ ftab, uint32_t csa_size,
+                                                        const uint8_t * __restrict__ pats, uint32_t m, uint32_t n_pat,
+                                                        uint64_t * __restrict__ out, FmRec * __restrict__ recs)
+{
+    __shared__ uint8_t c2c[256];
+    for (unsigned c = threadIdx.x; c < 256; c += blockDim.x)
+        c2c[c] = ftab->char2comp[c];
+    __syncthreads();
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_pat; q += gridDim.x * blockDim.x)
+    {
+        uint32_t l = 0, e = csa_size, rem = m;
+        uint64_t res = 0;
+        bool done = false;
+        const uint64_t end = (uint64_t)(q + 1) * m;
+        if (J.tab && m >= J.k)
+        {
+            const uint64_t tail = load_tail8(pats, end); // (J.k <= 8)
+            uint64_t key = 0;
+            bool ok = true;
+            for (uint32_t t = 0; t < J.k; ++t)
+            {
+                const unsigned c = (unsigned)(tail >> (56 - 8 * t)) & 0xFFu;
+                const unsigned cc = c2c[c];
+                ok = ok && !(cc == 0 && c > 0); // a character that does not occur: left to the search (it ends there)
+                key = key * J.sigma + cc;
+            }
+            if (ok)
+            {
+                const ulonglong2 en = *reinterpret_cast<const ulonglong2 *>(J.tab + 2 * key);
+                rem = m - J.k;
+                if (en.x > en.y)
+                    done = true; // empty interval: count 0
+                else
+                {
+                    l = (uint32_t)en.x;
+                    e = (uint32_t)en.y + 1;
+                    if (rem == 0)
+                    {
+                        done = true;
+                        res = e - l;
+                    }
+                    else if (VERIFY && e - l == 1 && rem >= 2)
+                    {
+                        done = true;
+                        res = kFmPending | ((uint64_t)rem << 32) | l;
+                    }
+                }
+            }
+        }
+        u32x4 h;
+        h.x = q;
+        h.y = l;
+        h.z = e;
+        h.w = done ? kFmDead : rem;
+        u32x4 * dst = reinterpret_cast<u32x4 *>(recs + q);
+        dst[0] = h;
+        if (done)
+            out[q] = res;
+        else
+            dst[1] = load_tail16(pats, (uint64_t)q * m + rem);
+    }
+}
+
+constexpr uint32_t kFlatChunk = 256; // records a wave claims at a time
+
+template <bool VERIFY>
+__global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restrict__ f_lines, const FmCountTab * __restrict__ tab_g,
+                                                       const FmRec * __restrict__ recs, uint32_t n_rec,
+                                                       uint32_t * __restrict__ ticket, const uint8_t * __restrict__ pats,
+                                                       uint32_t m, uint64_t * __restrict__ out)
+{
+    __shared__ FmCountTab T;
+    fm_stage_ctab(&T, tab_g);
+    const int lane = threadIdx.x & 63, s = lane & 3;
+    const uint64_t quads_below = (UINT64_C(0x1111111111111111) & ((UINT64_C(1) << (lane & ~3)) - 1)); // leaders of the quads in front
+    // the wave's current chunk of the work list, and the ticket of the next one (requested a chunk ahead)
+    uint32_t cur = 0, cur_end = 0;
+    bool drained = false; // no chunk left for this wave
+    uint32_t next_ticket = 0;
+    if (lane == 0)
+        next_ticket = atomicAdd(ticket, 1u);
+    // the search this quad holds ...
+    bool act = false;
+    uint32_t q = 0, l = 0, e = 0, rem = 0, wcnt = 0;
+    u32x4 w = {0, 0, 0, 0};
+    uint32_t a = 0, b = 0, cb = 0, left = 0, si = 0;
+    // ... and the record it takes next
+    bool nx = false;
+    u32x4 nh = {0, 0, 0, 0}, nw = {0, 0, 0, 0};
+    for (;;)
+    {
+        // 1. quads without a next record claim one (the wave's quads in order: the records of a wave stay neighbours)
+        const uint64_t want = __ballot(!nx && s == 0);
+        if (want && !drained)
+        {
+            if (cur == cur_end)
+            {
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_ticket);
+                const uint64_t lo = (uint64_t)t * kFlatChunk;
+                if (lo >= n_rec)
+                    drained = true;
+                else
+                {
+                    cur = (uint32_t)lo;
+                    cur_end = (uint32_t)(lo + kFlatChunk < n_rec ? lo + kFlatChunk : n_rec);
+                    if (lane == 0)
+                        next_ticket = atomicAdd(ticket, 1u);
+                }
+            }
+            if (!drained)
+            {
+                const uint32_t avail = cur_end - cur, rank = (uint32_t)__popcll(want & quads_below);
+                if (!nx && rank < avail)
+                {
+                    const u32x4 * src = reinterpret_cast<const u32x4 *>(recs + cur + rank);
+                    nh = src[0];
+                    nw = src[1];
+                    nx = true;
+                }
+                const uint32_t wanted = (uint32_t)__popcll(want);
+                cur += wanted < avail ? wanted : avail;
+            }
+        }
+        // 2. one fused step (three tree levels) of both ends of the interval
+        if (act && left)
+        {
+            const uint32_t st = T.steps[si];
+            ++si;
+            --left;
+            const uint32_t base = st & 0x0FFFFFFFu, t = st >> 28;
+            const uint32_t La = base + (a >> kFusedLog), Lb = base + (b >> kFusedLog);
+            const FSec xb = load_fsec<false>(f_lines, Lb, s);
+            FSec xa = xb;
+            if (La != Lb) // quad-uniform
+                xa = load_fsec<false>(f_lines, La, s);
+            a = quad_sum(fsec_count(xa, s, a & 255u, t));
+            b = quad_sum(fsec_count(xb, s, b & 255u, t));
+            if (b == 0)
+            { // a <= b: both chains stay 0 (wt_pc.hpp:386)
+                a = 0;
+                left = 0;
+            }
+            if (left == 0)
+            {
+                l = cb + a;
+                e = cb + b;
+            }
+        }
+        // 3. between two characters: is the search over?  then hand over to the next record; set up the next character
+        if (act && left == 0)
+        {
+            uint64_t res = 0;
+            bool fin = true;
+            if (l >= e)
+                res = 0;
+            else if (rem == 0)
+                res = e - l;
+            else if (VERIFY && e - l == 1 && rem >= 2)
+                res = kFmPending | ((uint64_t)rem << 32) | l;
+            else
+                fin = false;
+            if (fin)
+            {
+                if (s == 0)
+                    out[q] = res;
+                act = false;
+            }
+        }
+        if (!act && nx && nh.w == kFmDead)
+            nx = false; // answered by k_fm_start already
+        if (!act && nx)
+        {
+            q = nh.x;
+            l = nh.y;
+            e = nh.z;
+            rem = nh.w;
+            w = nw;
+            wcnt = rem < 16 ? rem : 16;
+            nx = false;
+            act = true;
+            left = 0;
+        }
+        if (act && left == 0)
+        { // (records on the list have l < e and rem >= 1)
+            if (wcnt == 0)
+            { // a pattern with more than 16 characters to go: the next 16
+                w = load_tail16(pats, (uint64_t)q * m + rem);
+                wcnt = rem < 16 ? rem : 16;
+            }
+            const uint32_t c = w.w >> 24;
+            w.w = __builtin_amdgcn_alignbit(w.w, w.z, 24);
+            w.z = __builtin_amdgcn_alignbit(w.z, w.y, 24);
+            w.y = __builtin_amdgcn_alignbit(w.y, w.x, 24);
+            w.x <<= 8;
+            --wcnt;
+            --rem;
+            const uint32_t meta = T.meta[c];
+            if (meta == 0)
+            { // the character does not occur (suffix_array_algorithm.hpp:180-184): ends at the top of the next iteration
+                l = 1;
+                e = 1;
+            }
+            else
+            {
+                cb = T.cb[c];
+                a = l;
+                b = e;
+                si = meta & 0xFFFFu;
+                left = meta >> 16;
+            }
+        }
+        if (drained && !__any(act || nx))
+            break; // (not drained and nobody busy: the claim at the top of the next iteration fetches a chunk or finds the end)
+    }
+}
+
+// count() of the patterns whose search stopped at a single suffix: the suffix stands at SA[l] in the text, so the pattern's
+// remaining characters pats[begin .. begin + rem) occur right in front of it or nowhere.  One lane per pattern.
+__global__ __launch_bounds__(256) void k_fm_verify2(const uint32_t * __restrict__ sa, const uint8_t * __restrict__ text,
+                                                    const uint8_t * __restrict__ pats, uint32_t m, uint32_t n_pat,
+                                                    uint64_t * __restrict__ out)
+{
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_pat; q += gridDim.x * blockDim.x)
+    {
+        const uint64_t v = out[q];
+        if (!(v >> 63))
+            continue;
+        const uint32_t l = (uint32_t)v, rem = (uint32_t)(v >> 32) & 0x7FFFFFFFu;
+        const uint8_t * p = pats + (uint64_t)q * m;
+        const uint32_t at = sa[l];
+        bool ok = at >= rem;
+        if (ok)
+        {
+            const uint8_t * t = text + (at - rem);
+            if (rem >= 8)
+            {
+                uint64_t diff = 0;
+                for (uint32_t j = 0; j + 8 <= rem; j += 8)
+                {
+                    uint64_t x, y;
+                    __builtin_memcpy(&x, t + j, 8);
+                    __builtin_memcpy(&y, p + j, 8);
+                    diff |= x ^ y;
+                }
+                uint64_t x, y; // the last eight bytes (they may overlap the chunk before)
+                __builtin_memcpy(&x, t + rem - 8, 8);
+                __builtin_memcpy(&y, p + rem - 8, 8);
+                ok = (diff | (x ^ y)) == 0;
+            }
+            else
+                for (uint32_t j = 0; j < rem; ++j)
+                    ok = ok && t[j] == p[j];
+        }
+        out[q] = ok ? 1 : 0;
+    }
+}
+
+// ---- the k-mer table: built from the suffix array and the text --------------------------------------------------------
+// the (up to) eight text bytes at p as a little-endian number, 0 beyond the text's end
+__device__ __forceinline__ uint64_t text_key8(const uint8_t * __restrict__ text, uint64_t n_text, uint64_t p)
+{
+    uint64_t v = 0;
+    if (p + 8 <= n_text)
+        __builtin_memcpy(&v, text + p, 8);
+    else
+        for (uint64_t j = 0; p + j < n_text; ++j)
+            v |= (uint64_t)text[p + j] << (8 * j);
+    return v;
+}
+__device__ __forceinline__ uint64_t low_bytes(uint64_t x, uint32_t k)
+{
+    return k >= 8 ? x : x & ((UINT64_C(1) << (8 * k)) - 1);
+}
+
+// dk[k] = number of distinct k-mers of the text, k = 1..8: suffix i starts a new run of k-mers when its first k bytes differ
+// from its predecessor's in suffix order (a suffix shorter than k has none; the text holds no 0 byte, so its padded key has one)
+__global__ __launch_bounds__(256) void k_deep_census(const uint32_t * __restrict__ sa, uint64_t n, const uint8_t * __restrict__ text,
+                                                     uint64_t n_text, unsigned long long * __restrict__ dk)
+{
+    __shared__ unsigned cnt[9];
+    if (threadIdx.x < 9)
+        cnt[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned mine[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t p = sa[i];
+        const uint64_t x = text_key8(text, n_text, p), y = i ? text_key8(text, n_text, sa[i - 1]) : 0;
+        const uint64_t d = x ^ y;
+        const unsigned fd = d ? (unsigned)(__builtin_ctzll(d) >> 3) : 8u; // first differing byte
+#pragma unroll
+        for (unsigned k = 1; k <= 8; ++k)
+            if (p + k <= n_text && (i == 0 || fd < k))
+                ++mine[k];
+    }
+    for (unsigned k = 1; k <= 8; ++k)
+        if (mine[k])
+            atomicAdd(&cnt[k], mine[k]);
+    __syncthreads();
+    if (threadIdx.x >= 1 && threadIdx.x < 9 && cnt[threadIdx.x])
+        atomicAdd(&dk[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+}
+
+// PASS 0: the first suffix of every k-mer's run claims a slot and stores l; PASS 1: the last one finds the slot and stores e
+template <int PASS>
+__global__ __launch_bounds__(256) void k_deep_fill(const uint32_t * __restrict__ sa, uint64_t n, const uint8_t * __restrict__ text,
+                                                   uint64_t n_text, uint32_t k, unsigned long long * __restrict__ tab,
+                                                   uint32_t n_buckets, unsigned * __restrict__ failed)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    {
+        const uint64_t p = sa[i];
+        if (p + k > n_text)
+            continue;
+        const uint64_t key = low_bytes(text_key8(text, n_text, p), k);
+        const uint64_t j = PASS == 0 ? i - 1 : i + 1;
+        if (j < n)
+        { // (i - 1 wraps for i == 0)
+            const uint64_t pj = sa[j];
+            if (pj + k <= n_text && low_bytes(text_key8(text, n_text, pj), k) == key)
+                continue; // not the end of the run this pass looks for
+        }
+        uint32_t b = deep_bucket(key, n_buckets);
+        bool done = false;
+        for (uint32_t tries = 0; tries < n_buckets && !done; ++tries)
+        {
+            unsigned long long * slot = tab + (uint64_t)b * 16;
+            for (int t = 0; t < 8 && !done; ++t)
+            {
+                if (PASS == 0)
+                {
+                    if (atomicCAS(slot + 2 * t, 0ull, (unsigned long long)key) == 0ull)
+                    {
+                        reinterpret_cast<uint32_t *>(slot + 2 * t + 1)[0] = (uint32_t)i;
+                        done = true;
+                    }
+                }
+                else if (slot[2 * t] == key)
+                {
+                    reinterpret_cast<uint32_t *>(slot + 2 * t + 1)[1] = (uint32_t)(i + 1);
+                    done = true;
+                }
+            }
+            b = b + 1 == n_buckets ? 0 : b + 1;
+        }
+        if (!done)
+            atomicAdd(failed, 1u);
+    }
+}
+
+} // namespace sdslhip
+
+using namespace sdslhip;
+
+namespace sdslhip {
+
+// the per-character tables of k_fm_count_flat, from the node table the fused layout was built on
+sdsl_hip_status fm_build_count_tab(sdsl_hip_fm_s * f)
+{
+    f->ctab_ok = false;
+    f->d_ctab.release();
+    const WtHost & w = sdsl_hip_wt_host(f->wt);
+    if (w.backend != 0 || !w.d_fused.p || !w.d_ftables.p || f->size >= (UINT64_C(1) << 32) || f->sigma < 2)
+        return SDSL_HIP_OK;
+    std::vector<WtFusedTables> ft(1);
+    SH_HIP(hipMemcpy(&ft[0], w.d_ftables.p, sizeof(WtFusedTables), hipMemcpyDeviceToHost));
+    const WtTables & T = w.d_tables_f.p ? w.tables_f : w.tables;
+    std::vector<FmCountTab> store(1);
+    FmCountTab & C = store[0];
+    memset(&C, 0, sizeof C);
+    uint32_t used = 0;
+    for (unsigned c = 0; c < 256; ++c)
+    {
+        const unsigned cc = f->tab.char2comp[c];
+        if (cc == 0 && c > 0)
+            continue;
+        if (T.c_to_leaf[c] == kWtUndef)
+            return SDSL_HIP_OK; // (an alphabet symbol without a leaf: not a tree this path understands)
+        uint64_t p = T.path[c];
+        unsigned left = (unsigned)(p >> 56), v = 0, steps = 0;
+        const uint32_t first = used;
+        while (left)
+        {
+            const unsigned k = left < 3 ? left : 3, t = (unsigned)p & ((1u << k) - 1u);
+            if (used >= kFmMaxSteps || ft[0].fline[v] >= (1u << 28) || v >= w.n_nodes)
+                return SDSL_HIP_OK;
+            C.steps[used++] = ft[0].fline[v] | (t << 28);
+            for (unsigned j = 0, tt = t; j < 3; ++j, tt >>= 1)
+            { // wt_descend
+                const unsigned nv = T.child[v][tt & 1];
+                v = nv == kWtUndef ? v : nv;
+            }
+            p >>= k;
+            left -= k;
+            ++steps;
+        }
+        if (steps == 0 || steps > 255)
+            return SDSL_HIP_OK;
+        C.cb[c] = (uint32_t)f->tab.C[cc];
+        C.meta[c] = first | (steps << 16);
+    }
+    SH_TRY(f->d_ctab.alloc(sizeof(FmCountTab)));
+    SH_HIP(hipMemcpy(f->d_ctab.p, &C, sizeof(FmCountTab), hipMemcpyHostToDevice));
+    f->ctab_ok = true;
+    return SDSL_HIP_OK;
+}
+
+// Builds the k-mer table from the resident suffix array and text.  k = the deepest depth (<= k_max <= 8) whose table — 16 bytes
+// per k-mer at a load of one half — stays within `budget_bytes`; k_max == 0 releases the table.
+sdsl_hip_status fm_build_deep(sdsl_hip_fm_s * f, uint32_t k_max, uint64_t budget_bytes)
+{
+    f->d_deep.release();
+    f->deep_k = 0;
+    f->deep_buckets = 0;
+    f->deep_kmers = 0;
+    if (k_max == 0)
+        return SDSL_HIP_OK;
+    if (!f->d_sa.p || !f->d_text.p || f->size < 2 || f->size >= (UINT64_C(1) << 32))
+    {
+        set_error("the k-mer table is built from the whole suffix array and the text: create the index from text (and before "
+                  "sdsl_hip_fm_drop_sa)");
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    SH_HIP(hipSetDevice(f->device));
+    if (k_max > 8)
+        k_max = 8;
+    const uint64_t n = f->size, n_text = f->size - 1;
+    DevBuf d_dk;
+    SH_TRY(d_dk.alloc(9 * 8 + 8, true));
+    const unsigned grid = grid_for(n, 256, 256u * 16u);
+    hipLaunchKernelGGL(k_deep_census, dim3(grid), dim3(256), 0, 0, f->d_sa.as<uint32_t>(), n, f->d_text.as<uint8_t>(), n_text,
+                       d_dk.as<unsigned long long>());
+    SH_HIP(hipGetLastError());
+    uint64_t dk[10];
+    SH_HIP(hipMemcpy(dk, d_dk.p, 10 * 8, hipMemcpyDeviceToHost));
+    uint32_t k = 0;
+    for (uint32_t t = 1; t <= k_max; ++t)
+        if (dk[t] && dk[t] * 32 <= budget_bytes)
+            k = t;
+    if (getenv("SDSL_HIP_TRACE_BUILD"))
+        fprintf(stderr, "[sdsl_hip] k-mer census: D1..D8 = %llu %llu %llu %llu %llu %llu %llu %llu, budget %llu MiB -> k = %u\n",
+                (unsigned long long)dk[1], (unsigned long long)dk[2], (unsigned long long)dk[3], (unsigned long long)dk[4],
+                (unsigned long long)dk[5], (unsigned long long)dk[6], (unsigned long long)dk[7], (unsigned long long)dk[8],
+                (unsigned long long)(budget_bytes >> 20), k);
+    if (k == 0)
+        return SDSL_HIP_OK;
+    const uint64_t nb = std::max<uint64_t>(1, (dk[k] + 3) / 4); // eight slots per bucket, four taken on average
+    if (nb >= (UINT64_C(1) << 32))
+        return SDSL_HIP_OK;
+    SH_TRY(f->d_deep.alloc(nb * 128, true));
+    unsigned * failed = reinterpret_cast<unsigned *>(d_dk.as<unsigned long long>() + 9);
+    hipLaunchKernelGGL((k_deep_fill<0>), dim3(grid), dim3(256), 0, 0, f->d_sa.as<uint32_t>(), n, f->d_text.as<uint8_t>(), n_text,
+                       k, f->d_deep.as<unsigned long long>(), (uint32_t)nb, failed);
+    hipLaunchKernelGGL((k_deep_fill<1>), dim3(grid), dim3(256), 0, 0, f->d_sa.as<uint32_t>(), n, f->d_text.as<uint8_t>(), n_text,
+                       k, f->d_deep.as<unsigned long long>(), (uint32_t)nb, failed);
+    SH_HIP(hipGetLastError());
+    unsigned bad = 0;
+    SH_HIP(hipMemcpy(&bad, failed, 4, hipMemcpyDeviceToHost));
+    if (bad)
+    { // cannot happen at this load; an index without the table is still complete
+        f->d_deep.release();
+        return SDSL_HIP_OK;
+    }
+    f->deep_k = k;
+    f->deep_buckets = (uint32_t)nb;
+    f->deep_kmers = dk[k];
+    return SDSL_HIP_OK;
+}
+
+// the default table of an index created from text: as deep as fits into the wavelet tree's own size (SDSL_HIP_FM_DEEP=<k_max>,
+// 0 = none; SDSL_HIP_FM_DEEP_MB=<budget>)
+sdsl_hip_status fm_build_deep_default(sdsl_hip_fm_s * f)
+{
+    const char * ek = getenv("SDSL_HIP_FM_DEEP");
+    const char * eb = getenv("SDSL_HIP_FM_DEEP_MB");
+    const uint32_t k_max = ek ? (uint32_t)std::max(0, atoi(ek)) : 8u;
+    const uint64_t budget = eb ? (uint64_t)atoll(eb) << 20 : std::max<uint64_t>(UINT64_C(1) << 20, sdsl_hip_wt_device_bytes(f->wt));
+    if (!f->ctab_ok || !f->d_sa.p || !f->d_text.p || f->size < 2)
+        return SDSL_HIP_OK;
+    return fm_build_deep(f, k_max, budget);
+}
+
+static bool fm_fast_enabled()
+{ // SDSL_HIP_FM_FAST=0: count() keeps to k_fm_count (fm.hip), for A/B
+    static const bool on = !(getenv("SDSL_HIP_FM_FAST") && atoi(getenv("SDSL_HIP_FM_FAST")) == 0);
+    return on;
+}
+
+bool fm_fast_applies(const sdsl_hip_fm_s * f, uint32_t m, uint64_t n_pat)
+{
+    static const uint64_t min_pat = getenv("SDSL_HIP_FM_FAST_MIN") ? (uint64_t)atoll(getenv("SDSL_HIP_FM_FAST_MIN")) : 4096;
+    return fm_fast_enabled() && f->ctab_ok && m >= 1 && m < (1u << 30) && n_pat >= min_pat && (!f->deep_k || m >= f->deep_k);
+}
+
+// count() of n_pat patterns of m bytes each, all in device memory; slabs of at most 2^25 patterns share one scratch area
+sdsl_hip_status fm_count_fast(sdsl_hip_fm_s * f, const uint8_t * d_pats, uint32_t m, uint64_t n_pat, uint64_t * d_out, bool verify,
+                              hipStream_t s)
+{
+    static const uint64_t slab_log = getenv("SDSL_HIP_FM_SLAB_LOG2") ? (uint64_t)atoi(getenv("SDSL_HIP_FM_SLAB_LOG2")) : 25;
+    const uint64_t slab = UINT64_C(1) << (slab_log >= 10 && slab_log <= 31 ? slab_log : 25);
+    const uint64_t per = std::min(slab, n_pat);
+    const WtHost & w = sdsl_hip_wt_host(f->wt);
+    const uint64_t n_slabs = (n_pat + per - 1) / per;
+    void * scratch = nullptr; // the slab's records + one chunk counter per slab
+    SH_HIP(hipMallocAsync(&scratch, per * sizeof(FmRec) + n_slabs * 4 + 64, s));
+    FmRec * recs = reinterpret_cast<FmRec *>(scratch);
+    uint32_t * ctr = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(scratch) + per * sizeof(FmRec));
+    hipError_t e = hipMemsetAsync(ctr, 0, n_slabs * 4, s);
+    const FmDeep D = f->deep();
+    FmJump J = f->jump();
+    if (J.k > 8)
+        J.tab = nullptr;
+    verify = verify && f->d_sa.p && f->d_text.p;
+    const uint32_t csa_size = (uint32_t)f->size;
+    for (uint64_t i = 0; i < n_slabs && e == hipSuccess; ++i)
+    {
+        const uint64_t lo = i * per;
+        const uint32_t cnt = (uint32_t)std::min(per, n_pat - lo);
+        const uint8_t * pp = d_pats + lo * m;
+        uint64_t * oo = d_out + lo;
+        uint32_t * ticket = ctr + i;
+        if (D.tab)
+        {
+            const unsigned g = grid_for(cnt, 64, 256u * 8u);
+            if (verify)
+                hipLaunchKernelGGL((k_fm_start<true>), dim3(g), dim3(256), 0, s, D, csa_size, pp, m, cnt, oo, recs);
+            else
+                hipLaunchKernelGGL((k_fm_start<false>), dim3(g), dim3(256), 0, s, D, csa_size, pp, m, cnt, oo, recs);
+        }
+        else if (verify)
+            hipLaunchKernelGGL((k_fm_start_dense<true>), dim3(grid_for(cnt, 256, 256u * 8u)), dim3(256), 0, s, J, f->d_tab.as<FmTables>(),
+                               csa_size, pp, m, cnt, oo, recs);
+        else
+            hipLaunchKernelGGL((k_fm_start_dense<false>), dim3(grid_for(cnt, 256, 256u * 8u)), dim3(256), 0, s, J, f->d_tab.as<FmTables>(),
+                               csa_size, pp, m, cnt, oo, recs);
+        const unsigned gf = grid_for(cnt, 256, 256u * 8u);
+        if (verify)
+            hipLaunchKernelGGL((k_fm_count_flat<true>), dim3(gf), dim3(256), 0, s, w.d_fused.as<uint64_t>(),
+                               f->d_ctab.as<FmCountTab>(), recs, cnt, ticket, pp, m, oo);
+        else
+            hipLaunchKernelGGL((k_fm_count_flat<false>), dim3(gf), dim3(256), 0, s, w.d_fused.as<uint64_t>(),
+                               f->d_ctab.as<FmCountTab>(), recs, cnt, ticket, pp, m, oo);
+        if (verify)
+            hipLaunchKernelGGL(k_fm_verify2, dim3(grid_for(cnt, 256, 256u * 16u)), dim3(256), 0, s, f->d_sa.as<uint32_t>(),
+                               f->d_text.as<uint8_t>(), pp, m, cnt, oo);
+        e = hipGetLastError();
+    }
+    (void)hipFreeAsync(scratch, s);
+    SH_HIP(e);
+    return SDSL_HIP_OK;
+}
+
+} // namespace sdslhip

@@ -55,6 +55,25 @@ __device__ __forceinline__ uint64_t fm_jump_start(const FmJump & J, const FmTabl
     return end - J.k;
 }
 
+// Per-byte tables of the flat count kernel (fm_count2.hip), 7 KiB of LDS: the path of every symbol through the fused wavelet
+// tree, spelled out as the steps the search takes — no node-table descent, no 64-bit path word in the loop.
+constexpr unsigned kFmMaxSteps = 1280;
+struct FmCountTab
+{
+    uint32_t cb[256];            // by byte c: C[char2comp[c]] (32 bits: the fused layout is for fewer than 2^32 symbols)
+    uint32_t meta[256];          // by byte c: first step | number of steps << 16; 0 = the byte does not occur
+    uint32_t steps[kFmMaxSteps]; // first line of the fused node (28 bits) | slot << 28
+};
+
+// The k-mer table ("deep jump"): the SA interval [l, e) of every k-mer (k <= 8 bytes) that occurs in the text, in an open hash
+// table of 128-byte buckets of eight 16-byte entries [k-mer as a little-endian number | l | e << 32]; key 0 = free (a k-mer
+// of the text holds no 0 byte).  One bucket fetch replaces the first k LF steps of a search.
+struct FmDeep
+{
+    const ulonglong2 * tab; // null = no table
+    uint32_t k, n_buckets;
+};
+
 struct WtHost;
 sdsl_hip_status fm_rrr_launch_count(const WtHost & wt, const FmTables * d_tab, FmJump jump, uint64_t csa_size,
                                     const uint8_t * d_pats, uint32_t m, const uint64_t * d_offsets, const uint32_t * d_order,

@@ -32,6 +32,20 @@ struct sdsl_hip_fm_s
     uint64_t n_sa_s = 0, n_isa_s = 0;
     sdslhip::DevBuf d_jump; // jump-start table (fm_device.hpp FmJump), sigma^jump_k (l, r) pairs
     uint32_t jump_k = 0;
+    // count() of large batches (fm_count2.hip): the per-byte step tables of the flat kernel and the k-mer table
+    sdslhip::DevBuf d_ctab;
+    bool ctab_ok = false;
+    sdslhip::DevBuf d_deep;
+    uint32_t deep_k = 0, deep_buckets = 0;
+    uint64_t deep_kmers = 0;
+    sdslhip::FmDeep deep() const
+    {
+        sdslhip::FmDeep d;
+        d.tab = deep_k ? d_deep.as<ulonglong2>() : nullptr;
+        d.k = deep_k;
+        d.n_buckets = deep_buckets;
+        return d;
+    }
     sdslhip::FmJump jump() const
     {
         sdslhip::FmJump j;
@@ -60,6 +74,13 @@ sdsl_hip_status sa_samples_to_host(const uint32_t * d_sa, uint64_t n, uint64_t s
 // samples from the full suffix array, left on the device (either output may be null)
 sdsl_hip_status sa_samples_device(const uint32_t * d_sa, uint64_t n, uint64_t sa_dens, uint64_t isa_dens, DevBuf * sa_s,
                                   DevBuf * isa_s);
+// fm_count2.hip
+sdsl_hip_status fm_build_count_tab(sdsl_hip_fm_s * f);
+sdsl_hip_status fm_build_deep(sdsl_hip_fm_s * f, uint32_t k_max, uint64_t budget_bytes);
+sdsl_hip_status fm_build_deep_default(sdsl_hip_fm_s * f);
+bool fm_fast_applies(const sdsl_hip_fm_s * f, uint32_t m, uint64_t n_pat);
+sdsl_hip_status fm_count_fast(sdsl_hip_fm_s * f, const uint8_t * d_pats, uint32_t m, uint64_t n_pat, uint64_t * d_out, bool verify,
+                              hipStream_t s);
 sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint32_t * vals_in, uint32_t * vals_out,
                                    uint64_t n, unsigned end_bit, hipStream_t s);
 // out[i] = in[0] + ... + in[i-1] (n entries), stream-ordered

@@ -622,6 +622,16 @@ class csa_wt(_Handle):
     def set_jump_depth(self, k: int):
         capi.check(capi.lib().sdsl_hip_fm_set_jump_depth(self._h, k))
 
+    def set_kmer_table(self, k_max: int, budget_bytes: int):
+        """(re)build the k-mer hash table of count() with the deepest k <= k_max that fits budget_bytes; k_max 0 releases it"""
+        capi.check(capi.lib().sdsl_hip_fm_set_kmer_table(self._h, k_max, budget_bytes))
+
+    def kmer_table_depth(self) -> int:
+        return capi.lib().sdsl_hip_fm_kmer_table_depth(self._h)
+
+    def kmer_table_bytes(self) -> int:
+        return capi.lib().sdsl_hip_fm_kmer_table_bytes(self._h)
+
     def alphabet(self):
         c2c = np.zeros(256, dtype=np.uint8)
         Cc = np.zeros(257, dtype=np.uint64)
