@@ -59,8 +59,10 @@ def parse():
     p.add_argument("--log-n", type=int, default=34, help="bit vector length = 2^log_n (BASELINE: 34)")
     p.add_argument("--queries", type=float, default=1e9, help="queries per step per GPU (BASELINE: 1e9)")
     p.add_argument("--extras", type=str, default=None,
-                   help="comma list of: select,rrr,sd,wt,fm,fm_sharded (or 'none'); default: the first five on one GPU, "
-                        "fm_sharded (configs[4]: 10^8 patterns sharded over the ranks) on several")
+                   help="comma list of: e2e,sweep,select,rrr,sd,shapes,wt,fm,fm_sharded,group (or 'none'); default: the first eight on one "
+                        "GPU, fm_sharded (configs[4]: 10^8 patterns sharded over the ranks) on several; group = rank 0 also drives all "
+                        "GPUs through the C ABI's device group (RCCL point-to-point between devices: opt-in, it has not run on "
+                        "hardware with more than one device yet and must not endanger the scaling run)")
     p.add_argument("--text-mib", type=int, default=1024, help="synthetic text size for the wt/fm extras (BASELINE: 1 GiB)")
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     p.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU time budget per cpu_baseline sample")
@@ -117,12 +119,13 @@ def spread_of(xs):
 
 
 def kernel_sources_sha():
-    """sha256 over the kernel sources a PMC measurement is valid for."""
+    """sha256 over the kernel sources a PMC measurement is valid for (every .hip / .hpp of the library)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("bv.hip", "bv_device.hpp", "bv_sorted.hip", "bv_sorted_dev.hpp", "bv_swc.hip", "bits.hpp", "wt.hip", "wt_device.hpp", "fm.hip",
-              "fm_device.hpp"):
-        h.update(open(os.path.join(ROOT, "sdsl-lite_amd", "csrc", f), "rb").read())
+    d = os.path.join(ROOT, "sdsl-lite_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -403,7 +406,7 @@ def group_leg(pkg, a, N, n_bits, nq, steps, warmup):
     repl_s = time.perf_counter() - t0
     idx_d, out_d = [], []
     for r in devs:
-        idx_d.append(to_dev(pkg.rnd_positions(7 + r, nq, n_bits + 1, 0), torch.device("cuda", r)))
+        idx_d.append(pkg.rnd_positions_device(7 + r, nq, n_bits + 1, 0, r))
         out_d.append(torch.empty_like(idx_d[r]))
 
     def step():
@@ -544,13 +547,15 @@ def main():
     # index: replicated (same seed on every rank); queries: this rank's resident shard.  SURVEY.md 8(d) streams.
     G = golden()
     t0 = time.perf_counter()
-    words = to_dev(pkg.set_random_bits(n_bits, 42), dev)
+    # (generated ON the device from generator checkpoints: a rank holds no host copy of its 2 GiB of words and 8 GB of positions —
+    # eight ranks on one node would hold 80 GB before the first kernel; the host only walks each generator once, a few seconds)
+    words = pkg.rnd_positions_device(42, (n_bits + 63) // 64, 0, 0, local)  # = util::set_random_bits (util.hpp:467-485)
     if a.extras is None:
-        a.extras = "select,rrr,sd,shapes,wt,fm" if world == 1 else "fm_sharded,group"
+        a.extras = "e2e,sweep,select,rrr,sd,shapes,wt,fm" if world == 1 else "fm_sharded"
     extras = [] if a.extras in ("", "none") else a.extras.split(",")
     bv = pkg.bit_vector(words, n_bits, device=local, select1="select" in extras, select0=False)
     index_bytes = bv.device_bytes()
-    idx = to_dev(pkg.rnd_positions(7 + rank, nq, n_bits + 1, 0), dev)
+    idx = pkg.rnd_positions_device(7 + rank, nq, n_bits + 1, 0, local)
     out = torch.empty_like(idx)
     gq = torch.Generator(device=dev).manual_seed(1007 + rank)  # secondary measurements without a reference digest
     setup_s = time.perf_counter() - t0
@@ -626,6 +631,77 @@ def main():
 
     ex = {}
     try:
+        if "e2e" in extras and world == 1 and rank == 0:
+            # kernel-only (the headline) AND end-to-end.  The same entry point handed HOST arrays: 16 bytes per
+            # query cross PCIe (8 up, 8 down); the library cuts the batch into chunks that travel on two streams, so upload,
+            # kernel and download overlap (common.hpp: host_pipeline_u64).  Never `value`.
+            ne = min(nq, 250_000_000)
+            want_e = out[:ne].cpu().numpy().view(np.uint64)
+            legs = {}
+            for kind in ("pageable", "pinned"):
+                if kind == "pageable":
+                    h_idx = idx[:ne].cpu().numpy().view(np.uint64)
+                    h_out = np.zeros(ne, dtype=np.uint64)
+                else:
+                    t_idx = torch.empty(ne, dtype=torch.int64).pin_memory()
+                    t_idx.copy_(idx[:ne])
+                    t_out = torch.zeros(ne, dtype=torch.int64).pin_memory()
+                    h_idx, h_out = t_idx.numpy().view(np.uint64), t_out.numpy().view(np.uint64)
+                bv.rank(h_idx, 1, h_out)  # warm-up (first touch of the result pages, the pipeline's staging buffers)
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    bv.rank(h_idx, 1, h_out)  # returns when the answers are in h_out
+                    ts.append(time.perf_counter() - t0)
+                sec = sorted(ts)[1]
+                legs[kind] = {"Grank/s": ne / sec / 1e9, "seconds": spread_of(ts), "pcie_GB/s_both_directions": 16 * ne / sec / 1e9,
+                              "same_answers": bool(np.array_equal(h_out, want_e))}
+            result["end_to_end"] = {"what": "sdsl_hip_bv_rank_batch on HOST arrays (positions in, answers out), wall clock around the call",
+                                    "queries": ne, "bytes_over_pcie_per_query": 16, **legs,
+                                    "pcie_note": "PCIe 5.0 x16: 64 GB/s per direction on paper, ~55 achievable; the kernel-only rate is `value`"}
+            del h_idx, h_out, want_e
+            if kind == "pinned":
+                del t_idx, t_out
+        if "sweep" in extras and world == 1 and rank == 0:
+            # where the routes cross: batch size x vector size, default dispatch / direct kernel / bucketed passes forced.
+            # (vector words and positions from the device's generator: no reference digest at these sizes, the routes check each other)
+            sweep = []
+            for ln in (30, a.log_n, 36):
+                nb = 1 << ln
+                if ln == a.log_n:
+                    bs_ = bv
+                else:
+                    w_ = torch.randint(-2**63, 2**63 - 1, (nb // 64,), device=dev, dtype=torch.int64, generator=gq)
+                    bs_ = pkg.bit_vector(w_, nb, device=local, select1=False, select0=False)
+                    del w_
+                for nqs in (10**5, 10**6, 10**7, 10**8, 10**9):
+                    if nqs > nq:
+                        continue
+                    qi = torch.randint(0, nb + 1, (nqs,), device=dev, dtype=torch.int64, generator=gq)
+                    o_ = [torch.empty_like(qi) for _ in range(3)]
+                    row = {"n_bits_log2": ln, "queries": nqs}
+                    for j, (route, opt) in enumerate((("default", -1), ("direct", 0), ("bucketed", 1))):
+                        pkg.set_option("rank_sorted", opt)
+                        pkg.set_option("trace_phases", 1)
+                        bs_.rank(qi, 1, o_[j])
+                        torch.cuda.synchronize()
+                        took_passes = bool(pkg.last_phases())
+                        pkg.set_option("trace_phases", 0)
+                        if route == "bucketed" and not took_passes:
+                            row[route] = None  # the passes do not apply to this vector / batch (bv_sorted.hip: bv_sorted_rank_possible)
+                            continue
+                        _, ms_ = time_steps(lambda: bs_.rank(qi, 1, o_[j]), 5 if nqs >= 10**8 else 20, 1, barrier)
+                        row[route] = {"Grank/s": nqs / ms_ / 1e6, "kernel_ms": ms_}
+                        if route == "default":
+                            row[route]["route"] = "bucketed" if took_passes else "direct"
+                    row["same_answers"] = bool(torch.equal(o_[0], o_[1]) and (row["bucketed"] is None or torch.equal(o_[0], o_[2])))
+                    sweep.append(row)
+                    del qi, o_
+                pkg.set_option("rank_sorted", -1)
+                if bs_ is not bv:
+                    del bs_
+                    torch.cuda.empty_cache()
+            ex["batch_sweep"] = sweep
         if "select" in extras:
             ones = bv.ones()
             si = to_dev(pkg.rnd_positions(11, nq, ones, 1), dev)  # 8(d): 1 + mt19937_64(11) % ones
@@ -895,27 +971,64 @@ def main():
                 m = 20
                 st = to_dev(pkg.rnd_positions(15, nq2, nt - m, 0), dev)  # 8(d): patterns cut at mt19937_64(15) % (n - m)
                 pats = text[(st.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()
-                fm_steps = []
-                _, ms = time_steps(lambda: csa.count(pats, m, out2), max(6, a.steps // 2), 1, barrier, per_step=fm_steps)
                 sum_l = float(lens[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
                 alg = 28 + 160 * sum_l
                 sum_steps = float(fsteps[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
-                assert bool((out2 >= 1).all()), "every pattern was cut from the text"
-                lf = (28 + 256 * sum_steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                rf, how = fused_frac("k_fm_count_bytes_per_pattern", nq2, ms, lf)
-                ex["fm_count"] = {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "kernel_ms_per_batch": spread_of(fm_steps),
-                                  "spread": (max(fm_steps) - min(fm_steps)) / ms, "patterns": nq2, "m": m,
-                                  "path": ("search until one suffix is left, then the remaining characters are compared with the text at "
-                                           "SA[l] (k_fm_count<verify> + k_fm_verify: the whole suffix array and the text are resident)")
-                                  if os.environ.get("SDSL_HIP_FM_VERIFY", "1") != "0" else "every character walked (SDSL_HIP_FM_VERIFY=0)",
-                                  "reference_digest_match": digest_matches(out2, c4["count"])
-                                  if c4ok and nq2 >= c4["count"]["n"] else None,
-                                  "fused_steps_per_pattern": sum_steps,
-                                  "roofline_frac": rf, "roofline_frac_source": how,
-                                  "survey_8d_model_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "algorithmic_bytes_per_pattern": alg,
-                                  "line_fetch_frac": lf,
-                                  "jump_depth": csa.jump_depth(), "note": FUSED_NOTE}
+
+                def count_leg(variant, what):
+                    """one timed leg of count(): >= 6 batches, every answer compared with the reference's digest; `roofline` from
+                    the PMC collection of exactly this variant (tools/collect_profiles.sh -> profiles/pmc_latest.json), valid
+                    only for these kernel sources"""
+                    steps_ms = []
+                    _, ms = time_steps(lambda: csa.count(pats, m, out2), max(6, a.steps // 2), 1, barrier, per_step=steps_ms)
+                    assert bool((out2 >= 1).all()), "every pattern was cut from the text"
+                    bpp = pmc_traffic("fm_count_%s_bytes_per_pattern" % variant)
+                    rpp = pmc_traffic("fm_count_%s_requests_per_pattern" % variant)
+                    return {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "kernel_ms_per_batch": spread_of(steps_ms),
+                            "spread": (max(steps_ms) - min(steps_ms)) / ms, "patterns": nq2, "m": m, "path": what,
+                            "reference_digest_match": digest_matches(out2, c4["count"]) if c4ok and nq2 >= c4["count"]["n"] else None,
+                            "index_bytes": csa.device_bytes(), "kmer_table": {"k": csa.kmer_table_depth(), "bytes": csa.kmer_table_bytes()},
+                            "jump_depth": csa.jump_depth(),
+                            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                         "traffic_bytes_per_pattern": bpp, "fabric_requests_per_pattern": rpp,
+                                         "achieved": bpp * nq2 / (ms * 1e-3) / 1e9 if bpp else None,
+                                         "frac": bpp * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if bpp else None,
+                                         "valu_issue_share": pmc_traffic("fm_count_%s_valu_issue_share" % variant),
+                                         "kernels": "k_fm_start + k_fm_count_flat + k_fm_verify2 (fm_count2.hip), summed",
+                                         "source": "PMC (TCC_EA0_RDREQ/WRREQ, SQ_INSTS_VALU) of tools/fm_probe.py on this text and these "
+                                                   "patterns, profiles/pmc_latest.json; null when it was not collected on these kernel sources"},
+                            "survey_8d_model_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "algorithmic_bytes_per_pattern": alg, "fused_steps_per_pattern_without_table": sum_steps, "note": FUSED_NOTE}
+
+                verify_on = os.environ.get("SDSL_HIP_FM_VERIFY", "1") != "0"
+                ex["fm_count"] = count_leg("default", "k-mer hash table (k = %d: one 128-byte bucket instead of k LF steps) -> flat search kernel "
+                                           "until one suffix is left%s (fm_count2.hip); no sort, patterns in the caller's order"
+                                           % (csa.kmer_table_depth(), " -> the remaining characters compared with the text at SA[l]: the whole "
+                                              "suffix array and the text are resident" if verify_on else ""))
+                ms = ex["fm_count"]["kernel_ms"]
+                if rank == 0 and world == 1:
+                    # end to end: patterns and answers in HOST memory (28 bytes per pattern over PCIe), pieces of 2^20 patterns
+                    # on two streams (fm.hip: host_pipeline_bytes)
+                    want_c = out2.cpu().numpy().view(np.uint64)
+                    h_p = pats.cpu().numpy()
+                    h_o = np.zeros(nq2, dtype=np.uint64)
+                    csa.count(h_p, m, h_o)
+                    ts = []
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        csa.count(h_p, m, h_o)
+                        ts.append(time.perf_counter() - t0)
+                    sec = sorted(ts)[1]
+                    ex["fm_count"]["end_to_end"] = {"what": "sdsl_hip_fm_count_batch on HOST arrays (pageable), wall clock around the call",
+                                                    "Mcount/s": nq2 / sec / 1e6, "seconds": spread_of(ts), "bytes_over_pcie_per_pattern": m + 8,
+                                                    "pcie_GB/s_both_directions": (m + 8) * nq2 / sec / 1e9,
+                                                    "same_answers": bool(np.array_equal(h_o, want_c))}
+                    del h_p, h_o, want_c
+                # the same index with the deepest table (HBM is there to be used: 32 bytes per distinct 8-mer)
+                wt_budget = wt.device_bytes()
+                csa.set_kmer_table(8, 64 << 30)
+                ex["fm_count_kmer8"] = count_leg("k8", "as fm_count with the k-mer table at its deepest (k = %d)" % csa.kmer_table_depth())
+                csa.set_kmer_table(8, wt_budget)  # back to the default depth
                 if rcsa is not None:
                     cb = cpu_time(lambda p: rcsa.count_batch(p.reshape(-1), m), [pats.view(-1, m)], out2, a.cpu_seconds,
                                   1e6, "20-byte patterns, sdsl::count of the real sdsl-lite on the index the GPU built "
@@ -942,6 +1055,11 @@ def main():
                 _, ms = time_steps(lambda: csa.sa(sidx), 2, 1, barrier)
                 assert torch.equal(csa.sa(sidx), want), "sampled SA walk != whole SA"
                 ex["fm_sa_access_dens32"] = {"Msa/s": sidx.numel() / ms / 1e3, "ms": ms, "queries": sidx.numel()}
+                # count() at the footprint of csa_wt<wt_huff<>, 32, 64> plus the k-mer table: no suffix array, no text, every
+                # character after the table's k is an LF step (suffix_array_algorithm.hpp:228-248)
+                ex["fm_count_sa_dropped"] = count_leg("dropped", "k-mer hash table (k = %d) -> flat search kernel over ALL remaining "
+                                                      "characters; suffix array and text released (SDSL's default samples kept)"
+                                                      % csa.kmer_table_depth())
                 eb = torch.randint(0, nt - 64, (10_000_000,), device=dev, dtype=torch.int64, generator=gq)
                 ee = eb + 63
                 eoff, etxt = csa.extract(eb, ee)
@@ -1018,7 +1136,6 @@ def main():
             t0 = time.perf_counter()
             csa = pkg.csa_wt(text=text, device=local)
             build = time.perf_counter() - t0
-            csa.drop_sa()
             m, total = 20, min(int(a.queries) // 10, 100_000_000)
             gp = torch.Generator(device=dev).manual_seed(99)  # the same batch on every rank; each takes its slice
             st = torch.randint(0, nt - m, (total,), device=dev, generator=gp)
@@ -1028,7 +1145,8 @@ def main():
             wall_s, _ = time_steps(lambda: csa.count(mine, m, res), 3, 1, barrier)
             wall_s = pkg.dist.max_over_ranks(wall_s, comm_dev)
             ok = bool((res >= 1).all())
-            fs = {"patterns_total": total, "m": m, "text_bytes": nt, "index_build_s": build,
+            fs = {"patterns_total": total, "m": m, "text_bytes": nt, "index_build_s": build, "index_bytes_per_gpu": csa.device_bytes(),
+                  "kmer_table_k": csa.kmer_table_depth(),
                   "text_broadcast_s": bcast,
                   "resident_shards": {"Mcount/s": total * 3 / wall_s / 1e6, "ms_per_batch": wall_s / 3 * 1e3,
                                       "all_patterns_found": ok, "scaling": "strong"}}

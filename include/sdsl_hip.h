@@ -104,6 +104,12 @@ sdsl_hip_status sdsl_hip_util_mt_checkpoints(uint64_t seed, uint64_t stride, uin
 sdsl_hip_status sdsl_hip_util_density_bits(uint64_t * words, uint64_t n_bits, uint64_t seed, uint32_t percent,
                                            const uint64_t * checkpoints, uint64_t n_checkpoints, uint64_t stride);
 sdsl_hip_status sdsl_hip_util_english_text(uint8_t * out, uint64_t n_bytes, uint64_t seed);
+/* The same stream as rnd_positions, written straight into DEVICE memory: `checkpoints` (host) = the generator's state before
+ * every `stride`-th draw (sdsl_hip_util_mt_checkpoints, 313 words each), one block per checkpoint regenerates its stretch.
+ * For processes that must not hold the stream on the host (one rank per GPU: eight times 8 GB).  Synchronises `stream`. */
+sdsl_hip_status sdsl_hip_util_rnd_positions_device(const uint64_t * checkpoints, uint64_t n_checkpoints, uint64_t stride,
+                                                   uint64_t count, uint64_t mod, uint64_t add, uint64_t * d_out, int32_t device,
+                                                   void * stream);
 
 /* ---- plain bit vector: rank_support_v5 / select_support_mcl ---------------------------
  * Replaces: rank_support_v5<b>::rank / operator() (rank_support_v5.hpp:131-154),
@@ -163,6 +169,17 @@ sdsl_hip_status sdsl_hip_bv_query_one(sdsl_hip_bv_t bv, int32_t what, int32_t bi
  * include it). */
 sdsl_hip_status sdsl_hip_bv_release_scratch(sdsl_hip_bv_t bv);
 uint64_t sdsl_hip_device_scratch_bytes(int32_t device);
+/* Stream capture.  A batch call with a hipStream_t only enqueues, so it can be captured into a HIP graph — but a graph bakes in the
+ * addresses it was captured with and its replays are ordered with nothing the library sees.  A large batch enqueued WHILE ITS STREAM
+ * IS BEING CAPTURED therefore never touches the device's shared pool: it works in a scratch area owned by the handle, which
+ * sdsl_hip_bv_reserve_capture_scratch / sdsl_hip_rrr_reserve_capture_scratch allocate beforehand for batches of up to max_queries
+ * (they also build the bucket plans of the handle's select directories and the spread sample's verdict word — nothing may be
+ * allocated or built during a capture).  Without a reservation of sufficient size a captured batch takes the direct kernel:
+ * same answers, the speed of small batches.  Replays of graphs captured from ONE handle must not overlap each other (they share
+ * that handle's area); they may overlap anything else, including large batches of other handles and un-captured batches of the
+ * same handle.  max_queries = 0 releases the area; so does destroying the handle — graphs captured from it are invalid
+ * afterwards (as they are after sdsl_hip_bv_release_scratch, which frees the verdict word with the pool). */
+sdsl_hip_status sdsl_hip_bv_reserve_capture_scratch(sdsl_hip_bv_t bv, uint64_t max_queries);
 uint64_t sdsl_hip_bv_size(sdsl_hip_bv_t bv);         /* bit_vector::size() */
 uint64_t sdsl_hip_bv_ones(sdsl_hip_bv_t bv);         /* == rank_1(size()) */
 uint64_t sdsl_hip_bv_device_bytes(sdsl_hip_bv_t bv); /* HBM footprint of the device layout */
@@ -196,6 +213,7 @@ sdsl_hip_status sdsl_hip_rrr_create_from_sdsl(const void * bytes, size_t len, in
  * size.  An index encoded on the GPU can thus be handed to unmodified SDSL code (load / load_from_file). */
 sdsl_hip_status sdsl_hip_rrr_serialize(sdsl_hip_rrr_t v, void * buf, size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_rrr_destroy(sdsl_hip_rrr_t v);
+sdsl_hip_status sdsl_hip_rrr_reserve_capture_scratch(sdsl_hip_rrr_t v, uint64_t max_queries); /* see sdsl_hip_bv_reserve_capture_scratch */
 uint64_t sdsl_hip_rrr_size(sdsl_hip_rrr_t v);
 uint64_t sdsl_hip_rrr_ones(sdsl_hip_rrr_t v);
 uint64_t sdsl_hip_rrr_device_bytes(sdsl_hip_rrr_t v);

@@ -229,6 +229,13 @@ public:
             throw std::runtime_error("rank_support_v5_hip: no vector set");
         hip_detail::check(sdsl_hip_bv_rank_batch(m_dev.get(), dev_bit, idx, n, out, stream), "sdsl_hip_bv_rank_batch");
     }
+    //! working memory for batches of up to n queries enqueued while `stream` is being captured into a HIP graph (sdsl_hip.h:
+    //! stream capture); shared by the supports of this vector on this device; 0 releases it
+    void reserve_capture_scratch(size_t n) const
+    {
+        if (m_dev)
+            hip_detail::check(sdsl_hip_bv_reserve_capture_scratch(m_dev.get(), n), "sdsl_hip_bv_reserve_capture_scratch");
+    }
     size_type size() const
     {
         return m_v->size();
@@ -355,6 +362,13 @@ public:
         if (!m_dev)
             throw std::runtime_error("select_support_mcl_hip: no vector set");
         hip_detail::check(sdsl_hip_bv_select_batch(m_dev.get(), dev_bit, i, n, out, stream), "sdsl_hip_bv_select_batch");
+    }
+    //! working memory for batches of up to n queries enqueued while `stream` is being captured into a HIP graph (sdsl_hip.h:
+    //! stream capture); shared by the supports of this vector on this device; 0 releases it
+    void reserve_capture_scratch(size_t n) const
+    {
+        if (m_dev)
+            hip_detail::check(sdsl_hip_bv_reserve_capture_scratch(m_dev.get(), n), "sdsl_hip_bv_reserve_capture_scratch");
     }
     size_type size() const
     {
@@ -622,6 +636,11 @@ public:
     void access_batch(size_type const * i, size_t n, uint8_t * out, void * stream = nullptr) const
     {
         hip_detail::check(sdsl_hip_rrr_access_batch(m_dev.get(), i, n, out, stream), "sdsl_hip_rrr_access_batch");
+    }
+    //! as rank_support_v5_hip::reserve_capture_scratch
+    void reserve_capture_scratch(size_t n) const
+    {
+        hip_detail::check(sdsl_hip_rrr_reserve_capture_scratch(m_dev.get(), n), "sdsl_hip_rrr_reserve_capture_scratch");
     }
     //! out[q] = get_int(idx[q], len)   (rrr_vector.hpp:308-356)
     void get_int_batch(size_type const * idx, uint8_t len, size_t n, uint64_t * out, void * stream = nullptr) const

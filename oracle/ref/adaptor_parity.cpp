@@ -645,8 +645,18 @@ int main(int argc, char ** argv)
         std::vector<uint64_t> cnt(np);
         mcsa.count_batch(pats.data(), m, np, cnt.data(), 2);
         ok = mcsa.size() == csa.size();
+        size_t shown = 0;
         for (size_t i = 0; i < np; ++i)
-            ok &= cnt[i] == count(csa, pats.begin() + i * m, pats.begin() + (i + 1) * m);
+        {
+            const uint64_t want = count(csa, pats.begin() + i * m, pats.begin() + (i + 1) * m);
+            if (cnt[i] != want && shown++ < 8) // (where and how a mismatch looks decides what to look for)
+                fprintf(stderr, "count_batch over the group, pass %d (%zu members): pattern %zu got %llu want %llu\n", pass, devs.size(), i,
+                        (unsigned long long)cnt[i], (unsigned long long)want);
+            ok &= cnt[i] == want;
+        }
+        if (shown)
+            fprintf(stderr, "count_batch over the group, pass %d: %zu of %zu patterns differ (sizes %llu / %llu)\n", pass, shown, np,
+                    (unsigned long long)mcsa.size(), (unsigned long long)csa.size());
         CHECK(ok, "csa_wt_multi_hip count_batch");
     }
     printf(g_fail ? "adaptor parity: %d FAILED\n" : "adaptor parity: all equal\n", g_fail);

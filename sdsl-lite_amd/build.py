@@ -85,6 +85,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
                                      or os.path.getmtime(tool) < os.path.getmtime(tool_src)):
         _run([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", tool_src, "-o", tool,
               "-Wl,-rpath,/opt/rocm/lib"])
+    # stress client over the C ABI on the SYSTEM HIP runtime (tests/test_gpu_stress_build.py; the Python tests run on the runtime torch ships)
+    st_src = os.path.join(HERE, "..", "tools", "cpp", "group_stress.cpp")
+    st_bin = os.path.join(LIBDIR, "group_stress")
+    if os.path.exists(st_src) and (force or rebuilt or not os.path.exists(st_bin) or os.path.getmtime(st_bin) < os.path.getmtime(st_src)):
+        _run(["g++", "-O2", "-std=c++17", st_src, "-I" + os.path.join(HERE, "..", "include"), "-L" + LIBDIR, "-lsdsl_hip",
+              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-o", st_bin])
     return LIB
 
 

@@ -49,6 +49,8 @@ SIGNATURES = {
     "sdsl_hip_util_mt_checkpoints": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
     "sdsl_hip_util_density_bits": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.c_uint64]),
     "sdsl_hip_util_english_text": (C.c_int32, [_vp, C.c_uint64, C.c_uint64]),
+    "sdsl_hip_util_rnd_positions_device": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, C.c_int32,
+                                                       _vp]),
     "sdsl_hip_group_create": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_group_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_group_size": (C.c_int32, [_vp]),
@@ -67,6 +69,8 @@ SIGNATURES = {
     "sdsl_hip_bv_serialize": (C.c_int32, [_vp, C.c_int32, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sdsl_hip_bv_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_bv_release_scratch": (C.c_int32, [_vp]),
+    "sdsl_hip_bv_reserve_capture_scratch": (C.c_int32, [_vp, C.c_uint64]),
+    "sdsl_hip_rrr_reserve_capture_scratch": (C.c_int32, [_vp, C.c_uint64]),
     "sdsl_hip_device_scratch_bytes": (C.c_uint64, [C.c_int32]),
     "sdsl_hip_bv_query_one": (C.c_int32, [_vp, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "sdsl_hip_bv_size": (C.c_uint64, [_vp]),

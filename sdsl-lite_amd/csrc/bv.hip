@@ -841,32 +841,10 @@ sdsl_hip_status bv_launch_select(const BvView & v, int bit, const uint64_t * d_i
 // not returns at once (SrGeom::go / BvView::skip_if).  Nothing is read back, nothing synchronises: the call stays asynchronous
 // on the caller's stream and can be captured into a graph (once the handle's scratch has its size: the first call allocates).
 
-// the device's scratch pool at the size a pass over `n` queries needs (the caller holds P.m); false: no room (the caller takes
-// the direct kernel)
-static bool bv_ensure_sort_scratch(BvHost & h, DeviceScratch & P, uint64_t n, hipStream_t s, sdsl_hip_status & st)
+static size_t bv_pass_scratch_bytes(const BvHost & h, uint64_t n)
 {
-    st = SDSL_HIP_OK;
     const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
-    const size_t need = bv_sorted_rank_scratch_bytes(h.view, pass);
-    if (P.ev && hipStreamWaitEvent(s, P.ev, 0) != hipSuccess)
-    {
-        st = SDSL_HIP_ERR_HIP;
-        return false;
-    }
-    if (P.buf.bytes < need)
-    {
-        if (P.ev)
-            (void)hipEventSynchronize(P.ev); // the old buffer may still be in use
-        P.buf.release();
-        if (P.buf.alloc(need) != SDSL_HIP_OK)
-            return false;
-    }
-    if (!P.ev && hipEventCreateWithFlags(&P.ev, hipEventDisableTiming) != hipSuccess)
-    {
-        st = SDSL_HIP_ERR_HIP;
-        return false;
-    }
-    return true;
+    return bv_sorted_rank_scratch_bytes(h.view, pass);
 }
 
 sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, uint64_t n, uint64_t * d_out, hipStream_t s)
@@ -889,10 +867,10 @@ sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, ui
                 return bv_launch_rank(h.view, bit, d_idx, n, d_out, s);
         }
         sdsl_hip_status st;
-        DeviceScratch & P = device_scratch(h.device);
-        std::lock_guard<std::mutex> plock(P.m);
-        if (!bv_ensure_sort_scratch(h, P, n, s, st))
-            return st != SDSL_HIP_OK ? st : bv_launch_rank(h.view, bit, d_idx, n, d_out, s); // no room for the scratch: direct kernel
+        ScratchLease L; // (ends — and records the pool's event — when this block is left, on every path)
+        SH_TRY(L.acquire(h.device, h.capture_scratch, bv_pass_scratch_bytes(h, n), s));
+        if (!L.p || (L.capturing && !h.spread_probe.p))
+            return bv_launch_rank(h.view, bit, d_idx, n, d_out, s); // no room for the scratch (or nothing reserved for a capture): direct kernel
         const uint32_t * go = nullptr;
         if (on_device && !h.spread_probe.p)
             SH_TRY(h.spread_probe.alloc(64));
@@ -903,7 +881,7 @@ sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, ui
                 SH_TRY(bv_sorted_rank_sample(h.view, d_idx, n, s, h.spread_probe.as<uint32_t>()));
                 go = h.spread_probe.as<uint32_t>() + 2;
             }
-            st = bv_launch_rank_sorted(h.view, bit, d_idx, n, d_out, s, P.buf.p, P.buf.bytes, go);
+            st = bv_launch_rank_sorted(h.view, bit, d_idx, n, d_out, s, L.p, L.bytes, go);
             if (st == SDSL_HIP_OK && go)
             {
                 TimingPause pause; // (one timer around both routes)
@@ -912,7 +890,6 @@ sdsl_hip_status bv_rank_dispatch(BvHost & h, int bit, const uint64_t * d_idx, ui
                 st = bv_launch_rank(dv, bit, d_idx, n, d_out, s);
             }
         }
-        SH_HIP(hipEventRecord(P.ev, s));
         return st;
     }
     return bv_launch_rank(h.view, bit, d_idx, n, d_out, s);
@@ -925,6 +902,8 @@ sdsl_hip_status bv_select_dispatch(BvHost & h, int bit, const uint64_t * d_i, ui
     if (mode != 0 && n > 0 && h.view.sel[bit] && (mode > 0 || (h.view.n_lines >= (UINT64_C(1) << 22) && n >= 2 * h.view.n_lines)))
     {
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
+        if (stream_is_capturing(s) && (!h.sel_plan[bit].ready || !h.spread_probe.p || !h.capture_scratch.p))
+            return bv_launch_select(h.view, bit, d_i, n, d_out, s); // nothing may be built or allocated during a capture
         SH_TRY(bv_select_sorted_prepare(h, bit)); // first use: the bucket boundaries (one small batch, synchronous)
         bool want = mode > 0 ? h.sel_plan[bit].ok : bv_sorted_select_applicable(h, bit, n);
         const bool on_device = mode < 0 && bv_sorted_device_verdict();
@@ -934,11 +913,12 @@ sdsl_hip_status bv_select_dispatch(BvHost & h, int bit, const uint64_t * d_i, ui
                 SH_TRY(h.spread_probe.alloc(64));
             SH_TRY(bv_sorted_select_is_spread(h, bit, d_i, n, s, h.spread_probe.p, want));
         }
-        sdsl_hip_status st = SDSL_HIP_OK;
-        DeviceScratch & P = device_scratch(h.device);
-        std::lock_guard<std::mutex> plock(P.m);
-        if (want && bv_ensure_sort_scratch(h, P, n, s, st))
+        ScratchLease L;
+        if (want)
+            SH_TRY(L.acquire(h.device, h.capture_scratch, bv_pass_scratch_bytes(h, n), s));
+        if (L.p)
         {
+            sdsl_hip_status st = SDSL_HIP_OK;
             const uint32_t * go = nullptr;
             if (on_device && !h.spread_probe.p)
                 SH_TRY(h.spread_probe.alloc(64));
@@ -949,7 +929,7 @@ sdsl_hip_status bv_select_dispatch(BvHost & h, int bit, const uint64_t * d_i, ui
                     SH_TRY(bv_sorted_select_sample(h, bit, d_i, n, s, h.spread_probe.as<uint32_t>()));
                     go = h.spread_probe.as<uint32_t>() + 2;
                 }
-                st = bv_launch_select_sorted(h, bit, d_i, n, d_out, s, P.buf.p, P.buf.bytes, go);
+                st = bv_launch_select_sorted(h, bit, d_i, n, d_out, s, L.p, L.bytes, go);
                 if (st == SDSL_HIP_OK && go)
                 {
                     TimingPause pause;
@@ -958,11 +938,8 @@ sdsl_hip_status bv_select_dispatch(BvHost & h, int bit, const uint64_t * d_i, ui
                     st = bv_launch_select(dv, bit, d_i, n, d_out, s);
                 }
             }
-            SH_HIP(hipEventRecord(P.ev, s));
             return st;
         }
-        if (st != SDSL_HIP_OK)
-            return st;
     }
     return bv_launch_select(h.view, bit, d_i, n, d_out, s);
 }
@@ -1267,6 +1244,32 @@ sdsl_hip_status sdsl_hip_bv_release_scratch(sdsl_hip_bv_t bv)
     SH_HIP(hipSetDevice(bv->h.device));
     bv->h.spread_probe.release();
     return device_scratch_release(bv->h.device);
+}
+
+sdsl_hip_status sdsl_hip_bv_reserve_capture_scratch(sdsl_hip_bv_t bv, uint64_t max_queries)
+{
+    if (!bv)
+    {
+        set_error("bv_reserve_capture_scratch: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    BvHost & h = bv->h;
+    std::lock_guard<std::mutex> lock(h.scratch_mutex);
+    SH_HIP(hipSetDevice(h.device));
+    if (max_queries == 0)
+    {
+        h.capture_scratch.release();
+        return SDSL_HIP_OK;
+    }
+    const size_t need = bv_pass_scratch_bytes(h, max_queries);
+    if (h.capture_scratch.bytes < need)
+        SH_TRY(h.capture_scratch.alloc(need));
+    if (!h.spread_probe.p)
+        SH_TRY(h.spread_probe.alloc(64));
+    for (int bit = 0; bit < 2; ++bit) // the bucket plans of the select directories the handle has (synchronous, once)
+        if (h.view.sel[bit])
+            SH_TRY(bv_select_sorted_prepare(h, bit));
+    return SDSL_HIP_OK;
 }
 
 uint64_t sdsl_hip_device_scratch_bytes(int32_t device)

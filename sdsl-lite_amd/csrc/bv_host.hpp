@@ -18,6 +18,33 @@ struct DeviceScratch
     hipEvent_t ev = nullptr;
 };
 DeviceScratch & device_scratch(int device); // (common.cpp; never destroyed: the runtime may be gone by the time statics are)
+
+// One large batch's hold on its working memory.
+//  * Outside a stream capture: the device's pool.  The lease holds the pool's mutex while the batch is being enqueued, makes the
+//    stream wait for the previous user's event and RECORDS the event when it ends — on every path, also when a launch failed
+//    half-way (kernels already queued behind the stream may still use the pool).
+//  * While the stream is being captured into a graph: the HANDLE's own capture scratch, reserved beforehand
+//    (sdsl_hip_*_reserve_capture_scratch).  A graph bakes the address in, and its replays are ordered with nothing the library
+//    can see: it must not hold the pool (which moves when it grows and is shared with every other handle on the device), and an
+//    event recorded inside a capture is not one later calls could wait on.  Without a reservation of sufficient size the
+//    lease stays empty and the caller takes the direct kernel (no allocation is legal during a capture).
+struct ScratchLease
+{
+    void * p = nullptr;
+    size_t bytes = 0;
+    bool capturing = false;
+    // SDSL_HIP_OK with p == nullptr: no room (the caller falls back to the direct kernel)
+    sdsl_hip_status acquire(int device, DevBuf & capture_buf, size_t need, hipStream_t s);
+    ~ScratchLease();
+    ScratchLease() = default;
+    ScratchLease(const ScratchLease &) = delete;
+    ScratchLease & operator=(const ScratchLease &) = delete;
+
+private:
+    DeviceScratch * pool = nullptr;
+    std::unique_lock<std::mutex> lock;
+    hipStream_t stream = nullptr;
+};
 void device_scratch_quiesce(int device);            // waits for the pool's last user (before a handle's memory is freed)
 sdsl_hip_status device_scratch_release(int device); // the same, then frees the pool
 
@@ -30,6 +57,7 @@ struct BvHost
     DevBuf sel[2]; // select sample directories
     DevBuf lmask[2], lidx[2], lpos[2]; // sparse stretches of the select directories (BvView::lmask ...)
     DevBuf spread_probe; // two words the spread sample of the automatic dispatch writes (bv_sorted.hip)
+    DevBuf capture_scratch; // working memory of large batches enqueued while the stream is being captured (ScratchLease)
     struct SelPlan // buckets of the bucketed batch select (bv_sorted.hip), built on first use
     {
         bool ready = false, ok = false;
@@ -40,7 +68,7 @@ struct BvHost
     std::mutex scratch_mutex; // the handle's own lazily built state (select plans, added directories, the spread probe)
     size_t device_bytes() const
     { // (without the device's scratch pool: sdsl_hip_device_scratch_bytes)
-        size_t b = lines.bytes + sel[0].bytes + sel[1].bytes + spread_probe.bytes;
+        size_t b = lines.bytes + sel[0].bytes + sel[1].bytes + spread_probe.bytes + capture_scratch.bytes;
         for (int i = 0; i < 2; ++i)
             b += lmask[i].bytes + lidx[i].bytes + lpos[i].bytes + sel_plan[i].bnd.bytes;
         return b;

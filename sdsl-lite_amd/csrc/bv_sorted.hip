@@ -1821,6 +1821,16 @@ sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit)
         P.bnd.release();
         return SDSL_HIP_OK;
     }
+    struct BndGuard // a failure below must not leave a half-made plan's memory behind
+    {
+        DevBuf & b;
+        bool keep = false;
+        ~BndGuard()
+        {
+            if (!keep)
+                b.release();
+        }
+    } bnd_guard{P.bnd};
     hipLaunchKernelGGL(k_sr_bnd_args, dim3((nf + 255) / 256), dim3(256), 0, 0, nf, (unsigned)B, args.as<uint64_t>());
     SH_HIP(hipGetLastError());
     {
@@ -1842,6 +1852,7 @@ sdsl_hip_status bv_select_sorted_prepare(BvHost & h, int bit)
     P.wide_frac = (double)wide / (double)total;
     P.ok = true;
     P.ready = true;
+    bnd_guard.keep = true;
     return SDSL_HIP_OK;
 }
 

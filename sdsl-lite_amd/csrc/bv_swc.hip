@@ -659,7 +659,7 @@ __global__ __launch_bounds__(TT, 6) void k_sw_unpermute_dma(const uint64_t * __r
     __shared__ unsigned hist[kBins], start[kBins], cursor[kBins], delta[kBins];
     __shared__ uint64_t sbase[kBins]; // what makes the answers of bin b absolute (P == 1) / relative to the pass-1 bin (P == 2)
     __shared__ unsigned wsum[kBins / 64];
-    __shared__ unsigned sh_item, sh_unit;
+    __shared__ unsigned sh_item;
     const unsigned t = threadIdx.x, l = t & 15;
     const unsigned wbase = __builtin_amdgcn_readfirstlane(t & ~63u);
     const unsigned bins = 1u << (P == 1 ? g.d1 : g.d2);

@@ -13,6 +13,7 @@ static bool g_timing = false;
 std::atomic<int> g_trace_phases{0};
 std::atomic<int> g_rrr_raw_budget{20}; // permille of the compressed size rrr_vector<63> may spend on raw classes (rrr.hip)
 std::atomic<int> g_select_sorted_mode{getenv("SDSL_HIP_SELECT_SORTED") ? atoi(getenv("SDSL_HIP_SELECT_SORTED")) : -1};
+std::atomic<int> g_wt_select_sorted_mode{getenv("SDSL_HIP_WT_SELECT_SORTED") ? atoi(getenv("SDSL_HIP_WT_SELECT_SORTED")) : -1};
 std::atomic<int> g_rank_sorted_mode{getenv("SDSL_HIP_RANK_SORTED") ? atoi(getenv("SDSL_HIP_RANK_SORTED")) : -1};
 std::atomic<int> g_rrr_sorted_mode{getenv("SDSL_HIP_RRR_SORTED") ? atoi(getenv("SDSL_HIP_RRR_SORTED")) : -1};
 std::atomic<int> g_rrr_format{getenv("SDSL_HIP_RRR_FORMAT") ? atoi(getenv("SDSL_HIP_RRR_FORMAT")) : -1}; // record format of new rrr vectors
@@ -242,6 +243,63 @@ DeviceScratch & device_scratch(int device)
         pools[d] = new DeviceScratch();
     return *pools[d];
 }
+bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return false;
+    }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+sdsl_hip_status ScratchLease::acquire(int device, DevBuf & capture_buf, size_t need, hipStream_t s)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess)
+    {
+        (void)hipGetLastError(); // (the legacy stream of a thread whose other streams are capturing: treated as not capturing)
+        cs = hipStreamCaptureStatusNone;
+    }
+    if (cs != hipStreamCaptureStatusNone)
+    {
+        capturing = true;
+        if (cs == hipStreamCaptureStatusActive && capture_buf.p && capture_buf.bytes >= need)
+        {
+            p = capture_buf.p;
+            bytes = capture_buf.bytes;
+        }
+        return SDSL_HIP_OK;
+    }
+    DeviceScratch & P = device_scratch(device);
+    std::unique_lock<std::mutex> l(P.m);
+    if (P.ev)
+        SH_HIP(hipStreamWaitEvent(s, P.ev, 0));
+    if (P.buf.bytes < need)
+    {
+        if (P.ev)
+            SH_HIP(hipEventSynchronize(P.ev)); // the old buffer may still be in use
+        P.buf.release();
+        if (P.buf.alloc(need) != SDSL_HIP_OK)
+            return SDSL_HIP_OK; // no room: direct kernel
+    }
+    if (!P.ev)
+        SH_HIP(hipEventCreateWithFlags(&P.ev, hipEventDisableTiming));
+    p = P.buf.p;
+    bytes = P.buf.bytes;
+    pool = &P;
+    stream = s;
+    lock = std::move(l);
+    return SDSL_HIP_OK;
+}
+
+ScratchLease::~ScratchLease()
+{
+    if (pool && pool->ev)
+        (void)hipEventRecord(pool->ev, stream); // whatever was enqueued against the pool lies in front of this
+}
+
 void device_scratch_quiesce(int device)
 {
     DeviceScratch & P = device_scratch(device);
@@ -305,6 +363,11 @@ sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value)
     if (name && !strcmp(name, "select_sorted"))
     {
         sdslhip::g_select_sorted_mode.store((int)value);
+        return SDSL_HIP_OK;
+    }
+    if (name && !strcmp(name, "wt_select_sorted"))
+    { // wavelet-tree select of large batches through the bucketed passes (wt_sorted.hip): 0 never, 1 from 4096 queries on, -1 automatic
+        sdslhip::g_wt_select_sorted_mode.store((int)value);
         return SDSL_HIP_OK;
     }
     if (name && !strcmp(name, "rrr_sorted"))

@@ -25,6 +25,7 @@ namespace sdslhip {
 extern std::atomic<int> g_rank_sorted_mode; // sdsl_hip_set_option("rank_sorted", ...)
 extern std::atomic<int> g_rrr_sorted_mode;  // sdsl_hip_set_option("rrr_sorted", ...)
 extern std::atomic<int> g_select_sorted_mode; // sdsl_hip_set_option("select_sorted", ...)
+extern std::atomic<int> g_wt_select_sorted_mode; // sdsl_hip_set_option("wt_select_sorted", ...)
 extern std::atomic<int> g_trace_phases;     // sdsl_hip_set_option("trace_phases", ...)
 void bv_sorted_clear_phases();              // bv_sorted.hip
 extern std::atomic<int> g_rrr_format;       // sdsl_hip_set_option("rrr_format", -1 | 0 | 1)
@@ -62,6 +63,8 @@ sdsl_hip_status hip_fail(hipError_t e, const char * what, const char * file, int
 
 // true if p points into device (or managed) memory
 bool is_device_ptr(const void * p);
+// true while `s` is being captured into a graph (then nothing may be allocated, built or synchronised)
+bool stream_is_capturing(hipStream_t s);
 sdsl_hip_status check_device(int32_t device); // validates index + gfx950, sets the device current
 
 // RAII device allocation (hipMalloc/hipFree on a fixed device)

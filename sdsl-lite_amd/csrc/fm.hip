@@ -792,38 +792,47 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
     const WtHost & w = sdsl_hip_wt_host(fm->wt);
     if (!ival && !offsets && use_jump && w.backend == 0 && fm_fast_applies(fm, m, n_pat))
     { // large batches of fixed-length patterns on the fused layout: k-mer table + flat kernel + text comparison (fm_count2.hip)
+        sdsl_hip_status st;
         {
             KernelTimer t(s);
-            SH_TRY(fm_count_fast(fm, (const uint8_t *)sp.dev, m, n_pat, (uint64_t *)sc.dev, fm_verify_enabled(), s));
+            st = fm_count_fast(fm, (const uint8_t *)sp.dev, m, n_pat, (uint64_t *)sc.dev, fm_verify_enabled(), s);
         }
-        SH_TRY(sc.finish(s));
-        if (sp.host)
-            SH_HIP(hipStreamSynchronize(s));
-        return SDSL_HIP_OK;
+        if (st == SDSL_HIP_OK)
+        {
+            SH_TRY(sc.finish(s));
+            if (sp.host)
+                SH_HIP(hipStreamSynchronize(s));
+            return SDSL_HIP_OK;
+        }
+        if (st != SDSL_HIP_ERR_NOMEM)
+            return st; // (no working memory — also: the stream is being captured — leaves the batch to the lock-step kernel below)
     }
     unsigned grid = grid_for(n_pat, kQPB, 256u * 8u);
     // Large batches are answered in suffix order (see k_fm_keys): one key kernel + one radix sort, no synchronisation
     static const int sort_knob = getenv("SDSL_HIP_FM_SORT") ? atoi(getenv("SDSL_HIP_FM_SORT")) : -1;
     const bool ordered = sort_knob < 0 ? (n_pat >= (UINT64_C(1) << 16) && n_pat < UINT64_C(0xFFFFFFFF)) : sort_knob != 0;
     uint32_t * d_order = nullptr;
-    void * scratch = nullptr;
+    // (keys, order and the sort's working memory: from the device's scratch pool, held until the search is enqueued — bv_host.hpp:
+    // ScratchLease; not the stream-ordered allocator, sa.hip: sort_pairs_u64_u32)
+    static DevBuf no_capture_scratch;
+    ScratchLease lease;
     KernelTimer t(s); // covers key generation + sort + search: the whole cost of the batch
     if (ordered)
     {
+        const size_t kb = (size_t)n_pat * 8, ib = (size_t)n_pat * 4, tb = (sort_pairs_u64_u32_temp_bytes(n_pat, 64u) + 255) & ~(size_t)255;
+        SH_TRY(lease.acquire(fm->device, no_capture_scratch, 2 * kb + 2 * ib + tb + 256, s));
+    }
+    if (ordered && lease.p)
+    {
         const size_t kb = (size_t)n_pat * 8, ib = (size_t)n_pat * 4;
-        SH_HIP(hipMallocAsync(&scratch, 2 * kb + 2 * ib, s));
-        uint64_t * k0 = (uint64_t *)scratch;
+        uint64_t * k0 = (uint64_t *)lease.p;
         uint64_t * k1 = k0 + n_pat;
         uint32_t * i0 = (uint32_t *)(k1 + n_pat);
         uint32_t * i1 = i0 + n_pat;
+        uint8_t * tmp = reinterpret_cast<uint8_t *>(lease.p) + ((2 * kb + 2 * ib + 255) & ~(size_t)255);
         hipLaunchKernelGGL(k_fm_keys, dim3(grid_for(n_pat, 256, 256u * 8u)), dim3(256), 0, s, (const uint8_t *)sp.dev, m,
                            offsets ? (const uint64_t *)so.dev : nullptr, n_pat, k0, i0);
-        sdsl_hip_status st = sort_pairs_u64_u32(k0, k1, i0, i1, n_pat, 64u, s);
-        if (st != SDSL_HIP_OK)
-        {
-            (void)hipFreeAsync(scratch, s);
-            return st;
-        }
+        SH_TRY(sort_pairs_u64_u32(k0, k1, i0, i1, n_pat, 64u, s, tmp, lease.bytes - (size_t)(tmp - reinterpret_cast<uint8_t *>(lease.p))));
         d_order = i1;
     }
     if (w.backend == 1)
@@ -866,8 +875,6 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
             hipLaunchKernelGGL((k_fm_count<false, false, false>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
                                m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
     }
-    if (scratch)
-        (void)hipFreeAsync(scratch, s);
     SH_HIP(hipGetLastError());
     if (ival)
     {

@@ -22,6 +22,7 @@
 // the suffixes that start with it); a k-mer that does not occur has an empty range, i.e. count 0.
 #include <chrono>
 
+#include "bv_host.hpp"
 #include "fm_host.hpp"
 
 namespace sdslhip {
@@ -684,8 +685,16 @@ sdsl_hip_status fm_count_fast(sdsl_hip_fm_s * f, const uint8_t * d_pats, uint32_
     const uint64_t per = std::min(slab, n_pat);
     const WtHost & w = sdsl_hip_wt_host(f->wt);
     const uint64_t n_slabs = (n_pat + per - 1) / per;
-    void * scratch = nullptr; // the slab's records + one chunk counter per slab
-    SH_HIP(hipMallocAsync(&scratch, per * sizeof(FmRec) + n_slabs * 4 + 64, s));
+    // the slab's records + one chunk counter per slab: from the device's scratch pool (bv_host.hpp: ScratchLease — one user at a time,
+    // ordered across streams by the pool's event).  NOT the stream-ordered allocator: two handles answering on two streams of one
+    // device were handed overlapping blocks by hipMallocAsync now and then (the first record of a slab came out as the other
+    // stream's: tools/cpp/group_stress.cpp, 4 rounds in 1500).
+    static DevBuf no_capture_scratch;
+    ScratchLease L;
+    SH_TRY(L.acquire(f->device, no_capture_scratch, per * sizeof(FmRec) + n_slabs * 4 + 64, s));
+    if (!L.p)
+        return SDSL_HIP_ERR_NOMEM; // (the caller falls back to the lock-step kernel)
+    void * scratch = L.p;
     FmRec * recs = reinterpret_cast<FmRec *>(scratch);
     uint32_t * ctr = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(scratch) + per * sizeof(FmRec));
     hipError_t e = hipMemsetAsync(ctr, 0, n_slabs * 4, s);
@@ -728,7 +737,6 @@ sdsl_hip_status fm_count_fast(sdsl_hip_fm_s * f, const uint8_t * d_pats, uint32_
                                f->d_text.as<uint8_t>(), pp, m, cnt, oo);
         e = hipGetLastError();
     }
-    (void)hipFreeAsync(scratch, s);
     SH_HIP(e);
     return SDSL_HIP_OK;
 }

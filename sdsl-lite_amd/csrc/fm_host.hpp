@@ -81,8 +81,9 @@ sdsl_hip_status fm_build_deep_default(sdsl_hip_fm_s * f);
 bool fm_fast_applies(const sdsl_hip_fm_s * f, uint32_t m, uint64_t n_pat);
 sdsl_hip_status fm_count_fast(sdsl_hip_fm_s * f, const uint8_t * d_pats, uint32_t m, uint64_t n_pat, uint64_t * d_out, bool verify,
                               hipStream_t s);
+size_t sort_pairs_u64_u32_temp_bytes(uint64_t n, unsigned end_bit);
 sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint32_t * vals_in, uint32_t * vals_out,
-                                   uint64_t n, unsigned end_bit, hipStream_t s);
+                                   uint64_t n, unsigned end_bit, hipStream_t s, void * tmp = nullptr, size_t tmp_bytes = 0);
 // out[i] = in[0] + ... + in[i-1] (n entries), stream-ordered
 sdsl_hip_status exclusive_scan_u64(const uint64_t * in, uint64_t * out, uint64_t n, hipStream_t s);
 

@@ -1252,6 +1252,32 @@ sdsl_hip_status sdsl_hip_rrr_destroy(sdsl_hip_rrr_t v)
     delete v;
     return SDSL_HIP_OK;
 }
+sdsl_hip_status sdsl_hip_rrr_reserve_capture_scratch(sdsl_hip_rrr_t v, uint64_t max_queries)
+{
+    if (!v)
+    {
+        set_error("rrr_reserve_capture_scratch: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    RrrHost & h = v->h;
+    std::lock_guard<std::mutex> lock(h.scratch_mutex);
+    SH_HIP(hipSetDevice(h.device));
+    if (max_queries == 0)
+    {
+        h.capture_scratch.release();
+        return SDSL_HIP_OK;
+    }
+    const uint64_t pass = max_queries < (UINT64_C(1) << 30) ? max_queries : (UINT64_C(1) << 30);
+    const size_t need = bv_swc_scratch_bytes(BvView{}, pass);
+    if (h.capture_scratch.bytes < need)
+        SH_TRY(h.capture_scratch.alloc(need));
+    if (!h.spread_probe.p)
+        SH_TRY(h.spread_probe.alloc(64));
+    for (int bit = 0; bit < 2; ++bit)
+        if (h.view.sel[bit])
+            SH_TRY(rrr_select_sorted_prepare(h, bit));
+    return SDSL_HIP_OK;
+}
 uint64_t sdsl_hip_rrr_size(sdsl_hip_rrr_t v)
 {
     return v ? v->h.view.n_bits : 0;
@@ -1344,26 +1370,14 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
     if (want)
     {
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
-        DeviceScratch & P = device_scratch(h.device);
-        std::lock_guard<std::mutex> plock(P.m);
         const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
-        const size_t need = bv_swc_scratch_bytes(BvView{}, pass);
-        if (P.ev)
-            SH_HIP(hipStreamWaitEvent(s, P.ev, 0));
-        bool have = P.buf.bytes >= need;
-        if (!have)
-        {
-            if (P.ev)
-                SH_HIP(hipEventSynchronize(P.ev));
-            P.buf.release();
-            have = P.buf.alloc(need) == SDSL_HIP_OK;
-        }
+        ScratchLease L; // (ends — and records the pool's event — when this block is left, on every path)
+        SH_TRY(L.acquire(h.device, h.capture_scratch, bv_swc_scratch_bytes(BvView{}, pass), s));
+        bool have = L.p != nullptr;
         if (have && !h.spread_probe.p)
-            have = h.spread_probe.alloc(64) == SDSL_HIP_OK;
+            have = !L.capturing && h.spread_probe.alloc(64) == SDSL_HIP_OK;
         if (have)
         {
-            if (!P.ev)
-                SH_HIP(hipEventCreateWithFlags(&P.ev, hipEventDisableTiming));
             sdsl_hip_status st;
             {
                 KernelTimer t(s);
@@ -1373,7 +1387,7 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
                     rrr_sorted_rank_sample(h.view, (const uint64_t *)in.dev, n, s, h.spread_probe.as<uint32_t>());
                     go = h.spread_probe.as<uint32_t>() + 2;
                 }
-                st = rrr_launch_rank_sorted(h.view, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s, P.buf.p, P.buf.bytes, go);
+                st = rrr_launch_rank_sorted(h.view, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s, L.p, L.bytes, go);
                 if (st == SDSL_HIP_OK && go)
                 {
                     RrrView dv = h.view;
@@ -1381,7 +1395,6 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
                     rrr_launch_rank_direct(dv, 0, bit, (const uint64_t *)in.dev, (uint64_t *)o.dev, nullptr, n, s);
                 }
             }
-            SH_HIP(hipEventRecord(P.ev, s));
             SH_TRY(st);
             SH_HIP(hipGetLastError());
             SH_TRY(o.finish(s));
@@ -1504,31 +1517,22 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
     if (mode != 0 && h.view.sel[bit] && (mode > 0 || (h.view.n_sb >= (UINT64_C(1) << 21) && n >= 8 * h.view.n_sb)))
     {
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
-        DeviceScratch & P = device_scratch(h.device);
-        std::lock_guard<std::mutex> plock(P.m);
-        SH_TRY(rrr_select_sorted_prepare(h, bit)); // first use: the bucket boundaries (one small batch, synchronous)
-        const bool want = mode > 0 ? h.sel_plan[bit].ok : rrr_sorted_select_applicable(h, bit, n);
+        const bool cap = stream_is_capturing(s); // (nothing may be built or allocated then)
+        bool have = !cap || (h.sel_plan[bit].ready && h.spread_probe.p && h.capture_scratch.p);
+        if (have)
+            SH_TRY(rrr_select_sorted_prepare(h, bit)); // first use: the bucket boundaries (one small batch, synchronous)
+        have = have && (mode > 0 ? h.sel_plan[bit].ok : rrr_sorted_select_applicable(h, bit, n));
         const uint64_t pass = n < (UINT64_C(1) << 30) ? n : (UINT64_C(1) << 30);
-        const size_t need = bv_swc_scratch_bytes(BvView{}, pass);
-        bool have = want;
+        ScratchLease L;
         if (have)
         {
-            if (P.ev)
-                SH_HIP(hipStreamWaitEvent(s, P.ev, 0));
-            if (P.buf.bytes < need)
-            {
-                if (P.ev)
-                    SH_HIP(hipEventSynchronize(P.ev));
-                P.buf.release();
-                have = P.buf.alloc(need) == SDSL_HIP_OK;
-            }
+            SH_TRY(L.acquire(h.device, h.capture_scratch, bv_swc_scratch_bytes(BvView{}, pass), s));
+            have = L.p != nullptr;
             if (have && !h.spread_probe.p)
-                have = h.spread_probe.alloc(64) == SDSL_HIP_OK;
+                have = !L.capturing && h.spread_probe.alloc(64) == SDSL_HIP_OK;
         }
         if (have)
         {
-            if (!P.ev)
-                SH_HIP(hipEventCreateWithFlags(&P.ev, hipEventDisableTiming));
             sdsl_hip_status st;
             {
                 KernelTimer t(s);
@@ -1538,7 +1542,7 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
                     rrr_sorted_select_sample(h, bit, (const uint64_t *)in.dev, n, s, h.spread_probe.as<uint32_t>());
                     go = h.spread_probe.as<uint32_t>() + 2;
                 }
-                st = rrr_launch_select_sorted(h, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s, P.buf.p, P.buf.bytes, go);
+                st = rrr_launch_select_sorted(h, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s, L.p, L.bytes, go);
                 if (st == SDSL_HIP_OK && go)
                 {
                     TimingPause pause;
@@ -1547,7 +1551,6 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
                     st = rrr_launch_select(dv, bit, (const uint64_t *)in.dev, n, (uint64_t *)o.dev, s);
                 }
             }
-            SH_HIP(hipEventRecord(P.ev, s));
             SH_TRY(st);
             SH_HIP(hipGetLastError());
             SH_TRY(o.finish(s));

@@ -16,6 +16,7 @@ struct RrrHost
     unsigned fmt = 0;         // record format (rrr_device.hpp: RrrFmtW / RrrFmtS); the vectors of a wavelet tree are always wide
     bool allow_slim = false;  // set by the stand-alone handle before the vector is built
     DevBuf spread_probe; // the verdict of the spread sample (rrr_sorted.hip); the passes' working memory is the device's pool (bv_host.hpp)
+    DevBuf capture_scratch; // working memory of large batches enqueued while the stream is being captured (ScratchLease)
     struct SelPlan // buckets of the bucketed batch select (rrr_sorted.hip), built on first use
     {
         bool ready = false, ok = false;
@@ -26,7 +27,7 @@ struct RrrHost
     std::mutex scratch_mutex;
     size_t device_bytes() const
     {
-        return rec.bytes + stream.bytes + tables.bytes + sel[0].bytes + sel[1].bytes + spread_probe.bytes;
+        return rec.bytes + stream.bytes + tables.bytes + sel[0].bytes + sel[1].bytes + spread_probe.bytes + capture_scratch.bytes;
     }
 };
 // large batches, bucketed by slice of the record array (rrr_sorted.hip)

@@ -672,6 +672,16 @@ sdsl_hip_status rrr_select_sorted_prepare(RrrHost & h, int bit)
         P.bnd.release();
         return SDSL_HIP_OK; // (no room right now: the query takes the direct kernel, the plan is tried again next time)
     }
+    struct BndGuard // a failure below must not leave a half-made plan's memory behind
+    {
+        DevBuf & b;
+        bool keep = false;
+        ~BndGuard()
+        {
+            if (!keep)
+                b.release();
+        }
+    } bnd_guard{P.bnd};
     hipLaunchKernelGGL(k_rs_bnd_args, dim3((nf + 255) / 256), dim3(256), 0, 0, nf, (unsigned)B, args.as<uint64_t>());
     SH_HIP(hipGetLastError());
     {
@@ -692,6 +702,7 @@ sdsl_hip_status rrr_select_sorted_prepare(RrrHost & h, int bit)
     P.wide_frac = (double)wide / (double)total;
     P.ok = true;
     P.ready = true;
+    bnd_guard.keep = true;
     return SDSL_HIP_OK;
 }
 

@@ -106,11 +106,10 @@ sdsl_hip_status exclusive_scan_u64(const uint64_t * in, uint64_t * out, uint64_t
         return SDSL_HIP_OK;
     size_t bytes = 0;
     SH_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s));
-    void * tmp = nullptr;
-    SH_HIP(hipMallocAsync(&tmp, bytes ? bytes : 16, s));
-    hipError_t e = rocprim::exclusive_scan(tmp, bytes, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s);
-    (void)hipFreeAsync(tmp, s);
-    SH_HIP(e);
+    DevBuf tmp; // (plain hipMalloc / hipFree — see sort_pairs_u64_u32)
+    SH_TRY(tmp.alloc(bytes ? bytes : 16));
+    SH_HIP(rocprim::exclusive_scan(tmp.p, bytes, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s));
+    SH_HIP(hipStreamSynchronize(s)); // (tmp is freed on return)
     return SDSL_HIP_OK;
 }
 
@@ -144,32 +143,71 @@ __global__ void k_sa_bwt(const uint8_t * __restrict__ s, const uint32_t * __rest
     }
 }
 
-// Stream-ordered sort of (u64 key, u32 value) pairs, used by fm.hip to order a pattern batch.  Scratch comes from
-// the stream-ordered allocator so that the call neither synchronises nor keeps state in the handle.
+// Sort of (u64 key, u32 value) pairs, used by fm.hip to order a pattern batch.  The working memory is the caller's (`tmp`, at
+// least sort_pairs_u64_u32_temp_bytes(n, end_bit) bytes: the query path takes it from the device's scratch pool) or, with
+// tmp == nullptr, a plain allocation that is freed — and the stream synchronised — before the call returns.
+// NOT hipMallocAsync / hipFreeAsync: on the ROCm 7.2 runtime a loop of index builds through these helpers hung inside the level
+// sort once in a few thousand builds, died with a GPU memory fault now and then and left wrong tables behind
+// (tools/cpp/group_stress.cpp, phase D) — none of it since the stream-ordered allocator is out of the library.
+size_t sort_pairs_u64_u32_temp_bytes(uint64_t n, unsigned end_bit)
+{
+    size_t bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0u,
+                                  end_bit) != hipSuccess)
+        return 0;
+    return bytes ? bytes : 16;
+}
 sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint32_t * vals_in, uint32_t * vals_out,
-                                   uint64_t n, unsigned end_bit, hipStream_t s)
+                                   uint64_t n, unsigned end_bit, hipStream_t s, void * tmp, size_t tmp_bytes)
 {
     size_t bytes = 0;
     SH_HIP(rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, s));
-    void * tmp = nullptr;
-    SH_HIP(hipMallocAsync(&tmp, bytes ? bytes : 16, s));
-    hipError_t e = rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, s);
-    (void)hipFreeAsync(tmp, s);
-    SH_HIP(e);
+    DevBuf own;
+    if (!tmp)
+    {
+        SH_TRY(own.alloc(bytes ? bytes : 16));
+        tmp = own.p;
+        tmp_bytes = own.bytes;
+    }
+    if (tmp_bytes < bytes)
+    {
+        set_error("sort_pairs: working memory too small");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_HIP(rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, end_bit, s));
+    if (own.p)
+        SH_HIP(hipStreamSynchronize(s));
     return SDSL_HIP_OK;
 }
 
-// Stable sort of u16 keys by the bit range [begin_bit, end_bit) only (wt.hip: one wavelet-tree level)
+// Stable sort of u16 keys by the bit range [begin_bit, end_bit) only (wt.hip: one wavelet-tree level); working memory as above
+size_t sort_keys_u16_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit)
+{
+    size_t bytes = 0;
+    if (rocprim::radix_sort_keys(nullptr, bytes, (uint16_t *)nullptr, (uint16_t *)nullptr, (size_t)n, begin_bit, end_bit) != hipSuccess)
+        return 0;
+    return bytes ? bytes : 16;
+}
 sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
-                              hipStream_t s)
+                              hipStream_t s, void * tmp, size_t tmp_bytes)
 {
     size_t bytes = 0;
     SH_HIP(rocprim::radix_sort_keys(nullptr, bytes, keys_in, keys_out, (size_t)n, begin_bit, end_bit, s));
-    void * tmp = nullptr;
-    SH_HIP(hipMallocAsync(&tmp, bytes ? bytes : 16, s));
-    hipError_t e = rocprim::radix_sort_keys(tmp, bytes, keys_in, keys_out, (size_t)n, begin_bit, end_bit, s);
-    (void)hipFreeAsync(tmp, s);
-    SH_HIP(e);
+    DevBuf own;
+    if (!tmp)
+    {
+        SH_TRY(own.alloc(bytes ? bytes : 16));
+        tmp = own.p;
+        tmp_bytes = own.bytes;
+    }
+    if (tmp_bytes < bytes)
+    {
+        set_error("sort_keys: working memory too small");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_HIP(rocprim::radix_sort_keys(tmp, bytes, keys_in, keys_out, (size_t)n, begin_bit, end_bit, s));
+    if (own.p)
+        SH_HIP(hipStreamSynchronize(s));
     return SDSL_HIP_OK;
 }
 

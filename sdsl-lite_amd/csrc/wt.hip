@@ -452,8 +452,9 @@ __global__ void k_wt_node_positions(const WtTables * __restrict__ T, uint32_t n_
         pos[v] = T->bv_pos[v];
 }
 
+size_t sort_keys_u16_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit);
 sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
-                              hipStream_t s);
+                              hipStream_t s, void * tmp, size_t tmp_bytes);
 
 sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t flags)
 {
@@ -482,15 +483,25 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
                        (flags & kWtShapeHuff8) ? 3u : ((flags & SDSL_HIP_WT_BLCD) ? 1u : ((flags & SDSL_HIP_WT_HUTU) ? 2u : 0u)),
                        wt.tables, wt.n_nodes, bv_size, wt.sigma));
     WtTables & T = wt.tables;
+    const bool tr_b = getenv("SDSL_HIP_TRACE_BUILD") != nullptr;
+    auto mark_b = [&](const char * what, unsigned d) {
+        if (tr_b)
+        {
+            const hipError_t e = hipDeviceSynchronize();
+            fprintf(stderr, "[sdsl_hip] wt build: %s %u (%s)\n", what, d, hipGetErrorString(e));
+        }
+    };
+    mark_b("shape, nodes", wt.n_nodes);
     // 3. bits, level by level
     const uint64_t nw = (bv_size + 63) >> 6;
     DevBuf d_words;
     SH_TRY(d_words.alloc((nw + 2) * 8, true));
     if (bv_size)
     {
-        DevBuf k0, k1;
+        DevBuf k0, k1, sort_tmp; // (the sort's working memory: one plain allocation for all levels, sa.hip: sort_pairs_u64_u32)
         SH_TRY(k0.alloc(n * 2));
         SH_TRY(k1.alloc(n * 2));
+        SH_TRY(sort_tmp.alloc(sort_keys_u16_temp_bytes(n, 1u, 10u)));
         uint64_t level_start = 0;
         for (unsigned d = 0; d < 57; ++d)
         {
@@ -516,10 +527,13 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
             hipLaunchKernelGGL(k_wt_level_keys, dim3(grid_for(n, 256 * 8, 256u * 8u)), dim3(256), 0, 0, d_text, n, tab,
                                k0.as<uint16_t>());
             SH_HIP(hipGetLastError());
-            SH_TRY(sort_keys_u16(k0.as<uint16_t>(), k1.as<uint16_t>(), n, 1u, 10u, nullptr)); // dead keys sort last
+            mark_b("level keys", d);
+            SH_TRY(sort_keys_u16(k0.as<uint16_t>(), k1.as<uint16_t>(), n, 1u, 10u, nullptr, sort_tmp.p, sort_tmp.bytes)); // dead keys sort last
+            mark_b("level sorted", d);
             hipLaunchKernelGGL(k_wt_pack_level, dim3(grid_for((alive + 63) >> 6, 256, 256u * 8u)), dim3(256), 0, 0,
                                k1.as<uint16_t>(), alive, level_start, d_words.as<unsigned long long>());
             SH_HIP(hipGetLastError());
+            mark_b("level packed", d);
             level_start += alive;
         }
         if (level_start != bv_size)
@@ -534,6 +548,7 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
     SH_TRY(bv_build_from_device_words(wt.bv, d_words.as<uint64_t>(), bv_size,
                                       (flags & kWtNoSelect) ? 0u : (SDSL_HIP_BV_SELECT1 | SDSL_HIP_BV_SELECT0),
                                       default_sel_shift()));
+    mark_b("rank lines built, bits", (unsigned)bv_size);
     // 5. bv_pos_rank of the inner nodes = rank_1 at the start of their slices (wt_helper.hpp:320-327)
     SH_TRY(wt.d_tables.alloc(sizeof(WtTables)));
     SH_HIP(hipMemcpy(wt.d_tables.p, &T, sizeof(WtTables), hipMemcpyHostToDevice));
@@ -1337,14 +1352,25 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         DevBuf d_sym;
         WtHost own;
         sdsl_hip_status st = d_sym.alloc(wt.size);
+        const bool tr = getenv("SDSL_HIP_TRACE_BUILD") != nullptr;
+        auto mark = [&](const char * what) {
+            if (tr)
+            {
+                const hipError_t e = hipDeviceSynchronize();
+                fprintf(stderr, "[sdsl_hip] fused build: %s (%s)\n", what, hipGetErrorString(e));
+            }
+        };
         if (st == SDSL_HIP_OK)
         {
             hipLaunchKernelGGL(k_wt_export_symbols, dim3(grid_for(wt.size, kQPB, 256u * 16u)), dim3(kBlock), 0, 0,
                                wt.view_binary(), d_sym.as<uint8_t>(), wt.size);
+            mark("symbols exported");
             st = wt_build_from_device_text(own, d_sym.as<uint8_t>(), wt.size, wt.device, kWtShapeHuff8 | kWtNoSelect);
+            mark("own-shape tree built");
         }
         if (st == SDSL_HIP_OK)
             st = fused_from(own, wt);
+        mark("fused layout derived");
         if (st == SDSL_HIP_OK && wt.d_fused.p)
         {
             wt.d_tables_f = std::move(own.d_tables);
@@ -1756,16 +1782,34 @@ sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, c
                                     (uint64_t *)so.dev, s));
     else
     {
-        KernelTimer t(s);
         const WtView view = wt->h.view();
-        if (view.f_lines && view.f_sel)
-            hipLaunchKernelGGL((k_wt_select_fused<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, view,
-                               wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev, (const uint8_t *)sc.dev,
-                               (uint64_t *)so.dev, n);
-        else // SDSL's tree and its binary levels
-            hipLaunchKernelGGL((k_wt_select<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s,
-                               wt->h.view_binary(), wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev,
-                               (const uint8_t *)sc.dev, (uint64_t *)so.dev, n);
+        bool done = false;
+        if (view.f_lines && view.f_sel && wt_select_sorted_applicable(wt->h, n))
+        { // a large batch: ordered by place in symbol order, answered bucket by bucket (wt_sorted.hip); working memory from the
+          // device's pool — none during a stream capture (ScratchLease), then the direct kernel below answers
+            static DevBuf no_capture_scratch;
+            ScratchLease L;
+            SH_TRY(L.acquire(wt->h.device, no_capture_scratch, wt_select_sorted_scratch_bytes(n), s));
+            if (L.p)
+            {
+                KernelTimer t(s);
+                SH_TRY(wt_launch_select_sorted(wt->h, wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev, (const uint8_t *)sc.dev, n,
+                                               (uint64_t *)so.dev, s, L.p, L.bytes));
+                done = true;
+            }
+        }
+        if (!done)
+        {
+            KernelTimer t(s);
+            if (view.f_lines && view.f_sel)
+                hipLaunchKernelGGL((k_wt_select_fused<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, view,
+                                   wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev, (const uint8_t *)sc.dev,
+                                   (uint64_t *)so.dev, n);
+            else // SDSL's tree and its binary levels
+                hipLaunchKernelGGL((k_wt_select<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s,
+                                   wt->h.view_binary(), wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev,
+                                   (const uint8_t *)sc.dev, (uint64_t *)so.dev, n);
+        }
     }
     SH_HIP(hipGetLastError());
     SH_TRY(so.finish(s));

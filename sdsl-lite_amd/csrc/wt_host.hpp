@@ -83,6 +83,12 @@ sdsl_hip_status wt_rrr_launch_select(const WtHost & wt, const uint64_t * d_occ, 
 sdsl_hip_status wt_rrr_launch_inverse_select(const WtHost & wt, const uint64_t * d_i, uint64_t n, uint64_t * d_rank,
                                              uint8_t * d_c, hipStream_t s);
 
+// select of a large batch, bucketed by the argument's place in symbol order (wt_sorted.hip)
+bool wt_select_sorted_applicable(const WtHost & wt, uint64_t n);
+size_t wt_select_sorted_scratch_bytes(uint64_t n);
+sdsl_hip_status wt_launch_select_sorted(const WtHost & wt, const uint64_t * d_occ, const uint64_t * d_i, const uint8_t * d_c, uint64_t n,
+                                        uint64_t * d_out, hipStream_t s, void * scratch, size_t scratch_bytes);
+
 sdsl_hip_status wt_launch_rank(const WtHost & wt, const uint64_t * d_i, const uint8_t * d_c, uint64_t n,
                                uint64_t * d_out, hipStream_t s);
 

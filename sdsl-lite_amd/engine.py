@@ -145,6 +145,11 @@ class bit_vector(_Handle):
         """Frees the working memory the bucketed batch rank keeps with the handle."""
         capi.check(capi.lib().sdsl_hip_bv_release_scratch(self._h))
 
+    def reserve_capture_scratch(self, max_queries: int):
+        """Working memory, owned by this handle, for large batches enqueued while their stream is being captured into a
+        graph (sdsl_hip.h: stream capture); 0 releases it."""
+        capi.check(capi.lib().sdsl_hip_bv_reserve_capture_scratch(self._h, max_queries))
+
     def rank(self, idx, bit: int = 1, out=None):
         idx = _as_array(idx, np.uint64, "idx")
         n = idx.numel() if _is_tensor(idx) else idx.size
@@ -275,6 +280,18 @@ def mt_checkpoints(seed: int, stride: int, n: int) -> np.ndarray:
     return out
 
 
+def rnd_positions_device(seed: int, count: int, mod: int = 0, add: int = 0, device: int = 0, stride: int = 1 << 20):
+    """rnd_positions, written straight into device memory (int64 tensor): the host only walks the generator once to save its
+    state every `stride` draws (a few MB); the device regenerates the stream from those checkpoints."""
+    out = torch.empty(count, dtype=torch.int64, device=torch.device("cuda", device))
+    if count:
+        n_ck = (count + stride - 1) // stride
+        ck = mt_checkpoints(seed, stride, n_ck)
+        capi.check(capi.lib().sdsl_hip_util_rnd_positions_device(_ptr(ck), n_ck, stride, count, mod, add, _ptr(out), device,
+                                                                 torch.cuda.current_stream(out.device).cuda_stream))
+    return out
+
+
 def density_bits(n_bits: int, seed: int, percent: int, checkpoints: np.ndarray | None = None, stride: int = 0) -> np.ndarray:
     """bit i = (i-th draw of mt19937_64(seed) % 100 < percent): the configs[2] vector, as uint64 words."""
     w = np.zeros((n_bits + 63) // 64, dtype=np.uint64)
@@ -320,6 +337,9 @@ class rrr_vector(_Handle):
                 raise ValueError(f"words too short for n_bits: {nw} words < ceil({n_bits} / 64)")
             capi.check(capi.lib().sdsl_hip_rrr_create(_ptr(w) if nw else None, n_bits, device, C.byref(self._h)))
         self.device = device
+
+    def reserve_capture_scratch(self, max_queries: int):
+        capi.check(capi.lib().sdsl_hip_rrr_reserve_capture_scratch(self._h, max_queries))
 
     def size(self) -> int:
         return capi.lib().sdsl_hip_rrr_size(self._h)

@@ -66,3 +66,34 @@ def test_two_ranks_sharded_fm_count(gpu):
     ro = d["extras"]["rank_root_owned_batch"]
     assert ro["queries"] == 2 * 2000000 and ro["matches_local"] is True and ro["Grank/s"] > 0
 
+
+
+def test_device_generator_equals_the_host_generator(gpu):
+    """bench.py draws its vector and its positions on the device from generator checkpoints (workload_dev.hip): the same
+    numbers as the host's mt19937_64 walk, for every way a stretch can start and end"""
+    import numpy as np
+    for seed, count, mod, add, stride in ((42, 100_003, 0, 0, 1 << 10), (7, 1_000_000, (1 << 34) + 1, 0, 312 * 64), (11, 5, 1000, 1, 1 << 20),
+                                          (9, 312 * 5, 100, 0, 312), (13, 70_001, (1 << 30) + 2, 3, 77_777), (5, 313, 0, 9, 100)):
+        want = gpu.rnd_positions(seed, count, mod, add)
+        got = gpu.rnd_positions_device(seed, count, mod, add, 0, stride).cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, want), (seed, count, mod, add, stride)
+
+
+def test_eight_ranks_on_one_gpu(gpu):
+    """the launch the driver makes on an 8-GPU node, with all eight ranks sharing the test box's GPU (gloo for the control
+    plane): eight replicas of the 2^34-bit index (2.45 GB each), every rank's positions drawn on the device, the root-owned batch
+    and the sharded count() of configs[4] — inside five minutes"""
+    import time
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--log-n", "34",
+                        "--queries", "2e7", "--text-mib", "64", "--backend", "gloo"], capture_output=True, text=True, timeout=900, env=env)
+    took = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["reference_digest_match"] is True
+    assert "error" not in d["extras"], d["extras"]
+    fs = d["extras"]["fm_count_sharded"]
+    assert fs["resident_shards"]["all_patterns_found"] is True and fs["root_owned_batch_matches"] is True
+    assert d["extras"]["rank_root_owned_batch"]["matches_local"] is True
+    assert took < 300, f"{took:.0f} s"

@@ -1,6 +1,10 @@
 """The default dispatch of a large batch is asynchronous and capturable: the spread sample's verdict stays
 on the device, both routes are enqueued and the one whose turn it is not returns at once.  One captured graph is replayed on a
-spread batch (bucketed route) and on a windowed one (direct route) in the same buffers; both must answer like the direct kernel."""
+spread batch (bucketed route) and on a windowed one (direct route) in the same buffers; both must answer like the direct kernel.
+
+A captured batch never works in the device's shared scratch pool: it uses the handle's own capture scratch
+(reserve_capture_scratch), so a replay may overlap other handles' large batches, survive the pool growing and being released;
+without a reservation the captured batch takes the direct kernel."""
 import numpy as np
 import pytest
 
@@ -23,7 +27,10 @@ def test_rank_and_select_in_default_mode_capture_into_a_graph(gpu):
     sout = torch.empty_like(sel)
     gpu.set_option("rank_sorted", -1)
     gpu.set_option("select_sorted", -1)
-    # warm-up outside the capture: the handle's scratch gets its size, the select plan is built
+    # before the capture: the handle's capture scratch gets its size, the select plans are built
+    before = bv.device_bytes()
+    bv.reserve_capture_scratch(nq)
+    assert bv.device_bytes() >= before + 12 * nq, "the capture scratch belongs to the handle"
     bv.rank(idx, 1, out)
     bv.select(sel, 1, sout)
     torch.cuda.synchronize()
@@ -69,4 +76,71 @@ def test_rank_and_select_in_default_mode_capture_into_a_graph(gpu):
     bv.rank(idx, 1, out)
     assert not gpu.last_phases(), "a windowed batch went through the passes"
     gpu.set_option("trace_phases", 0)
+    # 3: replays overlap another handle's large batches on another stream, the pool grows and is released in between
+    words2 = torch.randint(-2**63, 2**63 - 1, ((n_bits + 63) // 64,), device=dev, dtype=torch.int64, generator=g)
+    bv2 = gpu.bit_vector(words2, n_bits)
+    del words2
+    idx2 = torch.randint(0, n_bits + 1, (2 * nq,), device=dev, dtype=torch.int64, generator=g)  # a larger batch: the pool grows
+    out2 = torch.empty_like(idx2)
+    gpu.set_option("rank_sorted", 0)
+    want2 = bv2.rank(idx2, 1).clone()
+    gpu.set_option("rank_sorted", -1)
+    idx.copy_(torch.randint(0, n_bits + 1, (nq,), device=dev, dtype=torch.int64, generator=g))
+    sel.copy_(torch.randint(1, ones + 1, (nq,), device=dev, dtype=torch.int64, generator=g))
+    want_r, want_s = direct()
+    side = torch.cuda.Stream()
+    for round_ in range(4):
+        out.fill_(-7)
+        sout.fill_(-7)
+        out2.fill_(-7)
+        torch.cuda.synchronize()
+        graph.replay()
+        with torch.cuda.stream(side):
+            bv2.rank(idx2, 1, out2)
+            bv2.rank(idx2, 1, out2)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want_r) and torch.equal(sout, want_s), f"round {round_}: a replay that overlapped another batch"
+        assert torch.equal(out2, want2), f"round {round_}: the other handle's batch"
+        if round_ == 1:
+            bv2.release_scratch()  # the pool goes; the graph does not hold it
+    bv2.close()
+    bv.reserve_capture_scratch(0)
     bv.release_scratch()
+
+
+def test_a_captured_batch_without_a_reservation_takes_the_direct_kernel(gpu):
+    import torch
+    dev = torch.device("cuda:0")
+    n_bits = 448 * (1 << 22) + 999
+    g = torch.Generator(device=dev).manual_seed(9)
+    words = torch.randint(-2**63, 2**63 - 1, ((n_bits + 63) // 64,), device=dev, dtype=torch.int64, generator=g)
+    bv = gpu.bit_vector(words, n_bits)
+    rv = gpu.rrr_vector(words, n_bits)
+    del words
+    nq = 9_000_000
+    idx = torch.randint(0, n_bits + 1, (nq,), device=dev, dtype=torch.int64, generator=g)
+    sel = torch.randint(1, bv.ones() + 1, (nq,), device=dev, dtype=torch.int64, generator=g)
+    out, sout, rout = torch.empty_like(idx), torch.empty_like(sel), torch.empty_like(idx)
+    for opt in ("rank_sorted", "select_sorted", "rrr_sorted"):
+        gpu.set_option(opt, 1)  # "whenever possible": outside a capture these batches take the passes
+    try:
+        bv.rank(idx, 1, out)      # (the pool exists and has its size: a capture must still not use it)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            bv.rank(idx, 1, out)
+            bv.select(sel, 1, sout)
+            rv.rank(idx, 1, rout)
+        bv.release_scratch()      # the pool goes before the first replay
+        out.fill_(-7); sout.fill_(-7); rout.fill_(-7)
+        graph.replay()
+        torch.cuda.synchronize()
+    finally:
+        for opt in ("rank_sorted", "select_sorted", "rrr_sorted"):
+            gpu.set_option(opt, 0)
+    assert torch.equal(out, bv.rank(idx, 1)) and torch.equal(sout, bv.select(sel, 1)) and torch.equal(rout, rv.rank(idx, 1))
+    for opt in ("rank_sorted", "select_sorted", "rrr_sorted"):
+        gpu.set_option(opt, -1)
+    bv.close()
+    rv.close()

@@ -1,37 +1,24 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + PMC passes of the bench command.
-# Outputs land in gpurun_out/prof_$TAG/ ; tools/summarize_profiles.py turns them into profiles/*.
-TAG=${1:-r01}
-Q=${2:-1000000000}
-export TMPDIR=/tmp
+# Runs ON the GPU box (via gpurun): every profile the round commits, through ONE recipe (tools/prof.sh: a kernel trace and four
+# PMC passes per command).  tools/pmc_json.py + tools/prof_summary.py turn gpurun_out/prof_*/ into profiles/.
+# usage: tools/collect_profiles.sh [what ...]    what = bench fm rrr wt full (default: all)
 R=$PWD
-O=$R/gpurun_out/prof_$TAG
-mkdir -p $O
-cd /tmp
-BENCH="python $R/bench.py --steps 5 --warmup 1 --extras select --no-cpu --queries $Q"
-# the trace of the headline command has no extras, so that every k_rank launch in it is a full step and the
-# --stats average can be compared directly with bench.py's own HIP-event figure (roofline.kernel_ms)
-rocprofv3 --kernel-trace --stats -d $O/trace -o bench --output-format csv -- python $R/bench.py --steps 5 --warmup 1 --extras none --no-cpu --queries $Q > $O/bench_trace.log 2>&1
-echo "trace exit=$?"
-rocprofv3 --kernel-trace --stats -d $O/trace_select -o bench --output-format csv -- $BENCH > $O/bench_trace_select.log 2>&1
-echo "trace_select exit=$?"
-# PMC passes: counters only (no trace domains), separate runs per counter group (TCC has 4 slots)
-rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $O/pmc_rd -o bench --output-format csv -- $BENCH > $O/bench_pmc_rd.log 2>&1
-echo "pmc_rd exit=$?"
-rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum -d $O/pmc_wr -o bench --output-format csv -- $BENCH > $O/bench_pmc_wr.log 2>&1
-echo "pmc_wr exit=$?"
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o bench --output-format csv -- $BENCH > $O/bench_pmc_fetch.log 2>&1
-echo "pmc_fetch exit=$?"
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o bench --output-format csv -- $BENCH > $O/bench_pmc_write.log 2>&1
-echo "pmc_write exit=$?"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/pmc_sq -o bench --output-format csv -- $BENCH > $O/bench_pmc_sq.log 2>&1
-echo "pmc_sq exit=$?"
-grep -h '^{' $O/bench_trace.log | tail -1 > $O/bench_line_under_trace.json
-cd $R
-ls $O
-# kernel trace of the FULL default bench (all extras): per-kernel averages of the secondary kernels (wavelet tree, FM-index,
-# rrr, sd_vector, locate/extract walks)
-cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/trace_full -o bench --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/bench_trace_full.log 2>&1
-echo "trace_full exit=$?"
-cd $R
+WHAT=${@:-bench fm rrr wt full}
+for w in $WHAT; do
+  case $w in
+    bench) # the headline command without extras: every k_sw_* / k_sr_* dispatch belongs to a bucketed rank step
+      tools/prof.sh bench python $R/bench.py --steps 5 --warmup 1 --extras none --no-cpu ;;
+    fm)    # count() on the bench text and patterns, one table variant per run
+      tools/prof.sh fm_default python $R/tools/fm_probe.py 1024 1e8 default
+      tools/prof.sh fm_k8 python $R/tools/fm_probe.py 1024 1e8 k8
+      tools/prof.sh fm_dropped python $R/tools/fm_probe.py 1024 1e8 dropped ;;
+    rrr)   # configs[2], default dispatch (bucketed), one operation per run
+      tools/prof.sh rrr_rank python $R/tools/rrr_probe.py rank
+      tools/prof.sh rrr_select python $R/tools/rrr_probe.py select ;;
+    wt)    tools/prof.sh wt python $R/bench.py --steps 4 --warmup 1 --extras wt --no-cpu ;;
+    full)  # kernel trace only, of the default command
+      export TMPDIR=/tmp; O=$R/gpurun_out/prof_full; rm -rf $O; mkdir -p $O; cd /tmp
+      rocprofv3 --kernel-trace --stats -d $O/trace -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/stdout.txt 2> $O/trace.err
+      find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; cd $R ;;
+  esac
+done

@@ -22,11 +22,13 @@ st = bench.to_dev(pkg.rnd_positions(15, nq, nt - m, 0), dev)
 pats = text[(st.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()
 out = torch.empty(nq, dtype=torch.int64, device=dev)
 ref = None
+units = 0
 pkg.set_timing(True)
 
 
 def run(name):
-    global ref
+    global ref, units
+    units += 5 * nq
     csa.count(pats, m, out)
     torch.cuda.synchronize()
     ts = []
@@ -60,3 +62,4 @@ for v in variants:
     elif v.startswith("dk"):
         csa.set_kmer_table(int(v[2:]), 64 << 30) if csa.sampling()[2] else None
         run(f"dropped, k = {csa.kmer_table_depth()}")
+print(f"PROBE_UNITS {units}")
