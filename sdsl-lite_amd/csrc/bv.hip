@@ -12,6 +12,22 @@
 
 namespace sdslhip {
 
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t * __restrict__ p, uint32_t word, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        p[i] = word;
+}
+sdsl_hip_status fill_u32_async(void * p, uint32_t word, size_t bytes, hipStream_t s)
+{
+    if (bytes == 0)
+        return SDSL_HIP_OK;
+    const uint64_t n = bytes / 4;
+    hipLaunchKernelGGL(k_fill_u32, dim3(grid_for(n, 256, 256u * 8u)), dim3(256), 0, s, (uint32_t *)p, word, n);
+    SH_HIP(hipGetLastError());
+    return SDSL_HIP_OK;
+}
+
+
 // =========================================================================================
 // construction
 // =========================================================================================

@@ -1412,7 +1412,7 @@ sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const Selec
     }
     else
     {
-        SH_HIP(hipMemsetAsync(marked, 0, 4, s));
+        SH_TRY(fill_u32_async(marked, 0u, 4, s));
         hipLaunchKernelGGL(k_sr_select_bases, dim3((nf + 255) / 256), dim3(256), 0, s, nf, sp.nf, 0u, d2, sp.bnd, hf);
         if (bit)
             hipLaunchKernelGGL(k_sr_select_lds<1>, dim3(slice_blocks), dim3(kST), 0, s, v, nf, 0u, d2, sp.bm << sp.bs, sp.bnd, fstart, ioff,
@@ -1573,7 +1573,7 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         PhaseTimer pt(trace, s);
         pt.mark();
         if (sweep)
-            SH_HIP(hipMemsetAsync(b.tot2, 0, (kBins + 1) * 4, s));
+            SH_TRY(fill_u32_async(b.tot2, 0u, (kBins + 1) * 4, s));
         hipLaunchKernelGGL(K.hist1, G, T, 0, s, g, idx, nullptr, nullptr, nullptr, b.counts1, sweep ? b.tot2 : nullptr);
         pt.mark();
         hipLaunchKernelGGL(k_sr_bucket_totals, dim3(bins1), dim3(256), 0, s, g.G, b.counts1, b.btot);
@@ -1586,9 +1586,9 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         { // pass 2 in one sweep: no histogram pass, offsets by look-back (k_sr_partition2_sweep)
             pt.mark();
             hipLaunchKernelGGL(k_sr_bucket_scan, dim3(1), dim3(kBins), 0, s, bins2, g.tile, b.tot2, b.bstart2, nullptr);
-            SH_HIP(hipMemsetAsync(b.status, 0, ((size_t)g.tiles1 + kBins) * kBins * 4, s));
-            SH_HIP(hipMemsetAsync(b.ticket, 0, 4, s));
-            SH_HIP(hipMemsetAsync(b.fstart, 0xFF, ((size_t)nf + 1) * 4, s));
+            SH_TRY(fill_u32_async(b.status, 0u, ((size_t)g.tiles1 + kBins) * kBins * 4, s));
+            SH_TRY(fill_u32_async(b.ticket, 0u, 4, s));
+            SH_TRY(fill_u32_async(b.fstart, 0xFFFFFFFFu, ((size_t)nf + 1) * 4, s));
             pt.mark();
             // three blocks per CU (the 80-VGPR build: a dozen loop invariants live in scratch) cover the look-back's round trips
             // better than two: 4.06 -> 3.92 ms, same box; SDSL_HIP_SWEEP_BLOCKS=0 runs the 128-VGPR build at two per CU
@@ -1600,7 +1600,7 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         }
         else
         {
-            SH_HIP(hipMemsetAsync(b.fine_count, 0, (size_t)nf * 4, s));
+            SH_TRY(fill_u32_async(b.fine_count, 0u, (size_t)nf * 4, s));
             hipLaunchKernelGGL(K.hist2, G, T, 0, s, g, nullptr, b.keys1, b.tprefix2, b.bstart1, b.counts2, b.fine_count);
             pt.mark();
             hipLaunchKernelGGL(k_sr_bucket_totals, dim3(bins2), dim3(256), 0, s, g.G, b.counts2, b.btot);
@@ -1621,7 +1621,7 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         }
         else
         {
-            SH_HIP(hipMemsetAsync(b.btot, 0, 4, s)); // doubles as the "some answers are left to the fix-up pass" flag
+            SH_TRY(fill_u32_async(b.btot, 0u, 4, s)); // doubles as the "some answers are left to the fix-up pass" flag
             hipLaunchKernelGGL(k_sr_select_bases, dim3((nf + 255) / 256), dim3(256), 0, s, nf, sp.nf, g.d1, g.d2, sp.bnd, b.hf);
             pt.mark();
             // slices beyond sp.nf are empty (no items), so the kernel never reads bnd past sp.nf

@@ -916,8 +916,8 @@ sdsl_hip_status sw_run_with(const SwCallbacks & cb, int bit, const uint64_t * d_
         const uint64_t * idx = d_idx + done;
         PhaseTimer pt(trace, s);
         pt.mark();
-        SH_HIP(hipMemsetAsync(b.fine_h, 0, (size_t)kHB * w.nfw * 4, s));
-        SH_HIP(hipMemsetAsync(b.tickets, 0, 16, s));
+        SH_TRY(fill_u32_async(b.fine_h, 0u, (size_t)kHB * w.nfw * 4, s));
+        SH_TRY(fill_u32_async(b.tickets, 0u, 16, s));
         // (eight positions per thread and chunk: with sixteen, the positions, the prefetched ones and their keys did not fit 128
         // VGPRs — 6 spilled, 1.52 against 1.45 ms)
         sr_dispatch_op(g, [&](auto op)

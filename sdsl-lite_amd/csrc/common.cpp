@@ -130,8 +130,16 @@ sdsl_hip_status DevBuf::alloc(size_t n, bool zero)
     p = q;
     bytes = n;
     g_dev_bytes += n;
+    static const bool trace_alloc = getenv("SDSL_HIP_TRACE_ALLOC") != nullptr;
+    if (trace_alloc && n >= (1u << 20))
+        fprintf(stderr, "[sdsl_hip] alloc %p .. %p (%zu MiB)\n", q, (void *)((char *)q + n), n >> 20);
+    // SDSL_HIP_POISON=<byte>: every allocation that is not asked to be zero starts filled with that byte — fresh device memory is
+    // usually zero, which hides reads of memory nobody has written (tests/test_gpu_poison.py runs the large-batch paths this way)
+    static const int poison = getenv("SDSL_HIP_POISON") ? atoi(getenv("SDSL_HIP_POISON")) & 0xFF : -1;
     if (zero)
         SH_HIP(hipMemset(p, 0, n));
+    else if (poison >= 0)
+        SH_HIP(hipMemset(p, poison, n));
     return SDSL_HIP_OK;
 }
 
@@ -139,6 +147,9 @@ void DevBuf::release()
 {
     if (p)
     {
+        static const bool trace_alloc = getenv("SDSL_HIP_TRACE_ALLOC") != nullptr;
+        if (trace_alloc && bytes >= (1u << 20))
+            fprintf(stderr, "[sdsl_hip] free  %p (%zu MiB)\n", p, bytes >> 20);
         (void)hipFree(p);
         g_dev_bytes -= bytes;
     }

@@ -63,6 +63,10 @@ sdsl_hip_status hip_fail(hipError_t e, const char * what, const char * file, int
 
 // true if p points into device (or managed) memory
 bool is_device_ptr(const void * p);
+// `bytes` (a multiple of 4) at p = the 32-bit pattern `word`, as a KERNEL on `s`: the large-batch paths clear their counters this
+// way and not with hipMemsetAsync, whose node in a captured graph did not stay ordered with the kernels around it (a replayed
+// bucketed batch read counters that were being cleared and walked off its tables: tools/capture_probe.py tds)
+sdsl_hip_status fill_u32_async(void * p, uint32_t word, size_t bytes, hipStream_t s);
 // true while `s` is being captured into a graph (then nothing may be allocated, built or synchronised)
 bool stream_is_capturing(hipStream_t s);
 sdsl_hip_status check_device(int32_t device); // validates index + gfx950, sets the device current

@@ -697,7 +697,8 @@ sdsl_hip_status fm_count_fast(sdsl_hip_fm_s * f, const uint8_t * d_pats, uint32_
     void * scratch = L.p;
     FmRec * recs = reinterpret_cast<FmRec *>(scratch);
     uint32_t * ctr = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(scratch) + per * sizeof(FmRec));
-    hipError_t e = hipMemsetAsync(ctr, 0, n_slabs * 4, s);
+    SH_TRY(fill_u32_async(ctr, 0u, n_slabs * 4, s));
+    hipError_t e = hipSuccess;
     const FmDeep D = f->deep();
     FmJump J = f->jump();
     if (J.k > 8)

@@ -760,7 +760,7 @@ sdsl_hip_status rrr_launch_select_sorted(RrrHost & h, int bit, const uint64_t * 
     cb.answers = [&](const SrGeom & g, unsigned nf, const uint32_t * fstart, const uint32_t * ioff, uint32_t * keys2, uint64_t * hf, uint32_t * marked,
                      hipStream_t st) -> sdsl_hip_status
     {
-        SH_HIP(hipMemsetAsync(marked, 0, 4, st));
+        SH_TRY(fill_u32_async(marked, 0u, 4, st));
         hipLaunchKernelGGL(k_rs_select_bases, dim3((nf + 255) / 256), dim3(256), 0, st, nf, n_buckets, rec_bits, bnd, hf);
         // (slices beyond the plan's buckets have no keys, so the kernel never reads bnd past n_buckets)
         const dim3 grid(rlog == 7 ? 512u : 256u);

@@ -266,7 +266,7 @@ sdsl_hip_status wt_launch_select_sorted(const WtHost & wt, const uint64_t * d_oc
     cb.answers = [&](const SrGeom & g, unsigned nf, const uint32_t * fstart, const uint32_t * ioff, uint32_t * keys2, uint64_t * hf, uint32_t * marked,
                      hipStream_t st) -> sdsl_hip_status
     {
-        SH_HIP(hipMemsetAsync(marked, 0, 4, st));
+        SH_TRY(fill_u32_async(marked, 0u, 4, st));
         hipLaunchKernelGGL(k_wt_sel_zero_bases, dim3((nf + 255) / 256), dim3(256), 0, st, nf, hf);
         hipLaunchKernelGGL(k_wt_select_sorted, dim3(256u * 8u), dim3(kBlock), 0, st, view, d_occ, nf, g.d1, g.d2, g.kb, B, fstart, ioff, keys2, g.go);
         SH_HIP(hipGetLastError());

@@ -53,11 +53,18 @@ def test_rank_and_select_in_default_mode_capture_into_a_graph(gpu):
             gpu.set_option("rank_sorted", -1)
             gpu.set_option("select_sorted", -1)
 
-    # 1: a fresh spread batch in the captured buffers
+    # 1: a fresh spread batch in the captured buffers.  (The synchronisations are part of the test: with a traced batch in front
+    # of the capture and the device idle before the replay, round 3's graph walked off its tables — its counters were cleared by
+    # hipMemsetAsync nodes, which did not stay ordered with the kernels around them in the replayed graph (a GPU memory fault on
+    # the first replay; tools/capture_probe.py tds).  The passes clear their counters with a kernel now: common.hpp fill_u32_async.)
     idx.copy_(torch.randint(0, n_bits + 1, (nq,), device=dev, dtype=torch.int64, generator=g))
+    torch.cuda.synchronize()
     sel.copy_(torch.randint(1, ones + 1, (nq,), device=dev, dtype=torch.int64, generator=g))
+    torch.cuda.synchronize()
     out.fill_(-7)
+    torch.cuda.synchronize()
     sout.fill_(-7)
+    torch.cuda.synchronize()
     graph.replay()
     torch.cuda.synchronize()
     want_r, want_s = direct()
