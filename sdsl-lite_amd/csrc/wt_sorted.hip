@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_wt_sel_zero_bases(unsigned nf, uint64_t
 
 // One block per work item (the keys of one bucket, at most kItemKeys of them).  The walk is k_wt_select_fused's: a flat loop, one
 // iteration = one window probe of whatever fused step of whatever key the quad is at.
-__global__ __launch_bounds__(kBlock) void k_wt_select_sorted(WtView wt, const uint64_t * __restrict__ occ, unsigned nf, unsigned d1, unsigned d2,
+__global__ __launch_bounds__(kBlock) void k_wt_select_sorted(WtView wt, const uint64_t * __restrict__ occ, unsigned nf,
                                                              unsigned kb, unsigned B, const uint32_t * __restrict__ fstart,
                                                              const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys,
                                                              const uint32_t * __restrict__ go)
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_sorted(WtView wt, const ui
         const uint64_t fend = fstart[f + 1];
         const unsigned cnt = (unsigned)(lo + kItemKeys < fend ? kItemKeys : fend - lo);
         uint32_t * kp = keys + lo;
-        const uint64_t v0 = (uint64_t)sr_slice_of(f, d1, d2) * B; // the bucket's first place
+        const uint64_t v0 = (uint64_t)f * B; // the bucket's first place (the write-combined passes keep their tables in bucket order)
         const uint32_t kmask = (1u << kb) - 1u;
         unsigned nxt = gq; // this quad's next key of the item
         uint32_t key_nxt = nxt < cnt ? kp[nxt] : kBad;
@@ -268,7 +268,7 @@ sdsl_hip_status wt_launch_select_sorted(const WtHost & wt, const uint64_t * d_oc
     {
         SH_TRY(fill_u32_async(marked, 0u, 4, st));
         hipLaunchKernelGGL(k_wt_sel_zero_bases, dim3((nf + 255) / 256), dim3(256), 0, st, nf, hf);
-        hipLaunchKernelGGL(k_wt_select_sorted, dim3(256u * 8u), dim3(kBlock), 0, st, view, d_occ, nf, g.d1, g.d2, g.kb, B, fstart, ioff, keys2, g.go);
+        hipLaunchKernelGGL(k_wt_select_sorted, dim3(256u * 8u), dim3(kBlock), 0, st, view, d_occ, nf, g.kb, B, fstart, ioff, keys2, g.go);
         SH_HIP(hipGetLastError());
         return SDSL_HIP_OK;
     };
