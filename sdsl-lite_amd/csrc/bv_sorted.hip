@@ -1481,9 +1481,11 @@ bool bv_sorted_rank_possible(const BvView & v)
 bool bv_sorted_rank_applicable(const BvView & v, uint64_t n)
 {
     // worth it when the index is larger than the Infinity Cache (256 MiB = 2^22 lines; below that the direct kernel's
-    // gathers are served on-die at 52-58 G/s, what this path reaches) and the batch addresses every line at least twice
-    // (the slices are streamed once per batch whatever its size: 2^34 bits cost 0.45 ms before the first answer)
-    return bv_sorted_rank_possible(v) && v.n_lines >= (UINT64_C(1) << 22) && n >= 2 * v.n_lines;
+    // gathers are served on-die at 52-58 G/s, what this path reaches) and the batch addresses every line at least FOUR times:
+    // the slices are streamed once per batch whatever its size and the table kernels cost 0.2 ms, so on 2^34 bits the passes take
+    // 1.55 ms + 11.1 ns per 10^3 queries against the direct kernel's 23.1 — they cross at 1.3 x 10^8 queries = 3.4 per line
+    // (bench.py extras.batch_sweep: 10^8 queries 37.6 against 43.2 G/s, 10^9: 73.9 against 43.2; round 3 switched at two per line)
+    return bv_sorted_rank_possible(v) && v.n_lines >= (UINT64_C(1) << 22) && n >= 4 * v.n_lines;
 }
 
 namespace {

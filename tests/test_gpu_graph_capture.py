@@ -19,7 +19,7 @@ def test_rank_and_select_in_default_mode_capture_into_a_graph(gpu):
     words = torch.randint(-2**63, 2**63 - 1, ((n_bits + 63) // 64,), device=dev, dtype=torch.int64, generator=g)
     bv = gpu.bit_vector(words, n_bits)
     del words
-    nq = 9_000_000  # >= 2 x lines
+    nq = 17_000_000  # >= 4 x lines
     idx = torch.randint(0, n_bits + 1, (nq,), device=dev, dtype=torch.int64, generator=g)
     out = torch.empty_like(idx)
     ones = bv.ones()
@@ -125,7 +125,7 @@ def test_a_captured_batch_without_a_reservation_takes_the_direct_kernel(gpu):
     bv = gpu.bit_vector(words, n_bits)
     rv = gpu.rrr_vector(words, n_bits)
     del words
-    nq = 9_000_000
+    nq = 17_000_000
     idx = torch.randint(0, n_bits + 1, (nq,), device=dev, dtype=torch.int64, generator=g)
     sel = torch.randint(1, bv.ones() + 1, (nq,), device=dev, dtype=torch.int64, generator=g)
     out, sout, rout = torch.empty_like(idx), torch.empty_like(sel), torch.empty_like(idx)

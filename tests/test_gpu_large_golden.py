@@ -93,13 +93,13 @@ def test_c2_select_1_matches_reference_digests(gpu, c2_vector, mode):
 
 
 def test_c2_default_dispatch_takes_the_bucketed_path_at_bench_size(gpu, c2_vector):
-    """With no option set, a batch of >= 2 queries per rank line goes through bv_sorted.hip — for rank AND for select on
+    """With no option set, a batch of >= 4 queries per rank line (select: 2) goes through bv_sorted.hip — for rank AND for select on
     this very vector (its 2^33 + 116138 ones once pushed select over the 2^16-bucket limit and silently back to the
     direct kernel).  The first 10^7 answers are the reference's."""
     import torch
     bv, n = c2_vector
     c = G["c2"]
-    nq = 100_000_000
+    nq = 160_000_000
     gpu.set_option("trace_phases", 1)
     try:
         idx = torch.from_numpy(gpu.rnd_positions(c["rank_seed"], nq, n + 1, 0).view(np.int64)).cuda()
@@ -129,7 +129,7 @@ def test_c2_default_dispatch_keeps_local_batches_on_the_direct_kernel(gpu, c2_ve
     select, and the answers are those of the bucketed path."""
     import torch
     bv, n = c2_vector
-    nq = 100_000_000
+    nq = 160_000_000
     g = torch.Generator(device="cuda").manual_seed(3)
     if shape == "window":
         idx = (n // 3) + torch.randint(0, 1 << 20, (nq,), device="cuda", dtype=torch.int64, generator=g)
