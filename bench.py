@@ -771,6 +771,12 @@ def main():
                                   "path": "default dispatch (a spread batch of this size: the passes of bv_swc.hip around the slice-wise "
                                           "decoder of rrr_sorted.hip)",
                                   "roofline_frac": ALG_BYTES["rrr"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            bq = pmc_traffic("rrr_rank_bucketed_bytes_per_query")
+            ex["rrr63_rank_1"]["fabric_traffic"] = {
+                "bytes_per_query": bq, "frac_of_hbm_peak": bq * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if bq else None,
+                "note": "measured fabric bytes of ALL kernels of a bucketed step (tools/rrr_probe.py under the counters, "
+                        "profiles/pmc_latest.json) over the 8 TB/s peak — the honest fraction of this path: roofline_frac prices every "
+                        "query at SURVEY 8(d)'s 144 bytes, which a batch that reads each record once does not move (it can exceed 1)"}
             # the direct kernel (one record fetch and one block decode per query) beside it, same answers
             pkg.set_option("rrr_sorted", 0)
             out_d = torch.empty_like(out)
@@ -786,6 +792,9 @@ def main():
             _, ms = time_steps(lambda: rv.select(si, 1, out), max(2, a.steps // 2), 1, barrier)
             ex["rrr63_select_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms,
                                     "roofline_frac": ALG_BYTES["rrr"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            bq = pmc_traffic("rrr_select_bucketed_bytes_per_query")
+            ex["rrr63_select_1"]["fabric_traffic"] = {"bytes_per_query": bq,
+                                                      "frac_of_hbm_peak": bq * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if bq else None}
             pkg.set_option("rrr_sorted", 0)
             out_d = torch.empty_like(out)
             _, ms_d = time_steps(lambda: rv.select(si, 1, out_d), 2, 1, barrier)

@@ -325,6 +325,11 @@ sdsl_hip_status sdsl_hip_fm_serialize(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32
 sdsl_hip_status sdsl_hip_fm_serialize_ex(sdsl_hip_fm_t fm, int32_t layout, uint32_t sa_dens, uint32_t isa_dens, void * buf,
                                          size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm);
+/* The opposite, for an index loaded from an SDSL stream WITH its sampling densities: the text is read back through the ISA
+ * samples (suffix_array_algorithm.hpp:578-600, extract), suffix-sorted on the device, checked against the stream's own SA
+ * samples and kept together with the whole suffix array — and the k-mer table of count() is built: from then on the index
+ * answers like one created from text (count of large batches: the k-mer table + text comparison road).  About 1.5 s per GiB. */
+sdsl_hip_status sdsl_hip_fm_restore_suffix_array(sdsl_hip_fm_t fm);
 /* Jump-start table of count / interval / locate: the SA interval of every k-mer over the index's alphabet (16 bytes
  * each), read with the last k characters of a pattern instead of walking their k LF steps.  The entries are computed by
  * the search itself, so answers do not change.  Every index gets a default depth at creation (table <= half the wavelet

@@ -649,6 +649,66 @@ uint64_t sdsl_hip_fm_kmer_table_bytes(sdsl_hip_fm_t fm)
     return fm ? fm->d_deep.bytes : 0;
 }
 
+// The opposite of drop_sa, for an index that came from an SDSL stream: the text is read back through the ISA samples
+// (sdsl_hip_fm_extract_batch: thousands of independent walks), suffix-sorted on the device like a text handed to
+// sdsl_hip_fm_create_from_text, and the result is checked against the stream's own SA samples before it is kept.
+__global__ __launch_bounds__(256) void k_fm_check_samples(const uint32_t * __restrict__ sa, const uint64_t * __restrict__ samples,
+                                                          uint64_t n_samples, uint64_t dens, unsigned * __restrict__ bad)
+{
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_samples; k += (uint64_t)gridDim.x * blockDim.x)
+        if ((uint64_t)sa[k * dens] != samples[k])
+            atomicAdd(bad, 1u);
+}
+
+sdsl_hip_status sdsl_hip_fm_restore_suffix_array(sdsl_hip_fm_t fm)
+{
+    if (!fm)
+    {
+        set_error("fm_restore_suffix_array: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_HIP(hipSetDevice(fm->device));
+    if (!(fm->d_sa.p && fm->d_text.p))
+    {
+        if (fm->size < 2 || fm->size >= UINT64_C(0xFFFFFFFE) || !fm->isa_dens || !fm->sa_dens)
+        {
+            set_error("fm_restore_suffix_array: needs the index's SA and ISA samples (load the stream with its densities: "
+                      "sdsl_hip_fm_create_from_sdsl_ex) and fewer than 2^32 - 2 symbols");
+            return SDSL_HIP_ERR_UNSUPPORTED;
+        }
+        const uint64_t n_text = fm->size - 1;
+        DevBuf d_text, d_bwt, d_sa, d_bad;
+        SH_TRY(d_text.alloc(n_text));
+        const uint64_t b = 0, e = n_text - 1;
+        uint64_t total = 0;
+        SH_TRY(sdsl_hip_fm_extract_batch(fm, &b, &e, 1, nullptr, d_text.as<uint8_t>(), n_text, &total, nullptr));
+        if (total != n_text)
+        {
+            set_error("fm_restore_suffix_array: the index gave back %llu of %llu symbols", (unsigned long long)total, (unsigned long long)n_text);
+            return SDSL_HIP_ERR_FORMAT;
+        }
+        SH_TRY(sa_build_bwt_device(d_text.as<uint8_t>(), n_text, fm->device, d_bwt, d_sa));
+        SH_TRY(d_bad.alloc(4, true));
+        hipLaunchKernelGGL(k_fm_check_samples, dim3(grid_for(fm->n_sa_s, 256, 256u * 8u)), dim3(256), 0, 0, d_sa.as<uint32_t>(),
+                           fm->d_sa_s.as<uint64_t>(), fm->n_sa_s, (uint64_t)fm->sa_dens, d_bad.as<unsigned>());
+        SH_HIP(hipGetLastError());
+        unsigned bad = 0;
+        SH_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
+        if (bad)
+        { // (a stream whose samples and wavelet tree do not describe the same text)
+            set_error("fm_restore_suffix_array: %u of the stream's SA samples disagree with the suffix array of the text the index spells", bad);
+            return SDSL_HIP_ERR_FORMAT;
+        }
+        fm->d_sa = std::move(d_sa);
+        fm->d_text = std::move(d_text);
+    }
+    if (!fm->ctab_ok)
+        SH_TRY(fm_build_count_tab(fm));
+    if (!fm->deep_k)
+        SH_TRY(fm_build_deep_default(fm));
+    return SDSL_HIP_OK;
+}
+
 sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
 {
     if (!fm)

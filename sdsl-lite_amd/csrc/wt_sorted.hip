@@ -128,6 +128,18 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_sorted(WtView wt, const ui
         uint32_t * kp = keys + lo;
         const uint64_t v0 = (uint64_t)f * B; // the bucket's first place (the write-combined passes keep their tables in bucket order)
         const uint32_t kmask = (1u << kb) - 1u;
+        unsigned c0 = 0; // the symbol of the bucket's first place (block-uniform; 8 LDS steps once per item, not per key)
+        {
+            unsigned z = 256;
+            while (c0 + 1 < z)
+            {
+                const unsigned m = (c0 + z) >> 1;
+                if (first[m] <= (uint32_t)v0)
+                    c0 = m;
+                else
+                    z = m;
+            }
+        }
         unsigned nxt = gq; // this quad's next key of the item
         uint32_t key_nxt = nxt < cnt ? kp[nxt] : kBad;
         bool have = false;
@@ -161,16 +173,10 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_sorted(WtView wt, const ui
                 if (key >= kMark)
                     continue; // (kBad: no walk — the un-permute passes turn it into NPOS)
                 const uint32_t v = (uint32_t)(v0 + (key & kmask)); // place in symbol order, 0-based
-                unsigned a = 0, z = 256; // the symbol: first[c] <= v < first[c + 1]
-                while (a + 1 < z)
-                {
-                    const unsigned m = (a + z) >> 1;
-                    if (first[m] <= v)
-                        a = m;
-                    else
-                        z = m;
-                }
-                const unsigned c = a;
+                // the symbol: first[c] <= v < first[c + 1] — nearly always the one the bucket starts in, or the next present one
+                unsigned c = c0;
+                while (first[c + 1] <= v)
+                    ++c;
                 res = v - first[c];
                 cur = T.c_to_leaf[c];
                 p = T.path[c];

@@ -635,6 +635,10 @@ class csa_wt(_Handle):
     def drop_sa(self):
         capi.check(capi.lib().sdsl_hip_fm_drop_sa(self._h))
 
+    def restore_suffix_array(self):
+        """an index loaded from an SDSL stream with its densities gets its text, whole suffix array and k-mer table back"""
+        capi.check(capi.lib().sdsl_hip_fm_restore_suffix_array(self._h))
+
     def jump_depth(self) -> int:
         """characters of a pattern answered by the k-mer interval table instead of LF steps"""
         return capi.lib().sdsl_hip_fm_jump_depth(self._h)

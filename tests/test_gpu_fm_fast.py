@@ -88,3 +88,32 @@ def test_fast_count_equals_lock_step_kernel_on_a_larger_text(gpu):
     csa.drop_sa()
     assert np.array_equal(np.asarray(csa.count(flat, m)).astype(np.uint64), got)
     csa.close()
+
+
+def test_an_index_loaded_from_an_sdsl_stream_gets_text_suffix_array_and_table_back(gpu):
+    rng = np.random.default_rng(11)
+    n = 200_000
+    text = rng.integers(1, 30, n, dtype=np.uint8)
+    text[500:900] = text[7000:7400]
+    built = gpu.csa_wt(text=text)
+    blob = built.serialize(32, 64)
+    m, npat = 12, 20_000
+    st = rng.integers(0, n - m, npat)
+    pats = text[st[:, None] + np.arange(m)[None, :]].copy()
+    pats[::3, rng.integers(0, m)] = 7
+    flat = np.ascontiguousarray(pats.reshape(-1))
+    want = np.asarray(built.count(flat, m)).astype(np.uint64)
+    built.close()
+    loaded = gpu.csa_wt(sdsl_bytes=blob, select_is_mcl=False, sa_dens=32, isa_dens=64)
+    assert loaded.kmer_table_depth() == 0 and not loaded.sampling()[2]
+    assert np.array_equal(np.asarray(loaded.count(flat, m)).astype(np.uint64), want)  # dense table + flat kernel, every character walked
+    loaded.restore_suffix_array()
+    assert loaded.kmer_table_depth() >= 1 and loaded.sampling()[2], "text, suffix array and k-mer table are back"
+    assert np.array_equal(np.asarray(loaded.count(flat, m)).astype(np.uint64), want)
+    sidx = rng.integers(0, n + 1, 5000).astype(np.uint64)
+    assert np.array_equal(np.asarray(loaded.sa(sidx)), np.asarray(ol.OCsa(bytes(text)).sa(sidx)))
+    loaded.close()
+    bare = gpu.csa_wt(sdsl_bytes=blob, select_is_mcl=False)  # no densities: nothing to read the text back with
+    with pytest.raises(Exception):
+        bare.restore_suffix_array()
+    bare.close()

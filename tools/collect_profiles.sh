@@ -22,3 +22,15 @@ for w in $WHAT; do
       find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; cd $R ;;
   esac
 done
+# condensed results (what travels back: gpurun merges at most 64 MiB): the json of bench.py's roofline blocks, one per-kernel
+# table per profiled command, the kernel-trace statistics; the raw counter files stay on the box
+OUT=$R/gpurun_out/profiles_new; rm -rf $OUT; mkdir -p $OUT
+python $R/tools/pmc_json.py > $OUT/pmc_json.log 2>&1; cp $R/profiles/pmc_latest.json $OUT/ 2>/dev/null
+for d in $R/gpurun_out/prof_*/; do
+  t=$(basename $d); t=${t#prof_}
+  [ -d $d/rd ] && python $R/tools/prof_summary.py $t --min-ms 0.02 --md $OUT/pmc_$t.md --json $OUT/pmc_$t.json > /dev/null 2>&1
+  f=$(find $d/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -i "sdslhip\|^\"Name\|rocprim" $f | sed 's/(anonymous namespace):://g' | cut -c1-400 > $OUT/kernel_stats_$t.csv
+  grep -h "^{" $d/stdout.txt 2>/dev/null | tail -1 > $OUT/line_$t.json; [ -s $OUT/line_$t.json ] || rm -f $OUT/line_$t.json
+  grep -h "Mcount/s\|Gq/s\|PROBE_UNITS" $d/stdout.txt 2>/dev/null > $OUT/stdout_$t.txt; [ -s $OUT/stdout_$t.txt ] || rm -f $OUT/stdout_$t.txt
+done
+[ -z "$PROF_KEEP_RAW" ] && rm -rf $R/gpurun_out/prof_*
