@@ -101,6 +101,17 @@ void * ref_bv_create(const uint64_t * words, uint64_t n_bits)
     h->s0 = select_support_mcl<0>(&h->bv);
     return h;
 }
+// rank supports only (v5, both bit values): for vectors whose select supports would take minutes to build
+void * ref_bv_create_rank(const uint64_t * words, uint64_t n_bits)
+{
+    RefBv * h = new RefBv();
+    h->bv = bit_vector(n_bits, 0);
+    if (n_bits)
+        memcpy(h->bv.data(), words, ((n_bits + 63) >> 6) * 8);
+    h->r1 = rank_support_v5<1>(&h->bv);
+    h->r0 = rank_support_v5<0>(&h->bv);
+    return h;
+}
 void ref_bv_destroy(void * p)
 {
     delete (RefBv *)p;

@@ -346,12 +346,13 @@ __global__ __launch_bounds__(1024) void k_sr_fine_scan(unsigned nf, const uint32
 }
 
 // ones in front of every slice (what makes a slice-relative answer absolute)
-__global__ __launch_bounds__(256) void k_sr_slice_bases(BvView bv, unsigned nf, unsigned d1, unsigned d2, uint64_t * __restrict__ hf)
+__global__ __launch_bounds__(256) void k_sr_slice_bases(BvView bv, unsigned nf, unsigned d1, unsigned d2, uint64_t * __restrict__ hf,
+                                                        unsigned slog = kSliceLog)
 {
     const unsigned f = blockIdx.x * 256 + threadIdx.x;
     if (f < nf)
     {
-        const uint64_t L0 = (uint64_t)sr_slice_of(f, d1, d2) << kSliceLog;
+        const uint64_t L0 = (uint64_t)sr_slice_of(f, d1, d2) << slog;
         hf[f] = L0 < bv.n_lines ? bv.lines[L0 * kLW] : 0;
     }
 }
@@ -748,8 +749,14 @@ __global__ __launch_bounds__(1024) void k_sr_fine_scan_starts(unsigned nf, unsig
 // the slice: 20 bits | ones in word 0: 9 bits | in words 0..2: 9 bits | in words 0..4: 9 bits].  A query then reads
 // the header's 16 bytes and the one 16-byte pair that holds its word: two LDS reads and two popcounts instead of the
 // whole line (the first form of this kernel spent 1.4 wave instructions per key, 65 % of its time in the VALU).
+// MULTI (vectors of more than 2^26 lines): a slice covers 2^slog > 2^kSliceLog lines and is staged in rounds of 2^kSliceLog; every
+// round walks all keys of the item and answers — and stores — those whose line lies in the staged part (the others' stores go
+// beyond the buffer's end, i.e. nowhere).  The keys are read once per round (they sit in the L2 by then) and an answer is the
+// ones in front of the position relative to the WHOLE slice's first line, as the way back expects.
+template <bool MULTI>
 __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigned nf, unsigned d1, unsigned d2, const uint32_t * __restrict__ fstart,
-                                                     const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys, const uint32_t * __restrict__ go)
+                                                     const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys, const uint32_t * __restrict__ go,
+                                                     unsigned slog)
 {
     if (go && !*go)
         return;
@@ -780,7 +787,16 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
         }
         __syncthreads(); // also: everybody is done with the previous slice
         const unsigned f = sh_f;
-        const uint64_t L0 = (uint64_t)sr_slice_of(f, d1, d2) << kSliceLog;
+        const uint64_t Ls = (uint64_t)sr_slice_of(f, d1, d2) << (MULTI ? slog : kSliceLog); // the slice's first line
+        const unsigned n_sub = MULTI ? 1u << (slog - kSliceLog) : 1u;
+        const uint64_t Hs = MULTI ? bv.lines[Ls * kLW] : 0; // ones in front of the slice
+      for (unsigned sub = 0; sub < n_sub; ++sub)
+      {
+        const uint64_t L0 = Ls + ((uint64_t)sub << kSliceLog);
+        if (MULTI && L0 >= bv.n_lines)
+            break;
+        if (MULTI && sub)
+            __syncthreads(); // everybody is done with the part staged before
         const unsigned nl = (unsigned)(bv.n_lines - L0 < (UINT64_C(1) << kSliceLog) ? bv.n_lines - L0 : (UINT64_C(1) << kSliceLog));
         const v2u64 * src = reinterpret_cast<const v2u64 *>(bv.lines + L0 * kLW);
         for (unsigned i = t; i < nl * (kLW / 2); i += kRT)
@@ -826,7 +842,9 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
             {
                 if (u == 0 && i0 == 0 && t < head)
                     key[u] = kBad; // (a key of the line's head: the item in front of this one answers it)
-                const unsigned ln = key[u] == kBad ? 0 : key[u] >> kOffBits;
+                const unsigned lnf = key[u] == kBad ? 0 : key[u] >> kOffBits; // line inside the slice
+                const bool here = !MULTI || key[u] == kBad || (lnf >> kSliceLog) == sub; // staged in this round (kBad: answered in round 0)
+                const unsigned ln = MULTI ? (here ? lnf & ((1u << kSliceLog) - 1) : 0u) : lnf;
                 const unsigned off = key[u] & ((1u << kOffBits) - 1);
                 const v2u64 * w = slice + ln * (kLW / 2);
                 const unsigned wi = off >> 6, k = (wi + 1) >> 1; // data word of the position, 16-byte quarter holding it
@@ -836,11 +854,14 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
                 const uint64_t m = lo_set(off & 63);
                 const unsigned base = k ? (unsigned)(hx >> (11 + 9 * k)) & 0x1FFu : 0u;
                 const unsigned part = (wi & 1) ? popc64(x & m) : popc64(x) + popc64(y & m);
-                const uint32_t r1 = ((uint32_t)hx & 0xFFFFFu) + base + part;
-                uint32_t r = bit ? r1 : ln * (uint32_t)kDB + off - r1;
+                const uint32_t r1 = (MULTI ? (uint32_t)(H - Hs) : 0u) + ((uint32_t)hx & 0xFFFFFu) + base + part;
+                uint32_t r = bit ? r1 : lnf * (uint32_t)kDB + off - r1;
                 if (key[u] == kBad)
                     r = kBad;
-                __builtin_amdgcn_raw_buffer_store_b32(r, rs_k, (int)(u == 0 && i0 == 0 ? vo0 : t * 4u), (int)(i0 * 4u + (unsigned)u * kRT * 4u), kAuxNT);
+                unsigned vo = u == 0 && i0 == 0 ? vo0 : t * 4u;
+                if (MULTI && (!here || (key[u] == kBad && sub != 0)))
+                    vo = 0xFFFFFFFCu; // another round's key: not stored
+                __builtin_amdgcn_raw_buffer_store_b32(r, rs_k, (int)vo, (int)(i0 * 4u + (unsigned)u * kRT * 4u), kAuxNT);
             }
             if (i0 + kRT * U < cnth)
             {
@@ -849,6 +870,7 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
                     key[u] = nk[u];
             }
         }
+      } // rounds of a wide slice
     }
 }
 
@@ -1400,15 +1422,18 @@ SrKernels sr_kernels(unsigned per_cu)
 
 // the slices' answers in place over the final keys (tables in SLICE order: d1 = 0 makes sr_slice_of the identity) + the
 // per-slice bases the way back adds (bv_swc.hip)
-sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const SelectPlan & sp, unsigned nf, unsigned d2, const uint32_t * fstart,
+sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const SelectPlan & sp, unsigned nf, unsigned d2, unsigned slog, const uint32_t * fstart,
                                   const uint32_t * ioff, uint32_t * keys2, uint64_t * hf, uint32_t * marked, const uint32_t * go, hipStream_t s)
 {
     static const int rb_env = getenv("SDSL_HIP_SORTED_RANK_BLOCKS") ? atoi(getenv("SDSL_HIP_SORTED_RANK_BLOCKS")) : 0;
     const unsigned slice_blocks = rb_env >= 1 ? (unsigned)rb_env : 1024u;
     if (op == 0)
     {
-        hipLaunchKernelGGL(k_sr_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, s, v, nf, 0u, d2, hf);
-        hipLaunchKernelGGL(k_sr_rank_lds, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, 0u, d2, fstart, ioff, keys2, go);
+        hipLaunchKernelGGL(k_sr_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, s, v, nf, 0u, d2, hf, slog);
+        if (slog > kSliceLog)
+            hipLaunchKernelGGL(k_sr_rank_lds<true>, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, 0u, d2, fstart, ioff, keys2, go, slog);
+        else
+            hipLaunchKernelGGL(k_sr_rank_lds<false>, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, 0u, d2, fstart, ioff, keys2, go, slog);
     }
     else
     {
@@ -1473,9 +1498,10 @@ size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n)
     return a > c ? a : c;
 }
 
+static bool sr_use_swc();
 bool bv_sorted_rank_possible(const BvView & v)
 {
-    return v.n_lines >= 2 && v.n_lines <= (UINT64_C(1) << (kSliceLog + 16));
+    return v.n_lines >= 2 && v.n_lines <= (UINT64_C(1) << (kSliceLog + 16 + (sr_use_swc() ? kSliceExtraMax : 0u)));
 }
 
 bool bv_sorted_rank_applicable(const BvView & v, uint64_t n)
@@ -1619,7 +1645,7 @@ sdsl_hip_status sr_run(const BvView & v, int op, int bit, const SelectPlan & sp,
         {
             hipLaunchKernelGGL(k_sr_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, s, v, nf, g.d1, g.d2, b.hf);
             pt.mark();
-            hipLaunchKernelGGL(k_sr_rank_lds, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, g.d1, g.d2, b.fstart, b.ioff, b.keys2, (const uint32_t *)nullptr);
+            hipLaunchKernelGGL(k_sr_rank_lds<false>, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, g.d1, g.d2, b.fstart, b.ioff, b.keys2, (const uint32_t *)nullptr, kSliceLog);
         }
         else
         {

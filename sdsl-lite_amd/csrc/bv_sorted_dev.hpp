@@ -29,6 +29,8 @@ struct SrGeom
     uint64_t slice_bits; // bits of the vector a slice covers (rank_0: zeros in front of a slice = its first bit - ones in front)
     uint32_t rbits;  // op 2 (rank on rrr records): bits per record; a key is [record in the slice : 8 | block : 6 | bit : 6]
     uint32_t rlog;   // op 2: log2 of the records per slice (7 or 8)
+    uint32_t slog;   // op 0 / 4: log2 of the lines a slice covers: kSliceLog, or up to kSliceLog + kSliceExtraMax on vectors of more than
+                     // 2^26 lines — the answering kernel then stages a slice in rounds of 2^kSliceLog lines (bv_sorted.hip: k_sr_rank_lds)
     uint32_t over_is_size; // op 1: an argument beyond the last one is not NPOS but size() (select_support_rrr, rrr_vector.hpp:641-642):
                            // its key is kMark and the fix-up pass writes the answer
     const uint32_t * go; // automatic dispatch: the passes return at once when this word is zero (nullptr: always run)
@@ -45,6 +47,7 @@ constexpr unsigned kBins = 256;          // bins per pass (8-bit digits)
 constexpr unsigned kSliceLog = 10;       // lines per slice (64 KiB)
 constexpr unsigned kOffBits = 9;         // 448 < 2^9 in-line offsets
 constexpr unsigned kKey2Bits = kSliceLog + kOffBits;
+constexpr unsigned kSliceExtraMax = 3;   // a slice of up to 2^13 lines: vectors of up to 2^29 lines (2^37.8 bits)
 constexpr uint32_t kBad = 0xFFFFFFFFu;   // key / answer of a position beyond the vector (answer NPOS)
 constexpr uint32_t kMark = 0xFFFFFFFEu;  // select: answer left to the fix-up pass (bucket wider than an LDS slice)
 constexpr uint64_t kMark64 = SDSL_HIP_NPOS - 1;
@@ -163,9 +166,9 @@ __device__ __forceinline__ void sr_key1(uint64_t pos, const SrGeom & g, unsigned
     uint64_t L;
     unsigned off;
     line_of(pos, g.small, L, off);
-    const uint32_t l = (uint32_t)L; // < 2^26
-    dig = l >> (kSliceLog + g.d2);
-    key = (((l >> kSliceLog) & ((1u << g.d2) - 1)) << kKey2Bits) | ((l & ((1u << kSliceLog) - 1)) << kOffBits) | off;
+    const uint32_t l = (uint32_t)L; // < 2^29
+    dig = l >> (g.slog + g.d2);
+    key = (((l >> g.slog) & ((1u << g.d2) - 1)) << g.kb) | ((l & ((1u << g.slog) - 1)) << kOffBits) | off;
 }
 // The same with the kind of query fixed at compile time (OP = SrGeom::op; plain rank: 0 for vectors below 2^38 bits, 4 above) and
 // without per-key branches: the counting pass and pass 1 are bound by the instructions they issue per key (47 and 54 of them —
@@ -203,9 +206,9 @@ __device__ __forceinline__ void sr_key1_t(uint64_t pos, const SrGeom & g, unsign
         uint64_t L;
         unsigned off;
         line_of(pos, OP == 0, L, off);
-        const uint32_t l = (uint32_t)L; // < 2^26
-        dig = bad ? 0u : l >> (kSliceLog + g.d2);
-        key = bad ? kBad : (((l >> kSliceLog) & ((1u << g.d2) - 1)) << kKey2Bits) | ((l & ((1u << kSliceLog) - 1)) << kOffBits) | off;
+        const uint32_t l = (uint32_t)L; // < 2^29
+        dig = bad ? 0u : l >> (g.slog + g.d2);
+        key = bad ? kBad : (((l >> g.slog) & ((1u << g.d2) - 1)) << g.kb) | ((l & ((1u << g.slog) - 1)) << kOffBits) | off;
     }
 }
 // calls f with the compile-time kind of a geometry's queries
@@ -355,18 +358,21 @@ inline void sr_fill_geom(SrGeom & g, const BvView & v, int op, const SelectPlan 
     g.n_lines = v.n_lines;
     g.op = (uint32_t)op;
     unsigned f = 0; // bits of a slice / bucket index
+    g.slog = kSliceLog;
     if (op == 0)
     {
         unsigned lb = 0; // bits of a line index
         while ((v.n_lines - 1) >> lb)
             ++lb;
-        f = lb > kSliceLog ? lb - kSliceLog : 0;
-        g.kb = kKey2Bits;
+        if (lb > kSliceLog + 16) // more than 2^16 slices of 2^kSliceLog lines: wider slices, answered in rounds
+            g.slog = lb - 16;
+        f = lb > g.slog ? lb - g.slog : 0;
+        g.kb = g.slog + kOffBits;
         g.B = 0;
         g.bs = 0;
         g.binv = 0;
         g.total = 0;
-        g.slice_bits = (UINT64_C(1) << kSliceLog) * kDB;
+        g.slice_bits = (UINT64_C(1) << g.slog) * kDB;
     }
     else
     {
@@ -389,7 +395,7 @@ inline void sr_fill_geom(SrGeom & g, const BvView & v, int op, const SelectPlan 
         g.slice_bits = 0;
 }
 
-sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const SelectPlan & sp, unsigned nf, unsigned d2, const uint32_t * fstart,
+sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const SelectPlan & sp, unsigned nf, unsigned d2, unsigned slog, const uint32_t * fstart,
                                   const uint32_t * ioff, uint32_t * keys2, uint64_t * hf, uint32_t * marked, const uint32_t * go, hipStream_t s);
 void sr_launch_select_fixup(const BvView & v, int bit, const uint32_t * marked, const uint64_t * idx, uint64_t * out, uint64_t cnt,
                             const uint32_t * go, hipStream_t s);

@@ -868,7 +868,7 @@ sdsl_hip_status sw_run(const BvView & v, int op, int bit, const SelectPlan & sp,
     SwCallbacks cb;
     cb.fill = [&](SrGeom & g, uint64_t cnt) { sr_fill_geom(g, v, op, sp, cnt); };
     cb.answers = [&](const SrGeom & g, unsigned nf, const uint32_t * fstart, const uint32_t * ioff, uint32_t * keys2, uint64_t * hf,
-                     uint32_t * marked, hipStream_t st) { return sr_launch_answers(v, op, bit, sp, nf, g.d2, fstart, ioff, keys2, hf, marked, g.go, st); };
+                     uint32_t * marked, hipStream_t st) { return sr_launch_answers(v, op, bit, sp, nf, g.d2, g.slog, fstart, ioff, keys2, hf, marked, g.go, st); };
     if (op == 1)
         cb.fixup = [&](const uint32_t * marked, const uint64_t * idx, uint64_t * out, uint64_t cnt, hipStream_t st)
         { sr_launch_select_fixup(v, bit, marked, idx, out, cnt, go, st); };

@@ -1,6 +1,6 @@
 """BASELINE-size answers of the REAL sdsl-lite (run in the build container only; ~62 GB of RAM, 30-60 minutes).
 
-    python tests/golden/make_golden_large.py [c2] [c3] [c4] [c4sel]
+    python tests/golden/make_golden_large.py [c2] [c2w] [c3] [c4] [c4sel]
 
 Builds, through oracle/_ref/libsdsl_ref.so (the reference's headers compiled where they lie), the structures of
 BASELINE.json configs[1..4] on the SURVEY.md 8(d) inputs and stores what the GPU tests and bench.py compare against:
@@ -58,6 +58,29 @@ def main():
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
     R = ol.ref().L
     n = 1 << LOG_N
+
+    if "c2w" in want:
+        # rank_support_v5<1> / <0> of the real library on a 2^36-bit vector (words = mt19937_64(42) as for c2): beyond the 2^26
+        # rank lines the bucketed path handled until round 4 (a slice is 2^12 lines here, answered in four rounds)
+        t0 = time.time()
+        nw = 1 << 36
+        words = np.zeros(nw // 64 + 2, dtype=np.uint64)
+        R.ref_set_random_bits(words.ctypes.data, nw, 42)
+        h = R.ref_bv_create_rank(words.ctypes.data, nw)
+        del words
+        idx = pkg.rnd_positions(7, NQ, nw + 1, 0)
+        out = np.empty(NQ, dtype=np.uint64)
+        R.ref_bv_rank(h, 1, idx.ctypes.data, NQ, out.ctypes.data)
+        c2w = {"log_n": 36, "words_seed": 42, "rank_seed": 7, "rank_1": digest(out)}
+        R.ref_bv_rank(h, 0, idx.ctypes.data, NQ, out.ctypes.data)
+        c2w.update(rank_0=digest(out))
+        tot = np.empty(1, dtype=np.uint64)
+        R.ref_bv_rank(h, 1, np.array([nw], dtype=np.uint64).ctypes.data, 1, tot.ctypes.data)
+        c2w["ones"] = int(tot[0])
+        R.ref_bv_destroy(h)
+        res["c2w"] = c2w
+        json.dump(res, open(OUT, "w"))
+        print(f"c2w done in {time.time() - t0:.0f}s: ones={c2w['ones']}", flush=True)
 
     if "c2" in want:
         t0 = time.time()

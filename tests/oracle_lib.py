@@ -455,6 +455,7 @@ class OCsa:
 _REF_SIGS = {
     "ref_free": (None, [_vp]),
     "ref_bv_create": (_vp, [_vp, _u64]),
+    "ref_bv_create_rank": (_vp, [_vp, _u64]),
     "ref_bv_destroy": (None, [_vp]),
     "ref_bv_rank": (None, [_vp, C.c_int, _vp, _u64, _vp]),
     "ref_bv_rank_mt": (None, [_vp, C.c_int, _vp, _u64, _vp, C.c_int]),
