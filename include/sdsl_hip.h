@@ -475,7 +475,13 @@ sdsl_hip_status sdsl_hip_set_timing(int32_t enabled);
  * device (decoding them costs 63 dependent steps); within the budget the classes next to them follow, largest first, so
  * that fewer and fewer decoder steps remain per block (0: none beyond 11..52; a wavelet tree over text: 20 -> classes 9..54
  * raw, count 1.2x; 60 -> 4..59 raw, count 1.4x at +0.6 % of the index).  Answers and the serialised SDSL bytes do not
- * depend on it. */
+ * depend on it.
+ * "rrr_sparse_limit" (0..20, default 10): the largest class an rrr_vector<63> built or loaded AFTER the call may keep as an
+ * enumerative offset (and, through the complement, the smallest: 63 - limit); "rrr_raw_budget" then works downwards from
+ * there.  The default is about speed.  A vector of 10-30 % density consists of the classes 6..25: with the limit at 20 it
+ * takes 1.1-1.2 times the space of SDSL's rrr_vector<63> instead of 1.3-1.4 times, a block costs up to eighteen bisections
+ * to decode, and large batches stay on the direct kernels.  Answers and the serialised SDSL bytes do not depend on it
+ * (rrr_vector.hpp:158-270 stores every class as an offset). */
 sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value);
 /* "trace_phases" (0/1): the bucketed batch rank times each of its passes with HIP events on the launch stream (one host
  * synchronisation per call) and sdsl_hip_last_phases returns them as "select=0|1;hist1=ms;offs1=ms;part1=ms;..." for the

@@ -1511,6 +1511,10 @@ bool bv_sorted_rank_applicable(const BvView & v, uint64_t n)
     // the slices are streamed once per batch whatever its size and the table kernels cost 0.2 ms, so on 2^34 bits the passes take
     // 1.55 ms + 11.1 ns per 10^3 queries against the direct kernel's 23.1 — they cross at 1.3 x 10^8 queries = 3.4 per line
     // (bench.py extras.batch_sweep: 10^8 queries 37.6 against 43.2 G/s, 10^9: 73.9 against 43.2; round 3 switched at two per line)
+    // A vector of 2^20..2^22 lines lives in the Infinity Cache and the direct kernel runs at 49 G/s whatever the batch; the passes
+    // reach that at 10^8 queries and 61 G/s at 10^9 (extras.batch_sweep, 2^30 bits): from 2^29 queries on they are taken there too.
+    if (bv_sorted_rank_possible(v) && v.n_lines >= (UINT64_C(1) << 20) && v.n_lines < (UINT64_C(1) << 22))
+        return n >= (UINT64_C(1) << 29);
     return bv_sorted_rank_possible(v) && v.n_lines >= (UINT64_C(1) << 22) && n >= 4 * v.n_lines;
 }
 

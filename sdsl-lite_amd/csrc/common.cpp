@@ -11,6 +11,7 @@ static thread_local std::string g_err;
 static bool g_timing = false;
 // batched rank on a plain vector: -1 automatic, 0 always the direct kernel, 1 the bucketed path whenever it applies
 std::atomic<int> g_trace_phases{0};
+std::atomic<int> g_rrr_sparse_limit{10}; // largest class rrr_vector<63> may keep enumerative (rrr.hip: choose_sparse_max); up to 20
 std::atomic<int> g_rrr_raw_budget{20}; // permille of the compressed size rrr_vector<63> may spend on raw classes (rrr.hip)
 std::atomic<int> g_select_sorted_mode{getenv("SDSL_HIP_SELECT_SORTED") ? atoi(getenv("SDSL_HIP_SELECT_SORTED")) : -1};
 std::atomic<int> g_wt_select_sorted_mode{getenv("SDSL_HIP_WT_SELECT_SORTED") ? atoi(getenv("SDSL_HIP_WT_SELECT_SORTED")) : -1};
@@ -404,6 +405,16 @@ sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value)
             return SDSL_HIP_ERR_INVALID;
         }
         sdslhip::g_rrr_raw_budget.store((int)value);
+        return SDSL_HIP_OK;
+    }
+    if (name && !strcmp(name, "rrr_sparse_limit"))
+    { // the space / speed trade of rrr_vector<63> handles created from now on (rrr.hip: choose_sparse_max)
+        if (value < 0 || value > 20)
+        {
+            set_error("set_option: rrr_sparse_limit is the largest class kept enumerative (0..20, default 10)");
+            return SDSL_HIP_ERR_INVALID;
+        }
+        sdslhip::g_rrr_sparse_limit.store((int)value);
         return SDSL_HIP_OK;
     }
     if (name && !strcmp(name, "trace_phases"))

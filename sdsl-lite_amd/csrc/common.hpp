@@ -29,6 +29,7 @@ extern std::atomic<int> g_wt_select_sorted_mode; // sdsl_hip_set_option("wt_sele
 extern std::atomic<int> g_trace_phases;     // sdsl_hip_set_option("trace_phases", ...)
 void bv_sorted_clear_phases();              // bv_sorted.hip
 extern std::atomic<int> g_rrr_format;       // sdsl_hip_set_option("rrr_format", -1 | 0 | 1)
+extern std::atomic<int> g_rrr_sparse_limit; // sdsl_hip_set_option("rrr_sparse_limit", 0..20)
 extern std::atomic<int> g_rrr_raw_budget;   // sdsl_hip_set_option("rrr_raw_budget", permille)
 const char * last_error_message();
 void suppress_timing_in_this_thread(); // for good (pipeline worker threads)

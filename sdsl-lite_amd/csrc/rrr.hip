@@ -94,8 +94,8 @@ static RrrGeo geo_of(unsigned fmt)
 // inline area — is at least 5 % below the wide format's.
 static unsigned choose_format(const uint64_t hist[64], uint64_t n_blocks, const RrrTables & T, bool allow_slim)
 {
-    if (!allow_slim)
-        return 0;
+    if (!allow_slim || T.space[kEsc] != kRrrBS)
+        return 0; // (the slim format's escape is "class 15, raw": a vector that keeps class 15 enumerative stays wide)
     const int forced = g_rrr_format.load();
     if (forced == 0 || forced == 1)
         return (unsigned)forced;
@@ -129,15 +129,20 @@ static unsigned choose_sparse_max(const uint64_t hist[64], uint64_t n_bits)
     if (const char * e = getenv("SDSL_HIP_RRR_SPARSE_MAX"))
     { // experiment knob
         const int v = atoi(e);
-        if (v >= 0 && v <= 10)
+        if (v >= 0 && v <= 20)
             return (unsigned)v;
     }
+    // Where the search starts (option "rrr_sparse_limit", default 10).  A vector of 10-30 % density consists of classes 6..25, and
+    // with every class above 10 raw it takes 1.3-1.4 times SDSL's space; with the limit at 20 the classes up to 20 stay
+    // enumerative (1.12-1.14 times SDSL's: what is left is the 128-byte record), a block then costs up to eighteen bisections
+    // instead of eight, and the bucketed route (whose LDS image holds the binomial columns 3..10 only) is not taken.
+    const unsigned limit = (unsigned)std::min(20, std::max(0, g_rrr_sparse_limit.load()));
     const RrrTables & T = host_tables();
-    uint64_t size10 = 0; // about what the vector takes at t = 10: 13 bits of record per block + its field
+    uint64_t size10 = 0; // about what the vector takes at t = limit: 13 bits of record per block + its field
     for (unsigned k = 0; k < 64; ++k)
-        size10 += hist[k] * (13 + (k > 10 && k < 53 ? kRrrBS : (unsigned)T.sdsl_space[k]));
+        size10 += hist[k] * (13 + (k > limit && k < kRrrBS - limit ? kRrrBS : (unsigned)T.sdsl_space[k]));
     const int budget = g_rrr_raw_budget.load(); // permille of size10 (option "rrr_raw_budget", default 20)
-    unsigned t = 10;
+    unsigned t = limit;
     uint64_t extra = 0;
     while (t > 0)
     { // making classes t and 63 - t raw as well
@@ -1366,7 +1371,9 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
     // stays on the device, both routes are enqueued, the one whose turn it is not returns at once — as for the plain vector)
     RrrHost & h = v->h;
     const int mode = g_rrr_sorted_mode.load();
-    const bool want = mode == 0 ? false : (mode > 0 ? rrr_sorted_rank_possible(h.view) : rrr_sorted_rank_applicable(h.view, n));
+    // (a vector that keeps classes above 10 enumerative — option "rrr_sparse_limit" — is answered by the direct kernels: the slice
+    // decoder of rrr_sorted.hip stages the binomial columns of the classes up to 10)
+    const bool want = mode == 0 || h.sparse_max > 10 ? false : (mode > 0 ? rrr_sorted_rank_possible(h.view) : rrr_sorted_rank_applicable(h.view, n));
     if (want)
     {
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
@@ -1514,7 +1521,7 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
     // large spread batches: the bucketed path (rrr_sorted.hip), chosen as for rank (option "rrr_sorted")
     RrrHost & h = v->h;
     const int mode = g_rrr_sorted_mode.load();
-    if (mode != 0 && h.view.sel[bit] && (mode > 0 || (h.view.n_sb >= (UINT64_C(1) << 21) && n >= 8 * h.view.n_sb)))
+    if (mode != 0 && h.sparse_max <= 10 && h.view.sel[bit] && (mode > 0 || (h.view.n_sb >= (UINT64_C(1) << 21) && n >= 8 * h.view.n_sb)))
     {
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
         const bool cap = stream_is_capturing(s); // (nothing may be built or allocated then)
