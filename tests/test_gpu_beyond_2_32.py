@@ -1,0 +1,125 @@
+"""More than 2^32 symbols.  The reference's structures are width-agnostic (`int_vector<0>`, 64-bit positions: wt_pc.hpp:366-474,
+csa_wt.hpp:107-110, suffix_array_algorithm.hpp:167-248); 288 GB of HBM hold such inputs, so what can be built for them has to be
+right on them:
+
+* `wt_huff` over 2^32 + 10^6 symbols — rank, select and access against prefix counts computed on the device;
+* `csa_wt` over a 6.3-Gsymbol text, created from its BWT — `count`, the SA intervals, single backward-search steps and LF
+  against the CLOSED FORM of a periodic text (tests/periodic_text.py, checked against the oracle at small sizes on the CPU).
+
+Neither takes the fused 8-ary layout (its counts are 32-bit, wt.hip: wt_build_fused) nor the k-mer table and the text comparison
+of `count` (32-bit intervals, fm_count2.hip); building the index FROM TEXT needs the suffix sorter, which is 32-bit (sa.hip)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import periodic_text as pt
+
+pytestmark = pytest.mark.gpu
+
+
+def test_wt_huff_over_more_than_2_pow_32_symbols(gpu):
+    import torch
+    n, sigma = (1 << 32) + 1_000_003, 40
+    g = torch.Generator(device="cuda").manual_seed(5)
+    text = torch.empty(n, dtype=torch.uint8, device="cuda")
+    step = 1 << 28
+    for a in range(0, n, step):                        # a skewed alphabet: symbol = 1 + floor(sigma * u^2)
+        b = min(n, a + step)
+        u = torch.rand(b - a, device="cuda", generator=g)
+        text[a:b] = (1 + (u * u * sigma).to(torch.int64).clamp_(max=sigma - 1)).to(torch.uint8)
+    wt = gpu.wt_huff(text=text)
+    assert wt.size() == n and wt.sigma() == sigma
+    nq = 1_000_000
+    i = torch.randint(0, n + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
+    i[:1000] = n - torch.arange(1000, device="cuda")
+    i[1000:2000] = (1 << 32) - 500 + torch.arange(1000, device="cuda")
+    for c in (1, 2, sigma // 2, sigma, sigma + 3):
+        cs = torch.cumsum((text == c).to(torch.int64), 0)
+        want = torch.where(i > 0, cs[(i - 1).clamp_(min=0)], torch.zeros_like(i))
+        cc = torch.full((nq,), c, dtype=torch.uint8, device="cuda")
+        assert torch.equal(wt.rank(i, cc).to(torch.int64), want), f"rank(i, {c})"
+        total = int(cs[-1])
+        if total:
+            k = torch.randint(1, total + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
+            k[:1000] = total - torch.arange(1000, device="cuda").clamp_(max=total - 1)
+            assert torch.equal(wt.select(k, cc).to(torch.int64), torch.searchsorted(cs, k)), f"select(k, {c})"
+        del cs, want
+    cq = torch.randint(1, sigma + 1, (nq,), device="cuda", dtype=torch.int64, generator=g).to(torch.uint8)
+    j = torch.randint(0, n, (nq,), device="cuda", dtype=torch.int64, generator=g)
+    j[:1000] = n - 1 - torch.arange(1000, device="cuda")
+    assert torch.equal(wt.access(j).to(torch.uint8), text[j])
+    # mixed symbols in one batch: rank(j, text[j]) + 1 == inverse_select's rank, and select undoes it
+    r = wt.rank(j, text[j]).to(torch.int64)
+    assert torch.equal(wt.select(r + 1, text[j]).to(torch.int64), j)
+    del cq
+    wt.close()
+
+
+def test_csa_wt_over_more_than_2_pow_32_symbols_from_its_bwt(gpu):
+    import torch
+    p, k, sigma = 1 << 20, 6000, 20                                  # 6.3 Gsymbols: a third of the suffixes lie beyond 2^32
+    n = p * k
+    assert n > (1 << 32)
+    u = pt.unit(p, sigma, 9)
+    sau = pt.unit_suffix_array(u, ol.OCsa)
+    inv = np.empty(p, dtype=np.int64)
+    inv[sau] = np.arange(p)
+    bwt = pt.bwt_device(u, sau, k)
+    csa = gpu.csa_wt(bwt=bwt)
+    del bwt
+    assert csa.size() == n + 1 and csa.sigma() == sigma + 2          # V's bytes, '#', the sentinel
+    rng = np.random.default_rng(4)
+    for m in (1, 6, 20, 33):
+        npat = 6000
+        pos = rng.integers(0, n - m, npat)
+        pos[:200] = n - m - np.arange(200)                            # the text's end: the last copy's suffixes
+        pats = pt.text_at(u, pos, m).copy()
+        mut = rng.random(npat) < 0.3
+        pats[mut, rng.integers(0, m, int(mut.sum()))] = rng.integers(1, sigma + 3, int(mut.sum()), dtype=np.uint8)
+        flat = np.ascontiguousarray(pats.reshape(-1))
+        want = pt.count_in_text(u, k, pats)
+        got = np.asarray(csa.count(flat, m)).astype(np.uint64)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, f"m {m}: pattern {bytes(pats[bad[0]])!r}: got {got[bad[0]]}, want {want[bad[0]]}"
+        l, r = (np.asarray(a).astype(np.uint64) for a in csa.interval(flat, m))
+        occ = want > 0
+        assert np.array_equal((r + np.uint64(1) - l)[occ], want[occ])
+        assert (r[occ] > np.uint64(1 << 32)).any() and (l[occ] < np.uint64(1 << 32)).any()
+        # the interval itself: the suffixes that start with an occurring pattern are those of the offsets whose suffix of U U
+        # starts with it — consecutive ranks [ra, rb] — all k copies of each; a pattern that does not fit into the last copy
+        # contains '#', matches at ONE offset, and that offset loses its first (smallest) suffix
+        if m == 20:
+            uu = np.concatenate([u, u])
+            for q in np.flatnonzero(occ)[:300]:
+                i0 = int(pos[q] % p) if not mut[q] else None
+                if i0 is None:
+                    continue
+                ra = rb = int(inv[i0])
+                while ra > 0 and np.array_equal(uu[sau[ra - 1]:sau[ra - 1] + m], pats[q]):
+                    ra -= 1
+                while rb + 1 < p and np.array_equal(uu[sau[rb + 1]:sau[rb + 1] + m], pats[q]):
+                    rb += 1
+                first = 1 + ra * k + (1 if sau[ra] + m > p else 0)
+                assert int(l[q]) == first, (q, int(l[q]), first)
+    # LF at places on both sides of 2^32: the suffix in front of (offset i, copy j) is (i - 1, j); in front of offset 0 stands
+    # the '#' of the copy before
+    x = np.concatenate([rng.integers(1, n + 1, 200_000), np.array([1, n, (1 << 32) - 1, 1 << 32, (1 << 32) + 1])]).astype(np.int64)
+    rk, t = (x - 1) // k, (x - 1) % k
+    i = sau[rk]
+    want_lf = np.where(i > 0, 1 + inv[np.maximum(i - 1, 0)] * k + t, 1 + inv[p - 1] * k + t + 1)
+    whole = (i == 0) & (t == k - 1)                                   # the suffix that is all of T: LF leads to the sentinel's row
+    want_lf[whole] = 0
+    got_lf = np.asarray(csa.lf(x.astype(np.uint64))).astype(np.int64)
+    assert np.array_equal(got_lf, want_lf)
+    # single backward-search steps on intervals beyond 2^32 (suffix_array_algorithm.hpp:167-200): extend every pattern's interval
+    # by the character in front of one of its occurrences and compare with the search for the longer pattern
+    m = 12
+    pos = rng.integers(1, n - m, 4000)
+    pats = pt.text_at(u, pos, m)
+    longer = pt.text_at(u, pos - 1, m + 1)
+    l, r = csa.interval(np.ascontiguousarray(pats.reshape(-1)), m)
+    l2, r2 = csa.backward_search(l, r, np.ascontiguousarray(longer[:, 0]))
+    lw, rw = csa.interval(np.ascontiguousarray(longer.reshape(-1)), m + 1)
+    assert np.array_equal(np.asarray(l2), np.asarray(lw)) and np.array_equal(np.asarray(r2), np.asarray(rw))
+    assert (np.asarray(lw).astype(np.uint64) > np.uint64(1 << 32)).any()
+    csa.close()
