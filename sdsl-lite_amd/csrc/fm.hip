@@ -432,6 +432,34 @@ static sdsl_hip_status sdsl_hip_fm_create_from_text_ex_impl(const uint8_t * text
         return SDSL_HIP_ERR_INVALID;
     }
     DevBuf d_bwt, d_sa;
+    const char * force64 = getenv("SDSL_HIP_SA64"); // (test knob: the 64-bit sorter on a text of any size)
+    if (n_text + 1 >= UINT64_C(0xFFFFFFFE) || (force64 && atoi(force64) != 0))
+    { // 2^32 symbols and more: 64-bit suffixes (sa.hip).  The index keeps SA / ISA samples at SDSL's default densities instead of
+      // the whole array (csa_wt<..., 32, 64>: csa_wt.hpp:56), and neither the text nor the k-mer table: count() walks every
+      // character over the binary levels of the wavelet tree (the fused layout and the flat count kernel hold 32-bit counts).
+        SH_TRY(sa_build_bwt_device64(text, n_text, device, d_bwt, d_sa));
+        sdsl_hip_fm_s * f = new (std::nothrow) sdsl_hip_fm_s();
+        if (!f)
+            return SDSL_HIP_ERR_NOMEM;
+        const uint64_t n = n_text + 1;
+        sdsl_hip_status st = sa_samples_device64(d_sa.as<uint64_t>(), n, 32, 64, &f->d_sa_s, &f->d_isa_s);
+        d_sa.release();
+        if (st == SDSL_HIP_OK)
+        {
+            f->sa_dens = 32;
+            f->isa_dens = 64;
+            f->n_sa_s = (n + 31) / 32;
+            f->n_isa_s = (n + 63) / 64;
+            st = fm_from_device_bwt(f, d_bwt.as<uint8_t>(), n, device, flags);
+        }
+        if (st != SDSL_HIP_OK)
+        {
+            fm_free(f);
+            return st;
+        }
+        *out = f;
+        return SDSL_HIP_OK;
+    }
     SH_TRY(sa_build_bwt_device(text, n_text, device, d_bwt, d_sa)); // suffix array and BWT never leave the device
     sdsl_hip_fm_s * f = new (std::nothrow) sdsl_hip_fm_s();
     if (!f)
@@ -748,9 +776,13 @@ static sdsl_hip_status sdsl_hip_fm_serialize_ex_impl(sdsl_hip_fm_t fm, int32_t l
         set_error("fm_serialize: invalid argument");
         return SDSL_HIP_ERR_INVALID;
     }
-    if (!fm->d_sa.p)
+    // samples come from the whole suffix array or, without it, from the samples the index holds — at their densities only (an
+    // index of 2^32 symbols and more built from text keeps csa_wt's default 32 / 64; so does one loaded from a stream)
+    const bool from_samples = !fm->d_sa.p && fm->d_sa_s.p && fm->d_isa_s.p && fm->sa_dens == sa_dens && fm->isa_dens == isa_dens;
+    if (!fm->d_sa.p && !from_samples)
     {
-        set_error("fm_serialize: the suffix array is not available (index not created from text, or dropped)");
+        set_error("fm_serialize: the suffix array is not available (index not created from text, or dropped) and the index holds no "
+                  "samples of the densities %u / %u", sa_dens, isa_dens);
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
     SH_HIP(hipSetDevice(fm->device));
@@ -764,7 +796,15 @@ static sdsl_hip_status sdsl_hip_fm_serialize_ex_impl(sdsl_hip_fm_t fm, int32_t l
     // 2. SA and ISA samples as int_vector<0> of width hi(n)+1
     const uint64_t n = fm->size;
     std::vector<uint64_t> sa_s, isa_s;
-    SH_TRY(sa_samples_to_host(fm->d_sa.as<uint32_t>(), n, sa_dens, isa_dens, sa_s, isa_s));
+    if (from_samples)
+    {
+        sa_s.resize(fm->n_sa_s);
+        isa_s.resize(fm->n_isa_s);
+        SH_HIP(hipMemcpy(sa_s.data(), fm->d_sa_s.p, fm->n_sa_s * 8, hipMemcpyDeviceToHost));
+        SH_HIP(hipMemcpy(isa_s.data(), fm->d_isa_s.p, fm->n_isa_s * 8, hipMemcpyDeviceToHost));
+    }
+    else
+        SH_TRY(sa_samples_to_host(fm->d_sa.as<uint32_t>(), n, sa_dens, isa_dens, sa_s, isa_s));
     const uint8_t width = (uint8_t)(hi64(n) + 1);
     PackedBuilder ps(sa_s.size(), width), pi(isa_s.size(), width);
     for (uint64_t i = 0; i < sa_s.size(); ++i)

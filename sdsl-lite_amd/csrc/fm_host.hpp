@@ -69,6 +69,10 @@ struct FmLocView
 };
 
 sdsl_hip_status sa_build_bwt_device(const uint8_t * text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa);
+// texts of 2^32 - 2 bytes and more: 64-bit suffixes (d_sa: u64 per suffix)
+sdsl_hip_status sa_build_bwt_device64(const uint8_t * text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa);
+sdsl_hip_status sa_samples_device64(const uint64_t * d_sa, uint64_t n, uint64_t sa_dens, uint64_t isa_dens, DevBuf * sa_s,
+                                    DevBuf * isa_s);
 sdsl_hip_status sa_samples_to_host(const uint32_t * d_sa, uint64_t n, uint64_t sa_dens, uint64_t isa_dens,
                                    std::vector<uint64_t> & sa_s, std::vector<uint64_t> & isa_s);
 // samples from the full suffix array, left on the device (either output may be null)

@@ -123,3 +123,82 @@ def test_csa_wt_over_more_than_2_pow_32_symbols_from_its_bwt(gpu):
     assert np.array_equal(np.asarray(l2), np.asarray(lw)) and np.array_equal(np.asarray(r2), np.asarray(rw))
     assert (np.asarray(lw).astype(np.uint64) > np.uint64(1 << 32)).any()
     csa.close()
+
+
+def test_the_64_bit_suffix_sorter_on_small_texts(gpu, monkeypatch):
+    """SDSL_HIP_SA64=1 sends a text of any size through the sorter for 2^32 symbols and more (sa.hip: two stable sorts per
+    doubling round, 64-bit suffixes) and the index keeps SA / ISA samples instead of the whole array: suffix array, inverse,
+    count, locate and extract against the oracle, on texts with long repeats (many rounds) and on a periodic one."""
+    rng = np.random.default_rng(8)
+    texts = [rng.integers(1, 5, 70_001, dtype=np.uint8), np.tile(pt.unit(257, 3, 1), 41), np.full(5000, 7, dtype=np.uint8),
+             np.frombuffer(b"abracadabra", dtype=np.uint8), np.array([9], dtype=np.uint8)]
+    texts[0][30_000:34_000] = texts[0][1000:5000]
+    for text in texts:
+        n = text.size
+        ocsa = ol.OCsa(bytes(text))
+        monkeypatch.delenv("SDSL_HIP_SA64", raising=False)
+        ref = gpu.csa_wt(text=text)
+        monkeypatch.setenv("SDSL_HIP_SA64", "1")
+        csa = gpu.csa_wt(text=text)
+        assert csa.sampling() == (32, 64, False) and ref.sampling() == (0, 0, True)
+        assert csa.serialize(32, 64) == ref.serialize(32, 64), "the stream of csa_wt<wt_huff<>, 32, 64> from the samples the index keeps"
+        with pytest.raises(Exception):
+            csa.serialize(16, 64)
+        ref.close()
+        idx = np.arange(n + 1, dtype=np.uint64) if n < 20_000 else rng.integers(0, n + 1, 20_000).astype(np.uint64)
+        assert np.array_equal(np.asarray(csa.sa(idx)), np.asarray(ocsa.sa(idx)))
+        assert np.array_equal(np.asarray(csa.isa(idx)), np.asarray(ocsa.isa(idx)))
+        m = min(6, n)
+        st = rng.integers(0, n - m + 1, 3000)
+        pats = text[st[:, None] + np.arange(m)[None, :]].copy()
+        pats[::4, 0] = 3
+        want = np.array([ocsa.count(bytes(r)) for r in pats], dtype=np.uint64)
+        assert np.array_equal(np.asarray(csa.count(np.ascontiguousarray(pats.reshape(-1)), m)).astype(np.uint64), want)
+        for r in pats[:20]:
+            got = np.sort(np.asarray(csa.locate(np.ascontiguousarray(r), m)[1]))
+            assert np.array_equal(got, np.sort(ocsa.locate(bytes(r)))), bytes(r)
+        assert bytes(np.asarray(csa.extract(np.array([0], dtype=np.uint64), np.array([n - 1], dtype=np.uint64))[1])) == bytes(text)
+        csa.close()
+
+
+def test_csa_wt_from_a_text_of_more_than_2_pow_32_symbols(gpu):
+    """construct(csa, text) on 4.3 G symbols: the suffix sorter's array against the closed form (through the index's SA / ISA
+    samples: csa[i], isa[i]), the BWT through count, locate and extract."""
+    import torch
+    p, k, sigma = 1 << 20, 4100, 20
+    n = p * k
+    assert n > (1 << 32)
+    u = pt.unit(p, sigma, 9)
+    sau = pt.unit_suffix_array(u, ol.OCsa)
+    inv = np.empty(p, dtype=np.int64)
+    inv[sau] = np.arange(p)
+    text = torch.from_numpy(u).cuda().repeat(k)
+    csa = gpu.csa_wt(text=text)
+    assert csa.size() == n + 1 and csa.sigma() == sigma + 2 and csa.sampling() == (32, 64, False)
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.integers(1, n + 1, 100_000), np.array([0, 1, n, (1 << 32) - 1, 1 << 32, (1 << 32) + 1])]).astype(np.int64)
+    rk, t = (x - 1) // k, (x - 1) % k
+    want_sa = np.where(x > 0, sau[np.maximum(rk, 0)] + (k - 1 - t) * p, n)
+    assert np.array_equal(np.asarray(csa.sa(x.astype(np.uint64))).astype(np.int64), want_sa)
+    pos = np.concatenate([rng.integers(0, n, 100_000), np.array([0, n - 1, n, (1 << 32) - 1, 1 << 32])]).astype(np.int64)
+    want_isa = np.where(pos < n, 1 + inv[pos % p] * k + (k - 1 - pos // p), 0)
+    assert np.array_equal(np.asarray(csa.isa(pos.astype(np.uint64))).astype(np.int64), want_isa)
+    m = 24
+    st = rng.integers(0, n - m, 3000)
+    pats = pt.text_at(u, st, m).copy()
+    pats[::5, 3] = 1 + rng.integers(0, sigma + 1)
+    want = pt.count_in_text(u, k, pats)
+    assert np.array_equal(np.asarray(csa.count(np.ascontiguousarray(pats.reshape(-1)), m)).astype(np.uint64), want)
+    q = int(np.flatnonzero(want > 0)[0])
+    off, where = csa.locate(np.ascontiguousarray(pats[q]), m)
+    where = np.sort(np.asarray(where).astype(np.int64))
+    assert where.size == int(want[q]) and np.unique(where).size == where.size
+    assert all(np.array_equal(pt.text_at(u, where[:50], m)[i], pats[q]) for i in range(min(50, where.size)))
+    assert where[-1] > (1 << 32)
+    b = np.array([0, (1 << 32) - 10, n - 40], dtype=np.uint64)
+    e = b + np.uint64(39)
+    offs, got = csa.extract(b, e)
+    got = np.asarray(got)
+    for i in range(3):
+        assert np.array_equal(got[i * 40:(i + 1) * 40], pt.text_at(u, np.array([int(b[i])]), 40)[0])
+    csa.close()
