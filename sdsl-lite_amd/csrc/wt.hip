@@ -1106,6 +1106,32 @@ __global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint6
     reinterpret_cast<uint32_t *>(fl + line * kFusedWords + 4 * (t >> 1))[t & 1] = ok ? (uint32_t)i : 0u;
 }
 
+// Sequences of 2^32 symbols and more: the headers hold the low 32 bits of their counts; a count that passes a multiple of 2^32
+// between the headers of two consecutive lines shows as a header smaller than its predecessor (a line adds at most 256).  Thread
+// (line, t) of node u notes the line FROM which the count is past the multiple (WtFusedTables::cross_*).
+__global__ __launch_bounds__(256) void k_wt8_cross(const uint64_t * __restrict__ fl, uint64_t n_lines_u, uint32_t first_line, uint32_t u,
+                                                   uint32_t * __restrict__ n_out, uint32_t * __restrict__ line_out,
+                                                   uint32_t * __restrict__ key_out)
+{
+    const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t line = id >> 3;
+    const unsigned t = (unsigned)id & 7u;
+    if (line + 1 >= n_lines_u)
+        return;
+    const uint64_t * ln = fl + line * kFusedWords;
+    const uint32_t c0 = reinterpret_cast<const uint32_t *>(ln + 4 * (t >> 1))[t & 1];
+    const uint32_t c1 = reinterpret_cast<const uint32_t *>(ln + kFusedWords + 4 * (t >> 1))[t & 1];
+    if (c1 < c0)
+    {
+        const uint32_t e = atomicAdd(n_out, 1u);
+        if (e < kFusedMaxCross)
+        {
+            line_out[e] = first_line + (uint32_t)line + 1;
+            key_out[e] = (u << 3) | t;
+        }
+    }
+}
+
 // select directory of one fused node: thread (line, t) knows which occurrences of t fall into its line from two
 // neighbouring headers; if occurrence 256 * j is among them it finds its position in the line's match masks
 struct FselNodeArgs
@@ -1242,11 +1268,41 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
         hipLaunchKernelGGL(k_wt8_counts, dim3(grid_for(lines_v * 8, 256, 1u << 20)), dim3(256), 0, 0, view, v, lines_v, at);
     }
     SH_HIP(hipGetLastError());
+    if (wt.size >> 32)
+    { // where the counts pass multiples of 2^32 (wt_device.hpp: WtFusedTables)
+        DevBuf d_cross;
+        SH_TRY(d_cross.alloc((1 + 2 * kFusedMaxCross) * 4, true));
+        uint32_t * dc = d_cross.as<uint32_t>();
+        for (uint32_t v : roots)
+            if (size[v] >> 32)
+            {
+                const uint64_t lines_v = (size[v] >> kFusedLog) + 1;
+                hipLaunchKernelGGL(k_wt8_cross, dim3(grid_for(lines_v * 8, 256, 1u << 20)), dim3(256), 0, 0,
+                                   fl + (uint64_t)FT.fline[v] * kFusedWords, lines_v, FT.fline[v], v, dc, dc + 1, dc + 1 + kFusedMaxCross);
+            }
+        SH_HIP(hipGetLastError());
+        std::vector<uint32_t> h(1 + 2 * kFusedMaxCross);
+        SH_HIP(hipMemcpy(h.data(), dc, h.size() * 4, hipMemcpyDeviceToHost));
+        if (h[0] > kFusedMaxCross)
+        { // (a sequence of 2^36 symbols and more: the binary levels answer)
+            dst.d_fused.release();
+            return SDSL_HIP_OK;
+        }
+        FT.n_cross = h[0];
+        for (uint32_t e = 0; e < h[0]; ++e)
+        {
+            FT.cross_line[e] = h[1 + e];
+            FT.cross_key[e] = (uint16_t)h[1 + kFusedMaxCross + e];
+        }
+        if (trace)
+            fprintf(stderr, "[sdsl_hip] fused layout: %u places where a count passes a multiple of 2^32\n", h[0]);
+    }
     SH_TRY(dst.d_ftables.alloc(sizeof(WtFusedTables)));
     SH_HIP(hipMemcpy(dst.d_ftables.p, &FT, sizeof(WtFusedTables), hipMemcpyHostToDevice));
     // select directory (skipped for trees with more fused nodes than its table holds: select then walks the binary levels)
     const char * env_sel = getenv("SDSL_HIP_WT_FUSED_SELECT"); // 0: select keeps walking the binary levels
-    if (roots.size() <= (size_t)kFselMaxRoots && !(env_sel && atoi(env_sel) == 0))
+    // (and for sequences of 2^32 symbols and more: the directory holds 32-bit positions)
+    if (roots.size() <= (size_t)kFselMaxRoots && !(env_sel && atoi(env_sel) == 0) && !(wt.size >> 32))
     {
         std::vector<WtFusedSelTables> fs_store(1);
         WtFusedSelTables & FS = fs_store[0];
@@ -1312,9 +1368,9 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
     const char * env = getenv("SDSL_HIP_WT_FUSED");
     if (env && atoi(env) == 0)
         return SDSL_HIP_OK;
-    if (wt.backend != 0 || wt.sigma < 2 || wt.n_nodes < 3 || wt.size == 0 || wt.size >= (UINT64_C(1) << 32) ||
+    if (wt.backend != 0 || wt.sigma < 2 || wt.n_nodes < 3 || wt.size == 0 || wt.size >= (UINT64_C(1) << 36) ||
         !wt.d_tables.p)
-        return SDSL_HIP_OK;
+        return SDSL_HIP_OK; // (2^32 .. 2^36 symbols: rank / access / LF on the fused lines, select on the binary levels)
     // The fused layout serves rank / access / select, whose answers do not depend on the tree's shape, so it gets the
     // shape that suits it: an 8-ary Huffman tree (fewest fused steps per symbol) instead of SDSL's binary tree cut
     // into groups of three levels.  The symbols are read back from the binary levels, a throw-away binary tree of the

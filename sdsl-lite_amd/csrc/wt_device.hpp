@@ -28,9 +28,18 @@ struct WtTables // global-memory image, identical layout in LDS
     uint16_t c_to_leaf[256];
 };
 
+// Sequences of 2^32 symbols and more: a line's header keeps the LOW 32 bits of its counts, and the places where a count passes a
+// multiple of 2^32 are listed here — entry e: the count of slot (cross_key & 7) in fused node (cross_key >> 3) is below
+// j * 2^32 in front of every line before absolute line cross_line[e] and at least that from it on.  There is one entry per (node,
+// slot, j): a handful for a text of a few 2^32 symbols; the walk adds 2^32 for every entry of its (node, slot) at or in front of
+// its line.  Sequences below 2^32 symbols have no entries and never look (`wt.size >> 32` is kernel-uniform).
+constexpr unsigned kFusedMaxCross = 64;
 struct WtFusedTables // node tables of the fused layout (below); staged in LDS by the kernels that walk it
 {
     uint32_t fline[kWtMaxNodes]; // first line of the node's sequence (nodes at depth 0, 3, 6, ...)
+    uint32_t n_cross;
+    uint32_t cross_line[kFusedMaxCross];
+    uint16_t cross_key[kFusedMaxCross];
 };
 
 // select on the fused layout: for every fused node u and slot t the directory lists the position (inside u's sequence)
@@ -148,7 +157,7 @@ __device__ __forceinline__ void quad_wt_rank2_level(const WtView & wt, const WtT
 // slice of the binary tree), each symbol reduced to a 3-bit SLOT = its next three path bits (a leaf reached earlier
 // pads with zeros).  128-byte line = 4 sections of 32 bytes; section s = [count[2s] | count[2s+1] << 32, plane 0,
 // plane 1, plane 2] for positions 64s .. 64s+63 of the line's 256: count[t] = occurrences of slot t in the node's
-// sequence before the line (32 bits: the layout is built for sequences below 2^32), plane k = bit k of the slots.
+// sequence before the line (its low 32 bits: WtFusedTables lists where a count passes 2^32), plane k = bit k of the slots.
 // One fetch answers "how many of the first i symbols of u continue along slot t" = the offset inside the node three
 // levels down; the answers are those of the binary cascade, level for level.
 struct FSec
@@ -192,6 +201,24 @@ __device__ __forceinline__ unsigned fsec_count(const FSec & x, int s, unsigned o
     return cnt + hdr;
 }
 
+// the same summed over the quad — for every size of sequence: `u` the fused node, `abs_line` the line's index in the layout
+__device__ __forceinline__ uint64_t quad_fsec_count(const WtView & wt, const WtFusedTables * FT, const FSec & x, int s, unsigned off,
+                                                    unsigned t, unsigned u, uint64_t abs_line)
+{
+    if (!(wt.size >> 32)) // kernel-uniform
+        return quad_sum(fsec_count(x, s, off, t));
+    // header and in-line part apart: their sum may pass 2^32 inside the line
+    const uint64_t m = ((t & 1) ? x.p0 : ~x.p0) & ((t & 2) ? x.p1 : ~x.p1) & ((t & 4) ? x.p2 : ~x.p2);
+    const int tt = (int)off - 64 * s;
+    const unsigned cnt = tt <= 0 ? 0u : (tt >= 64 ? popc64(m) : popc64(m << (64 - tt)));
+    const unsigned hdr = (s == (int)(t >> 1)) ? (unsigned)(x.h >> (32 * (t & 1))) : 0u;
+    uint64_t hi = 0;
+    const unsigned key = (u << 3) | t, nc = FT->n_cross;
+    for (unsigned e = 0; e < nc; ++e)
+        hi += (FT->cross_key[e] == key && (uint64_t)FT->cross_line[e] <= abs_line) ? 1u : 0u;
+    return (hi << 32) + (uint64_t)quad_sum(hdr) + quad_sum(cnt);
+}
+
 // the slot stored at position `off` of the line (all four lanes get it)
 __device__ __forceinline__ unsigned quad_fsec_slot(const FSec & x, int s, unsigned off)
 {
@@ -232,9 +259,10 @@ __device__ __forceinline__ void quad_wt8_rank2_step(const WtView & wt, const WtT
     FSec xa = xb;
     if (La != Lb) // quad-uniform
         xa = load_fsec<NT>(wt.f_lines, La, s);
+    const unsigned u = v;
     v = wt_descend(T, v, t); // LDS lookups overlap the line fetches
-    a = quad_sum(fsec_count(xa, s, (unsigned)a & 255u, t));
-    b = quad_sum(fsec_count(xb, s, (unsigned)b & 255u, t));
+    a = quad_fsec_count(wt, FT, xa, s, (unsigned)a & 255u, t, u, La);
+    b = quad_fsec_count(wt, FT, xb, s, (unsigned)b & 255u, t, u, Lb);
     p >>= k;
     left -= k;
 }
@@ -256,9 +284,11 @@ __device__ __forceinline__ uint64_t quad_wt8_rank(const WtView & wt, const WtTab
     {
         const unsigned k = left < 3 ? left : 3;
         const unsigned t = (unsigned)p & ((1u << k) - 1u);
-        FSec x = load_fsec<NT>(wt.f_lines, FT->fline[v] + (res >> kFusedLog), s);
+        const uint64_t L = FT->fline[v] + (res >> kFusedLog);
+        FSec x = load_fsec<NT>(wt.f_lines, L, s);
+        const unsigned u = v;
         v = wt_descend(T, v, t); // LDS lookups overlap the line fetch
-        res = quad_sum(fsec_count(x, s, (unsigned)res & 255u, t));
+        res = quad_fsec_count(wt, FT, x, s, (unsigned)res & 255u, t, u, L);
         p >>= k;
         left -= k;
     }
@@ -361,10 +391,11 @@ template <bool NT>
 __device__ __forceinline__ void quad_wt8_invsel_step(const WtView & wt, const WtTables * T, const WtFusedTables * FT,
                                                      int s, unsigned & v, uint64_t & i)
 {
-    FSec x = load_fsec<NT>(wt.f_lines, FT->fline[v] + (i >> kFusedLog), s);
+    const uint64_t L = FT->fline[v] + (i >> kFusedLog);
+    FSec x = load_fsec<NT>(wt.f_lines, L, s);
     const unsigned off = (unsigned)i & 255u;
     const unsigned t = quad_fsec_slot(x, s, off);
-    i = quad_sum(fsec_count(x, s, off, t));
+    i = quad_fsec_count(wt, FT, x, s, off, t, v, L);
     v = wt_descend(T, v, t);
 }
 

@@ -634,9 +634,11 @@ def test_fm_built_on_gpu_serializes_to_sdsl_bytes(gpu, name):
     if ol.have_ref():
         t = gd.text(name)[:5000]
         assert gpu.csa_wt(text=t).serialize(1 << 20, 1 << 20) == ol.RCsa(t, also_fm_huff=True).serialize(1)
-    csa.drop_sa()
+    default_type = csa.serialize(32, 64)
+    csa.drop_sa()                                      # the samples 32 / 64 stay: the stream of csa_wt<..., 32, 64> can still be written
+    assert csa.serialize(32, 64) == default_type
     with pytest.raises(gpu.capi.SdslHipError):
-        csa.serialize(32, 64)
+        csa.serialize(1 << 20, 1 << 20)
 
 
 # ---------------------------------------------------------------------------------------------------
