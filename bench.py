@@ -59,7 +59,8 @@ def parse():
     p.add_argument("--log-n", type=int, default=34, help="bit vector length = 2^log_n (BASELINE: 34)")
     p.add_argument("--queries", type=float, default=1e9, help="queries per step per GPU (BASELINE: 1e9)")
     p.add_argument("--extras", type=str, default=None,
-                   help="comma list of: e2e,sweep,select,rrr,sd,shapes,wt,fm,fm_sharded,group (or 'none'); default: the first eight on one "
+                   help="comma list of: e2e,sweep,select,rrr,sd,shapes,wt,fm,big,fm_sharded,group (or 'none'); big = an index of 2^32 + 777 symbols "
+                        "(opt-in: 172 GB of working memory); default: the first eight on one "
                         "GPU, fm_sharded (configs[4]: 10^8 patterns sharded over the ranks) on several; group = rank 0 also drives all "
                         "GPUs through the C ABI's device group (RCCL point-to-point between devices: opt-in, it has not run on "
                         "hardware with more than one device yet and must not endanger the scaling run)")
@@ -1100,6 +1101,41 @@ def main():
                                           "sigma": c28.sigma(), "jump_depth": c28.jump_depth(),
                                           "text": "Zipf over a 4096-word lowercase vocabulary (round 1's stand-in)"}
                 del c28, t28, p28, st28
+
+        if "big" in extras and world == 1 and rank == 0:
+            # An index of more than 2^32 symbols (opt-in: 172 GB of working memory in the suffix sorter): csa_wt from a
+            # synthetic text of 2^32 + 777 symbols — 64-bit suffix sorter, fused lines with the 2^32-crossing list, SA / ISA
+            # samples instead of the whole array (answers checked by tests/test_gpu_beyond_2_32.py).
+            torch.cuda.empty_cache()
+            nb, sg = (1 << 32) + 777, 40
+            gb = torch.Generator(device=dev).manual_seed(1)
+            tb = torch.empty(nb, dtype=torch.uint8, device=dev)
+            for a0 in range(0, nb, 1 << 28):
+                b0 = min(nb, a0 + (1 << 28))
+                uu = torch.rand(b0 - a0, device=dev, generator=gb)
+                tb[a0:b0] = (1 + (uu * uu * sg).to(torch.int64).clamp_(max=sg - 1)).to(torch.uint8)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cb = pkg.csa_wt(text=tb, device=local)
+            torch.cuda.synchronize()
+            build_s = time.perf_counter() - t0
+            npb, mb = 10_000_000, 20
+            stb = torch.randint(0, nb - mb, (npb,), device=dev, dtype=torch.int64, generator=gb)
+            pb = tb[(stb.view(-1, 1) + torch.arange(mb, device=dev).view(1, mb)).reshape(-1)].contiguous()
+            ob = torch.empty(npb, dtype=torch.int64, device=dev)
+            _, ms_c = time_steps(lambda: cb.count(pb, mb, ob), 2, 1, barrier)
+            nrb = 100_000_000
+            ib = torch.randint(0, nb + 1, (nrb,), device=dev, dtype=torch.int64, generator=gb)
+            sb = tb[torch.randint(0, nb, (nrb,), device=dev, dtype=torch.int64, generator=gb)]
+            orb = torch.empty(nrb, dtype=torch.int64, device=dev)
+            wtb = cb.wavelet_tree
+            _, ms_r = time_steps(lambda: wtb.rank(ib, sb, out=orb), 2, 1, barrier)
+            ex["beyond_2_32"] = {"symbols": nb, "sigma": sg, "build_from_text_s": build_s, "resident_GB": cb.device_bytes() / 1e9,
+                                 "sampling": list(cb.sampling()), "count_Mcount/s": npb / ms_c / 1e3, "patterns": npb, "m": mb,
+                                 "every_pattern_found": bool((ob >= 1).all()), "wt_rank_Gq/s": nrb / ms_r / 1e6,
+                                 "note": "fused lines with the 2^32-crossing list; the flat count kernel and its k-mer table are 32-bit and not used"}
+            del wtb, cb, tb, pb, ob, ib, sb, orb, stb
+            torch.cuda.empty_cache()
 
         if "fm_sharded" in extras and world > 1:
             # the headline queries as a ROOT-OWNED batch (the end-to-end column): rank 0 holds all
