@@ -1563,9 +1563,11 @@ __global__ __launch_bounds__(1024) void k_sr_sample_spread(SrGeom g, const uint6
         out[0] = n_distinct;
         out[1] = n_valid;
         // uniformly random samples over S slices touch S * (1 - exp(-m / S)) of them; half of the samples' own number is far below
-        // that for every vector the bucketed path applies to (>= 2^12 slices) and far above what a window or a sorted batch gives
+        // that for every vector of >= 2^13 slices and far above what a window or a sorted batch gives.  A smaller vector has
+        // between half and all of its 2^(d1 + d2) nominal slices: a quarter of the nominal number then (2^30 bits = 2341 slices of
+        // 4096: uniform samples touch 1930 — the former limit of 2048 kept such a vector off the passes for good)
         const unsigned slices = 1u << (g.d1 + g.d2);
-        const unsigned limit = n_valid / 2 < slices / 2 ? n_valid / 2 : slices / 2;
+        const unsigned limit = n_valid / 2 < slices / 4 ? n_valid / 2 : slices / 4;
         out[2] = n_valid >= 1024 && n_distinct >= limit ? 1u : 0u; // the verdict: the batch is spread over the vector
     }
 }

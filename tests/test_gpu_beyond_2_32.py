@@ -6,8 +6,12 @@ right on them:
 * `csa_wt` over a 6.3-Gsymbol text, created from its BWT — `count`, the SA intervals, single backward-search steps and LF
   against the CLOSED FORM of a periodic text (tests/periodic_text.py, checked against the oracle at small sizes on the CPU).
 
-Neither takes the fused 8-ary layout (its counts are 32-bit, wt.hip: wt_build_fused) nor the k-mer table and the text comparison
-of `count` (32-bit intervals, fm_count2.hip); building the index FROM TEXT needs the suffix sorter, which is 32-bit (sa.hip)."""
+* `csa_wt` from a TEXT of 4.3 G symbols (64-bit suffix sorter, sa.hip): csa[i], isa[i], count, locate, extract against the same
+  closed form; the sorter on small texts against the oracle.
+
+Sequences of 2^32 .. 2^36 symbols walk the fused 8-ary layout with the list of places where a count passes a multiple of 2^32
+(wt_device.hpp: WtFusedTables::cross_*) for rank / access / LF / count; select walks the binary levels; the flat count kernel and
+its k-mer table (32-bit intervals, fm_count2.hip) are not used."""
 import numpy as np
 import pytest
 
