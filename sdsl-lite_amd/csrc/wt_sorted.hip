@@ -210,6 +210,227 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_sorted(WtView wt, const ui
     }
 }
 
+// ---- one LANE per key ------------------------------------------------------------------------------------------------
+// The quad form spends four lanes on every scalar step of a key's walk (bracket, interpolation, compare, the bookkeeping of the
+// flat loop) and the kernel was bound by exactly that: VALU share of issue 0.86, 7 of the call's 9 ms.  Inside a bucket the lines a
+// key needs are in the cache whoever fetches them, so here a lane walks its key alone: it reads the probed 128-byte line itself
+// (eight 16-byte loads), counts its four sections and finds the occurrence — about 2.4 times fewer lane-instructions per key.
+__device__ __forceinline__ bool lane_fsel_probe(const uint64_t * __restrict__ f_lines, uint64_t base_line, unsigned t, uint32_t k,
+                                                FselBracket & b, int tries, uint32_t & pos_out)
+{
+    const uint32_t span = b.phi - b.plo; // > 0
+    uint32_t pe;
+    if (tries >= 3 && (tries & 1))
+        pe = b.plo + (span >> 1);
+    else
+    {
+        const float f = (float)(k - b.lo_cnt) * __builtin_amdgcn_rcpf((float)(b.hi_cnt - b.lo_cnt));
+        const uint32_t o = (uint32_t)(f * (float)span);
+        pe = b.plo + (o >= span ? span - 1 : o);
+    }
+    const uint32_t g = pe >> kFusedLog;
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    const v2u64 * ln = reinterpret_cast<const v2u64 *>(f_lines + (base_line + g) * kFusedWords);
+    v2u64 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        w[i] = ln[i]; // section s: w[2s] = (header, plane 0), w[2s + 1] = (plane 1, plane 2)
+    const uint64_t x0 = (t & 1) ? 0 : ~UINT64_C(0), x1 = (t & 2) ? 0 : ~UINT64_C(0), x2 = (t & 4) ? 0 : ~UINT64_C(0);
+    uint64_t m[4];
+    unsigned c[4];
+#pragma unroll
+    for (int sct = 0; sct < 4; ++sct)
+    {
+        m[sct] = (w[2 * sct].y ^ x0) & (w[2 * sct + 1].x ^ x1) & (w[2 * sct + 1].y ^ x2);
+        c[sct] = popc64(m[sct]);
+    }
+    const unsigned hs = t >> 1;
+    const uint64_t h = hs == 0 ? w[0].x : (hs == 1 ? w[2].x : (hs == 2 ? w[4].x : w[6].x));
+    const uint32_t c0 = (uint32_t)(h >> (32 * (t & 1))), c_in = c[0] + c[1] + c[2] + c[3];
+    if (k < c0)
+    {
+        b.phi = g << kFusedLog;
+        b.hi_cnt = c0;
+        return false;
+    }
+    if (k >= c0 + c_in)
+    {
+        b.plo = (g + 1) << kFusedLog;
+        b.lo_cnt = c0 + c_in;
+        return false;
+    }
+    unsigned r = k - c0, sct = 0;
+    uint64_t mm = m[0];
+    if (r >= c[0])
+    {
+        r -= c[0];
+        sct = 1;
+        mm = m[1];
+        if (r >= c[1])
+        {
+            r -= c[1];
+            sct = 2;
+            mm = m[2];
+            if (r >= c[2])
+            {
+                r -= c[2];
+                sct = 3;
+                mm = m[3];
+            }
+        }
+    }
+    pos_out = (g << kFusedLog) + 64u * sct + sel64(mm, r + 1);
+    return true;
+}
+
+template <unsigned THREADS>
+__global__ __launch_bounds__(THREADS) void k_wt_select_sorted_lane(WtView wt, const uint64_t * __restrict__ occ, unsigned nf, unsigned kb,
+                                                                  unsigned B, const uint32_t * __restrict__ fstart,
+                                                                  const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys,
+                                                                  const uint32_t * __restrict__ go)
+{
+    if (go && !*go)
+        return;
+    __shared__ struct
+    {
+        uint64_t path[256];
+        uint16_t parent[kWtMaxNodes];
+        uint16_t c_to_leaf[256];
+    } T;
+    __shared__ WtFusedTables FT;
+    __shared__ WtFusedSelTables FS;
+    __shared__ uint32_t first[257];
+    __shared__ unsigned sh_f;
+    {
+        const uint64_t * src = reinterpret_cast<const uint64_t *>(wt.f_sel_tables);
+        uint64_t * dst = reinterpret_cast<uint64_t *>(&FS);
+        for (unsigned i = threadIdx.x; i < sizeof(WtFusedSelTables) / 8; i += blockDim.x)
+            dst[i] = src[i];
+        for (unsigned i = threadIdx.x; i < 256; i += blockDim.x)
+        {
+            T.path[i] = wt.tables->path[i];
+            T.c_to_leaf[i] = wt.tables->c_to_leaf[i];
+        }
+        for (unsigned i = threadIdx.x; i < kWtMaxNodes; i += blockDim.x)
+            T.parent[i] = wt.tables->parent[i];
+        if (threadIdx.x == 0)
+        {
+            uint64_t run = 0;
+            for (int c = 0; c < 256; ++c)
+            {
+                first[c] = (uint32_t)run;
+                run += occ[c];
+            }
+            first[256] = (uint32_t)run;
+        }
+    }
+    wt_stage_fused(&FT, wt); // ends with __syncthreads()
+    // One block per item: the lanes of a block share the lines of ONE bucket — with an item per wave four times as many buckets
+    // are in flight and their lines push each other out of the L2 (13.9 against 15.2 G/s).
+    const unsigned n_items = ioff[nf];
+    for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x)
+    {
+        if (threadIdx.x == 0)
+        {
+            unsigned a = 0, z = nf;
+            while (a + 1 < z)
+            {
+                const unsigned mid = (a + z) >> 1;
+                if (ioff[mid] <= item)
+                    a = mid;
+                else
+                    z = mid;
+            }
+            sh_f = a;
+        }
+        __syncthreads();
+        const unsigned f = sh_f;
+        const uint64_t lo = (uint64_t)fstart[f] + (uint64_t)(item - ioff[f]) * kItemKeys;
+        const uint64_t fend = fstart[f + 1];
+        const unsigned cnt = (unsigned)(lo + kItemKeys < fend ? kItemKeys : fend - lo);
+        uint32_t * kp = keys + lo;
+        const uint64_t v0 = (uint64_t)f * B;
+        const uint32_t kmask = (1u << kb) - 1u;
+        unsigned c0 = 0;
+        {
+            unsigned z = 256;
+            while (c0 + 1 < z)
+            {
+                const unsigned mid = (c0 + z) >> 1;
+                if (first[mid] <= (uint32_t)v0)
+                    c0 = mid;
+                else
+                    z = mid;
+            }
+        }
+        unsigned nxt = threadIdx.x; // this lane's next key of the item
+        uint32_t key_nxt = nxt < cnt ? kp[nxt] : kBad;
+        bool have = false;
+        unsigned mine = 0, groups = 0, len = 0, cur = 0, t = 0;
+        uint64_t p = 0, base_line = 0;
+        uint32_t res = 0;
+        int tries = 0;
+        FselBracket br{};
+        for (;;)
+        {
+            if (!have && nxt < cnt)
+            { // (one key per iteration: a kBad key costs its lane one round)
+                mine = nxt;
+                const uint32_t key = key_nxt;
+                nxt += THREADS;
+                if (nxt < cnt)
+                    key_nxt = kp[nxt];
+                if (key < kMark)
+                {
+                    const uint32_t v = (uint32_t)(v0 + (key & kmask));
+                    unsigned c = c0;
+                    while (first[c + 1] <= v)
+                        ++c;
+                    res = v - first[c];
+                    cur = T.c_to_leaf[c];
+                    p = T.path[c];
+                    len = (unsigned)(p >> 56);
+                    groups = (len + 2) / 3;
+                    have = true;
+                    tries = -1; // the group below is new
+                }
+            }
+            if (__ballot(have || nxt < cnt) == 0)
+                break;
+            if (!have)
+                continue;
+            if (tries < 0)
+            { // start of a fused step: the node three levels up (or the root's remainder), its slot, the directory bracket
+                const unsigned gq = groups - 1, nlev = len - 3 * gq < 3 ? len - 3 * gq : 3;
+                t = (unsigned)(p >> (3 * gq)) & ((1u << nlev) - 1u);
+                unsigned u = cur;
+                for (unsigned j = 0; j < nlev; ++j)
+                    u = T.parent[u];
+                cur = u;
+                len = 3 * gq;
+                base_line = FT.fline[u];
+                const unsigned rid = FS.root_id[u];
+                br = fsel_bracket(wt.f_sel, FS.off[rid][t], res, FS.cnt[rid][t]);
+                tries = 0;
+            }
+            uint32_t pos;
+            if (lane_fsel_probe(wt.f_lines, base_line, t, res, br, tries, pos))
+            {
+                res = pos;
+                tries = -1;
+                if (--groups == 0)
+                {
+                    kp[mine] = res;
+                    have = false;
+                }
+            }
+            else
+                ++tries;
+        }
+        __syncthreads(); // (thread 0 rewrites sh_f at the top of the next item)
+    }
+}
+
 } // namespace
 
 bool wt_select_sorted_applicable(const WtHost & wt, uint64_t n)
@@ -274,7 +495,17 @@ sdsl_hip_status wt_launch_select_sorted(const WtHost & wt, const uint64_t * d_oc
     {
         SH_TRY(fill_u32_async(marked, 0u, 4, st));
         hipLaunchKernelGGL(k_wt_sel_zero_bases, dim3((nf + 255) / 256), dim3(256), 0, st, nf, hf);
-        hipLaunchKernelGGL(k_wt_select_sorted, dim3(256u * 8u), dim3(kBlock), 0, st, view, d_occ, nf, g.kb, B, fstart, ioff, keys2, g.go);
+        static const bool quad_form = getenv("SDSL_HIP_WT_SEL_LANE") && atoi(getenv("SDSL_HIP_WT_SEL_LANE")) == 0; // (A/B knob)
+        static const unsigned lane_grid = getenv("SDSL_HIP_WT_SEL_GRID") ? (unsigned)atoi(getenv("SDSL_HIP_WT_SEL_GRID")) : 256u * 8u;      // measured: 256 x 4096 15.8,
+        static const unsigned lane_threads = getenv("SDSL_HIP_WT_SEL_THREADS") ? (unsigned)atoi(getenv("SDSL_HIP_WT_SEL_THREADS")) : 512u; // 512 x 2048 16.2, 1024 x 1024 15.8 G/s
+        if (quad_form)
+            hipLaunchKernelGGL(k_wt_select_sorted, dim3(256u * 8u), dim3(kBlock), 0, st, view, d_occ, nf, g.kb, B, fstart, ioff, keys2, g.go);
+        else if (lane_threads == 1024)
+            hipLaunchKernelGGL(k_wt_select_sorted_lane<1024>, dim3(lane_grid), dim3(1024), 0, st, view, d_occ, nf, g.kb, B, fstart, ioff, keys2, g.go);
+        else if (lane_threads == 512)
+            hipLaunchKernelGGL(k_wt_select_sorted_lane<512>, dim3(lane_grid), dim3(512), 0, st, view, d_occ, nf, g.kb, B, fstart, ioff, keys2, g.go);
+        else
+            hipLaunchKernelGGL(k_wt_select_sorted_lane<256>, dim3(lane_grid), dim3(256), 0, st, view, d_occ, nf, g.kb, B, fstart, ioff, keys2, g.go);
         SH_HIP(hipGetLastError());
         return SDSL_HIP_OK;
     };
