@@ -425,6 +425,10 @@ sdsl_hip_status sdsl_hip_sd_destroy(sdsl_hip_sd_t v);
 uint64_t sdsl_hip_sd_size(sdsl_hip_sd_t v);
 uint64_t sdsl_hip_sd_ones(sdsl_hip_sd_t v);
 uint32_t sdsl_hip_sd_low_width(sdsl_hip_sd_t v); /* sd_vector::wl */
+/* which of the vector's queries the one-lane-per-query kernels answer (decided when it is built, from a probe batch: bit 0 rank /
+ * access, bit 1 select_0; 0: the quad kernels — small, empty or clustered vectors, or SDSL_HIP_SD_NO_LANES).  Answers do not depend
+ * on it. */
+uint32_t sdsl_hip_sd_lane_kernels(sdsl_hip_sd_t v);
 uint64_t sdsl_hip_sd_device_bytes(sdsl_hip_sd_t v);
 sdsl_hip_status sdsl_hip_sd_rank_batch(sdsl_hip_sd_t v, int32_t bit, const uint64_t * idx, uint64_t n, uint64_t * out,
                                        void * stream);

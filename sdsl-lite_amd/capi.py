@@ -100,6 +100,7 @@ SIGNATURES = {
     "sdsl_hip_sd_size": (C.c_uint64, [_vp]),
     "sdsl_hip_sd_ones": (C.c_uint64, [_vp]),
     "sdsl_hip_sd_low_width": (C.c_uint32, [_vp]),
+    "sdsl_hip_sd_lane_kernels": (C.c_uint32, [_vp]),
     "sdsl_hip_sd_device_bytes": (C.c_uint64, [_vp]),
     "sdsl_hip_sd_rank_batch": (C.c_int32, [_vp, C.c_int32, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_sd_select_batch": (C.c_int32, [_vp, C.c_int32, _vp, C.c_uint64, _vp, _vp]),

@@ -32,18 +32,24 @@ struct SdView
     const uint64_t * sel0_dir;
     uint32_t sel0_shift;
     uint32_t per_bucket_fx; // entries per bucket of a uniformly filled vector, in 1/65536 (the estimate of quad_sd_select0)
+    // rank directory (device only, lane kernels): entry j = entries with a high part below j << rank_shift; nullptr = none
+    const uint64_t * rank_dir;
+    uint32_t rank_shift;
 };
+constexpr uint64_t kSdRedo = ~UINT64_C(0) - 1; // what a lane kernel writes where its short road did not lead (k_sd_redo answers those)
+constexpr uint8_t kSdRedo8 = 0xFE;
 
 struct SdHost
 {
     int device = 0;
     BvHost high;
-    DevBuf low, sel0_dir;
+    DevBuf low, sel0_dir, rank_dir;
+    bool lane_rank_ok = false, lane_sel0_ok = false; // the lane kernels answer this vector's queries on their short road (sd_probe_lanes)
     SdView view{};
     uint32_t low_width_when_empty = 64; // width SDSL's `low` reports for m == 0 (wl for built vectors)
     size_t device_bytes() const
     {
-        return high.device_bytes() + low.bytes + sel0_dir.bytes;
+        return high.device_bytes() + low.bytes + sel0_dir.bytes + rank_dir.bytes;
     }
 };
 
@@ -350,6 +356,312 @@ __global__ __launch_bounds__(kBlock) void k_sd_select(SdView v, const uint64_t *
     }
 }
 
+// ---- one LANE per query (round 4) ------------------------------------------------------------------------------
+// The quad kernels above spend four lanes on a chain of small dependent steps (580 instructions per lane and select_0, three
+// fabric requests per rank) and are bound by exactly that.  Here a lane walks alone and takes only the SHORT road: a directory
+// entry names a bucket at or in front of the wanted one and the entries in front of it, the zero that closes the bucket in front
+// of the wanted one is looked for in the line where a uniformly filled vector has it (or its neighbour), the bucket's end is read
+// off the same line.  Wherever that road does not lead — clustered data, runs that leave their line — the lane writes kSdRedo and
+// k_sd_redo answers the query with the quad code; a vector on which that happens often keeps the quad kernels (sd_probe_lanes).
+struct LaneLine
+{
+    uint64_t L;
+    uint64_t w[8]; // w[0] = ones in front of the line
+};
+__device__ __forceinline__ void lane_load_line(const BvView & hv, uint64_t L, LaneLine & x)
+{
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    const v2u64 * ln = reinterpret_cast<const v2u64 *>(hv.lines + L * kLW);
+    x.L = L;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        const v2u64 t = ln[i];
+        x.w[2 * i] = t.x;
+        x.w[2 * i + 1] = t.y;
+    }
+}
+// position of zero number z (0-based) if it lies in the line
+__device__ __forceinline__ bool lane_zero_in_line(const LaneLine & x, uint64_t z, uint64_t & pos)
+{
+    const uint64_t zb = x.L * kDB - x.w[0];
+    if (z < zb || z - zb >= kDB)
+        return false;
+    unsigned r = (unsigned)(z - zb);
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+    {
+        const unsigned c = 64u - popc64(x.w[i]);
+        if (r < c)
+        {
+            pos = x.L * kDB + 64u * (unsigned)(i - 1) + sel64(~x.w[i], r + 1);
+            return true;
+        }
+        r -= c;
+    }
+    return false;
+}
+// the first zero at or behind position p of the line (p inside it), NPOS if the line has none there
+__device__ __forceinline__ uint64_t lane_next_zero(const LaneLine & x, uint64_t p)
+{
+    const unsigned off = (unsigned)(p - x.L * kDB);
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+    {
+        const unsigned base = 64u * (unsigned)(i - 1);
+        if (base + 64u <= off)
+            continue;
+        uint64_t z = ~x.w[i];
+        if (base < off)
+            z &= ~lo_set(off - base);
+        if (z)
+            return x.L * kDB + base + (unsigned)__builtin_ctzll(z);
+    }
+    return SDSL_HIP_NPOS;
+}
+// zero number z of `high`, looked for in the line of x_est and the neighbour the header points to; the line it was found in stays in x
+__device__ __forceinline__ bool lane_find_zero(const BvView & hv, uint64_t z, uint64_t x_est, LaneLine & x, uint64_t & pos)
+{
+    uint64_t L = x_est / kDB;
+    L = L < hv.n_lines ? L : hv.n_lines - 1;
+    lane_load_line(hv, L, x);
+    if (lane_zero_in_line(x, z, pos))
+        return true;
+    const uint64_t zb = L * kDB - x.w[0];
+    if (z < zb ? L == 0 : L + 1 >= hv.n_lines)
+        return false;
+    lane_load_line(hv, z < zb ? L - 1 : L + 1, x);
+    return lane_zero_in_line(x, z, pos);
+}
+// the first zero at or behind `start` (x holds some line; reloaded when start lies elsewhere); looks one line further if needed
+__device__ __forceinline__ uint64_t lane_zero_from(const BvView & hv, uint64_t start, LaneLine & x)
+{
+    const uint64_t L = start / kDB;
+    if (L != x.L)
+        lane_load_line(hv, L, x);
+    uint64_t z = lane_next_zero(x, start);
+    if (z == SDSL_HIP_NPOS && L + 1 < hv.n_lines)
+    {
+        lane_load_line(hv, L + 1, x);
+        z = lane_next_zero(x, (L + 1) * kDB);
+    }
+    return z;
+}
+
+// rank_1(x) for x <= n (MODE 0) / "is bit x set" for x < n (MODE 1); false: not on the short road
+template <int MODE>
+__device__ __forceinline__ bool lane_sd_rank1(const SdView & v, uint64_t x, uint64_t & rank, bool & hit)
+{
+    const uint64_t h = x >> v.wl, val_low = x & lo_set(v.wl);
+    LaneLine ln;
+    uint64_t start = 0;
+    if (h > 0)
+    {
+        const uint64_t j = h >> v.rank_shift, c = j << v.rank_shift, bef = v.rank_dir[j];
+        // zero number h - 1 stands behind h - 1 zeros and the entries of the buckets below h: bef + those of the buckets c .. h - 1
+        const uint64_t x_est = bef + (h - 1) + (((h - c) * (uint64_t)v.per_bucket_fx) >> 16);
+        uint64_t p;
+        if (!lane_find_zero(v.high, h - 1, x_est, ln, p))
+            return false;
+        start = p + 1;
+    }
+    else
+        lane_load_line(v.high, 0, ln);
+    const uint64_t begin = start - h;
+    const uint64_t nz = lane_zero_from(v.high, start, ln);
+    if (nz == SDSL_HIP_NPOS)
+        return false; // (a run of entries longer than a line: a clustered bucket)
+    const uint64_t end = nz - h;
+    uint64_t lo = begin, hi = end;
+    while (lo < hi)
+    {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (sd_low(v, mid) < val_low)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (MODE == 1)
+        hit = lo < end && sd_low(v, lo) == val_low;
+    rank = lo;
+    return true;
+}
+
+// select_0(i), i in [1, n - m]; false: not on the short road
+__device__ __forceinline__ bool lane_sd_select0(const SdView & v, uint64_t i, uint64_t & pos_out)
+{
+    const uint64_t k = i - 1;
+    const uint64_t e = v.sel0_dir[k >> v.sel0_shift];
+    const uint64_t c = e >> 32, bef = e & 0xFFFFFFFFu;
+    const uint64_t b = (k + bef) >> v.wl; // >= c, and f(b) <= k whatever lies between c and b
+    uint64_t before = bef;
+    LaneLine ln;
+    ln.L = ~UINT64_C(0);
+    if (b > c)
+    {
+        const uint64_t x_est = bef + c + (b - c - 1) + (((b - c) * (uint64_t)v.per_bucket_fx) >> 16);
+        uint64_t p;
+        if (!lane_find_zero(v.high, b - 1, x_est, ln, p))
+            return false;
+        before = p + 1 - b;
+    }
+    uint64_t fb = (b << v.wl) - before, start = before + b;
+    uint64_t z = lane_zero_from(v.high, start, ln);
+    if (z == SDSL_HIP_NPOS)
+        return false;
+    uint64_t bb = b, f_next = fb + (UINT64_C(1) << v.wl) - (z - start); // f(b + 1)
+    for (int step = 0; step < 4 && k >= f_next; ++step)
+    { // the entries between c and b push the answer into one of the next buckets
+        const uint64_t st2 = z + 1;
+        const uint64_t z2 = lane_zero_from(v.high, st2, ln);
+        if (z2 == SDSL_HIP_NPOS)
+            return false;
+        ++bb;
+        fb = f_next;
+        f_next = fb + (UINT64_C(1) << v.wl) - (z2 - st2);
+        start = st2;
+        z = z2;
+    }
+    if (k >= f_next)
+        return false; // (clustered data: the bracket search of the quad kernel)
+    const uint64_t begin = (bb << v.wl) - fb, cnt = z - bb - begin, r = k - fb;
+    uint64_t lo = 0, hi = cnt; // first t with low_t - t > r
+    while (lo < hi)
+    {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (sd_low(v, begin + mid) <= r + mid)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    pos_out = (bb << v.wl) + r + lo;
+    return true;
+}
+
+template <int MODE> // 0: rank (bit b), 1: access
+__global__ __launch_bounds__(kBlock) void k_sd_rank_lane(SdView v, int bit, const uint64_t * __restrict__ xq, uint64_t * __restrict__ out,
+                                                         uint8_t * __restrict__ out8, uint64_t n, uint32_t * __restrict__ redo_count)
+{
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += (uint64_t)gridDim.x * kBlock)
+    {
+        const uint64_t x = __builtin_nontemporal_load(xq + q);
+        uint64_t r1 = 0;
+        bool hit = false, ok = true;
+        const bool inside = MODE == 1 ? x < v.n : x <= v.n;
+        if (inside)
+            ok = lane_sd_rank1<MODE>(v, x, r1, hit);
+        if (!ok && redo_count)
+            atomicAdd(redo_count, 1u);
+        if (MODE == 1)
+            out8[q] = !ok ? kSdRedo8 : (inside ? (hit ? 1 : 0) : 0xFF);
+        else
+            __builtin_nontemporal_store(!ok ? kSdRedo : (inside ? (bit ? r1 : x - r1) : SDSL_HIP_NPOS), out + q);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sd_select0_lane(SdView v, const uint64_t * __restrict__ iq, uint64_t * __restrict__ out, uint64_t n,
+                                                            uint32_t * __restrict__ redo_count)
+{
+    const uint64_t total = v.n - v.m;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < n; q += (uint64_t)gridDim.x * kBlock)
+    {
+        const uint64_t i = __builtin_nontemporal_load(iq + q);
+        uint64_t r = SDSL_HIP_NPOS;
+        if (i >= 1 && i <= total && !lane_sd_select0(v, i, r))
+        {
+            r = kSdRedo;
+            if (redo_count)
+                atomicAdd(redo_count, 1u);
+        }
+        __builtin_nontemporal_store(r, out + q);
+    }
+}
+
+// the queries a lane kernel left: a wave looks at 64 answers, its quads take the marked ones sixteen at a time
+template <int KIND> // 0: rank, 1: access, 2: select_0
+__global__ __launch_bounds__(kBlock) void k_sd_redo(SdView v, int bit, const uint64_t * __restrict__ in, uint64_t * __restrict__ out,
+                                                    uint8_t * __restrict__ out8, uint64_t n)
+{
+    const unsigned lane = threadIdx.x & 63u;
+    const int s = (int)(lane & 3u);
+    const unsigned gq = lane >> 2;
+    for (uint64_t base = (uint64_t)blockIdx.x * kBlock + (threadIdx.x - lane); base < n; base += (uint64_t)gridDim.x * kBlock)
+    {
+        const uint64_t q = base + lane;
+        const bool flag = q < n && (KIND == 1 ? out8[q] == kSdRedo8 : out[q] == kSdRedo);
+        uint64_t mask = __ballot(flag);
+        while (mask)
+        { // (wave-uniform)
+            int mybit = -1;
+            for (unsigned j = 0; j < 16 && mask; ++j)
+            {
+                const int bpos = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                if (j == gq)
+                    mybit = bpos;
+            }
+            if (mybit >= 0)
+            {
+                const uint64_t qq = base + (unsigned)mybit;
+                const uint64_t x = in[qq];
+                if (KIND == 2)
+                {
+                    const uint64_t r = quad_sd_select0<false>(v, s, x);
+                    if (s == 0)
+                        out[qq] = r;
+                }
+                else
+                {
+                    bool hit = false;
+                    const uint64_t r1 = quad_sd_rank1<false>(v, s, x, &hit);
+                    if (s == 0)
+                    {
+                        if (KIND == 1)
+                            out8[qq] = hit ? 1 : 0;
+                        else
+                            out[qq] = bit ? r1 : x - r1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// rank directory: entries with a high part below j << shift = (position of zero number (j << shift) - 1) + 1 - (j << shift)
+__global__ __launch_bounds__(kBlock) void k_sd_rank_dir(SdView v, uint32_t shift, uint64_t n_entries, uint64_t * __restrict__ dir)
+{
+    const int s = threadIdx.x & (kG - 1);
+    const unsigned gq = threadIdx.x / kG;
+    for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n_entries; base += (uint64_t)gridDim.x * kQPB)
+    {
+        const uint64_t j = base + gq;
+        if (j >= n_entries)
+            continue;
+        const uint64_t c = j << shift;
+        uint64_t val = 0;
+        if (c > 0)
+        {
+            bool mine;
+            const uint64_t p = quad_select<0, false>(v.high, s, c - 1, mine);
+            val = quad_gather_u64(p, mine) + 1 - c;
+        }
+        if (s == 0)
+            dir[j] = val;
+    }
+}
+__global__ __launch_bounds__(256) void k_sd_probe_args(uint64_t n_args, uint64_t mod, uint64_t add, uint64_t * __restrict__ a)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_args)
+    {
+        uint64_t x = (i + 1) * UINT64_C(0x9E3779B97F4A7C15);
+        x ^= x >> 29;
+        x *= UINT64_C(0xBF58476D1CE4E5B9);
+        x ^= x >> 32;
+        a[i] = add + x % mod;
+    }
+}
+
 // ---- construction --------------------------------------------------------------------------------------------
 // entry i of the sorted position list: wl low bits into `low`, a one at (pos >> wl) + i into `high`
 __global__ __launch_bounds__(256) void k_sd_fill(const uint64_t * __restrict__ pos, uint64_t m, uint32_t wl,
@@ -401,6 +713,9 @@ static void sd_finish_view(SdHost & h, uint64_t n, uint64_t m, uint32_t wl)
     h.view.wl = wl;
     h.view.sel0_dir = nullptr;
     h.view.sel0_shift = 0;
+    h.view.rank_dir = nullptr;
+    h.view.rank_shift = 0;
+    h.lane_rank_ok = h.lane_sel0_ok = false;
     {
         const double per = (double)m / (double)((n >> wl) + 1) * 65536.0;
         h.view.per_bucket_fx = per > 4e9 ? 0xFFFFFFFFu : (uint32_t)per;
@@ -437,6 +752,91 @@ static void sd_build_sel0_dir(SdHost & h)
     }
     h.view.sel0_dir = h.sel0_dir.as<uint64_t>();
     h.view.sel0_shift = shift;
+}
+
+// The rank directory of the lane kernels (at most 2^19 entries, like the select_0 directory) and the verdict whether this vector's
+// queries stay on the lane kernels' short road: 2^14 pseudo-random arguments through either kernel, at most 3 % marked for the
+// quad code.  (Clustered data: the window guess misses, runs leave their line — there the quad kernels, with their bracket search
+// and select directories, are the faster road.)  Errors leave the vector on the quad kernels.
+static void sd_build_lane_tables(SdHost & h)
+{
+    const SdView & v = h.view;
+    if (getenv("SDSL_HIP_SD_NO_LANES") || v.m == 0 || v.n < (UINT64_C(1) << 16))
+        return;
+    const uint64_t n_buckets = (v.n >> v.wl) + 1;
+    uint32_t shift = 0;
+    while ((n_buckets >> shift) + 1 > (UINT64_C(1) << 19))
+        ++shift;
+    const uint64_t n_entries = (n_buckets >> shift) + 1;
+    if (h.rank_dir.alloc(n_entries * 8) != SDSL_HIP_OK)
+        return;
+    hipLaunchKernelGGL(k_sd_rank_dir, dim3(grid_for(n_entries, kQPB, 256u * 8u)), dim3(kBlock), 0, 0, v, shift, n_entries, h.rank_dir.as<uint64_t>());
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+    {
+        h.rank_dir.release();
+        return;
+    }
+    h.view.rank_dir = h.rank_dir.as<uint64_t>();
+    h.view.rank_shift = shift;
+    constexpr uint64_t kProbe = 1u << 14;
+    DevBuf args, outs, cnt;
+    if (args.alloc(kProbe * 8) != SDSL_HIP_OK || outs.alloc(kProbe * 8) != SDSL_HIP_OK || cnt.alloc(8, true) != SDSL_HIP_OK)
+        return;
+    uint32_t redo[2] = {~0u, ~0u};
+    hipLaunchKernelGGL(k_sd_probe_args, dim3(kProbe / 256), dim3(256), 0, 0, kProbe, v.n + 1, (uint64_t)0, args.as<uint64_t>());
+    hipLaunchKernelGGL((k_sd_rank_lane<0>), dim3(kProbe / kBlock), dim3(kBlock), 0, 0, h.view, 1, args.as<uint64_t>(), outs.as<uint64_t>(),
+                       (uint8_t *)nullptr, kProbe, cnt.as<uint32_t>());
+    const uint64_t zeros = v.n - v.m;
+    if (h.view.sel0_dir && zeros)
+    {
+        hipLaunchKernelGGL(k_sd_probe_args, dim3(kProbe / 256), dim3(256), 0, 0, kProbe, zeros, (uint64_t)1, args.as<uint64_t>());
+        hipLaunchKernelGGL(k_sd_select0_lane, dim3(kProbe / kBlock), dim3(kBlock), 0, 0, h.view, args.as<uint64_t>(), outs.as<uint64_t>(), kProbe,
+                           cnt.as<uint32_t>() + 1);
+    }
+    if (hipGetLastError() != hipSuccess || hipMemcpy(redo, cnt.p, 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return;
+    const uint32_t limit = (uint32_t)(kProbe * 3 / 100);
+    h.lane_rank_ok = redo[0] <= limit;
+    h.lane_sel0_ok = h.view.sel0_dir && zeros && redo[1] <= limit;
+    if (getenv("SDSL_HIP_TRACE_BUILD"))
+        fprintf(stderr, "[sdsl_hip] sd_vector: lane kernels: %u / %u of %llu probe queries left their short road (rank / select_0): %s / %s\n", redo[0],
+                redo[1], (unsigned long long)kProbe, h.lane_rank_ok ? "lanes" : "quads", h.lane_sel0_ok ? "lanes" : "quads");
+}
+
+// enqueue rank / access / select_0 on whichever kernels the vector takes
+static void sd_launch_rank(const SdHost & h, int mode, int bit, const uint64_t * d_in, uint64_t * d_out, uint8_t * d_out8, uint64_t n, hipStream_t st)
+{
+    if (h.lane_rank_ok && (const void *)d_in != (const void *)d_out) // (the marked queries are read again: not in place)
+    {
+        const dim3 g(grid_for(n, kBlock, 256u * 8u)), gr(grid_for(n, kBlock, 256u * 4u));
+        if (mode == 1)
+        {
+            hipLaunchKernelGGL((k_sd_rank_lane<1>), g, dim3(kBlock), 0, st, h.view, bit, d_in, d_out, d_out8, n, (uint32_t *)nullptr);
+            hipLaunchKernelGGL((k_sd_redo<1>), gr, dim3(kBlock), 0, st, h.view, bit, d_in, d_out, d_out8, n);
+        }
+        else
+        {
+            hipLaunchKernelGGL((k_sd_rank_lane<0>), g, dim3(kBlock), 0, st, h.view, bit, d_in, d_out, d_out8, n, (uint32_t *)nullptr);
+            hipLaunchKernelGGL((k_sd_redo<0>), gr, dim3(kBlock), 0, st, h.view, bit, d_in, d_out, d_out8, n);
+        }
+        return;
+    }
+    if (mode == 1)
+        hipLaunchKernelGGL((k_sd_rank<1>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, st, h.view, bit, d_in, d_out, d_out8, n);
+    else
+        hipLaunchKernelGGL((k_sd_rank<0>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, st, h.view, bit, d_in, d_out, d_out8, n);
+}
+static void sd_launch_select(const SdHost & h, int bit, const uint64_t * d_in, uint64_t * d_out, uint64_t n, hipStream_t st)
+{
+    if (bit)
+        hipLaunchKernelGGL((k_sd_select<1>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, st, h.view, d_in, d_out, n);
+    else if (h.lane_sel0_ok && (const void *)d_in != (const void *)d_out)
+    {
+        hipLaunchKernelGGL(k_sd_select0_lane, dim3(grid_for(n, kBlock, 256u * 8u)), dim3(kBlock), 0, st, h.view, d_in, d_out, n, (uint32_t *)nullptr);
+        hipLaunchKernelGGL((k_sd_redo<2>), dim3(grid_for(n, kBlock, 256u * 4u)), dim3(kBlock), 0, st, h.view, 0, d_in, d_out, (uint8_t *)nullptr, n);
+    }
+    else
+        hipLaunchKernelGGL((k_sd_select<0>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, st, h.view, d_in, d_out, n);
 }
 
 // sd_vector(begin, end) with an explicit size (sd_vector.hpp:217-305; the iterator constructor takes size = last + 1)
@@ -484,6 +884,7 @@ static sdsl_hip_status sd_build_from_device_positions(SdHost & h, const uint64_t
     SH_HIP(hipDeviceSynchronize());
     sd_finish_view(h, n, m, wl);
     sd_build_sel0_dir(h);
+    sd_build_lane_tables(h);
     return SDSL_HIP_OK;
 }
 
@@ -528,6 +929,7 @@ static sdsl_hip_status sd_build_from_stream(SdHost & h, StreamReader & rd, int d
     SH_HIP(hipDeviceSynchronize());
     sd_finish_view(h, n, m, wl);
     sd_build_sel0_dir(h);
+    sd_build_lane_tables(h);
     return SDSL_HIP_OK;
 }
 
@@ -705,6 +1107,10 @@ uint64_t sdsl_hip_sd_ones(sdsl_hip_sd_t v)
 {
     return v ? v->h.view.m : 0;
 }
+uint32_t sdsl_hip_sd_lane_kernels(sdsl_hip_sd_t v)
+{
+    return v ? (v->h.lane_rank_ok ? 1u : 0u) | (v->h.lane_sel0_ok ? 2u : 0u) : 0u;
+}
 uint32_t sdsl_hip_sd_low_width(sdsl_hip_sd_t v)
 {
     return v ? v->h.view.wl : 0;
@@ -728,12 +1134,11 @@ sdsl_hip_status sdsl_hip_sd_rank_batch(sdsl_hip_sd_t v, int32_t bit, const uint6
         return SDSL_HIP_OK;
     if (n >= kPipelineMinQueries && !is_device_ptr(idx) && !is_device_ptr(out))
     { // host arrays on both sides: chunked over two streams (common.hpp host_pipeline_u64)
-        const SdView sv = v->h.view;
+        const SdHost * hp = &v->h;
         return host_pipeline_u64(v->h.device, idx, out, n,
-                                 [sv, bit](const uint64_t * d_in, uint64_t * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
+                                 [hp, bit](const uint64_t * d_in, uint64_t * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
                                  {
-                                     hipLaunchKernelGGL((k_sd_rank<0>), dim3(grid_for(cnt, kQPB, 256u * 8u)), dim3(kBlock), 0, st,
-                                                        sv, bit, d_in, d_out, (uint8_t *)nullptr, cnt);
+                                     sd_launch_rank(*hp, 0, bit, d_in, d_out, (uint8_t *)nullptr, cnt, st);
                                      SH_HIP(hipGetLastError());
                                      return SDSL_HIP_OK;
                                  });
@@ -743,8 +1148,7 @@ sdsl_hip_status sdsl_hip_sd_rank_batch(sdsl_hip_sd_t v, int32_t bit, const uint6
     SH_TRY(o.out(out, n * 8));
     {
         KernelTimer t(s);
-        hipLaunchKernelGGL((k_sd_rank<0>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, v->h.view, bit,
-                           (const uint64_t *)in.dev, (uint64_t *)o.dev, (uint8_t *)nullptr, n);
+        sd_launch_rank(v->h, 0, bit, (const uint64_t *)in.dev, (uint64_t *)o.dev, (uint8_t *)nullptr, n, s);
     }
     SH_HIP(hipGetLastError());
     SH_TRY(o.finish(s));
@@ -769,8 +1173,7 @@ sdsl_hip_status sdsl_hip_sd_access_batch(sdsl_hip_sd_t v, const uint64_t * idx, 
     SH_TRY(o.out(out, n));
     {
         KernelTimer t(s);
-        hipLaunchKernelGGL((k_sd_rank<1>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, v->h.view, 1,
-                           (const uint64_t *)in.dev, (uint64_t *)nullptr, (uint8_t *)o.dev, n);
+        sd_launch_rank(v->h, 1, 1, (const uint64_t *)in.dev, (uint64_t *)nullptr, (uint8_t *)o.dev, n, s);
     }
     SH_HIP(hipGetLastError());
     SH_TRY(o.finish(s));
@@ -793,16 +1196,11 @@ sdsl_hip_status sdsl_hip_sd_select_batch(sdsl_hip_sd_t v, int32_t bit, const uin
         return SDSL_HIP_OK;
     if (n >= kPipelineMinQueries && !is_device_ptr(i) && !is_device_ptr(out))
     {
-        const SdView sv = v->h.view;
+        const SdHost * hp = &v->h;
         return host_pipeline_u64(v->h.device, i, out, n,
-                                 [sv, bit](const uint64_t * d_in, uint64_t * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
+                                 [hp, bit](const uint64_t * d_in, uint64_t * d_out, uint64_t cnt, hipStream_t st) -> sdsl_hip_status
                                  {
-                                     if (bit)
-                                         hipLaunchKernelGGL((k_sd_select<1>), dim3(grid_for(cnt, kQPB, 256u * 8u)), dim3(kBlock), 0,
-                                                            st, sv, d_in, d_out, cnt);
-                                     else
-                                         hipLaunchKernelGGL((k_sd_select<0>), dim3(grid_for(cnt, kQPB, 256u * 8u)), dim3(kBlock), 0,
-                                                            st, sv, d_in, d_out, cnt);
+                                     sd_launch_select(*hp, bit, d_in, d_out, cnt, st);
                                      SH_HIP(hipGetLastError());
                                      return SDSL_HIP_OK;
                                  });
@@ -812,12 +1210,7 @@ sdsl_hip_status sdsl_hip_sd_select_batch(sdsl_hip_sd_t v, int32_t bit, const uin
     SH_TRY(o.out(out, n * 8));
     {
         KernelTimer t(s);
-        if (bit)
-            hipLaunchKernelGGL((k_sd_select<1>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, v->h.view,
-                               (const uint64_t *)in.dev, (uint64_t *)o.dev, n);
-        else
-            hipLaunchKernelGGL((k_sd_select<0>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, v->h.view,
-                               (const uint64_t *)in.dev, (uint64_t *)o.dev, n);
+        sd_launch_select(v->h, bit, (const uint64_t *)in.dev, (uint64_t *)o.dev, n, s);
     }
     SH_HIP(hipGetLastError());
     SH_TRY(o.finish(s));

@@ -429,6 +429,10 @@ class sd_vector(_Handle):
     def low_width(self) -> int:
         return capi.lib().sdsl_hip_sd_low_width(self._h)
 
+    def lane_kernels(self) -> int:
+        """bit 0: rank / access, bit 1: select_0 are answered by the one-lane-per-query kernels (sd.hip)"""
+        return capi.lib().sdsl_hip_sd_lane_kernels(self._h)
+
     def serialize(self) -> bytes:
         """the bytes of sd_vector<>::serialize"""
         return _serialize(capi.lib().sdsl_hip_sd_serialize, self._h)
