@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
             { // next character (suffix_array_algorithm.hpp:176-200)
                 if (!(it > begin && r + 1 - l > 0))
                     break;
-                if (VERIFY && !WANT_IVAL && l == r && it > begin + 1)
+                if (VERIFY && !WANT_IVAL && l == r && it > begin + 1 && it - begin < (csa_size >> 32 ? (UINT64_C(1) << 23) : (UINT64_C(1) << 31)))
                 { // one suffix left and at least two characters to go: k_fm_verify compares them with the text
                     pending = true;
                     break;
@@ -154,26 +154,29 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
                 out_l[q] = l;
                 out_r[q] = r;
             }
-            else // (pending: [1 : 1 | characters left : 31 | the suffix : 32] — the fused layout is for < 2^32 symbols)
-                out_cnt[q] = VERIFY && pending ? (UINT64_C(1) << 63) | ((uint64_t)(it - begin) << 32) | l : r + 1 - l;
+            else // (pending: [1 : 1 | characters left : 31 | the suffix : 32], or [1 | 23 | 40] on an index of 2^32 suffixes and more)
+                out_cnt[q] = VERIFY && pending ? (UINT64_C(1) << 63) | ((uint64_t)(it - begin) << (csa_size >> 32 ? 40 : 32)) | l : r + 1 - l;
         }
     }
 }
 
 // count() of the patterns whose search stopped at a single suffix: the suffix stands at SA[l] in the text, so the pattern's
 // remaining characters pats[begin .. begin + rem) occur there or nowhere.  One lane per pattern.
-__global__ __launch_bounds__(256) void k_fm_verify(const uint32_t * __restrict__ sa, const uint8_t * __restrict__ text,
+template <class SA>
+__global__ __launch_bounds__(256) void k_fm_verify(const SA * __restrict__ sa, const uint8_t * __restrict__ text,
                                                    const uint8_t * __restrict__ pats, uint32_t m, const uint64_t * __restrict__ offsets,
-                                                   uint64_t n_pat, uint64_t * __restrict__ out_cnt)
+                                                   uint64_t n_pat, uint64_t * __restrict__ out_cnt, uint64_t csa_size)
 {
+    const unsigned LB = csa_size >> 32 ? 40 : 32; // (the packing of k_fm_count's pending word)
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_pat; q += (uint64_t)gridDim.x * blockDim.x)
     {
         const uint64_t v = out_cnt[q];
         if (!(v >> 63))
             continue;
-        const uint32_t l = (uint32_t)v, rem = (uint32_t)(v >> 32) & 0x7FFFFFFFu;
+        const uint64_t l = v & ((UINT64_C(1) << LB) - 1);
+        const uint32_t rem = (uint32_t)((v >> LB) & ((UINT64_C(1) << (63 - LB)) - 1));
         const uint64_t begin = offsets ? offsets[q] : q * (uint64_t)m;
-        const uint32_t at = sa[l];
+        const uint64_t at = sa[l];
         bool ok = at >= rem;
         if (ok)
         {
@@ -443,7 +446,19 @@ static sdsl_hip_status sdsl_hip_fm_create_from_text_ex_impl(const uint8_t * text
             return SDSL_HIP_ERR_NOMEM;
         const uint64_t n = n_text + 1;
         sdsl_hip_status st = sa_samples_device64(d_sa.as<uint64_t>(), n, 32, 64, &f->d_sa_s, &f->d_isa_s);
-        d_sa.release();
+        // the whole suffix array (8 bytes per suffix) and the text stay beside the samples, as for a small index: count() finishes
+        // single suffixes against the text, csa[i] and locate are gathers; sdsl_hip_fm_drop_sa releases both (SDSL_HIP_FM_KEEP_SA64=0:
+        // never kept).  No room for them: the index works from its samples.
+        const char * keep_env = getenv("SDSL_HIP_FM_KEEP_SA64");
+        if (keep_env && atoi(keep_env) == 0)
+            d_sa.release();
+        else
+        {
+            f->d_sa64 = std::move(d_sa);
+            if (fm_verify_enabled() && f->d_text.alloc(n_text) == SDSL_HIP_OK)
+                if (hipMemcpy(f->d_text.p, text, n_text, hipMemcpyDefault) != hipSuccess)
+                    f->d_text.release();
+        }
         if (st == SDSL_HIP_OK)
         {
             f->sa_dens = 32;
@@ -752,6 +767,7 @@ sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
         fm->n_isa_s = (n + 63) / 64;
     }
     fm->d_sa.release();
+    fm->d_sa64.release();
     fm->d_text.release(); // (only useful beside the whole suffix array)
     return SDSL_HIP_OK;
 }
@@ -853,7 +869,7 @@ uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm)
 }
 uint64_t sdsl_hip_fm_device_bytes(sdsl_hip_fm_t fm)
 {
-    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes + fm->d_sa_s.bytes + fm->d_isa_s.bytes + fm->d_jump.bytes + fm->d_sa.bytes + fm->d_text.bytes + fm->d_ctab.bytes + fm->d_deep.bytes : 0;
+    return fm ? sdsl_hip_wt_device_bytes(fm->wt) + fm->d_tab.bytes + fm->d_sa_s.bytes + fm->d_isa_s.bytes + fm->d_jump.bytes + fm->d_sa.bytes + fm->d_sa64.bytes + fm->d_text.bytes + fm->d_ctab.bytes + fm->d_deep.bytes : 0;
 }
 sdsl_hip_wt_t sdsl_hip_fm_wavelet_tree(sdsl_hip_fm_t fm)
 {
@@ -943,9 +959,9 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
                                    ival ? nullptr : (uint64_t *)sc.dev, ival ? (uint64_t *)sl.dev : nullptr,
                                    ival ? (uint64_t *)sr.dev : nullptr, s, verify));
         if (verify)
-            hipLaunchKernelGGL(k_fm_verify, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa.as<uint32_t>(),
+            hipLaunchKernelGGL(k_fm_verify<uint32_t>, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa.as<uint32_t>(),
                                fm->d_text.as<uint8_t>(), (const uint8_t *)sp.dev, m, offsets ? (const uint64_t *)so.dev : nullptr, n_pat,
-                               (uint64_t *)sc.dev);
+                               (uint64_t *)sc.dev, fm->size);
     }
     else
     {
@@ -965,8 +981,15 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
         {
             hipLaunchKernelGGL((k_fm_count<false, false, true, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
                                m, oo, d_order, n_pat, oc, ol, orr, fm->d_sa.as<uint32_t>(), fm->d_text.as<uint8_t>());
-            hipLaunchKernelGGL(k_fm_verify, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa.as<uint32_t>(),
-                               fm->d_text.as<uint8_t>(), pp, m, oo, n_pat, oc);
+            hipLaunchKernelGGL(k_fm_verify<uint32_t>, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa.as<uint32_t>(),
+                               fm->d_text.as<uint8_t>(), pp, m, oo, n_pat, oc, fm->size);
+        }
+        else if (v.f_lines && fm->d_sa64.p && fm->d_text.p && fm_verify_enabled() && fm->size < (UINT64_C(1) << 40))
+        { // 2^32 suffixes and more: the pending word holds 40 bits of suffix and 23 of length (the kernel walks longer remainders)
+            hipLaunchKernelGGL((k_fm_count<false, false, true, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
+                               m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, fm->d_text.as<uint8_t>());
+            hipLaunchKernelGGL(k_fm_verify<uint64_t>, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa64.as<uint64_t>(),
+                               fm->d_text.as<uint8_t>(), pp, m, oo, n_pat, oc, fm->size);
         }
         else if (v.f_lines)
             hipLaunchKernelGGL((k_fm_count<false, false, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,

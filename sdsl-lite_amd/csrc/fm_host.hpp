@@ -23,6 +23,7 @@ struct sdsl_hip_fm_s
     sdslhip::FmTables tab;
     sdslhip::DevBuf d_tab;
     sdslhip::DevBuf d_sa; // suffix array (u32 per suffix) of an index created from text; empty otherwise
+    sdslhip::DevBuf d_sa64; // the same as u64 per suffix, for an index of 2^32 symbols and more created from text (d_sa is empty then)
     sdslhip::DevBuf d_text; // the text itself, kept beside the whole suffix array: count() verifies a pattern whose interval has
                             // shrunk to ONE suffix against the text instead of walking its remaining characters (fm.hip)
     // SA-order SA samples SA[k*sa_dens] and text-order ISA samples ISA[k*isa_dens] (csa_sampling_strategy.hpp:72-135,

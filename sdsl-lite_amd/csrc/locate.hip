@@ -203,7 +203,8 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
 }
 
 // SA[i] from the whole suffix array
-__global__ __launch_bounds__(256) void k_fm_sa_full(const uint32_t * __restrict__ sa, uint64_t size,
+template <class SA>
+__global__ __launch_bounds__(256) void k_fm_sa_full(const SA * __restrict__ sa, uint64_t size,
                                                     const uint64_t * __restrict__ idx, uint64_t n,
                                                     uint64_t * __restrict__ out)
 {
@@ -395,7 +396,15 @@ static sdsl_hip_status sa_lookup(sdsl_hip_fm_s * f, const uint64_t * d_idx, uint
     if (f->d_sa.p)
     {
         KernelTimer t(s);
-        hipLaunchKernelGGL(k_fm_sa_full, dim3(grid_for(n, 256, 256u * 16u)), dim3(256), 0, s, f->d_sa.as<uint32_t>(),
+        hipLaunchKernelGGL(k_fm_sa_full<uint32_t>, dim3(grid_for(n, 256, 256u * 16u)), dim3(256), 0, s, f->d_sa.as<uint32_t>(),
+                           f->size, d_idx, n, d_out);
+        SH_HIP(hipGetLastError());
+        return SDSL_HIP_OK;
+    }
+    if (f->d_sa64.p)
+    {
+        KernelTimer t(s);
+        hipLaunchKernelGGL(k_fm_sa_full<uint64_t>, dim3(grid_for(n, 256, 256u * 16u)), dim3(256), 0, s, f->d_sa64.as<uint64_t>(),
                            f->size, d_idx, n, d_out);
         SH_HIP(hipGetLastError());
         return SDSL_HIP_OK;
@@ -422,7 +431,7 @@ sdsl_hip_status sdsl_hip_fm_sampling(sdsl_hip_fm_t fm, uint32_t * sa_dens, uint3
     if (isa_dens)
         *isa_dens = fm->isa_dens;
     if (has_full_sa)
-        *has_full_sa = fm->d_sa.p ? 1 : 0;
+        *has_full_sa = fm->d_sa.p || fm->d_sa64.p ? 1 : 0;
     return SDSL_HIP_OK;
 }
 

@@ -144,7 +144,7 @@ def test_the_64_bit_suffix_sorter_on_small_texts(gpu, monkeypatch):
         ref = gpu.csa_wt(text=text)
         monkeypatch.setenv("SDSL_HIP_SA64", "1")
         csa = gpu.csa_wt(text=text)
-        assert csa.sampling() == (32, 64, False) and ref.sampling() == (0, 0, True)
+        assert csa.sampling() == (32, 64, True) and ref.sampling() == (0, 0, True)  # samples AND the 64-bit suffix array
         assert csa.serialize(32, 64) == ref.serialize(32, 64), "the stream of csa_wt<wt_huff<>, 32, 64> from the samples the index keeps"
         with pytest.raises(Exception):
             csa.serialize(16, 64)
@@ -162,6 +162,10 @@ def test_the_64_bit_suffix_sorter_on_small_texts(gpu, monkeypatch):
             got = np.sort(np.asarray(csa.locate(np.ascontiguousarray(r), m)[1]))
             assert np.array_equal(got, np.sort(ocsa.locate(bytes(r)))), bytes(r)
         assert bytes(np.asarray(csa.extract(np.array([0], dtype=np.uint64), np.array([n - 1], dtype=np.uint64))[1])) == bytes(text)
+        csa.drop_sa()                                   # from the samples alone: the walks, and count() without the text
+        assert csa.sampling() == (32, 64, False)
+        assert np.array_equal(np.asarray(csa.sa(idx)), np.asarray(ocsa.sa(idx)))
+        assert np.array_equal(np.asarray(csa.count(np.ascontiguousarray(pats.reshape(-1)), m)).astype(np.uint64), want)
         csa.close()
 
 
@@ -178,7 +182,7 @@ def test_csa_wt_from_a_text_of_more_than_2_pow_32_symbols(gpu):
     inv[sau] = np.arange(p)
     text = torch.from_numpy(u).cuda().repeat(k)
     csa = gpu.csa_wt(text=text)
-    assert csa.size() == n + 1 and csa.sigma() == sigma + 2 and csa.sampling() == (32, 64, False)
+    assert csa.size() == n + 1 and csa.sigma() == sigma + 2 and csa.sampling() == (32, 64, True)
     rng = np.random.default_rng(6)
     x = np.concatenate([rng.integers(1, n + 1, 100_000), np.array([0, 1, n, (1 << 32) - 1, 1 << 32, (1 << 32) + 1])]).astype(np.int64)
     rk, t = (x - 1) // k, (x - 1) % k
@@ -205,4 +209,10 @@ def test_csa_wt_from_a_text_of_more_than_2_pow_32_symbols(gpu):
     got = np.asarray(got)
     for i in range(3):
         assert np.array_equal(got[i * 40:(i + 1) * 40], pt.text_at(u, np.array([int(b[i])]), 40)[0])
+    # the same from the samples alone (no 64-bit suffix array, no text: every character an LF step, csa[i] a walk)
+    csa.drop_sa()
+    assert csa.sampling() == (32, 64, False)
+    assert np.array_equal(np.asarray(csa.count(np.ascontiguousarray(pats.reshape(-1)), m)).astype(np.uint64), want)
+    assert np.array_equal(np.asarray(csa.sa(x[:20_000].astype(np.uint64))).astype(np.int64), want_sa[:20_000])
+    assert np.array_equal(np.asarray(csa.isa(pos[:20_000].astype(np.uint64))).astype(np.int64), want_isa[:20_000])
     csa.close()

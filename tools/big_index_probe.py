@@ -52,6 +52,11 @@ def main():
     print(f"wt.rank(i, c), {nq} queries, symbols drawn from the text: {rate(lambda: wt.rank(i, c, out=o), nq) / 1e9:.1f} G/s")
     idx = torch.randint(0, n + 1, (1_000_000,), device="cuda", dtype=torch.int64, generator=g)
     print(f"csa[i], 10^6 places: {rate(lambda: csa.sa(idx), 1_000_000) / 1e6:.1f} M/s")
+    csa.drop_sa()
+    print(f"after drop_sa (samples 32 / 64 only, {csa.device_bytes() / 1e9:.2f} GB resident):")
+    r = rate(lambda: csa.count(pats, m, out=out), npat)
+    print(f"count: {r / 1e6:.0f} Mcount/s; every pattern found: {bool((out >= 1).all())}")
+    print(f"csa[i], 10^6 places: {rate(lambda: csa.sa(idx), 1_000_000) / 1e6:.1f} M/s")
 
 
 if __name__ == "__main__":
