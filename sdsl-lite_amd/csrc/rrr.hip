@@ -897,6 +897,8 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
         SH_HIP(hipMemcpy(hist, dh.p, sizeof hist, hipMemcpyDeviceToHost));
         h.sparse_max = choose_sparse_max(hist, n_bits);
         h.fmt = choose_format(hist, n_blocks, tables_for(h.sparse_max), h.allow_slim);
+        if (h.fmt == 1 && n_bits >= (UINT64_C(1) << 40))
+            h.fmt = 0; // (a slim record holds 40 bits of rank: also when the format was forced)
     }
     const RrrTables T = tables_for(h.sparse_max);
 again:
