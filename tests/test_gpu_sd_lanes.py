@@ -29,6 +29,12 @@ def make(name):
             bits[s:s + rng.integers(1, 60_000)] = True
     elif name == "dense":
         bits[:] = rng.random(N) < 0.5
+    elif name == "all_ones":
+        bits[:] = True
+    elif name == "single":
+        bits[N // 3] = True
+    elif name == "first_half":  # one run: every entry in the buckets of the first half, none in the second
+        bits[:N // 2] = True
     elif name == "ends":
         bits[rng.integers(0, N, N // 500)] = True
         bits[:3] = True
@@ -42,7 +48,7 @@ def pack(bits):
     return np.packbits(b.reshape(-1, 8), axis=1, bitorder="little").reshape(-1).view(np.uint64).copy()
 
 
-@pytest.mark.parametrize("name,lanes", [("sparse", 3), ("medium", 3), ("clumps", 3), ("clustered", None), ("dense", None), ("ends", 3)])
+@pytest.mark.parametrize("name,lanes", [("sparse", 3), ("medium", 3), ("clumps", 3), ("clustered", None), ("dense", None), ("ends", 3), ("all_ones", None), ("single", None), ("first_half", None)])
 def test_lane_kernels_equal_numpy_and_the_quad_kernels(gpu, name, lanes):
     bits = make(name)
     w = pack(bits)
@@ -69,11 +75,13 @@ def test_lane_kernels_equal_numpy_and_the_quad_kernels(gpu, name, lanes):
     inside = x[x < N]
     assert np.array_equal(np.asarray(v.access(inside)).astype(bool), bits[inside.astype(np.int64)])
     zi = np.searchsorted(zeros, ones[rng.integers(0, ones.size, 150_000)]).astype(np.int64) + rng.integers(-2, 3, 150_000)  # zeros next to entries
-    i = np.concatenate([rng.integers(1, zeros.size + 1, 400_000), np.clip(zi, 1, zeros.size), np.arange(1, 3000),
-                        np.arange(zeros.size - 3000, zeros.size + 1)]).astype(np.uint64)
-    got = np.asarray(v.select(i, 0))
-    assert np.array_equal(got, zeros[i - np.uint64(1)]), "select_0"
-    assert np.array_equal(np.asarray(quad.select(i, 0)), got)
+    zs = max(zeros.size, 1)
+    i = np.concatenate([rng.integers(1, zs + 1, 400_000), np.clip(zi, 1, zs), np.arange(1, min(3000, zs + 1)),
+                        np.arange(max(1, zs - 3000), zs + 1)]).astype(np.uint64)
+    if zeros.size:
+        got = np.asarray(v.select(i, 0))
+        assert np.array_equal(got, zeros[i - np.uint64(1)]), "select_0"
+        assert np.array_equal(np.asarray(quad.select(i, 0)), got)
     # outside the precondition: NPOS for rank beyond size() and select_0(0) / beyond the number of zeros; 0xFF for operator[] beyond
     bad = np.array([N + 1, 2 ** 63, 2 ** 64 - 1], dtype=np.uint64)
     assert (np.asarray(v.rank(bad, 1)) == np.uint64(2 ** 64 - 1)).all()
