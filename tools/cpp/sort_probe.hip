@@ -1,3 +1,4 @@
+// (hipcc --offload-arch=gfx950 -O2 -std=c++17 tools/cpp/sort_probe.hip -o sdsl-lite_amd/lib/sort_probe)
 // Does rocPRIM's radix_sort_pairs / inclusive_scan handle MORE than 2^32 items?  (sa.hip's 64-bit suffix sorter depends on it.)
 // keys: a hash of the index truncated to `bits` bits; values: the index.  Checks: keys non-decreasing, equal keys keep their
 // values in increasing order (stability), every value's key is its hash, scan total.
