@@ -1106,29 +1106,47 @@ __global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint6
     reinterpret_cast<uint32_t *>(fl + line * kFusedWords + 4 * (t >> 1))[t & 1] = ok ? (uint32_t)i : 0u;
 }
 
-// Sequences of 2^32 symbols and more: the headers hold the low 32 bits of their counts; a count that passes a multiple of 2^32
-// between the headers of two consecutive lines shows as a header smaller than its predecessor (a line adds at most 256).  Thread
-// (line, t) of node u notes the line FROM which the count is past the multiple (WtFusedTables::cross_*).
+// Sequences of 2^32 symbols and more: the headers hold the low 32 bits of their counts; a count that reaches a multiple of 2^32
+// inside a line shows as a next header (for the node's last line: the slot's total) smaller than this one — a line adds at most 256.
+// Thread (line, t) of node u notes the PLACE (absolute line << 8 | offset) at which the count is first j * 2^32 or more: one past the
+// occurrence that completes the multiple (WtFusedTables::cross_*).
+struct FcrossArgs
+{
+    uint64_t total[8]; // occurrences of every slot in the node
+};
 __global__ __launch_bounds__(256) void k_wt8_cross(const uint64_t * __restrict__ fl, uint64_t n_lines_u, uint32_t first_line, uint32_t u,
-                                                   uint32_t * __restrict__ n_out, uint32_t * __restrict__ line_out,
+                                                   FcrossArgs a, uint32_t * __restrict__ n_out, uint64_t * __restrict__ pos_out,
                                                    uint32_t * __restrict__ key_out)
 {
     const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t line = id >> 3;
     const unsigned t = (unsigned)id & 7u;
-    if (line + 1 >= n_lines_u)
+    if (line >= n_lines_u)
         return;
     const uint64_t * ln = fl + line * kFusedWords;
     const uint32_t c0 = reinterpret_cast<const uint32_t *>(ln + 4 * (t >> 1))[t & 1];
-    const uint32_t c1 = reinterpret_cast<const uint32_t *>(ln + kFusedWords + 4 * (t >> 1))[t & 1];
-    if (c1 < c0)
+    const uint32_t c1 = line + 1 < n_lines_u ? reinterpret_cast<const uint32_t *>(ln + kFusedWords + 4 * (t >> 1))[t & 1] : (uint32_t)a.total[t];
+    if (c1 >= c0 || (line + 1 == n_lines_u && a.total[t] < (UINT64_C(1) << 32)))
+        return; // (c1 < c0 in the last line of a slot with fewer than 2^32 occurrences cannot happen; the test keeps junk totals out)
+    uint32_t r = 0u - c0; // occurrences of t the line must add to reach the multiple: 1 .. 256
+    unsigned off = 256;
+    for (unsigned g = 0; g < 4; ++g)
     {
-        const uint32_t e = atomicAdd(n_out, 1u);
-        if (e < kFusedMaxCross)
+        const uint64_t p0 = ln[4 * g + 1], p1 = ln[4 * g + 2], p2 = ln[4 * g + 3];
+        const uint64_t m = ((t & 1) ? p0 : ~p0) & ((t & 2) ? p1 : ~p1) & ((t & 4) ? p2 : ~p2);
+        const uint32_t c = popc64(m);
+        if (r <= c)
         {
-            line_out[e] = first_line + (uint32_t)line + 1;
-            key_out[e] = (u << 3) | t;
+            off = 64u * g + sel64(m, r) + 1u;
+            break;
         }
+        r -= c;
+    }
+    const uint32_t e = atomicAdd(n_out, 1u);
+    if (e < kFusedMaxCross)
+    {
+        pos_out[e] = (((uint64_t)first_line + line) << kFusedLog) + off;
+        key_out[e] = (u << 3) | t;
     }
 }
 
@@ -1269,33 +1287,55 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
     }
     SH_HIP(hipGetLastError());
     if (wt.size >> 32)
-    { // where the counts pass multiples of 2^32 (wt_device.hpp: WtFusedTables)
-        DevBuf d_cross;
-        SH_TRY(d_cross.alloc((1 + 2 * kFusedMaxCross) * 4, true));
-        uint32_t * dc = d_cross.as<uint32_t>();
+    { // where the counts reach multiples of 2^32 (wt_device.hpp: WtFusedTables)
+        DevBuf d_n, d_pos, d_key;
+        SH_TRY(d_n.alloc(4, true));
+        SH_TRY(d_pos.alloc(kFusedMaxCross * 8, true));
+        SH_TRY(d_key.alloc(kFusedMaxCross * 4, true));
         for (uint32_t v : roots)
             if (size[v] >> 32)
             {
+                FcrossArgs ca;
+                for (unsigned t = 0; t < 8; ++t)
+                { // the node three levels down along t, or the leaf met earlier (then the rest of t must be zero)
+                    uint32_t x = v;
+                    bool ok = true;
+                    for (unsigned k = 0; k < 3; ++k)
+                    {
+                        if (T.child[x][0] == kWtUndef)
+                        {
+                            ok = (t >> k) == 0;
+                            break;
+                        }
+                        x = T.child[x][(t >> k) & 1];
+                    }
+                    ca.total[t] = ok ? size[x] : 0;
+                }
                 const uint64_t lines_v = (size[v] >> kFusedLog) + 1;
                 hipLaunchKernelGGL(k_wt8_cross, dim3(grid_for(lines_v * 8, 256, 1u << 20)), dim3(256), 0, 0,
-                                   fl + (uint64_t)FT.fline[v] * kFusedWords, lines_v, FT.fline[v], v, dc, dc + 1, dc + 1 + kFusedMaxCross);
+                                   fl + (uint64_t)FT.fline[v] * kFusedWords, lines_v, FT.fline[v], v, ca, d_n.as<uint32_t>(), d_pos.as<uint64_t>(),
+                                   d_key.as<uint32_t>());
             }
         SH_HIP(hipGetLastError());
-        std::vector<uint32_t> h(1 + 2 * kFusedMaxCross);
-        SH_HIP(hipMemcpy(h.data(), dc, h.size() * 4, hipMemcpyDeviceToHost));
-        if (h[0] > kFusedMaxCross)
+        uint32_t n_cross = 0;
+        std::vector<uint64_t> hp(kFusedMaxCross);
+        std::vector<uint32_t> hk(kFusedMaxCross);
+        SH_HIP(hipMemcpy(&n_cross, d_n.p, 4, hipMemcpyDeviceToHost));
+        SH_HIP(hipMemcpy(hp.data(), d_pos.p, kFusedMaxCross * 8, hipMemcpyDeviceToHost));
+        SH_HIP(hipMemcpy(hk.data(), d_key.p, kFusedMaxCross * 4, hipMemcpyDeviceToHost));
+        if (n_cross > kFusedMaxCross)
         { // (a sequence of 2^36 symbols and more: the binary levels answer)
             dst.d_fused.release();
             return SDSL_HIP_OK;
         }
-        FT.n_cross = h[0];
-        for (uint32_t e = 0; e < h[0]; ++e)
+        FT.n_cross = n_cross;
+        for (uint32_t e = 0; e < n_cross; ++e)
         {
-            FT.cross_line[e] = h[1 + e];
-            FT.cross_key[e] = (uint16_t)h[1 + kFusedMaxCross + e];
+            FT.cross_pos[e] = hp[e];
+            FT.cross_key[e] = (uint16_t)hk[e];
         }
         if (trace)
-            fprintf(stderr, "[sdsl_hip] fused layout: %u places where a count passes a multiple of 2^32\n", h[0]);
+            fprintf(stderr, "[sdsl_hip] fused layout: %u places where a count reaches a multiple of 2^32\n", n_cross);
     }
     SH_TRY(dst.d_ftables.alloc(sizeof(WtFusedTables)));
     SH_HIP(hipMemcpy(dst.d_ftables.p, &FT, sizeof(WtFusedTables), hipMemcpyHostToDevice));

@@ -28,18 +28,19 @@ struct WtTables // global-memory image, identical layout in LDS
     uint16_t c_to_leaf[256];
 };
 
-// Sequences of 2^32 symbols and more: a line's header keeps the LOW 32 bits of its counts, and the places where a count passes a
-// multiple of 2^32 are listed here — entry e: the count of slot (cross_key & 7) in fused node (cross_key >> 3) is below
-// j * 2^32 in front of every line before absolute line cross_line[e] and at least that from it on.  There is one entry per (node,
-// slot, j): a handful for a text of a few 2^32 symbols; the walk adds 2^32 for every entry of its (node, slot) at or in front of
-// its line.  Sequences below 2^32 symbols have no entries and never look (`wt.size >> 32` is kernel-uniform).
+// Sequences of 2^32 symbols and more: a line's header keeps the LOW 32 bits of its counts and the walk adds them up modulo 2^32,
+// exactly as for a small sequence; the PLACES where a count reaches a multiple of 2^32 are listed here — entry e: the count of slot
+// (cross_key & 7) in fused node (cross_key >> 3), taken at place cross_pos[e] = (absolute line << 8) + offset inside the line, is
+// the first to be j * 2^32 or more.  Counts grow with the place, so the high part of a count is the number of its (node, slot)'s
+// entries at or in front of its place: a handful for a text of a few 2^32 symbols.  Sequences below 2^32 symbols have no entries and
+// never look (`wt.size >> 32` is kernel-uniform).
 constexpr unsigned kFusedMaxCross = 64;
 struct WtFusedTables // node tables of the fused layout (below); staged in LDS by the kernels that walk it
 {
     uint32_t fline[kWtMaxNodes]; // first line of the node's sequence (nodes at depth 0, 3, 6, ...)
     uint32_t n_cross;
-    uint32_t cross_line[kFusedMaxCross];
     uint16_t cross_key[kFusedMaxCross];
+    uint64_t cross_pos[kFusedMaxCross];
 };
 
 // select on the fused layout: for every fused node u and slot t the directory lists the position (inside u's sequence)
@@ -205,18 +206,15 @@ __device__ __forceinline__ unsigned fsec_count(const FSec & x, int s, unsigned o
 __device__ __forceinline__ uint64_t quad_fsec_count(const WtView & wt, const WtFusedTables * FT, const FSec & x, int s, unsigned off,
                                                     unsigned t, unsigned u, uint64_t abs_line)
 {
+    const unsigned lo = quad_sum(fsec_count(x, s, off, t)); // (modulo 2^32: header and in-line part may pass a multiple together)
     if (!(wt.size >> 32)) // kernel-uniform
-        return quad_sum(fsec_count(x, s, off, t));
-    // header and in-line part apart: their sum may pass 2^32 inside the line
-    const uint64_t m = ((t & 1) ? x.p0 : ~x.p0) & ((t & 2) ? x.p1 : ~x.p1) & ((t & 4) ? x.p2 : ~x.p2);
-    const int tt = (int)off - 64 * s;
-    const unsigned cnt = tt <= 0 ? 0u : (tt >= 64 ? popc64(m) : popc64(m << (64 - tt)));
-    const unsigned hdr = (s == (int)(t >> 1)) ? (unsigned)(x.h >> (32 * (t & 1))) : 0u;
-    uint64_t hi = 0;
+        return lo;
+    const uint64_t place = (abs_line << kFusedLog) + off;
     const unsigned key = (u << 3) | t, nc = FT->n_cross;
+    unsigned hi = 0;
     for (unsigned e = 0; e < nc; ++e)
-        hi += (FT->cross_key[e] == key && (uint64_t)FT->cross_line[e] <= abs_line) ? 1u : 0u;
-    return (hi << 32) + (uint64_t)quad_sum(hdr) + quad_sum(cnt);
+        hi += (FT->cross_key[e] == key && FT->cross_pos[e] <= place) ? 1u : 0u;
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // the slot stored at position `off` of the line (all four lanes get it)
