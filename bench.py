@@ -860,6 +860,7 @@ def main():
             assert bool((sd.access(o_sd[:1_000_000]) == 0).all())
             ex["sd_vector"] = {"ones": pos.numel(), "universe_log2": 40, "low_width": sd.low_width(),
                                "bits_per_one": sd.device_bytes() * 8 / pos.numel(), "build_s": sd_build,
+                               "lane_kernels": {"rank": bool(sd.lane_kernels() & 1), "select_0": bool(sd.lane_kernels() & 2)},
                                "rank_1_Gq/s": nq_sd / ms_r / 1e6, "select_1_Gq/s": nq_sd / ms_s / 1e6,
                                "select_0_Gq/s": nq_sd / ms_z / 1e6, "queries": nq_sd}
             del sd, pos, xi, si, zi, zr, o_sd
@@ -974,6 +975,8 @@ def main():
                 chk = wt_t.rank(out2[:1_000_000], gc[:1_000_000])
                 assert torch.equal(chk, ks[:1_000_000] - 1), "rank(select(k, c), c) != k - 1"
                 ex["wt_huff_select"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2,
+                                        "path": "bucketed by place in symbol order, one lane per key (wt_sorted.hip)" if nq2 >= (1 << 23)
+                                        else "direct fused select",
                                         "reference_digest_match": digest_matches(out2, c4["wt_select"])
                                         if c4ok and "wt_select" in c4 and nq2 >= c4["wt_select"]["n"] else None}
                 del occ_c, ks, chk, wt_t
