@@ -15,9 +15,19 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def _last_json(out):
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out
+    """the contract: ONE JSON line, the LAST line of stdout, compact (bench.py: LINE_LIMIT)"""
+    all_lines = [l for l in out.splitlines() if l.strip()]
+    lines = [l for l in all_lines if l.startswith("{")]
+    assert len(lines) == 1 and all_lines[-1] == lines[0], out[-3000:]
+    assert len(lines[0].encode()) < 4096, len(lines[0])
     return json.loads(lines[0])
+
+
+def _extras(d):
+    """the legs' blocks: the sidecar the line points to"""
+    assert d["extras_file"], d
+    side = json.load(open(os.path.join(ROOT, d["extras_file"])))
+    return side["extras"]
 
 
 def test_single_gpu_contract(gpu):
@@ -32,7 +42,10 @@ def test_single_gpu_contract(gpu):
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     cb = d["cpu_baseline"]
     assert cb["cores"] == 1 and cb["kind"] in ("reference", "port") and cb["matches_gpu"] is True
-    assert "select_1" in d["extras"]
+    assert rf["traffic"] is None or "committed PMC" in rf["traffic_source"]
+    ex = _extras(d)
+    assert "select_1" in ex and "select_1" in d["summary"] and d["extras_error"] is None
+    assert "headline" in ex and ex["headline"]["cpu_baseline_all_cores"]["matches_gpu"] is True and ex["headline"]["roofline"]["phases_ms"] is None
 
 
 def test_two_ranks_share_the_gpu(gpu):
@@ -57,13 +70,16 @@ def test_two_ranks_sharded_fm_count(gpu):
                         "--text-mib", "16", "--backend", "gloo"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
-    fs = d["extras"]["fm_count_sharded"]
-    assert "error" not in d["extras"], d["extras"]
+    ex = _extras(d)
+    fs = ex["fm_count_sharded"]
+    assert "error" not in ex and d["extras_error"] is None, ex
+    assert d["secondary"]["n_gpus"] == 2 and d["secondary"]["value"] == pytest.approx(fs["resident_shards"]["Mcount/s"], rel=1e-3)
+    assert d["scaling_columns"]["end_to_end_root_owned_batch_Grank/s"] > 0
     assert fs["patterns_total"] == 200000 and fs["resident_shards"]["all_patterns_found"] is True
     assert fs["root_owned_batch_matches"] is True
     assert fs["resident_shards"]["Mcount/s"] > 0 and fs["root_owned_batch"]["Mcount/s"] > 0
     assert fs["root_owned_batch_pipelined"]["matches"] is True and fs["text_broadcast_s"] >= 0
-    ro = d["extras"]["rank_root_owned_batch"]
+    ro = ex["rank_root_owned_batch"]
     assert ro["queries"] == 2 * 2000000 and ro["matches_local"] is True and ro["Grank/s"] > 0
 
 
@@ -92,8 +108,9 @@ def test_eight_ranks_on_one_gpu(gpu):
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["reference_digest_match"] is True
-    assert "error" not in d["extras"], d["extras"]
-    fs = d["extras"]["fm_count_sharded"]
+    ex = _extras(d)
+    assert "error" not in ex, ex
+    fs = ex["fm_count_sharded"]
     assert fs["resident_shards"]["all_patterns_found"] is True and fs["root_owned_batch_matches"] is True
-    assert d["extras"]["rank_root_owned_batch"]["matches_local"] is True
+    assert ex["rank_root_owned_batch"]["matches_local"] is True
     assert took < 300, f"{took:.0f} s"
