@@ -280,8 +280,10 @@ def compact_line(result, ex, sidecar, text_mib):
     line["extras_legs"] = [k for k in ex if k not in ("error", "leg_seconds")] or None
     line["extras_error"] = ex.get("error")
     keep_exact = {"value": line["value"], "ms_per_step": line["ms_per_step"]}
+    rf_exact = {k: line["roofline"][k] for k in ("achieved", "frac", "kernel_ms")}  # frac == achieved / peak must hold to the last digit
     line = sig(line)
     line.update(keep_exact)
+    line["roofline"].update(rf_exact)
     for drop in (None, "extras_legs", "summary", "cpu_baseline_all_cores", "end_to_end", "scaling_columns"):
         if drop:
             line.pop(drop, None)

@@ -670,7 +670,7 @@ def leg_sharded(c):
     wall_s, _ = time_steps(lambda: csa.count(mine, m, res), 3, 1, barrier)
     wall_s = pkg.dist.max_over_ranks(wall_s, comm_dev)
     ok = bool((res >= 1).all())
-    fs = {"patterns_total": total, "m": m, "text_bytes": nt, "index_build_s": build, "index_bytes_per_gpu": csa.device_bytes(),
+    fs = {"n_gpus": world, "patterns_total": total, "m": m, "text_bytes": nt, "index_build_s": build, "index_bytes_per_gpu": csa.device_bytes(),
           "kmer_table_k": csa.kmer_table_depth(),
           "text_broadcast_s": bcast,
           "resident_shards": {"Mcount/s": total * 3 / wall_s / 1e6, "ms_per_batch": wall_s / 3 * 1e3,

@@ -352,6 +352,22 @@ uint32_t sdsl_hip_fm_jump_depth(sdsl_hip_fm_t fm);
 sdsl_hip_status sdsl_hip_fm_set_kmer_table(sdsl_hip_fm_t fm, uint32_t k_max, uint64_t budget_bytes);
 uint32_t sdsl_hip_fm_kmer_table_depth(sdsl_hip_fm_t fm);
 uint64_t sdsl_hip_fm_kmer_table_bytes(sdsl_hip_fm_t fm);
+/* The index at a chosen footprint.  The reference's csa_wt holds a wavelet tree, SA samples, ISA samples and the alphabet
+ * (csa_wt.hpp:389-402; 0.93 bytes per symbol for csa_wt<wt_huff<>, 32, 64> on English text); an index created from text here
+ * holds the whole suffix array, the text, both tree layouts and a k-mer table on top (8.3 bytes per symbol) because that is what
+ * makes count() fastest.  sdsl_hip_fm_set_footprint(fm, max_bytes) gives HBM back until sdsl_hip_fm_device_bytes(fm) <= max_bytes,
+ * in the order that costs count() least per byte: (1) SDSL's binary tree levels with their select directories (rebuilt from the
+ * fused lines for the time of a serialize call; select keeps the fused directory); (2) suffix array and text -> SDSL's default
+ * samples SA 32 / ISA 64 (csa_wt.hpp:56), 32 bits each, the dense jump table cut to <= 4 MiB, the k-mer table rebuilt as deep as
+ * the remaining budget allows.  Answers never change; csa[i] / locate / extract walk LF steps from the samples as the reference
+ * does (csa_wt.hpp:363-381).  Floor: fused tree lines + samples + alphabet (about 0.9 bytes per symbol of English text, i.e.
+ * the reference's own footprint); a budget below it is SDSL_HIP_ERR_INVALID and the message names the floor.  Plain tree with
+ * the fused layout, fewer than 2^32 symbols; nothing may be in flight on the handle.  One-way (restore_suffix_array brings
+ * suffix array, text and the default table back). */
+sdsl_hip_status sdsl_hip_fm_set_footprint(sdsl_hip_fm_t fm, uint64_t max_bytes);
+/* resident bytes by part: [0] binary tree levels + select directories (or the rrr vector), [1] fused tree lines + directory,
+ * [2] whole suffix array, [3] text, [4] SA + ISA samples, [5] k-mer table, [6] dense jump table, [7] alphabet / node tables */
+void sdsl_hip_fm_footprint_parts(sdsl_hip_fm_t fm, uint64_t parts[8]);
 sdsl_hip_status sdsl_hip_fm_destroy(sdsl_hip_fm_t fm);
 uint64_t sdsl_hip_fm_size(sdsl_hip_fm_t fm);  /* csa.size() = text length + 1 */
 uint64_t sdsl_hip_fm_sigma(sdsl_hip_fm_t fm); /* csa.sigma */

@@ -139,6 +139,8 @@ SIGNATURES = {
     "sdsl_hip_fm_set_kmer_table": (C.c_int32, [_vp, C.c_uint32, C.c_uint64]),
     "sdsl_hip_fm_kmer_table_depth": (C.c_uint32, [_vp]),
     "sdsl_hip_fm_kmer_table_bytes": (C.c_uint64, [_vp]),
+    "sdsl_hip_fm_set_footprint": (C.c_int32, [_vp, C.c_uint64]),
+    "sdsl_hip_fm_footprint_parts": (None, [_vp, _vp]),
     "sdsl_hip_fm_sampling": (C.c_int32, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)]),
     "sdsl_hip_fm_sa_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_fm_isa_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),

@@ -681,6 +681,8 @@ sdsl_hip_status sdsl_hip_fm_set_kmer_table(sdsl_hip_fm_t fm, uint32_t k_max, uin
         set_error("fm_set_kmer_table: null handle");
         return SDSL_HIP_ERR_INVALID;
     }
+    SH_HIP(hipSetDevice(fm->device));
+    SH_HIP(hipDeviceSynchronize()); // batches in flight on any stream may still read the table that is about to be replaced
     return fm_build_deep(fm, k_max, budget_bytes);
 }
 uint32_t sdsl_hip_fm_kmer_table_depth(sdsl_hip_fm_t fm)
@@ -696,20 +698,22 @@ uint64_t sdsl_hip_fm_kmer_table_bytes(sdsl_hip_fm_t fm)
 // (sdsl_hip_fm_extract_batch: thousands of independent walks), suffix-sorted on the device like a text handed to
 // sdsl_hip_fm_create_from_text, and the result is checked against the stream's own SA samples before it is kept.
 __global__ __launch_bounds__(256) void k_fm_check_samples(const uint32_t * __restrict__ sa, const uint64_t * __restrict__ samples,
-                                                          uint64_t n_samples, uint64_t dens, unsigned * __restrict__ bad)
+                                                          uint32_t s32, uint64_t n_samples, uint64_t dens, unsigned * __restrict__ bad)
 {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_samples; k += (uint64_t)gridDim.x * blockDim.x)
-        if ((uint64_t)sa[k * dens] != samples[k])
+        if ((uint64_t)sa[k * dens] != loc_sample(samples, s32, k))
             atomicAdd(bad, 1u);
 }
 
-sdsl_hip_status sdsl_hip_fm_restore_suffix_array(sdsl_hip_fm_t fm)
+__global__ __launch_bounds__(256) void k_fm_narrow_samples(const uint64_t * __restrict__ in, uint32_t * __restrict__ out, uint64_t n)
 {
-    if (!fm)
-    {
-        set_error("fm_restore_suffix_array: null handle");
-        return SDSL_HIP_ERR_INVALID;
-    }
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x)
+        out[k] = (uint32_t)in[k];
+}
+
+// the whole suffix array and the text back in HBM (no tables rebuilt)
+static sdsl_hip_status fm_ensure_sa_text(sdsl_hip_fm_t fm)
+{
     SH_HIP(hipSetDevice(fm->device));
     if (!(fm->d_sa.p && fm->d_text.p))
     {
@@ -733,7 +737,7 @@ sdsl_hip_status sdsl_hip_fm_restore_suffix_array(sdsl_hip_fm_t fm)
         SH_TRY(sa_build_bwt_device(d_text.as<uint8_t>(), n_text, fm->device, d_bwt, d_sa));
         SH_TRY(d_bad.alloc(4, true));
         hipLaunchKernelGGL(k_fm_check_samples, dim3(grid_for(fm->n_sa_s, 256, 256u * 8u)), dim3(256), 0, 0, d_sa.as<uint32_t>(),
-                           fm->d_sa_s.as<uint64_t>(), fm->n_sa_s, (uint64_t)fm->sa_dens, d_bad.as<unsigned>());
+                           fm->d_sa_s.as<uint64_t>(), fm->samples32 ? 1u : 0u, fm->n_sa_s, (uint64_t)fm->sa_dens, d_bad.as<unsigned>());
         SH_HIP(hipGetLastError());
         unsigned bad = 0;
         SH_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
@@ -745,6 +749,17 @@ sdsl_hip_status sdsl_hip_fm_restore_suffix_array(sdsl_hip_fm_t fm)
         fm->d_sa = std::move(d_sa);
         fm->d_text = std::move(d_text);
     }
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_restore_suffix_array(sdsl_hip_fm_t fm)
+{
+    if (!fm)
+    {
+        set_error("fm_restore_suffix_array: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_TRY(fm_ensure_sa_text(fm));
     if (!fm->ctab_ok)
         SH_TRY(fm_build_count_tab(fm));
     if (!fm->deep_k)
@@ -770,6 +785,148 @@ sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
     fm->d_sa64.release();
     fm->d_text.release(); // (only useful beside the whole suffix array)
     return SDSL_HIP_OK;
+}
+
+// ---- the index at a chosen footprint ------------------------------------------------------------------------------------
+// What the reference's csa_wt holds (csa_wt.hpp:389-402: wavelet tree, SA samples, ISA samples, alphabet) is 0.93 bytes per symbol
+// for csa_wt<wt_huff<>, 32, 64> on English text; an index created from text here holds 8.3 (whole suffix array, text, both tree
+// layouts, k-mer table), because HBM is there to be used.  sdsl_hip_fm_set_footprint gives memory back in the order that costs
+// count() least per byte:
+//   1. SDSL's binary tree levels with their select directories (serialisation and select on trees without the fused directory
+//      rebuild them from the fused lines when asked: wt_restore_binary) — count() / rank / access / LF walks lose nothing;
+//   2. the whole suffix array and the text (the single-suffix shortcut of count(), csa[i] as a gather) -> SDSL's default samples
+//      (32 / 64), packed to 32 bits per sample; the dense jump table shrinks to <= 4 MiB; the k-mer table is rebuilt first, as deep
+//      as the budget still allows (it is built FROM suffix array and text; an index that has dropped them gets them back for the
+//      time of the call: fm_ensure_sa_text).
+// What remains at the floor: the fused lines (4 bits per symbol and fused level), the samples, the alphabet tables.
+void sdsl_hip_fm_footprint_parts(sdsl_hip_fm_t fm, uint64_t parts[8])
+{
+    for (int i = 0; i < 8; ++i)
+        parts[i] = 0;
+    if (!fm)
+        return;
+    const WtHost & w = sdsl_hip_wt_host(fm->wt);
+    parts[0] = w.bv.device_bytes() + w.rrr.device_bytes();
+    parts[1] = w.d_fused.bytes + w.d_ftables.bytes + w.d_fsel.bytes + w.d_fsel_tables.bytes + w.d_tables_f.bytes;
+    parts[2] = fm->d_sa.bytes + fm->d_sa64.bytes;
+    parts[3] = fm->d_text.bytes;
+    parts[4] = fm->d_sa_s.bytes + fm->d_isa_s.bytes;
+    parts[5] = fm->d_deep.bytes;
+    parts[6] = fm->d_jump.bytes;
+    parts[7] = fm->d_tab.bytes + fm->d_ctab.bytes + w.d_tables.bytes;
+}
+
+static sdsl_hip_status fm_pack_samples32(sdsl_hip_fm_s * f)
+{
+    if (f->samples32 || !f->sa_dens || !f->isa_dens || f->size >= (UINT64_C(1) << 32))
+        return SDSL_HIP_OK;
+    DevBuf a, b;
+    SH_TRY(a.alloc(std::max<uint64_t>(f->n_sa_s, 1) * 4));
+    SH_TRY(b.alloc(std::max<uint64_t>(f->n_isa_s, 1) * 4));
+    hipLaunchKernelGGL(k_fm_narrow_samples, dim3(grid_for(f->n_sa_s, 256, 256u * 8u)), dim3(256), 0, 0, f->d_sa_s.as<uint64_t>(),
+                       a.as<uint32_t>(), f->n_sa_s);
+    hipLaunchKernelGGL(k_fm_narrow_samples, dim3(grid_for(f->n_isa_s, 256, 256u * 8u)), dim3(256), 0, 0, f->d_isa_s.as<uint64_t>(),
+                       b.as<uint32_t>(), f->n_isa_s);
+    SH_HIP(hipGetLastError());
+    SH_HIP(hipDeviceSynchronize());
+    f->d_sa_s = std::move(a);
+    f->d_isa_s = std::move(b);
+    f->samples32 = true;
+    return SDSL_HIP_OK;
+}
+
+static sdsl_hip_status sdsl_hip_fm_set_footprint_impl(sdsl_hip_fm_t fm, uint64_t max_bytes)
+{
+    if (!fm)
+    {
+        set_error("fm_set_footprint: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_HIP(hipSetDevice(fm->device));
+    SH_HIP(hipDeviceSynchronize()); // nothing in flight may still read what is released below
+    if (sdsl_hip_fm_device_bytes(fm) <= max_bytes)
+        return SDSL_HIP_OK;
+    WtHost & w = sdsl_hip_wt_host(fm->wt);
+    if (w.backend == 0 && w.d_fused.p && !fm->ctab_ok)
+        SH_TRY(fm_build_count_tab(fm)); // (an index loaded from a stream gets the flat kernel's tables on first need)
+    if (w.backend != 0 || !w.d_fused.p || !fm->ctab_ok || fm->size >= (UINT64_C(1) << 32))
+    {
+        set_error("fm_set_footprint: the compact forms exist for an index on the plain wavelet tree with its fused layout and fewer "
+                  "than 2^32 symbols (this one holds %llu bytes; for a smaller index of any size: SDSL_HIP_WT_RRR63)",
+                  (unsigned long long)sdsl_hip_fm_device_bytes(fm));
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    uint64_t parts[8];
+    sdsl_hip_fm_footprint_parts(fm, parts);
+    // 1. the binary levels alone
+    if (sdsl_hip_fm_device_bytes(fm) - parts[0] <= max_bytes)
+        return wt_drop_binary(w);
+    // 2. samples instead of suffix array and text: what is the floor, what is left for the k-mer table?
+    const uint64_t n = fm->size;
+    const bool make_samples = !fm->sa_dens || !fm->isa_dens;
+    if (make_samples && !fm->d_sa.p)
+    {
+        set_error("fm_set_footprint: this index has neither its suffix array nor SA / ISA samples (created from a BWT, or loaded "
+                  "without densities): there is nothing smaller to fall back to");
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    const uint64_t n_sa_s = make_samples ? (n + 31) / 32 : fm->n_sa_s, n_isa_s = make_samples ? (n + 63) / 64 : fm->n_isa_s;
+    // the dense jump table (small batches, intervals, ragged patterns) keeps a depth of at most 4 MiB and 1/16 byte per symbol
+    const uint64_t jump_cap = std::min<uint64_t>(UINT64_C(4) << 20, n / 16);
+    uint32_t jk = 0;
+    uint64_t jump_bytes = 16;
+    while (jk < fm->jump_k && jump_bytes * fm->sigma <= jump_cap)
+    {
+        jump_bytes *= fm->sigma;
+        ++jk;
+    }
+    const uint64_t floor_bytes = parts[1] + parts[7] + (n_sa_s + n_isa_s) * 4 + (jk ? jump_bytes : 0);
+    if (floor_bytes > max_bytes)
+    {
+        set_error("fm_set_footprint: the smallest form of this index (fused tree lines, SA / ISA samples at %u / %u, alphabet) is %llu "
+                  "bytes; %llu were asked for.  csa_wt<wt_huff<rrr_vector<63>>> (SDSL_HIP_WT_RRR63) is the smaller structure",
+                  make_samples ? 32u : fm->sa_dens, make_samples ? 64u : fm->isa_dens, (unsigned long long)floor_bytes,
+                  (unsigned long long)max_bytes);
+        return SDSL_HIP_ERR_INVALID;
+    }
+    if (make_samples)
+    {
+        SH_TRY(sa_samples_device(fm->d_sa.as<uint32_t>(), n, 32, 64, &fm->d_sa_s, &fm->d_isa_s));
+        fm->sa_dens = 32;
+        fm->isa_dens = 64;
+        fm->n_sa_s = n_sa_s;
+        fm->n_isa_s = n_isa_s;
+        fm->samples32 = false;
+    }
+    const uint64_t table_budget = max_bytes - floor_bytes;
+    if (fm->d_deep.bytes > table_budget || (!fm->deep_k && table_budget >= (UINT64_C(64) << 10)))
+    {
+        if (table_budget < 128)
+            SH_TRY(fm_build_deep(fm, 0, 0));
+        else
+        {
+            SH_TRY(fm_ensure_sa_text(fm));
+            SH_TRY(fm_build_deep(fm, 8, table_budget));
+        }
+    }
+    fm->d_sa.release();
+    fm->d_sa64.release();
+    fm->d_text.release();
+    SH_TRY(fm_pack_samples32(fm));
+    if (jk != fm->jump_k)
+        SH_TRY(fm_build_jump_k(fm, jk));
+    SH_TRY(wt_drop_binary(w));
+    if (sdsl_hip_fm_device_bytes(fm) > max_bytes)
+    {
+        set_error("internal: fm_set_footprint left %llu bytes, %llu were asked for", (unsigned long long)sdsl_hip_fm_device_bytes(fm),
+                  (unsigned long long)max_bytes);
+        return SDSL_HIP_ERR_HIP;
+    }
+    return SDSL_HIP_OK;
+}
+sdsl_hip_status sdsl_hip_fm_set_footprint(sdsl_hip_fm_t fm, uint64_t max_bytes)
+{
+    return guarded("fm_set_footprint", [&] { return sdsl_hip_fm_set_footprint_impl(fm, max_bytes); });
 }
 
 static sdsl_hip_status sdsl_hip_fm_serialize_impl(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens, void * buf, size_t cap,
@@ -816,8 +973,19 @@ static sdsl_hip_status sdsl_hip_fm_serialize_ex_impl(sdsl_hip_fm_t fm, int32_t l
     {
         sa_s.resize(fm->n_sa_s);
         isa_s.resize(fm->n_isa_s);
-        SH_HIP(hipMemcpy(sa_s.data(), fm->d_sa_s.p, fm->n_sa_s * 8, hipMemcpyDeviceToHost));
-        SH_HIP(hipMemcpy(isa_s.data(), fm->d_isa_s.p, fm->n_isa_s * 8, hipMemcpyDeviceToHost));
+        if (fm->samples32)
+        { // packed by sdsl_hip_fm_set_footprint: u32 per sample
+            std::vector<uint32_t> t(std::max(fm->n_sa_s, fm->n_isa_s));
+            SH_HIP(hipMemcpy(t.data(), fm->d_sa_s.p, fm->n_sa_s * 4, hipMemcpyDeviceToHost));
+            std::copy(t.begin(), t.begin() + fm->n_sa_s, sa_s.begin());
+            SH_HIP(hipMemcpy(t.data(), fm->d_isa_s.p, fm->n_isa_s * 4, hipMemcpyDeviceToHost));
+            std::copy(t.begin(), t.begin() + fm->n_isa_s, isa_s.begin());
+        }
+        else
+        {
+            SH_HIP(hipMemcpy(sa_s.data(), fm->d_sa_s.p, fm->n_sa_s * 8, hipMemcpyDeviceToHost));
+            SH_HIP(hipMemcpy(isa_s.data(), fm->d_isa_s.p, fm->n_isa_s * 8, hipMemcpyDeviceToHost));
+        }
     }
     else
         SH_TRY(sa_samples_to_host(fm->d_sa.as<uint32_t>(), n, sa_dens, isa_dens, sa_s, isa_s));
@@ -923,81 +1091,88 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
         if (st != SDSL_HIP_ERR_NOMEM)
             return st; // (no working memory — also: the stream is being captured — leaves the batch to the lock-step kernel below)
     }
-    unsigned grid = grid_for(n_pat, kQPB, 256u * 8u);
-    // Large batches are answered in suffix order (see k_fm_keys): one key kernel + one radix sort, no synchronisation
-    static const int sort_knob = getenv("SDSL_HIP_FM_SORT") ? atoi(getenv("SDSL_HIP_FM_SORT")) : -1;
-    const bool ordered = sort_knob < 0 ? (n_pat >= (UINT64_C(1) << 16) && n_pat < UINT64_C(0xFFFFFFFF)) : sort_knob != 0;
-    uint32_t * d_order = nullptr;
-    // (keys, order and the sort's working memory: from the device's scratch pool, held until the search is enqueued — bv_host.hpp:
-    // ScratchLease; not the stream-ordered allocator, sa.hip: sort_pairs_u64_u32)
-    static DevBuf no_capture_scratch;
-    ScratchLease lease;
-    KernelTimer t(s); // covers key generation + sort + search: the whole cost of the batch
-    if (ordered)
-    {
-        const size_t kb = (size_t)n_pat * 8, ib = (size_t)n_pat * 4, tb = (sort_pairs_u64_u32_temp_bytes(n_pat, 64u) + 255) & ~(size_t)255;
-        SH_TRY(lease.acquire(fm->device, no_capture_scratch, 2 * kb + 2 * ib + tb + 256, s));
-    }
-    if (ordered && lease.p)
-    {
-        const size_t kb = (size_t)n_pat * 8, ib = (size_t)n_pat * 4;
-        uint64_t * k0 = (uint64_t *)lease.p;
-        uint64_t * k1 = k0 + n_pat;
-        uint32_t * i0 = (uint32_t *)(k1 + n_pat);
-        uint32_t * i1 = i0 + n_pat;
-        uint8_t * tmp = reinterpret_cast<uint8_t *>(lease.p) + ((2 * kb + 2 * ib + 255) & ~(size_t)255);
-        hipLaunchKernelGGL(k_fm_keys, dim3(grid_for(n_pat, 256, 256u * 8u)), dim3(256), 0, s, (const uint8_t *)sp.dev, m,
-                           offsets ? (const uint64_t *)so.dev : nullptr, n_pat, k0, i0);
-        SH_TRY(sort_pairs_u64_u32(k0, k1, i0, i1, n_pat, 64u, s, tmp, lease.bytes - (size_t)(tmp - reinterpret_cast<uint8_t *>(lease.p))));
-        d_order = i1;
-    }
-    if (w.backend == 1)
-    {
-        const bool verify = !ival && fm->d_sa.p && fm->d_text.p && fm_verify_enabled() && fm->size < (UINT64_C(1) << 32);
-        SH_TRY(fm_rrr_launch_count(w, fm->d_tab.as<FmTables>(), jump, fm->size, (const uint8_t *)sp.dev, m,
-                                   offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat,
-                                   ival ? nullptr : (uint64_t *)sc.dev, ival ? (uint64_t *)sl.dev : nullptr,
-                                   ival ? (uint64_t *)sr.dev : nullptr, s, verify));
-        if (verify)
-            hipLaunchKernelGGL(k_fm_verify<uint32_t>, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa.as<uint32_t>(),
-                               fm->d_text.as<uint8_t>(), (const uint8_t *)sp.dev, m, offsets ? (const uint64_t *)so.dev : nullptr, n_pat,
-                               (uint64_t *)sc.dev, fm->size);
-    }
-    else
-    {
-        const FmTables * tab = fm->d_tab.as<FmTables>();
-        const uint8_t * pp = (const uint8_t *)sp.dev;
-        const uint64_t * oo = offsets ? (const uint64_t *)so.dev : nullptr;
-        uint64_t *oc = ival ? nullptr : (uint64_t *)sc.dev, *ol = ival ? (uint64_t *)sl.dev : nullptr,
-                 *orr = ival ? (uint64_t *)sr.dev : nullptr;
-        const WtView v = w.view();
-        if (ival && v.f_lines)
-            hipLaunchKernelGGL((k_fm_count<false, true, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp, m,
-                               oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
-        else if (ival)
-            hipLaunchKernelGGL((k_fm_count<false, true, false>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
-                               m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
-        else if (v.f_lines && fm->d_sa.p && fm->d_text.p && fm_verify_enabled())
+    // everything that uses the device's scratch pool is enqueued inside this scope: the lease (the pool's mutex) ends with the last
+    // kernel that reads the scratch, BEFORE the results are copied out and the stream is waited for — other handles' large batches on
+    // this device are not held up for the length of this one
+    auto enqueue = [&]() -> sdsl_hip_status {
+        unsigned grid = grid_for(n_pat, kQPB, 256u * 8u);
+        // Large batches are answered in suffix order (see k_fm_keys): one key kernel + one radix sort, no synchronisation
+        static const int sort_knob = getenv("SDSL_HIP_FM_SORT") ? atoi(getenv("SDSL_HIP_FM_SORT")) : -1;
+        const bool ordered = sort_knob < 0 ? (n_pat >= (UINT64_C(1) << 16) && n_pat < UINT64_C(0xFFFFFFFF)) : sort_knob != 0;
+        uint32_t * d_order = nullptr;
+        // (keys, order and the sort's working memory: from the device's scratch pool, held until the search is enqueued — bv_host.hpp:
+        // ScratchLease; not the stream-ordered allocator, sa.hip: sort_pairs_u64_u32)
+        static DevBuf no_capture_scratch;
+        ScratchLease lease;
+        KernelTimer t(s); // covers key generation + sort + search: the whole cost of the batch
+        if (ordered)
         {
-            hipLaunchKernelGGL((k_fm_count<false, false, true, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
-                               m, oo, d_order, n_pat, oc, ol, orr, fm->d_sa.as<uint32_t>(), fm->d_text.as<uint8_t>());
-            hipLaunchKernelGGL(k_fm_verify<uint32_t>, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa.as<uint32_t>(),
-                               fm->d_text.as<uint8_t>(), pp, m, oo, n_pat, oc, fm->size);
+            const size_t kb = (size_t)n_pat * 8, ib = (size_t)n_pat * 4, tb = (sort_pairs_u64_u32_temp_bytes(n_pat, 64u) + 255) & ~(size_t)255;
+            SH_TRY(lease.acquire(fm->device, no_capture_scratch, 2 * kb + 2 * ib + tb + 256, s));
         }
-        else if (v.f_lines && fm->d_sa64.p && fm->d_text.p && fm_verify_enabled() && fm->size < (UINT64_C(1) << 40))
-        { // 2^32 suffixes and more: the pending word holds 40 bits of suffix and 23 of length (the kernel walks longer remainders)
-            hipLaunchKernelGGL((k_fm_count<false, false, true, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
-                               m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, fm->d_text.as<uint8_t>());
-            hipLaunchKernelGGL(k_fm_verify<uint64_t>, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa64.as<uint64_t>(),
-                               fm->d_text.as<uint8_t>(), pp, m, oo, n_pat, oc, fm->size);
+        if (ordered && lease.p)
+        {
+            const size_t kb = (size_t)n_pat * 8, ib = (size_t)n_pat * 4;
+            uint64_t * k0 = (uint64_t *)lease.p;
+            uint64_t * k1 = k0 + n_pat;
+            uint32_t * i0 = (uint32_t *)(k1 + n_pat);
+            uint32_t * i1 = i0 + n_pat;
+            uint8_t * tmp = reinterpret_cast<uint8_t *>(lease.p) + ((2 * kb + 2 * ib + 255) & ~(size_t)255);
+            hipLaunchKernelGGL(k_fm_keys, dim3(grid_for(n_pat, 256, 256u * 8u)), dim3(256), 0, s, (const uint8_t *)sp.dev, m,
+                               offsets ? (const uint64_t *)so.dev : nullptr, n_pat, k0, i0);
+            SH_TRY(sort_pairs_u64_u32(k0, k1, i0, i1, n_pat, 64u, s, tmp, lease.bytes - (size_t)(tmp - reinterpret_cast<uint8_t *>(lease.p))));
+            d_order = i1;
         }
-        else if (v.f_lines)
-            hipLaunchKernelGGL((k_fm_count<false, false, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
-                               m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
+        if (w.backend == 1)
+        {
+            const bool verify = !ival && fm->d_sa.p && fm->d_text.p && fm_verify_enabled() && fm->size < (UINT64_C(1) << 32);
+            SH_TRY(fm_rrr_launch_count(w, fm->d_tab.as<FmTables>(), jump, fm->size, (const uint8_t *)sp.dev, m,
+                                       offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat,
+                                       ival ? nullptr : (uint64_t *)sc.dev, ival ? (uint64_t *)sl.dev : nullptr,
+                                       ival ? (uint64_t *)sr.dev : nullptr, s, verify));
+            if (verify)
+                hipLaunchKernelGGL(k_fm_verify<uint32_t>, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa.as<uint32_t>(),
+                                   fm->d_text.as<uint8_t>(), (const uint8_t *)sp.dev, m, offsets ? (const uint64_t *)so.dev : nullptr, n_pat,
+                                   (uint64_t *)sc.dev, fm->size);
+        }
         else
-            hipLaunchKernelGGL((k_fm_count<false, false, false>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
-                               m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
-    }
+        {
+            const FmTables * tab = fm->d_tab.as<FmTables>();
+            const uint8_t * pp = (const uint8_t *)sp.dev;
+            const uint64_t * oo = offsets ? (const uint64_t *)so.dev : nullptr;
+            uint64_t *oc = ival ? nullptr : (uint64_t *)sc.dev, *ol = ival ? (uint64_t *)sl.dev : nullptr,
+                     *orr = ival ? (uint64_t *)sr.dev : nullptr;
+            const WtView v = w.view();
+            if (ival && v.f_lines)
+                hipLaunchKernelGGL((k_fm_count<false, true, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp, m,
+                                   oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
+            else if (ival)
+                hipLaunchKernelGGL((k_fm_count<false, true, false>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
+                                   m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
+            else if (v.f_lines && fm->d_sa.p && fm->d_text.p && fm_verify_enabled())
+            {
+                hipLaunchKernelGGL((k_fm_count<false, false, true, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
+                                   m, oo, d_order, n_pat, oc, ol, orr, fm->d_sa.as<uint32_t>(), fm->d_text.as<uint8_t>());
+                hipLaunchKernelGGL(k_fm_verify<uint32_t>, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa.as<uint32_t>(),
+                                   fm->d_text.as<uint8_t>(), pp, m, oo, n_pat, oc, fm->size);
+            }
+            else if (v.f_lines && fm->d_sa64.p && fm->d_text.p && fm_verify_enabled() && fm->size < (UINT64_C(1) << 40))
+            { // 2^32 suffixes and more: the pending word holds 40 bits of suffix and 23 of length (the kernel walks longer remainders)
+                hipLaunchKernelGGL((k_fm_count<false, false, true, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
+                                   m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, fm->d_text.as<uint8_t>());
+                hipLaunchKernelGGL(k_fm_verify<uint64_t>, dim3(grid_for(n_pat, 256, 256u * 16u)), dim3(256), 0, s, fm->d_sa64.as<uint64_t>(),
+                                   fm->d_text.as<uint8_t>(), pp, m, oo, n_pat, oc, fm->size);
+            }
+            else if (v.f_lines)
+                hipLaunchKernelGGL((k_fm_count<false, false, true>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
+                                   m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
+            else
+                hipLaunchKernelGGL((k_fm_count<false, false, false>), dim3(grid), dim3(kBlock), 0, s, v, tab, jump, fm->size, pp,
+                                   m, oo, d_order, n_pat, oc, ol, orr, (const uint32_t *)nullptr, (const uint8_t *)nullptr);
+        }
+        return SDSL_HIP_OK;
+    };
+    SH_TRY(enqueue());
     SH_HIP(hipGetLastError());
     if (ival)
     {

@@ -593,16 +593,22 @@ sdsl_hip_status fm_build_count_tab(sdsl_hip_fm_s * f)
 // per k-mer at a load of one half — stays within `budget_bytes`; k_max == 0 releases the table.
 sdsl_hip_status fm_build_deep(sdsl_hip_fm_s * f, uint32_t k_max, uint64_t budget_bytes)
 {
-    f->d_deep.release();
-    f->deep_k = 0;
-    f->deep_buckets = 0;
-    f->deep_kmers = 0;
+    auto release = [&]() {
+        f->d_deep.release();
+        f->deep_k = 0;
+        f->deep_buckets = 0;
+        f->deep_kmers = 0;
+    };
     if (k_max == 0)
+    {
+        release();
         return SDSL_HIP_OK;
+    }
+    // preconditions first: a call that cannot build leaves the table the index has (it may be one that can no longer be rebuilt)
     if (!f->d_sa.p || !f->d_text.p || f->size < 2 || f->size >= (UINT64_C(1) << 32))
     {
         set_error("the k-mer table is built from the whole suffix array and the text: create the index from text (and before "
-                  "sdsl_hip_fm_drop_sa)");
+                  "sdsl_hip_fm_drop_sa), or sdsl_hip_fm_restore_suffix_array first");
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
     SH_HIP(hipSetDevice(f->device));
@@ -626,25 +632,27 @@ sdsl_hip_status fm_build_deep(sdsl_hip_fm_s * f, uint32_t k_max, uint64_t budget
                 (unsigned long long)dk[1], (unsigned long long)dk[2], (unsigned long long)dk[3], (unsigned long long)dk[4],
                 (unsigned long long)dk[5], (unsigned long long)dk[6], (unsigned long long)dk[7], (unsigned long long)dk[8],
                 (unsigned long long)(budget_bytes >> 20), k);
-    if (k == 0)
+    const uint64_t nb = k ? std::max<uint64_t>(1, (dk[k] + 3) / 4) : 0; // eight slots per bucket, four taken on average
+    if (k == 0 || nb >= (UINT64_C(1) << 32))
+    { // no depth fits the budget: the caller asked for a table smaller than the smallest
+        release();
         return SDSL_HIP_OK;
-    const uint64_t nb = std::max<uint64_t>(1, (dk[k] + 3) / 4); // eight slots per bucket, four taken on average
-    if (nb >= (UINT64_C(1) << 32))
-        return SDSL_HIP_OK;
-    SH_TRY(f->d_deep.alloc(nb * 128, true));
+    }
+    if (k == f->deep_k && nb == f->deep_buckets)
+        return SDSL_HIP_OK; // the table the index has is the one asked for
+    DevBuf d_new; // built beside the old table, swapped in when it is complete
+    SH_TRY(d_new.alloc(nb * 128, true));
     unsigned * failed = reinterpret_cast<unsigned *>(d_dk.as<unsigned long long>() + 9);
     hipLaunchKernelGGL((k_deep_fill<0>), dim3(grid), dim3(256), 0, 0, f->d_sa.as<uint32_t>(), n, f->d_text.as<uint8_t>(), n_text,
-                       k, f->d_deep.as<unsigned long long>(), (uint32_t)nb, failed);
+                       k, d_new.as<unsigned long long>(), (uint32_t)nb, failed);
     hipLaunchKernelGGL((k_deep_fill<1>), dim3(grid), dim3(256), 0, 0, f->d_sa.as<uint32_t>(), n, f->d_text.as<uint8_t>(), n_text,
-                       k, f->d_deep.as<unsigned long long>(), (uint32_t)nb, failed);
+                       k, d_new.as<unsigned long long>(), (uint32_t)nb, failed);
     SH_HIP(hipGetLastError());
     unsigned bad = 0;
     SH_HIP(hipMemcpy(&bad, failed, 4, hipMemcpyDeviceToHost));
     if (bad)
-    { // cannot happen at this load; an index without the table is still complete
-        f->d_deep.release();
-        return SDSL_HIP_OK;
-    }
+        return SDSL_HIP_OK; // cannot happen at this load; the index keeps what it had and is complete without any table
+    f->d_deep = std::move(d_new);
     f->deep_k = k;
     f->deep_buckets = (uint32_t)nb;
     f->deep_kmers = dk[k];

@@ -31,6 +31,7 @@ struct sdsl_hip_fm_s
     sdslhip::DevBuf d_sa_s, d_isa_s;
     uint32_t sa_dens = 0, isa_dens = 0;
     uint64_t n_sa_s = 0, n_isa_s = 0;
+    bool samples32 = false; // the samples are u32 each (sdsl_hip_fm_set_footprint packs them; fewer than 2^32 symbols)
     sdslhip::DevBuf d_jump; // jump-start table (fm_device.hpp FmJump), sigma^jump_k (l, r) pairs
     uint32_t jump_k = 0;
     // count() of large batches (fm_count2.hip): the per-byte step tables of the flat kernel and the k-mer table
@@ -67,7 +68,14 @@ struct FmLocView
     const uint64_t * isa_s;   // or null
     uint64_t sa_dens, isa_dens, n_isa_s;
     uint64_t size;
+    uint32_t s32;             // samples are 32 bits wide (read through loc_sample)
 };
+
+// sample i of a sample array that is u64 or, packed (sdsl_hip_fm_set_footprint), u32 per entry
+__device__ __forceinline__ uint64_t loc_sample(const uint64_t * p, uint32_t s32, uint64_t i)
+{
+    return s32 ? (uint64_t)reinterpret_cast<const uint32_t *>(p)[i] : p[i];
+}
 
 sdsl_hip_status sa_build_bwt_device(const uint8_t * text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa);
 // texts of 2^32 - 2 bytes and more: 64-bit suffixes (d_sa: u64 per suffix)

@@ -85,7 +85,7 @@ __device__ __forceinline__ void isa_sample_right(const FmLocView & L, uint64_t i
 {
     const uint64_t ci = (i / L.isa_dens + 1) % L.n_isa_s;
     pos = ci * L.isa_dens;
-    order = L.isa_s[ci];
+    order = loc_sample(L.isa_s, L.s32, ci);
 }
 
 template <class P, int MODE>
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
             uint64_t r = SDSL_HIP_NPOS;
             if (j % L.sa_dens == 0)
             {
-                r = L.sa_s[j / L.sa_dens] + taken; // (csa_wt.hpp:373-380)
+                r = loc_sample(L.sa_s, L.s32, j / L.sa_dens) + taken; // (csa_wt.hpp:373-380)
                 r = r < L.size ? r : r - L.size;
             }
             if (s == 0)
@@ -349,6 +349,7 @@ static FmLocView loc_view(const sdsl_hip_fm_s * f)
     L.isa_dens = f->isa_dens;
     L.n_isa_s = f->n_isa_s;
     L.size = f->size;
+    L.s32 = f->samples32 ? 1u : 0u;
     return L;
 }
 

@@ -479,9 +479,21 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
         set_error("wt_create: SDSL_HIP_WT_BLCD and SDSL_HIP_WT_HUTU exclude each other");
         return SDSL_HIP_ERR_INVALID;
     }
-    SH_TRY(build_shape(wt.occ,
-                       (flags & kWtShapeHuff8) ? 3u : ((flags & SDSL_HIP_WT_BLCD) ? 1u : ((flags & SDSL_HIP_WT_HUTU) ? 2u : 0u)),
-                       wt.tables, wt.n_nodes, bv_size, wt.sigma));
+    if (flags & kWtShapeGiven)
+    { // the caller has put the node table, n_nodes and sigma into `wt` (wt_restore_binary: whatever shape the tree has)
+        for (int c = 0; c < 256; ++c)
+            if (wt.tables.c_to_leaf[c] != kWtUndef)
+                bv_size += wt.occ[c] * (wt.tables.path[c] >> 56);
+            else if (wt.occ[c])
+            {
+                set_error("internal: symbol %d occurs in the sequence but has no leaf in the given tree shape", c);
+                return SDSL_HIP_ERR_HIP;
+            }
+    }
+    else
+        SH_TRY(build_shape(wt.occ,
+                           (flags & kWtShapeHuff8) ? 3u : ((flags & SDSL_HIP_WT_BLCD) ? 1u : ((flags & SDSL_HIP_WT_HUTU) ? 2u : 0u)),
+                           wt.tables, wt.n_nodes, bv_size, wt.sigma));
     WtTables & T = wt.tables;
     const bool tr_b = getenv("SDSL_HIP_TRACE_BUILD") != nullptr;
     auto mark_b = [&](const char * what, unsigned d) {
@@ -1083,27 +1095,28 @@ __global__ __launch_bounds__(256) void k_wt8_planes(WtView wt, unsigned u, uint6
 __global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint64_t n_lines_u, uint64_t * __restrict__ fl)
 {
     const WtTables * T = wt.tables;
-    const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t line = id >> 3;
-    const unsigned t = (unsigned)id & 7u;
-    if (line >= n_lines_u)
-        return;
-    unsigned v = u;
-    uint64_t i = line << kFusedLog;
-    bool ok = true;
-    for (unsigned k = 0; k < 3; ++k)
+    // grid-stride: the launch caps its grid (2^20 blocks = 2^25 lines = 2^33 symbols per pass), a node of a 2^36-symbol sequence has more
+    for (uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x; id < n_lines_u * 8; id += (uint64_t)gridDim.x * 256)
     {
-        if (T->child[v][0] == kWtUndef)
-        { // a leaf above the third level: its slot is the path padded with zeros
-            ok = (t >> k) == 0;
-            break;
+        const uint64_t line = id >> 3;
+        const unsigned t = (unsigned)id & 7u;
+        unsigned v = u;
+        uint64_t i = line << kFusedLog;
+        bool ok = true;
+        for (unsigned k = 0; k < 3; ++k)
+        {
+            if (T->child[v][0] == kWtUndef)
+            { // a leaf above the third level: its slot is the path padded with zeros
+                ok = (t >> k) == 0;
+                break;
+            }
+            const unsigned bit = (t >> k) & 1;
+            const uint64_t r = lane_rank1(wt.bv.lines, T->bv_pos[v] + i, nullptr) - T->bv_pos_rank[v];
+            i = bit ? r : i - r;
+            v = T->child[v][bit];
         }
-        const unsigned bit = (t >> k) & 1;
-        const uint64_t r = lane_rank1(wt.bv.lines, T->bv_pos[v] + i, nullptr) - T->bv_pos_rank[v];
-        i = bit ? r : i - r;
-        v = T->child[v][bit];
+        reinterpret_cast<uint32_t *>(fl + line * kFusedWords + 4 * (t >> 1))[t & 1] = ok ? (uint32_t)i : 0u;
     }
-    reinterpret_cast<uint32_t *>(fl + line * kFusedWords + 4 * (t >> 1))[t & 1] = ok ? (uint32_t)i : 0u;
 }
 
 // Sequences of 2^32 symbols and more: the headers hold the low 32 bits of their counts; a count that reaches a multiple of 2^32
@@ -1118,35 +1131,35 @@ __global__ __launch_bounds__(256) void k_wt8_cross(const uint64_t * __restrict__
                                                    FcrossArgs a, uint32_t * __restrict__ n_out, uint64_t * __restrict__ pos_out,
                                                    uint32_t * __restrict__ key_out)
 {
-    const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t line = id >> 3;
-    const unsigned t = (unsigned)id & 7u;
-    if (line >= n_lines_u)
-        return;
-    const uint64_t * ln = fl + line * kFusedWords;
-    const uint32_t c0 = reinterpret_cast<const uint32_t *>(ln + 4 * (t >> 1))[t & 1];
-    const uint32_t c1 = line + 1 < n_lines_u ? reinterpret_cast<const uint32_t *>(ln + kFusedWords + 4 * (t >> 1))[t & 1] : (uint32_t)a.total[t];
-    if (c1 >= c0 || (line + 1 == n_lines_u && a.total[t] < (UINT64_C(1) << 32)))
-        return; // (c1 < c0 in the last line of a slot with fewer than 2^32 occurrences cannot happen; the test keeps junk totals out)
-    uint32_t r = 0u - c0; // occurrences of t the line must add to reach the multiple: 1 .. 256
-    unsigned off = 256;
-    for (unsigned g = 0; g < 4; ++g)
-    {
-        const uint64_t p0 = ln[4 * g + 1], p1 = ln[4 * g + 2], p2 = ln[4 * g + 3];
-        const uint64_t m = ((t & 1) ? p0 : ~p0) & ((t & 2) ? p1 : ~p1) & ((t & 4) ? p2 : ~p2);
-        const uint32_t c = popc64(m);
-        if (r <= c)
+    for (uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x; id < n_lines_u * 8; id += (uint64_t)gridDim.x * 256)
+    { // (grid-stride, as k_wt8_counts)
+        const uint64_t line = id >> 3;
+        const unsigned t = (unsigned)id & 7u;
+        const uint64_t * ln = fl + line * kFusedWords;
+        const uint32_t c0 = reinterpret_cast<const uint32_t *>(ln + 4 * (t >> 1))[t & 1];
+        const uint32_t c1 = line + 1 < n_lines_u ? reinterpret_cast<const uint32_t *>(ln + kFusedWords + 4 * (t >> 1))[t & 1] : (uint32_t)a.total[t];
+        if (c1 >= c0 || (line + 1 == n_lines_u && a.total[t] < (UINT64_C(1) << 32)))
+            continue; // (c1 < c0 in the last line of a slot with fewer than 2^32 occurrences cannot happen; the test keeps junk totals out)
+        uint32_t r = 0u - c0; // occurrences of t the line must add to reach the multiple: 1 .. 256
+        unsigned off = 256;
+        for (unsigned g = 0; g < 4; ++g)
         {
-            off = 64u * g + sel64(m, r) + 1u;
-            break;
+            const uint64_t p0 = ln[4 * g + 1], p1 = ln[4 * g + 2], p2 = ln[4 * g + 3];
+            const uint64_t m = ((t & 1) ? p0 : ~p0) & ((t & 2) ? p1 : ~p1) & ((t & 4) ? p2 : ~p2);
+            const uint32_t c = popc64(m);
+            if (r <= c)
+            {
+                off = 64u * g + sel64(m, r) + 1u;
+                break;
+            }
+            r -= c;
         }
-        r -= c;
-    }
-    const uint32_t e = atomicAdd(n_out, 1u);
-    if (e < kFusedMaxCross)
-    {
-        pos_out[e] = (((uint64_t)first_line + line) << kFusedLog) + off;
-        key_out[e] = (u << 3) | t;
+        const uint32_t e = atomicAdd(n_out, 1u);
+        if (e < kFusedMaxCross)
+        {
+            pos_out[e] = (((uint64_t)first_line + line) << kFusedLog) + off;
+            key_out[e] = (u << 3) | t;
+        }
     }
 }
 
@@ -1190,11 +1203,13 @@ __global__ __launch_bounds__(256) void k_wt8_sel_dir(const uint64_t * __restrict
         dir[a.off[t] + a.n_samples[t] - 1] = a.size;
 }
 
-// the symbol sequence of a tree (wt[0 .. size)), read back through the binary levels
+// the symbol sequence of a tree (wt[0 .. size)), read back through the binary levels (view_binary()) or the fused lines (view())
 __global__ __launch_bounds__(kBlock) void k_wt_export_symbols(WtView wt, uint8_t * __restrict__ out, uint64_t n)
 {
     __shared__ WtTables T;
+    __shared__ WtFusedTables FT;
     wt_stage_tables(&T, wt.tables);
+    wt_stage_fused(&FT, wt);
     const int s = threadIdx.x & (kG - 1);
     const unsigned gq = threadIdx.x / kG;
     for (uint64_t base = (uint64_t)blockIdx.x * kQPB; base < n; base += (uint64_t)gridDim.x * kQPB)
@@ -1203,10 +1218,98 @@ __global__ __launch_bounds__(kBlock) void k_wt_export_symbols(WtView wt, uint8_t
         if (q >= n)
             continue;
         unsigned c = 0;
-        quad_wt_inverse_select<false>(wt, &T, nullptr, s, q, c);
+        quad_wt_inverse_select<false>(wt, &T, &FT, s, q, c);
         if (s == 0)
             out[q] = (uint8_t)c;
     }
+}
+
+// ---- the tree without its binary levels (sdsl_hip_fm_set_footprint) --------------------------------------------------
+// rank, access, inverse_select, the LF walks, count and — with its directory — select walk the fused lines only; SDSL's binary
+// levels (rank lines + both select directories: 1.27 bits per tree bit) are needed for serialisation and for select on a tree
+// without the fused directory.  They can be released and are rebuilt from the fused lines when one of those is asked for: the
+// symbol sequence is read back (k_wt_export_symbols over view()), and the level builder runs on it with the tree's own node
+// table (kWtShapeGiven), so trees of any shape (loaded wt_blcd / wt_hutu streams too) come back bit for bit.
+sdsl_hip_status wt_drop_binary(WtHost & wt)
+{
+    if (wt.binary_dropped)
+        return SDSL_HIP_OK;
+    if (wt.backend != 0 || !wt.d_fused.p || !wt.d_ftables.p)
+    {
+        set_error("the binary levels can only be released on a plain tree that has its fused layout (fewer than 2^36 symbols, "
+                  "SDSL_HIP_WT_FUSED not 0)");
+        return SDSL_HIP_ERR_UNSUPPORTED;
+    }
+    BvHost & b = wt.bv;
+    std::lock_guard<std::mutex> lk(b.scratch_mutex);
+    b.lines.release();
+    b.cnts.release();
+    for (int i = 0; i < 2; ++i)
+    {
+        b.sel[i].release();
+        b.lmask[i].release();
+        b.lidx[i].release();
+        b.lpos[i].release();
+        b.sel_plan[i].bnd.release();
+        b.sel_plan[i].ready = b.sel_plan[i].ok = false;
+    }
+    b.spread_probe.release();
+    b.capture_scratch.release();
+    wt.bv_dropped_view = b.view; // n_bits, ones, ... stay readable (wt_bv_bits)
+    BvView v{};
+    v.n_bits = b.view.n_bits;
+    v.n_lines = b.view.n_lines;
+    v.ones = b.view.ones;
+    b.view = v;
+    wt.binary_dropped = true;
+    return SDSL_HIP_OK;
+}
+
+sdsl_hip_status wt_restore_binary(WtHost & wt)
+{
+    if (!wt.binary_dropped)
+        return SDSL_HIP_OK;
+    SH_HIP(hipSetDevice(wt.device));
+    WtHost tmp;
+    {
+        DevBuf d_sym;
+        SH_TRY(d_sym.alloc(std::max<uint64_t>(wt.size, 1)));
+        if (wt.size)
+            hipLaunchKernelGGL(k_wt_export_symbols, dim3(grid_for(wt.size, kQPB, 256u * 16u)), dim3(kBlock), 0, 0, wt.view(),
+                               d_sym.as<uint8_t>(), wt.size);
+        SH_HIP(hipGetLastError());
+        tmp.tables = wt.tables;
+        tmp.n_nodes = wt.n_nodes;
+        tmp.sigma = wt.sigma;
+        SH_TRY(wt_build_from_device_text(tmp, d_sym.as<uint8_t>(), wt.size, wt.device, kWtShapeGiven));
+    }
+    if (tmp.bv.view.n_bits != wt.bv.view.n_bits || memcmp(tmp.tables.bv_pos_rank, wt.tables.bv_pos_rank, sizeof tmp.tables.bv_pos_rank) != 0)
+    {
+        set_error("internal: the binary levels rebuilt from the fused lines do not match the tree's node table");
+        return SDSL_HIP_ERR_HIP;
+    }
+    BvHost & b = wt.bv;
+    std::lock_guard<std::mutex> lk(b.scratch_mutex);
+    b.view = tmp.bv.view;
+    b.lines = std::move(tmp.bv.lines);
+    for (int i = 0; i < 2; ++i)
+    {
+        b.sel[i] = std::move(tmp.bv.sel[i]);
+        b.lmask[i] = std::move(tmp.bv.lmask[i]);
+        b.lidx[i] = std::move(tmp.bv.lidx[i]);
+        b.lpos[i] = std::move(tmp.bv.lpos[i]);
+    }
+    wt.binary_dropped = false;
+    return SDSL_HIP_OK;
+}
+
+// blocks per launch of k_wt8_counts / k_wt8_cross (they stride over what the grid does not cover; SDSL_HIP_WT8_GRID_CAP lets a test
+// reach the striding with a small tree: tests/test_gpu_wt_layouts.py)
+static unsigned wt8_grid_cap()
+{
+    const char * e = getenv("SDSL_HIP_WT8_GRID_CAP");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? (unsigned)v : (1u << 20);
 }
 
 // Builds the fused layout (lines, node tables, select directory) of the tree `src` into `dst`.  Leaves dst.d_fused
@@ -1283,7 +1386,7 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
         if (size[v])
             hipLaunchKernelGGL(k_wt8_planes, dim3(grid_for((size[v] + 63) >> 6, 4, 256u * 8u)), dim3(256), 0, 0, view, v,
                                size[v], at);
-        hipLaunchKernelGGL(k_wt8_counts, dim3(grid_for(lines_v * 8, 256, 1u << 20)), dim3(256), 0, 0, view, v, lines_v, at);
+        hipLaunchKernelGGL(k_wt8_counts, dim3(grid_for(lines_v * 8, 256, wt8_grid_cap())), dim3(256), 0, 0, view, v, lines_v, at);
     }
     SH_HIP(hipGetLastError());
     if (wt.size >> 32)
@@ -1312,7 +1415,7 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
                     ca.total[t] = ok ? size[x] : 0;
                 }
                 const uint64_t lines_v = (size[v] >> kFusedLog) + 1;
-                hipLaunchKernelGGL(k_wt8_cross, dim3(grid_for(lines_v * 8, 256, 1u << 20)), dim3(256), 0, 0,
+                hipLaunchKernelGGL(k_wt8_cross, dim3(grid_for(lines_v * 8, 256, wt8_grid_cap())), dim3(256), 0, 0,
                                    fl + (uint64_t)FT.fline[v] * kFusedWords, lines_v, FT.fline[v], v, ca, d_n.as<uint32_t>(), d_pos.as<uint64_t>(),
                                    d_key.as<uint32_t>());
             }
@@ -1639,6 +1742,21 @@ sdsl_hip_status sdsl_hip_wt_serialize_into(sdsl_hip_wt_s * wt, int32_t layout, S
         set_error("wt_serialize: null handle or unknown layout");
         return SDSL_HIP_ERR_INVALID;
     }
+    // a tree whose binary levels were released (wt_drop_binary) gets them back for the time of the call
+    struct Redrop
+    {
+        WtHost * h = nullptr;
+        ~Redrop()
+        {
+            if (h)
+                (void)wt_drop_binary(*h);
+        }
+    } redrop;
+    if (wt->h.binary_dropped)
+    {
+        SH_TRY(wt_restore_binary(wt->h));
+        redrop.h = &wt->h;
+    }
     const WtHost & h = wt->h;
     SH_HIP(hipSetDevice(h.device));
     if (h.backend == 1)
@@ -1878,6 +1996,8 @@ sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, c
                                     (uint64_t *)so.dev, s));
     else
     {
+        if (wt->h.binary_dropped && !(wt->h.d_fused.p && wt->h.d_fsel.p))
+            SH_TRY(wt_restore_binary(wt->h)); // (a tree without the fused select directory selects on its binary levels)
         const WtView view = wt->h.view();
         bool done = false;
         if (view.f_lines && view.f_sel && wt_select_sorted_applicable(wt->h, n))

@@ -24,6 +24,8 @@ struct WtHost
     DevBuf d_fsel, d_fsel_tables; // its select directory (wt_device.hpp: WtFusedSelTables), optional
     WtTables tables;    // host copy (code lengths, alphabet queries)
     uint64_t occ[256];  // occurrences of every byte (== wt.rank(size(), c))
+    bool binary_dropped = false; // wt_drop_binary: bv holds no lines (only n_bits); everything walks the fused layout
+    BvView bv_dropped_view{};    // the view as it was (counts of the select directories etc.), for diagnostics
     // what the query kernels see: with a fused layout, the node table of the tree the fused layout was built from
     WtView view() const
     {
@@ -65,12 +67,16 @@ struct WtHost
 // SDSL_HIP_WT_BLCD (balanced shape instead of Huffman); internal: kWtShapeHuff8, kWtNoSelect
 constexpr uint32_t kWtShapeHuff8 = 0x100u; // 8-ary Huffman tree written as a binary tree (the fused layout's own shape)
 constexpr uint32_t kWtNoSelect = 0x200u;   // no select directories on the bit vector
+constexpr uint32_t kWtShapeGiven = 0x400u; // wt.tables / n_nodes / sigma are set by the caller: build the bits of THAT tree
 sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t flags = 0);
 // Parses wt_pc::serialize output (wt_pc.hpp:713-726) and uploads; advances the reader.
 // layout: 0 = plain bv + select_support_scan (zero bytes), 1 = plain bv + select_support_mcl, 2 = rrr_vector<63> with
 // its own rank/select supports (zero bytes)
 sdsl_hip_status wt_build_from_stream(WtHost & wt, StreamReader & rd, int layout, int device);
 uint64_t wt_bv_bits(const WtHost & wt);
+// SDSL's binary levels released / rebuilt from the fused lines (wt.hip; plain backend with the fused layout only)
+sdsl_hip_status wt_drop_binary(WtHost & wt);
+sdsl_hip_status wt_restore_binary(WtHost & wt);
 // Derives the fused layout from the finished binary tree (plain backend, fewer than 2^32 symbols; SDSL_HIP_WT_FUSED=0
 // in the environment turns it off).  A no-op otherwise.
 sdsl_hip_status wt_build_fused(WtHost & wt);

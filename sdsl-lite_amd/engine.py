@@ -654,6 +654,17 @@ class csa_wt(_Handle):
         """(re)build the k-mer hash table of count() with the deepest k <= k_max that fits budget_bytes; k_max 0 releases it"""
         capi.check(capi.lib().sdsl_hip_fm_set_kmer_table(self._h, k_max, budget_bytes))
 
+    def set_footprint(self, max_bytes: int):
+        """give HBM back until device_bytes() <= max_bytes (binary tree levels first, then suffix array and text -> SDSL's default
+        samples with the k-mer table as deep as the budget still allows); answers never change"""
+        capi.check(capi.lib().sdsl_hip_fm_set_footprint(self._h, int(max_bytes)))
+
+    def footprint_parts(self) -> dict:
+        p = (C.c_uint64 * 8)()
+        capi.lib().sdsl_hip_fm_footprint_parts(self._h, p)
+        names = ("wt_binary_levels", "wt_fused_lines", "suffix_array", "text", "sa_isa_samples", "kmer_table", "jump_table", "tables")
+        return {k: int(v) for k, v in zip(names, p)}
+
     def kmer_table_depth(self) -> int:
         return capi.lib().sdsl_hip_fm_kmer_table_depth(self._h)
 

@@ -1,0 +1,157 @@
+"""sdsl_hip_fm_set_footprint: the index gives HBM back (binary tree levels, then suffix array and text -> SDSL's default samples packed to
+32 bits, k-mer table as deep as the budget allows) and every query keeps its answers — count of large and small batches, intervals,
+csa[i], isa[i], lf, psi, locate, extract, the tree's rank / select / access — and the serialised stream stays byte-identical to the one
+the real library loads (the binary levels are rebuilt from the fused lines for the time of the call).  Oracle: the C restatement."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def answers(csa, text, rng_seed=5):
+    rng = np.random.default_rng(rng_seed)
+    n = text.size
+    m, npat = 12, 30_000
+    st = rng.integers(0, n - m, npat)
+    pats = text[st[:, None] + np.arange(m)[None, :]].copy()
+    pats[::4, rng.integers(0, m)] = text[rng.integers(0, n)]
+    flat = np.ascontiguousarray(pats.reshape(-1))
+    out = {"count": np.asarray(csa.count(flat, m)).astype(np.uint64),
+           "count_small": np.asarray(csa.count(flat[: 100 * m], m)).astype(np.uint64)}
+    lo, hi = csa.interval(flat[: 2000 * m], m)
+    out["l"], out["r"] = np.asarray(lo), np.asarray(hi)
+    idx = rng.integers(0, n + 1, 3000).astype(np.uint64)
+    out["sa"] = np.asarray(csa.sa(idx))
+    out["isa"] = np.asarray(csa.isa(idx))
+    out["lf"] = np.asarray(csa.lf(idx))
+    out["psi"] = np.asarray(csa.psi(idx))
+    off, pos = csa.locate(flat[: 300 * m], m)
+    out["loc_off"] = np.asarray(off)
+    out["loc"] = np.concatenate([np.sort(np.asarray(pos)[int(off[i]):int(off[i + 1])]) for i in range(300)]) if len(pos) else np.zeros(0)
+    b = rng.integers(0, n - 200, 200).astype(np.uint64)
+    eo, et = csa.extract(b, b + np.uint64(150))
+    out["ext"] = np.asarray(et)
+    wt = csa.wavelet_tree
+    qi = rng.integers(0, n + 2, 5000).astype(np.uint64)
+    qc = text[rng.integers(0, n, 5000)]
+    out["wt_rank"] = np.asarray(wt.rank(qi, qc))
+    out["wt_access"] = np.asarray(wt.access(qi[qi <= n]))
+    occ = np.bincount(text, minlength=256)
+    k = (1 + rng.integers(0, 1 << 40, 5000) % np.maximum(occ[qc], 1)).astype(np.uint64)
+    out["wt_select"] = np.asarray(wt.select(k, qc))
+    return out
+
+
+def same(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in a)
+
+
+@pytest.mark.parametrize("shape", ["english", "sigma3"])
+def test_every_stage_keeps_every_answer(gpu, shape):
+    if shape == "english":
+        text = gpu.english_text(3 << 20, 21)
+    else:
+        text = np.random.default_rng(2).integers(1, 4, 400_000, dtype=np.uint8)
+    ocsa = ol.OCsa(bytes(text))
+    csa = gpu.csa_wt(text=text)
+    before = answers(csa, text)
+    rng = np.random.default_rng(5)
+    assert np.array_equal(before["count"][:500], np.asarray(ocsa.count_batch(np.ascontiguousarray(
+        _pats(text, 5)[: 500 * 12]), 12)).astype(np.uint64))
+    blob = csa.serialize(32, 64, gpu.capi.LAYOUT_BV_MCL)
+    full = csa.device_bytes()
+    parts = csa.footprint_parts()
+    assert sum(parts.values()) == full and parts["wt_binary_levels"] > 0 and parts["suffix_array"] == 4 * (text.size + 1)
+    # stage 1: only the binary levels have to go
+    csa.set_footprint(full - parts["wt_binary_levels"] // 2)
+    p1 = csa.footprint_parts()
+    assert p1["wt_binary_levels"] == 0 and p1["suffix_array"] == parts["suffix_array"] and csa.device_bytes() <= full - parts["wt_binary_levels"] // 2
+    assert same(before, answers(csa, text))
+    assert csa.serialize(32, 64, gpu.capi.LAYOUT_BV_MCL) == blob, "the stream must not change"
+    assert csa.footprint_parts()["wt_binary_levels"] == 0, "the levels rebuilt for serialize are released again"
+    # stage 2: 1.5 x the reference's own stream (sigma 3: 2.2 x — a fused line spends 4 bits per symbol and fused level whatever the
+    # alphabet, the reference's Huffman levels 1.7 bits on three symbols)
+    budget = int((1.5 if shape == "english" else 2.2) * len(blob))
+    csa.set_footprint(budget)
+    p2 = csa.footprint_parts()
+    assert csa.device_bytes() <= budget and p2["suffix_array"] == 0 and p2["text"] == 0 and p2["wt_binary_levels"] == 0
+    assert p2["sa_isa_samples"] == 4 * ((text.size + 32) // 32 + (text.size + 64) // 64)
+    assert csa.sampling() == (32, 64, False)
+    assert same(before, answers(csa, text))
+    assert csa.serialize(32, 64, gpu.capi.LAYOUT_BV_MCL) == blob
+    # the k-mer table cannot be rebuilt without suffix array and text: the call fails and the table the index has stays
+    k_now = csa.kmer_table_depth()
+    with pytest.raises(Exception):
+        csa.set_kmer_table(8, 1 << 30)
+    assert csa.kmer_table_depth() == k_now
+    # stage 3: the floor (no k-mer table at all)
+    floor = sum(v for k, v in p2.items() if k != "kmer_table")
+    csa.set_footprint(floor)
+    assert csa.device_bytes() <= floor and csa.kmer_table_depth() == 0
+    assert same(before, answers(csa, text))
+    with pytest.raises(Exception) as e:
+        csa.set_footprint(floor // 2)
+    assert "smallest form" in str(e.value)
+    # and back: suffix array, text and the default table return, answers unchanged
+    csa.restore_suffix_array()
+    assert csa.footprint_parts()["suffix_array"] > 0 and csa.kmer_table_depth() >= 1
+    assert same(before, answers(csa, text))
+    csa.close()
+
+
+def _pats(text, seed):
+    rng = np.random.default_rng(seed)
+    n, m, npat = text.size, 12, 30_000
+    st = rng.integers(0, n - m, npat)
+    pats = text[st[:, None] + np.arange(m)[None, :]].copy()
+    pats[::4, rng.integers(0, m)] = text[rng.integers(0, n)]
+    return pats.reshape(-1)
+
+
+def test_a_loaded_stream_can_be_shrunk_too(gpu):
+    """an index loaded from the real library's stream (no suffix array, no text): the binary levels go, the samples are packed, and a
+    k-mer table within the budget is built from suffix array and text that exist only for the time of the call"""
+    text = gpu.english_text(2 << 20, 4)
+    built = gpu.csa_wt(text=text)
+    blob = built.serialize(32, 64, gpu.capi.LAYOUT_BV_MCL)
+    want = answers(built, text)
+    built.close()
+    csa = gpu.csa_wt(sdsl_bytes=blob, select_is_mcl=True, sa_dens=32, isa_dens=64)
+    assert csa.kmer_table_depth() == 0
+    budget = int(1.5 * len(blob))
+    csa.set_footprint(budget)
+    p = csa.footprint_parts()
+    assert csa.device_bytes() <= budget and p["wt_binary_levels"] == 0 and p["suffix_array"] == 0 and p["text"] == 0
+    assert csa.kmer_table_depth() >= 2, "the budget leaves room for a table"
+    assert same(want, answers(csa, text))
+    assert csa.serialize(32, 64, gpu.capi.LAYOUT_BV_MCL) == blob
+    csa.close()
+
+
+def test_what_cannot_be_shrunk_says_so(gpu):
+    text = gpu.english_text(1 << 20, 9)
+    crrr = gpu.csa_wt(text=text, rrr=True)
+    crrr.set_footprint(1 << 40)  # already below: nothing to do
+    with pytest.raises(Exception) as e:
+        crrr.set_footprint(1000)
+    assert "plain wavelet tree" in str(e.value)
+    crrr.close()
+
+
+def test_fused_header_kernels_stride_over_what_the_grid_does_not_cover(gpu, monkeypatch):
+    """k_wt8_counts / k_wt8_cross are launched with a capped grid (2^20 blocks) and stride over the rest — a node of 2^33 symbols and
+    more has more lines than that.  With the cap at 8 blocks a 2^21-symbol tree is built entirely by the striding."""
+    rng = np.random.default_rng(8)
+    text = rng.integers(1, 60, 1 << 21, dtype=np.uint8)
+    qi = rng.integers(0, text.size + 1, 200_000).astype(np.uint64)
+    qc = text[rng.integers(0, text.size, 200_000)]
+    wt = gpu.wt_huff(text=text)
+    want = np.asarray(wt.rank(qi, qc))
+    wt.close()
+    monkeypatch.setenv("SDSL_HIP_WT8_GRID_CAP", "8")
+    wt2 = gpu.wt_huff(text=text)
+    assert wt2.fused_steps().any()
+    assert np.array_equal(np.asarray(wt2.rank(qi, qc)), want)
+    wt2.close()
