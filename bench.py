@@ -39,6 +39,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from bench_common import (ALG_BYTES, HBM_PEAK_GBS, box_facts, digest_matches, golden, host_cpu_limits, kernel_sources_sha,  # noqa: E402
                           pmc_traffic, set_mempolicy_interleave, spread_of, time_steps)
+from bench_common import cpu_time, synthetic_text, to_dev  # noqa: E402,F401  (the probes under tools/ reach them through this module)
 
 LINE_LIMIT = 4096  # bytes; the driver keeps a bounded tail of stdout (round 4: a 23 KB line came back unparsed)
 

@@ -459,6 +459,14 @@ def leg_text(c):
         alg = 28 + 160 * sum_l
         sum_steps = float(fsteps[pats.view(-1, m)[:, :m - 1].long()].double().sum(dim=1).mean())
 
+        def route_of(ix):
+            """which road count() takes on this index, in a few words (the line's secondary.route)"""
+            p = ix.footprint_parts()
+            return ("k-mer table k=%d -> flat fused-tree search%s" % (ix.kmer_table_depth(), " -> text comparison at one suffix" if p["suffix_array"] and verify_on else "")
+                    + ("; tree: fused lines only" if not p["wt_binary_levels"] else ""))
+
+        verify_on = os.environ.get("SDSL_HIP_FM_VERIFY", "1") != "0"
+
         def count_leg(variant, what):
             """one timed leg of count(): >= 6 batches, every answer compared with the reference's digest; `roofline` from
             the PMC collection of exactly this variant (tools/collect_profiles.sh -> profiles/pmc_latest.json), valid
@@ -469,7 +477,8 @@ def leg_text(c):
             bpp = pmc_traffic("fm_count_%s_bytes_per_pattern" % variant)
             rpp = pmc_traffic("fm_count_%s_requests_per_pattern" % variant)
             return {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "kernel_ms_per_batch": spread_of(steps_ms),
-                    "spread": (max(steps_ms) - min(steps_ms)) / ms, "patterns": nq2, "m": m, "path": what,
+                    "spread": (max(steps_ms) - min(steps_ms)) / ms, "patterns": nq2, "m": m, "path": what, "route": route_of(csa),
+                    "resident_bytes_by_part": csa.footprint_parts(),
                     "reference_digest_match": digest_matches(out2, c4["count"]) if c4ok and nq2 >= c4["count"]["n"] else None,
                     "index_bytes": csa.device_bytes(), "kmer_table": {"k": csa.kmer_table_depth(), "bytes": csa.kmer_table_bytes()},
                     "jump_depth": csa.jump_depth(),
@@ -484,7 +493,6 @@ def leg_text(c):
                     "survey_8d_model_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "algorithmic_bytes_per_pattern": alg, "fused_steps_per_pattern_without_table": sum_steps, "note": FUSED_NOTE}
 
-        verify_on = os.environ.get("SDSL_HIP_FM_VERIFY", "1") != "0"
         ex["fm_count"] = count_leg("default", "k-mer hash table (k = %d: one 128-byte bucket instead of k LF steps) -> flat search kernel "
                                    "until one suffix is left%s (fm_count2.hip); no sort, patterns in the caller's order"
                                    % (csa.kmer_table_depth(), " -> the remaining characters compared with the text at SA[l]: the whole "
@@ -552,6 +560,39 @@ def leg_text(c):
         _, ms = time_steps(lambda: csa.extract(eb, ee), 2, 1, barrier)
         ex["fm_extract_64B"] = {"GB/s": etxt.numel() / ms / 1e6, "ms": ms, "snippets": eb.numel()}
         del eoff, etxt, want
+        # count() against resident bytes: the index gives HBM back step by step (sdsl_hip_fm_set_footprint) down to the reference's
+        # own footprint — csa_wt<wt_huff<>, 32, 64> of this text serialises to `sdsl_stream_bytes` (csa_wt.hpp:389-402) — and count()
+        # is timed and digest-checked at every step.  "lean" = 1.5 x the reference's bytes: fused tree lines, 32-bit samples, the
+        # k-mer table the rest of the budget holds; that row carries its own PMC roofline (variant "lean" of tools/fm_probe.py)
+        sdsl_bytes = ex["text"].get("sdsl_stream_bytes")
+        if not sdsl_bytes:
+            sdsl_bytes = len(csa.serialize(32, 64, pkg.capi.LAYOUT_BV_MCL))
+            ex["text"]["sdsl_stream_bytes"] = sdsl_bytes
+        rows = [("k8", ex["fm_count_kmer8"]), ("default", ex["fm_count"]), ("sa_dropped", ex["fm_count_sa_dropped"])]
+        for name, budget in (("lean_k6", 2.75 * sdsl_bytes), ("lean", 1.5 * sdsl_bytes), ("lean_1.3x", 1.3 * sdsl_bytes), ("floor", 0)):
+            try:
+                if name == "floor":
+                    p_ = csa.footprint_parts()
+                    budget = sum(v for k_, v in p_.items() if k_ != "kmer_table")
+                csa.set_footprint(int(budget))
+            except Exception as e_:
+                ex.setdefault("fm_footprint_errors", {})[name] = str(e_)
+                continue
+            leg = count_leg("lean" if name == "lean" else "none", "sdsl_hip_fm_set_footprint(%d): %s" % (int(budget), route_of(csa)))
+            leg["x_sdsl_stream_bytes"] = leg["index_bytes"] / sdsl_bytes
+            rows.append((name, leg))
+            if name == "lean":
+                ex["fm_count_lean"] = leg
+        ex["fm_count_vs_resident_bytes"] = {
+            "sdsl_stream_bytes": sdsl_bytes, "what": "count() of the same 20-byte patterns on the same index at shrinking footprints; every row "
+            "compared with the real library's digest",
+            "rows": [{"name": nm, "index_bytes": lg["index_bytes"], "x_sdsl_stream_bytes": lg["index_bytes"] / sdsl_bytes,
+                      "Mcount/s": lg["Mcount/s"], "kmer_k": lg["kmer_table"]["k"], "route": lg["route"],
+                      "reference_digest_match": lg["reference_digest_match"],
+                      "roofline_frac": lg["roofline"]["frac"]} for nm, lg in sorted(rows, key=lambda r: -r[1]["index_bytes"])]}
+        # csa[i] and extract on the lean index walk the same fused lines: one figure each, beside the ones above
+        _, ms = time_steps(lambda: csa.sa(sidx), 2, 1, barrier)
+        ex["fm_sa_access_dens32"]["lean_index_Msa/s"] = sidx.numel() / ms / 1e3
         # the compressed flavour csa_wt<wt_huff<rrr_vector<63>>> on the same patterns
         del csa, wt
         torch.cuda.empty_cache()

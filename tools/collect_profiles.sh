@@ -11,7 +11,8 @@ for w in $WHAT; do
     fm)    # count() on the bench text and patterns, one table variant per run
       tools/prof.sh fm_default python $R/tools/fm_probe.py 1024 1e8 default
       tools/prof.sh fm_k8 python $R/tools/fm_probe.py 1024 1e8 k8
-      tools/prof.sh fm_dropped python $R/tools/fm_probe.py 1024 1e8 dropped ;;
+      tools/prof.sh fm_dropped python $R/tools/fm_probe.py 1024 1e8 dropped
+      tools/prof.sh fm_lean python $R/tools/fm_probe.py 1024 1e8 lean ;;
     rrr)   # configs[2], default dispatch (bucketed), one operation per run
       tools/prof.sh rrr_rank python $R/tools/rrr_probe.py rank
       tools/prof.sh rrr_select python $R/tools/rrr_probe.py select ;;

@@ -59,6 +59,11 @@ for v in variants:
     elif v == "dropped":
         csa.drop_sa()
         run("suffix array and text dropped")
+    elif v == "lean":  # 1.5 x the bytes of the reference's csa_wt<wt_huff<>, 32, 64> stream (bench_extras.py: fm_count_lean)
+        blob = len(csa.serialize(32, 64, pkg.capi.LAYOUT_BV_MCL))
+        csa.set_footprint(int(1.5 * blob))
+        print(f"  footprint {csa.device_bytes()} B = {csa.device_bytes() / blob:.3f} x the SDSL stream ({blob} B): {csa.footprint_parts()}")
+        run("lean (1.5 x SDSL's bytes)")
     elif v.startswith("dk"):
         csa.set_kmer_table(int(v[2:]), 64 << 30) if csa.sampling()[2] else None
         run(f"dropped, k = {csa.kmer_table_depth()}")

@@ -94,7 +94,7 @@ if B:
                 sel[c] = sum(B["per"][k][c].get(i, 0.0) for i in bigw) / len(bigw) if bigw else 0.0
             r, w = bytes_of(collections.defaultdict(float, sel))
             out["k_rank_bytes_per_launch"] = r + w
-for variant in ("default", "k8", "dropped"):
+for variant in ("default", "k8", "dropped", "lean"):
     F = load("fm_" + variant)
     if F and F["units"]:
         g = group(F, lambda k: k.startswith("k_fm_start") or k.startswith("k_fm_count_flat") or k.startswith("k_fm_verify2"))
