@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON the GPU box (via gpurun): every profile the round commits, through ONE recipe (tools/prof.sh: a kernel trace and four
 # PMC passes per command).  tools/pmc_json.py + tools/prof_summary.py turn gpurun_out/prof_*/ into profiles/.
-# usage: tools/collect_profiles.sh [what ...]    what = bench fm rrr wt full (default: all)
+# usage: tools/collect_profiles.sh [what ...]    what = bench fm rrr wt walks sd full (default: all)
 R=$PWD
-WHAT=${@:-bench fm rrr wt full}
+WHAT=${@:-bench fm rrr wt walks sd full}
 for w in $WHAT; do
   case $w in
     bench) # the headline command without extras: every k_sw_* / k_sr_* dispatch belongs to a bucketed rank step
@@ -16,7 +16,16 @@ for w in $WHAT; do
     rrr)   # configs[2], default dispatch (bucketed), one operation per run
       tools/prof.sh rrr_rank python $R/tools/rrr_probe.py rank
       tools/prof.sh rrr_select python $R/tools/rrr_probe.py select ;;
-    wt)    tools/prof.sh wt python $R/bench.py --steps 4 --warmup 1 --extras wt --no-cpu ;;
+    wt)    tools/prof.sh wt python $R/bench.py --steps 4 --warmup 1 --extras wt --no-cpu
+           tools/prof.sh wt_select python $R/tools/kernel_probe.py wt_select ;;
+    walks) # the LF walks behind csa[i] / extract / locate on SDSL's default samples, and count() on the rrr-compressed index
+      tools/prof.sh walk_sa python $R/tools/kernel_probe.py sa
+      tools/prof.sh walk_extract python $R/tools/kernel_probe.py extract
+      tools/prof.sh walk_locate python $R/tools/kernel_probe.py locate
+      tools/prof.sh rrr_count python $R/tools/kernel_probe.py rrr_count ;;
+    sd)    tools/prof.sh sd_rank python $R/tools/kernel_probe.py sd_rank
+           tools/prof.sh sd_select1 python $R/tools/kernel_probe.py sd_select1
+           tools/prof.sh sd_select0 python $R/tools/kernel_probe.py sd_select0 ;;
     full)  # kernel trace only, of the default command
       export TMPDIR=/tmp; O=$R/gpurun_out/prof_full; rm -rf $O; mkdir -p $O; cd /tmp
       rocprofv3 --kernel-trace --stats -d $O/trace -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/stdout.txt 2> $O/trace.err
@@ -29,9 +38,9 @@ OUT=$R/gpurun_out/profiles_new; rm -rf $OUT; mkdir -p $OUT
 python $R/tools/pmc_json.py > $OUT/pmc_json.log 2>&1; cp $R/profiles/pmc_latest.json $OUT/ 2>/dev/null
 for d in $R/gpurun_out/prof_*/; do
   t=$(basename $d); t=${t#prof_}
-  [ -d $d/rd ] && python $R/tools/prof_summary.py $t --min-ms 0.02 --md $OUT/pmc_$t.md --json $OUT/pmc_$t.json > /dev/null 2>&1
-  f=$(find $d/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -i "sdslhip\|^\"Name\|rocprim" $f | sed 's/(anonymous namespace):://g' | cut -c1-400 > $OUT/kernel_stats_$t.csv
+  [ -d $d/rd ] && python $R/tools/prof_summary.py $t --min-ms 0.02 --md $OUT/pmc_$t.md --json $OUT/pmc_$t.json --stats-csv $OUT/kernel_stats_$t.csv > /dev/null 2>&1
+  [ -d $d/rd ] || python $R/tools/prof_summary.py $t --stats-csv $OUT/kernel_stats_$t.csv > /dev/null 2>&1
   grep -h "^{" $d/stdout.txt 2>/dev/null | tail -1 > $OUT/line_$t.json; [ -s $OUT/line_$t.json ] || rm -f $OUT/line_$t.json
-  grep -h "Mcount/s\|Gq/s\|PROBE_UNITS" $d/stdout.txt 2>/dev/null > $OUT/stdout_$t.txt; [ -s $OUT/stdout_$t.txt ] || rm -f $OUT/stdout_$t.txt
+  grep -h "Mcount/s\|Gq/s\|G.*/s\|PROBE_UNITS" $d/stdout.txt 2>/dev/null > $OUT/stdout_$t.txt; [ -s $OUT/stdout_$t.txt ] || rm -f $OUT/stdout_$t.txt
 done
 [ -z "$PROF_KEEP_RAW" ] && rm -rf $R/gpurun_out/prof_*

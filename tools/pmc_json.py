@@ -109,6 +109,24 @@ for op in ("rank", "select"):
         g = group(Rr, lambda k: k.startswith("k_sr_") or k.startswith("k_sw_") or k.startswith("k_rs_") or k.startswith("k_rrr_"))
         out["rrr_%s_bucketed_bytes_per_query" % op] = (g["read"] + g["written"]) / Rr["units"]
         out["rrr_%s_bucketed_kernel_ms_per_1e9_under_tracer" % op] = g["ms"] / Rr["units"] * 1e9
+# the secondary kernels (tools/kernel_probe.py): everything the probe launched except the index build, per unit of PROBE_UNITS
+PROBES = {"walk_sa": ("fm_sa", lambda k: k.startswith("k_fm_walk")), "walk_extract": ("fm_extract", lambda k: k.startswith(("k_fm_walk", "k_fm_piece", "k_fm_lengths"))),
+          "walk_locate": ("fm_locate", lambda k: k.startswith(("k_fm_walk", "k_fm_expand", "k_fm_lengths"))),
+          "rrr_count": ("fm_count_rrr63", lambda k: k.startswith("k_fm_count_rrr") or k.startswith("k_fm_verify") or k.startswith("k_fm_keys")),
+          "wt_select": ("wt_select", lambda k: k.startswith(("k_wt_sel", "k_sw_", "k_sr_"))),
+          "sd_rank": ("sd_rank", lambda k: k.startswith(("k_sd_rank<", "k_sd_rank_lane", "k_sd_redo")) or k in ("k_sd_rank",)),
+          "sd_select1": ("sd_select1", lambda k: k.startswith("k_sd_select") and "select0" not in k),
+          "sd_select0": ("sd_select0", lambda k: k.startswith(("k_sd_select", "k_sd_redo")))}
+for tag_, (key, pred) in PROBES.items():
+    Pp = load(tag_)
+    if Pp and Pp["units"]:
+        g = group(Pp, pred)
+        u = Pp["units"]
+        out[key + "_bytes_per_unit"] = (g["read"] + g["written"]) / u
+        out[key + "_requests_per_unit"] = g["requests"] / u
+        out[key + "_valu_issue_share"] = g["valu"] / (g["gui"] / 8 * 1024 / 4) if g["gui"] else None
+        out[key + "_kernel_ms_per_1e8_under_tracer"] = g["ms"] / u * 1e8
+        out[key + "_kernels"] = sorted(k for k in Pp["trace"] if pred(k))
 W = load("wt")
 if W:
     for k in W["per"]:

@@ -19,6 +19,8 @@ ap.add_argument("--units", type=float, default=0.0)
 ap.add_argument("--md", default=None)
 ap.add_argument("--json", default=None)
 ap.add_argument("--min-ms", type=float, default=0.0, help="drop kernels whose average launch is shorter")
+ap.add_argument("--stats-csv", default=None, help="rewrite the tracer's kernel_stats.csv with short kernel names, ALL eight columns of every "
+                "row kept (round 4 cut the lines at 400 characters and lost the figures of the kernels with the longest signatures)")
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + a.tag)
@@ -29,6 +31,18 @@ def short(name):
     s = m.group(0) if m else name.split("(")[0][:70]
     return s.replace("sdslhip::", "").replace("(anonymous namespace)::", "")
 
+
+if a.stats_csv:
+    with open(a.stats_csv, "w", newline="") as fo:
+        wr = None
+        for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if wr is None:
+                    wr = csv.DictWriter(fo, fieldnames=list(r.keys()), quoting=csv.QUOTE_NONNUMERIC)
+                    wr.writeheader()
+                if "sdslhip" in r["Name"] or "rocprim" in r["Name"]:
+                    r["Name"] = short(r["Name"]) if "sdslhip" in r["Name"] else r["Name"].split("(")[0][:120]
+                    wr.writerow(r)
 
 want = [w for w in a.match.split(",") if w]
 trace = {}
