@@ -82,6 +82,19 @@ def pmc_traffic(kernel_key):
         return None
 
 
+def pmc_roofline(key, units, ms):
+    """roofline block of a secondary kernel from the committed PMC collection (tools/kernel_probe.py under tools/prof.sh ->
+    profiles/pmc_latest.json: <key>_bytes_per_unit / _requests_per_unit / _valu_issue_share), priced at THIS run's rate: fabric bytes the
+    kernels move per unit x units / measured time, over the HBM peak.  All None when the collection is not of these kernel sources."""
+    b = pmc_traffic(key + "_bytes_per_unit")
+    return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic_bytes_per_unit": b,
+            "fabric_requests_per_unit": pmc_traffic(key + "_requests_per_unit"),
+            "achieved": b * units / (ms * 1e-3) / 1e9 if b else None, "frac": b * units / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if b else None,
+            "valu_issue_share": pmc_traffic(key + "_valu_issue_share"), "kernels": pmc_traffic(key + "_kernels"),
+            "traffic_source": "committed PMC collection (profiles/pmc_latest.json), measured fabric bytes — these kernels have no closed-form "
+                              "byte model: walk lengths are geometric, lines per tree step depend on the symbol"}
+
+
 def golden():
     try:
         return json.load(open(os.path.join(ROOT, "tests", "golden", "golden_large.json")))
@@ -98,6 +111,19 @@ def digest_matches(ans_dev, want):
     first = np.array(want["first"], dtype=np.uint64)
     return bool(np.array_equal(a[: first.size], first) and int(np.add.reduce(a, dtype=np.uint64)) == want["sum"]
                 and int(np.bitwise_xor.reduce(a)) == want["xor"] and hashlib.sha256(a.tobytes()).hexdigest() == want["sha256"])
+
+
+def digests_match(ans_dev, block, key):
+    """block[key] (the first n answers) AND block[key + "_strided"] (every stride-th answer of the first `count`: the whole BASELINE batch)
+    when the batch is long enough for them; None when neither applies"""
+    res = None
+    w = block.get(key)
+    if w and ans_dev.numel() >= w["n"]:
+        res = digest_matches(ans_dev, w)
+    ws = block.get(key + "_strided")
+    if ws and ans_dev.numel() >= ws["count"] and res is not False:
+        res = digest_matches(ans_dev[: ws["count"]: ws["stride"]].contiguous(), ws)
+    return res
 
 
 def to_dev(host_u64, dev):

@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-from bench_common import (ALG_BYTES, FUSED_NOTE, HBM_PEAK_GBS, ROOT, cpu_time, digest_matches, fused_frac, golden, pmc_traffic,
+from bench_common import (ALG_BYTES, FUSED_NOTE, HBM_PEAK_GBS, ROOT, cpu_time, digest_matches, digests_match, fused_frac, golden, pmc_roofline, pmc_traffic,
                           spread_of, synthetic_text, time_steps, to_dev)
 
 SIDECAR = os.path.join(ROOT, "bench_extras.json")
@@ -173,7 +173,7 @@ def leg_select(c):
                       "phases_ms": sph if sel_bucketed else None,
                       "roofline_frac": ALG_BYTES["select"] * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if a.log_n == G.get("c2", {}).get("log_n") and nq >= G["c2"]["select_1"]["n"]:
-        ex["select_1"]["reference_digest_match"] = digest_matches(out, G["c2"]["select_1"])
+        ex["select_1"]["reference_digest_match"] = digests_match(out, G["c2"], "select_1")
     # the default above is the bucketed path for a batch of this size; the direct kernel beside it
     pkg.set_option("select_sorted", 0)
     out_d = torch.empty_like(out)
@@ -325,7 +325,9 @@ def leg_sd(c):
                        "bits_per_one": sd.device_bytes() * 8 / pos.numel(), "build_s": sd_build,
                        "lane_kernels": {"rank": bool(sd.lane_kernels() & 1), "select_0": bool(sd.lane_kernels() & 2)},
                        "rank_1_Gq/s": nq_sd / ms_r / 1e6, "select_1_Gq/s": nq_sd / ms_s / 1e6,
-                       "select_0_Gq/s": nq_sd / ms_z / 1e6, "queries": nq_sd}
+                       "select_0_Gq/s": nq_sd / ms_z / 1e6, "queries": nq_sd,
+                       "roofline": {"rank_1": pmc_roofline("sd_rank", nq_sd, ms_r), "select_1": pmc_roofline("sd_select1", nq_sd, ms_s),
+                                    "select_0": pmc_roofline("sd_select0", nq_sd, ms_z)}}
     del sd, pos, xi, si, zi, zr, o_sd
 
 
@@ -362,7 +364,13 @@ def leg_text(c):
     csa = pkg.csa_wt(text=text, device=local)
     build = time.perf_counter() - t0
     c4 = G.get("c4", {})
-    c4ok = rank == 0 and not a.text_file and nt == (1 << c4.get("text_log", -1)) and "wt_rank" in c4
+    if a.text_file:
+        # a text of the user's: digests from `make_golden_large.py c4 c4sel c4s --text-file FILE`, if they were made (same bytes used)
+        gf = os.path.join(ROOT, "tests", "golden", "golden_large_%s.json" % os.path.basename(a.text_file))
+        c4 = json.load(open(gf)).get("c4", {}) if os.path.exists(gf) else {}
+        c4ok = rank == 0 and c4.get("text_bytes") == nt and "wt_rank" in c4
+    else:
+        c4ok = rank == 0 and nt == (1 << c4.get("text_log", -1)) and "wt_rank" in c4
     wt = csa.wavelet_tree
     lens = torch.from_numpy(wt.code_lengths().astype(np.int64)).to(dev)
     fsteps = torch.from_numpy(wt.fused_steps().astype(np.int64)).to(dev)
@@ -414,8 +422,7 @@ def leg_text(c):
         lf = (17 + 128 * steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         rf, how = fused_frac("k_wt_rank_bytes_per_query", nq2, ms, lf)
         ex["wt_huff_rank"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2,
-                              "reference_digest_match": digest_matches(out2, c4["wt_rank"])
-                              if c4ok and nq2 >= c4["wt_rank"]["n"] else None,
+                              "reference_digest_match": digests_match(out2, c4, "wt_rank") if c4ok else None,
                               "roofline_frac": rf, "roofline_frac_source": how,
                               "survey_8d_model_frac": alg * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "algorithmic_bytes_per_query": alg,
@@ -449,7 +456,8 @@ def leg_text(c):
                                 "path": "bucketed by place in symbol order, one lane per key (wt_sorted.hip)" if nq2 >= (1 << 23)
                                 else "direct fused select",
                                 "reference_digest_match": digest_matches(out2, c4["wt_select"])
-                                if c4ok and "wt_select" in c4 and nq2 >= c4["wt_select"]["n"] else None}
+                                if c4ok and "wt_select" in c4 and nq2 >= c4["wt_select"]["n"] else None,
+                                "roofline": pmc_roofline("wt_select", nq2, ms)}
         del occ_c, ks, chk, wt_t
     if "fm" in c.extras:
         m = 20
@@ -479,7 +487,7 @@ def leg_text(c):
             return {"Mcount/s": nq2 / ms / 1e3, "kernel_ms": ms, "kernel_ms_per_batch": spread_of(steps_ms),
                     "spread": (max(steps_ms) - min(steps_ms)) / ms, "patterns": nq2, "m": m, "path": what, "route": route_of(csa),
                     "resident_bytes_by_part": csa.footprint_parts(),
-                    "reference_digest_match": digest_matches(out2, c4["count"]) if c4ok and nq2 >= c4["count"]["n"] else None,
+                    "reference_digest_match": digests_match(out2, c4, "count") if c4ok else None,
                     "index_bytes": csa.device_bytes(), "kmer_table": {"k": csa.kmer_table_depth(), "bytes": csa.kmer_table_bytes()},
                     "jump_depth": csa.jump_depth(),
                     "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -546,7 +554,8 @@ def leg_text(c):
         csa.drop_sa()
         _, ms = time_steps(lambda: csa.sa(sidx), 2, 1, barrier)
         assert torch.equal(csa.sa(sidx), want), "sampled SA walk != whole SA"
-        ex["fm_sa_access_dens32"] = {"Msa/s": sidx.numel() / ms / 1e3, "ms": ms, "queries": sidx.numel()}
+        ex["fm_sa_access_dens32"] = {"Msa/s": sidx.numel() / ms / 1e3, "ms": ms, "queries": sidx.numel(),
+                                     "roofline": pmc_roofline("fm_sa", sidx.numel(), ms)}
         # count() at the footprint of csa_wt<wt_huff<>, 32, 64> plus the k-mer table: no suffix array, no text, every
         # character after the table's k is an LF step (suffix_array_algorithm.hpp:228-248)
         ex["fm_count_sa_dropped"] = count_leg("dropped", "k-mer hash table (k = %d) -> flat search kernel over ALL remaining "
@@ -558,7 +567,8 @@ def leg_text(c):
         assert torch.equal(etxt.view(-1, 64)[:4096],
                            text[(eb[:4096].view(-1, 1) + torch.arange(64, device=dev).view(1, 64))])
         _, ms = time_steps(lambda: csa.extract(eb, ee), 2, 1, barrier)
-        ex["fm_extract_64B"] = {"GB/s": etxt.numel() / ms / 1e6, "ms": ms, "snippets": eb.numel()}
+        ex["fm_extract_64B"] = {"GB/s": etxt.numel() / ms / 1e6, "ms": ms, "snippets": eb.numel(),
+                                "roofline": pmc_roofline("fm_extract", etxt.numel(), ms)}
         del eoff, etxt, want
         # count() against resident bytes: the index gives HBM back step by step (sdsl_hip_fm_set_footprint) down to the reference's
         # own footprint — csa_wt<wt_huff<>, 32, 64> of this text serialises to `sdsl_stream_bytes` (csa_wt.hpp:389-402) — and count()
@@ -602,7 +612,7 @@ def leg_text(c):
         nq3 = min(nq2, 20_000_000)
         _, ms = time_steps(lambda: crrr.count(pats[: nq3 * m], m, out2[:nq3]), 2, 1, barrier)
         ex["fm_count_rrr63"] = {"Mcount/s": nq3 / ms / 1e3, "kernel_ms": ms, "patterns": nq3, "m": m,
-                                "index_bytes": crrr.device_bytes(), "index_build_s": rb}
+                                "index_bytes": crrr.device_bytes(), "index_build_s": rb, "roofline": pmc_roofline("fm_count_rrr63", nq3, ms)}
         del crrr
         # second data point: the sigma = 28 lowercase text round 1 reported on (an easier alphabet: shorter codes, a
         # deeper k-mer table)

@@ -1,6 +1,6 @@
 """BASELINE-size answers of the REAL sdsl-lite (run in the build container only; ~62 GB of RAM, 30-60 minutes).
 
-    python tests/golden/make_golden_large.py [c2] [c2w] [c3] [c4] [c4sel]
+    python tests/golden/make_golden_large.py [c2] [c2w] [c3] [c4] [c4sel] [c2s] [c4s] [--text-file FILE]
 
 Builds, through oracle/_ref/libsdsl_ref.so (the reference's headers compiled where they lie), the structures of
 BASELINE.json configs[1..4] on the SURVEY.md 8(d) inputs and stores what the GPU tests and bench.py compare against:
@@ -15,6 +15,12 @@ per query stream the sum, the xor and the sha256 of the answers plus the first 1
   c4  text = the library's English-class stand-in (sdsl_hip_util_english_text, seed 1234), 2^30 bytes;
       csa_wt<wt_huff<bit_vector, rank_support_v5<>>> built by sdsl::construct_im; 10^6 wavelet_tree.rank(i, c) with
       i = mt19937_64(13) % (n+1), c = text[mt19937_64(14) % n]; 10^6 count() of the 20 bytes at mt19937_64(15) % (n-20)
+
+  c2s / c4s  STRIDED digests over the WHOLE BASELINE batch (every 100th answer of the 10^9 rank_1 / select_1 queries of c2, of the
+      10^8 rank(i, c) / count() queries of c4) instead of its first 10^7: a wrong answer anywhere in the batch has a 1 % chance per
+      answer of being seen, a systematic one (a slab, a bucket, a chunk boundary) is seen for sure
+  --text-file FILE   c4 / c4sel / c4s on a text of your own (e.g. Pizza&Chili english.1GB: first 2^TEXT_LOG bytes, zero bytes dropped)
+      — the digests go to golden_large_<basename>.json beside this script; bench.py --text-file FILE picks that file up
 
 Everything written is DATA (seeded inputs are regenerated, never stored): tests/golden/golden_large.json,
 tests/golden/mt9_checkpoints.bin.
@@ -51,10 +57,37 @@ def digest(ans: np.ndarray) -> dict:
             "sha256": hashlib.sha256(a.tobytes()).hexdigest(), "first": [int(x) for x in a[:10_000]]}
 
 
+STRIDE = int(os.environ.get("GOLDEN_STRIDE", "100"))
+NQ_FULL = int(os.environ.get("GOLDEN_NQ_FULL", str(10**9)))            # BASELINE configs[1]: 10^9 queries
+NQ_TEXT_FULL = int(os.environ.get("GOLDEN_NQ_TEXT_FULL", str(10**8)))  # configs[3], [4]: 10^8 queries / patterns
+
+
+def strided(ans: np.ndarray, count: int) -> dict:
+    d = digest(ans)
+    d.update(stride=STRIDE, count=count)  # answers 0, stride, 2 * stride, ... of the first `count`
+    return d
+
+
+def load_text(pkg, text_file):
+    nt = 1 << TEXT_LOG
+    if text_file:
+        raw = np.fromfile(text_file, dtype=np.uint8, count=nt)
+        return np.ascontiguousarray(raw[raw != 0])
+    return pkg.english_text(nt, 1234)
+
+
 def main():
+    global OUT
     assert ol.have_ref(), "build oracle/_ref first (make -C oracle)"
     pkg = importlib.import_module("sdsl-lite_amd")
-    want = set(sys.argv[1:]) or {"c2", "c3", "c4"}
+    argv = sys.argv[1:]
+    text_file = None
+    if "--text-file" in argv:
+        i = argv.index("--text-file")
+        text_file = argv[i + 1]
+        del argv[i:i + 2]
+        OUT = os.path.join(HERE, "golden_large_%s.json" % os.path.basename(text_file))
+    want = set(argv) or {"c2", "c3", "c4"}
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
     R = ol.ref().L
     n = 1 << LOG_N
@@ -113,6 +146,44 @@ def main():
         print(f"c2 done in {time.time() - t0:.0f}s: ones={ones}", flush=True)
         json.dump(res, open(OUT, "w"))
 
+    if "c2s" in want:
+        t0 = time.time()
+        words = np.zeros(n // 64 + 2, dtype=np.uint64)
+        R.ref_set_random_bits(words.ctypes.data, n, 42)
+        h = R.ref_bv_create(words.ctypes.data, n)
+        ns = (NQ_FULL + STRIDE - 1) // STRIDE
+        idx = np.ascontiguousarray(pkg.rnd_positions(7, NQ_FULL, n + 1, 0)[::STRIDE])
+        out = np.empty(ns, dtype=np.uint64)
+        R.ref_bv_rank(h, 1, idx.ctypes.data, ns, out.ctypes.data)
+        res["c2"]["rank_1_strided"] = strided(out, NQ_FULL)
+        del idx
+        si = np.ascontiguousarray(pkg.rnd_positions(11, NQ_FULL, res["c2"]["ones"], 1)[::STRIDE])
+        R.ref_bv_select(h, 1, si.ctypes.data, ns, out.ctypes.data)
+        res["c2"]["select_1_strided"] = strided(out, NQ_FULL)
+        R.ref_bv_destroy(h)
+        del words, si, out
+        print(f"c2s done in {time.time() - t0:.0f}s", flush=True)
+        json.dump(res, open(OUT, "w"))
+
+    if "c4s" in want:
+        t0 = time.time()
+        text = load_text(pkg, text_file)
+        nt = int(text.size)
+        if not text_file:
+            assert hashlib.sha256(text.tobytes()).hexdigest() == res["c4"]["text_sha256"]
+        csa = ol.RCsa(text=text.tobytes())
+        print(f"c4s csa built {time.time() - t0:.0f}s", flush=True)
+        ns = (NQ_TEXT_FULL + STRIDE - 1) // STRIDE
+        gi = np.ascontiguousarray(pkg.rnd_positions(13, NQ_TEXT_FULL, nt + 2, 0)[::STRIDE])
+        gc = np.ascontiguousarray(text[pkg.rnd_positions(14, NQ_TEXT_FULL, nt, 0)[::STRIDE].astype(np.int64)])
+        res.setdefault("c4", {})["wt_rank_strided"] = strided(csa.wt_rank(gi, gc), NQ_TEXT_FULL)
+        m = 20
+        st = pkg.rnd_positions(15, NQ_TEXT_FULL, nt - m, 0)[::STRIDE].astype(np.int64)
+        pats = np.ascontiguousarray(text[st[:, None] + np.arange(m)[None, :]].reshape(-1))
+        res["c4"]["count_strided"] = strided(csa.count_batch(pats, m), NQ_TEXT_FULL)
+        print(f"c4s done in {time.time() - t0:.0f}s", flush=True)
+        json.dump(res, open(OUT, "w"))
+
     if "c3" in want:
         t0 = time.time()
         n_ck = (n + CKPT_STRIDE - 1) // CKPT_STRIDE
@@ -147,9 +218,9 @@ def main():
     if "c4sel" in want:
         # wt_huff<>::select on the same text (wt_pc.hpp:443-474): c = text[mt19937_64(14) % n] as for rank, k = 1 + mt19937_64(16) % occ(c)
         t0 = time.time()
-        nt = 1 << TEXT_LOG
-        text = pkg.english_text(nt, 1234)
-        assert hashlib.sha256(text.tobytes()).hexdigest() == res["c4"]["text_sha256"]
+        text = load_text(pkg, text_file)
+        nt = int(text.size)
+        assert text_file or hashlib.sha256(text.tobytes()).hexdigest() == res["c4"]["text_sha256"]
         wt = ol.RWt(text)
         print(f"c4sel wt built {time.time() - t0:.0f}s", flush=True)
         nqs = int(os.environ.get("GOLDEN_NQ_WTSEL", str(10**6)))
@@ -162,11 +233,11 @@ def main():
 
     if "c4" in want:
         t0 = time.time()
-        nt = 1 << TEXT_LOG
-        text = pkg.english_text(nt, 1234)
+        text = load_text(pkg, text_file)
+        nt = int(text.size)
         cnt = np.bincount(text, minlength=256)
         p = cnt[cnt > 0] / nt
-        c4 = {"text_log": TEXT_LOG, "text_seed": 1234, "text_sha256": hashlib.sha256(text.tobytes()).hexdigest(),
+        c4 = {"text_log": TEXT_LOG, "text_bytes": nt, "text_file": os.path.basename(text_file) if text_file else None, "text_seed": 1234, "text_sha256": hashlib.sha256(text.tobytes()).hexdigest(),
               "sigma_without_sentinel": int((cnt > 0).sum()), "H0": float(-(p * np.log2(p)).sum())}
         csa = ol.RCsa(text=text.tobytes())
         print(f"c4 csa built {time.time() - t0:.0f}s", flush=True)
@@ -179,6 +250,7 @@ def main():
         st = pkg.rnd_positions(15, NQ_TEXT, nt - m, 0).astype(np.int64)
         pats = np.ascontiguousarray(text[st[:, None] + np.arange(m)[None, :]].reshape(-1))
         c4.update(pattern_seed=15, m=m, count=digest(csa.count_batch(pats, m)))
+        c4.update({k: v for k, v in res.get("c4", {}).items() if k.endswith("_strided") or k.startswith("wt_select") or k == "wt_k_seed"})
         res["c4"] = c4
         print(f"c4 done in {time.time() - t0:.0f}s", flush=True)
         json.dump(res, open(OUT, "w"))

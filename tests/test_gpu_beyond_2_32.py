@@ -216,3 +216,57 @@ def test_csa_wt_from_a_text_of_more_than_2_pow_32_symbols(gpu):
     assert np.array_equal(np.asarray(csa.sa(x[:20_000].astype(np.uint64))).astype(np.int64), want_sa[:20_000])
     assert np.array_equal(np.asarray(csa.isa(pos[:20_000].astype(np.uint64))).astype(np.int64), want_isa[:20_000])
     csa.close()
+
+
+def test_an_index_of_more_than_2_pow_32_symbols_against_the_real_library(gpu):
+    """The regime pinned to sdsl-lite itself (only a closed form stood behind it).  A csa_wt over a random skewed text
+    of 2^32 + 777 symbols is built on the GPU (64-bit suffix sorter), serialised as csa_wt<wt_huff<bit_vector, rank_support_v5<>>, 32, 64>
+    and LOADED BY THE REAL LIBRARY on the host (oracle/_ref; divsufsort of 4 GiB does not fit a test, loading 4 GB does); both then
+    answer the same count / csa[i] / isa[i] / wavelet_tree.rank / extract queries, with arguments on both sides of 2^32."""
+    import torch
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref (the real sdsl-lite, built in the container that holds /root/reference) did not travel with the repo")
+    n, sigma = (1 << 32) + 777, 40
+    g = torch.Generator(device="cuda").manual_seed(1)
+    text = torch.empty(n, dtype=torch.uint8, device="cuda")
+    for a in range(0, n, 1 << 28):
+        b = min(n, a + (1 << 28))
+        u = torch.rand(b - a, device="cuda", generator=g)
+        text[a:b] = (1 + (u * u * sigma).to(torch.int64).clamp_(max=sigma - 1)).to(torch.uint8)
+    csa = gpu.csa_wt(text=text)
+    assert csa.size() == n + 1 and csa.sampling()[:2] == (32, 64)
+    blob = csa.serialize(32, 64, gpu.capi.LAYOUT_BV_MCL)
+    ref = ol.RCsa(sdsl_bytes=blob)
+    del blob
+    assert ref.size() == n + 1 and ref.sigma() == csa.sigma()
+    rng = np.random.default_rng(12)
+    nq, m = 100_000, 20
+    st = np.concatenate([rng.integers(0, n - m, nq - 4), np.array([0, (1 << 32) - 10, (1 << 32) - 1, n - m])]).astype(np.int64)
+    th = torch.from_numpy(st).cuda()
+    pats = text[(th.view(-1, 1) + torch.arange(m, device="cuda").view(1, m)).reshape(-1)].contiguous()
+    mut = torch.from_numpy(rng.random(nq) < 0.25).cuda()
+    pv = pats.view(-1, m)
+    pv[mut, 7] = (pv[mut, 7] % sigma) + 1                          # a quarter of the patterns changed in one place
+    flat = pats.cpu().numpy()
+    want = ref.count_batch(flat, m)
+    for stage in ("suffix array and text resident", "samples only"):
+        got = np.asarray(csa.count(flat, m)).astype(np.uint64)
+        assert np.array_equal(got, want), f"count ({stage}): first difference at {np.flatnonzero(got != want)[:3]}"
+        short = np.ascontiguousarray(flat.reshape(-1, m)[:20_000, m - 5:]).reshape(-1)   # 5-byte patterns: wide intervals across 2^32
+        l, r = csa.interval(short, 5)
+        lw, rw = ref.interval_batch(short, 5)
+        assert np.array_equal(np.asarray(l), lw) and np.array_equal(np.asarray(r), rw), stage
+        assert (rw > np.uint64(1 << 32)).any() and (lw < np.uint64(1 << 32)).any()
+        idx = np.concatenate([rng.integers(0, n + 1, 20_000), np.array([0, 1, n, (1 << 32) - 1, 1 << 32, (1 << 32) + 1])]).astype(np.uint64)
+        assert np.array_equal(np.asarray(csa.sa(idx)), ref.sa(idx)), f"csa[i] ({stage})"
+        assert np.array_equal(np.asarray(csa.isa(idx)), ref.isa(idx)), f"isa[i] ({stage})"
+        qi = np.concatenate([rng.integers(0, n + 2, 100_000), np.array([0, n + 1, 1 << 32, (1 << 32) + 1])]).astype(np.uint64)
+        qc = rng.integers(1, sigma + 3, qi.size).astype(np.uint8)
+        assert np.array_equal(np.asarray(csa.wavelet_tree.rank(qi, qc)), ref.wt_rank(qi, qc)), f"wavelet_tree.rank ({stage})"
+        b = np.array([0, (1 << 32) - 30, n - 64], dtype=np.uint64)
+        off, got_t = csa.extract(b, b + np.uint64(63))
+        got_t = np.asarray(got_t)
+        for i in range(3):
+            assert bytes(got_t[i * 64:(i + 1) * 64]) == ref.extract(int(b[i]), int(b[i]) + 63), f"extract ({stage})"
+        csa.drop_sa()
+    csa.close()

@@ -225,3 +225,64 @@ def test_c4_wt_rank_and_count_match_reference_digests(gpu):
         check(wt_t.select(ks, gcs).cpu().numpy(), c["wt_select"], "configs[3] wt_huff select(k, c)")
         return
     csa.close()
+
+
+def check_strided(ans_dev, want, what):
+    """every `stride`-th answer of the whole BASELINE batch against the real library's (make_golden_large.py c2s / c4s)"""
+    assert ans_dev.numel() == want["count"], what
+    check(ans_dev[:: want["stride"]].contiguous().cpu().numpy(), want, what)
+
+
+def test_c2_whole_batch_strided_digests(gpu, c2_vector):
+    """configs[1] in full: all 10^9 rank_1 and all 10^9 select_1 queries through the default dispatch (the bucketed passes), every 100th
+    answer compared with the real rank_support_v5 / select_support_mcl — the first-10^7 digests above see one slab of the batch only"""
+    import torch
+    bv, n = c2_vector
+    c = G["c2"]
+    if "rank_1_strided" not in c:
+        pytest.skip("golden_large.json holds no strided digests (make_golden_large.py c2s)")
+    w = c["rank_1_strided"]
+    idx = gpu.rnd_positions_device(c["rank_seed"], w["count"], n + 1, 0, 0)
+    out = torch.empty_like(idx)
+    bv.rank(idx, 1, out)
+    check_strided(out, w, "configs[1] rank_1, whole batch")
+    w = c["select_1_strided"]
+    idx = gpu.rnd_positions_device(c["select_seed"], w["count"], c["ones"], 1, 0)
+    bv.select(idx, 1, out)
+    check_strided(out, w, "configs[1] select_1, whole batch")
+    del idx, out
+    bv.release_scratch()
+
+
+def test_c4_whole_batch_strided_digests_at_both_footprints(gpu):
+    """configs[3] / [4] in full: 10^8 rank(i, c) and 10^8 count() of 20-byte patterns, every 100th answer against the real library's
+    csa_wt<wt_huff<>> — on the index as created from text AND on the same index reduced to 1.5 x the reference's own bytes
+    (sdsl_hip_fm_set_footprint: fused tree lines, 32-bit samples, the k-mer table the budget holds)"""
+    import torch
+    c = G["c4"]
+    if "count_strided" not in c:
+        pytest.skip("golden_large.json holds no strided digests (make_golden_large.py c4s)")
+    nt = 1 << c["text_log"]
+    text = torch.from_numpy(gpu.english_text(nt, c["text_seed"])).cuda()
+    csa = gpu.csa_wt(text=text, device=0)
+    w = c["wt_rank_strided"]
+    gi = gpu.rnd_positions_device(c["wt_i_seed"], w["count"], nt + 2, 0, 0)
+    gc = text[gpu.rnd_positions_device(c["wt_c_seed"], w["count"], nt, 0, 0)]
+    out = torch.empty(w["count"], dtype=torch.int64, device="cuda")
+    csa.wavelet_tree.rank(gi, gc, out)
+    check_strided(out, w, "configs[3] wt_huff rank(i, c), whole batch")
+    del gi, gc
+    w = c["count_strided"]
+    m = c["m"]
+    st = gpu.rnd_positions_device(c["pattern_seed"], w["count"], nt - m, 0, 0)
+    pats = text[(st.view(-1, 1) + torch.arange(m, device="cuda").view(1, m)).reshape(-1)].contiguous()
+    del st
+    csa.count(pats, m, out)
+    check_strided(out, w, "configs[4] count, whole batch")
+    blob_bytes = len(csa.serialize(32, 64, gpu.capi.LAYOUT_BV_MCL))
+    csa.set_footprint(int(1.5 * blob_bytes))
+    assert csa.device_bytes() <= 1.5 * blob_bytes and csa.footprint_parts()["suffix_array"] == 0
+    out.zero_()
+    csa.count(pats, m, out)
+    check_strided(out, w, "configs[4] count at 1.5 x the reference's footprint, whole batch")
+    csa.close()
