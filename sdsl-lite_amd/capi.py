@@ -133,6 +133,7 @@ SIGNATURES = {
     "sdsl_hip_fm_create_from_sdsl_ex": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32,
                                                    C.POINTER(_vp)]),
     "sdsl_hip_fm_drop_sa": (C.c_int32, [_vp]),
+    "sdsl_hip_fm_drop_sa_ex": (C.c_int32, [_vp, C.c_uint32, C.c_uint32]),
     "sdsl_hip_fm_restore_suffix_array": (C.c_int32, [_vp]),
     "sdsl_hip_fm_set_jump_depth": (C.c_int32, [_vp, C.c_uint32]),
     "sdsl_hip_fm_jump_depth": (C.c_uint32, [_vp]),

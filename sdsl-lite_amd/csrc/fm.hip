@@ -767,24 +767,43 @@ sdsl_hip_status sdsl_hip_fm_restore_suffix_array(sdsl_hip_fm_t fm)
     return SDSL_HIP_OK;
 }
 
-sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
+// drop_sa with the sampling densities of the caller's csa_wt type (t_dens / t_inv_dens, csa_wt.hpp:51-57; 0 = keep what the index
+// has, or SDSL's defaults 32 / 64 if it has none).  Samples of other densities than the index holds can only be taken while the whole
+// suffix array is still there.
+sdsl_hip_status sdsl_hip_fm_drop_sa_ex(sdsl_hip_fm_t fm, uint32_t sa_dens, uint32_t isa_dens)
 {
     if (!fm)
         return SDSL_HIP_ERR_INVALID;
     SH_HIP(hipSetDevice(fm->device));
-    if (fm->d_sa.p && fm->sa_dens == 0)
-    { // keep SDSL's default sampling (csa_wt<..., 32, 64>) so that SA / ISA / locate / extract keep working
+    const uint32_t want_sa = sa_dens ? sa_dens : (fm->sa_dens ? fm->sa_dens : 32u), want_isa = isa_dens ? isa_dens : (fm->isa_dens ? fm->isa_dens : 64u);
+    if (want_sa != fm->sa_dens || want_isa != fm->isa_dens)
+    {
+        if (!fm->d_sa.p && !fm->d_sa64.p)
+        {
+            set_error("fm_drop_sa: samples of densities %u / %u can only be taken from the whole suffix array, which this index no longer "
+                      "has (it holds %u / %u)", want_sa, want_isa, fm->sa_dens, fm->isa_dens);
+            return SDSL_HIP_ERR_UNSUPPORTED;
+        }
         const uint64_t n = fm->size;
-        SH_TRY(sa_samples_device(fm->d_sa.as<uint32_t>(), n, 32, 64, &fm->d_sa_s, &fm->d_isa_s));
-        fm->sa_dens = 32;
-        fm->isa_dens = 64;
-        fm->n_sa_s = (n + 31) / 32;
-        fm->n_isa_s = (n + 63) / 64;
+        if (fm->d_sa.p)
+            SH_TRY(sa_samples_device(fm->d_sa.as<uint32_t>(), n, want_sa, want_isa, &fm->d_sa_s, &fm->d_isa_s));
+        else
+            SH_TRY(sa_samples_device64(fm->d_sa64.as<uint64_t>(), n, want_sa, want_isa, &fm->d_sa_s, &fm->d_isa_s));
+        fm->sa_dens = want_sa;
+        fm->isa_dens = want_isa;
+        fm->n_sa_s = (n + want_sa - 1) / want_sa;
+        fm->n_isa_s = (n + want_isa - 1) / want_isa;
+        fm->samples32 = false;
     }
     fm->d_sa.release();
     fm->d_sa64.release();
     fm->d_text.release(); // (only useful beside the whole suffix array)
     return SDSL_HIP_OK;
+}
+
+sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
+{
+    return sdsl_hip_fm_drop_sa_ex(fm, 0, 0);
 }
 
 // ---- the index at a chosen footprint ------------------------------------------------------------------------------------

@@ -105,6 +105,30 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
     bool busy = false;
     uint64_t j = 0, i = 0, steps = 0, taken = 0, emit_from = 0, base = 0;
     unsigned v = 0;
+    // extract: the walk yields the text from its end, one byte per LF step at descending addresses.  Byte stores reached the fabric as
+    // 52 write requests per 64-byte snippet (profiles/walk_extract_r05_pmc.md: 27 x the bytes written); the bytes are collected in a
+    // word — the byte for the lowest address arrives last, so shifting left as they come builds the little-endian word — and an
+    // aligned group of eight leaves as ONE store.
+    uint64_t acc = 0;
+    unsigned acc_n = 0;
+    auto emit = [&](unsigned c, bool last) {
+        acc = (acc << 8) | c;
+        ++acc_n;
+        uint8_t * at = out_text + (base - taken);
+        if (acc_n == 8 && (reinterpret_cast<uintptr_t>(at) & 7) == 0)
+        {
+            if (s == 0)
+                *reinterpret_cast<uint64_t *>(at) = acc;
+            acc_n = 0;
+        }
+        else if (last || (reinterpret_cast<uintptr_t>(at) & 7) == 0)
+        { // the ragged ends of a snippet: fewer than eight bytes above an aligned address, or the snippet's first bytes
+            if (s == 0)
+                for (unsigned k = 0; k < acc_n; ++k)
+                    at[k] = (uint8_t)(acc >> (8 * k));
+            acc_n = 0;
+        }
+    };
     // between two LF steps: is the walk finished?  Then the answer is written and the walker is free again.
     auto settle = [&]() {
         bool done;
@@ -195,8 +219,8 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
             const unsigned c = (unsigned)S.T.bv_pos_rank[v];
             j = S.F.C[S.F.char2comp[c]] + i;
             ++taken;
-            if (MODE == kWalkExtract && taken >= emit_from && s == 0)
-                out_text[base - taken] = (uint8_t)c;
+            if (MODE == kWalkExtract && taken >= emit_from)
+                emit(c, taken == steps);
             settle();
         }
     }

@@ -636,8 +636,10 @@ class csa_wt(_Handle):
         capi.check(L.sdsl_hip_fm_serialize_ex(self._h, layout, sa_dens, isa_dens, _ptr(buf), need.value, C.byref(need)))
         return buf[: need.value].tobytes()
 
-    def drop_sa(self):
-        capi.check(capi.lib().sdsl_hip_fm_drop_sa(self._h))
+    def drop_sa(self, sa_dens: int = 0, isa_dens: int = 0):
+        """release the whole suffix array and the text, keep samples (densities of the caller's csa_wt type; 0 = what the index holds,
+        else SDSL's defaults 32 / 64)"""
+        capi.check(capi.lib().sdsl_hip_fm_drop_sa_ex(self._h, sa_dens, isa_dens))
 
     def restore_suffix_array(self):
         """an index loaded from an SDSL stream with its densities gets its text, whole suffix array and k-mer table back"""

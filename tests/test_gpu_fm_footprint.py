@@ -155,3 +155,45 @@ def test_fused_header_kernels_stride_over_what_the_grid_does_not_cover(gpu, monk
     assert wt2.fused_steps().any()
     assert np.array_equal(np.asarray(wt2.rank(qi, qc)), want)
     wt2.close()
+
+
+def test_samples_at_the_densities_of_the_callers_type(gpu):
+    """csa_wt<wt_huff<>, t_dens, t_inv_dens>: drop_sa(8, 16) keeps SA samples every 8th suffix and ISA samples every 16th position; the walks
+    and the stream written from those samples equal what the whole suffix array gives"""
+    text = gpu.english_text(1 << 20, 13)
+    ocsa = ol.OCsa(bytes(text))
+    full = gpu.csa_wt(text=text)
+    blob_8_16 = full.serialize(8, 16)
+    full.close()
+    csa = gpu.csa_wt(text=text)
+    csa.drop_sa(8, 16)
+    assert csa.sampling() == (8, 16, False)
+    idx = np.random.default_rng(1).integers(0, text.size + 1, 20_000).astype(np.uint64)
+    assert np.array_equal(np.asarray(csa.sa(idx)), np.asarray(ocsa.sa(idx)))
+    assert np.array_equal(np.asarray(csa.isa(idx)), np.asarray(ocsa.isa(idx)))
+    off, txt = csa.extract(np.array([3, 1000, text.size - 300], dtype=np.uint64), np.array([259, 1001, text.size - 1], dtype=np.uint64))
+    assert bytes(np.asarray(txt)) == bytes(text[3:260]) + bytes(text[1000:1002]) + bytes(text[text.size - 300:])
+    assert csa.serialize(8, 16) == blob_8_16
+    with pytest.raises(Exception):
+        csa.drop_sa(32, 64)  # other densities need the suffix array back
+    csa.restore_suffix_array()
+    csa.drop_sa(32, 64)
+    assert csa.sampling() == (32, 64, False)
+    assert np.array_equal(np.asarray(csa.sa(idx)), np.asarray(ocsa.sa(idx)))
+    csa.close()
+
+
+def test_extract_of_every_alignment_and_length(gpu):
+    """the walk collects its bytes into aligned words (locate.hip: emit): every start alignment x every length around the word size, and
+    neighbouring snippets that share a word"""
+    text = gpu.english_text(1 << 18, 3)
+    csa = gpu.csa_wt(text=text)
+    csa.drop_sa()
+    b = np.array([s0 + 100 * k for k, s0 in enumerate(range(1000, 1064))] * 1, dtype=np.uint64)
+    for ln in (1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 200):
+        e = b + np.uint64(ln - 1)
+        off, txt = csa.extract(b, e)
+        txt = np.asarray(txt)
+        want = np.concatenate([text[int(x):int(x) + ln] for x in b])
+        assert np.array_equal(txt, want), ln
+    csa.close()

@@ -30,7 +30,7 @@ if what in ("sa", "extract", "locate", "rrr_count", "wt_select"):
 if what in ("sa", "extract", "locate"):
     csa = pkg.csa_wt(text=text)
     if what == "locate":
-        m, npat = 20, int(float(sys.argv[3])) if len(sys.argv) > 3 else 1_000_000
+        m, npat = 20, int(float(sys.argv[3])) if len(sys.argv) > 3 else 10_000_000
         st = bench.to_dev(pkg.rnd_positions(15, npat, nt - m, 0), dev)
         pats = text[(st.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()
         lq, rq = csa.interval(pats, m)
