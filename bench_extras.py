@@ -551,6 +551,9 @@ def leg_text(c):
         del off, pos
         sidx = torch.randint(0, nt + 1, (20_000_000,), device=dev, dtype=torch.int64, generator=gq)
         want = csa.sa(sidx)
+        eb = torch.randint(0, nt - 64, (10_000_000,), device=dev, dtype=torch.int64, generator=gq)
+        ee = eb + 63
+        _, ms_t = time_steps(lambda: csa.extract(eb, ee), 2, 1, barrier)  # text still resident: a copy (locate.hip: k_fm_extract_copy)
         # the sampling densities are template parameters of the reference's type (csa_wt.hpp:51-57): one denser point first
         # (csa_wt<..., 8, 16>), then the suffix array is brought back and SDSL's defaults 32 / 64 are taken
         csa.drop_sa(8, 16)
@@ -568,14 +571,13 @@ def leg_text(c):
         ex["fm_count_sa_dropped"] = count_leg("dropped", "k-mer hash table (k = %d) -> flat search kernel over ALL remaining "
                                               "characters; suffix array and text released (SDSL's default samples kept)"
                                               % csa.kmer_table_depth())
-        eb = torch.randint(0, nt - 64, (10_000_000,), device=dev, dtype=torch.int64, generator=gq)
-        ee = eb + 63
         eoff, etxt = csa.extract(eb, ee)
         assert torch.equal(etxt.view(-1, 64)[:4096],
                            text[(eb[:4096].view(-1, 1) + torch.arange(64, device=dev).view(1, 64))])
         _, ms = time_steps(lambda: csa.extract(eb, ee), 2, 1, barrier)
         ex["fm_extract_64B"] = {"GB/s": etxt.numel() / ms / 1e6, "ms": ms, "snippets": eb.numel(),
-                                "roofline": pmc_roofline("fm_extract", etxt.numel(), ms)}
+                                "roofline": pmc_roofline("fm_extract", etxt.numel(), ms),
+                                "with_text_resident_GB/s": etxt.numel() / ms_t / 1e6}
         del eoff, etxt, want
         # count() against resident bytes: the index gives HBM back step by step (sdsl_hip_fm_set_footprint) down to the reference's
         # own footprint — csa_wt<wt_huff<>, 32, 64> of this text serialises to `sdsl_stream_bytes` (csa_wt.hpp:389-402) — and count()

@@ -97,7 +97,9 @@ sdsl_hip_status fm_count_fast(sdsl_hip_fm_s * f, const uint8_t * d_pats, uint32_
 size_t sort_pairs_u64_u32_temp_bytes(uint64_t n, unsigned end_bit);
 sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint32_t * vals_in, uint32_t * vals_out,
                                    uint64_t n, unsigned end_bit, hipStream_t s, void * tmp = nullptr, size_t tmp_bytes = 0);
-// out[i] = in[0] + ... + in[i-1] (n entries), stream-ordered
-sdsl_hip_status exclusive_scan_u64(const uint64_t * in, uint64_t * out, uint64_t n, hipStream_t s);
+// out[i] = in[0] + ... + in[i-1] (n entries).  With working memory of the caller's (>= exclusive_scan_u64_temp_bytes(n)): stream-ordered,
+// nothing allocated, nothing waited for; without: allocates, and synchronises the stream before the memory is returned
+size_t exclusive_scan_u64_temp_bytes(uint64_t n);
+sdsl_hip_status exclusive_scan_u64(const uint64_t * in, uint64_t * out, uint64_t n, hipStream_t s, void * tmp = nullptr, size_t tmp_bytes = 0);
 
 } // namespace sdslhip

@@ -359,6 +359,41 @@ __global__ __launch_bounds__(256) void k_fm_expand(const uint64_t * __restrict__
     }
 }
 
+// extract on an index that still holds its text (created from text, before drop_sa / set_footprint): the answer is a copy.  A thread
+// fills 16 consecutive output bytes; off[] says which ranges they belong to (a range's bytes are text[b .. e], position size - 1 being
+// the sentinel's 0).  Invalid ranges have length 0 (k_fm_lengths) and are stepped over.
+__global__ __launch_bounds__(256) void k_fm_extract_copy(const uint8_t * __restrict__ text, uint64_t n_text, const uint64_t * __restrict__ b,
+                                                         const uint64_t * __restrict__ off, uint64_t n, uint64_t total,
+                                                         uint8_t * __restrict__ out)
+{
+    for (uint64_t z0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; z0 < total; z0 += (uint64_t)gridDim.x * blockDim.x * 16)
+    {
+        uint64_t lo = 0, hi = n; // largest p with off[p] <= z0
+        while (hi - lo > 1)
+        {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (off[mid] <= z0)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        uint64_t p = lo, o_lo = off[p], o_hi = off[p + 1], src = b[p];
+        const uint64_t z1 = z0 + 16 < total ? z0 + 16 : total;
+        for (uint64_t z = z0; z < z1; ++z)
+        {
+            while (z >= o_hi)
+            { // next range (empty ones have o_lo == o_hi)
+                ++p;
+                o_lo = o_hi;
+                o_hi = off[p + 1];
+                src = b[p];
+            }
+            const uint64_t at = src + (z - o_lo);
+            out[z] = at < n_text ? text[at] : (uint8_t)0;
+        }
+    }
+}
+
 } // namespace sdslhip
 
 using namespace sdslhip;
@@ -542,24 +577,32 @@ sdsl_hip_status sdsl_hip_fm_extract_batch(sdsl_hip_fm_t fm, const uint64_t * beg
     hipStream_t s = (hipStream_t)stream;
     SH_HIP(hipSetDevice(fm->device));
     *total = 0;
-    SH_TRY(ensure_isa_samples(fm));
+    if (!fm->d_text.p)
+        SH_TRY(ensure_isa_samples(fm)); // (with the text resident the answer is a copy: no walk, no samples)
     Staged sb, se;
     SH_TRY(sb.in(begin, n * 8, s));
     SH_TRY(se.in(end, n * 8, s));
-    DevBuf d_len, d_off;
-    SH_TRY(d_len.alloc((n + 1) * 8));
-    SH_TRY(d_off.alloc((n + 1) * 8));
+    // ONE allocation for the call's four (n + 1)-entry arrays and the scans' working memory (seven hipMalloc / hipFree pairs and two
+    // synchronising scans used to cost 6 ms of a 39 ms call)
+    const size_t col = ((size_t)(n + 1) * 8 + 255) & ~(size_t)255, scan_tmp = (exclusive_scan_u64_temp_bytes(n + 1) + 255) & ~(size_t)255;
+    DevBuf work;
+    SH_TRY(work.alloc(4 * col + scan_tmp));
+    uint64_t * d_len = work.as<uint64_t>();
+    uint64_t * d_off = reinterpret_cast<uint64_t *>(work.as<uint8_t>() + col);
+    uint64_t * d_cnt = reinterpret_cast<uint64_t *>(work.as<uint8_t>() + 2 * col);
+    uint64_t * d_poff = reinterpret_cast<uint64_t *>(work.as<uint8_t>() + 3 * col);
+    void * d_scan = work.as<uint8_t>() + 4 * col;
     hipLaunchKernelGGL((k_fm_lengths<true>), dim3(grid_for(n + 1, 256, 256u * 8u)), dim3(256), 0, s,
-                       (const uint64_t *)sb.dev, (const uint64_t *)se.dev, fm->size, n, d_len.as<uint64_t>());
+                       (const uint64_t *)sb.dev, (const uint64_t *)se.dev, fm->size, n, d_len);
     SH_HIP(hipGetLastError());
-    SH_TRY(exclusive_scan_u64(d_len.as<uint64_t>(), d_off.as<uint64_t>(), n + 1, s));
-    SH_HIP(hipMemcpyAsync(total, d_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    SH_TRY(exclusive_scan_u64(d_len, d_off, n + 1, s, d_scan, scan_tmp));
+    SH_HIP(hipMemcpyAsync(total, d_off + n, 8, hipMemcpyDeviceToHost, s));
     SH_HIP(hipStreamSynchronize(s));
     if (out_offsets)
     {
         Staged so;
         SH_TRY(so.out(out_offsets, (n + 1) * 8));
-        SH_HIP(hipMemcpyAsync(so.dev, d_off.p, (n + 1) * 8, hipMemcpyDeviceToDevice, s));
+        SH_HIP(hipMemcpyAsync(so.dev, d_off, (n + 1) * 8, hipMemcpyDeviceToDevice, s));
         SH_TRY(so.finish(s));
         SH_HIP(hipStreamSynchronize(s));
     }
@@ -575,27 +618,34 @@ sdsl_hip_status sdsl_hip_fm_extract_batch(sdsl_hip_fm_t fm, const uint64_t * beg
         return SDSL_HIP_OK;
     Staged st;
     SH_TRY(st.out(out_text, *total));
+    if (fm->d_text.p)
+    { // the text is resident (an index created from text that has not given it back): a copy instead of LF walks
+        {
+            KernelTimer t(s);
+            hipLaunchKernelGGL(k_fm_extract_copy, dim3(grid_for((*total + 15) / 16, 256, 256u * 16u)), dim3(256), 0, s, fm->d_text.as<uint8_t>(),
+                               fm->size - 1, (const uint64_t *)sb.dev, d_off, n, *total, (uint8_t *)st.dev);
+        }
+        SH_HIP(hipGetLastError());
+        SH_TRY(st.finish(s));
+        SH_HIP(hipStreamSynchronize(s));
+        return SDSL_HIP_OK;
+    }
     // cut the ranges at the ISA sample positions: one walk per piece
     const uint64_t d = fm->isa_dens;
-    DevBuf d_cnt, d_poff, d_pb, d_pe, d_po;
-    SH_TRY(d_cnt.alloc((n + 1) * 8));
-    SH_TRY(d_poff.alloc((n + 1) * 8));
     hipLaunchKernelGGL(k_fm_piece_count, dim3(grid_for(n + 1, 256, 256u * 8u)), dim3(256), 0, s, (const uint64_t *)sb.dev,
-                       (const uint64_t *)se.dev, fm->size, d, n, d_cnt.as<uint64_t>());
+                       (const uint64_t *)se.dev, fm->size, d, n, d_cnt);
     SH_HIP(hipGetLastError());
-    SH_TRY(exclusive_scan_u64(d_cnt.as<uint64_t>(), d_poff.as<uint64_t>(), n + 1, s));
+    SH_TRY(exclusive_scan_u64(d_cnt, d_poff, n + 1, s, d_scan, scan_tmp));
     uint64_t pieces = 0;
-    SH_HIP(hipMemcpyAsync(&pieces, d_poff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    SH_HIP(hipMemcpyAsync(&pieces, d_poff + n, 8, hipMemcpyDeviceToHost, s));
     SH_HIP(hipStreamSynchronize(s));
-    SH_TRY(d_pb.alloc(pieces * 8));
-    SH_TRY(d_pe.alloc(pieces * 8));
-    SH_TRY(d_po.alloc(pieces * 8));
+    DevBuf d_pieces; // begin, end and output offset of every piece: one allocation
+    SH_TRY(d_pieces.alloc(std::max<uint64_t>(pieces, 1) * 24));
+    uint64_t *d_pb = d_pieces.as<uint64_t>(), *d_pe = d_pb + pieces, *d_po = d_pe + pieces;
     hipLaunchKernelGGL(k_fm_piece_fill, dim3(grid_for(pieces, 256, 256u * 16u)), dim3(256), 0, s, (const uint64_t *)sb.dev,
-                       (const uint64_t *)se.dev, d, d_off.as<uint64_t>(), d_poff.as<uint64_t>(), n, pieces,
-                       d_pb.as<uint64_t>(), d_pe.as<uint64_t>(), d_po.as<uint64_t>());
+                       (const uint64_t *)se.dev, d, d_off, d_poff, n, pieces, d_pb, d_pe, d_po);
     SH_HIP(hipGetLastError());
-    SH_TRY(launch_walk<kWalkExtract>(fm, d_pb.as<uint64_t>(), d_pe.as<uint64_t>(), d_po.as<uint64_t>(), pieces, nullptr,
-                                     (uint8_t *)st.dev, s));
+    SH_TRY(launch_walk<kWalkExtract>(fm, d_pb, d_pe, d_po, pieces, nullptr, (uint8_t *)st.dev, s));
     SH_TRY(st.finish(s));
     SH_HIP(hipStreamSynchronize(s));
     return SDSL_HIP_OK;
@@ -616,20 +666,22 @@ sdsl_hip_status sdsl_hip_fm_sa_range_batch(sdsl_hip_fm_t fm, const uint64_t * l,
     Staged sl, sr;
     SH_TRY(sl.in(l, n * 8, s));
     SH_TRY(sr.in(r, n * 8, s));
-    DevBuf d_len, d_off;
-    SH_TRY(d_len.alloc((n + 1) * 8));
-    SH_TRY(d_off.alloc((n + 1) * 8));
+    const size_t col = ((size_t)(n + 1) * 8 + 255) & ~(size_t)255, scan_tmp = (exclusive_scan_u64_temp_bytes(n + 1) + 255) & ~(size_t)255;
+    DevBuf work; // lengths, offsets and the scan's working memory: one allocation, no synchronising scan
+    SH_TRY(work.alloc(2 * col + scan_tmp));
+    uint64_t * d_len = work.as<uint64_t>();
+    uint64_t * d_off = reinterpret_cast<uint64_t *>(work.as<uint8_t>() + col);
     hipLaunchKernelGGL((k_fm_lengths<false>), dim3(grid_for(n + 1, 256, 256u * 8u)), dim3(256), 0, s,
-                       (const uint64_t *)sl.dev, (const uint64_t *)sr.dev, fm->size, n, d_len.as<uint64_t>());
+                       (const uint64_t *)sl.dev, (const uint64_t *)sr.dev, fm->size, n, d_len);
     SH_HIP(hipGetLastError());
-    SH_TRY(exclusive_scan_u64(d_len.as<uint64_t>(), d_off.as<uint64_t>(), n + 1, s));
-    SH_HIP(hipMemcpyAsync(total, d_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    SH_TRY(exclusive_scan_u64(d_len, d_off, n + 1, s, work.as<uint8_t>() + 2 * col, scan_tmp));
+    SH_HIP(hipMemcpyAsync(total, d_off + n, 8, hipMemcpyDeviceToHost, s));
     SH_HIP(hipStreamSynchronize(s));
     if (out_offsets)
     {
         Staged so;
         SH_TRY(so.out(out_offsets, (n + 1) * 8));
-        SH_HIP(hipMemcpyAsync(so.dev, d_off.p, (n + 1) * 8, hipMemcpyDeviceToDevice, s));
+        SH_HIP(hipMemcpyAsync(so.dev, d_off, (n + 1) * 8, hipMemcpyDeviceToDevice, s));
         SH_TRY(so.finish(s));
         SH_HIP(hipStreamSynchronize(s));
     }
@@ -646,7 +698,7 @@ sdsl_hip_status sdsl_hip_fm_sa_range_batch(sdsl_hip_fm_t fm, const uint64_t * l,
     Staged sp;
     SH_TRY(sp.out(out_pos, *total * 8));
     hipLaunchKernelGGL(k_fm_expand, dim3(grid_for(*total, 256, 256u * 16u)), dim3(256), 0, s, (const uint64_t *)sl.dev,
-                       d_off.as<uint64_t>(), n, *total, (uint64_t *)sp.dev);
+                       d_off, n, *total, (uint64_t *)sp.dev);
     SH_HIP(hipGetLastError());
     SH_TRY(sa_lookup(fm, (const uint64_t *)sp.dev, *total, (uint64_t *)sp.dev, s));
     SH_TRY(sp.finish(s));

@@ -114,13 +114,29 @@ sdsl_hip_status sa_samples_device64(const uint64_t * d_sa, uint64_t n, uint64_t 
     return sa_samples_device_t(d_sa, n, sa_dens, isa_dens, sa_s, isa_s);
 }
 
-sdsl_hip_status exclusive_scan_u64(const uint64_t * in, uint64_t * out, uint64_t n, hipStream_t s)
+size_t exclusive_scan_u64_temp_bytes(uint64_t n)
+{
+    size_t bytes = 0;
+    if (n == 0 || rocprim::exclusive_scan(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0, (size_t)n,
+                                          rocprim::plus<uint64_t>(), nullptr) != hipSuccess)
+        return 16;
+    return bytes ? bytes : 16;
+}
+
+// with the caller's working memory (>= exclusive_scan_u64_temp_bytes(n)): stream-ordered, no allocation, no synchronisation; without:
+// a plain hipMalloc / hipFree around the scan and a stream synchronise before the memory goes back (see sort_pairs_u64_u32)
+sdsl_hip_status exclusive_scan_u64(const uint64_t * in, uint64_t * out, uint64_t n, hipStream_t s, void * tmp_p, size_t tmp_bytes)
 {
     if (n == 0)
         return SDSL_HIP_OK;
     size_t bytes = 0;
     SH_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s));
-    DevBuf tmp; // (plain hipMalloc / hipFree — see sort_pairs_u64_u32)
+    if (tmp_p && tmp_bytes >= bytes)
+    {
+        SH_HIP(rocprim::exclusive_scan(tmp_p, bytes, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s));
+        return SDSL_HIP_OK;
+    }
+    DevBuf tmp;
     SH_TRY(tmp.alloc(bytes ? bytes : 16));
     SH_HIP(rocprim::exclusive_scan(tmp.p, bytes, in, out, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), s));
     SH_HIP(hipStreamSynchronize(s)); // (tmp is freed on return)

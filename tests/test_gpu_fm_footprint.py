@@ -183,12 +183,16 @@ def test_samples_at_the_densities_of_the_callers_type(gpu):
     csa.close()
 
 
-def test_extract_of_every_alignment_and_length(gpu):
-    """the walk collects its bytes into aligned words (locate.hip: emit): every start alignment x every length around the word size, and
-    neighbouring snippets that share a word"""
+@pytest.mark.parametrize("mode", ["text resident: a copy", "samples: LF walks"])
+def test_extract_of_every_alignment_and_length(gpu, mode):
+    """the walk collects its bytes into aligned words (locate.hip: emit), the copy of a resident text fills 16 output bytes per thread across
+    range borders: every start alignment x every length around the word size, neighbouring snippets that share a word, the sentinel"""
     text = gpu.english_text(1 << 18, 3)
     csa = gpu.csa_wt(text=text)
-    csa.drop_sa()
+    if mode.startswith("samples"):
+        csa.drop_sa()
+    off, txt = csa.extract(np.array([text.size - 5, 7, 9], dtype=np.uint64), np.array([text.size, 6, 9], dtype=np.uint64))  # to the sentinel; b > e: empty
+    assert bytes(np.asarray(txt)) == bytes(text[-5:]) + b"\0" + bytes(text[9:10]) and list(np.asarray(off)) == [0, 6, 6, 7]
     b = np.array([s0 + 100 * k for k, s0 in enumerate(range(1000, 1064))] * 1, dtype=np.uint64)
     for ln in (1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 200):
         e = b + np.uint64(ln - 1)
