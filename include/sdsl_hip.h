@@ -208,6 +208,14 @@ sdsl_hip_status sdsl_hip_bv_export_words(sdsl_hip_bv_t bv, uint64_t * words_out,
 sdsl_hip_status sdsl_hip_rrr_create(const uint64_t * words, uint64_t n_bits, int32_t device, sdsl_hip_rrr_t * out);
 /* from the bytes written by rrr_vector<63>::serialize (rrr_vector.hpp:366-378) */
 sdsl_hip_status sdsl_hip_rrr_create_from_sdsl(const void * bytes, size_t len, int32_t device, sdsl_hip_rrr_t * out);
+/* A sibling representation kept COMPRESSED on the device: the serialize() bytes of bit_vector_il<t_bs> (bit_vector_il.hpp:212-224),
+ * of the rrr_vector<15> specialisation (rrr_vector_15.hpp:409-420) or of any rrr_vector<t_bs, int_vector<>, t_k>
+ * (rrr_vector.hpp:366-378) — kind as for sdsl_hip_bv_create_from_sdsl — are decoded on the device and re-encoded at once as this
+ * library's rrr_vector<63> records (sdsl_hip_bv_create_from_sdsl keeps such a vector as plain rank lines instead: 1.14 + 0.13 bits
+ * per bit whatever its density).  rank / select / access answers are those of the source vector (rank_support_rrr / select_support_rrr:
+ * rrr_vector.hpp:503-544, 639-726; rrr_vector_15.hpp:135-300 — the same numbers for the same bits); sdsl_hip_rrr_serialize writes
+ * rrr_vector<63>'s stream, not the source type's. */
+sdsl_hip_status sdsl_hip_rrr_create_from_sibling(const void * bytes, size_t len, int32_t kind, int32_t device, sdsl_hip_rrr_t * out);
 /* Writes exactly the bytes rrr_vector<63>::serialize would write for the same bit vector (rrr_vector.hpp:366-378):
  * size, bt (with SDSL's superblock inversion, :203-228), btnr, btnrp, rank samples, invert.  buf == NULL queries the
  * size.  An index encoded on the GPU can thus be handed to unmodified SDSL code (load / load_from_file). */

@@ -1069,6 +1069,23 @@ public:
     {
         return m_dev.get();
     }
+    //! Resident bytes of the device image, and the two knobs that trade them against the speed of count():
+    //! restore_suffix_array() reads the text back through the samples, sorts its suffixes on the device and keeps the whole suffix array,
+    //! the text and a k-mer table beside the tree (8 bytes per symbol more: count() of large batches gets its fastest road, csa[i] and
+    //! extract become gathers); set_footprint(max_bytes) gives memory back down to the host type's own footprint (csa_wt.hpp:389-402:
+    //! tree + samples + alphabet), keeping the k-mer table the budget still holds.  Answers are the same in every state.
+    size_type device_bytes() const
+    {
+        return sdsl_hip_fm_device_bytes(m_dev.get());
+    }
+    void restore_suffix_array()
+    {
+        hip_detail::check(sdsl_hip_fm_restore_suffix_array(m_dev.get()), "sdsl_hip_fm_restore_suffix_array");
+    }
+    void set_footprint(size_type max_bytes)
+    {
+        hip_detail::check(sdsl_hip_fm_set_footprint(m_dev.get(), max_bytes), "sdsl_hip_fm_set_footprint");
+    }
 };
 
 //! The serialised form of wt_pc carries its node table, so the same adaptor serves every byte-alphabet shape:

@@ -403,6 +403,24 @@ int main(int argc, char ** argv)
             CHECK(extract(d1, csa.size() - 3, csa.size() - 1) == extract(csa, csa.size() - 3, csa.size() - 1),
                   "extract at the end (sentinel included)");
         }
+        // the same device image with everything HBM offers (suffix array, text, k-mer table) and back at the host type's footprint
+        {
+            const uint64_t stream_bytes = size_in_bytes(csa), as_loaded = d1.device_bytes();
+            d1.restore_suffix_array();
+            CHECK(d1.device_bytes() > as_loaded + 4 * csa.size(), "restore_suffix_array keeps suffix array and text");
+            std::vector<uint64_t> o4(q);
+            count_batch(d1, pats.data(), m, q, o4.data());
+            CHECK(o4 == o1, "count after restore_suffix_array");
+            CHECK(extract(d1, 10, 60) == extract(csa, 10, 60), "extract from the resident text");
+            // (what the image took as loaded from the stream is always reachable; on a text of a GiB the floor is 1.1 x stream_bytes,
+            // on this small one the fixed tables weigh more)
+            d1.set_footprint(as_loaded);
+            CHECK(d1.device_bytes() <= as_loaded, "set_footprint");
+            (void)stream_bytes;
+            count_batch(d1, pats.data(), m, q, o4.data());
+            CHECK(o4 == o1, "count at the reduced footprint");
+            CHECK(d1[7] == csa[7] and extract(d1, 10, 60) == extract(csa, 10, 60), "csa[i] / extract at the reduced footprint");
+        }
         // SDSL's README index family: csa_wt<wt_huff<rrr_vector<63>>>
         {
             csa_wt<wt_huff<rrr_vector<63>>, 32, 64> crrr;

@@ -83,6 +83,7 @@ SIGNATURES = {
     "sdsl_hip_bv_export_words": (C.c_int32, [_vp, _vp, _vp]),
     "sdsl_hip_rrr_create": (C.c_int32, [_vp, C.c_uint64, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_rrr_create_from_sdsl": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.POINTER(_vp)]),
+    "sdsl_hip_rrr_create_from_sibling": (C.c_int32, [_vp, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "sdsl_hip_rrr_serialize": (C.c_int32, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "sdsl_hip_rrr_destroy": (C.c_int32, [_vp]),
     "sdsl_hip_rrr_size": (C.c_uint64, [_vp]),

@@ -1230,6 +1230,40 @@ sdsl_hip_status sdsl_hip_rrr_create_from_sdsl(const void * bytes, size_t len, in
     return guarded("rrr_create_from_sdsl", [&] { return sdsl_hip_rrr_create_from_sdsl_impl(bytes, len, device, out); });
 }
 
+// A sibling representation (bit_vector_il<>, the rrr_vector<15> specialisation, any rrr_vector<t_bs, int_vector<>, t_k>) kept COMPRESSED in
+// HBM: its stream is decoded on the device (bv_compressed.hip) and the bits are re-encoded at once as this library's rrr records — the
+// plain words exist for the time of the call only.  The resident form is the device's rrr_vector<63> layout (a 5 %-dense rrr_vector<15>
+// of 0.58 bits/bit in SDSL is 0.40 here); rank / select / access do not depend on the representation.
+static sdsl_hip_status sdsl_hip_rrr_create_from_sibling_impl(const void * bytes, size_t len, int32_t kind, int32_t device, sdsl_hip_rrr_t * out)
+{
+    if (!out || !bytes)
+    {
+        set_error("rrr_create_from_sibling: null argument");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    SH_TRY(check_device(device));
+    DevBuf d_words;
+    uint64_t n_bits = 0;
+    SH_TRY(compressed_stream_to_device_words(bytes, len, kind, d_words, n_bits));
+    sdsl_hip_rrr_s * r = new (std::nothrow) sdsl_hip_rrr_s();
+    if (!r)
+        return SDSL_HIP_ERR_NOMEM;
+    r->h.allow_slim = true;
+    const sdsl_hip_status st = rrr_build_device(r->h, d_words.as<uint64_t>(), n_bits, device);
+    if (st != SDSL_HIP_OK)
+    {
+        delete r;
+        return st;
+    }
+    *out = r;
+    return SDSL_HIP_OK;
+}
+sdsl_hip_status sdsl_hip_rrr_create_from_sibling(const void * bytes, size_t len, int32_t kind, int32_t device, sdsl_hip_rrr_t * out)
+{
+    return guarded("rrr_create_from_sibling", [&] { return sdsl_hip_rrr_create_from_sibling_impl(bytes, len, kind, device, out); });
+}
+
 static sdsl_hip_status sdsl_hip_rrr_serialize_impl(sdsl_hip_rrr_t v, void * buf, size_t cap, size_t * written)
 {
     if (!v)

@@ -323,9 +323,14 @@ class rrr_vector(_Handle):
     """Device rrr_vector<63, int_vector<>, 32> with its rank/select supports (rrr_vector.hpp:68)."""
     _destroy = "sdsl_hip_rrr_destroy"
 
-    def __init__(self, words=None, n_bits: int | None = None, device: int = 0, sdsl_bytes: bytes | None = None):
+    def __init__(self, words=None, n_bits: int | None = None, device: int = 0, sdsl_bytes: bytes | None = None, sibling_kind: int | None = None):
+        """sibling_kind (capi.SIBLING_IL / SIBLING_RRR15 / SIBLING_RRR(t_bs, t_k)): sdsl_bytes are the stream of that sibling type; it is
+        decoded on the device and kept compressed as rrr records"""
         super().__init__()
-        if sdsl_bytes is not None:
+        if sdsl_bytes is not None and sibling_kind is not None:
+            buf = np.frombuffer(sdsl_bytes, dtype=np.uint8)
+            capi.check(capi.lib().sdsl_hip_rrr_create_from_sibling(_ptr(buf), buf.size, sibling_kind, device, C.byref(self._h)))
+        elif sdsl_bytes is not None:
             buf = np.frombuffer(sdsl_bytes, dtype=np.uint8)
             capi.check(capi.lib().sdsl_hip_rrr_create_from_sdsl(_ptr(buf), buf.size, device, C.byref(self._h)))
         else:

@@ -207,6 +207,38 @@ def test_sibling_streams_are_decoded_on_the_device(gpu, n, kind):
         assert e.value.status == gpu.capi.ERR_FORMAT
 
 
+@pytest.mark.parametrize("n", [0, 15, 961, 100_003, 3_000_001])
+@pytest.mark.parametrize("kind", [0, 1, 4, 6])
+def test_sibling_streams_stay_compressed_on_request(gpu, n, kind):
+    """sdsl_hip_rrr_create_from_sibling: the same streams (bit_vector_il<512>, rrr_vector<15, ., 32> generic, rrr_vector<31>, the
+    rrr_vector<15> specialisation of the REAL library) decoded on the device and kept as rrr records: rank / select / access / get_int of
+    the source bits, and a sparse vector resident in fewer bytes than the source type's own stream"""
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not present")
+    d = (0.05, 0.5, 0.97, 0.3)[(n + kind) % 4]
+    w = mk(n, d, n + 7)
+    blob = ol.ref_sibling_bytes(w, n, kind)
+    K = gpu.capi
+    ck = {0: K.SIBLING_IL, 1: K.SIBLING_RRR(15, 32), 4: K.SIBLING_RRR(31, 32), 6: K.SIBLING_RRR15}[kind]
+    v = gpu.rrr_vector(sdsl_bytes=blob, sibling_kind=ck)
+    plain = gpu.bit_vector(w, n)
+    assert v.size() == n and v.ones() == plain.ones()
+    if n:
+        idx = np.random.default_rng(n).integers(0, n + 1, size=20_000, dtype=np.uint64)
+        assert np.array_equal(v.rank(idx, 1), plain.rank(idx, 1)) and np.array_equal(v.rank(idx, 0), plain.rank(idx, 0))
+        if plain.ones():
+            i = np.random.default_rng(n + 1).integers(1, plain.ones() + 1, size=20_000, dtype=np.uint64)
+            assert np.array_equal(v.select(i, 1), plain.select(i, 1))
+        pos = idx[idx < n]
+        bits = unpack_bits(w, n)
+        assert np.array_equal(v.access(pos), bits[pos.astype(np.int64)])
+        assert v.serialize() == gpu.rrr_vector(w, n).serialize(), "the stream written is rrr_vector<63>'s of the same bits"
+    if n >= 3_000_000 and d <= 0.05 and kind in (1, 6):
+        assert v.device_bytes() < len(blob), (v.device_bytes(), len(blob))
+    with pytest.raises(gpu.capi.SdslHipError):
+        gpu.rrr_vector(sdsl_bytes=blob[: max(1, len(blob) // 2)], sibling_kind=ck)
+
+
 @pytest.mark.parametrize("d", [0.05, 0.5, 0.97])
 def test_rrr_get_int_matches_reference(gpu, d):
     """rrr_vector::get_int(idx, len) (rrr_vector.hpp:308-356): windows of every length at every alignment to the 63-bit
