@@ -247,7 +247,7 @@ def leg_rrr(c):
     del out_d
     c3ok = a.log_n == c3.get("log_n") and nq >= c3.get("rank_1", {}).get("n", 1 << 62) and rank == 0
     if c3ok:
-        ex["rrr63_rank_1"]["reference_digest_match"] = digest_matches(out, c3["rank_1"]) and rv.ones() == c3["ones"]
+        ex["rrr63_rank_1"]["reference_digest_match"] = digests_match(out, c3, "rank_1") and rv.ones() == c3["ones"]
     si = to_dev(pkg.rnd_positions(11, nq, rv.ones(), 1), dev)
     _, ms = time_steps(lambda: rv.select(si, 1, out), max(2, a.steps // 2), 1, barrier)
     ex["rrr63_select_1"] = {"Gq/s": nq / ms / 1e6, "kernel_ms": ms,
@@ -263,7 +263,7 @@ def leg_rrr(c):
                                              "roofline_frac": ALG_BYTES["rrr"] * nq / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS}
     del out_d
     if c3ok:
-        ex["rrr63_select_1"]["reference_digest_match"] = digest_matches(out, c3["select_1"])
+        ex["rrr63_select_1"]["reference_digest_match"] = digests_match(out, c3, "select_1")
     assert bool((rv.rank(out[: 1 << 20].clone(), 1) == si[: 1 << 20] - 1).all())
     if rank == 0 and world == 1 and not a.no_cpu:
         import oracle_lib as ol

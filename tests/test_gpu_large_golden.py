@@ -254,6 +254,30 @@ def test_c2_whole_batch_strided_digests(gpu, c2_vector):
     bv.release_scratch()
 
 
+def test_c3_whole_batch_strided_digests(gpu):
+    """configs[2] in full: 10^9 rank_1 and 10^9 select_1 on the 5 %-dense 2^34-bit rrr_vector<63> through the default dispatch (the
+    bucketed decoder of rrr_sorted.hip), every 100th answer against the real library's"""
+    import torch
+    c = G["c3"]
+    if "rank_1_strided" not in c:
+        pytest.skip("golden_large.json holds no strided digests for configs[2] (make_golden_large.py c3s)")
+    n = 1 << c["log_n"]
+    ck = np.fromfile(os.path.join(HERE, "golden", "mt9_checkpoints.bin"), dtype=np.uint64).reshape(-1, 313)
+    words = gpu.density_bits(n, c["bits_seed"], c["percent"], ck, c["checkpoint_stride"])
+    rv = gpu.rrr_vector(words, n, device=0)
+    del words
+    w = c["rank_1_strided"]
+    idx = gpu.rnd_positions_device(c["rank_seed"], w["count"], n + 1, 0, 0)
+    out = torch.empty_like(idx)
+    rv.rank(idx, 1, out)
+    check_strided(out, w, "configs[2] rrr rank_1, whole batch")
+    w = c["select_1_strided"]
+    idx = gpu.rnd_positions_device(c["select_seed"], w["count"], c["ones"], 1, 0)
+    rv.select(idx, 1, out)
+    check_strided(out, w, "configs[2] rrr select_1, whole batch")
+    rv.close()
+
+
 def test_c4_whole_batch_strided_digests_at_both_footprints(gpu):
     """configs[3] / [4] in full: 10^8 rank(i, c) and 10^8 count() of 20-byte patterns, every 100th answer against the real library's
     csa_wt<wt_huff<>> — on the index as created from text AND on the same index reduced to 1.5 x the reference's own bytes
