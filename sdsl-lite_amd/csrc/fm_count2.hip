@@ -21,6 +21,7 @@
 // The k-mer table holds, for every k-mer that occurs in the text, exactly the [l, r] the k LF steps produce (the SA range of
 // the suffixes that start with it); a k-mer that does not occur has an empty range, i.e. count 0.
 #include <chrono>
+#include <type_traits>
 
 #include "bv_host.hpp"
 #include "fm_host.hpp"
@@ -90,25 +91,70 @@ struct FmRec
     u32x4 w;               // pattern bytes [rem - 16, rem) of the pattern
 };
 static_assert(sizeof(FmRec) == 32, "FmRec is two 16-byte loads");
+// WIDE (2^32 .. 2^39 symbols): l and e are 40-bit numbers, their top bytes ride in the record's fourth word:
+// [rem : 16 | l >> 32 : 8 | e >> 32 : 8]; patterns are shorter than 65535 bytes there
+template <bool WIDE>
+struct FmPos
+{
+    typedef uint32_t type;
+};
+template <>
+struct FmPos<true>
+{
+    typedef uint64_t type;
+};
 
 constexpr uint64_t kFmPending = UINT64_C(1) << 63;
+constexpr uint32_t kFmDead = 0xFFFFFFFFu; // FmRec::rem of a pattern that k_fm_start has already answered
+
+template <bool WIDE>
+__device__ __forceinline__ u32x4 rec_head(uint32_t q, typename FmPos<WIDE>::type l, typename FmPos<WIDE>::type e, uint32_t rem, bool dead)
+{
+    u32x4 h;
+    h.x = q;
+    h.y = (uint32_t)l;
+    h.z = (uint32_t)e;
+    if (dead)
+        h.w = kFmDead;
+    else if (WIDE)
+        h.w = (rem & 0xFFFFu) | ((uint32_t)((uint64_t)l >> 32) & 0xFFu) << 16 | ((uint32_t)((uint64_t)e >> 32) & 0xFFu) << 24;
+    else
+        h.w = rem;
+    return h;
+}
+// what a search that has stopped at ONE suffix leaves for k_fm_verify2: [1 | characters left | the suffix's SA index]
+template <bool WIDE>
+__device__ __forceinline__ uint64_t pending_word(uint32_t rem, typename FmPos<WIDE>::type l)
+{
+    return WIDE ? kFmPending | ((uint64_t)(rem & 0x7FFFFFu) << 40) | (uint64_t)l : kFmPending | ((uint64_t)rem << 32) | (uint64_t)l;
+}
 
 // quad lookup of `key` in the k-mer table: true (and [l, e)) if present
-__device__ __forceinline__ bool quad_deep_find(const FmDeep & D, int s, uint64_t key, uint32_t & l, uint32_t & e)
+template <bool WIDE>
+__device__ __forceinline__ bool quad_deep_find(const FmDeep & D, int s, uint64_t key, typename FmPos<WIDE>::type & l,
+                                               typename FmPos<WIDE>::type & e)
 {
+    constexpr uint64_t kmask = WIDE ? (UINT64_C(1) << 48) - 1 : ~UINT64_C(0);
     uint32_t b = deep_bucket(key, D.n_buckets);
     for (uint32_t tries = 0; tries < D.n_buckets; ++tries)
     {
         const ulonglong2 * bp = D.tab + (uint64_t)b * 8 + 2 * s;
         const ulonglong2 e0 = bp[0], e1 = bp[1];
-        const bool h0 = e0.x == key, h1 = e1.x == key;
+        const bool h0 = (e0.x & kmask) == key, h1 = (e1.x & kmask) == key;
         const unsigned lh = h0 ? (unsigned)e0.y : (h1 ? (unsigned)e1.y : 0u);
         const unsigned eh = h0 ? (unsigned)(e0.y >> 32) : (h1 ? (unsigned)(e1.y >> 32) : 0u);
+        const unsigned top = WIDE ? (h0 ? (unsigned)(e0.x >> 48) : (h1 ? (unsigned)(e1.x >> 48) : 0u)) : 0u;
         const unsigned hit = quad_sum((h0 || h1) ? 1u : 0u);
         if (hit)
         { // keys are unique: exactly one lane holds it
             l = quad_sum(lh);
             e = quad_sum(eh);
+            if (WIDE)
+            {
+                const uint64_t t = quad_sum(top);
+                l = (typename FmPos<WIDE>::type)((uint64_t)l | (t & 0xFFu) << 32);
+                e = (typename FmPos<WIDE>::type)((uint64_t)e | (t >> 8) << 32);
+            }
             return true;
         }
         const unsigned full = quad_sum((e0.x != 0 ? 1u : 0u) + (e1.x != 0 ? 1u : 0u));
@@ -119,24 +165,24 @@ __device__ __forceinline__ bool quad_deep_find(const FmDeep & D, int s, uint64_t
     return false;
 }
 
-constexpr uint32_t kFmDead = 0xFFFFFFFFu; // FmRec::rem of a pattern that k_fm_start has already answered
-
-template <bool VERIFY>
-__global__ __launch_bounds__(256) void k_fm_start(FmDeep D, uint32_t csa_size, const uint8_t * __restrict__ pats, uint32_t m,
+template <bool VERIFY, bool WIDE>
+__global__ __launch_bounds__(256) void k_fm_start(FmDeep D, uint64_t csa_size, const uint8_t * __restrict__ pats, uint32_t m,
                                                   uint32_t n_pat, uint64_t * __restrict__ out, FmRec * __restrict__ recs)
 {
+    typedef typename FmPos<WIDE>::type pos_t;
     const int s = threadIdx.x & 3;
     const uint32_t quads = (gridDim.x * blockDim.x) >> 2;
     for (uint32_t q = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; q < n_pat; q += quads)
     {
-        uint32_t l = 0, e = csa_size, rem = m;
+        pos_t l = 0, e = (pos_t)csa_size;
+        uint32_t rem = m;
         const uint64_t end = (uint64_t)(q + 1) * m;
         const uint64_t key = load_tail8(pats, end) >> (8 * (8 - D.k));
         uint64_t res = 0;
         bool done = false;
         if (has_zero_byte(key, D.k))
             ; // a 0 byte is the sentinel's character: left to the search, from the whole interval
-        else if (!quad_deep_find(D, s, key, l, e))
+        else if (!quad_deep_find<WIDE>(D, s, key, l, e))
             done = true; // the pattern's last k bytes do not occur in the text: count 0
         else
         {
@@ -149,14 +195,10 @@ __global__ __launch_bounds__(256) void k_fm_start(FmDeep D, uint32_t csa_size, c
             else if (VERIFY && e - l == 1 && rem >= 2)
             { // (one character left: its LF step is cheaper than SA[l] + the text)
                 done = true;
-                res = kFmPending | ((uint64_t)rem << 32) | l;
+                res = pending_word<WIDE>(rem, l);
             }
         }
-        u32x4 h;
-        h.x = q;
-        h.y = l;
-        h.z = e;
-        h.w = done ? kFmDead : rem;
+        const u32x4 h = rec_head<WIDE>(q, l, e, rem, done);
         u32x4 * dst = reinterpret_cast<u32x4 *>(recs + q);
         if (done)
         {
@@ -181,18 +223,20 @@ __global__ __launch_bounds__(256) void k_fm_start(FmDeep D, uint32_t csa_size, c
 // without a k-mer hash table: the dense table of fm.hip (FmJump: every k-mer over the compact alphabet, sigma^k entries) takes
 // the pattern's last J.k characters — unsorted, but only the entries of k-mers that occur are ever touched (a few MiB that
 // stay in the L2) — or the search starts from the whole interval.  One pattern per lane.
-template <bool VERIFY>
-__global__ __launch_bounds__(256) void k_fm_start_dense(FmJump J, const FmTables * __restrict__ ftab, uint32_t csa_size,
+template <bool VERIFY, bool WIDE>
+__global__ __launch_bounds__(256) void k_fm_start_dense(FmJump J, const FmTables * __restrict__ ftab, uint64_t csa_size,
                                                         const uint8_t * __restrict__ pats, uint32_t m, uint32_t n_pat,
                                                         uint64_t * __restrict__ out, FmRec * __restrict__ recs)
 {
+    typedef typename FmPos<WIDE>::type pos_t;
     __shared__ uint8_t c2c[256];
     for (unsigned c = threadIdx.x; c < 256; c += blockDim.x)
         c2c[c] = ftab->char2comp[c];
     __syncthreads();
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_pat; q += gridDim.x * blockDim.x)
     {
-        uint32_t l = 0, e = csa_size, rem = m;
+        pos_t l = 0, e = (pos_t)csa_size;
+        uint32_t rem = m;
         uint64_t res = 0;
         bool done = false;
         const uint64_t end = (uint64_t)(q + 1) * m;
@@ -216,8 +260,8 @@ __global__ __launch_bounds__(256) void k_fm_start_dense(FmJump J, const FmTables
                     done = true; // empty interval: count 0
                 else
                 {
-                    l = (uint32_t)en.x;
-                    e = (uint32_t)en.y + 1;
+                    l = (pos_t)en.x;
+                    e = (pos_t)(en.y + 1);
                     if (rem == 0)
                     {
                         done = true;
@@ -226,18 +270,13 @@ __global__ __launch_bounds__(256) void k_fm_start_dense(FmJump J, const FmTables
                     else if (VERIFY && e - l == 1 && rem >= 2)
                     {
                         done = true;
-                        res = kFmPending | ((uint64_t)rem << 32) | l;
+                        res = pending_word<WIDE>(rem, l);
                     }
                 }
             }
         }
-        u32x4 h;
-        h.x = q;
-        h.y = l;
-        h.z = e;
-        h.w = done ? kFmDead : rem;
         u32x4 * dst = reinterpret_cast<u32x4 *>(recs + q);
-        dst[0] = h;
+        dst[0] = rec_head<WIDE>(q, l, e, rem, done);
         if (done)
             out[q] = res;
         else
@@ -247,14 +286,33 @@ __global__ __launch_bounds__(256) void k_fm_start_dense(FmJump J, const FmTables
 
 constexpr uint32_t kFlatChunk = 256; // records a wave claims at a time
 
-template <bool VERIFY>
-__global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restrict__ f_lines, const FmCountTab * __restrict__ tab_g,
+template <bool WIDE>
+struct FmCtabOf
+{
+    typedef FmCountTab type;
+};
+template <>
+struct FmCtabOf<true>
+{
+    typedef FmCountTabW type;
+};
+
+template <bool VERIFY, bool WIDE>
+__global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restrict__ f_lines, const typename FmCtabOf<WIDE>::type * __restrict__ tab_g,
                                                        const FmRec * __restrict__ recs, uint32_t n_rec,
                                                        uint32_t * __restrict__ ticket, const uint8_t * __restrict__ pats,
                                                        uint32_t m, uint64_t * __restrict__ out)
 {
-    __shared__ FmCountTab T;
-    fm_stage_ctab(&T, tab_g);
+    typedef typename FmPos<WIDE>::type pos_t;
+    __shared__ typename FmCtabOf<WIDE>::type T;
+    {
+        static_assert(sizeof(T) % 8 == 0, "the tables are copied in 8-byte words");
+        const uint64_t * src = reinterpret_cast<const uint64_t *>(tab_g);
+        uint64_t * dst = reinterpret_cast<uint64_t *>(&T);
+        for (unsigned i = threadIdx.x; i < sizeof(T) / 8; i += blockDim.x)
+            dst[i] = src[i];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, s = lane & 3;
     const uint64_t quads_below = (UINT64_C(0x1111111111111111) & ((UINT64_C(1) << (lane & ~3)) - 1)); // leaders of the quads in front
     // the wave's current chunk of the work list, and the ticket of the next one (requested a chunk ahead)
@@ -265,12 +323,27 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
         next_ticket = atomicAdd(ticket, 1u);
     // the search this quad holds ...
     bool act = false;
-    uint32_t q = 0, l = 0, e = 0, rem = 0, wcnt = 0;
+    uint32_t q = 0, rem = 0, wcnt = 0;
+    pos_t l = 0, e = 0, a = 0, b = 0, cb = 0;
     u32x4 w = {0, 0, 0, 0};
-    uint32_t a = 0, b = 0, cb = 0, left = 0, si = 0;
+    uint32_t left = 0, si = 0;
     // ... and the record it takes next
     bool nx = false;
     u32x4 nh = {0, 0, 0, 0}, nw = {0, 0, 0, 0};
+    // WIDE: a count inside a node = the header's low 32 bits + the matches in the line (modulo 2^32), its high part = how many of the
+    // (node, slot)'s listed places lie at or in front of the position (wt_device.hpp: quad_fsec_count)
+    auto count_at = [&](const FSec & x, pos_t p, uint32_t line, uint32_t t, uint32_t step) -> pos_t {
+        const uint32_t lo = quad_sum(fsec_count(x, s, (uint32_t)p & 255u, t));
+        if (!WIDE)
+            return (pos_t)lo;
+        const FmCountTabW & W = reinterpret_cast<const FmCountTabW &>(T);
+        const uint64_t place = ((uint64_t)line << kFusedLog) + ((uint32_t)p & 255u);
+        const unsigned key = ((unsigned)W.snode[step] << 3) | t, nc = W.n_cross;
+        unsigned hi = 0;
+        for (unsigned c = 0; c < nc; ++c)
+            hi += (W.cross_key[c] == key && W.cross_pos[c] <= place) ? 1u : 0u;
+        return (pos_t)(((uint64_t)hi << 32) | lo);
+    };
     for (;;)
     {
         // 1. quads without a next record claim one (the wave's quads in order: the records of a wave stay neighbours)
@@ -308,17 +381,18 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
         // 2. one fused step (three tree levels) of both ends of the interval
         if (act && left)
         {
+            const uint32_t step = si;
             const uint32_t st = T.steps[si];
             ++si;
             --left;
             const uint32_t base = st & 0x0FFFFFFFu, t = st >> 28;
-            const uint32_t La = base + (a >> kFusedLog), Lb = base + (b >> kFusedLog);
+            const uint32_t La = base + (uint32_t)(a >> kFusedLog), Lb = base + (uint32_t)(b >> kFusedLog);
             const FSec xb = load_fsec<false>(f_lines, Lb, s);
             FSec xa = xb;
             if (La != Lb) // quad-uniform
                 xa = load_fsec<false>(f_lines, La, s);
-            a = quad_sum(fsec_count(xa, s, a & 255u, t));
-            b = quad_sum(fsec_count(xb, s, b & 255u, t));
+            a = count_at(xa, a, La, t, step);
+            b = count_at(xb, b, Lb, t, step);
             if (b == 0)
             { // a <= b: both chains stay 0 (wt_pc.hpp:386)
                 a = 0;
@@ -340,7 +414,7 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
             else if (rem == 0)
                 res = e - l;
             else if (VERIFY && e - l == 1 && rem >= 2)
-                res = kFmPending | ((uint64_t)rem << 32) | l;
+                res = pending_word<WIDE>(rem, l);
             else
                 fin = false;
             if (fin)
@@ -358,6 +432,12 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
             l = nh.y;
             e = nh.z;
             rem = nh.w;
+            if (WIDE)
+            {
+                l = (pos_t)((uint64_t)l | (uint64_t)((nh.w >> 16) & 0xFFu) << 32);
+                e = (pos_t)((uint64_t)e | (uint64_t)(nh.w >> 24) << 32);
+                rem = nh.w & 0xFFFFu;
+            }
             w = nw;
             wcnt = rem < 16 ? rem : 16;
             nx = false;
@@ -387,6 +467,8 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
             else
             {
                 cb = T.cb[c];
+                if (WIDE)
+                    cb = (pos_t)((uint64_t)cb | (uint64_t)reinterpret_cast<const FmCountTabW &>(T).cbh[c] << 32);
                 a = l;
                 b = e;
                 si = meta & 0xFFFFu;
@@ -400,18 +482,21 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
 
 // count() of the patterns whose search stopped at a single suffix: the suffix stands at SA[l] in the text, so the pattern's
 // remaining characters pats[begin .. begin + rem) occur right in front of it or nowhere.  One lane per pattern.
-__global__ __launch_bounds__(256) void k_fm_verify2(const uint32_t * __restrict__ sa, const uint8_t * __restrict__ text,
+template <class SA>
+__global__ __launch_bounds__(256) void k_fm_verify2(const SA * __restrict__ sa, const uint8_t * __restrict__ text,
                                                     const uint8_t * __restrict__ pats, uint32_t m, uint32_t n_pat,
                                                     uint64_t * __restrict__ out)
 {
+    constexpr bool WIDE = sizeof(SA) == 8; // the pending word of an index of 2^32 suffixes and more: [1 | length : 23 | suffix : 40]
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_pat; q += gridDim.x * blockDim.x)
     {
         const uint64_t v = out[q];
         if (!(v >> 63))
             continue;
-        const uint32_t l = (uint32_t)v, rem = (uint32_t)(v >> 32) & 0x7FFFFFFFu;
+        const uint64_t l = WIDE ? v & ((UINT64_C(1) << 40) - 1) : (uint64_t)(uint32_t)v;
+        const uint32_t rem = WIDE ? (uint32_t)(v >> 40) & 0x7FFFFFu : (uint32_t)(v >> 32) & 0x7FFFFFFFu;
         const uint8_t * p = pats + (uint64_t)q * m;
-        const uint32_t at = sa[l];
+        const uint64_t at = sa[l];
         bool ok = at >= rem;
         if (ok)
         {
@@ -458,7 +543,8 @@ __device__ __forceinline__ uint64_t low_bytes(uint64_t x, uint32_t k)
 
 // dk[k] = number of distinct k-mers of the text, k = 1..8: suffix i starts a new run of k-mers when its first k bytes differ
 // from its predecessor's in suffix order (a suffix shorter than k has none; the text holds no 0 byte, so its padded key has one)
-__global__ __launch_bounds__(256) void k_deep_census(const uint32_t * __restrict__ sa, uint64_t n, const uint8_t * __restrict__ text,
+template <class SA>
+__global__ __launch_bounds__(256) void k_deep_census(const SA * __restrict__ sa, uint64_t n, const uint8_t * __restrict__ text,
                                                      uint64_t n_text, unsigned long long * __restrict__ dk)
 {
     __shared__ unsigned cnt[9];
@@ -486,11 +572,14 @@ __global__ __launch_bounds__(256) void k_deep_census(const uint32_t * __restrict
 }
 
 // PASS 0: the first suffix of every k-mer's run claims a slot and stores l; PASS 1: the last one finds the slot and stores e
-template <int PASS>
-__global__ __launch_bounds__(256) void k_deep_fill(const uint32_t * __restrict__ sa, uint64_t n, const uint8_t * __restrict__ text,
+// (SA = uint64_t: an index of 2^32 suffixes and more, k <= 6; bits 32..39 of l and e go into the two top bytes of the key word)
+template <int PASS, class SA>
+__global__ __launch_bounds__(256) void k_deep_fill(const SA * __restrict__ sa, uint64_t n, const uint8_t * __restrict__ text,
                                                    uint64_t n_text, uint32_t k, unsigned long long * __restrict__ tab,
                                                    uint32_t n_buckets, unsigned * __restrict__ failed)
 {
+    constexpr bool WIDE = sizeof(SA) == 8;
+    constexpr unsigned long long kmask = WIDE ? (1ull << 48) - 1 : ~0ull;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
     {
         const uint64_t p = sa[i];
@@ -513,15 +602,18 @@ __global__ __launch_bounds__(256) void k_deep_fill(const uint32_t * __restrict__
             {
                 if (PASS == 0)
                 {
-                    if (atomicCAS(slot + 2 * t, 0ull, (unsigned long long)key) == 0ull)
+                    const unsigned long long kw = (unsigned long long)key | (WIDE ? ((unsigned long long)(i >> 32) & 0xFFull) << 48 : 0ull);
+                    if (atomicCAS(slot + 2 * t, 0ull, kw) == 0ull)
                     {
                         reinterpret_cast<uint32_t *>(slot + 2 * t + 1)[0] = (uint32_t)i;
                         done = true;
                     }
                 }
-                else if (slot[2 * t] == key)
+                else if ((slot[2 * t] & kmask) == key)
                 {
                     reinterpret_cast<uint32_t *>(slot + 2 * t + 1)[1] = (uint32_t)(i + 1);
+                    if (WIDE)
+                        atomicOr(slot + 2 * t, (((unsigned long long)(i + 1) >> 32) & 0xFFull) << 56);
                     done = true;
                 }
             }
@@ -544,13 +636,14 @@ sdsl_hip_status fm_build_count_tab(sdsl_hip_fm_s * f)
     f->ctab_ok = false;
     f->d_ctab.release();
     const WtHost & w = sdsl_hip_wt_host(f->wt);
-    if (w.backend != 0 || !w.d_fused.p || !w.d_ftables.p || f->size >= (UINT64_C(1) << 32) || f->sigma < 2)
+    if (w.backend != 0 || !w.d_fused.p || !w.d_ftables.p || f->size >= (UINT64_C(1) << 39) || f->sigma < 2)
         return SDSL_HIP_OK;
+    const bool wide = f->size >= (UINT64_C(1) << 32);
     std::vector<WtFusedTables> ft(1);
     SH_HIP(hipMemcpy(&ft[0], w.d_ftables.p, sizeof(WtFusedTables), hipMemcpyDeviceToHost));
     const WtTables & T = w.d_tables_f.p ? w.tables_f : w.tables;
-    std::vector<FmCountTab> store(1);
-    FmCountTab & C = store[0];
+    std::vector<FmCountTabW> store(1);
+    FmCountTabW & C = store[0];
     memset(&C, 0, sizeof C);
     uint32_t used = 0;
     for (unsigned c = 0; c < 256; ++c)
@@ -568,6 +661,7 @@ sdsl_hip_status fm_build_count_tab(sdsl_hip_fm_s * f)
             const unsigned k = left < 3 ? left : 3, t = (unsigned)p & ((1u << k) - 1u);
             if (used >= kFmMaxSteps || ft[0].fline[v] >= (1u << 28) || v >= w.n_nodes)
                 return SDSL_HIP_OK;
+            C.snode[used] = (uint16_t)v;
             C.steps[used++] = ft[0].fline[v] | (t << 28);
             for (unsigned j = 0, tt = t; j < 3; ++j, tt >>= 1)
             { // wt_descend
@@ -581,10 +675,16 @@ sdsl_hip_status fm_build_count_tab(sdsl_hip_fm_s * f)
         if (steps == 0 || steps > 255)
             return SDSL_HIP_OK;
         C.cb[c] = (uint32_t)f->tab.C[cc];
+        C.cbh[c] = (uint32_t)(f->tab.C[cc] >> 32);
         C.meta[c] = first | (steps << 16);
     }
-    SH_TRY(f->d_ctab.alloc(sizeof(FmCountTab)));
-    SH_HIP(hipMemcpy(f->d_ctab.p, &C, sizeof(FmCountTab), hipMemcpyHostToDevice));
+    C.n_cross = ft[0].n_cross;
+    memcpy(C.cross_key, ft[0].cross_key, sizeof C.cross_key);
+    memcpy(C.cross_pos, ft[0].cross_pos, sizeof C.cross_pos);
+    // (the narrow kernel reads the first sizeof(FmCountTab) bytes, the wide one — 2^32 symbols and more — all of it)
+    const size_t bytes = wide ? sizeof(FmCountTabW) : sizeof(FmCountTab);
+    SH_TRY(f->d_ctab.alloc(bytes));
+    SH_HIP(hipMemcpy(f->d_ctab.p, &C, bytes, hipMemcpyHostToDevice));
     f->ctab_ok = true;
     return SDSL_HIP_OK;
 }
@@ -605,21 +705,26 @@ sdsl_hip_status fm_build_deep(sdsl_hip_fm_s * f, uint32_t k_max, uint64_t budget
         return SDSL_HIP_OK;
     }
     // preconditions first: a call that cannot build leaves the table the index has (it may be one that can no longer be rebuilt)
-    if (!f->d_sa.p || !f->d_text.p || f->size < 2 || f->size >= (UINT64_C(1) << 32))
+    const bool wide = f->size >= (UINT64_C(1) << 32); // 64-bit suffix array, 40-bit intervals, k <= 6
+    if (!(wide ? f->d_sa64.p : f->d_sa.p) || !f->d_text.p || f->size < 2 || f->size >= (UINT64_C(1) << 39))
     {
         set_error("the k-mer table is built from the whole suffix array and the text: create the index from text (and before "
                   "sdsl_hip_fm_drop_sa), or sdsl_hip_fm_restore_suffix_array first");
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
     SH_HIP(hipSetDevice(f->device));
-    if (k_max > 8)
-        k_max = 8;
+    if (k_max > (wide ? 6u : 8u))
+        k_max = wide ? 6u : 8u;
     const uint64_t n = f->size, n_text = f->size - 1;
     DevBuf d_dk;
     SH_TRY(d_dk.alloc(9 * 8 + 8, true));
     const unsigned grid = grid_for(n, 256, 256u * 16u);
-    hipLaunchKernelGGL(k_deep_census, dim3(grid), dim3(256), 0, 0, f->d_sa.as<uint32_t>(), n, f->d_text.as<uint8_t>(), n_text,
-                       d_dk.as<unsigned long long>());
+    if (wide)
+        hipLaunchKernelGGL(k_deep_census<uint64_t>, dim3(grid), dim3(256), 0, 0, f->d_sa64.as<uint64_t>(), n, f->d_text.as<uint8_t>(), n_text,
+                           d_dk.as<unsigned long long>());
+    else
+        hipLaunchKernelGGL(k_deep_census<uint32_t>, dim3(grid), dim3(256), 0, 0, f->d_sa.as<uint32_t>(), n, f->d_text.as<uint8_t>(), n_text,
+                           d_dk.as<unsigned long long>());
     SH_HIP(hipGetLastError());
     uint64_t dk[10];
     SH_HIP(hipMemcpy(dk, d_dk.p, 10 * 8, hipMemcpyDeviceToHost));
@@ -643,10 +748,20 @@ sdsl_hip_status fm_build_deep(sdsl_hip_fm_s * f, uint32_t k_max, uint64_t budget
     DevBuf d_new; // built beside the old table, swapped in when it is complete
     SH_TRY(d_new.alloc(nb * 128, true));
     unsigned * failed = reinterpret_cast<unsigned *>(d_dk.as<unsigned long long>() + 9);
-    hipLaunchKernelGGL((k_deep_fill<0>), dim3(grid), dim3(256), 0, 0, f->d_sa.as<uint32_t>(), n, f->d_text.as<uint8_t>(), n_text,
-                       k, d_new.as<unsigned long long>(), (uint32_t)nb, failed);
-    hipLaunchKernelGGL((k_deep_fill<1>), dim3(grid), dim3(256), 0, 0, f->d_sa.as<uint32_t>(), n, f->d_text.as<uint8_t>(), n_text,
-                       k, d_new.as<unsigned long long>(), (uint32_t)nb, failed);
+    if (wide)
+    {
+        hipLaunchKernelGGL((k_deep_fill<0, uint64_t>), dim3(grid), dim3(256), 0, 0, f->d_sa64.as<uint64_t>(), n, f->d_text.as<uint8_t>(),
+                           n_text, k, d_new.as<unsigned long long>(), (uint32_t)nb, failed);
+        hipLaunchKernelGGL((k_deep_fill<1, uint64_t>), dim3(grid), dim3(256), 0, 0, f->d_sa64.as<uint64_t>(), n, f->d_text.as<uint8_t>(),
+                           n_text, k, d_new.as<unsigned long long>(), (uint32_t)nb, failed);
+    }
+    else
+    {
+        hipLaunchKernelGGL((k_deep_fill<0, uint32_t>), dim3(grid), dim3(256), 0, 0, f->d_sa.as<uint32_t>(), n, f->d_text.as<uint8_t>(), n_text,
+                           k, d_new.as<unsigned long long>(), (uint32_t)nb, failed);
+        hipLaunchKernelGGL((k_deep_fill<1, uint32_t>), dim3(grid), dim3(256), 0, 0, f->d_sa.as<uint32_t>(), n, f->d_text.as<uint8_t>(), n_text,
+                           k, d_new.as<unsigned long long>(), (uint32_t)nb, failed);
+    }
     SH_HIP(hipGetLastError());
     unsigned bad = 0;
     SH_HIP(hipMemcpy(&bad, failed, 4, hipMemcpyDeviceToHost));
@@ -667,7 +782,7 @@ sdsl_hip_status fm_build_deep_default(sdsl_hip_fm_s * f)
     const char * eb = getenv("SDSL_HIP_FM_DEEP_MB");
     const uint32_t k_max = ek ? (uint32_t)std::max(0, atoi(ek)) : 8u;
     const uint64_t budget = eb ? (uint64_t)atoll(eb) << 20 : std::max<uint64_t>(UINT64_C(1) << 20, sdsl_hip_wt_device_bytes(f->wt));
-    if (!f->ctab_ok || !f->d_sa.p || !f->d_text.p || f->size < 2)
+    if (!f->ctab_ok || !(f->d_sa.p || f->d_sa64.p) || !f->d_text.p || f->size < 2)
         return SDSL_HIP_OK;
     return fm_build_deep(f, k_max, budget);
 }
@@ -681,7 +796,8 @@ static bool fm_fast_enabled()
 bool fm_fast_applies(const sdsl_hip_fm_s * f, uint32_t m, uint64_t n_pat)
 {
     static const uint64_t min_pat = getenv("SDSL_HIP_FM_FAST_MIN") ? (uint64_t)atoll(getenv("SDSL_HIP_FM_FAST_MIN")) : 4096;
-    return fm_fast_enabled() && f->ctab_ok && m >= 1 && m < (1u << 30) && n_pat >= min_pat && (!f->deep_k || m >= f->deep_k);
+    const bool wide = f->size >= (UINT64_C(1) << 32); // (a wide record keeps the characters left in 16 bits)
+    return fm_fast_enabled() && f->ctab_ok && m >= 1 && m < (wide ? 65535u : (1u << 30)) && n_pat >= min_pat && (!f->deep_k || m >= f->deep_k);
 }
 
 // count() of n_pat patterns of m bytes each, all in device memory; slabs of at most 2^25 patterns share one scratch area
@@ -711,8 +827,29 @@ sdsl_hip_status fm_count_fast(sdsl_hip_fm_s * f, const uint8_t * d_pats, uint32_
     FmJump J = f->jump();
     if (J.k > 8)
         J.tab = nullptr;
-    verify = verify && f->d_sa.p && f->d_text.p;
-    const uint32_t csa_size = (uint32_t)f->size;
+    const bool wide = f->size >= (UINT64_C(1) << 32);
+    verify = verify && (wide ? f->d_sa64.p : f->d_sa.p) && f->d_text.p;
+    const uint64_t csa_size = f->size;
+    // one slab: start kernel (k-mer table, or the dense table / the whole interval), flat search, text comparison
+    auto run_slab = [&](auto verify_c, auto wide_c, const uint8_t * pp, uint32_t cnt, uint64_t * oo, uint32_t * ticket) {
+        constexpr bool V = decltype(verify_c)::value, W = decltype(wide_c)::value;
+        if (D.tab)
+            hipLaunchKernelGGL((k_fm_start<V, W>), dim3(grid_for(cnt, 64, 256u * 8u)), dim3(256), 0, s, D, csa_size, pp, m, cnt, oo, recs);
+        else
+            hipLaunchKernelGGL((k_fm_start_dense<V, W>), dim3(grid_for(cnt, 256, 256u * 8u)), dim3(256), 0, s, J, f->d_tab.as<FmTables>(),
+                               csa_size, pp, m, cnt, oo, recs);
+        hipLaunchKernelGGL((k_fm_count_flat<V, W>), dim3(grid_for(cnt, 256, 256u * 8u)), dim3(256), 0, s, w.d_fused.as<uint64_t>(),
+                           f->d_ctab.as<typename FmCtabOf<W>::type>(), recs, cnt, ticket, pp, m, oo);
+        if (V)
+        {
+            if (W)
+                hipLaunchKernelGGL(k_fm_verify2<uint64_t>, dim3(grid_for(cnt, 256, 256u * 16u)), dim3(256), 0, s, f->d_sa64.as<uint64_t>(),
+                                   f->d_text.as<uint8_t>(), pp, m, cnt, oo);
+            else
+                hipLaunchKernelGGL(k_fm_verify2<uint32_t>, dim3(grid_for(cnt, 256, 256u * 16u)), dim3(256), 0, s, f->d_sa.as<uint32_t>(),
+                                   f->d_text.as<uint8_t>(), pp, m, cnt, oo);
+        }
+    };
     for (uint64_t i = 0; i < n_slabs && e == hipSuccess; ++i)
     {
         const uint64_t lo = i * per;
@@ -720,30 +857,17 @@ sdsl_hip_status fm_count_fast(sdsl_hip_fm_s * f, const uint8_t * d_pats, uint32_
         const uint8_t * pp = d_pats + lo * m;
         uint64_t * oo = d_out + lo;
         uint32_t * ticket = ctr + i;
-        if (D.tab)
+        if (wide)
         {
-            const unsigned g = grid_for(cnt, 64, 256u * 8u);
             if (verify)
-                hipLaunchKernelGGL((k_fm_start<true>), dim3(g), dim3(256), 0, s, D, csa_size, pp, m, cnt, oo, recs);
+                run_slab(std::true_type(), std::true_type(), pp, cnt, oo, ticket);
             else
-                hipLaunchKernelGGL((k_fm_start<false>), dim3(g), dim3(256), 0, s, D, csa_size, pp, m, cnt, oo, recs);
+                run_slab(std::false_type(), std::true_type(), pp, cnt, oo, ticket);
         }
         else if (verify)
-            hipLaunchKernelGGL((k_fm_start_dense<true>), dim3(grid_for(cnt, 256, 256u * 8u)), dim3(256), 0, s, J, f->d_tab.as<FmTables>(),
-                               csa_size, pp, m, cnt, oo, recs);
+            run_slab(std::true_type(), std::false_type(), pp, cnt, oo, ticket);
         else
-            hipLaunchKernelGGL((k_fm_start_dense<false>), dim3(grid_for(cnt, 256, 256u * 8u)), dim3(256), 0, s, J, f->d_tab.as<FmTables>(),
-                               csa_size, pp, m, cnt, oo, recs);
-        const unsigned gf = grid_for(cnt, 256, 256u * 8u);
-        if (verify)
-            hipLaunchKernelGGL((k_fm_count_flat<true>), dim3(gf), dim3(256), 0, s, w.d_fused.as<uint64_t>(),
-                               f->d_ctab.as<FmCountTab>(), recs, cnt, ticket, pp, m, oo);
-        else
-            hipLaunchKernelGGL((k_fm_count_flat<false>), dim3(gf), dim3(256), 0, s, w.d_fused.as<uint64_t>(),
-                               f->d_ctab.as<FmCountTab>(), recs, cnt, ticket, pp, m, oo);
-        if (verify)
-            hipLaunchKernelGGL(k_fm_verify2, dim3(grid_for(cnt, 256, 256u * 16u)), dim3(256), 0, s, f->d_sa.as<uint32_t>(),
-                               f->d_text.as<uint8_t>(), pp, m, cnt, oo);
+            run_slab(std::false_type(), std::false_type(), pp, cnt, oo, ticket);
         e = hipGetLastError();
     }
     SH_HIP(e);

@@ -58,6 +58,7 @@ __device__ __forceinline__ uint64_t fm_jump_start(const FmJump & J, const FmTabl
 // Per-byte tables of the flat count kernel (fm_count2.hip), 7 KiB of LDS: the path of every symbol through the fused wavelet
 // tree, spelled out as the steps the search takes — no node-table descent, no 64-bit path word in the loop.
 constexpr unsigned kFmMaxSteps = 1280;
+// (an index of 2^32 symbols and more uses FmCountTabW, which begins with these fields)
 struct FmCountTab
 {
     uint32_t cb[256];            // by byte c: C[char2comp[c]] (32 bits: the fused layout is for fewer than 2^32 symbols)
@@ -65,9 +66,21 @@ struct FmCountTab
     uint32_t steps[kFmMaxSteps]; // first line of the fused node (28 bits) | slot << 28
 };
 
+// the same for 2^32 .. 2^39 symbols: the high words of C[], the fused node of every step and the layout's list of places where a count
+// passes a multiple of 2^32 (wt_device.hpp: WtFusedTables::cross_*) — 11 KiB of LDS
+struct FmCountTabW : FmCountTab
+{
+    uint32_t cbh[256];            // by byte c: C[char2comp[c]] >> 32
+    uint16_t snode[kFmMaxSteps];  // fused node of step i
+    uint32_t n_cross;
+    uint16_t cross_key[kFusedMaxCross];
+    uint64_t cross_pos[kFusedMaxCross];
+};
+
 // The k-mer table ("deep jump"): the SA interval [l, e) of every k-mer (k <= 8 bytes) that occurs in the text, in an open hash
 // table of 128-byte buckets of eight 16-byte entries [k-mer as a little-endian number | l | e << 32]; key 0 = free (a k-mer
-// of the text holds no 0 byte).  One bucket fetch replaces the first k LF steps of a search.
+// of the text holds no 0 byte).  One bucket fetch replaces the first k LF steps of a search.  An index of 2^32 symbols and more keeps
+// k <= 6 and the bits 32..39 of l and e in the two top bytes of the key word: [k-mer : 48 | l >> 32 : 8 | e >> 32 : 8], [l | e << 32].
 struct FmDeep
 {
     const ulonglong2 * tab; // null = no table
