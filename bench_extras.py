@@ -670,7 +670,9 @@ def leg_big(c):
     ex["beyond_2_32"] = {"symbols": nb, "sigma": sg, "build_from_text_s": build_s, "resident_GB": cb.device_bytes() / 1e9,
                          "sampling": list(cb.sampling()), "count_Mcount/s": npb / ms_c / 1e3, "patterns": npb, "m": mb,
                          "every_pattern_found": bool((ob >= 1).all()), "wt_rank_Gq/s": nrb / ms_r / 1e6,
-                         "note": "fused lines with the 2^32-crossing list; the flat count kernel and its k-mer table are 32-bit and not used"}
+                         "kmer_table": {"k": cb.kmer_table_depth(), "bytes": cb.kmer_table_bytes()},
+                             "note": "fused lines with the 2^32-crossing list; count: k-mer table with 40-bit intervals -> wide flat search kernel -> "
+                                     "text comparison at one suffix (fm_count2.hip, WIDE variants)"}
     del wtb, cb, tb, pb, ob, ib, sb, orb, stb
     torch.cuda.empty_cache()
 

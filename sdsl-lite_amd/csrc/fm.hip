@@ -437,9 +437,9 @@ static sdsl_hip_status sdsl_hip_fm_create_from_text_ex_impl(const uint8_t * text
     DevBuf d_bwt, d_sa;
     const char * force64 = getenv("SDSL_HIP_SA64"); // (test knob: the 64-bit sorter on a text of any size)
     if (n_text + 1 >= UINT64_C(0xFFFFFFFE) || (force64 && atoi(force64) != 0))
-    { // 2^32 symbols and more: 64-bit suffixes (sa.hip).  The index keeps SA / ISA samples at SDSL's default densities instead of
-      // the whole array (csa_wt<..., 32, 64>: csa_wt.hpp:56), and neither the text nor the k-mer table: count() walks every
-      // character over the binary levels of the wavelet tree (the fused layout and the flat count kernel hold 32-bit counts).
+    { // 2^32 symbols and more: 64-bit suffixes (sa.hip).  The index keeps SA / ISA samples at SDSL's default densities
+      // (csa_wt<..., 32, 64>: csa_wt.hpp:56) AND, room permitting, the whole 64-bit suffix array, the text and a k-mer table with
+      // 40-bit intervals (k <= 6): count() of large batches takes the wide variants of the flat kernels (fm_count2.hip).
         SH_TRY(sa_build_bwt_device64(text, n_text, device, d_bwt, d_sa));
         sdsl_hip_fm_s * f = new (std::nothrow) sdsl_hip_fm_s();
         if (!f)
@@ -467,6 +467,8 @@ static sdsl_hip_status sdsl_hip_fm_create_from_text_ex_impl(const uint8_t * text
             f->n_isa_s = (n + 63) / 64;
             st = fm_from_device_bwt(f, d_bwt.as<uint8_t>(), n, device, flags);
         }
+        if (st == SDSL_HIP_OK)
+            st = fm_build_deep_default(f);
         if (st != SDSL_HIP_OK)
         {
             fm_free(f);

@@ -782,7 +782,8 @@ sdsl_hip_status fm_build_deep_default(sdsl_hip_fm_s * f)
     const char * eb = getenv("SDSL_HIP_FM_DEEP_MB");
     const uint32_t k_max = ek ? (uint32_t)std::max(0, atoi(ek)) : 8u;
     const uint64_t budget = eb ? (uint64_t)atoll(eb) << 20 : std::max<uint64_t>(UINT64_C(1) << 20, sdsl_hip_wt_device_bytes(f->wt));
-    if (!f->ctab_ok || !(f->d_sa.p || f->d_sa64.p) || !f->d_text.p || f->size < 2)
+    // (the suffix array of the index's width: a small text sent through the 64-bit sorter by SDSL_HIP_SA64 has none of 32 bits)
+    if (!f->ctab_ok || !(f->size >= (UINT64_C(1) << 32) ? f->d_sa64.p : f->d_sa.p) || !f->d_text.p || f->size < 2)
         return SDSL_HIP_OK;
     return fm_build_deep(f, k_max, budget);
 }
