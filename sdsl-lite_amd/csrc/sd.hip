@@ -803,10 +803,19 @@ static void sd_build_lane_tables(SdHost & h)
                 redo[1], (unsigned long long)kProbe, h.lane_rank_ok ? "lanes" : "quads", h.lane_sel0_ok ? "lanes" : "quads");
 }
 
+// the lane kernels mark what they leave to k_sd_redo in `out` and k_sd_redo reads the marked queries' ARGUMENTS again: argument and
+// answer arrays must not share a byte (any overlap, not only in == out; the quad kernels read an argument before they write its answer
+// and take either)
+static bool sd_ranges_disjoint(const void * in, const void * out, uint64_t n, size_t out_elem)
+{
+    const uintptr_t a = (uintptr_t)in, b = (uintptr_t)out;
+    return a + n * 8 <= b || b + n * out_elem <= a;
+}
+
 // enqueue rank / access / select_0 on whichever kernels the vector takes
 static void sd_launch_rank(const SdHost & h, int mode, int bit, const uint64_t * d_in, uint64_t * d_out, uint8_t * d_out8, uint64_t n, hipStream_t st)
 {
-    if (h.lane_rank_ok && (const void *)d_in != (const void *)d_out) // (the marked queries are read again: not in place)
+    if (h.lane_rank_ok && sd_ranges_disjoint(d_in, mode == 1 ? (const void *)d_out8 : (const void *)d_out, n, mode == 1 ? 1 : 8))
     {
         const dim3 g(grid_for(n, kBlock, 256u * 8u)), gr(grid_for(n, kBlock, 256u * 4u));
         if (mode == 1)
@@ -830,7 +839,7 @@ static void sd_launch_select(const SdHost & h, int bit, const uint64_t * d_in, u
 {
     if (bit)
         hipLaunchKernelGGL((k_sd_select<1>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, st, h.view, d_in, d_out, n);
-    else if (h.lane_sel0_ok && (const void *)d_in != (const void *)d_out)
+    else if (h.lane_sel0_ok && sd_ranges_disjoint(d_in, d_out, n, 8))
     {
         hipLaunchKernelGGL(k_sd_select0_lane, dim3(grid_for(n, kBlock, 256u * 8u)), dim3(kBlock), 0, st, h.view, d_in, d_out, n, (uint32_t *)nullptr);
         hipLaunchKernelGGL((k_sd_redo<2>), dim3(grid_for(n, kBlock, 256u * 4u)), dim3(kBlock), 0, st, h.view, 0, d_in, d_out, (uint8_t *)nullptr, n);
