@@ -114,3 +114,36 @@ def test_eight_ranks_on_one_gpu(gpu):
     assert fs["resident_shards"]["all_patterns_found"] is True and fs["root_owned_batch_matches"] is True
     assert ex["rank_root_owned_batch"]["matches_local"] is True
     assert took < 300, f"{took:.0f} s"
+
+
+def test_goldens_and_bench_on_a_text_file_of_the_users(gpu, tmp_path):
+    """The recipe for a maintainer who holds Pizza&Chili's english.1GB (not available offline): `make_golden_large.py c4 c4sel c4s
+    --text-file FILE` makes the real library's digests for THAT text, `bench.py --text-file FILE` finds them and reports
+    reference_digest_match for wt.rank / wt.select / count on it.  Here at 1 MiB with a text that holds zero bytes (they are dropped)."""
+    import numpy as np
+    import oracle_lib as ol
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref (the real sdsl-lite) did not travel with the repo")
+    text = gpu.english_text(1 << 20, 77).copy()
+    text[::5000] = 0
+    f = tmp_path / "mytext.1MB"
+    text.tofile(str(f))
+    gold = os.path.join(ROOT, "tests", "golden", "golden_large_mytext.1MB.json")
+    env = dict(os.environ, GOLDEN_TEXT_LOG="20", GOLDEN_NQ_TEXT="20000", GOLDEN_NQ_WTSEL="20000", GOLDEN_NQ_TEXT_FULL="400000", GOLDEN_STRIDE="100")
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "make_golden_large.py"), "c4", "c4sel", "c4s", "--text-file", str(f)],
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and os.path.exists(gold), r.stdout[-2000:] + r.stderr[-2000:]
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-n", "24", "--queries", "4e5",
+                            "--no-cpu", "--extras", "wt,fm", "--text-file", str(f), "--text-mib", "1"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = _last_json(r.stdout)
+        ex = _extras(d)
+        assert d["extras_error"] is None, ex.get("error")
+        assert ex["text"]["bytes"] == int((text != 0).sum()) and "mytext.1MB" in ex["text"]["kind"]
+        assert ex["wt_huff_rank"]["reference_digest_match"] is True and ex["wt_huff_select"]["reference_digest_match"] is True
+        assert ex["fm_count"]["reference_digest_match"] is True and d["secondary"]["reference_digest_match"] is True
+        assert ex["fm_count_lean"]["reference_digest_match"] is True
+    finally:
+        if os.path.exists(gold):
+            os.remove(gold)
