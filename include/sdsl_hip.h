@@ -272,6 +272,12 @@ uint64_t sdsl_hip_wt_bv_size(sdsl_hip_wt_t wt);  /* wt.bv.size() */
  * fused level, the levels being those of an 8-ary Huffman tree of its own).  SDSL_HIP_WT_FUSED=0 in the environment at
  * creation time leaves it out; answers are the same. */
 uint64_t sdsl_hip_wt_device_bytes(sdsl_hip_wt_t wt);
+/* Releases SDSL's binary tree levels (rank lines + both select directories: 1.27 bits per tree bit) of a plain tree that has its
+ * fused layout: rank / access / inverse_select / select keep walking the fused lines (wt_huff<> of a 1 GiB English text: 1.63 GB ->
+ * 0.91 GB resident, 1.4 x the reference's stream); sdsl_hip_wt_serialize rebuilds them from the fused lines for the time of the call
+ * (0.9 s per GiB, same bytes), select on a tree without the fused directory rebuilds them for good.  Nothing may be in flight on
+ * the handle.  (sdsl_hip_fm_set_footprint does this to an FM-index's tree.) */
+sdsl_hip_status sdsl_hip_wt_release_binary_levels(sdsl_hip_wt_t wt);
 /* sum over c of count(c) * code_length(c) / size() is what bench.py needs for the roofline */
 sdsl_hip_status sdsl_hip_wt_code_lengths(sdsl_hip_wt_t wt, uint8_t len_out[256]);
 /* fetches a rank / access / select of symbol c costs on the fused layout (its depth in the layout's own 8-ary tree);

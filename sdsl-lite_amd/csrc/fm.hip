@@ -1147,7 +1147,7 @@ static sdsl_hip_status fm_run(sdsl_hip_fm_t fm, const uint8_t * pats, uint32_t m
         if (w.backend == 1)
         {
             const bool verify = !ival && fm->d_sa.p && fm->d_text.p && fm_verify_enabled() && fm->size < (UINT64_C(1) << 32);
-            SH_TRY(fm_rrr_launch_count(w, fm->d_tab.as<FmTables>(), jump, fm->size, (const uint8_t *)sp.dev, m,
+            SH_TRY(fm_rrr_launch_count(w, fm->d_tab.as<FmTables>(), jump, use_jump ? fm->deep() : FmDeep{nullptr, 0, 0}, fm->size, (const uint8_t *)sp.dev, m,
                                        offsets ? (const uint64_t *)so.dev : nullptr, d_order, n_pat,
                                        ival ? nullptr : (uint64_t *)sc.dev, ival ? (uint64_t *)sl.dev : nullptr,
                                        ival ? (uint64_t *)sr.dev : nullptr, s, verify));

@@ -59,32 +59,6 @@ __device__ __forceinline__ u32x4 load_tail16(const uint8_t * __restrict__ pats, 
     return v;
 }
 
-__device__ __forceinline__ uint64_t load_tail8(const uint8_t * __restrict__ pats, uint64_t end)
-{
-    uint64_t v;
-    if (end >= 8)
-        __builtin_memcpy(&v, pats + end - 8, 8);
-    else
-    {
-        v = 0;
-        for (uint64_t j = 0; j < end; ++j)
-            v |= (uint64_t)pats[j] << (8 * (8 - end + j));
-    }
-    return v;
-}
-
-constexpr uint64_t kDeepMul = UINT64_C(0x9E3779B97F4A7C15);
-__device__ __forceinline__ uint32_t deep_bucket(uint64_t key, uint32_t n_buckets)
-{
-    return (uint32_t)__umul64hi(key * kDeepMul, (uint64_t)n_buckets);
-}
-// does any of the low k bytes of x equal zero?
-__device__ __forceinline__ bool has_zero_byte(uint64_t x, uint32_t k)
-{
-    const uint64_t m = k >= 8 ? ~UINT64_C(0) : ((UINT64_C(1) << (8 * k)) - 1);
-    return (((x - UINT64_C(0x0101010101010101)) & ~x & UINT64_C(0x8080808080808080)) & m) != 0;
-}
-
 struct FmRec
 {
     uint32_t q, l, e, rem; // pattern number inside the slab, interval [l, e), characters still to process
@@ -783,7 +757,9 @@ sdsl_hip_status fm_build_deep_default(sdsl_hip_fm_s * f)
     const uint32_t k_max = ek ? (uint32_t)std::max(0, atoi(ek)) : 8u;
     const uint64_t budget = eb ? (uint64_t)atoll(eb) << 20 : std::max<uint64_t>(UINT64_C(1) << 20, sdsl_hip_wt_device_bytes(f->wt));
     // (the suffix array of the index's width: a small text sent through the 64-bit sorter by SDSL_HIP_SA64 has none of 32 bits)
-    if (!f->ctab_ok || !(f->size >= (UINT64_C(1) << 32) ? f->d_sa64.p : f->d_sa.p) || !f->d_text.p || f->size < 2)
+    // who reads it: the flat kernels of the plain index (ctab_ok), and the lane kernel of the rrr-compressed one below 2^32 symbols
+    const bool rrr_user = sdsl_hip_wt_host(f->wt).backend == 1 && f->size < (UINT64_C(1) << 32);
+    if (!(f->ctab_ok || rrr_user) || !(f->size >= (UINT64_C(1) << 32) ? f->d_sa64.p : f->d_sa.p) || !f->d_text.p || f->size < 2)
         return SDSL_HIP_OK;
     return fm_build_deep(f, k_max, budget);
 }

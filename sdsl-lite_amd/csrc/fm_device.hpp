@@ -87,8 +87,62 @@ struct FmDeep
     uint32_t k, n_buckets;
 };
 
+// ---- helpers of the k-mer table lookup, shared by fm_count2.hip (a quad per pattern) and wt_rrr.hip (a lane per pattern) ----
+__device__ __forceinline__ uint64_t load_tail8(const uint8_t * __restrict__ pats, uint64_t end)
+{
+    uint64_t v;
+    if (end >= 8)
+        __builtin_memcpy(&v, pats + end - 8, 8);
+    else
+    {
+        v = 0;
+        for (uint64_t j = 0; j < end; ++j)
+            v |= (uint64_t)pats[j] << (8 * (8 - end + j));
+    }
+    return v;
+}
+
+constexpr uint64_t kDeepMul = UINT64_C(0x9E3779B97F4A7C15);
+__device__ __forceinline__ uint32_t deep_bucket(uint64_t key, uint32_t n_buckets)
+{
+    return (uint32_t)__umul64hi(key * kDeepMul, (uint64_t)n_buckets);
+}
+// does any of the low k bytes of x equal zero?
+__device__ __forceinline__ bool has_zero_byte(uint64_t x, uint32_t k)
+{
+    const uint64_t m = k >= 8 ? ~UINT64_C(0) : ((UINT64_C(1) << (8 * k)) - 1);
+    return (((x - UINT64_C(0x0101010101010101)) & ~x & UINT64_C(0x8080808080808080)) & m) != 0;
+}
+
+// one LANE looks `key` up (narrow entries: fewer than 2^32 symbols): true and [l, e) if the k-mer occurs in the text
+__device__ __forceinline__ bool lane_deep_find(const FmDeep & D, uint64_t key, uint64_t & l, uint64_t & e)
+{
+    uint32_t b = deep_bucket(key, D.n_buckets);
+    for (uint32_t tries = 0; tries < D.n_buckets; ++tries)
+    {
+        const ulonglong2 * bp = D.tab + (uint64_t)b * 8;
+        unsigned used = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+        {
+            const ulonglong2 en = bp[t];
+            if (en.x == key)
+            {
+                l = (uint32_t)en.y;
+                e = en.y >> 32;
+                return true;
+            }
+            used += en.x != 0 ? 1u : 0u;
+        }
+        if (used < 8)
+            return false; // an insertion would have used the free slot
+        b = b + 1 == D.n_buckets ? 0 : b + 1;
+    }
+    return false;
+}
+
 struct WtHost;
-sdsl_hip_status fm_rrr_launch_count(const WtHost & wt, const FmTables * d_tab, FmJump jump, uint64_t csa_size,
+sdsl_hip_status fm_rrr_launch_count(const WtHost & wt, const FmTables * d_tab, FmJump jump, FmDeep deep, uint64_t csa_size,
                                     const uint8_t * d_pats, uint32_t m, const uint64_t * d_offsets, const uint32_t * d_order,
                                     uint64_t n_pat, uint64_t * d_cnt, uint64_t * d_l, uint64_t * d_r, hipStream_t s, bool verify = false);
 sdsl_hip_status fm_rrr_launch_backward_step(const WtHost & wt, const FmTables * d_tab, uint64_t csa_size,

@@ -1872,6 +1872,18 @@ uint64_t sdsl_hip_wt_device_bytes(sdsl_hip_wt_t wt)
     return wt ? wt->h.device_bytes() : 0;
 }
 
+sdsl_hip_status sdsl_hip_wt_release_binary_levels(sdsl_hip_wt_t wt)
+{
+    if (!wt)
+    {
+        set_error("wt_release_binary_levels: null handle");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    SH_HIP(hipSetDevice(wt->h.device));
+    SH_HIP(hipDeviceSynchronize()); // nothing in flight may still read the levels
+    return wt_drop_binary(wt->h);
+}
+
 sdsl_hip_status sdsl_hip_wt_fused_steps(sdsl_hip_wt_t wt, uint8_t steps_out[256])
 {
     if (!wt || !steps_out)

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_wt_select_rrr(WtView wt, const 
 // characters to go stops and leaves [1 : 1 | characters left : 31 | the suffix : 32] for k_fm_verify (fm.hip), which compares
 // them with the text — on this index every LF step it saves is a cascade of block decodes.
 template <bool WANT_IVAL, bool VERIFY = false>
-__global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const FmTables * __restrict__ ftab, FmJump J,
+__global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const FmTables * __restrict__ ftab, FmJump J, FmDeep D,
                                                               uint64_t csa_size, const uint8_t * __restrict__ pats,
                                                               uint32_t m, const uint64_t * __restrict__ offsets,
                                                               const uint32_t * __restrict__ order, uint64_t n_pat,
@@ -159,7 +159,34 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const F
             r = 0;
             end = begin;
         }
-        uint64_t it = fm_jump_start(J, F, pats, begin, end, l, r);
+        // the pattern's last D.k bytes in ONE bucket of the k-mer hash table (fm_count2.hip: the SA interval of every k-mer that occurs
+        // in the text; a k-mer that is not in it does not occur) — every LF step it saves is a cascade of block decodes here; else the
+        // dense table over the compact alphabet
+        uint64_t it = end;
+        bool started = false;
+        if (D.tab && end - begin >= D.k && end - begin <= csa_size)
+        {
+            const uint64_t key = load_tail8(pats, end) >> (8 * (8 - D.k));
+            if (!has_zero_byte(key, D.k))
+            {
+                uint64_t lo = 0, hi = 0;
+                if (lane_deep_find(D, key, lo, hi))
+                {
+                    l = lo;
+                    r = hi - 1;
+                    it = end - D.k;
+                }
+                else
+                { // count 0; the interval of an absent pattern is (l, r) with r + 1 == l as the reference leaves it after its last step
+                    l = 1;
+                    r = 0;
+                    it = begin;
+                }
+                started = true;
+            }
+        }
+        if (!started)
+            it = fm_jump_start(J, F, pats, begin, end, l, r);
         unsigned c_next = it > begin ? pats[it - 1] : 0;
         unsigned left = 0, v = 0;
         uint64_t a = 0, b = 0, p = 0, cb = 0;
@@ -349,21 +376,23 @@ sdsl_hip_status wt_rrr_launch_inverse_select(const WtHost & wt, const uint64_t *
     return SDSL_HIP_OK;
 }
 
-sdsl_hip_status fm_rrr_launch_count(const WtHost & wt, const FmTables * d_tab, FmJump jump, uint64_t csa_size,
+sdsl_hip_status fm_rrr_launch_count(const WtHost & wt, const FmTables * d_tab, FmJump jump, FmDeep deep, uint64_t csa_size,
                                     const uint8_t * d_pats, uint32_t m, const uint64_t * d_offsets, const uint32_t * d_order,
                                     uint64_t n_pat, uint64_t * d_cnt, uint64_t * d_l, uint64_t * d_r, hipStream_t s, bool verify)
 {
     if (n_pat == 0)
         return SDSL_HIP_OK;
+    if (csa_size >= (UINT64_C(1) << 32) || d_l)
+        deep.tab = nullptr; // (the lane lookup reads narrow entries; intervals keep the reference's exact (l, r) of an absent pattern)
     if (d_l)
         hipLaunchKernelGGL((k_fm_count_rrr<true>), dim3(wt_rrr_grid(n_pat)), dim3(kWtRrrBlock), 0, s, wt.view(), d_tab,
-                           jump, csa_size, d_pats, m, d_offsets, d_order, n_pat, (uint64_t *)nullptr, d_l, d_r);
+                           jump, deep, csa_size, d_pats, m, d_offsets, d_order, n_pat, (uint64_t *)nullptr, d_l, d_r);
     else if (verify && csa_size < (UINT64_C(1) << 32))
         hipLaunchKernelGGL((k_fm_count_rrr<false, true>), dim3(wt_rrr_grid(n_pat)), dim3(kWtRrrBlock), 0, s, wt.view(), d_tab,
-                           jump, csa_size, d_pats, m, d_offsets, d_order, n_pat, d_cnt, (uint64_t *)nullptr, (uint64_t *)nullptr);
+                           jump, deep, csa_size, d_pats, m, d_offsets, d_order, n_pat, d_cnt, (uint64_t *)nullptr, (uint64_t *)nullptr);
     else
         hipLaunchKernelGGL((k_fm_count_rrr<false>), dim3(wt_rrr_grid(n_pat)), dim3(kWtRrrBlock), 0, s, wt.view(), d_tab,
-                           jump, csa_size, d_pats, m, d_offsets, d_order, n_pat, d_cnt, (uint64_t *)nullptr, (uint64_t *)nullptr);
+                           jump, deep, csa_size, d_pats, m, d_offsets, d_order, n_pat, d_cnt, (uint64_t *)nullptr, (uint64_t *)nullptr);
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }

@@ -515,6 +515,10 @@ class wt_huff(_Handle):
     def device_bytes(self) -> int:
         return capi.lib().sdsl_hip_wt_device_bytes(self._h)
 
+    def release_binary_levels(self):
+        """keep only the fused lines (rank / access / inverse_select / select walk them); serialize rebuilds SDSL's levels for the call"""
+        capi.check(capi.lib().sdsl_hip_wt_release_binary_levels(self._h))
+
     def serialize(self, layout: int = 0) -> bytes:
         """the bytes of wt_huff<bit_vector, rank_support_v5<>, select_support_scan<>, select_support_scan<0>> (layout 0),
         wt_huff<bit_vector, rank_support_v5<>> with mcl selects (capi.LAYOUT_BV_MCL) or wt_huff<> with SDSL's default

@@ -201,3 +201,24 @@ def test_extract_of_every_alignment_and_length(gpu, mode):
         want = np.concatenate([text[int(x):int(x) + ln] for x in b])
         assert np.array_equal(txt, want), ln
     csa.close()
+
+
+@pytest.mark.parametrize("shape", ["huff", "blcd", "hutu"])
+def test_a_wavelet_tree_without_its_binary_levels(gpu, shape):
+    """sdsl_hip_wt_release_binary_levels on a stand-alone tree of every byte shape: same rank / select / access / inverse_select, fewer
+    bytes, and the serialised stream — whose levels are rebuilt from the fused lines with the tree's own node table — stays what it was"""
+    text = gpu.english_text(1 << 20, 31)
+    wt = gpu.wt_huff(text=text, balanced=(shape == "blcd"), hutu=(shape == "hutu"))
+    rng = np.random.default_rng(2)
+    qi = rng.integers(0, text.size + 1, 50_000).astype(np.uint64)
+    qc = text[rng.integers(0, text.size, 50_000)]
+    occ = np.bincount(text, minlength=256)
+    k = (1 + rng.integers(0, 1 << 40, 50_000) % occ[qc]).astype(np.uint64)
+    before = (np.asarray(wt.rank(qi, qc)), np.asarray(wt.select(k, qc)), np.asarray(wt.access(qi[qi < text.size])), wt.serialize(gpu.capi.LAYOUT_BV_MCL))
+    full = wt.device_bytes()
+    wt.release_binary_levels()
+    assert wt.device_bytes() < 0.62 * full
+    after = (np.asarray(wt.rank(qi, qc)), np.asarray(wt.select(k, qc)), np.asarray(wt.access(qi[qi < text.size])), wt.serialize(gpu.capi.LAYOUT_BV_MCL))
+    assert all(np.array_equal(a, b) if not isinstance(a, bytes) else a == b for a, b in zip(before, after))
+    assert wt.device_bytes() < 0.62 * full, "the levels rebuilt for serialize are released again"
+    wt.close()
