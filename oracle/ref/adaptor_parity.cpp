@@ -535,6 +535,18 @@ int main(int argc, char ** argv)
         for (size_t i = 0; i < 2000; ++i)
             dwant += r1(q[i]);
         CHECK(dsum == dwant, "rank_on_device");
+        {
+            double best = 1e30;
+            for (int rep = 0; rep < 3; ++rep)
+            {
+                auto tf = std::chrono::steady_clock::now();
+                volatile uint64_t sink = hip_detail::fingerprint(&bv).a;
+                (void)sink;
+                best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf).count());
+            }
+            printf("content fingerprint of the 2^28-bit vector (32 MiB, taken once per support construction): %.2f ms = %.1f GB/s\n", best,
+                   (double)(bv.size() / 8) / best / 1e6);
+        }
         printf("scalar rs(i), 10^6 calls on 2^28 bits: %.1f ns per call (rank_support_v5<1> itself: %.1f ns; through the device: %.2f us); "
                "the same queries as one rank_batch from host arrays: %.2f ns per query\n", ns, ns_ref, us_dev, ns_b);
         // supports of one vector share one device replica; a select support adds its directory to it
