@@ -382,7 +382,7 @@ uint64_t sdsl_hip_fm_kmer_table_bytes(sdsl_hip_fm_t fm);
  * the remaining budget allows.  Answers never change; csa[i] / locate / extract walk LF steps from the samples as the reference
  * does (csa_wt.hpp:363-381).  Floor: fused tree lines + samples + alphabet (about 0.9 bytes per symbol of English text, i.e.
  * the reference's own footprint); a budget below it is SDSL_HIP_ERR_INVALID and the message names the floor.  Plain tree with
- * the fused layout, fewer than 2^32 symbols; nothing may be in flight on the handle.  One-way (restore_suffix_array brings
+ * the fused layout (an index of 2^32 symbols and more keeps 64-bit samples); nothing may be in flight on the handle.  One-way (restore_suffix_array brings
  * suffix array, text and the default table back). */
 sdsl_hip_status sdsl_hip_fm_set_footprint(sdsl_hip_fm_t fm, uint64_t max_bytes);
 /* resident bytes by part: [0] binary tree levels + select directories (or the rrr vector), [1] fused tree lines + directory,

@@ -699,7 +699,9 @@ uint64_t sdsl_hip_fm_kmer_table_bytes(sdsl_hip_fm_t fm)
 // The opposite of drop_sa, for an index that came from an SDSL stream: the text is read back through the ISA samples
 // (sdsl_hip_fm_extract_batch: thousands of independent walks), suffix-sorted on the device like a text handed to
 // sdsl_hip_fm_create_from_text, and the result is checked against the stream's own SA samples before it is kept.
-__global__ __launch_bounds__(256) void k_fm_check_samples(const uint32_t * __restrict__ sa, const uint64_t * __restrict__ samples,
+} // extern "C" (a kernel template)
+template <class SA>
+__global__ __launch_bounds__(256) void k_fm_check_samples(const SA * __restrict__ sa, const uint64_t * __restrict__ samples,
                                                           uint32_t s32, uint64_t n_samples, uint64_t dens, unsigned * __restrict__ bad)
 {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_samples; k += (uint64_t)gridDim.x * blockDim.x)
@@ -707,6 +709,7 @@ __global__ __launch_bounds__(256) void k_fm_check_samples(const uint32_t * __res
             atomicAdd(bad, 1u);
 }
 
+extern "C" {
 __global__ __launch_bounds__(256) void k_fm_narrow_samples(const uint64_t * __restrict__ in, uint32_t * __restrict__ out, uint64_t n)
 {
     for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x)
@@ -717,12 +720,13 @@ __global__ __launch_bounds__(256) void k_fm_narrow_samples(const uint64_t * __re
 static sdsl_hip_status fm_ensure_sa_text(sdsl_hip_fm_t fm)
 {
     SH_HIP(hipSetDevice(fm->device));
-    if (!(fm->d_sa.p && fm->d_text.p))
+    const bool wide = fm->size >= UINT64_C(0xFFFFFFFE); // the 64-bit sorter and suffix array (sa.hip), as at creation
+    if (!((wide ? fm->d_sa64.p : fm->d_sa.p) && fm->d_text.p))
     {
-        if (fm->size < 2 || fm->size >= UINT64_C(0xFFFFFFFE) || !fm->isa_dens || !fm->sa_dens)
+        if (fm->size < 2 || fm->size >= (UINT64_C(1) << 39) || !fm->isa_dens || !fm->sa_dens)
         {
             set_error("fm_restore_suffix_array: needs the index's SA and ISA samples (load the stream with its densities: "
-                      "sdsl_hip_fm_create_from_sdsl_ex) and fewer than 2^32 - 2 symbols");
+                      "sdsl_hip_fm_create_from_sdsl_ex) and fewer than 2^39 symbols");
             return SDSL_HIP_ERR_UNSUPPORTED;
         }
         const uint64_t n_text = fm->size - 1;
@@ -736,10 +740,19 @@ static sdsl_hip_status fm_ensure_sa_text(sdsl_hip_fm_t fm)
             set_error("fm_restore_suffix_array: the index gave back %llu of %llu symbols", (unsigned long long)total, (unsigned long long)n_text);
             return SDSL_HIP_ERR_FORMAT;
         }
-        SH_TRY(sa_build_bwt_device(d_text.as<uint8_t>(), n_text, fm->device, d_bwt, d_sa));
         SH_TRY(d_bad.alloc(4, true));
-        hipLaunchKernelGGL(k_fm_check_samples, dim3(grid_for(fm->n_sa_s, 256, 256u * 8u)), dim3(256), 0, 0, d_sa.as<uint32_t>(),
-                           fm->d_sa_s.as<uint64_t>(), fm->samples32 ? 1u : 0u, fm->n_sa_s, (uint64_t)fm->sa_dens, d_bad.as<unsigned>());
+        if (wide)
+        {
+            SH_TRY(sa_build_bwt_device64(d_text.as<uint8_t>(), n_text, fm->device, d_bwt, d_sa));
+            hipLaunchKernelGGL(k_fm_check_samples<uint64_t>, dim3(grid_for(fm->n_sa_s, 256, 256u * 8u)), dim3(256), 0, 0, d_sa.as<uint64_t>(),
+                               fm->d_sa_s.as<uint64_t>(), fm->samples32 ? 1u : 0u, fm->n_sa_s, (uint64_t)fm->sa_dens, d_bad.as<unsigned>());
+        }
+        else
+        {
+            SH_TRY(sa_build_bwt_device(d_text.as<uint8_t>(), n_text, fm->device, d_bwt, d_sa));
+            hipLaunchKernelGGL(k_fm_check_samples<uint32_t>, dim3(grid_for(fm->n_sa_s, 256, 256u * 8u)), dim3(256), 0, 0, d_sa.as<uint32_t>(),
+                               fm->d_sa_s.as<uint64_t>(), fm->samples32 ? 1u : 0u, fm->n_sa_s, (uint64_t)fm->sa_dens, d_bad.as<unsigned>());
+        }
         SH_HIP(hipGetLastError());
         unsigned bad = 0;
         SH_HIP(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
@@ -748,7 +761,10 @@ static sdsl_hip_status fm_ensure_sa_text(sdsl_hip_fm_t fm)
             set_error("fm_restore_suffix_array: %u of the stream's SA samples disagree with the suffix array of the text the index spells", bad);
             return SDSL_HIP_ERR_FORMAT;
         }
-        fm->d_sa = std::move(d_sa);
+        if (wide)
+            fm->d_sa64 = std::move(d_sa);
+        else
+            fm->d_sa = std::move(d_sa);
         fm->d_text = std::move(d_text);
     }
     return SDSL_HIP_OK;
@@ -822,6 +838,8 @@ sdsl_hip_status sdsl_hip_fm_drop_sa(sdsl_hip_fm_t fm)
 // What remains at the floor: the fused lines (4 bits per symbol and fused level), the samples, the alphabet tables.
 void sdsl_hip_fm_footprint_parts(sdsl_hip_fm_t fm, uint64_t parts[8])
 {
+    if (!parts)
+        return;
     for (int i = 0; i < 8; ++i)
         parts[i] = 0;
     if (!fm)
@@ -870,10 +888,10 @@ static sdsl_hip_status sdsl_hip_fm_set_footprint_impl(sdsl_hip_fm_t fm, uint64_t
     WtHost & w = sdsl_hip_wt_host(fm->wt);
     if (w.backend == 0 && w.d_fused.p && !fm->ctab_ok)
         SH_TRY(fm_build_count_tab(fm)); // (an index loaded from a stream gets the flat kernel's tables on first need)
-    if (w.backend != 0 || !w.d_fused.p || !fm->ctab_ok || fm->size >= (UINT64_C(1) << 32))
+    if (w.backend != 0 || !w.d_fused.p || !fm->ctab_ok)
     {
-        set_error("fm_set_footprint: the compact forms exist for an index on the plain wavelet tree with its fused layout and fewer "
-                  "than 2^32 symbols (this one holds %llu bytes; for a smaller index of any size: SDSL_HIP_WT_RRR63)",
+        set_error("fm_set_footprint: the compact forms exist for an index on the plain wavelet tree with its fused layout (fewer than "
+                  "2^36 symbols; this one holds %llu bytes; for a smaller index of any size: SDSL_HIP_WT_RRR63)",
                   (unsigned long long)sdsl_hip_fm_device_bytes(fm));
         return SDSL_HIP_ERR_UNSUPPORTED;
     }
@@ -884,8 +902,9 @@ static sdsl_hip_status sdsl_hip_fm_set_footprint_impl(sdsl_hip_fm_t fm, uint64_t
         return wt_drop_binary(w);
     // 2. samples instead of suffix array and text: what is the floor, what is left for the k-mer table?
     const uint64_t n = fm->size;
+    const bool wide = n >= (UINT64_C(1) << 32); // 64-bit suffix array; the samples stay 64 bits wide
     const bool make_samples = !fm->sa_dens || !fm->isa_dens;
-    if (make_samples && !fm->d_sa.p)
+    if (make_samples && !(wide ? fm->d_sa64.p : fm->d_sa.p))
     {
         set_error("fm_set_footprint: this index has neither its suffix array nor SA / ISA samples (created from a BWT, or loaded "
                   "without densities): there is nothing smaller to fall back to");
@@ -901,7 +920,7 @@ static sdsl_hip_status sdsl_hip_fm_set_footprint_impl(sdsl_hip_fm_t fm, uint64_t
         jump_bytes *= fm->sigma;
         ++jk;
     }
-    const uint64_t floor_bytes = parts[1] + parts[7] + (n_sa_s + n_isa_s) * 4 + (jk ? jump_bytes : 0);
+    const uint64_t floor_bytes = parts[1] + parts[7] + (n_sa_s + n_isa_s) * (wide ? 8 : 4) + (jk ? jump_bytes : 0);
     if (floor_bytes > max_bytes)
     {
         set_error("fm_set_footprint: the smallest form of this index (fused tree lines, SA / ISA samples at %u / %u, alphabet) is %llu "
@@ -912,7 +931,10 @@ static sdsl_hip_status sdsl_hip_fm_set_footprint_impl(sdsl_hip_fm_t fm, uint64_t
     }
     if (make_samples)
     {
-        SH_TRY(sa_samples_device(fm->d_sa.as<uint32_t>(), n, 32, 64, &fm->d_sa_s, &fm->d_isa_s));
+        if (wide)
+            SH_TRY(sa_samples_device64(fm->d_sa64.as<uint64_t>(), n, 32, 64, &fm->d_sa_s, &fm->d_isa_s));
+        else
+            SH_TRY(sa_samples_device(fm->d_sa.as<uint32_t>(), n, 32, 64, &fm->d_sa_s, &fm->d_isa_s));
         fm->sa_dens = 32;
         fm->isa_dens = 64;
         fm->n_sa_s = n_sa_s;

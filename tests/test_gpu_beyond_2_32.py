@@ -249,7 +249,19 @@ def test_an_index_of_more_than_2_pow_32_symbols_against_the_real_library(gpu):
     pv[mut, 7] = (pv[mut, 7] % sigma) + 1                          # a quarter of the patterns changed in one place
     flat = pats.cpu().numpy()
     want = ref.count_batch(flat, m)
-    for stage in ("suffix array and text resident", "samples only"):
+    full_bytes = csa.device_bytes()
+    for stage in ("suffix array and text resident", "samples only", "footprint: fused lines + samples + a k-mer table within 8 GB",
+                  "suffix array and text restored"):
+        if stage.startswith("footprint"):
+            # set_footprint on an index of 2^32 symbols and more: the 64-bit suffix array and the text come back for the time of the call
+            # (the k-mer table is built from them), the binary levels go, the samples stay 64 bits wide
+            csa.set_footprint(8 << 30)
+            parts = csa.footprint_parts()
+            assert csa.device_bytes() <= (8 << 30) and parts["wt_binary_levels"] == 0 and parts["suffix_array"] == 0 and parts["text"] == 0
+            assert parts["sa_isa_samples"] == 8 * ((n + 32) // 32 + (n + 64) // 64) and csa.kmer_table_depth() >= 1
+        elif stage.endswith("restored"):
+            csa.restore_suffix_array()
+            assert csa.footprint_parts()["suffix_array"] == 8 * (n + 1) and csa.sampling() == (32, 64, True)
         got = np.asarray(csa.count(flat, m)).astype(np.uint64)
         assert np.array_equal(got, want), f"count ({stage}): first difference at {np.flatnonzero(got != want)[:3]}"
         short = np.ascontiguousarray(flat.reshape(-1, m)[:20_000, m - 5:]).reshape(-1)   # 5-byte patterns: wide intervals across 2^32
@@ -268,5 +280,7 @@ def test_an_index_of_more_than_2_pow_32_symbols_against_the_real_library(gpu):
         got_t = np.asarray(got_t)
         for i in range(3):
             assert bytes(got_t[i * 64:(i + 1) * 64]) == ref.extract(int(b[i]), int(b[i]) + 63), f"extract ({stage})"
-        csa.drop_sa()
+        if stage.startswith("suffix array and text resident"):
+            csa.drop_sa()
+    assert csa.device_bytes() < full_bytes  # (the binary levels stay released)
     csa.close()
