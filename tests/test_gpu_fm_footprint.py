@@ -222,3 +222,57 @@ def test_a_wavelet_tree_without_its_binary_levels(gpu, shape):
     assert all(np.array_equal(a, b) if not isinstance(a, bytes) else a == b for a, b in zip(before, after))
     assert wt.device_bytes() < 0.62 * full, "the levels rebuilt for serialize are released again"
     wt.close()
+
+
+import golden_data as gd  # noqa: E402
+
+
+@pytest.mark.parametrize("name", [t for t in gd.TEXTS if t not in ("empty.txt", "all_symbols.txt")])
+def test_the_references_own_fixtures_at_every_footprint(gpu, name):
+    """test/test_cases of the reference (a 100-fold 'a': sigma 1; one byte; tiny periodic texts; faust.txt): the golden count / interval
+    vectors of the real library on the index as created, with the binary levels released, at the floor, and restored — or a clean refusal
+    where a structure does not exist for the text (no fused layout for a one-symbol alphabet), never a changed answer"""
+    g = gd.text_golden()
+    if f"{name}/csa_meta" not in g.files:
+        pytest.skip("text contains a 0 byte: not indexable (construct.hpp:41)")
+    data = gd.text(name)
+    csa = gpu.csa_wt(text=data)
+    oc = ol.OCsa(data)
+    n = len(data)
+
+    def check(stage):
+        for m in (1, 2, 4, 20):
+            if f"{name}/pat{m}" in g.files:
+                pats = g[f"{name}/pat{m}"]
+                assert np.array_equal(csa.count(pats, m), g[f"{name}/count{m}"]), (stage, m)
+                l, r = csa.interval(pats, m)
+                assert np.array_equal(l, g[f"{name}/ival_l{m}"]) and np.array_equal(r, g[f"{name}/ival_r{m}"]), (stage, m)
+        idx = np.arange(n + 1, dtype=np.uint64) if n < 5000 else np.random.default_rng(1).integers(0, n + 1, 5000).astype(np.uint64)
+        assert np.array_equal(np.asarray(csa.sa(idx)), np.asarray(oc.sa(idx))), stage
+        assert np.array_equal(np.asarray(csa.isa(idx)), np.asarray(oc.isa(idx))), stage
+        if n:
+            off, txt = csa.extract(np.array([0], dtype=np.uint64), np.array([n - 1], dtype=np.uint64))
+            assert bytes(np.asarray(txt)) == bytes(data), stage
+
+    check("as created")
+    blob = csa.serialize(32, 64)
+    parts = csa.footprint_parts()
+    try:
+        csa.set_footprint(csa.device_bytes() - max(1, parts["wt_binary_levels"] // 2))
+    except gpu.capi.SdslHipError as e:
+        assert e.status in (gpu.capi.ERR_UNSUPPORTED, gpu.capi.ERR_INVALID), e
+        check("after a refused set_footprint")
+        assert csa.serialize(32, 64) == blob
+        csa.close()
+        return
+    check("binary levels released")
+    p = csa.footprint_parts()
+    floor = sum(v for k, v in p.items() if k not in ("kmer_table", "suffix_array", "text", "wt_binary_levels", "sa_isa_samples", "jump_table"))
+    floor += 4 * ((n + 32) // 32 + (n + 64) // 64) + 4096
+    csa.set_footprint(floor + (1 << 16))
+    assert csa.footprint_parts()["suffix_array"] == 0
+    check("at the floor")
+    assert csa.serialize(32, 64) == blob
+    csa.restore_suffix_array()
+    check("restored")
+    csa.close()
