@@ -269,8 +269,11 @@ def test_the_references_own_fixtures_at_every_footprint(gpu, name):
     p = csa.footprint_parts()
     floor = sum(v for k, v in p.items() if k not in ("kmer_table", "suffix_array", "text", "wt_binary_levels", "sa_isa_samples", "jump_table"))
     floor += 4 * ((n + 32) // 32 + (n + 64) // 64) + 4096
+    was = csa.device_bytes()
     csa.set_footprint(floor + (1 << 16))
-    assert csa.footprint_parts()["suffix_array"] == 0
+    assert csa.device_bytes() <= floor + (1 << 16)
+    if was > floor + (1 << 16):  # (a text of 100 bytes is below any budget as it stands)
+        assert csa.footprint_parts()["suffix_array"] == 0
     check("at the floor")
     assert csa.serialize(32, 64) == blob
     csa.restore_suffix_array()
