@@ -274,8 +274,8 @@ uint64_t sdsl_hip_wt_bv_size(sdsl_hip_wt_t wt);  /* wt.bv.size() */
 uint64_t sdsl_hip_wt_device_bytes(sdsl_hip_wt_t wt);
 /* Releases SDSL's binary tree levels (rank lines + both select directories: 1.27 bits per tree bit) of a plain tree that has its
  * fused layout: rank / access / inverse_select / select keep walking the fused lines (wt_huff<> of a 1 GiB English text: 1.63 GB ->
- * 0.91 GB resident, 1.4 x the reference's stream); sdsl_hip_wt_serialize rebuilds them from the fused lines for the time of the call
- * (0.9 s per GiB, same bytes), select on a tree without the fused directory rebuilds them for good.  Nothing may be in flight on
+ * 0.91 GB resident, 1.4 x the reference's stream); sdsl_hip_wt_serialize derives the tree's bits from the fused lines into a buffer of the call
+ * (same bytes; the handle is not touched), select on a tree without the fused directory rebuilds the levels for good.  Nothing may be in flight on
  * the handle.  (sdsl_hip_fm_set_footprint does this to an FM-index's tree.) */
 sdsl_hip_status sdsl_hip_wt_release_binary_levels(sdsl_hip_wt_t wt);
 /* sum over c of count(c) * code_length(c) / size() is what bench.py needs for the roofline */
@@ -376,8 +376,8 @@ uint64_t sdsl_hip_fm_kmer_table_bytes(sdsl_hip_fm_t fm);
  * (csa_wt.hpp:389-402; 0.93 bytes per symbol for csa_wt<wt_huff<>, 32, 64> on English text); an index created from text here
  * holds the whole suffix array, the text, both tree layouts and a k-mer table on top (8.3 bytes per symbol) because that is what
  * makes count() fastest.  sdsl_hip_fm_set_footprint(fm, max_bytes) gives HBM back until sdsl_hip_fm_device_bytes(fm) <= max_bytes,
- * in the order that costs count() least per byte: (1) SDSL's binary tree levels with their select directories (rebuilt from the
- * fused lines for the time of a serialize call; select keeps the fused directory); (2) suffix array and text -> SDSL's default
+ * in the order that costs count() least per byte: (1) SDSL's binary tree levels with their select directories (a serialize call derives
+ * the tree's bits from the fused lines into a buffer of its own; select keeps the fused directory); (2) suffix array and text -> SDSL's default
  * samples SA 32 / ISA 64 (csa_wt.hpp:56), 32 bits each, the dense jump table cut to <= 4 MiB, the k-mer table rebuilt as deep as
  * the remaining budget allows.  Answers never change; csa[i] / locate / extract walk LF steps from the samples as the reference
  * does (csa_wt.hpp:363-381).  Floor: fused tree lines + samples + alphabet (about 0.9 bytes per symbol of English text, i.e.

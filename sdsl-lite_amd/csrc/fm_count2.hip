@@ -308,15 +308,17 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
     // (node, slot)'s listed places lie at or in front of the position (wt_device.hpp: quad_fsec_count)
     auto count_at = [&](const FSec & x, pos_t p, uint32_t line, uint32_t t, uint32_t step) -> pos_t {
         const uint32_t lo = quad_sum(fsec_count(x, s, (uint32_t)p & 255u, t));
-        if (!WIDE)
+        if constexpr (WIDE)
+        {
+            const uint64_t place = ((uint64_t)line << kFusedLog) + ((uint32_t)p & 255u);
+            const unsigned key = ((unsigned)T.snode[step] << 3) | t, nc = T.n_cross;
+            unsigned hi = 0;
+            for (unsigned c = 0; c < nc; ++c)
+                hi += (T.cross_key[c] == key && T.cross_pos[c] <= place) ? 1u : 0u;
+            return (pos_t)(((uint64_t)hi << 32) | lo);
+        }
+        else
             return (pos_t)lo;
-        const FmCountTabW & W = reinterpret_cast<const FmCountTabW &>(T);
-        const uint64_t place = ((uint64_t)line << kFusedLog) + ((uint32_t)p & 255u);
-        const unsigned key = ((unsigned)W.snode[step] << 3) | t, nc = W.n_cross;
-        unsigned hi = 0;
-        for (unsigned c = 0; c < nc; ++c)
-            hi += (W.cross_key[c] == key && W.cross_pos[c] <= place) ? 1u : 0u;
-        return (pos_t)(((uint64_t)hi << 32) | lo);
     };
     for (;;)
     {
@@ -441,8 +443,8 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
             else
             {
                 cb = T.cb[c];
-                if (WIDE)
-                    cb = (pos_t)((uint64_t)cb | (uint64_t)reinterpret_cast<const FmCountTabW &>(T).cbh[c] << 32);
+                if constexpr (WIDE)
+                    cb = (pos_t)((uint64_t)cb | (uint64_t)T.cbh[c] << 32);
                 a = l;
                 b = e;
                 si = meta & 0xFFFFu;

@@ -456,7 +456,7 @@ size_t sort_keys_u16_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit
 sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
                               hipStream_t s, void * tmp, size_t tmp_bytes);
 
-sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t flags)
+sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t flags, DevBuf * words_out)
 {
     const uint32_t backend = (flags & SDSL_HIP_WT_RRR63) ? 1u : 0u;
     SH_HIP(hipSetDevice(device));
@@ -554,6 +554,12 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
                       (unsigned long long)bv_size);
             return SDSL_HIP_ERR_HIP;
         }
+    }
+    if (words_out)
+    { // the caller wants the tree's bits in SDSL's word layout and nothing else (the serialiser of a tree without its binary levels)
+        wt.bv.view.n_bits = bv_size;
+        *words_out = std::move(d_words);
+        return SDSL_HIP_OK;
     }
     // 4. rank lines + select directories
     wt.bv.device = device;
@@ -1742,21 +1748,6 @@ sdsl_hip_status sdsl_hip_wt_serialize_into(sdsl_hip_wt_s * wt, int32_t layout, S
         set_error("wt_serialize: null handle or unknown layout");
         return SDSL_HIP_ERR_INVALID;
     }
-    // a tree whose binary levels were released (wt_drop_binary) gets them back for the time of the call
-    struct Redrop
-    {
-        WtHost * h = nullptr;
-        ~Redrop()
-        {
-            if (h)
-                (void)wt_drop_binary(*h);
-        }
-    } redrop;
-    if (wt->h.binary_dropped)
-    {
-        SH_TRY(wt_restore_binary(wt->h));
-        redrop.h = &wt->h;
-    }
     const WtHost & h = wt->h;
     SH_HIP(hipSetDevice(h.device));
     if (h.backend == 1)
@@ -1780,7 +1771,28 @@ sdsl_hip_status sdsl_hip_wt_serialize_into(sdsl_hip_wt_s * wt, int32_t layout, S
     const uint64_t nb = h.bv.view.n_bits, W = (nb + 63) >> 6;
     // the bit vector back in SDSL's word layout
     std::vector<uint64_t> words(W + 1, 0);
-    if (W)
+    if (W && h.binary_dropped)
+    { // a tree whose binary levels were released (wt_drop_binary): the symbols are read out of the fused lines and the level builder
+      // writes the bits of the tree's own node table — into a buffer of this call; the handle is not touched (readers may run beside it)
+        DevBuf d_sym, d;
+        SH_TRY(d_sym.alloc(h.size));
+        hipLaunchKernelGGL(k_wt_export_symbols, dim3(grid_for(h.size, kQPB, 256u * 16u)), dim3(kBlock), 0, 0, h.view(), d_sym.as<uint8_t>(),
+                           h.size);
+        SH_HIP(hipGetLastError());
+        WtHost tmp;
+        tmp.tables = h.tables;
+        tmp.n_nodes = h.n_nodes;
+        tmp.sigma = h.sigma;
+        SH_TRY(wt_build_from_device_text(tmp, d_sym.as<uint8_t>(), h.size, h.device, kWtShapeGiven, &d));
+        if (tmp.bv.view.n_bits != nb)
+        {
+            set_error("internal: the levels rebuilt from the fused lines hold %llu bits, the tree %llu", (unsigned long long)tmp.bv.view.n_bits,
+                      (unsigned long long)nb);
+            return SDSL_HIP_ERR_HIP;
+        }
+        SH_HIP(hipMemcpy(words.data(), d.p, W * 8, hipMemcpyDeviceToHost));
+    }
+    else if (W)
     {
         DevBuf d;
         SH_TRY(d.alloc(W * 8));

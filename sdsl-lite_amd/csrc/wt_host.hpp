@@ -68,7 +68,9 @@ struct WtHost
 constexpr uint32_t kWtShapeHuff8 = 0x100u; // 8-ary Huffman tree written as a binary tree (the fused layout's own shape)
 constexpr uint32_t kWtNoSelect = 0x200u;   // no select directories on the bit vector
 constexpr uint32_t kWtShapeGiven = 0x400u; // wt.tables / n_nodes / sigma are set by the caller: build the bits of THAT tree
-sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t flags = 0);
+// words_out: stop after the level builder and hand back the tree's bits as SDSL's words (no rank lines, no directories)
+sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t flags = 0,
+                                          DevBuf * words_out = nullptr);
 // Parses wt_pc::serialize output (wt_pc.hpp:713-726) and uploads; advances the reader.
 // layout: 0 = plain bv + select_support_scan (zero bytes), 1 = plain bv + select_support_mcl, 2 = rrr_vector<63> with
 // its own rank/select supports (zero bytes)
