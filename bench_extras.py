@@ -566,11 +566,12 @@ def leg_text(c):
         assert torch.equal(csa.sa(sidx), want), "sampled SA walk != whole SA"
         ex["fm_sa_access_dens32"] = {"Msa/s": sidx.numel() / ms / 1e3, "ms": ms, "queries": sidx.numel(),
                                      "roofline": pmc_roofline("fm_sa", sidx.numel(), ms), "at_dens_8_16": dense}
-        # locate on the samples: the occurrences of 10^6 patterns, every one an LF walk to the next sampled suffix (csa_wt.hpp:363-381)
-        lq6, rq6 = csa.interval(pats[: 1_000_000 * m], m)
+        # locate on the samples: the occurrences of 10^7 patterns, every one an LF walk to the next sampled suffix (csa_wt.hpp:363-381)
+        n_loc = min(nq2, 10_000_000)
+        lq6, rq6 = csa.interval(pats[: n_loc * m], m)
         off6, pos6 = csa.sa_range(lq6, rq6)
         _, ms6 = time_steps(lambda: csa.sa_range(lq6, rq6), 2, 1, barrier)
-        ex["fm_locate_dens32"] = {"Gocc/s": pos6.numel() / ms6 / 1e6, "ms": ms6, "patterns": 1_000_000, "occurrences": pos6.numel(),
+        ex["fm_locate_dens32"] = {"Gocc/s": pos6.numel() / ms6 / 1e6, "ms": ms6, "patterns": n_loc, "occurrences": pos6.numel(),
                                   "roofline": pmc_roofline("fm_locate", pos6.numel(), ms6)}
         del lq6, rq6, off6, pos6
         # count() at the footprint of csa_wt<wt_huff<>, 32, 64> plus the k-mer table: no suffix array, no text, every
