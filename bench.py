@@ -66,8 +66,9 @@ def parse():
                    help="ranks: one process per GPU (torch.distributed; --gpus N > 1 without WORLD_SIZE launches the ranks itself); "
                         "group: ONE process drives all N GPUs through the C ABI's device group (sdsl_hip_group_*: RCCL broadcast at "
                         "load time, scatter / kernels / gather per batch)")
-    p.add_argument("--extras-budget-s", type=float, default=1500.0, help="wall-clock budget of all the legs together; when it runs out the "
-                   "line is printed with what is finished and the process leaves")
+    p.add_argument("--extras-budget-s", type=float, default=None, help="wall-clock budget of all the legs together (default: 1500 s on one GPU, "
+                   "600 s on several: a collective that never completes must not hold the scaling run); when it runs out the line is printed "
+                   "with what is finished and the process leaves")
     p.add_argument("--sidecar", type=str, default=None, help="where the legs' blocks go (default: bench_extras.json next to bench.py)")
     p.add_argument("--text-file", type=str, default=None, help="a text for the wt / fm extras instead of the synthetic stand-in "
                    "(e.g. Pizza&Chili english.1GB; the first --text-mib MiB are used, zero bytes are dropped)")
@@ -386,6 +387,8 @@ def main():
     words = pkg.rnd_positions_device(42, (n_bits + 63) // 64, 0, 0, local)  # = util::set_random_bits (util.hpp:467-485)
     if a.extras is None:
         a.extras = "e2e,sweep,select,rrr,sd,shapes,wt,fm" if world == 1 else "fm_sharded"
+    if a.extras_budget_s is None:
+        a.extras_budget_s = 1500.0 if world == 1 else 600.0
     extras = [] if a.extras in ("", "none") else a.extras.split(",")
     bv = pkg.bit_vector(words, n_bits, device=local, select1="select" in extras, select0=False)
     index_bytes = bv.device_bytes()

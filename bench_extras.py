@@ -458,7 +458,19 @@ def leg_text(c):
                                 "reference_digest_match": digest_matches(out2, c4["wt_select"])
                                 if c4ok and "wt_select" in c4 and nq2 >= c4["wt_select"]["n"] else None,
                                 "roofline": pmc_roofline("wt_select", nq2, ms)}
-        del occ_c, ks, chk, wt_t
+        # the same tree at the reference's footprint: SDSL's binary levels released (sdsl_hip_wt_release_binary_levels), rank and select on
+        # the fused lines alone; bytes against the stream wt_huff<bit_vector, rank_support_v5<>, select_support_mcl<>, ...> serialises to
+        full_b = wt_t.device_bytes()
+        want_sel = out2.clone()
+        wt_stream = len(wt_t.serialize(pkg.capi.LAYOUT_BV_MCL))
+        wt_t.release_binary_levels()
+        _, ms_s = time_steps(lambda: wt_t.select(ks, gc, out2), 2, 1, barrier)
+        same_sel = bool(torch.equal(out2, want_sel))
+        _, ms_r = time_steps(lambda: wt_t.rank(gi, gc, out2), 2, 1, barrier)
+        ex["wt_huff_fused_lines_only"] = {"device_bytes": wt_t.device_bytes(), "device_bytes_with_binary_levels": full_b,
+                                          "sdsl_stream_bytes": wt_stream, "x_sdsl_stream_bytes": wt_t.device_bytes() / wt_stream,
+                                          "rank_Gq/s": nq2 / ms_r / 1e6, "select_Gq/s": nq2 / ms_s / 1e6, "select_same_answers": same_sel}
+        del occ_c, ks, chk, wt_t, want_sel
     if "fm" in c.extras:
         m = 20
         st = to_dev(pkg.rnd_positions(15, nq2, nt - m, 0), dev)  # 8(d): patterns cut at mt19937_64(15) % (n - m)
