@@ -308,10 +308,11 @@ sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, c
  * Texts of fewer than 2^32 - 2 bytes keep the whole suffix array (4 bytes per symbol), the text and the k-mer table of
  * count() on the device (sdsl_hip_fm_drop_sa releases them).  Longer texts (below 2^40 bytes; the reference switches to its
  * 64-bit sorter the same way, construct_sa.hpp:120-153) are sorted with 64-bit suffixes — 40 bytes of working memory per
- * symbol — and keep the suffix array as 8 bytes per suffix and the text, plus SA / ISA samples at csa_wt's default densities
- * 32 / 64 (csa_wt.hpp:56), which are what sdsl_hip_fm_drop_sa leaves and what sdsl_hip_fm_serialize writes (densities 32 / 64
- * only); every query is answered (rank, LF and count on the fused layout up to 2^36 symbols; select, and count's k-mer table,
- * are 32-bit structures: select walks the binary levels, count runs at about 60 % of the small index's rate). */
+ * symbol — and keep the suffix array as 8 bytes per suffix, the text and a k-mer table with 40-bit intervals (k <= 6), plus SA /
+ * ISA samples at csa_wt's default densities 32 / 64 (csa_wt.hpp:56), which are what sdsl_hip_fm_drop_sa leaves and what
+ * sdsl_hip_fm_serialize writes; every query is answered (rank, LF and count on the fused layout up to 2^36 symbols, count of
+ * large batches through the 40-bit variants of its kernels; the fused select directory is a 32-bit structure: select walks the
+ * binary levels there). */
 sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int32_t device, sdsl_hip_fm_t * out);
 sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_text, int32_t device,
                                              sdsl_hip_fm_t * out);
