@@ -56,6 +56,13 @@ def _run(cmd: list[str]) -> None:
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJDIR, exist_ok=True)
+    # SDSL_HIP_FUSED_K=3|4 in the environment builds the other form of the fused wavelet-tree lines (wt_device.hpp); the objects
+    # remember the flags they were built with
+    extra = ["-DSDSL_HIP_FUSED_K=" + os.environ["SDSL_HIP_FUSED_K"]] if os.environ.get("SDSL_HIP_FUSED_K") else []
+    extra += os.environ.get("SDSL_HIP_EXTRA_FLAGS", "").split()
+    stamp = os.path.join(OBJDIR, "flags.txt")
+    if (open(stamp).read() if os.path.exists(stamp) else "") != " ".join(extra):
+        force = True
     hdr_m = _headers_mtime()
     objs, cmds = [], []
     for src in _sources():
@@ -63,7 +70,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         objs.append(obj)
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_m)):
             continue
-        cmd = [hipcc, f"--offload-arch={ARCH}", *CXXFLAGS, "-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", *CXXFLAGS, *extra, "-x", "hip", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         cmds.append(cmd)
@@ -72,6 +79,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(cmds), os.cpu_count() or 1)) as ex:
             list(ex.map(_run, cmds))
+        with open(stamp, "w") as fh:
+            fh.write(" ".join(extra))
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB, "-Wl,-rpath,/opt/rocm/lib",
                "-Wl,--no-undefined"]

@@ -12,7 +12,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libsdsl_hip.so")
+LIB_PATH = os.environ.get("SDSL_HIP_LIB") or os.path.join(HERE, "lib", "libsdsl_hip.so")  # (SDSL_HIP_LIB: another build of the same library, tools/ab_fused.sh)
 HEADER_PATH = os.path.join(HERE, "..", "include", "sdsl_hip.h")
 
 OK = 0

@@ -272,7 +272,8 @@ struct FmCtabOf<true>
 };
 
 template <bool VERIFY, bool WIDE>
-__global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restrict__ f_lines, const typename FmCtabOf<WIDE>::type * __restrict__ tab_g,
+__global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restrict__ f_lines, const uint32_t * __restrict__ f_super,
+                                                       const uint32_t * __restrict__ f_super_hi, const typename FmCtabOf<WIDE>::type * __restrict__ tab_g,
                                                        const FmRec * __restrict__ recs, uint32_t n_rec,
                                                        uint32_t * __restrict__ ticket, const uint8_t * __restrict__ pats,
                                                        uint32_t m, uint64_t * __restrict__ out)
@@ -306,11 +307,13 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
     u32x4 nh = {0, 0, 0, 0}, nw = {0, 0, 0, 0};
     // WIDE: a count inside a node = the header's low 32 bits + the matches in the line (modulo 2^32), its high part = how many of the
     // (node, slot)'s listed places lie at or in front of the position (wt_device.hpp: quad_fsec_count)
-    auto count_at = [&](const FSec & x, pos_t p, uint32_t line, uint32_t t, uint32_t step) -> pos_t {
-        const uint32_t lo = quad_sum(fsec_count(x, s, (uint32_t)p & 255u, t));
-        if constexpr (WIDE)
+    auto count_at = [&](const FSec & x, uint32_t off, uint32_t line, uint32_t t, uint32_t step, uint64_t sup) -> pos_t {
+        const uint32_t lo = quad_sum(fsec_count(x, s, off, t));
+        if constexpr (kFK == 4)
+            return (pos_t)(sup + lo); // 16-ary lines: the superblock's count + the line's relative one
+        else if constexpr (WIDE)
         {
-            const uint64_t place = ((uint64_t)line << kFusedLog) + ((uint32_t)p & 255u);
+            const uint64_t place = ((uint64_t)line << 8) + off;
             const unsigned key = ((unsigned)T.snode[step] << 3) | t, nc = T.n_cross;
             unsigned hi = 0;
             for (unsigned c = 0; c < nc; ++c)
@@ -362,13 +365,19 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
             ++si;
             --left;
             const uint32_t base = st & 0x0FFFFFFFu, t = st >> 28;
-            const uint32_t La = base + (uint32_t)(a >> kFusedLog), Lb = base + (uint32_t)(b >> kFusedLog);
+            const uint32_t la = (uint32_t)fused_line(a), lb = (uint32_t)fused_line(b);
+            const uint32_t La = base + la, Lb = base + lb;
             const FSec xb = load_fsec<false>(f_lines, Lb, s);
             FSec xa = xb;
             if (La != Lb) // quad-uniform
                 xa = load_fsec<false>(f_lines, La, s);
-            a = count_at(xa, a, La, t, step);
-            b = count_at(xb, b, Lb, t, step);
+            const uint64_t sb = fused_super(f_super, f_super_hi, WIDE, base, Lb, t); // (16-ary lines; a cache-resident word beside the line)
+            uint64_t sa = sb;
+            if constexpr (kFK == 4)
+                if ((La >> kFSuperLog) != (Lb >> kFSuperLog))
+                    sa = fused_super(f_super, f_super_hi, WIDE, base, La, t);
+            a = count_at(xa, fused_off(a, la), La, t, step, sa);
+            b = count_at(xb, fused_off(b, lb), Lb, t, step, sb);
             if (b == 0)
             { // a <= b: both chains stay 0 (wt_pc.hpp:386)
                 a = 0;
@@ -634,12 +643,12 @@ sdsl_hip_status fm_build_count_tab(sdsl_hip_fm_s * f)
         const uint32_t first = used;
         while (left)
         {
-            const unsigned k = left < 3 ? left : 3, t = (unsigned)p & ((1u << k) - 1u);
+            const unsigned k = left < kFK ? left : kFK, t = (unsigned)p & ((1u << k) - 1u);
             if (used >= kFmMaxSteps || ft[0].fline[v] >= (1u << 28) || v >= w.n_nodes)
                 return SDSL_HIP_OK;
             C.snode[used] = (uint16_t)v;
             C.steps[used++] = ft[0].fline[v] | (t << 28);
-            for (unsigned j = 0, tt = t; j < 3; ++j, tt >>= 1)
+            for (unsigned j = 0, tt = t; j < kFK; ++j, tt >>= 1)
             { // wt_descend
                 const unsigned nv = T.child[v][tt & 1];
                 v = nv == kWtUndef ? v : nv;
@@ -818,7 +827,8 @@ sdsl_hip_status fm_count_fast(sdsl_hip_fm_s * f, const uint8_t * d_pats, uint32_
             hipLaunchKernelGGL((k_fm_start_dense<V, W>), dim3(grid_for(cnt, 256, 256u * 8u)), dim3(256), 0, s, J, f->d_tab.as<FmTables>(),
                                csa_size, pp, m, cnt, oo, recs);
         hipLaunchKernelGGL((k_fm_count_flat<V, W>), dim3(grid_for(cnt, 256, 256u * 8u)), dim3(256), 0, s, w.d_fused.as<uint64_t>(),
-                           f->d_ctab.as<typename FmCtabOf<W>::type>(), recs, cnt, ticket, pp, m, oo);
+                           w.d_fsuper.as<uint32_t>(), w.d_fsuper_hi.as<uint32_t>(), f->d_ctab.as<typename FmCtabOf<W>::type>(), recs, cnt, ticket, pp,
+                           m, oo);
         if (V)
         {
             if (W)

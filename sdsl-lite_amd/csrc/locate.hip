@@ -38,12 +38,17 @@ struct LocPlain
         wt_stage_tables(&S->T, wt.tables);
         wt_stage_fused(&S->FT, wt);
     }
-    static __device__ __forceinline__ void level(const WtView & wt, const Shared * S, int s, unsigned & v, uint64_t & i)
+    template <class I>
+    static __device__ __forceinline__ void level(const WtView & wt, const Shared * S, int s, unsigned & v, I & i)
     {
-        if (wt.f_lines) // up to three levels per step
+        if (wt.f_lines) // several levels per step
             quad_wt8_invsel_step<false>(wt, &S->T, &S->FT, s, v, i);
         else
-            quad_wt_invsel_level<false>(wt, &S->T, s, v, i);
+        {
+            uint64_t i64 = i;
+            quad_wt_invsel_level<false>(wt, &S->T, s, v, i64);
+            i = (I)i64;
+        }
     }
 };
 
@@ -62,11 +67,12 @@ struct LocRrr
         rrr_stage_tables(&S->RT, wt.rrr.tables);
         wt_stage_tables(&S->T, wt.tables);
     }
-    static __device__ __forceinline__ void level(const WtView & wt, const Shared * S, int, unsigned & v, uint64_t & i)
+    template <class I>
+    static __device__ __forceinline__ void level(const WtView & wt, const Shared * S, int, unsigned & v, I & i)
     {
         unsigned bit = 0;
         const uint64_t r = rrr_rank1(wt.rrr, &S->RT, S->T.bv_pos[v] + i, &bit) - S->T.bv_pos_rank[v];
-        i = bit ? r : i - r;
+        i = (I)(bit ? r : i - r);
         v = S->T.child[v][bit];
     }
 };
@@ -88,7 +94,9 @@ __device__ __forceinline__ void isa_sample_right(const FmLocView & L, uint64_t i
     order = loc_sample(L.isa_s, L.s32, ci);
 }
 
-template <class P, int MODE>
+// WIDE = false: an index of fewer than 2^32 symbols — positions, step counts and SA values are 32-bit in the loop (registers and
+// instructions: the walks are bound by both)
+template <class P, int MODE, bool WIDE>
 __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTables * __restrict__ ftab, FmLocView L,
                                                          const uint64_t * __restrict__ in0,
                                                          const uint64_t * __restrict__ in1,
@@ -103,7 +111,10 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
     uint64_t q = (uint64_t)blockIdx.x * kWalkers + threadIdx.x / P::kLanes;
     uint64_t a_next = q < n ? in0[q] : 0; // the walker's next argument, loaded one query ahead
     bool busy = false;
-    uint64_t j = 0, i = 0, steps = 0, taken = 0, emit_from = 0, base = 0;
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type pos_t;
+    const pos_t size = (pos_t)L.size; // (WIDE = false: size < 2^32)
+    pos_t j = 0, i = 0, steps = 0, taken = 0, emit_from = 0;
+    uint64_t base = 0;
     unsigned v = 0;
     // extract: the walk yields the text from its end, one byte per LF step at descending addresses.  Byte stores reached the fabric as
     // 52 write requests per 64-byte snippet (profiles/walk_extract_r05_pmc.md: 27 x the bytes written); the bytes are collected in a
@@ -129,11 +140,17 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
             acc_n = 0;
         }
     };
+    // "is SA index j sampled": a 64-bit division by a run-time value is some hundred instructions, paid after EVERY LF step of a csa[i]
+    // walk — more than the step's own counting; the densities of real csa_wt types are powers of two (kernel-uniform test): a mask
+    const bool sa_pow2 = (L.sa_dens & (L.sa_dens - 1)) == 0;
+    const unsigned sa_shift = (unsigned)__builtin_ctzll(L.sa_dens | (UINT64_C(1) << 63));
+    auto sa_sampled = [&](pos_t x) { return sa_pow2 ? (x & (pos_t)(L.sa_dens - 1)) == 0 : x % (pos_t)L.sa_dens == 0; };
     // between two LF steps: is the walk finished?  Then the answer is written and the walker is free again.
     auto settle = [&]() {
         bool done;
+        const bool hit = MODE == kWalkSa && sa_sampled(j);
         if (MODE == kWalkSa) // LF is one cycle of length n in a consistent index: a longer walk means a broken one
-            done = j % L.sa_dens == 0 || taken > L.size;
+            done = hit || taken > size;
         else
             done = taken == steps;
         if (!done)
@@ -145,9 +162,9 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
         if (MODE == kWalkSa)
         {
             uint64_t r = SDSL_HIP_NPOS;
-            if (j % L.sa_dens == 0)
+            if (hit)
             {
-                r = loc_sample(L.sa_s, L.s32, j / L.sa_dens) + taken; // (csa_wt.hpp:373-380)
+                r = loc_sample(L.sa_s, L.s32, sa_pow2 ? j >> sa_shift : j / (pos_t)L.sa_dens) + taken; // (csa_wt.hpp:373-380)
                 r = r < L.size ? r : r - L.size;
             }
             if (s == 0)
@@ -174,16 +191,17 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
             taken = 0;
             if (MODE == kWalkSa || MODE == kWalkLf)
             {
-                j = a;
+                j = (pos_t)a; // (a < size where it is used)
                 steps = 1;
             }
             else if (MODE == kWalkIsa)
             {
                 if (ok)
                 { // (suffix_array_helper.hpp:522-531)
-                    uint64_t pos;
-                    isa_sample_right(L, a, j, pos);
-                    steps = pos < a ? pos + L.size - a : pos - a;
+                    uint64_t pos, j64;
+                    isa_sample_right(L, a, j64, pos);
+                    j = (pos_t)j64;
+                    steps = (pos_t)(pos < a ? pos + L.size - a : pos - a);
                 }
             }
             else
@@ -192,11 +210,12 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
                 ok = ok && a <= e && e < L.size;
                 if (ok)
                 {
-                    uint64_t pos;
-                    isa_sample_right(L, e, j, pos);
-                    steps = pos <= e ? pos + L.size - e : pos - e; // P - e with P > e (position 0 taken as n)
+                    uint64_t pos, j64;
+                    isa_sample_right(L, e, j64, pos);
+                    j = (pos_t)j64;
+                    steps = (pos_t)(pos <= e ? pos + L.size - e : pos - e); // P - e with P > e (position 0 taken as n)
                     emit_from = steps;                             // the steps-th character of the walk is text[e]
-                    steps += e - a;            // ... and text[a] is the last one
+                    steps += (pos_t)(e - a);   // ... and text[a] is the last one
                     base = out_off[q] + (e - a) + emit_from; // text[P-k] goes to out_off[q] + (P-k-a) = base - k
                 }
             }
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
         if (S.T.child[v][0] == kWtUndef)
         { // leaf: the LF step is complete (suffix_array_helper.hpp:352-358)
             const unsigned c = (unsigned)S.T.bv_pos_rank[v];
-            j = S.F.C[S.F.char2comp[c]] + i;
+            j = (pos_t)S.F.C[S.F.char2comp[c]] + i;
             ++taken;
             if (MODE == kWalkExtract && taken >= emit_from)
                 emit(c, taken == steps);
@@ -438,11 +457,14 @@ static sdsl_hip_status launch_walk(sdsl_hip_fm_s * f, const uint64_t * d_in0, co
     const FmLocView L = loc_view(f);
     KernelTimer t(s);
     if (w.backend == 1)
-        hipLaunchKernelGGL((k_fm_walk<LocRrr, MODE>), dim3(grid_for(n, LocRrr::kThreads, 256u * 3u)),
+        hipLaunchKernelGGL((k_fm_walk<LocRrr, MODE, true>), dim3(grid_for(n, LocRrr::kThreads, 256u * 3u)),
                            dim3(LocRrr::kThreads), 0, s, w.view(), f->d_tab.as<FmTables>(), L, d_in0, d_in1, d_off, n,
                            d_out, d_text);
+    else if (f->size >> 32)
+        hipLaunchKernelGGL((k_fm_walk<LocPlain, MODE, true>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(LocPlain::kThreads), 0, s,
+                           w.view(), f->d_tab.as<FmTables>(), L, d_in0, d_in1, d_off, n, d_out, d_text);
     else
-        hipLaunchKernelGGL((k_fm_walk<LocPlain, MODE>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(LocPlain::kThreads), 0, s,
+        hipLaunchKernelGGL((k_fm_walk<LocPlain, MODE, false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(LocPlain::kThreads), 0, s,
                            w.view(), f->d_tab.as<FmTables>(), L, d_in0, d_in1, d_off, n, d_out, d_text);
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;

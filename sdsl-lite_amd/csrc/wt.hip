@@ -241,7 +241,8 @@ static int shape_huff8(const uint64_t occ[256], std::vector<ShapeTmp> & tmp)
         }
     if (heap.size() < 2)
         return -1;
-    while ((heap.size() - 1) % 7 != 0)
+    constexpr int ARY = (int)kFSlots; // 8 or 16 (kFK levels of the binary tree per fused step)
+    while ((heap.size() - 1) % (ARY - 1) != 0)
     {
         heap.push(Item(0, (int)nodes.size()));
         nodes.push_back(N8{0, -2, {}});
@@ -249,7 +250,7 @@ static int shape_huff8(const uint64_t occ[256], std::vector<ShapeTmp> & tmp)
     while (heap.size() > 1)
     {
         N8 in{0, -1, {}};
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < ARY; ++k)
         {
             const Item it = heap.top();
             heap.pop();
@@ -282,7 +283,7 @@ static int shape_huff8(const uint64_t occ[256], std::vector<ShapeTmp> & tmp)
         }
         if (nd.kids.size() < 2)
             ok = false;
-        if (nd.kids.size() < 8) // fewer than eight children: they must all be leaves (depth <= 3 is then enough)
+        if (nd.kids.size() < (size_t)ARY) // fewer than ARY children: they must all be leaves (depth <= kFK is then enough)
             for (int k : nd.kids)
                 if (nodes[k].sym < 0)
                     ok = false;
@@ -961,13 +962,13 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_fused(WtView wt, const uin
     FselBracket br{};
     // the fused step that takes node `cur`'s offset `res` up into the fused node above it
     auto start_group = [&]() {
-        const unsigned g = groups - 1, nlev = len - 3 * g < 3 ? len - 3 * g : 3;
-        t = (unsigned)(p >> (3 * g)) & ((1u << nlev) - 1u);
+        const unsigned g = groups - 1, nlev = len - kFK * g < kFK ? len - kFK * g : kFK;
+        t = (unsigned)(p >> (kFK * g)) & ((1u << nlev) - 1u);
         unsigned u = cur;
         for (unsigned k = 0; k < nlev; ++k)
             u = T.parent[u];
         cur = u;
-        len = 3 * g; // levels above u
+        len = kFK * g; // levels above u
         base_line = FT.fline[u];
         const unsigned rid = FS.root_id[u];
         br = fsel_bracket(wt.f_sel, FS.off[rid][t], res, FS.cnt[rid][t]);
@@ -1006,7 +1007,7 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_fused(WtView wt, const uin
             res = (uint32_t)(i - 1);
             p = T.path[c];
             len = (unsigned)(p >> 56);
-            groups = (len + 2) / 3;
+            groups = (len + kFK - 1) / kFK;
             have = true;
             start_group();
         }
@@ -1015,7 +1016,7 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_fused(WtView wt, const uin
         if (have)
         {
             uint64_t pos;
-            if (quad_fsel_probe<NT>(wt.f_lines, base_line, s, t, res, br, tries, pos))
+            if (quad_fsel_probe<NT>(wt, base_line, s, t, res, br, tries, pos))
             {
                 res = (uint32_t)pos;
                 if (--groups == 0)
@@ -1051,77 +1052,114 @@ __global__ __launch_bounds__(256) void k_wt8_planes(WtView wt, unsigned u, uint6
     wt_stage_tables(&T, wt.tables);
     const unsigned lane = threadIdx.x & 63;
     const uint64_t below = (UINT64_C(1) << lane) - 1; // lanes before this one
-    const uint64_t n_groups = (size_u + 63) >> 6;
+    // a wave takes one section of a line: kFLane consecutive positions (64, or 48 of the 16-ary form: lanes 48..63 idle)
+    const uint64_t n_groups = (size_u + kFLane - 1) / kFLane;
     const uint64_t * lines = wt.bv.lines;
     for (uint64_t g = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6; g < n_groups; g += (uint64_t)gridDim.x * 4)
     { // wave-uniform trip count
-        const uint64_t j0 = g * 64, j = j0 + lane;
-        const bool act = j < size_u;
-        const uint64_t m_act = __ballot(act);
-        unsigned b0 = 0, b1 = 0, b2 = 0;
-        // level 0: node u itself (an inner node)
-        if (act)
-            b0 = bv_bit(lines, T.bv_pos[u] + j);
-        const uint64_t m0 = __ballot(b0);
-        const uint64_t r0 = lane_rank1(lines, T.bv_pos[u] + j0, nullptr) - T.bv_pos_rank[u]; // ones before the group
-        const uint64_t start1 = b0 ? r0 : j0 - r0; // where the group's symbols of this branch start inside the child
-        const uint64_t same0 = (b0 ? m0 : ~m0) & m_act;
-        const uint64_t i1 = start1 + (uint64_t)__popcll(same0 & below);
-        const unsigned v1 = T.child[u][b0];
-        const bool in1 = act && T.child[v1][0] != kWtUndef;
-        // level 1
-        if (in1)
-            b1 = bv_bit(lines, T.bv_pos[v1] + i1);
-        const uint64_t m1 = __ballot(b1);
-        uint64_t i2 = 0;
-        unsigned v2 = v1;
-        if (in1)
+        const uint64_t j0 = g * kFLane, j = j0 + lane;
+        bool in = lane < kFLane && j < size_u; // still at an inner node
+        uint64_t same = __ballot(in);           // the lanes that took the same branches as this one
+        uint64_t start = j0, i = j;             // offset inside node v of the group's first symbol on this lane's path / of this lane's symbol
+        unsigned v = u;
+        uint64_t planes[kFK];
+#pragma unroll
+        for (unsigned k = 0; k < kFK; ++k)
         {
-            const uint64_t r1 = lane_rank1(lines, T.bv_pos[v1] + start1, nullptr) - T.bv_pos_rank[v1];
-            const uint64_t start2 = b1 ? r1 : start1 - r1;
-            const uint64_t same1 = same0 & (b1 ? m1 : ~m1);
-            i2 = start2 + (uint64_t)__popcll(same1 & below);
-            v2 = T.child[v1][b1];
+            unsigned bit = 0;
+            if (in)
+                bit = bv_bit(lines, T.bv_pos[v] + i);
+            const uint64_t m = __ballot(bit);
+            planes[k] = m;
+            if (k + 1 < kFK && in)
+            { // ones in front of the path's first symbol: the same for all lanes on this path
+                const uint64_t r = lane_rank1(lines, T.bv_pos[v] + start, nullptr) - T.bv_pos_rank[v];
+                start = bit ? r : start - r;
+                same &= bit ? m : ~m;
+                i = start + (uint64_t)__popcll(same & below);
+                v = T.child[v][bit];
+                in = T.child[v][0] != kWtUndef;
+            }
         }
-        // level 2: only the bit is needed
-        if (in1 && T.child[v2][0] != kWtUndef)
-            b2 = bv_bit(lines, T.bv_pos[v2] + i2);
-        const uint64_t m2 = __ballot(b2);
         if (lane == 0)
         {
             uint64_t * sec = fl + (g >> 2) * kFusedWords + (g & 3) * 4;
-            sec[1] = m0;
-            sec[2] = m1;
-            sec[3] = m2;
+            if constexpr (kFK == 3)
+            {
+                sec[1] = planes[0];
+                sec[2] = planes[1];
+                sec[3] = planes[2];
+            }
+            else
+            { // three words of 16 positions, a 16-bit field per plane (wt_device.hpp: fsec16_pack)
+                uint64_t pl[4] = {planes[0], planes[1], planes[2], planes[kFK - 1]};
+                sec[1] = fsec16_pack(pl, 0);
+                sec[2] = fsec16_pack(pl, 1);
+                sec[3] = fsec16_pack(pl, 2);
+            }
         }
     }
 }
 
-// counts: thread (line, t) cascades position 256 * line of node u down slot t's bits
-__global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint64_t n_lines_u, uint64_t * __restrict__ fl)
+// position i of node u taken down slot t's bits: the slot's count in front of i (ok = false: no such slot under u)
+__device__ __forceinline__ uint64_t wt8_cascade(const WtView & wt, const WtTables * T, unsigned u, uint64_t i, unsigned t, bool & ok)
+{
+    unsigned v = u;
+    ok = true;
+    for (unsigned k = 0; k < kFK; ++k)
+    {
+        if (T->child[v][0] == kWtUndef)
+        { // a leaf above the last level: its slot is the path padded with zeros
+            ok = (t >> k) == 0;
+            break;
+        }
+        const unsigned bit = (t >> k) & 1;
+        const uint64_t r = lane_rank1(wt.bv.lines, T->bv_pos[v] + i, nullptr) - T->bv_pos_rank[v];
+        i = bit ? r : i - r;
+        v = T->child[v][bit];
+    }
+    return i;
+}
+
+// counts: thread (line, t) cascades the line's first position of node u down slot t's bits.  16-ary: the header holds the count
+// relative to the first line of the line's superblock (wt_device.hpp: fused_super; superblocks are counted in absolute lines,
+// `first_line` = the node's first), whose own count the thread cascades as well and stores if the line is that one; in the superblock
+// the node starts in, the counts are the node's own.  fl = the node's first line, sup_lo / sup_hi = the whole tables.
+__global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint64_t n_lines_u, uint64_t * __restrict__ fl, uint64_t first_line,
+                                                    uint32_t * __restrict__ sup_lo, uint32_t * __restrict__ sup_hi)
 {
     const WtTables * T = wt.tables;
     // grid-stride: the launch caps its grid (2^20 blocks = 2^25 lines = 2^33 symbols per pass), a node of a 2^36-symbol sequence has more
-    for (uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x; id < n_lines_u * 8; id += (uint64_t)gridDim.x * 256)
+    for (uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x; id < n_lines_u * kFSlots; id += (uint64_t)gridDim.x * 256)
     {
-        const uint64_t line = id >> 3;
-        const unsigned t = (unsigned)id & 7u;
-        unsigned v = u;
-        uint64_t i = line << kFusedLog;
-        bool ok = true;
-        for (unsigned k = 0; k < 3; ++k)
+        const uint64_t line = id / kFSlots;
+        const unsigned t = (unsigned)id & (kFSlots - 1);
+        bool ok;
+        const uint64_t c = wt8_cascade(wt, T, u, line * kFusedPos, t, ok);
+        if constexpr (kFK == 3)
+            reinterpret_cast<uint32_t *>(fl + line * kFusedWords + 4 * (t >> 1))[t & 1] = ok ? (uint32_t)c : 0u;
+        else
         {
-            if (T->child[v][0] == kWtUndef)
-            { // a leaf above the third level: its slot is the path padded with zeros
-                ok = (t >> k) == 0;
-                break;
+            const uint64_t abs_line = first_line + line, sabs = abs_line & ~(uint64_t)((1u << kFSuperLog) - 1); // the superblock's first line
+            uint64_t cs = 0; // (the superblock the node starts in: counted from the node's start)
+            if (sabs > first_line)
+            {
+                bool ok2;
+                cs = sabs == abs_line ? c : wt8_cascade(wt, T, u, (sabs - first_line) * kFusedPos, t, ok2);
+                if (sabs == abs_line)
+                {
+                    const uint64_t at = (abs_line >> kFSuperLog) * kFSlots + t;
+                    sup_lo[at] = ok ? (uint32_t)c : 0u;
+                    if (sup_hi)
+                        sup_hi[at] = ok ? (uint32_t)(c >> 32) : 0u;
+                }
             }
-            const unsigned bit = (t >> k) & 1;
-            const uint64_t r = lane_rank1(wt.bv.lines, T->bv_pos[v] + i, nullptr) - T->bv_pos_rank[v];
-            i = bit ? r : i - r;
-            v = T->child[v][bit];
+            const uint32_t rel = ok ? (uint32_t)(c - cs) : 0u; // < 2^(16 + kFSpare)
+            uint64_t * sec = fl + line * kFusedWords + 4 * (t >> 2);
+            reinterpret_cast<uint16_t *>(sec)[t & 3] = (uint16_t)rel;
+            if (kFSpare != 0 && (rel >> 16)) // the top bits of field t & 3 of the section's third word (k_wt8_planes has written the word)
+                atomicOr(reinterpret_cast<unsigned long long *>(sec + 3), (unsigned long long)(rel >> 16) << (16 * (t & 3) + 16 - kFSpare));
         }
-        reinterpret_cast<uint32_t *>(fl + line * kFusedWords + 4 * (t >> 1))[t & 1] = ok ? (uint32_t)i : 0u;
     }
 }
 
@@ -1131,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint6
 // occurrence that completes the multiple (WtFusedTables::cross_*).
 struct FcrossArgs
 {
-    uint64_t total[8]; // occurrences of every slot in the node
+    uint64_t total[kFSlots]; // occurrences of every slot in the node
 };
 __global__ __launch_bounds__(256) void k_wt8_cross(const uint64_t * __restrict__ fl, uint64_t n_lines_u, uint32_t first_line, uint32_t u,
                                                    FcrossArgs a, uint32_t * __restrict__ n_out, uint64_t * __restrict__ pos_out,
@@ -1163,7 +1201,7 @@ __global__ __launch_bounds__(256) void k_wt8_cross(const uint64_t * __restrict__
         const uint32_t e = atomicAdd(n_out, 1u);
         if (e < kFusedMaxCross)
         {
-            pos_out[e] = (((uint64_t)first_line + line) << kFusedLog) + off;
+            pos_out[e] = (((uint64_t)first_line + line) << 8) + off; // (8-ary lines only: 256 positions)
             key_out[e] = (u << 3) | t;
         }
     }
@@ -1173,33 +1211,47 @@ __global__ __launch_bounds__(256) void k_wt8_cross(const uint64_t * __restrict__
 // neighbouring headers; if occurrence 256 * j is among them it finds its position in the line's match masks
 struct FselNodeArgs
 {
-    uint32_t cnt[8], off[8], n_samples[8];
+    uint32_t cnt[kFSlots], off[kFSlots], n_samples[kFSlots];
     uint32_t size;
 };
-__global__ __launch_bounds__(256) void k_wt8_sel_dir(const uint64_t * __restrict__ fl, uint64_t n_lines, FselNodeArgs a,
-                                                     uint32_t * __restrict__ dir)
+// the absolute count of slot t in front of line `line` of a node (fl: the node's first line, `first_line` its index, sup: the whole table)
+__device__ __forceinline__ uint32_t wt8_header_abs(const uint64_t * fl, const uint32_t * sup, uint64_t first_line, uint64_t line, unsigned t)
+{
+    if constexpr (kFK == 3)
+        return reinterpret_cast<const uint32_t *>(fl + line * kFusedWords + 4 * (t >> 1))[t & 1];
+    else
+    {
+        const uint64_t * sec = fl + line * kFusedWords + 4 * (t >> 2);
+        return (uint32_t)fused_super(sup, nullptr, false, first_line, first_line + line, t) + fsec16_count_field(sec[0], sec[3], t & 3);
+    }
+}
+// the positions of section g of a line that hold slot t
+__device__ __forceinline__ uint64_t wt8_section_match(const uint64_t * ln, unsigned g, unsigned t)
+{
+    return fsec_match_words(ln[4 * g + 1], ln[4 * g + 2], ln[4 * g + 3], t);
+}
+__global__ __launch_bounds__(256) void k_wt8_sel_dir(const uint64_t * __restrict__ fl, const uint32_t * __restrict__ sup, uint64_t first_line,
+                                                     uint64_t n_lines, FselNodeArgs a, uint32_t * __restrict__ dir)
 {
     const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t line = id >> 3;
-    const unsigned t = (unsigned)id & 7u;
+    const uint64_t line = id / kFSlots;
+    const unsigned t = (unsigned)id & (kFSlots - 1);
     if (line >= n_lines || a.off[t] == kFselNone)
         return;
     const uint64_t * ln = fl + line * kFusedWords;
-    const uint32_t c0 = reinterpret_cast<const uint32_t *>(ln + 4 * (t >> 1))[t & 1];
-    const uint32_t c1 = line + 1 < n_lines ? reinterpret_cast<const uint32_t *>(ln + kFusedWords + 4 * (t >> 1))[t & 1]
-                                          : a.cnt[t];
+    const uint32_t c0 = wt8_header_abs(fl, sup, first_line, line, t);
+    const uint32_t c1 = line + 1 < n_lines ? wt8_header_abs(fl, sup, first_line, line + 1, t) : a.cnt[t];
     constexpr uint32_t S = 1u << kFselLog;
     for (uint32_t j = (c0 + S - 1) >> kFselLog; c1 > c0 && (j << kFselLog) < c1; ++j)
     {
         uint32_t r = (j << kFselLog) - c0; // rank of the wanted occurrence inside the line
         for (unsigned g = 0; g < 4; ++g)
         {
-            const uint64_t p0 = ln[4 * g + 1], p1 = ln[4 * g + 2], p2 = ln[4 * g + 3];
-            const uint64_t m = ((t & 1) ? p0 : ~p0) & ((t & 2) ? p1 : ~p1) & ((t & 4) ? p2 : ~p2);
+            const uint64_t m = wt8_section_match(ln, g, t);
             const uint32_t c = popc64(m);
             if (r < c)
             {
-                dir[a.off[t] + j] = (uint32_t)(line << kFusedLog) + 64u * g + sel64(m, r + 1);
+                dir[a.off[t] + j] = (uint32_t)(line * kFusedPos) + kFLane * g + sel64(m, r + 1);
                 break;
             }
             r -= c;
@@ -1364,14 +1416,15 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
     std::vector<uint32_t> roots;
     for (uint32_t v : order)
     {
-        if (T.child[v][0] == kWtUndef || depth[v] % 3 != 0)
+        if (T.child[v][0] == kWtUndef || depth[v] % kFK != 0)
             continue;
         FT.fline[v] = (uint32_t)total;
-        total += (size[v] >> kFusedLog) + 1;
+        total += fused_lines_for(size[v]);
         roots.push_back(v);
     }
     if (total >= (UINT64_C(1) << 32))
         return SDSL_HIP_OK;
+    const uint64_t n_super = kFK == 4 ? (total >> kFSuperLog) + 1 : 0; // (16-ary lines: wt_device.hpp, fused_super)
     SH_HIP(hipSetDevice(wt.device));
     const bool trace = getenv("SDSL_HIP_TRACE_BUILD") != nullptr;
     auto now = [&]() {
@@ -1382,20 +1435,32 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
     const auto t0 = now();
     SH_TRY(dst.d_fused.alloc(total * kFusedWords * 8));
     SH_HIP(hipMemsetAsync(dst.d_fused.p, 0, total * kFusedWords * 8, 0));
+    if (n_super)
+    {
+        SH_TRY(dst.d_fsuper.alloc(n_super * kFSlots * 4));
+        SH_HIP(hipMemsetAsync(dst.d_fsuper.p, 0, n_super * kFSlots * 4, 0));
+        if (wt.size >> 32)
+        {
+            SH_TRY(dst.d_fsuper_hi.alloc(n_super * kFSlots * 4));
+            SH_HIP(hipMemsetAsync(dst.d_fsuper_hi.p, 0, n_super * kFSlots * 4, 0));
+        }
+    }
     const WtView view = wt.view_binary();
     uint64_t * fl = dst.d_fused.as<uint64_t>();
+    uint32_t * sup_lo = dst.d_fsuper.as<uint32_t>(), * sup_hi = dst.d_fsuper_hi.as<uint32_t>();
     const auto t1 = now();
     for (uint32_t v : roots)
     {
-        const uint64_t lines_v = (size[v] >> kFusedLog) + 1;
+        const uint64_t lines_v = fused_lines_for(size[v]);
         uint64_t * at = fl + (uint64_t)FT.fline[v] * kFusedWords;
         if (size[v])
-            hipLaunchKernelGGL(k_wt8_planes, dim3(grid_for((size[v] + 63) >> 6, 4, 256u * 8u)), dim3(256), 0, 0, view, v,
+            hipLaunchKernelGGL(k_wt8_planes, dim3(grid_for((size[v] + kFLane - 1) / kFLane, 4, 256u * 8u)), dim3(256), 0, 0, view, v,
                                size[v], at);
-        hipLaunchKernelGGL(k_wt8_counts, dim3(grid_for(lines_v * 8, 256, wt8_grid_cap())), dim3(256), 0, 0, view, v, lines_v, at);
+        hipLaunchKernelGGL(k_wt8_counts, dim3(grid_for(lines_v * kFSlots, 256, wt8_grid_cap())), dim3(256), 0, 0, view, v, lines_v, at,
+                           (uint64_t)FT.fline[v], sup_lo, sup_hi);
     }
     SH_HIP(hipGetLastError());
-    if (wt.size >> 32)
+    if (kFK == 3 && (wt.size >> 32))
     { // where the counts reach multiples of 2^32 (wt_device.hpp: WtFusedTables)
         DevBuf d_n, d_pos, d_key;
         SH_TRY(d_n.alloc(4, true));
@@ -1405,11 +1470,11 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
             if (size[v] >> 32)
             {
                 FcrossArgs ca;
-                for (unsigned t = 0; t < 8; ++t)
+                for (unsigned t = 0; t < kFSlots; ++t)
                 { // the node three levels down along t, or the leaf met earlier (then the rest of t must be zero)
                     uint32_t x = v;
                     bool ok = true;
-                    for (unsigned k = 0; k < 3; ++k)
+                    for (unsigned k = 0; k < kFK; ++k)
                     {
                         if (T.child[x][0] == kWtUndef)
                         {
@@ -1420,7 +1485,7 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
                     }
                     ca.total[t] = ok ? size[x] : 0;
                 }
-                const uint64_t lines_v = (size[v] >> kFusedLog) + 1;
+                const uint64_t lines_v = fused_lines_for(size[v]);
                 hipLaunchKernelGGL(k_wt8_cross, dim3(grid_for(lines_v * 8, 256, wt8_grid_cap())), dim3(256), 0, 0,
                                    fl + (uint64_t)FT.fline[v] * kFusedWords, lines_v, FT.fline[v], v, ca, d_n.as<uint32_t>(), d_pos.as<uint64_t>(),
                                    d_key.as<uint32_t>());
@@ -1463,11 +1528,11 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
             const uint32_t u = roots[r];
             FS.root_id[u] = (uint16_t)r;
             args[r].size = (uint32_t)size[u];
-            for (unsigned t = 0; t < 8; ++t)
-            { // the node three levels down along t, or the leaf met earlier (then the rest of t must be zero)
+            for (unsigned t = 0; t < kFSlots; ++t)
+            { // the node kFK levels down along t, or the leaf met earlier (then the rest of t must be zero)
                 uint32_t x = u;
                 bool ok = true;
-                for (unsigned k = 0; k < 3; ++k)
+                for (unsigned k = 0; k < kFK; ++k)
                 {
                     if (T.child[x][0] == kWtUndef)
                     {
@@ -1492,9 +1557,9 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
             for (size_t r = 0; r < roots.size(); ++r)
             {
                 const uint32_t u = roots[r];
-                const uint64_t lines_u = (size[u] >> kFusedLog) + 1;
-                hipLaunchKernelGGL(k_wt8_sel_dir, dim3(grid_for(lines_u * 8, 256, 1u << 20)), dim3(256), 0, 0,
-                                   fl + (uint64_t)FT.fline[u] * kFusedWords, lines_u, args[r], dst.d_fsel.as<uint32_t>());
+                const uint64_t lines_u = fused_lines_for(size[u]);
+                hipLaunchKernelGGL(k_wt8_sel_dir, dim3(grid_for(lines_u * kFSlots, 256, 1u << 20)), dim3(256), 0, 0,
+                                   fl + (uint64_t)FT.fline[u] * kFusedWords, sup_lo, (uint64_t)FT.fline[u], lines_u, args[r], dst.d_fsel.as<uint32_t>());
             }
             SH_HIP(hipGetLastError());
             SH_TRY(dst.d_fsel_tables.alloc(sizeof(WtFusedSelTables)));
@@ -1584,6 +1649,8 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         }
         wt.d_fused.release();
         wt.d_ftables.release();
+        wt.d_fsuper.release();
+        wt.d_fsuper_hi.release();
         wt.d_fsel.release();
         wt.d_fsel_tables.release();
     }
@@ -1594,6 +1661,8 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
             fprintf(stderr, "[sdsl_hip] fused layout not built: %s\n", last_error_message());
         wt.d_fused.release();
         wt.d_ftables.release();
+        wt.d_fsuper.release();
+        wt.d_fsuper_hi.release();
         wt.d_fsel.release();
         wt.d_fsel_tables.release();
         (void)hipGetLastError();
@@ -1902,7 +1971,7 @@ sdsl_hip_status sdsl_hip_wt_fused_steps(sdsl_hip_wt_t wt, uint8_t steps_out[256]
         return SDSL_HIP_ERR_INVALID;
     const WtTables & T = wt->h.d_tables_f.p ? wt->h.tables_f : wt->h.tables;
     for (int c = 0; c < 256; ++c)
-        steps_out[c] = !wt->h.d_fused.p || T.c_to_leaf[c] == kWtUndef ? 0 : (uint8_t)(((T.path[c] >> 56) + 2) / 3);
+        steps_out[c] = !wt->h.d_fused.p || T.c_to_leaf[c] == kWtUndef ? 0 : (uint8_t)(((T.path[c] >> 56) + kFK - 1) / kFK);
     return SDSL_HIP_OK;
 }
 

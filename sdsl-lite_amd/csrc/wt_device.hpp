@@ -10,6 +10,12 @@
 #ifndef SDSL_HIP_FSEL_LOG
 #define SDSL_HIP_FSEL_LOG 8
 #endif
+#ifndef SDSL_HIP_FUSED_K
+#define SDSL_HIP_FUSED_K 4 // tree levels per fused step: 4 (16 slots, 192 - 4 * spare positions per line; the default) or 3 (8 slots, 256 positions)
+#endif
+#ifndef SDSL_HIP_FUSED_SPARE
+#define SDSL_HIP_FUSED_SPARE 2 // 16-ary lines: width of the line's relative counts = 16 + spare bits (0, 2 or 4)
+#endif
 #include "bv_device.hpp"
 #include "rrr_device.hpp"
 
@@ -47,12 +53,12 @@ struct WtFusedTables // node tables of the fused layout (below); staged in LDS b
 // of every 256th occurrence of t and ends with u's size.  off[root_id[u]][t] is where the list of (u, t) starts in
 // WtView::f_sel, cnt[..][t] the number of occurrences.
 constexpr unsigned kFselLog = SDSL_HIP_FSEL_LOG; // the directory lists every 2^kFselLog-th occurrence
-constexpr int kFselMaxRoots = 80; // a balanced tree over 256 symbols has 1 + 8 + 64 = 73
+constexpr int kFselMaxRoots = SDSL_HIP_FUSED_K == 3 ? 80 : 40; // a balanced tree over 256 symbols has 1 + 8 + 64 = 73 (16-ary: 1 + 16)
 constexpr uint32_t kFselNone = 0xFFFFFFFFu;
 struct WtFusedSelTables
 {
-    uint32_t off[kFselMaxRoots][8];
-    uint32_t cnt[kFselMaxRoots][8];
+    uint32_t off[kFselMaxRoots][1u << SDSL_HIP_FUSED_K];
+    uint32_t cnt[kFselMaxRoots][1u << SDSL_HIP_FUSED_K];
     uint16_t root_id[kWtMaxNodes];
 };
 
@@ -65,8 +71,10 @@ struct WtView
     uint64_t size;  // number of symbols
     uint64_t sigma; // effective alphabet size
     uint32_t n_nodes;
-    const uint64_t * f_lines; // fused (8-ary) layout of the same tree, nullptr if not built
+    const uint64_t * f_lines; // fused (8-ary / 16-ary) layout of the same tree, nullptr if not built
     const WtFusedTables * f_tables;
+    const uint32_t * f_super;    // 16-ary lines: the counts at every 256th line (low words; [superblock][slot]), else nullptr
+    const uint32_t * f_super_hi; // their high words (sequences of 2^32 symbols and more), else nullptr
     const uint32_t * f_sel;                      // select directory of the fused layout (below), nullptr if not built
     const struct WtFusedSelTables * f_sel_tables;
 };
@@ -161,12 +169,51 @@ __device__ __forceinline__ void quad_wt_rank2_level(const WtView & wt, const WtT
 // sequence before the line (its low 32 bits: WtFusedTables lists where a count passes 2^32), plane k = bit k of the slots.
 // One fetch answers "how many of the first i symbols of u continue along slot t" = the offset inside the node three
 // levels down; the answers are those of the binary cascade, level for level.
+// The 16-ary form (SDSL_HIP_FUSED_K = 4) collapses FOUR levels: 16 slots, 192 positions per line, section s = [four 16-bit counts of
+// slots 4s .. 4s+3 | three words, word j = positions 48s + 16j .. + 15: bit k of their slots in bits 16k .. 16k+15]; the counts are relative to
+// the line's SUPERBLOCK (256 lines; every fused node starts on a superblock), whose 16 absolute counts live in WtView::f_super — a table
+// of 0.4 % of the lines that the caches hold, read beside the line.  Fewer steps per symbol (16-ary Huffman: 1.23 on the bench text against
+// 1.63) at 5.3 bits per position and step (8-ary: 4).
+constexpr unsigned kFK = SDSL_HIP_FUSED_K; // tree levels per fused step
+static_assert(kFK == 3 || kFK == 4, "SDSL_HIP_FUSED_K is 3 or 4");
+constexpr unsigned kFSlots = 1u << kFK;
+// 16-ary lines: a section's relative counts are 16 + kFSpare bits wide — the low 16 in the header word, the rest in the top bits of
+// the third word's four fields, which then hold 16 - kFSpare positions.  Wider counts reach further, so the superblocks are longer and
+// their table smaller: 1.7 MB for the 1 GiB index at 16 bits, where a fifth of its reads missed the L2 (the lines stream through it)
+// and went to the fabric after all; 0.45 MB at 18 bits.
+constexpr unsigned kFSpare = kFK == 3 ? 0u : (unsigned)SDSL_HIP_FUSED_SPARE;
+static_assert(kFSpare == 0 || kFSpare == 2 || kFSpare == 4, "SDSL_HIP_FUSED_SPARE is 0, 2 or 4");
+constexpr unsigned kFLane = kFK == 3 ? 64u : 48u - kFSpare; // positions per section (lane of the quad)
+constexpr unsigned kFusedPos = 4 * kFLane;                  // positions per line
+constexpr unsigned kFusedWords = 16;
+constexpr unsigned kFSuperLog = 8 + kFSpare; // 16-ary: lines per superblock, 2^kFSuperLog * kFusedPos < 2^(16 + kFSpare)
+static_assert(kFK == 3 || (UINT64_C(1) << kFSuperLog) * kFusedPos < (UINT64_C(1) << (16 + kFSpare)), "relative counts must fit");
+constexpr uint32_t kFWord2Mask = 0xFFFFu >> kFSpare; // the positions of a section's third word
+
+// line and offset of position i of a fused node's sequence (i < 2^38)
+__device__ __host__ __forceinline__ uint64_t fused_line(uint64_t i)
+{
+    if constexpr (kFK == 3)
+        return i >> 8;
+    else // (kFusedPos is a multiple of 8: a 32-bit division by a constant after the shift)
+        return (uint64_t)((uint32_t)(i >> 3) / (kFusedPos >> 3));
+}
+__device__ __host__ __forceinline__ unsigned fused_off(uint64_t i, uint64_t line)
+{
+    if constexpr (kFK == 3)
+        return (unsigned)i & 255u;
+    else
+        return (unsigned)i - (unsigned)line * kFusedPos;
+}
+__device__ __host__ __forceinline__ uint64_t fused_lines_for(uint64_t size) // lines of a node of `size` positions (position `size` is addressable)
+{
+    return size / kFusedPos + 1;
+}
+
 struct FSec
 {
-    uint64_t h, p0, p1, p2;
+    uint64_t h, p0, p1, p2; // header word; 8-ary: planes 0..2 of 64 positions; 16-ary: three words of 16 positions x 4 planes
 };
-constexpr unsigned kFusedLog = 8; // 256 positions per line
-constexpr unsigned kFusedWords = 16;
 
 template <bool NT>
 __device__ __forceinline__ FSec load_fsec(const uint64_t * fl, uint64_t L, int s)
@@ -174,7 +221,12 @@ __device__ __forceinline__ FSec load_fsec(const uint64_t * fl, uint64_t L, int s
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
     const v2u64 * ptr = reinterpret_cast<const v2u64 *>(fl + L * kFusedWords) + 2 * s;
     v2u64 a, b;
-    if (NT)
+#ifdef SDSL_HIP_FUSED_NT
+    constexpr bool nt = true;
+#else
+    constexpr bool nt = NT;
+#endif
+    if (nt)
     {
         a = __builtin_nontemporal_load(ptr);
         b = __builtin_nontemporal_load(ptr + 1);
@@ -192,50 +244,146 @@ __device__ __forceinline__ FSec load_fsec(const uint64_t * fl, uint64_t L, int s
     return x;
 }
 
+// 16-ary: the 16 positions of word w that hold slot t, as a 16-bit mask.  xm = fsec16_xor(t): every plane's field inverted where the
+// slot's bit is 0, so that a position matches where all four fields have a 1.
+__device__ __host__ __forceinline__ uint64_t fsec16_xor(unsigned t)
+{
+    return ((t & 1) ? 0 : UINT64_C(0xFFFF)) | ((t & 2) ? 0 : UINT64_C(0xFFFF0000)) | ((t & 4) ? 0 : UINT64_C(0xFFFF00000000)) |
+           ((t & 8) ? 0 : UINT64_C(0xFFFF000000000000));
+}
+__device__ __host__ __forceinline__ uint32_t fsec16_word_match(uint64_t w, uint64_t xm)
+{
+    const uint64_t f = w ^ xm;
+    const uint32_t g = (uint32_t)f & (uint32_t)(f >> 32); // planes 0 & 2 | planes 1 & 3 << 16
+    return g & (g >> 16) & 0xFFFFu;
+}
+// the words of a 16-ary section from its four 48-bit planes (the builder's ballots)
+__device__ __host__ __forceinline__ uint64_t fsec16_pack(const uint64_t planes[4], unsigned j)
+{
+    return ((planes[0] >> (16 * j)) & 0xFFFF) | (((planes[1] >> (16 * j)) & 0xFFFF) << 16) | (((planes[2] >> (16 * j)) & 0xFFFF) << 32) |
+           (((planes[3] >> (16 * j)) & 0xFFFF) << 48);
+}
+
+// the positions of the section that hold slot t (bit i = position i of the section's kFLane)
+__device__ __host__ __forceinline__ uint64_t fsec_match_words(uint64_t p0, uint64_t p1, uint64_t p2, unsigned t)
+{
+    if constexpr (kFK == 3)
+        return ((t & 1) ? p0 : ~p0) & ((t & 2) ? p1 : ~p1) & ((t & 4) ? p2 : ~p2);
+    else
+    {
+        const uint64_t xm = fsec16_xor(t);
+        const uint32_t lo = fsec16_word_match(p0, xm) | (fsec16_word_match(p1, xm) << 16);
+        return (uint64_t)lo | ((uint64_t)(fsec16_word_match(p2, xm) & kFWord2Mask) << 32);
+    }
+}
+__device__ __forceinline__ uint64_t fsec_match(const FSec & x, unsigned t)
+{
+    return fsec_match_words(x.p0, x.p1, x.p2, t);
+}
+
+// 16-ary: relative count k (0..3) of a section: 16 bits in the header word, kFSpare more in the top bits of field k of the third word
+__device__ __host__ __forceinline__ unsigned fsec16_count_field(uint64_t h, uint64_t w2, unsigned k)
+{
+    unsigned c = (unsigned)(h >> (16 * k)) & 0xFFFFu;
+    if constexpr (kFSpare != 0)
+        c |= ((unsigned)(w2 >> (16 * k + 16 - kFSpare)) & ((1u << kFSpare) - 1u)) << 16;
+    return c;
+}
+
+// this lane's part of the line's header count for slot t (8-ary: the low 32 bits of the absolute count; 16-ary: relative to the superblock)
+__device__ __forceinline__ unsigned fsec_header(const FSec & x, int s, unsigned t)
+{
+    if constexpr (kFK == 3)
+        return (s == (int)(t >> 1)) ? (unsigned)(x.h >> (32 * (t & 1))) : 0u;
+    else
+        return (s == (int)(t >> 2)) ? fsec16_count_field(x.h, x.p2, t & 3) : 0u;
+}
+
 // this lane's share of "slot t among the first `off` positions of the line, plus the line's count for t"
 __device__ __forceinline__ unsigned fsec_count(const FSec & x, int s, unsigned off, unsigned t)
 {
-    const uint64_t m = ((t & 1) ? x.p0 : ~x.p0) & ((t & 2) ? x.p1 : ~x.p1) & ((t & 4) ? x.p2 : ~x.p2);
-    const int tt = (int)off - 64 * s;
-    const unsigned cnt = tt <= 0 ? 0u : (tt >= 64 ? popc64(m) : popc64(m << (64 - tt)));
-    const unsigned hdr = (s == (int)(t >> 1)) ? (unsigned)(x.h >> (32 * (t & 1))) : 0u;
-    return cnt + hdr;
+    const uint64_t m = fsec_match(x, t);
+    const int tt = (int)off - (int)kFLane * s;
+    const unsigned cnt = tt <= 0 ? 0u : (tt >= (int)kFLane ? popc64(m) : popc64(m << (64 - tt)));
+    return cnt + fsec_header(x, s, t);
 }
 
-// the same summed over the quad — for every size of sequence: `u` the fused node, `abs_line` the line's index in the layout
+// 16-ary: the superblock's count for slot t (what the header of line `abs_line` is relative to); 0 on 8-ary lines.  Superblocks are
+// counted in ABSOLUTE lines (superblock = abs_line >> kFSuperLog), nodes start anywhere: a line in the superblock its node starts
+// in (`node_first` = the node's first line) counts from the node's start — base 0, nothing to read; every later superblock of the
+// node has its record.  The address does not depend on the line's content: callers issue the read beside the line's.
+__device__ __forceinline__ uint64_t fused_super(const uint32_t * f_super, const uint32_t * f_super_hi, bool wide, uint64_t node_first,
+                                                uint64_t abs_line, unsigned t)
+{
+    if constexpr (kFK == 4)
+    {
+        const uint64_t sb = abs_line >> kFSuperLog;
+        if (sb == (node_first >> kFSuperLog))
+            return 0;
+        const uint64_t idx = sb * kFSlots + t;
+        uint64_t v = f_super[idx];
+        if (wide) // kernel-uniform
+            v |= (uint64_t)f_super_hi[idx] << 32;
+        return v;
+    }
+    else
+        return 0;
+}
+__device__ __forceinline__ uint64_t fused_super(const WtView & wt, uint64_t node_first, uint64_t abs_line, unsigned t)
+{
+    return fused_super(wt.f_super, wt.f_super_hi, (wt.size >> 32) != 0, node_first, abs_line, t);
+}
+
+// the same summed over the quad — for every size of sequence: `u` the fused node, `abs_line` the line's index in the layout,
+// `sup` = fused_super(wt, abs_line, t)
 __device__ __forceinline__ uint64_t quad_fsec_count(const WtView & wt, const WtFusedTables * FT, const FSec & x, int s, unsigned off,
-                                                    unsigned t, unsigned u, uint64_t abs_line)
+                                                    unsigned t, unsigned u, uint64_t abs_line, uint64_t sup)
 {
     const unsigned lo = quad_sum(fsec_count(x, s, off, t)); // (modulo 2^32: header and in-line part may pass a multiple together)
-    if (!(wt.size >> 32)) // kernel-uniform
-        return lo;
-    const uint64_t place = (abs_line << kFusedLog) + off;
-    const unsigned key = (u << 3) | t, nc = FT->n_cross;
-    unsigned hi = 0;
-    for (unsigned e = 0; e < nc; ++e)
-        hi += (FT->cross_key[e] == key && FT->cross_pos[e] <= place) ? 1u : 0u;
-    return ((uint64_t)hi << 32) | lo;
+    if constexpr (kFK == 4)
+        return sup + lo;
+    else
+    {
+        if (!(wt.size >> 32)) // kernel-uniform
+            return lo;
+        const uint64_t place = (abs_line << 8) + off;
+        const unsigned key = (u << 3) | t, nc = FT->n_cross;
+        unsigned hi = 0;
+        for (unsigned e = 0; e < nc; ++e)
+            hi += (FT->cross_key[e] == key && FT->cross_pos[e] <= place) ? 1u : 0u;
+        return ((uint64_t)hi << 32) | lo;
+    }
 }
 
 // the slot stored at position `off` of the line (all four lanes get it)
 __device__ __forceinline__ unsigned quad_fsec_slot(const FSec & x, int s, unsigned off)
 {
     unsigned t = 0;
-    if ((int)(off >> 6) == s)
+    const int tt = (int)off - (int)kFLane * s;
+    if (tt >= 0 && tt < (int)kFLane)
     {
-        const unsigned b = off & 63;
-        t = (unsigned)((x.p0 >> b) & 1) | ((unsigned)((x.p1 >> b) & 1) << 1) | ((unsigned)((x.p2 >> b) & 1) << 2);
+        if constexpr (kFK == 3)
+            t = (unsigned)((x.p0 >> tt) & 1) | ((unsigned)((x.p1 >> tt) & 1) << 1) | ((unsigned)((x.p2 >> tt) & 1) << 2);
+        else
+        {
+            // (the word is picked by mask arithmetic: a select chain over the three words becomes an indexed access through scratch memory)
+            const unsigned jw = (unsigned)tt >> 4;
+            const uint64_t k1 = UINT64_C(0) - (uint64_t)(jw == 1), k2 = UINT64_C(0) - (uint64_t)(jw == 2);
+            const uint64_t w = (x.p0 & ~(k1 | k2)) | (x.p1 & k1) | (x.p2 & k2);
+            const uint64_t f = w >> (tt & 15);
+            t = (unsigned)(f & 1) | ((unsigned)(f >> 15) & 2u) | ((unsigned)(f >> 30) & 4u) | ((unsigned)(f >> 45) & 8u);
+        }
     }
     return quad_sum(t);
 }
 
-// follow slot t down the binary node table: three levels, or fewer when a leaf comes first (its slot pads with zeros).
+// follow slot t down the binary node table: kFK levels, or fewer when a leaf comes first (its slot pads with zeros).
 // (A precomputed [node][slot] table would save two LDS reads per step but costs 8 KiB of LDS per workgroup, and the
 // lost occupancy cost more than the reads: 28.9 -> 22.4 G wt.rank/s.)
 __device__ __forceinline__ unsigned wt_descend(const WtTables * T, unsigned v, unsigned t)
 {
 #pragma unroll
-    for (unsigned j = 0; j < 3; ++j, t >>= 1)
+    for (unsigned j = 0; j < kFK; ++j, t >>= 1)
     {
         const unsigned nv = T->child[v][t & 1];
         v = nv == kWtUndef ? v : nv;
@@ -249,18 +397,24 @@ __device__ __forceinline__ void quad_wt8_rank2_step(const WtView & wt, const WtT
                                                     unsigned & v, uint64_t & p, unsigned & left, uint64_t & a,
                                                     uint64_t & b)
 {
-    const unsigned k = left < 3 ? left : 3;
+    const unsigned k = left < kFK ? left : kFK;
     const unsigned t = (unsigned)p & ((1u << k) - 1u);
     const uint64_t base = FT->fline[v];
-    const uint64_t La = base + (a >> kFusedLog), Lb = base + (b >> kFusedLog);
+    const uint64_t la = fused_line(a), lb = fused_line(b);
+    const uint64_t La = base + la, Lb = base + lb;
     FSec xb = load_fsec<NT>(wt.f_lines, Lb, s);
     FSec xa = xb;
     if (La != Lb) // quad-uniform
         xa = load_fsec<NT>(wt.f_lines, La, s);
+    const uint64_t sb = fused_super(wt, base, Lb, t);
+    uint64_t sa = sb;
+    if constexpr (kFK == 4)
+        if ((La >> kFSuperLog) != (Lb >> kFSuperLog))
+            sa = fused_super(wt, base, La, t);
     const unsigned u = v;
     v = wt_descend(T, v, t); // LDS lookups overlap the line fetches
-    a = quad_fsec_count(wt, FT, xa, s, (unsigned)a & 255u, t, u, La);
-    b = quad_fsec_count(wt, FT, xb, s, (unsigned)b & 255u, t, u, Lb);
+    a = quad_fsec_count(wt, FT, xa, s, fused_off(a, la), t, u, La, sa);
+    b = quad_fsec_count(wt, FT, xb, s, fused_off(b, lb), t, u, Lb, sb);
     p >>= k;
     left -= k;
 }
@@ -280,13 +434,14 @@ __device__ __forceinline__ uint64_t quad_wt8_rank(const WtView & wt, const WtTab
     unsigned v = 0;
     while (left && res)
     {
-        const unsigned k = left < 3 ? left : 3;
+        const unsigned k = left < kFK ? left : kFK;
         const unsigned t = (unsigned)p & ((1u << k) - 1u);
-        const uint64_t L = FT->fline[v] + (res >> kFusedLog);
+        const uint64_t nf = FT->fline[v], li = fused_line(res), L = nf + li;
         FSec x = load_fsec<NT>(wt.f_lines, L, s);
+        const uint64_t sup = fused_super(wt, nf, L, t);
         const unsigned u = v;
         v = wt_descend(T, v, t); // LDS lookups overlap the line fetch
-        res = quad_fsec_count(wt, FT, x, s, (unsigned)res & 255u, t, u, L);
+        res = quad_fsec_count(wt, FT, x, s, fused_off(res, li), t, u, L, sup);
         p >>= k;
         left -= k;
     }
@@ -319,7 +474,7 @@ __device__ __forceinline__ FselBracket fsel_bracket(const uint32_t * dir, uint32
 
 // one probe; on a hit all four lanes get the position
 template <bool NT>
-__device__ __forceinline__ bool quad_fsel_probe(const uint64_t * f_lines, uint64_t base_line, int s, unsigned t, uint32_t k,
+__device__ __forceinline__ bool quad_fsel_probe(const WtView & wt, uint64_t base_line, int s, unsigned t, uint32_t k,
                                                 FselBracket & b, int tries, uint64_t & pos_out)
 {
     const uint32_t span = b.phi - b.plo; // > 0
@@ -332,21 +487,22 @@ __device__ __forceinline__ bool quad_fsel_probe(const uint64_t * f_lines, uint64
         const uint32_t o = (uint32_t)(f * (float)span);
         pe = b.plo + (o >= span ? span - 1 : o);
     }
-    const uint32_t g = pe >> kFusedLog;
-    const FSec x = load_fsec<NT>(f_lines, base_line + g, s);
-    const uint64_t m = ((t & 1) ? x.p0 : ~x.p0) & ((t & 2) ? x.p1 : ~x.p1) & ((t & 4) ? x.p2 : ~x.p2);
+    const uint32_t g = (uint32_t)fused_line(pe);
+    const FSec x = load_fsec<NT>(wt.f_lines, base_line + g, s);
+    const uint32_t sup = (uint32_t)fused_super(wt.f_super, nullptr, false, base_line, base_line + g, t); // (the directory holds 32-bit positions)
+    const uint64_t m = fsec_match(x, t);
     const unsigned c_lane = popc64(m);
-    const unsigned hdr = (s == (int)(t >> 1)) ? (unsigned)(x.h >> (32 * (t & 1))) : 0u;
-    const uint32_t c0 = quad_sum(hdr), c_in = quad_sum(c_lane);
+    const unsigned hdr = fsec_header(x, s, t);
+    const uint32_t c0 = sup + quad_sum(hdr), c_in = quad_sum(c_lane);
     if (k < c0)
     {
-        b.phi = g << kFusedLog;
+        b.phi = g * kFusedPos;
         b.hi_cnt = c0;
         return false;
     }
     if (k >= c0 + c_in)
     {
-        b.plo = (g + 1) << kFusedLog;
+        b.plo = (g + 1) * kFusedPos;
         b.lo_cnt = c0 + c_in;
         return false;
     }
@@ -354,7 +510,7 @@ __device__ __forceinline__ bool quad_fsel_probe(const uint64_t * f_lines, uint64
     const bool mine = r >= ex && r < ex + c_lane;
     uint64_t pos = 0;
     if (mine)
-        pos = ((uint64_t)g << kFusedLog) + 64u * (unsigned)s + sel64(m, r - ex + 1);
+        pos = (uint64_t)g * kFusedPos + kFLane * (unsigned)s + sel64(m, r - ex + 1);
     pos_out = quad_gather_u64(pos, mine);
     return true;
 }
@@ -385,16 +541,40 @@ __device__ __forceinline__ void quad_wt_rank2(const WtView & wt, const WtTables 
 }
 
 // one fused step of wt_pc::inverse_select from node v (depth 0, 3, ...) at offset i: up to three levels
-template <bool NT>
+template <bool NT, class I>
 __device__ __forceinline__ void quad_wt8_invsel_step(const WtView & wt, const WtTables * T, const WtFusedTables * FT,
-                                                     int s, unsigned & v, uint64_t & i)
+                                                     int s, unsigned & v, I & i)
 {
-    const uint64_t L = FT->fline[v] + (i >> kFusedLog);
+    const uint64_t nf = FT->fline[v], li = fused_line(i), L = nf + li;
     FSec x = load_fsec<NT>(wt.f_lines, L, s);
-    const unsigned off = (unsigned)i & 255u;
-    const unsigned t = quad_fsec_slot(x, s, off);
-    i = quad_fsec_count(wt, FT, x, s, off, t, v, L);
-    v = wt_descend(T, v, t);
+    const unsigned off = fused_off(i, li);
+    if constexpr (kFK == 4)
+    { // the slot is only known once the line has arrived: every lane fetches the superblock's counts of ITS four slots beside the
+      // line (the quad reads the whole 64-byte record, one request to the cache) and the slot's owner adds its one
+        typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+        const bool wide = (wt.size >> 32) != 0; // kernel-uniform
+        u32x4s sv = {0, 0, 0, 0};
+        if (!wide) // (read whatever the line's superblock is — the record exists — and dropped below where the node starts in it: a
+                   // load under a lane-dependent condition costs the walk its overlap with the line's)
+            sv = *reinterpret_cast<const u32x4s *>(wt.f_super + (L >> kFSuperLog) * kFSlots + 4 * s);
+        const unsigned t = quad_fsec_slot(x, s, off);
+        if (!wide)
+        {
+            const unsigned k = t & 3u;
+            const unsigned own = k == 0 ? sv.x : (k == 1 ? sv.y : (k == 2 ? sv.z : sv.w));
+            const bool use = s == (int)(t >> 2) && (L >> kFSuperLog) != (nf >> kFSuperLog); // (the node's first superblock counts from 0)
+            i = (I)quad_sum(fsec_count(x, s, off, t) + (use ? own : 0u));
+        }
+        else
+            i = (I)quad_fsec_count(wt, FT, x, s, off, t, v, L, fused_super(wt, nf, L, t));
+        v = wt_descend(T, v, t);
+    }
+    else
+    {
+        const unsigned t = quad_fsec_slot(x, s, off);
+        i = (I)quad_fsec_count(wt, FT, x, s, off, t, v, L, 0);
+        v = wt_descend(T, v, t);
+    }
 }
 
 // one level of wt_pc::inverse_select from inner node v at offset i of its slice: the bit at the position and the

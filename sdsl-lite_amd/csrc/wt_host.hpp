@@ -18,6 +18,7 @@ struct WtHost
     DevBuf d_tables;    // WtTables image in HBM
     DevBuf d_fused;     // the fused (8-ary) layout used by the rank-type traversals (wt_device.hpp), optional
     DevBuf d_ftables;   // its node tables (WtFusedTables)
+    DevBuf d_fsuper, d_fsuper_hi; // 16-ary lines: the superblocks' counts (wt_device.hpp), low / high words
     DevBuf d_tables_f;  // node table of the fused layout's OWN tree shape (8-ary Huffman written as a binary tree); empty
                         // when the fused layout was derived from the SDSL-shaped tree itself
     WtTables tables_f;  // host copy of it
@@ -32,6 +33,8 @@ struct WtHost
         WtView v = view_binary();
         v.f_lines = d_fused.as<uint64_t>();
         v.f_tables = d_ftables.as<WtFusedTables>();
+        v.f_super = d_fsuper.as<uint32_t>();
+        v.f_super_hi = d_fsuper_hi.as<uint32_t>();
         v.f_sel = d_fsel.as<uint32_t>();
         v.f_sel_tables = d_fsel_tables.as<WtFusedSelTables>();
         if (v.f_lines && d_tables_f.p)
@@ -51,13 +54,15 @@ struct WtHost
         v.n_nodes = n_nodes;
         v.f_lines = nullptr;
         v.f_tables = nullptr;
+        v.f_super = nullptr;
+        v.f_super_hi = nullptr;
         v.f_sel = nullptr;
         v.f_sel_tables = nullptr;
         return v;
     }
     size_t device_bytes() const
     {
-        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes + d_ftables.bytes + d_fsel.bytes + d_fsel_tables.bytes + d_tables_f.bytes;
+        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes + d_ftables.bytes + d_fsuper.bytes + d_fsuper_hi.bytes + d_fsel.bytes + d_fsel_tables.bytes + d_tables_f.bytes;
     }
 };
 
@@ -65,7 +70,7 @@ struct WtHost
 // stable radix sort per tree level, from a symbol sequence that already lives in device memory.
 // flags: SDSL_HIP_WT_RRR63 (bit vector as rrr_vector<63> instead of rank lines + select directories),
 // SDSL_HIP_WT_BLCD (balanced shape instead of Huffman); internal: kWtShapeHuff8, kWtNoSelect
-constexpr uint32_t kWtShapeHuff8 = 0x100u; // 8-ary Huffman tree written as a binary tree (the fused layout's own shape)
+constexpr uint32_t kWtShapeHuff8 = 0x100u; // 2^kFK-ary Huffman tree written as a binary tree (the fused layout's own shape)
 constexpr uint32_t kWtNoSelect = 0x200u;   // no select directories on the bit vector
 constexpr uint32_t kWtShapeGiven = 0x400u; // wt.tables / n_nodes / sigma are set by the caller: build the bits of THAT tree
 // words_out: stop after the level builder and hand back the tree's bits as SDSL's words (no rank lines, no directories)

@@ -149,13 +149,13 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_sorted(WtView wt, const ui
         int tries = 0;
         FselBracket br{};
         auto start_group = [&]() {
-            const unsigned g = groups - 1, nlev = len - 3 * g < 3 ? len - 3 * g : 3;
-            t = (unsigned)(p >> (3 * g)) & ((1u << nlev) - 1u);
+            const unsigned g = groups - 1, nlev = len - kFK * g < kFK ? len - kFK * g : kFK;
+            t = (unsigned)(p >> (kFK * g)) & ((1u << nlev) - 1u);
             unsigned u = cur;
             for (unsigned k = 0; k < nlev; ++k)
                 u = T.parent[u];
             cur = u;
-            len = 3 * g;
+            len = kFK * g;
             base_line = FT.fline[u];
             const unsigned rid = FS.root_id[u];
             br = fsel_bracket(wt.f_sel, FS.off[rid][t], res, FS.cnt[rid][t]);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_sorted(WtView wt, const ui
                 cur = T.c_to_leaf[c];
                 p = T.path[c];
                 len = (unsigned)(p >> 56);
-                groups = (len + 2) / 3;
+                groups = (len + kFK - 1) / kFK;
                 have = true;
                 start_group();
             }
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_sorted(WtView wt, const ui
             if (have)
             {
                 uint64_t pos;
-                if (quad_fsel_probe<false>(wt.f_lines, base_line, s, t, res, br, tries, pos))
+                if (quad_fsel_probe<false>(wt, base_line, s, t, res, br, tries, pos))
                 {
                     res = (uint32_t)pos;
                     if (--groups == 0)
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_sorted(WtView wt, const ui
 // flat loop) and the kernel was bound by exactly that: VALU share of issue 0.86, 7 of the call's 9 ms.  Inside a bucket the lines a
 // key needs are in the cache whoever fetches them, so here a lane walks its key alone: it reads the probed 128-byte line itself
 // (eight 16-byte loads), counts its four sections and finds the occurrence — about 2.4 times fewer lane-instructions per key.
-__device__ __forceinline__ bool lane_fsel_probe(const uint64_t * __restrict__ f_lines, uint64_t base_line, unsigned t, uint32_t k,
-                                                FselBracket & b, int tries, uint32_t & pos_out)
+__device__ __forceinline__ bool lane_fsel_probe(const uint64_t * __restrict__ f_lines, const uint32_t * __restrict__ f_super,
+                                                uint64_t base_line, unsigned t, uint32_t k, FselBracket & b, int tries, uint32_t & pos_out)
 {
     const uint32_t span = b.phi - b.plo; // > 0
     uint32_t pe;
@@ -228,34 +228,48 @@ __device__ __forceinline__ bool lane_fsel_probe(const uint64_t * __restrict__ f_
         const uint32_t o = (uint32_t)(f * (float)span);
         pe = b.plo + (o >= span ? span - 1 : o);
     }
-    const uint32_t g = pe >> kFusedLog;
+    const uint32_t g = (uint32_t)fused_line(pe);
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
     const v2u64 * ln = reinterpret_cast<const v2u64 *>(f_lines + (base_line + g) * kFusedWords);
     v2u64 w[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-        w[i] = ln[i]; // section s: w[2s] = (header, plane 0), w[2s + 1] = (plane 1, plane 2)
+        w[i] = ln[i]; // section s: w[2s] = (header, plane 0), w[2s + 1] = (plane 1, plane 2)  [16-ary: header, three words of 16 positions]
+    const uint32_t sup = (uint32_t)fused_super(f_super, nullptr, false, base_line, base_line + g, t);
     const uint64_t x0 = (t & 1) ? 0 : ~UINT64_C(0), x1 = (t & 2) ? 0 : ~UINT64_C(0), x2 = (t & 4) ? 0 : ~UINT64_C(0);
     uint64_t m[4];
     unsigned c[4];
 #pragma unroll
     for (int sct = 0; sct < 4; ++sct)
     {
-        m[sct] = (w[2 * sct].y ^ x0) & (w[2 * sct + 1].x ^ x1) & (w[2 * sct + 1].y ^ x2);
+        if constexpr (kFK == 3)
+            m[sct] = (w[2 * sct].y ^ x0) & (w[2 * sct + 1].x ^ x1) & (w[2 * sct + 1].y ^ x2);
+        else
+            m[sct] = fsec_match_words(w[2 * sct].y, w[2 * sct + 1].x, w[2 * sct + 1].y, t);
         c[sct] = popc64(m[sct]);
     }
-    const unsigned hs = t >> 1;
-    const uint64_t h = hs == 0 ? w[0].x : (hs == 1 ? w[2].x : (hs == 2 ? w[4].x : w[6].x));
-    const uint32_t c0 = (uint32_t)(h >> (32 * (t & 1))), c_in = c[0] + c[1] + c[2] + c[3];
+    uint32_t c0;
+    {
+        const unsigned hs = kFK == 3 ? t >> 1 : t >> 2;
+        const uint64_t h = hs == 0 ? w[0].x : (hs == 1 ? w[2].x : (hs == 2 ? w[4].x : w[6].x));
+        if constexpr (kFK == 3)
+            c0 = (uint32_t)(h >> (32 * (t & 1)));
+        else
+        {
+            const uint64_t w2 = hs == 0 ? w[1].y : (hs == 1 ? w[3].y : (hs == 2 ? w[5].y : w[7].y)); // the section's third word: the count's top bits
+            c0 = sup + fsec16_count_field(h, w2, t & 3);
+        }
+    }
+    const uint32_t c_in = c[0] + c[1] + c[2] + c[3];
     if (k < c0)
     {
-        b.phi = g << kFusedLog;
+        b.phi = g * kFusedPos;
         b.hi_cnt = c0;
         return false;
     }
     if (k >= c0 + c_in)
     {
-        b.plo = (g + 1) << kFusedLog;
+        b.plo = (g + 1) * kFusedPos;
         b.lo_cnt = c0 + c_in;
         return false;
     }
@@ -279,7 +293,7 @@ __device__ __forceinline__ bool lane_fsel_probe(const uint64_t * __restrict__ f_
             }
         }
     }
-    pos_out = (g << kFusedLog) + 64u * sct + sel64(mm, r + 1);
+    pos_out = g * kFusedPos + kFLane * sct + sel64(mm, r + 1);
     return true;
 }
 
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(THREADS) void k_wt_select_sorted_lane(WtView wt, co
                     cur = T.c_to_leaf[c];
                     p = T.path[c];
                     len = (unsigned)(p >> 56);
-                    groups = (len + 2) / 3;
+                    groups = (len + kFK - 1) / kFK;
                     have = true;
                     tries = -1; // the group below is new
                 }
@@ -401,20 +415,20 @@ __global__ __launch_bounds__(THREADS) void k_wt_select_sorted_lane(WtView wt, co
                 continue;
             if (tries < 0)
             { // start of a fused step: the node three levels up (or the root's remainder), its slot, the directory bracket
-                const unsigned gq = groups - 1, nlev = len - 3 * gq < 3 ? len - 3 * gq : 3;
-                t = (unsigned)(p >> (3 * gq)) & ((1u << nlev) - 1u);
+                const unsigned gq = groups - 1, nlev = len - kFK * gq < kFK ? len - kFK * gq : kFK;
+                t = (unsigned)(p >> (kFK * gq)) & ((1u << nlev) - 1u);
                 unsigned u = cur;
                 for (unsigned j = 0; j < nlev; ++j)
                     u = T.parent[u];
                 cur = u;
-                len = 3 * gq;
+                len = kFK * gq;
                 base_line = FT.fline[u];
                 const unsigned rid = FS.root_id[u];
                 br = fsel_bracket(wt.f_sel, FS.off[rid][t], res, FS.cnt[rid][t]);
                 tries = 0;
             }
             uint32_t pos;
-            if (lane_fsel_probe(wt.f_lines, base_line, t, res, br, tries, pos))
+            if (lane_fsel_probe(wt.f_lines, wt.f_super, base_line, t, res, br, tries, pos))
             {
                 res = pos;
                 tries = -1;
