@@ -280,9 +280,12 @@ uint64_t sdsl_hip_wt_device_bytes(sdsl_hip_wt_t wt);
 sdsl_hip_status sdsl_hip_wt_release_binary_levels(sdsl_hip_wt_t wt);
 /* sum over c of count(c) * code_length(c) / size() is what bench.py needs for the roofline */
 sdsl_hip_status sdsl_hip_wt_code_lengths(sdsl_hip_wt_t wt, uint8_t len_out[256]);
-/* fetches a rank / access / select of symbol c costs on the fused layout (its depth in the layout's own 8-ary tree);
+/* fetches a rank / access / select of symbol c costs on the fused layout (its depth in the layout's own 16-ary tree);
  * all zero when the handle has no fused layout */
 sdsl_hip_status sdsl_hip_wt_fused_steps(sdsl_hip_wt_t wt, uint8_t steps_out[256]);
+/* the form of the fused lines this library was built with: tree levels per fetch (4; 3 in a SDSL_HIP_FUSED_K=3 build), positions per
+ * 128-byte line (184; 256), lines per superblock (1024; 0 = none).  Diagnostic, for tests and the bench's traffic model. */
+void sdsl_hip_wt_fused_geometry(uint32_t * levels, uint32_t * positions_per_line, uint32_t * lines_per_superblock);
 /* out[q] = occurrences of c[q] in [0, i[q]),  i[q] in [0, size()]   (wt.rank(i,c)) */
 sdsl_hip_status sdsl_hip_wt_rank_batch(sdsl_hip_wt_t wt, const uint64_t * i, const uint8_t * c, uint64_t n,
                                        uint64_t * out, void * stream);

@@ -119,6 +119,7 @@ SIGNATURES = {
     "sdsl_hip_wt_device_bytes": (C.c_uint64, [_vp]),
     "sdsl_hip_wt_code_lengths": (C.c_int32, [_vp, _vp]),
     "sdsl_hip_wt_fused_steps": (C.c_int32, [_vp, _vp]),
+    "sdsl_hip_wt_fused_geometry": (None, [_vp, _vp, _vp]),
     "sdsl_hip_wt_release_binary_levels": (C.c_int32, [_vp]),
     "sdsl_hip_wt_rank_batch": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, _vp, _vp]),
     "sdsl_hip_wt_access_batch": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, _vp]),

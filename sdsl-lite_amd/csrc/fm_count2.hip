@@ -675,7 +675,7 @@ sdsl_hip_status fm_build_count_tab(sdsl_hip_fm_s * f)
 }
 
 // Builds the k-mer table from the resident suffix array and text.  k = the deepest depth (<= k_max <= 8) whose table — 16 bytes
-// per k-mer at a load of one half — stays within `budget_bytes`; k_max == 0 releases the table.
+// per k-mer at a load of one half, up to 0.7 where the budget is that tight — stays within `budget_bytes`; k_max == 0 releases the table.
 sdsl_hip_status fm_build_deep(sdsl_hip_fm_s * f, uint32_t k_max, uint64_t budget_bytes)
 {
     auto release = [&]() {
@@ -714,15 +714,17 @@ sdsl_hip_status fm_build_deep(sdsl_hip_fm_s * f, uint32_t k_max, uint64_t budget
     uint64_t dk[10];
     SH_HIP(hipMemcpy(dk, d_dk.p, 10 * 8, hipMemcpyDeviceToHost));
     uint32_t k = 0;
+    // a depth fits when its k-mers fill the budget's buckets to 0.7 at most (eight slots per bucket: one bucket in twenty then hands a
+    // k-mer on to its neighbour); with room to spare the table is laid out at a load of one half
     for (uint32_t t = 1; t <= k_max; ++t)
-        if (dk[t] && dk[t] * 32 <= budget_bytes)
+        if (dk[t] && dk[t] * 23 <= budget_bytes)
             k = t;
     if (getenv("SDSL_HIP_TRACE_BUILD"))
         fprintf(stderr, "[sdsl_hip] k-mer census: D1..D8 = %llu %llu %llu %llu %llu %llu %llu %llu, budget %llu MiB -> k = %u\n",
                 (unsigned long long)dk[1], (unsigned long long)dk[2], (unsigned long long)dk[3], (unsigned long long)dk[4],
                 (unsigned long long)dk[5], (unsigned long long)dk[6], (unsigned long long)dk[7], (unsigned long long)dk[8],
                 (unsigned long long)(budget_bytes >> 20), k);
-    const uint64_t nb = k ? std::max<uint64_t>(1, (dk[k] + 3) / 4) : 0; // eight slots per bucket, four taken on average
+    const uint64_t nb = k ? std::max<uint64_t>(1, std::min<uint64_t>((dk[k] + 3) / 4, budget_bytes / 128)) : 0; // eight slots per bucket, four (at most 5.6) taken on average
     if (k == 0 || nb >= (UINT64_C(1) << 32))
     { // no depth fits the budget: the caller asked for a table smaller than the smallest
         release();

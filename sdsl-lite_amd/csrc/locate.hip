@@ -38,17 +38,52 @@ struct LocPlain
         wt_stage_tables(&S->T, wt.tables);
         wt_stage_fused(&S->FT, wt);
     }
+    // one step from node v at offset i; true: a leaf is reached, c = its symbol
     template <class I>
-    static __device__ __forceinline__ void level(const WtView & wt, const Shared * S, int s, unsigned & v, I & i)
+    static __device__ __forceinline__ bool step(const WtView & wt, const Shared * S, int s, unsigned & v, I & i, unsigned & c)
     {
-        if (wt.f_lines) // several levels per step
-            quad_wt8_invsel_step<false>(wt, &S->T, &S->FT, s, v, i);
-        else
+        if (S->T.child[v][0] != kWtUndef) // (a one-symbol tree is a single leaf)
         {
-            uint64_t i64 = i;
-            quad_wt_invsel_level<false>(wt, &S->T, s, v, i64);
-            i = (I)i64;
+            if (wt.f_lines) // several levels per step
+                quad_wt8_invsel_step<false>(wt, &S->T, &S->FT, s, v, i);
+            else
+            {
+                uint64_t i64 = i;
+                quad_wt_invsel_level<false>(wt, &S->T, s, v, i64);
+                i = (I)i64;
+            }
         }
+        c = (unsigned)S->T.bv_pos_rank[v];
+        return S->T.child[v][0] == kWtUndef;
+    }
+};
+
+// the fused lines walked by fused node (wt_device.hpp: WtFusedWalk): v is the fused node's index, no binary node table in LDS
+struct LocFused
+{
+    static constexpr unsigned kLanes = kG, kThreads = kBlock;
+    struct Shared
+    {
+        WtFusedWalk W;
+        FmTables F;
+    };
+    static __device__ __forceinline__ void stage(Shared * S, const WtView & wt, const FmTables * ftab)
+    {
+        fm_stage_tables(&S->F, ftab);
+        const uint64_t * src = reinterpret_cast<const uint64_t *>(wt.f_walk);
+        uint64_t * dst = reinterpret_cast<uint64_t *>(&S->W);
+        static_assert(sizeof(WtFusedWalk) % 8 == 0, "copied in 8-byte words");
+        for (unsigned k = threadIdx.x; k < sizeof(WtFusedWalk) / 8; k += blockDim.x)
+            dst[k] = src[k];
+        __syncthreads();
+    }
+    template <class I>
+    static __device__ __forceinline__ bool step(const WtView & wt, const Shared * S, int s, unsigned & v, I & i, unsigned & c)
+    {
+        const unsigned e = quad_wtf_invsel_step<false>(wt, &S->W, s, v, i);
+        c = e & 0xFFu;
+        v = e;
+        return (e & kFWalkLeaf) != 0;
     }
 };
 
@@ -68,12 +103,17 @@ struct LocRrr
         wt_stage_tables(&S->T, wt.tables);
     }
     template <class I>
-    static __device__ __forceinline__ void level(const WtView & wt, const Shared * S, int, unsigned & v, I & i)
+    static __device__ __forceinline__ bool step(const WtView & wt, const Shared * S, int, unsigned & v, I & i, unsigned & c)
     {
-        unsigned bit = 0;
-        const uint64_t r = rrr_rank1(wt.rrr, &S->RT, S->T.bv_pos[v] + i, &bit) - S->T.bv_pos_rank[v];
-        i = (I)(bit ? r : i - r);
-        v = S->T.child[v][bit];
+        if (S->T.child[v][0] != kWtUndef)
+        {
+            unsigned bit = 0;
+            const uint64_t r = rrr_rank1(wt.rrr, &S->RT, S->T.bv_pos[v] + i, &bit) - S->T.bv_pos_rank[v];
+            i = (I)(bit ? r : i - r);
+            v = S->T.child[v][bit];
+        }
+        c = (unsigned)S->T.bv_pos_rank[v];
+        return S->T.child[v][0] == kWtUndef;
     }
 };
 
@@ -231,11 +271,9 @@ __global__ __launch_bounds__(P::kThreads) void k_fm_walk(WtView wt, const FmTabl
         }
         if (!busy)
             break; // out of queries
-        if (S.T.child[v][0] != kWtUndef) // (a one-symbol tree is a single leaf)
-            P::level(wt, &S, s, v, i);
-        if (S.T.child[v][0] == kWtUndef)
+        unsigned c;
+        if (P::step(wt, &S, s, v, i, c))
         { // leaf: the LF step is complete (suffix_array_helper.hpp:352-358)
-            const unsigned c = (unsigned)S.T.bv_pos_rank[v];
             j = (pos_t)S.F.C[S.F.char2comp[c]] + i;
             ++taken;
             if (MODE == kWalkExtract && taken >= emit_from)
@@ -460,6 +498,12 @@ static sdsl_hip_status launch_walk(sdsl_hip_fm_s * f, const uint64_t * d_in0, co
         hipLaunchKernelGGL((k_fm_walk<LocRrr, MODE, true>), dim3(grid_for(n, LocRrr::kThreads, 256u * 3u)),
                            dim3(LocRrr::kThreads), 0, s, w.view(), f->d_tab.as<FmTables>(), L, d_in0, d_in1, d_off, n,
                            d_out, d_text);
+    else if (w.d_fwalk.p && w.d_fused.p && (f->size >> 32))
+        hipLaunchKernelGGL((k_fm_walk<LocFused, MODE, true>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(LocFused::kThreads), 0, s,
+                           w.view(), f->d_tab.as<FmTables>(), L, d_in0, d_in1, d_off, n, d_out, d_text);
+    else if (w.d_fwalk.p && w.d_fused.p)
+        hipLaunchKernelGGL((k_fm_walk<LocFused, MODE, false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(LocFused::kThreads), 0, s,
+                           w.view(), f->d_tab.as<FmTables>(), L, d_in0, d_in1, d_off, n, d_out, d_text);
     else if (f->size >> 32)
         hipLaunchKernelGGL((k_fm_walk<LocPlain, MODE, true>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(LocPlain::kThreads), 0, s,
                            w.view(), f->d_tab.as<FmTables>(), L, d_in0, d_in1, d_off, n, d_out, d_text);

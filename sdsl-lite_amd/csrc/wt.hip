@@ -1513,6 +1513,40 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
     }
     SH_TRY(dst.d_ftables.alloc(sizeof(WtFusedTables)));
     SH_HIP(hipMemcpy(dst.d_ftables.p, &FT, sizeof(WtFusedTables), hipMemcpyHostToDevice));
+    // the layout by fused node (wt_device.hpp: WtFusedWalk) for the walks of inverse_select
+    if (roots.size() <= (size_t)kFselMaxRoots && (kFK == 4 || !(wt.size >> 32)))
+    {
+        std::vector<WtFusedWalk> fw_store(1);
+        WtFusedWalk & FW = fw_store[0];
+        memset(&FW, 0xFF, sizeof FW);
+        FW.n_roots = (uint32_t)roots.size();
+        std::vector<uint32_t> rid(N, 0);
+        for (size_t r = 0; r < roots.size(); ++r)
+            rid[roots[r]] = (uint32_t)r;
+        for (size_t r = 0; r < roots.size(); ++r)
+        {
+            FW.rline[r] = FT.fline[roots[r]];
+            for (unsigned t = 0; t < kFSlots; ++t)
+            { // the node kFK levels down along t, or the leaf met earlier (then the rest of t must be zero)
+                uint32_t x = roots[r];
+                bool ok = true;
+                for (unsigned k = 0; k < kFK; ++k)
+                {
+                    if (T.child[x][0] == kWtUndef)
+                    {
+                        ok = (t >> k) == 0;
+                        break;
+                    }
+                    x = T.child[x][(t >> k) & 1];
+                }
+                if (!ok)
+                    continue;
+                FW.succ[r][t] = T.child[x][0] == kWtUndef ? (uint16_t)(kFWalkLeaf | (T.bv_pos_rank[x] & 0xFF)) : (uint16_t)rid[x];
+            }
+        }
+        SH_TRY(dst.d_fwalk.alloc(sizeof(WtFusedWalk)));
+        SH_HIP(hipMemcpy(dst.d_fwalk.p, &FW, sizeof(WtFusedWalk), hipMemcpyHostToDevice));
+    }
     // select directory (skipped for trees with more fused nodes than its table holds: select then walks the binary levels)
     const char * env_sel = getenv("SDSL_HIP_WT_FUSED_SELECT"); // 0: select keeps walking the binary levels
     // (and for sequences of 2^32 symbols and more: the directory holds 32-bit positions)
@@ -1651,6 +1685,7 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         wt.d_ftables.release();
         wt.d_fsuper.release();
         wt.d_fsuper_hi.release();
+        wt.d_fwalk.release();
         wt.d_fsel.release();
         wt.d_fsel_tables.release();
     }
@@ -1663,6 +1698,7 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         wt.d_ftables.release();
         wt.d_fsuper.release();
         wt.d_fsuper_hi.release();
+        wt.d_fwalk.release();
         wt.d_fsel.release();
         wt.d_fsel_tables.release();
         (void)hipGetLastError();
@@ -1963,6 +1999,16 @@ sdsl_hip_status sdsl_hip_wt_release_binary_levels(sdsl_hip_wt_t wt)
     SH_HIP(hipSetDevice(wt->h.device));
     SH_HIP(hipDeviceSynchronize()); // nothing in flight may still read the levels
     return wt_drop_binary(wt->h);
+}
+
+void sdsl_hip_wt_fused_geometry(uint32_t * levels, uint32_t * positions_per_line, uint32_t * lines_per_superblock)
+{
+    if (levels)
+        *levels = kFK;
+    if (positions_per_line)
+        *positions_per_line = kFusedPos;
+    if (lines_per_superblock)
+        *lines_per_superblock = kFK == 4 ? 1u << kFSuperLog : 0u;
 }
 
 sdsl_hip_status sdsl_hip_wt_fused_steps(sdsl_hip_wt_t wt, uint8_t steps_out[256])

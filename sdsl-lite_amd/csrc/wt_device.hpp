@@ -62,6 +62,17 @@ struct WtFusedSelTables
     uint16_t root_id[kWtMaxNodes];
 };
 
+// The fused layout BY FUSED NODE, for the walks that only ever stand on one (inverse_select: the LF walks): first line and, per slot,
+// what comes next — the fused node below, or the symbol where the slot ends at a leaf.  One LDS read per step instead of the binary
+// node table's descent (kFK dependent reads), and 1.5 KiB of LDS instead of the node table's 13.5.
+constexpr uint16_t kFWalkLeaf = 0x8000u, kFWalkNone = 0xFFFFu;
+struct WtFusedWalk
+{
+    uint32_t n_roots, pad_;
+    uint32_t rline[kFselMaxRoots];
+    uint16_t succ[kFselMaxRoots][1u << SDSL_HIP_FUSED_K]; // next fused node | kFWalkLeaf + symbol | kFWalkNone
+};
+
 struct WtView
 {
     BvView bv;   // backend 0: the bit vector as rank lines
@@ -75,6 +86,7 @@ struct WtView
     const WtFusedTables * f_tables;
     const uint32_t * f_super;    // 16-ary lines: the counts at every 256th line (low words; [superblock][slot]), else nullptr
     const uint32_t * f_super_hi; // their high words (sequences of 2^32 symbols and more), else nullptr
+    const struct WtFusedWalk * f_walk; // the layout by fused node (nullptr: more fused nodes than the table holds, or 8-ary lines of 2^32 symbols and more)
     const uint32_t * f_sel;                      // select directory of the fused layout (below), nullptr if not built
     const struct WtFusedSelTables * f_sel_tables;
 };
@@ -575,6 +587,41 @@ __device__ __forceinline__ void quad_wt8_invsel_step(const WtView & wt, const Wt
         i = (I)quad_fsec_count(wt, FT, x, s, off, t, v, L, 0);
         v = wt_descend(T, v, t);
     }
+}
+
+// the same from fused node r by the table of fused nodes (WtFusedWalk, in LDS): returns the table's entry for the slot found at i
+template <bool NT, class I>
+__device__ __forceinline__ unsigned quad_wtf_invsel_step(const WtView & wt, const WtFusedWalk * W, int s, unsigned r, I & i)
+{
+    unsigned v = 0; // (the node tables are not touched: 16-ary lines, or 8-ary lines of fewer than 2^32 symbols)
+    const uint64_t nf = W->rline[r], li = fused_line(i), L = nf + li;
+    FSec x = load_fsec<NT>(wt.f_lines, L, s);
+    const unsigned off = fused_off(i, li);
+    unsigned t;
+    if constexpr (kFK == 4)
+    {
+        typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+        const bool wide = (wt.size >> 32) != 0; // kernel-uniform
+        u32x4s sv = {0, 0, 0, 0};
+        if (!wide)
+            sv = *reinterpret_cast<const u32x4s *>(wt.f_super + (L >> kFSuperLog) * kFSlots + 4 * s);
+        t = quad_fsec_slot(x, s, off);
+        if (!wide)
+        {
+            const unsigned k = t & 3u;
+            const unsigned own = k == 0 ? sv.x : (k == 1 ? sv.y : (k == 2 ? sv.z : sv.w));
+            const bool use = s == (int)(t >> 2) && (L >> kFSuperLog) != (nf >> kFSuperLog);
+            i = (I)quad_sum(fsec_count(x, s, off, t) + (use ? own : 0u));
+        }
+        else
+            i = (I)quad_fsec_count(wt, nullptr, x, s, off, t, v, L, fused_super(wt, nf, L, t));
+    }
+    else
+    {
+        t = quad_fsec_slot(x, s, off);
+        i = (I)quad_sum(fsec_count(x, s, off, t));
+    }
+    return W->succ[r][t];
 }
 
 // one level of wt_pc::inverse_select from inner node v at offset i of its slice: the bit at the position and the

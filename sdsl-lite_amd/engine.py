@@ -303,6 +303,13 @@ def density_bits(n_bits: int, seed: int, percent: int, checkpoints: np.ndarray |
     return w
 
 
+def fused_geometry() -> dict:
+    """the form of the fused wavelet-tree lines the library was built with (sdsl_hip_wt_fused_geometry)"""
+    lv, pp, sb = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    capi.lib().sdsl_hip_wt_fused_geometry(C.byref(lv), C.byref(pp), C.byref(sb))
+    return {"levels_per_fetch": lv.value, "positions_per_line": pp.value, "lines_per_superblock": sb.value}
+
+
 def english_text(n_bytes: int, seed: int) -> np.ndarray:
     """The English-class stand-in text of the configs[3]/[4] benchmarks (uint8, no zero byte)."""
     out = np.empty(n_bytes, dtype=np.uint8)

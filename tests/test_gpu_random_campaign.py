@@ -1,7 +1,7 @@
 """GPU: a seeded campaign of random wavelet trees / FM-indexes against the oracle.  Alphabet sizes sit around the
-boundaries of the fused layout's 8-ary tree (1 + 7k leaves fill it exactly; 8, 9, 15, 16, 57, 64, 65 ... do not), symbol
-frequencies go from uniform to steeply skewed (deep Huffman paths), lengths from a handful of symbols to a few lines of
-the fused layout — every query type on every tree."""
+boundaries of the fused layout's 16-ary tree (1 + 15k leaves fill it exactly: 16, 31, 46, 61, 241, 256; their neighbours do
+not) and of its 8-ary form (1 + 7k), symbol frequencies go from uniform to steeply skewed (deep Huffman paths), lengths
+from a handful of symbols to a few lines of the fused layout — every query type on every tree."""
 import numpy as np
 import pytest
 
@@ -10,7 +10,7 @@ import oracle_lib as ol
 pytestmark = pytest.mark.gpu
 NPOS = np.uint64(2**64 - 1)
 
-SIGMAS = [2, 3, 7, 8, 9, 15, 16, 17, 50, 57, 58, 64, 65, 128, 200, 255]
+SIGMAS = [2, 3, 7, 8, 9, 15, 16, 17, 30, 31, 32, 46, 50, 57, 58, 61, 64, 65, 128, 200, 240, 241, 242, 255]
 
 
 def _random_text(rng, sigma, n, skew):

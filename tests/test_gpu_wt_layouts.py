@@ -1,7 +1,8 @@
-"""GPU: the plain wavelet tree keeps two layouts in HBM — SDSL's binary levels (select, export) and the fused 8-ary
-layout (three levels per fetch: rank, backward search, inverse_select, LF walks).  SDSL_HIP_WT_FUSED=0 at creation time
-leaves the fused layout out, so every traversal takes the binary path; both must give the oracle's answers on the
-same inputs, for trees whose depth is not a multiple of three, with leaves at depth 1 and 2, and for every shape."""
+"""GPU: the plain wavelet tree keeps two layouts in HBM — SDSL's binary levels (select, export) and the fused 16-ary
+layout (four levels per fetch; three in a SDSL_HIP_FUSED_K=3 build: rank, backward search, inverse_select, LF walks).
+SDSL_HIP_WT_FUSED=0 at creation time leaves the fused layout out, so every traversal takes the binary path; both must give
+the oracle's answers on the same inputs, for trees whose depth is not a multiple of the fused step, with leaves at every
+depth below it, and for every shape."""
 import numpy as np
 import pytest
 
@@ -27,7 +28,7 @@ def _text(name):
 @pytest.mark.parametrize("fused", ["1", "derived_shape", "0", "no_select_directory"])
 @pytest.mark.parametrize("name", list(TEXTS))
 def test_wavelet_tree_queries_on_both_layouts(gpu, monkeypatch, name, fused):
-    """"1": fused layout with its own 8-ary Huffman shape (the default); "derived_shape": fused layout cut out of SDSL's
+    """"1": fused layout with its own 16-ary Huffman shape (the default); "derived_shape": fused layout cut out of SDSL's
     binary tree; "0": binary levels only; "no_select_directory": fused layout, select on the binary levels"""
     monkeypatch.setenv("SDSL_HIP_WT_FUSED", "0" if fused == "0" else "1")
     monkeypatch.setenv("SDSL_HIP_WT_FUSED_SELECT", "0" if fused == "no_select_directory" else "1")
@@ -102,10 +103,12 @@ def test_the_knob_decides_what_is_resident(gpu, monkeypatch):
     assert both > plain and default == both
     wt = gpu.wt_huff(text=text)
     steps, lens = wt.fused_steps(), wt.code_lengths()
-    assert np.all((steps > 0) == (lens > 0)) and np.all(steps[lens > 0] <= (lens[lens > 0] + 2) // 3 + 1)
+    k = gpu.fused_geometry()["levels_per_fetch"]
+    assert k in (3, 4)
+    assert np.all((steps > 0) == (lens > 0)) and np.all(steps[lens > 0] <= (lens[lens > 0] + k - 1) // k + 1)
     cnt = np.bincount(np.frombuffer(text, dtype=np.uint8), minlength=256)
-    # the layout's own shape is an 8-ary Huffman tree: never more expected steps than SDSL's tree cut in threes
-    assert (cnt * steps).sum() <= (cnt * ((lens.astype(np.int64) + 2) // 3)).sum()
+    # the layout's own shape is a 2^k-ary Huffman tree: never more expected steps than SDSL's tree cut into groups of k levels
+    assert (cnt * steps).sum() <= (cnt * ((lens.astype(np.int64) + k - 1) // k)).sum()
     monkeypatch.setenv("SDSL_HIP_WT_FUSED", "0")
     assert not gpu.wt_huff(text=text).fused_steps().any()
     monkeypatch.setenv("SDSL_HIP_WT_FUSED", "1")
@@ -113,6 +116,40 @@ def test_the_knob_decides_what_is_resident(gpu, monkeypatch):
     with_knob = gpu.wt_huff(text=text, rrr=True).device_bytes()
     monkeypatch.setenv("SDSL_HIP_WT_FUSED", "0")
     assert gpu.wt_huff(text=text, rrr=True).device_bytes() == with_knob
+
+
+@pytest.mark.parametrize("sigma,skew", [(3, 0.0), (20, 1.0), (200, 1.5)])
+def test_lines_superblocks_and_node_starts(gpu, sigma, skew):
+    """A sequence of several superblocks per fused node (16-ary lines: 1024 lines of 184 positions each), nodes that start in the
+    middle of a superblock, positions on both sides of every line and superblock boundary of the root and around the places where
+    the deeper nodes change superblocks: rank, inverse_select and select against prefix counts computed here."""
+    geo = gpu.fused_geometry()
+    ppl, lps = geo["positions_per_line"], max(1, geo["lines_per_superblock"])
+    rng = np.random.default_rng(sigma)
+    n = 3 * ppl * lps + 12345
+    alphabet = np.sort(rng.choice(np.arange(1, 256), size=sigma, replace=False)).astype(np.uint8)
+    w = np.arange(1, sigma + 1, dtype=np.float64) ** (-skew)
+    arr = alphabet[rng.choice(sigma, size=n, p=w / w.sum())]
+    wt = gpu.wt_huff(text=arr.tobytes())
+    edges = np.concatenate([np.arange(0, n, ppl * lps), np.arange(0, n, ppl)[:: max(1, lps // 7)], [n]])
+    i = np.unique(np.clip(np.concatenate([edges - 1, edges, edges + 1, rng.integers(0, n + 1, 20000)]), 0, n)).astype(np.uint64)
+    # prefix counts per symbol at the probed positions
+    for c in alphabet[:: max(1, sigma // 12)]:
+        pre = np.concatenate([[0], np.cumsum(arr == c)]).astype(np.uint64)
+        assert np.array_equal(wt.rank(i, np.full(i.size, c, dtype=np.uint8)), pre[i.astype(np.int64)]), int(c)
+        occ = np.flatnonzero(arr == c)
+        # select around the occurrences whose rank inside deeper nodes crosses lines / superblocks: every ppl-th and its neighbours
+        kk = np.unique(np.clip(np.concatenate([np.arange(1, occ.size + 1, ppl), np.arange(1, occ.size + 1, ppl) + 1,
+                                               np.arange(ppl, occ.size + 1, ppl * lps), [1, occ.size]]), 1, occ.size)).astype(np.uint64)
+        assert np.array_equal(wt.select(kk, np.full(kk.size, c, dtype=np.uint8)), occ[kk.astype(np.int64) - 1].astype(np.uint64)), int(c)
+    j = i[i < n]
+    r, ch = wt.inverse_select(j)
+    assert np.array_equal(ch, arr[j.astype(np.int64)])
+    order = np.argsort(arr, kind="stable")
+    rank_of = np.empty(n, dtype=np.int64)
+    first = np.searchsorted(arr[order], arr[order], side="left")
+    rank_of[order] = np.arange(n) - first
+    assert np.array_equal(r, rank_of[j.astype(np.int64)].astype(np.uint64))
 
 
 def test_loaded_streams_get_the_fused_layout_too(gpu):
