@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a streaming copy achieves
 FUSED_NOTE = ("survey_8d_model_frac prices the query as SURVEY.md 8(d) does (80 bytes per tree level: the REFERENCE's level-by-level walk); "
-              "the kernel walks the fused layout (one 128-byte line per level of its own 8-ary tree) and does not move those bytes, so that "
+              "the kernel walks the fused layout (one 128-byte line per level of its own 16-ary tree) and does not move those bytes, so that "
               "figure can exceed 1 and is no roofline fraction.  roofline_frac is: measured fabric traffic of the kernel (PMC, "
               "profiles/pmc_latest.json, when it was collected on these kernel sources) over the 8 TB/s peak, else line_fetch_frac — the "
               "lines the fused walk addresses x 128 B, an upper bound on its HBM traffic (small nodes stay in cache, the k-mer table "

@@ -418,7 +418,7 @@ def leg_text(c):
     if "wt" in c.extras:
         _, ms = time_steps(lambda: wt.rank(gi, gc, out2), max(2, a.steps // 2), 1, barrier)
         alg = 17 + 80 * hbar
-        steps = float(fsteps[gc.long()].double().mean())  # fused layout: depth in its own 8-ary tree
+        steps = float(fsteps[gc.long()].double().mean())  # fused layout: depth in its own 16-ary tree
         lf = (17 + 128 * steps) * nq2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         rf, how = fused_frac("k_wt_rank_bytes_per_query", nq2, ms, lf)
         ex["wt_huff_rank"] = {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "queries": nq2,

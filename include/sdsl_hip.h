@@ -266,15 +266,15 @@ sdsl_hip_status sdsl_hip_wt_destroy(sdsl_hip_wt_t wt);
 uint64_t sdsl_hip_wt_size(sdsl_hip_wt_t wt);     /* wt.size()  */
 uint64_t sdsl_hip_wt_sigma(sdsl_hip_wt_t wt);    /* wt.sigma   */
 uint64_t sdsl_hip_wt_bv_size(sdsl_hip_wt_t wt);  /* wt.bv.size() */
-/* HBM held by the handle.  A plain (non-rrr) tree with fewer than 2^32 symbols keeps TWO layouts: SDSL's binary levels
- * (select, writers) and a fused three-levels-per-fetch layout that rank / operator[] / inverse_select — and through
- * them backward_search, count, csa[i], isa, extract, locate — and select walk (4 bits per symbol per
- * fused level, the levels being those of an 8-ary Huffman tree of its own).  SDSL_HIP_WT_FUSED=0 in the environment at
+/* HBM held by the handle.  A plain (non-rrr) tree with fewer than 2^36 symbols keeps TWO layouts: SDSL's binary levels
+ * (select, writers) and a fused four-levels-per-fetch layout that rank / operator[] / inverse_select — and through
+ * them backward_search, count, csa[i], isa, extract, locate — and select walk (5.6 bits per symbol per
+ * fused level, the levels being those of a 16-ary Huffman tree of its own).  SDSL_HIP_WT_FUSED=0 in the environment at
  * creation time leaves it out; answers are the same. */
 uint64_t sdsl_hip_wt_device_bytes(sdsl_hip_wt_t wt);
 /* Releases SDSL's binary tree levels (rank lines + both select directories: 1.27 bits per tree bit) of a plain tree that has its
- * fused layout: rank / access / inverse_select / select keep walking the fused lines (wt_huff<> of a 1 GiB English text: 1.63 GB ->
- * 0.91 GB resident, 1.4 x the reference's stream); sdsl_hip_wt_serialize derives the tree's bits from the fused lines into a buffer of the call
+ * fused layout: rank / access / inverse_select / select keep walking the fused lines (wt_huff<> of a 1 GiB English text: 1.65 GB ->
+ * 0.94 GB resident, 1.17 x the reference's stream); sdsl_hip_wt_serialize derives the tree's bits from the fused lines into a buffer of the call
  * (same bytes; the handle is not touched), select on a tree without the fused directory rebuilds the levels for good.  Nothing may be in flight on
  * the handle.  (sdsl_hip_fm_set_footprint does this to an FM-index's tree.) */
 sdsl_hip_status sdsl_hip_wt_release_binary_levels(sdsl_hip_wt_t wt);

@@ -772,6 +772,192 @@ __global__ __launch_bounds__(kBlock) void k_wt_rank(WtView wt, const uint64_t * 
     }
 }
 
+// ---- flat loops over a batch: which query a quad takes next --------------------------------------------------------------
+// A wave works through chunks of kFlatChunkQ consecutive queries (chunk w, w + waves, ...); the quads that are out of work take the
+// chunk's next queries in quad order, so what the quads of one iteration fetch are neighbours in the argument arrays, and a line of
+// arguments is used up by the wave that first touched it.  (Handing every quad its own strided sequence reads each line of arguments
+// once per quad: 10 G/s instead of 25.)
+constexpr uint32_t kFlatChunkQ = 256;
+struct WaveChunks
+{
+    uint64_t chunk, n_chunks, step, n, cur = 0, cur_end = 0;
+    uint64_t quads_below;
+    bool drained = false;
+    __device__ __forceinline__ WaveChunks(uint64_t n_)
+    {
+        n = n_;
+        n_chunks = (n_ + kFlatChunkQ - 1) / kFlatChunkQ;
+        step = (uint64_t)gridDim.x * (blockDim.x / 64);
+        chunk = (uint64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+        const int lane = threadIdx.x & 63;
+        quads_below = UINT64_C(0x1111111111111111) & ((UINT64_C(1) << (lane & ~3)) - 1); // leaders of the quads in front
+    }
+    // quads with `wants` (quad-uniform) get the index of their next query; false: none (for now, or for good when drained)
+    __device__ __forceinline__ bool claim(bool wants, int s, uint64_t & q_out)
+    {
+        const uint64_t want = __ballot(wants && s == 0);
+        bool got = false;
+        if (want && !drained)
+        {
+            if (cur == cur_end)
+            {
+                if (chunk >= n_chunks)
+                    drained = true;
+                else
+                {
+                    cur = chunk * kFlatChunkQ;
+                    cur_end = cur + kFlatChunkQ < n ? cur + kFlatChunkQ : n;
+                    chunk += step;
+                }
+            }
+            if (!drained)
+            {
+                const uint64_t avail = cur_end - cur, rank = (uint64_t)__popcll(want & quads_below);
+                if (wants && rank < avail)
+                {
+                    q_out = cur + rank;
+                    got = true;
+                }
+                const uint64_t wanted = (uint64_t)__popcll(want);
+                cur += wanted < avail ? wanted : avail;
+            }
+        }
+        return got;
+    }
+};
+
+// rank(i, c) on the fused lines as a FLAT loop: one iteration is one fused step of whatever query the quad holds, and a quad that is
+// done takes its next query at once (its arguments fetched an iteration ahead).  Code lengths differ — the bench text: 1.23 steps on
+// average, three at most — and the loop above makes a wave wait for the longest of its sixteen; here nobody waits.  The path of c comes
+// from the per-symbol step table (wt_device.hpp: WtStepTab, 6 KiB of LDS instead of the node tables' 16).
+__global__ __launch_bounds__(kBlock) void k_wt_rank_flat(WtView wt, const uint64_t * __restrict__ iq, const uint8_t * __restrict__ cq,
+                                                         uint64_t * __restrict__ out, uint64_t n)
+{
+    __shared__ WtStepTab ST;
+    {
+        const uint64_t * src = reinterpret_cast<const uint64_t *>(wt.f_steps);
+        uint64_t * dst = reinterpret_cast<uint64_t *>(&ST);
+        for (unsigned k = threadIdx.x; k < sizeof(WtStepTab) / 8; k += blockDim.x)
+            dst[k] = src[k];
+        __syncthreads();
+    }
+    const int s = threadIdx.x & (kG - 1);
+    const bool wide = (wt.size >> 32) != 0; // kernel-uniform
+    WaveChunks wc(n);
+    bool have = false, nx = false;
+    uint64_t q = 0, res = 0, q_n = 0, i_n = 0;
+    unsigned c_n = 0;
+    uint32_t si = 0, left = 0;
+    for (;;)
+    {
+        // 1. quads without a next query claim one and request its arguments
+        if (wc.claim(!nx, s, q_n))
+        {
+            i_n = iq[q_n];
+            c_n = cq[q_n];
+            nx = true;
+        }
+        // 2. one fused step
+        if (have)
+        {
+            const uint32_t st = ST.steps[si];
+            ++si;
+            --left;
+            const uint32_t base = st & 0x0FFFFFFFu, t = st >> 28;
+            const uint64_t li = fused_line(res), L = base + li;
+            const FSec x = load_fsec<false>(wt.f_lines, L, s);
+            const uint64_t sup = fused_super(wt.f_super, wt.f_super_hi, wide, base, L, t);
+            res = sup + quad_sum(fsec_count(x, s, fused_off(res, li), t)); // (8-ary lines: fewer than 2^32 symbols here, sup = 0)
+            if (left == 0 || res == 0)
+            { // (wt_pc.hpp:386: a count of 0 stays 0)
+                if (s == 0)
+                    __builtin_nontemporal_store(res, out + q);
+                have = false;
+            }
+        }
+        // 3. a quad that is free takes the query it has requested; the ones that need no walk are answered on the spot
+        if (!have && nx)
+        {
+            nx = false;
+            q = q_n;
+            const uint32_t meta = ST.meta[c_n];
+            if (i_n <= wt.size && meta != 0 && i_n != 0)
+            {
+                res = i_n;
+                si = meta & 0xFFFFu;
+                left = meta >> 16;
+                have = true;
+            }
+            else if (s == 0) // past the end: NPOS; c does not occur (wt_pc.hpp:374-377) or nothing in front of position 0: 0
+                __builtin_nontemporal_store(i_n > wt.size ? (uint64_t)SDSL_HIP_NPOS : UINT64_C(0), out + q);
+        }
+        if (wc.drained && !__any(have || nx))
+            break;
+    }
+}
+
+// inverse_select / operator[] on the fused lines as the same flat loop, walked by fused node (wt_device.hpp: WtFusedWalk)
+template <bool WITH_RANK>
+__global__ __launch_bounds__(kBlock) void k_wt_inverse_select_flat(WtView wt, const uint64_t * __restrict__ iq, uint64_t * __restrict__ out_rank,
+                                                                   uint8_t * __restrict__ out_c, uint64_t n)
+{
+    __shared__ WtFusedWalk W;
+    {
+        const uint64_t * src = reinterpret_cast<const uint64_t *>(wt.f_walk);
+        uint64_t * dst = reinterpret_cast<uint64_t *>(&W);
+        for (unsigned k = threadIdx.x; k < sizeof(WtFusedWalk) / 8; k += blockDim.x)
+            dst[k] = src[k];
+        __syncthreads();
+    }
+    const int s = threadIdx.x & (kG - 1);
+    WaveChunks wc(n);
+    bool have = false, nx = false;
+    uint64_t q = 0, i = 0, q_n = 0, i_n = 0;
+    unsigned r = 0;
+    for (;;)
+    {
+        if (wc.claim(!nx, s, q_n))
+        {
+            i_n = iq[q_n];
+            nx = true;
+        }
+        if (have)
+        {
+            const unsigned e = quad_wtf_invsel_step<false>(wt, &W, s, r, i);
+            r = e;
+            if (e & kFWalkLeaf)
+            {
+                if (s == 0)
+                {
+                    __builtin_nontemporal_store((uint8_t)(e & 0xFFu), out_c + q);
+                    if (WITH_RANK)
+                        __builtin_nontemporal_store(i, out_rank + q);
+                }
+                have = false;
+            }
+        }
+        if (!have && nx)
+        {
+            nx = false;
+            q = q_n;
+            i = i_n;
+            if (i < wt.size)
+            {
+                r = 0;
+                have = true;
+            }
+            else if (s == 0)
+            { // outside the sequence
+                __builtin_nontemporal_store((uint8_t)0xFF, out_c + q);
+                if (WITH_RANK)
+                    __builtin_nontemporal_store((uint64_t)SDSL_HIP_NPOS, out_rank + q);
+            }
+        }
+        if (wc.drained && !__any(have || nx))
+            break;
+    }
+}
+
 // operator[] and inverse_select share one traversal
 template <bool NT, bool WITH_RANK>
 __global__ __launch_bounds__(kBlock) void k_wt_inverse_select(WtView wt, const uint64_t * __restrict__ iq,
@@ -1547,6 +1733,49 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
         SH_TRY(dst.d_fwalk.alloc(sizeof(WtFusedWalk)));
         SH_HIP(hipMemcpy(dst.d_fwalk.p, &FW, sizeof(WtFusedWalk), hipMemcpyHostToDevice));
     }
+    // the layout by symbol (wt_device.hpp: WtStepTab) for rank(i, c)
+    if (kFK == 4 || !(wt.size >> 32))
+    {
+        std::vector<WtStepTab> st_store(1);
+        WtStepTab & ST = st_store[0];
+        memset(&ST, 0, sizeof ST);
+        uint32_t used = 0;
+        bool fits = true;
+        for (unsigned c = 0; c < 256 && fits; ++c)
+        {
+            if (T.c_to_leaf[c] == kWtUndef)
+                continue;
+            uint64_t p = T.path[c];
+            unsigned left = (unsigned)(p >> 56), v = 0, steps = 0;
+            const uint32_t first = used;
+            while (left && fits)
+            {
+                const unsigned k = left < kFK ? left : kFK, t = (unsigned)p & ((1u << k) - 1u);
+                if (used >= kWtMaxSteps || FT.fline[v] >= (1u << 28))
+                {
+                    fits = false;
+                    break;
+                }
+                ST.steps[used++] = FT.fline[v] | (t << 28);
+                for (unsigned j = 0, tt = t; j < kFK; ++j, tt >>= 1)
+                { // wt_descend
+                    const unsigned nv = T.child[v][tt & 1];
+                    v = nv == kWtUndef ? v : nv;
+                }
+                p >>= k;
+                left -= k;
+                ++steps;
+            }
+            if (steps == 0 || steps > 255)
+                fits = false;
+            ST.meta[c] = first | (steps << 16);
+        }
+        if (fits)
+        {
+            SH_TRY(dst.d_fsteps.alloc(sizeof(WtStepTab)));
+            SH_HIP(hipMemcpy(dst.d_fsteps.p, &ST, sizeof(WtStepTab), hipMemcpyHostToDevice));
+        }
+    }
     // select directory (skipped for trees with more fused nodes than its table holds: select then walks the binary levels)
     const char * env_sel = getenv("SDSL_HIP_WT_FUSED_SELECT"); // 0: select keeps walking the binary levels
     // (and for sequences of 2^32 symbols and more: the directory holds 32-bit positions)
@@ -1686,6 +1915,7 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         wt.d_fsuper.release();
         wt.d_fsuper_hi.release();
         wt.d_fwalk.release();
+        wt.d_fsteps.release();
         wt.d_fsel.release();
         wt.d_fsel_tables.release();
     }
@@ -1699,6 +1929,7 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         wt.d_fsuper.release();
         wt.d_fsuper_hi.release();
         wt.d_fwalk.release();
+        wt.d_fsteps.release();
         wt.d_fsel.release();
         wt.d_fsel_tables.release();
         (void)hipGetLastError();
@@ -1717,7 +1948,11 @@ sdsl_hip_status wt_launch_rank(const WtHost & wt, const uint64_t * d_i, const ui
     if (n == 0)
         return SDSL_HIP_OK;
     KernelTimer t(s);
-    hipLaunchKernelGGL((k_wt_rank<false>), dim3(wt_grid(n)), dim3(kBlock), 0, s, wt.view(), d_i, d_c, d_out, n);
+    static const bool flat = !(getenv("SDSL_HIP_WT_RANK_FLAT") && atoi(getenv("SDSL_HIP_WT_RANK_FLAT")) == 0);
+    if (wt.d_fused.p && wt.d_fsteps.p && wt.sigma >= 2 && flat)
+        hipLaunchKernelGGL(k_wt_rank_flat, dim3(wt_grid(n)), dim3(kBlock), 0, s, wt.view(), d_i, d_c, d_out, n);
+    else
+        hipLaunchKernelGGL((k_wt_rank<false>), dim3(wt_grid(n)), dim3(kBlock), 0, s, wt.view(), d_i, d_c, d_out, n);
     SH_HIP(hipGetLastError());
     return SDSL_HIP_OK;
 }
@@ -2092,7 +2327,17 @@ sdsl_hip_status sdsl_hip_wt_inverse_select_batch(sdsl_hip_wt_t wt, const uint64_
     {
         KernelTimer t(s);
         unsigned grid = grid_for(n, kQPB, 256u * 8u);
-        if (out_rank)
+        static const bool flat = !(getenv("SDSL_HIP_WT_RANK_FLAT") && atoi(getenv("SDSL_HIP_WT_RANK_FLAT")) == 0);
+        if (wt->h.d_fused.p && wt->h.d_fwalk.p && wt->h.sigma >= 2 && flat)
+        {
+            if (out_rank)
+                hipLaunchKernelGGL(k_wt_inverse_select_flat<true>, dim3(grid), dim3(kBlock), 0, s, wt->h.view(), (const uint64_t *)si.dev,
+                                   (uint64_t *)sr.dev, (uint8_t *)sc.dev, n);
+            else
+                hipLaunchKernelGGL(k_wt_inverse_select_flat<false>, dim3(grid), dim3(kBlock), 0, s, wt->h.view(), (const uint64_t *)si.dev,
+                                   (uint64_t *)nullptr, (uint8_t *)sc.dev, n);
+        }
+        else if (out_rank)
             hipLaunchKernelGGL((k_wt_inverse_select<false, true>), dim3(grid), dim3(kBlock), 0, s, wt->h.view(),
                                (const uint64_t *)si.dev, (uint64_t *)sr.dev, (uint8_t *)sc.dev, n);
         else

@@ -73,6 +73,16 @@ struct WtFusedWalk
     uint16_t succ[kFselMaxRoots][1u << SDSL_HIP_FUSED_K]; // next fused node | kFWalkLeaf + symbol | kFWalkNone
 };
 
+// The fused layout BY SYMBOL, for rank(i, c): the steps of c's path spelled out as (first line of the fused node, slot) — what the flat
+// count kernel keeps per byte (fm_device.hpp: FmCountTab), without the FM-index's C[].  meta[c] = first step | steps << 16 (0: c does
+// not occur), steps[] = first line (28 bits) | slot << 28.
+constexpr unsigned kWtMaxSteps = 1280;
+struct WtStepTab
+{
+    uint32_t meta[256];
+    uint32_t steps[kWtMaxSteps];
+};
+
 struct WtView
 {
     BvView bv;   // backend 0: the bit vector as rank lines
@@ -86,6 +96,7 @@ struct WtView
     const WtFusedTables * f_tables;
     const uint32_t * f_super;    // 16-ary lines: the counts at every 256th line (low words; [superblock][slot]), else nullptr
     const uint32_t * f_super_hi; // their high words (sequences of 2^32 symbols and more), else nullptr
+    const struct WtStepTab * f_steps;  // the layout by symbol (nullptr: paths longer than the table, or 8-ary lines of 2^32 symbols and more)
     const struct WtFusedWalk * f_walk; // the layout by fused node (nullptr: more fused nodes than the table holds, or 8-ary lines of 2^32 symbols and more)
     const uint32_t * f_sel;                      // select directory of the fused layout (below), nullptr if not built
     const struct WtFusedSelTables * f_sel_tables;
@@ -171,21 +182,23 @@ __device__ __forceinline__ void quad_wt_rank2_level(const WtView & wt, const WtT
     v = T->child[v][bit];
 }
 
-// ---- fused layout: three tree levels per memory access -----------------------------------------
+// ---- fused layout: several tree levels per memory access ----------------------------------------
 // A rank cascade is a chain of DEPENDENT random line fetches, one per tree level, and the fetch rate is what bounds it
-// (DESIGN.md §3.1).  The fused layout stores the same tree a second time with three binary levels collapsed into one
-// 8-ary level: every node u at depth 0, 3, 6, ... owns the sequence of the symbols routed through it (the order of its
-// slice of the binary tree), each symbol reduced to a 3-bit SLOT = its next three path bits (a leaf reached earlier
-// pads with zeros).  128-byte line = 4 sections of 32 bytes; section s = [count[2s] | count[2s+1] << 32, plane 0,
-// plane 1, plane 2] for positions 64s .. 64s+63 of the line's 256: count[t] = occurrences of slot t in the node's
-// sequence before the line (its low 32 bits: WtFusedTables lists where a count passes 2^32), plane k = bit k of the slots.
-// One fetch answers "how many of the first i symbols of u continue along slot t" = the offset inside the node three
-// levels down; the answers are those of the binary cascade, level for level.
-// The 16-ary form (SDSL_HIP_FUSED_K = 4) collapses FOUR levels: 16 slots, 192 positions per line, section s = [four 16-bit counts of
-// slots 4s .. 4s+3 | three words, word j = positions 48s + 16j .. + 15: bit k of their slots in bits 16k .. 16k+15]; the counts are relative to
-// the line's SUPERBLOCK (256 lines; every fused node starts on a superblock), whose 16 absolute counts live in WtView::f_super — a table
-// of 0.4 % of the lines that the caches hold, read beside the line.  Fewer steps per symbol (16-ary Huffman: 1.23 on the bench text against
-// 1.63) at 5.3 bits per position and step (8-ary: 4).
+// (DESIGN.md §3.1).  The fused layout stores the same tree a second time with kFK binary levels collapsed into one
+// 2^kFK-ary level: every node u at depth 0, kFK, 2 kFK, ... owns the sequence of the symbols routed through it (the order of its
+// slice of the binary tree), each symbol reduced to a SLOT = its next kFK path bits (a leaf reached earlier pads with zeros).
+// One fetch answers "how many of the first i symbols of u continue along slot t" = the offset inside the node kFK levels down;
+// the answers are those of the binary cascade, level for level.
+//
+// The 16-ary form (SDSL_HIP_FUSED_K = 4, the default): 16 slots, 128-byte line = 4 sections of 32 bytes, one per lane of the quad;
+// section s = [four 16-bit counts of slots 4s .. 4s+3 | three words, word j = positions 16j .. 16j+15 of the section: bit k of their
+// slots in bits 16k .. 16k+15].  The counts are relative to the line's SUPERBLOCK (2^kFSuperLog lines), whose 16 absolute counts live
+// in WtView::f_super — a table of 0.05 % of the lines that the caches hold, read beside the line.  16-ary Huffman: 1.23 steps per symbol
+// of the bench text against the 8-ary tree's 1.63, at 5.6 bits per position and step against 4.
+//
+// The 8-ary form (SDSL_HIP_FUSED_K = 3; rounds 2-5): section s = [count[2s] | count[2s+1] << 32, plane 0, plane 1, plane 2] for
+// positions 64s .. 64s+63 of the line's 256: count[t] = occurrences of slot t in the node's sequence before the line (its low 32
+// bits: WtFusedTables lists where a count passes 2^32), plane k = bit k of the slots.
 constexpr unsigned kFK = SDSL_HIP_FUSED_K; // tree levels per fused step
 static_assert(kFK == 3 || kFK == 4, "SDSL_HIP_FUSED_K is 3 or 4");
 constexpr unsigned kFSlots = 1u << kFK;
@@ -233,12 +246,7 @@ __device__ __forceinline__ FSec load_fsec(const uint64_t * fl, uint64_t L, int s
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
     const v2u64 * ptr = reinterpret_cast<const v2u64 *>(fl + L * kFusedWords) + 2 * s;
     v2u64 a, b;
-#ifdef SDSL_HIP_FUSED_NT
-    constexpr bool nt = true;
-#else
-    constexpr bool nt = NT;
-#endif
-    if (nt)
+    if (NT) // (tried for every walk: non-temporal line loads cost a fifth of the rate, 16-ary or 8-ary)
     {
         a = __builtin_nontemporal_load(ptr);
         b = __builtin_nontemporal_load(ptr + 1);

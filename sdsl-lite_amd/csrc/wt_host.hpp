@@ -20,6 +20,7 @@ struct WtHost
     DevBuf d_ftables;   // its node tables (WtFusedTables)
     DevBuf d_fsuper, d_fsuper_hi; // 16-ary lines: the superblocks' counts (wt_device.hpp), low / high words
     DevBuf d_fwalk;     // the layout by fused node (WtFusedWalk), optional
+    DevBuf d_fsteps;    // the layout by symbol (WtStepTab), optional
     DevBuf d_tables_f;  // node table of the fused layout's OWN tree shape (8-ary Huffman written as a binary tree); empty
                         // when the fused layout was derived from the SDSL-shaped tree itself
     WtTables tables_f;  // host copy of it
@@ -37,6 +38,7 @@ struct WtHost
         v.f_super = d_fsuper.as<uint32_t>();
         v.f_super_hi = d_fsuper_hi.as<uint32_t>();
         v.f_walk = d_fwalk.as<WtFusedWalk>();
+        v.f_steps = d_fsteps.as<WtStepTab>();
         v.f_sel = d_fsel.as<uint32_t>();
         v.f_sel_tables = d_fsel_tables.as<WtFusedSelTables>();
         if (v.f_lines && d_tables_f.p)
@@ -59,13 +61,14 @@ struct WtHost
         v.f_super = nullptr;
         v.f_super_hi = nullptr;
         v.f_walk = nullptr;
+        v.f_steps = nullptr;
         v.f_sel = nullptr;
         v.f_sel_tables = nullptr;
         return v;
     }
     size_t device_bytes() const
     {
-        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes + d_ftables.bytes + d_fsuper.bytes + d_fsuper_hi.bytes + d_fwalk.bytes + d_fsel.bytes + d_fsel_tables.bytes + d_tables_f.bytes;
+        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes + d_ftables.bytes + d_fsuper.bytes + d_fsuper_hi.bytes + d_fwalk.bytes + d_fsteps.bytes + d_fsel.bytes + d_fsel_tables.bytes + d_tables_f.bytes;
     }
 };
 
