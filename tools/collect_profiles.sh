@@ -28,7 +28,7 @@ for w in $WHAT; do
            tools/prof.sh sd_select0 python $R/tools/kernel_probe.py sd_select0 ;;
     full)  # kernel trace only, of the default command
       export TMPDIR=/tmp; O=$R/gpurun_out/prof_full; rm -rf $O; mkdir -p $O; cd /tmp
-      rocprofv3 --kernel-trace --stats -d $O/trace -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/stdout.txt 2> $O/trace.err
+      timeout -k 10 900 rocprofv3 --kernel-trace --stats -d $O/trace -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --no-cpu > $O/stdout.txt 2> $O/trace.err
       find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; cd $R ;;
   esac
 done
