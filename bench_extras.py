@@ -661,7 +661,7 @@ def leg_big(c):
     a, pkg, dev, local, rank, world, barrier, comm_dev, G, gq = c.a, c.pkg, c.dev, c.local, c.rank, c.world, c.barrier, c.comm_dev, c.G, c.gq
     nq, n_bits, bv, words, idx, out, ex = c.nq, c.n_bits, c.bv, c.words, c.idx, c.out, c.ex
     # An index of more than 2^32 symbols (opt-in: 172 GB of working memory in the suffix sorter): csa_wt from a
-    # synthetic text of 2^32 + 777 symbols — 64-bit suffix sorter, fused lines with the 2^32-crossing list, SA / ISA
+    # synthetic text of 2^32 + 777 symbols — 64-bit suffix sorter, fused lines with 64-bit superblock counts, SA / ISA
     # samples instead of the whole array (answers checked by tests/test_gpu_beyond_2_32.py).
     torch.cuda.empty_cache()
     nb, sg = (1 << 32) + 777, 40
@@ -691,7 +691,7 @@ def leg_big(c):
                          "sampling": list(cb.sampling()), "count_Mcount/s": npb / ms_c / 1e3, "patterns": npb, "m": mb,
                          "every_pattern_found": bool((ob >= 1).all()), "wt_rank_Gq/s": nrb / ms_r / 1e6,
                          "kmer_table": {"k": cb.kmer_table_depth(), "bytes": cb.kmer_table_bytes()},
-                             "note": "fused lines with the 2^32-crossing list; count: k-mer table with 40-bit intervals -> wide flat search kernel -> "
+                             "note": "fused 16-ary lines with 64-bit superblock counts; count: k-mer table with 40-bit intervals -> wide flat search kernel -> "
                                      "text comparison at one suffix (fm_count2.hip, WIDE variants)"}
     del wtb, cb, tb, pb, ob, ib, sb, orb, stb
     torch.cuda.empty_cache()

@@ -846,7 +846,7 @@ void sdsl_hip_fm_footprint_parts(sdsl_hip_fm_t fm, uint64_t parts[8])
         return;
     const WtHost & w = sdsl_hip_wt_host(fm->wt);
     parts[0] = w.bv.device_bytes() + w.rrr.device_bytes();
-    parts[1] = w.d_fused.bytes + w.d_ftables.bytes + w.d_fsuper.bytes + w.d_fsuper_hi.bytes + w.d_fwalk.bytes + w.d_fsteps.bytes + w.d_fsel.bytes + w.d_fsel_tables.bytes + w.d_tables_f.bytes;
+    parts[1] = w.d_fused.bytes + w.d_ftables.bytes + w.d_fsuper.bytes + w.d_fwalk.bytes + w.d_fsteps.bytes + w.d_fsel.bytes + w.d_fsel_tables.bytes + w.d_tables_f.bytes;
     parts[2] = fm->d_sa.bytes + fm->d_sa64.bytes;
     parts[3] = fm->d_text.bytes;
     parts[4] = fm->d_sa_s.bytes + fm->d_isa_s.bytes;

@@ -273,7 +273,7 @@ struct FmCtabOf<true>
 
 template <bool VERIFY, bool WIDE>
 __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restrict__ f_lines, const uint32_t * __restrict__ f_super,
-                                                       const uint32_t * __restrict__ f_super_hi, const typename FmCtabOf<WIDE>::type * __restrict__ tab_g,
+                                                       const typename FmCtabOf<WIDE>::type * __restrict__ tab_g,
                                                        const FmRec * __restrict__ recs, uint32_t n_rec,
                                                        uint32_t * __restrict__ ticket, const uint8_t * __restrict__ pats,
                                                        uint32_t m, uint64_t * __restrict__ out)
@@ -371,11 +371,11 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
             FSec xa = xb;
             if (La != Lb) // quad-uniform
                 xa = load_fsec<false>(f_lines, La, s);
-            const uint64_t sb = fused_super(f_super, f_super_hi, WIDE, base, Lb, t); // (16-ary lines; a cache-resident word beside the line)
+            const uint64_t sb = fused_super(f_super, WIDE, base, Lb, t); // (16-ary lines; a cache-resident word beside the line)
             uint64_t sa = sb;
             if constexpr (kFK == 4)
                 if ((La >> kFSuperLog) != (Lb >> kFSuperLog))
-                    sa = fused_super(f_super, f_super_hi, WIDE, base, La, t);
+                    sa = fused_super(f_super, WIDE, base, La, t);
             a = count_at(xa, fused_off(a, la), La, t, step, sa);
             b = count_at(xb, fused_off(b, lb), Lb, t, step, sb);
             if (b == 0)
@@ -829,7 +829,7 @@ sdsl_hip_status fm_count_fast(sdsl_hip_fm_s * f, const uint8_t * d_pats, uint32_
             hipLaunchKernelGGL((k_fm_start_dense<V, W>), dim3(grid_for(cnt, 256, 256u * 8u)), dim3(256), 0, s, J, f->d_tab.as<FmTables>(),
                                csa_size, pp, m, cnt, oo, recs);
         hipLaunchKernelGGL((k_fm_count_flat<V, W>), dim3(grid_for(cnt, 256, 256u * 8u)), dim3(256), 0, s, w.d_fused.as<uint64_t>(),
-                           w.d_fsuper.as<uint32_t>(), w.d_fsuper_hi.as<uint32_t>(), f->d_ctab.as<typename FmCtabOf<W>::type>(), recs, cnt, ticket, pp,
+                           w.d_fsuper.as<uint32_t>(), f->d_ctab.as<typename FmCtabOf<W>::type>(), recs, cnt, ticket, pp,
                            m, oo);
         if (V)
         {

@@ -866,7 +866,7 @@ __global__ __launch_bounds__(kBlock) void k_wt_rank_flat(WtView wt, const uint64
             const uint32_t base = st & 0x0FFFFFFFu, t = st >> 28;
             const uint64_t li = fused_line(res), L = base + li;
             const FSec x = load_fsec<false>(wt.f_lines, L, s);
-            const uint64_t sup = fused_super(wt.f_super, wt.f_super_hi, wide, base, L, t);
+            const uint64_t sup = fused_super(wt.f_super, wide, base, L, t);
             res = sup + quad_sum(fsec_count(x, s, fused_off(res, li), t)); // (8-ary lines: fewer than 2^32 symbols here, sup = 0)
             if (left == 0 || res == 0)
             { // (wt_pc.hpp:386: a count of 0 stays 0)
@@ -1310,9 +1310,9 @@ __device__ __forceinline__ uint64_t wt8_cascade(const WtView & wt, const WtTable
 // counts: thread (line, t) cascades the line's first position of node u down slot t's bits.  16-ary: the header holds the count
 // relative to the first line of the line's superblock (wt_device.hpp: fused_super; superblocks are counted in absolute lines,
 // `first_line` = the node's first), whose own count the thread cascades as well and stores if the line is that one; in the superblock
-// the node starts in, the counts are the node's own.  fl = the node's first line, sup_lo / sup_hi = the whole tables.
+// the node starts in, the counts are the node's own.  fl = the node's first line, sup = the whole table (64-bit records if `wide`).
 __global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint64_t n_lines_u, uint64_t * __restrict__ fl, uint64_t first_line,
-                                                    uint32_t * __restrict__ sup_lo, uint32_t * __restrict__ sup_hi)
+                                                    uint32_t * __restrict__ sup, bool wide)
 {
     const WtTables * T = wt.tables;
     // grid-stride: the launch caps its grid (2^20 blocks = 2^25 lines = 2^33 symbols per pass), a node of a 2^36-symbol sequence has more
@@ -1335,9 +1335,10 @@ __global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint6
                 if (sabs == abs_line)
                 {
                     const uint64_t at = (abs_line >> kFSuperLog) * kFSlots + t;
-                    sup_lo[at] = ok ? (uint32_t)c : 0u;
-                    if (sup_hi)
-                        sup_hi[at] = ok ? (uint32_t)(c >> 32) : 0u;
+                    if (wide)
+                        reinterpret_cast<uint64_t *>(sup)[at] = ok ? c : UINT64_C(0);
+                    else
+                        sup[at] = ok ? (uint32_t)c : 0u;
                 }
             }
             const uint32_t rel = ok ? (uint32_t)(c - cs) : 0u; // < 2^(16 + kFSpare)
@@ -1408,7 +1409,7 @@ __device__ __forceinline__ uint32_t wt8_header_abs(const uint64_t * fl, const ui
     else
     {
         const uint64_t * sec = fl + line * kFusedWords + 4 * (t >> 2);
-        return (uint32_t)fused_super(sup, nullptr, false, first_line, first_line + line, t) + fsec16_count_field(sec[0], sec[3], t & 3);
+        return (uint32_t)fused_super(sup, false, first_line, first_line + line, t) + fsec16_count_field(sec[0], sec[3], t & 3);
     }
 }
 // the positions of section g of a line that hold slot t
@@ -1621,19 +1622,15 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
     const auto t0 = now();
     SH_TRY(dst.d_fused.alloc(total * kFusedWords * 8));
     SH_HIP(hipMemsetAsync(dst.d_fused.p, 0, total * kFusedWords * 8, 0));
+    const bool sup_wide = (wt.size >> 32) != 0; // 64-bit records
     if (n_super)
     {
-        SH_TRY(dst.d_fsuper.alloc(n_super * kFSlots * 4));
-        SH_HIP(hipMemsetAsync(dst.d_fsuper.p, 0, n_super * kFSlots * 4, 0));
-        if (wt.size >> 32)
-        {
-            SH_TRY(dst.d_fsuper_hi.alloc(n_super * kFSlots * 4));
-            SH_HIP(hipMemsetAsync(dst.d_fsuper_hi.p, 0, n_super * kFSlots * 4, 0));
-        }
+        SH_TRY(dst.d_fsuper.alloc(n_super * kFSlots * (sup_wide ? 8 : 4)));
+        SH_HIP(hipMemsetAsync(dst.d_fsuper.p, 0, n_super * kFSlots * (sup_wide ? 8 : 4), 0));
     }
     const WtView view = wt.view_binary();
     uint64_t * fl = dst.d_fused.as<uint64_t>();
-    uint32_t * sup_lo = dst.d_fsuper.as<uint32_t>(), * sup_hi = dst.d_fsuper_hi.as<uint32_t>();
+    uint32_t * sup_lo = dst.d_fsuper.as<uint32_t>();
     const auto t1 = now();
     for (uint32_t v : roots)
     {
@@ -1643,7 +1640,7 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
             hipLaunchKernelGGL(k_wt8_planes, dim3(grid_for((size[v] + kFLane - 1) / kFLane, 4, 256u * 8u)), dim3(256), 0, 0, view, v,
                                size[v], at);
         hipLaunchKernelGGL(k_wt8_counts, dim3(grid_for(lines_v * kFSlots, 256, wt8_grid_cap())), dim3(256), 0, 0, view, v, lines_v, at,
-                           (uint64_t)FT.fline[v], sup_lo, sup_hi);
+                           (uint64_t)FT.fline[v], sup_lo, sup_wide);
     }
     SH_HIP(hipGetLastError());
     if (kFK == 3 && (wt.size >> 32))
@@ -1913,7 +1910,6 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         wt.d_fused.release();
         wt.d_ftables.release();
         wt.d_fsuper.release();
-        wt.d_fsuper_hi.release();
         wt.d_fwalk.release();
         wt.d_fsteps.release();
         wt.d_fsel.release();
@@ -1927,7 +1923,6 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         wt.d_fused.release();
         wt.d_ftables.release();
         wt.d_fsuper.release();
-        wt.d_fsuper_hi.release();
         wt.d_fwalk.release();
         wt.d_fsteps.release();
         wt.d_fsel.release();

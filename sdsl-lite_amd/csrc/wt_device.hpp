@@ -94,8 +94,8 @@ struct WtView
     uint32_t n_nodes;
     const uint64_t * f_lines; // fused (8-ary / 16-ary) layout of the same tree, nullptr if not built
     const WtFusedTables * f_tables;
-    const uint32_t * f_super;    // 16-ary lines: the counts at every 256th line (low words; [superblock][slot]), else nullptr
-    const uint32_t * f_super_hi; // their high words (sequences of 2^32 symbols and more), else nullptr
+    const uint32_t * f_super;    // 16-ary lines: the superblocks' counts, [superblock][slot]: 32-bit, or — sequences of 2^32 symbols and
+                                 // more — 64-bit (one record = one 128-byte line either way it is read: a word per step), else nullptr
     const struct WtStepTab * f_steps;  // the layout by symbol (nullptr: paths longer than the table, or 8-ary lines of 2^32 symbols and more)
     const struct WtFusedWalk * f_walk; // the layout by fused node (nullptr: more fused nodes than the table holds, or 8-ary lines of 2^32 symbols and more)
     const uint32_t * f_sel;                      // select directory of the fused layout (below), nullptr if not built
@@ -332,8 +332,7 @@ __device__ __forceinline__ unsigned fsec_count(const FSec & x, int s, unsigned o
 // counted in ABSOLUTE lines (superblock = abs_line >> kFSuperLog), nodes start anywhere: a line in the superblock its node starts
 // in (`node_first` = the node's first line) counts from the node's start — base 0, nothing to read; every later superblock of the
 // node has its record.  The address does not depend on the line's content: callers issue the read beside the line's.
-__device__ __forceinline__ uint64_t fused_super(const uint32_t * f_super, const uint32_t * f_super_hi, bool wide, uint64_t node_first,
-                                                uint64_t abs_line, unsigned t)
+__device__ __forceinline__ uint64_t fused_super(const uint32_t * f_super, bool wide, uint64_t node_first, uint64_t abs_line, unsigned t)
 {
     if constexpr (kFK == 4)
     {
@@ -341,17 +340,16 @@ __device__ __forceinline__ uint64_t fused_super(const uint32_t * f_super, const 
         if (sb == (node_first >> kFSuperLog))
             return 0;
         const uint64_t idx = sb * kFSlots + t;
-        uint64_t v = f_super[idx];
-        if (wide) // kernel-uniform
-            v |= (uint64_t)f_super_hi[idx] << 32;
-        return v;
+        if (wide) // kernel-uniform: 64-bit records
+            return reinterpret_cast<const uint64_t *>(f_super)[idx];
+        return f_super[idx];
     }
     else
         return 0;
 }
 __device__ __forceinline__ uint64_t fused_super(const WtView & wt, uint64_t node_first, uint64_t abs_line, unsigned t)
 {
-    return fused_super(wt.f_super, wt.f_super_hi, (wt.size >> 32) != 0, node_first, abs_line, t);
+    return fused_super(wt.f_super, (wt.size >> 32) != 0, node_first, abs_line, t);
 }
 
 // the same summed over the quad — for every size of sequence: `u` the fused node, `abs_line` the line's index in the layout,
@@ -509,7 +507,7 @@ __device__ __forceinline__ bool quad_fsel_probe(const WtView & wt, uint64_t base
     }
     const uint32_t g = (uint32_t)fused_line(pe);
     const FSec x = load_fsec<NT>(wt.f_lines, base_line + g, s);
-    const uint32_t sup = (uint32_t)fused_super(wt.f_super, nullptr, false, base_line, base_line + g, t); // (the directory holds 32-bit positions)
+    const uint32_t sup = (uint32_t)fused_super(wt.f_super, false, base_line, base_line + g, t); // (the directory holds 32-bit positions)
     const uint64_t m = fsec_match(x, t);
     const unsigned c_lane = popc64(m);
     const unsigned hdr = fsec_header(x, s, t);

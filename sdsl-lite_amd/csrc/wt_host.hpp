@@ -18,7 +18,7 @@ struct WtHost
     DevBuf d_tables;    // WtTables image in HBM
     DevBuf d_fused;     // the fused (8-ary) layout used by the rank-type traversals (wt_device.hpp), optional
     DevBuf d_ftables;   // its node tables (WtFusedTables)
-    DevBuf d_fsuper, d_fsuper_hi; // 16-ary lines: the superblocks' counts (wt_device.hpp), low / high words
+    DevBuf d_fsuper;    // 16-ary lines: the superblocks' counts (wt_device.hpp), 32-bit or — 2^32 symbols and more — 64-bit records
     DevBuf d_fwalk;     // the layout by fused node (WtFusedWalk), optional
     DevBuf d_fsteps;    // the layout by symbol (WtStepTab), optional
     DevBuf d_tables_f;  // node table of the fused layout's OWN tree shape (8-ary Huffman written as a binary tree); empty
@@ -36,7 +36,6 @@ struct WtHost
         v.f_lines = d_fused.as<uint64_t>();
         v.f_tables = d_ftables.as<WtFusedTables>();
         v.f_super = d_fsuper.as<uint32_t>();
-        v.f_super_hi = d_fsuper_hi.as<uint32_t>();
         v.f_walk = d_fwalk.as<WtFusedWalk>();
         v.f_steps = d_fsteps.as<WtStepTab>();
         v.f_sel = d_fsel.as<uint32_t>();
@@ -59,7 +58,6 @@ struct WtHost
         v.f_lines = nullptr;
         v.f_tables = nullptr;
         v.f_super = nullptr;
-        v.f_super_hi = nullptr;
         v.f_walk = nullptr;
         v.f_steps = nullptr;
         v.f_sel = nullptr;
@@ -68,7 +66,7 @@ struct WtHost
     }
     size_t device_bytes() const
     {
-        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes + d_ftables.bytes + d_fsuper.bytes + d_fsuper_hi.bytes + d_fwalk.bytes + d_fsteps.bytes + d_fsel.bytes + d_fsel_tables.bytes + d_tables_f.bytes;
+        return bv.device_bytes() + rrr.device_bytes() + d_tables.bytes + d_fused.bytes + d_ftables.bytes + d_fsuper.bytes + d_fwalk.bytes + d_fsteps.bytes + d_fsel.bytes + d_fsel_tables.bytes + d_tables_f.bytes;
     }
 };
 

@@ -235,7 +235,7 @@ __device__ __forceinline__ bool lane_fsel_probe(const uint64_t * __restrict__ f_
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         w[i] = ln[i]; // section s: w[2s] = (header, plane 0), w[2s + 1] = (plane 1, plane 2)  [16-ary: header, three words of 16 positions]
-    const uint32_t sup = (uint32_t)fused_super(f_super, nullptr, false, base_line, base_line + g, t);
+    const uint32_t sup = (uint32_t)fused_super(f_super, false, base_line, base_line + g, t);
     const uint64_t x0 = (t & 1) ? 0 : ~UINT64_C(0), x1 = (t & 2) ? 0 : ~UINT64_C(0), x2 = (t & 4) ? 0 : ~UINT64_C(0);
     uint64_t m[4];
     unsigned c[4];
