@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(256) void k_wt8_planes(WtView wt, unsigned u, uint6
     wt_stage_tables(&T, wt.tables);
     const unsigned lane = threadIdx.x & 63;
     const uint64_t below = (UINT64_C(1) << lane) - 1; // lanes before this one
-    // a wave takes one section of a line: kFLane consecutive positions (64, or 48 of the 16-ary form: lanes 48..63 idle)
+    // a wave takes one section of a line: kFLane consecutive positions (64, or 46 of the 16-ary form: the other lanes idle)
     const uint64_t n_groups = (size_u + kFLane - 1) / kFLane;
     const uint64_t * lines = wt.bv.lines;
     for (uint64_t g = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6; g < n_groups; g += (uint64_t)gridDim.x * 4)
