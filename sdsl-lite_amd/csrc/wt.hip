@@ -1102,7 +1102,8 @@ __global__ __launch_bounds__(kBlock) void k_wt_select(WtView wt, const uint64_t 
 // wt_pc::select on the fused layout: the same flat persistent loop, but one iteration is one probe of a FUSED step
 // (three tree levels): the path of c is cut into groups of three levels from the root, and the walk goes from the
 // deepest group up, each group one select of its slot inside the fused node above it.
-template <bool NT>
+// (WIDE: a sequence of 2^32 symbols and more on 16-ary lines — positions, counts and the directory's entries are 64-bit)
+template <bool NT, bool WIDE>
 __global__ __launch_bounds__(kBlock) void k_wt_select_fused(WtView wt, const uint64_t * __restrict__ occ,
                                                             const uint64_t * __restrict__ iq,
                                                             const uint8_t * __restrict__ cq, uint64_t * __restrict__ out,
@@ -1141,11 +1142,13 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_fused(WtView wt, const uin
     uint64_t i_nxt = q_next < n ? iq[q_next] : 0;
     unsigned c_nxt = q_next < n ? cq[q_next] : 0;
     bool have = false;
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type pos_t;
+    const pos_t * dir = reinterpret_cast<const pos_t *>(wt.f_sel);
     uint64_t q = 0, p = 0, base_line = 0;
-    uint32_t res = 0;
+    pos_t res = 0;
     unsigned groups = 0, len = 0, cur = 0, t = 0;
     int tries = 0;
-    FselBracket br{};
+    FselBracketT<pos_t> br{};
     // the fused step that takes node `cur`'s offset `res` up into the fused node above it
     auto start_group = [&]() {
         const unsigned g = groups - 1, nlev = len - kFK * g < kFK ? len - kFK * g : kFK;
@@ -1157,7 +1160,10 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_fused(WtView wt, const uin
         len = kFK * g; // levels above u
         base_line = FT.fline[u];
         const unsigned rid = FS.root_id[u];
-        br = fsel_bracket(wt.f_sel, FS.off[rid][t], res, FS.cnt[rid][t]);
+        pos_t total = FS.cnt[rid][t];
+        if constexpr (WIDE)
+            total |= (pos_t)FS.cnt_hi[rid][t] << 32;
+        br = fsel_bracket_t<pos_t>(dir, FS.off[rid][t], res, total);
         tries = 0;
     };
     for (;;)
@@ -1190,7 +1196,7 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_fused(WtView wt, const uin
                     out[q] = direct;
                 continue;
             }
-            res = (uint32_t)(i - 1);
+            res = (pos_t)(i - 1);
             p = T.path[c];
             len = (unsigned)(p >> 56);
             groups = (len + kFK - 1) / kFK;
@@ -1202,9 +1208,9 @@ __global__ __launch_bounds__(kBlock) void k_wt_select_fused(WtView wt, const uin
         if (have)
         {
             uint64_t pos;
-            if (quad_fsel_probe<NT>(wt, base_line, s, t, res, br, tries, pos))
+            if (quad_fsel_probe_t<NT, pos_t>(wt, base_line, s, t, res, br, tries, pos))
             {
-                res = (uint32_t)pos;
+                res = (pos_t)pos;
                 if (--groups == 0)
                 {
                     if (s == 0)
@@ -1398,18 +1404,20 @@ __global__ __launch_bounds__(256) void k_wt8_cross(const uint64_t * __restrict__
 // neighbouring headers; if occurrence 256 * j is among them it finds its position in the line's match masks
 struct FselNodeArgs
 {
-    uint32_t cnt[kFSlots], off[kFSlots], n_samples[kFSlots];
-    uint32_t size;
+    uint64_t cnt[kFSlots];
+    uint32_t off[kFSlots], n_samples[kFSlots];
+    uint64_t size;
 };
 // the absolute count of slot t in front of line `line` of a node (fl: the node's first line, `first_line` its index, sup: the whole table)
-__device__ __forceinline__ uint32_t wt8_header_abs(const uint64_t * fl, const uint32_t * sup, uint64_t first_line, uint64_t line, unsigned t)
+template <bool WIDE>
+__device__ __forceinline__ uint64_t wt8_header_abs(const uint64_t * fl, const uint32_t * sup, uint64_t first_line, uint64_t line, unsigned t)
 {
     if constexpr (kFK == 3)
         return reinterpret_cast<const uint32_t *>(fl + line * kFusedWords + 4 * (t >> 1))[t & 1];
     else
     {
         const uint64_t * sec = fl + line * kFusedWords + 4 * (t >> 2);
-        return (uint32_t)fused_super(sup, false, first_line, first_line + line, t) + fsec16_count_field(sec[0], sec[3], t & 3);
+        return fused_super(sup, WIDE, first_line, first_line + line, t) + fsec16_count_field(sec[0], sec[3], t & 3);
     }
 }
 // the positions of section g of a line that hold slot t
@@ -1417,35 +1425,41 @@ __device__ __forceinline__ uint64_t wt8_section_match(const uint64_t * ln, unsig
 {
     return fsec_match_words(ln[4 * g + 1], ln[4 * g + 2], ln[4 * g + 3], t);
 }
+// (WIDE: 2^32 symbols and more on 16-ary lines: 64-bit directory entries; grid-stride: a node of such a sequence has more lines than a grid covers)
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_wt8_sel_dir(const uint64_t * __restrict__ fl, const uint32_t * __restrict__ sup, uint64_t first_line,
-                                                     uint64_t n_lines, FselNodeArgs a, uint32_t * __restrict__ dir)
+                                                     uint64_t n_lines, FselNodeArgs a, void * __restrict__ dir_)
 {
-    const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t line = id / kFSlots;
-    const unsigned t = (unsigned)id & (kFSlots - 1);
-    if (line >= n_lines || a.off[t] == kFselNone)
-        return;
-    const uint64_t * ln = fl + line * kFusedWords;
-    const uint32_t c0 = wt8_header_abs(fl, sup, first_line, line, t);
-    const uint32_t c1 = line + 1 < n_lines ? wt8_header_abs(fl, sup, first_line, line + 1, t) : a.cnt[t];
-    constexpr uint32_t S = 1u << kFselLog;
-    for (uint32_t j = (c0 + S - 1) >> kFselLog; c1 > c0 && (j << kFselLog) < c1; ++j)
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type pos_t;
+    pos_t * dir = reinterpret_cast<pos_t *>(dir_);
+    for (uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x; id < n_lines * kFSlots; id += (uint64_t)gridDim.x * 256)
     {
-        uint32_t r = (j << kFselLog) - c0; // rank of the wanted occurrence inside the line
-        for (unsigned g = 0; g < 4; ++g)
+        const uint64_t line = id / kFSlots;
+        const unsigned t = (unsigned)id & (kFSlots - 1);
+        if (a.off[t] == kFselNone)
+            continue;
+        const uint64_t * ln = fl + line * kFusedWords;
+        const pos_t c0 = (pos_t)wt8_header_abs<WIDE>(fl, sup, first_line, line, t);
+        const pos_t c1 = line + 1 < n_lines ? (pos_t)wt8_header_abs<WIDE>(fl, sup, first_line, line + 1, t) : (pos_t)a.cnt[t];
+        constexpr pos_t S = (pos_t)1 << kFselLog;
+        for (pos_t j = (c0 + S - 1) >> kFselLog; c1 > c0 && (j << kFselLog) < c1; ++j)
         {
-            const uint64_t m = wt8_section_match(ln, g, t);
-            const uint32_t c = popc64(m);
-            if (r < c)
+            uint32_t r = (uint32_t)((j << kFselLog) - c0); // rank of the wanted occurrence inside the line
+            for (unsigned g = 0; g < 4; ++g)
             {
-                dir[a.off[t] + j] = (uint32_t)(line * kFusedPos) + kFLane * g + sel64(m, r + 1);
-                break;
+                const uint64_t m = wt8_section_match(ln, g, t);
+                const uint32_t c = popc64(m);
+                if (r < c)
+                {
+                    dir[a.off[t] + j] = (pos_t)(line * kFusedPos) + kFLane * g + sel64(m, r + 1);
+                    break;
+                }
+                r -= c;
             }
-            r -= c;
         }
+        if (line + 1 == n_lines)
+            dir[a.off[t] + a.n_samples[t] - 1] = (pos_t)a.size;
     }
-    if (line + 1 == n_lines)
-        dir[a.off[t] + a.n_samples[t] - 1] = a.size;
 }
 
 // the symbol sequence of a tree (wt[0 .. size)), read back through the binary levels (view_binary()) or the fused lines (view())
@@ -1775,8 +1789,8 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
     }
     // select directory (skipped for trees with more fused nodes than its table holds: select then walks the binary levels)
     const char * env_sel = getenv("SDSL_HIP_WT_FUSED_SELECT"); // 0: select keeps walking the binary levels
-    // (and for sequences of 2^32 symbols and more: the directory holds 32-bit positions)
-    if (roots.size() <= (size_t)kFselMaxRoots && !(env_sel && atoi(env_sel) == 0) && !(wt.size >> 32))
+    // (8-ary lines of 2^32 symbols and more: the directory holds 32-bit positions there; 16-ary lines get 64-bit entries)
+    if (roots.size() <= (size_t)kFselMaxRoots && !(env_sel && atoi(env_sel) == 0) && (kFK == 4 || !(wt.size >> 32)))
     {
         std::vector<WtFusedSelTables> fs_store(1);
         WtFusedSelTables & FS = fs_store[0];
@@ -1787,7 +1801,7 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
         {
             const uint32_t u = roots[r];
             FS.root_id[u] = (uint16_t)r;
-            args[r].size = (uint32_t)size[u];
+            args[r].size = size[u];
             for (unsigned t = 0; t < kFSlots; ++t)
             { // the node kFK levels down along t, or the leaf met earlier (then the rest of t must be zero)
                 uint32_t x = u;
@@ -1805,7 +1819,9 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
                 args[r].off[t] = kFselNone;
                 if (!ok || size[x] == 0)
                     continue;
-                args[r].cnt[t] = FS.cnt[r][t] = (uint32_t)size[x];
+                args[r].cnt[t] = size[x];
+                FS.cnt[r][t] = (uint32_t)size[x];
+                FS.cnt_hi[r][t] = (uint8_t)(size[x] >> 32);
                 args[r].n_samples[t] = (uint32_t)((size[x] + (1u << kFselLog) - 1) >> kFselLog) + 1;
                 args[r].off[t] = FS.off[r][t] = (uint32_t)n_dir;
                 n_dir += args[r].n_samples[t];
@@ -1813,13 +1829,18 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
         }
         if (n_dir < (UINT64_C(1) << 32))
         {
-            SH_TRY(dst.d_fsel.alloc((n_dir + 1) * 4));
+            SH_TRY(dst.d_fsel.alloc((n_dir + 1) * (sup_wide ? 8 : 4)));
             for (size_t r = 0; r < roots.size(); ++r)
             {
                 const uint32_t u = roots[r];
                 const uint64_t lines_u = fused_lines_for(size[u]);
-                hipLaunchKernelGGL(k_wt8_sel_dir, dim3(grid_for(lines_u * kFSlots, 256, 1u << 20)), dim3(256), 0, 0,
-                                   fl + (uint64_t)FT.fline[u] * kFusedWords, sup_lo, (uint64_t)FT.fline[u], lines_u, args[r], dst.d_fsel.as<uint32_t>());
+                const dim3 grid(grid_for(lines_u * kFSlots, 256, wt8_grid_cap()));
+                if (sup_wide)
+                    hipLaunchKernelGGL(k_wt8_sel_dir<true>, grid, dim3(256), 0, 0, fl + (uint64_t)FT.fline[u] * kFusedWords, sup_lo,
+                                       (uint64_t)FT.fline[u], lines_u, args[r], dst.d_fsel.p);
+                else
+                    hipLaunchKernelGGL(k_wt8_sel_dir<false>, grid, dim3(256), 0, 0, fl + (uint64_t)FT.fline[u] * kFusedWords, sup_lo,
+                                       (uint64_t)FT.fline[u], lines_u, args[r], dst.d_fsel.p);
             }
             SH_HIP(hipGetLastError());
             SH_TRY(dst.d_fsel_tables.alloc(sizeof(WtFusedSelTables)));
@@ -2396,8 +2417,11 @@ sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, c
         if (!done)
         {
             KernelTimer t(s);
-            if (view.f_lines && view.f_sel)
-                hipLaunchKernelGGL((k_wt_select_fused<false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, view,
+            if (view.f_lines && view.f_sel && (view.size >> 32))
+                hipLaunchKernelGGL((k_wt_select_fused<false, true>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, view,
+                                   wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev, (const uint8_t *)sc.dev, (uint64_t *)so.dev, n);
+            else if (view.f_lines && view.f_sel)
+                hipLaunchKernelGGL((k_wt_select_fused<false, false>), dim3(grid_for(n, kQPB, 256u * 8u)), dim3(kBlock), 0, s, view,
                                    wt->d_occ.as<uint64_t>(), (const uint64_t *)si.dev, (const uint8_t *)sc.dev,
                                    (uint64_t *)so.dev, n);
             else // SDSL's tree and its binary levels

@@ -60,6 +60,7 @@ struct WtFusedSelTables
     uint32_t off[kFselMaxRoots][1u << SDSL_HIP_FUSED_K];
     uint32_t cnt[kFselMaxRoots][1u << SDSL_HIP_FUSED_K];
     uint16_t root_id[kWtMaxNodes];
+    uint8_t cnt_hi[kFselMaxRoots][1u << SDSL_HIP_FUSED_K]; // bits 32..39 of cnt (sequences of 2^32 symbols and more: 64-bit directory entries)
 };
 
 // The fused layout BY FUSED NODE, for the walks that only ever stand on one (inverse_select: the LF walks): first line and, per slot,
@@ -98,7 +99,7 @@ struct WtView
                                  // more — 64-bit (one record = one 128-byte line either way it is read: a word per step), else nullptr
     const struct WtStepTab * f_steps;  // the layout by symbol (nullptr: paths longer than the table, or 8-ary lines of 2^32 symbols and more)
     const struct WtFusedWalk * f_walk; // the layout by fused node (nullptr: more fused nodes than the table holds, or 8-ary lines of 2^32 symbols and more)
-    const uint32_t * f_sel;                      // select directory of the fused layout (below), nullptr if not built
+    const uint32_t * f_sel;                      // select directory of the fused layout (below; 64-bit entries for 2^32 symbols and more), nullptr if not built
     const struct WtFusedSelTables * f_sel_tables;
 };
 
@@ -472,15 +473,18 @@ __device__ __forceinline__ uint64_t quad_wt8_rank(const WtView & wt, const WtTab
 // size as the last entry); the guess is interpolated between two (position, count) pairs, the probed line's header
 // count for t and the popcount of its match mask say whether the occurrence is inside, and a miss replaces one end of
 // the bracket by (line edge, exact count) — the scheme of §3.2 of DESIGN.md.
-struct FselBracket
+template <class P> // P: uint32_t, or uint64_t for sequences of 2^32 symbols and more (16-ary lines)
+struct FselBracketT
 { // lo_cnt occurrences lie in front of position plo, hi_cnt in front of phi; lo_cnt <= k < hi_cnt
-    uint32_t plo, phi, lo_cnt, hi_cnt;
+    P plo, phi, lo_cnt, hi_cnt;
 };
+typedef FselBracketT<uint32_t> FselBracket;
 
-__device__ __forceinline__ FselBracket fsel_bracket(const uint32_t * dir, uint32_t off, uint32_t k, uint32_t total)
+template <class P>
+__device__ __forceinline__ FselBracketT<P> fsel_bracket_t(const P * dir, uint32_t off, P k, P total)
 {
-    const uint32_t j = k >> kFselLog;
-    FselBracket b;
+    const P j = k >> kFselLog;
+    FselBracketT<P> b;
     b.plo = dir[off + j];
     b.phi = dir[off + j + 1];
     b.lo_cnt = j << kFselLog;
@@ -489,48 +493,59 @@ __device__ __forceinline__ FselBracket fsel_bracket(const uint32_t * dir, uint32
         b.hi_cnt = total; // the last entry is the node's size: all `total` occurrences lie in front of it
     return b;
 }
+__device__ __forceinline__ FselBracket fsel_bracket(const uint32_t * dir, uint32_t off, uint32_t k, uint32_t total)
+{
+    return fsel_bracket_t<uint32_t>(dir, off, k, total);
+}
 
 // one probe; on a hit all four lanes get the position
-template <bool NT>
-__device__ __forceinline__ bool quad_fsel_probe(const WtView & wt, uint64_t base_line, int s, unsigned t, uint32_t k,
-                                                FselBracket & b, int tries, uint64_t & pos_out)
+template <bool NT, class P>
+__device__ __forceinline__ bool quad_fsel_probe_t(const WtView & wt, uint64_t base_line, int s, unsigned t, P k, FselBracketT<P> & b,
+                                                  int tries, uint64_t & pos_out)
 {
-    const uint32_t span = b.phi - b.plo; // > 0
-    uint32_t pe;
+    const P span = b.phi - b.plo; // > 0
+    P pe;
     if (tries >= 3 && (tries & 1))
         pe = b.plo + (span >> 1);
     else
     {
         const float f = (float)(k - b.lo_cnt) * __builtin_amdgcn_rcpf((float)(b.hi_cnt - b.lo_cnt));
-        const uint32_t o = (uint32_t)(f * (float)span);
+        const P o = (P)(f * (float)span);
         pe = b.plo + (o >= span ? span - 1 : o);
     }
     const uint32_t g = (uint32_t)fused_line(pe);
     const FSec x = load_fsec<NT>(wt.f_lines, base_line + g, s);
-    const uint32_t sup = (uint32_t)fused_super(wt.f_super, false, base_line, base_line + g, t); // (the directory holds 32-bit positions)
+    const P sup = (P)fused_super(wt.f_super, sizeof(P) == 8, base_line, base_line + g, t);
     const uint64_t m = fsec_match(x, t);
     const unsigned c_lane = popc64(m);
     const unsigned hdr = fsec_header(x, s, t);
-    const uint32_t c0 = sup + quad_sum(hdr), c_in = quad_sum(c_lane);
+    const P c0 = sup + quad_sum(hdr);
+    const uint32_t c_in = quad_sum(c_lane);
     if (k < c0)
     {
-        b.phi = g * kFusedPos;
+        b.phi = (P)g * kFusedPos;
         b.hi_cnt = c0;
         return false;
     }
     if (k >= c0 + c_in)
     {
-        b.plo = (g + 1) * kFusedPos;
+        b.plo = (P)(g + 1) * kFusedPos;
         b.lo_cnt = c0 + c_in;
         return false;
     }
-    const unsigned r = k - c0, ex = quad_excl(c_lane, s);
+    const unsigned r = (unsigned)(k - c0), ex = quad_excl(c_lane, s);
     const bool mine = r >= ex && r < ex + c_lane;
     uint64_t pos = 0;
     if (mine)
         pos = (uint64_t)g * kFusedPos + kFLane * (unsigned)s + sel64(m, r - ex + 1);
     pos_out = quad_gather_u64(pos, mine);
     return true;
+}
+template <bool NT>
+__device__ __forceinline__ bool quad_fsel_probe(const WtView & wt, uint64_t base_line, int s, unsigned t, uint32_t k, FselBracket & b,
+                                                int tries, uint64_t & pos_out)
+{
+    return quad_fsel_probe_t<NT, uint32_t>(wt, base_line, s, t, k, b, tries, pos_out);
 }
 
 // both cascades of one LF step (backward_search)

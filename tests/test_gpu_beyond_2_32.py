@@ -9,9 +9,10 @@ right on them:
 * `csa_wt` from a TEXT of 4.3 G symbols (64-bit suffix sorter, sa.hip): csa[i], isa[i], count, locate, extract against the same
   closed form; the sorter on small texts against the oracle.
 
-Sequences of 2^32 .. 2^36 symbols walk the fused 8-ary layout with the list of places where a count passes a multiple of 2^32
-(wt_device.hpp: WtFusedTables::cross_*) for rank / access / LF / count; select walks the binary levels; the flat count kernel and
-its k-mer table (32-bit intervals, fm_count2.hip) are not used."""
+Sequences of 2^32 .. 2^36 symbols walk the fused lines: 16-ary with 64-bit superblock counts and a select directory of 64-bit
+entries (rank / access / LF / count / select; wt_device.hpp), or — a SDSL_HIP_FUSED_K=3 build — 8-ary with the list of places
+where a count passes a multiple of 2^32 (select on the binary levels there); count takes the WIDE flat kernels and the k-mer
+table with 40-bit intervals (fm_count2.hip)."""
 import numpy as np
 import pytest
 
