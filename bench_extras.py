@@ -600,13 +600,14 @@ def leg_text(c):
                                 "with_text_resident_GB/s": etxt.numel() / ms_t / 1e6}
         # long ranges: a range is cut at the ISA samples and every piece walks exactly its own symbols (a 64-byte snippet also walks the
         # 32 steps from the sample behind it): 256 ranges of 1 MiB, compared with the text
-        lb = torch.arange(256, device=dev, dtype=torch.int64) * ((nt - (1 << 20) - 1) // 256) + 17
-        le = lb + (1 << 20) - 1
+        rl = min(1 << 20, max(64, nt // 1024))  # (1 MiB each on the bench text; a small text of the user's: shorter ones)
+        lb = torch.arange(256, device=dev, dtype=torch.int64) * ((nt - rl - 18) // 256) + 17
+        le = lb + rl - 1
         loff, ltxt = csa.extract(lb, le)
-        assert torch.equal(ltxt[: 1 << 20], text[17:17 + (1 << 20)]) and torch.equal(ltxt[-(1 << 20):], text[int(lb[-1]):int(le[-1]) + 1])
+        assert torch.equal(ltxt[:rl], text[17:17 + rl]) and torch.equal(ltxt[-rl:], text[int(lb[-1]):int(le[-1]) + 1])
         _, ms_l = time_steps(lambda: csa.extract(lb, le), 2, 1, barrier)
         ex["fm_extract_64B"]["long_ranges_GB/s"] = ltxt.numel() / ms_l / 1e6
-        ex["fm_extract_64B"]["long_ranges"] = "256 x 1 MiB, cut at the ISA samples into 4.2 M pieces walked in parallel"
+        ex["fm_extract_64B"]["long_ranges"] = "256 x %d bytes, cut at the ISA samples into pieces walked in parallel" % rl
         del eoff, etxt, want, loff, ltxt
         # count() against resident bytes: the index gives HBM back step by step (sdsl_hip_fm_set_footprint) down to the reference's
         # own footprint — csa_wt<wt_huff<>, 32, 64> of this text serialises to `sdsl_stream_bytes` (csa_wt.hpp:389-402) — and count()
