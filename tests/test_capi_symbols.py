@@ -36,3 +36,16 @@ def test_invalid_arguments(pkg):
     assert lib.sdsl_hip_bv_create(None, 64, 0, 0, None) == pkg.capi.ERR_INVALID
     assert lib.sdsl_hip_bv_rank_batch(None, 1, None, 0, None, None) == pkg.capi.ERR_INVALID
     assert b"" != lib.sdsl_hip_last_error()
+
+
+def test_fused_geometry_of_the_build(pkg):
+    """the form of the fused wavelet-tree lines is a compile-time choice (wt_device.hpp: SDSL_HIP_FUSED_K); the library says which one
+    it was built with, and the numbers hang together: four sections of a 128-byte line, relative counts that fit their fields"""
+    g = pkg.fused_geometry()
+    assert g["levels_per_fetch"] in (3, 4)
+    if g["levels_per_fetch"] == 4:  # 16-ary: 46 positions per section, counts of 18 bits relative to superblocks of 1024 lines
+        assert g["positions_per_line"] % 4 == 0 and g["positions_per_line"] in (192, 184, 176)
+        bits = 16 + (192 - g["positions_per_line"]) // 4
+        assert g["lines_per_superblock"] * g["positions_per_line"] < (1 << bits)
+    else:                          # 8-ary: 64 positions per section, absolute 32-bit counts
+        assert g["positions_per_line"] == 256 and g["lines_per_superblock"] == 0
