@@ -118,6 +118,30 @@ def test_the_knob_decides_what_is_resident(gpu, monkeypatch):
     assert gpu.wt_huff(text=text, rrr=True).device_bytes() == with_knob
 
 
+@pytest.mark.parametrize("extra", [0, 1, -1])
+def test_sequences_that_end_on_a_line_or_a_superblock(gpu, extra):
+    """n a multiple of the positions of a line / of a superblock (and one more, one less), two symbols: the root node is the whole
+    sequence, position n is addressable (rank(n, c)), the last line is empty or holds one position"""
+    geo = gpu.fused_geometry()
+    ppl, lps = geo["positions_per_line"], max(1, geo["lines_per_superblock"])
+    rng = np.random.default_rng(11 + extra)
+    for n in (ppl * 7 + extra, ppl * lps + extra, 2 * ppl * lps + extra):
+        arr = rng.choice(np.array([65, 66], dtype=np.uint8), size=n, p=[0.7, 0.3])
+        wt = gpu.wt_huff(text=arr.tobytes())
+        i = np.unique(np.clip(np.concatenate([[0, 1, n - 1, n], np.arange(0, n + 1, ppl), np.arange(0, n + 1, ppl) - 1,
+                                              rng.integers(0, n + 1, 5000)]), 0, n)).astype(np.uint64)
+        for c in (65, 66, 67):
+            pre = np.concatenate([[0], np.cumsum(arr == c)]).astype(np.uint64)
+            assert np.array_equal(wt.rank(i, np.full(i.size, c, dtype=np.uint8)), pre[i.astype(np.int64)]), (n, c)
+        for c in (65, 66):
+            occ = np.flatnonzero(arr == c)
+            kk = np.unique(np.concatenate([[1, occ.size], rng.integers(1, occ.size + 1, 3000)])).astype(np.uint64)
+            assert np.array_equal(wt.select(kk, np.full(kk.size, c, dtype=np.uint8)), occ[kk.astype(np.int64) - 1].astype(np.uint64)), (n, c)
+        j = i[i < n]
+        assert np.array_equal(wt.access(j), arr[j.astype(np.int64)])
+        wt.close()
+
+
 @pytest.mark.parametrize("sigma,skew", [(3, 0.0), (20, 1.0), (200, 1.5)])
 def test_lines_superblocks_and_node_starts(gpu, sigma, skew):
     """A sequence of several superblocks per fused node (16-ary lines: 1024 lines of 184 positions each), nodes that start in the
