@@ -210,19 +210,23 @@ sdsl_hip_status sort_pairs_u64_u32(uint64_t * keys_in, uint64_t * keys_out, uint
     return SDSL_HIP_OK;
 }
 
-// Stable sort of u16 keys by the bit range [begin_bit, end_bit) only (wt.hip: one wavelet-tree level); working memory as above
+// Stable sort of u16 keys by the bit range [begin_bit, end_bit) only (wt.hip: one wavelet-tree level).  The two key buffers are the
+// sort's ping and pong (rocPRIM's double_buffer form: the working memory is histograms only — the plain form keeps a third buffer of n
+// keys, 69 GB for a sequence of 2^35 symbols); *sorted_out = whichever of the two holds the result.
 size_t sort_keys_u16_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit)
 {
     size_t bytes = 0;
-    if (rocprim::radix_sort_keys(nullptr, bytes, (uint16_t *)nullptr, (uint16_t *)nullptr, (size_t)n, begin_bit, end_bit) != hipSuccess)
+    rocprim::double_buffer<uint16_t> db((uint16_t *)nullptr, (uint16_t *)nullptr);
+    if (rocprim::radix_sort_keys(nullptr, bytes, db, (size_t)n, begin_bit, end_bit) != hipSuccess)
         return 0;
     return bytes ? bytes : 16;
 }
-sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
-                              hipStream_t s, void * tmp, size_t tmp_bytes)
+sdsl_hip_status sort_keys_u16(uint16_t * keys, uint16_t * other, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t s, void * tmp,
+                              size_t tmp_bytes, uint16_t ** sorted_out)
 {
     size_t bytes = 0;
-    SH_HIP(rocprim::radix_sort_keys(nullptr, bytes, keys_in, keys_out, (size_t)n, begin_bit, end_bit, s));
+    rocprim::double_buffer<uint16_t> db(keys, other);
+    SH_HIP(rocprim::radix_sort_keys(nullptr, bytes, db, (size_t)n, begin_bit, end_bit, s));
     DevBuf own;
     if (!tmp)
     {
@@ -235,7 +239,8 @@ sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t 
         set_error("sort_keys: working memory too small");
         return SDSL_HIP_ERR_INVALID;
     }
-    SH_HIP(rocprim::radix_sort_keys(tmp, bytes, keys_in, keys_out, (size_t)n, begin_bit, end_bit, s));
+    SH_HIP(rocprim::radix_sort_keys(tmp, bytes, db, (size_t)n, begin_bit, end_bit, s));
+    *sorted_out = db.current();
     if (own.p)
         SH_HIP(hipStreamSynchronize(s));
     return SDSL_HIP_OK;

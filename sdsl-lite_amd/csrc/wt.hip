@@ -454,8 +454,8 @@ __global__ void k_wt_node_positions(const WtTables * __restrict__ T, uint32_t n_
 }
 
 size_t sort_keys_u16_temp_bytes(uint64_t n, unsigned begin_bit, unsigned end_bit);
-sdsl_hip_status sort_keys_u16(uint16_t * keys_in, uint16_t * keys_out, uint64_t n, unsigned begin_bit, unsigned end_bit,
-                              hipStream_t s, void * tmp, size_t tmp_bytes);
+sdsl_hip_status sort_keys_u16(uint16_t * keys, uint16_t * other, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t s, void * tmp,
+                              size_t tmp_bytes, uint16_t ** sorted_out);
 
 sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, uint64_t n, int device, uint32_t flags, DevBuf * words_out)
 {
@@ -541,10 +541,11 @@ sdsl_hip_status wt_build_from_device_text(WtHost & wt, const uint8_t * d_text, u
                                k0.as<uint16_t>());
             SH_HIP(hipGetLastError());
             mark_b("level keys", d);
-            SH_TRY(sort_keys_u16(k0.as<uint16_t>(), k1.as<uint16_t>(), n, 1u, 10u, nullptr, sort_tmp.p, sort_tmp.bytes)); // dead keys sort last
+            uint16_t * sorted = nullptr;
+            SH_TRY(sort_keys_u16(k0.as<uint16_t>(), k1.as<uint16_t>(), n, 1u, 10u, nullptr, sort_tmp.p, sort_tmp.bytes, &sorted)); // dead keys sort last
             mark_b("level sorted", d);
             hipLaunchKernelGGL(k_wt_pack_level, dim3(grid_for((alive + 63) >> 6, 256, 256u * 8u)), dim3(256), 0, 0,
-                               k1.as<uint16_t>(), alive, level_start, d_words.as<unsigned long long>());
+                               sorted, alive, level_start, d_words.as<unsigned long long>());
             SH_HIP(hipGetLastError());
             mark_b("level packed", d);
             level_start += alive;
@@ -1921,6 +1922,8 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         }
         if (st == SDSL_HIP_OK)
             st = fused_from(own, wt);
+        if (tr && st != SDSL_HIP_OK)
+            fprintf(stderr, "[sdsl_hip] fused build in its own shape failed (%s): deriving it from the binary tree\n", last_error_message());
         mark("fused layout derived");
         if (st == SDSL_HIP_OK && wt.d_fused.p)
         {
@@ -1935,6 +1938,7 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
         wt.d_fsteps.release();
         wt.d_fsel.release();
         wt.d_fsel_tables.release();
+        (void)hipGetLastError(); // (a failed allocation stays the runtime's "last error" until it is read: the launches below check it)
     }
     // the fused layout is an accelerator: if it cannot be built (memory), the handle works on its binary levels
     if (fused_from(wt, wt) != SDSL_HIP_OK)

@@ -216,13 +216,22 @@ constexpr unsigned kFSuperLog = 8 + kFSpare; // 16-ary: lines per superblock, 2^
 static_assert(kFK == 3 || (UINT64_C(1) << kFSuperLog) * kFusedPos < (UINT64_C(1) << (16 + kFSpare)), "relative counts must fit");
 constexpr uint32_t kFWord2Mask = 0xFFFFu >> kFSpare; // the positions of a section's third word
 
-// line and offset of position i of a fused node's sequence (i < 2^38)
+// line and offset of position i of a fused node's sequence: exact for every 64-bit i (wt_pc.hpp:371-399 is size_type throughout).
+// 16-ary: kFusedPos is a multiple of 8, so below 2^35 the quotient is a 32-bit division by a constant after a shift — the form every
+// walk takes on every text this part has met; positions from 2^35 on (a root node of 32 Gi symbols and more) take the 64-bit
+// division.  kFusedLine32Bits ties the fast path's range to the shift: tests/cpp/fused_addr_check.cpp walks both sides of it.
+constexpr unsigned kFusedLine32Bits = 35; // (i >> 3) fits 32 bits below this
+static_assert(kFK == 3 || kFusedPos % 8 == 0, "the 32-bit form of fused_line divides (i >> 3) by kFusedPos / 8");
 __device__ __host__ __forceinline__ uint64_t fused_line(uint64_t i)
 {
     if constexpr (kFK == 3)
         return i >> 8;
-    else // (kFusedPos is a multiple of 8: a 32-bit division by a constant after the shift)
-        return (uint64_t)((uint32_t)(i >> 3) / (kFusedPos >> 3));
+    else
+    {
+        if (__builtin_expect((i >> kFusedLine32Bits) == 0, 1))
+            return (uint64_t)((uint32_t)(i >> 3) / (kFusedPos >> 3));
+        return i / kFusedPos;
+    }
 }
 __device__ __host__ __forceinline__ unsigned fused_off(uint64_t i, uint64_t line)
 {

@@ -285,3 +285,58 @@ def test_an_index_of_more_than_2_pow_32_symbols_against_the_real_library(gpu):
             csa.drop_sa()
     assert csa.device_bytes() < full_bytes  # (the binary levels stay released)
     csa.close()
+
+
+def test_wt_huff_over_more_than_2_pow_35_symbols(gpu):
+    """Positions from 2^35 on inside ONE node of the fused 16-ary layout: (i >> 3) no longer fits 32 bits there, the form of the
+    line arithmetic that round 5 shipped (wt_device.hpp: fused_line; tests/test_fused_addressing.py is its host-side check).  The
+    sequence is periodic — a unit of P symbols, P prime — so rank / select / access have closed forms:
+        rank(i, c) = (i div P) * occ_c + prefix_c[i mod P],    select(k, c) = ((k - 1) div occ_c) * P + where_c[(k - 1) mod occ_c].
+    The reference is 64-bit throughout (wt_pc.hpp:371-399, 401-474)."""
+    import torch
+    free, total = torch.cuda.mem_get_info()
+    if free < (230 << 30):
+        pytest.skip(f"needs 230 GB of free HBM (text 34 GB + the level sorter's 140 GB), {free >> 30} GB free")
+    P, sigma = 1_000_003, 24
+    n = (1 << 35) + 5 * P + 17
+    rng = np.random.default_rng(35)
+    uh = (1 + np.minimum((rng.random(P) ** 2 * sigma).astype(np.int64), sigma - 1)).astype(np.uint8)   # skewed: codes of several lengths
+    unit = torch.from_numpy(uh).cuda()
+    reps = (n + P - 1) // P
+    text = unit.repeat(reps)[:n].contiguous()
+    assert text.numel() == n
+    wt = gpu.wt_huff(text=text)
+    del text
+    torch.cuda.empty_cache()
+    assert wt.size() == n and wt.sigma() == sigma
+    assert wt.fused_steps().any(), "the fused layout was not built: this test is about its lines"
+    nq = 2_000_000
+    g = torch.Generator(device="cuda").manual_seed(7)
+    i = torch.randint(0, n + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
+    i[:1000] = n - torch.arange(1000, device="cuda")
+    i[1000:3000] = (1 << 35) - 1000 + torch.arange(2000, device="cuda")                    # both sides of 2^35
+    i[3000:5000] = (1 << 32) - 1000 + torch.arange(2000, device="cuda")
+    i[5000:nq // 2] = torch.randint(1 << 35, n + 1, (nq // 2 - 5000,), device="cuda", dtype=torch.int64, generator=g)
+    full, part = i // P, i % P
+    occ_all = np.bincount(uh, minlength=256)
+    for c in (1, 2, sigma // 2, sigma, sigma + 3):
+        pre = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), torch.cumsum((unit == c).to(torch.int64), 0)])
+        want = full * int(occ_all[c]) + pre[part]
+        cc = torch.full((nq,), c, dtype=torch.uint8, device="cuda")
+        got = wt.rank(i, cc).to(torch.int64)
+        assert torch.equal(got, want), f"rank(i, {c}): first difference at i = {int(i[(got != want).nonzero()[0, 0]])}"
+        tot = int(want.new_tensor(n // P * int(occ_all[c])) + pre[n % P])
+        if tot:
+            where = torch.nonzero(unit == c).view(-1)
+            k = torch.randint(1, tot + 1, (nq,), device="cuda", dtype=torch.int64, generator=g)
+            k[:1000] = tot - torch.arange(1000, device="cuda").clamp_(max=tot - 1)
+            want_s = ((k - 1) // int(occ_all[c])) * P + where[(k - 1) % int(occ_all[c])]
+            got_s = wt.select(k, cc).to(torch.int64)
+            assert torch.equal(got_s, want_s), f"select(k, {c})"
+            assert int(want_s.max()) >= (1 << 35)
+    j = i.clamp(max=n - 1)
+    sym = unit[j % P]
+    assert torch.equal(wt.access(j).to(torch.uint8), sym)
+    r = wt.rank(j, sym).to(torch.int64)                      # mixed symbols in one batch; select undoes inverse_select
+    assert torch.equal(wt.select(r + 1, sym).to(torch.int64), j)
+    wt.close()

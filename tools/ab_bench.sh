@@ -5,12 +5,13 @@ L=sdsl-lite_amd/lib
 ARGS=${*:---extras none --no-cpu --steps 8}
 for v in ${VARIANTS:-A B A B}; do
   cp $L/$v.so $L/libsdsl_hip.so
-  python bench.py $ARGS 2>/dev/null | python -c "
+  python bench.py $ARGS --sidecar /tmp/ab_$v.json 2>/dev/null | python -c "
 import json,sys
-j=json.loads(sys.stdin.read()); r=j['roofline']
-print('$v', round(r['kernel_ms_per_step']['median'],3), {k: round(v,3) for k,v in r['phases_ms'].items()}, j['reference_digest_match'])
-for k,v in j.get('extras',{}).items():
-    if isinstance(v,dict) and 'kernel_ms' in v: print('   ',k, round(v['kernel_ms'],3), v.get('phases_ms'))
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']
+print('$v', 'headline kernel ms', round(r['kernel_ms_per_step']['median'],3), 'digest', j['reference_digest_match'])
+sec=j.get('secondary') or {}
+print('    count Mcount/s', sec.get('value'), 'lean', (sec.get('lean') or {}).get('Mcount/s'))
+for k,v in (j.get('summary') or {}).items(): print('   ',k, {a:b for a,b in v.items() if not isinstance(b,bool)})
 "
 done
 cp $L/B.so $L/libsdsl_hip.so
