@@ -157,10 +157,10 @@ sdsl_hip_status sdsl_hip_bv_create_from_sdsl(const void * bytes, size_t len, int
                                              sdsl_hip_bv_t * out);
 sdsl_hip_status sdsl_hip_bv_serialize(sdsl_hip_bv_t bv, int32_t what, void * buf, size_t cap, size_t * written);
 sdsl_hip_status sdsl_hip_bv_destroy(sdsl_hip_bv_t bv);
-/* ONE query, value in, value out: what = 0 rank_<bit>(arg), 1 select_<bit>(arg).  This is what the scalar operator() of
- * the C++ adaptors calls: the argument and the answer travel through a mapped pinned mailbox, so the call costs one
- * kernel launch and one stream synchronisation (about 10 microseconds) — correct, but a loop of such
- * calls is latency-bound: batch whenever there is a loop. */
+/* ONE query, value in, value out: what = 0 rank_<bit>(arg), 1 select_<bit>(arg).  The argument and the answer travel through a
+ * mapped pinned mailbox, so the call costs one kernel launch and one stream synchronisation (about 14 microseconds) — correct, but
+ * never the right thing in a loop.  The C++ adaptors do NOT answer their scalar operator() with it (they forward to the caller's own
+ * SDSL object); it is what their rank_on_device / select_on_device members call, for checking the device image. */
 sdsl_hip_status sdsl_hip_bv_query_one(sdsl_hip_bv_t bv, int32_t what, int32_t bit, uint64_t arg, uint64_t * out);
 /* The bucketed batch paths (large rank / select batches on plain and rrr vectors) work in ONE scratch pool per device, shared by
  * every handle on it and kept between calls: 12 bytes per query of the largest pass so far (at most 2^30 queries' worth) plus

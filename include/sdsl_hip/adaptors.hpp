@@ -15,15 +15,22 @@
 // rank/select/operator(), size(), set_vector, serialize/load writing and reading SDSL's OWN byte
 // format, ==/!=, nested typedefs) so that it satisfies the t_rank / t_select concepts
 // (rank_support_v5.hpp:44-200, select_support_mcl.hpp:64-117, rrr_vector.hpp:455-600).
-// The batch members have no CPU path.  The scalar members of the supports of a plain bit_vector forward to the caller's SDSL
-// (the header includes it anyway: it is the caller's library, not this one's); those of the compressed / tree types, which
-// hold no host-side SDSL object, are one-element batches through a pinned mailbox (about 14 microseconds).  Supports of one
+// The batch members have no CPU path.  SCALAR members never reach the device, for any type (a one-element launch
+// is never the right thing): they forward to the caller's own SDSL object (the header includes SDSL anyway: it is the caller's
+// library, not this one's).  The supports of a plain bit_vector build SDSL's support over the caller's vector on the first scalar
+// call; rrr_vector_hip / sd_vector_hip / wt_huff_hip / csa_wt_hip keep a NON-OWNING pointer to the host object they were
+// constructed from — SDSL's own convention for everything that supports another object (rank_support.hpp:33) — so that object must
+// outlive the adaptor's scalar calls (batch calls only need the device image).  An adaptor that was constructed from something
+// else (plain bits, a position list) loads SDSL's type from the device image's own serialised bytes on the first scalar call
+// (std::call_once).  The old road — a one-element batch through a pinned mailbox, about 14 microseconds — stays as *_on_device
+// members for checking the device image.  Supports of one
 // bit_vector share ONE device replica per device (ref-counted; select directories are added when a select support asks).
 // Errors surface as
 // std::runtime_error carrying sdsl_hip_last_error() (SDSL itself throws std::logic_error /
 // std::bad_alloc on its own failures, memory_management.hpp:907-910).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -181,17 +188,20 @@ inline bv_ptr make_device_bv(bit_vector const * v, int device, uint32_t flags, u
     e.dev = made;
     e.bits = v->bit_size();
     e.print = print;
-    std::lock_guard<std::mutex> lock(R.m);
-    auto hit = R.map.find(key);
-    if (hit != R.map.end() and hit->second.bits == e.bits and hit->second.print == print)
-        if (bv_ptr other = hit->second.dev.lock())
-        { // another thread made the same replica meanwhile: keep one
-            if (flags)
-                check(sdsl_hip_bv_add_select(other.get(), flags), "sdsl_hip_bv_add_select");
-            return other;
-        }
-    R.map[key] = e;
-    return made;
+    bv_ptr other;
+    {
+        std::lock_guard<std::mutex> lock(R.m);
+        auto hit = R.map.find(key);
+        if (hit != R.map.end() and hit->second.bits == e.bits and hit->second.print == print)
+            other = hit->second.dev.lock(); // another thread made the same replica meanwhile: keep one
+        if (!other)
+            R.map[key] = e;
+    }
+    if (!other)
+        return made;
+    if (flags) // (a device build of its own: outside the lock, like the one above)
+        check(sdsl_hip_bv_add_select(other.get(), flags), "sdsl_hip_bv_add_select");
+    return other;
 }
 //! The caller's own SDSL support over the same vector, built when the first scalar query arrives (thread-safe; shared by
 //! copies of the adaptor, which support the same vector)
@@ -206,6 +216,152 @@ struct lazy_host_support
         return *s;
     }
 };
+//! ---- the host side of the compressed / tree adaptors --------------------------------------------------------------------
+//! What a scalar member needs from the caller's SDSL object, behind one virtual call (a nanosecond beside SDSL's 100+ ns for
+//! a rank on rrr_vector<63> or 600 ns for wt.rank on a GiB of text), so that one adaptor class serves every host type it
+//! can be constructed from.
+struct host_bits // rrr_vector<...>, sd_vector<...>: the vector and its four supports
+{
+    virtual ~host_bits() = default;
+    virtual uint64_t rank(uint64_t i, bool b) const = 0;
+    virtual uint64_t select(uint64_t i, bool b) const = 0;
+    virtual bool access(uint64_t i) const = 0;
+    virtual uint64_t get_int(uint64_t i, uint8_t len) const = 0;
+};
+template <class t_vec>
+struct host_bits_of final : host_bits
+{
+    std::unique_ptr<t_vec> owned; // (only when the adaptor was not constructed from a t_vec: loaded from the device image)
+    t_vec const * v;
+    typename t_vec::rank_1_type r1;
+    typename t_vec::rank_0_type r0;
+    typename t_vec::select_1_type s1;
+    typename t_vec::select_0_type s0;
+    explicit host_bits_of(t_vec const * p) : v(p), r1(p), r0(p), s1(p), s0(p)
+    {}
+    explicit host_bits_of(std::unique_ptr<t_vec> o) : owned(std::move(o)), v(owned.get()), r1(v), r0(v), s1(v), s0(v)
+    {}
+    uint64_t rank(uint64_t i, bool b) const override
+    {
+        return b ? r1(i) : r0(i);
+    }
+    uint64_t select(uint64_t i, bool b) const override
+    {
+        return b ? s1(i) : s0(i);
+    }
+    bool access(uint64_t i) const override
+    {
+        return (*v)[i];
+    }
+    uint64_t get_int(uint64_t i, uint8_t len) const override
+    {
+        return v->get_int(i, len);
+    }
+};
+struct host_wt // wt_huff / wt_blcd / wt_hutu over any bit vector
+{
+    virtual ~host_wt() = default;
+    virtual uint64_t rank(uint64_t i, uint8_t c) const = 0;
+    virtual uint64_t select(uint64_t i, uint8_t c) const = 0;
+    virtual uint8_t access(uint64_t i) const = 0;
+    virtual std::pair<uint64_t, uint8_t> inverse_select(uint64_t i) const = 0;
+};
+template <class t_wt>
+struct host_wt_of final : host_wt
+{
+    t_wt const * w;
+    explicit host_wt_of(t_wt const * p) : w(p)
+    {}
+    uint64_t rank(uint64_t i, uint8_t c) const override
+    {
+        return w->rank(i, c);
+    }
+    uint64_t select(uint64_t i, uint8_t c) const override
+    {
+        return w->select(i, c);
+    }
+    uint8_t access(uint64_t i) const override
+    {
+        return (uint8_t)(*w)[i];
+    }
+    std::pair<uint64_t, uint8_t> inverse_select(uint64_t i) const override
+    {
+        auto r = w->inverse_select(i);
+        return std::make_pair((uint64_t)r.first, (uint8_t)r.second);
+    }
+};
+struct host_csa // csa_wt<...>: csa[i] and the one-pattern forms of count / locate / extract
+{
+    virtual ~host_csa() = default;
+    virtual uint64_t sa(uint64_t i) const = 0;
+    virtual uint64_t count(uint8_t const * p, size_t m) const = 0;
+    virtual std::vector<uint64_t> locate(uint8_t const * p, size_t m) const = 0;
+    virtual std::string extract(uint64_t begin, uint64_t end) const = 0;
+};
+template <class t_csa>
+struct host_csa_of final : host_csa
+{
+    t_csa const * c;
+    explicit host_csa_of(t_csa const * p) : c(p)
+    {}
+    uint64_t sa(uint64_t i) const override
+    {
+        return (*c)[i];
+    }
+    uint64_t count(uint8_t const * p, size_t m) const override
+    {
+        return sdsl::count(*c, p, p + m);
+    }
+    std::vector<uint64_t> locate(uint8_t const * p, size_t m) const override
+    {
+        auto occ = sdsl::locate(*c, p, p + m);
+        return std::vector<uint64_t>(occ.begin(), occ.end());
+    }
+    std::string extract(uint64_t begin, uint64_t end) const override
+    {
+        auto t = sdsl::extract(*c, begin, end);
+        return std::string(t.begin(), t.end());
+    }
+};
+//! made when the first scalar call arrives (thread-safe; copies of an adaptor share it)
+template <class t_iface>
+struct lazy_host
+{
+    std::once_flag once;
+    std::function<std::unique_ptr<t_iface>()> make;
+    std::unique_ptr<t_iface> h;
+    explicit lazy_host(std::function<std::unique_ptr<t_iface>()> f) : make(std::move(f))
+    {}
+    t_iface const & get()
+    {
+        std::call_once(once, [&] {
+            h = make();
+            make = nullptr;
+        });
+        return *h;
+    }
+};
+template <class t_iface>
+inline t_iface const & host_of(std::shared_ptr<lazy_host<t_iface>> const & h, char const * who)
+{
+    if (!h)
+        throw std::runtime_error(std::string(who) + ": scalar call on an adaptor without a host object (default-constructed)");
+    return h->get();
+}
+//! SDSL's type loaded from the bytes the device image serialises to (they are SDSL's own format)
+template <class t_vec, class t_serialize>
+inline std::unique_ptr<t_vec> load_from_device(t_serialize && serialize, char const * what)
+{
+    size_t len = 0;
+    (void)serialize((void *)nullptr, (size_t)0, &len); // size query
+    std::string bytes(len, 0);
+    check(serialize((void *)&bytes[0], len, &len), what);
+    std::istringstream iss(bytes);
+    std::istream & in = iss; // (an istringstream lvalue would select the cereal overload of load)
+    std::unique_ptr<t_vec> v(new t_vec());
+    v->load(in);
+    return v;
+}
 constexpr bool pattern_ok(unsigned t_b, unsigned t_pat_len)
 {
     return (t_pat_len == 1 and t_b <= 1) or (t_pat_len == 2 and (t_b == 10 or t_b == 01 or t_b == 00 or t_b == 11));
@@ -644,6 +800,9 @@ public:
 
 //! Device image of an rrr_vector<63> (rrr_vector.hpp:68) built from the host object's own serialised
 //! arrays; exposes the rank/select/access members of rank_support_rrr / select_support_rrr in batch form.
+//! Scalar members (operator[], get_int, and rank / select of the supports below) are answered by the HOST object the adaptor was
+//! constructed from (non-owning pointer: it must outlive those calls); constructed from plain bits, the adaptor loads an
+//! rrr_vector<63> from the device image's serialised bytes when the first scalar call arrives.
 class rrr_vector_hip
 {
 public:
@@ -658,7 +817,16 @@ private:
             sdsl_hip_rrr_destroy(p);
         }
     };
+    typedef hip_detail::lazy_host<hip_detail::host_bits> lazy_type;
     std::shared_ptr<sdsl_hip_rrr_s> m_dev;
+    std::shared_ptr<lazy_type> m_host;
+
+    template <class t_vec>
+    void host_is(t_vec const * v)
+    {
+        m_host = std::make_shared<lazy_type>(
+            [v] { return std::unique_ptr<hip_detail::host_bits>(new hip_detail::host_bits_of<t_vec>(v)); });
+    }
 
 public:
     rrr_vector_hip() = default;
@@ -668,18 +836,29 @@ public:
         sdsl_hip_rrr_t h = nullptr;
         hip_detail::check(sdsl_hip_rrr_create_from_sdsl(s.data(), s.size(), device, &h), "sdsl_hip_rrr_create_from_sdsl");
         m_dev.reset(h, deleter());
+        host_is(&v);
     }
+    //! from plain bits (no pointer to `bv` is kept: the host side, if a scalar call ever asks for it, is the rrr_vector<63> the
+    //! device image serialises to)
     explicit rrr_vector_hip(bit_vector const & bv, int device = 0)
     {
         sdsl_hip_rrr_t h = nullptr;
         hip_detail::check(sdsl_hip_rrr_create(bv.data(), bv.bit_size(), device, &h), "sdsl_hip_rrr_create");
         m_dev.reset(h, deleter());
+        std::shared_ptr<sdsl_hip_rrr_s> dev = m_dev;
+        m_host = std::make_shared<lazy_type>([dev] {
+            auto ser = [&](void * buf, size_t cap, size_t * len) { return sdsl_hip_rrr_serialize(dev.get(), buf, cap, len); };
+            return std::unique_ptr<hip_detail::host_bits>(
+                new hip_detail::host_bits_of<host_type>(hip_detail::load_from_device<host_type>(ser, "sdsl_hip_rrr_serialize")));
+        });
     }
     //! any other rrr_vector<t_bs, t_rac, t_k> (block sizes 15, 31, 127, ..., other sample rates): the device keeps its
     //! own layout (block size 63), so the vector is handed over through its plain bits — the answers are the same
     template <uint16_t t_bs, class t_rac, uint16_t t_k>
     explicit rrr_vector_hip(rrr_vector<t_bs, t_rac, t_k> const & v, int device = 0) : rrr_vector_hip(to_bit_vector(v), device)
-    {}
+    {
+        host_is(&v); // scalar calls: the caller's own vector
+    }
     size_type size() const
     {
         return sdsl_hip_rrr_size(m_dev.get());
@@ -708,13 +887,27 @@ public:
     {
         hip_detail::check(sdsl_hip_rrr_get_int_batch(m_dev.get(), idx, len, n, out, stream), "sdsl_hip_rrr_get_int_batch");
     }
+    //! the host side of the scalar members
+    hip_detail::host_bits const & host() const
+    {
+        return hip_detail::host_of(m_host, "rrr_vector_hip");
+    }
     uint64_t get_int(size_type idx, uint8_t len = 64) const
+    {
+        return host().get_int(idx, len);
+    }
+    bool operator[](size_type i) const
+    {
+        return host().access(i);
+    }
+    //! the same through the device (one launch + one synchronisation each): for checking the device image
+    uint64_t get_int_on_device(size_type idx, uint8_t len = 64) const
     {
         uint64_t r = 0;
         get_int_batch(&idx, len, 1, &r);
         return r;
     }
-    bool operator[](size_type i) const
+    bool access_on_device(size_type i) const
     {
         uint8_t b = 0;
         access_batch(&i, 1, &b);
@@ -733,7 +926,12 @@ public:
     typedef rrr_vector_hip::size_type size_type;
     explicit rank_support_rrr_hip(rrr_vector_hip const * v = nullptr) : m_v(v)
     {}
+    //! answered by the host vector's own rank_support_rrr (rrr_vector.hpp:503-544)
     size_type rank(size_type i) const
+    {
+        return m_v->host().rank(i, t_b != 0);
+    }
+    size_type rank_on_device(size_type i) const
     {
         size_type r = 0;
         m_v->rank_batch<t_b>(&i, 1, &r);
@@ -768,7 +966,12 @@ public:
     typedef rrr_vector_hip::size_type size_type;
     explicit select_support_rrr_hip(rrr_vector_hip const * v = nullptr) : m_v(v)
     {}
+    //! answered by the host vector's own select_support_rrr (rrr_vector.hpp:602)
     size_type select(size_type i) const
+    {
+        return m_v->host().select(i, t_b != 0);
+    }
+    size_type select_on_device(size_type i) const
     {
         size_type r = 0;
         m_v->select_batch<t_b>(&i, 1, &r);
@@ -794,6 +997,8 @@ public:
 
 //! Device image of an sd_vector<> (sd_vector.hpp:134), built from the host object's own serialised arrays, from a
 //! plain bit_vector or from a sorted position list; rank_support_sd / select_support_sd members in batch form.
+//! Scalar members: the host sd_vector<> the adaptor was constructed from (non-owning pointer), else an sd_vector<> loaded from
+//! the device image's serialised bytes on the first scalar call.
 class sd_vector_hip
 {
 public:
@@ -808,7 +1013,19 @@ private:
             sdsl_hip_sd_destroy(p);
         }
     };
+    typedef hip_detail::lazy_host<hip_detail::host_bits> lazy_type;
     std::shared_ptr<sdsl_hip_sd_s> m_dev;
+    std::shared_ptr<lazy_type> m_host;
+
+    void host_from_device()
+    {
+        std::shared_ptr<sdsl_hip_sd_s> dev = m_dev;
+        m_host = std::make_shared<lazy_type>([dev] {
+            auto ser = [&](void * buf, size_t cap, size_t * len) { return sdsl_hip_sd_serialize(dev.get(), buf, cap, len); };
+            return std::unique_ptr<hip_detail::host_bits>(
+                new hip_detail::host_bits_of<host_type>(hip_detail::load_from_device<host_type>(ser, "sdsl_hip_sd_serialize")));
+        });
+    }
 
 public:
     sd_vector_hip() = default;
@@ -818,12 +1035,16 @@ public:
         sdsl_hip_sd_t h = nullptr;
         hip_detail::check(sdsl_hip_sd_create_from_sdsl(s.data(), s.size(), device, &h, nullptr), "sdsl_hip_sd_create_from_sdsl");
         m_dev.reset(h, deleter());
+        host_type const * p = &v;
+        m_host = std::make_shared<lazy_type>(
+            [p] { return std::unique_ptr<hip_detail::host_bits>(new hip_detail::host_bits_of<host_type>(p)); });
     }
     explicit sd_vector_hip(bit_vector const & bv, int device = 0)
     {
         sdsl_hip_sd_t h = nullptr;
         hip_detail::check(sdsl_hip_sd_create(bv.data(), bv.bit_size(), device, &h), "sdsl_hip_sd_create");
         m_dev.reset(h, deleter());
+        host_from_device();
     }
     //! strictly increasing positions of the ones and the size of the vector (sd_vector_builder's arguments)
     sd_vector_hip(uint64_t const * positions, size_t m, size_type n, int device = 0)
@@ -831,6 +1052,7 @@ public:
         sdsl_hip_sd_t h = nullptr;
         hip_detail::check(sdsl_hip_sd_create_from_positions(positions, m, n, device, &h), "sdsl_hip_sd_create_from_positions");
         m_dev.reset(h, deleter());
+        host_from_device();
     }
     size_type size() const
     {
@@ -850,7 +1072,15 @@ public:
     {
         hip_detail::check(sdsl_hip_sd_access_batch(m_dev.get(), i, n, out, stream), "sdsl_hip_sd_access_batch");
     }
+    hip_detail::host_bits const & host() const
+    {
+        return hip_detail::host_of(m_host, "sd_vector_hip");
+    }
     bool operator[](size_type i) const
+    {
+        return host().access(i);
+    }
+    bool access_on_device(size_type i) const
     {
         uint8_t b = 0;
         access_batch(&i, 1, &b);
@@ -869,7 +1099,12 @@ public:
     typedef sd_vector_hip::size_type size_type;
     explicit rank_support_sd_hip(sd_vector_hip const * v = nullptr) : m_v(v)
     {}
+    //! answered by the host vector's own rank_support_sd (sd_vector.hpp:527)
     size_type rank(size_type i) const
+    {
+        return m_v->host().rank(i, t_b != 0);
+    }
+    size_type rank_on_device(size_type i) const
     {
         size_type r = 0;
         m_v->rank_batch<t_b>(&i, 1, &r);
@@ -904,7 +1139,12 @@ public:
     typedef sd_vector_hip::size_type size_type;
     explicit select_support_sd_hip(sd_vector_hip const * v = nullptr) : m_v(v)
     {}
+    //! answered by the host vector's own select_support_sd (sd_vector.hpp:676)
     size_type select(size_type i) const
+    {
+        return m_v->host().select(i, t_b != 0);
+    }
+    size_type select_on_device(size_type i) const
     {
         size_type r = 0;
         m_v->select_batch<t_b>(&i, 1, &r);
@@ -947,10 +1187,14 @@ private:
             sdsl_hip_wt_destroy(p);
         }
     };
+    typedef hip_detail::lazy_host<hip_detail::host_wt> lazy_type;
     std::shared_ptr<sdsl_hip_wt_s> m_dev;
+    std::shared_ptr<lazy_type> m_host;
 
 public:
     wt_huff_hip() = default;
+    //! `wt` is the caller's tree: the device image is made from its serialised bytes, the scalar members below forward to it
+    //! through a non-owning pointer (it must outlive them, as a bit_vector outlives its supports: rank_support.hpp:33)
     template <class t_wt>
     explicit wt_huff_hip(t_wt const & wt, int layout, int device = 0)
     {
@@ -960,16 +1204,22 @@ public:
         hip_detail::check(sdsl_hip_wt_create_from_sdsl(s.data(), s.size(), layout, device, &h, &used),
                           "sdsl_hip_wt_create_from_sdsl");
         m_dev.reset(h, deleter());
+        t_wt const * p = &wt;
+        m_host = std::make_shared<lazy_type>(
+            [p] { return std::unique_ptr<hip_detail::host_wt>(new hip_detail::host_wt_of<t_wt>(p)); });
     }
     size_type size() const
     {
         return sdsl_hip_wt_size(m_dev.get());
     }
+    hip_detail::host_wt const & host() const
+    {
+        return hip_detail::host_of(m_host, "wt_huff_hip");
+    }
+    //! wt.rank(i, c) (wt_pc.hpp:371-399), one query: the host tree's own walk
     size_type rank(size_type i, value_type c) const
     {
-        size_type r = 0;
-        rank_batch(&i, &c, 1, &r);
-        return r;
+        return host().rank(i, c);
     }
     //! out[q] = wt.rank(i[q], c[q])   (wt_pc.hpp:371-399)
     void rank_batch(size_type const * i, value_type const * c, size_t n, size_type * out, void * stream = nullptr) const
@@ -982,9 +1232,7 @@ public:
     }
     value_type operator[](size_type i) const
     {
-        value_type c = 0;
-        access_batch(&i, 1, &c);
-        return c;
+        return host().access(i);
     }
     void select_batch(size_type const * i, value_type const * c, size_t n, size_type * out, void * stream = nullptr) const
     {
@@ -992,11 +1240,32 @@ public:
     }
     size_type select(size_type i, value_type c) const
     {
+        return host().select(i, c);
+    }
+    std::pair<size_type, value_type> inverse_select(size_type i) const
+    {
+        return host().inverse_select(i);
+    }
+    //! the same queries through the device (one launch + one synchronisation each): for checking the device image
+    size_type rank_on_device(size_type i, value_type c) const
+    {
+        size_type r = 0;
+        rank_batch(&i, &c, 1, &r);
+        return r;
+    }
+    value_type access_on_device(size_type i) const
+    {
+        value_type c = 0;
+        access_batch(&i, 1, &c);
+        return c;
+    }
+    size_type select_on_device(size_type i, value_type c) const
+    {
         size_type r = 0;
         select_batch(&i, &c, 1, &r);
         return r;
     }
-    std::pair<size_type, value_type> inverse_select(size_type i) const
+    std::pair<size_type, value_type> inverse_select_on_device(size_type i) const
     {
         size_type r = 0;
         value_type c = 0;
@@ -1006,7 +1275,8 @@ public:
     }
 };
 
-//! Device image of a csa_wt over such a wavelet tree, restricted to backward_search / count.
+//! Device image of a csa_wt over such a wavelet tree.  Scalar forms — csa[i], count / locate / extract of ONE pattern or range —
+//! are answered by the caller's csa_wt (non-owning pointer, as above); the batch forms by the device.
 class csa_wt_hip
 {
 public:
@@ -1020,7 +1290,9 @@ private:
             sdsl_hip_fm_destroy(p);
         }
     };
+    typedef hip_detail::lazy_host<hip_detail::host_csa> lazy_type;
     std::shared_ptr<sdsl_hip_fm_s> m_dev;
+    std::shared_ptr<lazy_type> m_host;
 
 public:
     csa_wt_hip() = default;
@@ -1031,18 +1303,29 @@ public:
         std::string s = hip_detail::to_stream(csa);
         sdsl_hip_fm_t h = nullptr;
         // the densities are template arguments of the host type, not part of its stream: hand them over so that the
-        // SA / ISA samples are kept and operator[], isa, locate, extract work on the device
+        // SA / ISA samples are kept and sa_batch, isa_batch, locate_batch, extract_batch work on the device
         hip_detail::check(sdsl_hip_fm_create_from_sdsl_ex(s.data(), s.size(), layout, t_csa::sa_sample_dens,
                                                           t_csa::isa_sample_dens, device, &h),
                           "sdsl_hip_fm_create_from_sdsl_ex");
         m_dev.reset(h, deleter());
+        t_csa const * p = &csa;
+        m_host = std::make_shared<lazy_type>(
+            [p] { return std::unique_ptr<hip_detail::host_csa>(new hip_detail::host_csa_of<t_csa>(p)); });
     }
     size_type size() const
     {
         return sdsl_hip_fm_size(m_dev.get());
     }
-    //! csa[i] (csa_wt.hpp:363-381); one-element batch — use sa_batch in loops
+    hip_detail::host_csa const & host() const
+    {
+        return hip_detail::host_of(m_host, "csa_wt_hip");
+    }
+    //! csa[i] (csa_wt.hpp:363-381): the host index's own walk — use sa_batch for many
     size_type operator[](size_type i) const
+    {
+        return host().sa(i);
+    }
+    size_type sa_on_device(size_type i) const
     {
         size_type r = 0;
         sa_batch(&i, 1, &r);
@@ -1099,9 +1382,17 @@ inline void count_batch(csa_wt_hip const & csa, uint8_t const * patterns, uint32
 {
     hip_detail::check(sdsl_hip_fm_count_batch(csa.handle(), patterns, m, n, out, stream), "sdsl_hip_fm_count_batch");
 }
-//! sdsl::count for one pattern, the reference's own call shape
+//! sdsl::count for one pattern, the reference's own call shape: answered by the caller's own csa_wt (one pattern is no batch)
 template <class t_pat_iter>
 inline uint64_t count(csa_wt_hip const & csa, t_pat_iter begin, t_pat_iter end)
+{
+    std::vector<uint8_t> p(begin, end);
+    uint8_t dummy = 0;
+    return csa.host().count(p.empty() ? &dummy : p.data(), p.size());
+}
+//! the same through the device (a ragged batch of one): for checking the device image
+template <class t_pat_iter>
+inline uint64_t count_on_device(csa_wt_hip const & csa, t_pat_iter begin, t_pat_iter end)
 {
     std::vector<uint8_t> p(begin, end);
     uint64_t offs[2] = {0, p.size()}, r = 0;
@@ -1129,9 +1420,17 @@ inline void locate_batch(csa_wt_hip const & csa, uint8_t const * patterns, uint3
                                                      &total, nullptr),
                           "sdsl_hip_fm_sa_range_batch");
 }
-//! sdsl::locate for one pattern, the reference's own call shape
+//! sdsl::locate for one pattern, the reference's own call shape: the caller's own csa_wt answers
 template <class t_pat_iter>
 inline std::vector<uint64_t> locate(csa_wt_hip const & csa, t_pat_iter begin, t_pat_iter end)
+{
+    std::vector<uint8_t> p(begin, end);
+    uint8_t dummy = 0;
+    return csa.host().locate(p.empty() ? &dummy : p.data(), p.size());
+}
+//! the same through the device
+template <class t_pat_iter>
+inline std::vector<uint64_t> locate_on_device(csa_wt_hip const & csa, t_pat_iter begin, t_pat_iter end)
 {
     std::vector<uint8_t> p(begin, end);
     std::vector<uint64_t> off, pos;
@@ -1163,8 +1462,13 @@ inline void extract_batch(csa_wt_hip const & csa, uint64_t const * begin, uint64
                                                     nullptr),
                           "sdsl_hip_fm_extract_batch");
 }
-//! sdsl::extract for one range, the reference's own call shape (returns the string)
+//! sdsl::extract for one range, the reference's own call shape (returns the string): the caller's own csa_wt answers
 inline std::string extract(csa_wt_hip const & csa, uint64_t begin, uint64_t end)
+{
+    return csa.host().extract(begin, end);
+}
+//! the same through the device
+inline std::string extract_on_device(csa_wt_hip const & csa, uint64_t begin, uint64_t end)
 {
     std::vector<uint64_t> off;
     std::vector<uint8_t> t;

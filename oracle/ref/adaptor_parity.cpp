@@ -129,7 +129,7 @@ int main(int argc, char ** argv)
                     if (ones)
                     {
                         uint64_t k = 1 + rng() % ones;
-                        ok &= hsel(k) == r15s(k);
+                        ok &= hsel(k) == r15s(k) and (t >= 20 or hsel.select_on_device(k) == r15s(k));
                     }
                 }
                 CHECK(ok, "rank on bit_vector_il<512>, select on rrr_vector<15> through their bits");
@@ -212,7 +212,27 @@ int main(int argc, char ** argv)
                         ok &= o[k] == ss0(a[k]);
                 }
                 CHECK(ok, "select_support_sd<1> / <0>");
-                CHECK(dsv[n / 2] == sv[n / 2] and dsv.size() == sv.size(), "sd_vector::operator[] / size");
+                CHECK(dsv[n / 2] == sv[n / 2] and dsv.access_on_device(n / 2) == sv[n / 2] and dsv.size() == sv.size(),
+                      "sd_vector::operator[] (host) / access_on_device / size");
+                // scalar members: the host object (dsv: the caller's sd_vector; dsv2, made from plain bits: an sd_vector<> loaded from
+                // the device image's own bytes) — and the same queries through the device
+                bool oksc = true;
+                for (int t = 0; t < 40; ++t)
+                {
+                    uint64_t x = rng() % (n + 1);
+                    oksc &= hr1(x) == sr1(x) and hr0(x) == sr0(x) and hr1.rank_on_device(x) == sr1(x) and hr0.rank_on_device(x) == sr0(x);
+                    if (ones)
+                    {
+                        uint64_t k = 1 + rng() % ones;
+                        oksc &= hs1(k) == ss1(k) and hs1.select_on_device(k) == ss1(k);
+                    }
+                    if (n - ones)
+                    {
+                        uint64_t k = 1 + rng() % (n - ones);
+                        oksc &= hs0(k) == ss0(k) and hs0.select_on_device(k) == ss0(k);
+                    }
+                }
+                CHECK(oksc, "sd supports: scalar calls (host) and *_on_device agree with sd_vector<>'s supports");
             }
             // rrr_vector<63>
             rrr_vector<63> rv(bv);
@@ -246,7 +266,31 @@ int main(int argc, char ** argv)
             for (size_t k = 0; k < q; ++k)
                 ok &= o[k] == s0(a[k]);
             CHECK(ok, "select_support_rrr<0,63>");
-            CHECK(dv[n / 2] == rv[n / 2], "rrr operator[]");
+            CHECK(dv[n / 2] == rv[n / 2] and dv.access_on_device(n / 2) == rv[n / 2] and dv2[n / 2] == rv[n / 2], "rrr operator[] (host) / access_on_device");
+            {
+                bool oksc = true;
+                for (int t = 0; t < 40; ++t)
+                {
+                    uint64_t x = rng() % (n + 1);
+                    oksc &= hr1(x) == r1(x) and hr1.rank_on_device(x) == r1(x);
+                    if (ones)
+                    {
+                        uint64_t k = 1 + rng() % ones;
+                        oksc &= hs1(k) == s1(k) and hs1.select_on_device(k) == s1(k);
+                    }
+                    if (n - ones)
+                    {
+                        uint64_t k = 1 + rng() % (n - ones);
+                        oksc &= hs0(k) == s0(k) and hs0.select_on_device(k) == s0(k);
+                    }
+                    if (n >= 64)
+                    {
+                        uint64_t y = rng() % (n - 63);
+                        oksc &= dv.get_int(y, 64) == rv.get_int(y, 64) and dv.get_int_on_device(y, 37) == rv.get_int(y, 37) and dv2.get_int(y, 64) == rv.get_int(y, 64);
+                    }
+                }
+                CHECK(oksc, "rrr supports: scalar calls (host: the caller's vector, or one loaded from the device image) and *_on_device");
+            }
             // encoded on the GPU, loaded into an unmodified rrr_vector<63>
             {
                 sdsl_hip_rrr_t h = nullptr;
@@ -295,8 +339,11 @@ int main(int argc, char ** argv)
             ok &= o[k] == wt.rank(i[k], c[k]);
         CHECK(ok, "wt_huff::rank");
         uint64_t p = bytes.size() / 3;
-        CHECK(dw[p] == wt[p] and dw.inverse_select(p) == wt.inverse_select(p), "wt_huff::operator[] / inverse_select");
-        CHECK(dw.select(1, bytes[p]) == wt.select(1, bytes[p]), "wt_huff::select");
+        CHECK(dw[p] == wt[p] and dw.inverse_select(p) == wt.inverse_select(p), "wt_huff::operator[] / inverse_select (host)");
+        CHECK(dw.select(1, bytes[p]) == wt.select(1, bytes[p]) and dw.rank(p, bytes[p]) == wt.rank(p, bytes[p]), "wt_huff::select / rank (host)");
+        CHECK(dw.access_on_device(p) == wt[p] and dw.inverse_select_on_device(p) == wt.inverse_select(p) and
+                  dw.select_on_device(1, bytes[p]) == wt.select(1, bytes[p]) and dw.rank_on_device(p, bytes[p]) == wt.rank(p, bytes[p]),
+              "wt_huff: the same scalar queries through the device");
         // the compressed flavour through the same adaptor
         wt_huff<rrr_vector<63>> wr(bytes.begin(), bytes.end());
         wt_huff_hip dr(wr, SDSL_HIP_LAYOUT_RRR63);
@@ -305,7 +352,9 @@ int main(int argc, char ** argv)
         for (size_t k = 0; k < q; ++k)
             okr &= o[k] == wr.rank(i[k], c[k]);
         CHECK(okr, "wt_huff<rrr_vector<63>>::rank");
-        CHECK(dr[p] == wr[p] and dr.inverse_select(p) == wr.inverse_select(p), "wt_huff<rrr>::operator[] / inverse_select");
+        CHECK(dr[p] == wr[p] and dr.inverse_select(p) == wr.inverse_select(p) and dr.access_on_device(p) == wr[p] and
+                  dr.inverse_select_on_device(p) == wr.inverse_select(p),
+              "wt_huff<rrr>::operator[] / inverse_select (host and device)");
         std::vector<uint64_t> si(q);
         std::vector<uint8_t> sc(q);
         for (size_t k = 0; k < q; ++k)
@@ -330,7 +379,70 @@ int main(int argc, char ** argv)
             oks &= o[k] == wb.rank(i[k], c[k]) and o2[k] == wh.rank(i[k], c[k]);
         CHECK(oks, "wt_blcd::rank / wt_hutu::rank");
         CHECK(db[p] == wb[p] and dh.inverse_select(p) == wh.inverse_select(p) and db.select(2, bytes[p]) == wb.select(2, bytes[p]),
-              "wt_blcd / wt_hutu access, inverse_select, select");
+              "wt_blcd / wt_hutu access, inverse_select, select (host)");
+        CHECK(db.access_on_device(p) == wb[p] and dh.inverse_select_on_device(p) == wh.inverse_select(p) and
+                  db.select_on_device(2, bytes[p]) == wb.select(2, bytes[p]),
+              "wt_blcd / wt_hutu access, inverse_select, select (device)");
+        // what a scalar call costs through the adaptors of the compressed / tree types: 10^6 wt.rank and 10^6
+        // rank on an rrr_vector<63>, one at a time, against the unmodified objects — the adaptor forwards to them
+        {
+            const size_t nq = 1000000;
+            std::vector<uint64_t> qi(nq);
+            std::vector<uint8_t> qc(nq);
+            for (size_t k = 0; k < nq; ++k)
+            {
+                qi[k] = rng() % (bytes.size() + 1);
+                qc[k] = bytes[rng() % bytes.size()];
+            }
+            bit_vector big(1 << 26, 0);
+            for (uint64_t x = 0; x < big.size(); x += 1 + rng() % 40)
+                big[x] = 1;
+            rrr_vector<63> brv(big);
+            rrr_vector<63>::rank_1_type br1(&brv);
+            rrr_vector_hip bdv(brv);
+            rank_support_rrr_hip<1> bhr(&bdv);
+            std::vector<uint64_t> qr(nq);
+            for (auto & x : qr)
+                x = rng() % (big.size() + 1);
+            (void)dw.rank(qi[0], qc[0]);
+            (void)bhr(qr[0]);
+            double ns_wt = 1e30, ns_wt_ref = 1e30, ns_rrr = 1e30, ns_rrr_ref = 1e30;
+            uint64_t s_a = 0, s_b = 0, s_c = 0, s_d = 0;
+            for (int rep = 0; rep < 5; ++rep)
+            { // (best of five passes each, interleaved: the box's CPUs are shared)
+                auto t0 = std::chrono::steady_clock::now();
+                s_a = 0;
+                for (size_t k = 0; k < nq; ++k)
+                    s_a += dw.rank(qi[k], qc[k]);
+                ns_wt = std::min(ns_wt, std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq);
+                t0 = std::chrono::steady_clock::now();
+                s_b = 0;
+                for (size_t k = 0; k < nq; ++k)
+                    s_b += wt.rank(qi[k], qc[k]);
+                ns_wt_ref = std::min(ns_wt_ref, std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq);
+                t0 = std::chrono::steady_clock::now();
+                s_c = 0;
+                for (size_t k = 0; k < nq; ++k)
+                    s_c += bhr(qr[k]);
+                ns_rrr = std::min(ns_rrr, std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq);
+                t0 = std::chrono::steady_clock::now();
+                s_d = 0;
+                for (size_t k = 0; k < nq; ++k)
+                    s_d += br1(qr[k]);
+                ns_rrr_ref = std::min(ns_rrr_ref, std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / nq);
+            }
+            auto t0 = std::chrono::steady_clock::now();
+            uint64_t s_dev = 0;
+            for (size_t k = 0; k < 2000; ++k)
+                s_dev += dw.rank_on_device(qi[k], qc[k]);
+            const double us_dev = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 2000;
+            CHECK(s_a == s_b and s_c == s_d, "scalar loops through wt_huff_hip / rank_support_rrr_hip sum like the reference objects");
+            printf("scalar wt.rank(i, c), 10^6 calls: %.1f ns per call through wt_huff_hip (wt_huff<> itself: %.1f ns; through the device: %.2f us); "
+                   "scalar rank on rrr_vector<63> (2^26 bits), 10^6 calls: %.1f ns through rank_support_rrr_hip (rank_support_rrr<1, 63> itself: %.1f ns)\n",
+                   ns_wt, ns_wt_ref, us_dev, ns_rrr, ns_rrr_ref);
+            CHECK(ns_wt <= 1.3 * ns_wt_ref + 5.0, "a scalar wt.rank loop through the adaptor runs within 1.3x of wt_huff<>");
+            CHECK(ns_rrr <= 1.3 * ns_rrr_ref + 5.0, "a scalar rank loop through rank_support_rrr_hip runs within 1.3x of rank_support_rrr<1, 63>");
+        }
     }
     {
         csa_t csa;
@@ -360,7 +472,8 @@ int main(int argc, char ** argv)
         }
         CHECK(ok, "count(csa_wt)");
         std::string und = "sea";
-        CHECK(count(d1, und.begin(), und.end()) == count(csa, und.begin(), und.end()), "count single");
+        CHECK(count(d1, und.begin(), und.end()) == count(csa, und.begin(), und.end()), "count single (host)");
+        CHECK(count_on_device(d1, und.begin(), und.end()) == count(csa, und.begin(), und.end()), "count single (device)");
         CHECK(d1.size() == csa.size(), "csa size");
         // the rest of the API on the default-density index (samples travel with the adaptor)
         {
@@ -384,7 +497,7 @@ int main(int argc, char ** argv)
             for (size_t k = 0; k < qq; ++k)
                 oks &= o[k] == csa.psi[idx[k]];
             CHECK(oks, "csa.lf[] / csa.psi[]");
-            CHECK(d1[7] == csa[7], "csa_wt_hip::operator[]");
+            CHECK(d1[7] == csa[7] and d1.sa_on_device(7) == csa[7], "csa_wt_hip::operator[] (host) / sa_on_device");
             std::vector<uint64_t> off, pos;
             locate_batch(d1, pats.data(), m, 200, off, pos);
             bool okl = off.size() == 201;
@@ -396,11 +509,13 @@ int main(int argc, char ** argv)
                     okl &= ref[t] == pos[off[k] + t];
             }
             CHECK(okl, "locate(csa_wt)");
-            auto one = locate(d1, und.begin(), und.end());
+            auto one = locate_on_device(d1, und.begin(), und.end());
+            auto one_host = locate(d1, und.begin(), und.end());
             auto one_ref = locate(csa, und.begin(), und.end());
-            CHECK(one.size() == one_ref.size() and std::equal(one.begin(), one.end(), one_ref.begin()), "locate single");
-            CHECK(extract(d1, 10, 60) == extract(csa, 10, 60), "extract(csa_wt)");
-            CHECK(extract(d1, csa.size() - 3, csa.size() - 1) == extract(csa, csa.size() - 3, csa.size() - 1),
+            CHECK(one.size() == one_ref.size() and std::equal(one.begin(), one.end(), one_ref.begin()), "locate single (device)");
+            CHECK(one_host.size() == one_ref.size() and std::equal(one_host.begin(), one_host.end(), one_ref.begin()), "locate single (host)");
+            CHECK(extract_on_device(d1, 10, 60) == extract(csa, 10, 60) and extract(d1, 10, 60) == extract(csa, 10, 60), "extract(csa_wt)");
+            CHECK(extract_on_device(d1, csa.size() - 3, csa.size() - 1) == extract(csa, csa.size() - 3, csa.size() - 1),
                   "extract at the end (sentinel included)");
         }
         // the same device image with everything HBM offers (suffix array, text, k-mer table) and back at the host type's footprint
@@ -411,7 +526,7 @@ int main(int argc, char ** argv)
             std::vector<uint64_t> o4(q);
             count_batch(d1, pats.data(), m, q, o4.data());
             CHECK(o4 == o1, "count after restore_suffix_array");
-            CHECK(extract(d1, 10, 60) == extract(csa, 10, 60), "extract from the resident text");
+            CHECK(extract_on_device(d1, 10, 60) == extract(csa, 10, 60), "extract from the resident text");
             // (what the image took as loaded from the stream is always reachable; on a text of a GiB the floor is 1.1 x stream_bytes,
             // on this small one the fixed tables weigh more)
             d1.set_footprint(as_loaded);
@@ -419,7 +534,7 @@ int main(int argc, char ** argv)
             (void)stream_bytes;
             count_batch(d1, pats.data(), m, q, o4.data());
             CHECK(o4 == o1, "count at the reduced footprint");
-            CHECK(d1[7] == csa[7] and extract(d1, 10, 60) == extract(csa, 10, 60), "csa[i] / extract at the reduced footprint");
+            CHECK(d1.sa_on_device(7) == csa[7] and extract_on_device(d1, 10, 60) == extract(csa, 10, 60), "csa[i] / extract at the reduced footprint");
         }
         // SDSL's README index family: csa_wt<wt_huff<rrr_vector<63>>>
         {
