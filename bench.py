@@ -234,7 +234,8 @@ def summary_of(ex):
                         ("wt_huff_select", ("Gq/s", "reference_digest_match")),
                         ("sd_vector", ("rank_1_Gq/s", "select_1_Gq/s", "select_0_Gq/s")),
                         ("fm_sa_access_dens32", ("Msa/s",)), ("fm_extract_64B", ("GB/s", "long_ranges_GB/s", "with_text_resident_GB/s")),
-                        ("fm_locate_dens32", ("Gocc/s",)), ("fm_count_rrr63", ("Mcount/s",))):
+                        ("fm_locate_dens32", ("Gocc/s",)), ("fm_count_rrr63", ("Mcount/s", "x_sdsl_stream_bytes")),
+                        ("fm_count_rrr63_lean", ("Mcount/s", "x_sdsl_stream_bytes", "same_answers_as_plain_index"))):
         if key in ex:
             s[key] = pick(ex[key], *fields)
     return s or None

@@ -643,15 +643,34 @@ def leg_text(c):
         _, ms = time_steps(lambda: csa.sa(sidx), 2, 1, barrier)
         ex["fm_sa_access_dens32"]["lean_index_Msa/s"] = sidx.numel() / ms / 1e3
         # the compressed flavour csa_wt<wt_huff<rrr_vector<63>>> on the same patterns
+        nq3 = min(nq2, 20_000_000)
+        csa.count(pats[: nq3 * m], m, out2[:nq3])
+        plain_counts = out2[:nq3].clone()  # (digest-checked above: every leg of the plain index compared all nq2 with the real library's)
         del csa, wt
         torch.cuda.empty_cache()
         t0 = time.perf_counter()
         crrr = pkg.csa_wt(text=text, device=local, rrr=True)
         rb = time.perf_counter() - t0
-        nq3 = min(nq2, 20_000_000)
         _, ms = time_steps(lambda: crrr.count(pats[: nq3 * m], m, out2[:nq3]), 2, 1, barrier)
         ex["fm_count_rrr63"] = {"Mcount/s": nq3 / ms / 1e3, "kernel_ms": ms, "patterns": nq3, "m": m,
-                                "index_bytes": crrr.device_bytes(), "index_build_s": rb, "roofline": pmc_roofline("fm_count_rrr63", nq3, ms)}
+                                "index_bytes": crrr.device_bytes(), "index_build_s": rb, "roofline": pmc_roofline("fm_count_rrr63", nq3, ms),
+                                "same_answers_as_plain_index": bool(torch.equal(out2[:nq3], plain_counts))}
+        # ... and at a compressed size (round 6): suffix array and text -> SDSL's samples, the k-mer table the budget holds — 1.5 x the bytes
+        # the real library's csa_wt<wt_huff<rrr_vector<63>>, 32, 64> serialises to (our serialiser writes its stream byte for byte)
+        try:
+            rrr_stream = len(crrr.serialize(32, 64, pkg.capi.LAYOUT_RRR63))
+            crrr.set_footprint(int(1.5 * rrr_stream))
+            _, ms = time_steps(lambda: crrr.count(pats[: nq3 * m], m, out2[:nq3]), 2, 1, barrier)
+            lean = {"Mcount/s": nq3 / ms / 1e3, "kernel_ms": ms, "patterns": nq3, "m": m, "index_bytes": crrr.device_bytes(),
+                    "sdsl_stream_bytes": rrr_stream, "x_sdsl_stream_bytes": crrr.device_bytes() / rrr_stream,
+                    "resident_bytes_by_part": crrr.footprint_parts(), "kmer_table": {"k": crrr.kmer_table_depth(), "bytes": crrr.kmer_table_bytes()},
+                    "roofline": pmc_roofline("fm_count_rrr63_lean", nq3, ms)}
+            lean["same_answers_as_plain_index"] = bool(torch.equal(out2[:nq3], plain_counts))
+            ex["fm_count_rrr63_lean"] = lean
+            ex["fm_count_rrr63"]["sdsl_stream_bytes"] = rrr_stream
+            ex["fm_count_rrr63"]["x_sdsl_stream_bytes"] = ex["fm_count_rrr63"]["index_bytes"] / rrr_stream
+        except Exception as e_:
+            ex.setdefault("fm_footprint_errors", {})["rrr63_lean"] = str(e_)
         del crrr
         # second data point: the sigma = 28 lowercase text round 1 reported on (an easier alphabet: shorter codes, a
         # deeper k-mer table)

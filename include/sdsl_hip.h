@@ -104,6 +104,10 @@ sdsl_hip_status sdsl_hip_util_mt_checkpoints(uint64_t seed, uint64_t stride, uin
 sdsl_hip_status sdsl_hip_util_density_bits(uint64_t * words, uint64_t n_bits, uint64_t seed, uint32_t percent,
                                            const uint64_t * checkpoints, uint64_t n_checkpoints, uint64_t stride);
 sdsl_hip_status sdsl_hip_util_english_text(uint8_t * out, uint64_t n_bytes, uint64_t seed);
+/* The same text with `percent` (<= 95) of its 64 KiB blocks replaced by rotated copies of earlier blocks: the duplicated passages of a
+ * real collection (english.1GB concatenates Gutenberg books) that keep the suffix-array interval of a pattern drawn from the text
+ * wide for many characters (benchmark/indexing_count/src/genpatterns.c:183-203 draws its patterns that way).  percent 0 = english_text. */
+sdsl_hip_status sdsl_hip_util_english_text_repetitive(uint8_t * out, uint64_t n_bytes, uint64_t seed, uint32_t percent);
 /* The same stream as rnd_positions, written straight into DEVICE memory: `checkpoints` (host) = the generator's state before
  * every `stride`-th draw (sdsl_hip_util_mt_checkpoints, 313 words each), one block per checkpoint regenerates its stretch.
  * For processes that must not hold the stream on the host (one rank per GPU: eight times 8 GB).  Synchronises `stream`. */

@@ -9,4 +9,4 @@ from . import capi, dist  # noqa: F401
 from .engine import *  # noqa: F401,F403
 from .engine import (bit_vector, rank_support_v5, select_support_mcl, rrr_vector, sd_vector, wt_huff, csa_wt, count,  # noqa: F401
                      set_timing, last_kernel_ms, set_random_bits, rnd_positions, rnd_positions_device, mt_checkpoints, density_bits,
-                     english_text, set_option, last_phases, device_group, device_scratch_bytes, fused_geometry)
+                     english_text, english_text_repetitive, set_option, last_phases, device_group, device_scratch_bytes, fused_geometry)

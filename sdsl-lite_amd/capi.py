@@ -49,6 +49,7 @@ SIGNATURES = {
     "sdsl_hip_util_mt_checkpoints": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_uint64, _vp]),
     "sdsl_hip_util_density_bits": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_uint64, C.c_uint64]),
     "sdsl_hip_util_english_text": (C.c_int32, [_vp, C.c_uint64, C.c_uint64]),
+    "sdsl_hip_util_english_text_repetitive": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, C.c_uint32]),
     "sdsl_hip_util_rnd_positions_device": (C.c_int32, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, C.c_int32,
                                                        _vp]),
     "sdsl_hip_group_create": (C.c_int32, [_vp, C.c_int32, C.POINTER(_vp)]),

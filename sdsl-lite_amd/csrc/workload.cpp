@@ -490,4 +490,57 @@ sdsl_hip_status sdsl_hip_util_english_text(uint8_t * out, uint64_t n_bytes, uint
     return SDSL_HIP_OK;
 }
 
+
+// The repetitive stand-in (round 6).  The real english.1GB is a concatenation of Gutenberg books: licence boilerplate, headers and
+// re-editions repeat whole passages, so a 20-byte pattern drawn from the text keeps a WIDE suffix-array interval for many characters
+// (genpatterns.c:183-203 draws patterns from the text itself) — while in the independent blocks above it occurs 1.017 times on average
+// and the search is down to one suffix after a dozen characters.  Here `percent` of the 64 KiB blocks are COPIES of an earlier block,
+// rotated by a block-specific shift (copies are not aligned in real collections either): block b is a copy iff mix(seed, b) % 100 <
+// percent; its source is drawn among ALL earlier blocks, and a source that is itself a copy hands on to its own source, so popular
+// passages accumulate copies.  Every block is still produced from (seed, block index) alone — in parallel, prefix-stable.
+static inline uint64_t mix64(uint64_t x)
+{
+    x += UINT64_C(0x9E3779B97F4A7C15);
+    x = (x ^ (x >> 30)) * UINT64_C(0xBF58476D1CE4E5B9);
+    x = (x ^ (x >> 27)) * UINT64_C(0x94D049BB133111EB);
+    return x ^ (x >> 31);
+}
+sdsl_hip_status sdsl_hip_util_english_text_repetitive(uint8_t * out, uint64_t n_bytes, uint64_t seed, uint32_t percent)
+{
+    if (!out && n_bytes)
+    {
+        set_error("english_text_repetitive: null output");
+        return SDSL_HIP_ERR_INVALID;
+    }
+    if (percent > 95)
+    {
+        set_error("english_text_repetitive: at most 95 %% of the blocks can be copies (got %u)", percent);
+        return SDSL_HIP_ERR_INVALID;
+    }
+    const TextModel model(seed);
+    constexpr uint64_t kBlock = UINT64_C(1) << 16;
+    parallel_blocks((n_bytes + kBlock - 1) / kBlock,
+                    [&](uint64_t b)
+                    {
+                        const uint64_t lo = b * kBlock, len = std::min(kBlock, n_bytes - lo);
+                        uint64_t src = b, shift = 0;
+                        while (src > 0 && mix64(seed * 31 + src) % 100 < percent)
+                        { // a copy: of a block in front of it (the shifts of a chain add up)
+                            shift += mix64(seed * 131 + src) % kBlock;
+                            src = mix64(seed * 17 + src) % src;
+                        }
+                        if (src == b)
+                        {
+                            model.fill(out + lo, len, seed, b);
+                            return;
+                        }
+                        std::vector<uint8_t> tmp(kBlock);
+                        model.fill(tmp.data(), kBlock, seed, src);
+                        shift %= kBlock;
+                        for (uint64_t j = 0; j < len; ++j)
+                            out[lo + j] = tmp[(j + shift) & (kBlock - 1)];
+                    });
+    return SDSL_HIP_OK;
+}
+
 } // extern "C"

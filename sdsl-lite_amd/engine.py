@@ -318,6 +318,15 @@ def english_text(n_bytes: int, seed: int) -> np.ndarray:
     return out
 
 
+def english_text_repetitive(n_bytes: int, seed: int, percent: int = 30) -> np.ndarray:
+    """english_text with `percent` of its 64 KiB blocks replaced by rotated copies of earlier blocks (duplicated passages, as in a
+    real collection): patterns drawn from it keep wide suffix-array intervals for many characters."""
+    out = np.empty(n_bytes, dtype=np.uint8)
+    if n_bytes:
+        capi.check(capi.lib().sdsl_hip_util_english_text_repetitive(_ptr(out), n_bytes, seed, percent))
+    return out
+
+
 def _serialize(fn, handle) -> bytes:
     need = C.c_size_t(0)
     capi.check(fn(handle, None, 0, C.byref(need)))

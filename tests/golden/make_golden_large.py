@@ -1,6 +1,6 @@
 """BASELINE-size answers of the REAL sdsl-lite (run in the build container only; ~62 GB of RAM, 30-60 minutes).
 
-    python tests/golden/make_golden_large.py [c2] [c2w] [c3] [c4] [c4sel] [c2s] [c4s] [--text-file FILE]
+    python tests/golden/make_golden_large.py [c2] [c2w] [c3] [c4] [c4sel] [c2s] [c4s] [c4r] [--text-file FILE]
 
 Builds, through oracle/_ref/libsdsl_ref.so (the reference's headers compiled where they lie), the structures of
 BASELINE.json configs[1..4] on the SURVEY.md 8(d) inputs and stores what the GPU tests and bench.py compare against:
@@ -278,6 +278,39 @@ def main():
         c4.update({k: v for k, v in res.get("c4", {}).items() if k.endswith("_strided") or k.startswith("wt_select") or k == "wt_k_seed"})
         res["c4"] = c4
         print(f"c4 done in {time.time() - t0:.0f}s", flush=True)
+        json.dump(res, open(OUT, "w"))
+
+
+    if "c4r" in want:
+        # the REPETITIVE stand-in (round 6): english_text_repetitive(2^30, 1234, 30) — 30 % of the 64 KiB blocks are rotated copies of earlier
+        # ones, so patterns drawn from the text (genpatterns.c:183-203) keep wide SA intervals; first NQ_TEXT answers + every STRIDE-th of 10^8
+        t0 = time.time()
+        nt = 1 << TEXT_LOG
+        pct = int(os.environ.get("GOLDEN_REP_PERCENT", "30"))
+        text = pkg.english_text_repetitive(nt, 1234, pct)
+        cnt = np.bincount(text, minlength=256)
+        p = cnt[cnt > 0] / nt
+        c4r = {"text_log": TEXT_LOG, "text_bytes": nt, "text_seed": 1234, "copy_percent": pct, "text_sha256": hashlib.sha256(text.tobytes()).hexdigest(),
+               "sigma_without_sentinel": int((cnt > 0).sum()), "H0": float(-(p * np.log2(p)).sum())}
+        csa = ol.RCsa(text=text.tobytes())
+        print(f"c4r csa built {time.time() - t0:.0f}s", flush=True)
+        c4r["csa_size"] = int(csa.size())
+        c4r["sigma"] = int(csa.sigma())
+        m = 20
+        gi = pkg.rnd_positions(13, NQ_TEXT_FULL, nt + 2, 0)
+        gci = pkg.rnd_positions(14, NQ_TEXT_FULL, nt, 0).astype(np.int64)
+        st = pkg.rnd_positions(15, NQ_TEXT_FULL, nt - m, 0).astype(np.int64)
+        c4r.update(wt_i_seed=13, wt_c_seed=14, wt_rank=digest(csa.wt_rank(np.ascontiguousarray(gi[:NQ_TEXT]), np.ascontiguousarray(text[gci[:NQ_TEXT]]))))
+        pats = np.ascontiguousarray(text[st[:NQ_TEXT, None] + np.arange(m)[None, :]].reshape(-1))
+        cnts = csa.count_batch(pats, m)
+        c4r.update(pattern_seed=15, m=m, count=digest(cnts), mean_count=float(np.asarray(cnts, dtype=np.float64).mean()),
+                   share_count_1=float((np.asarray(cnts) == 1).mean()))
+        c4r["wt_rank_strided"] = strided(csa.wt_rank(np.ascontiguousarray(gi[::STRIDE]), np.ascontiguousarray(text[gci[::STRIDE]])), NQ_TEXT_FULL)
+        sts = st[::STRIDE]
+        pats = np.ascontiguousarray(text[sts[:, None] + np.arange(m)[None, :]].reshape(-1))
+        c4r["count_strided"] = strided(csa.count_batch(pats, m), NQ_TEXT_FULL)
+        res["c4r"] = c4r
+        print(f"c4r done in {time.time() - t0:.0f}s: mean count {c4r['mean_count']:.3f}, share with count 1: {c4r['share_count_1']:.3f}", flush=True)
         json.dump(res, open(OUT, "w"))
 
 

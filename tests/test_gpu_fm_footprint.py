@@ -134,10 +134,59 @@ def test_what_cannot_be_shrunk_says_so(gpu):
     text = gpu.english_text(1 << 20, 9)
     crrr = gpu.csa_wt(text=text, rrr=True)
     crrr.set_footprint(1 << 40)  # already below: nothing to do
+    before = crrr.footprint_parts()
     with pytest.raises(Exception) as e:
         crrr.set_footprint(1000)
-    assert "plain wavelet tree" in str(e.value)
+    assert "smallest form" in str(e.value) and "rrr-compressed tree" in str(e.value)
+    assert crrr.footprint_parts() == before, "a refused call leaves the index as it was"
     crrr.close()
+    # created from a BWT: no suffix array and no samples to fall back to
+    bw = gpu.csa_wt(bwt=np.asarray(ol.OCsa(bytes(text[:50_000])).bwt()))
+    with pytest.raises(Exception) as e:
+        bw.set_footprint(1000)
+    assert "nothing smaller" in str(e.value) or "smallest form" in str(e.value)
+    bw.close()
+
+
+@pytest.mark.parametrize("source", ["text", "stream"])
+def test_the_compressed_index_at_a_compressed_size(gpu, source):
+    """csa_wt<wt_huff<rrr_vector<63>>> (csa_wt.hpp:389-402, rrr_vector.hpp:366-378): created from text the device image holds suffix array,
+    text and a k-mer table — 11 x the type's own stream; set_footprint takes it down to 1.5 x that stream (rrr tree, 32-bit samples, the
+    k-mer table the rest of the budget holds) with every answer unchanged, and the stream it serialises to stays the real library's."""
+    text = gpu.english_text(3 << 20, 17)
+    built = gpu.csa_wt(text=text, rrr=True)
+    blob = built.serialize(32, 64, gpu.capi.LAYOUT_RRR63)
+    want = answers(built, text)
+    if ol.have_ref():
+        assert blob == ol.ref_csa_rrr_bytes(bytes(text)), "the stream is the real library's csa_wt<wt_huff<rrr_vector<63>>, 32, 64>"
+    if source == "text":
+        csa = built
+        assert csa.device_bytes() > 5 * len(blob)
+    else:
+        built.close()
+        csa = gpu.csa_wt(sdsl_bytes=blob, rrr=True, sa_dens=32, isa_dens=64)
+    # (on the 1 GiB bench text the floor is 1.27 x the stream and 1.5 x leaves room for a k-mer table of depth 4: bench.py's row
+    # fm_count_rrr63_lean; on three MiB the 128-byte records of the device's rrr layout weigh more: 1.58 x)
+    budget = int(1.8 * len(blob))
+    csa.set_footprint(budget)
+    p = csa.footprint_parts()
+    assert csa.device_bytes() <= budget and p["suffix_array"] == 0 and p["text"] == 0 and p["wt_fused_lines"] == 0
+    assert csa.kmer_table_depth() >= 1, "the budget leaves room for a table"
+    assert p["sa_isa_samples"] == 4 * ((text.size + 1 + 31) // 32 + (text.size + 1 + 63) // 64), "SDSL's samples at 32 / 64, 32 bits each"
+    assert csa.sampling() == (32, 64, False)
+    assert same(want, answers(csa, text))
+    assert csa.serialize(32, 64, gpu.capi.LAYOUT_RRR63) == blob
+    # a second, smaller budget: the k-mer table goes, nothing else can
+    floor = sum(v for k, v in p.items() if k != "kmer_table")
+    csa.set_footprint(floor)
+    assert csa.device_bytes() <= floor and csa.kmer_table_depth() == 0
+    assert same(want, answers(csa, text))
+    with pytest.raises(Exception):
+        csa.set_footprint(floor - (1 << 16))
+    assert same(want, answers(csa, text)), "a refused call changes nothing"
+    csa.restore_suffix_array()
+    assert csa.sampling() == (32, 64, True) and same(want, answers(csa, text))
+    csa.close()
 
 
 def test_fused_header_kernels_stride_over_what_the_grid_does_not_cover(gpu, monkeypatch):
