@@ -538,6 +538,11 @@ sdsl_hip_status sdsl_hip_set_timing(int32_t enabled);
  * to decode, and large batches stay on the direct kernels.  Answers and the serialised SDSL bytes do not depend on it
  * (rrr_vector.hpp:158-270 stores every class as an offset). */
 sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value);
+/* The library's size gates by name (INTEGRATION.md 5 tabulates them; the reference itself is 64-bit throughout and bounded by host
+ * memory alone, int_vector.hpp / wt_pc.hpp:366-474).  Sizes from the returned value ON are refused or take the other road named in the
+ * table: "bv_bits", "bv_bucketed_bits", "rrr_bits", "rrr_bucketed_bits", "wt_fused_symbols", "wt_select_bucketed_symbols",
+ * "fm_fast_symbols", "sorter32_symbols", "sorter64_symbols", "step_table_lines".  0 = unknown name. */
+uint64_t sdsl_hip_limit(const char * what);
 /* "trace_phases" (0/1): the bucketed batch rank times each of its passes with HIP events on the launch stream (one host
  * synchronisation per call) and sdsl_hip_last_phases returns them as "select=0|1;hist1=ms;offs1=ms;part1=ms;..." for the
  * most recent bucketed batch since the option was last set (empty: no batch took that path) */

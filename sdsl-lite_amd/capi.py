@@ -42,6 +42,7 @@ SIGNATURES = {
     "sdsl_hip_version": (C.c_char_p, []),
     "sdsl_hip_device_count": (C.c_int32, []),
     "sdsl_hip_set_option": (C.c_int32, [C.c_char_p, C.c_int64]),
+    "sdsl_hip_limit": (C.c_uint64, [C.c_char_p]),
     "sdsl_hip_last_phases": (C.c_int32, [C.c_char_p, C.c_size_t]),
     "sdsl_hip_bv_layout_info": (C.c_int32, [_vp, C.POINTER(C.c_uint64)]),
     "sdsl_hip_util_set_random_bits": (C.c_int32, [_vp, C.c_uint64, C.c_uint64]),

@@ -393,7 +393,7 @@ sdsl_hip_status bv_build_from_device_words(BvHost & bv, const uint64_t * d_words
     bv.view.n_bits = n_bits;
     bv.view.n_lines = n_bits / kDB + 1;
     bv.view.n_lines += bv.view.n_lines & 1; // even: select probes aligned pairs of lines
-    if (n_bits >= (UINT64_C(1) << 40))
+    if (n_bits >= kLimBvBits)
     {
         set_error("bit vector of %llu bits exceeds the 2^40-bit limit of the select directory",
                   (unsigned long long)n_bits);

@@ -1499,9 +1499,10 @@ size_t bv_sorted_rank_scratch_bytes(const BvView & v, uint64_t n)
 }
 
 static bool sr_use_swc();
+static_assert(kLimBvBucketedLinesLog == kSliceLog + 16 + kSliceExtraMax, "limits.hpp names what the slices allow");
 bool bv_sorted_rank_possible(const BvView & v)
 {
-    return v.n_lines >= 2 && v.n_lines <= (UINT64_C(1) << (kSliceLog + 16 + (sr_use_swc() ? kSliceExtraMax : 0u)));
+    return v.n_lines >= 2 && v.n_lines <= (UINT64_C(1) << (sr_use_swc() ? kLimBvBucketedLinesLog : kSliceLog + 16));
 }
 
 bool bv_sorted_rank_applicable(const BvView & v, uint64_t n)

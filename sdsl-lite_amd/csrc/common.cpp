@@ -365,6 +365,35 @@ int32_t sdsl_hip_device_count(void)
     return ok;
 }
 
+// The size gates (limits.hpp), by name: what INTEGRATION.md 5 tabulates and tests/test_size_limits.py compares the table with.
+// 0 = no such name.
+uint64_t sdsl_hip_limit(const char * what)
+{
+    using namespace sdslhip;
+    if (!what)
+        return 0;
+    static const struct
+    {
+        const char * name;
+        uint64_t value;
+    } table[] = {
+        {"bv_bits", kLimBvBits},
+        {"bv_bucketed_bits", (UINT64_C(1) << kLimBvBucketedLinesLog) * 448},
+        {"rrr_bits", kLimRrrBits},
+        {"rrr_bucketed_bits", kLimRrrBucketedRecords * 34 * 63},
+        {"wt_fused_symbols", kLimWtFusedSymbols},
+        {"wt_select_bucketed_symbols", kLimWtSelectBucketedSymbols},
+        {"fm_fast_symbols", kLimFmFastSymbols},
+        {"sorter32_symbols", kLimSorter32Symbols},
+        {"sorter64_symbols", kLimSorter64Symbols},
+        {"step_table_lines", UINT64_C(1) << kLimStepTableLineBits},
+    };
+    for (const auto & e : table)
+        if (!strcmp(what, e.name))
+            return e.value;
+    return 0;
+}
+
 sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value)
 {
     if (name && !strcmp(name, "rank_sorted"))

@@ -1,6 +1,7 @@
 // common.hpp — shared host-side plumbing of libsdsl_hip (error state, pointer classification,
 // device buffers, staging of host-resident batches, kernel timing).  gfx950 only.
 #pragma once
+#include "limits.hpp"
 #include <algorithm>
 #include <atomic>
 #include <mutex>

@@ -436,7 +436,7 @@ static sdsl_hip_status sdsl_hip_fm_create_from_text_ex_impl(const uint8_t * text
     }
     DevBuf d_bwt, d_sa;
     const char * force64 = getenv("SDSL_HIP_SA64"); // (test knob: the 64-bit sorter on a text of any size)
-    if (n_text + 1 >= UINT64_C(0xFFFFFFFE) || (force64 && atoi(force64) != 0))
+    if (n_text + 1 >= kLimSorter32Symbols || (force64 && atoi(force64) != 0))
     { // 2^32 symbols and more: 64-bit suffixes (sa.hip).  The index keeps SA / ISA samples at SDSL's default densities
       // (csa_wt<..., 32, 64>: csa_wt.hpp:56) AND, room permitting, the whole 64-bit suffix array, the text and a k-mer table with
       // 40-bit intervals (k <= 6): count() of large batches takes the wide variants of the flat kernels (fm_count2.hip).
@@ -720,10 +720,10 @@ __global__ __launch_bounds__(256) void k_fm_narrow_samples(const uint64_t * __re
 static sdsl_hip_status fm_ensure_sa_text(sdsl_hip_fm_t fm)
 {
     SH_HIP(hipSetDevice(fm->device));
-    const bool wide = fm->size >= UINT64_C(0xFFFFFFFE); // the 64-bit sorter and suffix array (sa.hip), as at creation
+    const bool wide = fm->d_sa64.p || (!fm->d_sa.p && fm->size >= kLimSorter32Symbols); // the 64-bit sorter and suffix array (sa.hip), as at creation
     if (!((wide ? fm->d_sa64.p : fm->d_sa.p) && fm->d_text.p))
     {
-        if (fm->size < 2 || fm->size >= (UINT64_C(1) << 39) || !fm->isa_dens || !fm->sa_dens)
+        if (fm->size < 2 || fm->size >= kLimFmFastSymbols || !fm->isa_dens || !fm->sa_dens)
         {
             set_error("fm_restore_suffix_array: needs the index's SA and ISA samples (load the stream with its densities: "
                       "sdsl_hip_fm_create_from_sdsl_ex) and fewer than 2^39 symbols");

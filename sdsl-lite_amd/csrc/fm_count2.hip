@@ -621,7 +621,7 @@ sdsl_hip_status fm_build_count_tab(sdsl_hip_fm_s * f)
     f->ctab_ok = false;
     f->d_ctab.release();
     const WtHost & w = sdsl_hip_wt_host(f->wt);
-    if (w.backend != 0 || !w.d_fused.p || !w.d_ftables.p || f->size >= (UINT64_C(1) << 39) || f->sigma < 2)
+    if (w.backend != 0 || !w.d_fused.p || !w.d_ftables.p || f->size >= kLimFmFastSymbols || f->sigma < 2)
         return SDSL_HIP_OK;
     const bool wide = f->size >= (UINT64_C(1) << 32);
     std::vector<WtFusedTables> ft(1);
@@ -644,7 +644,7 @@ sdsl_hip_status fm_build_count_tab(sdsl_hip_fm_s * f)
         while (left)
         {
             const unsigned k = left < kFK ? left : kFK, t = (unsigned)p & ((1u << k) - 1u);
-            if (used >= kFmMaxSteps || ft[0].fline[v] >= (1u << 28) || v >= w.n_nodes)
+            if (used >= kFmMaxSteps || ft[0].fline[v] >= (1u << kLimStepTableLineBits) || v >= w.n_nodes)
                 return SDSL_HIP_OK;
             C.snode[used] = (uint16_t)v;
             C.steps[used++] = ft[0].fline[v] | (t << 28);
@@ -691,7 +691,7 @@ sdsl_hip_status fm_build_deep(sdsl_hip_fm_s * f, uint32_t k_max, uint64_t budget
     }
     // preconditions first: a call that cannot build leaves the table the index has (it may be one that can no longer be rebuilt)
     const bool wide = f->size >= (UINT64_C(1) << 32); // 64-bit suffix array, 40-bit intervals, k <= 6
-    if (!(wide ? f->d_sa64.p : f->d_sa.p) || !f->d_text.p || f->size < 2 || f->size >= (UINT64_C(1) << 39))
+    if (!(wide ? f->d_sa64.p : f->d_sa.p) || !f->d_text.p || f->size < 2 || f->size >= kLimFmFastSymbols)
     {
         set_error("the k-mer table is built from the whole suffix array and the text: create the index from text (and before "
                   "sdsl_hip_fm_drop_sa), or sdsl_hip_fm_restore_suffix_array first");

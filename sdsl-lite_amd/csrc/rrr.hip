@@ -176,7 +176,7 @@ static sdsl_hip_status rrr_parse_sdsl(StreamReader & rd, RrrArrays & A)
     if (!rd.u64(n) || !rd.int_vector(bt) || !rd.int_vector(btnr, 1) || !rd.int_vector(btnrp) || !rd.int_vector(rank)
         || !rd.int_vector(inv, 1))
         goto bad;
-    if (n >= (UINT64_C(1) << 40))
+    if (n >= kLimRrrBits)
     { // the limit the plain bit vector enforces too; also keeps n + 63 and everything derived from it from wrapping
         set_error("rrr_vector<63> stream declares %llu bits: beyond the supported 2^40", (unsigned long long)n);
         return SDSL_HIP_ERR_FORMAT;

@@ -551,7 +551,7 @@ static unsigned rs_rlog(const RrrView & v)
 
 bool rrr_sorted_rank_possible(const RrrView & v)
 {
-    return v.n_sb >= 2 && ((v.n_sb + 255) >> 8) <= 65536;
+    return v.n_sb >= 2 && v.n_sb <= kLimRrrBucketedRecords;
 }
 
 bool rrr_sorted_rank_applicable(const RrrView & v, uint64_t n)

@@ -250,7 +250,7 @@ sdsl_hip_status sort_keys_u16(uint16_t * keys, uint16_t * other, uint64_t n, uns
 sdsl_hip_status sa_build_bwt_device(const uint8_t * text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa)
 {
     const uint64_t n = n_text + 1;
-    if (n >= UINT64_C(0xFFFFFFFE))
+    if (n >= kLimSorter32Symbols)
     {
         set_error("device suffix sorter handles texts below 2^32-2 bytes (got %llu)", (unsigned long long)n_text);
         return SDSL_HIP_ERR_UNSUPPORTED;
@@ -398,7 +398,7 @@ __global__ void k_sa64_bwt(const uint8_t * __restrict__ s, const uint64_t * __re
 sdsl_hip_status sa_build_bwt_device64(const uint8_t * text, uint64_t n_text, int device, DevBuf & d_bwt, DevBuf & d_sa)
 {
     const uint64_t n = n_text + 1;
-    if (n >= (UINT64_C(1) << 40))
+    if (n >= kLimSorter64Symbols)
     {
         set_error("device suffix sorter handles texts below 2^40 bytes (got %llu)", (unsigned long long)n_text);
         return SDSL_HIP_ERR_UNSUPPORTED;

@@ -1763,7 +1763,7 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
             while (left && fits)
             {
                 const unsigned k = left < kFK ? left : kFK, t = (unsigned)p & ((1u << k) - 1u);
-                if (used >= kWtMaxSteps || FT.fline[v] >= (1u << 28))
+                if (used >= kWtMaxSteps || FT.fline[v] >= (1u << kLimStepTableLineBits))
                 {
                     fits = false;
                     break;
@@ -1864,7 +1864,7 @@ sdsl_hip_status wt_build_fused(WtHost & wt)
     const char * env = getenv("SDSL_HIP_WT_FUSED");
     if (env && atoi(env) == 0)
         return SDSL_HIP_OK;
-    if (wt.backend != 0 || wt.sigma < 2 || wt.n_nodes < 3 || wt.size == 0 || wt.size >= (UINT64_C(1) << 36) ||
+    if (wt.backend != 0 || wt.sigma < 2 || wt.n_nodes < 3 || wt.size == 0 || wt.size >= kLimWtFusedSymbols ||
         !wt.d_tables.p)
         return SDSL_HIP_OK; // (2^32 .. 2^36 symbols: rank / access / LF on the fused lines, select on the binary levels)
     // The fused layout serves rank / access / select, whose answers do not depend on the tree's shape, so it gets the

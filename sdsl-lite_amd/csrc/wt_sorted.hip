@@ -450,7 +450,7 @@ __global__ __launch_bounds__(THREADS) void k_wt_select_sorted_lane(WtView wt, co
 bool wt_select_sorted_applicable(const WtHost & wt, uint64_t n)
 {
     const int mode = g_wt_select_sorted_mode.load();
-    if (mode == 0 || wt.backend != 0 || !wt.d_fused.p || !wt.d_fsel.p || wt.size < 2 || wt.size >= (UINT64_C(1) << 32))
+    if (mode == 0 || wt.backend != 0 || !wt.d_fused.p || !wt.d_fsel.p || wt.size < 2 || wt.size >= kLimWtSelectBucketedSymbols)
         return false;
     return mode > 0 ? n >= 4096 : n >= (UINT64_C(1) << 23);
 }
