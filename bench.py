@@ -90,6 +90,30 @@ def self_launch(a):
 
 
 
+def pin_to_gpu_numa_node(local):
+    """One rank per GPU: keep the rank's host threads (the launch thread, the generators' workers) on the NUMA node the GPU hangs off —
+    on a two-socket 8-GPU node a rank scheduled on the far socket pays the inter-socket hop on every launch and every host-array copy.
+    Best effort: sysfs says which node (pci_bus_id of the device -> /sys/bus/pci/devices/<id>/numa_node -> its cpulist); where any of
+    it is missing (containers, single-socket hosts report -1) nothing changes.  Returns what was done, for the line's config."""
+    try:
+        p = torch.cuda.get_device_properties(local)
+        bus = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bus}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return {"numa_node": node, "cpus": len(allowed)}
+    except Exception:
+        return None
+
+
 def cpu_baseline(pkg, words_dev, n_bits, idx_dev, gpu_out_dev, seconds):
     """The reference's CPU path on this host: real sdsl-lite (oracle/_ref, kind 'reference') if the
     prebuilt library travelled with the repo, else the C restatement (kind 'port').  One thread, scalar
@@ -248,7 +272,7 @@ def compact_line(result, ex, sidecar, text_mib):
     line = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                        "vs_baseline", "dtype", "data", "reference_digest_match")}
     line["config"] = pick(result["config"], "workload", "n_bits", "queries_per_step_per_gpu", "parallelism", "index_bytes_per_gpu",
-                          "batch_scratch_bytes_per_gpu")
+                          "batch_scratch_bytes_per_gpu", "rank0_host_affinity")
     line["config"]["workload"] = clip(line["config"]["workload"], 320)
     rf = result["roofline"]
     line["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms",
@@ -375,6 +399,7 @@ def main():
         assert n_dev >= world, f"{world} ranks but {n_dev} visible device(s)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    pinned = pin_to_gpu_numa_node(local) if world > 1 and a.backend == "nccl" else None
     comm_dev = dev if a.backend == "nccl" else torch.device("cpu")
     pkg = importlib.import_module("sdsl-lite_amd")
     n_bits = 1 << a.log_n
@@ -442,7 +467,7 @@ def main():
         "config": {"workload": "configs[1]: batched rank_1, 2^%d-bit random bit_vector (words = mt19937_64(42)), %d queries per step "
                                "per GPU at mt19937_64(7 + rank) %% (n + 1), index + queries + results resident in HBM" % (a.log_n, nq),
                    "n_bits": n_bits, "queries_per_step_per_gpu": nq, "parallelism": "replicated index, query shards x%d" % world,
-                   "index_bytes_per_gpu": index_bytes, "batch_scratch_bytes_per_gpu": scratch_bytes},
+                   "index_bytes_per_gpu": index_bytes, "batch_scratch_bytes_per_gpu": scratch_bytes, "rank0_host_affinity": pinned},
         "reference_digest_match": ref_ok,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

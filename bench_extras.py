@@ -41,7 +41,7 @@ def write_sidecar(c, path=None):
 # leg name -> (function, runs on several ranks?, runs on one rank?)
 def legs_table():
     return {"e2e": (leg_e2e, False), "sweep": (leg_sweep, False), "select": (leg_select, True), "rrr": (leg_rrr, True), "sd": (leg_sd, True),
-            "shapes": (leg_shapes, False), "text": (leg_text, True), "big": (leg_big, False), "fm_sharded": (leg_sharded, True)}
+            "shapes": (leg_shapes, False), "text": (leg_text, True), "rep": (leg_repetitive, False), "big": (leg_big, False), "fm_sharded": (leg_sharded, True)}
 
 
 def run_extras(c):
@@ -51,8 +51,10 @@ def run_extras(c):
     want = list(c.extras)
     if "wt" in want or "fm" in want:
         want.append("text")
+    if "fm" in want:
+        want.append("rep")
     c.done = []
-    for name in ("e2e", "sweep", "select", "rrr", "sd", "shapes", "text", "big", "fm_sharded"):
+    for name in ("e2e", "sweep", "select", "rrr", "sd", "shapes", "text", "rep", "big", "fm_sharded"):
         if name not in want:
             continue
         fn, multi = T[name]
@@ -60,7 +62,7 @@ def run_extras(c):
             continue
         if name == "fm_sharded" and c.world == 1:
             continue
-        if name in ("e2e", "sweep", "shapes", "big") and c.rank != 0:
+        if name in ("e2e", "sweep", "shapes", "big", "rep") and c.rank != 0:
             continue
         t0 = time.perf_counter()
         try:
@@ -684,6 +686,64 @@ def leg_text(c):
                                   "sigma": c28.sigma(), "jump_depth": c28.jump_depth(),
                                   "text": "Zipf over a 4096-word lowercase vocabulary (round 1's stand-in)"}
         del c28, t28, p28, st28
+
+
+def leg_repetitive(c):
+    """configs[3] / [4] on the REPETITIVE stand-in (round 6; VERDICT r05: the independent blocks of the first stand-in give a 20-byte pattern
+    1.017 occurrences on average, and count()'s default route — ... -> text comparison at one suffix — lives off that; the real english.1GB
+    concatenates books that repeat whole passages).  english_text_repetitive(2^30, 1234, 30): 30 % of the 64 KiB blocks are rotated copies of
+    earlier ones; patterns drawn from the text as genpatterns.c:183-203 draws them occur 2.4 times on average, 46 % of them more than
+    once.  wt.rank and count() at the default footprint and at 1.5 x the reference's stream, all 10^8 answers against the digests of the
+    real library (tests/golden/make_golden_large.py c4r)."""
+    a, pkg, dev, local, rank, barrier, G, ex = c.a, c.pkg, c.dev, c.local, c.rank, c.barrier, c.G, c.ex
+    if a.text_file:
+        return
+    torch.cuda.empty_cache()
+    nt = a.text_mib << 20
+    c4r = G.get("c4r", {})
+    ok = nt == (1 << c4r.get("text_log", -1)) and "count" in c4r
+    text = torch.from_numpy(pkg.english_text_repetitive(nt, 1234, 30)).to(dev)
+    t0 = time.perf_counter()
+    csa = pkg.csa_wt(text=text, device=local)
+    build = time.perf_counter() - t0
+    nq2 = min(c.nq, 100_000_000)
+    m = 20
+    gi = to_dev(pkg.rnd_positions(13, nq2, nt + 2, 0), dev)
+    gc = text[to_dev(pkg.rnd_positions(14, nq2, nt, 0), dev)]
+    out2 = torch.empty(nq2, dtype=torch.int64, device=dev)
+    wt = csa.wavelet_tree
+    _, ms = time_steps(lambda: wt.rank(gi, gc, out=out2), 3, 1, barrier)
+    block = {"text": "english_text_repetitive(%d, 1234, 30): 30 %% of the 64 KiB blocks are rotated copies of earlier blocks" % nt,
+             "index_build_s": build, "mean_count_of_a_20_byte_pattern": c4r.get("mean_count"), "share_of_patterns_occurring_once": c4r.get("share_count_1"),
+             "wt_rank": {"Gq/s": nq2 / ms / 1e6, "kernel_ms": ms, "reference_digest_match": digests_match(out2, c4r, "wt_rank") if ok else None}}
+    del gi, gc
+    st = to_dev(pkg.rnd_positions(15, nq2, nt - m, 0), dev)
+    pats = text[(st.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()
+    del st
+
+    def leg(name):
+        steps_ms = []
+        _, ms_ = time_steps(lambda: csa.count(pats, m, out2), 4, 1, barrier, per_step=steps_ms)
+        return {"Mcount/s": nq2 / ms_ / 1e3, "kernel_ms": ms_, "kernel_ms_per_batch": spread_of(steps_ms), "patterns": nq2, "m": m,
+                "index_bytes": csa.device_bytes(), "kmer_table": {"k": csa.kmer_table_depth(), "bytes": csa.kmer_table_bytes()},
+                "resident_bytes_by_part": csa.footprint_parts(), "reference_digest_match": digests_match(out2, c4r, "count") if ok else None}
+
+    block["count_default"] = leg("default")
+    sdsl_bytes = len(csa.serialize(32, 64, pkg.capi.LAYOUT_BV_MCL))
+    block["sdsl_stream_bytes"] = sdsl_bytes
+    csa.drop_sa()
+    block["count_sa_dropped"] = leg("sa_dropped")
+    try:
+        csa.set_footprint(int(1.5 * sdsl_bytes))
+        block["count_lean"] = leg("lean")
+        block["count_lean"]["x_sdsl_stream_bytes"] = block["count_lean"]["index_bytes"] / sdsl_bytes
+    except Exception as e_:
+        block["count_lean_error"] = str(e_)
+    first = ex.get("fm_count", {}).get("Mcount/s")
+    if first:
+        block["default_route_vs_first_stand_in"] = block["count_default"]["Mcount/s"] / first
+    ex["fm_count_repetitive"] = block
+    del csa, wt, text, pats, out2
 
 
 def leg_big(c):

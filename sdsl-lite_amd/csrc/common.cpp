@@ -11,7 +11,9 @@ static thread_local std::string g_err;
 static bool g_timing = false;
 // batched rank on a plain vector: -1 automatic, 0 always the direct kernel, 1 the bucketed path whenever it applies
 std::atomic<int> g_trace_phases{0};
-std::atomic<int> g_rrr_sparse_limit{10}; // largest class rrr_vector<63> may keep enumerative (rrr.hip: choose_sparse_max); up to 20
+std::atomic<int64_t> g_group_timeout_ms{getenv("SDSL_HIP_GROUP_TIMEOUT_MS") ? atoll(getenv("SDSL_HIP_GROUP_TIMEOUT_MS")) : 120000}; // group.cpp: deadline of a batch
+std::atomic<int> g_group_test_stall{-1}; // group.cpp: test hook (a member whose scatter stream never gets going)
+std::atomic<int> g_rrr_sparse_limit{20}; // largest class rrr_vector<63> may keep enumerative (rrr.hip: choose_sparse_max); up to 20
 std::atomic<int> g_rrr_raw_budget{20}; // permille of the compressed size rrr_vector<63> may spend on raw classes (rrr.hip)
 std::atomic<int> g_select_sorted_mode{getenv("SDSL_HIP_SELECT_SORTED") ? atoi(getenv("SDSL_HIP_SELECT_SORTED")) : -1};
 std::atomic<int> g_wt_select_sorted_mode{getenv("SDSL_HIP_WT_SELECT_SORTED") ? atoi(getenv("SDSL_HIP_WT_SELECT_SORTED")) : -1};
@@ -440,10 +442,25 @@ sdsl_hip_status sdsl_hip_set_option(const char * name, int64_t value)
     { // the space / speed trade of rrr_vector<63> handles created from now on (rrr.hip: choose_sparse_max)
         if (value < 0 || value > 20)
         {
-            set_error("set_option: rrr_sparse_limit is the largest class kept enumerative (0..20, default 10)");
+            set_error("set_option: rrr_sparse_limit is the largest class kept enumerative (0..20, default 20)");
             return SDSL_HIP_ERR_INVALID;
         }
         sdslhip::g_rrr_sparse_limit.store((int)value);
+        return SDSL_HIP_OK;
+    }
+    if (name && !strcmp(name, "group_timeout_ms"))
+    { // deadline of one device-group batch (group.cpp); 0 = wait for ever
+        if (value < 0)
+        {
+            set_error("set_option: group_timeout_ms is a number of milliseconds (0 = no deadline)");
+            return SDSL_HIP_ERR_INVALID;
+        }
+        sdslhip::g_group_timeout_ms.store(value);
+        return SDSL_HIP_OK;
+    }
+    if (name && !strcmp(name, "group_test_stall"))
+    { // TEST HOOK: member `value` of the next group batch gets a kernel on its scatter stream that spins until the option is set to -1
+        sdslhip::group_test_stall_set((int)value);
         return SDSL_HIP_OK;
     }
     if (name && !strcmp(name, "trace_phases"))

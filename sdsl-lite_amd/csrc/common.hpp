@@ -27,6 +27,9 @@ extern std::atomic<int> g_rank_sorted_mode; // sdsl_hip_set_option("rank_sorted"
 extern std::atomic<int> g_rrr_sorted_mode;  // sdsl_hip_set_option("rrr_sorted", ...)
 extern std::atomic<int> g_select_sorted_mode; // sdsl_hip_set_option("select_sorted", ...)
 extern std::atomic<int> g_wt_select_sorted_mode; // sdsl_hip_set_option("wt_select_sorted", ...)
+extern std::atomic<int64_t> g_group_timeout_ms; // sdsl_hip_set_option("group_timeout_ms", ...), SDSL_HIP_GROUP_TIMEOUT_MS
+extern std::atomic<int> g_group_test_stall;
+void group_test_stall_set(int member); // group.cpp
 extern std::atomic<int> g_trace_phases;     // sdsl_hip_set_option("trace_phases", ...)
 void bv_sorted_clear_phases();              // bv_sorted.hip
 extern std::atomic<int> g_rrr_format;       // sdsl_hip_set_option("rrr_format", -1 | 0 | 1)

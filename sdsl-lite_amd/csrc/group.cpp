@@ -10,8 +10,10 @@
 // The reference has no multi-device layer; the caller-visible contract is the batch call of the single-GPU ABI
 // (sdsl_hip_bv_rank_batch etc.), same arguments, same answers.
 // RCCL is loaded with dlopen at group creation, so a process that never creates a group does not pay for it.
+#include <chrono>
 #include <dlfcn.h>
 #include <memory>
+#include <thread>
 #include <rccl/rccl.h>
 
 #include "bv_host.hpp"
@@ -108,8 +110,15 @@ struct sdsl_hip_group_s
     // processes that cannot load librccl, and the only transport that accepts the same device twice (a group of two on a
     // one-GPU box: the sharding, the chunk pipeline and the event chains of G > 1 then run where only one GPU is at hand).
     bool copy = false;
+    bool poisoned = false; // a batch ran into its deadline: work that cannot be cancelled may still sit in the streams
     ~sdsl_hip_group_s()
     {
+        if (poisoned)
+        { // stuck work may still read the buffers, and CommDestroy / hipFree would wait for it: the group's device resources are leaked
+            (void)new std::vector<DevBuf>(std::move(in));
+            (void)new std::vector<DevBuf>(std::move(out));
+            return;
+        }
         const Rccl * R = rccl();
         for (int r = 0; r < n; ++r)
         {
@@ -128,6 +137,32 @@ struct sdsl_hip_group_s
         }
     }
 };
+
+namespace sdslhip {
+// TEST HOOK (sdsl_hip_set_option("group_test_stall", member)): a peer that never gets to its part of the batch — in the copy
+// transport "a receive that is never posted" is a scatter stream that never reaches its copy.  The kernel spins on a word of pinned
+// host memory; setting the option to -1 releases it.
+static uint32_t * g_stall_flag = nullptr; // pinned, mapped
+__global__ void k_group_stall(volatile uint32_t * flag)
+{
+    while (*flag == 0)
+        __builtin_amdgcn_s_sleep(127);
+}
+void group_test_stall_set(int member)
+{
+    if (member < 0)
+    {
+        if (g_stall_flag)
+            __atomic_store_n(g_stall_flag, 1u, __ATOMIC_SEQ_CST);
+        g_group_test_stall.store(-1);
+        return;
+    }
+    if (!g_stall_flag && hipHostMalloc((void **)&g_stall_flag, 64, hipHostMallocMapped) != hipSuccess)
+        return;
+    __atomic_store_n(g_stall_flag, 0u, __ATOMIC_SEQ_CST);
+    g_group_test_stall.store(member);
+}
+} // namespace sdslhip
 
 namespace {
 
@@ -265,19 +300,72 @@ sdsl_hip_status group_run(sdsl_hip_group_s * g, const uint8_t * d_in, size_t in_
         }
         return SDSL_HIP_OK;
     };
+    if (g->poisoned)
+    {
+        set_error("device group: an earlier batch ran into its deadline and may still hold the group's streams; destroy the group");
+        return SDSL_HIP_ERR_HIP;
+    }
+    const int stall = g_group_test_stall.load();
+    if (stall >= 0 && stall < G && g_stall_flag)
+    { // (test hook: this member's scatter stream is held)
+        (void)hipSetDevice(g->dev[stall]);
+        void * dflag = nullptr;
+        if (hipHostGetDevicePointer(&dflag, g_stall_flag, 0) == hipSuccess)
+            hipLaunchKernelGGL(k_group_stall, dim3(1), dim3(1), 0, g->s_in[stall], (volatile uint32_t *)dflag);
+    }
     sdsl_hip_status st = body();
-    for (int r = 0; r < G; ++r)
-    { // the call is synchronous for the caller: everything has landed in d_out on return
+    // The call is synchronous for the caller: everything has landed in d_out on return — or the DEADLINE has passed (option
+    // "group_timeout_ms", SDSL_HIP_GROUP_TIMEOUT_MS; default 120 s, 0 = none).  A collective whose peer never turns up does not
+    // raise an error anywhere: its stream simply never drains, and hipStreamSynchronize would wait with it for ever (a first 8-GPU run
+    // is the first time RCCL point-to-point between distinct devices executes at all).  So the wait is a poll of one event per
+    // stream against the clock; on expiry the call names the member, its device and the stage that did not finish, returns
+    // SDSL_HIP_ERR_HIP and marks the group unusable (the work that is stuck cannot be cancelled: destroy the group).
+    const int64_t limit_ms = g_group_timeout_ms.load();
+    const auto t_start = std::chrono::steady_clock::now();
+    static const char * const stage[3] = {"scatter (shards to the members)", "kernels", "gather (answers to the root)"};
+    for (int r = 0; r < G && st == SDSL_HIP_OK; ++r)
+    {
         (void)hipSetDevice(g->dev[r]);
+        int k = 0;
         for (hipStream_t s : {g->s_in[r], g->s_k[r], g->s_out[r]})
         {
-            hipError_t e = hipStreamSynchronize(s);
-            if (e != hipSuccess && st == SDSL_HIP_OK)
-                st = hip_fail(e, "group stream synchronize", __FILE__, __LINE__);
+            hipEvent_t done = nullptr;
+            hipError_t e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+            if (e == hipSuccess)
+                e = hipEventRecord(done, s);
+            while (e == hipSuccess)
+            {
+                e = hipEventQuery(done);
+                if (e != hipErrorNotReady)
+                    break;
+                e = hipSuccess;
+                const int64_t waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
+                if (limit_ms > 0 && waited > limit_ms)
+                {
+                    set_error("device group: member %d (device %d) did not finish its %s within %lld ms (option group_timeout_ms): a peer that never "
+                              "posted its side of a transfer, or a kernel that does not end.  The group is unusable now; destroy it", r, g->dev[r],
+                              stage[k], (long long)limit_ms);
+                    st = SDSL_HIP_ERR_HIP;
+                    g->poisoned = true;
+                    break;
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(waited < 5 ? 20 : 200));
+            }
+            if (done)
+                ev.push_back(done);
+            if (st != SDSL_HIP_OK)
+                break;
+            if (e != hipSuccess)
+            {
+                st = hip_fail(e, "group stream wait", __FILE__, __LINE__);
+                break;
+            }
+            ++k;
         }
     }
-    for (hipEvent_t e : ev)
-        (void)hipEventDestroy(e);
+    if (!g->poisoned)
+        for (hipEvent_t e : ev)
+            (void)hipEventDestroy(e);
     (void)hipSetDevice(g->dev[0]);
     return st;
 }

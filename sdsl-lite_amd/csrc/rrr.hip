@@ -124,7 +124,7 @@ static unsigned choose_format(const uint64_t hist[64], uint64_t n_blocks, const 
 // always raw: the sparse decoder does not take them); hist[k] = blocks of class k.  Measured on the compressed FM-index of
 // the 1 GiB text (profiles/rrr_raw_classes_r02.txt): t = 10 -> 369, 9 -> 384, 6 -> 437, 3 -> 469, 0 -> 460 Mcount/s at
 // 5.10 .. 5.16 GB; a 5 %-dense vector gets t = 7 (+0.6 % of its length) and keeps its speed (it is bound by the fetches).
-static unsigned choose_sparse_max(const uint64_t hist[64], uint64_t n_bits)
+static unsigned choose_sparse_max(const uint64_t hist[64], uint64_t n_bits, bool standalone)
 {
     if (const char * e = getenv("SDSL_HIP_RRR_SPARSE_MAX"))
     { // experiment knob
@@ -132,11 +132,15 @@ static unsigned choose_sparse_max(const uint64_t hist[64], uint64_t n_bits)
         if (v >= 0 && v <= 20)
             return (unsigned)v;
     }
-    // Where the search starts (option "rrr_sparse_limit", default 10).  A vector of 10-30 % density consists of classes 6..25, and
-    // with every class above 10 raw it takes 1.3-1.4 times SDSL's space; with the limit at 20 the classes up to 20 stay
-    // enumerative (1.12-1.14 times SDSL's: what is left is the 128-byte record), a block then costs up to eighteen bisections
-    // instead of eight, and the bucketed route (whose LDS image holds the binomial columns 3..10 only) is not taken.
-    const unsigned limit = (unsigned)std::min(20, std::max(0, g_rrr_sparse_limit.load()));
+    // Where the search starts (option "rrr_sparse_limit"; default 20 since round 6, 10 before).  A vector of 10-30 % density consists of
+    // classes 6..25, and with every class above 10 raw it takes 1.3-1.4 times SDSL's space; with the limit at 20 the classes up to 20
+    // stay enumerative (1.12-1.16 times SDSL's: what is left is the 128-byte record) and a block costs up to eighteen bisections
+    // instead of eight.  The bucketed route decodes every block of a slice ONCE whatever its class (rrr_sorted.hip: its LDS image
+    // holds the binomial columns 3..20 for such a vector), so large batches keep their speed.  The vectors INSIDE a wavelet tree stay
+    // at 10 at most: count() on csa_wt<wt_huff<rrr_vector<63>>> decodes a block per tree level and lane, and that index is sized by
+    // its raw middle classes anyway.
+    const int opt = g_rrr_sparse_limit.load();
+    const unsigned limit = (unsigned)std::min(standalone ? 20 : 10, std::max(0, opt));
     const RrrTables & T = host_tables();
     uint64_t size10 = 0; // about what the vector takes at t = limit: 13 bits of record per block + its field
     for (unsigned k = 0; k < 64; ++k)
@@ -672,7 +676,7 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
         uint64_t hist[64] = {};
         for (uint64_t b = 0; b < A.n_blocks; ++b)
             ++hist[A.cls[b]];
-        h.sparse_max = choose_sparse_max(hist, A.n_bits);
+        h.sparse_max = choose_sparse_max(hist, A.n_bits, h.allow_slim);
         h.fmt = choose_format(hist, A.n_blocks, tables_for(h.sparse_max), h.allow_slim);
     }
     const RrrTables T = tables_for(h.sparse_max);
@@ -861,6 +865,7 @@ static sdsl_hip_status rrr_upload(RrrHost & h, const RrrArrays & A, int device)
     h.view.sel_shift[1] = shb[1];
     h.view.sel_pshift = ps;
     h.view.fmt = h.fmt;
+    h.view.sparse_max = h.sparse_max;
     return SDSL_HIP_OK;
 }
 
@@ -895,7 +900,7 @@ sdsl_hip_status rrr_build_device(RrrHost & h, const uint64_t * d_words, uint64_t
         SH_HIP(hipGetLastError());
         uint64_t hist[64];
         SH_HIP(hipMemcpy(hist, dh.p, sizeof hist, hipMemcpyDeviceToHost));
-        h.sparse_max = choose_sparse_max(hist, n_bits);
+        h.sparse_max = choose_sparse_max(hist, n_bits, h.allow_slim);
         h.fmt = choose_format(hist, n_blocks, tables_for(h.sparse_max), h.allow_slim);
         if (h.fmt == 1 && n_bits >= (UINT64_C(1) << 40))
             h.fmt = 0; // (a slim record holds 40 bits of rank: also when the format was forced)
@@ -965,6 +970,7 @@ again:
     h.view.sel_shift[1] = shb[1];
     h.view.sel_pshift = ps;
     h.view.fmt = h.fmt;
+    h.view.sparse_max = h.sparse_max;
     return SDSL_HIP_OK;
 }
 
@@ -1407,9 +1413,9 @@ sdsl_hip_status sdsl_hip_rrr_rank_batch(sdsl_hip_rrr_t v, int32_t bit, const uin
     // stays on the device, both routes are enqueued, the one whose turn it is not returns at once — as for the plain vector)
     RrrHost & h = v->h;
     const int mode = g_rrr_sorted_mode.load();
-    // (a vector that keeps classes above 10 enumerative — option "rrr_sparse_limit" — is answered by the direct kernels: the slice
-    // decoder of rrr_sorted.hip stages the binomial columns of the classes up to 10)
-    const bool want = mode == 0 || h.sparse_max > 10 ? false : (mode > 0 ? rrr_sorted_rank_possible(h.view) : rrr_sorted_rank_applicable(h.view, n));
+    // (a vector that keeps classes above 10 enumerative — option "rrr_sparse_limit" — takes the same route since round 6: the slice
+    // decoder of rrr_sorted.hip stages the binomial columns 3..20 for it)
+    const bool want = mode == 0 ? false : (mode > 0 ? rrr_sorted_rank_possible(h.view) : rrr_sorted_rank_applicable(h.view, n));
     if (want)
     {
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
@@ -1557,7 +1563,7 @@ sdsl_hip_status sdsl_hip_rrr_select_batch(sdsl_hip_rrr_t v, int32_t bit, const u
     // large spread batches: the bucketed path (rrr_sorted.hip), chosen as for rank (option "rrr_sorted")
     RrrHost & h = v->h;
     const int mode = g_rrr_sorted_mode.load();
-    if (mode != 0 && h.sparse_max <= 10 && h.view.sel[bit] && (mode > 0 || (h.view.n_sb >= (UINT64_C(1) << 21) && n >= 8 * h.view.n_sb)))
+    if (mode != 0 && h.view.sel[bit] && (mode > 0 || (h.view.n_sb >= (UINT64_C(1) << 21) && n >= 8 * h.view.n_sb)))
     {
         std::lock_guard<std::mutex> lock(h.scratch_mutex);
         const bool cap = stream_is_capturing(s); // (nothing may be built or allocated then)

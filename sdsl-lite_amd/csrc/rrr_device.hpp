@@ -62,6 +62,7 @@ struct RrrView
     // is then answered by the bucketed path enqueued beside it, rrr_sorted.hip); nullptr everywhere else
     const uint32_t * skip_if;
     uint32_t fmt; // record format: 0 = RrrFmtW (34 blocks, 7-bit classes), 1 = RrrFmtS (42 blocks, 4-bit classes)
+    uint32_t sparse_max; // classes 0..sparse_max and 63-sparse_max..63 are enumerative offsets, the rest raw (<= 20: rrr.hip, choose_sparse_max)
 };
 
 // ---- device: block decoder -----------------------------------------------------------------------

@@ -21,9 +21,19 @@ namespace {
 
 static_assert(kSrRecBits == RrrFmtW::SB && kSrRecBitsSlim == RrrFmtS::SB, "bv_sorted_dev.hpp: kSrRecBits* must be the record lengths of rrr_device.hpp");
 constexpr unsigned kRsT = 1024;      // threads of an answering block
-constexpr unsigned kRsCol0 = 3, kRsCols = 8; // binomial columns the sparse decoder reads: classes 3..10 after the complement
-                                             // (the last two set bits come in closed form)
-constexpr unsigned kRsTop0 = 53;     // C(63, k) is needed for the complemented classes only: k >= 63 - 10
+constexpr unsigned kRsCol0 = 3;      // first binomial column the sparse decoder reads (the last two set bits come in closed form)
+// ... and how many: classes 3..10 after the complement for a vector whose enumerative classes end at 10 (every vector until round 5), 3..20
+// for one that keeps the classes up to 20 enumerative (option "rrr_sparse_limit", the default of stand-alone vectors since round 6:
+// 10-30 % density at SDSL's space).  5 KiB more of LDS; a wide-record slice then takes 76 KiB and two answering blocks still fit a CU.
+__host__ __device__ constexpr unsigned rs_cols(unsigned sparse_max)
+{
+    return sparse_max > 10 ? 18u : 8u;
+}
+// C(63, k) is needed for the complemented classes only: k >= 63 - sparse_max
+__host__ __device__ constexpr unsigned rs_top0(unsigned sparse_max)
+{
+    return sparse_max > 10 ? 43u : 53u;
+}
 constexpr unsigned kRsBins = 16;     // decode-cost classes of the per-slice counting sort
 
 // Records may be decoded in CHUNKS of a slice (what only the decoder needs is then sized for a chunk of NC blocks, what the keys
@@ -39,8 +49,9 @@ constexpr unsigned rs_chunks()
 struct RsLds
 { // carved out of dynamic LDS; NB = blocks of a slice, NC = blocks of a chunk
     uint64_t * raw;      // [NB] the slice's blocks, plain
-    uint64_t * cbin;     // [64][kRsCols]: C(m, kRsCol0 + j)
-    uint64_t * top;      // [11]: C(63, kRsTop0 + j)
+    uint64_t * cbin;     // [64][cols]: C(m, kRsCol0 + j)
+    uint64_t * top;      // [64 - top0]: C(63, top0 + j)
+    unsigned cols, top0; // rs_cols / rs_top0 of the vector
     uint64_t * rptr;     // [S]: first word of the record's stretch of the overflow stream
     uint32_t * rones;    // [S]: ones in front of the record, relative to the slice
     uint16_t * pre;      // [NB] ones of the record in front of the block
@@ -51,10 +62,12 @@ struct RsLds
     unsigned * cnt;      // [kRsBins + 1]
 };
 
-__device__ __forceinline__ RsLds rs_carve(unsigned char * base, unsigned S, unsigned K, unsigned chunks, bool packed_cls)
+__device__ __forceinline__ RsLds rs_carve(unsigned char * base, unsigned S, unsigned K, unsigned chunks, bool packed_cls, unsigned sparse_max)
 {
     const unsigned NB = S * K, NC = NB / chunks;
     RsLds L;
+    L.cols = rs_cols(sparse_max);
+    L.top0 = rs_top0(sparse_max);
     unsigned char * p = base;
     auto take = [&](size_t bytes) -> unsigned char *
     {
@@ -63,8 +76,8 @@ __device__ __forceinline__ RsLds rs_carve(unsigned char * base, unsigned S, unsi
         return r;
     };
     L.raw = (uint64_t *)take((size_t)NB * 8);
-    L.cbin = (uint64_t *)take(64 * kRsCols * 8);
-    L.top = (uint64_t *)take((64 - kRsTop0) * 8);
+    L.cbin = (uint64_t *)take(64 * L.cols * 8);
+    L.top = (uint64_t *)take((64 - L.top0) * 8);
     L.rptr = (uint64_t *)take((size_t)S * 8);
     L.rones = (uint32_t *)take((size_t)S * 4);
     L.pre = (uint16_t *)take((size_t)NB * 2);
@@ -76,11 +89,11 @@ __device__ __forceinline__ RsLds rs_carve(unsigned char * base, unsigned S, unsi
     return L;
 }
 
-size_t rs_lds_bytes(unsigned S, unsigned fmt)
+size_t rs_lds_bytes(unsigned S, unsigned fmt, unsigned sparse_max)
 {
     const size_t NB = (size_t)S * (fmt ? RrrFmtS::K : RrrFmtW::K), NC = NB / (fmt ? rs_chunks<RrrFmtS>() : rs_chunks<RrrFmtW>());
     auto up = [](size_t b) { return (b + 15) & ~(size_t)15; };
-    return up(NB * 8) + up(64 * kRsCols * 8) + up((64 - kRsTop0) * 8) + up((size_t)S * 8) + up((size_t)S * 4) + up(NB * 2) + 2 * up(NC * 2)
+    return up(NB * 8) + up(64 * rs_cols(sparse_max) * 8) + up((64 - rs_top0(sparse_max)) * 8) + up((size_t)S * 8) + up((size_t)S * 4) + up(NB * 2) + 2 * up(NC * 2)
            + up(fmt ? 0 : NC) + up(64) + up((kRsBins + 1) * 4);
 }
 
@@ -91,7 +104,7 @@ __device__ __forceinline__ uint64_t rs_decode(const RsLds & L, unsigned k, uint6
         return f;
     const bool flip = k > 31;
     unsigned kk = flip ? kRrrBS - k : k;
-    uint64_t nr = flip ? L.top[k - kRsTop0] - 1 - f : f;
+    uint64_t nr = flip ? L.top[k - L.top0] - 1 - f : f;
     uint64_t bits = 0;
     int hi = 62;
     while (kk > 2)
@@ -100,13 +113,13 @@ __device__ __forceinline__ uint64_t rs_decode(const RsLds & L, unsigned k, uint6
         while (lo < h)
         {
             const int mid = (lo + h + 1) >> 1;
-            if (L.cbin[mid * kRsCols + kk - kRsCol0] <= nr)
+            if (L.cbin[mid * L.cols + kk - kRsCol0] <= nr)
                 lo = mid;
             else
                 h = mid - 1;
         }
         bits |= UINT64_C(1) << (62 - lo);
-        nr -= L.cbin[lo * kRsCols + kk - kRsCol0];
+        nr -= L.cbin[lo * L.cols + kk - kRsCol0];
         --kk;
         hi = lo - 1;
     }
@@ -278,14 +291,14 @@ __global__ __launch_bounds__(kRsT) void k_rs_rank_lds(RrrView v, int bit, unsign
     if (go && !*go)
         return;
     const unsigned S = 1u << rlog, t = threadIdx.x;
-    const RsLds L = rs_carve(rs_lds, S, F::K, rs_chunks<F>(), F::id != 0);
+    const RsLds L = rs_carve(rs_lds, S, F::K, rs_chunks<F>(), F::id != 0, v.sparse_max);
     // the tables the decoder reads, once per block of threads
-    for (unsigned i = t; i < 64 * kRsCols; i += kRsT)
-        L.cbin[i] = v.tables->binom[i / kRsCols][kRsCol0 + i % kRsCols];
+    for (unsigned i = t; i < 64 * L.cols; i += kRsT)
+        L.cbin[i] = v.tables->binom[i / L.cols][kRsCol0 + i % L.cols];
     for (unsigned i = t; i < 64; i += kRsT)
     {
-        if (i >= kRsTop0)
-            L.top[i - kRsTop0] = v.tables->binom[63][i];
+        if (i >= L.top0)
+            L.top[i - L.top0] = v.tables->binom[63][i];
         L.space[i] = v.tables->space[i];
     }
     const unsigned n_items = ioff[nf];
@@ -377,13 +390,13 @@ __global__ __launch_bounds__(kRsT) void k_rs_select_lds(RrrView v, unsigned nf, 
     if (go && !*go)
         return;
     const unsigned S = 1u << rlog, t = threadIdx.x;
-    const RsLds L = rs_carve(rs_lds, S, F::K, rs_chunks<F>(), F::id != 0);
-    for (unsigned i = t; i < 64 * kRsCols; i += kRsT)
-        L.cbin[i] = v.tables->binom[i / kRsCols][kRsCol0 + i % kRsCols];
+    const RsLds L = rs_carve(rs_lds, S, F::K, rs_chunks<F>(), F::id != 0, v.sparse_max);
+    for (unsigned i = t; i < 64 * L.cols; i += kRsT)
+        L.cbin[i] = v.tables->binom[i / L.cols][kRsCol0 + i % L.cols];
     for (unsigned i = t; i < 64; i += kRsT)
     {
-        if (i >= kRsTop0)
-            L.top[i - kRsTop0] = v.tables->binom[63][i];
+        if (i >= L.top0)
+            L.top[i - L.top0] = v.tables->binom[63][i];
         L.space[i] = v.tables->space[i];
     }
     const unsigned n_items = ioff[nf];
@@ -599,7 +612,7 @@ sdsl_hip_status rrr_launch_rank_sorted(const RrrView & v, int bit, const uint64_
         return SDSL_HIP_ERR_INVALID;
     }
     const unsigned rlog = rs_rlog(v);
-    const size_t lds = rs_lds_bytes(1u << rlog, v.fmt);
+    const size_t lds = rs_lds_bytes(1u << rlog, v.fmt, v.sparse_max);
     SH_HIP(hipFuncSetAttribute((const void *)k_rs_rank_lds<RrrFmtW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SH_HIP(hipFuncSetAttribute((const void *)k_rs_rank_lds<RrrFmtS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SwCallbacks cb;
@@ -746,7 +759,7 @@ sdsl_hip_status rrr_launch_select_sorted(RrrHost & h, int bit, const uint64_t * 
     }
     const RrrView & v = h.view;
     const unsigned rlog = P.rlog;
-    const size_t lds = rs_lds_bytes(1u << rlog, v.fmt);
+    const size_t lds = rs_lds_bytes(1u << rlog, v.fmt, v.sparse_max);
     const uint64_t rec_bits = v.fmt ? RrrFmtS::SB : RrrFmtW::SB;
     SH_HIP(hipFuncSetAttribute((const void *)k_rs_select_lds<1, RrrFmtW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SH_HIP(hipFuncSetAttribute((const void *)k_rs_select_lds<0, RrrFmtW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -104,3 +104,59 @@ def test_group_fm_count_equals_single_gpu(pkg, group):
     finally:
         for r in range(n):
             L.sdsl_hip_fm_destroy(reps[r])
+
+
+def test_a_peer_that_never_turns_up_is_an_error_not_a_hang(pkg):
+    """Round 6: a batch has a deadline (option group_timeout_ms).  Three members on device 0 over the copy transport; member 1's scatter stream
+    is held by the test hook (`group_test_stall`: a kernel that spins on a host word — in the copy transport a receive that is never posted
+    IS a scatter stream that never reaches its copy).  The call must come back inside ten seconds with SDSL_HIP_ERR_HIP, name the member and
+    the stage, refuse further batches on the group — and a fresh group works once the peer is released."""
+    import os
+    import time
+    L = pkg.capi.lib()
+    os.environ["SDSL_HIP_GROUP_TRANSPORT"] = "copy"
+    try:
+        g = C.c_void_p(None)
+        pkg.capi.check(L.sdsl_hip_group_create((C.c_int32 * 3)(0, 0, 0), 3, C.byref(g)))
+        rng = np.random.default_rng(3)
+        n_bits = (1 << 20) + 5
+        words = rng.integers(0, 2**63, size=(n_bits + 63) // 64, dtype=np.int64).astype(np.uint64)
+        bv = pkg.bit_vector(words, n_bits, device=0)
+        reps = (C.c_void_p * 3)()
+        pkg.capi.check(L.sdsl_hip_group_bv_replicate(g, bv._h, reps))
+        nq = 100_000
+        idx = rng.integers(0, n_bits + 1, size=nq).astype(np.uint64)
+        got = np.empty(nq, dtype=np.uint64)
+        pkg.capi.check(L.sdsl_hip_group_bv_rank_batch(g, reps, 1, idx.ctypes.data, nq, got.ctypes.data, 2))
+        assert np.array_equal(got, bv.rank(idx, 1))
+        pkg.set_option("group_timeout_ms", 2000)
+        pkg.set_option("group_test_stall", 1)
+        t0 = time.time()
+        st = L.sdsl_hip_group_bv_rank_batch(g, reps, 1, idx.ctypes.data, nq, got.ctypes.data, 2)
+        took = time.time() - t0
+        msg = L.sdsl_hip_last_error().decode()
+        pkg.set_option("group_test_stall", -1)            # the peer turns up after all: the stuck stream drains
+        assert st == pkg.capi.ERR_HIP, (st, msg)
+        assert took < 10.0, took
+        assert "member 1" in msg and "scatter" in msg and "group_timeout_ms" in msg, msg
+        st2 = L.sdsl_hip_group_bv_rank_batch(g, reps, 1, idx.ctypes.data, nq, got.ctypes.data, 2)
+        assert st2 == pkg.capi.ERR_HIP and "destroy" in L.sdsl_hip_last_error().decode()
+        import torch
+        torch.cuda.synchronize()
+        for r in range(1, 3):
+            L.sdsl_hip_bv_destroy(reps[r])
+        pkg.capi.check(L.sdsl_hip_group_destroy(g))
+        # a fresh group on the same device answers
+        pkg.set_option("group_timeout_ms", 120000)
+        g2 = C.c_void_p(None)
+        pkg.capi.check(L.sdsl_hip_group_create((C.c_int32 * 3)(0, 0, 0), 3, C.byref(g2)))
+        pkg.capi.check(L.sdsl_hip_group_bv_replicate(g2, bv._h, reps))
+        pkg.capi.check(L.sdsl_hip_group_bv_rank_batch(g2, reps, 1, idx.ctypes.data, nq, got.ctypes.data, 2))
+        assert np.array_equal(got, bv.rank(idx, 1))
+        for r in range(1, 3):
+            L.sdsl_hip_bv_destroy(reps[r])
+        pkg.capi.check(L.sdsl_hip_group_destroy(g2))
+    finally:
+        pkg.set_option("group_test_stall", -1)
+        pkg.set_option("group_timeout_ms", 120000)
+        del os.environ["SDSL_HIP_GROUP_TRANSPORT"]

@@ -310,3 +310,49 @@ def test_c4_whole_batch_strided_digests_at_both_footprints(gpu):
     csa.count(pats, m, out)
     check_strided(out, w, "configs[4] count at 1.5 x the reference's footprint, whole batch")
     csa.close()
+
+
+def test_c4r_the_repetitive_stand_in_matches_reference_digests(gpu):
+    """configs[3] / [4] on the REPETITIVE stand-in (english_text_repetitive(2^30, 1234, 30): 30 % of the 64 KiB blocks are rotated copies of
+    earlier ones — the duplicated passages of a real collection; a 20-byte pattern cut from the text occurs 2.4 times on average and 46 % of
+    the patterns more than once, against 1.017 times on the first stand-in): the first 10^6 and every 100th of 10^8 wt.rank / count answers
+    of the real csa_wt<wt_huff<>> (make_golden_large.py c4r) — with suffix array and text resident (the single-suffix shortcut fires late
+    or never for half of the patterns), with both dropped, and at 1.5 x the reference's bytes."""
+    import torch
+    c = G.get("c4r")
+    if not c:
+        pytest.skip("golden_large.json holds no c4r block (make_golden_large.py c4r)")
+    nt = 1 << c["text_log"]
+    host = gpu.english_text_repetitive(nt, c["text_seed"], c["copy_percent"])
+    assert hashlib.sha256(host.tobytes()).hexdigest() == c["text_sha256"]
+    text = torch.from_numpy(host).cuda()
+    del host
+    csa = gpu.csa_wt(text=text, device=0)
+    assert csa.size() == c["csa_size"] and csa.sigma() == c["sigma"]
+    w = c["wt_rank_strided"]
+    gi = gpu.rnd_positions_device(c["wt_i_seed"], w["count"], nt + 2, 0, 0)
+    gc = text[gpu.rnd_positions_device(c["wt_c_seed"], w["count"], nt, 0, 0)]
+    out = torch.empty(w["count"], dtype=torch.int64, device="cuda")
+    csa.wavelet_tree.rank(gi, gc, out)
+    check(out[: c["wt_rank"]["n"]].cpu().numpy(), c["wt_rank"], "wt_huff rank(i, c) on the repetitive text, first answers")
+    check_strided(out, w, "wt_huff rank(i, c) on the repetitive text, whole batch")
+    del gi, gc
+    w = c["count_strided"]
+    m = c["m"]
+    st = gpu.rnd_positions_device(c["pattern_seed"], w["count"], nt - m, 0, 0)
+    pats = text[(st.view(-1, 1) + torch.arange(m, device="cuda").view(1, m)).reshape(-1)].contiguous()
+    del st
+    for stage in ("suffix array and text resident", "samples only", "1.5 x the reference's bytes"):
+        if stage == "samples only":
+            blob_bytes = len(csa.serialize(32, 64, gpu.capi.LAYOUT_BV_MCL))
+            csa.drop_sa()
+        elif stage.startswith("1.5"):
+            csa.set_footprint(int(1.5 * blob_bytes))
+            assert csa.device_bytes() <= 1.5 * blob_bytes
+        out.zero_()
+        csa.count(pats, m, out)
+        check(out[: c["count"]["n"]].cpu().numpy(), c["count"], f"count on the repetitive text ({stage}), first answers")
+        check_strided(out, w, f"count on the repetitive text ({stage}), whole batch")
+    mean = float(out[: c["count"]["n"]].double().mean())
+    assert abs(mean - c["mean_count"]) < 1e-9 and mean > 2.0
+    csa.close()

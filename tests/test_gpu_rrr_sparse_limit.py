@@ -1,4 +1,4 @@
-"""Option "rrr_sparse_limit": an rrr_vector<63> of 10-30 % density keeps the classes up to 20 (instead of 10) enumerative — the
+"""Option "rrr_sparse_limit" (default 20 since round 6; 10 before): an rrr_vector<63> of 10-30 % density keeps the classes up to 20 (instead of 10) enumerative — the
 space of SDSL's vector plus the record overhead instead of 63 raw bits for every block of eleven or more ones (rrr.hip:
 choose_sparse_max; the reference decodes every class from its offset, rrr_vector.hpp:158-270 / rrr_helper.hpp:480-534).  The
 decoder then walks up to eighteen bisections per block; every query kernel, the device encoder, the loader and the writer of
@@ -22,7 +22,7 @@ def build(gpu, w, n_bits, limit, **kw):
     try:
         return gpu.rrr_vector(w, n_bits) if w is not None else gpu.rrr_vector(**kw)
     finally:
-        gpu.set_option("rrr_sparse_limit", 10)
+        gpu.set_option("rrr_sparse_limit", 20)  # (the default since round 6)
 
 
 @pytest.mark.parametrize("n_bits,d", [(700_001, 0.10), (700_001, 0.15), (900_000, 0.20), (500_000, 0.30), (600_000, 0.85),
@@ -41,7 +41,7 @@ def test_limit_20_equals_default_numpy_and_sdsl_bytes(gpu, n_bits, d):
     cum = np.concatenate([[0], np.cumsum(bits, dtype=np.int64)]).astype(np.uint64)
     idx = np.concatenate([rng.integers(0, n_bits + 1, 80_000, dtype=np.uint64), np.arange(min(n_bits + 1, 5000), dtype=np.uint64),
                           np.arange(max(0, n_bits - 5000), n_bits + 1, dtype=np.uint64)])
-    for route in (0, 1):                                # 1: "whenever possible" — not possible here, the direct kernels answer
+    for route in (0, 1):                                # 1: "whenever possible" — the bucketed route, whose slice decoder holds the columns 3..20 (round 6)
         gpu.set_option("rrr_sorted", route)
         try:
             assert np.array_equal(np.asarray(cmp.rank(idx, 1)), cum[idx]), "rank_1 against numpy"
@@ -90,3 +90,38 @@ def test_space_against_sdsl_between_10_and_30_percent(gpu):
     for d, r10, r20 in rows:
         assert r20 <= 1.25, rows
         assert r20 <= r10 - (0.0 if d <= 0.10 else 0.10), rows
+
+
+def test_the_default_is_20_and_large_batches_stay_bucketed(gpu):
+    """a stand-alone vector of 20 % density built with NO option set keeps the classes up to 20 enumerative (smaller than with the limit at
+    10) and a large batch takes the bucketed route on it (last_phases names its passes) with the direct kernels' answers; the vectors
+    inside a wavelet tree keep the limit 10 (count() decodes a block per level and lane)."""
+    import torch
+    n_bits = 1 << 28
+    w = gpu.density_bits(n_bits, 27, 20)
+    v = gpu.rrr_vector(w, n_bits)
+    gpu.set_option("rrr_sparse_limit", 10)
+    try:
+        old = gpu.rrr_vector(w, n_bits)
+    finally:
+        gpu.set_option("rrr_sparse_limit", 20)
+    assert v.device_bytes() < 0.92 * old.device_bytes()
+    idx = torch.randint(0, n_bits + 1, (30_000_000,), device="cuda", dtype=torch.int64)
+    gpu.set_option("trace_phases", 1)
+    gpu.set_option("rrr_sorted", 1)
+    try:
+        got = v.rank(idx, 1)
+        phases = gpu.last_phases()
+        sel_i = torch.randint(1, v.ones() + 1, (20_000_000,), device="cuda", dtype=torch.int64)
+        got_s = v.select(sel_i, 1)
+    finally:
+        gpu.set_option("rrr_sorted", 0)
+        gpu.set_option("trace_phases", 0)
+    try:
+        assert phases, "the batch did not take the bucketed route"
+        assert torch.equal(got, v.rank(idx, 1)) and torch.equal(got, old.rank(idx, 1))
+        assert torch.equal(got_s, v.select(sel_i, 1)) and torch.equal(got_s, old.select(sel_i, 1))
+    finally:
+        gpu.set_option("rrr_sorted", -1)
+    v.close()
+    old.close()

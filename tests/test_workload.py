@@ -6,6 +6,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -64,3 +65,31 @@ def test_golden_large_has_every_config(pkg):
         for k in keys:
             assert len(g[c][k]["first"]) == 10_000 and len(g[c][k]["sha256"]) == 64
     assert g["c4"]["sigma"] >= 200 and 4.5 <= g["c4"]["H0"] <= 4.8
+
+
+def test_the_repetitive_text_copies_whole_blocks_and_stays_prefix_stable(pkg):
+    """english_text_repetitive: percent 0 is english_text; with 30 % copies a prefix of the text is the text of that length, no zero byte,
+    the alphabet statistics stay English-class, and a copied block is a ROTATION of the (chain of) earlier block(s) it copies"""
+    import hashlib
+    n = 1 << 23
+    plain = pkg.english_text(n, 1234)
+    rep = pkg.english_text_repetitive(n, 1234, 30)
+    assert np.array_equal(pkg.english_text_repetitive(1 << 20, 1234, 0), plain[: 1 << 20])
+    assert np.array_equal(pkg.english_text_repetitive(1 << 20, 1234, 30), rep[: 1 << 20]) and (rep != 0).all()
+    blk = 1 << 16
+    nb = n // blk
+    same = np.array([np.array_equal(rep[b * blk:(b + 1) * blk], plain[b * blk:(b + 1) * blk]) for b in range(nb)])
+    assert same[0] and 0.55 < same.mean() < 0.85, same.mean()
+    # every copied block is a rotation of an ORIGINAL block in front of it
+    digests = {hashlib.sha256(np.sort(plain[b * blk:(b + 1) * blk]).tobytes()).hexdigest(): b for b in range(nb) if same[b]}
+    for b in np.flatnonzero(~same)[:20]:
+        src = digests.get(hashlib.sha256(np.sort(rep[b * blk:(b + 1) * blk]).tobytes()).hexdigest())
+        assert src is not None and src < b, b
+        s = plain[src * blk:(src + 1) * blk]
+        dbl = np.concatenate([s, s]).tobytes()
+        assert rep[b * blk:(b + 1) * blk].tobytes() in dbl, "a rotation of its source"
+    cnt = np.bincount(rep, minlength=256)
+    p = cnt[cnt > 0] / n
+    assert (cnt > 0).sum() > 200 and 4.3 < float(-(p * np.log2(p)).sum()) < 4.8
+    with pytest.raises(Exception):
+        pkg.english_text_repetitive(1 << 12, 1, 96)

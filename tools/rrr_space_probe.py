@@ -40,7 +40,7 @@ def main():
         for limit in (10, 20):
             pkg.set_option("rrr_sparse_limit", limit)
             v = pkg.rrr_vector(w, n_bits)
-            pkg.set_option("rrr_sparse_limit", 10)
+            pkg.set_option("rrr_sparse_limit", 20)
             if sdsl is None:
                 sdsl = len(v.serialize()) * 8 / n_bits
             bpb = v.device_bytes() * 8 / n_bits
