@@ -753,6 +753,14 @@ __global__ __launch_bounds__(1024) void k_sr_fine_scan_starts(unsigned nf, unsig
 // round walks all keys of the item and answers — and stores — those whose line lies in the staged part (the others' stores go
 // beyond the buffer's end, i.e. nowhere).  The keys are read once per round (they sit in the L2 by then) and an answer is the
 // ones in front of the position relative to the WHOLE slice's first line, as the way back expects.
+// (MULTI, round 6: the keys are read once per round and a 128-byte line of answers is completed by up to eight rounds — through the
+// caches (AUX 0) the re-reads hit the L2 and the partial stores of a line merge there before they leave for HBM; streamed
+// (non-temporal) they went out as partial sectors.  SDSL_HIP_WIDE_NT=1 at compile time keeps the streamed form for A/B.)
+#ifdef SDSL_HIP_WIDE_NT
+constexpr bool kWideCached = false;
+#else
+constexpr bool kWideCached = true;
+#endif
 template <bool MULTI>
 __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigned nf, unsigned d1, unsigned d2, const uint32_t * __restrict__ fstart,
                                                      const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys, const uint32_t * __restrict__ go,
@@ -815,7 +823,12 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
         uint32_t key[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            buf_load(rs_k, t * 4u, (unsigned)u * kRT * 4u, key[u]);
+            {
+                if constexpr (MULTI && kWideCached)
+                    buf_load_cached(rs_k, t * 4u, (unsigned)u * kRT * 4u, key[u]);
+                else
+                    buf_load(rs_k, t * 4u, (unsigned)u * kRT * 4u, key[u]);
+            }
         __syncthreads();
         const uint64_t H = slice[0].x;
         __syncthreads();
@@ -835,7 +848,12 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    buf_load(rs_k, t * 4u, n0 + (unsigned)u * kRT * 4u, nk[u]);
+                    {
+                    if constexpr (MULTI && kWideCached)
+                        buf_load_cached(rs_k, t * 4u, n0 + (unsigned)u * kRT * 4u, nk[u]);
+                    else
+                        buf_load(rs_k, t * 4u, n0 + (unsigned)u * kRT * 4u, nk[u]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -861,7 +879,7 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
                 unsigned vo = u == 0 && i0 == 0 ? vo0 : t * 4u;
                 if (MULTI && (!here || (key[u] == kBad && sub != 0)))
                     vo = 0xFFFFFFFCu; // another round's key: not stored
-                __builtin_amdgcn_raw_buffer_store_b32(r, rs_k, (int)vo, (int)(i0 * 4u + (unsigned)u * kRT * 4u), kAuxNT);
+                __builtin_amdgcn_raw_buffer_store_b32(r, rs_k, (int)vo, (int)(i0 * 4u + (unsigned)u * kRT * 4u), MULTI && kWideCached ? 0 : kAuxNT);
             }
             if (i0 + kRT * U < cnth)
             {

@@ -263,6 +263,11 @@ __device__ __forceinline__ void buf_load(rsrc_t r, unsigned voff, unsigned soff,
 {
     out = __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, kAuxNT);
 }
+// the same through the caches (AUX 0): for data that is read again soon
+__device__ __forceinline__ void buf_load_cached(rsrc_t r, unsigned voff, unsigned soff, uint32_t & out)
+{
+    out = __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ void buf_load(rsrc_t r, unsigned voff, unsigned soff, uint64_t & out)
 {
     typedef unsigned v2u32 __attribute__((ext_vector_type(2)));

