@@ -317,9 +317,10 @@ sdsl_hip_status sdsl_hip_wt_select_batch(sdsl_hip_wt_t wt, const uint64_t * i, c
  * 64-bit sorter the same way, construct_sa.hpp:120-153) are sorted with 64-bit suffixes — 40 bytes of working memory per
  * symbol — and keep the suffix array as 8 bytes per suffix, the text and a k-mer table with 40-bit intervals (k <= 6), plus SA /
  * ISA samples at csa_wt's default densities 32 / 64 (csa_wt.hpp:56), which are what sdsl_hip_fm_drop_sa leaves and what
- * sdsl_hip_fm_serialize writes; every query is answered (rank, LF and count on the fused layout up to 2^36 symbols, count of
- * large batches through the 40-bit variants of its kernels; the fused select directory is a 32-bit structure: select walks the
- * binary levels there). */
+ * sdsl_hip_fm_serialize writes; every query is answered (rank, LF, count and select on the fused 16-ary lines up to 2^36 symbols —
+ * 64-bit superblock counts and select-directory entries from 2^32 symbols on, line arithmetic exact for every position — count of
+ * large batches through the 40-bit variants of its kernels; from 2^36 symbols on the binary levels answer.  sdsl_hip_limit names
+ * every gate, INTEGRATION.md 3b tabulates them). */
 sdsl_hip_status sdsl_hip_fm_create_from_bwt(const uint8_t * bwt, uint64_t n, int32_t device, sdsl_hip_fm_t * out);
 sdsl_hip_status sdsl_hip_fm_create_from_text(const uint8_t * text, uint64_t n_text, int32_t device,
                                              sdsl_hip_fm_t * out);

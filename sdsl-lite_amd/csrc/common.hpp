@@ -107,6 +107,13 @@ struct DevBuf
     }
     sdsl_hip_status alloc(size_t n, bool zero = false);
     void release();
+    // gives the memory up WITHOUT freeing it: hipFree waits for the device, and a device with work that will never finish (a device
+    // group past its deadline, group.cpp) must not take the caller's thread with it
+    void leak()
+    {
+        p = nullptr;
+        bytes = 0;
+    }
     template <class T>
     T * as() const
     {

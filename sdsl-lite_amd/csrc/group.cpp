@@ -13,6 +13,7 @@
 #include <chrono>
 #include <dlfcn.h>
 #include <memory>
+#include <string>
 #include <thread>
 #include <rccl/rccl.h>
 
@@ -322,47 +323,60 @@ sdsl_hip_status group_run(sdsl_hip_group_s * g, const uint8_t * d_in, size_t in_
     // SDSL_HIP_ERR_HIP and marks the group unusable (the work that is stuck cannot be cancelled: destroy the group).
     const int64_t limit_ms = g_group_timeout_ms.load();
     const auto t_start = std::chrono::steady_clock::now();
-    static const char * const stage[3] = {"scatter (shards to the members)", "kernels", "gather (answers to the root)"};
+    static const char * const stage[3] = {"scatter", "kernels", "gather"};
+    std::vector<hipEvent_t> done((size_t)G * 3, nullptr);
     for (int r = 0; r < G && st == SDSL_HIP_OK; ++r)
     {
         (void)hipSetDevice(g->dev[r]);
         int k = 0;
         for (hipStream_t s : {g->s_in[r], g->s_k[r], g->s_out[r]})
         {
-            hipEvent_t done = nullptr;
-            hipError_t e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+            hipError_t e = hipEventCreateWithFlags(&done[(size_t)r * 3 + k], hipEventDisableTiming);
             if (e == hipSuccess)
-                e = hipEventRecord(done, s);
-            while (e == hipSuccess)
-            {
-                e = hipEventQuery(done);
-                if (e != hipErrorNotReady)
-                    break;
-                e = hipSuccess;
-                const int64_t waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
-                if (limit_ms > 0 && waited > limit_ms)
-                {
-                    set_error("device group: member %d (device %d) did not finish its %s within %lld ms (option group_timeout_ms): a peer that never "
-                              "posted its side of a transfer, or a kernel that does not end.  The group is unusable now; destroy it", r, g->dev[r],
-                              stage[k], (long long)limit_ms);
-                    st = SDSL_HIP_ERR_HIP;
-                    g->poisoned = true;
-                    break;
-                }
-                std::this_thread::sleep_for(std::chrono::microseconds(waited < 5 ? 20 : 200));
-            }
-            if (done)
-                ev.push_back(done);
-            if (st != SDSL_HIP_OK)
-                break;
-            if (e != hipSuccess)
-            {
+                e = hipEventRecord(done[(size_t)r * 3 + k], s);
+            if (e != hipSuccess && st == SDSL_HIP_OK)
                 st = hip_fail(e, "group stream wait", __FILE__, __LINE__);
-                break;
-            }
             ++k;
         }
     }
+    for (size_t i = 0; i < done.size() && st == SDSL_HIP_OK;)
+    { // (in order: when the last one is ready, all are)
+        const hipError_t e = done[i] ? hipEventQuery(done[i]) : hipSuccess;
+        if (e == hipSuccess)
+        {
+            ++i;
+            continue;
+        }
+        if (e != hipErrorNotReady)
+        {
+            st = hip_fail(e, "group stream wait", __FILE__, __LINE__);
+            break;
+        }
+        const int64_t waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count();
+        if (limit_ms > 0 && waited > limit_ms)
+        { // every stage that has not finished, by member (stages behind a stuck one wait for it; so may another member's stream that
+          // shares its hardware queue — the first member listed with ALL its later stages is where to look)
+            std::string who;
+            for (size_t j = 0; j < done.size(); ++j)
+                if (done[j] && hipEventQuery(done[j]) == hipErrorNotReady)
+                {
+                    char buf[96];
+                    snprintf(buf, sizeof buf, "%smember %d (device %d) %s", who.empty() ? "" : ", ", (int)(j / 3), g->dev[j / 3], stage[j % 3]);
+                    who += buf;
+                }
+            (void)hipGetLastError();
+            set_error("device group: not finished within %lld ms (option group_timeout_ms): %s — a peer that never posted its side of a "
+                      "transfer, or a kernel that does not end.  The group is unusable now; destroy it", (long long)limit_ms, who.c_str());
+            st = SDSL_HIP_ERR_HIP;
+            g->poisoned = true;
+            break;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(waited < 5 ? 20 : 200));
+    }
+    (void)hipGetLastError(); // (hipErrorNotReady of the polls is not an error of the call)
+    for (hipEvent_t e : done)
+        if (e)
+            ev.push_back(e);
     if (!g->poisoned)
         for (hipEvent_t e : ev)
             (void)hipEventDestroy(e);
@@ -654,12 +668,22 @@ static sdsl_hip_status group_bv_query(sdsl_hip_group_t g, const sdsl_hip_bv_t * 
     SH_TRY(in.in(arg, n * 8, nullptr));
     SH_TRY(o.out(out, n * 8));
     SH_HIP(hipDeviceSynchronize()); // staging copies ran on the null stream; the group's streams are non-blocking
-    SH_TRY(group_run(g, (const uint8_t *)in.dev, 8, (uint8_t *)o.dev, 8, n, chunks,
-                     [&](int r, const uint8_t * pin, uint8_t * pout, uint64_t cnt, hipStream_t s) -> sdsl_hip_status
-                     {
-                         return select ? sdsl_hip_bv_select_batch(replicas[r], bit, (const uint64_t *)pin, cnt, (uint64_t *)pout, s)
-                                       : sdsl_hip_bv_rank_batch(replicas[r], bit, (const uint64_t *)pin, cnt, (uint64_t *)pout, s);
-                     }));
+    const sdsl_hip_status st =
+        group_run(g, (const uint8_t *)in.dev, 8, (uint8_t *)o.dev, 8, n, chunks,
+                  [&](int r, const uint8_t * pin, uint8_t * pout, uint64_t cnt, hipStream_t s) -> sdsl_hip_status
+                  {
+                      return select ? sdsl_hip_bv_select_batch(replicas[r], bit, (const uint64_t *)pin, cnt, (uint64_t *)pout, s)
+                                    : sdsl_hip_bv_rank_batch(replicas[r], bit, (const uint64_t *)pin, cnt, (uint64_t *)pout, s);
+                  });
+    if (st != SDSL_HIP_OK)
+    {
+        if (g->poisoned)
+        { // stuck work may still read the staging copies, and freeing them would wait for it
+            in.tmp.leak();
+            o.tmp.leak();
+        }
+        return st;
+    }
     return o.finish(nullptr);
 }
 
@@ -777,9 +801,18 @@ sdsl_hip_status sdsl_hip_group_fm_count_batch(sdsl_hip_group_t g, const sdsl_hip
     SH_TRY(in.in(patterns, n_patterns * m, nullptr));
     SH_TRY(o.out(out, n_patterns * 8));
     SH_HIP(hipDeviceSynchronize());
-    SH_TRY(group_run(g, (const uint8_t *)in.dev, m, (uint8_t *)o.dev, 8, n_patterns, chunks,
-                     [&](int r, const uint8_t * pin, uint8_t * pout, uint64_t cnt, hipStream_t s) -> sdsl_hip_status
-                     { return sdsl_hip_fm_count_batch(replicas[r], pin, m, cnt, (uint64_t *)pout, s); }));
+    const sdsl_hip_status st = group_run(g, (const uint8_t *)in.dev, m, (uint8_t *)o.dev, 8, n_patterns, chunks,
+                                         [&](int r, const uint8_t * pin, uint8_t * pout, uint64_t cnt, hipStream_t s) -> sdsl_hip_status
+                                         { return sdsl_hip_fm_count_batch(replicas[r], pin, m, cnt, (uint64_t *)pout, s); });
+    if (st != SDSL_HIP_OK)
+    {
+        if (g->poisoned)
+        {
+            in.tmp.leak();
+            o.tmp.leak();
+        }
+        return st;
+    }
     return o.finish(nullptr);
 }
 

@@ -16,12 +16,12 @@ struct WtHost
     BvHost bv;          // the concatenated WT bit vector as rank lines (+ select directories)
     RrrHost rrr;        // ... or as an rrr_vector<63>
     DevBuf d_tables;    // WtTables image in HBM
-    DevBuf d_fused;     // the fused (8-ary) layout used by the rank-type traversals (wt_device.hpp), optional
+    DevBuf d_fused;     // the fused layout (16-ary lines; 8-ary in a SDSL_HIP_FUSED_K=3 build) walked by rank / access / LF / count / select (wt_device.hpp), optional
     DevBuf d_ftables;   // its node tables (WtFusedTables)
     DevBuf d_fsuper;    // 16-ary lines: the superblocks' counts (wt_device.hpp), 32-bit or — 2^32 symbols and more — 64-bit records
     DevBuf d_fwalk;     // the layout by fused node (WtFusedWalk), optional
     DevBuf d_fsteps;    // the layout by symbol (WtStepTab), optional
-    DevBuf d_tables_f;  // node table of the fused layout's OWN tree shape (8-ary Huffman written as a binary tree); empty
+    DevBuf d_tables_f;  // node table of the fused layout's OWN tree shape (2^kFK-ary Huffman written as a binary tree); empty
                         // when the fused layout was derived from the SDSL-shaped tree itself
     WtTables tables_f;  // host copy of it
     DevBuf d_fsel, d_fsel_tables; // its select directory (wt_device.hpp: WtFusedSelTables), optional
@@ -88,7 +88,7 @@ uint64_t wt_bv_bits(const WtHost & wt);
 // SDSL's binary levels released / rebuilt from the fused lines (wt.hip; plain backend with the fused layout only)
 sdsl_hip_status wt_drop_binary(WtHost & wt);
 sdsl_hip_status wt_restore_binary(WtHost & wt);
-// Derives the fused layout from the finished binary tree (plain backend, fewer than 2^32 symbols; SDSL_HIP_WT_FUSED=0
+// Derives the fused layout from the finished binary tree (plain backend, fewer than kLimWtFusedSymbols = 2^36 symbols; SDSL_HIP_WT_FUSED=0
 // in the environment turns it off).  A no-op otherwise.
 sdsl_hip_status wt_build_fused(WtHost & wt);
 
