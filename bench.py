@@ -252,8 +252,8 @@ def summary_of(ex):
     """a few figures of the other legs for the line (everything else: the sidecar)"""
     s = {}
     for key, fields in (("select_1", ("Gq/s", "roofline_frac", "reference_digest_match")),
-                        ("rrr63_rank_1", ("Gq/s", "bits_per_bit", "reference_digest_match")),
-                        ("rrr63_select_1", ("Gq/s", "reference_digest_match")),
+                        ("rrr63_rank_1", ("Gq/s", "bits_per_bit", "traffic_frac", "reference_digest_match")),
+                        ("rrr63_select_1", ("Gq/s", "traffic_frac", "reference_digest_match")),
                         ("wt_huff_rank", ("Gq/s", "roofline_frac", "reference_digest_match")),
                         ("wt_huff_select", ("Gq/s", "reference_digest_match")),
                         ("sd_vector", ("rank_1_Gq/s", "select_1_Gq/s", "select_0_Gq/s")),

@@ -239,6 +239,8 @@ def leg_rrr(c):
         "note": "measured fabric bytes of ALL kernels of a bucketed step (tools/rrr_probe.py under the counters, "
                 "profiles/pmc_latest.json) over the 8 TB/s peak — the honest fraction of this path: roofline_frac prices every "
                 "query at SURVEY 8(d)'s 144 bytes, which a batch that reads each record once does not move (it can exceed 1)"}
+    ex["rrr63_rank_1"]["traffic_frac"] = ex["rrr63_rank_1"]["fabric_traffic"]["frac_of_hbm_peak"]  # (what the line's summary carries)
+    ex["rrr63_rank_1"]["survey_8d_model_frac"] = ex["rrr63_rank_1"].pop("roofline_frac")          # (> 1 is possible: not a roofline fraction)
     # the direct kernel (one record fetch and one block decode per query) beside it, same answers
     pkg.set_option("rrr_sorted", 0)
     out_d = torch.empty_like(out)
@@ -257,6 +259,8 @@ def leg_rrr(c):
     bq = pmc_traffic("rrr_select_bucketed_bytes_per_query")
     ex["rrr63_select_1"]["fabric_traffic"] = {"bytes_per_query": bq,
                                               "frac_of_hbm_peak": bq * nq / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if bq else None}
+    ex["rrr63_select_1"]["traffic_frac"] = ex["rrr63_select_1"]["fabric_traffic"]["frac_of_hbm_peak"]
+    ex["rrr63_select_1"]["survey_8d_model_frac"] = ex["rrr63_select_1"].pop("roofline_frac")
     pkg.set_option("rrr_sorted", 0)
     out_d = torch.empty_like(out)
     _, ms_d = time_steps(lambda: rv.select(si, 1, out_d), 2, 1, barrier)

@@ -1314,9 +1314,32 @@ __device__ __forceinline__ uint64_t wt8_cascade(const WtView & wt, const WtTable
     return i;
 }
 
+// 16-ary lines, first: the superblock records of node u — thread (superblock, t) cascades the first position of every superblock that
+// starts inside the node (the one the node starts in counts from the node's start and has no record of its own)
+__global__ __launch_bounds__(256) void k_wt8_supers(WtView wt, unsigned u, uint64_t n_lines_u, uint64_t first_line, uint32_t * __restrict__ sup, bool wide)
+{
+    const WtTables * T = wt.tables;
+    const uint64_t sb0 = (first_line >> kFSuperLog) + 1, sb1 = (first_line + n_lines_u - 1) >> kFSuperLog; // records sb0 .. sb1
+    if (sb1 < sb0)
+        return;
+    const uint64_t n = (sb1 - sb0 + 1) * kFSlots;
+    for (uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x; id < n; id += (uint64_t)gridDim.x * 256)
+    {
+        const uint64_t sb = sb0 + id / kFSlots;
+        const unsigned t = (unsigned)id & (kFSlots - 1);
+        bool ok;
+        const uint64_t c = wt8_cascade(wt, T, u, ((sb << kFSuperLog) - first_line) * kFusedPos, t, ok);
+        const uint64_t at = sb * kFSlots + t;
+        if (wide)
+            reinterpret_cast<uint64_t *>(sup)[at] = ok ? c : UINT64_C(0);
+        else
+            sup[at] = ok ? (uint32_t)c : 0u;
+    }
+}
+
 // counts: thread (line, t) cascades the line's first position of node u down slot t's bits.  16-ary: the header holds the count
 // relative to the first line of the line's superblock (wt_device.hpp: fused_super; superblocks are counted in absolute lines,
-// `first_line` = the node's first), whose own count the thread cascades as well and stores if the line is that one; in the superblock
+// `first_line` = the node's first), whose own count k_wt8_supers has written; in the superblock
 // the node starts in, the counts are the node's own.  fl = the node's first line, sup = the whole table (64-bit records if `wide`).
 __global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint64_t n_lines_u, uint64_t * __restrict__ fl, uint64_t first_line,
                                                     uint32_t * __restrict__ sup, bool wide)
@@ -1336,19 +1359,12 @@ __global__ __launch_bounds__(256) void k_wt8_counts(WtView wt, unsigned u, uint6
             const uint64_t abs_line = first_line + line, sabs = abs_line & ~(uint64_t)((1u << kFSuperLog) - 1); // the superblock's first line
             uint64_t cs = 0; // (the superblock the node starts in: counted from the node's start)
             if (sabs > first_line)
-            {
-                bool ok2;
-                cs = sabs == abs_line ? c : wt8_cascade(wt, T, u, (sabs - first_line) * kFusedPos, t, ok2);
-                if (sabs == abs_line)
-                {
-                    const uint64_t at = (abs_line >> kFSuperLog) * kFSlots + t;
-                    if (wide)
-                        reinterpret_cast<uint64_t *>(sup)[at] = ok ? c : UINT64_C(0);
-                    else
-                        sup[at] = ok ? (uint32_t)c : 0u;
-                }
+            { // the superblock's own count: k_wt8_supers has written it (round 5 cascaded it again in every one of the superblock's
+              // 2^kFSuperLog lines: twice the rank walks of the whole pass)
+                const uint64_t at = (abs_line >> kFSuperLog) * kFSlots + t;
+                cs = wide ? reinterpret_cast<const uint64_t *>(sup)[at] : (uint64_t)sup[at];
             }
-            const uint32_t rel = ok ? (uint32_t)(c - cs) : 0u; // < 2^(16 + kFSpare)
+            const uint32_t rel = ok ? (uint32_t)(c - cs) : 0u; // < 2^(16 + kFSpare); modulo 2^32 when the record holds the low word only
             uint64_t * sec = fl + line * kFusedWords + 4 * (t >> 2);
             reinterpret_cast<uint16_t *>(sec)[t & 3] = (uint16_t)rel;
             if (kFSpare != 0 && (rel >> 16)) // the top bits of field t & 3 of the section's third word (k_wt8_planes has written the word)
@@ -1654,6 +1670,9 @@ static sdsl_hip_status fused_from(const WtHost & src, WtHost & dst)
         if (size[v])
             hipLaunchKernelGGL(k_wt8_planes, dim3(grid_for((size[v] + kFLane - 1) / kFLane, 4, 256u * 8u)), dim3(256), 0, 0, view, v,
                                size[v], at);
+        if (kFK == 4)
+            hipLaunchKernelGGL(k_wt8_supers, dim3(grid_for(((lines_v >> kFSuperLog) + 2) * kFSlots, 256, wt8_grid_cap())), dim3(256), 0, 0, view, v, lines_v,
+                               (uint64_t)FT.fline[v], sup_lo, sup_wide);
         hipLaunchKernelGGL(k_wt8_counts, dim3(grid_for(lines_v * kFSlots, 256, wt8_grid_cap())), dim3(256), 0, 0, view, v, lines_v, at,
                            (uint64_t)FT.fline[v], sup_lo, sup_wide);
     }

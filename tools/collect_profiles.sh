@@ -22,7 +22,8 @@ for w in $WHAT; do
       tools/prof.sh walk_sa python $R/tools/kernel_probe.py sa
       tools/prof.sh walk_extract python $R/tools/kernel_probe.py extract
       tools/prof.sh walk_locate python $R/tools/kernel_probe.py locate
-      tools/prof.sh rrr_count python $R/tools/kernel_probe.py rrr_count ;;
+      tools/prof.sh rrr_count python $R/tools/kernel_probe.py rrr_count
+      tools/prof.sh rrr_count_lean python $R/tools/kernel_probe.py rrr_count_lean ;;
     sd)    tools/prof.sh sd_rank python $R/tools/kernel_probe.py sd_rank
            tools/prof.sh sd_select1 python $R/tools/kernel_probe.py sd_select1
            tools/prof.sh sd_select0 python $R/tools/kernel_probe.py sd_select0 ;;

@@ -1,6 +1,6 @@
 """One operation of the secondary kernels per run, for the profiler (tools/prof.sh) and as a quick rate check: the bench's text and
 sizes, PROBE_UNITS = what tools/pmc_json.py divides the counters by.
-usage: kernel_probe.py <sa|extract|locate|rrr_count|sd_rank|sd_select0|sd_select1|wt_select> [text MiB = 1024] [queries]"""
+usage: kernel_probe.py <sa|extract|locate|rrr_count|rrr_count_lean|sd_rank|sd_select0|sd_select1|wt_select> [text MiB = 1024] [queries]"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,7 +24,7 @@ def run(name, fn, units, unit_name):
     print(f"PROBE_UNITS {units * (REPS + 1)}")
 
 
-if what in ("sa", "extract", "locate", "rrr_count", "wt_select"):
+if what in ("sa", "extract", "locate", "rrr_count", "rrr_count_lean", "wt_select"):
     nt = mib << 20
     text = torch.from_numpy(pkg.english_text(nt, 1234)).to(dev)
 if what in ("sa", "extract", "locate"):
@@ -47,8 +47,11 @@ if what in ("sa", "extract", "locate"):
     else:
         off, pos = csa.sa_range(lq, rq)
         run("locate (sa_range of %d intervals, %d occurrences)" % (npat, pos.numel()), lambda: csa.sa_range(lq, rq), pos.numel(), "occ")
-elif what == "rrr_count":
+elif what in ("rrr_count", "rrr_count_lean"):
     crrr = pkg.csa_wt(text=text, rrr=True)
+    if what == "rrr_count_lean":  # 1.5 x the bytes of the real library's csa_wt<wt_huff<rrr_vector<63>>, 32, 64> stream (bench_extras.py: fm_count_rrr63_lean)
+        crrr.set_footprint(int(1.5 * len(crrr.serialize(32, 64, pkg.capi.LAYOUT_RRR63))))
+        print(f"  footprint {crrr.device_bytes()} B: {crrr.footprint_parts()}")
     m, npat = 20, int(float(sys.argv[3])) if len(sys.argv) > 3 else 20_000_000
     st = bench.to_dev(pkg.rnd_positions(15, npat, nt - m, 0), dev)
     pats = text[(st.view(-1, 1) + torch.arange(m, device=dev).view(1, m)).reshape(-1)].contiguous()

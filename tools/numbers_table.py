@@ -71,7 +71,7 @@ for key, name, wl in (("select_1", "bucketed select_1", "10^9 select_1, 2^34 bit
         row(name, wl, d.get("Gq/s"), "G/s", d.get("kernel_ms"), d, d.get("reference_digest_match"), cpu_of(d))
         k = d.get("direct_kernel")
         if k:
-            rows.append(f"| … direct kernel | same | **{f(k.get('Gq/s'), 1)} G/s** | {f(k.get('kernel_ms'), 2)} | {f(k.get('frac'), 2)} | — | — | — | {f(k.get('same_answers'))} | — |")
+            rows.append(f"| … direct kernel | same | **{f(k.get('Gq/s'), 1)} G/s** | {f(k.get('kernel_ms'), 2)} | {f(k.get('frac', k.get('roofline_frac')), 2)} | — | — | — | {f(k.get('same_answers'))} | — |")
 sd = ex.get("sd_vector")
 if sd:
     rows.append(f"| `sd_vector<>` rank_1 / select_1 / select_0 | {f(sd.get('queries'))} queries, 2^{sd.get('universe_log2')} universe, {f(sd.get('ones'))} ones | **{f(sd.get('rank_1_Gq/s'))} / {f(sd.get('select_1_Gq/s'))} / {f(sd.get('select_0_Gq/s'))} G/s** | — | "

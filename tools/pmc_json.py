@@ -113,6 +113,7 @@ for op in ("rank", "select"):
 PROBES = {"walk_sa": ("fm_sa", lambda k: k.startswith("k_fm_walk")), "walk_extract": ("fm_extract", lambda k: k.startswith(("k_fm_walk", "k_fm_piece", "k_fm_lengths"))),
           "walk_locate": ("fm_locate", lambda k: k.startswith(("k_fm_walk", "k_fm_expand", "k_fm_lengths"))),
           "rrr_count": ("fm_count_rrr63", lambda k: k.startswith("k_fm_count_rrr") or k.startswith("k_fm_verify") or k.startswith("k_fm_keys")),
+          "rrr_count_lean": ("fm_count_rrr63_lean", lambda k: k.startswith("k_fm_count_rrr") or k.startswith("k_fm_verify") or k.startswith("k_fm_keys")),
           "wt_select": ("wt_select", lambda k: k.startswith(("k_wt_sel", "k_sw_", "k_sr_"))),
           "sd_rank": ("sd_rank", lambda k: k.startswith(("k_sd_rank<", "k_sd_rank_lane", "k_sd_redo")) or k in ("k_sd_rank",)),
           "sd_select1": ("sd_select1", lambda k: k.startswith("k_sd_select") and "select0" not in k),
