@@ -1,12 +1,15 @@
 """ONE numbers table for DESIGN.md, generated — no figure in it is typed by hand.
 Sources: the committed line (profiles/bench_<tag>_line.json), its sidecar (profiles/bench_extras_<tag>.json) and the condensed counter
 collection the line quotes (profiles/pmc_latest.json).  usage: python tools/numbers_table.py [tag = r06] > docs/design/NUMBERS.md"""
+import io
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+tag = args[0] if args else "r06"
+WRITE = "--write" in sys.argv  # docs/design/NUMBERS.md and the block between the NUMBERS markers of README.md
 line = json.load(open(os.path.join(ROOT, "profiles", f"bench_{tag}_line.json")))
 side = json.load(open(os.path.join(ROOT, "profiles", f"bench_extras_{tag}.json")))
 ex = side.get("extras", side)
@@ -121,6 +124,8 @@ d = ex.get("beyond_2_32")
 if d:
     rows.append(f"| index of {f(d.get('symbols'))} symbols | built from text in {f(d.get('build_from_text_s'))} s, {f(d.get('resident_GB'))} GB resident | " + " / ".join(f"{k}: {f(v)}" for k, v in d.items() if k.endswith('/s')) + " | — | — | — | — | — | — | — |")
 
+_real_stdout = sys.stdout
+sys.stdout = buf = io.StringIO()
 print(f"# Numbers (generated by tools/numbers_table.py {tag}; do not edit)")
 print()
 print(f"Sources: `profiles/bench_{tag}_line.json` (the ONE line of `python bench.py`), `profiles/bench_extras_{tag}.json` (its sidecar), `profiles/pmc_latest.json` "
@@ -155,3 +160,20 @@ ph = (h.get("roofline") or {}).get("phases_ms")
 if ph:
     print()
     print("**Where the headline's step goes** (ms, medians): " + ", ".join(f"{k} {f(v, 2)}" for k, v in ph.items()))
+
+sys.stdout = _real_stdout
+text = buf.getvalue()
+if not WRITE:
+    sys.stdout.write(text)
+else:
+    with open(os.path.join(ROOT, "docs", "design", "NUMBERS.md"), "w") as fo:
+        fo.write(text)
+    rd = os.path.join(ROOT, "README.md")
+    r = open(rd).read()
+    a, b = "<!-- NUMBERS:BEGIN (tools/numbers_table.py --write) -->", "<!-- NUMBERS:END -->"
+    if a in r and b in r:
+        main_table = text[text.index("| kernel / route |"):]
+        main_table = main_table[:main_table.index("\n\n")] if "\n\n" in main_table else main_table
+        r = r[:r.index(a) + len(a)] + "\n" + main_table + "\n" + r[r.index(b):]
+        open(rd, "w").write(r)
+    print("wrote docs/design/NUMBERS.md" + (" and README.md's table" if a in r else ""))
