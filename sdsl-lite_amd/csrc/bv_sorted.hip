@@ -761,19 +761,22 @@ constexpr bool kWideCached = false;
 #else
 constexpr bool kWideCached = true;
 #endif
-template <bool MULTI>
-__global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigned nf, unsigned d1, unsigned d2, const uint32_t * __restrict__ fstart,
+// SUBLOG / THREADS (round 6): lines staged per round and threads of a block.  The single-round kernel is <false, kSliceLog, kRT>: 64 KiB of
+// lines, two blocks of 512 threads per CU.  Wide slices take <true, kSliceLog + 1, 2 * kRT>: 128 KiB per round and ONE block of 1024 threads
+// per CU — the same waves per CU, half the rounds, i.e. half the walks over an item's keys (2^36 bits: two rounds instead of four).
+template <bool MULTI, unsigned SUBLOG = kSliceLog, unsigned THREADS = kRT>
+__global__ __launch_bounds__(THREADS) void k_sr_rank_lds(BvView bv, int bit, unsigned nf, unsigned d1, unsigned d2, const uint32_t * __restrict__ fstart,
                                                      const uint32_t * __restrict__ ioff, uint32_t * __restrict__ keys, const uint32_t * __restrict__ go,
                                                      unsigned slog)
 {
     if (go && !*go)
         return;
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
-    __shared__ v2u64 slice[(kLW << kSliceLog) / 2]; // 64 KiB
+    __shared__ v2u64 slice[(kLW << SUBLOG) / 2]; // 64 KiB (SUBLOG 10) or 128 KiB (11)
     // the rewritten headers live in an array of their own: inside the lines they all sit at multiples of 64 bytes, i.e. in
     // 4 of the 64 LDS banks, and a wave's 64 random header reads serialise 16-fold (SQ_LDS_BANK_CONFLICT was 75 % of the
     // LDS cycles); packed, consecutive headers are 8 bytes apart and random reads spread over all banks
-    __shared__ uint64_t hdr[1u << kSliceLog];
+    __shared__ uint64_t hdr[1u << SUBLOG];
     __shared__ unsigned sh_f;
     constexpr int U = 8;
     const unsigned t = threadIdx.x;
@@ -795,19 +798,19 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
         }
         __syncthreads(); // also: everybody is done with the previous slice
         const unsigned f = sh_f;
-        const uint64_t Ls = (uint64_t)sr_slice_of(f, d1, d2) << (MULTI ? slog : kSliceLog); // the slice's first line
-        const unsigned n_sub = MULTI ? 1u << (slog - kSliceLog) : 1u;
+        const uint64_t Ls = (uint64_t)sr_slice_of(f, d1, d2) << (MULTI ? slog : SUBLOG); // the slice's first line
+        const unsigned n_sub = MULTI ? 1u << (slog - SUBLOG) : 1u;
         const uint64_t Hs = MULTI ? bv.lines[Ls * kLW] : 0; // ones in front of the slice
       for (unsigned sub = 0; sub < n_sub; ++sub)
       {
-        const uint64_t L0 = Ls + ((uint64_t)sub << kSliceLog);
+        const uint64_t L0 = Ls + ((uint64_t)sub << SUBLOG);
         if (MULTI && L0 >= bv.n_lines)
             break;
         if (MULTI && sub)
             __syncthreads(); // everybody is done with the part staged before
-        const unsigned nl = (unsigned)(bv.n_lines - L0 < (UINT64_C(1) << kSliceLog) ? bv.n_lines - L0 : (UINT64_C(1) << kSliceLog));
+        const unsigned nl = (unsigned)(bv.n_lines - L0 < (UINT64_C(1) << SUBLOG) ? bv.n_lines - L0 : (UINT64_C(1) << SUBLOG));
         const v2u64 * src = reinterpret_cast<const v2u64 *>(bv.lines + L0 * kLW);
-        for (unsigned i = t; i < nl * (kLW / 2); i += kRT)
+        for (unsigned i = t; i < nl * (kLW / 2); i += THREADS)
             slice[i] = __builtin_nontemporal_load(src + i);
         const uint64_t lo = (uint64_t)fstart[f] + (uint64_t)(item - ioff[f]) * kItemKeys;
         const uint64_t fend = fstart[f + 1];
@@ -825,14 +828,14 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
         for (int u = 0; u < U; ++u)
             {
                 if constexpr (MULTI && kWideCached)
-                    buf_load_cached(rs_k, t * 4u, (unsigned)u * kRT * 4u, key[u]);
+                    buf_load_cached(rs_k, t * 4u, (unsigned)u * THREADS * 4u, key[u]);
                 else
-                    buf_load(rs_k, t * 4u, (unsigned)u * kRT * 4u, key[u]);
+                    buf_load(rs_k, t * 4u, (unsigned)u * THREADS * 4u, key[u]);
             }
         __syncthreads();
         const uint64_t H = slice[0].x;
         __syncthreads();
-        for (unsigned ln = t; ln < nl; ln += kRT)
+        for (unsigned ln = t; ln < nl; ln += THREADS)
         {
             v2u64 * w = slice + ln * (kLW / 2);
             const v2u64 a = w[0], b = w[1], c = w[2];
@@ -840,19 +843,19 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
             hdr[ln] = (a.x - H) | ((uint64_t)ca << 20) | ((uint64_t)cb << 29) | ((uint64_t)cc << 38);
         }
         __syncthreads();
-        for (unsigned i0 = 0; i0 < cnth; i0 += kRT * U)
+        for (unsigned i0 = 0; i0 < cnth; i0 += THREADS * U)
         { // the next round's keys are requested before this round's answers are stored (loads and stores share a counter)
             uint32_t nk[U];
-            const unsigned n0 = (i0 + kRT * U) * 4u;
-            if (i0 + kRT * U < cnth)
+            const unsigned n0 = (i0 + THREADS * U) * 4u;
+            if (i0 + THREADS * U < cnth)
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     {
                     if constexpr (MULTI && kWideCached)
-                        buf_load_cached(rs_k, t * 4u, n0 + (unsigned)u * kRT * 4u, nk[u]);
+                        buf_load_cached(rs_k, t * 4u, n0 + (unsigned)u * THREADS * 4u, nk[u]);
                     else
-                        buf_load(rs_k, t * 4u, n0 + (unsigned)u * kRT * 4u, nk[u]);
+                        buf_load(rs_k, t * 4u, n0 + (unsigned)u * THREADS * 4u, nk[u]);
                 }
             }
 #pragma unroll
@@ -861,8 +864,8 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
                 if (u == 0 && i0 == 0 && t < head)
                     key[u] = kBad; // (a key of the line's head: the item in front of this one answers it)
                 const unsigned lnf = key[u] == kBad ? 0 : key[u] >> kOffBits; // line inside the slice
-                const bool here = !MULTI || key[u] == kBad || (lnf >> kSliceLog) == sub; // staged in this round (kBad: answered in round 0)
-                const unsigned ln = MULTI ? (here ? lnf & ((1u << kSliceLog) - 1) : 0u) : lnf;
+                const bool here = !MULTI || key[u] == kBad || (lnf >> SUBLOG) == sub; // staged in this round (kBad: answered in round 0)
+                const unsigned ln = MULTI ? (here ? lnf & ((1u << SUBLOG) - 1) : 0u) : lnf;
                 const unsigned off = key[u] & ((1u << kOffBits) - 1);
                 const v2u64 * w = slice + ln * (kLW / 2);
                 const unsigned wi = off >> 6, k = (wi + 1) >> 1; // data word of the position, 16-byte quarter holding it
@@ -879,9 +882,9 @@ __global__ __launch_bounds__(kRT) void k_sr_rank_lds(BvView bv, int bit, unsigne
                 unsigned vo = u == 0 && i0 == 0 ? vo0 : t * 4u;
                 if (MULTI && (!here || (key[u] == kBad && sub != 0)))
                     vo = 0xFFFFFFFCu; // another round's key: not stored
-                __builtin_amdgcn_raw_buffer_store_b32(r, rs_k, (int)vo, (int)(i0 * 4u + (unsigned)u * kRT * 4u), MULTI && kWideCached ? 0 : kAuxNT);
+                __builtin_amdgcn_raw_buffer_store_b32(r, rs_k, (int)vo, (int)(i0 * 4u + (unsigned)u * THREADS * 4u), MULTI && kWideCached ? 0 : kAuxNT);
             }
-            if (i0 + kRT * U < cnth)
+            if (i0 + THREADS * U < cnth)
             {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -1449,7 +1452,13 @@ sdsl_hip_status sr_launch_answers(const BvView & v, int op, int bit, const Selec
     {
         hipLaunchKernelGGL(k_sr_slice_bases, dim3((nf + 255) / 256), dim3(256), 0, s, v, nf, 0u, d2, hf, slog);
         if (slog > kSliceLog)
-            hipLaunchKernelGGL(k_sr_rank_lds<true>, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, 0u, d2, fstart, ioff, keys2, go, slog);
+        {
+#ifdef SDSL_HIP_WIDE_ROUNDS_1K
+            hipLaunchKernelGGL((k_sr_rank_lds<true>), dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, 0u, d2, fstart, ioff, keys2, go, slog);
+#else
+            hipLaunchKernelGGL((k_sr_rank_lds<true, kSliceLog + 1, 2 * kRT>), dim3(slice_blocks), dim3(2 * kRT), 0, s, v, bit, nf, 0u, d2, fstart, ioff, keys2, go, slog);
+#endif
+        }
         else
             hipLaunchKernelGGL(k_sr_rank_lds<false>, dim3(slice_blocks), dim3(kRT), 0, s, v, bit, nf, 0u, d2, fstart, ioff, keys2, go, slog);
     }

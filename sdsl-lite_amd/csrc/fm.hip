@@ -955,6 +955,7 @@ static sdsl_hip_status sdsl_hip_fm_set_footprint_impl(sdsl_hip_fm_t fm, uint64_t
     const uint64_t table_budget = max_bytes - floor_bytes;
     const bool table_user = !rrr || n < (UINT64_C(1) << 32);
     bool drop_table = false;
+    sdsl_hip_status deep_st = SDSL_HIP_OK;
     if (!table_user || table_budget < 128)
         drop_table = fm->deep_k != 0;
     else if (fm->d_deep.bytes > table_budget || (!fm->deep_k && table_budget >= (UINT64_C(64) << 10)))
@@ -964,13 +965,17 @@ static sdsl_hip_status sdsl_hip_fm_set_footprint_impl(sdsl_hip_fm_t fm, uint64_t
             if (!fm->d_text.p)
                 drop_table = fm->deep_k != 0; // created without a resident text: no table can be built
             else
-                SH_TRY(fm_build_deep(fm, 8, table_budget));
+                deep_st = fm_build_deep(fm, 8, table_budget);
         }
         else
         {
             SH_TRY(fm_ensure_sa_text(fm));
-            SH_TRY(fm_build_deep(fm, 8, table_budget));
+            deep_st = fm_build_deep(fm, 8, table_budget);
         }
+        // (an index whose suffix array is not of the width its intervals call for — 2^32 - 2 or 2^32 - 1 symbols, or a small
+        // text sent through the 64-bit sorter by SDSL_HIP_SA64 — cannot build the table: it goes without one, the call does not fail)
+        if (deep_st != SDSL_HIP_OK && deep_st != SDSL_HIP_ERR_UNSUPPORTED)
+            return deep_st;
         if (fm->d_deep.bytes > table_budget)
             drop_table = true; // (no depth fits: fm_build_deep kept what there was)
     }
