@@ -96,11 +96,28 @@ __device__ __forceinline__ u32x4 rec_head(uint32_t q, typename FmPos<WIDE>::type
         h.w = rem;
     return h;
 }
-// what a search that has stopped at ONE suffix leaves for k_fm_verify2: [1 | characters left | the suffix's SA index]
+// What a search that has stopped at a FEW suffixes leaves for k_fm_verify2: [1 | suffixes - 1 : 3 | characters left | the first suffix's SA
+// index].  Round 3 stopped at ONE suffix (a random 20-byte pattern of the first stand-in text occurs 1.017 times); in a collection with
+// duplicated passages (tests: english_text_repetitive, 2.4 occurrences on average) half of the patterns never get down to one suffix and
+// walked every remaining character.  The remaining characters stand in front of each of the interval's suffixes or not: comparing them at
+// s <= kFmVerifyMax suffixes costs 1 + s fetches (the SA entries share a line) against 1.3 fused lines per remaining character.
+#ifndef SDSL_HIP_FM_VERIFY_MAX
+#define SDSL_HIP_FM_VERIFY_MAX 8
+#endif
+constexpr uint32_t kFmVerifyMax = SDSL_HIP_FM_VERIFY_MAX; // 1: round 3's form (A/B)
+static_assert(kFmVerifyMax >= 1 && kFmVerifyMax <= 8, "three bits hold suffixes - 1");
 template <bool WIDE>
-__device__ __forceinline__ uint64_t pending_word(uint32_t rem, typename FmPos<WIDE>::type l)
+__device__ __forceinline__ uint64_t pending_word(uint32_t rem, typename FmPos<WIDE>::type l, uint32_t s = 1)
 {
-    return WIDE ? kFmPending | ((uint64_t)(rem & 0x7FFFFFu) << 40) | (uint64_t)l : kFmPending | ((uint64_t)rem << 32) | (uint64_t)l;
+    return WIDE ? kFmPending | ((uint64_t)(s - 1) << 60) | ((uint64_t)(rem & 0xFFFFFu) << 40) | (uint64_t)l
+                : kFmPending | ((uint64_t)(s - 1) << 60) | ((uint64_t)(rem & 0x0FFFFFFFu) << 32) | (uint64_t)l;
+}
+// is the text comparison the cheaper end of a search with `rem` characters to go on the interval [l, e)?
+template <bool WIDE>
+__device__ __forceinline__ bool verify_pays(uint64_t l, uint64_t e, uint32_t rem)
+{
+    const uint64_t s = e - l; // (one character left: its LF step is cheaper than SA[l] + the text)
+    return s >= 1 && s <= kFmVerifyMax && rem >= 2 && rem >= s && rem < (WIDE ? (1u << 20) : (1u << 28));
 }
 
 // quad lookup of `key` in the k-mer table: true (and [l, e)) if present
@@ -166,10 +183,10 @@ __global__ __launch_bounds__(256) void k_fm_start(FmDeep D, uint64_t csa_size, c
                 done = true;
                 res = e - l;
             }
-            else if (VERIFY && e - l == 1 && rem >= 2)
-            { // (one character left: its LF step is cheaper than SA[l] + the text)
+            else if (VERIFY && verify_pays<WIDE>(l, e, rem))
+            {
                 done = true;
-                res = pending_word<WIDE>(rem, l);
+                res = pending_word<WIDE>(rem, l, (uint32_t)(e - l));
             }
         }
         const u32x4 h = rec_head<WIDE>(q, l, e, rem, done);
@@ -241,10 +258,10 @@ __global__ __launch_bounds__(256) void k_fm_start_dense(FmJump J, const FmTables
                         done = true;
                         res = e - l;
                     }
-                    else if (VERIFY && e - l == 1 && rem >= 2)
+                    else if (VERIFY && verify_pays<WIDE>(l, e, rem))
                     {
                         done = true;
-                        res = pending_word<WIDE>(rem, l);
+                        res = pending_word<WIDE>(rem, l, (uint32_t)(e - l));
                     }
                 }
             }
@@ -398,8 +415,8 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
                 res = 0;
             else if (rem == 0)
                 res = e - l;
-            else if (VERIFY && e - l == 1 && rem >= 2)
-                res = pending_word<WIDE>(rem, l);
+            else if (VERIFY && verify_pays<WIDE>(l, e, rem))
+                res = pending_word<WIDE>(rem, l, (uint32_t)(e - l));
             else
                 fin = false;
             if (fin)
@@ -465,47 +482,73 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
     }
 }
 
-// count() of the patterns whose search stopped at a single suffix: the suffix stands at SA[l] in the text, so the pattern's
-// remaining characters pats[begin .. begin + rem) occur right in front of it or nowhere.  One lane per pattern.
+// count() of the patterns whose search stopped at a few suffixes: suffix i of the interval stands at SA[i] in the text, so the pattern's
+// remaining characters pats[begin .. begin + rem) occur right in front of it or not — the count is the number of suffixes where they
+// do.  One lane per pattern (the SA entries of an interval are neighbours: one line).
 template <class SA>
 __global__ __launch_bounds__(256) void k_fm_verify2(const SA * __restrict__ sa, const uint8_t * __restrict__ text,
                                                     const uint8_t * __restrict__ pats, uint32_t m, uint32_t n_pat,
                                                     uint64_t * __restrict__ out)
 {
-    constexpr bool WIDE = sizeof(SA) == 8; // the pending word of an index of 2^32 suffixes and more: [1 | length : 23 | suffix : 40]
+    constexpr bool WIDE = sizeof(SA) == 8; // the pending word of an index of 2^32 suffixes and more: [1 | s - 1 : 3 | length : 20 | suffix : 40]
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_pat; q += gridDim.x * blockDim.x)
     {
         const uint64_t v = out[q];
         if (!(v >> 63))
             continue;
         const uint64_t l = WIDE ? v & ((UINT64_C(1) << 40) - 1) : (uint64_t)(uint32_t)v;
-        const uint32_t rem = WIDE ? (uint32_t)(v >> 40) & 0x7FFFFFu : (uint32_t)(v >> 32) & 0x7FFFFFFFu;
+        const uint32_t rem = WIDE ? (uint32_t)(v >> 40) & 0xFFFFFu : (uint32_t)(v >> 32) & 0x0FFFFFFFu;
+        const uint32_t ns = (uint32_t)(v >> 60) & 7u; // suffixes - 1
         const uint8_t * p = pats + (uint64_t)q * m;
-        const uint64_t at = sa[l];
-        bool ok = at >= rem;
-        if (ok)
+        uint64_t at[kFmVerifyMax];
+#pragma unroll
+        for (uint32_t j = 0; j < kFmVerifyMax; ++j)
+            at[j] = j <= ns ? (uint64_t)sa[l + j] : 0; // (all requested before the first text byte is)
+        uint64_t pw[2] = {0, 0}; // the pattern's first 16 of the remaining bytes (rem <= 16: every 20-byte pattern behind a k-mer table)
+        if (rem >= 8)
         {
-            const uint8_t * t = text + (at - rem);
-            if (rem >= 8)
+            __builtin_memcpy(&pw[0], p, 8);
+            __builtin_memcpy(&pw[1], p + (rem >= 16 ? 8 : rem - 8), 8);
+        }
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kFmVerifyMax; ++j)
+        {
+            if (j > ns)
+                break;
+            bool ok = at[j] >= rem;
+            if (ok)
             {
-                uint64_t diff = 0;
-                for (uint32_t j = 0; j + 8 <= rem; j += 8)
+                const uint8_t * t = text + (at[j] - rem);
+                if (rem >= 8)
                 {
                     uint64_t x, y;
-                    __builtin_memcpy(&x, t + j, 8);
-                    __builtin_memcpy(&y, p + j, 8);
-                    diff |= x ^ y;
+                    __builtin_memcpy(&x, t, 8);
+                    __builtin_memcpy(&y, t + (rem >= 16 ? 8 : rem - 8), 8);
+                    uint64_t diff = (x ^ pw[0]) | (y ^ pw[1]);
+                    for (uint32_t k = 16; k + 8 <= rem; k += 8)
+                    {
+                        uint64_t a, b;
+                        __builtin_memcpy(&a, t + k, 8);
+                        __builtin_memcpy(&b, p + k, 8);
+                        diff |= a ^ b;
+                    }
+                    if (rem > 16)
+                    { // the last eight bytes (they may overlap the chunk before)
+                        uint64_t a, b;
+                        __builtin_memcpy(&a, t + rem - 8, 8);
+                        __builtin_memcpy(&b, p + rem - 8, 8);
+                        diff |= a ^ b;
+                    }
+                    ok = diff == 0;
                 }
-                uint64_t x, y; // the last eight bytes (they may overlap the chunk before)
-                __builtin_memcpy(&x, t + rem - 8, 8);
-                __builtin_memcpy(&y, p + rem - 8, 8);
-                ok = (diff | (x ^ y)) == 0;
+                else
+                    for (uint32_t k = 0; k < rem; ++k)
+                        ok = ok && t[k] == p[k];
             }
-            else
-                for (uint32_t j = 0; j < rem; ++j)
-                    ok = ok && t[j] == p[j];
+            cnt += ok ? 1u : 0u;
         }
-        out[q] = ok ? 1 : 0;
+        out[q] = cnt;
     }
 }
 
