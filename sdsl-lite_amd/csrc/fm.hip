@@ -93,8 +93,10 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
             { // next character (suffix_array_algorithm.hpp:176-200)
                 if (!(it > begin && r + 1 - l > 0))
                     break;
-                if (VERIFY && !WANT_IVAL && l == r && it > begin + 1 && it - begin < (csa_size >> 32 ? (UINT64_C(1) << 23) : (UINT64_C(1) << 31)))
-                { // one suffix left and at least two characters to go: k_fm_verify compares them with the text
+                if (VERIFY && !WANT_IVAL && r - l < kFmVerifyMax && it > begin + 1 && it < end && it - begin > r - l &&
+                    it - begin < (csa_size >> 32 ? (UINT64_C(1) << 20) : (UINT64_C(1) << 28)) && it - begin <= 16 &&
+                    !fm_tail_has_zero(load_tail16(pats, it), (uint32_t)(it - begin)))
+                { // a few suffixes left and at least that many (two) characters to go: k_fm_verify compares them with the text at each
                     pending = true;
                     break;
                 }
@@ -154,38 +156,51 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
                 out_l[q] = l;
                 out_r[q] = r;
             }
-            else // (pending: [1 : 1 | characters left : 31 | the suffix : 32], or [1 | 23 | 40] on an index of 2^32 suffixes and more)
-                out_cnt[q] = VERIFY && pending ? (UINT64_C(1) << 63) | ((uint64_t)(it - begin) << (csa_size >> 32 ? 40 : 32)) | l : r + 1 - l;
+            else // (pending: fm_device.hpp, fm_pending_word)
+                out_cnt[q] = VERIFY && pending ? fm_pending_word(csa_size >> 32 ? 40 : 32, l, r + 1 - l, it - begin) : r + 1 - l;
         }
     }
 }
 
-// count() of the patterns whose search stopped at a single suffix: the suffix stands at SA[l] in the text, so the pattern's
-// remaining characters pats[begin .. begin + rem) occur there or nowhere.  One lane per pattern.
+// count() of the patterns whose search stopped at a few suffixes: suffix i of the interval stands at SA[i] in the text, so the pattern's
+// remaining characters pats[begin .. begin + rem) stand right in front of it or not; the count is the number of suffixes where they do.
+// One lane per pattern.
 template <class SA>
 __global__ __launch_bounds__(256) void k_fm_verify(const SA * __restrict__ sa, const uint8_t * __restrict__ text,
                                                    const uint8_t * __restrict__ pats, uint32_t m, const uint64_t * __restrict__ offsets,
                                                    uint64_t n_pat, uint64_t * __restrict__ out_cnt, uint64_t csa_size)
 {
-    const unsigned LB = csa_size >> 32 ? 40 : 32; // (the packing of k_fm_count's pending word)
+    const unsigned LB = csa_size >> 32 ? 40 : 32; // (the packing of the pending word: fm_device.hpp)
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_pat; q += (uint64_t)gridDim.x * blockDim.x)
     {
         const uint64_t v = out_cnt[q];
         if (!(v >> 63))
             continue;
         const uint64_t l = v & ((UINT64_C(1) << LB) - 1);
-        const uint32_t rem = (uint32_t)((v >> LB) & ((UINT64_C(1) << (63 - LB)) - 1));
+        const uint32_t rem = (uint32_t)((v >> LB) & ((UINT64_C(1) << (60 - LB)) - 1));
+        const uint32_t ns = (uint32_t)(v >> 60) & 7u; // suffixes - 1
         const uint64_t begin = offsets ? offsets[q] : q * (uint64_t)m;
-        const uint64_t at = sa[l];
-        bool ok = at >= rem;
-        if (ok)
+        const uint8_t * p = pats + begin;
+        uint64_t at[kFmVerifyMax];
+#pragma unroll
+        for (uint32_t j = 0; j < kFmVerifyMax; ++j)
+            at[j] = j <= ns ? (uint64_t)sa[l + j] : 0;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kFmVerifyMax; ++j)
         {
-            const uint8_t * t = text + (at - rem);
-            const uint8_t * p = pats + begin;
-            for (uint32_t j = 0; j < rem && ok; ++j)
-                ok = t[j] == p[j];
+            if (j > ns)
+                break;
+            bool ok = at[j] >= rem;
+            if (ok)
+            {
+                const uint8_t * t = text + (at[j] - rem);
+                for (uint32_t k = 0; k < rem && ok; ++k)
+                    ok = t[k] == p[k];
+            }
+            cnt += ok ? 1u : 0u;
         }
-        out_cnt[q] = ok ? 1 : 0;
+        out_cnt[q] = cnt;
     }
 }
 

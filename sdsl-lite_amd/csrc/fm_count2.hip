@@ -39,25 +39,7 @@ __device__ __forceinline__ void fm_stage_ctab(FmCountTab * lds, const FmCountTab
     __syncthreads();
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-// the 16 bytes in front of byte offset `end` of the pattern array (as a little-endian 128-bit number: .w's top byte is the
-// byte at end - 1); what lies in front of the array's first byte reads as 0
-__device__ __forceinline__ u32x4 load_tail16(const uint8_t * __restrict__ pats, uint64_t end)
-{
-    u32x4 v;
-    if (end >= 16)
-        __builtin_memcpy(&v, pats + end - 16, 16);
-    else
-    {
-        uint8_t b[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            b[j] = (uint64_t)(15 - j) < end ? pats[end - 16 + j] : 0; // (only reached for the first pattern of a batch)
-        __builtin_memcpy(&v, b, 16);
-    }
-    return v;
-}
+// (u32x4, load_tail16, fm_tail_has_zero: fm_device.hpp)
 
 struct FmRec
 {
@@ -101,11 +83,7 @@ __device__ __forceinline__ u32x4 rec_head(uint32_t q, typename FmPos<WIDE>::type
 // duplicated passages (tests: english_text_repetitive, 2.4 occurrences on average) half of the patterns never get down to one suffix and
 // walked every remaining character.  The remaining characters stand in front of each of the interval's suffixes or not: comparing them at
 // s <= kFmVerifyMax suffixes costs 1 + s fetches (the SA entries share a line) against 1.3 fused lines per remaining character.
-#ifndef SDSL_HIP_FM_VERIFY_MAX
-#define SDSL_HIP_FM_VERIFY_MAX 8
-#endif
-constexpr uint32_t kFmVerifyMax = SDSL_HIP_FM_VERIFY_MAX; // 1: round 3's form (A/B)
-static_assert(kFmVerifyMax >= 1 && kFmVerifyMax <= 8, "three bits hold suffixes - 1");
+// (kFmVerifyMax: fm_device.hpp)
 template <bool WIDE>
 __device__ __forceinline__ uint64_t pending_word(uint32_t rem, typename FmPos<WIDE>::type l, uint32_t s = 1)
 {
@@ -113,11 +91,13 @@ __device__ __forceinline__ uint64_t pending_word(uint32_t rem, typename FmPos<WI
                 : kFmPending | ((uint64_t)(s - 1) << 60) | ((uint64_t)(rem & 0x0FFFFFFFu) << 32) | (uint64_t)l;
 }
 // is the text comparison the cheaper end of a search with `rem` characters to go on the interval [l, e)?
+// (`m` = the pattern's length: at least ONE character must have gone through the index — a pattern may END with the sentinel byte 0, which
+// the index holds and the text buffer does not; a 0 anywhere else never matches, in the index or in the text)
 template <bool WIDE>
-__device__ __forceinline__ bool verify_pays(uint64_t l, uint64_t e, uint32_t rem)
+__device__ __forceinline__ bool verify_pays(uint64_t l, uint64_t e, uint32_t rem, uint32_t m)
 {
     const uint64_t s = e - l; // (one character left: its LF step is cheaper than SA[l] + the text)
-    return s >= 1 && s <= kFmVerifyMax && rem >= 2 && rem >= s && rem < (WIDE ? (1u << 20) : (1u << 28));
+    return s >= 1 && s <= kFmVerifyMax && rem >= 2 && rem >= s && rem < m && rem < (WIDE ? (1u << 20) : (1u << 28));
 }
 
 // quad lookup of `key` in the k-mer table: true (and [l, e)) if present
@@ -183,7 +163,7 @@ __global__ __launch_bounds__(256) void k_fm_start(FmDeep D, uint64_t csa_size, c
                 done = true;
                 res = e - l;
             }
-            else if (VERIFY && verify_pays<WIDE>(l, e, rem))
+            else if (VERIFY && verify_pays<WIDE>(l, e, rem, m) && rem <= 16 && !fm_tail_has_zero(load_tail16(pats, (uint64_t)q * m + rem), rem))
             {
                 done = true;
                 res = pending_word<WIDE>(rem, l, (uint32_t)(e - l));
@@ -258,7 +238,7 @@ __global__ __launch_bounds__(256) void k_fm_start_dense(FmJump J, const FmTables
                         done = true;
                         res = e - l;
                     }
-                    else if (VERIFY && verify_pays<WIDE>(l, e, rem))
+                    else if (VERIFY && verify_pays<WIDE>(l, e, rem, m) && rem <= 16 && !fm_tail_has_zero(load_tail16(pats, (uint64_t)q * m + rem), rem))
                     {
                         done = true;
                         res = pending_word<WIDE>(rem, l, (uint32_t)(e - l));
@@ -415,7 +395,7 @@ __global__ __launch_bounds__(256) void k_fm_count_flat(const uint64_t * __restri
                 res = 0;
             else if (rem == 0)
                 res = e - l;
-            else if (VERIFY && verify_pays<WIDE>(l, e, rem))
+            else if (VERIFY && verify_pays<WIDE>(l, e, rem, m) && rem == wcnt && !fm_tail_has_zero(w, wcnt)) // (w: the next wcnt characters)
                 res = pending_word<WIDE>(rem, l, (uint32_t)(e - l));
             else
                 fin = false;
@@ -830,7 +810,9 @@ bool fm_fast_applies(const sdsl_hip_fm_s * f, uint32_t m, uint64_t n_pat)
 {
     static const uint64_t min_pat = getenv("SDSL_HIP_FM_FAST_MIN") ? (uint64_t)atoll(getenv("SDSL_HIP_FM_FAST_MIN")) : 4096;
     const bool wide = f->size >= (UINT64_C(1) << 32); // (a wide record keeps the characters left in 16 bits)
-    return fm_fast_enabled() && f->ctab_ok && m >= 1 && m < (wide ? 65535u : (1u << 30)) && n_pat >= min_pat && (!f->deep_k || m >= f->deep_k);
+    // (a pattern longer than the index counts 0 whatever it holds — suffix_array_algorithm.hpp:466-467; the index is cyclic through its
+    // sentinel, so a search would let "a\\0a" occur in the text "a" — the lock-step kernel knows the rule, such batches go there)
+    return fm_fast_enabled() && f->ctab_ok && m >= 1 && m <= f->size && m < (wide ? 65535u : (1u << 30)) && n_pat >= min_pat && (!f->deep_k || m >= f->deep_k);
 }
 
 // count() of n_pat patterns of m bytes each, all in device memory; slabs of at most 2^25 patterns share one scratch area

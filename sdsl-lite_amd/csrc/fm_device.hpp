@@ -57,6 +57,59 @@ __device__ __forceinline__ uint64_t fm_jump_start(const FmJump & J, const FmTabl
 
 // Per-byte tables of the flat count kernel (fm_count2.hip), 7 KiB of LDS: the path of every symbol through the fused wavelet
 // tree, spelled out as the steps the search takes — no node-table descent, no 64-bit path word in the loop.
+// count() hands a search over to the TEXT when its interval is down to a few suffixes: the remaining characters stand in front of each
+// of them or not (fm_count2.hip: verify_pays; fm.hip: k_fm_verify; DESIGN: 04_wavelet_tree_fm_index.md, "count stops at a FEW suffixes").
+// The pending word a search leaves: [1 | suffixes - 1 : 3 | characters left : 60 - LB | first suffix : LB], LB = 32 or 40.
+#ifndef SDSL_HIP_FM_VERIFY_MAX
+#define SDSL_HIP_FM_VERIFY_MAX 8
+#endif
+constexpr uint32_t kFmVerifyMax = SDSL_HIP_FM_VERIFY_MAX; // 1: round 3's form — one suffix (A/B)
+static_assert(kFmVerifyMax >= 1 && kFmVerifyMax <= 8, "three bits hold suffixes - 1");
+// The index is the BWT of text + sentinel, i.e. of a CYCLIC string: backward search lets a pattern run through the sentinel (count("b\\0a")
+// is 1 on the text "ab": suffix_array_algorithm.hpp:167-201 does not care), the text buffer does not hold it.  A search may only be
+// handed to the text if none of the characters it still has to match is the byte 0 (round 3's single-suffix shortcut missed this).  The
+// test runs on the pattern's next sixteen bytes, which the flat kernels hold in registers; a search with more than sixteen characters to
+// go walks on until it has that few.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// the 16 bytes in front of byte offset `end` of the pattern array (as a little-endian 128-bit number: .w's top byte is the
+// byte at end - 1); what lies in front of the array's first byte reads as 0
+__device__ __forceinline__ u32x4 load_tail16(const uint8_t * __restrict__ pats, uint64_t end)
+{
+    u32x4 v;
+    if (end >= 16)
+        __builtin_memcpy(&v, pats + end - 16, 16);
+    else
+    {
+        uint8_t b[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            b[j] = (uint64_t)(15 - j) < end ? pats[end - 16 + j] : 0; // (only reached for the first pattern of a batch)
+        __builtin_memcpy(&v, b, 16);
+    }
+    return v;
+}
+
+// does any of the TOP `valid` (<= 16) bytes of the 128-bit number w — the next `valid` characters a search will process — equal zero?
+// (bytes below them belong to the pattern in front, or lie in front of the array: filled with ones so that no borrow reaches the test)
+__device__ __forceinline__ bool fm_tail_has_zero(u32x4 w, uint32_t valid)
+{
+    uint32_t x[4] = {w.w, w.z, w.y, w.x}; // most significant word first
+    bool z = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+        const int v = (int)valid - 4 * j; // valid top bytes of word j
+        const uint32_t fill = v >= 4 ? 0u : (v <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu >> (8 * v));
+        const uint32_t y = x[j] | fill;
+        z = z || ((y - 0x01010101u) & ~y & 0x80808080u) != 0;
+    }
+    return z;
+}
+SH_HD uint64_t fm_pending_word(unsigned LB, uint64_t l, uint64_t suffixes, uint64_t rem)
+{
+    return (UINT64_C(1) << 63) | ((suffixes - 1) << 60) | (rem << LB) | l;
+}
 constexpr unsigned kFmMaxSteps = 1280;
 // (an index of 2^32 symbols and more uses FmCountTabW, which begins with these fields)
 struct FmCountTab

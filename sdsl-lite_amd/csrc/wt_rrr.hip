@@ -129,9 +129,10 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_wt_select_rrr(WtView wt, const 
 
 // count / interval (suffix_array_algorithm.hpp:228-248, 464-471), one pattern per lane.  Both cascades of an LF
 // step (rank at l and at r+1, :195-196) advance level by level (rrr_rank2).
-// VERIFY (count only; the whole suffix array and the text are resident): a search that is down to ONE suffix with two or more
-// characters to go stops and leaves [1 : 1 | characters left : 31 | the suffix : 32] for k_fm_verify (fm.hip), which compares
-// them with the text — on this index every LF step it saves is a cascade of block decodes.
+// VERIFY (count only; the whole suffix array and the text are resident): a search that is down to a FEW suffixes (<= kFmVerifyMax; round 3:
+// one) with two or more characters to go stops and leaves the pending word of fm_device.hpp for k_fm_verify (fm.hip), which compares
+// them with the text in front of each suffix — on this index every LF step it saves is a cascade of block decodes (8 fabric requests per
+// character against 1 + s for the comparison), so the text takes over as soon as the interval is that narrow.
 template <bool WANT_IVAL, bool VERIFY = false>
 __global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const FmTables * __restrict__ ftab, FmJump J, FmDeep D,
                                                               uint64_t csa_size, const uint8_t * __restrict__ pats,
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const F
             { // next character (suffix_array_algorithm.hpp:176-200)
                 if (!(it > begin && r + 1 - l > 0))
                     break;
-                if (VERIFY && !WANT_IVAL && l == r && it > begin + 1)
+                if (VERIFY && !WANT_IVAL && r - l < kFmVerifyMax && it > begin + 1 && it < end && it - begin < (1u << 28) && it - begin <= 16 &&
+                    !fm_tail_has_zero(load_tail16(pats, it), (uint32_t)(it - begin)))
                 {
                     pending = true;
                     break;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const F
             out_r[q] = r;
         }
         else
-            out_cnt[q] = VERIFY && pending ? (UINT64_C(1) << 63) | ((uint64_t)(it - begin) << 32) | l : r + 1 - l;
+            out_cnt[q] = VERIFY && pending ? fm_pending_word(32, l, r + 1 - l, it - begin) : r + 1 - l;
     }
 }
 

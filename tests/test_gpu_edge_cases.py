@@ -134,3 +134,31 @@ def test_sd_select0_on_skewed_vectors(gpu, shape):
     assert np.all(sd.select(np.array([0, zeros.size + 1], dtype=np.uint64), 0) == NPOS)
     ones_i = np.arange(1, pos.size + 1, dtype=np.uint64)
     assert np.array_equal(sd.select(ones_i, 1), pos)
+
+
+@pytest.mark.parametrize("rrr", [False, True])
+def test_patterns_that_end_with_the_sentinel_on_texts_of_a_few_suffixes(gpu, rrr):
+    """count() hands a search over to the text when the interval is down to a few suffixes (round 6: up to eight) — but the sentinel byte 0 is
+    in the index and not in the text buffer, so a pattern that ENDS with it must go through the index for at least one character.  On a text
+    of fewer than eight suffixes the WHOLE interval is that narrow before anything has been matched: large batches (the flat kernels) and
+    small ones (the lock-step kernel), patterns with the sentinel at the end / in the middle / nowhere, against the oracle
+    (suffix_array_algorithm.hpp:464-471)."""
+    for text in (b"a", b"ab", b"abcab", b"aaaaaa", b"abababa"):
+        csa = gpu.csa_wt(text=text, rrr=rrr)
+        o = ol.OCsa(text)
+        alphabet = sorted(set(text)) + [0]
+        for m in (2, 3, 4):
+            rng = np.random.default_rng(m + len(text))
+            pats = np.array(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), (6000, m))]
+            pats[:len(text), :] = 0
+            for i in range(min(len(text), 6000)):                    # every suffix of the text followed by the sentinel, cut to m bytes
+                s = (text[i:] + b"\x00")[-m:]
+                pats[i, m - len(s):] = np.frombuffer(s, dtype=np.uint8)
+                pats[i, :m - len(s)] = text[0]
+            want = np.array([o.count(bytes(r)) for r in pats], dtype=np.uint64)
+            flat = np.ascontiguousarray(pats.reshape(-1))
+            assert np.array_equal(np.asarray(csa.count(flat, m)).astype(np.uint64), want), (text, m, "large batch")
+            assert np.array_equal(np.asarray(csa.count(flat[: 50 * m], m)).astype(np.uint64), want[:50]), (text, m, "small batch")
+            if m <= len(text) + 1:
+                assert want.max() >= 1, "the text's last m - 1 bytes + the sentinel occur"
+        csa.close()
