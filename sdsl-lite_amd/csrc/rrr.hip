@@ -130,7 +130,7 @@ static unsigned choose_sparse_max(const uint64_t hist[64], uint64_t n_bits, bool
     { // experiment knob
         const int v = atoi(e);
         if (v >= 0 && v <= 20)
-            return (unsigned)v;
+            return (unsigned)(standalone ? v : std::min(v, 10)); // (the kernels over a wavelet tree's vectors stage the columns 0..10 only)
     }
     // Where the search starts (option "rrr_sparse_limit"; default 20 since round 6, 10 before).  A vector of 10-30 % density consists of
     // classes 6..25, and with every class above 10 raw it takes 1.3-1.4 times SDSL's space; with the limit at 20 the classes up to 20

@@ -36,6 +36,22 @@ struct RrrTables
     uint8_t space[64];
     uint8_t sdsl_space[64]; // SDSL's width of the offset field, hi(C(63,k))+1 for every class (parser / serialiser)
     uint8_t space2[256];    // space[b & 15] + space[b >> 4]: two 4-bit class fields of the slim record format at once
+    SH_HD uint64_t C(unsigned m, unsigned k) const { return binom[m][k]; }
+    SH_HD uint64_t C63(unsigned k) const { return binom[63][k]; }
+};
+
+// What the kernels over the vectors INSIDE a wavelet tree stage in LDS instead (wt_rrr.hip; round 6): those vectors keep at most the classes
+// 0..10 and 53..63 enumerative (rrr.hip, choose_sparse_max: limit 10 when not stand-alone), so the decoder reads the binomial columns 0..10
+// and C(63, k) for k >= 53 only — 5.8 KiB instead of 33: seven blocks of 256 threads per CU instead of three of 512 (by LDS), i.e. the 70
+// VGPRs of those kernels decide the occupancy (7 waves per SIMD) and not the table.  Wide records only (no space2).
+constexpr unsigned kWtCols = 11;
+struct RrrTablesWt
+{
+    uint64_t binom[64][kWtCols]; // C(m, k), k <= 10 (a row stride of 11 words: the lanes of a wave decoding one class at different rows spread over the banks)
+    uint64_t top[kWtCols];       // C(63, 53 + j)
+    uint8_t space[64];
+    SH_HD uint64_t C(unsigned m, unsigned k) const { return binom[m][k]; }
+    SH_HD uint64_t C63(unsigned k) const { return top[k - 53]; }
 };
 
 // RAW classes.  Decoding a block from its offset costs one bisection per set (or, via the complement, unset) bit, and a WAVE
@@ -71,7 +87,8 @@ struct RrrView
 // `stop`: only the positions below it are wanted (rank needs the bits in front of its position): set bits come out in
 // increasing position, so the loop ends at the first one at or behind `stop` — a wave then runs as many rounds as its lane
 // with the most set bits IN FRONT of its position, not in its whole block
-__device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsigned k, uint64_t nr, unsigned stop = kRrrBS)
+template <class TT>
+__device__ __forceinline__ uint64_t rrr_decode_sparse(const TT * T, unsigned k, uint64_t nr, unsigned stop = kRrrBS)
 {
     uint64_t bits = 0;
     int hi = 62; // candidate rows m = 62 - position
@@ -82,7 +99,7 @@ __device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsig
         while (lo < h)
         {
             int mid = (lo + h + 1) >> 1;
-            if (T->binom[mid][k] <= nr)
+            if (T->C(mid, k) <= nr)
                 lo = mid;
             else
                 h = mid - 1;
@@ -90,7 +107,7 @@ __device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsig
         if (62 - lo >= (int)stop)
             return bits;
         bits |= UINT64_C(1) << (62 - lo);
-        nr -= T->binom[lo][k];
+        nr -= T->C(lo, k);
         --k;
         hi = lo - 1;
     }
@@ -118,12 +135,13 @@ __device__ __forceinline__ uint64_t rrr_decode_sparse(const RrrTables * T, unsig
 // the 63-bit block of class k whose device field holds f (rrr_helper.hpp:480-534 for the enumerative classes: blocks of a
 // class are numbered in lexicographic order of (b0, b1, ...), 0 < 1)
 // (stop < 63: only the bits at positions below `stop` are valid in the result)
-__device__ __forceinline__ uint64_t rrr_decode_block(const RrrTables * T, unsigned k, uint64_t f, unsigned stop = kRrrBS)
+template <class TT>
+__device__ __forceinline__ uint64_t rrr_decode_block(const TT * T, unsigned k, uint64_t f, unsigned stop = kRrrBS)
 {
     if (rrr_raw_width(T->space[k]))
         return f;
     const bool flip = k > 31; // the complement of a block with k ones is the block with 63-k ones and offset C(63,k)-1-nr
-    uint64_t bits = rrr_decode_sparse(T, flip ? kRrrBS - k : k, flip ? T->binom[63][k] - 1 - f : f, stop);
+    uint64_t bits = rrr_decode_sparse(T, flip ? kRrrBS - k : k, flip ? T->C63(k) - 1 - f : f, stop);
     if (flip)
         bits = ~bits & lo_set(kRrrBS);
     return bits;
@@ -135,6 +153,19 @@ __device__ __forceinline__ void rrr_stage_tables(RrrTables * lds, const RrrTable
     uint64_t * dst = reinterpret_cast<uint64_t *>(lds);
     for (unsigned i = threadIdx.x; i < sizeof(RrrTables) / 8; i += blockDim.x)
         dst[i] = src[i];
+    __syncthreads();
+}
+
+__device__ __forceinline__ void rrr_stage_tables(RrrTablesWt * lds, const RrrTables * g)
+{
+    for (unsigned i = threadIdx.x; i < 64 * kWtCols; i += blockDim.x)
+        lds->binom[i / kWtCols][i % kWtCols] = g->binom[i / kWtCols][i % kWtCols];
+    for (unsigned i = threadIdx.x; i < 64; i += blockDim.x)
+    {
+        lds->space[i] = g->space[i];
+        if (i >= 53)
+            lds->top[i - 53] = g->binom[63][i];
+    }
     __syncthreads();
 }
 
@@ -201,7 +232,8 @@ SH_HD unsigned sum_fields9(uint64_t x)
 }
 
 // sum of space[] over the nine class fields of m (class 0 adds nothing: space[0] == 0)
-__device__ __forceinline__ unsigned rrr_space_sum9(const RrrTables * T, uint64_t m)
+template <class TT>
+__device__ __forceinline__ unsigned rrr_space_sum9(const TT * T, uint64_t m)
 {
     const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 28); // fields 0..3 | fields 4..8
     unsigned bits = 0;
@@ -300,7 +332,8 @@ struct RankTail
     unsigned k, off;
 };
 
-__device__ __forceinline__ RankTail rrr_rank_head(const RrrView & v, const RrrTables * T, uint64_t i)
+template <class TT>
+__device__ __forceinline__ RankTail rrr_rank_head(const RrrView & v, const TT * T, uint64_t i)
 {
     RankTail t;
     const uint64_t sb = i / kRecSB; // one 64-bit division; everything below it is 32-bit
@@ -352,8 +385,8 @@ __device__ __forceinline__ RankTail rrs_rank_head(const RrrView & v, const RrrTa
     t.nr = rrr_field_t<F::INL0, F::INLW>(v, r, ptr, bits, T->space[t.k]);
     return t;
 }
-template <class F>
-__device__ __forceinline__ RankTail rrr_rank_head_f(const RrrView & v, const RrrTables * T, uint64_t i)
+template <class F, class TT>
+__device__ __forceinline__ RankTail rrr_rank_head_f(const RrrView & v, const TT * T, uint64_t i)
 {
     if constexpr (F::id == 0)
         return rrr_rank_head(v, T, i);
@@ -362,8 +395,8 @@ __device__ __forceinline__ RankTail rrr_rank_head_f(const RrrView & v, const Rrr
 }
 
 // rank_1(pos); optionally the bit at pos (pos < n_bits then)
-template <class F = RrrFmtW>
-__device__ __forceinline__ uint64_t rrr_rank1(const RrrView & v, const RrrTables * T, uint64_t pos,
+template <class F = RrrFmtW, class TT>
+__device__ __forceinline__ uint64_t rrr_rank1(const RrrView & v, const TT * T, uint64_t pos,
                                               unsigned * bit_out = nullptr)
 {
     const RankTail t = rrr_rank_head_f<F>(v, T, pos);
@@ -379,7 +412,8 @@ __device__ __forceinline__ uint64_t rrr_rank1(const RrrView & v, const RrrTables
 // the SA interval is narrow both positions usually fall into the same 63-bit block: then b reuses a's head and
 // decoded block; and a b that starts a block needs no decode at all — for an interval of size one (b == a + 1) one
 // of the two always holds.
-__device__ __forceinline__ void rrr_rank2(const RrrView & v, const RrrTables * T, uint64_t pa, uint64_t pb, uint64_t & ra,
+template <class TT>
+__device__ __forceinline__ void rrr_rank2(const RrrView & v, const TT * T, uint64_t pa, uint64_t pb, uint64_t & ra,
                                           uint64_t & rb)
 {
     const uint64_t blk_a = pa / kRrrBS, blk_b = pb / kRrrBS;
@@ -504,8 +538,8 @@ struct RrrSelLoc
     unsigned k, rel, want; // class, position of the offset field among the record's offsets, rank of the argument inside the block
 };
 
-template <int BIT>
-__device__ __forceinline__ RrrSelLoc rrr_sel_locate_w(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
+template <int BIT, class TT>
+__device__ __forceinline__ RrrSelLoc rrr_sel_locate_w(const RrrView & v, const TT * T, uint64_t k0, const RrrSelHit & h)
 {
     const uint64_t g = h.g, before = h.before, P = h.P, c0 = h.c0, c1 = h.c1, c2 = h.c2, c3 = h.c3;
     // inside record g: the group of 9 blocks.  Zeros before block 9q are 567q - ones (every block in front of
@@ -638,18 +672,18 @@ __device__ __forceinline__ RrrSelLoc rrr_sel_locate_s(const RrrView & v, const R
     L.want = want;
     return L;
 }
-template <int BIT, class F = RrrFmtW>
-__device__ __forceinline__ RrrSelLoc rrr_sel_locate(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
+template <int BIT, class F = RrrFmtW, class TT>
+__device__ __forceinline__ RrrSelLoc rrr_sel_locate(const RrrView & v, const TT * T, uint64_t k0, const RrrSelHit & h)
 {
     if constexpr (F::id == 0)
         return rrr_sel_locate_w<BIT>(v, T, k0, h);
     else
-        return rrr_sel_locate_s<BIT>(v, T, k0, h);
+        return rrr_sel_locate_s<BIT>(v, T, k0, h); // (slim records: full tables only)
 }
 
 // does the offset field of the located block reach into the overflow stream (a second, random fetch)?
-template <class F = RrrFmtW>
-__device__ __forceinline__ bool rrr_sel_in_stream(const RrrTables * T, const RrrSelLoc & L)
+template <class F = RrrFmtW, class TT>
+__device__ __forceinline__ bool rrr_sel_in_stream(const TT * T, const RrrSelLoc & L)
 {
     return L.rel + T->space[L.k] > F::INLB;
 }
@@ -660,8 +694,8 @@ __device__ __forceinline__ uint64_t rrr_field_inline(const uint64_t * r, unsigne
     return read_bits(r + F::INL0, rel, len);
 }
 
-template <int BIT>
-__device__ __forceinline__ uint64_t rrr_sel_decode(const RrrView & v, const RrrTables * T, const RrrSelLoc & L, uint64_t nr)
+template <int BIT, class TT>
+__device__ __forceinline__ uint64_t rrr_sel_decode(const RrrView & v, const TT * T, const RrrSelLoc & L, uint64_t nr)
 {
     uint64_t bits = rrr_decode_block(T, L.k, nr);
     if (!BIT)
@@ -672,15 +706,15 @@ __device__ __forceinline__ uint64_t rrr_sel_decode(const RrrView & v, const RrrT
     return L.bstart + sel64(bits, L.want + 1);
 }
 
-template <int BIT, class F = RrrFmtW>
-__device__ __forceinline__ uint64_t rrr_sel_finish(const RrrView & v, const RrrTables * T, uint64_t k0, const RrrSelHit & h)
+template <int BIT, class F = RrrFmtW, class TT>
+__device__ __forceinline__ uint64_t rrr_sel_finish(const RrrView & v, const TT * T, uint64_t k0, const RrrSelHit & h)
 {
     const RrrSelLoc L = rrr_sel_locate<BIT, F>(v, T, k0, h);
     return rrr_sel_decode<BIT>(v, T, L, rrr_field_t<F::INL0, F::INLW>(v, h.r, L.ptr, L.rel, T->space[L.k]));
 }
 
-template <int BIT, class F = RrrFmtW>
-__device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTables * T, uint64_t k0, uint32_t smp0,
+template <int BIT, class F = RrrFmtW, class TT>
+__device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const TT * T, uint64_t k0, uint32_t smp0,
                                                uint32_t smp1)
 {
     RrrSelState st;
@@ -692,8 +726,8 @@ __device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTable
     return rrr_sel_finish<BIT, F>(v, T, k0, h);
 }
 
-template <int BIT, class F = RrrFmtW>
-__device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const RrrTables * T, uint64_t k0)
+template <int BIT, class F = RrrFmtW, class TT>
+__device__ __forceinline__ uint64_t rrr_select(const RrrView & v, const TT * T, uint64_t k0)
 {
     const uint64_t js = k0 >> v.sel_shift[BIT];
     return rrr_select<BIT, F>(v, T, k0, v.sel[BIT][js], v.sel[BIT][js + 1]);

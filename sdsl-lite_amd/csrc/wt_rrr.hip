@@ -7,21 +7,28 @@
 // Execution model: one QUERY PER LANE, no cooperation (rrr_device.hpp: a lane needs 40 bytes of a superblock record
 // plus the offset field for one rank).  These kernels are VALU-bound by the block decoder, not by memory, so the
 // loops are flat — one iteration is one tree level of whatever the lane is working on — and lanes never wait for
-// each other at query or character boundaries.  LDS holds the node table (13.5 KiB) and the binomial table (32 KiB).
+// each other at query or character boundaries.  LDS holds the node table (13.5 KiB) and the binomial columns 0..10 (5.8 KiB).
 #include "fm_device.hpp"
 #include "wt_host.hpp"
 
 namespace sdslhip {
 
-constexpr unsigned kWtRrrBlock = 512;
+// 256 threads and the compact binomial table (rrr_device.hpp: RrrTablesWt): 21 KiB of LDS per block, so the kernels' 70 VGPRs set the
+// occupancy — 7 waves per SIMD; with the full table (33 KiB) in blocks of 512 it was 6, set by LDS (SDSL_HIP_WT_RRR_BLOCK=512 at compile
+// time: that block size, for A/B)
+#ifndef SDSL_HIP_WT_RRR_BLOCK
+#define SDSL_HIP_WT_RRR_BLOCK 256
+#endif
+constexpr unsigned kWtRrrBlock = SDSL_HIP_WT_RRR_BLOCK;
+constexpr unsigned kWtRrrWaves = kWtRrrBlock == 256 ? 7 : 6; // waves per SIMD the register allocation aims at (second argument of __launch_bounds__)
 
 // wt_pc::rank (wt_pc.hpp:371-399)
-__global__ __launch_bounds__(kWtRrrBlock) void k_wt_rank_rrr(WtView wt, const uint64_t * __restrict__ iq,
+__global__ __launch_bounds__(kWtRrrBlock, kWtRrrWaves) void k_wt_rank_rrr(WtView wt, const uint64_t * __restrict__ iq,
                                                              const uint8_t * __restrict__ cq, uint64_t * __restrict__ out,
                                                              uint64_t n)
 {
     __shared__ WtTables T;
-    __shared__ RrrTables RT;
+    __shared__ RrrTablesWt RT;
     rrr_stage_tables(&RT, wt.rrr.tables);
     wt_stage_tables(&T, wt.tables);
     for (uint64_t q = (uint64_t)blockIdx.x * kWtRrrBlock + threadIdx.x; q < n; q += (uint64_t)gridDim.x * kWtRrrBlock)
@@ -57,12 +64,12 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_wt_rank_rrr(WtView wt, const ui
 
 // wt_pc::inverse_select / operator[] (wt_pc.hpp:411-430, 336-357)
 template <bool WITH_RANK>
-__global__ __launch_bounds__(kWtRrrBlock) void k_wt_invsel_rrr(WtView wt, const uint64_t * __restrict__ iq,
+__global__ __launch_bounds__(kWtRrrBlock, kWtRrrWaves) void k_wt_invsel_rrr(WtView wt, const uint64_t * __restrict__ iq,
                                                                uint64_t * __restrict__ out_rank,
                                                                uint8_t * __restrict__ out_c, uint64_t n)
 {
     __shared__ WtTables T;
-    __shared__ RrrTables RT;
+    __shared__ RrrTablesWt RT;
     rrr_stage_tables(&RT, wt.rrr.tables);
     wt_stage_tables(&T, wt.tables);
     for (uint64_t q = (uint64_t)blockIdx.x * kWtRrrBlock + threadIdx.x; q < n; q += (uint64_t)gridDim.x * kWtRrrBlock)
@@ -84,13 +91,13 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_wt_invsel_rrr(WtView wt, const 
 }
 
 // wt_pc::select (wt_pc.hpp:441-480): bottom-up, one rrr select per level whose bit value is the path bit
-__global__ __launch_bounds__(kWtRrrBlock) void k_wt_select_rrr(WtView wt, const uint64_t * __restrict__ occ,
+__global__ __launch_bounds__(kWtRrrBlock, kWtRrrWaves) void k_wt_select_rrr(WtView wt, const uint64_t * __restrict__ occ,
                                                                const uint64_t * __restrict__ iq,
                                                                const uint8_t * __restrict__ cq,
                                                                uint64_t * __restrict__ out, uint64_t n)
 {
     __shared__ WtTables T;
-    __shared__ RrrTables RT;
+    __shared__ RrrTablesWt RT;
     rrr_stage_tables(&RT, wt.rrr.tables);
     wt_stage_tables(&T, wt.tables);
     for (uint64_t q = (uint64_t)blockIdx.x * kWtRrrBlock + threadIdx.x; q < n; q += (uint64_t)gridDim.x * kWtRrrBlock)
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_wt_select_rrr(WtView wt, const 
 // them with the text in front of each suffix — on this index every LF step it saves is a cascade of block decodes (8 fabric requests per
 // character against 1 + s for the comparison), so the text takes over as soon as the interval is that narrow.
 template <bool WANT_IVAL, bool VERIFY = false>
-__global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const FmTables * __restrict__ ftab, FmJump J, FmDeep D,
+__global__ __launch_bounds__(kWtRrrBlock, kWtRrrWaves) void k_fm_count_rrr(WtView wt, const FmTables * __restrict__ ftab, FmJump J, FmDeep D,
                                                               uint64_t csa_size, const uint8_t * __restrict__ pats,
                                                               uint32_t m, const uint64_t * __restrict__ offsets,
                                                               const uint32_t * __restrict__ order, uint64_t n_pat,
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const F
                                                               uint64_t * __restrict__ out_l, uint64_t * __restrict__ out_r)
 {
     __shared__ WtTables T;
-    __shared__ RrrTables RT;
+    __shared__ RrrTablesWt RT;
     __shared__ FmTables F;
     fm_stage_tables(&F, ftab);
     rrr_stage_tables(&RT, wt.rrr.tables);
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_count_rrr(WtView wt, const F
 }
 
 // one LF step per element (suffix_array_algorithm.hpp:167-201)
-__global__ __launch_bounds__(kWtRrrBlock) void k_fm_backward_step_rrr(WtView wt, const FmTables * __restrict__ ftab,
+__global__ __launch_bounds__(kWtRrrBlock, kWtRrrWaves) void k_fm_backward_step_rrr(WtView wt, const FmTables * __restrict__ ftab,
                                                                       uint64_t csa_size, const uint64_t * __restrict__ lq,
                                                                       const uint64_t * __restrict__ rq,
                                                                       const uint8_t * __restrict__ cq, uint64_t n,
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_backward_step_rrr(WtView wt,
                                                                       uint64_t * __restrict__ out_r)
 {
     __shared__ WtTables T;
-    __shared__ RrrTables RT;
+    __shared__ RrrTablesWt RT;
     __shared__ FmTables F;
     fm_stage_tables(&F, ftab);
     rrr_stage_tables(&RT, wt.rrr.tables);
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(kWtRrrBlock) void k_fm_backward_step_rrr(WtView wt,
 
 static unsigned wt_rrr_grid(uint64_t n)
 {
-    return grid_for(n, kWtRrrBlock, 256u * 3u);
+    return grid_for(n, kWtRrrBlock, 256u * (kWtRrrBlock == 256 ? 7u : 3u));
 }
 
 sdsl_hip_status wt_rrr_launch_rank(const WtHost & wt, const uint64_t * d_i, const uint8_t * d_c, uint64_t n,
