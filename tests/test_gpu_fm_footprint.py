@@ -328,3 +328,26 @@ def test_the_references_own_fixtures_at_every_footprint(gpu, name):
     csa.restore_suffix_array()
     check("restored")
     csa.close()
+
+
+def test_an_index_whose_suffix_array_is_wider_than_its_intervals_shrinks_too(gpu, monkeypatch):
+    """an index that holds the 64-BIT suffix array although its intervals are 32 bits wide (2^32 - 2 or 2^32 - 1 symbols; or any
+    text sent through the 64-bit sorter by SDSL_HIP_SA64) cannot build a k-mer table — set_footprint failed there AFTER it had changed the
+    index.  Now: the call is transactional, and such an index goes without a table instead of failing."""
+    text = gpu.english_text(1 << 20, 31)
+    ref = gpu.csa_wt(text=text)
+    want = answers(ref, text)
+    blob = ref.serialize(32, 64, gpu.capi.LAYOUT_BV_MCL)
+    ref.close()
+    monkeypatch.setenv("SDSL_HIP_SA64", "1")
+    csa = gpu.csa_wt(text=text)
+    monkeypatch.delenv("SDSL_HIP_SA64")
+    assert csa.sampling() == (32, 64, True) and csa.footprint_parts()["suffix_array"] == 8 * (text.size + 1)
+    assert same(want, answers(csa, text))
+    budget = int(1.6 * len(blob))
+    csa.set_footprint(budget)
+    p = csa.footprint_parts()
+    assert csa.device_bytes() <= budget and p["suffix_array"] == 0 and p["text"] == 0 and p["wt_binary_levels"] == 0
+    assert same(want, answers(csa, text))
+    assert csa.serialize(32, 64, gpu.capi.LAYOUT_BV_MCL) == blob
+    csa.close()
