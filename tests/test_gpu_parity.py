@@ -225,9 +225,12 @@ def test_sibling_streams_stay_compressed_on_request(gpu, n, kind):
     assert v.size() == n and v.ones() == plain.ones()
     if n:
         idx = np.random.default_rng(n).integers(0, n + 1, size=20_000, dtype=np.uint64)
+        orc = ol.ORrr(w, n)                       # the oracle on the same bits (this test compared two HIP paths only)
+        assert np.array_equal(v.rank(idx, 1), orc.rank(idx, 1)) and np.array_equal(v.rank(idx, 0), orc.rank(idx, 0))
         assert np.array_equal(v.rank(idx, 1), plain.rank(idx, 1)) and np.array_equal(v.rank(idx, 0), plain.rank(idx, 0))
         if plain.ones():
             i = np.random.default_rng(n + 1).integers(1, plain.ones() + 1, size=20_000, dtype=np.uint64)
+            assert np.array_equal(v.select(i, 1), orc.select(i, 1))
             assert np.array_equal(v.select(i, 1), plain.select(i, 1))
         pos = idx[idx < n]
         bits = unpack_bits(w, n)
