@@ -488,7 +488,7 @@ def leg_text(c):
         def route_of(ix):
             """which road count() takes on this index, in a few words (the line's secondary.route)"""
             p = ix.footprint_parts()
-            return ("k-mer table k=%d -> flat fused-tree search%s" % (ix.kmer_table_depth(), " -> text comparison at one suffix" if p["suffix_array"] and verify_on else "")
+            return ("k-mer table k=%d -> flat fused-tree search%s" % (ix.kmer_table_depth(), " -> text comparison at <= 8 suffixes" if p["suffix_array"] and verify_on else "")
                     + ("; tree: fused lines only" if not p["wt_binary_levels"] else ""))
 
         verify_on = os.environ.get("SDSL_HIP_FM_VERIFY", "1") != "0"
@@ -520,8 +520,8 @@ def leg_text(c):
                     "algorithmic_bytes_per_pattern": alg, "fused_steps_per_pattern_without_table": sum_steps, "note": FUSED_NOTE}
 
         ex["fm_count"] = count_leg("default", "k-mer hash table (k = %d: one 128-byte bucket instead of k LF steps) -> flat search kernel "
-                                   "until one suffix is left%s (fm_count2.hip); no sort, patterns in the caller's order"
-                                   % (csa.kmer_table_depth(), " -> the remaining characters compared with the text at SA[l]: the whole "
+                                   "until at most eight suffixes are left%s (fm_count2.hip); no sort, patterns in the caller's order"
+                                   % (csa.kmer_table_depth(), " -> the remaining characters compared with the text in front of each of them: the whole "
                                       "suffix array and the text are resident" if verify_on else ""))
         ms = ex["fm_count"]["kernel_ms"]
         if rank == 0 and world == 1:
@@ -785,7 +785,7 @@ def leg_big(c):
                          "every_pattern_found": bool((ob >= 1).all()), "wt_rank_Gq/s": nrb / ms_r / 1e6,
                          "kmer_table": {"k": cb.kmer_table_depth(), "bytes": cb.kmer_table_bytes()},
                              "note": "fused 16-ary lines with 64-bit superblock counts; count: k-mer table with 40-bit intervals -> wide flat search kernel -> "
-                                     "text comparison at one suffix (fm_count2.hip, WIDE variants)"}
+                                     "text comparison at <= 8 suffixes (fm_count2.hip, WIDE variants)"}
     del wtb, cb, tb, pb, ob, ib, sb, orb, stb
     torch.cuda.empty_cache()
 
