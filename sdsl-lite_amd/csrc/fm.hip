@@ -86,14 +86,17 @@ __global__ __launch_bounds__(kBlock) void k_fm_count(WtView wt, const FmTables *
         // state of the character being processed
         unsigned left = 0, v = 0;
         uint64_t a = 0, b = 0, p = 0, cb = 0;
-        bool pending = false; // VERIFY: the search stopped at a single suffix with characters left (see k_fm_verify)
+        bool pending = false; // VERIFY: the search stopped at a few suffixes with characters left (see k_fm_verify)
+        uint64_t prev_size = 0;
         for (;;)
         {
             if (left == 0)
             { // next character (suffix_array_algorithm.hpp:176-200)
                 if (!(it > begin && r + 1 - l > 0))
                     break;
-                if (VERIFY && !WANT_IVAL && r - l < kFmVerifyMax && it > begin + 1 && it < end && it - begin > r - l &&
+                const bool stable = r + 1 - l == prev_size; // (fm_count2.hip, verify_pays: s > 1 only for an interval that has stopped shrinking)
+                prev_size = r + 1 - l;
+                if (VERIFY && !WANT_IVAL && r - l < kFmVerifyMax && (l == r || stable) && it > begin + 1 && it < end && it - begin > r - l &&
                     it - begin < (csa_size >> 32 ? (UINT64_C(1) << 20) : (UINT64_C(1) << 28)) && it - begin <= 16 &&
                     !fm_tail_has_zero(load_tail16(pats, it), (uint32_t)(it - begin)))
                 { // a few suffixes left and at least that many (two) characters to go: k_fm_verify compares them with the text at each
